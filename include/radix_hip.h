@@ -1,0 +1,201 @@
+/*
+ * radix_hip.h -- C ABI of libradix_hip.so: the MI355X (gfx950) RadixAttention hot path.
+ *
+ * Every entry point replaces ONE kernel/operator of the reference (bytedance-iaas/sglang,
+ * paths relative to python/sglang/); the citation next to each prototype names it.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a DEVICE pointer owned by the caller
+ *     unless marked HOST; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - calls are stream-ordered, re-entrant, allocate nothing, never synchronise the host,
+ *     and are therefore hipGraph-capturable.
+ *   - return value: 0 (RX_OK) or a negative rx_status; rx_last_error() gives a
+ *     thread-local message for the last failing call.  Nothing throws.
+ *   - strides are in ELEMENTS of the tensor's dtype unless the name ends in _bytes.
+ *   - slot 0 / page 0 is the reserved padding sink of the reference's pools
+ *     (srt/mem_cache/allocator/token.py:41-46, paged.py:329-337).
+ */
+#ifndef RADIX_HIP_H_
+#define RADIX_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RX_ABI_VERSION 1
+
+typedef enum rx_status {
+  RX_OK = 0,
+  RX_ERR_INVALID_ARG = -1,  /* null pointer, negative size, misaligned buffer ... */
+  RX_ERR_UNSUPPORTED = -2,  /* shape / dtype the gfx950 kernels do not cover      */
+  RX_ERR_LAUNCH = -3        /* hipLaunchKernel / hipGetLastError reported failure */
+} rx_status;
+
+typedef enum rx_dtype { RX_BF16 = 0, RX_F16 = 1 } rx_dtype;
+
+/* Device-side error word bits (optional `err_flag`, int32, caller-zeroed): the kernels OR
+ * these in instead of the reference's always-on device assert (kvcache.cuh:209). */
+#define RX_DEVERR_SLOT_OOB 1 /* a KV slot index fell outside [0, size_limit) */
+
+int rx_version(void);
+const char* rx_last_error(void);
+
+/* ---- K1: KV store -------------------------------------------------------------------
+ * store_cache (kernels/ops/kvcache/kvcache.py:57-110) -> store_kvcache
+ * (kernels/jit/csrc/elementwise/kvcache.cuh:189-219), called from
+ * MHATokenToKVPool._store_kv_layer (srt/mem_cache/memory_pool.py:2383-2430).
+ *   k_cache[loc[i]] = k[i];  v_cache[loc[i]] = v[i]   (byte rows)
+ * Rows with loc == skip_index (reference default 0) are not written; pass -1 to disable.
+ * loc outside [0, size_limit) is not written and sets RX_DEVERR_SLOT_OOB in *err_flag.
+ * Row byte counts and all strides must be multiples of 4 (reference: kvcache.py:38-45). */
+int rx_store_kv(const void* k, const void* v, void* k_cache, void* v_cache, const void* loc,
+                int64_t n, int64_t k_row_bytes, int64_t v_row_bytes, int64_t k_stride_bytes,
+                int64_t v_stride_bytes, int64_t kc_stride_bytes, int64_t vc_stride_bytes,
+                int loc_is_i64, int64_t size_limit, int64_t skip_index, int32_t* err_flag,
+                void* stream);
+
+/* ---- K2: ragged kv-index build --------------------------------------------------------
+ * create_flashinfer_kv_indices_triton (kernels/ops/kvcache/kv_indices.py:8-46) plus the
+ * cumsum of TritonAttnBackend._fill_kv_indptr_and_indices (triton_backend.py:386-404).
+ *   kv_indptr[0] = 0; kv_indptr[i+1] = kv_indptr[i] + lens[i]            (int32)
+ *   kv_indices[kv_indptr[i] + j] = req_to_token[req_pool_indices[i]][kv_start[i] + j]
+ * kv_start may be NULL (= 0).  req_to_token is int32[*, row_stride]. */
+int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,
+                        const void* req_pool_indices, int pool_idx_is_i64, const void* lens,
+                        int lens_is_i64, const int32_t* kv_start, int32_t* kv_indptr_out,
+                        void* kv_indices_out, int out_is_i64, int bs, void* stream);
+
+/* ---- K3: kv-split scheduler -----------------------------------------------------------
+ * get_num_kv_splits_triton (kernels/ops/attention/metadata.py:11-60).
+ * out is int32[num_seq * num_group]. */
+int rx_num_kv_splits(const void* seq_lens, int seq_lens_is_i64, int num_seq, int num_group,
+                     int num_head, int num_kv_head, int max_kv_splits, int device_core_count,
+                     int32_t* out, void* stream);
+
+/* ---- KV buffer addressing shared by decode / extend ------------------------------------
+ * element offset of (slot, kv_head) = (slot / page_size) * page_stride
+ *                                   + (slot % page_size) * tok_stride + kv_head * head_stride
+ * NHD [slots, Hkv, D] (memory_pool.py:2030-2041): page_stride = page_size * Hkv*D,
+ *     tok_stride = Hkv*D, head_stride = D.
+ * HND [pages, Hkv, page, D] (memory_pool.py:2032-2036): page_stride = Hkv*page*D,
+ *     tok_stride = D, head_stride = page*D.
+ * (mirrors _extract_kv_strides, kernels/ops/attention/decode_attention.py:39-88) */
+typedef struct rx_kv_layout {
+  const void* k_buf;
+  const void* v_buf;
+  int32_t page_size;
+  int64_t k_page_stride, k_tok_stride, k_head_stride;
+  int64_t v_page_stride, v_tok_stride, v_head_stride;
+} rx_kv_layout;
+
+/* ---- K4/K5/K6: decode attention ---------------------------------------------------------
+ * decode_attention_fwd (kernels/ops/attention/decode_attention.py:968-1044): stage 1
+ * _fwd_grouped_kernel_stage1 (:383-608) / _fwd_kernel_stage1 (:96-281), stage 2
+ * _fwd_kernel_stage2 (:731-805); caller TritonAttnBackend.forward_decode
+ * (srt/layers/attention/triton_backend.py:1714-1864).
+ *
+ * Token -> slot lookup, one of:
+ *   (a) kv_indptr (int32[bs+1]) + kv_indices (int32 or int64)  -- the reference contract;
+ *   (b) kv_indices == NULL: req_to_token (int32[*, req_row_stride]) + req_pool_indices +
+ *       seq_lens, read in-kernel (what decode_attention_cpu does, aot/csrc/cpu/decode.cpp:1586);
+ *       saves the 8 MiB/step kv_indices round trip.
+ * Split-KV: request b is cut into num_kv_splits[b] (<= max_kv_splits) pieces of
+ * cdiv(cdiv(seq,splits),32)*32 tokens exactly as the reference (:466-472); partials go to
+ * attn_logits fp32[bs,Hq,max_kv_splits,Dv] / attn_lse fp32[bs,Hq,max_kv_splits] and are
+ * merged by the stage-2 kernel.  num_kv_splits == NULL or max_kv_splits == 1 runs a single
+ * pass that writes `o` directly (no scratch traffic). */
+typedef struct rx_decode_params {
+  const void* q; /* [bs, Hq, Dk] */
+  void* o;       /* [bs, Hq, Dv] */
+  int64_t q_stride_t, q_stride_h, o_stride_t, o_stride_h;
+  rx_kv_layout kv;
+  const int32_t* kv_indptr; /* mode (a) */
+  const void* kv_indices;   /* mode (a); NULL selects mode (b) */
+  int32_t kv_indices_is_i64;
+  const int32_t* req_to_token; /* mode (b) */
+  int64_t req_row_stride;
+  const void* req_pool_indices;
+  int32_t req_pool_indices_is_i64;
+  const void* seq_lens;
+  int32_t seq_lens_is_i64;
+  const int32_t* num_kv_splits; /* int32[bs] or NULL */
+  int32_t max_kv_splits;
+  float* attn_logits;
+  float* attn_lse;
+  int32_t bs, num_q_heads, num_kv_heads, head_dim, v_head_dim;
+  float sm_scale, k_scale, v_scale, logit_cap;
+  const float* sinks; /* fp32[Hq] or NULL (stage 2, :796-798) */
+  int32_t dtype;      /* rx_dtype of q / kv / o */
+} rx_decode_params;
+
+int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);
+
+/* ---- K7: extend attention ---------------------------------------------------------------
+ * extend_attention_fwd (kernels/ops/attention/extend_attention.py:664-812) -> _fwd_kernel
+ * (:241-661); caller TritonAttnBackend.forward_extend (triton_backend.py:1250-1437).
+ * Request i owns queries qo_indptr[i]..qo_indptr[i+1] (new tokens; their K/V are the
+ * contiguous k_extend/v_extend rows) and a cached prefix kv_indices[kv_indptr[i]..kv_indptr[i+1]]
+ * read from the paged buffers.  lse (fp32 [T, Hq], natural log) optional. */
+typedef struct rx_extend_params {
+  const void* q;        /* [T, Hq, Dk] */
+  const void* k_extend; /* [T, Hkv, Dk] */
+  const void* v_extend; /* [T, Hkv, Dv] */
+  void* o;              /* [T, Hq, Dv] */
+  int64_t q_stride_t, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_t,
+      o_stride_h;
+  rx_kv_layout kv;
+  const void* qo_indptr; /* [bs+1] */
+  int32_t qo_indptr_is_i64;
+  const int32_t* kv_indptr; /* [bs+1] */
+  const void* kv_indices;
+  int32_t kv_indices_is_i64;
+  float* lse; /* or NULL */
+  int64_t lse_stride_t, lse_stride_h;
+  int32_t bs, max_extend_len, num_q_heads, num_kv_heads, head_dim, v_head_dim;
+  float sm_scale, k_scale, v_scale, logit_cap;
+  int32_t is_causal, skip_prefix, skip_extend, sliding_window_size; /* window <= 0: off */
+  const float* sinks;
+  int32_t dtype;
+} rx_extend_params;
+
+int rx_extend_attn(const rx_extend_params* p /* HOST */, void* stream);
+
+/* ---- K9: paged slot allocation -----------------------------------------------------------
+ * alloc_extend_kernel / alloc_decode_kernel (kernels/ops/memory/allocator.py:16-135), called
+ * by PagedTokenToKVPoolAllocator.alloc_extend / alloc_decode (allocator/paged.py:172-259).
+ * All index tensors int64.  out_indices has sum(seq_lens - prefix_lens) (extend) / bs (decode)
+ * entries.  The caller advances its free-page list afterwards, as the reference does. */
+int rx_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const int64_t* last_loc,
+                    const int64_t* free_pages, int64_t* out_indices, int bs, int page_size,
+                    void* stream);
+int rx_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc, const int64_t* free_pages,
+                    int64_t* out_indices, int bs, int page_size, void* stream);
+
+/* ---- K11: req_to_token row write -----------------------------------------------------------
+ * write_req_to_token_pool_triton (called srt/mem_cache/allocation.py:75-84): for request i
+ *   req_to_token[req_pool_indices[i]][0:pre_lens[i]] = prefix_tensors[i][0:pre_lens[i]]
+ *   req_to_token[req_pool_indices[i]][pre_lens[i]:seq_lens[i]] =
+ *       out_cache_loc[extend_offset_i : extend_offset_i + seq_lens[i]-pre_lens[i]]
+ * prefix_ptrs is a device array of bs device pointers to int64 prefix index lists
+ * (entries may be NULL when pre_lens[i] == 0). */
+int rx_write_req_to_token(int32_t* req_to_token, int64_t row_stride,
+                          const int64_t* req_pool_indices, const int64_t* const* prefix_ptrs,
+                          const int64_t* pre_lens, const int64_t* seq_lens,
+                          const int64_t* extend_lens, const int64_t* out_cache_loc, int bs,
+                          void* stream);
+
+/* ---- K10: KV move (all layers) ---------------------------------------------------------------
+ * copy_all_layer_kv_cache_tiled (kernels/ops/kvcache/cache_move.py:60-133) used by
+ * MHATokenToKVPool.move_kv_cache (memory_pool.py:2775-2842):
+ *   for every buffer b: buf_b[tgt_loc[i]] = buf_b[src_loc[i]]   (row_bytes[b] bytes each)
+ * data_ptrs: device uint64[num_bufs] base addresses; row_bytes: device int64[num_bufs]
+ * (the pool's data_ptrs / data_strides tables, memory_pool.py:2005-2028). */
+int rx_move_kv(const uint64_t* data_ptrs, const int64_t* row_bytes, int num_bufs,
+               const int64_t* tgt_loc, const int64_t* src_loc, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADIX_HIP_H_ */

@@ -1,0 +1,636 @@
+"""CPU oracle for the RadixAttention hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The product (``sglang_amd``) never does: it fails
+loudly when the HIP library is missing.
+
+Every function restates, in numpy, the algorithm of one reference function
+(path relative to /root/reference/python/sglang/).  Parity status: PINNED --
+the golden fixtures under ``tests/golden`` were produced by running the
+reference's own Triton kernels (TRITON_INTERPRET=1), paged allocators and
+compiled C++ CPU kernels in the build container (``tests/golden/make_golden.py``),
+and ``tests/test_oracle_golden.py`` checks this file against every one of them.
+
+bf16/fp16 tensors are passed as numpy ``uint16`` bit patterns (bf16) or
+``float16``; helpers below convert.  All attention math is done in float64 so
+the oracle is the "exact" answer the tolerance is measured from.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# dtype helpers
+# --------------------------------------------------------------------------
+
+
+def bf16_to_f32(x_u16: np.ndarray) -> np.ndarray:
+    """bf16 bit patterns (uint16) -> float32."""
+    x = np.ascontiguousarray(x_u16).astype(np.uint32) << 16
+    return x.view(np.float32)
+
+
+def f32_to_bf16(x: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bit patterns, round-to-nearest-even (NaN kept quiet)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    rounded = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    nan = np.isnan(x)
+    out = rounded.astype(np.uint16)
+    out[nan] = 0x7FC0
+    return out
+
+
+def to_f64(x: np.ndarray) -> np.ndarray:
+    """Accept bf16-bits (uint16), float16, float32 -> float64."""
+    if x.dtype == np.uint16:
+        return bf16_to_f32(x).astype(np.float64)
+    return x.astype(np.float64)
+
+
+# --------------------------------------------------------------------------
+# a4  ReqToTokenPool            srt/mem_cache/memory_pool.py:256-326
+# --------------------------------------------------------------------------
+
+
+class ReqToTokenPoolOracle:
+    """req_to_token int32[size+1, max_context_len]; row 0 is the padding sink
+    (memory_pool.py:273-281); free-list of slots 1..size, FIFO alloc
+    (memory_pool.py:306-307), append on free (:318)."""
+
+    def __init__(self, size: int, max_context_len: int):
+        self.size = size
+        self.max_context_len = max_context_len
+        self.req_to_token = np.zeros((size + 1, max_context_len), dtype=np.int32)
+        self.free_slots = list(range(1, size + 1))
+
+    def available_size(self) -> int:
+        return len(self.free_slots)
+
+    def alloc(self, need_size: int) -> Optional[List[int]]:
+        if need_size > len(self.free_slots):
+            return None
+        sel = self.free_slots[:need_size]
+        self.free_slots = self.free_slots[need_size:]
+        return sel
+
+    def free(self, idx: int) -> None:
+        self.free_slots.append(idx)
+
+    def write(self, indices, values) -> None:
+        self.req_to_token[indices] = values
+
+    def clear(self) -> None:
+        self.free_slots = list(range(1, self.size + 1))
+
+
+# --------------------------------------------------------------------------
+# a5  allocators     srt/mem_cache/allocator/{base,token,paged}.py
+#                    kernels/ops/memory/allocator.py:16-135
+# --------------------------------------------------------------------------
+
+
+class TokenAllocatorOracle:
+    """TokenToKVPoolAllocator (allocator/token.py:27-84): page_size == 1,
+    free_pages = arange(1, size+1) (:41-46), alloc = head slice (:53-62),
+    free = append (or to release_pages when need_sort) (:64-74)."""
+
+    def __init__(self, size: int, need_sort: bool = False):
+        self.size = size
+        self.page_size = 1
+        self.need_sort = need_sort
+        self.clear()
+
+    def clear(self):
+        self.free_pages = np.arange(1, self.size + 1, dtype=np.int64)
+        self.release_pages = np.empty((0,), dtype=np.int64)
+        self.is_not_in_free_group = True
+        self.free_group: List[np.ndarray] = []
+
+    def available_size(self):
+        return len(self.free_pages) + len(self.release_pages)
+
+    def merge_and_sort_free(self):  # allocator/base.py:70-76
+        if len(self.release_pages) > 0:
+            self.free_pages = np.sort(
+                np.concatenate((self.free_pages, self.release_pages)), kind="stable"
+            )
+            self.release_pages = np.empty((0,), dtype=np.int64)
+
+    def alloc(self, need_size: int):
+        if self.need_sort and need_size > len(self.free_pages):
+            self.merge_and_sort_free()
+        if need_size > len(self.free_pages):
+            return None
+        sel = self.free_pages[:need_size].copy()
+        self.free_pages = self.free_pages[need_size:]
+        return sel
+
+    def free(self, free_index: np.ndarray):
+        free_index = np.asarray(free_index, dtype=np.int64)
+        if free_index.size == 0:
+            return
+        if self.is_not_in_free_group:
+            if self.need_sort:
+                self.release_pages = np.concatenate((self.release_pages, free_index))
+            else:
+                self.free_pages = np.concatenate((self.free_pages, free_index))
+        else:
+            self.free_group.append(free_index)
+
+    def free_group_begin(self):  # base.py:60-62
+        self.is_not_in_free_group = False
+        self.free_group = []
+
+    def free_group_end(self):  # base.py:64-67
+        self.is_not_in_free_group = True
+        if self.free_group:
+            self.free(np.concatenate(self.free_group))
+
+
+def alloc_extend_ref(prefix_lens, seq_lens, last_loc, free_pages, page_size):
+    """alloc_extend_kernel (kernels/ops/memory/allocator.py:16-100) ==
+    alloc_extend_naive (allocator/paged.py:45-102).  Returns out_indices int64
+    of length sum(seq_lens - prefix_lens).  Three parts per request: fill the
+    old partial page after last_loc, whole new pages taken in order from
+    free_pages, then the new partial page."""
+    prefix_lens = np.asarray(prefix_lens, dtype=np.int64)
+    seq_lens = np.asarray(seq_lens, dtype=np.int64)
+    last_loc = np.asarray(last_loc, dtype=np.int64)
+    free_pages = np.asarray(free_pages, dtype=np.int64)
+    ps = page_size
+    extend_lens = seq_lens - prefix_lens
+    out = np.empty((int(extend_lens.sum()),), dtype=np.int64)
+    pages_after = (seq_lens + ps - 1) // ps
+    pages_before = (prefix_lens + ps - 1) // ps
+    new_pages = pages_after - pages_before
+    out_start = np.cumsum(extend_lens) - extend_lens
+    page_start = np.cumsum(new_pages) - new_pages
+    for i in range(len(seq_lens)):
+        pre, seq = int(prefix_lens[i]), int(seq_lens[i])
+        o = int(out_start[i])
+        n1 = min(seq, (pre + ps - 1) // ps * ps) - pre
+        out[o : o + n1] = last_loc[i] + 1 + np.arange(n1)
+        if pre + n1 == seq:
+            continue
+        n2 = seq // ps * ps - (pre + ps - 1) // ps * ps
+        off = np.arange(n2)
+        out[o + n1 : o + n1 + n2] = (
+            free_pages[int(page_start[i]) + off // ps] * ps + off % ps
+        )
+        if pre + n1 + n2 == seq:
+            continue
+        n3 = seq - seq // ps * ps
+        start = free_pages[int(page_start[i]) + int(new_pages[i]) - 1]
+        out[o + n1 + n2 : o + n1 + n2 + n3] = start * ps + np.arange(n3)
+    return out
+
+
+def alloc_decode_ref(seq_lens, last_loc, free_pages, page_size):
+    """alloc_decode_kernel (kernels/ops/memory/allocator.py:103-135): a request
+    whose new token opens a page ((seq_len-1) % page == 0) takes the next free
+    page, otherwise last_loc + 1."""
+    seq_lens = np.asarray(seq_lens, dtype=np.int64)
+    last_loc = np.asarray(last_loc, dtype=np.int64)
+    free_pages = np.asarray(free_pages, dtype=np.int64)
+    ps = page_size
+    pre = seq_lens - 1
+    new_pages = (seq_lens + ps - 1) // ps - (pre + ps - 1) // ps
+    page_start = np.cumsum(new_pages) - new_pages
+    out = np.empty((len(seq_lens),), dtype=np.int64)
+    for i in range(len(seq_lens)):
+        if new_pages[i] == 0:
+            out[i] = last_loc[i] + 1
+        else:
+            out[i] = free_pages[int(page_start[i])] * ps
+    return out
+
+
+class PagedAllocatorOracle:
+    """PagedTokenToKVPoolAllocator (allocator/paged.py:105-345)."""
+
+    def __init__(self, size: int, page_size: int, need_sort: bool = False):
+        self.size = size
+        self.page_size = page_size
+        self.num_pages = size // page_size
+        self.need_sort = need_sort
+        self.clear()
+
+    def clear(self):  # paged.py:329-337: page 0 reserved for padded writes
+        self.free_pages = np.arange(1, self.num_pages + 1, dtype=np.int64)
+        self.release_pages = np.empty((0,), dtype=np.int64)
+        self.is_not_in_free_group = True
+        self.free_group: List[np.ndarray] = []
+        self.free_page_reps_group: List[np.ndarray] = []
+
+    def available_size(self):  # base.py:54-55
+        return (len(self.free_pages) + len(self.release_pages)) * self.page_size
+
+    def merge_and_sort_free(self):
+        if len(self.release_pages) > 0:
+            self.free_pages = np.sort(
+                np.concatenate((self.free_pages, self.release_pages)), kind="stable"
+            )
+            self.release_pages = np.empty((0,), dtype=np.int64)
+
+    def alloc(self, need_size: int):  # paged.py:149-170
+        num_pages = need_size // self.page_size
+        if self.need_sort and num_pages > len(self.free_pages):
+            self.merge_and_sort_free()
+        if num_pages > len(self.free_pages):
+            return None
+        pages = self.free_pages[:num_pages]
+        self.free_pages = self.free_pages[num_pages:]
+        return (pages[:, None] * self.page_size + np.arange(self.page_size)).reshape(-1)
+
+    def alloc_extend(self, prefix_lens, seq_lens, last_loc):  # paged.py:172-220
+        prefix_lens = np.asarray(prefix_lens, dtype=np.int64)
+        seq_lens = np.asarray(seq_lens, dtype=np.int64)
+        ps = self.page_size
+        extend_num_tokens = int((seq_lens - prefix_lens).sum())
+        bs = len(prefix_lens)
+        if self.need_sort and extend_num_tokens // ps + bs + 1 > len(self.free_pages):
+            self.merge_and_sort_free()
+        num_new = int(((seq_lens + ps - 1) // ps - (prefix_lens + ps - 1) // ps).sum())
+        if num_new > len(self.free_pages):
+            return None
+        out = alloc_extend_ref(prefix_lens, seq_lens, last_loc, self.free_pages, ps)
+        self.free_pages = self.free_pages[num_new:]
+        return out
+
+    def alloc_decode(self, seq_lens, last_loc):  # paged.py:222-259
+        seq_lens = np.asarray(seq_lens, dtype=np.int64)
+        ps = self.page_size
+        bs = len(seq_lens)
+        if self.need_sort and bs > len(self.free_pages):
+            self.merge_and_sort_free()
+        # get_num_new_pages(decode=True), srt/utils/common.py:4311-4314
+        num_new = int((seq_lens % ps == 1).sum())
+        if num_new > len(self.free_pages):
+            return None
+        out = alloc_decode_ref(seq_lens, last_loc, self.free_pages, ps)
+        self.free_pages = self.free_pages[num_new:]
+        return out
+
+    def _release_page_ids(self, *page_ids):  # paged.py:308-312: LIFO prepend
+        if self.need_sort:
+            self.release_pages = np.concatenate((*page_ids, self.release_pages))
+        else:
+            self.free_pages = np.concatenate((*page_ids, self.free_pages))
+
+    def free(self, free_index):  # paged.py:261-271 (torch.unique == sorted unique)
+        free_index = np.asarray(free_index, dtype=np.int64)
+        if free_index.size == 0:
+            return
+        if self.is_not_in_free_group:
+            self._release_page_ids(np.unique(free_index // self.page_size))
+        else:
+            self.free_group.append(free_index)
+
+    def free_segment(self, free_index, start_pos: int):  # paged.py:273-301
+        free_index = np.asarray(free_index, dtype=np.int64)
+        if free_index.size == 0:
+            return
+        ps = self.page_size
+        offset = start_pos % ps
+        if offset == 0:
+            pieces = (free_index[::ps],)
+        else:
+            pieces = (free_index[:1], free_index[ps - offset :: ps])
+        if self.is_not_in_free_group:
+            self._release_page_ids(*(p // ps for p in pieces))
+        else:
+            self.free_page_reps_group.extend(pieces)
+
+    def free_group_begin(self):  # paged.py:314-316
+        self.is_not_in_free_group = False
+        self.free_group = []
+        self.free_page_reps_group = []
+
+    def free_group_end(self):  # paged.py:318-327
+        self.is_not_in_free_group = True
+        if self.free_group:
+            self.free(np.concatenate(self.free_group))
+        if self.free_page_reps_group:
+            self._release_page_ids(
+                np.concatenate(self.free_page_reps_group) // self.page_size
+            )
+            self.free_page_reps_group = []
+
+
+# --------------------------------------------------------------------------
+# a10 kv-index builder    kernels/ops/kvcache/kv_indices.py:8-46
+#                         + cumsum of triton_backend.py:386-404
+# --------------------------------------------------------------------------
+
+
+def build_kv_indices(req_to_token, req_pool_indices, lens, kv_start=None,
+                     out_dtype=np.int64):
+    """kv_indptr[0]=0, kv_indptr[1:]=cumsum(lens) (int32, triton_backend.py:393-394);
+    kv_indices[kv_indptr[i]:kv_indptr[i+1]] = req_to_token[req_pool_indices[i],
+    kv_start[i] : kv_start[i]+lens[i]] (kv_indices.py:22-46)."""
+    req_to_token = np.asarray(req_to_token)
+    lens = np.asarray(lens, dtype=np.int64)
+    bs = len(lens)
+    kv_indptr = np.zeros((bs + 1,), dtype=np.int32)
+    kv_indptr[1:] = np.cumsum(lens)
+    kv_indices = np.empty((int(kv_indptr[-1]),), dtype=out_dtype)
+    for i in range(bs):
+        s = 0 if kv_start is None else int(kv_start[i])
+        kv_indices[kv_indptr[i] : kv_indptr[i + 1]] = req_to_token[
+            int(req_pool_indices[i]), s : s + int(lens[i])
+        ]
+    return kv_indptr, kv_indices
+
+
+# --------------------------------------------------------------------------
+# a11 kv-split scheduler   kernels/ops/attention/metadata.py:11-60
+# --------------------------------------------------------------------------
+
+
+def _cdiv(a, b):
+    return -(-a // b)
+
+
+def num_kv_splits(seq_lens, num_group, num_head, num_kv_head, max_kv_splits,
+                  device_core_count):
+    """get_num_kv_splits_triton (metadata.py:11-60).  Output int32[num_seq*num_group],
+    entry (i*num_group + g) = splits of sequence i.  float32 log2 as in Triton."""
+    seq_lens = np.asarray(seq_lens, dtype=np.int64)
+    num_seq = len(seq_lens)
+    max_seq_len = int(seq_lens.max())
+    min_seq_len = int(seq_lens.min())
+    if max_seq_len * 8 < min_seq_len * 10:
+        min_seq_len = max_seq_len
+    max_kv_splits_1 = min(_cdiv(max_seq_len, min_seq_len), max_kv_splits)
+    kv_chunk_size_1 = _cdiv(max_seq_len, max_kv_splits_1)
+    ext_seq_len = np.float32(max_seq_len) / np.float32(64.0)
+    ext_device_core_count = int(
+        np.float32(device_core_count)
+        * np.maximum(np.log2(ext_seq_len, dtype=np.float32), np.float32(1.0))
+    )
+    block_h, num_kv_group = 16, num_head // num_kv_head
+    if num_kv_group == 1:
+        token_grid = num_seq * num_group * num_head
+    else:
+        block_h = min(block_h, num_kv_group)
+        token_grid = num_seq * num_group * _cdiv(num_head, block_h)
+    max_kv_splits_2 = min(_cdiv(ext_device_core_count, token_grid), max_kv_splits)
+    kv_chunk_size_2 = _cdiv(max_seq_len, max_kv_splits_2)
+    splits = np.maximum(_cdiv(seq_lens, kv_chunk_size_1), _cdiv(seq_lens, kv_chunk_size_2))
+    return np.repeat(splits.astype(np.int32), num_group)
+
+
+# --------------------------------------------------------------------------
+# a8  KV store       kernels/jit/csrc/elementwise/kvcache.cuh:189-219
+#                    wrapper kernels/ops/kvcache/kvcache.py:57-110
+# --------------------------------------------------------------------------
+
+
+def store_kv(k, v, k_cache, v_cache, loc, size_limit=0, reserved_skip_index=0):
+    """k_cache[loc[i]] = k[i]; v_cache[loc[i]] = v[i] (row copy, in place);
+    rows whose loc == reserved_skip_index (default slot 0) are skipped
+    (kvcache.cuh:215-217); loc outside [0, size_limit) is an error
+    (device assert kvcache.cuh:209)."""
+    loc = np.asarray(loc).astype(np.int64)
+    if size_limit <= 0:
+        size_limit = k_cache.shape[0]
+    if loc.size and (loc.min() < 0 or loc.max() >= size_limit):
+        raise IndexError("store_kv: loc out of [0, size_limit)")
+    kc = k_cache.reshape(k_cache.shape[0], -1)
+    vc = v_cache.reshape(v_cache.shape[0], -1)
+    k2 = k.reshape(k.shape[0], -1)
+    v2 = v.reshape(v.shape[0], -1)
+    for i, idx in enumerate(loc):
+        if idx == reserved_skip_index:
+            continue
+        kc[idx] = k2[i]
+        vc[idx] = v2[i]
+
+
+def move_kv(buffers: Sequence[np.ndarray], tgt_loc, src_loc):
+    """move_kv_cache (memory_pool.py:2775-2842 -> cache_move.py:60-133): for every
+    K and V buffer of every layer, buf[tgt_loc[i]] = buf[src_loc[i]].  Reads are
+    taken before writes per row (the kernel copies row by row; tgt/src are
+    disjoint in the reference's callers)."""
+    tgt = np.asarray(tgt_loc).astype(np.int64)
+    src = np.asarray(src_loc).astype(np.int64)
+    for buf in buffers:
+        rows = buf.reshape(buf.shape[0], -1)
+        rows[tgt] = rows[src].copy()
+
+
+# --------------------------------------------------------------------------
+# a12 decode attention   kernels/ops/attention/decode_attention.py:383-805, 968-1044
+# --------------------------------------------------------------------------
+
+
+def _tanh_cap(x, cap):
+    return cap * np.tanh(x / cap) if cap > 0 else x
+
+
+def _gather_kv(buf, slots, kv_head):
+    """buf [slots, Hkv, D] (NHD, memory_pool.py:2030-2041) -> [n, D] float64."""
+    return to_f64(buf[slots, kv_head])
+
+
+def decode_attention(q, k_buffer, v_buffer, kv_indptr, kv_indices, sm_scale,
+                     k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
+                     return_lse=False):
+    """Semantics of decode_attention_fwd (decode_attention.py:968-1044):
+    o[b,h] = softmax(q[b,h]·K[idx]^T * sm_scale*k_scale [tanh cap]) · V[idx] * v_scale,
+    idx = kv_indices[kv_indptr[b]:kv_indptr[b+1]], kv head = h // (Hq/Hkv).
+    Optional per-head sink logit joins the denominator (stage2 :796-798).
+    Returns o float64 [bs,Hq,Dv] (+ natural-log lse [bs,Hq])."""
+    bs, hq, _ = q.shape
+    hkv = k_buffer.shape[-2]
+    dv = v_buffer.shape[-1]
+    group = hq // hkv
+    qf = to_f64(q)
+    o = np.zeros((bs, hq, dv), dtype=np.float64)
+    lse = np.full((bs, hq), -np.inf, dtype=np.float64)
+    for b in range(bs):
+        idx = np.asarray(kv_indices[kv_indptr[b] : kv_indptr[b + 1]]).astype(np.int64)
+        if idx.size == 0:
+            continue
+        for kvh in range(hkv):
+            kk = _gather_kv(k_buffer, idx, kvh)
+            vv = _gather_kv(v_buffer, idx, kvh)
+            for h in range(kvh * group, (kvh + 1) * group):
+                s = _tanh_cap(kk @ qf[b, h] * (sm_scale * k_scale), logit_cap)
+                m = s.max()
+                p = np.exp(s - m)
+                den = p.sum()
+                if sinks is not None:
+                    den = den + math.exp(float(sinks[h]) - m)
+                o[b, h] = (p @ vv) / den * v_scale
+                lse[b, h] = m + math.log(p.sum())
+    return (o, lse) if return_lse else o
+
+
+_MIN_BLOCK_KV = 32  # decode_attention.py:36
+
+
+def decode_attention_split(q, k_buffer, v_buffer, kv_indptr, kv_indices,
+                           num_kv_splits_arr, max_kv_splits, sm_scale,
+                           k_scale=1.0, v_scale=1.0, logit_cap=0.0):
+    """Restates the two-stage split-KV layout: stage 1 (decode_attention.py:
+    466-594) writes, for split s of request b covering
+    [s*L, min((s+1)*L, seq)) with L = cdiv(cdiv(seq, splits), 32)*32,
+    attn_logits[b,h,s,:] = acc/e_sum and attn_lse[b,h,s] = e_max + log(e_sum);
+    stage 2 (:731-805) merges.  Returns (attn_logits, attn_lse, o); untouched
+    split entries are NaN so tests can check which entries must be written."""
+    bs, hq, _ = q.shape
+    hkv = k_buffer.shape[-2]
+    dv = v_buffer.shape[-1]
+    group = hq // hkv
+    qf = to_f64(q)
+    logits = np.full((bs, hq, max_kv_splits, dv), np.nan, dtype=np.float64)
+    lse = np.full((bs, hq, max_kv_splits), np.nan, dtype=np.float64)
+    o = np.zeros((bs, hq, dv), dtype=np.float64)
+    for b in range(bs):
+        idx = np.asarray(kv_indices[kv_indptr[b] : kv_indptr[b + 1]]).astype(np.int64)
+        seq = idx.size
+        splits = int(num_kv_splits_arr[b])
+        per = _cdiv(_cdiv(seq, splits), _MIN_BLOCK_KV) * _MIN_BLOCK_KV if seq else 0
+        for h in range(hq):
+            kvh = h // group
+            e_max, e_sum, acc = -np.inf, 0.0, np.zeros(dv)
+            for s in range(max_kv_splits):
+                lo, hi = per * s, min(per * (s + 1), seq)
+                if hi <= lo:
+                    continue
+                kk = _gather_kv(k_buffer, idx[lo:hi], kvh)
+                vv = _gather_kv(v_buffer, idx[lo:hi], kvh)
+                sc = _tanh_cap(kk @ qf[b, h] * (sm_scale * k_scale), logit_cap)
+                m = sc.max()
+                p = np.exp(sc - m)
+                logits[b, h, s] = (p @ vv) / p.sum()
+                lse[b, h, s] = m + math.log(p.sum())
+                n_max = max(lse[b, h, s], e_max)
+                old = math.exp(e_max - n_max)
+                w = math.exp(lse[b, h, s] - n_max)
+                acc = acc * old + w * logits[b, h, s]
+                e_sum = e_sum * old + w
+                e_max = n_max
+            if e_sum > 0:
+                o[b, h] = acc / e_sum * v_scale
+    return logits, lse, o
+
+
+# --------------------------------------------------------------------------
+# a13 extend attention   kernels/ops/attention/extend_attention.py:241-661, 664-812
+# --------------------------------------------------------------------------
+
+
+def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr,
+                     kv_indptr, kv_indices, is_causal=True, sm_scale=None,
+                     k_scale=1.0, v_scale=1.0, logit_cap=0.0,
+                     sliding_window_size=-1, sinks=None, skip_prefix=False,
+                     skip_extend=False, return_lse=False):
+    """Semantics of extend_attention_fwd (extend_attention.py:664-812).  Request i
+    has prefix tokens kv_indices[kv_indptr[i]:kv_indptr[i+1]] read from the cache
+    (stage 1, :372-510; scaled by k_scale / v_scale) and E_i = qo_indptr[i+1]-
+    qo_indptr[i] new tokens whose K/V are the contiguous k_extend/v_extend rows
+    (stage 2, :512-631).  Query m (0-based inside the extend part) sees every
+    prefix token and extend tokens n <= m when causal, all E_i otherwise.
+    sliding window W>0: q_abs <= kv_abs + W (:385-390, :556-561).
+    Returns o float64 [T,Hq,Dv] (+ lse [T,Hq])."""
+    t, hq, dq = q_extend.shape
+    hkv = k_extend.shape[1]
+    dv = v_extend.shape[-1]
+    group = hq // hkv
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(dq)
+    qf, kf, vf = to_f64(q_extend), to_f64(k_extend), to_f64(v_extend)
+    o = np.zeros((t, hq, dv), dtype=np.float64)
+    lse = np.full((t, hq), -np.inf, dtype=np.float64)
+    bs = len(qo_indptr) - 1
+    for i in range(bs):
+        q0, q1 = int(qo_indptr[i]), int(qo_indptr[i + 1])
+        e = q1 - q0
+        idx = np.asarray(kv_indices[kv_indptr[i] : kv_indptr[i + 1]]).astype(np.int64)
+        p_len = idx.size
+        for kvh in range(hkv):
+            if p_len and not skip_prefix:
+                kp = _gather_kv(k_buffer, idx, kvh)
+                vp = _gather_kv(v_buffer, idx, kvh)
+            else:
+                kp = np.zeros((0, dq)); vp = np.zeros((0, dv))
+            ke = kf[q0:q1, kvh]
+            ve = vf[q0:q1, kvh]
+            for h in range(kvh * group, (kvh + 1) * group):
+                for m in range(e):
+                    parts_s, parts_v = [], []
+                    if kp.shape[0]:
+                        s1 = _tanh_cap(kp @ qf[q0 + m, h] * (sm_scale * k_scale), logit_cap)
+                        if sliding_window_size > 0:
+                            keep = (p_len + m) <= (np.arange(p_len) + sliding_window_size)
+                            s1 = np.where(keep, s1, -np.inf)
+                        parts_s.append(s1); parts_v.append(vp * v_scale)
+                    if not skip_extend:
+                        n_end = (m + 1) if is_causal else e
+                        s2 = _tanh_cap(ke[:n_end] @ qf[q0 + m, h] * sm_scale, logit_cap)
+                        if sliding_window_size > 0:
+                            keep = m <= (np.arange(n_end) + sliding_window_size)
+                            s2 = np.where(keep, s2, -np.inf)
+                        parts_s.append(s2); parts_v.append(ve[:n_end])
+                    if not parts_s:
+                        continue
+                    s = np.concatenate(parts_s)
+                    vv = np.concatenate(parts_v, axis=0)
+                    mx = s.max()
+                    if not np.isfinite(mx):
+                        continue
+                    p = np.exp(s - mx)
+                    den = p.sum()
+                    lse[q0 + m, h] = mx + math.log(den)
+                    if sinks is not None:
+                        den = den + math.exp(float(sinks[h]) - mx)
+                    o[q0 + m, h] = (p @ vv) / den
+    return (o, lse) if return_lse else o
+
+
+# --------------------------------------------------------------------------
+# a14 torch-native semantics   srt/layers/attention/torch_native_backend.py:61-277
+# --------------------------------------------------------------------------
+
+
+def sdpa_decode_req_to_token(q, k_cache, v_cache, req_to_token, req_pool_indices,
+                             seq_lens, scaling):
+    """_run_sdpa_forward_decode (:176-277): per request, K/V =
+    cache[req_to_token[req_pool_idx, :seq_len]], one query token, no mask."""
+    kv_indptr, kv_indices = build_kv_indices(req_to_token, req_pool_indices, seq_lens)
+    return decode_attention(q, k_cache, v_cache, kv_indptr, kv_indices, scaling)
+
+
+def sdpa_extend_req_to_token(q, k_cache, v_cache, req_to_token, req_pool_indices,
+                             seq_lens, extend_prefix_lens, extend_seq_lens, scaling,
+                             causal=True):
+    """_run_sdpa_forward_extend (:61-174): the new tokens' K/V are read back from
+    the cache (they were stored before the call), queries sit at positions
+    prefix..seq-1 of a causal mask over the whole sequence."""
+    t, hq, _ = q.shape
+    hkv = k_cache.shape[-2]
+    group = hq // hkv
+    dv = v_cache.shape[-1]
+    qf = to_f64(q)
+    o = np.zeros((t, hq, dv), dtype=np.float64)
+    start = 0
+    for i in range(len(seq_lens)):
+        e, pre, seq = int(extend_seq_lens[i]), int(extend_prefix_lens[i]), int(seq_lens[i])
+        idx = np.asarray(req_to_token[int(req_pool_indices[i]), :seq]).astype(np.int64)
+        for kvh in range(hkv):
+            kk = _gather_kv(k_cache, idx, kvh)
+            vv = _gather_kv(v_cache, idx, kvh)
+            for h in range(kvh * group, (kvh + 1) * group):
+                for m in range(e):
+                    n_end = pre + m + 1 if causal else seq
+                    s = kk[:n_end] @ qf[start + m, h] * scaling
+                    p = np.exp(s - s.max())
+                    o[start + m, h] = (p @ vv[:n_end]) / p.sum()
+        start += e
+    return o

@@ -1,0 +1,380 @@
+"""Generate golden fixtures by RUNNING THE REFERENCE in the build container.
+
+    cd /root/repo && python tests/golden/make_golden.py
+
+Imports the reference's own kernels from /root/reference (Triton kernels under
+TRITON_INTERPRET=1 on CPU tensors; the paged/token allocators on device="cpu")
+and stores (inputs, outputs) as small .npz files next to this script.  Only the
+.npz data travels to the GPU box; the tests never import the reference.
+
+Fixture families:
+  F1 allocator op sequences      -> alloc_*.npz
+  F2 kv-indices                  -> kv_indices.npz
+  F3 num_kv_splits               -> kv_splits.npz
+  F4 store (torch index_put fallback of memory_pool.py:189-192) -> store_kv.npz
+  F5 decode attention (Triton decode_attention_fwd) -> decode_*.npz
+  F6 extend attention (Triton extend_attention_fwd) -> extend_*.npz
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import  # noqa: E402
+
+_ref_import.install()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from sglang.kernels.ops.attention.decode_attention import decode_attention_fwd  # noqa: E402
+from sglang.kernels.ops.attention.extend_attention import extend_attention_fwd  # noqa: E402
+from sglang.kernels.ops.attention.metadata import get_num_kv_splits_triton  # noqa: E402
+from sglang.kernels.ops.kvcache.kv_indices import (  # noqa: E402
+    create_flashinfer_kv_indices_triton,
+)
+from sglang.srt.mem_cache.allocator.paged import PagedTokenToKVPoolAllocator  # noqa: E402
+from sglang.srt.mem_cache.allocator.token import TokenToKVPoolAllocator  # noqa: E402
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    """bf16 tensor -> uint16 bit patterns; others -> numpy."""
+    if t.dtype == torch.bfloat16:
+        return t.contiguous().view(torch.uint16).numpy().copy()
+    return t.contiguous().numpy().copy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrs.items()})
+
+
+# ------------------------------------------------------------------ F1
+def gen_allocator(page_size: int, need_sort: bool, seed: int):
+    """Drive the reference allocator with a small scheduler-like workload and
+    log every call's inputs, result and the free list afterwards."""
+    rng = np.random.default_rng(seed)
+    size = 64 * max(page_size, 4)
+    if page_size == 1:
+        alloc = TokenToKVPoolAllocator(size, torch.bfloat16, "cpu", None, need_sort)
+    else:
+        alloc = PagedTokenToKVPoolAllocator(
+            size, page_size, torch.bfloat16, "cpu", None, need_sort
+        )
+    log = []
+    reqs = {}  # rid -> list of slots
+    next_rid = 0
+
+    def snap():
+        return alloc.free_pages.numpy().tolist(), alloc.release_pages.numpy().tolist()
+
+    for step in range(40):
+        op = rng.choice(["extend", "decode", "free", "free_segment", "sort", "group_free"],
+                        p=[0.3, 0.3, 0.15, 0.1, 0.05, 0.1])
+        if op == "extend" or not reqs:
+            bs = int(rng.integers(1, 4))
+            rids, prefix, seqs, last = [], [], [], []
+            for _ in range(bs):
+                if reqs and rng.random() < 0.5:
+                    rid = int(rng.choice(list(reqs.keys())))
+                    if rid in rids:
+                        continue
+                else:
+                    rid = next_rid
+                    next_rid += 1
+                    reqs[rid] = []
+                pre = len(reqs[rid])
+                ext = int(rng.integers(1, 3 * page_size + 3))
+                rids.append(rid); prefix.append(pre); seqs.append(pre + ext)
+                last.append(reqs[rid][-1] if pre else -1)
+            if page_size == 1:
+                need = int(sum(s - p for s, p in zip(seqs, prefix)))
+                out = alloc.alloc(need)
+                res = None if out is None else out.numpy().tolist()
+                log.append(dict(op="alloc", need=need, out=res, free=snap()))
+            else:
+                pl = torch.tensor(prefix, dtype=torch.int64)
+                sl = torch.tensor(seqs, dtype=torch.int64)
+                ll = torch.tensor(last, dtype=torch.int64)
+                out = alloc.alloc_extend(pl, pl, sl, sl, ll, int((sl - pl).sum()))
+                res = None if out is None else out.numpy().tolist()
+                log.append(dict(op="alloc_extend", prefix_lens=prefix, seq_lens=seqs,
+                                last_loc=last, out=res, free=snap()))
+            if res is not None:
+                o = 0
+                for rid, p, s in zip(rids, prefix, seqs):
+                    reqs[rid].extend(res[o : o + s - p]); o += s - p
+            else:
+                for rid in rids:
+                    if not reqs[rid]:
+                        del reqs[rid]
+        elif op == "decode":
+            rids = [r for r in reqs if reqs[r]]
+            if not rids:
+                continue
+            rids = list(rng.choice(rids, size=min(len(rids), int(rng.integers(1, 5))), replace=False))
+            seqs = [len(reqs[r]) + 1 for r in rids]
+            last = [reqs[r][-1] for r in rids]
+            if page_size == 1:
+                out = alloc.alloc(len(rids))
+                res = None if out is None else out.numpy().tolist()
+                log.append(dict(op="alloc", need=len(rids), out=res, free=snap()))
+            else:
+                sl = torch.tensor(seqs, dtype=torch.int64)
+                out = alloc.alloc_decode(sl, sl, torch.tensor(last, dtype=torch.int64))
+                res = None if out is None else out.numpy().tolist()
+                log.append(dict(op="alloc_decode", seq_lens=seqs, last_loc=last,
+                                out=res, free=snap()))
+            if res is not None:
+                for r, x in zip(rids, res):
+                    reqs[int(r)].append(x)
+        elif op == "free":
+            rid = int(rng.choice(list(reqs.keys())))
+            idx = reqs.pop(rid)
+            alloc.free(torch.tensor(idx, dtype=torch.int64))
+            log.append(dict(op="free", idx=idx, free=snap()))
+        elif op == "free_segment" and page_size > 1:
+            rid = int(rng.choice(list(reqs.keys())))
+            row = reqs[rid]
+            if len(row) < page_size + 1:
+                continue
+            # free the tail from a page boundary onward (a page is freed by one call)
+            start = (int(rng.integers(0, len(row))) // page_size) * page_size
+            idx = row[start:]
+            reqs[rid] = row[:start]
+            if not reqs[rid]:
+                del reqs[rid]
+            alloc.free_segment(torch.tensor(idx, dtype=torch.int64), start_pos=start)
+            log.append(dict(op="free_segment", idx=idx, start_pos=start, free=snap()))
+        elif op == "sort":
+            alloc.merge_and_sort_free()
+            log.append(dict(op="merge_and_sort_free", free=snap()))
+        elif op == "group_free" and len(reqs) >= 2:
+            alloc.free_group_begin()
+            freed = []
+            for rid in list(reqs.keys())[:2]:
+                idx = reqs.pop(rid)
+                alloc.free(torch.tensor(idx, dtype=torch.int64))
+                freed.append(idx)
+            alloc.free_group_end()
+            log.append(dict(op="free_group", idx=freed, free=snap()))
+    return dict(page_size=page_size, need_sort=need_sort, size=size, log=log)
+
+
+def f1():
+    cases = []
+    for ps in (1, 4, 16, 32):
+        for need_sort in (False, True):
+            cases.append(gen_allocator(ps, need_sort, seed=100 + ps))
+    with open(os.path.join(HERE, "alloc_sequences.json"), "w") as f:
+        json.dump(cases, f)
+    print("wrote alloc_sequences.json", [len(c["log"]) for c in cases])
+
+
+# ------------------------------------------------------------------ F2
+def f2():
+    rng = np.random.default_rng(7)
+    out = {}
+    for ci, (batch, max_batch, ctx) in enumerate([(1, 8, 64), (5, 16, 300), (37, 64, 700)]):
+        r2t = torch.from_numpy(rng.integers(0, 1 << 20, size=(max_batch, ctx)).astype(np.int32))
+        rpi = torch.from_numpy(rng.choice(max_batch, size=batch, replace=False).astype(np.int32))
+        lens = torch.from_numpy(rng.integers(0, ctx // 2, size=batch).astype(np.int32))
+        start = torch.from_numpy(rng.integers(0, ctx // 2, size=batch).astype(np.int32))
+        for use_start in (False, True):
+            kv_indptr = torch.zeros((batch + 1,), dtype=torch.int32)
+            kv_indptr[1:] = torch.cumsum(lens, 0)
+            kv_indices = torch.full((int(kv_indptr[-1]),), -1, dtype=torch.int64)
+            create_flashinfer_kv_indices_triton[(batch,)](
+                r2t, rpi, lens, kv_indptr, start if use_start else None, kv_indices, r2t.stride(0)
+            )
+            tag = f"c{ci}_{int(use_start)}"
+            out.update({f"{tag}_req_to_token": r2t.numpy(), f"{tag}_req_pool_indices": rpi.numpy(),
+                        f"{tag}_lens": lens.numpy(), f"{tag}_start": start.numpy(),
+                        f"{tag}_kv_indptr": kv_indptr.numpy(), f"{tag}_kv_indices": kv_indices.numpy()})
+    save("kv_indices.npz", **out)
+
+
+# ------------------------------------------------------------------ F3
+def f3():
+    rng = np.random.default_rng(11)
+    rows = []
+    import triton
+    for (hq, hkv) in [(32, 8), (16, 4), (8, 2), (4, 1), (12, 12), (128, 1), (64, 8)]:
+        for bs in (1, 3, 64, 256, 300):
+            for kind in ("uniform", "ragged", "short"):
+                if kind == "uniform":
+                    sl = np.full((bs,), 4096)
+                elif kind == "ragged":
+                    sl = rng.integers(1, 8192, size=bs)
+                else:
+                    sl = rng.integers(1, 64, size=bs)
+                for max_splits in (8, 16):
+                    for num_group in (1, 2):
+                        seq = torch.from_numpy(sl.astype(np.int32))
+                        outp = torch.zeros((bs * num_group,), dtype=torch.int32)
+                        sched = 256 if bs < 256 else triton.next_power_of_2(bs)
+                        get_num_kv_splits_triton[(1,)](outp, seq, bs, num_group, hq, hkv,
+                                                       max_splits, 256, MAX_NUM_SEQ=sched)
+                        rows.append(dict(hq=hq, hkv=hkv, max_splits=max_splits, num_group=num_group,
+                                         cores=256, seq_lens=sl.tolist(), out=outp.numpy().tolist()))
+    with open(os.path.join(HERE, "kv_splits.json"), "w") as f:
+        json.dump(rows, f)
+    print("wrote kv_splits.json", len(rows))
+
+
+# ------------------------------------------------------------------ F4
+def f4():
+    g = torch.Generator().manual_seed(3)
+    out = {}
+    for ci, (n, rows, hkv, d, idt) in enumerate([(7, 40, 2, 64, torch.int64), (33, 200, 8, 128, torch.int32)]):
+        k = torch.randn(n, hkv, d, generator=g).to(torch.bfloat16)
+        v = torch.randn(n, hkv, d, generator=g).to(torch.bfloat16)
+        kc = torch.randn(rows, hkv, d, generator=g).to(torch.bfloat16)
+        vc = torch.randn(rows, hkv, d, generator=g).to(torch.bfloat16)
+        loc = (torch.randperm(rows - 1, generator=g)[:n] + 1).to(idt)  # unique, never slot 0
+        kc0, vc0 = kc.clone(), vc.clone()
+        # the reference's torch fallback (memory_pool.py:189-192)
+        kc[loc.long()] = k
+        vc[loc.long()] = v
+        out.update({f"c{ci}_k": bits(k), f"c{ci}_v": bits(v), f"c{ci}_kc_in": bits(kc0),
+                    f"c{ci}_vc_in": bits(vc0), f"c{ci}_loc": loc.numpy(),
+                    f"c{ci}_kc_out": bits(kc), f"c{ci}_vc_out": bits(vc)})
+    save("store_kv.npz", **out)
+
+
+# ------------------------------------------------------------------ F5
+def run_decode(q, kb, vb, kv_indptr, kv_indices, num_kv_splits, max_kv_splits, sm_scale,
+               logit_cap=0.0):
+    b, hq, _ = q.shape
+    dv = vb.shape[-1]
+    o = torch.zeros(b, hq, dv, dtype=q.dtype)
+    attn_logits = torch.zeros(b, hq, max_kv_splits, dv, dtype=torch.float32)
+    attn_lse = torch.zeros(b, hq, max_kv_splits, dtype=torch.float32)
+    decode_attention_fwd(q, kb, vb, o, kv_indptr, kv_indices, attn_logits, attn_lse,
+                         num_kv_splits, max_kv_splits, sm_scale, 1.0, 1.0, logit_cap=logit_cap)
+    return o, attn_logits, attn_lse
+
+
+def f5():
+    torch.manual_seed(42)
+    # Triton's CPU interpreter has no bf16 scalar support (InterpreterBuilder.get_bf16
+    # is missing), so the Triton-derived goldens use fp16; bf16 goldens come from the
+    # compiled reference C++ CPU kernels (oracle/_ref, see f8).
+    dtype = torch.float16
+    cases = {}
+    # (a) the reference's own decode test configs (test_triton_attention_kernels.py:563-573)
+    for ci, (B, HQ, HKV, D) in enumerate([(2, 4, 4, 64), (2, 4, 2, 64), (2, 4, 4, 80), (2, 4, 4, 13)]):
+        S = 10
+        q = torch.randn(B, HQ, D).to(dtype)
+        kb = torch.randn(B * S, HKV, D).to(dtype)
+        vb = torch.randn(B * S, HKV, D).to(dtype)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.cumsum(torch.full((B,), S), 0)
+        kv_indices = torch.arange(B * S)
+        nsplit = torch.full((B,), 4, dtype=torch.int32)
+        o, al, lse = run_decode(q, kb, vb, kv_indptr, kv_indices, nsplit, 8, 1.0 / D**0.5)
+        cases[f"ref{ci}"] = dict(q=q, kb=kb, vb=vb, kv_indptr=kv_indptr, kv_indices=kv_indices,
+                                 nsplit=nsplit, max_splits=8, sm_scale=1.0 / D**0.5, o=o,
+                                 attn_logits=al, attn_lse=lse)
+    # (b) grouped configs (:663-676), trimmed to interpreter-friendly sizes
+    for ci, (B, S, HQ, HKV, D, DV) in enumerate([(2, 5, 16, 16, 64, 64), (2, 100, 16, 1, 64, 64),
+                                                  (2, 37, 128, 2, 128, 128)]):
+        q = torch.randn(B, HQ, D).to(dtype)
+        kb = torch.randn(B * S, HKV, D).to(dtype)
+        vb = torch.randn(B * S, HKV, DV).to(dtype)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.cumsum(torch.full((B,), S), 0)
+        kv_indices = torch.arange(B * S)
+        nsplit = torch.full((B,), 4, dtype=torch.int32)
+        o, al, lse = run_decode(q, kb, vb, kv_indptr, kv_indices, nsplit, 8, 1.0 / D**0.5)
+        cases[f"grp{ci}"] = dict(q=q, kb=kb, vb=vb, kv_indptr=kv_indptr, kv_indices=kv_indices,
+                                 nsplit=nsplit, max_splits=8, sm_scale=1.0 / D**0.5, o=o,
+                                 attn_logits=al, attn_lse=lse)
+    # (c) Llama-shaped GQA, ragged lengths, shuffled slots, K3-chosen splits, logit cap variant
+    rng = np.random.default_rng(5)
+    for ci, (HQ, HKV, cap) in enumerate([(32, 8, 0.0), (16, 4, 0.0), (8, 2, 30.0), (4, 1, 0.0)]):
+        D = 128
+        lens = np.array([33, 1, 150, 64], dtype=np.int32)
+        B = len(lens)
+        total = int(lens.sum())
+        pool = total + 17
+        q = torch.randn(B, HQ, D).to(dtype)
+        kb = torch.randn(pool, HKV, D).to(dtype)
+        vb = torch.randn(pool, HKV, D).to(dtype)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.from_numpy(np.cumsum(lens))
+        kv_indices = torch.from_numpy((rng.permutation(pool - 1)[:total] + 1).astype(np.int64))
+        nsplit = torch.zeros(B, dtype=torch.int32)
+        get_num_kv_splits_triton[(1,)](nsplit, torch.from_numpy(lens), B, 1, HQ, HKV, 8, 256,
+                                       MAX_NUM_SEQ=256)
+        o, al, lse = run_decode(q, kb, vb, kv_indptr, kv_indices, nsplit, 8, 1.0 / D**0.5,
+                                logit_cap=cap)
+        cases[f"llama{ci}"] = dict(q=q, kb=kb, vb=vb, kv_indptr=kv_indptr, kv_indices=kv_indices,
+                                   nsplit=nsplit, max_splits=8, sm_scale=1.0 / D**0.5,
+                                   logit_cap=cap, o=o, attn_logits=al, attn_lse=lse)
+    flat = {}
+    for name, c in cases.items():
+        for k, v in c.items():
+            flat[f"{name}.{k}"] = bits(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+    save("decode.npz", **flat)
+
+
+# ------------------------------------------------------------------ F6
+def f6():
+    torch.manual_seed(42)
+    dtype = torch.float16
+    rng = np.random.default_rng(9)
+    cases = {}
+    cfgs = [
+        # name, Hq, Hkv, D, prefix lens, extend lens, causal, logit_cap
+        ("gqa128", 12, 4, 128, [16, 33, 0], [5, 20, 9], True, 0.0),
+        ("gqa64", 4, 2, 64, [0, 7], [40, 1], True, 0.0),
+        ("mha96", 4, 4, 96, [12, 3], [9, 17], True, 0.0),
+        ("noncausal", 8, 2, 128, [10, 0], [6, 11], False, 0.0),
+        ("llama_cap", 32, 8, 128, [64, 5], [3, 33], True, 50.0),
+    ]
+    for name, HQ, HKV, D, pre, ext, causal, cap in cfgs:
+        pre = np.array(pre, dtype=np.int32); ext = np.array(ext, dtype=np.int32)
+        B = len(pre)
+        T = int(ext.sum())
+        total = int((pre + ext).sum())
+        pool = total + 9
+        slots = rng.permutation(pool - 1)[:total] + 1
+        kb = torch.randn(pool, HKV, D).to(dtype)
+        vb = torch.randn(pool, HKV, D).to(dtype)
+        q = torch.randn(T, HQ, D).to(dtype)
+        k_ext = torch.empty(T, HKV, D, dtype=dtype)
+        v_ext = torch.empty(T, HKV, D, dtype=dtype)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.from_numpy(np.cumsum(pre))
+        qo_indptr = torch.zeros(B + 1, dtype=torch.int64)
+        qo_indptr[1:] = torch.from_numpy(np.cumsum(ext))
+        kv_indices = torch.empty(int(pre.sum()), dtype=torch.int64)
+        so = 0
+        for i in range(B):
+            s = slots[so : so + pre[i] + ext[i]]; so += pre[i] + ext[i]
+            kv_indices[kv_indptr[i] : kv_indptr[i + 1]] = torch.from_numpy(s[: pre[i]])
+            es = torch.from_numpy(s[pre[i] :])
+            k_ext[qo_indptr[i] : qo_indptr[i + 1]] = kb[es]
+            v_ext[qo_indptr[i] : qo_indptr[i + 1]] = vb[es]
+        o = torch.zeros(T, HQ, D, dtype=dtype)
+        lse = torch.zeros(T, HQ, dtype=torch.float32)
+        extend_attention_fwd(q, k_ext, v_ext, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None,
+                             causal, None, int(ext.max()), 1.0, 1.0, sm_scale=1.0 / D**0.5,
+                             logit_cap=cap, lse_extend=lse)
+        cases[name] = dict(q=q, k_ext=k_ext, v_ext=v_ext, kb=kb, vb=vb, qo_indptr=qo_indptr,
+                           kv_indptr=kv_indptr, kv_indices=kv_indices, causal=int(causal),
+                           sm_scale=1.0 / D**0.5, logit_cap=cap, o=o, lse=lse)
+    flat = {}
+    for name, c in cases.items():
+        for k, v in c.items():
+            flat[f"{name}.{k}"] = bits(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+    save("extend.npz", **flat)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6"]
+    for w in which:
+        globals()[w]()

@@ -1,0 +1,186 @@
+"""Pin the CPU oracle (oracle/radix_oracle.py) against the golden vectors produced
+by the reference's own kernels/allocators (tests/golden/make_golden.py).
+Integer paths must match bit-exactly; attention within the reference's own
+tolerances (test_triton_attention_kernels.py:559 atol=rtol=1e-2 for decode,
+:307 rtol=1e-2/atol=1e-3 for extend) -- the fp64 oracle vs the fp16 Triton output.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import radix_oracle as orc
+
+
+def _load_npz(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _cases(npz):
+    out = {}
+    for key in npz.files:
+        case, field = key.split(".", 1)
+        out.setdefault(case, {})[field] = npz[key]
+    return out
+
+
+# ------------------------------------------------------------------ F1
+def _replay_allocator(case, alloc):
+    for step, ent in enumerate(case["log"]):
+        op = ent["op"]
+        if op == "alloc":
+            out = alloc.alloc(ent["need"])
+        elif op == "alloc_extend":
+            out = alloc.alloc_extend(ent["prefix_lens"], ent["seq_lens"], ent["last_loc"])
+        elif op == "alloc_decode":
+            out = alloc.alloc_decode(ent["seq_lens"], ent["last_loc"])
+        elif op == "free":
+            alloc.free(np.array(ent["idx"], dtype=np.int64)); out = "skip"
+        elif op == "free_segment":
+            alloc.free_segment(np.array(ent["idx"], dtype=np.int64), ent["start_pos"]); out = "skip"
+        elif op == "merge_and_sort_free":
+            alloc.merge_and_sort_free(); out = "skip"
+        elif op == "free_group":
+            alloc.free_group_begin()
+            for idx in ent["idx"]:
+                alloc.free(np.array(idx, dtype=np.int64))
+            alloc.free_group_end(); out = "skip"
+        else:
+            raise AssertionError(op)
+        if not isinstance(out, str):
+            want = ent["out"]
+            if want is None:
+                assert out is None, (step, op)
+            else:
+                assert out is not None and out.tolist() == want, (step, op)
+        free, rel = ent["free"]
+        assert alloc.free_pages.tolist() == free, (step, op)
+        assert alloc.release_pages.tolist() == rel, (step, op)
+
+
+def test_allocator_sequences_bit_exact(golden_dir):
+    with open(os.path.join(golden_dir, "alloc_sequences.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 8
+    for case in cases:
+        ps = case["page_size"]
+        if ps == 1:
+            alloc = orc.TokenAllocatorOracle(case["size"], case["need_sort"])
+        else:
+            alloc = orc.PagedAllocatorOracle(case["size"], ps, case["need_sort"])
+        _replay_allocator(case, alloc)
+
+
+# ------------------------------------------------------------------ F2
+def test_kv_indices_bit_exact(golden_dir):
+    z = _load_npz(golden_dir, "kv_indices.npz")
+    for ci in range(3):
+        for use_start in (0, 1):
+            t = f"c{ci}_{use_start}_"
+            kv_indptr, kv_indices = orc.build_kv_indices(
+                z[t + "req_to_token"], z[t + "req_pool_indices"], z[t + "lens"],
+                z[t + "start"] if use_start else None)
+            assert np.array_equal(kv_indptr, z[t + "kv_indptr"])
+            assert kv_indptr.dtype == np.int32
+            assert np.array_equal(kv_indices, z[t + "kv_indices"])
+
+
+# ------------------------------------------------------------------ F3
+def test_num_kv_splits_bit_exact(golden_dir):
+    with open(os.path.join(golden_dir, "kv_splits.json")) as f:
+        rows = json.load(f)
+    assert len(rows) >= 400
+    for r in rows:
+        got = orc.num_kv_splits(r["seq_lens"], r["num_group"], r["hq"], r["hkv"],
+                                r["max_splits"], r["cores"])
+        assert got.tolist() == r["out"], {k: r[k] for k in ("hq", "hkv", "max_splits", "num_group")}
+
+
+# ------------------------------------------------------------------ F4
+def test_store_kv_bit_exact(golden_dir):
+    z = _load_npz(golden_dir, "store_kv.npz")
+    for ci in range(2):
+        kc, vc = z[f"c{ci}_kc_in"].copy(), z[f"c{ci}_vc_in"].copy()
+        orc.store_kv(z[f"c{ci}_k"], z[f"c{ci}_v"], kc, vc, z[f"c{ci}_loc"])
+        assert np.array_equal(kc, z[f"c{ci}_kc_out"])
+        assert np.array_equal(vc, z[f"c{ci}_vc_out"])
+
+
+def test_store_kv_skips_reserved_slot_and_rejects_oob():
+    k = np.arange(12, dtype=np.uint16).reshape(3, 4)
+    kc = np.zeros((5, 4), dtype=np.uint16)
+    vc = np.zeros((5, 4), dtype=np.uint16)
+    orc.store_kv(k, k + 100, kc, vc, np.array([2, 0, 4]))
+    assert np.array_equal(kc[2], k[0]) and np.array_equal(kc[4], k[2])
+    assert not kc[0].any() and not vc[0].any()  # slot 0 is the padding sink: skipped
+    with pytest.raises(IndexError):
+        orc.store_kv(k, k, kc, vc, np.array([1, 5, 2]))
+
+
+# ------------------------------------------------------------------ F5
+def test_decode_attention_vs_triton_golden(golden_dir):
+    cases = _cases(_load_npz(golden_dir, "decode.npz"))
+    assert len(cases) >= 11
+    for name, c in cases.items():
+        cap = float(c["logit_cap"]) if "logit_cap" in c else 0.0
+        o, lse = orc.decode_attention(c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"],
+                                      float(c["sm_scale"]), logit_cap=cap, return_lse=True)
+        want = c["o"].astype(np.float64)
+        np.testing.assert_allclose(o, want, atol=1e-2, rtol=1e-2, err_msg=name)
+        # split layout: which (b,h,s) entries exist and what they hold
+        logits, lse_s, o2 = orc.decode_attention_split(
+            c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"], c["nsplit"],
+            int(c["max_splits"]), float(c["sm_scale"]), logit_cap=cap)
+        np.testing.assert_allclose(o2, o, atol=1e-9, rtol=1e-9, err_msg=name)
+        written = ~np.isnan(lse_s)
+        np.testing.assert_allclose(lse_s[written], c["attn_lse"].astype(np.float64)[written],
+                                   atol=2e-3, rtol=2e-3, err_msg=name)
+        np.testing.assert_allclose(logits[written], c["attn_logits"].astype(np.float64)[written],
+                                   atol=5e-3, rtol=1e-2, err_msg=name)
+
+
+# ------------------------------------------------------------------ F6
+def test_extend_attention_vs_triton_golden(golden_dir):
+    cases = _cases(_load_npz(golden_dir, "extend.npz"))
+    assert len(cases) == 5
+    for name, c in cases.items():
+        o, lse = orc.extend_attention(
+            c["q"], c["k_ext"], c["v_ext"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"],
+            c["kv_indices"], is_causal=bool(c["causal"]), sm_scale=float(c["sm_scale"]),
+            logit_cap=float(c["logit_cap"]), return_lse=True)
+        np.testing.assert_allclose(o, c["o"].astype(np.float64), atol=2e-3, rtol=1e-2, err_msg=name)
+        np.testing.assert_allclose(lse, c["lse"].astype(np.float64), atol=2e-3, rtol=1e-3,
+                                   err_msg=name)
+
+
+def test_sdpa_semantics_match_kernel_semantics():
+    """torch_native (req_to_token gather + causal SDPA over the whole sequence) and the
+    Triton contract (prefix from cache + contiguous new K/V) describe the same function."""
+    rng = np.random.default_rng(0)
+    hq, hkv, d = 4, 2, 16
+    pre = np.array([3, 0]); ext = np.array([4, 5]); seq = pre + ext
+    pool = 32
+    kb = rng.standard_normal((pool, hkv, d)).astype(np.float32)
+    vb = rng.standard_normal((pool, hkv, d)).astype(np.float32)
+    r2t = np.zeros((3, 16), dtype=np.int32)
+    slots = rng.permutation(pool - 1)[: seq.sum()] + 1
+    r2t[1, : seq[0]] = slots[: seq[0]]; r2t[2, : seq[1]] = slots[seq[0]:]
+    rpi = np.array([1, 2])
+    q = rng.standard_normal((ext.sum(), hq, d)).astype(np.float32)
+    a = orc.sdpa_extend_req_to_token(q, kb, vb, r2t, rpi, seq, pre, ext, 0.25)
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, pre)
+    qo = np.concatenate([[0], np.cumsum(ext)])
+    k_ext = np.concatenate([kb[r2t[1, pre[0]:seq[0]]], kb[r2t[2, pre[1]:seq[1]]]])
+    v_ext = np.concatenate([vb[r2t[1, pre[0]:seq[0]]], vb[r2t[2, pre[1]:seq[1]]]])
+    b = orc.extend_attention(q, k_ext, v_ext, kb, vb, qo, kv_indptr, kv_indices, sm_scale=0.25)
+    np.testing.assert_allclose(a, b, atol=1e-12)
+
+
+def test_bf16_roundtrip():
+    x = np.array([1.0, -2.5, 3.14159, 1e-3, 65504.0, np.nan], dtype=np.float32)
+    b = orc.f32_to_bf16(x)
+    y = orc.bf16_to_f32(b)
+    assert np.isnan(y[-1])
+    np.testing.assert_allclose(y[:-1], x[:-1], rtol=2**-8)
+    assert orc.f32_to_bf16(np.array([1.00390625], dtype=np.float32))[0] == 0x3F80  # ties-to-even
