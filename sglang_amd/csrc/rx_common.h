@@ -1,0 +1,95 @@
+// Shared host/device helpers for libradix_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/radix_hip.h"
+
+namespace rx {
+
+// thread-local last-error string (rx_last_error)
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(RX_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return RX_OK;
+}
+
+#define RX_REQUIRE(cond, ...)                                   \
+  do {                                                          \
+    if (!(cond)) return ::rx::fail(RX_ERR_INVALID_ARG, __VA_ARGS__); \
+  } while (0)
+
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+__device__ __forceinline__ int64_t load_idx(const void* p, int64_t i, bool is64) {
+  return is64 ? reinterpret_cast<const int64_t*>(p)[i]
+              : static_cast<int64_t>(reinterpret_cast<const int32_t*>(p)[i]);
+}
+
+// ---- 16-bit float helpers -------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_t;  // builtin's type
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+struct BF16 {
+  using vec8 = bf16x8;
+  using scalar = __bf16;
+  static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  // ds_read_b64_tr_b16: 4 rows x 16 cols block per 16 lanes, delivered column-major
+  static __device__ __forceinline__ u32x2 ds_read_tr(const void* lds_addr) {
+    auto p = (__attribute__((address_space(3))) bf16x4*)(uintptr_t)(uint32_t)(uintptr_t)lds_addr;
+    bf16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p);
+    return __builtin_bit_cast(u32x2, r);
+  }
+  static __device__ __forceinline__ float to_f32(uint16_t b) {
+    return __builtin_bit_cast(float, static_cast<uint32_t>(b) << 16);
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float f) {
+    __bf16 h = static_cast<__bf16>(f);  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(uint16_t, h);
+  }
+};
+
+struct F16 {
+  using vec8 = f16x8;
+  using scalar = _Float16;
+  static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ u32x2 ds_read_tr(const void* lds_addr) {
+    auto p = (__attribute__((address_space(3))) fp16x4_t*)(uintptr_t)(uint32_t)(uintptr_t)lds_addr;
+    fp16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16(p);
+    return __builtin_bit_cast(u32x2, r);
+  }
+  static __device__ __forceinline__ float to_f32(uint16_t b) {
+    return static_cast<float>(__builtin_bit_cast(_Float16, b));
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float f) {
+    return __builtin_bit_cast(uint16_t, static_cast<_Float16>(f));
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return static_cast<uint32_t>(T::from_f32(lo)) | (static_cast<uint32_t>(T::from_f32(hi)) << 16);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+}  // namespace rx

@@ -1,0 +1,569 @@
+// K4/K5/K6: split-KV decode attention for gfx950.
+//
+// Reference: decode_attention_fwd (kernels/ops/attention/decode_attention.py:968-1044),
+// stage 1 _fwd_grouped_kernel_stage1 (:383-608), stage 2 _fwd_kernel_stage2 (:731-805).
+//
+// MI355X design (not a translation of the Triton tiling):
+//   * one 256-thread workgroup = 4 independent waves per (request, kv head, q-block, kv split);
+//     wave w streams KV tiles w, w+4, ... of 32 tokens and keeps its own online-softmax state;
+//     the four states are merged once through LDS at the end.  No barrier in the main loop.
+//   * K goes HBM -> VGPR directly in MFMA A-operand shape (lane = (token&15, 8-element d
+//     group)), 16 B per lane, every byte of a 256-B head row is fetched exactly once.
+//   * S^T = K Q^T  with v_mfma_f32_16x16x32 (A = K tile, B = Q^T kept in registers, the up-to-16
+//     query heads of the GQA group on the N axis).  The accumulator layout puts one q head per
+//     (lane & 15) and 4 tokens per lane, so the bf16 P fragment IS the B operand of the next
+//     product with no lane movement.
+//   * O^T = V^T P^T: V is written once to a wave-private, XOR-swizzled LDS tile (ds_write_b128)
+//     and read back transposed with ds_read_b64_tr_b16 as the A operand.
+//   * softmax statistics live on the lane: the row max needs two cross-lane steps
+//     (ds_bpermute via __shfl_xor 16/32), the row sum is reduced once after the loop.
+//   * next tile's K/V loads are issued right after the current tile's operands are consumed,
+//     so every wave keeps ~16 KiB of HBM reads in flight under its softmax + PV work.
+#include "rx_common.h"
+
+namespace rx {
+
+struct DecodeArgs {
+  const uint16_t* q;
+  uint16_t* o;
+  int64_t q_stride_t, q_stride_h, o_stride_t, o_stride_h;
+  const uint16_t* k_buf;
+  const uint16_t* v_buf;
+  int32_t page_size;
+  int64_t k_page_stride, k_tok_stride, k_head_stride;
+  int64_t v_page_stride, v_tok_stride, v_head_stride;
+  const int32_t* kv_indptr;
+  const void* kv_indices;
+  const int32_t* req_to_token;
+  int64_t req_row_stride;
+  const void* req_pool_indices;
+  int32_t rpi64;
+  const void* seq_lens;
+  int32_t sl64;
+  const int32_t* num_kv_splits;
+  int32_t max_kv_splits;
+  float* attn_logits;
+  float* attn_lse;
+  int32_t bs, hq, hkv, group, qblocks;
+  float sm_scale;  // sm_scale * k_scale
+  float v_scale, logit_cap;
+  const float* sinks;
+};
+
+constexpr int kMinBlockKV = 32;  // decode_attention.py:36 (_MIN_BLOCK_KV)
+constexpr int kTile = 32;        // tokens per wave tile (K of the PV MFMA)
+constexpr int kWavesPerWG = 4;
+
+// XOR swizzle of the 16-byte chunk index inside a V row of the LDS tile.  Makes both the
+// ds_write_b128 of 8 consecutive rows and the ds_read_b64_tr_b16 of an 8-row x 32-byte
+// window conflict-free (bank = addr/4 mod 32 for writes, mod 64 for tr reads).
+template <int D>
+__device__ __forceinline__ int v_swizzle(int row) {
+  if constexpr (D == 64) return row & 7;
+  return ((row & 7) << 1) | ((row >> 2) & 1);
+}
+
+template <bool LINEAR>
+__device__ __forceinline__ int64_t slot_offset(int64_t slot, int32_t page_size,
+                                               int64_t page_stride, int64_t tok_stride) {
+  if constexpr (LINEAR) return slot * tok_stride;
+  return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
+}
+
+struct SeqInfo {
+  int32_t seq_len;
+  const void* idx;  // token -> slot list of this request
+};
+
+template <typename IdxT>
+__device__ __forceinline__ SeqInfo seq_info(const DecodeArgs& a, int b) {
+  SeqInfo s;
+  if (a.kv_indices) {
+    const int32_t beg = a.kv_indptr[b];
+    s.seq_len = a.kv_indptr[b + 1] - beg;
+    s.idx = reinterpret_cast<const IdxT*>(a.kv_indices) + beg;
+  } else {
+    const int64_t req = load_idx(a.req_pool_indices, b, a.rpi64);
+    s.seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
+    s.idx = a.req_to_token + req * a.req_row_stride;  // IdxT == int32_t in this mode
+  }
+  return s;
+}
+
+__device__ __forceinline__ void split_range(int32_t seq_len, int32_t splits, int32_t split,
+                                            int32_t& lo, int32_t& hi) {
+  // decode_attention.py:466-472
+  const int32_t per =
+      ((seq_len + splits - 1) / splits + kMinBlockKV - 1) / kMinBlockKV * kMinBlockKV;
+  lo = per * split;
+  hi = min(lo + per, seq_len);
+}
+
+template <typename T, int D, typename IdxT, bool LINEAR>
+__global__ __launch_bounds__(256) void decode_mfma_kernel(const DecodeArgs a) {
+  using vec8 = typename T::vec8;
+  constexpr int KS = D / 32;  // k-steps of the QK^T product
+  constexpr int NB = D / 16;  // 16-wide d blocks of the output
+  constexpr int ROW_BYTES = D * 2;
+  constexpr int TILE_BYTES = kTile * ROW_BYTES;  // == 16 * D * 4 (fp32 O^T of one wave)
+  __shared__ __attribute__((aligned(16))) char smem[kWavesPerWG * TILE_BYTES + 2 * 4 * 16 * 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int split = bid % a.max_kv_splits;
+  bid /= a.max_kv_splits;
+  const int qb = bid % a.qblocks;
+  bid /= a.qblocks;
+  const int kvh = bid % a.hkv;
+  const int b = bid / a.hkv;
+
+  const SeqInfo si = seq_info<IdxT>(a, b);
+  const IdxT* idx = reinterpret_cast<const IdxT*>(si.idx);
+  const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
+  const bool single = (a.max_kv_splits == 1);
+  const int gq = qb * 16 + r;            // q head inside the GQA group handled by this lane
+  const bool q_valid = gq < a.group;
+  const int h = kvh * a.group + gq;      // global q head
+
+  if (split >= splits) return;
+  int32_t lo, hi;
+  split_range(si.seq_len, splits, split, lo, hi);
+  if (hi <= lo) {
+    if (single && si.seq_len == 0) {  // empty request: define the output (reference: 0/0)
+      for (int i = tid; i < 16 * D; i += 256) {
+        const int q = i / D, d = i % D;
+        if (qb * 16 + q < a.group)
+          a.o[b * a.o_stride_t + (kvh * a.group + qb * 16 + q) * a.o_stride_h + d] = 0;
+      }
+    }
+    return;
+  }
+  const int ntiles = (hi - lo + kTile - 1) / kTile;
+
+  // ---- Q^T fragments (B operand): lane (r,g) holds Q[h][32s + 8g .. +8] ----------------
+  vec8 qf[KS];
+  {
+    const uint16_t* qp = a.q + b * a.q_stride_t + (q_valid ? h : 0) * a.q_stride_h + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      u32x4 raw = q_valid ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
+      qf[s] = __builtin_bit_cast(vec8, raw);
+    }
+  }
+
+  const uint16_t* kbase = a.k_buf + kvh * a.k_head_stride + 8 * g;
+  const uint16_t* vbase = a.v_buf + kvh * a.v_head_stride + 8 * g;
+  char* vt = smem + w * TILE_BYTES;  // this wave's V tile
+
+  f32x4 oacc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY;  // running max (log2 domain), identical in the 4 lanes of a q head
+  float l_run = 0.f;        // this lane's partial row sum
+
+  const float scale_log2 = a.sm_scale * kLog2e;
+
+  auto load_slots = [&](int t, int64_t& s0, int64_t& s1) {
+    const int32_t t0 = min(lo + t * kTile + r, hi - 1);
+    const int32_t t1 = min(lo + t * kTile + 16 + r, hi - 1);
+    s0 = static_cast<int64_t>(idx[t0]);
+    s1 = static_cast<int64_t>(idx[t1]);
+  };
+  u32x4 kf[2][KS], vf[2][KS];
+  auto load_kv = [&](int64_t s0, int64_t s1) {
+    const int64_t ko0 = slot_offset<LINEAR>(s0, a.page_size, a.k_page_stride, a.k_tok_stride);
+    const int64_t ko1 = slot_offset<LINEAR>(s1, a.page_size, a.k_page_stride, a.k_tok_stride);
+    const int64_t vo0 = slot_offset<LINEAR>(s0, a.page_size, a.v_page_stride, a.v_tok_stride);
+    const int64_t vo1 = slot_offset<LINEAR>(s1, a.page_size, a.v_page_stride, a.v_tok_stride);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kf[0][s] = *reinterpret_cast<const u32x4*>(kbase + ko0 + 32 * s);
+      kf[1][s] = *reinterpret_cast<const u32x4*>(kbase + ko1 + 32 * s);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      vf[0][s] = *reinterpret_cast<const u32x4*>(vbase + vo0 + 32 * s);
+      vf[1][s] = *reinterpret_cast<const u32x4*>(vbase + vo1 + 32 * s);
+    }
+  };
+
+  int t = w;
+  int64_t n0 = 0, n1 = 0;
+  if (t < ntiles) {
+    int64_t s0, s1;
+    load_slots(t, s0, s1);
+    load_kv(s0, s1);
+    if (t + kWavesPerWG < ntiles) load_slots(t + kWavesPerWG, n0, n1);
+  }
+
+  for (; t < ntiles; t += kWavesPerWG) {
+    // ---- S^T[token][q] = K Q^T ---------------------------------------------------------
+    f32x4 sacc[2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      sacc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        sacc[bb] = T::mfma(__builtin_bit_cast(vec8, kf[bb][s]), qf[s], sacc[bb]);
+    }
+    // ---- V tile -> LDS (row = token, swizzled 16-B chunks) -------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int row = 16 * bb + r;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int chunk = (4 * s + g) ^ v_swizzle<D>(row);
+        *reinterpret_cast<u32x4*>(vt + row * ROW_BYTES + chunk * 16) = vf[bb][s];
+      }
+    }
+    // ---- prefetch the next tile (registers of this tile are free again) ------------------
+    if (t + kWavesPerWG < ntiles) {
+      load_kv(n0, n1);
+      if (t + 2 * kWavesPerWG < ntiles) load_slots(t + 2 * kWavesPerWG, n0, n1);
+    }
+    // ---- online softmax on the lane ------------------------------------------------------
+    float sv[8];
+    const int tok_base = lo + t * kTile + 4 * g;
+    float mt = -INFINITY;
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x = sacc[bb][i];
+        if (a.logit_cap > 0.f) {
+          x = a.logit_cap * tanhf(x * a.sm_scale / a.logit_cap) * kLog2e;
+        } else {
+          x *= scale_log2;
+        }
+        x = (tok_base + 16 * bb + i < hi) ? x : -INFINITY;
+        sv[bb * 4 + i] = x;
+        mt = fmaxf(mt, x);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16));
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sv[j] = fast_exp2(sv[j] - m_new);
+      psum += sv[j];
+    }
+    l_run = l_run * alpha + psum;
+    u32x4 praw;
+    praw[0] = pack2<T>(sv[0], sv[1]);
+    praw[1] = pack2<T>(sv[2], sv[3]);
+    praw[2] = pack2<T>(sv[4], sv[5]);
+    praw[3] = pack2<T>(sv[6], sv[7]);
+    const vec8 pf = __builtin_bit_cast(vec8, praw);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) oacc[nb] *= alpha;
+
+    // ---- O^T += V^T P^T, V^T fragments by transposed LDS reads ---------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const int qd = r >> 2, pp = r & 3;
+      const int row0 = 4 * g + qd;  // + 16 for the second 16-token block
+      const int sw = v_swizzle<D>(row0);  // same for row0 + 16
+      const char* rp0 = vt + row0 * ROW_BYTES + 8 * (pp & 1);
+      const char* rp1 = rp0 + 16 * ROW_BYTES;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int chunk = (2 * nb + (pp >> 1)) ^ sw;
+        const u32x2 lo2 = T::ds_read_tr(rp0 + chunk * 16);
+        const u32x2 hi2 = T::ds_read_tr(rp1 + chunk * 16);
+        const u32x4 av = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+        oacc[nb] = T::mfma(__builtin_bit_cast(vec8, av), pf, oacc[nb]);
+      }
+    }
+  }
+
+  // ---- merge the four waves through LDS ----------------------------------------------------
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  float* sm_m = reinterpret_cast<float*>(smem + kWavesPerWG * TILE_BYTES);
+  float* sm_l = sm_m + kWavesPerWG * 16;
+  __syncthreads();  // every wave is done with its V tile
+  {
+    float* ot = reinterpret_cast<float*>(vt);  // [16 q][D] fp32
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      *reinterpret_cast<f32x4*>(ot + r * D + 16 * nb + 4 * g) = oacc[nb];
+    if (g == 0) {
+      sm_m[w * 16 + r] = m_run;
+      sm_l[w * 16 + r] = l_run;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 16 * D; i += 256) {
+    const int q = i / D, d = i % D;
+    const int gq2 = qb * 16 + q;
+    if (gq2 >= a.group) continue;
+    const int hh = kvh * a.group + gq2;
+    float mx = sm_m[q];
+#pragma unroll
+    for (int ww = 1; ww < kWavesPerWG; ++ww) mx = fmaxf(mx, sm_m[ww * 16 + q]);
+    float lsum = 0.f, acc = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < kWavesPerWG; ++ww) {
+      const float sc = fast_exp2(sm_m[ww * 16 + q] - mx);
+      lsum += sm_l[ww * 16 + q] * sc;
+      acc += reinterpret_cast<const float*>(smem + ww * TILE_BYTES)[q * D + d] * sc;
+    }
+    if (single) {
+      float den = lsum;
+      if (a.sinks) den += fast_exp2(a.sinks[hh] * kLog2e - mx);
+      a.o[b * a.o_stride_t + hh * a.o_stride_h + d] = T::from_f32(acc / den * a.v_scale);
+    } else {
+      const int64_t row = (static_cast<int64_t>(b) * a.hq + hh) * a.max_kv_splits + split;
+      a.attn_logits[row * D + d] = acc / lsum;
+      if (d == 0) a.attn_lse[row] = mx * kLn2 + __logf(lsum);
+    }
+  }
+}
+
+// ---- generic fallback: any head dims (Dk != Dv, 13, 80, 96, 576/512 ...) --------------------
+// One wave per (request, q head, split); lane = token for QK^T, lane = d for PV.  Correctness
+// path for shapes outside the MFMA kernel; same outputs / scratch layout.
+template <typename T, typename IdxT, bool LINEAR>
+__global__ __launch_bounds__(64) void decode_generic_kernel(const DecodeArgs a, int dk, int dv) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  float* qs = reinterpret_cast<float*>(dyn_smem);  // [dk]
+  const int lane = threadIdx.x;
+  int bid = blockIdx.x;
+  const int split = bid % a.max_kv_splits;
+  bid /= a.max_kv_splits;
+  const int h = bid % a.hq;
+  const int b = bid / a.hq;
+  const int kvh = h / a.group;
+  const SeqInfo si = seq_info<IdxT>(a, b);
+  const IdxT* idx = reinterpret_cast<const IdxT*>(si.idx);
+  const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
+  const bool single = (a.max_kv_splits == 1);
+  if (split >= splits) return;
+  int32_t lo, hi;
+  split_range(si.seq_len, splits, split, lo, hi);
+  if (hi <= lo) {
+    if (single && si.seq_len == 0)
+      for (int d = lane; d < dv; d += 64) a.o[b * a.o_stride_t + h * a.o_stride_h + d] = 0;
+    return;
+  }
+  for (int d = lane; d < dk; d += 64)
+    qs[d] = T::to_f32(a.q[b * a.q_stride_t + h * a.q_stride_h + d]);
+  __syncthreads();
+  constexpr int MAXV = 8;  // dv <= 512
+  float acc[MAXV];
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) acc[j] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int base = lo; base < hi; base += 64) {
+    const int tok = base + lane;
+    const bool valid = tok < hi;
+    const int64_t slot = static_cast<int64_t>(idx[valid ? tok : hi - 1]);
+    const uint16_t* kp = a.k_buf + kvh * a.k_head_stride +
+                         slot_offset<LINEAR>(slot, a.page_size, a.k_page_stride, a.k_tok_stride);
+    float s = 0.f;
+    for (int d = 0; d < dk; ++d) s += qs[d] * T::to_f32(kp[d]);
+    s *= a.sm_scale;
+    if (a.logit_cap > 0.f) s = a.logit_cap * tanhf(s / a.logit_cap);
+    s = valid ? s * kLog2e : -INFINITY;
+    float mt = s;
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) mt = fmaxf(mt, __shfl_xor(mt, dd));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = fast_exp2(m_run - m_new);
+    const float p = fast_exp2(s - m_new);
+    float ps = p;
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) ps += __shfl_xor(ps, dd);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) acc[j] *= alpha;
+    const int nvalid = min(64, hi - base);
+    const int64_t voff =
+        slot_offset<LINEAR>(slot, a.page_size, a.v_page_stride, a.v_tok_stride);
+    for (int j = 0; j < nvalid; ++j) {
+      const float pj = __shfl(p, j);
+      const int64_t vo = __shfl(voff, j);
+      const uint16_t* vp = a.v_buf + kvh * a.v_head_stride + vo;
+#pragma unroll
+      for (int c = 0; c < MAXV; ++c) {
+        const int d = lane + 64 * c;
+        if (d < dv) acc[c] += pj * T::to_f32(vp[d]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < MAXV; ++c) {
+    const int d = lane + 64 * c;
+    if (d >= dv) continue;
+    if (single) {
+      float den = l_run;
+      if (a.sinks) den += fast_exp2(a.sinks[h] * kLog2e - m_run);
+      a.o[b * a.o_stride_t + h * a.o_stride_h + d] = T::from_f32(acc[c] / den * a.v_scale);
+    } else {
+      const int64_t row = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits + split;
+      a.attn_logits[row * dv + d] = acc[c] / l_run;
+      if (d == 0) a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
+    }
+  }
+}
+
+// ---- stage 2: merge the kv splits (decode_attention.py:731-805) --------------------------------
+template <typename T>
+__global__ __launch_bounds__(128) void decode_merge_kernel(const DecodeArgs a, int dv) {
+  const int h = blockIdx.x % a.hq;
+  const int b = blockIdx.x / a.hq;
+  int32_t seq_len;
+  if (a.kv_indices) {
+    seq_len = a.kv_indptr[b + 1] - a.kv_indptr[b];
+  } else {
+    seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
+  }
+  const int32_t splits = a.num_kv_splits ? a.num_kv_splits[b] : 1;
+  const int64_t row0 = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits;
+  for (int d = threadIdx.x; d < dv; d += 128) {
+    float e_sum = 0.f, e_max = -INFINITY, acc = 0.f;
+    for (int s = 0; s < a.max_kv_splits; ++s) {
+      int32_t lo, hi;
+      split_range(seq_len, splits, s, lo, hi);
+      if (s < splits && hi > lo) {
+        const float tv = a.attn_logits[(row0 + s) * dv + d];
+        const float tl = a.attn_lse[row0 + s];
+        const float n_max = fmaxf(tl, e_max);
+        const float old_scale = __expf(e_max - n_max);
+        const float w = __expf(tl - n_max);
+        acc = acc * old_scale + w * tv;
+        e_sum = e_sum * old_scale + w;
+        e_max = n_max;
+      }
+    }
+    if (a.sinks) e_sum += __expf(a.sinks[h] - e_max);
+    a.o[b * a.o_stride_t + h * a.o_stride_h + d] = T::from_f32(acc / e_sum * a.v_scale);
+  }
+}
+
+template <typename T, typename IdxT, bool LINEAR>
+static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
+  if (mfma_ok) {
+    const unsigned grid = static_cast<unsigned>(a.bs) * a.hkv * a.qblocks * a.max_kv_splits;
+    if (dk == 64)
+      hipLaunchKernelGGL((decode_mfma_kernel<T, 64, IdxT, LINEAR>), dim3(grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR>), dim3(grid), dim3(256), 0, s, a);
+  } else {
+    if (dv > 512) return fail(RX_ERR_UNSUPPORTED, "rx_decode_attn: v_head_dim %d > 512", dv);
+    const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.max_kv_splits;
+    hipLaunchKernelGGL((decode_generic_kernel<T, IdxT, LINEAR>), dim3(grid), dim3(64),
+                       dk * sizeof(float), s, a, dk, dv);
+  }
+  if (a.max_kv_splits > 1)
+    hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(a.bs * a.hq), dim3(128), 0, s, a, dv);
+  return check_launch("rx_decode_attn");
+}
+
+template <typename T>
+static int dispatch_decode(const DecodeArgs& a, int dk, int dv, bool idx64, bool linear,
+                           hipStream_t s) {
+  if (idx64) {
+    return linear ? launch_decode<T, int64_t, true>(a, dk, dv, s)
+                  : launch_decode<T, int64_t, false>(a, dk, dv, s);
+  }
+  return linear ? launch_decode<T, int32_t, true>(a, dk, dv, s)
+                : launch_decode<T, int32_t, false>(a, dk, dv, s);
+}
+
+}  // namespace rx
+
+using namespace rx;
+
+extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
+  RX_REQUIRE(p, "rx_decode_attn: params is null");
+  RX_REQUIRE(p->bs >= 0, "rx_decode_attn: bs < 0");
+  if (p->bs == 0) return RX_OK;
+  RX_REQUIRE(p->q && p->o && p->kv.k_buf && p->kv.v_buf, "rx_decode_attn: null q/o/k_buf/v_buf");
+  RX_REQUIRE(p->num_q_heads > 0 && p->num_kv_heads > 0 && p->num_q_heads % p->num_kv_heads == 0,
+             "rx_decode_attn: Hq=%d must be a positive multiple of Hkv=%d", p->num_q_heads,
+             p->num_kv_heads);
+  RX_REQUIRE(p->head_dim > 0 && p->v_head_dim > 0, "rx_decode_attn: bad head dims");
+  RX_REQUIRE(p->kv.page_size >= 1, "rx_decode_attn: page_size < 1");
+  RX_REQUIRE(p->dtype == RX_BF16 || p->dtype == RX_F16, "rx_decode_attn: dtype %d", p->dtype);
+  const bool mode_a = p->kv_indices != nullptr;
+  if (mode_a) {
+    RX_REQUIRE(p->kv_indptr, "rx_decode_attn: kv_indices given without kv_indptr");
+  } else {
+    RX_REQUIRE(p->req_to_token && p->req_pool_indices && p->seq_lens,
+               "rx_decode_attn: neither kv_indices nor req_to_token/req_pool_indices/seq_lens");
+  }
+  const int max_splits = p->max_kv_splits < 1 ? 1 : p->max_kv_splits;
+  if (max_splits > 1)
+    RX_REQUIRE(p->attn_logits && p->attn_lse && p->num_kv_splits,
+               "rx_decode_attn: max_kv_splits=%d needs attn_logits, attn_lse and num_kv_splits",
+               max_splits);
+  const int dk = p->head_dim, dv = p->v_head_dim;
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
+  if (mfma_ok) {
+    // 16-byte vector loads: every stride a multiple of 8 elements, bases 16-byte aligned
+    const int64_t all = p->q_stride_t | p->q_stride_h | p->kv.k_page_stride | p->kv.k_tok_stride |
+                        p->kv.k_head_stride | p->kv.v_page_stride | p->kv.v_tok_stride |
+                        p->kv.v_head_stride;
+    RX_REQUIRE(all % 8 == 0, "rx_decode_attn: q/kv strides must be multiples of 8 elements");
+    RX_REQUIRE((((uintptr_t)p->q | (uintptr_t)p->kv.k_buf | (uintptr_t)p->kv.v_buf) & 15) == 0,
+               "rx_decode_attn: q/k_buf/v_buf must be 16-byte aligned");
+  }
+  DecodeArgs a;
+  a.q = (const uint16_t*)p->q;
+  a.o = (uint16_t*)p->o;
+  a.q_stride_t = p->q_stride_t;
+  a.q_stride_h = p->q_stride_h;
+  a.o_stride_t = p->o_stride_t;
+  a.o_stride_h = p->o_stride_h;
+  a.k_buf = (const uint16_t*)p->kv.k_buf;
+  a.v_buf = (const uint16_t*)p->kv.v_buf;
+  a.page_size = p->kv.page_size;
+  a.k_page_stride = p->kv.k_page_stride;
+  a.k_tok_stride = p->kv.k_tok_stride;
+  a.k_head_stride = p->kv.k_head_stride;
+  a.v_page_stride = p->kv.v_page_stride;
+  a.v_tok_stride = p->kv.v_tok_stride;
+  a.v_head_stride = p->kv.v_head_stride;
+  a.kv_indptr = p->kv_indptr;
+  a.kv_indices = p->kv_indices;
+  a.req_to_token = p->req_to_token;
+  a.req_row_stride = p->req_row_stride;
+  a.req_pool_indices = p->req_pool_indices;
+  a.rpi64 = p->req_pool_indices_is_i64;
+  a.seq_lens = p->seq_lens;
+  a.sl64 = p->seq_lens_is_i64;
+  a.num_kv_splits = max_splits > 1 ? p->num_kv_splits : nullptr;
+  a.max_kv_splits = max_splits;
+  a.attn_logits = p->attn_logits;
+  a.attn_lse = p->attn_lse;
+  a.bs = p->bs;
+  a.hq = p->num_q_heads;
+  a.hkv = p->num_kv_heads;
+  a.group = p->num_q_heads / p->num_kv_heads;
+  a.qblocks = (a.group + 15) / 16;
+  a.sm_scale = p->sm_scale * p->k_scale;
+  a.v_scale = p->v_scale;
+  a.logit_cap = p->logit_cap;
+  a.sinks = p->sinks;
+  const bool linear = p->kv.page_size == 1 ||
+                      (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
+                       p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
+  const bool idx64 = mode_a && p->kv_indices_is_i64;
+  auto s = static_cast<hipStream_t>(stream);
+  return p->dtype == RX_BF16 ? dispatch_decode<BF16>(a, dk, dv, idx64, linear, s)
+                             : dispatch_decode<F16>(a, dk, dv, idx64, linear, s);
+}

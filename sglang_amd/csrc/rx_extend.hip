@@ -1,0 +1,508 @@
+// K7: ragged extend (prefill-with-cached-prefix) attention for gfx950.
+//
+// Reference: extend_attention_fwd (kernels/ops/attention/extend_attention.py:664-812),
+// kernel _fwd_kernel (:241-661): stage 1 over the cached prefix gathered through kv_indices
+// (:372-510), stage 2 over the new, contiguous K/V with the causal triangle (:512-631).
+//
+// MI355X design: the same transposed formulation as the decode kernel.  A wave owns 32 query
+// rows of one (request, q head) -- two 16-query N blocks of v_mfma_f32_16x16x32 -- and streams
+// 32-token KV tiles: S^T = K Q^T (K straight from HBM/L2 in A-operand shape), softmax on the
+// lane, O^T += V^T P^T with V^T read by ds_read_b64_tr_b16 from a wave-private swizzled LDS
+// tile.  The four waves of a workgroup take four consecutive query blocks of the same
+// (request, head): they walk the same KV rows at the same time, so three of the four K/V reads
+// are served by the CU's L1.  Prefix and extend stages share one tile body; the next tile's
+// K/V (and the slot indices of the tile after it) are in flight under the current tile's math.
+#include "rx_common.h"
+
+namespace rx {
+
+struct ExtendArgs {
+  const uint16_t* q;
+  const uint16_t* k_ext;
+  const uint16_t* v_ext;
+  uint16_t* o;
+  int64_t q_stride_t, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_t,
+      o_stride_h;
+  const uint16_t* k_buf;
+  const uint16_t* v_buf;
+  int32_t page_size;
+  int64_t k_page_stride, k_tok_stride, k_head_stride;
+  int64_t v_page_stride, v_tok_stride, v_head_stride;
+  const void* qo_indptr;
+  int32_t qo64;
+  const int32_t* kv_indptr;
+  const void* kv_indices;
+  float* lse;
+  int64_t lse_stride_t, lse_stride_h;
+  int32_t bs, hq, hkv, group, mblocks;
+  float sm_scale, k_scale, v_scale, logit_cap;
+  int32_t causal, skip_prefix, skip_extend, window;
+  const float* sinks;
+};
+
+constexpr int kQPerWave = 32;
+constexpr int kETile = 32;
+
+template <int D>
+__device__ __forceinline__ int v_swz(int row) {
+  if constexpr (D == 64) return row & 7;
+  return ((row & 7) << 1) | ((row >> 2) & 1);
+}
+
+template <bool LINEAR>
+__device__ __forceinline__ int64_t slot_off(int64_t slot, int32_t page_size, int64_t page_stride,
+                                            int64_t tok_stride) {
+  if constexpr (LINEAR) return slot * tok_stride;
+  return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
+}
+
+struct Rows {
+  const uint16_t* k0;
+  const uint16_t* k1;
+  const uint16_t* v0;
+  const uint16_t* v1;
+};
+
+template <typename T, int D, typename IdxT, bool LINEAR>
+__global__ __launch_bounds__(256) void extend_mfma_kernel(const ExtendArgs a) {
+  using vec8 = typename T::vec8;
+  constexpr int KS = D / 32;
+  constexpr int NB = D / 16;
+  constexpr int ROW_BYTES = D * 2;
+  constexpr int TILE_BYTES = kETile * ROW_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int mb = bid % a.mblocks;
+  bid /= a.mblocks;
+  const int h = bid % a.hq;
+  const int req = bid / a.hq;
+  const int kvh = h / a.group;
+
+  const int64_t qo0 = load_idx(a.qo_indptr, req, a.qo64);
+  const int32_t E = static_cast<int32_t>(load_idx(a.qo_indptr, req + 1, a.qo64) - qo0);
+  const int32_t kv0 = a.kv_indptr[req];
+  const int32_t P = a.kv_indptr[req + 1] - kv0;  // prefix length
+  const int32_t qbase = (mb * 4 + w) * kQPerWave;
+  if (qbase >= E) return;  // wave-uniform; no workgroup barriers below
+  const IdxT* idx = reinterpret_cast<const IdxT*>(a.kv_indices) + kv0;
+
+  // ---- Q^T fragments: block c, lane (r,g) holds Q[qbase+16c+r][h][32s+8g..] -------------------
+  vec8 qf[2][KS];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int m = qbase + 16 * c + r;
+    const bool ok = m < E;
+    const uint16_t* qp = a.q + (qo0 + (ok ? m : 0)) * a.q_stride_t + h * a.q_stride_h + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
+      qf[c][s] = __builtin_bit_cast(vec8, raw);
+    }
+  }
+
+  const int32_t n_end = a.skip_extend ? 0 : (a.causal ? min(E, qbase + kQPerWave) : E);
+  const int32_t p_len = a.skip_prefix ? 0 : P;
+  const int nt1 = (p_len + kETile - 1) / kETile;
+  const int nt2 = (n_end + kETile - 1) / kETile;
+  const int nt = nt1 + nt2;
+
+  const uint16_t* kbuf_h = a.k_buf + kvh * a.k_head_stride + 8 * g;
+  const uint16_t* vbuf_h = a.v_buf + kvh * a.v_head_stride + 8 * g;
+  const uint16_t* kext_h = a.k_ext + qo0 * a.k_stride_t + kvh * a.k_stride_h + 8 * g;
+  const uint16_t* vext_h = a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h + 8 * g;
+
+  auto rows_for = [&](int t) -> Rows {
+    Rows rw;
+    if (t < nt1) {
+      const int32_t t0 = min(t * kETile + r, p_len - 1);
+      const int32_t t1 = min(t * kETile + 16 + r, p_len - 1);
+      const int64_t s0 = static_cast<int64_t>(idx[t0]);
+      const int64_t s1 = static_cast<int64_t>(idx[t1]);
+      rw.k0 = kbuf_h + slot_off<LINEAR>(s0, a.page_size, a.k_page_stride, a.k_tok_stride);
+      rw.k1 = kbuf_h + slot_off<LINEAR>(s1, a.page_size, a.k_page_stride, a.k_tok_stride);
+      rw.v0 = vbuf_h + slot_off<LINEAR>(s0, a.page_size, a.v_page_stride, a.v_tok_stride);
+      rw.v1 = vbuf_h + slot_off<LINEAR>(s1, a.page_size, a.v_page_stride, a.v_tok_stride);
+    } else {
+      const int te = t - nt1;
+      const int64_t t0 = min(te * kETile + r, n_end - 1);
+      const int64_t t1 = min(te * kETile + 16 + r, n_end - 1);
+      rw.k0 = kext_h + t0 * a.k_stride_t;
+      rw.k1 = kext_h + t1 * a.k_stride_t;
+      rw.v0 = vext_h + t0 * a.v_stride_t;
+      rw.v1 = vext_h + t1 * a.v_stride_t;
+    }
+    return rw;
+  };
+  u32x4 kf[2][KS], vf[2][KS];
+  auto load_kv = [&](const Rows& rw) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      kf[0][s] = *reinterpret_cast<const u32x4*>(rw.k0 + 32 * s);
+      kf[1][s] = *reinterpret_cast<const u32x4*>(rw.k1 + 32 * s);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      vf[0][s] = *reinterpret_cast<const u32x4*>(rw.v0 + 32 * s);
+      vf[1][s] = *reinterpret_cast<const u32x4*>(rw.v1 + 32 * s);
+    }
+  };
+
+  char* vt = smem + w * TILE_BYTES;
+  f32x4 oacc[2][NB];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) oacc[c][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY};
+  float l_run[2] = {0.f, 0.f};
+
+  Rows nxt;
+  if (nt > 0) {
+    Rows cur = rows_for(0);
+    load_kv(cur);
+    if (nt > 1) nxt = rows_for(1);
+  }
+
+  for (int t = 0; t < nt; ++t) {
+    const bool prefix = t < nt1;
+    const float sc = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
+    // ---- S^T = K Q^T for both query blocks --------------------------------------------------
+    f32x4 sacc[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) sacc[c][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const vec8 ka = __builtin_bit_cast(vec8, kf[bb][s]);
+        sacc[0][bb] = T::mfma(ka, qf[0][s], sacc[0][bb]);
+        sacc[1][bb] = T::mfma(ka, qf[1][s], sacc[1][bb]);
+      }
+    // ---- V tile -> LDS -------------------------------------------------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int row = 16 * bb + r;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int chunk = (4 * s + g) ^ v_swz<D>(row);
+        *reinterpret_cast<u32x4*>(vt + row * ROW_BYTES + chunk * 16) = vf[bb][s];
+      }
+    }
+    if (t + 1 < nt) {
+      load_kv(nxt);
+      if (t + 2 < nt) nxt = rows_for(t + 2);
+    }
+    // ---- masks + online softmax ------------------------------------------------------------------
+    const int nbase = (prefix ? t : t - nt1) * kETile + 4 * g;  // token index of element (bb=0,i=0)
+    vec8 pf[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int m = qbase + 16 * c + r;  // query index inside the extend part
+      float sv[8];
+      float mt = -INFINITY;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = nbase + 16 * bb + i;
+          float x = sacc[c][bb][i] * sc;
+          if (a.logit_cap > 0.f) x = a.logit_cap * tanhf(x / a.logit_cap);
+          x *= kLog2e;
+          bool keep;
+          if (prefix) {
+            keep = n < p_len;
+            if (a.window > 0) keep = keep && (P + m <= n + a.window);
+          } else {
+            keep = n < n_end && (!a.causal || n <= m);
+            if (a.window > 0) keep = keep && (m <= n + a.window);
+          }
+          x = keep ? x : -INFINITY;
+          sv[bb * 4 + i] = x;
+          mt = fmaxf(mt, x);
+        }
+      mt = fmaxf(mt, __shfl_xor(mt, 16));
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      // fully masked row so far: keep the max finite (extend_attention.py:474-475)
+      const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
+      const float m_new = fmaxf(m_run[c], mt_fixed);
+      const float alpha = fast_exp2(m_run[c] - m_new);
+      m_run[c] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sv[j] = fast_exp2(sv[j] - m_new);
+        psum += sv[j];
+      }
+      l_run[c] = l_run[c] * alpha + psum;
+      const float vs = prefix ? a.v_scale : 1.0f;
+      u32x4 praw;
+      praw[0] = pack2<T>(sv[0] * vs, sv[1] * vs);
+      praw[1] = pack2<T>(sv[2] * vs, sv[3] * vs);
+      praw[2] = pack2<T>(sv[4] * vs, sv[5] * vs);
+      praw[3] = pack2<T>(sv[6] * vs, sv[7] * vs);
+      pf[c] = __builtin_bit_cast(vec8, praw);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) oacc[c][nb] *= alpha;
+    }
+    // ---- O^T += V^T P^T ------------------------------------------------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      const int qd = r >> 2, pp = r & 3;
+      const int row0 = 4 * g + qd;
+      const int sw = v_swz<D>(row0);
+      const char* rp0 = vt + row0 * ROW_BYTES + 8 * (pp & 1);
+      const char* rp1 = rp0 + 16 * ROW_BYTES;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int chunk = (2 * nb + (pp >> 1)) ^ sw;
+        const u32x2 lo2 = T::ds_read_tr(rp0 + chunk * 16);
+        const u32x2 hi2 = T::ds_read_tr(rp1 + chunk * 16);
+        const vec8 av = __builtin_bit_cast(vec8, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]});
+        oacc[0][nb] = T::mfma(av, pf[0], oacc[0][nb]);
+        oacc[1][nb] = T::mfma(av, pf[1], oacc[1][nb]);
+      }
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    float l = l_run[c];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const int m = qbase + 16 * c + r;
+    if (m >= E) continue;
+    float den = l;
+    if (a.sinks) den += fast_exp2(a.sinks[h] * kLog2e - m_run[c]);
+    const float inv = 1.0f / den;
+    uint16_t* op = a.o + (qo0 + m) * a.o_stride_t + h * a.o_stride_h + 4 * g;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      u32x2 pk;
+      pk[0] = pack2<T>(oacc[c][nb][0] * inv, oacc[c][nb][1] * inv);
+      pk[1] = pack2<T>(oacc[c][nb][2] * inv, oacc[c][nb][3] * inv);
+      *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
+    }
+    if (a.lse && g == 0)
+      a.lse[(qo0 + m) * a.lse_stride_t + h * a.lse_stride_h] = m_run[c] * kLn2 + __logf(l);
+  }
+}
+
+// ---- generic fallback: one wave per (query token, q head); any head dims <= 512 -------------------
+template <typename T, typename IdxT, bool LINEAR>
+__global__ __launch_bounds__(64) void extend_generic_kernel(const ExtendArgs a, int dk, int dv,
+                                                            const int32_t* tok2req) {
+  extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
+  float* qs = reinterpret_cast<float*>(dyn_smem);
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x % a.hq;
+  const int64_t tq = blockIdx.x / a.hq;  // global query token
+  // find the request owning tq (bs is small; linear scan by every lane)
+  int req = 0;
+  for (int i = 0; i < a.bs; ++i)
+    if (load_idx(a.qo_indptr, i + 1, a.qo64) <= tq) req = i + 1;
+  if (req >= a.bs) return;
+  (void)tok2req;
+  const int kvh = h / a.group;
+  const int64_t qo0 = load_idx(a.qo_indptr, req, a.qo64);
+  const int32_t E = static_cast<int32_t>(load_idx(a.qo_indptr, req + 1, a.qo64) - qo0);
+  const int32_t m = static_cast<int32_t>(tq - qo0);
+  const int32_t kv0 = a.kv_indptr[req];
+  const int32_t P = a.kv_indptr[req + 1] - kv0;
+  const IdxT* idx = reinterpret_cast<const IdxT*>(a.kv_indices) + kv0;
+  const int32_t p_len = a.skip_prefix ? 0 : P;
+  const int32_t n_end = a.skip_extend ? 0 : (a.causal ? m + 1 : E);
+  for (int d = lane; d < dk; d += 64) qs[d] = T::to_f32(a.q[tq * a.q_stride_t + h * a.q_stride_h + d]);
+  __syncthreads();
+  constexpr int MAXV = 8;
+  float acc[MAXV];
+#pragma unroll
+  for (int j = 0; j < MAXV; ++j) acc[j] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int total = p_len + n_end;
+  for (int base = 0; base < total; base += 64) {
+    const int n = base + lane;
+    const bool inb = n < total;
+    const int nn = inb ? n : total - 1;
+    const bool prefix = nn < p_len;
+    const uint16_t *kp, *vp;
+    if (prefix) {
+      const int64_t slot = static_cast<int64_t>(idx[nn]);
+      kp = a.k_buf + kvh * a.k_head_stride +
+           slot_off<LINEAR>(slot, a.page_size, a.k_page_stride, a.k_tok_stride);
+      vp = a.v_buf + kvh * a.v_head_stride +
+           slot_off<LINEAR>(slot, a.page_size, a.v_page_stride, a.v_tok_stride);
+    } else {
+      kp = a.k_ext + (qo0 + nn - p_len) * a.k_stride_t + kvh * a.k_stride_h;
+      vp = a.v_ext + (qo0 + nn - p_len) * a.v_stride_t + kvh * a.v_stride_h;
+    }
+    float s = 0.f;
+    for (int d = 0; d < dk; ++d) s += qs[d] * T::to_f32(kp[d]);
+    s *= prefix ? a.sm_scale * a.k_scale : a.sm_scale;
+    if (a.logit_cap > 0.f) s = a.logit_cap * tanhf(s / a.logit_cap);
+    bool keep = inb;
+    if (a.window > 0) {
+      if (prefix) keep = keep && (P + m <= nn + a.window);
+      else keep = keep && (m <= (nn - p_len) + a.window);
+    }
+    s = keep ? s * kLog2e : -INFINITY;
+    float mt = s;
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) mt = fmaxf(mt, __shfl_xor(mt, dd));
+    const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
+    const float m_new = fmaxf(m_run, mt_fixed);
+    const float alpha = fast_exp2(m_run - m_new);
+    const float p = fast_exp2(s - m_new);
+    float ps = p;
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) ps += __shfl_xor(ps, dd);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) acc[j] *= alpha;
+    const float pv = p * (prefix ? a.v_scale : 1.0f);
+    const int nvalid = min(64, total - base);
+    for (int j = 0; j < nvalid; ++j) {
+      const float pj = __shfl(pv, j);
+      const uint16_t* vpj = reinterpret_cast<const uint16_t*>(
+          __shfl(reinterpret_cast<uint64_t>(vp), j));
+#pragma unroll
+      for (int c = 0; c < MAXV; ++c) {
+        const int d = lane + 64 * c;
+        if (d < dv) acc[c] += pj * T::to_f32(vpj[d]);
+      }
+    }
+  }
+  float den = l_run;
+  if (a.sinks) den += fast_exp2(a.sinks[h] * kLog2e - m_run);
+#pragma unroll
+  for (int c = 0; c < MAXV; ++c) {
+    const int d = lane + 64 * c;
+    if (d < dv) a.o[tq * a.o_stride_t + h * a.o_stride_h + d] = T::from_f32(acc[c] / den);
+  }
+  if (a.lse && lane == 0)
+    a.lse[tq * a.lse_stride_t + h * a.lse_stride_h] = m_run * kLn2 + __logf(l_run);
+}
+
+template <typename T, typename IdxT, bool LINEAR>
+static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, hipStream_t s) {
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
+  if (mfma_ok) {
+    const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
+    if (dk == 64)
+      hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR>), dim3(grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((extend_mfma_kernel<T, 128, IdxT, LINEAR>), dim3(grid), dim3(256), 0, s, a);
+  } else {
+    if (dv > 512) return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: v_head_dim %d > 512", dv);
+    const unsigned grid = static_cast<unsigned>(total_q * a.hq);
+    hipLaunchKernelGGL((extend_generic_kernel<T, IdxT, LINEAR>), dim3(grid), dim3(64),
+                       dk * sizeof(float), s, a, dk, dv, (const int32_t*)nullptr);
+  }
+  return check_launch("rx_extend_attn");
+}
+
+}  // namespace rx
+
+using namespace rx;
+
+// total_q for the generic path is bs * max_extend_len (an upper bound); blocks past the real
+// token count exit early.
+extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
+  RX_REQUIRE(p, "rx_extend_attn: params is null");
+  RX_REQUIRE(p->bs >= 0 && p->max_extend_len >= 0, "rx_extend_attn: negative sizes");
+  if (p->bs == 0 || p->max_extend_len == 0) return RX_OK;
+  RX_REQUIRE(p->q && p->o && p->k_extend && p->v_extend, "rx_extend_attn: null q/k/v/o");
+  RX_REQUIRE(p->qo_indptr && p->kv_indptr, "rx_extend_attn: null indptr");
+  RX_REQUIRE(p->num_q_heads > 0 && p->num_kv_heads > 0 && p->num_q_heads % p->num_kv_heads == 0,
+             "rx_extend_attn: Hq=%d must be a positive multiple of Hkv=%d", p->num_q_heads,
+             p->num_kv_heads);
+  RX_REQUIRE(p->dtype == RX_BF16 || p->dtype == RX_F16, "rx_extend_attn: dtype %d", p->dtype);
+  RX_REQUIRE(p->kv.page_size >= 1, "rx_extend_attn: page_size < 1");
+  if (!p->skip_prefix)
+    RX_REQUIRE(p->kv.k_buf && p->kv.v_buf && p->kv_indices,
+               "rx_extend_attn: prefix stage needs k_buf, v_buf and kv_indices");
+  const int dk = p->head_dim, dv = p->v_head_dim;
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
+  if (mfma_ok) {
+    const int64_t all = p->q_stride_t | p->q_stride_h | p->k_stride_t | p->k_stride_h |
+                        p->v_stride_t | p->v_stride_h | p->kv.k_page_stride | p->kv.k_tok_stride |
+                        p->kv.k_head_stride | p->kv.v_page_stride | p->kv.v_tok_stride |
+                        p->kv.v_head_stride;
+    RX_REQUIRE(all % 8 == 0, "rx_extend_attn: q/k/v strides must be multiples of 8 elements");
+    RX_REQUIRE((p->o_stride_t | p->o_stride_h) % 4 == 0,
+               "rx_extend_attn: o strides must be multiples of 4 elements");
+    RX_REQUIRE((((uintptr_t)p->q | (uintptr_t)p->k_extend | (uintptr_t)p->v_extend |
+                 (uintptr_t)p->kv.k_buf | (uintptr_t)p->kv.v_buf) & 15) == 0 &&
+                   ((uintptr_t)p->o & 7) == 0,
+               "rx_extend_attn: q/k/v/k_buf/v_buf must be 16-byte and o 8-byte aligned");
+  }
+  ExtendArgs a;
+  a.q = (const uint16_t*)p->q;
+  a.k_ext = (const uint16_t*)p->k_extend;
+  a.v_ext = (const uint16_t*)p->v_extend;
+  a.o = (uint16_t*)p->o;
+  a.q_stride_t = p->q_stride_t;
+  a.q_stride_h = p->q_stride_h;
+  a.k_stride_t = p->k_stride_t;
+  a.k_stride_h = p->k_stride_h;
+  a.v_stride_t = p->v_stride_t;
+  a.v_stride_h = p->v_stride_h;
+  a.o_stride_t = p->o_stride_t;
+  a.o_stride_h = p->o_stride_h;
+  a.k_buf = (const uint16_t*)p->kv.k_buf;
+  a.v_buf = (const uint16_t*)p->kv.v_buf;
+  a.page_size = p->kv.page_size;
+  a.k_page_stride = p->kv.k_page_stride;
+  a.k_tok_stride = p->kv.k_tok_stride;
+  a.k_head_stride = p->kv.k_head_stride;
+  a.v_page_stride = p->kv.v_page_stride;
+  a.v_tok_stride = p->kv.v_tok_stride;
+  a.v_head_stride = p->kv.v_head_stride;
+  a.qo_indptr = p->qo_indptr;
+  a.qo64 = p->qo_indptr_is_i64;
+  a.kv_indptr = p->kv_indptr;
+  a.kv_indices = p->kv_indices;
+  a.lse = p->lse;
+  a.lse_stride_t = p->lse_stride_t;
+  a.lse_stride_h = p->lse_stride_h;
+  a.bs = p->bs;
+  a.hq = p->num_q_heads;
+  a.hkv = p->num_kv_heads;
+  a.group = p->num_q_heads / p->num_kv_heads;
+  a.mblocks = (p->max_extend_len + 4 * kQPerWave - 1) / (4 * kQPerWave);
+  a.sm_scale = p->sm_scale;
+  a.k_scale = p->k_scale;
+  a.v_scale = p->v_scale;
+  a.logit_cap = p->logit_cap;
+  a.causal = p->is_causal;
+  a.skip_prefix = p->skip_prefix;
+  a.skip_extend = p->skip_extend;
+  a.window = p->sliding_window_size;
+  a.sinks = p->sinks;
+  const bool linear = p->kv.page_size == 1 ||
+                      (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
+                       p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
+  const bool idx64 = p->kv_indices_is_i64 != 0;
+  const int64_t total_q = static_cast<int64_t>(p->bs) * p->max_extend_len;
+  auto s = static_cast<hipStream_t>(stream);
+#define RX_GO(TT)                                                                          \
+  (idx64 ? (linear ? launch_extend<TT, int64_t, true>(a, dk, dv, total_q, s)               \
+                   : launch_extend<TT, int64_t, false>(a, dk, dv, total_q, s))             \
+         : (linear ? launch_extend<TT, int32_t, true>(a, dk, dv, total_q, s)               \
+                   : launch_extend<TT, int32_t, false>(a, dk, dv, total_q, s)))
+  return p->dtype == RX_BF16 ? RX_GO(BF16) : RX_GO(F16);
+#undef RX_GO
+}

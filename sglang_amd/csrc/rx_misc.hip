@@ -1,0 +1,418 @@
+// Integer / byte kernels of the RadixAttention path: KV store (K1), kv-index build (K2),
+// kv-split scheduler (K3), paged slot allocation (K9), KV move (K10), req_to_token write (K11).
+// All HBM-bound byte movers: 16-byte per-lane accesses, one wave (or a fraction) per row.
+#include "rx_common.h"
+
+namespace rx {
+
+static thread_local char g_err[512];
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1  store_kv.  Reference: store_kvcache, kernels/jit/csrc/elementwise/kvcache.cuh:189-219
+// (one warp or 1/2/4 warps per row).  Here: 256-thread blocks, each 64-lane wave copies the
+// K row and the V row of one token with 16-byte vectors (a 2 KiB Llama row = 2 sweeps of a
+// wave); rows whose byte count is not a multiple of 16 fall back to 4-byte units.
+// ---------------------------------------------------------------------------------------
+template <int VEC>  // bytes per lane access: 16 or 4
+__global__ __launch_bounds__(256) void store_kv_kernel(
+    const char* __restrict__ k, const char* __restrict__ v, char* __restrict__ kc,
+    char* __restrict__ vc, const void* __restrict__ loc, int64_t n, int64_t k_row, int64_t v_row,
+    int64_t ks, int64_t vs, int64_t kcs, int64_t vcs, int loc64, int64_t size_limit,
+    int64_t skip_index, int32_t* err_flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t idx = load_idx(loc, row, loc64);
+  if (idx == skip_index) return;
+  if (idx < 0 || idx >= size_limit) {
+    if (lane == 0 && err_flag) atomicOr(err_flag, RX_DEVERR_SLOT_OOB);
+    return;
+  }
+  using V = typename std::conditional<VEC == 16, u32x4, uint32_t>::type;
+  const char* ksrc = k + row * ks;
+  const char* vsrc = v + row * vs;
+  char* kdst = kc + idx * kcs;
+  char* vdst = vc + idx * vcs;
+  for (int64_t off = lane * VEC; off < k_row; off += 64 * VEC)
+    *reinterpret_cast<V*>(kdst + off) = *reinterpret_cast<const V*>(ksrc + off);
+  for (int64_t off = lane * VEC; off < v_row; off += 64 * VEC)
+    *reinterpret_cast<V*>(vdst + off) = *reinterpret_cast<const V*>(vsrc + off);
+}
+
+// ---------------------------------------------------------------------------------------
+// K2  kv_indptr scan + ragged gather of req_to_token rows.
+// Reference: create_flashinfer_kv_indices_triton (kv_indices.py:8-46), grid (bs,), 512-wide.
+// Here: one 1024-thread block scans lens -> kv_indptr (bs is at most a few thousand), then a
+// (chunk, bs) grid copies 1024-token chunks, 4 B per lane coalesced.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void indptr_scan_kernel(const void* __restrict__ lens,
+                                                           int lens64, int bs,
+                                                           int32_t* __restrict__ out) {
+  __shared__ int32_t wave_sums[16];
+  __shared__ int32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) {
+    carry_s = 0;
+    out[0] = 0;
+  }
+  __syncthreads();
+  for (int base = 0; base < bs; base += 1024) {
+    const int i = base + tid;
+    int32_t x = (i < bs) ? static_cast<int32_t>(load_idx(lens, i, lens64)) : 0;
+    // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wave_sums[wid] = x;
+    __syncthreads();
+    int32_t prefix = carry_s;
+    for (int w = 0; w < wid; ++w) prefix += wave_sums[w];
+    if (i < bs) out[i + 1] = prefix + x;
+    __syncthreads();
+    if (tid == 1023) carry_s = prefix + x;
+    __syncthreads();
+  }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void kv_indices_gather_kernel(
+    const int32_t* __restrict__ req_to_token, int64_t row_stride,
+    const void* __restrict__ req_pool_indices, int pool64, const int32_t* __restrict__ kv_start,
+    const int32_t* __restrict__ kv_indptr, OutT* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int32_t beg = kv_indptr[b];
+  const int32_t len = kv_indptr[b + 1] - beg;
+  const int32_t chunk0 = blockIdx.x * 1024;
+  if (chunk0 >= len) return;
+  const int64_t req = load_idx(req_pool_indices, b, pool64);
+  const int32_t* src = req_to_token + req * row_stride + (kv_start ? kv_start[b] : 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int32_t t = chunk0 + j * 256 + threadIdx.x;
+    if (t < len) out[static_cast<int64_t>(beg) + t] = static_cast<OutT>(src[t]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K3  num_kv_splits.  Reference: get_num_kv_splits_triton (metadata.py:11-60), grid (1,).
+// Integer-exact restatement; the only float op is log2(max_seq/64) in fp32 as in Triton.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t cdiv32(int32_t a, int32_t b) { return (a + b - 1) / b; }
+
+__global__ __launch_bounds__(1024) void num_kv_splits_kernel(
+    const void* __restrict__ seq_lens, int is64, int num_seq, int num_group, int num_head,
+    int num_kv_head, int max_kv_splits, int device_core_count, int32_t* __restrict__ out) {
+  __shared__ int32_t smax[16], smin[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int32_t mx = 0, mn = INT32_MAX;
+  for (int i = tid; i < num_seq; i += 1024) {
+    const int32_t s = static_cast<int32_t>(load_idx(seq_lens, i, is64));
+    mx = max(mx, s);
+    mn = min(mn, s);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    mx = max(mx, __shfl_xor(mx, d));
+    mn = min(mn, __shfl_xor(mn, d));
+  }
+  if (lane == 0) {
+    smax[wid] = mx;
+    smin[wid] = mn;
+  }
+  __syncthreads();
+  mx = smax[0];
+  mn = smin[0];
+  for (int w = 1; w < 16; ++w) {
+    mx = max(mx, smax[w]);
+    mn = min(mn, smin[w]);
+  }
+  const int32_t max_seq_len = mx;
+  int32_t min_seq_len = mn;
+  if (max_seq_len * 8 < min_seq_len * 10) min_seq_len = max_seq_len;
+  const int32_t max_kv_splits_1 = min(cdiv32(max_seq_len, min_seq_len), max_kv_splits);
+  const int32_t kv_chunk_size_1 = cdiv32(max_seq_len, max_kv_splits_1);
+  const float ext_seq_len = static_cast<float>(max_seq_len) / 64.0f;
+  const int32_t ext_cores = static_cast<int32_t>(
+      static_cast<float>(device_core_count) * fmaxf(__log2f(ext_seq_len), 1.0f));
+  int32_t block_h = 16;
+  const int32_t num_kv_group = num_head / num_kv_head;
+  int32_t token_grid;
+  if (num_kv_group == 1) {
+    token_grid = num_seq * num_group * num_head;
+  } else {
+    block_h = min(block_h, num_kv_group);
+    token_grid = num_seq * num_group * cdiv32(num_head, block_h);
+  }
+  const int32_t max_kv_splits_2 = min(cdiv32(ext_cores, token_grid), max_kv_splits);
+  const int32_t kv_chunk_size_2 = cdiv32(max_seq_len, max_kv_splits_2);
+  for (int i = tid; i < num_seq; i += 1024) {
+    const int32_t s = static_cast<int32_t>(load_idx(seq_lens, i, is64));
+    const int32_t n = max(cdiv32(s, kv_chunk_size_1), cdiv32(s, kv_chunk_size_2));
+    for (int g = 0; g < num_group; ++g) out[i * num_group + g] = n;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// K9  paged allocation.  Reference: alloc_extend_kernel / alloc_decode_kernel
+// (kernels/ops/memory/allocator.py:16-135), grid (bs,), each program re-sums the lens of the
+// requests before it.  Same decomposition here: one 256-thread block per request.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t block_sum_256(int64_t x, int64_t* sh) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+  __syncthreads();
+  const int64_t r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void alloc_extend_kernel(
+    const int64_t* __restrict__ pre_lens, const int64_t* __restrict__ seq_lens,
+    const int64_t* __restrict__ last_loc, const int64_t* __restrict__ free_pages,
+    int64_t* __restrict__ out, int page_size) {
+  __shared__ int64_t sh[4];
+  const int pid = blockIdx.x, tid = threadIdx.x;
+  const int64_t ps = page_size;
+  int64_t ext_before = 0, pages_before = 0;
+  for (int i = tid; i < pid; i += 256) {
+    const int64_t s = seq_lens[i], p = pre_lens[i];
+    ext_before += s - p;
+    pages_before += (s + ps - 1) / ps - (p + ps - 1) / ps;
+  }
+  const int64_t out_start = block_sum_256(ext_before, sh);
+  const int64_t page_start = block_sum_256(pages_before, sh);
+  const int64_t seq = seq_lens[pid], pre = pre_lens[pid];
+  const int64_t new_pages = (seq + ps - 1) / ps - (pre + ps - 1) / ps;
+  // part 1: finish the old partial page
+  const int64_t pre_up = (pre + ps - 1) / ps * ps;
+  const int64_t n1 = min(seq, pre_up) - pre;
+  const int64_t ll = last_loc[pid];
+  for (int64_t j = tid; j < n1; j += 256) out[out_start + j] = ll + 1 + j;
+  if (pre + n1 == seq) return;
+  // part 2: whole new pages
+  const int64_t n2 = seq / ps * ps - pre_up;
+  for (int64_t j = tid; j < n2; j += 256)
+    out[out_start + n1 + j] = free_pages[page_start + j / ps] * ps + j % ps;
+  if (pre + n1 + n2 == seq) return;
+  // part 3: the new partial page
+  const int64_t n3 = seq - seq / ps * ps;
+  const int64_t start = free_pages[page_start + new_pages - 1];
+  for (int64_t j = tid; j < n3; j += 256) out[out_start + n1 + n2 + j] = start * ps + j;
+}
+
+__global__ __launch_bounds__(256) void alloc_decode_kernel(
+    const int64_t* __restrict__ seq_lens, const int64_t* __restrict__ last_loc,
+    const int64_t* __restrict__ free_pages, int64_t* __restrict__ out, int page_size) {
+  __shared__ int64_t sh[4];
+  const int pid = blockIdx.x, tid = threadIdx.x;
+  const int64_t ps = page_size;
+  int64_t pages_before = 0;
+  for (int i = tid; i < pid; i += 256) {
+    const int64_t s = seq_lens[i];
+    pages_before += (s + ps - 1) / ps - (s - 1 + ps - 1) / ps;
+  }
+  const int64_t page_start = block_sum_256(pages_before, sh);
+  if (tid != 0) return;
+  const int64_t s = seq_lens[pid];
+  const int64_t mine = (s + ps - 1) / ps - (s - 1 + ps - 1) / ps;
+  out[pid] = (mine == 0) ? last_loc[pid] + 1 : free_pages[page_start] * ps;
+}
+
+// ---------------------------------------------------------------------------------------
+// K11  write_req_to_token.  Reference: write_req_to_token_pool_triton
+// (called srt/mem_cache/allocation.py:75-84), grid (bs,).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void write_req_to_token_kernel(
+    int32_t* __restrict__ req_to_token, int64_t row_stride,
+    const int64_t* __restrict__ req_pool_indices, const int64_t* const* __restrict__ prefix_ptrs,
+    const int64_t* __restrict__ pre_lens, const int64_t* __restrict__ seq_lens,
+    const int64_t* __restrict__ extend_lens, const int64_t* __restrict__ out_cache_loc) {
+  __shared__ int64_t sh[4];
+  const int pid = blockIdx.x, tid = threadIdx.x;
+  int64_t before = 0;
+  for (int i = tid; i < pid; i += 256) before += extend_lens[i];
+  const int64_t ext_off = block_sum_256(before, sh);
+  int32_t* row = req_to_token + req_pool_indices[pid] * row_stride;
+  const int64_t pre = pre_lens[pid], seq = seq_lens[pid];
+  const int64_t* pfx = prefix_ptrs ? prefix_ptrs[pid] : nullptr;
+  if (pfx)
+    for (int64_t j = tid; j < pre; j += 256) row[j] = static_cast<int32_t>(pfx[j]);
+  for (int64_t j = tid; j < seq - pre; j += 256)
+    row[pre + j] = static_cast<int32_t>(out_cache_loc[ext_off + j]);
+}
+
+// ---------------------------------------------------------------------------------------
+// K10  move_kv over every layer buffer.  Reference: copy_all_layer_kv_cache_tiled
+// (kernels/ops/kvcache/cache_move.py:60-133): grid (buffer, token-tile); one wave per row.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void move_kv_kernel(const uint64_t* __restrict__ data_ptrs,
+                                                      const int64_t* __restrict__ row_bytes,
+                                                      const int64_t* __restrict__ tgt,
+                                                      const int64_t* __restrict__ src,
+                                                      int64_t n) {
+  const int buf = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  char* base = reinterpret_cast<char*>(data_ptrs[buf]);
+  const int64_t rb = row_bytes[buf];
+  const char* s = base + src[i] * rb;
+  char* d = base + tgt[i] * rb;
+  if ((rb & 15) == 0) {
+    for (int64_t off = lane * 16; off < rb; off += 64 * 16)
+      *reinterpret_cast<u32x4*>(d + off) = *reinterpret_cast<const u32x4*>(s + off);
+  } else {
+    for (int64_t off = lane * 4; off < rb; off += 64 * 4)
+      *reinterpret_cast<uint32_t*>(d + off) = *reinterpret_cast<const uint32_t*>(s + off);
+  }
+}
+
+}  // namespace rx
+
+using namespace rx;
+
+extern "C" {
+
+int rx_version(void) { return RX_ABI_VERSION; }
+const char* rx_last_error(void) { return rx::err_buf(); }
+
+int rx_store_kv(const void* k, const void* v, void* k_cache, void* v_cache, const void* loc,
+                int64_t n, int64_t k_row_bytes, int64_t v_row_bytes, int64_t k_stride_bytes,
+                int64_t v_stride_bytes, int64_t kc_stride_bytes, int64_t vc_stride_bytes,
+                int loc_is_i64, int64_t size_limit, int64_t skip_index, int32_t* err_flag,
+                void* stream) {
+  RX_REQUIRE(n >= 0, "rx_store_kv: n=%lld < 0", (long long)n);
+  if (n == 0) return RX_OK;
+  RX_REQUIRE(k && v && k_cache && v_cache && loc, "rx_store_kv: null pointer");
+  RX_REQUIRE(k_row_bytes > 0 && v_row_bytes > 0 && k_row_bytes % 4 == 0 && v_row_bytes % 4 == 0,
+             "rx_store_kv: row bytes (%lld,%lld) must be positive multiples of 4",
+             (long long)k_row_bytes, (long long)v_row_bytes);
+  RX_REQUIRE(size_limit > 0, "rx_store_kv: size_limit must be > 0");
+  const bool vec16 = ((k_row_bytes | v_row_bytes | k_stride_bytes | v_stride_bytes |
+                       kc_stride_bytes | vc_stride_bytes) % 16 == 0) &&
+                     (((uintptr_t)k | (uintptr_t)v | (uintptr_t)k_cache | (uintptr_t)v_cache) % 16 == 0);
+  if (!vec16)
+    RX_REQUIRE(((k_stride_bytes | v_stride_bytes | kc_stride_bytes | vc_stride_bytes) % 4 == 0) &&
+                   (((uintptr_t)k | (uintptr_t)v | (uintptr_t)k_cache | (uintptr_t)v_cache) % 4 == 0),
+               "rx_store_kv: strides / base pointers must be 4-byte aligned");
+  const dim3 grid(static_cast<unsigned>((n + 3) / 4)), block(256);
+  auto s = static_cast<hipStream_t>(stream);
+  if (vec16)
+    hipLaunchKernelGGL(store_kv_kernel<16>, grid, block, 0, s, (const char*)k, (const char*)v,
+                       (char*)k_cache, (char*)v_cache, loc, n, k_row_bytes, v_row_bytes,
+                       k_stride_bytes, v_stride_bytes, kc_stride_bytes, vc_stride_bytes,
+                       loc_is_i64, size_limit, skip_index, err_flag);
+  else
+    hipLaunchKernelGGL(store_kv_kernel<4>, grid, block, 0, s, (const char*)k, (const char*)v,
+                       (char*)k_cache, (char*)v_cache, loc, n, k_row_bytes, v_row_bytes,
+                       k_stride_bytes, v_stride_bytes, kc_stride_bytes, vc_stride_bytes,
+                       loc_is_i64, size_limit, skip_index, err_flag);
+  return check_launch("rx_store_kv");
+}
+
+int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,
+                        const void* req_pool_indices, int pool_idx_is_i64, const void* lens,
+                        int lens_is_i64, const int32_t* kv_start, int32_t* kv_indptr_out,
+                        void* kv_indices_out, int out_is_i64, int bs, void* stream) {
+  RX_REQUIRE(bs >= 0, "rx_build_kv_indices: bs < 0");
+  RX_REQUIRE(kv_indptr_out, "rx_build_kv_indices: kv_indptr_out is null");
+  auto s = static_cast<hipStream_t>(stream);
+  if (bs == 0) {
+    hipMemsetAsync(kv_indptr_out, 0, sizeof(int32_t), s);
+    return check_launch("rx_build_kv_indices(memset)");
+  }
+  RX_REQUIRE(req_to_token && req_pool_indices && lens, "rx_build_kv_indices: null pointer");
+  hipLaunchKernelGGL(indptr_scan_kernel, dim3(1), dim3(1024), 0, s, lens, lens_is_i64, bs,
+                     kv_indptr_out);
+  if (kv_indices_out) {
+    // chunks of 1024 tokens; grid.x covers the longest possible row
+    const unsigned chunks = static_cast<unsigned>((row_stride + 1023) / 1024);
+    const dim3 grid(chunks ? chunks : 1, bs);
+    if (out_is_i64)
+      hipLaunchKernelGGL(kv_indices_gather_kernel<int64_t>, grid, dim3(256), 0, s, req_to_token,
+                         row_stride, req_pool_indices, pool_idx_is_i64, kv_start, kv_indptr_out,
+                         (int64_t*)kv_indices_out);
+    else
+      hipLaunchKernelGGL(kv_indices_gather_kernel<int32_t>, grid, dim3(256), 0, s, req_to_token,
+                         row_stride, req_pool_indices, pool_idx_is_i64, kv_start, kv_indptr_out,
+                         (int32_t*)kv_indices_out);
+  }
+  return check_launch("rx_build_kv_indices");
+}
+
+int rx_num_kv_splits(const void* seq_lens, int seq_lens_is_i64, int num_seq, int num_group,
+                     int num_head, int num_kv_head, int max_kv_splits, int device_core_count,
+                     int32_t* out, void* stream) {
+  RX_REQUIRE(seq_lens && out, "rx_num_kv_splits: null pointer");
+  RX_REQUIRE(num_seq > 0 && num_group > 0 && num_head > 0 && num_kv_head > 0 &&
+                 max_kv_splits > 0 && num_head % num_kv_head == 0,
+             "rx_num_kv_splits: bad sizes");
+  hipLaunchKernelGGL(num_kv_splits_kernel, dim3(1), dim3(1024), 0,
+                     static_cast<hipStream_t>(stream), seq_lens, seq_lens_is_i64, num_seq,
+                     num_group, num_head, num_kv_head, max_kv_splits, device_core_count, out);
+  return check_launch("rx_num_kv_splits");
+}
+
+int rx_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const int64_t* last_loc,
+                    const int64_t* free_pages, int64_t* out_indices, int bs, int page_size,
+                    void* stream) {
+  RX_REQUIRE(bs >= 0 && page_size > 0, "rx_alloc_extend: bad sizes");
+  if (bs == 0) return RX_OK;
+  RX_REQUIRE(prefix_lens && seq_lens && last_loc && free_pages && out_indices,
+             "rx_alloc_extend: null pointer");
+  hipLaunchKernelGGL(alloc_extend_kernel, dim3(bs), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), prefix_lens, seq_lens, last_loc,
+                     free_pages, out_indices, page_size);
+  return check_launch("rx_alloc_extend");
+}
+
+int rx_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc, const int64_t* free_pages,
+                    int64_t* out_indices, int bs, int page_size, void* stream) {
+  RX_REQUIRE(bs >= 0 && page_size > 0, "rx_alloc_decode: bad sizes");
+  if (bs == 0) return RX_OK;
+  RX_REQUIRE(seq_lens && last_loc && free_pages && out_indices, "rx_alloc_decode: null pointer");
+  hipLaunchKernelGGL(alloc_decode_kernel, dim3(bs), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), seq_lens, last_loc, free_pages,
+                     out_indices, page_size);
+  return check_launch("rx_alloc_decode");
+}
+
+int rx_write_req_to_token(int32_t* req_to_token, int64_t row_stride,
+                          const int64_t* req_pool_indices, const int64_t* const* prefix_ptrs,
+                          const int64_t* pre_lens, const int64_t* seq_lens,
+                          const int64_t* extend_lens, const int64_t* out_cache_loc, int bs,
+                          void* stream) {
+  RX_REQUIRE(bs >= 0, "rx_write_req_to_token: bs < 0");
+  if (bs == 0) return RX_OK;
+  RX_REQUIRE(req_to_token && req_pool_indices && pre_lens && seq_lens && extend_lens &&
+                 out_cache_loc,
+             "rx_write_req_to_token: null pointer");
+  hipLaunchKernelGGL(write_req_to_token_kernel, dim3(bs), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), req_to_token, row_stride, req_pool_indices,
+                     prefix_ptrs, pre_lens, seq_lens, extend_lens, out_cache_loc);
+  return check_launch("rx_write_req_to_token");
+}
+
+int rx_move_kv(const uint64_t* data_ptrs, const int64_t* row_bytes, int num_bufs,
+               const int64_t* tgt_loc, const int64_t* src_loc, int64_t n, void* stream) {
+  RX_REQUIRE(num_bufs >= 0 && n >= 0, "rx_move_kv: bad sizes");
+  if (num_bufs == 0 || n == 0) return RX_OK;
+  RX_REQUIRE(data_ptrs && row_bytes && tgt_loc && src_loc, "rx_move_kv: null pointer");
+  hipLaunchKernelGGL(move_kv_kernel, dim3(static_cast<unsigned>((n + 3) / 4), num_bufs),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), data_ptrs, row_bytes,
+                     tgt_loc, src_loc, n);
+  return check_launch("rx_move_kv");
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""ctypes binding of libradix_hip.so (include/radix_hip.h).
+
+The product path has NO fallback: if the shared object is missing and cannot be built, or a
+call returns a negative status, this module raises.  Nothing under ``oracle/`` is imported.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+from . import build as _build
+
+_lock = threading.Lock()
+_lib = None
+
+c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
+
+RX_BF16, RX_F16 = 0, 1
+RX_DEVERR_SLOT_OOB = 1
+
+
+class RxKvLayout(C.Structure):
+    _fields_ = [
+        ("k_buf", c_void_p), ("v_buf", c_void_p), ("page_size", c_int32),
+        ("k_page_stride", c_int64), ("k_tok_stride", c_int64), ("k_head_stride", c_int64),
+        ("v_page_stride", c_int64), ("v_tok_stride", c_int64), ("v_head_stride", c_int64),
+    ]
+
+
+class RxDecodeParams(C.Structure):
+    _fields_ = [
+        ("q", c_void_p), ("o", c_void_p),
+        ("q_stride_t", c_int64), ("q_stride_h", c_int64), ("o_stride_t", c_int64), ("o_stride_h", c_int64),
+        ("kv", RxKvLayout),
+        ("kv_indptr", c_void_p), ("kv_indices", c_void_p), ("kv_indices_is_i64", c_int32),
+        ("req_to_token", c_void_p), ("req_row_stride", c_int64),
+        ("req_pool_indices", c_void_p), ("req_pool_indices_is_i64", c_int32),
+        ("seq_lens", c_void_p), ("seq_lens_is_i64", c_int32),
+        ("num_kv_splits", c_void_p), ("max_kv_splits", c_int32),
+        ("attn_logits", c_void_p), ("attn_lse", c_void_p),
+        ("bs", c_int32), ("num_q_heads", c_int32), ("num_kv_heads", c_int32),
+        ("head_dim", c_int32), ("v_head_dim", c_int32),
+        ("sm_scale", c_float), ("k_scale", c_float), ("v_scale", c_float), ("logit_cap", c_float),
+        ("sinks", c_void_p), ("dtype", c_int32),
+    ]
+
+
+class RxExtendParams(C.Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k_extend", c_void_p), ("v_extend", c_void_p), ("o", c_void_p),
+        ("q_stride_t", c_int64), ("q_stride_h", c_int64), ("k_stride_t", c_int64), ("k_stride_h", c_int64),
+        ("v_stride_t", c_int64), ("v_stride_h", c_int64), ("o_stride_t", c_int64), ("o_stride_h", c_int64),
+        ("kv", RxKvLayout),
+        ("qo_indptr", c_void_p), ("qo_indptr_is_i64", c_int32),
+        ("kv_indptr", c_void_p), ("kv_indices", c_void_p), ("kv_indices_is_i64", c_int32),
+        ("lse", c_void_p), ("lse_stride_t", c_int64), ("lse_stride_h", c_int64),
+        ("bs", c_int32), ("max_extend_len", c_int32), ("num_q_heads", c_int32), ("num_kv_heads", c_int32),
+        ("head_dim", c_int32), ("v_head_dim", c_int32),
+        ("sm_scale", c_float), ("k_scale", c_float), ("v_scale", c_float), ("logit_cap", c_float),
+        ("is_causal", c_int32), ("skip_prefix", c_int32), ("skip_extend", c_int32),
+        ("sliding_window_size", c_int32),
+        ("sinks", c_void_p), ("dtype", c_int32),
+    ]
+
+
+# symbol -> (restype, argtypes); every prototype of include/radix_hip.h
+PROTOTYPES = {
+    "rx_version": (c_int, []),
+    "rx_last_error": (C.c_char_p, []),
+    "rx_store_kv": (c_int, [c_void_p] * 5 + [c_int64] * 7 + [c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "rx_build_kv_indices": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rx_num_kv_splits": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_void_p]),
+    "rx_decode_attn": (c_int, [C.POINTER(RxDecodeParams), c_void_p]),
+    "rx_extend_attn": (c_int, [C.POINTER(RxExtendParams), c_void_p]),
+    "rx_alloc_extend": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "rx_alloc_decode": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "rx_write_req_to_token": (c_int, [c_void_p, c_int64] + [c_void_p] * 6 + [c_int, c_void_p]),
+    "rx_move_kv": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+}
+
+
+class RadixHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True):
+    """Load (building first if the .so is absent/stale and hipcc exists).  Raises on failure."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if build_if_missing and _build.needs_build():
+            try:
+                _build.build()
+            except Exception as e:  # stale-but-present lib is still usable on a GPU box w/o sources
+                if not os.path.exists(path):
+                    raise RadixHipError(f"libradix_hip.so missing and build failed: {e}") from e
+        if not os.path.exists(path):
+            raise RadixHipError(f"{path} not found: run `python -m sglang_amd.build`")
+        lib = C.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)  # AttributeError if the header and the .so disagree
+            fn.restype = res
+            fn.argtypes = args
+        if lib.rx_version() != 1:
+            raise RadixHipError(f"ABI version mismatch: {lib.rx_version()}")
+        _lib = lib
+        return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().rx_last_error()
+        raise RadixHipError(f"{what or 'libradix_hip'} failed with status {status}: "
+                            f"{msg.decode() if msg else ''}")

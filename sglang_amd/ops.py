@@ -1,0 +1,359 @@
+"""Operator-level host API: same names, argument meaning and error behaviour as the
+reference's Python operators for this path, implemented by calls into libradix_hip.so.
+
+torch is used for device memory and streams only.  Each wrapper cites the reference
+operator it replaces (paths relative to /root/reference/python/sglang/).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as _L
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _is64(t: torch.Tensor, name: str) -> int:
+    if t.dtype == torch.int64:
+        return 1
+    if t.dtype == torch.int32:
+        return 0
+    raise TypeError(f"{name} must be int32 or int64, got {t.dtype}")
+
+
+def _rx_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return _L.RX_BF16
+    if t.dtype == torch.float16:
+        return _L.RX_F16
+    raise TypeError(f"unsupported dtype {t.dtype}: the HIP path computes in bf16/fp16")
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "sglang_amd ops run on the GPU through libradix_hip.so only; got a "
+                f"{t.device} tensor (there is no CPU fallback)")
+
+
+# --------------------------------------------------------------------------------------
+# K1  store_cache            kernels/ops/kvcache/kvcache.py:57-110
+# --------------------------------------------------------------------------------------
+def store_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                indices: torch.Tensor, *, row_bytes: int = 0, v_row_bytes: int = 0,
+                size_limit: int = 0, reserved_skip_index: int = 0,
+                err_flag: Optional[torch.Tensor] = None) -> None:
+    """k_cache[indices[i]] = k[i]; v_cache[indices[i]] = v[i].  k/v are (N, H*D) views whose
+    rows may be strided; caches are (rows, H*D).  Writes to ``reserved_skip_index`` (slot 0)
+    are skipped; an index outside [0, size_limit) is dropped and flagged in ``err_flag``."""
+    _require_cuda(k, v, k_cache, v_cache, indices)
+    k2 = k.reshape(k.shape[0], -1) if k.dim() != 2 else k
+    v2 = v.reshape(v.shape[0], -1) if v.dim() != 2 else v
+    kc = k_cache.view(k_cache.shape[0], -1) if k_cache.dim() != 2 else k_cache
+    vc = v_cache.view(v_cache.shape[0], -1) if v_cache.dim() != 2 else v_cache
+    if k2.stride(-1) != 1 or v2.stride(-1) != 1 or kc.stride(-1) != 1 or vc.stride(-1) != 1:
+        raise ValueError("store_cache: innermost dimension must be contiguous")
+    if indices.dim() != 1 or indices.shape[0] != k2.shape[0] or v2.shape[0] != k2.shape[0]:
+        raise ValueError("store_cache: indices / k / v batch sizes differ")
+    es = k2.element_size()
+    row_bytes = row_bytes or k2.shape[-1] * es
+    v_row_bytes = v_row_bytes or v2.shape[-1] * v2.element_size()
+    if size_limit <= 0:
+        size_limit = kc.shape[0]
+    idx = indices if indices.is_contiguous() else indices.contiguous()
+    st = _L.load().rx_store_kv(
+        _ptr(k2), _ptr(v2), _ptr(kc), _ptr(vc), _ptr(idx), k2.shape[0], row_bytes, v_row_bytes,
+        k2.stride(0) * es, v2.stride(0) * v2.element_size(), kc.stride(0) * kc.element_size(),
+        vc.stride(0) * vc.element_size(), _is64(idx, "indices"), size_limit, reserved_skip_index,
+        _ptr(err_flag), _stream(k))
+    _L.check(st, "rx_store_kv")
+
+
+# --------------------------------------------------------------------------------------
+# K2  kv-index build         kernels/ops/kvcache/kv_indices.py:8-46 (+ triton_backend.py:386-404)
+# --------------------------------------------------------------------------------------
+def build_kv_indices(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
+                     lens: torch.Tensor, kv_indptr: torch.Tensor,
+                     kv_indices: Optional[torch.Tensor], kv_start: Optional[torch.Tensor] = None):
+    """Fills kv_indptr[:bs+1] (int32) with the exclusive scan of ``lens`` and, when given,
+    kv_indices with the ragged gather of req_to_token rows."""
+    _require_cuda(req_to_token, req_pool_indices, lens, kv_indptr, kv_indices, kv_start)
+    bs = lens.shape[0]
+    if req_to_token.dtype != torch.int32 or kv_indptr.dtype != torch.int32:
+        raise TypeError("req_to_token and kv_indptr must be int32")
+    if kv_indptr.numel() < bs + 1:
+        raise ValueError("kv_indptr too small")
+    if kv_start is not None and kv_start.dtype != torch.int32:
+        kv_start = kv_start.to(torch.int32)
+    st = _L.load().rx_build_kv_indices(
+        _ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices),
+        _is64(req_pool_indices, "req_pool_indices"), _ptr(lens), _is64(lens, "lens"),
+        _ptr(kv_start), _ptr(kv_indptr), _ptr(kv_indices),
+        0 if kv_indices is None else _is64(kv_indices, "kv_indices"), bs, _stream(req_to_token))
+    _L.check(st, "rx_build_kv_indices")
+    return kv_indptr[: bs + 1]
+
+
+# --------------------------------------------------------------------------------------
+# K3  get_num_kv_splits      kernels/ops/attention/metadata.py:11-60
+# --------------------------------------------------------------------------------------
+def get_num_kv_splits(num_kv_splits: torch.Tensor, seq_lens: torch.Tensor, num_head: int,
+                      num_kv_head: int, max_kv_splits: int, device_core_count: int) -> None:
+    _require_cuda(num_kv_splits, seq_lens)
+    num_token, num_seq = num_kv_splits.shape[0], seq_lens.shape[0]
+    num_group = num_token // num_seq
+    assert num_group * num_seq == num_token, (
+        f"num_seq({num_seq}), num_token({num_token}), something goes wrong!")
+    if num_kv_splits.dtype != torch.int32:
+        raise TypeError("num_kv_splits must be int32")
+    st = _L.load().rx_num_kv_splits(_ptr(seq_lens), _is64(seq_lens, "seq_lens"), num_seq,
+                                    num_group, num_head, num_kv_head, max_kv_splits,
+                                    device_core_count, _ptr(num_kv_splits), _stream(seq_lens))
+    _L.check(st, "rx_num_kv_splits")
+
+
+# --------------------------------------------------------------------------------------
+# KV buffer strides          _extract_kv_strides, kernels/ops/attention/decode_attention.py:39-88
+# --------------------------------------------------------------------------------------
+def _kv_layout(k_buffer: torch.Tensor, v_buffer: torch.Tensor, page_size: int) -> _L.RxKvLayout:
+    lay = _L.RxKvLayout()
+    lay.k_buf = k_buffer.data_ptr()
+    lay.v_buf = v_buffer.data_ptr()
+    lay.page_size = page_size
+
+    def strides(buf):
+        if buf.dim() == 4:  # [pages, page_size, H, D]  (page-major shared view)
+            assert buf.shape[1] == page_size
+            return buf.stride(0), buf.stride(1), buf.stride(2)
+        if buf.dim() == 3:  # [slots, H, D]
+            return buf.stride(0) * page_size, buf.stride(0), buf.stride(1)
+        raise ValueError(f"unexpected KV buffer ndim={buf.dim()}, shape={tuple(buf.shape)}")
+
+    lay.k_page_stride, lay.k_tok_stride, lay.k_head_stride = strides(k_buffer)
+    lay.v_page_stride, lay.v_tok_stride, lay.v_head_stride = strides(v_buffer)
+    if k_buffer.stride(-1) != 1 or v_buffer.stride(-1) != 1:
+        raise ValueError("KV buffers must be contiguous in head_dim")
+    return lay
+
+
+def kv_layout_hnd(k_buffer: torch.Tensor, v_buffer: torch.Tensor) -> _L.RxKvLayout:
+    """HND pool [pages, H, page, D] (memory_pool.py:2032-2036)."""
+    lay = _L.RxKvLayout()
+    lay.k_buf = k_buffer.data_ptr()
+    lay.v_buf = v_buffer.data_ptr()
+    lay.page_size = k_buffer.shape[2]
+    lay.k_page_stride, lay.k_head_stride, lay.k_tok_stride = (k_buffer.stride(0), k_buffer.stride(1),
+                                                              k_buffer.stride(2))
+    lay.v_page_stride, lay.v_head_stride, lay.v_tok_stride = (v_buffer.stride(0), v_buffer.stride(1),
+                                                              v_buffer.stride(2))
+    return lay
+
+
+# --------------------------------------------------------------------------------------
+# K4-K6  decode_attention_fwd   kernels/ops/attention/decode_attention.py:968-1044
+# --------------------------------------------------------------------------------------
+def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
+                         num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap=0.0,
+                         sinks=None, xai_temperature_len=-1, has_mla=False, use_pdl=False,
+                         page_size: int = 1, score_mod=None, aux_tensors=None, kv_layout=None):
+    """Same contract as the reference.  q [bs,Hq,Dk], o [bs,Hq,Dv], kv_indptr int32[bs+1],
+    kv_indices int32/int64, attn_logits fp32[bs,Hq,max_kv_splits,Dv], attn_lse fp32[bs,Hq,S].
+    ``max_kv_splits == 1`` (or num_kv_splits None) runs the single-pass kernel."""
+    if xai_temperature_len > 0 or score_mod is not None or aux_tensors is not None or has_mla:
+        raise NotImplementedError("xai temperature / score_mod / MLA are outside the HIP path")
+    _require_cuda(q, k_buffer, v_buffer, o, kv_indptr, kv_indices)
+    if max_kv_splits > 1:
+        assert max_kv_splits == attn_logits.shape[2]
+        assert q.shape[0] <= attn_logits.shape[0]
+    assert q.shape[0] <= kv_indptr.shape[0] - 1
+    p = _L.RxDecodeParams()
+    _fill_decode_common(p, q, k_buffer, v_buffer, o, attn_logits, attn_lse, num_kv_splits,
+                        max_kv_splits, sm_scale, k_scale, v_scale, logit_cap, sinks, page_size,
+                        kv_layout)
+    if kv_indptr.dtype != torch.int32:
+        raise TypeError("kv_indptr must be int32")
+    p.kv_indptr = kv_indptr.data_ptr()
+    p.kv_indices = kv_indices.data_ptr()
+    p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
+    _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
+
+
+def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
+                               attn_logits, attn_lse, num_kv_splits, max_kv_splits, sm_scale,
+                               k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
+                               page_size: int = 1, kv_layout=None):
+    """MI355X-native entry: the kernel walks req_to_token itself (as the reference's CPU kernel
+    decode_attention_cpu does, aot/csrc/cpu/decode.cpp:1586), so no kv_indices are materialised."""
+    _require_cuda(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens)
+    if req_to_token.dtype != torch.int32:
+        raise TypeError("req_to_token must be int32")
+    p = _L.RxDecodeParams()
+    _fill_decode_common(p, q, k_buffer, v_buffer, o, attn_logits, attn_lse, num_kv_splits,
+                        max_kv_splits, sm_scale, k_scale, v_scale, logit_cap, sinks, page_size,
+                        kv_layout)
+    p.kv_indices = None
+    p.req_to_token = req_to_token.data_ptr()
+    p.req_row_stride = req_to_token.stride(0)
+    p.req_pool_indices = req_pool_indices.data_ptr()
+    p.req_pool_indices_is_i64 = _is64(req_pool_indices, "req_pool_indices")
+    p.seq_lens = seq_lens.data_ptr()
+    p.seq_lens_is_i64 = _is64(seq_lens, "seq_lens")
+    _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
+
+
+def _fill_decode_common(p, q, k_buffer, v_buffer, o, attn_logits, attn_lse, num_kv_splits,
+                        max_kv_splits, sm_scale, k_scale, v_scale, logit_cap, sinks, page_size,
+                        kv_layout):
+    if q.dim() != 3 or o.dim() != 3:
+        raise ValueError("q/o must be [bs, heads, dim]")
+    if q.stride(-1) != 1 or o.stride(-1) != 1:
+        raise ValueError("q/o must be contiguous in head_dim")
+    p.q, p.o = q.data_ptr(), o.data_ptr()
+    p.q_stride_t, p.q_stride_h = q.stride(0), q.stride(1)
+    p.o_stride_t, p.o_stride_h = o.stride(0), o.stride(1)
+    p.kv = kv_layout if kv_layout is not None else _kv_layout(k_buffer, v_buffer, page_size)
+    p.num_kv_splits = None if num_kv_splits is None else num_kv_splits.data_ptr()
+    p.max_kv_splits = max(1, int(max_kv_splits)) if num_kv_splits is not None else 1
+    if p.max_kv_splits > 1:
+        if attn_logits.dtype != torch.float32 or attn_lse.dtype != torch.float32:
+            raise TypeError("attn_logits / attn_lse must be float32")
+        if not attn_logits.is_contiguous() or not attn_lse.is_contiguous():
+            raise ValueError("attn_logits / attn_lse must be contiguous")
+        if num_kv_splits.dtype != torch.int32:
+            raise TypeError("num_kv_splits must be int32")
+        p.attn_logits, p.attn_lse = attn_logits.data_ptr(), attn_lse.data_ptr()
+    p.bs, p.num_q_heads = q.shape[0], q.shape[1]
+    p.num_kv_heads = k_buffer.shape[-2] if kv_layout is None else k_buffer.shape[1]
+    p.head_dim, p.v_head_dim = q.shape[-1], o.shape[-1]
+    p.sm_scale, p.k_scale, p.v_scale, p.logit_cap = sm_scale, k_scale, v_scale, logit_cap
+    if sinks is not None:
+        if sinks.dtype != torch.float32:
+            sinks = sinks.float()
+        p._keep = sinks
+        p.sinks = sinks.data_ptr()
+    p.dtype = _rx_dtype(q)
+    if k_buffer.dtype != q.dtype or v_buffer.dtype != q.dtype or o.dtype != q.dtype:
+        raise TypeError("q, k_buffer, v_buffer and o must share one 16-bit dtype")
+
+
+# --------------------------------------------------------------------------------------
+# K7  extend_attention_fwd      kernels/ops/attention/extend_attention.py:664-812
+# --------------------------------------------------------------------------------------
+def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
+                         kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr,
+                         max_len_extend, k_scale, v_scale, sm_scale=None, logit_cap=0.0,
+                         skip_prefix_custom_mask=True, sliding_window_size=-1, sinks=None,
+                         window_kv_offsets=None, xai_temperature_len=-1, lse_extend=None,
+                         skip_prefix=False, skip_extend=False, page_size: int = 1,
+                         score_mod=None, aux_tensors=None, kv_layout=None):
+    if custom_mask is not None or xai_temperature_len > 0 or score_mod is not None:
+        raise NotImplementedError("custom_mask / xai temperature / score_mod: outside the HIP path")
+    _require_cuda(q_extend, k_extend, v_extend, o_extend, qo_indptr, kv_indptr)
+    for name, t in (("q", q_extend), ("k", k_extend), ("v", v_extend), ("o", o_extend)):
+        if t.dim() != 3 or t.stride(-1) != 1:
+            raise ValueError(f"{name}_extend must be [T, heads, dim] and contiguous in dim")
+    if kv_indptr.dtype != torch.int32:
+        raise TypeError("kv_indptr must be int32")
+    p = _L.RxExtendParams()
+    p.q, p.k_extend, p.v_extend, p.o = (q_extend.data_ptr(), k_extend.data_ptr(),
+                                        v_extend.data_ptr(), o_extend.data_ptr())
+    p.q_stride_t, p.q_stride_h = q_extend.stride(0), q_extend.stride(1)
+    p.k_stride_t, p.k_stride_h = k_extend.stride(0), k_extend.stride(1)
+    p.v_stride_t, p.v_stride_h = v_extend.stride(0), v_extend.stride(1)
+    p.o_stride_t, p.o_stride_h = o_extend.stride(0), o_extend.stride(1)
+    if k_buffer is not None:
+        p.kv = kv_layout if kv_layout is not None else _kv_layout(k_buffer, v_buffer, page_size)
+    else:
+        p.kv.page_size = 1
+        skip_prefix = True
+    p.qo_indptr = qo_indptr.data_ptr()
+    p.qo_indptr_is_i64 = _is64(qo_indptr, "qo_indptr")
+    p.kv_indptr = kv_indptr.data_ptr()
+    if kv_indices is not None:
+        p.kv_indices = kv_indices.data_ptr()
+        p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
+    if lse_extend is not None:
+        if lse_extend.dtype != torch.float32:
+            raise TypeError("lse_extend must be float32")
+        p.lse = lse_extend.data_ptr()
+        p.lse_stride_t, p.lse_stride_h = lse_extend.stride(0), lse_extend.stride(1)
+    p.bs = qo_indptr.shape[0] - 1
+    p.max_extend_len = int(max_len_extend)
+    p.num_q_heads, p.num_kv_heads = q_extend.shape[1], k_extend.shape[1]
+    p.head_dim, p.v_head_dim = q_extend.shape[-1], v_extend.shape[-1]
+    p.sm_scale = sm_scale or 1.0 / (q_extend.shape[-1] ** 0.5)
+    p.k_scale, p.v_scale, p.logit_cap = k_scale, v_scale, logit_cap
+    p.is_causal, p.skip_prefix, p.skip_extend = int(bool(is_causal)), int(skip_prefix), int(skip_extend)
+    p.sliding_window_size = int(sliding_window_size) if sliding_window_size and sliding_window_size > 0 else 0
+    if sinks is not None:
+        if sinks.dtype != torch.float32:
+            sinks = sinks.float()
+        p._keep = sinks
+        p.sinks = sinks.data_ptr()
+    p.dtype = _rx_dtype(q_extend)
+    _L.check(_L.load().rx_extend_attn(C.byref(p), _stream(q_extend)), "rx_extend_attn")
+
+
+# --------------------------------------------------------------------------------------
+# K9  paged allocation kernels   kernels/ops/memory/allocator.py:16-135
+# --------------------------------------------------------------------------------------
+def alloc_extend(prefix_lens, seq_lens, last_loc, free_pages, out_indices, page_size: int):
+    _require_cuda(prefix_lens, seq_lens, last_loc, free_pages, out_indices)
+    for n, t in (("prefix_lens", prefix_lens), ("seq_lens", seq_lens), ("last_loc", last_loc),
+                 ("free_pages", free_pages), ("out_indices", out_indices)):
+        if t.dtype != torch.int64:
+            raise TypeError(f"{n} must be int64")
+    st = _L.load().rx_alloc_extend(_ptr(prefix_lens), _ptr(seq_lens), _ptr(last_loc),
+                                   _ptr(free_pages), _ptr(out_indices), prefix_lens.shape[0],
+                                   page_size, _stream(seq_lens))
+    _L.check(st, "rx_alloc_extend")
+
+
+def alloc_decode(seq_lens, last_loc, free_pages, out_indices, page_size: int):
+    _require_cuda(seq_lens, last_loc, free_pages, out_indices)
+    for n, t in (("seq_lens", seq_lens), ("last_loc", last_loc), ("free_pages", free_pages),
+                 ("out_indices", out_indices)):
+        if t.dtype != torch.int64:
+            raise TypeError(f"{n} must be int64")
+    st = _L.load().rx_alloc_decode(_ptr(seq_lens), _ptr(last_loc), _ptr(free_pages),
+                                   _ptr(out_indices), seq_lens.shape[0], page_size,
+                                   _stream(seq_lens))
+    _L.check(st, "rx_alloc_decode")
+
+
+# --------------------------------------------------------------------------------------
+# K11 write_req_to_token_pool    called srt/mem_cache/allocation.py:75-84
+# --------------------------------------------------------------------------------------
+def write_req_to_token(req_to_token, req_pool_indices, prefix_ptrs, pre_lens, seq_lens,
+                       extend_lens, out_cache_loc):
+    _require_cuda(req_to_token, req_pool_indices, pre_lens, seq_lens, extend_lens, out_cache_loc)
+    st = _L.load().rx_write_req_to_token(
+        _ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _ptr(prefix_ptrs),
+        _ptr(pre_lens), _ptr(seq_lens), _ptr(extend_lens), _ptr(out_cache_loc),
+        req_pool_indices.shape[0], _stream(req_to_token))
+    _L.check(st, "rx_write_req_to_token")
+
+
+# --------------------------------------------------------------------------------------
+# K10 move_kv_cache              kernels/ops/kvcache/cache_move.py:60-133
+# --------------------------------------------------------------------------------------
+def move_kv(data_ptrs: torch.Tensor, row_bytes: torch.Tensor, tgt_loc: torch.Tensor,
+            src_loc: torch.Tensor):
+    _require_cuda(data_ptrs, row_bytes, tgt_loc, src_loc)
+    if data_ptrs.dtype not in (torch.uint64, torch.int64) or row_bytes.dtype != torch.int64:
+        raise TypeError("data_ptrs must be (u)int64 and row_bytes int64")
+    if tgt_loc.dtype != torch.int64 or src_loc.dtype != torch.int64:
+        raise TypeError("tgt_loc / src_loc must be int64")
+    st = _L.load().rx_move_kv(_ptr(data_ptrs), _ptr(row_bytes), data_ptrs.shape[0], _ptr(tgt_loc),
+                              _ptr(src_loc), tgt_loc.shape[0], _stream(tgt_loc))
+    _L.check(st, "rx_move_kv")
