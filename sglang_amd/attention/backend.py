@@ -1,0 +1,276 @@
+"""HipRadixAttnBackend: the drop-in AttentionBackend for the RadixAttention path on MI355X.
+
+Mirrors the method set the reference's runners call on a backend
+(srt/layers/attention/base_attn_backend.py:21-281) and the behaviour of its closest
+analogue TritonAttnBackend (srt/layers/attention/triton_backend.py:116-1864):
+
+  __init__(model_runner)                     triton_backend.py:121-302
+  init_forward_metadata(fb)                  :714-960   (once per eager forward)
+  forward(q, k, v, layer, fb, save_kv_cache) base_attn_backend.py:188-231
+  forward_decode / forward_extend            :1714-1864 / :1250-1437
+  init_cuda_graph_state, init_forward_metadata_out_graph / _in_graph,
+  get_cuda_graph_seq_len_fill_value          :962-1206
+
+Every kernel is a call into libradix_hip.so (sglang_amd.ops); there is no torch or CPU fallback.
+
+Two decode index modes:
+  * "paged"   (default, MI355X-native): the decode kernel walks req_to_token itself, so a
+    decode forward builds NO kv_indices (the reference rewrites 8 MiB of int64 per step at
+    bs=256/ctx=4k) and, when the host-side split schedule says one pass suffices, no fp32
+    partials either.
+  * "indices" (reference contract): kv_indptr / kv_indices / num_kv_splits / attn_logits /
+    attn_lse exactly as TritonAttnBackend.ForwardMetadata (:91-113) lays them out.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..forward_batch import ForwardBatch
+from ..mem_cache.memory_pool import KVWriteLoc
+
+
+@dataclass
+class ForwardMetadata:
+    """Subset of triton_backend.py:91-113 that the dense path uses."""
+
+    attn_logits: Optional[torch.Tensor]
+    attn_lse: Optional[torch.Tensor]
+    max_extend_len: Optional[int]
+    num_kv_splits: Optional[torch.Tensor]
+    kv_indptr: Optional[torch.Tensor]
+    kv_indices: Optional[torch.Tensor]
+    qo_indptr: Optional[torch.Tensor]
+    max_kv_splits: int = 1
+
+
+def host_num_kv_splits(seq_lens: np.ndarray, num_head: int, num_kv_head: int, max_kv_splits: int,
+                       device_core_count: int) -> np.ndarray:
+    """Host restatement of get_num_kv_splits_triton (kernels/ops/attention/metadata.py:11-60)
+    used only to pick the launch shape (single pass vs split-KV) without a device sync; the
+    values the kernels consume come from rx_num_kv_splits."""
+    seq_lens = np.asarray(seq_lens, dtype=np.int64)
+    num_seq = len(seq_lens)
+    mx, mn = int(seq_lens.max()), int(seq_lens.min())
+    if mx * 8 < mn * 10:
+        mn = mx
+    mn = max(mn, 1)
+    s1 = min(-(-mx // mn), max_kv_splits)
+    c1 = -(-mx // s1)
+    ext = np.float32(mx) / np.float32(64.0)
+    cores = int(np.float32(device_core_count) * np.maximum(np.log2(ext, dtype=np.float32), np.float32(1.0)))
+    group = num_head // num_kv_head
+    if group == 1:
+        token_grid = num_seq * num_head
+    else:
+        token_grid = num_seq * (-(-num_head // min(16, group)))
+    s2 = max(1, min(-(-cores // token_grid), max_kv_splits))
+    c2 = -(-mx // s2)
+    return np.maximum(-(-seq_lens // c1), -(-seq_lens // c2)).astype(np.int32)
+
+
+class HipRadixAttnBackend:
+    needs_cpu_seq_lens: bool = True
+    supports_ragged_verify_graph: bool = False
+
+    def __init__(self, model_runner, decode_index_mode: str = "paged",
+                 max_kv_splits: Optional[int] = None):
+        self.device = model_runner.device
+        self.req_to_token_pool = model_runner.req_to_token_pool
+        self.token_to_kv_pool = model_runner.token_to_kv_pool
+        self.token_to_kv_pool_allocator = getattr(model_runner, "token_to_kv_pool_allocator", None)
+        self.req_to_token = self.req_to_token_pool.req_to_token
+        self.page_size = getattr(model_runner, "page_size", 1) or 1
+        mc = model_runner.model_config
+        tp = getattr(model_runner, "tp_size", 1)
+        self.num_head = mc.num_attention_heads // tp
+        self.num_kv_head = max(1, mc.num_key_value_heads // tp)
+        self.v_head_dim = self.token_to_kv_pool.get_value_buffer(
+            getattr(self.token_to_kv_pool, "start_layer", 0)).shape[-1]
+        self.max_context_len = mc.context_len
+        sa = getattr(model_runner, "server_args", None)
+        self.max_kv_splits = max_kv_splits or getattr(sa, "triton_attention_num_kv_splits", 8)
+        self.device_core_count = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if decode_index_mode not in ("paged", "indices"):
+            raise ValueError(f"decode_index_mode must be 'paged' or 'indices', got {decode_index_mode}")
+        self.decode_index_mode = decode_index_mode
+        max_bs = self.req_to_token_pool.size
+        self.kv_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
+        self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int64, device=self.device)
+        self.forward_metadata: Optional[ForwardMetadata] = None
+        self._scratch_logits = None
+        self._scratch_lse = None
+        self._graph = None  # static buffers of init_cuda_graph_state
+
+    # ------------------------------------------------------------------ scratch
+    def _scratch(self, bs: int):
+        need = (bs, self.num_head, self.max_kv_splits, self.v_head_dim)
+        if self._scratch_logits is None or self._scratch_logits.shape[0] < bs:
+            self._scratch_logits = torch.empty(need, dtype=torch.float32, device=self.device)
+            self._scratch_lse = torch.empty(need[:3], dtype=torch.float32, device=self.device)
+        return self._scratch_logits[:bs], self._scratch_lse[:bs]
+
+    # ------------------------------------------------------------------ metadata
+    def init_forward_metadata(self, forward_batch: ForwardBatch):
+        self.init_forward_metadata_out_graph(forward_batch)
+        self.init_forward_metadata_in_graph(forward_batch)
+
+    def init_forward_metadata_in_graph(self, forward_batch: ForwardBatch):
+        """Graph-recordable part: nothing -- the kernels read seq_lens / req_to_token directly."""
+
+    def init_forward_metadata_out_graph(self, forward_batch: ForwardBatch, in_capture: bool = False):
+        bs = forward_batch.batch_size
+        mode = forward_batch.forward_mode
+        if mode.is_idle():
+            self.forward_metadata = ForwardMetadata(None, None, None, None, None, None, None)
+            return
+        if mode.is_decode():
+            self.forward_metadata = self._decode_metadata(forward_batch, bs, in_capture)
+        else:
+            self.forward_metadata = self._extend_metadata(forward_batch, bs)
+
+    def _decode_metadata(self, fb: ForwardBatch, bs: int, in_capture: bool) -> ForwardMetadata:
+        use_graph_bufs = self._graph is not None and (in_capture or self._graph.get("active"))
+        splits_needed = True
+        if not use_graph_bufs and fb.seq_lens_cpu is not None and self.max_kv_splits > 1:
+            host = host_num_kv_splits(np.asarray(fb.seq_lens_cpu), self.num_head, self.num_kv_head,
+                                      self.max_kv_splits, self.device_core_count)
+            splits_needed = bool(host.max() > 1)
+        elif self.max_kv_splits <= 1:
+            splits_needed = False
+        kv_indptr = kv_indices = None
+        if self.decode_index_mode == "indices":
+            if use_graph_bufs:
+                kv_indices = self._graph["kv_indices"]
+            else:
+                total = fb.seq_lens_sum if fb.seq_lens_sum is not None else bs * self.max_context_len
+                kv_indices = torch.empty(total, dtype=torch.int64, device=self.device)
+            kv_indptr = ops.build_kv_indices(self.req_to_token, fb.req_pool_indices, fb.seq_lens,
+                                             self.kv_indptr, kv_indices)
+        if not splits_needed:
+            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1)
+        if use_graph_bufs:
+            num_kv_splits = self._graph["num_kv_splits"][:bs]
+            attn_logits, attn_lse = self._graph["attn_logits"][:bs], self._graph["attn_lse"][:bs]
+        else:
+            num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+            attn_logits, attn_lse = self._scratch(bs)
+        ops.get_num_kv_splits(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head,
+                              self.max_kv_splits, self.device_core_count)
+        return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices,
+                               None, self.max_kv_splits)
+
+    def _extend_metadata(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
+        # prefix-only kv indices + qo_indptr (triton_backend.py:869-924)
+        if fb.extend_prefix_lens_cpu is not None:
+            total = int(sum(fb.extend_prefix_lens_cpu))
+        else:
+            total = bs * self.max_context_len
+        kv_indices = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+        kv_indptr = ops.build_kv_indices(self.req_to_token, fb.req_pool_indices,
+                                         fb.extend_prefix_lens, self.kv_indptr, kv_indices)
+        qo_indptr = self.qo_indptr[: bs + 1]
+        qo_indptr[1:] = torch.cumsum(fb.extend_seq_lens, dim=0)
+        if fb.extend_seq_lens_cpu is not None:
+            max_extend_len = max(fb.extend_seq_lens_cpu)
+        else:
+            max_extend_len = int(fb.extend_seq_lens.max())
+        return ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr)
+
+    # ------------------------------------------------------------------ graph support
+    def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int):
+        """Address-stable buffers (triton_backend.py:962-1063)."""
+        self._graph = {
+            "active": False,
+            "num_kv_splits": torch.full((max_bs,), 1, dtype=torch.int32, device=self.device),
+            "attn_logits": torch.zeros((max_bs, self.num_head, self.max_kv_splits, self.v_head_dim),
+                                       dtype=torch.float32, device=self.device),
+            "attn_lse": torch.zeros((max_bs, self.num_head, self.max_kv_splits),
+                                    dtype=torch.float32, device=self.device),
+            "kv_indices": torch.zeros((max_bs * self.max_context_len,), dtype=torch.int64,
+                                      device=self.device) if self.decode_index_mode == "indices" else None,
+        }
+
+    def get_cuda_graph_seq_len_fill_value(self):
+        return 1  # triton_backend.py:1205-1206
+
+    def on_after_cuda_graph_warmup(self):
+        pass
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache: bool = True, **kwargs):
+        mode = forward_batch.forward_mode
+        if mode.is_idle():
+            return q.new_empty(q.shape[0], layer.tp_q_head_num * layer.v_head_dim)
+        if mode.is_decode():
+            return self.forward_decode(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache, **kwargs)
+        return self.forward_extend(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache, **kwargs)
+
+    @staticmethod
+    def _scales(layer):
+        if layer.k_scale is not None and layer.v_scale is not None:
+            return layer.k_scale_float, layer.v_scale_float
+        return 1.0, 1.0
+
+    def forward_decode(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, sinks=None):
+        q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
+        if layer.qk_head_dim != layer.v_head_dim:
+            o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
+        else:
+            o = torch.empty_like(q)
+        if save_kv_cache and k is not None:
+            self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(forward_batch.out_cache_loc), k, v,
+                                                layer.k_scale, layer.v_scale)
+        md = self.forward_metadata
+        k_descale, v_descale = self._scales(layer)
+        k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+        q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+        o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
+        lay = ops.kv_layout_hnd(k_buf, v_buf) if getattr(self.token_to_kv_pool, "use_hnd", False) else None
+        if self.decode_index_mode == "indices":
+            ops.decode_attention_fwd(q3, k_buf, v_buf, o3, md.kv_indptr, md.kv_indices, md.attn_logits,
+                                     md.attn_lse, md.num_kv_splits, md.max_kv_splits, layer.scaling,
+                                     k_descale, v_descale, logit_cap=layer.logit_cap, sinks=sinks,
+                                     page_size=self.page_size, kv_layout=lay)
+        else:
+            ops.decode_attention_fwd_paged(q3, k_buf, v_buf, o3, self.req_to_token,
+                                           forward_batch.req_pool_indices, forward_batch.seq_lens,
+                                           md.attn_logits, md.attn_lse, md.num_kv_splits,
+                                           md.max_kv_splits, layer.scaling, k_descale, v_descale,
+                                           logit_cap=layer.logit_cap, sinks=sinks,
+                                           page_size=self.page_size, kv_layout=lay)
+        return o
+
+    def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, sinks=None):
+        if layer.qk_head_dim != layer.v_head_dim:
+            o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
+        else:
+            o = torch.empty_like(q)
+        if k is None or v is None:
+            raise ValueError("forward_extend needs the new tokens' k and v")
+        if save_kv_cache:
+            self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(forward_batch.out_cache_loc), k, v,
+                                                layer.k_scale, layer.v_scale)
+        md = self.forward_metadata
+        k_descale, v_descale = self._scales(layer)
+        causal = not (layer.is_cross_attention or layer.attn_type.value == "encoder_only")
+        k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+        lay = ops.kv_layout_hnd(k_buf, v_buf) if getattr(self.token_to_kv_pool, "use_hnd", False) else None
+        window = layer.sliding_window_size if (layer.sliding_window_size is not None
+                                               and layer.sliding_window_size > -1) else -1
+        ops.extend_attention_fwd(
+            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+            k.view(-1, layer.tp_k_head_num, layer.qk_head_dim),
+            v.view(-1, layer.tp_v_head_num, layer.v_head_dim),
+            o.view(-1, layer.tp_q_head_num, layer.v_head_dim), k_buf, v_buf, md.qo_indptr,
+            md.kv_indptr, md.kv_indices, None, causal, None, md.max_extend_len, k_descale, v_descale,
+            sm_scale=layer.scaling, logit_cap=layer.logit_cap, sliding_window_size=window, sinks=sinks,
+            page_size=self.page_size, kv_layout=lay)
+        return o
+
+    def support_triton(self):
+        return False

@@ -139,11 +139,12 @@ __global__ __launch_bounds__(1024) void num_kv_splits_kernel(
   const int32_t max_seq_len = mx;
   int32_t min_seq_len = mn;
   if (max_seq_len * 8 < min_seq_len * 10) min_seq_len = max_seq_len;
+  if (min_seq_len < 1) min_seq_len = 1;  // empty request: the reference divides by zero here
   const int32_t max_kv_splits_1 = min(cdiv32(max_seq_len, min_seq_len), max_kv_splits);
   const int32_t kv_chunk_size_1 = cdiv32(max_seq_len, max_kv_splits_1);
   const float ext_seq_len = static_cast<float>(max_seq_len) / 64.0f;
   const int32_t ext_cores = static_cast<int32_t>(
-      static_cast<float>(device_core_count) * fmaxf(__log2f(ext_seq_len), 1.0f));
+      static_cast<float>(device_core_count) * fmaxf(log2f(ext_seq_len), 1.0f));
   int32_t block_h = 16;
   const int32_t num_kv_group = num_head / num_kv_head;
   int32_t token_grid;
@@ -329,7 +330,7 @@ int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,
   RX_REQUIRE(kv_indptr_out, "rx_build_kv_indices: kv_indptr_out is null");
   auto s = static_cast<hipStream_t>(stream);
   if (bs == 0) {
-    hipMemsetAsync(kv_indptr_out, 0, sizeof(int32_t), s);
+    (void)hipMemsetAsync(kv_indptr_out, 0, sizeof(int32_t), s);
     return check_launch("rx_build_kv_indices(memset)");
   }
   RX_REQUIRE(req_to_token && req_pool_indices && lens, "rx_build_kv_indices: null pointer");

@@ -1,0 +1,84 @@
+"""Input record of the path: the fields of the reference's ForwardBatch that the attention
+backend and the KV pools read (srt/model_executor/forward_batch_info.py:412-638) and the
+ForwardMode predicates it dispatches on (:98-196).  Same names, same meaning."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from enum import IntEnum, auto
+from typing import List, Optional
+
+import torch
+
+
+class ForwardMode(IntEnum):
+    EXTEND = auto()
+    DECODE = auto()
+    MIXED = auto()
+    IDLE = auto()
+
+    def is_prefill(self):
+        return self.is_extend()
+
+    def is_extend(self):
+        return self in (ForwardMode.EXTEND, ForwardMode.MIXED)
+
+    def is_decode(self):
+        return self == ForwardMode.DECODE
+
+    def is_mixed(self):
+        return self == ForwardMode.MIXED
+
+    def is_idle(self):
+        return self == ForwardMode.IDLE
+
+    def is_decode_or_idle(self):
+        return self in (ForwardMode.DECODE, ForwardMode.IDLE)
+
+
+@dataclass
+class ForwardBatch:
+    forward_mode: ForwardMode
+    batch_size: int
+    req_pool_indices: torch.Tensor  # int32/int64 [bs]
+    seq_lens: torch.Tensor  # int32/int64 [bs]
+    out_cache_loc: Optional[torch.Tensor]  # int64 [num_tokens]
+    seq_lens_sum: Optional[int] = None
+    seq_lens_cpu: Optional[torch.Tensor] = None
+    positions: Optional[torch.Tensor] = None
+    # extend-only
+    extend_num_tokens: Optional[int] = None
+    extend_seq_lens: Optional[torch.Tensor] = None  # int32 [bs]
+    extend_prefix_lens: Optional[torch.Tensor] = None  # int32 [bs]
+    extend_start_loc: Optional[torch.Tensor] = None
+    extend_seq_lens_cpu: Optional[List[int]] = None
+    extend_prefix_lens_cpu: Optional[List[int]] = None
+    encoder_lens: Optional[torch.Tensor] = None
+    spec_info: object = None
+
+    @classmethod
+    def for_decode(cls, req_pool_indices, seq_lens, out_cache_loc, seq_lens_cpu=None):
+        """ForwardBatch.init_new for a decode batch (:705-970; positions = seq_lens-1 :902-904)."""
+        if seq_lens_cpu is None:
+            seq_lens_cpu = seq_lens.cpu()
+        return cls(forward_mode=ForwardMode.DECODE, batch_size=len(seq_lens),
+                   req_pool_indices=req_pool_indices, seq_lens=seq_lens,
+                   out_cache_loc=out_cache_loc, seq_lens_sum=int(seq_lens_cpu.sum()),
+                   seq_lens_cpu=seq_lens_cpu, positions=torch.clamp(seq_lens - 1, min=0).to(torch.int64))
+
+    @classmethod
+    def for_extend(cls, req_pool_indices, seq_lens, out_cache_loc, extend_prefix_lens_cpu,
+                   extend_seq_lens_cpu):
+        """ForwardBatch.init_new for an extend batch (:905-931)."""
+        dev = seq_lens.device
+        pre = torch.tensor(extend_prefix_lens_cpu, dtype=torch.int32, device=dev)
+        ext = torch.tensor(extend_seq_lens_cpu, dtype=torch.int32, device=dev)
+        start = torch.zeros_like(ext)
+        start[1:] = torch.cumsum(ext[:-1], dim=0)
+        seq_cpu = seq_lens.cpu()
+        return cls(forward_mode=ForwardMode.EXTEND, batch_size=len(seq_lens),
+                   req_pool_indices=req_pool_indices, seq_lens=seq_lens,
+                   out_cache_loc=out_cache_loc, seq_lens_sum=int(seq_cpu.sum()),
+                   seq_lens_cpu=seq_cpu, extend_num_tokens=int(sum(extend_seq_lens_cpu)),
+                   extend_seq_lens=ext, extend_prefix_lens=pre, extend_start_loc=start,
+                   extend_seq_lens_cpu=list(extend_seq_lens_cpu),
+                   extend_prefix_lens_cpu=list(extend_prefix_lens_cpu))

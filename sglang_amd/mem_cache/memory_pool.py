@@ -1,0 +1,183 @@
+"""Request->token table and the physical KV pool, with the contract of the reference's
+ReqToTokenPool (srt/mem_cache/memory_pool.py:256-326) and MHATokenToKVPool (:1740-2842):
+per layer ``k_buffer[l]``, ``v_buffer[l]`` of shape [size + page_size, Hkv, D] (NHD, :2030-2041)
+or [pages, Hkv, page, D] (HND, :2032-2036); slot 0 / page 0 is the padding sink.
+
+HBM layout for MI355X: one allocation per (layer, K|V) so a layer's K rows are a contiguous
+2 KiB * slots span (Llama-3-8B TP1); 288 GB holds 32 layers x (256 x 4096 + 16) slots = 128 GiB
+resident at the metric shape.  Writes go through rx_store_kv, moves through rx_move_kv.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from .. import ops
+
+
+@dataclass
+class KVWriteLoc:
+    """memory_pool.py:1531-1564; only ``loc`` is meaningful for the plain MHA pool."""
+
+    loc: torch.Tensor
+    swa_loc: Optional[torch.Tensor] = None
+    full_loc: Optional[torch.Tensor] = None
+
+
+def unwrap_write_loc(loc_info):
+    if isinstance(loc_info, KVWriteLoc):
+        return loc_info.loc, loc_info.swa_loc, loc_info.full_loc
+    return loc_info, None, None
+
+
+class ReqToTokenPool:
+    """req_to_token int32[size + 1, max_context_len]; row 0 is the padding row that
+    graph-padded batches read (memory_pool.py:273-281)."""
+
+    def __init__(self, size: int, max_context_len: int, device: str):
+        self.size = size
+        self._alloc_size = size + 1
+        self.max_context_len = max_context_len
+        self.device = device
+        self.req_to_token = torch.zeros((self._alloc_size, max_context_len), dtype=torch.int32,
+                                        device=device)
+        self.free_slots = list(range(1, self._alloc_size))
+
+    def write(self, indices, values):
+        self.req_to_token[indices] = values
+
+    def available_size(self):
+        return len(self.free_slots)
+
+    def alloc(self, need_size: int = 1) -> Optional[List[int]]:
+        """Hands out ``need_size`` row ids FIFO (the reference takes Req objects and stamps
+        req.req_pool_idx; the id order is the same, memory_pool.py:306-314)."""
+        if need_size > len(self.free_slots):
+            return None
+        select_index = self.free_slots[:need_size]
+        self.free_slots = self.free_slots[need_size:]
+        return select_index
+
+    def free(self, free_index):
+        if isinstance(free_index, int):
+            self.free_slots.append(free_index)
+        else:
+            self.free_slots.extend(free_index)
+
+    def clear(self):
+        self.free_slots = list(range(1, self._alloc_size))
+
+
+class MHATokenToKVPool:
+    """Physical K/V storage for multi-head / grouped-query attention."""
+
+    def __init__(self, size: int, page_size: int, dtype: torch.dtype, head_num: int, head_dim: int,
+                 layer_num: int, device: str, v_head_dim: Optional[int] = None,
+                 start_layer: int = 0, use_hnd: bool = False):
+        self.size = size
+        self.page_size = page_size
+        self.dtype = dtype
+        self.store_dtype = dtype
+        self.head_num = head_num
+        self.head_dim = head_dim
+        self.v_head_dim = head_dim if v_head_dim is None else v_head_dim
+        self.layer_num = layer_num
+        self.device = device
+        self.start_layer = start_layer
+        self.use_hnd = use_hnd
+        self.row_dim = head_num * head_dim
+        self.v_row_dim = head_num * self.v_head_dim
+        self.num_pages = (size + page_size) // page_size
+        self.err_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self._create_buffers()
+        self._build_ptr_tables()
+
+    def _kv_buffer_shapes(self):
+        if self.use_hnd:
+            return ((self.num_pages, self.head_num, self.page_size, self.head_dim),
+                    (self.num_pages, self.head_num, self.page_size, self.v_head_dim))
+        rows = self.size + self.page_size
+        return ((rows, self.head_num, self.head_dim), (rows, self.head_num, self.v_head_dim))
+
+    def _create_buffers(self):
+        k_shape, v_shape = self._kv_buffer_shapes()
+        self.k_buffer = [torch.zeros(k_shape, dtype=self.store_dtype, device=self.device)
+                         for _ in range(self.layer_num)]
+        self.v_buffer = [torch.zeros(v_shape, dtype=self.store_dtype, device=self.device)
+                         for _ in range(self.layer_num)]
+
+    def _build_ptr_tables(self):
+        """data_ptrs / data_strides tables of memory_pool.py:2005-2028 (k0..kL-1, v0..vL-1)."""
+        bufs = self.k_buffer + self.v_buffer
+        self.data_ptrs = torch.tensor([b.data_ptr() for b in bufs], dtype=torch.int64,
+                                      device=self.device)
+        self.data_strides = torch.tensor(
+            [b.stride(0) * b.element_size() for b in bufs], dtype=torch.int64, device=self.device)
+
+    def get_kv_size_bytes(self):
+        k = sum(b.numel() * b.element_size() for b in self.k_buffer)
+        v = sum(b.numel() * b.element_size() for b in self.v_buffer)
+        return k, v
+
+    def get_key_buffer(self, layer_id: int):
+        return self.k_buffer[layer_id - self.start_layer]
+
+    def get_value_buffer(self, layer_id: int):
+        return self.v_buffer[layer_id - self.start_layer]
+
+    def get_kv_buffer(self, layer_id: int):
+        return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
+
+    def get_v_head_dim(self):
+        return self.v_head_dim
+
+    def get_contiguous_buf_infos(self):
+        bufs = self.k_buffer + self.v_buffer
+        return ([b.data_ptr() for b in bufs], [b.nbytes for b in bufs],
+                [b[0].nbytes * (1 if not self.use_hnd else 1) for b in bufs])
+
+    def set_kv_buffer(self, layer, loc_info, cache_k: torch.Tensor, cache_v: torch.Tensor,
+                      k_scale: Optional[float] = None, v_scale: Optional[float] = None,
+                      layer_id_override: Optional[int] = None):
+        """memory_pool.py:2305-2381 -> _store_kv_layer (:2383-2430) -> rx_store_kv."""
+        loc, _, _ = unwrap_write_loc(loc_info)
+        layer_id = layer_id_override if layer_id_override is not None else layer.layer_id
+        if cache_k.dtype != self.dtype:
+            if k_scale is not None:
+                cache_k.div_(k_scale)
+            if v_scale is not None:
+                cache_v.div_(v_scale)
+            cache_k = cache_k.to(self.dtype)
+            cache_v = cache_v.to(self.dtype)
+        li = layer_id - self.start_layer
+        if self.use_hnd:
+            # a slot is [page, :, off, :]: scatter by (page, off) (memory_pool.py:2372-2379)
+            pages = loc // self.page_size
+            offs = loc % self.page_size
+            self.k_buffer[li][pages, :, offs, :] = cache_k
+            self.v_buffer[li][pages, :, offs, :] = cache_v
+            return
+        n = loc.shape[0]
+        ops.store_cache(cache_k.reshape(n, self.row_dim) if cache_k.dim() == 3 else cache_k,
+                        cache_v.reshape(n, self.v_row_dim) if cache_v.dim() == 3 else cache_v,
+                        self.k_buffer[li].view(-1, self.row_dim),
+                        self.v_buffer[li].view(-1, self.v_row_dim), loc,
+                        size_limit=self.size + self.page_size, err_flag=self.err_flag)
+
+    def move_kv_cache(self, tgt_loc: torch.Tensor, src_loc: torch.Tensor):
+        """memory_pool.py:2775-2842: every layer's K and V rows src -> tgt in one launch."""
+        if tgt_loc.numel() == 0:
+            return
+        if self.use_hnd:
+            raise NotImplementedError("move_kv_cache on the HND layout")
+        ops.move_kv(self.data_ptrs, self.data_strides, tgt_loc.to(torch.int64),
+                    src_loc.to(torch.int64))
+
+    def check_errors(self) -> int:
+        """Host poll of the device error word (replaces the reference's device assert)."""
+        v = int(self.err_flag.item())
+        if v:
+            self.err_flag.zero_()
+        return v

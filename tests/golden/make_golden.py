@@ -14,6 +14,7 @@ Fixture families:
   F4 store (torch index_put fallback of memory_pool.py:189-192) -> store_kv.npz
   F5 decode attention (Triton decode_attention_fwd) -> decode_*.npz
   F6 extend attention (Triton extend_attention_fwd) -> extend_*.npz
+  F8 bf16 decode/extend from the compiled reference C++ CPU kernels -> cpu_native.npz
 """
 import json
 import os
@@ -374,7 +375,77 @@ def f6():
     save("extend.npz", **flat)
 
 
+# ------------------------------------------------------------------ F8
+def f8():
+    """bf16 goldens from the reference's compiled native CPU kernels (oracle/_ref, built by
+    oracle/build_ref.py from aot/csrc/cpu/{decode,extend}.cpp): decode_attention_cpu walks
+    req_to_token and writes the new K/V at loc in-kernel (decode.cpp:940)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import build_ref
+
+    m = build_ref.load() or __import__("importlib").import_module("oracle.build_ref").load()
+    if m is None:
+        build_ref.build()
+        m = build_ref.load()
+    torch.manual_seed(42)
+    dt = torch.bfloat16
+    out = {}
+    for ci, (HQ, HKV, D, lens) in enumerate([(32, 8, 128, [100, 33, 257, 1]), (12, 12, 64, [7, 64, 65]),
+                                             (16, 2, 128, [300, 31])]):
+        lens = torch.tensor(lens, dtype=torch.int64)
+        B = len(lens)
+        pool = int(lens.sum()) + 11
+        kb = torch.randn(pool, HKV, D).to(dt); vb = torch.randn(pool, HKV, D).to(dt)
+        q = torch.randn(B, HQ, D).to(dt)
+        r2t = torch.zeros(B + 1, int(lens.max()) + 3, dtype=torch.int32)
+        perm = torch.randperm(pool - 1) + 1
+        o = 0
+        for i, n in enumerate(lens.tolist()):
+            r2t[i + 1, :n] = perm[o:o + n].int(); o += n
+        rpi = torch.arange(1, B + 1, dtype=torch.int64)
+        newk = torch.randn(B, HKV, D).to(dt); newv = torch.randn(B, HKV, D).to(dt)
+        loc = torch.tensor([r2t[i + 1, lens[i] - 1].item() for i in range(B)], dtype=torch.int64)
+        res = torch.zeros(B, HQ, D, dtype=dt)
+        attn_logits = torch.zeros(B, HQ, 8, D + 1)
+        kb_in, vb_in = kb.clone(), vb.clone()
+        m.decode_attention_cpu(q, kb, vb, res, newk, newv, loc, attn_logits, r2t, rpi, lens,
+                               D ** -0.5, 0.0, False, 0, None, None)
+        t = f"dec{ci}."
+        out.update({t + "q": bits(q), t + "kb_in": bits(kb_in), t + "vb_in": bits(vb_in),
+                    t + "kb_out": bits(kb), t + "vb_out": bits(vb), t + "new_k": bits(newk),
+                    t + "new_v": bits(newv), t + "loc": loc.numpy(), t + "req_to_token": r2t.numpy(),
+                    t + "req_pool_indices": rpi.numpy(), t + "seq_lens": lens.numpy(),
+                    t + "sm_scale": np.asarray(D ** -0.5), t + "o": bits(res)})
+    for ci, (HQ, HKV, D, pre, ext) in enumerate([(12, 4, 128, [16, 33, 0], [5, 20, 9]),
+                                                 (32, 8, 128, [64, 5], [3, 40])]):
+        pre = torch.tensor(pre, dtype=torch.int64); ext = torch.tensor(ext, dtype=torch.int64)
+        seq = pre + ext
+        B, T = len(pre), int(ext.sum())
+        pool = int(seq.sum()) + 7
+        kb = torch.randn(pool, HKV, D).to(dt); vb = torch.randn(pool, HKV, D).to(dt)
+        q = torch.randn(T, HQ, D).to(dt)
+        r2t = torch.zeros(B + 1, int(seq.max()) + 2, dtype=torch.int32)
+        perm = torch.randperm(pool - 1) + 1
+        o = 0
+        for i, n in enumerate(seq.tolist()):
+            r2t[i + 1, :n] = perm[o:o + n].int(); o += n
+        rpi = torch.arange(1, B + 1, dtype=torch.int64)
+        start = torch.zeros(B, dtype=torch.int64); start[1:] = torch.cumsum(ext[:-1], 0)
+        k_ext = torch.cat([kb[r2t[i + 1, pre[i]:seq[i]].long()] for i in range(B)])
+        v_ext = torch.cat([vb[r2t[i + 1, pre[i]:seq[i]].long()] for i in range(B)])
+        res = torch.zeros(T, HQ, D, dtype=dt)
+        m.extend_attention_cpu(q, k_ext, v_ext, res, kb, vb, r2t, rpi, seq, ext.int(), start.int(), int(ext.max()),
+                               D ** -0.5, 0.0, False, 0, None, None, None)
+        t = f"ext{ci}."
+        out.update({t + "q": bits(q), t + "k_ext": bits(k_ext), t + "v_ext": bits(v_ext), t + "kb": bits(kb),
+                    t + "vb": bits(vb), t + "req_to_token": r2t.numpy(), t + "req_pool_indices": rpi.numpy(),
+                    t + "seq_lens": seq.numpy(), t + "extend_seq_lens": ext.numpy(),
+                    t + "extend_prefix_lens": pre.numpy(), t + "sm_scale": np.asarray(D ** -0.5),
+                    t + "o": bits(res)})
+    save("cpu_native.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f8"]
     for w in which:
         globals()[w]()
