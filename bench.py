@@ -1,0 +1,406 @@
+#!/usr/bin/env python3
+"""RadixAttention hot-path bench on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one decode step of the attention path of Llama-3-8B (bf16, 32 layers, Hq=32, Hkv=8,
+D=128) at bs=256 / ctx=4096 / page_size=16 with shuffled pages: per layer
+  KV store of the new token (rx_store_kv) -> paged split-KV decode attention (rx_decode_attn)
+  -> o_proj row-parallel GEMM (library GEMM) -> [N>1: RCCL all-reduce on a side stream,
+  overlapped with the next layer's attention].
+With N GPUs the path is tensor-parallel (Hq/N, max(1,Hkv/N) heads per rank; same page table on
+every rank), total work fixed => "scaling": "strong".  value = bs / step time (decode tokens/s).
+
+Also reported on the same JSON line:
+  roofline      -- decode attention kernel: algorithmic KV+Q+O bytes per launch / average launch
+                   duration measured with HIP events inside the timed region, vs 8 TB/s.
+  cpu_baseline  -- (N=1, rank 0) the same decode on the host cores: the reference's own compiled
+                   C++ CPU kernel (oracle/_ref, kind "reference") when it loads and runs here, else
+                   the C restatement (oracle/rx_oracle.c, kind "port"); one layer, bounded sample.
+  extend        -- config-3 extend (256 requests sharing a 3584-token radix prefix + 512 new
+                   tokens each, chunks of 32 requests): achieved TFLOP/s of rx_extend_attn.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s float4-copy measured)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bs", type=int, default=256)
+    ap.add_argument("--ctx", type=int, default=4096)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--page-size", type=int, default=16)
+    ap.add_argument("--index-mode", default="paged", choices=["paged", "indices"])
+    ap.add_argument("--max-kv-splits", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extend", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-worker", default=None, choices=["reference", "port"])
+    return ap.parse_args()
+
+
+class _Cfg:
+    pass
+
+
+def build_world(args):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return rank, world, local_rank
+
+
+def make_decode_state(args, tp, dev):
+    """Pools, page table and per-layer synthetic q/k/v for one rank."""
+    from sglang_amd.attention.backend import HipRadixAttnBackend
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
+
+    HQ, HKV, D, HID = 32, 8, 128, 4096
+    hq, hkv = HQ // tp, max(1, HKV // tp)
+    bs, ctx, ps, L = args.bs, args.ctx, args.page_size, args.layers
+    pages_per_req = (ctx + ps - 1) // ps
+    size = bs * pages_per_req * ps
+    free_b, total_b = torch.cuda.mem_get_info()
+    per_layer = 2 * (size + ps) * hkv * D * 2
+    distinct = L
+    while distinct > 1 and distinct * per_layer > free_b - (12 << 30):
+        distinct //= 2
+    pool = MHATokenToKVPool(size, ps, torch.bfloat16, hkv, D, distinct, dev)
+    g = torch.Generator(device=dev).manual_seed(42)
+    for l in range(distinct):
+        pool.k_buffer[l].normal_(generator=g)
+        pool.v_buffer[l].normal_(generator=g)
+    r2t_pool = ReqToTokenPool(bs, ctx + ps, dev)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(np.arange(1, bs * pages_per_req + 1))  # shuffled pages, page 0 reserved
+    slots = (perm.reshape(bs, pages_per_req)[:, :, None] * ps + np.arange(ps)[None, None, :]).reshape(bs, -1)
+    rows = r2t_pool.alloc(bs)
+    r2t_pool.req_to_token[rows, : slots.shape[1]] = torch.from_numpy(slots.astype(np.int32)).to(dev)
+
+    class MC:
+        num_attention_heads, num_key_value_heads, context_len = HQ, HKV, ctx + ps
+
+    class MR:
+        device = dev
+        req_to_token_pool = r2t_pool
+        token_to_kv_pool = pool
+        model_config = MC
+        page_size = ps
+        tp_size = tp
+
+        class server_args:
+            triton_attention_num_kv_splits = args.max_kv_splits
+
+    backend = HipRadixAttnBackend(MR, decode_index_mode=args.index_mode)
+    layers = [RadixAttention(hq, D, D ** -0.5, hkv, l % distinct) for l in range(L)]
+    st = _Cfg()
+    st.backend, st.layers, st.pool, st.r2t = backend, layers, pool, r2t_pool
+    st.hq, st.hkv, st.D, st.hid, st.distinct = hq, hkv, D, HID, distinct
+    st.req_pool_indices = torch.tensor(rows, dtype=torch.int64, device=dev)
+    st.seq_lens = torch.full((bs,), ctx, dtype=torch.int64, device=dev)
+    st.seq_lens_cpu = torch.full((bs,), ctx, dtype=torch.int64)
+    st.out_cache_loc = r2t_pool.req_to_token[rows, ctx - 1].to(torch.int64)
+    st.q = torch.randn(bs, hq * D, device=dev, generator=g).to(torch.bfloat16)
+    st.k = torch.randn(bs, hkv * D, device=dev, generator=g).to(torch.bfloat16)
+    st.v = torch.randn(bs, hkv * D, device=dev, generator=g).to(torch.bfloat16)
+    st.w_o = (torch.randn(hq * D, HID, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    st.slots = slots
+    return st
+
+
+def decode_step(st, fb, world, comm_stream, ev_pairs=None):
+    """One decode step of the attention path over all layers."""
+    import torch.distributed as dist
+
+    be = st.backend
+    be.init_forward_metadata(fb)
+    main = torch.cuda.current_stream()
+    pending = None
+    for li, layer in enumerate(st.layers):
+        if ev_pairs is not None:
+            # time store+attention of this layer; the attention kernel dominates (>99%)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            be.token_to_kv_pool.set_kv_buffer(layer, fb.out_cache_loc, st.k, st.v)
+            e0.record()
+            o = be.forward_decode(st.q, None, None, layer, fb, save_kv_cache=False)
+            e1.record()
+            ev_pairs.append((e0, e1))
+        else:
+            o = layer(st.q, st.k, st.v, fb, be)
+        y = torch.matmul(o, st.w_o)  # row-parallel o_proj partial sum [bs, hidden]
+        if world > 1:
+            done = torch.cuda.Event()
+            done.record(main)
+            comm_stream.wait_event(done)
+            with torch.cuda.stream(comm_stream):
+                dist.all_reduce(y)
+                y.record_stream(comm_stream)
+            pending = torch.cuda.Event()
+            pending.record(comm_stream)
+    if pending is not None:
+        main.wait_event(pending)
+
+
+def time_steps(fn, steps, warmup, world):
+    import torch.distributed as dist
+
+    for _ in range(warmup):
+        fn()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def _cpu_model():
+    model, flags = "unknown", set()
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            if line.startswith("flags") and not flags:
+                flags = set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    isa = [f for f in ("avx512f", "avx512_bf16", "amx_bf16") if f in flags]
+    return f"{model}; {os.cpu_count()} logical CPUs; isa: {','.join(isa) or 'none of avx512f/avx512_bf16/amx_bf16'}"
+
+
+def cpu_worker(args):
+    """Runs in a child process that never touches the GPU: times one layer of the decode path on
+    the host cores with synthetic data of the bench's shapes and prints one JSON line."""
+    kind = args.cpu_worker
+    bs, ctx, ps = args.bs, args.ctx, args.page_size
+    HQ, HKV, D = 32, 8, 128
+    pages = bs * ((ctx + ps - 1) // ps)
+    slots_n = (pages + 1) * ps
+    ncores = os.cpu_count()
+    torch.set_num_threads(ncores)
+    g = torch.Generator().manual_seed(42)
+    kb = torch.empty(slots_n, HKV, D, dtype=torch.bfloat16).normal_(generator=g)
+    vb = torch.empty(slots_n, HKV, D, dtype=torch.bfloat16).normal_(generator=g)
+    q = torch.randn(bs, HQ, D, generator=g).to(torch.bfloat16)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(np.arange(1, pages + 1))
+    slots = (perm.reshape(bs, -1)[:, :, None] * ps + np.arange(ps)[None, None, :]).reshape(bs, -1)[:, :ctx]
+    r2t = torch.zeros(bs + 1, ctx + ps, dtype=torch.int32)
+    r2t[1:, :ctx] = torch.from_numpy(slots.astype(np.int32))
+    rpi = torch.arange(1, bs + 1, dtype=torch.int64)
+    lens = torch.full((bs,), ctx, dtype=torch.int64)
+    if kind == "reference":
+        from oracle import build_ref
+
+        m = build_ref.load()
+        if m is None:
+            raise SystemExit("oracle/_ref not built")
+        out = torch.zeros(bs, HQ, D, dtype=torch.bfloat16)
+        attn_logits = torch.zeros(bs, HQ, 8, D + 1)
+        loc = r2t[1:, ctx - 1].to(torch.int64)
+        k_new = torch.randn(bs, HKV, D, generator=g).to(torch.bfloat16)
+        v_new = torch.randn(bs, HKV, D, generator=g).to(torch.bfloat16)
+
+        def run():
+            m.decode_attention_cpu(q, kb, vb, out, k_new, v_new, loc, attn_logits, r2t, rpi, lens,
+                                   D ** -0.5, 0.0, False, 0, None, None)
+        threads = torch.get_num_threads()
+        what = "decode_attention_cpu, the reference's own aot/csrc/cpu/decode.cpp built by oracle/build_ref.py"
+    else:
+        from oracle import c_oracle
+
+        bits = lambda t: t.contiguous().view(torch.uint16).numpy()
+        kbb, vbb, qb = bits(kb), bits(vb), bits(q)
+        r2tn, rpin, lensn = r2t.numpy(), rpi.numpy(), lens.numpy()
+
+        def run():
+            c_oracle.decode_bf16(qb, kbb, vbb, r2tn, rpin, lensn, D ** -0.5)
+        threads = c_oracle.num_threads()
+        what = "oracle/rx_oracle.c decode (C restatement, OpenMP)"
+    run()
+    ts = []
+    t_end = time.perf_counter() + args.cpu_seconds
+    while len(ts) < 3 or (time.perf_counter() < t_end and len(ts) < 100):
+        t0 = time.perf_counter(); run(); ts.append(time.perf_counter() - t0)
+    t_layer = float(np.median(ts))
+    print(json.dumps({"value": bs / (args.layers * t_layer), "unit": "tokens/s", "cores": threads,
+                      "kind": kind, "ms_per_layer": t_layer * 1e3,
+                      "sample": f"{what}; ONE of {args.layers} layers at the bench shape (bs={bs}, ctx={ctx}, "
+                                f"Hq=32, Hkv=8, D=128, bf16, page_size={ps} shuffled pages = 4 GiB of KV), "
+                                f"median of {len(ts)} runs = {t_layer*1e3:.1f} ms/layer; tokens/s = "
+                                f"bs/({args.layers}*t_layer); host: {_cpu_model()}"}))
+
+
+def cpu_baseline(args):
+    """Spawn the CPU worker as a child (a reference build using ISA this host lacks would die with
+    SIGILL; the child isolates that) -- reference kernel first, C port as the fallback."""
+    import subprocess
+
+    base = [sys.executable, os.path.abspath(__file__), "--bs", str(args.bs), "--ctx", str(args.ctx),
+            "--layers", str(args.layers), "--page-size", str(args.page_size),
+            "--cpu-seconds", str(args.cpu_seconds)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(os.cpu_count()), OMP_WAIT_POLICY="passive")
+    errors = []
+    for kind in ("reference", "port"):
+        try:
+            r = subprocess.run(base + ["--cpu-worker", kind], capture_output=True, text=True, env=env,
+                               timeout=args.cpu_seconds * 6 + 240)
+            if r.returncode == 0:
+                res = json.loads(r.stdout.strip().splitlines()[-1])
+                if errors:
+                    res["note"] = "; ".join(errors)
+                return res
+            errors.append(f"{kind}: rc={r.returncode} {r.stderr.strip()[-200:]}")
+        except Exception as e:
+            errors.append(f"{kind}: {e}")
+    return {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": "; ".join(errors)}
+
+
+def extend_bench(args, dev, tp):
+    """Config 3: bs=256 sharing one 3584-token prefix (radix hit) + 512 new tokens each,
+    chunked to 32 requests (16 Ki tokens) per forward; one layer."""
+    from sglang_amd import ops
+
+    HQ, HKV, D = 32 // tp, max(1, 8 // tp), 128
+    P, E, chunk, nchunks = 3584, 512, 32, 8
+    g = torch.Generator(device=dev).manual_seed(1)
+    pool = P + chunk * E + 16
+    kb = torch.randn(pool, HKV, D, device=dev, generator=g).to(torch.bfloat16)
+    vb = torch.randn(pool, HKV, D, device=dev, generator=g).to(torch.bfloat16)
+    T = chunk * E
+    q = torch.randn(T, HQ, D, device=dev, generator=g).to(torch.bfloat16)
+    k_ext = torch.randn(T, HKV, D, device=dev, generator=g).to(torch.bfloat16)
+    v_ext = torch.randn(T, HKV, D, device=dev, generator=g).to(torch.bfloat16)
+    o = torch.empty_like(q)
+    prefix_slots = torch.arange(16, 16 + P, device=dev, dtype=torch.int64)
+    kv_indices = prefix_slots.repeat(chunk)  # identical rows: every request hits the same pages
+    kv_indptr = (torch.arange(chunk + 1, device=dev) * P).to(torch.int32)
+    qo_indptr = (torch.arange(chunk + 1, device=dev) * E).to(torch.int64)
+
+    def run():
+        ops.extend_attention_fwd(q, k_ext, v_ext, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True,
+                                 None, E, 1.0, 1.0, sm_scale=D ** -0.5, page_size=1)
+
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(nchunks):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / nchunks
+    flops = 4.0 * HQ * D * chunk * (E * P + E * (E + 1) / 2)
+    tflops = flops / (ms * 1e-3) / 1e12
+    return {"metric": "extend attention TFLOP/s (config 3: 3584-token shared prefix + 512 new, bf16)",
+            "tflops": tflops, "ms_per_chunk": ms, "chunk_requests": chunk, "flops_per_chunk": flops,
+            "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": None}}
+
+
+def main():
+    args = parse()
+    if args.cpu_worker:
+        return cpu_worker(args)
+    rank, world, local_rank = build_world(args)
+    dev = torch.device("cuda", local_rank)
+    from sglang_amd.forward_batch import ForwardBatch
+
+    st = make_decode_state(args, world, dev)
+    fb = ForwardBatch.for_decode(st.req_pool_indices, st.seq_lens, st.out_cache_loc, st.seq_lens_cpu)
+    comm_stream = torch.cuda.Stream() if world > 1 else None
+
+    ev_pairs = []
+    timed = {"on": False}
+
+    def step():
+        decode_step(st, fb, world, comm_stream, ev_pairs if timed["on"] else None)
+
+    # warmup untimed, then EXACTLY K timed steps (events are recorded inside the timed region)
+    for _ in range(args.warmup):
+        step()
+    timed["on"] = True
+    dt = time_steps(step, args.steps, 0, world)
+    timed["on"] = False
+    ms_per_step = dt / args.steps * 1e3
+    value = args.bs / (dt / args.steps)
+
+    # roofline of the dominant kernel (decode attention), per launch
+    bs, ctx, L = args.bs, args.ctx, args.layers
+    b_kv = bs * ctx * (st.hkv * st.D + st.hkv * st.D) * 2
+    b_qo = 2 * bs * st.hq * st.D * 2
+    bytes_per_launch = b_kv + b_qo
+    dur_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
+    achieved = bytes_per_launch / (dur_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rx::decode_mfma_kernel",
+                "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dur_ms, "launches": len(ev_pairs)}
+
+    out = {
+        "metric": "decode tokens/s (RadixAttention path, Llama-3-8B attention blocks, bs=256 ctx=4k)",
+        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[2]-shaped decode: Llama-3-8B bf16 attention path, bs=%d, ctx=%d, "
+                               "%d layers, page_size=%d shuffled pages, TP=%d (Hq=%d,Hkv=%d per GPU), "
+                               "per layer: KV store + paged decode attention + o_proj GEMM%s"
+                               % (bs, ctx, L, args.page_size, world, st.hq, st.hkv,
+                                  " + RCCL all-reduce (side stream)" if world > 1 else ""),
+                   "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{world}",
+                   "index_mode": args.index_mode, "distinct_layer_buffers": st.distinct,
+                   "kv_bytes_resident_per_gpu": int(sum(st.pool.get_kv_size_bytes()))},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_extend:
+        try:
+            out["extend"] = extend_bench(args, dev, world)
+        except Exception as e:
+            out["extend"] = {"error": str(e)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
