@@ -367,8 +367,19 @@ def main():
     bytes_per_launch = b_kv + b_qo
     dur_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
     achieved = bytes_per_launch / (dur_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+        if cand and world == 1 and (bs, ctx) == (256, 4096):
+            for k, v in json.load(open(cand[-1]))["kernels"].items():
+                if "decode_mfma_kernel" in k and "hbm_traffic_bytes_per_launch" in v:
+                    traffic, traffic_src = v["hbm_traffic_bytes_per_launch"], os.path.basename(cand[-1])
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rx::decode_mfma_kernel",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "rx::decode_mfma_kernel",
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dur_ms, "launches": len(ev_pairs)}
 
     out = {
