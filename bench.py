@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-extend", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-worker", default=None, choices=["reference", "port"])
+    ap.add_argument("--extend-only", action="store_true", help="dev: run only the extend leg")
     return ap.parse_args()
 
 
@@ -339,6 +340,9 @@ def main():
         return cpu_worker(args)
     rank, world, local_rank = build_world(args)
     dev = torch.device("cuda", local_rank)
+    if args.extend_only:
+        print(json.dumps(extend_bench(args, dev, world)))
+        return
     from sglang_amd.forward_batch import ForwardBatch
 
     st = make_decode_state(args, world, dev)

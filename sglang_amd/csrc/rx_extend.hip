@@ -56,21 +56,24 @@ __device__ __forceinline__ int64_t slot_off(int64_t slot, int32_t page_size, int
   return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
 }
 
-struct Rows {
-  const uint16_t* k0;
-  const uint16_t* k1;
-  const uint16_t* v0;
-  const uint16_t* v1;
-};
+// One 256-thread workgroup = 128 query rows of one (request, q head): wave w owns rows
+// [32w, 32w+32) as two 16-query N blocks.  KV tiles of 64 tokens are staged ONCE per workgroup:
+// global -> registers (full 256-B rows, 16 lanes per row, issued one tile ahead) -> XOR-swizzled
+// LDS image (double buffered, one barrier per tile).  Each wave then reads its K A-fragments with
+// ds_read_b128 and its V^T fragments with ds_read_b64_tr_b16 from the same image layout.
+constexpr int kTT = 64;  // tokens per LDS tile
 
 template <typename T, int D, typename IdxT, bool LINEAR>
-__global__ __launch_bounds__(256) void extend_mfma_kernel(const ExtendArgs a) {
+__global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a) {
   using vec8 = typename T::vec8;
   constexpr int KS = D / 32;
   constexpr int NB = D / 16;
   constexpr int ROW_BYTES = D * 2;
-  constexpr int TILE_BYTES = kETile * ROW_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  constexpr int CPR = ROW_BYTES / 16;      // 16-byte chunks per row
+  constexpr int RPP = 256 / CPR;           // rows staged per pass of the 256 threads
+  constexpr int NPASS = kTT / RPP;         // passes per tile (4 at D=128, 2 at D=64)
+  constexpr int TILE_BYTES = kTT * ROW_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][K|V]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -88,8 +91,10 @@ __global__ __launch_bounds__(256) void extend_mfma_kernel(const ExtendArgs a) {
   const int32_t E = static_cast<int32_t>(load_idx(a.qo_indptr, req + 1, a.qo64) - qo0);
   const int32_t kv0 = a.kv_indptr[req];
   const int32_t P = a.kv_indptr[req + 1] - kv0;  // prefix length
-  const int32_t qbase = (mb * 4 + w) * kQPerWave;
-  if (qbase >= E) return;  // wave-uniform; no workgroup barriers below
+  const int32_t qb0 = mb * 4 * kQPerWave;
+  if (qb0 >= E) return;  // workgroup-uniform
+  const int32_t qbase = qb0 + w * kQPerWave;
+  const bool active = qbase < E;  // inactive waves still stage tiles and hit the barriers
   const IdxT* idx = reinterpret_cast<const IdxT*>(a.kv_indices) + kv0;
 
   // ---- Q^T fragments: block c, lane (r,g) holds Q[qbase+16c+r][h][32s+8g..] -------------------
@@ -106,177 +111,216 @@ __global__ __launch_bounds__(256) void extend_mfma_kernel(const ExtendArgs a) {
     }
   }
 
-  const int32_t n_end = a.skip_extend ? 0 : (a.causal ? min(E, qbase + kQPerWave) : E);
   const int32_t p_len = a.skip_prefix ? 0 : P;
-  const int nt1 = (p_len + kETile - 1) / kETile;
-  const int nt2 = (n_end + kETile - 1) / kETile;
+  const int32_t n_end_wg = a.skip_extend ? 0 : (a.causal ? min(E, qb0 + 4 * kQPerWave) : E);
+  const int32_t n_end_w = a.skip_extend ? 0 : (a.causal ? min(E, qbase + kQPerWave) : E);
+  const int nt1 = (p_len + kTT - 1) / kTT;
+  const int nt2 = (n_end_wg + kTT - 1) / kTT;
   const int nt = nt1 + nt2;
 
-  const uint16_t* kbuf_h = a.k_buf + kvh * a.k_head_stride + 8 * g;
-  const uint16_t* vbuf_h = a.v_buf + kvh * a.v_head_stride + 8 * g;
-  const uint16_t* kext_h = a.k_ext + qo0 * a.k_stride_t + kvh * a.k_stride_h + 8 * g;
-  const uint16_t* vext_h = a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h + 8 * g;
+  // ---- cooperative staging: thread -> (row = pass*RPP + tid/CPR, chunk = tid%CPR) ---------------
+  const int st_row = tid / CPR, st_chunk = tid % CPR;
+  const uint16_t* kbuf_h = a.k_buf + kvh * a.k_head_stride + 8 * st_chunk;
+  const uint16_t* vbuf_h = a.v_buf + kvh * a.v_head_stride + 8 * st_chunk;
+  const uint16_t* kext_h = a.k_ext + qo0 * a.k_stride_t + kvh * a.k_stride_h + 8 * st_chunk;
+  const uint16_t* vext_h = a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h + 8 * st_chunk;
 
-  auto rows_for = [&](int t) -> Rows {
-    Rows rw;
+  int64_t slot[NPASS];  // prefix tiles: KV slot; extend tiles: row index inside the extend part
+  auto load_idx_tile = [&](int t) {
     if (t < nt1) {
-      const int32_t t0 = min(t * kETile + r, p_len - 1);
-      const int32_t t1 = min(t * kETile + 16 + r, p_len - 1);
-      const int64_t s0 = static_cast<int64_t>(idx[t0]);
-      const int64_t s1 = static_cast<int64_t>(idx[t1]);
-      rw.k0 = kbuf_h + slot_off<LINEAR>(s0, a.page_size, a.k_page_stride, a.k_tok_stride);
-      rw.k1 = kbuf_h + slot_off<LINEAR>(s1, a.page_size, a.k_page_stride, a.k_tok_stride);
-      rw.v0 = vbuf_h + slot_off<LINEAR>(s0, a.page_size, a.v_page_stride, a.v_tok_stride);
-      rw.v1 = vbuf_h + slot_off<LINEAR>(s1, a.page_size, a.v_page_stride, a.v_tok_stride);
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i)
+        slot[i] = static_cast<int64_t>(idx[min(t * kTT + i * RPP + st_row, p_len - 1)]);
     } else {
-      const int te = t - nt1;
-      const int64_t t0 = min(te * kETile + r, n_end - 1);
-      const int64_t t1 = min(te * kETile + 16 + r, n_end - 1);
-      rw.k0 = kext_h + t0 * a.k_stride_t;
-      rw.k1 = kext_h + t1 * a.k_stride_t;
-      rw.v0 = vext_h + t0 * a.v_stride_t;
-      rw.v1 = vext_h + t1 * a.v_stride_t;
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i)
+        slot[i] = min((t - nt1) * kTT + i * RPP + st_row, n_end_wg - 1);
     }
-    return rw;
   };
-  u32x4 kf[2][KS], vf[2][KS];
-  auto load_kv = [&](const Rows& rw) {
+  u32x4 stg_k[NPASS], stg_v[NPASS];
+  auto issue_loads = [&](int t) {
+    if (t < nt1) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      kf[0][s] = *reinterpret_cast<const u32x4*>(rw.k0 + 32 * s);
-      kf[1][s] = *reinterpret_cast<const u32x4*>(rw.k1 + 32 * s);
+      for (int i = 0; i < NPASS; ++i) {
+        stg_k[i] = *reinterpret_cast<const u32x4*>(
+            kbuf_h + slot_off<LINEAR>(slot[i], a.page_size, a.k_page_stride, a.k_tok_stride));
+        stg_v[i] = *reinterpret_cast<const u32x4*>(
+            vbuf_h + slot_off<LINEAR>(slot[i], a.page_size, a.v_page_stride, a.v_tok_stride));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        stg_k[i] = *reinterpret_cast<const u32x4*>(kext_h + slot[i] * a.k_stride_t);
+        stg_v[i] = *reinterpret_cast<const u32x4*>(vext_h + slot[i] * a.v_stride_t);
+      }
     }
+  };
+  auto write_lds = [&](int buf) {
+    char* kt = smem + buf * 2 * TILE_BYTES;
+    char* vt = kt + TILE_BYTES;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      vf[0][s] = *reinterpret_cast<const u32x4*>(rw.v0 + 32 * s);
-      vf[1][s] = *reinterpret_cast<const u32x4*>(rw.v1 + 32 * s);
+    for (int i = 0; i < NPASS; ++i) {
+      const int row = i * RPP + st_row;
+      const int off = row * ROW_BYTES + ((st_chunk ^ v_swz<D>(row)) & (CPR - 1)) * 16;
+      *reinterpret_cast<u32x4*>(kt + off) = stg_k[i];
+      *reinterpret_cast<u32x4*>(vt + off) = stg_v[i];
     }
   };
 
-  char* vt = smem + w * TILE_BYTES;
   f32x4 oacc[2][NB];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) oacc[c][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY};
+  float m_run[2] = {-INFINITY, -INFINITY};  // running max, log2 domain
   float l_run[2] = {0.f, 0.f};
 
-  Rows nxt;
+  // ---- prologue -----------------------------------------------------------------------------------
   if (nt > 0) {
-    Rows cur = rows_for(0);
-    load_kv(cur);
-    if (nt > 1) nxt = rows_for(1);
+    load_idx_tile(0);
+    issue_loads(0);
+    if (nt > 1) load_idx_tile(1);
+    write_lds(0);
+    if (nt > 1) {
+      issue_loads(1);
+      if (nt > 2) load_idx_tile(2);
+    }
   }
+  __syncthreads();
+
+  const int swr = v_swz<D>(r);  // swizzle of rows 16k + r
+  const int qd = r >> 2, pp = r & 3;
+  const int vrow0 = 4 * g + qd;  // V^T read: row inside a 16-token block
+  const int swv = v_swz<D>(vrow0);
 
   for (int t = 0; t < nt; ++t) {
+    const char* kt = smem + (t & 1) * 2 * TILE_BYTES;
+    const char* vt = kt + TILE_BYTES;
     const bool prefix = t < nt1;
-    const float sc = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
-    // ---- S^T = K Q^T for both query blocks --------------------------------------------------
-    f32x4 sacc[2][2];
+    const int tile_n0 = (prefix ? t : t - nt1) * kTT;
+    const int32_t lim = prefix ? p_len : n_end_w;
+    if (active) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+      for (int hh = 0; hh < 2; ++hh) {
+        const int n0 = tile_n0 + 32 * hh;  // first token of this 32-token half
+        if (n0 >= lim) continue;           // nothing visible to this wave (wave-uniform)
+        const float cs = (prefix ? a.sm_scale * a.k_scale : a.sm_scale);
+        // ---- S^T = K Q^T ---------------------------------------------------------------------------
+        f32x4 sacc[2][2];
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) sacc[c][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb)
+          for (int bb = 0; bb < 2; ++bb) sacc[c][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const vec8 ka = __builtin_bit_cast(vec8, kf[bb][s]);
-        sacc[0][bb] = T::mfma(ka, qf[0][s], sacc[0][bb]);
-        sacc[1][bb] = T::mfma(ka, qf[1][s], sacc[1][bb]);
-      }
-    // ---- V tile -> LDS -------------------------------------------------------------------------
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+        for (int bb = 0; bb < 2; ++bb) {
+          const char* krow = kt + (32 * hh + 16 * bb + r) * ROW_BYTES;
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb) {
-      const int row = 16 * bb + r;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const int chunk = (4 * s + g) ^ v_swz<D>(row);
-        *reinterpret_cast<u32x4*>(vt + row * ROW_BYTES + chunk * 16) = vf[bb][s];
-      }
-    }
-    if (t + 1 < nt) {
-      load_kv(nxt);
-      if (t + 2 < nt) nxt = rows_for(t + 2);
-    }
-    // ---- masks + online softmax ------------------------------------------------------------------
-    const int nbase = (prefix ? t : t - nt1) * kETile + 4 * g;  // token index of element (bb=0,i=0)
-    vec8 pf[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int m = qbase + 16 * c + r;  // query index inside the extend part
-      float sv[8];
-      float mt = -INFINITY;
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int n = nbase + 16 * bb + i;
-          float x = sacc[c][bb][i] * sc;
-          if (a.logit_cap > 0.f) x = a.logit_cap * tanhf(x / a.logit_cap);
-          x *= kLog2e;
-          bool keep;
-          if (prefix) {
-            keep = n < p_len;
-            if (a.window > 0) keep = keep && (P + m <= n + a.window);
-          } else {
-            keep = n < n_end && (!a.causal || n <= m);
-            if (a.window > 0) keep = keep && (m <= n + a.window);
+          for (int s = 0; s < KS; ++s) {
+            const int chunk = ((4 * s + g) ^ swr) & (CPR - 1);
+            const vec8 ka = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(krow + chunk * 16));
+            sacc[0][bb] = T::mfma(ka, qf[0][s], sacc[0][bb]);
+            sacc[1][bb] = T::mfma(ka, qf[1][s], sacc[1][bb]);
           }
-          x = keep ? x : -INFINITY;
-          sv[bb * 4 + i] = x;
-          mt = fmaxf(mt, x);
         }
-      mt = fmaxf(mt, __shfl_xor(mt, 16));
-      mt = fmaxf(mt, __shfl_xor(mt, 32));
-      // fully masked row so far: keep the max finite (extend_attention.py:474-475)
-      const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
-      const float m_new = fmaxf(m_run[c], mt_fixed);
-      const float alpha = fast_exp2(m_run[c] - m_new);
-      m_run[c] = m_new;
-      float psum = 0.f;
+        // ---- masks + online softmax (lane = one query per block c, 8 tokens) -------------------------
+        bool full;  // every (query, token) pair of this half is visible: skip the mask code
+        if (prefix) full = (n0 + 32 <= p_len) && a.window <= 0;
+        else full = (n0 + 32 <= E) && (!a.causal || n0 + 31 <= qbase) && a.window <= 0;
+        const bool capped = a.logit_cap > 0.f;
+        const float c2 = capped ? kLog2e : cs * kLog2e;
+        vec8 pf[2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        sv[j] = fast_exp2(sv[j] - m_new);
-        psum += sv[j];
+        for (int c = 0; c < 2; ++c) {
+          const int m = qbase + 16 * c + r;
+          float sv[8];
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
+          if (capped) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * cs / a.logit_cap);
+          }
+          if (!full) {
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int n = n0 + 16 * bb + 4 * g + i;
+                bool keep;
+                if (prefix) {
+                  keep = n < p_len;
+                  if (a.window > 0) keep = keep && (P + m <= n + a.window);
+                } else {
+                  keep = n < n_end_w && (!a.causal || n <= m);
+                  if (a.window > 0) keep = keep && (m <= n + a.window);
+                }
+                sv[bb * 4 + i] = keep ? sv[bb * 4 + i] : -INFINITY;
+              }
+          }
+          float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])),
+                           fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+          mt = fmaxf(mt, __shfl_xor(mt, 16));
+          mt = fmaxf(mt, __shfl_xor(mt, 32));
+          mt *= c2;  // c2 > 0: max commutes with the scale
+          // fully masked row so far: keep the max finite (extend_attention.py:474-475)
+          const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
+          const float m_new = fmaxf(m_run[c], mt_fixed);
+          const float alpha = fast_exp2(m_run[c] - m_new);
+          m_run[c] = m_new;
+          float psum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+            psum += sv[j];
+          }
+          l_run[c] = l_run[c] * alpha + psum;
+          const float vs = prefix ? a.v_scale : 1.0f;
+          if (vs != 1.0f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sv[j] *= vs;
+          }
+          u32x4 praw;
+          praw[0] = pack2<T>(sv[0], sv[1]);
+          praw[1] = pack2<T>(sv[2], sv[3]);
+          praw[2] = pack2<T>(sv[4], sv[5]);
+          praw[3] = pack2<T>(sv[6], sv[7]);
+          pf[c] = __builtin_bit_cast(vec8, praw);
+          // rescale O only when some row's max moved (alpha == 1 exactly otherwise)
+          if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) oacc[c][nb] *= alpha;
+          }
+        }
+        // ---- O^T += V^T P^T --------------------------------------------------------------------------
+        {
+          const char* rp0 = vt + (32 * hh + vrow0) * ROW_BYTES + 8 * (pp & 1);
+          const char* rp1 = rp0 + 16 * ROW_BYTES;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int chunk = ((2 * nb + (pp >> 1)) ^ swv) & (CPR - 1);
+            const u32x2 lo2 = T::ds_read_tr(rp0 + chunk * 16);
+            const u32x2 hi2 = T::ds_read_tr(rp1 + chunk * 16);
+            const vec8 av = __builtin_bit_cast(vec8, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]});
+            oacc[0][nb] = T::mfma(av, pf[0], oacc[0][nb]);
+            oacc[1][nb] = T::mfma(av, pf[1], oacc[1][nb]);
+          }
+        }
       }
-      l_run[c] = l_run[c] * alpha + psum;
-      const float vs = prefix ? a.v_scale : 1.0f;
-      u32x4 praw;
-      praw[0] = pack2<T>(sv[0] * vs, sv[1] * vs);
-      praw[1] = pack2<T>(sv[2] * vs, sv[3] * vs);
-      praw[2] = pack2<T>(sv[4] * vs, sv[5] * vs);
-      praw[3] = pack2<T>(sv[6] * vs, sv[7] * vs);
-      pf[c] = __builtin_bit_cast(vec8, praw);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) oacc[c][nb] *= alpha;
     }
-    // ---- O^T += V^T P^T ------------------------------------------------------------------------
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-      const int qd = r >> 2, pp = r & 3;
-      const int row0 = 4 * g + qd;
-      const int sw = v_swz<D>(row0);
-      const char* rp0 = vt + row0 * ROW_BYTES + 8 * (pp & 1);
-      const char* rp1 = rp0 + 16 * ROW_BYTES;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int chunk = (2 * nb + (pp >> 1)) ^ sw;
-        const u32x2 lo2 = T::ds_read_tr(rp0 + chunk * 16);
-        const u32x2 hi2 = T::ds_read_tr(rp1 + chunk * 16);
-        const vec8 av = __builtin_bit_cast(vec8, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]});
-        oacc[0][nb] = T::mfma(av, pf[0], oacc[0][nb]);
-        oacc[1][nb] = T::mfma(av, pf[1], oacc[1][nb]);
+    // ---- stage the next tile: registers (loaded one tile ago) -> the other LDS buffer ---------------
+    if (t + 1 < nt) {
+      write_lds((t + 1) & 1);
+      if (t + 2 < nt) {
+        issue_loads(t + 2);
+        if (t + 3 < nt) load_idx_tile(t + 3);
       }
     }
+    __syncthreads();
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------
+  if (!active) return;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     float l = l_run[c];
