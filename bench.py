@@ -129,22 +129,25 @@ def make_decode_state(args, tp, dev):
     st.q = torch.randn(bs, hq * D, device=dev, generator=g).to(torch.bfloat16)
     st.k = torch.randn(bs, hkv * D, device=dev, generator=g).to(torch.bfloat16)
     st.v = torch.randn(bs, hkv * D, device=dev, generator=g).to(torch.bfloat16)
-    st.w_o = (torch.randn(hq * D, HID, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    from sglang_amd.parallel import RowParallelOProj, TPGroup, shard_heads
+
+    rank = int(os.environ.get("RANK", "0"))
+    w_full = (torch.randn(HQ * D, HID, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    st.shard = shard_heads(HQ, HKV, tp, rank)
+    st.o_proj = RowParallelOProj(w_full, st.shard, D, TPGroup())
+    del w_full
     st.slots = slots
     return st
 
 
-def decode_step(st, fb, world, comm_stream, ev_pairs=None):
+def decode_step(st, fb, world, ev_pairs=None):
     """One decode step of the attention path over all layers."""
-    import torch.distributed as dist
-
     be = st.backend
     be.init_forward_metadata(fb)
-    main = torch.cuda.current_stream()
     pending = None
-    for li, layer in enumerate(st.layers):
+    for layer in st.layers:
         if ev_pairs is not None:
-            # time store+attention of this layer; the attention kernel dominates (>99%)
+            # HIP events around the attention launch of this layer (the roofline kernel)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             be.token_to_kv_pool.set_kv_buffer(layer, fb.out_cache_loc, st.k, st.v)
@@ -154,18 +157,11 @@ def decode_step(st, fb, world, comm_stream, ev_pairs=None):
             ev_pairs.append((e0, e1))
         else:
             o = layer(st.q, st.k, st.v, fb, be)
-        y = torch.matmul(o, st.w_o)  # row-parallel o_proj partial sum [bs, hidden]
-        if world > 1:
-            done = torch.cuda.Event()
-            done.record(main)
-            comm_stream.wait_event(done)
-            with torch.cuda.stream(comm_stream):
-                dist.all_reduce(y)
-                y.record_stream(comm_stream)
-            pending = torch.cuda.Event()
-            pending.record(comm_stream)
+        # row-parallel o_proj + (N>1) sum all-reduce on the side stream: it overlaps the next
+        # layer's KV store + attention on the main stream
+        pending = st.o_proj.forward(o, overlap=world > 1)
     if pending is not None:
-        main.wait_event(pending)
+        pending.wait()
 
 
 def time_steps(fn, steps, warmup, world):
@@ -347,13 +343,12 @@ def main():
 
     st = make_decode_state(args, world, dev)
     fb = ForwardBatch.for_decode(st.req_pool_indices, st.seq_lens, st.out_cache_loc, st.seq_lens_cpu)
-    comm_stream = torch.cuda.Stream() if world > 1 else None
 
     ev_pairs = []
     timed = {"on": False}
 
     def step():
-        decode_step(st, fb, world, comm_stream, ev_pairs if timed["on"] else None)
+        decode_step(st, fb, world, ev_pairs if timed["on"] else None)
 
     # warmup untimed, then EXACTLY K timed steps (events are recorded inside the timed region)
     for _ in range(args.warmup):

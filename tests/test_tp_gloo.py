@@ -1,0 +1,92 @@
+"""Multi-process CPU tests (gloo, world_size 2) of the tensor-parallel path: head sharding,
+row-parallel o_proj and the sum all-reduce reproduce the unsharded attention block.  The
+attention of each shard is produced by the oracle here (the product computes it on the GPU only);
+what is under test is sglang_amd.parallel."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import radix_oracle as orc
+from sglang_amd.parallel import shard_heads
+
+
+def test_shard_heads_matches_llama_rules():
+    # Llama-3-8B / 70B: Hq 32/64, Hkv 8 (models/llama.py:158-171)
+    s = shard_heads(32, 8, 2, 1)
+    assert (s.num_q_heads, s.num_kv_heads, s.q_head_start, s.kv_head_start, s.kv_replicas) == (16, 4, 16, 4, 1)
+    s = shard_heads(32, 8, 8, 5)
+    assert (s.num_q_heads, s.num_kv_heads, s.q_head_start, s.kv_head_start) == (4, 1, 20, 5)
+    s = shard_heads(64, 8, 16, 5)  # kv heads replicated: 2 ranks per kv head
+    assert (s.num_q_heads, s.num_kv_heads, s.kv_head_start, s.kv_replicas) == (4, 1, 2, 2)
+    with pytest.raises(ValueError):
+        shard_heads(32, 8, 3, 0)
+    with pytest.raises(ValueError):
+        shard_heads(32, 8, 12, 0)
+    # the q heads of a rank all map onto the kv heads it owns
+    for tp in (1, 2, 4, 8, 16):
+        for rk in range(tp):
+            s = shard_heads(64, 8, tp, rk)
+            for hq in range(s.q_head_start, s.q_head_start + s.num_q_heads):
+                kvh = hq // (64 // 8)
+                assert s.kv_head_start <= kvh < s.kv_head_start + s.num_kv_heads
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sglang_amd.parallel import RowParallelOProj, TPGroup, shard_heads
+
+        rng = np.random.default_rng(0)  # same data on every rank (the scheduler state is replicated)
+        bs, HQ, HKV, D, HID = 3, 8, 2, 16, 32
+        lens = np.array([5, 9, 2])
+        pool = 32
+        kb = rng.standard_normal((pool, HKV, D)).astype(np.float32)
+        vb = rng.standard_normal((pool, HKV, D)).astype(np.float32)
+        q = rng.standard_normal((bs, HQ, D)).astype(np.float32)
+        w_o = rng.standard_normal((HQ * D, HID)).astype(np.float32)
+        r2t = np.zeros((bs + 1, 16), dtype=np.int32)
+        perm = rng.permutation(pool - 1) + 1
+        o = 0
+        for i, n in enumerate(lens):
+            r2t[i + 1, :n] = perm[o:o + n]; o += n
+        rpi = np.arange(1, bs + 1)
+        kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
+        full = orc.decode_attention(q, kb, vb, kv_indptr, kv_indices, D ** -0.5)
+        want = full.reshape(bs, HQ * D) @ w_o.astype(np.float64)
+
+        group = TPGroup()
+        assert group.world_size == world and group.rank == rank
+        sh = shard_heads(HQ, HKV, world, rank)
+        qs = q[:, sh.q_head_start: sh.q_head_start + sh.num_q_heads]
+        ks = kb[:, sh.kv_head_start: sh.kv_head_start + sh.num_kv_heads]
+        vs = vb[:, sh.kv_head_start: sh.kv_head_start + sh.num_kv_heads]
+        part = orc.decode_attention(qs, ks, vs, kv_indptr, kv_indices, D ** -0.5)  # same page table
+        proj = RowParallelOProj(torch.from_numpy(w_o).double(), sh, D, group)
+        y = proj.forward(torch.from_numpy(part.reshape(bs, -1)), overlap=(rank == 0)).wait()
+        np.testing.assert_allclose(y.numpy(), want, atol=1e-9)
+        # max-over-ranks timing reduction used by bench.py
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == world
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp2_row_parallel_allreduce_matches_unsharded(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
