@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-worker", default=None, choices=["reference", "port"])
     ap.add_argument("--extend-only", action="store_true", help="dev: run only the extend leg")
+    ap.add_argument("--tp-sim", type=int, default=0, help="dev: run ONE rank's shard of a TP=N job on one GPU (no collective)")
     return ap.parse_args()
 
 
@@ -341,7 +342,7 @@ def main():
         return
     from sglang_amd.forward_batch import ForwardBatch
 
-    st = make_decode_state(args, world, dev)
+    st = make_decode_state(args, args.tp_sim or world, dev)
     fb = ForwardBatch.for_decode(st.req_pool_indices, st.seq_lens, st.out_cache_loc, st.seq_lens_cpu)
 
     ev_pairs = []
@@ -356,6 +357,12 @@ def main():
     timed["on"] = True
     dt = time_steps(step, args.steps, 0, world)
     timed["on"] = False
+    # host enqueue time of one step (GPU idle at start, no sync inside): launch-path overhead
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    host_enqueue_ms = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
     ms_per_step = dt / args.steps * 1e3
     value = args.bs / (dt / args.steps)
 
@@ -392,7 +399,7 @@ def main():
                                % (bs, ctx, L, args.page_size, world, st.hq, st.hkv,
                                   " + RCCL all-reduce (side stream)" if world > 1 else ""),
                    "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{world}",
-                   "index_mode": args.index_mode, "distinct_layer_buffers": st.distinct,
+                   "index_mode": args.index_mode, "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
                    "kv_bytes_resident_per_gpu": int(sum(st.pool.get_kv_size_bytes()))},
         "roofline": roofline,
     }

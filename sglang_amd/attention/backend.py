@@ -105,6 +105,9 @@ class HipRadixAttnBackend:
         self._scratch_logits = None
         self._scratch_lse = None
         self._graph = None  # static buffers of init_cuda_graph_state
+        self._md_version = 0  # bumped by every init_forward_metadata_out_graph
+        self._decode_launchers = {}  # layer_id -> ops.DecodeLauncher
+        self._cur_fb = None
 
     # ------------------------------------------------------------------ scratch
     def _scratch(self, bs: int):
@@ -125,6 +128,7 @@ class HipRadixAttnBackend:
     def init_forward_metadata_out_graph(self, forward_batch: ForwardBatch, in_capture: bool = False):
         bs = forward_batch.batch_size
         mode = forward_batch.forward_mode
+        self._md_version += 1
         if mode.is_idle():
             self.forward_metadata = ForwardMetadata(None, None, None, None, None, None, None)
             return
@@ -226,23 +230,33 @@ class HipRadixAttnBackend:
             self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(forward_batch.out_cache_loc), k, v,
                                                 layer.k_scale, layer.v_scale)
         md = self.forward_metadata
-        k_descale, v_descale = self._scales(layer)
-        k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
         q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
-        lay = ops.kv_layout_hnd(k_buf, v_buf) if getattr(self.token_to_kv_pool, "use_hnd", False) else None
-        if self.decode_index_mode == "indices":
-            ops.decode_attention_fwd(q3, k_buf, v_buf, o3, md.kv_indptr, md.kv_indices, md.attn_logits,
-                                     md.attn_lse, md.num_kv_splits, md.max_kv_splits, layer.scaling,
-                                     k_descale, v_descale, logit_cap=layer.logit_cap, sinks=sinks,
-                                     page_size=self.page_size, kv_layout=lay)
-        else:
-            ops.decode_attention_fwd_paged(q3, k_buf, v_buf, o3, self.req_to_token,
-                                           forward_batch.req_pool_indices, forward_batch.seq_lens,
-                                           md.attn_logits, md.attn_lse, md.num_kv_splits,
-                                           md.max_kv_splits, layer.scaling, k_descale, v_descale,
-                                           logit_cap=layer.logit_cap, sinks=sinks,
-                                           page_size=self.page_size, kv_layout=lay)
+        ln = self._decode_launchers.get(layer.layer_id)
+        if ln is None:
+            k_descale, v_descale = self._scales(layer)
+            k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+            hnd = getattr(self.token_to_kv_pool, "use_hnd", False)
+            ln = self._decode_launchers[layer.layer_id] = ops.DecodeLauncher(
+                k_buf, v_buf, self.page_size, layer.tp_q_head_num,
+                k_buf.shape[1] if hnd else k_buf.shape[-2], layer.qk_head_dim, layer.v_head_dim,
+                layer.scaling, k_descale, v_descale, layer.logit_cap,
+                kv_layout=ops.kv_layout_hnd(k_buf, v_buf) if hnd else None)
+        if ln.version != self._md_version:
+            if self.decode_index_mode == "indices":
+                ln.set_metadata(self._md_version, q3.shape[0], kv_indptr=md.kv_indptr,
+                                kv_indices=md.kv_indices, num_kv_splits=md.num_kv_splits,
+                                max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
+                                attn_lse=md.attn_lse)
+            else:
+                ln.set_metadata(self._md_version, q3.shape[0], req_to_token=self.req_to_token,
+                                req_pool_indices=forward_batch.req_pool_indices,
+                                seq_lens=forward_batch.seq_lens, num_kv_splits=md.num_kv_splits,
+                                max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
+                                attn_lse=md.attn_lse)
+        if sinks is not None and sinks.dtype != torch.float32:
+            sinks = sinks.float()
+        ln(q3, o3, torch.cuda.current_stream(q.device).cuda_stream, sinks)
         return o
 
     def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, sinks=None):

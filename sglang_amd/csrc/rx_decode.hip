@@ -113,13 +113,16 @@ __global__ __launch_bounds__(256) void decode_mfma_kernel(const DecodeArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
 
+  // split is the SLOWEST grid dimension: workgroups are dealt round-robin over the 8 XCDs, and
+  // with split fastest only `splits` of every `max_kv_splits` consecutive blocks do any work, i.e.
+  // the live blocks would pile onto splits/8 of the chip (measured: 2 live splits of 8 -> 2.0 TB/s).
   int bid = blockIdx.x;
-  const int split = bid % a.max_kv_splits;
-  bid /= a.max_kv_splits;
   const int qb = bid % a.qblocks;
   bid /= a.qblocks;
   const int kvh = bid % a.hkv;
-  const int b = bid / a.hkv;
+  bid /= a.hkv;
+  const int b = bid % a.bs;
+  const int split = bid / a.bs;
 
   const SeqInfo si = seq_info<IdxT>(a, b);
   const IdxT* idx = reinterpret_cast<const IdxT*>(si.idx);
@@ -339,11 +342,11 @@ __global__ __launch_bounds__(64) void decode_generic_kernel(const DecodeArgs a, 
   extern __shared__ __attribute__((aligned(16))) char dyn_smem[];
   float* qs = reinterpret_cast<float*>(dyn_smem);  // [dk]
   const int lane = threadIdx.x;
-  int bid = blockIdx.x;
-  const int split = bid % a.max_kv_splits;
-  bid /= a.max_kv_splits;
+  int bid = blockIdx.x;  // split slowest (see decode_mfma_kernel)
   const int h = bid % a.hq;
-  const int b = bid / a.hq;
+  bid /= a.hq;
+  const int b = bid % a.bs;
+  const int split = bid / a.bs;
   const int kvh = h / a.group;
   const SeqInfo si = seq_info<IdxT>(a, b);
   const IdxT* idx = reinterpret_cast<const IdxT*>(si.idx);

@@ -93,6 +93,7 @@ class MHATokenToKVPool:
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=device)
         self._create_buffers()
         self._build_ptr_tables()
+        self._store_launchers = [None] * layer_num
 
     def _kv_buffer_shapes(self):
         if self.use_hnd:
@@ -160,11 +161,21 @@ class MHATokenToKVPool:
             self.v_buffer[li][pages, :, offs, :] = cache_v
             return
         n = loc.shape[0]
-        ops.store_cache(cache_k.reshape(n, self.row_dim) if cache_k.dim() == 3 else cache_k,
-                        cache_v.reshape(n, self.v_row_dim) if cache_v.dim() == 3 else cache_v,
-                        self.k_buffer[li].view(-1, self.row_dim),
-                        self.v_buffer[li].view(-1, self.v_row_dim), loc,
-                        size_limit=self.size + self.page_size, err_flag=self.err_flag)
+        k2 = cache_k.reshape(n, self.row_dim) if cache_k.dim() == 3 else cache_k
+        v2 = cache_v.reshape(n, self.v_row_dim) if cache_v.dim() == 3 else cache_v
+        if (not k2.is_cuda or k2.stride(1) != 1 or v2.stride(1) != 1 or loc.dim() != 1
+                or loc.dtype not in (torch.int32, torch.int64) or not loc.is_contiguous()):
+            # uncommon shapes: the fully checked wrapper
+            ops.store_cache(k2, v2, self.k_buffer[li].view(-1, self.row_dim),
+                            self.v_buffer[li].view(-1, self.v_row_dim), loc,
+                            size_limit=self.size + self.page_size, err_flag=self.err_flag)
+            return
+        launcher = self._store_launchers[li]
+        if launcher is None:
+            launcher = self._store_launchers[li] = ops.StoreLauncher(
+                self.k_buffer[li].view(-1, self.row_dim), self.v_buffer[li].view(-1, self.v_row_dim),
+                self.size + self.page_size, self.err_flag)
+        launcher(k2, v2, loc, torch.cuda.current_stream(k2.device).cuda_stream)
 
     def move_kv_cache(self, tgt_loc: torch.Tensor, src_loc: torch.Tensor):
         """memory_pool.py:2775-2842: every layer's K and V rows src -> tgt in one launch."""

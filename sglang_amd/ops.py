@@ -246,6 +246,88 @@ def _fill_decode_common(p, q, k_buffer, v_buffer, o, attn_logits, attn_lse, num_
         raise TypeError("q, k_buffer, v_buffer and o must share one 16-bit dtype")
 
 
+class DecodeLauncher:
+    """rx_decode_params pre-filled for one layer: the KV layout, head geometry and scales are set
+    once; ``set_metadata`` writes the per-forward fields (shared by all layers of a forward) and
+    ``__call__`` only patches q / o.  Keeps the per-layer host cost of a decode step to a few
+    microseconds (the generic ``decode_attention_fwd*`` wrappers re-derive everything per call)."""
+
+    def __init__(self, k_buffer, v_buffer, page_size, num_q_heads, num_kv_heads, head_dim, v_head_dim,
+                 sm_scale, k_scale=1.0, v_scale=1.0, logit_cap=0.0, kv_layout=None):
+        _require_cuda(k_buffer, v_buffer)
+        self._lib = _L.load()
+        p = self.p = _L.RxDecodeParams()
+        p.kv = kv_layout if kv_layout is not None else _kv_layout(k_buffer, v_buffer, page_size)
+        p.num_q_heads, p.num_kv_heads = num_q_heads, num_kv_heads
+        p.head_dim, p.v_head_dim = head_dim, v_head_dim
+        p.sm_scale, p.k_scale, p.v_scale, p.logit_cap = sm_scale, k_scale, v_scale, logit_cap
+        p.dtype = _rx_dtype(k_buffer)
+        p.max_kv_splits = 1
+        self._ref = C.byref(p)
+        self._keep = ()
+        self.version = -1
+
+    def set_metadata(self, version, bs, *, kv_indptr=None, kv_indices=None, req_to_token=None,
+                     req_pool_indices=None, seq_lens=None, num_kv_splits=None, max_kv_splits=1,
+                     attn_logits=None, attn_lse=None):
+        p = self.p
+        p.bs = bs
+        if kv_indices is not None:
+            p.kv_indptr, p.kv_indices = kv_indptr.data_ptr(), kv_indices.data_ptr()
+            p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
+        else:
+            p.kv_indices = None
+            p.req_to_token, p.req_row_stride = req_to_token.data_ptr(), req_to_token.stride(0)
+            p.req_pool_indices = req_pool_indices.data_ptr()
+            p.req_pool_indices_is_i64 = _is64(req_pool_indices, "req_pool_indices")
+            p.seq_lens, p.seq_lens_is_i64 = seq_lens.data_ptr(), _is64(seq_lens, "seq_lens")
+        if num_kv_splits is not None and max_kv_splits > 1:
+            p.num_kv_splits, p.max_kv_splits = num_kv_splits.data_ptr(), max_kv_splits
+            p.attn_logits, p.attn_lse = attn_logits.data_ptr(), attn_lse.data_ptr()
+        else:
+            p.num_kv_splits, p.max_kv_splits = None, 1
+        self._keep = (kv_indptr, kv_indices, req_to_token, req_pool_indices, seq_lens, num_kv_splits,
+                      attn_logits, attn_lse)
+        self.version = version
+
+    def __call__(self, q3, o3, stream_ptr, sinks=None):
+        p = self.p
+        p.q, p.o = q3.data_ptr(), o3.data_ptr()
+        p.q_stride_t, p.q_stride_h = q3.stride(0), q3.stride(1)
+        p.o_stride_t, p.o_stride_h = o3.stride(0), o3.stride(1)
+        p.sinks = None if sinks is None else sinks.data_ptr()
+        st = self._lib.rx_decode_attn(self._ref, stream_ptr)
+        if st:
+            _L.check(st, "rx_decode_attn")
+
+
+class StoreLauncher:
+    """rx_store_kv with the cache-side arguments of one layer pre-computed."""
+
+    def __init__(self, k_cache2d, v_cache2d, size_limit, err_flag, reserved_skip_index=0):
+        _require_cuda(k_cache2d, v_cache2d)
+        self._lib = _L.load()
+        self.kc, self.vc = k_cache2d, v_cache2d
+        es = k_cache2d.element_size()
+        self._tail = None
+        self.k_row_bytes = k_cache2d.shape[1] * es
+        self.v_row_bytes = v_cache2d.shape[1] * es
+        self.kcs, self.vcs = k_cache2d.stride(0) * es, v_cache2d.stride(0) * es
+        self.es = es
+        self.size_limit, self.skip = size_limit, reserved_skip_index
+        self.err = None if err_flag is None else err_flag.data_ptr()
+        self._err_keep = err_flag
+
+    def __call__(self, k2, v2, loc, stream_ptr):
+        st = self._lib.rx_store_kv(k2.data_ptr(), v2.data_ptr(), self.kc.data_ptr(), self.vc.data_ptr(),
+                                   loc.data_ptr(), k2.shape[0], self.k_row_bytes, self.v_row_bytes,
+                                   k2.stride(0) * self.es, v2.stride(0) * self.es, self.kcs, self.vcs,
+                                   1 if loc.dtype == torch.int64 else 0, self.size_limit, self.skip,
+                                   self.err, stream_ptr)
+        if st:
+            _L.check(st, "rx_store_kv")
+
+
 # --------------------------------------------------------------------------------------
 # K7  extend_attention_fwd      kernels/ops/attention/extend_attention.py:664-812
 # --------------------------------------------------------------------------------------
