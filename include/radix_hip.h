@@ -195,6 +195,39 @@ int rx_write_req_to_token(int32_t* req_to_token, int64_t row_stride,
 int rx_move_kv(const uint64_t* data_ptrs, const int64_t* row_bytes, int num_bufs,
                const int64_t* tgt_loc, const int64_t* src_loc, int64_t n, void* stream);
 
+/* ---- a16: native radix tree of cached KV prefixes (HOST side; no GPU work) -----------------------
+ * RadixCache (srt/mem_cache/radix_cache.py:279-812): match_prefix :352-410, insert :412-432 /
+ * :704-757, _split_node :674-694, inc/dec_lock_ref :592-626, evict :562-590, eviction policies
+ * srt/mem_cache/evict_policy.py.  All pointers below are HOST pointers.  Token ids and KV slot
+ * ids are int64; lengths are silently truncated to a multiple of page_size as the reference does.
+ * Nodes are addressed by id; rx_radix_root() is the id of the root (never evicted).
+ * eviction_policy: 0 lru, 1 lfu, 2 fifo, 3 mru, 4 filo, 5 priority, 6 slru. */
+typedef struct rx_radix rx_radix;
+rx_radix* rx_radix_create(int page_size, int eviction_policy);
+void rx_radix_destroy(rx_radix* t);
+void rx_radix_reset(rx_radix* t);
+int64_t rx_radix_root(const rx_radix* t);
+/* returns the matched length (writes that many slot ids to out_indices, which may be NULL);
+ * -1 if cap is too small.  *last_node = deepest matched node (the root when nothing matched). */
+int64_t rx_radix_match_prefix(rx_radix* t, const int64_t* token_ids, int64_t n, const char* extra_key,
+                              int64_t* out_indices, int64_t cap, int64_t* last_node);
+/* returns the length of the prefix that was already cached. */
+int64_t rx_radix_insert(rx_radix* t, const int64_t* token_ids, const int64_t* values, int64_t n,
+                        const char* extra_key, int64_t priority, int chunked, int64_t* last_node);
+/* return the change of evictable size (INT64_MIN for an unknown node id). */
+int64_t rx_radix_inc_lock_ref(rx_radix* t, int64_t node_id);
+int64_t rx_radix_dec_lock_ref(rx_radix* t, int64_t node_id);
+/* evicts leaves in policy order until >= num_tokens slots are freed; slot ids are written node by
+ * node to out_slots and each node's count to out_seg_lens; returns the number of slots freed. */
+int64_t rx_radix_evict(rx_radix* t, int64_t num_tokens, int64_t* out_slots, int64_t slot_cap,
+                       int64_t* out_seg_lens, int64_t seg_cap, int64_t* num_segments);
+int64_t rx_radix_evictable_size(const rx_radix* t);
+int64_t rx_radix_protected_size(const rx_radix* t);
+int64_t rx_radix_total_size(const rx_radix* t);
+int64_t rx_radix_num_nodes(const rx_radix* t);
+/* info6 = {parent id, key length, lock_ref, hit_count, #children, priority}; -1 if unknown id. */
+int rx_radix_node_info(const rx_radix* t, int64_t node_id, int64_t* info6);
+
 #ifdef __cplusplus
 }
 #endif

@@ -634,3 +634,200 @@ def sdpa_extend_req_to_token(q, k_cache, v_cache, req_to_token, req_pool_indices
                     o[start + m, h] = (p @ vv[:n_end]) / p.sum()
         start += e
     return o
+
+
+# --------------------------------------------------------------------------
+# a16 RadixCache     srt/mem_cache/radix_cache.py:279-812, evict_policy.py
+# --------------------------------------------------------------------------
+
+
+class _RNode:
+    __slots__ = ("id", "parent", "key", "value", "children", "lock_ref", "hit_count", "priority",
+                 "last_access", "creation", "extra")
+
+    def __init__(self, nid, now, priority=0):
+        self.id, self.parent, self.key, self.value = nid, None, [], []
+        self.children, self.lock_ref, self.hit_count, self.priority = {}, 0, 0, priority
+        self.last_access = self.creation = now
+        self.extra = None
+
+
+class RadixTreeOracle:
+    """Pure-Python restatement of RadixCache's tree logic (no torch): match_prefix with node
+    split (:352-410, :642-694), insert (:704-757), lock refs (:592-626), heap eviction over
+    evictable leaves (:562-590) with the policy keys of evict_policy.py.  Time is a logical
+    clock: (tick, node id) reproduces the order of the reference's time.monotonic() stamps."""
+
+    def __init__(self, page_size=1, policy="lru"):
+        self.page_size, self.policy = page_size, policy
+        self._ids = 0
+        self._clock = 0
+        self.reset()
+
+    def _now(self):
+        self._clock += 1
+        return self._clock
+
+    def _new(self, priority=0):
+        n = _RNode(self._ids, self._now(), priority)
+        self._ids += 1
+        return n
+
+    def reset(self):
+        self.root = self._new(-(1 << 62))
+        self.root.lock_ref = 1
+        self.evictable_size_ = 0
+        self.protected_size_ = 0
+        self.leaves = set()
+
+    def _ck(self, extra, toks):
+        return (extra, tuple(toks[: self.page_size]))
+
+    def _match(self, a, b):
+        n = min(len(a), len(b))
+        i = 0
+        while i < n and a[i] == b[i]:
+            i += 1
+        return i // self.page_size * self.page_size
+
+    def _leaf(self, n):
+        if n.lock_ref > 0 or n.children:
+            self.leaves.discard(n)
+        else:
+            self.leaves.add(n)
+
+    def _split(self, child, k):
+        nn = self._new(child.priority)
+        nn.hit_count, nn.extra, nn.parent, nn.lock_ref = child.hit_count, child.extra, child.parent, child.lock_ref
+        old = self._ck(child.extra, child.key)
+        nn.key, nn.value = child.key[:k], child.value[:k]
+        child.key, child.value = child.key[k:], child.value[k:]
+        nn.children[self._ck(child.extra, child.key)] = child
+        child.parent = nn
+        nn.parent.children[old] = nn
+        return nn
+
+    def match_prefix(self, tokens, extra=None):
+        tokens = list(tokens)[: len(tokens) // self.page_size * self.page_size]
+        node = self.root
+        if not tokens:
+            return [], node
+        now = self._now()
+        node.last_access = now
+        out = []
+        while tokens:
+            child = node.children.get(self._ck(extra, tokens))
+            if child is None:
+                break
+            child.last_access = now
+            pl = self._match(child.key, tokens)
+            if pl < len(child.key):
+                nn = self._split(child, pl)
+                out += nn.value
+                node = nn
+                break
+            out += child.value
+            node = child
+            tokens = tokens[pl:]
+        return out, node
+
+    def insert(self, tokens, values, extra=None, priority=0, chunked=False):
+        n = len(tokens) // self.page_size * self.page_size
+        tokens, values = list(tokens)[:n], list(values)[:n]
+        node = self.root
+        now = self._now()
+        node.last_access = now
+        node.priority = max(node.priority, priority)
+        total = 0
+        while tokens:
+            child = node.children.get(self._ck(extra, tokens))
+            if child is None:
+                break
+            node = child
+            node.last_access = now
+            pl = self._match(node.key, tokens)
+            total += pl
+            tokens, values = tokens[pl:], values[pl:]
+            if pl < len(node.key):
+                node = self._split(node, pl)
+            node.priority = max(node.priority, priority)
+            if not chunked:
+                node.hit_count += 1
+        if tokens:
+            nn = self._new(priority)
+            nn.parent, nn.extra, nn.key, nn.value = node, extra, tokens, values
+            if not chunked:
+                nn.hit_count += 1
+            node.children[self._ck(extra, tokens)] = nn
+            self.evictable_size_ += len(tokens)
+            self._leaf(node)
+            self._leaf(nn)
+            node = nn
+        return total, node
+
+    def inc_lock_ref(self, node):
+        delta = 0
+        while node is not self.root:
+            if node.lock_ref == 0:
+                self.evictable_size_ -= len(node.key)
+                self.protected_size_ += len(node.key)
+                delta -= len(node.key)
+            node.lock_ref += 1
+            self._leaf(node)
+            node = node.parent
+        return delta
+
+    def dec_lock_ref(self, node):
+        delta = 0
+        while node is not self.root:
+            if node.lock_ref == 1:
+                self.evictable_size_ += len(node.key)
+                self.protected_size_ -= len(node.key)
+                delta += len(node.key)
+            node.lock_ref -= 1
+            self._leaf(node)
+            node = node.parent
+        return delta
+
+    def _prio(self, n):
+        p = self.policy
+        if p == "lfu":
+            return (n.hit_count, n.last_access, n.id)
+        if p == "fifo":
+            return (n.creation, 0, n.id)
+        if p == "mru":
+            return (-n.last_access, 0, n.id)
+        if p == "filo":
+            return (-n.creation, 0, n.id)
+        if p == "priority":
+            return (n.priority, n.last_access, n.id)
+        if p == "slru":
+            return (1 if n.hit_count >= 2 else 0, n.last_access, n.id)
+        return (n.last_access, 0, n.id)
+
+    def evict(self, num_tokens):
+        import heapq
+
+        heap = [(self._prio(n), n.id, n) for n in self.leaves]
+        heapq.heapify(heap)
+        segments, evicted = [], 0
+        while evicted < num_tokens and heap:
+            _, _, x = heapq.heappop(heap)
+            segments.append(list(x.value))
+            evicted += len(x.value)
+            par = x.parent
+            del par.children[self._ck(x.extra, x.key)]
+            self.evictable_size_ -= len(x.key)
+            self.leaves.discard(x)
+            self._leaf(par)
+            if not par.children and par.lock_ref == 0:
+                heapq.heappush(heap, (self._prio(par), par.id, par))
+        return evicted, segments
+
+    def total_size(self):
+        total, stack = 0, [self.root]
+        while stack:
+            n = stack.pop()
+            total += len(n.value)
+            stack.extend(n.children.values())
+        return total

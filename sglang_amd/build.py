@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "libradix_hip.so")
-SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_extend.hip", "rx_allreduce.hip"]
+SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_extend.hip", "rx_radix.cpp"]
 HEADERS = ["rx_common.h", os.path.join(ROOT, "include", "radix_hip.h")]
 
 
@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, "build", os.path.splitext(src)[0] + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
                "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-c", sp, "-o", obj]
         if verbose:

@@ -79,6 +79,24 @@ PROTOTYPES = {
     "rx_alloc_decode": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "rx_write_req_to_token": (c_int, [c_void_p, c_int64] + [c_void_p] * 6 + [c_int, c_void_p]),
     "rx_move_kv": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    # host-side radix tree
+    "rx_radix_create": (c_void_p, [c_int, c_int]),
+    "rx_radix_destroy": (None, [c_void_p]),
+    "rx_radix_reset": (None, [c_void_p]),
+    "rx_radix_root": (c_int64, [c_void_p]),
+    "rx_radix_match_prefix": (c_int64, [c_void_p, c_void_p, c_int64, C.c_char_p, c_void_p, c_int64,
+                                        C.POINTER(c_int64)]),
+    "rx_radix_insert": (c_int64, [c_void_p, c_void_p, c_void_p, c_int64, C.c_char_p, c_int64, c_int,
+                                  C.POINTER(c_int64)]),
+    "rx_radix_inc_lock_ref": (c_int64, [c_void_p, c_int64]),
+    "rx_radix_dec_lock_ref": (c_int64, [c_void_p, c_int64]),
+    "rx_radix_evict": (c_int64, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                 C.POINTER(c_int64)]),
+    "rx_radix_evictable_size": (c_int64, [c_void_p]),
+    "rx_radix_protected_size": (c_int64, [c_void_p]),
+    "rx_radix_total_size": (c_int64, [c_void_p]),
+    "rx_radix_num_nodes": (c_int64, [c_void_p]),
+    "rx_radix_node_info": (c_int, [c_void_p, c_int64, c_void_p]),
 }
 
 

@@ -1,0 +1,346 @@
+"""RadixCache: the prefix tree that makes requests share KV pages.
+
+Public contract of the reference's RadixCache (srt/mem_cache/radix_cache.py:279-812) over the
+native tree in libradix_hip.so (csrc/rx_radix.cpp): ``match_prefix`` -> MatchResult,
+``insert`` -> InsertResult, ``evict``, ``inc_lock_ref`` / ``dec_lock_ref``, ``evictable_size``,
+``protected_size``, ``total_size``, ``cache_finished_req`` / ``cache_unfinished_req``.
+Token ids and KV slot ids cross the C ABI as int64 host arrays; matched slot runs come back as
+one int64 tensor on the allocator's device (one H2D copy per match instead of a torch.cat of
+per-node device tensors).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from array import array
+from dataclasses import dataclass
+from typing import Any, List, NamedTuple, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import lib as _L
+
+_POLICIES = {"lru": 0, "lfu": 1, "fifo": 2, "mru": 3, "filo": 4, "priority": 5, "slru": 6}
+
+
+class RadixKey:
+    """Token ids (+ optional namespace ``extra_key``), radix_cache.py:59-219 without the bigram
+    (EAGLE) view."""
+
+    __slots__ = ("token_ids", "extra_key")
+
+    def __init__(self, token_ids: Sequence[int], extra_key: Optional[str] = None):
+        self.token_ids = token_ids
+        self.extra_key = extra_key
+
+    def __len__(self):
+        return len(self.token_ids)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, int):
+            idx = slice(idx, idx + 1)
+        return RadixKey(self.token_ids[idx], self.extra_key)
+
+    def page_aligned(self, page_size: int) -> "RadixKey":
+        if page_size == 1:
+            return self
+        return self[: len(self) // page_size * page_size]
+
+    def as_int64(self) -> np.ndarray:
+        t = self.token_ids
+        if isinstance(t, np.ndarray):
+            return np.ascontiguousarray(t, dtype=np.int64)
+        if isinstance(t, array) and t.typecode == "q":
+            return np.frombuffer(t, dtype=np.int64) if len(t) else np.empty(0, dtype=np.int64)
+        return np.asarray(list(t), dtype=np.int64)
+
+
+class TreeNode:
+    """Handle of a native node (the reference hands TreeNode objects to req.last_node)."""
+
+    __slots__ = ("_cache", "id")
+
+    def __init__(self, cache: "RadixCache", node_id: int):
+        self._cache, self.id = cache, node_id
+
+    def _info(self):
+        info = (C.c_int64 * 6)()
+        if self._cache._lib.rx_radix_node_info(self._cache._h, self.id, info) != 0:
+            raise KeyError(f"radix node {self.id} no longer exists (evicted)")
+        return list(info)
+
+    @property
+    def parent(self) -> Optional["TreeNode"]:
+        p = self._info()[0]
+        return None if p < 0 else TreeNode(self._cache, p)
+
+    @property
+    def lock_ref(self) -> int:
+        return self._info()[2]
+
+    @property
+    def hit_count(self) -> int:
+        return self._info()[3]
+
+    @property
+    def num_children(self) -> int:
+        return self._info()[4]
+
+    @property
+    def priority(self) -> int:
+        return self._info()[5]
+
+    def key_len(self) -> int:
+        return self._info()[1]
+
+    def __eq__(self, other):
+        return isinstance(other, TreeNode) and other.id == self.id and other._cache is self._cache
+
+    def __hash__(self):
+        return hash(self.id)
+
+    def __repr__(self):
+        return f"TreeNode(id={self.id})"
+
+
+@dataclass
+class MatchPrefixParams:
+    key: RadixKey
+
+
+class MatchResult(NamedTuple):
+    device_indices: torch.Tensor
+    last_device_node: Any
+    last_host_node: Any
+    best_match_node: Any = None
+    host_hit_length: int = 0
+
+
+@dataclass
+class InsertParams:
+    key: RadixKey
+    value: Optional[torch.Tensor] = None
+    priority: int = 0
+    chunked: bool = False
+
+
+@dataclass
+class InsertResult:
+    prefix_len: int
+    last_device_node: Any = None
+
+
+@dataclass
+class EvictParams:
+    num_tokens: int
+
+
+@dataclass
+class EvictResult:
+    num_tokens_evicted: int = 0
+
+
+@dataclass
+class IncLockRefResult:
+    delta: int
+
+
+@dataclass
+class DecLockRefResult:
+    delta: int
+
+
+@dataclass
+class Req:
+    """The fields of managers/schedule_batch.Req that the cache touches."""
+
+    origin_input_ids: List[int]
+    output_ids: List[int]
+    req_pool_idx: Optional[int] = None
+    extra_key: Optional[str] = None
+    priority: int = 0
+    prefix_indices: Optional[torch.Tensor] = None
+    last_node: Optional[TreeNode] = None
+    cache_protected_len: int = 0
+    fill_ids: Optional[List[int]] = None
+
+    def get_fill_ids(self):
+        return self.fill_ids if self.fill_ids is not None else self.origin_input_ids + self.output_ids
+
+
+class RadixCache:
+    def __init__(self, req_to_token_pool=None, token_to_kv_pool_allocator=None, page_size: int = 1,
+                 disable: bool = False, eviction_policy: str = "lru", disable_finished_insert: bool = False):
+        self.disable = disable
+        self.req_to_token_pool = req_to_token_pool
+        self.token_to_kv_pool_allocator = token_to_kv_pool_allocator
+        self.page_size = page_size
+        self.disable_finished_insert = disable_finished_insert
+        self.eviction_policy = eviction_policy.lower()
+        if self.eviction_policy not in _POLICIES:
+            raise ValueError(f"unknown eviction policy {eviction_policy!r}; one of {sorted(_POLICIES)}")
+        dev = getattr(token_to_kv_pool_allocator, "device", "cpu") if token_to_kv_pool_allocator else "cpu"
+        self.device = torch.device(dev) if isinstance(dev, (str, torch.device)) else torch.device("cpu")
+        self._lib = _L.load()
+        self._h = self._lib.rx_radix_create(page_size, _POLICIES[self.eviction_policy])
+        if not self._h:
+            raise _L.RadixHipError("rx_radix_create failed")
+        self.root_node = TreeNode(self, self._lib.rx_radix_root(self._h))
+        self._empty = torch.empty((0,), dtype=torch.int64, device=self.device)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.rx_radix_destroy(h)
+
+    @classmethod
+    def create_simulated(cls, disable: bool = False, mock_allocator=None, page_size: int = 1):
+        """radix_cache.py:309-325."""
+        return cls(None, mock_allocator, page_size, disable)
+
+    # ------------------------------------------------------------------ public API
+    def reset(self):
+        self._lib.rx_radix_reset(self._h)
+        self.root_node = TreeNode(self, self._lib.rx_radix_root(self._h))
+
+    def match_prefix(self, params: MatchPrefixParams) -> MatchResult:
+        key = params.key if isinstance(params, MatchPrefixParams) else params
+        if self.disable or len(key) == 0:
+            return MatchResult(self._empty, self.root_node, self.root_node, self.root_node)
+        toks = key.as_int64()
+        out = np.empty(len(toks), dtype=np.int64)
+        last = C.c_int64(0)
+        n = self._lib.rx_radix_match_prefix(
+            self._h, toks.ctypes.data, len(toks),
+            None if key.extra_key is None else key.extra_key.encode(), out.ctypes.data, len(out),
+            C.byref(last))
+        if n < 0:
+            raise _L.RadixHipError("rx_radix_match_prefix failed")
+        node = TreeNode(self, last.value)
+        idx = torch.from_numpy(out[:n].copy()).to(self.device) if n else self._empty
+        return MatchResult(idx, node, node, node)
+
+    def insert(self, params: InsertParams) -> InsertResult:
+        if self.disable:
+            return InsertResult(prefix_len=0)
+        key = params.key.page_aligned(self.page_size)
+        toks = key.as_int64()
+        if params.value is not None:
+            vals = params.value[: len(key)].detach().to("cpu", torch.int64).contiguous().numpy()
+        else:  # debug / test fallback: token ids as values (radix_cache.py:425-427)
+            vals = toks.copy()
+        last = C.c_int64(0)
+        pl = self._lib.rx_radix_insert(
+            self._h, toks.ctypes.data, vals.ctypes.data, len(toks),
+            None if key.extra_key is None else key.extra_key.encode(), int(params.priority or 0),
+            int(bool(params.chunked)), C.byref(last))
+        return InsertResult(prefix_len=int(pl), last_device_node=TreeNode(self, last.value))
+
+    def evict(self, params: EvictParams) -> EvictResult:
+        if self.disable:
+            return EvictResult()
+        want = params.num_tokens if isinstance(params, EvictParams) else int(params)
+        cap = self._lib.rx_radix_evictable_size(self._h)
+        if cap == 0 or want <= 0:
+            return EvictResult(0)
+        slots = np.empty(cap, dtype=np.int64)
+        nodes_cap = self._lib.rx_radix_num_nodes(self._h)
+        seg_lens = np.empty(nodes_cap, dtype=np.int64)
+        nseg = C.c_int64(0)
+        n = self._lib.rx_radix_evict(self._h, want, slots.ctypes.data, cap, seg_lens.ctypes.data,
+                                     nodes_cap, C.byref(nseg))
+        if self.token_to_kv_pool_allocator is not None and n:
+            off = 0
+            dev_slots = torch.from_numpy(slots[:n].copy()).to(self.device)
+            for i in range(nseg.value):  # one page-exact segment per evicted node, in heap order
+                ln = int(seg_lens[i])
+                self.token_to_kv_pool_allocator.free_segment(dev_slots[off: off + ln], start_pos=0)
+                off += ln
+        return EvictResult(num_tokens_evicted=int(n))
+
+    def inc_lock_ref(self, node: TreeNode) -> IncLockRefResult:
+        if self.disable:
+            return IncLockRefResult(delta=0)
+        d = self._lib.rx_radix_inc_lock_ref(self._h, node.id)
+        if d == -(1 << 63):
+            raise KeyError(f"radix node {node.id} does not exist")
+        return IncLockRefResult(delta=int(d))
+
+    def dec_lock_ref(self, node: TreeNode, params=None) -> DecLockRefResult:
+        if self.disable:
+            return DecLockRefResult(delta=0)
+        d = self._lib.rx_radix_dec_lock_ref(self._h, node.id)
+        if d == -(1 << 63):
+            raise KeyError(f"radix node {node.id} does not exist")
+        return DecLockRefResult(delta=int(d))
+
+    def evictable_size(self):
+        return int(self._lib.rx_radix_evictable_size(self._h))
+
+    def protected_size(self):
+        return int(self._lib.rx_radix_protected_size(self._h))
+
+    def total_size(self):
+        return int(self._lib.rx_radix_total_size(self._h))
+
+    def num_nodes(self):
+        return int(self._lib.rx_radix_num_nodes(self._h))
+
+    # ------------------------------------------------------------------ request hooks
+    def cache_finished_req(self, req: Req, is_insert: bool = True, *, kv_len_to_handle: int):
+        """radix_cache.py:434-486."""
+        if self.disable_finished_insert:
+            is_insert = False
+        r2t = self.req_to_token_pool.req_to_token
+        if self.disable:
+            kv_indices = r2t[req.req_pool_idx, req.cache_protected_len: kv_len_to_handle]
+            self.token_to_kv_pool_allocator.free_segment(kv_indices.to(torch.int64),
+                                                         start_pos=req.cache_protected_len)
+            return
+        token_ids = (req.origin_input_ids + req.output_ids)[:kv_len_to_handle]
+        kv_indices = r2t[req.req_pool_idx, : len(token_ids)].to(torch.int64)
+        radix_key = RadixKey(token_ids, req.extra_key).page_aligned(self.page_size)
+        key_len = len(radix_key)
+        values = kv_indices[:key_len].clone()
+        if is_insert:
+            result = self.insert(InsertParams(key=radix_key, value=values, priority=req.priority or 0))
+            freed_end = result.prefix_len
+        else:
+            freed_end = key_len
+        # duplicates / uninserted range, then the unaligned tail
+        self.token_to_kv_pool_allocator.free_segments([
+            (kv_indices[req.cache_protected_len: freed_end], req.cache_protected_len),
+            (kv_indices[key_len:], key_len),
+        ])
+        if req.last_node is not None:
+            self.dec_lock_ref(req.last_node)
+
+    def cache_unfinished_req(self, req: Req, chunked: bool = False):
+        """radix_cache.py:488-553."""
+        if self.disable:
+            return
+        token_ids = req.get_fill_ids()
+        r2t = self.req_to_token_pool.req_to_token
+        kv_indices = r2t[req.req_pool_idx, : len(token_ids)].to(torch.int64)
+        radix_key = RadixKey(token_ids, req.extra_key).page_aligned(self.page_size)
+        values = kv_indices[: len(radix_key)].clone()
+        result = self.insert(InsertParams(key=radix_key, value=values, chunked=chunked,
+                                          priority=req.priority or 0))
+        new_prefix_len = result.prefix_len
+        self.token_to_kv_pool_allocator.free_segment(
+            kv_indices[req.cache_protected_len: new_prefix_len], start_pos=req.cache_protected_len)
+        match = self.match_prefix(MatchPrefixParams(key=radix_key))
+        new_indices, new_last_node = match.device_indices, match.last_device_node
+        assert len(new_indices) == len(radix_key), f"{len(new_indices)=}, {len(radix_key)=}"
+        # the prefix may now point at pages shared with an earlier request
+        r2t[req.req_pool_idx, req.cache_protected_len: len(new_indices)] = \
+            new_indices[req.cache_protected_len:].to(torch.int32)
+        req.cache_protected_len = len(new_indices)
+        if req.last_node is not None:
+            self.dec_lock_ref(req.last_node)
+        self.inc_lock_ref(new_last_node)
+        if len(new_indices) < len(kv_indices):
+            req.prefix_indices = torch.cat([new_indices, kv_indices[len(new_indices):]])
+        else:
+            req.prefix_indices = new_indices
+        req.last_node = new_last_node

@@ -14,6 +14,7 @@ Fixture families:
   F4 store (torch index_put fallback of memory_pool.py:189-192) -> store_kv.npz
   F5 decode attention (Triton decode_attention_fwd) -> decode_*.npz
   F6 extend attention (Triton extend_attention_fwd) -> extend_*.npz
+  F7 radix tree op sequences (reference RadixCache, recording allocator) -> radix_sequences.json
   F8 bf16 decode/extend from the compiled reference C++ CPU kernels -> cpu_native.npz
 """
 import json
@@ -375,6 +376,121 @@ def f6():
     save("extend.npz", **flat)
 
 
+# ------------------------------------------------------------------ F7
+def _import_ref_radix():
+    """The reference RadixCache needs only its tree logic here: stub the modules it imports for
+    type names / metrics / events so `radix_cache.py` itself runs unmodified."""
+    import sglang  # noqa: F401  (the real package first)
+
+    for name in ["sglang.srt.mem_cache.memory_pool", "sglang.srt.observability.metrics_collector",
+                 "sglang.srt.mem_cache.events", "sglang.srt.mem_cache.cpp_utils",
+                 "sglang.srt.mem_cache.cpp_utils.native_hash", "sglang.kernels.ops.kvcache.mla_buffer"]:
+        if name not in sys.modules:
+            m = _ref_import._Stub(name)
+            m.__path__ = []
+            sys.modules[name] = m
+
+    class _Mixin:
+        def _record_all_cleared_event(self): pass
+        def _record_store_event(self, n): pass
+        def _record_remove_event(self, n): pass
+
+    sys.modules["sglang.srt.mem_cache.events"].KVCacheEventMixin = _Mixin
+    from sglang.srt.mem_cache import base_prefix_cache as bpc
+    from sglang.srt.mem_cache import radix_cache as rc
+    from sglang.srt.mem_cache.cache_init_params import CacheInitParams
+
+    return rc, bpc, CacheInitParams
+
+
+class _RecordingAllocator:
+    device = "cpu"
+
+    def __init__(self):
+        self.freed = []
+
+    def free_segment(self, idx, *, start_pos):
+        self.freed.append(idx.tolist())
+
+
+def gen_radix(page_size, policy, seed):
+    from array import array
+
+    rc, bpc, CacheInitParams = _import_ref_radix()
+    rng = np.random.default_rng(seed)
+    alloc = _RecordingAllocator()
+    cache = rc.RadixCache(CacheInitParams(disable=False, req_to_token_pool=None,
+                                          token_to_kv_pool_allocator=alloc, page_size=page_size,
+                                          eviction_policy=policy))
+    log, held = [], []  # held: (handle id, node) locked nodes
+    next_slot = [1]
+    hid = [0]
+
+    def rand_key():
+        # small vocabulary + page-wise construction => many shared prefixes and mid-node splits
+        npages = int(rng.integers(1, 6))
+        toks = []
+        for _ in range(npages):
+            toks.extend([int(rng.integers(0, 3))] * page_size if rng.random() < 0.7 else
+                        [int(x) for x in rng.integers(0, 3, size=page_size)])
+        toks.extend(int(x) for x in rng.integers(0, 3, size=int(rng.integers(0, page_size))))
+        return toks
+
+    def sizes():
+        return [cache.evictable_size(), cache.protected_size(), cache.total_size()]
+
+    for _ in range(120):
+        op = rng.choice(["insert", "match", "lock", "unlock", "evict"], p=[0.35, 0.3, 0.12, 0.1, 0.13])
+        extra = None if rng.random() < 0.85 else "lora1"
+        if op == "insert":
+            toks = rand_key()
+            vals = list(range(next_slot[0], next_slot[0] + len(toks)))
+            next_slot[0] += len(toks)
+            prio = int(rng.integers(0, 3))
+            chunked = bool(rng.random() < 0.2)
+            r = cache.insert(bpc.InsertParams(key=rc.RadixKey(array("q", toks), extra),
+                                              value=torch.tensor(vals, dtype=torch.int64),
+                                              priority=prio, chunked=chunked))
+            log.append(dict(op="insert", tokens=toks, values=vals, extra=extra, priority=prio,
+                            chunked=chunked, prefix_len=r.prefix_len, sizes=sizes()))
+        elif op == "match":
+            toks = rand_key()
+            m = cache.match_prefix(bpc.MatchPrefixParams(key=rc.RadixKey(array("q", toks), extra)))
+            log.append(dict(op="match", tokens=toks, extra=extra, indices=m.device_indices.tolist(),
+                            last_is_root=m.last_device_node is cache.root_node,
+                            last_key_len=len(m.last_device_node.key), sizes=sizes()))
+        elif op == "lock":
+            toks = rand_key()
+            m = cache.match_prefix(bpc.MatchPrefixParams(key=rc.RadixKey(array("q", toks), extra)))
+            d = cache.inc_lock_ref(m.last_device_node).delta
+            held.append((hid[0], m.last_device_node))
+            log.append(dict(op="lock", tokens=toks, extra=extra, indices=m.device_indices.tolist(),
+                            handle=hid[0], delta=d, sizes=sizes()))
+            hid[0] += 1
+        elif op == "unlock" and held:
+            i = int(rng.integers(0, len(held)))
+            h, node = held.pop(i)
+            d = cache.dec_lock_ref(node).delta
+            log.append(dict(op="unlock", handle=h, delta=d, sizes=sizes()))
+        elif op == "evict":
+            n = int(rng.integers(1, 4 * page_size + 2))
+            alloc.freed = []
+            r = cache.evict(bpc.EvictParams(num_tokens=n))
+            log.append(dict(op="evict", num_tokens=n, evicted=r.num_tokens_evicted,
+                            segments=alloc.freed, sizes=sizes()))
+    return dict(page_size=page_size, policy=policy, log=log)
+
+
+def f7():
+    cases = []
+    for ps, pol, seed in [(1, "lru", 1), (4, "lru", 2), (16, "lru", 3), (1, "lfu", 4), (4, "fifo", 5),
+                          (1, "priority", 6), (4, "mru", 7), (1, "filo", 8), (4, "slru", 9)]:
+        cases.append(gen_radix(ps, pol, seed))
+    with open(os.path.join(HERE, "radix_sequences.json"), "w") as f:
+        json.dump(cases, f)
+    print("wrote radix_sequences.json", [len(c["log"]) for c in cases])
+
+
 # ------------------------------------------------------------------ F8
 def f8():
     """bf16 goldens from the reference's compiled native CPU kernels (oracle/_ref, built by
@@ -446,6 +562,6 @@ def f8():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f8"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8"]
     for w in which:
         globals()[w]()
