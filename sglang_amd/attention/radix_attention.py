@@ -40,8 +40,8 @@ class RadixAttention:
     def forward(self, q, k, v, forward_batch, attn_backend, save_kv_cache: bool = True, **kwargs):
         if k is not None:
             assert v is not None
-            k = k.view(-1, self.tp_k_head_num, self.qk_head_dim)
-            v = v.view(-1, self.tp_v_head_num, self.v_head_dim)
+            k = k.reshape(-1, self.tp_k_head_num, self.qk_head_dim)
+            v = v.reshape(-1, self.tp_v_head_num, self.v_head_dim)
         return attn_backend.forward(q, k, v, self, forward_batch, save_kv_cache, **kwargs)
 
     __call__ = forward

@@ -192,3 +192,84 @@ class MHATokenToKVPool:
         if v:
             self.err_flag.zero_()
         return v
+
+
+class MLATokenToKVPool:
+    """Latent-KV pool for MLA models (memory_pool.py:3906-4179): ONE buffer per layer,
+    [size + page_size, 1, kv_lora_rank + qk_rope_head_dim]; the value view is the first
+    kv_lora_rank columns of the same rows (:4006-4014), so decode reads each row once for both
+    products.  bf16/fp16 rows only in this round (fp8 rows + the MFMA MLA decode kernel are the next
+    step; the generic HIP decode kernel serves Dk=576 / Dv=512 meanwhile)."""
+
+    def __init__(self, size: int, page_size: int, dtype: torch.dtype, kv_lora_rank: int,
+                 qk_rope_head_dim: int, layer_num: int, device: str, start_layer: int = 0):
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise NotImplementedError(f"MLATokenToKVPool: dtype {dtype} (fp8 latent rows are not built yet)")
+        self.size, self.page_size, self.dtype, self.store_dtype = size, page_size, dtype, dtype
+        self.kv_lora_rank, self.qk_rope_head_dim = kv_lora_rank, qk_rope_head_dim
+        self.kv_cache_dim = kv_lora_rank + qk_rope_head_dim
+        self.layer_num, self.device, self.start_layer = layer_num, device, start_layer
+        self.use_hnd = False
+        self.err_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        # slot 0 absorbs the writes of padded tokens (:3967)
+        self.kv_buffer = [torch.zeros((size + page_size, 1, self.kv_cache_dim), dtype=dtype, device=device)
+                          for _ in range(layer_num)]
+        self.data_ptrs = torch.tensor([b.data_ptr() for b in self.kv_buffer], dtype=torch.int64, device=device)
+        self.data_strides = torch.tensor([b.stride(0) * b.element_size() for b in self.kv_buffer],
+                                         dtype=torch.int64, device=device)
+
+    def get_kv_size_bytes(self):
+        return sum(b.numel() * b.element_size() for b in self.kv_buffer)
+
+    def get_key_buffer(self, layer_id: int):
+        return self.kv_buffer[layer_id - self.start_layer]
+
+    def get_value_buffer(self, layer_id: int):
+        return self.kv_buffer[layer_id - self.start_layer][..., : self.kv_lora_rank]
+
+    def get_kv_buffer(self, layer_id: int):
+        return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
+
+    def get_v_head_dim(self):
+        return self.kv_lora_rank
+
+    def _write_two(self, layer_id, loc, a, b):
+        """dst[loc, :a_cols] = a ; dst[loc, a_cols:] = b  in one rx_store_kv launch."""
+        buf = self.kv_buffer[layer_id - self.start_layer].view(-1, self.kv_cache_dim)
+        n = loc.shape[0]
+        a2, b2 = a.reshape(n, -1), b.reshape(n, -1)
+        ops.store_cache(a2, b2, buf[:, : a2.shape[1]], buf[:, a2.shape[1]:], loc,
+                        size_limit=self.size + self.page_size, reserved_skip_index=-1,
+                        err_flag=self.err_flag)
+
+    def set_kv_buffer(self, layer, loc_info, cache_k: torch.Tensor, cache_v: torch.Tensor = None, *_, **__):
+        """memory_pool.py:4022-4044: the whole latent row comes in as cache_k; cache_v is unused."""
+        loc, _, _ = unwrap_write_loc(loc_info)
+        if cache_k.dtype != self.dtype:
+            cache_k = cache_k.to(self.dtype)
+        k2 = cache_k.reshape(loc.shape[0], self.kv_cache_dim)
+        self._write_two(layer.layer_id, loc, k2[:, : self.kv_lora_rank], k2[:, self.kv_lora_rank:])
+
+    def set_mla_kv_buffer(self, layer, loc: torch.Tensor, cache_k_nope: torch.Tensor,
+                          cache_k_rope: torch.Tensor):
+        """memory_pool.py:4095-4115 (two-tensor write of [nope | rope])."""
+        if cache_k_nope.dtype != self.dtype:
+            cache_k_nope, cache_k_rope = cache_k_nope.to(self.dtype), cache_k_rope.to(self.dtype)
+        self._write_two(layer.layer_id, loc, cache_k_nope, cache_k_rope)
+
+    def get_mla_kv_buffer(self, layer, loc: torch.Tensor, dst_dtype: Optional[torch.dtype] = None):
+        """memory_pool.py:4117-4138."""
+        rows = self.get_key_buffer(layer.layer_id)[loc.long()]
+        dst_dtype = dst_dtype or self.dtype
+        return (rows[..., : self.kv_lora_rank].to(dst_dtype).contiguous(),
+                rows[..., self.kv_lora_rank:].to(dst_dtype).contiguous())
+
+    def move_kv_cache(self, tgt_loc: torch.Tensor, src_loc: torch.Tensor):
+        if tgt_loc.numel():
+            ops.move_kv(self.data_ptrs, self.data_strides, tgt_loc.to(torch.int64), src_loc.to(torch.int64))
+
+    def check_errors(self) -> int:
+        v = int(self.err_flag.item())
+        if v:
+            self.err_flag.zero_()
+        return v

@@ -212,3 +212,60 @@ def test_decode_step_is_hip_graph_capturable():
     torch.cuda.synchronize()
     fresh = hs.layer(q, k, v, fb, hs.backend)
     assert torch.equal(out, fresh) and not torch.equal(out, eager)
+
+
+def test_mla_latent_pool_and_decode():
+    """Config-5-shaped MLA decode (absorbed form): Hq=16 per GPU, Hkv=1, Dk=576 (512 latent + 64
+    rope), Dv=512 = first 512 columns of the SAME rows (triton_backend.py:1739-1757, memory_pool.py:
+    3906-4179), through MLATokenToKVPool + HipRadixAttnBackend (generic HIP decode kernel)."""
+    from sglang_amd.attention.backend import HipRadixAttnBackend
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+    from sglang_amd.mem_cache.memory_pool import MLATokenToKVPool, ReqToTokenPool
+
+    hq, rank, rope = 16, 512, 64
+    lens = [70, 129, 5]
+    bs = len(lens)
+    pool = MLATokenToKVPool(1024, 1, torch.bfloat16, rank, rope, 1, DEV)
+    r2t = ReqToTokenPool(4, 256, DEV)
+    g = torch.Generator().manual_seed(0)
+    perm = torch.randperm(1023, generator=g) + 1
+    rows = r2t.alloc(bs)
+    layer = RadixAttention(hq, rank + rope, (128 + 64) ** -0.5, 1, 0, v_head_dim=rank)
+    off = 0
+    for r, n in zip(rows, lens):
+        slots = perm[off: off + n].to(DEV); off += n
+        r2t.req_to_token[r, :n] = slots.int()
+        nope = torch.randn(n, 1, rank, generator=g).to(torch.bfloat16).to(DEV)
+        rp = torch.randn(n, 1, rope, generator=g).to(torch.bfloat16).to(DEV)
+        pool.set_mla_kv_buffer(layer, slots, nope, rp)
+        back_n, back_r = pool.get_mla_kv_buffer(layer, slots)
+        assert torch.equal(back_n, nope) and torch.equal(back_r, rp)
+
+    class MC:
+        num_attention_heads, num_key_value_heads, context_len = hq, 1, 256
+
+    class MR:
+        device = DEV
+        req_to_token_pool = r2t
+        token_to_kv_pool = pool
+        model_config = MC
+        page_size = 1
+
+    be = HipRadixAttnBackend(MR)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    seq = torch.tensor(lens, dtype=torch.int64)
+    # the new token's latent row goes in through set_kv_buffer (whole 576-wide row)
+    loc = torch.tensor([int(r2t.req_to_token[r, n - 1]) for r, n in zip(rows, lens)], device=DEV)
+    k_new = torch.randn(bs, 1, rank + rope, generator=g).to(torch.bfloat16).to(DEV)
+    q = torch.randn(bs, hq * (rank + rope), generator=g).to(torch.bfloat16).to(DEV)
+    fb = ForwardBatch.for_decode(rpi, seq.to(DEV), loc, seq)
+    be.init_forward_metadata(fb)
+    o = layer(q, k_new, k_new[..., :rank], fb, be)
+    assert o.shape == (bs, hq * rank)
+    kb = pool.get_key_buffer(0)
+    want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, rank + rope)), _bits(kb),
+                                        _bits(kb[..., :rank].contiguous()), _bits(r2t.req_to_token),
+                                        np.array(rows), np.array(lens), layer.scaling)
+    got = o.view(bs, hq, rank).float().cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-2
