@@ -82,9 +82,27 @@ struct F16 {
   }
 };
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// two fp32 -> one dword of two 16-bit floats (RNE).  The vector convert lets hipcc emit ONE
+// v_cvt_pk_bf16_f32 per pair (two scalar casts cost cvt + cvt + shift + or).
 template <typename T>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return static_cast<uint32_t>(T::from_f32(lo)) | (static_cast<uint32_t>(T::from_f32(hi)) << 16);
+  const f32x2 f = {lo, hi};
+  if constexpr (sizeof(typename T::scalar) == 2 && __is_same(typename T::scalar, __bf16)) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
+  } else {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));
+  }
+}
+
+// KV slot -> element offset with 32-bit operands (slots and per-token strides are < 2^31):
+// one v_mad_u64_u32 instead of a 64x64-bit multiply.
+__device__ __forceinline__ int64_t mul_u32(int64_t slot, int64_t stride) {
+  return static_cast<int64_t>(static_cast<uint64_t>(static_cast<uint32_t>(slot)) *
+                              static_cast<uint32_t>(stride));
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

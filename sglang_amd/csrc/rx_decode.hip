@@ -66,7 +66,7 @@ __device__ __forceinline__ int v_swizzle(int row) {
 template <bool LINEAR>
 __device__ __forceinline__ int64_t slot_offset(int64_t slot, int32_t page_size,
                                                int64_t page_stride, int64_t tok_stride) {
-  if constexpr (LINEAR) return slot * tok_stride;
+  if constexpr (LINEAR) return mul_u32(slot, tok_stride);
   return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
 }
 

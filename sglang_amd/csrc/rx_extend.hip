@@ -52,7 +52,7 @@ __device__ __forceinline__ int v_swz(int row) {
 template <bool LINEAR>
 __device__ __forceinline__ int64_t slot_off(int64_t slot, int32_t page_size, int64_t page_stride,
                                             int64_t tok_stride) {
-  if constexpr (LINEAR) return slot * tok_stride;
+  if constexpr (LINEAR) return mul_u32(slot, tok_stride);
   return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
 }
 
@@ -63,7 +63,7 @@ __device__ __forceinline__ int64_t slot_off(int64_t slot, int32_t page_size, int
 // ds_read_b128 and its V^T fragments with ds_read_b64_tr_b16 from the same image layout.
 constexpr int kTT = 64;  // tokens per LDS tile
 
-template <typename T, int D, typename IdxT, bool LINEAR>
+template <typename T, int D, typename IdxT, bool LINEAR, bool VSCALE>
 __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a) {
   using vec8 = typename T::vec8;
   constexpr int KS = D / 32;
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
             psum += sv[j];
           }
           l_run[c] = l_run[c] * alpha + psum;
-          const float vs = prefix ? a.v_scale : 1.0f;
-          if (vs != 1.0f) {
+          if constexpr (VSCALE) {  // fp8-style per-tensor V scale: prefix (cached) part only
+            const float vs = prefix ? a.v_scale : 1.0f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) sv[j] *= vs;
           }
@@ -445,10 +445,14 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
   const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
   if (mfma_ok) {
     const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
-    if (dk == 64)
-      hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR>), dim3(grid), dim3(256), 0, s, a);
-    else
-      hipLaunchKernelGGL((extend_mfma_kernel<T, 128, IdxT, LINEAR>), dim3(grid), dim3(256), 0, s, a);
+    const bool vs = a.v_scale != 1.0f;
+    if (dk == 64) {
+      if (vs) hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, true>), dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, false>), dim3(grid), dim3(256), 0, s, a);
+    } else {
+      if (vs) hipLaunchKernelGGL((extend_mfma_kernel<T, 128, IdxT, LINEAR, true>), dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((extend_mfma_kernel<T, 128, IdxT, LINEAR, false>), dim3(grid), dim3(256), 0, s, a);
+    }
   } else {
     if (dv > 512) return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: v_head_dim %d > 512", dv);
     const unsigned grid = static_cast<unsigned>(total_q * a.hq);
