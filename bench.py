@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--page-size", type=int, default=16)
     ap.add_argument("--index-mode", default="paged", choices=["paged", "indices"])
+    ap.add_argument("--kv-layout", default="hnd", choices=["nhd", "hnd"],
+                    help="hnd = [pages, Hkv, page, D] (MI355X-native default: a head's 16 tokens of a page are one "
+                         "contiguous 4 KiB run); nhd = [slots, Hkv, D] (the reference's default)")
     ap.add_argument("--max-kv-splits", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extend", action="store_true")
@@ -67,12 +70,20 @@ def build_world(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # dev dry-run of the multi-rank control flow on a 1-GPU box: RX_BENCH_BACKEND=gloo puts every
+    # rank on device 0 and reduces through the host (never used for reported numbers)
+    backend = os.environ.get("RX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     return rank, world, local_rank
 
 
@@ -92,7 +103,7 @@ def make_decode_state(args, tp, dev):
     distinct = L
     while distinct > 1 and distinct * per_layer > free_b - (12 << 30):
         distinct //= 2
-    pool = MHATokenToKVPool(size, ps, torch.bfloat16, hkv, D, distinct, dev)
+    pool = MHATokenToKVPool(size, ps, torch.bfloat16, hkv, D, distinct, dev, use_hnd=(args.kv_layout == "hnd"))
     g = torch.Generator(device=dev).manual_seed(42)
     for l in range(distinct):
         pool.k_buffer[l].normal_(generator=g)
@@ -394,12 +405,12 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[2]-shaped decode: Llama-3-8B bf16 attention path, bs=%d, ctx=%d, "
-                               "%d layers, page_size=%d shuffled pages, TP=%d (Hq=%d,Hkv=%d per GPU), "
+                               "%d layers, page_size=%d shuffled pages, %s KV layout, TP=%d (Hq=%d,Hkv=%d per GPU), "
                                "per layer: KV store + paged decode attention + o_proj GEMM%s"
-                               % (bs, ctx, L, args.page_size, world, st.hq, st.hkv,
+                               % (bs, ctx, L, args.page_size, args.kv_layout.upper(), world, st.hq, st.hkv,
                                   " + RCCL all-reduce (side stream)" if world > 1 else ""),
                    "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{world}",
-                   "index_mode": args.index_mode, "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
+                   "index_mode": args.index_mode, "kv_layout": args.kv_layout, "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
                    "kv_bytes_resident_per_gpu": int(sum(st.pool.get_kv_size_bytes()))},
         "roofline": roofline,
     }

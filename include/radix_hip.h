@@ -90,6 +90,15 @@ typedef struct rx_kv_layout {
   int64_t v_page_stride, v_tok_stride, v_head_stride;
 } rx_kv_layout;
 
+
+/* K1 for pools whose slot is not one contiguous row (HND [pages, Hkv, page, D]): 16-bit k [n, Hkv*Dk]
+ * / v [n, Hkv*Dv] rows (token strides in elements) scattered to the rx_kv_layout addresses.  The
+ * reference uses torch index_put for this layout (srt/mem_cache/memory_pool.py:2372-2379). */
+int rx_store_kv_layout(const void* k, const void* v, const rx_kv_layout* lay /* HOST */,
+                       const void* loc, int64_t n, int num_kv_heads, int head_dim, int v_head_dim,
+                       int64_t k_stride_t, int64_t v_stride_t, int loc_is_i64, int64_t size_limit,
+                       int64_t skip_index, int32_t* err_flag, void* stream);
+
 /* ---- K4/K5/K6: decode attention ---------------------------------------------------------
  * decode_attention_fwd (kernels/ops/attention/decode_attention.py:968-1044): stage 1
  * _fwd_grouped_kernel_stage1 (:383-608) / _fwd_kernel_stage1 (:96-281), stage 2

@@ -10,7 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "libradix_hip.so")
+# RX_LIB_NAME / RX_CFLAGS: developer knobs for A/B-ing kernel variants built side by side
+LIB_PATH = os.path.join(HERE, os.environ.get("RX_LIB_NAME", "libradix_hip.so"))
 SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_extend.hip", "rx_radix.cpp"]
 HEADERS = ["rx_common.h", os.path.join(ROOT, "include", "radix_hip.h")]
 
@@ -42,9 +43,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        obj = os.path.join(HERE, "build", os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(HERE, "build", os.path.splitext(src)[0] + os.environ.get("RX_LIB_NAME", "") + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
                "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-c", sp, "-o", obj]
+        cmd[1:1] = os.environ.get("RX_CFLAGS", "").split()
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

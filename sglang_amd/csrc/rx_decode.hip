@@ -67,6 +67,11 @@ template <bool LINEAR>
 __device__ __forceinline__ int64_t slot_offset(int64_t slot, int32_t page_size,
                                                int64_t page_stride, int64_t tok_stride) {
   if constexpr (LINEAR) return mul_u32(slot, tok_stride);
+  // page_size < 0 encodes a power-of-two page: -(log2(page) + 1)  (shift/mask instead of div/mod)
+  if (page_size < 0) {
+    const int sh = -page_size - 1;
+    return mul_u32(slot >> sh, page_stride) + mul_u32(slot & ((1 << sh) - 1), tok_stride);
+  }
   return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
 }
 
@@ -99,8 +104,23 @@ __device__ __forceinline__ void split_range(int32_t seq_len, int32_t splits, int
   hi = min(lo + per, seq_len);
 }
 
+#ifndef RX_DEC_MINW
+#define RX_DEC_MINW 1  // min waves per SIMD requested from the register allocator
+#endif
+#ifndef RX_DEC_NT
+#define RX_DEC_NT 0  // 1: non-temporal K/V loads
+#endif
+
+__device__ __forceinline__ u32x4 kv_load16(const uint16_t* p) {
+#if RX_DEC_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#else
+  return *reinterpret_cast<const u32x4*>(p);
+#endif
+}
+
 template <typename T, int D, typename IdxT, bool LINEAR>
-__global__ __launch_bounds__(256) void decode_mfma_kernel(const DecodeArgs a) {
+__global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const DecodeArgs a) {
   using vec8 = typename T::vec8;
   constexpr int KS = D / 32;  // k-steps of the QK^T product
   constexpr int NB = D / 16;  // 16-wide d blocks of the output
@@ -184,13 +204,13 @@ __global__ __launch_bounds__(256) void decode_mfma_kernel(const DecodeArgs a) {
     const int64_t vo1 = slot_offset<LINEAR>(s1, a.page_size, a.v_page_stride, a.v_tok_stride);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      kf[0][s] = *reinterpret_cast<const u32x4*>(kbase + ko0 + 32 * s);
-      kf[1][s] = *reinterpret_cast<const u32x4*>(kbase + ko1 + 32 * s);
+      kf[0][s] = kv_load16(kbase + ko0 + 32 * s);
+      kf[1][s] = kv_load16(kbase + ko1 + 32 * s);
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      vf[0][s] = *reinterpret_cast<const u32x4*>(vbase + vo0 + 32 * s);
-      vf[1][s] = *reinterpret_cast<const u32x4*>(vbase + vo1 + 32 * s);
+      vf[0][s] = kv_load16(vbase + vo0 + 32 * s);
+      vf[1][s] = kv_load16(vbase + vo1 + 32 * s);
     }
   };
 
@@ -535,6 +555,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.k_buf = (const uint16_t*)p->kv.k_buf;
   a.v_buf = (const uint16_t*)p->kv.v_buf;
   a.page_size = p->kv.page_size;
+  if ((a.page_size & (a.page_size - 1)) == 0) a.page_size = -(__builtin_ctz(a.page_size) + 1);
   a.k_page_stride = p->kv.k_page_stride;
   a.k_tok_stride = p->kv.k_tok_stride;
   a.k_head_stride = p->kv.k_head_stride;

@@ -53,6 +53,10 @@ template <bool LINEAR>
 __device__ __forceinline__ int64_t slot_off(int64_t slot, int32_t page_size, int64_t page_stride,
                                             int64_t tok_stride) {
   if constexpr (LINEAR) return mul_u32(slot, tok_stride);
+  if (page_size < 0) {  // power-of-two page: -(log2(page) + 1)
+    const int sh = -page_size - 1;
+    return mul_u32(slot >> sh, page_stride) + mul_u32(slot & ((1 << sh) - 1), tok_stride);
+  }
   return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
 }
 
@@ -513,6 +517,7 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   a.k_buf = (const uint16_t*)p->kv.k_buf;
   a.v_buf = (const uint16_t*)p->kv.v_buf;
   a.page_size = p->kv.page_size;
+  if ((a.page_size & (a.page_size - 1)) == 0) a.page_size = -(__builtin_ctz(a.page_size) + 1);
   a.k_page_stride = p->kv.k_page_stride;
   a.k_tok_stride = p->kv.k_tok_stride;
   a.k_head_stride = p->kv.k_head_stride;

@@ -47,6 +47,38 @@ __global__ __launch_bounds__(256) void store_kv_kernel(
     *reinterpret_cast<V*>(vdst + off) = *reinterpret_cast<const V*>(vsrc + off);
 }
 
+
+// K1 for paged (HND) pools: dst(slot, head) = (slot/page)*page_stride + (slot%page)*tok_stride +
+// head*head_stride.  The reference scatters with torch index_put for this layout
+// (memory_pool.py:2372-2379); here one wave per token walks the heads with 16-byte vectors.
+__global__ __launch_bounds__(256) void store_kv_layout_kernel(
+    const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, uint16_t* __restrict__ kc,
+    uint16_t* __restrict__ vc, const void* __restrict__ loc, int64_t n, int hkv, int dk, int dv,
+    int64_t k_stride_t, int64_t v_stride_t, int page_size, int64_t kps, int64_t kts, int64_t khs,
+    int64_t vps, int64_t vts, int64_t vhs, int loc64, int64_t size_limit, int64_t skip_index,
+    int32_t* err_flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t idx = load_idx(loc, row, loc64);
+  if (idx == skip_index) return;
+  if (idx < 0 || idx >= size_limit) {
+    if (lane == 0 && err_flag) atomicOr(err_flag, RX_DEVERR_SLOT_OOB);
+    return;
+  }
+  const int64_t pg = idx / page_size, off = idx % page_size;
+  for (int e = lane * 8; e < hkv * dk; e += 64 * 8) {  // 8 elements = 16 B per lane
+    const int h = e / dk, d = e % dk;
+    *reinterpret_cast<u32x4*>(kc + pg * kps + off * kts + h * khs + d) =
+        *reinterpret_cast<const u32x4*>(k + row * k_stride_t + e);
+  }
+  for (int e = lane * 8; e < hkv * dv; e += 64 * 8) {
+    const int h = e / dv, d = e % dv;
+    *reinterpret_cast<u32x4*>(vc + pg * vps + off * vts + h * vhs + d) =
+        *reinterpret_cast<const u32x4*>(v + row * v_stride_t + e);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // K2  kv_indptr scan + ragged gather of req_to_token rows.
 // Reference: create_flashinfer_kv_indices_triton (kv_indices.py:8-46), grid (bs,), 512-wide.
@@ -320,6 +352,30 @@ int rx_store_kv(const void* k, const void* v, void* k_cache, void* v_cache, cons
                        k_stride_bytes, v_stride_bytes, kc_stride_bytes, vc_stride_bytes,
                        loc_is_i64, size_limit, skip_index, err_flag);
   return check_launch("rx_store_kv");
+}
+
+
+int rx_store_kv_layout(const void* k, const void* v, const rx_kv_layout* lay, const void* loc,
+                       int64_t n, int num_kv_heads, int head_dim, int v_head_dim,
+                       int64_t k_stride_t, int64_t v_stride_t, int loc_is_i64, int64_t size_limit,
+                       int64_t skip_index, int32_t* err_flag, void* stream) {
+  RX_REQUIRE(n >= 0, "rx_store_kv_layout: n < 0");
+  if (n == 0) return RX_OK;
+  RX_REQUIRE(k && v && lay && lay->k_buf && lay->v_buf && loc, "rx_store_kv_layout: null pointer");
+  RX_REQUIRE(num_kv_heads > 0 && head_dim > 0 && v_head_dim > 0 && head_dim % 8 == 0 &&
+                 v_head_dim % 8 == 0,
+             "rx_store_kv_layout: head dims must be positive multiples of 8 (16-bit elements)");
+  const int64_t all = k_stride_t | v_stride_t | lay->k_page_stride | lay->k_tok_stride |
+                      lay->k_head_stride | lay->v_page_stride | lay->v_tok_stride | lay->v_head_stride;
+  RX_REQUIRE(all % 8 == 0 && lay->page_size >= 1 && size_limit > 0,
+             "rx_store_kv_layout: strides must be multiples of 8 elements");
+  hipLaunchKernelGGL(store_kv_layout_kernel, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), (const uint16_t*)k, (const uint16_t*)v,
+                     (uint16_t*)lay->k_buf, (uint16_t*)lay->v_buf, loc, n, num_kv_heads, head_dim,
+                     v_head_dim, k_stride_t, v_stride_t, lay->page_size, lay->k_page_stride,
+                     lay->k_tok_stride, lay->k_head_stride, lay->v_page_stride, lay->v_tok_stride,
+                     lay->v_head_stride, loc_is_i64, size_limit, skip_index, err_flag);
+  return check_launch("rx_store_kv_layout");
 }
 
 int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,

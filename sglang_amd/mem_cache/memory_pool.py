@@ -94,6 +94,7 @@ class MHATokenToKVPool:
         self._create_buffers()
         self._build_ptr_tables()
         self._store_launchers = [None] * layer_num
+        self._hnd_layouts = [None] * layer_num
 
     def _kv_buffer_shapes(self):
         if self.use_hnd:
@@ -155,10 +156,12 @@ class MHATokenToKVPool:
         li = layer_id - self.start_layer
         if self.use_hnd:
             # a slot is [page, :, off, :]: scatter by (page, off) (memory_pool.py:2372-2379)
-            pages = loc // self.page_size
-            offs = loc % self.page_size
-            self.k_buffer[li][pages, :, offs, :] = cache_k
-            self.v_buffer[li][pages, :, offs, :] = cache_v
+            lay = self._hnd_layouts[li]
+            if lay is None:
+                lay = self._hnd_layouts[li] = ops.kv_layout_hnd(self.k_buffer[li], self.v_buffer[li])
+            ops.store_cache_layout(cache_k, cache_v, lay, loc, self.head_num, self.head_dim,
+                                   self.v_head_dim, size_limit=self.num_pages * self.page_size,
+                                   err_flag=self.err_flag)
             return
         n = loc.shape[0]
         k2 = cache_k.reshape(n, self.row_dim) if cache_k.dim() == 3 else cache_k

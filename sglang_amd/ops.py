@@ -79,6 +79,22 @@ def store_cache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache
     _L.check(st, "rx_store_kv")
 
 
+def store_cache_layout(k, v, layout: "_L.RxKvLayout", indices, num_kv_heads, head_dim, v_head_dim, *,
+                       size_limit: int, reserved_skip_index: int = 0, err_flag=None) -> None:
+    """KV store into a pool addressed by an rx_kv_layout (HND pools): k [n, Hkv*Dk], v [n, Hkv*Dv]."""
+    _require_cuda(k, v, indices)
+    k2 = k.reshape(k.shape[0], -1)
+    v2 = v.reshape(v.shape[0], -1)
+    if k2.stride(-1) != 1 or v2.stride(-1) != 1:
+        raise ValueError("store_cache_layout: innermost dimension must be contiguous")
+    idx = indices if indices.is_contiguous() else indices.contiguous()
+    st = _L.load().rx_store_kv_layout(_ptr(k2), _ptr(v2), C.byref(layout), _ptr(idx), k2.shape[0],
+                                      num_kv_heads, head_dim, v_head_dim, k2.stride(0), v2.stride(0),
+                                      _is64(idx, "indices"), size_limit, reserved_skip_index,
+                                      _ptr(err_flag), _stream(k2))
+    _L.check(st, "rx_store_kv_layout")
+
+
 # --------------------------------------------------------------------------------------
 # K2  kv-index build         kernels/ops/kvcache/kv_indices.py:8-46 (+ triton_backend.py:386-404)
 # --------------------------------------------------------------------------------------

@@ -269,3 +269,103 @@ def test_mla_latent_pool_and_decode():
                                         np.array(rows), np.array(lens), layer.scaling)
     got = o.view(bs, hq, rank).float().cpu().numpy()
     assert np.abs(got - want).max() <= 1e-2
+
+
+def test_hnd_pool_store_and_decode():
+    """HND pool [pages, Hkv, page, D] (memory_pool.py:2032-2036): rx_store_kv_layout scatter +
+    paged decode through the backend equal the NHD result bit for bit."""
+    from sglang_amd.attention.backend import HipRadixAttnBackend
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+    from sglang_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
+
+    hq, hkv, d, ps = 8, 2, 128, 16
+    lens = [40, 17, 129]
+    g = torch.Generator().manual_seed(0)
+    outs = []
+    for use_hnd in (False, True):
+        pool = MHATokenToKVPool(512, ps, torch.bfloat16, hkv, d, 1, DEV, use_hnd=use_hnd)
+        r2t = ReqToTokenPool(4, 256, DEV)
+        rows = r2t.alloc(3)
+        layer = RadixAttention(hq, d, d ** -0.5, hkv, 0)
+        gg = torch.Generator().manual_seed(1)
+        perm = torch.randperm(511, generator=gg) + 1
+        off = 0
+        for r, n in zip(rows, lens):
+            slots = perm[off: off + n].to(DEV); off += n
+            r2t.req_to_token[r, :n] = slots.int()
+            k = torch.randn(n, hkv, d, generator=gg).to(torch.bfloat16).to(DEV)
+            v = torch.randn(n, hkv, d, generator=gg).to(torch.bfloat16).to(DEV)
+            pool.set_kv_buffer(layer, slots, k, v)
+            if use_hnd:  # the scatter landed at [page, head, off, :]
+                kb = pool.get_key_buffer(0)
+                assert torch.equal(kb[slots // ps, :, slots % ps, :], k)
+
+        class MC:
+            num_attention_heads, num_key_value_heads, context_len = hq, hkv, 256
+
+        class MR:
+            device = DEV
+            req_to_token_pool = r2t
+            token_to_kv_pool = pool
+            model_config = MC
+            page_size = ps
+
+        be = HipRadixAttnBackend(MR)
+        rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+        seq = torch.tensor(lens, dtype=torch.int64)
+        q = torch.randn(3, hq * d, generator=gg).to(torch.bfloat16).to(DEV)
+        fb = ForwardBatch.for_decode(rpi, seq.to(DEV), None, seq)
+        be.init_forward_metadata(fb)
+        outs.append(be.forward_decode(q, None, None, layer, fb, save_kv_cache=False))
+        assert pool.check_errors() == 0
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_hnd_pool_extend_with_prefix():
+    """Extend (prefix gathered from an HND pool through the shift/mask page addressing)."""
+    from sglang_amd.attention.backend import HipRadixAttnBackend
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+    from sglang_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
+
+    hq, hkv, d, ps = 8, 2, 128, 16
+    pre, ext = [48, 0, 130], [20, 70, 3]
+    outs = []
+    for use_hnd in (False, True):
+        pool = MHATokenToKVPool(1024, ps, torch.float16, hkv, d, 1, DEV, use_hnd=use_hnd)
+        r2t = ReqToTokenPool(4, 512, DEV)
+        rows = r2t.alloc(3)
+        layer = RadixAttention(hq, d, d ** -0.5, hkv, 0)
+        gg = torch.Generator().manual_seed(1)
+        perm = torch.randperm(1023, generator=gg) + 1
+        off, locs = 0, []
+        for r, p, e in zip(rows, pre, ext):
+            slots = perm[off: off + p + e].to(DEV); off += p + e
+            r2t.req_to_token[r, : p + e] = slots.int()
+            if p:
+                pool.set_kv_buffer(layer, slots[:p], torch.randn(p, hkv, d, generator=gg).half().to(DEV),
+                                   torch.randn(p, hkv, d, generator=gg).half().to(DEV))
+            locs.append(slots[p:])
+
+        class MC:
+            num_attention_heads, num_key_value_heads, context_len = hq, hkv, 512
+
+        class MR:
+            device = DEV
+            req_to_token_pool = r2t
+            token_to_kv_pool = pool
+            model_config = MC
+            page_size = ps
+
+        be = HipRadixAttnBackend(MR)
+        T = sum(ext)
+        q = torch.randn(T, hq * d, generator=gg).half().to(DEV)
+        k = torch.randn(T, hkv * d, generator=gg).half().to(DEV)
+        v = torch.randn(T, hkv * d, generator=gg).half().to(DEV)
+        fb = ForwardBatch.for_extend(torch.tensor(rows, device=DEV), torch.tensor([p + e for p, e in zip(pre, ext)], device=DEV),
+                                     torch.cat(locs), pre, ext)
+        be.init_forward_metadata(fb)
+        outs.append(layer(q, k, v, fb, be))
+        assert pool.check_errors() == 0
+    assert torch.equal(outs[0], outs[1])
