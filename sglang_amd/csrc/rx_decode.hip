@@ -507,6 +507,17 @@ static int dispatch_decode(const DecodeArgs& a, int dk, int dv, bool idx64, bool
                 : launch_decode<T, int32_t, false>(a, dk, dv, s);
 }
 
+int launch_decode_mla(const rx_decode_params* p, hipStream_t s);  // rx_decode_mla.hip
+
+template <typename T>
+static int run_mla(const rx_decode_params* p, const DecodeArgs& a, hipStream_t s) {
+  const int rc = launch_decode_mla(p, s);
+  if (rc != RX_OK) return rc;
+  if (a.max_kv_splits > 1)
+    hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(a.bs * a.hq), dim3(128), 0, s, a, p->v_head_dim);
+  return check_launch("rx_decode_attn(mla)");
+}
+
 }  // namespace rx
 
 using namespace rx;
@@ -588,6 +599,13 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
   const bool idx64 = mode_a && p->kv_indices_is_i64;
   auto s = static_cast<hipStream_t>(stream);
+  // MLA latent rows: Dk 576 / Dv 512, one kv head, V = the first 512 columns of the K rows
+  const bool mla = dk == 576 && dv == 512 && p->num_kv_heads == 1 && p->kv.v_buf == p->kv.k_buf &&
+                   p->kv.v_tok_stride == p->kv.k_tok_stride && p->kv.v_page_stride == p->kv.k_page_stride &&
+                   ((p->q_stride_t | p->q_stride_h | p->kv.k_tok_stride | p->kv.k_page_stride) % 8 == 0) &&
+                   (((uintptr_t)p->q | (uintptr_t)p->kv.k_buf) & 15) == 0 &&
+                   ((p->o_stride_t | p->o_stride_h) % 4 == 0) && ((uintptr_t)p->o & 7) == 0;
+  if (mla) return p->dtype == RX_BF16 ? run_mla<BF16>(p, a, s) : run_mla<F16>(p, a, s);
   return p->dtype == RX_BF16 ? dispatch_decode<BF16>(a, dk, dv, idx64, linear, s)
                              : dispatch_decode<F16>(a, dk, dv, idx64, linear, s);
 }

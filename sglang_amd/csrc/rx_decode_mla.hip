@@ -1,0 +1,328 @@
+// MLA (absorbed) decode attention for gfx950: Dk = 576 (512 latent + 64 rope), Dv = 512, Hkv = 1,
+// V = the first 512 columns of the SAME latent rows.
+//
+// Reference: the HAS_MLA branch of _fwd_grouped_kernel_stage1
+// (kernels/ops/attention/decode_attention.py:383-608, v = trans(k) at :556-557, BLOCK_DMODEL=512 /
+// BLOCK_DPE=64 at :638-646), driven by TritonAttnBackend.forward_decode
+// (srt/layers/attention/triton_backend.py:1739-1757,1858) over MLATokenToKVPool
+// (srt/mem_cache/memory_pool.py:3906-4179).  Same split-KV scratch contract and stage 2 as the
+// dense path (rx_decode.hip).
+//
+// MI355X design.  A latent row is 1152 B (bf16) and is needed twice: all 576 columns for q.k and
+// the first 512 for p.v.  One workgroup (4 waves) = one (request, 16-head q block, kv split):
+//   * 32-token tiles are staged ONCE per workgroup: whole 1152-B rows, coalesced 16 B/lane,
+//     HBM -> registers (issued one tile ahead) -> LDS (double buffered, one barrier per tile).
+//     Every HBM byte is read once and serves both products.
+//   * the 16 q heads sit on the N axis of v_mfma_f32_16x16x32 -- MLA's 16 heads per GPU at TP=8
+//     fill the tile exactly.  Each wave computes the full S^T = K Q^T (18 k-steps x 2 token blocks;
+//     redundant across the 4 waves, but MFMA is ~10 % busy in this HBM-bound kernel and it makes
+//     the softmax statistics identical in every wave: no cross-wave exchange at all).
+//   * each wave owns one 128-column slice of Dv: O^T[128w..128w+128) += V^T P^T with V^T fragments
+//     read transposed (ds_read_b64_tr_b16) straight out of the staged K rows.
+// Rows are padded to 1168 B in LDS (stride = 73 x 16 B, odd in 16-B units) to spread the banks.
+#include "rx_common.h"
+
+namespace rx {
+
+struct MlaArgs {
+  const uint16_t* q;
+  uint16_t* o;
+  int64_t q_stride_t, q_stride_h, o_stride_t, o_stride_h;
+  const uint16_t* kv_buf;
+  int32_t page_size;  // encoded like DecodeArgs (negative = power of two)
+  int64_t page_stride, tok_stride;
+  const int32_t* kv_indptr;
+  const void* kv_indices;
+  const int32_t* req_to_token;
+  int64_t req_row_stride;
+  const void* req_pool_indices;
+  int32_t rpi64;
+  const void* seq_lens;
+  int32_t sl64;
+  const int32_t* num_kv_splits;
+  int32_t max_kv_splits;
+  float* attn_logits;
+  float* attn_lse;
+  int32_t bs, hq, qblocks;
+  float sm_scale, v_scale, logit_cap;
+  const float* sinks;
+};
+
+constexpr int kMlaDk = 576, kMlaDv = 512;
+constexpr int kMlaTile = 32;
+constexpr int kMlaRowBytes = kMlaDk * 2;          // 1152
+constexpr int kMlaLdsRow = kMlaRowBytes + 16;     // 1168: padded LDS row stride
+constexpr int kMlaChunks = kMlaRowBytes / 16;     // 72 16-byte chunks per row
+constexpr int kMlaStage = kMlaTile * kMlaChunks / 256;  // 9 chunks per thread per tile
+
+template <bool LINEAR>
+__device__ __forceinline__ int64_t mla_slot_off(int64_t slot, int32_t page_size, int64_t page_stride,
+                                                int64_t tok_stride) {
+  if constexpr (LINEAR) return mul_u32(slot, tok_stride);
+  if (page_size < 0) {
+    const int sh = -page_size - 1;
+    return mul_u32(slot >> sh, page_stride) + mul_u32(slot & ((1 << sh) - 1), tok_stride);
+  }
+  return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
+}
+
+template <typename T, typename IdxT, bool LINEAR>
+__global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
+  using vec8 = typename T::vec8;
+  constexpr int KS = kMlaDk / 32;       // 18 k-steps
+  constexpr int NBW = kMlaDv / 16 / 4;  // 8 d-blocks of 16 per wave
+  __shared__ __attribute__((aligned(16))) char smem[2 * kMlaTile * kMlaLdsRow];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  int bid = blockIdx.x;  // split slowest (XCD balance, see rx_decode.hip)
+  const int qb = bid % a.qblocks;
+  bid /= a.qblocks;
+  const int b = bid % a.bs;
+  const int split = bid / a.bs;
+
+  int32_t seq_len;
+  const IdxT* idx;
+  if (a.kv_indices) {
+    const int32_t beg = a.kv_indptr[b];
+    seq_len = a.kv_indptr[b + 1] - beg;
+    idx = reinterpret_cast<const IdxT*>(a.kv_indices) + beg;
+  } else {
+    const int64_t req = load_idx(a.req_pool_indices, b, a.rpi64);
+    seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
+    idx = reinterpret_cast<const IdxT*>(a.req_to_token + req * a.req_row_stride);
+  }
+  const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
+  const bool single = (a.max_kv_splits == 1);
+  const int h = qb * 16 + r;
+  const bool q_valid = h < a.hq;
+  if (split >= splits) return;
+  const int32_t per = ((seq_len + splits - 1) / splits + 31) / 32 * 32;  // decode_attention.py:466-472
+  const int32_t lo = per * split;
+  const int32_t hi = min(lo + per, seq_len);
+  if (hi <= lo) {
+    if (single && seq_len == 0)
+      for (int i = tid; i < 16 * kMlaDv; i += 256) {
+        const int q = i / kMlaDv, d = i % kMlaDv;
+        if (qb * 16 + q < a.hq) a.o[b * a.o_stride_t + (qb * 16 + q) * a.o_stride_h + d] = 0;
+      }
+    return;
+  }
+  const int ntiles = (hi - lo + kMlaTile - 1) / kMlaTile;
+
+  // ---- Q^T fragments for all 18 k-steps (72 VGPRs) ------------------------------------------------
+  vec8 qf[KS];
+  {
+    const uint16_t* qp = a.q + b * a.q_stride_t + (q_valid ? h : 0) * a.q_stride_h + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      u32x4 raw = q_valid ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
+      qf[s] = __builtin_bit_cast(vec8, raw);
+    }
+  }
+
+  // ---- cooperative staging: thread handles chunks c = tid + 256 i, row = c / 72, col = c % 72 ------
+  int st_row[kMlaStage], st_col[kMlaStage];
+#pragma unroll
+  for (int i = 0; i < kMlaStage; ++i) {
+    const int c = tid + 256 * i;
+    st_row[i] = c / kMlaChunks;
+    st_col[i] = c % kMlaChunks;
+  }
+  u32x4 stg[kMlaStage];
+  int32_t slot_n[kMlaStage];  // slots of the tile whose loads are issued next (fetched a tile early)
+  auto load_slots = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < kMlaStage; ++i)
+      slot_n[i] = static_cast<int32_t>(idx[min(lo + t * kMlaTile + st_row[i], hi - 1)]);
+  };
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < kMlaStage; ++i)
+      stg[i] = *reinterpret_cast<const u32x4*>(
+          a.kv_buf + mla_slot_off<LINEAR>(slot_n[i], a.page_size, a.page_stride, a.tok_stride) +
+          8 * st_col[i]);
+  };
+  auto write_lds = [&](int buf) {
+    char* kt = smem + buf * kMlaTile * kMlaLdsRow;
+#pragma unroll
+    for (int i = 0; i < kMlaStage; ++i)
+      *reinterpret_cast<u32x4*>(kt + st_row[i] * kMlaLdsRow + st_col[i] * 16) = stg[i];
+  };
+
+  f32x4 oacc[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c2 = (a.logit_cap > 0.f) ? kLog2e : a.sm_scale * kLog2e;
+
+  load_slots(0);
+  issue_loads();
+  if (ntiles > 1) load_slots(1);
+  write_lds(0);
+  if (ntiles > 1) {
+    issue_loads();
+    if (ntiles > 2) load_slots(2);
+  }
+  __syncthreads();
+
+  const int qd = r >> 2, pp = r & 3;
+  for (int t = 0; t < ntiles; ++t) {
+    const char* kt = smem + (t & 1) * kMlaTile * kMlaLdsRow;
+    // ---- S^T = K Q^T over all 576 columns --------------------------------------------------------
+    f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const vec8 ka = __builtin_bit_cast(
+            vec8, *reinterpret_cast<const u32x4*>(kt + (16 * bb + r) * kMlaLdsRow + (4 * s + g) * 16));
+        sacc[bb] = T::mfma(ka, qf[s], sacc[bb]);
+      }
+    }
+    // ---- online softmax (identical in all four waves) -----------------------------------------------
+    float sv[8];
+    const int tok_base = lo + t * kMlaTile + 4 * g;
+    float mt = -INFINITY;
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float x = sacc[bb][i];
+        if (a.logit_cap > 0.f) x = a.logit_cap * tanhf(x * a.sm_scale / a.logit_cap);
+        x = (tok_base + 16 * bb + i < hi) ? x : -INFINITY;
+        sv[bb * 4 + i] = x;
+        mt = fmaxf(mt, x);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16));
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    mt *= c2;
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+      psum += sv[j];
+    }
+    l_run = l_run * alpha + psum;
+    u32x4 praw;
+    praw[0] = pack2<T>(sv[0], sv[1]);
+    praw[1] = pack2<T>(sv[2], sv[3]);
+    praw[2] = pack2<T>(sv[4], sv[5]);
+    praw[3] = pack2<T>(sv[6], sv[7]);
+    const vec8 pf = __builtin_bit_cast(vec8, praw);
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) oacc[nb] *= alpha;
+    }
+    // ---- O^T[128w + ...] += V^T P^T, V = columns [0,512) of the staged rows -------------------------
+    {
+      const char* rp0 = kt + (4 * g + qd) * kMlaLdsRow + (128 * w) * 2 + 8 * pp;
+      const char* rp1 = rp0 + 16 * kMlaLdsRow;
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        const u32x2 lo2 = T::ds_read_tr(rp0 + nb * 32);
+        const u32x2 hi2 = T::ds_read_tr(rp1 + nb * 32);
+        const vec8 av = __builtin_bit_cast(vec8, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]});
+        oacc[nb] = T::mfma(av, pf, oacc[nb]);
+      }
+    }
+    // ---- stage the next tile into the other buffer -------------------------------------------------
+    if (t + 1 < ntiles) {
+      write_lds((t + 1) & 1);
+      if (t + 2 < ntiles) {
+        issue_loads();
+        if (t + 3 < ntiles) load_slots(t + 3);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: every wave holds the full statistics and its own 128 output columns -------------
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  if (!q_valid) return;
+  if (single) {
+    float den = l_run;
+    if (a.sinks) den += fast_exp2(a.sinks[h] * kLog2e - m_run);
+    const float inv = a.v_scale / den;
+    uint16_t* op = a.o + b * a.o_stride_t + h * a.o_stride_h + 128 * w + 4 * g;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      u32x2 pk;
+      pk[0] = pack2<T>(oacc[nb][0] * inv, oacc[nb][1] * inv);
+      pk[1] = pack2<T>(oacc[nb][2] * inv, oacc[nb][3] * inv);
+      *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
+    }
+  } else {
+    const int64_t row = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits + split;
+    const float inv = 1.0f / l_run;
+    float* lp = a.attn_logits + row * kMlaDv + 128 * w + 4 * g;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) *reinterpret_cast<f32x4*>(lp + 16 * nb) = oacc[nb] * inv;
+    if (w == 0 && g == 0) a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
+  }
+}
+
+}  // namespace rx
+
+namespace rx {
+// called from rx_decode_attn (rx_decode.hip) when head_dim == 576 and v_head_dim == 512, Hkv == 1
+// and V aliases K's first 512 columns
+int launch_decode_mla(const rx_decode_params* p, hipStream_t s) {
+  MlaArgs a;
+  a.q = (const uint16_t*)p->q;
+  a.o = (uint16_t*)p->o;
+  a.q_stride_t = p->q_stride_t;
+  a.q_stride_h = p->q_stride_h;
+  a.o_stride_t = p->o_stride_t;
+  a.o_stride_h = p->o_stride_h;
+  a.kv_buf = (const uint16_t*)p->kv.k_buf;
+  a.page_size = p->kv.page_size;
+  if ((a.page_size & (a.page_size - 1)) == 0) a.page_size = -(__builtin_ctz(a.page_size) + 1);
+  a.page_stride = p->kv.k_page_stride;
+  a.tok_stride = p->kv.k_tok_stride;
+  a.kv_indptr = p->kv_indptr;
+  a.kv_indices = p->kv_indices;
+  a.req_to_token = p->req_to_token;
+  a.req_row_stride = p->req_row_stride;
+  a.req_pool_indices = p->req_pool_indices;
+  a.rpi64 = p->req_pool_indices_is_i64;
+  a.seq_lens = p->seq_lens;
+  a.sl64 = p->seq_lens_is_i64;
+  const int max_splits = p->max_kv_splits < 1 ? 1 : p->max_kv_splits;
+  a.num_kv_splits = max_splits > 1 ? p->num_kv_splits : nullptr;
+  a.max_kv_splits = max_splits;
+  a.attn_logits = p->attn_logits;
+  a.attn_lse = p->attn_lse;
+  a.bs = p->bs;
+  a.hq = p->num_q_heads;
+  a.qblocks = (p->num_q_heads + 15) / 16;
+  a.sm_scale = p->sm_scale * p->k_scale;
+  a.v_scale = p->v_scale;
+  a.logit_cap = p->logit_cap;
+  a.sinks = p->sinks;
+  const bool linear = p->kv.page_size == 1 || p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride;
+  const bool idx64 = p->kv_indices != nullptr && p->kv_indices_is_i64;
+  const unsigned grid = static_cast<unsigned>(a.bs) * a.qblocks * a.max_kv_splits;
+#define RX_MLA_GO(TT)                                                                                \
+  do {                                                                                               \
+    if (idx64) {                                                                                     \
+      if (linear) hipLaunchKernelGGL((decode_mla_kernel<TT, int64_t, true>), dim3(grid), dim3(256), 0, s, a);  \
+      else hipLaunchKernelGGL((decode_mla_kernel<TT, int64_t, false>), dim3(grid), dim3(256), 0, s, a);        \
+    } else {                                                                                         \
+      if (linear) hipLaunchKernelGGL((decode_mla_kernel<TT, int32_t, true>), dim3(grid), dim3(256), 0, s, a);  \
+      else hipLaunchKernelGGL((decode_mla_kernel<TT, int32_t, false>), dim3(grid), dim3(256), 0, s, a);        \
+    }                                                                                                \
+  } while (0)
+  if (p->dtype == RX_BF16) RX_MLA_GO(BF16);
+  else RX_MLA_GO(F16);
+#undef RX_MLA_GO
+  return RX_OK;
+}
+}  // namespace rx

@@ -429,3 +429,49 @@ def test_move_kv_and_write_req_to_token(ops):
     assert got[4, :8].tolist() == [100, 101, 102, 1000, 1001, 1002, 1003, 1004]
     assert got[1, :4].tolist() == [1005, 1006, 1007, 1008]
     assert got[2, :30].tolist() == list(range(200, 210)) + list(range(1009, 1029))
+
+
+# ---------------------------------------------------------------------------- MLA decode kernel
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,page_size", [(16, 1), (128, 16), (5, 64)])
+def test_decode_mla_kernel(ops, dtype, hq, page_size):
+    """rx::decode_mla_kernel (Dk 576 / Dv 512, V = first 512 columns of the latent rows): single pass
+    and split-KV + stage 2, ragged lengths incl. tile-boundary cases, vs the fp64 oracle.
+    Shapes of the reference's MLA test (test_triton_attention_kernels.py:674: (2,128,1,576,512))."""
+    rng = np.random.default_rng(hq + page_size)
+    lens = np.array([1, 31, 32, 33, 700, 64, 2049], dtype=np.int64)
+    bs = len(lens)
+    g = torch.Generator().manual_seed(hq)
+    npages = int(sum((n + page_size - 1) // page_size for n in lens)) + 2
+    pool = npages * page_size
+    kv = torch.randn(pool, 1, 576, generator=g).to(dtype)
+    q = torch.randn(bs, hq, 576, generator=g).to(dtype)
+    pages = rng.permutation(np.arange(1, npages))
+    r2t = np.zeros((bs + 1, 2100), dtype=np.int32)
+    pi = 0
+    for i, n in enumerate(lens):
+        k = (n + page_size - 1) // page_size
+        sl = np.concatenate([np.arange(p * page_size, (p + 1) * page_size) for p in pages[pi: pi + k]]); pi += k
+        r2t[i + 1, :n] = sl[:n]
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    sm = (128 + 64) ** -0.5
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
+    kvn = _np(kv)
+    want = orc.decode_attention(_np(q), kvn, kvn[..., :512], kv_indptr, kv_indices, sm)
+    tol = 3e-3 if dtype == torch.float16 else 1e-2
+    kvd, qd = kv.to(DEV), q.to(DEV)
+    o = torch.zeros(bs, hq, 512, dtype=dtype, device=DEV)
+    ops.decode_attention_fwd_paged(qd, kvd, kvd[..., :512], o, _t(r2t), _t(rpi), _t(lens), None, None, None, 1, sm,
+                                   page_size=page_size)
+    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
+    assert err <= tol, ("single", err)
+    S = 8
+    nsplit = torch.zeros(bs, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits(nsplit, _t(lens).int(), hq, 1, S, 256)
+    al = torch.zeros(bs, hq, S, 512, dtype=torch.float32, device=DEV)
+    lse = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+    o2 = torch.zeros_like(o)
+    ops.decode_attention_fwd(qd, kvd, kvd[..., :512], o2, _t(kv_indptr), _t(kv_indices), al, lse, nsplit, S, sm,
+                             1.0, 1.0, page_size=page_size)
+    err2 = np.abs(_np(o2.float()).astype(np.float64) - want).max()
+    assert err2 <= tol, ("split", err2)
