@@ -107,6 +107,20 @@ __device__ __forceinline__ int64_t mul_u32(int64_t slot, int64_t stride) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// max over the four lanes {l, l^16, l^32, l^48} that hold one query's scores in the S^T accumulator
+// layout.  gfx950 half/row swaps (v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute
+// round trips through the LDS crossbar: no lgkmcnt wait on the softmax critical path.  Inline asm
+// because hipcc (ROCm 7.2) folds fmax(r[0], r[1]) of the builtin's result pair away; the s_nop's are
+// the VALU-write -> permlane-read wait states (cdna_hip_programming.md T21).
+__device__ __forceinline__ float quad_row_max(float x) {
+  float a = x, b = x;
+  asm volatile(
+      "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1\n\t"
+      "v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1"
+      : "+v"(a), "+v"(b));
+  return a;
+}
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 

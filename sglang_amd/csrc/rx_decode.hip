@@ -268,8 +268,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
         sv[bb * 4 + i] = x;
         mt = fmaxf(mt, x);
       }
-    mt = fmaxf(mt, __shfl_xor(mt, 16));
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    mt = quad_row_max(mt);
     const float m_new = fmaxf(m_run, mt);
     const float alpha = fast_exp2(m_run - m_new);
     m_run = m_new;

@@ -197,8 +197,7 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
         sv[bb * 4 + i] = x;
         mt = fmaxf(mt, x);
       }
-    mt = fmaxf(mt, __shfl_xor(mt, 16));
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    mt = quad_row_max(mt);
     mt *= c2;
     const float m_new = fmaxf(m_run, mt);
     const float alpha = fast_exp2(m_run - m_new);

@@ -226,6 +226,17 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
             sacc[1][bb] = T::mfma(ka, qf[1][s], sacc[1][bb]);
           }
         }
+        // ---- V^T fragments of the first half of the d blocks: issued BEFORE the softmax math so the
+        // LDS round trip hides under it (they depend on the staged tile only, not on P) ------------------
+        const char* rp0 = vt + (32 * hh + vrow0) * ROW_BYTES + 8 * (pp & 1);
+        const char* rp1 = rp0 + 16 * ROW_BYTES;
+        u32x2 vlo[NB], vhi[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB / 2; ++nb) {
+          const int chunk = ((2 * nb + (pp >> 1)) ^ swv) & (CPR - 1);
+          vlo[nb] = T::ds_read_tr(rp0 + chunk * 16);
+          vhi[nb] = T::ds_read_tr(rp1 + chunk * 16);
+        }
         // ---- masks + online softmax (lane = one query per block c, 8 tokens) -------------------------
         bool full;  // every (query, token) pair of this half is visible: skip the mask code
         if (prefix) full = (n0 + 32 <= p_len) && a.window <= 0;
@@ -264,8 +275,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
           }
           float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])),
                            fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-          mt = fmaxf(mt, __shfl_xor(mt, 16));
-          mt = fmaxf(mt, __shfl_xor(mt, 32));
+          mt = quad_row_max(mt);
           mt *= c2;  // c2 > 0: max commutes with the scale
           // fully masked row so far: keep the max finite (extend_attention.py:474-475)
           const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
@@ -297,18 +307,17 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
           }
         }
         // ---- O^T += V^T P^T --------------------------------------------------------------------------
-        {
-          const char* rp0 = vt + (32 * hh + vrow0) * ROW_BYTES + 8 * (pp & 1);
-          const char* rp1 = rp0 + 16 * ROW_BYTES;
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const int chunk = ((2 * nb + (pp >> 1)) ^ swv) & (CPR - 1);
-            const u32x2 lo2 = T::ds_read_tr(rp0 + chunk * 16);
-            const u32x2 hi2 = T::ds_read_tr(rp1 + chunk * 16);
-            const vec8 av = __builtin_bit_cast(vec8, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]});
-            oacc[0][nb] = T::mfma(av, pf[0], oacc[0][nb]);
-            oacc[1][nb] = T::mfma(av, pf[1], oacc[1][nb]);
-          }
+        for (int nb = NB / 2; nb < NB; ++nb) {  // second half of the fragments: in flight under the MFMAs
+          const int chunk = ((2 * nb + (pp >> 1)) ^ swv) & (CPR - 1);
+          vlo[nb] = T::ds_read_tr(rp0 + chunk * 16);
+          vhi[nb] = T::ds_read_tr(rp1 + chunk * 16);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const vec8 av = __builtin_bit_cast(vec8, u32x4{vlo[nb][0], vlo[nb][1], vhi[nb][0], vhi[nb][1]});
+          oacc[0][nb] = T::mfma(av, pf[0], oacc[0][nb]);
+          oacc[1][nb] = T::mfma(av, pf[1], oacc[1][nb]);
         }
       }
     }
