@@ -178,6 +178,10 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
     }
   }
 
+  // The Q fragments must have LANDED before the tile loop: hipcc's waitcnt pass merges the loop-entry
+  // state (Q loads possibly pending) into the loop header and would otherwise emit vmcnt(0) in front
+  // of the first MFMA of EVERY iteration, i.e. wait for the next tile's prefetch before computing.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
   const uint16_t* kbase = a.k_buf + kvh * a.k_head_stride + 8 * g;
   const uint16_t* vbase = a.v_buf + kvh * a.v_head_stride + 8 * g;
   char* vt = smem + w * TILE_BYTES;  // this wave's V tile

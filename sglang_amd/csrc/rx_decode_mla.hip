@@ -124,6 +124,10 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
     }
   }
 
+  // The Q fragments must have LANDED before the tile loop: hipcc's waitcnt pass merges the loop-entry
+  // state (Q loads possibly pending) into the loop header and would otherwise emit vmcnt(0) in front
+  // of the first MFMA of EVERY iteration, i.e. wait for the next tile's prefetch before computing.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
   // ---- cooperative staging: thread handles chunks c = tid + 256 i, row = c / 72, col = c % 72 ------
   int st_row[kMlaStage], st_col[kMlaStage];
 #pragma unroll

@@ -115,6 +115,10 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
     }
   }
 
+  // The Q fragments must have LANDED before the tile loop: hipcc's waitcnt pass merges the loop-entry
+  // state (Q loads possibly pending) into the loop header and would otherwise emit vmcnt(0) in front
+  // of the first MFMA of EVERY iteration, i.e. wait for the next tile's prefetch before computing.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
   const int32_t p_len = a.skip_prefix ? 0 : P;
   const int32_t n_end_wg = a.skip_extend ? 0 : (a.causal ? min(E, qb0 + 4 * kQPerWave) : E);
   const int32_t n_end_w = a.skip_extend ? 0 : (a.causal ? min(E, qbase + kQPerWave) : E);
