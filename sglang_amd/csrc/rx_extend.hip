@@ -40,7 +40,10 @@ struct ExtendArgs {
   const float* sinks;
 };
 
-constexpr int kQPerWave = 32;
+#ifndef RX_EXT_CB
+#define RX_EXT_CB 2
+#endif
+constexpr int kQPerWave = 16 * RX_EXT_CB;
 constexpr int kETile = 32;
 
 template <int D>
@@ -65,10 +68,24 @@ __device__ __forceinline__ int64_t slot_off(int64_t slot, int32_t page_size, int
 // global -> registers (full 256-B rows, 16 lanes per row, issued one tile ahead) -> XOR-swizzled
 // LDS image (double buffered, one barrier per tile).  Each wave then reads its K A-fragments with
 // ds_read_b128 and its V^T fragments with ds_read_b64_tr_b16 from the same image layout.
-constexpr int kTT = 64;  // tokens per LDS tile
+#ifndef RX_EXT_TT
+#define RX_EXT_TT 64
+#endif
+constexpr int kTT = RX_EXT_TT;  // tokens per LDS tile
+
+#ifndef RX_EXT_CB
+#define RX_EXT_CB 2  // 16-query N blocks per wave (2 -> 32 queries / wave, 128 / workgroup)
+#endif
+#ifndef RX_EXT_TT
+#define RX_EXT_TT 64  // tokens per staged LDS tile
+#endif
+#ifndef RX_EXT_MINW
+#define RX_EXT_MINW 2
+#endif
+constexpr int kCB = RX_EXT_CB;
 
 template <typename T, int D, typename IdxT, bool LINEAR, bool VSCALE>
-__global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a) {
+__global__ __launch_bounds__(256, RX_EXT_MINW) void extend_mfma_kernel(const ExtendArgs a) {
   using vec8 = typename T::vec8;
   constexpr int KS = D / 32;
   constexpr int NB = D / 16;
@@ -102,9 +119,9 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
   const IdxT* idx = reinterpret_cast<const IdxT*>(a.kv_indices) + kv0;
 
   // ---- Q^T fragments: block c, lane (r,g) holds Q[qbase+16c+r][h][32s+8g..] -------------------
-  vec8 qf[2][KS];
+  vec8 qf[kCB][KS];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < kCB; ++c) {
     const int m = qbase + 16 * c + r;
     const bool ok = m < E;
     const uint16_t* qp = a.q + (qo0 + (ok ? m : 0)) * a.q_stride_t + h * a.q_stride_h + 8 * g;
@@ -175,13 +192,17 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
     }
   };
 
-  f32x4 oacc[2][NB];
+  f32x4 oacc[kCB][NB];
 #pragma unroll
-  for (int c = 0; c < 2; ++c)
+  for (int c = 0; c < kCB; ++c)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) oacc[c][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY};  // running max, log2 domain
-  float l_run[2] = {0.f, 0.f};
+  float m_run[kCB], l_run[kCB];  // running max (log2 domain) / this lane's partial row sum
+#pragma unroll
+  for (int c = 0; c < kCB; ++c) {
+    m_run[c] = -INFINITY;
+    l_run[c] = 0.f;
+  }
 
   // ---- prologue -----------------------------------------------------------------------------------
   if (nt > 0) {
@@ -209,14 +230,14 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
     const int32_t lim = prefix ? p_len : n_end_w;
     if (active) {
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
+      for (int hh = 0; hh < kTT / 32; ++hh) {
         const int n0 = tile_n0 + 32 * hh;  // first token of this 32-token half
         if (n0 >= lim) continue;           // nothing visible to this wave (wave-uniform)
         const float cs = (prefix ? a.sm_scale * a.k_scale : a.sm_scale);
         // ---- S^T = K Q^T ---------------------------------------------------------------------------
-        f32x4 sacc[2][2];
+        f32x4 sacc[kCB][2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < kCB; ++c)
 #pragma unroll
           for (int bb = 0; bb < 2; ++bb) sacc[c][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -226,8 +247,8 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
           for (int s = 0; s < KS; ++s) {
             const int chunk = ((4 * s + g) ^ swr) & (CPR - 1);
             const vec8 ka = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(krow + chunk * 16));
-            sacc[0][bb] = T::mfma(ka, qf[0][s], sacc[0][bb]);
-            sacc[1][bb] = T::mfma(ka, qf[1][s], sacc[1][bb]);
+#pragma unroll
+            for (int c = 0; c < kCB; ++c) sacc[c][bb] = T::mfma(ka, qf[c][s], sacc[c][bb]);
           }
         }
         // ---- V^T fragments of the first half of the d blocks: issued BEFORE the softmax math so the
@@ -247,9 +268,9 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
         else full = (n0 + 32 <= E) && (!a.causal || n0 + 31 <= qbase) && a.window <= 0;
         const bool capped = a.logit_cap > 0.f;
         const float c2 = capped ? kLog2e : cs * kLog2e;
-        vec8 pf[2];
+        vec8 pf[kCB];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < kCB; ++c) {
           const int m = qbase + 16 * c + r;
           float sv[8];
 #pragma unroll
@@ -320,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const vec8 av = __builtin_bit_cast(vec8, u32x4{vlo[nb][0], vlo[nb][1], vhi[nb][0], vhi[nb][1]});
-          oacc[0][nb] = T::mfma(av, pf[0], oacc[0][nb]);
-          oacc[1][nb] = T::mfma(av, pf[1], oacc[1][nb]);
+#pragma unroll
+          for (int c = 0; c < kCB; ++c) oacc[c][nb] = T::mfma(av, pf[c], oacc[c][nb]);
         }
       }
     }
@@ -339,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void extend_mfma_kernel(const ExtendArgs a)
   // ---- epilogue -------------------------------------------------------------------------------------
   if (!active) return;
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < kCB; ++c) {
     float l = l_run[c];
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
