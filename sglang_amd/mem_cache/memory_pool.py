@@ -94,7 +94,6 @@ class MHATokenToKVPool:
         self._create_buffers()
         self._build_ptr_tables()
         self._store_launchers = [None] * layer_num
-        self._hnd_layouts = [None] * layer_num
 
     def _kv_buffer_shapes(self):
         if self.use_hnd:
@@ -154,31 +153,36 @@ class MHATokenToKVPool:
             cache_k = cache_k.to(self.dtype)
             cache_v = cache_v.to(self.dtype)
         li = layer_id - self.start_layer
-        if self.use_hnd:
-            # a slot is [page, :, off, :]: scatter by (page, off) (memory_pool.py:2372-2379)
-            lay = self._hnd_layouts[li]
-            if lay is None:
-                lay = self._hnd_layouts[li] = ops.kv_layout_hnd(self.k_buffer[li], self.v_buffer[li])
-            ops.store_cache_layout(cache_k, cache_v, lay, loc, self.head_num, self.head_dim,
-                                   self.v_head_dim, size_limit=self.num_pages * self.page_size,
-                                   err_flag=self.err_flag)
-            return
         n = loc.shape[0]
         k2 = cache_k.reshape(n, self.row_dim) if cache_k.dim() == 3 else cache_k
         v2 = cache_v.reshape(n, self.v_row_dim) if cache_v.dim() == 3 else cache_v
-        if (not k2.is_cuda or k2.stride(1) != 1 or v2.stride(1) != 1 or loc.dim() != 1
-                or loc.dtype not in (torch.int32, torch.int64) or not loc.is_contiguous()):
-            # uncommon shapes: the fully checked wrapper
-            ops.store_cache(k2, v2, self.k_buffer[li].view(-1, self.row_dim),
-                            self.v_buffer[li].view(-1, self.v_row_dim), loc,
-                            size_limit=self.size + self.page_size, err_flag=self.err_flag)
+        if not (k2.is_cuda and v2.is_cuda and loc.is_cuda):
+            raise RuntimeError("set_kv_buffer: k, v and loc must be GPU tensors (there is no CPU fallback)")
+        if loc.dim() != 1 or loc.dtype not in (torch.int32, torch.int64):
+            raise TypeError("set_kv_buffer: loc must be a 1-D int32/int64 tensor")
+        if k2.stride(1) != 1:
+            k2 = k2.contiguous()
+        if v2.stride(1) != 1:
+            v2 = v2.contiguous()
+        if not loc.is_contiguous():
+            loc = loc.contiguous()
+        stream = torch.cuda.current_stream(k2.device).cuda_stream
+        if self.use_hnd:
+            # a slot is [page, :, off, :] (memory_pool.py:2372-2379): HIP scatter by (page, off, head)
+            launcher = self._store_launchers[li]
+            if launcher is None:
+                lay = ops.kv_layout_hnd(self.k_buffer[li], self.v_buffer[li])
+                launcher = self._store_launchers[li] = ops.StoreLayoutLauncher(
+                    lay, self.head_num, self.head_dim, self.v_head_dim,
+                    self.num_pages * self.page_size, self.err_flag)
+            launcher(k2, v2, loc, stream)
             return
         launcher = self._store_launchers[li]
         if launcher is None:
             launcher = self._store_launchers[li] = ops.StoreLauncher(
                 self.k_buffer[li].view(-1, self.row_dim), self.v_buffer[li].view(-1, self.v_row_dim),
                 self.size + self.page_size, self.err_flag)
-        launcher(k2, v2, loc, torch.cuda.current_stream(k2.device).cuda_stream)
+        launcher(k2, v2, loc, stream)
 
     def move_kv_cache(self, tgt_loc: torch.Tensor, src_loc: torch.Tensor):
         """memory_pool.py:2775-2842: every layer's K and V rows src -> tgt in one launch."""

@@ -317,6 +317,27 @@ class DecodeLauncher:
             _L.check(st, "rx_decode_attn")
 
 
+class StoreLayoutLauncher:
+    """rx_store_kv_layout with the pool-side arguments of one layer pre-computed (HND pools)."""
+
+    def __init__(self, layout, num_kv_heads, head_dim, v_head_dim, size_limit, err_flag,
+                 reserved_skip_index=0):
+        self._lib = _L.load()
+        self.layout, self._ref = layout, C.byref(layout)
+        self.h, self.dk, self.dv = num_kv_heads, head_dim, v_head_dim
+        self.size_limit, self.skip = size_limit, reserved_skip_index
+        self.err = None if err_flag is None else err_flag.data_ptr()
+        self._err_keep = err_flag
+
+    def __call__(self, k2, v2, loc, stream_ptr):
+        st = self._lib.rx_store_kv_layout(k2.data_ptr(), v2.data_ptr(), self._ref, loc.data_ptr(),
+                                          k2.shape[0], self.h, self.dk, self.dv, k2.stride(0),
+                                          v2.stride(0), 1 if loc.dtype == torch.int64 else 0,
+                                          self.size_limit, self.skip, self.err, stream_ptr)
+        if st:
+            _L.check(st, "rx_store_kv_layout")
+
+
 class StoreLauncher:
     """rx_store_kv with the cache-side arguments of one layer pre-computed."""
 
