@@ -475,3 +475,101 @@ def test_decode_mla_kernel(ops, dtype, hq, page_size):
                              1.0, 1.0, page_size=page_size)
     err2 = np.abs(_np(o2.float()).astype(np.float64) - want).max()
     assert err2 <= tol, ("split", err2)
+
+
+# ---------------------------------------------------------------------------- edge cases
+def test_decode_edge_cases(ops):
+    """bs=1 with a 40k-token context (forces real split-KV), an empty request inside a batch,
+    page_size 64, int32 request indices / seq lens, q taken as a strided slice of a fused qkv buffer."""
+    rng = np.random.default_rng(99)
+    hq, hkv, d, ps = 32, 8, 128, 64
+    lens = np.array([40000, 0, 65, 1], dtype=np.int64)
+    bs = len(lens)
+    q, kb, vb, r2t, rpi = _make_paged_case(rng, bs, hq, hkv, d, lens, ps, torch.bfloat16)
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
+    want = orc.decode_attention(_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, d ** -0.5)
+    kbd, vbd = kb.to(DEV), vb.to(DEV)
+    qkv = torch.zeros(bs, (hq + 2 * hkv) * d, dtype=torch.bfloat16, device=DEV)
+    qkv[:, : hq * d] = q.view(bs, -1).to(DEV)
+    q_view = qkv[:, : hq * d].view(bs, hq, d)  # row stride (hq+2hkv)*d: not contiguous
+    assert not q_view.is_contiguous()
+    S = 16
+    lens32 = _t(lens).to(torch.int32)
+    nsplit = torch.zeros(bs, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits(nsplit, torch.clamp(lens32, min=1), hq, hkv, S, 256)
+    assert int(nsplit.max()) > 1
+    al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
+    lse = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+    o = torch.full((bs, hq, d), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.decode_attention_fwd_paged(q_view, kbd, vbd, o, _t(r2t), _t(rpi).to(torch.int32), lens32, al, lse, nsplit,
+                                   S, d ** -0.5, page_size=ps)
+    got = _np(o.float()).astype(np.float64)
+    live = lens > 0
+    assert np.abs(got[live] - want[live]).max() <= 1e-2
+    # single pass: the empty request gets a defined (zero) output
+    o1 = torch.full((bs, hq, d), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.decode_attention_fwd_paged(q_view, kbd, vbd, o1, _t(r2t), _t(rpi), _t(lens), None, None, None, 1,
+                                   d ** -0.5, page_size=ps)
+    got1 = _np(o1.float()).astype(np.float64)
+    assert np.abs(got1[live] - want[live]).max() <= 1e-2 and np.all(got1[~live] == 0)
+
+
+def test_extend_edge_cases(ops):
+    """one request longer than the 128-query workgroup tile with no prefix, one single-token extend on a
+    long prefix, an empty extend inside the batch (qo_indptr repeats), fp16, int32 kv_indices."""
+    rng = np.random.default_rng(5)
+    hq, hkv, d = 8, 2, 128
+    pre = np.array([0, 700, 33], dtype=np.int32)
+    ext = np.array([300, 1, 0], dtype=np.int32)
+    T, total = int(ext.sum()), int((pre + ext).sum())
+    pool = total + 3
+    slots = rng.permutation(pool - 1)[:total] + 1
+    g = torch.Generator().manual_seed(2)
+    kb = torch.randn(pool, hkv, d, generator=g).half()
+    vb = torch.randn(pool, hkv, d, generator=g).half()
+    q = torch.randn(T, hq, d, generator=g).half()
+    kv_indptr = np.concatenate([[0], np.cumsum(pre)]).astype(np.int32)
+    qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
+    kv_indices = np.empty(int(pre.sum()), dtype=np.int64)
+    ext_slots = np.empty(T, dtype=np.int64)
+    so = 0
+    for i in range(len(pre)):
+        s = slots[so: so + pre[i] + ext[i]]; so += pre[i] + ext[i]
+        kv_indices[kv_indptr[i]: kv_indptr[i + 1]] = s[: pre[i]]
+        ext_slots[qo[i]: qo[i + 1]] = s[pre[i]:]
+    ke, ve = kb[ext_slots], vb[ext_slots]
+    want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
+                                sm_scale=d ** -0.5)
+    o = torch.zeros(T, hq, d, dtype=torch.float16, device=DEV)
+    ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo).to(torch.int32),
+                             _t(kv_indptr), _t(kv_indices).to(torch.int32), None, True, None, int(ext.max()),
+                             1.0, 1.0)
+    assert np.abs(_np(o.float()).astype(np.float64) - want).max() <= 3e-3
+
+
+def test_k_and_v_scales(ops):
+    """fp8-style per-tensor k/v scales multiply the logits / the prefix values (extend_attention.py:458,
+    :508; decode_attention.py:1001-1003)."""
+    rng = np.random.default_rng(8)
+    hq, hkv, d = 4, 2, 64
+    lens = np.array([50, 9], dtype=np.int64)
+    q, kb, vb, r2t, rpi = _make_paged_case(rng, 2, hq, hkv, d, lens, 1, torch.float16)
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
+    want = orc.decode_attention(_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, 0.2, k_scale=0.5, v_scale=2.0)
+    o = torch.zeros(2, hq, d, dtype=torch.float16, device=DEV)
+    ops.decode_attention_fwd(q.to(DEV), kb.to(DEV), vb.to(DEV), o, _t(kv_indptr), _t(kv_indices), None, None, None,
+                             1, 0.2, 0.5, 2.0)
+    assert np.abs(_np(o.float()) - want).max() <= 4e-3
+    # extend: scales apply to the cached prefix only
+    pre, ext = np.array([20], dtype=np.int32), np.array([40], dtype=np.int32)
+    g = torch.Generator().manual_seed(4)
+    kbe = torch.randn(64, hkv, d, generator=g).half(); vbe = torch.randn(64, hkv, d, generator=g).half()
+    qe = torch.randn(40, hq, d, generator=g).half()
+    ke = torch.randn(40, hkv, d, generator=g).half(); ve = torch.randn(40, hkv, d, generator=g).half()
+    kvi = np.arange(1, 21, dtype=np.int64)
+    want_e = orc.extend_attention(_np(qe), _np(ke), _np(ve), _np(kbe), _np(vbe), np.array([0, 40]), np.array([0, 20], dtype=np.int32),
+                                  kvi, sm_scale=0.2, k_scale=0.5, v_scale=2.0)
+    oe = torch.zeros(40, hq, d, dtype=torch.float16, device=DEV)
+    ops.extend_attention_fwd(qe.to(DEV), ke.to(DEV), ve.to(DEV), oe, kbe.to(DEV), vbe.to(DEV), _t(np.array([0, 40])),
+                             _t(np.array([0, 20], dtype=np.int32)), _t(kvi), None, True, None, 40, 0.5, 2.0, sm_scale=0.2)
+    assert np.abs(_np(oe.float()) - want_e).max() <= 6e-3
