@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 # RX_LIB_NAME / RX_CFLAGS: developer knobs for A/B-ing kernel variants built side by side
 LIB_PATH = os.path.join(HERE, os.environ.get("RX_LIB_NAME", "libradix_hip.so"))
-SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_decode_mla.hip", "rx_extend.hip", "rx_radix.cpp"]
+SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_decode_mla.hip", "rx_extend.hip", "rx_extend32.hip", "rx_radix.cpp"]
 HEADERS = ["rx_common.h", os.path.join(ROOT, "include", "radix_hip.h")]
 
 

@@ -12,6 +12,8 @@
 // (request, head): they walk the same KV rows at the same time, so three of the four K/V reads
 // are served by the CU's L1.  Prefix and extend stages share one tile body; the next tile's
 // K/V (and the slot indices of the tile after it) are in flight under the current tile's math.
+#include <cstdlib>
+
 #include "rx_common.h"
 
 namespace rx {
@@ -500,6 +502,8 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
   return check_launch("rx_extend_attn");
 }
 
+int launch_extend32(const rx_extend_params* p, hipStream_t s);  // rx_extend32.hip (D = 128)
+
 }  // namespace rx
 
 using namespace rx;
@@ -534,6 +538,10 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
                  (uintptr_t)p->kv.k_buf | (uintptr_t)p->kv.v_buf) & 15) == 0 &&
                    ((uintptr_t)p->o & 7) == 0,
                "rx_extend_attn: q/k/v/k_buf/v_buf must be 16-byte and o 8-byte aligned");
+  }
+  if (mfma_ok && dk == 128 && !getenv("RX_EXTEND_16X16")) {  // 32x32x16 fast path
+    const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));
+    return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }
   ExtendArgs a;
   a.q = (const uint16_t*)p->q;
