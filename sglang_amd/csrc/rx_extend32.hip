@@ -223,17 +223,31 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
       const float c2 = capped ? kLog2e : cs * kLog2e;
       // ---- S^T blocks -----------------------------------------------------------------------------
       f32x16 sacc[2];
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sacc[b][i] = 0.f;
         if (b < nblk) {
           const char* krow = kt + (32 * b + ql) * kRow;
+          // K fragments are fetched two k-steps ahead of the MFMA that consumes them: a ds_read_b128
+          // round trip is ~100+ cycles, an MFMA 32; without the explicit distance hipcc issues each
+          // read right in front of its MFMA and the matrix pipe idles on lgkmcnt(0)
+          u32x4 kfr[KS];
+          kfr[0] = *reinterpret_cast<const u32x4*>(krow + (((0 + h) ^ kswz) << 4));
+          kfr[1] = *reinterpret_cast<const u32x4*>(krow + (((2 + h) ^ kswz) << 4));
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const int chunk = (2 * ks + h) ^ kswz;
-            const vec8 ka = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(krow + (chunk << 4)));
-            sacc[b] = mfma32<T>(ka, qf[ks], sacc[b]);
+            if (ks + 2 < KS)
+              kfr[ks + 2] = *reinterpret_cast<const u32x4*>(krow + (((2 * (ks + 2) + h) ^ kswz) << 4));
+            // the first MFMA takes the literal zero as C: no 16-register clear per block
+            sacc[b] = mfma32<T>(__builtin_bit_cast(vec8, kfr[ks]), qf[ks], ks == 0 ? zero16 : sacc[b]);
+          }
+          // pin the interleave (2 reads up front, then read / MFMA alternating) so the distance survives
+          // instruction scheduling: masks 0x100 = DS read, 0x008 = MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 2 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           }
         }
       }
@@ -300,23 +314,30 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
 #pragma unroll
         for (int db = 0; db < DB; ++db) oacc[db] *= alpha;
       }
-      // ---- O^T += V^T P^T --------------------------------------------------------------------------
+      // ---- O^T += V^T P^T: the V^T fragments of k-step i+1 are in flight under the MFMAs of step i ----
+      {
+        const int nsteps = 2 * nblk;  // k-steps of 16 tokens
+        u32x4 vfr[2][DB];
+        auto load_v = [&](int step, u32x4 (&dst)[DB]) {
+          const int r0 = 16 * step;
+          const char* rlo = vt + (r0 + vrow_lo) * kRow + vbyte;
+          const char* rhi = vt + (r0 + vrow_hi) * kRow + vbyte;
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        if (b < nblk) {
+          for (int db = 0; db < DB; ++db) {
+            const u32x2 lo2 = T::ds_read_tr(rlo + (((4 * db + vcol) ^ vsw_lo) << 4));
+            const u32x2 hi2 = T::ds_read_tr(rhi + (((4 * db + vcol) ^ vsw_hi) << 4));
+            dst[db] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+          }
+        };
+        load_v(0, vfr[0]);
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int r0 = 32 * b + 16 * s;  // first token of this k-step inside the tile
-            const char* rlo = vt + (r0 + vrow_lo) * kRow + vbyte;
-            const char* rhi = vt + (r0 + vrow_hi) * kRow + vbyte;
-            const vec8 pb = __builtin_bit_cast(vec8, pk[b][s]);
+        for (int step = 0; step < 4; ++step) {
+          if (step < nsteps) {
+            if (step + 1 < nsteps) load_v(step + 1, vfr[(step + 1) & 1]);
+            const vec8 pb = __builtin_bit_cast(vec8, pk[step >> 1][step & 1]);
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
-              const u32x2 lo2 = T::ds_read_tr(rlo + (((4 * db + vcol) ^ vsw_lo) << 4));
-              const u32x2 hi2 = T::ds_read_tr(rhi + (((4 * db + vcol) ^ vsw_hi) << 4));
-              const vec8 av = __builtin_bit_cast(vec8, u32x4{lo2[0], lo2[1], hi2[0], hi2[1]});
-              oacc[db] = mfma32<T>(av, pb, oacc[db]);
-            }
+            for (int db = 0; db < DB; ++db)
+              oacc[db] = mfma32<T>(__builtin_bit_cast(vec8, vfr[step & 1][db]), pb, oacc[db]);
           }
         }
       }
