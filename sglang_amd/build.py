@@ -13,6 +13,9 @@ ROOT = os.path.dirname(HERE)
 # RX_LIB_NAME / RX_CFLAGS: developer knobs for A/B-ing kernel variants built side by side
 LIB_PATH = os.path.join(HERE, os.environ.get("RX_LIB_NAME", "libradix_hip.so"))
 SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_decode_mla.hip", "rx_extend.hip", "rx_extend32.hip", "rx_radix.cpp"]
+# rx_extend32: without -fno-honor-nans every fmaxf on an MFMA result is preceded by a canonicalising
+# v_max_f32 x, x, x (one extra VALU per score in a VALU-issue-bound loop).  The kernel creates no NaN.
+EXTRA_FLAGS = {"rx_extend32.hip": ["-fno-honor-nans"]}
 HEADERS = ["rx_common.h", os.path.join(ROOT, "include", "radix_hip.h")]
 
 
@@ -46,7 +49,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(HERE, "build", os.path.splitext(src)[0] + os.environ.get("RX_LIB_NAME", "") + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
                "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-c", sp, "-o", obj]
-        cmd[1:1] = os.environ.get("RX_CFLAGS", "").split()
+        cmd[1:1] = EXTRA_FLAGS.get(src, []) + os.environ.get("RX_CFLAGS", "").split()
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -8,16 +8,17 @@
 // fragment instructions.
 //
 // Workgroup = NW waves (8 -> 256 queries, 4 -> 128) of one (request, q head); wave = 32 queries.
-// KV tiles of 64 tokens are staged once per workgroup (global -> registers one tile ahead -> swizzled
-// LDS, double buffered, one barrier per tile):
+// KV tiles of 64 tokens are staged once per workgroup (global -> registers, in flight for one whole
+// tile -> padded LDS rows, double buffered, one barrier per tile, written AFTER the barrier):
 //   S^T[tok][q] = K Q^T : A = K fragment (lane = (token&31, 8-wide d half)) by ds_read_b128,
 //                         B = Q^T kept in 32 VGPRs.
-//   softmax on the lane (exp2(fma(s, c, -m)), exact lazy rescale), P packed to bf16 IS the B operand
-//   of the next product (registers 8s..8s+7 of an S block = k-step s, cdna_hip_programming.md §3).
+//   softmax on the lane (packed-fp32 exp2(fma(s, c, -m)), exact lazy rescale), P packed to bf16 IS
+//   the B operand of the next product (registers 8s..8s+7 of an S block = k-step s,
+//   cdna_hip_programming.md §3).
 //   O^T[d][q] += V^T P^T : A = V^T fragment by two ds_read_b64_tr_b16 per k-step in the matching
 //                         permuted token order (16s + 8(j>>2) + 4h + (j&3)).
-// LDS image: 256-B rows, 16-byte chunk index XOR ((row&3)<<2 | (row>>2)&3): conflict-free for the
-// staging ds_write_b128, the K ds_read_b128 and the V transposed reads.
+// Fully visible tiles run as a wave-level software pipeline (32-token online-softmax steps, MFMAs of
+// one block under the softmax VALU of the other); boundary tiles take a plain masked path.
 #include "rx_common.h"
 
 namespace rx {
@@ -48,8 +49,13 @@ struct Ext32Args {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kD = 128, kRow = 256, kTok = 64;  // head dim, bytes per row, tokens per tile
+// LDS images: padded rows instead of an XOR swizzle, so that fragment addresses are lane constant +
+// immediate.  K rows step 17 chunks of 16 B: the 16 rows one ds_read_b128 pass touches land on 16
+// different chunk positions.  V rows step 20 chunks: the 4 rows x 64 B of a ds_read_b64_tr_b16
+// half-wave land on 4 different 64-B bank groups.  Staging writes whole 256-B rows: conflict-free.
+constexpr int kKStride = kRow + 16, kVStride = kRow + 64;
+constexpr int kKTile = kTok * kKStride, kVTile = kTok * kVStride, kBufBytes = kKTile + kVTile;
 
-__device__ __forceinline__ int swz32(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 template <bool LINEAR>
 __device__ __forceinline__ int64_t slot_off32(int64_t slot, int32_t page_size, int64_t page_stride,
@@ -73,11 +79,16 @@ __device__ __forceinline__ f32x16 mfma32<F16>(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// This file is compiled with -fno-honor-nans (sglang_amd/build.py): with NaNs honoured hipcc
+// canonicalises every MFMA result before fmaxf (v_max_f32 x, x, x -- one extra VALU per score).
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }  // v_max3_f32
+__device__ __forceinline__ float max2f(float a, float b) { return fmaxf(a, b); }
+
 // max over lanes l and l^32 (one query's two register halves)
 __device__ __forceinline__ float half_swap_max(float x) {
   float a = x, b = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1"
-               : "+v"(a), "+v"(b));
+  // not volatile: a pure function of its inputs, so the LDS fragment reads may move across it
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
   return a;
 }
 
@@ -89,9 +100,8 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
   constexpr int THREADS = 64 * NW;
   constexpr int RPP = THREADS / 16;            // rows staged per pass
   constexpr int NPASS = kTok / RPP;            // 2 (NW=8) or 4 (NW=4)
-  constexpr int TILE_BYTES = kTok * kRow;      // 16 KiB
   constexpr int QPW = 32;                      // queries per wave
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][K|V]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -172,14 +182,12 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
     }
   };
   auto write_lds = [&](int buf) {
-    char* kt = smem + buf * 2 * TILE_BYTES;
-    char* vt = kt + TILE_BYTES;
+    char* kt = smem + buf * kBufBytes + st_row * kKStride + st_chunk * 16;
+    char* vt = smem + buf * kBufBytes + kKTile + st_row * kVStride + st_chunk * 16;
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
-      const int row = i * RPP + st_row;
-      const int off = row * kRow + ((st_chunk ^ swz32(row)) << 4);
-      *reinterpret_cast<u32x4*>(kt + off) = stg_k[i];
-      *reinterpret_cast<u32x4*>(vt + off) = stg_v[i];
+      *reinterpret_cast<u32x4*>(kt + i * RPP * kKStride) = stg_k[i];
+      *reinterpret_cast<u32x4*>(vt + i * RPP * kVStride) = stg_v[i];
     }
   };
 
@@ -200,61 +208,251 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
       if (nt > 2) load_idx_tile(2);
     }
   }
-  __syncthreads();
 
-  // per-lane LDS addressing constants
-  const int kswz = swz32(ql);                       // K rows 32 b + ql
+  // per-lane LDS read offsets: both images are padded rows, so every fragment address is ONE lane
+  // constant plus an immediate (block / k-step / d-block distance)
   const int tq = lane & 15, qd = tq >> 2, pp = tq & 3, dg = (lane >> 4) & 1;
-  // V^T reads: rows 16 s + 4 h + qd (+8); chunk = 4 db + 2 dg + (pp >> 1); swizzle uses row & 15
-  const int vrow_lo = 4 * h + qd, vrow_hi = 8 + 4 * h + qd;
-  const int vsw_lo = swz32(vrow_lo), vsw_hi = swz32(vrow_hi);
-  const int vcol = 2 * dg + (pp >> 1), vbyte = 8 * (pp & 1);
+  const int kaddr = ql * kKStride + h * 16;                                        // K row 32 b + ql
+  const int vaddr = kKTile + (4 * h + qd) * kVStride + (2 * dg + (pp >> 1)) * 16 + 8 * (pp & 1);
   const bool capped = a.logit_cap > 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  for (int t = 0; t < nt; ++t) {
-    const char* kt = smem + (t & 1) * 2 * TILE_BYTES;
-    const char* vt = kt + TILE_BYTES;
-    const bool prefix = t < nt1;
-    const int tile_n0 = (prefix ? t : t - nt1) * kTok;
-    const int32_t lim = prefix ? p_len : n_end_w;
-    if (active && tile_n0 < lim) {
-      const int nblk = (tile_n0 + 32 < lim) ? 2 : 1;  // visible 32-token blocks of this tile
-      const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
-      const float c2 = capped ? kLog2e : cs * kLog2e;
-      // ---- S^T blocks -----------------------------------------------------------------------------
+  // K fragment (block b, k-step ks): lane (ql, h) <- K[32 b + ql][16 ks + 8 h .. +8]
+  auto load_k = [&](const char* tile, int b, int ks) {
+    return *reinterpret_cast<const u32x4*>(tile + kaddr + b * 32 * kKStride + ks * 32);
+  };
+  // V^T fragments of k-step `step` (16 tokens): rows 16 step + 4 h + qd (+8), d block db
+  auto load_v = [&](const char* tile, int step, u32x4 (&dst)[DB]) {
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const u32x2 lo2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64);
+      const u32x2 hi2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64 + 8 * kVStride);
+      dst[db] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+    }
+  };
+  // exp2(s c2 - m) on one 32-token block, P packed to 16-bit as the next product's B operand; returns
+  // the lane's partial row sum.  Scalar fp32 on purpose: v_pk_*_f32 beside MFMAs costs more than the
+  // two scalar ops it replaces (MI355X_MICROARCH.md, per-instruction cycle constants).
+  auto exp_pack = [&](f32x16& sc, float c2, float m_new, float vs, u32x4 (&pk)[2]) -> float {
+    float ps = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v0 = fast_exp2(__builtin_fmaf(sc[2 * i], c2, -m_new));
+      float v1 = fast_exp2(__builtin_fmaf(sc[2 * i + 1], c2, -m_new));
+      ps += v0 + v1;
+      if constexpr (VSCALE) {
+        v0 *= vs;
+        v1 *= vs;
+      }
+      pk[i >> 2][i & 3] = pack2<T>(v0, v1);
+    }
+    return ps;
+  };
+  auto row_max16 = [&](const f32x16& sc) -> float {
+    float m01 = max3f(sc[0], sc[1], sc[2]), m23 = max3f(sc[3], sc[4], sc[5]);
+    m01 = max3f(m01, sc[6], sc[7]);
+    m23 = max3f(m23, sc[8], sc[9]);
+    m01 = max3f(m01, sc[10], sc[11]);
+    m23 = max3f(m23, sc[12], sc[13]);
+    m01 = max3f(m01, sc[14], sc[15]);
+    return max2f(m01, m23);
+  };
+
+  // Per-tile facts.  `fast` = both 32-token blocks fully visible to every query of this wave: no mask.
+  struct TileInfo {
+    bool prefix, work, full, fast;
+    int tile_n0, nblk;
+    float cs, c2, vs;
+  };
+  auto tile_info = [&](int t) {
+    TileInfo ti;
+    ti.prefix = t < nt1;
+    ti.tile_n0 = (ti.prefix ? t : t - nt1) * kTok;
+    const int32_t lim = ti.prefix ? p_len : n_end_w;
+    ti.work = active && ti.tile_n0 < lim;
+    ti.nblk = (ti.tile_n0 + 32 < lim) ? 2 : 1;  // visible 32-token blocks of this tile
+    ti.cs = ti.prefix ? a.sm_scale * a.k_scale : a.sm_scale;
+    ti.c2 = capped ? kLog2e : ti.cs * kLog2e;
+    ti.vs = ti.prefix ? a.v_scale : 1.0f;
+    const int n_hi = ti.tile_n0 + 32 * ti.nblk;
+    if (ti.prefix) ti.full = n_hi <= p_len && a.window <= 0;
+    else ti.full = n_hi <= E && (!a.causal || n_hi - 1 <= qbase) && a.window <= 0;
+    ti.fast = ti.work && ti.full && ti.nblk == 2 && !capped && (LINEAR || a.page_size < 0);
+    return ti;
+  };
+  // one barrier per tile; tile t+1 is written AFTER it (its readers, tile t-1's products, are done)
+  // and tile t+2's global loads are re-issued at once, so they have this whole tile to land
+  auto tile_sync_and_stage = [&](int t) {
+    __syncthreads();
+    if (t + 1 < nt) {
+      write_lds((t + 1) & 1);
+      if (t + 2 < nt) {
+        issue_loads(t + 2);
+        if (t + 3 < nt) load_idx_tile(t + 3);
+      }
+    }
+  };
+
+  // The two tile bodies live in two separate inner loops (runs of fast tiles, runs of boundary
+  // tiles): with both bodies inside one loop hipcc's allocator spills 147 registers, each alone fits.
+  // Waves of one workgroup may be in different loops at the same t; every tile is one barrier either way.
+  int t = 0;
+  while (t < nt) {
+    for (; t + 3 < nt; ++t) {
+      const TileInfo ti = tile_info(t);
+      if (!ti.fast) break;
+      __syncthreads();
+      const char* tile = smem + (t & 1) * kBufBytes;
+      const float c2 = ti.c2, vs = ti.vs;
+      // ===== fast body: a hand-ordered wave-level software pipeline.  Measured before it: the tile's
+      // phases (QK^T MFMAs, softmax VALU, PV MFMAs, staging) cost their SUM -- hipcc issues all MFMAs
+      // of a phase back to back and the in-order wave then does its VALU with the matrix pipe idle.
+      // Here every MFMA is followed by one slice of independent work, fenced so the order survives:
+      //   QK^T(b0)            | K fragment reads two k-steps ahead
+      //   QK^T(b1)            | softmax of block 0 (its own online-softmax step: no wait for b1's max)
+      //   PV(b0), k-steps 0,1 | softmax of block 1, V^T fragment reads
+      //   PV(b1), k-steps 2,3 | staging: tile t+1 registers -> LDS, tile t+2 global loads
+      // (tile t+1 may be written any time after barrier t: its buffer's last readers were tile t-1's)
+      f32x16 s0, s1;
+      u32x4 pk0[2], pk1[2];
+      u32x4 vfa[DB], vfb[DB];
+      float ma, mb, m0, m1, alpha0, alpha1;
+      f32x2 ps0 = {0.f, 0.f}, ps1 = {0.f, 0.f};
+      // one slice of a block's softmax; j = 0..6
+      auto sm_slice = [&](int j, f32x16& sc, float m_prev, float& m_new, float& alpha, f32x2& ps, u32x4 (&pk)[2]) {
+        if (j == 0) {
+          ma = max3f(sc[0], sc[1], sc[2]);
+          mb = max3f(sc[3], sc[4], sc[5]);
+          ma = max3f(ma, sc[6], sc[7]);
+          mb = max3f(mb, sc[8], sc[9]);
+          asm volatile("" ::"v"(ma), "v"(mb));  // anchors: hipcc otherwise sinks a slice to its first use
+        } else if (j == 1) {
+          ma = max3f(ma, sc[10], sc[11]);
+          mb = max3f(mb, sc[12], sc[13]);
+          ma = max3f(ma, sc[14], sc[15]);
+          ma = max2f(ma, mb);
+          asm volatile("" ::"v"(ma));
+        } else if (j == 2) {
+          float mt = half_swap_max(ma) * c2;
+          mt = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
+          m_new = max2f(m_prev, mt);
+          alpha = fast_exp2(m_prev - m_new);
+          asm volatile("" ::"v"(m_new), "v"(alpha));
+        } else {
+          const int e = 4 * (j - 3);
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fast_exp2(__builtin_fmaf(sc[e + i], c2, -m_new));
+          ps[0] += v[0] + v[2];
+          ps[1] += v[1] + v[3];
+          if constexpr (VSCALE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= vs;
+          }
+          const int pi = 2 * (j - 3);
+          pk[pi >> 2][pi & 3] = pack2<T>(v[0], v[1]);
+          pk[(pi + 1) >> 2][(pi + 1) & 3] = pack2<T>(v[2], v[3]);
+          asm volatile("" ::"v"(pk[pi >> 2][pi & 3]), "v"(pk[(pi + 1) >> 2][(pi + 1) & 3]), "v"(ps));
+        }
+      };
+      auto load_v2 = [&](int step, int db0, u32x4 (&dst)[DB]) {  // two d blocks = 4 transposed reads
+#pragma unroll
+        for (int db = db0; db < db0 + 2; ++db) {
+          const u32x2 lo2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64);
+          const u32x2 hi2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64 + 8 * kVStride);
+          dst[db] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+        }
+      };
+      {
+        u32x4 kf[2 * KS];
+        kf[0] = load_k(tile, 0, 0);
+        kf[1] = load_k(tile, 0, 1);
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) {
+          if (i + 2 < 2 * KS) kf[i + 2] = load_k(tile, (i + 2) >> 3, (i + 2) & 7);
+          else load_v2(0, 2 * (i + 2 - 2 * KS), vfa);
+          if (i < KS) {
+            s0 = mfma32<T>(__builtin_bit_cast(vec8, kf[i]), qf[i], i == 0 ? zero16 : s0);
+          } else {
+            s1 = mfma32<T>(__builtin_bit_cast(vec8, kf[i]), qf[i - KS], i == KS ? zero16 : s1);
+            if (i > KS) sm_slice(i - KS - 1, s0, m_run, m0, alpha0, ps0, pk0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(alpha0 != 1.0f) != 0) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db) oacc[db] *= alpha0;
+      }
+      // PV(b0): k-steps 0 (vfa), 1 (vfb) | softmax of block 1
+#pragma unroll
+      for (int g = 0; g < 2 * DB; ++g) {
+        if (g < 2) load_v2(1, 2 * g, vfb);
+        if (g < DB) oacc[g] = mfma32<T>(__builtin_bit_cast(vec8, vfa[g]), __builtin_bit_cast(vec8, pk0[0]), oacc[g]);
+        else oacc[g - DB] = mfma32<T>(__builtin_bit_cast(vec8, vfb[g - DB]), __builtin_bit_cast(vec8, pk0[1]), oacc[g - DB]);
+        if (g >= DB && g < DB + 2) load_v2(2, 2 * (g - DB), vfa);
+        if (g < 7) sm_slice(g, s1, m0, m1, alpha1, ps1, pk1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      l_run = (l_run * alpha0 + (ps0[0] + ps0[1])) * alpha1 + (ps1[0] + ps1[1]);
+      m_run = m1;
+      if (__builtin_amdgcn_ballot_w64(alpha1 != 1.0f) != 0) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db) oacc[db] *= alpha1;
+      }
+      // PV(b1): k-steps 2 (vfa), 3 (vfb) | staging
+      {
+        const int t2 = t + 2;
+        const bool pre = t2 < nt1;
+        const uint16_t* kb = pre ? kbuf_h : kext_h;
+        const uint16_t* vb = pre ? vbuf_h : vext_h;
+        const int64_t kts = pre ? a.k_tok_stride : a.k_stride_t, vts = pre ? a.v_tok_stride : a.v_stride_t;
+        const int sh = (LINEAR || !pre) ? 31 : -a.page_size - 1;  // extend rows are never paged
+        const uint32_t lo_mask = (1u << sh) - 1u;
+#pragma unroll
+        for (int g = 0; g < 2 * DB; ++g) {
+          if (g < 2) load_v2(3, 2 * g, vfb);
+          if (g < DB) oacc[g] = mfma32<T>(__builtin_bit_cast(vec8, vfa[g]), __builtin_bit_cast(vec8, pk1[0]), oacc[g]);
+          else oacc[g - DB] = mfma32<T>(__builtin_bit_cast(vec8, vfb[g - DB]), __builtin_bit_cast(vec8, pk1[1]), oacc[g - DB]);
+          if (g == 2) write_lds((t + 1) & 1);
+          if (g >= 3 && g < 3 + NPASS && g - 3 < NPASS) {
+            const int i = g - 3;
+            const uint32_t sl = static_cast<uint32_t>(slot[i]);
+            stg_k[i] = *reinterpret_cast<const u32x4*>(kb + mul_u32(sl >> sh, a.k_page_stride) + mul_u32(sl & lo_mask, kts));
+            stg_v[i] = *reinterpret_cast<const u32x4*>(vb + mul_u32(sl >> sh, a.v_page_stride) + mul_u32(sl & lo_mask, vts));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (NPASS > 2 * DB - 3) {
+#pragma unroll
+          for (int i = 2 * DB - 3; i < NPASS; ++i) {
+            const uint32_t sl = static_cast<uint32_t>(slot[i]);
+            stg_k[i] = *reinterpret_cast<const u32x4*>(kb + mul_u32(sl >> sh, a.k_page_stride) + mul_u32(sl & lo_mask, kts));
+            stg_v[i] = *reinterpret_cast<const u32x4*>(vb + mul_u32(sl >> sh, a.v_page_stride) + mul_u32(sl & lo_mask, vts));
+          }
+        }
+        load_idx_tile(t + 3);
+      }
+    }
+    for (; t < nt; ++t) {
+      const TileInfo ti = tile_info(t);
+      if (ti.fast && t + 3 < nt) break;
+      tile_sync_and_stage(t);
+      if (!ti.work) continue;
+      const char* tile = smem + (t & 1) * kBufBytes;
+      const bool prefix = ti.prefix, full = ti.full;
+      const int tile_n0 = ti.tile_n0, nblk = ti.nblk;
+      const float cs = ti.cs, c2 = ti.c2, vs = ti.vs;
+      // ===== boundary tiles: causal diagonal, ragged ends, window, logit cap =========================
       f32x16 sacc[2];
-      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         if (b < nblk) {
-          const char* krow = kt + (32 * b + ql) * kRow;
-          // K fragments are fetched two k-steps ahead of the MFMA that consumes them: a ds_read_b128
-          // round trip is ~100+ cycles, an MFMA 32; without the explicit distance hipcc issues each
-          // read right in front of its MFMA and the matrix pipe idles on lgkmcnt(0)
-          u32x4 kfr[KS];
-          kfr[0] = *reinterpret_cast<const u32x4*>(krow + (((0 + h) ^ kswz) << 4));
-          kfr[1] = *reinterpret_cast<const u32x4*>(krow + (((2 + h) ^ kswz) << 4));
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 2 < KS)
-              kfr[ks + 2] = *reinterpret_cast<const u32x4*>(krow + (((2 * (ks + 2) + h) ^ kswz) << 4));
-            // the first MFMA takes the literal zero as C: no 16-register clear per block
-            sacc[b] = mfma32<T>(__builtin_bit_cast(vec8, kfr[ks]), qf[ks], ks == 0 ? zero16 : sacc[b]);
-          }
-          // pin the interleave (2 reads up front, then read / MFMA alternating) so the distance survives
-          // instruction scheduling: masks 0x100 = DS read, 0x008 = MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 2 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          }
+          for (int ks = 0; ks < KS; ++ks)
+            sacc[b] = mfma32<T>(__builtin_bit_cast(vec8, load_k(tile, b, ks)), qf[ks], ks == 0 ? zero16 : sacc[b]);
         }
       }
-      // ---- masks + online softmax: lane = one query, 16 tokens per block ------------------------------
-      bool full;
-      if (prefix) full = (tile_n0 + 32 * nblk <= p_len) && a.window <= 0;
-      else full = (tile_n0 + 32 * nblk <= E) && (!a.causal || tile_n0 + 32 * nblk - 1 <= qbase) && a.window <= 0;
       float mt = -INFINITY;
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -278,8 +476,7 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
               sacc[b][i] = keep ? sacc[b][i] : -INFINITY;
             }
           }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) mt = fmaxf(mt, sacc[b][i]);
+          mt = fmaxf(mt, row_max16(sacc[b]));
         }
       }
       mt = half_swap_max(mt);
@@ -291,65 +488,24 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
       float psum = 0.f;
       u32x4 pk[2][2];  // [block][k-step within block]: 8 bf16 = registers 8s..8s+7
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        if (b < nblk) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            sacc[b][i] = fast_exp2(__builtin_fmaf(sacc[b][i], c2, -m_new));
-            psum += sacc[b][i];
-          }
-          if constexpr (VSCALE) {
-            const float vs = prefix ? a.v_scale : 1.0f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[b][i] *= vs;
-          }
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pk[b][s][j] = pack2<T>(sacc[b][8 * s + 2 * j], sacc[b][8 * s + 2 * j + 1]);
-        }
-      }
+      for (int b = 0; b < 2; ++b)
+        if (b < nblk) psum += exp_pack(sacc[b], c2, m_new, vs, pk[b]);
       l_run = l_run * alpha + psum;
       if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) oacc[db] *= alpha;
       }
-      // ---- O^T += V^T P^T: the V^T fragments of k-step i+1 are in flight under the MFMAs of step i ----
-      {
-        const int nsteps = 2 * nblk;  // k-steps of 16 tokens
-        u32x4 vfr[2][DB];
-        auto load_v = [&](int step, u32x4 (&dst)[DB]) {
-          const int r0 = 16 * step;
-          const char* rlo = vt + (r0 + vrow_lo) * kRow + vbyte;
-          const char* rhi = vt + (r0 + vrow_hi) * kRow + vbyte;
 #pragma unroll
-          for (int db = 0; db < DB; ++db) {
-            const u32x2 lo2 = T::ds_read_tr(rlo + (((4 * db + vcol) ^ vsw_lo) << 4));
-            const u32x2 hi2 = T::ds_read_tr(rhi + (((4 * db + vcol) ^ vsw_hi) << 4));
-            dst[db] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
-          }
-        };
-        load_v(0, vfr[0]);
+      for (int step = 0; step < 4; ++step) {
+        if (step < 2 * nblk) {
+          u32x4 vf[DB];
+          load_v(tile, step, vf);
+          const vec8 pb = __builtin_bit_cast(vec8, pk[step >> 1][step & 1]);
 #pragma unroll
-        for (int step = 0; step < 4; ++step) {
-          if (step < nsteps) {
-            if (step + 1 < nsteps) load_v(step + 1, vfr[(step + 1) & 1]);
-            const vec8 pb = __builtin_bit_cast(vec8, pk[step >> 1][step & 1]);
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-              oacc[db] = mfma32<T>(__builtin_bit_cast(vec8, vfr[step & 1][db]), pb, oacc[db]);
-          }
+          for (int db = 0; db < DB; ++db) oacc[db] = mfma32<T>(__builtin_bit_cast(vec8, vf[db]), pb, oacc[db]);
         }
       }
     }
-    if (t + 1 < nt) {
-      write_lds((t + 1) & 1);
-      if (t + 2 < nt) {
-        issue_loads(t + 2);
-        if (t + 3 < nt) load_idx_tile(t + 3);
-      }
-    }
-    __syncthreads();
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------
@@ -382,8 +538,15 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
 template <int NW>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
-#define RX_E32(TT, IT, LIN, VS) \
-  hipLaunchKernelGGL((extend_mfma32_kernel<TT, IT, LIN, VS, NW>), dim3(grid), dim3(64 * NW), 0, s, a)
+  constexpr unsigned kLds = 2 * kBufBytes;  // 74 KiB: above the 64 KiB static limit, hence dynamic
+#define RX_E32(TT, IT, LIN, VS)                                                                        \
+  do {                                                                                                 \
+    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW>;                                             \
+    static const hipError_t attr = hipFuncSetAttribute(                                                \
+        reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);       \
+    (void)attr;                                                                                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), kLds, s, a);                                   \
+  } while (0)
 #define RX_E32_VS(TT, IT, LIN) \
   do { if (vs) RX_E32(TT, IT, LIN, true); else RX_E32(TT, IT, LIN, false); } while (0)
 #define RX_E32_LIN(TT, IT) \
