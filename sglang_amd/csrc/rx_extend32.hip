@@ -21,6 +21,10 @@
 // one block under the softmax VALU of the other); boundary tiles take a plain masked path.
 #include "rx_common.h"
 
+#ifndef RX_EXT32_STAMP
+#define RX_EXT32_STAMP 0  // 1: diagnostic build with s_memtime phase stamps (tools/ext_stamps.py); outputs are clobbered
+#endif
+
 namespace rx {
 
 struct Ext32Args {
@@ -108,12 +112,16 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, h = lane >> 5;
 
+  // XCD-aware decode of the block index: workgroups go to the 8 XCDs round robin, so kv head =
+  // block mod Hkv pins each kv head's K/V rows (the shared prefix: 1.8 MB per head at config 3) to
+  // one XCD's 4-MiB L2 instead of streaming all heads through every L2.
   int bid = blockIdx.x;
+  const int kvh = bid % a.hkv;
+  bid /= a.hkv;
   const int mb = bid % a.mblocks;
   bid /= a.mblocks;
-  const int head = bid % a.hq;
-  const int req = bid / a.hq;
-  const int kvh = head / a.group;
+  const int head = kvh * a.group + bid % a.group;
+  const int req = bid / a.group;
 
   const int64_t qo0 = load_idx(a.qo_indptr, req, a.qo64);
   const int32_t E = static_cast<int32_t>(load_idx(a.qo_indptr, req + 1, a.qo64) - qo0);
@@ -296,12 +304,26 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
   // The two tile bodies live in two separate inner loops (runs of fast tiles, runs of boundary
   // tiles): with both bodies inside one loop hipcc's allocator spills 147 registers, each alone fits.
   // Waves of one workgroup may be in different loops at the same t; every tile is one barrier either way.
+#if RX_EXT32_STAMP
+  uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define RX_STAMP(i)                                                   \
+  do {                                                                \
+    const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();     \
+    st_acc[i] += now_ - st_prev;                                      \
+    st_prev = now_;                                                   \
+  } while (0)
+  uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
+#else
+#define RX_STAMP(i)
+#endif
   int t = 0;
   while (t < nt) {
     for (; t + 3 < nt; ++t) {
       const TileInfo ti = tile_info(t);
       if (!ti.fast) break;
+      RX_STAMP(5);
       __syncthreads();
+      RX_STAMP(0);
       const char* tile = smem + (t & 1) * kBufBytes;
       const float c2 = ti.c2, vs = ti.vs;
       // ===== fast body: a hand-ordered wave-level software pipeline.  Measured before it: the tile's
@@ -380,6 +402,7 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      RX_STAMP(1);
       if (__builtin_amdgcn_ballot_w64(alpha0 != 1.0f) != 0) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) oacc[db] *= alpha0;
@@ -396,6 +419,7 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
       }
       l_run = (l_run * alpha0 + (ps0[0] + ps0[1])) * alpha1 + (ps1[0] + ps1[1]);
       m_run = m1;
+      RX_STAMP(2);
       if (__builtin_amdgcn_ballot_w64(alpha1 != 1.0f) != 0) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) oacc[db] *= alpha1;
@@ -433,7 +457,9 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
         }
         load_idx_tile(t + 3);
       }
+      RX_STAMP(3);
     }
+    RX_STAMP(5);
     for (; t < nt; ++t) {
       const TileInfo ti = tile_info(t);
       if (ti.fast && t + 3 < nt) break;
@@ -508,6 +534,7 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
     }
   }
 
+  RX_STAMP(4);
   // ---- epilogue -------------------------------------------------------------------------------------
   if (!active) return;
   float l = l_run;
@@ -532,6 +559,12 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
     }
   }
   if (a.lse && h == 0) a.lse[(qo0 + m) * a.lse_stride_t + head * a.lse_stride_h] = m_run * kLn2 + __logf(l);
+#if RX_EXT32_STAMP
+  if (lane == 0) {  // diagnostic build: the stamps REPLACE the first 24 bytes of the wave's first output row
+    uint32_t* dbg = reinterpret_cast<uint32_t*>(a.o + (qo0 + qbase) * a.o_stride_t + head * a.o_stride_h);
+    for (int i = 0; i < 6; ++i) dbg[i] = st_acc[i];
+  }
+#endif
 }
 
 // launcher used by rx_extend.hip for head_dim == v_head_dim == 128
