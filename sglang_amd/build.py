@@ -15,7 +15,9 @@ LIB_PATH = os.path.join(HERE, os.environ.get("RX_LIB_NAME", "libradix_hip.so"))
 SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_decode_mla.hip", "rx_extend.hip", "rx_extend32.hip", "rx_radix.cpp"]
 # rx_extend32: without -fno-honor-nans every fmaxf on an MFMA result is preceded by a canonicalising
 # v_max_f32 x, x, x (one extra VALU per score in a VALU-issue-bound loop).  The kernel creates no NaN.
-EXTRA_FLAGS = {"rx_extend32.hip": ["-fno-honor-nans"]}
+# -amdgpu-mfma-vgpr-form: at one wave per SIMD hipcc otherwise puts every MFMA result in AGPRs and
+# copies each 16-register accumulator back for the softmax VALU (2000+ v_accvgpr moves in the kernel).
+EXTRA_FLAGS = {"rx_extend32.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 HEADERS = ["rx_common.h", os.path.join(ROOT, "include", "radix_hip.h")]
 
 

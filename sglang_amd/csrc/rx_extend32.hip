@@ -96,15 +96,15 @@ __device__ __forceinline__ float half_swap_max(float x) {
   return a;
 }
 
-template <typename T, typename IdxT, bool LINEAR, bool VSCALE, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Args a) {
+template <typename T, typename IdxT, bool LINEAR, bool VSCALE, int NW, int QB>
+__global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel(const Ext32Args a) {
   using vec8 = typename T::vec8;
   constexpr int KS = kD / 16;                  // 8 k-steps of the QK^T product
   constexpr int DB = kD / 32;                  // 4 output d blocks of 32
   constexpr int THREADS = 64 * NW;
   constexpr int RPP = THREADS / 16;            // rows staged per pass
   constexpr int NPASS = kTok / RPP;            // 2 (NW=8) or 4 (NW=4)
-  constexpr int QPW = 32;                      // queries per wave
+  constexpr int QPW = 32 * QB;                 // queries per wave: QB blocks of 32
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
 
   const int tid = threadIdx.x;
@@ -132,17 +132,21 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
   const int32_t qbase = qb0 + w * QPW;
   const bool active = qbase < E;
   const IdxT* idx = reinterpret_cast<const IdxT*>(a.kv_indices) + kv0;
-  const int m = qbase + ql;  // this lane's query (index inside the extend part)
+  // this lane's queries (index inside the extend part): one per 32-query block
+  int m[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) m[qb] = qbase + 32 * qb + ql;
 
   // ---- Q^T fragments: lane (q, h) holds Q[q][16 ks + 8 h .. +8] ------------------------------------
-  vec8 qf[KS];
-  {
-    const bool ok = m < E;
-    const uint16_t* qp = a.q + (qo0 + (ok ? m : 0)) * a.q_stride_t + head * a.q_stride_h + 8 * h;
+  vec8 qf[QB][KS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const bool ok = m[qb] < E;
+    const uint16_t* qp = a.q + (qo0 + (ok ? m[qb] : 0)) * a.q_stride_t + head * a.q_stride_h + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 16 * ks) : u32x4{0, 0, 0, 0};
-      qf[ks] = __builtin_bit_cast(vec8, raw);
+      qf[qb][ks] = __builtin_bit_cast(vec8, raw);
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // Q landed before the loop (see rx_extend.hip)
@@ -199,12 +203,17 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
     }
   };
 
-  f32x16 oacc[DB];
+  f32x16 oacc[QB][DB];
+  float m_run[QB], l_run[QB];
 #pragma unroll
-  for (int db = 0; db < DB; ++db)
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY;
+    l_run[qb] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[qb][db][i] = 0.f;
+  }
 
   if (nt > 0) {
     load_idx_tile(0);
@@ -230,13 +239,10 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
     return *reinterpret_cast<const u32x4*>(tile + kaddr + b * 32 * kKStride + ks * 32);
   };
   // V^T fragments of k-step `step` (16 tokens): rows 16 step + 4 h + qd (+8), d block db
-  auto load_v = [&](const char* tile, int step, u32x4 (&dst)[DB]) {
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      const u32x2 lo2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64);
-      const u32x2 hi2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64 + 8 * kVStride);
-      dst[db] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
-    }
+  auto load_v1 = [&](const char* tile, int step, int db) {
+    const u32x2 lo2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64);
+    const u32x2 hi2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64 + 8 * kVStride);
+    return u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
   };
   // exp2(s c2 - m) on one 32-token block, P packed to 16-bit as the next product's B operand; returns
   // the lane's partial row sum.  Scalar fp32 on purpose: v_pk_*_f32 beside MFMAs costs more than the
@@ -301,9 +307,6 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
     }
   };
 
-  // The two tile bodies live in two separate inner loops (runs of fast tiles, runs of boundary
-  // tiles): with both bodies inside one loop hipcc's allocator spills 147 registers, each alone fits.
-  // Waves of one workgroup may be in different loops at the same t; every tile is one barrier either way.
 #if RX_EXT32_STAMP
   uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
 #define RX_STAMP(i)                                                   \
@@ -316,6 +319,10 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
 #else
 #define RX_STAMP(i)
 #endif
+
+  // The two tile bodies live in two separate inner loops (runs of fast tiles, runs of boundary
+  // tiles): with both bodies inside one loop hipcc's allocator spills 147 registers, each alone fits.
+  // Waves of one workgroup may be in different loops at the same t; every tile is one barrier either way.
   int t = 0;
   while (t < nt) {
     for (; t + 3 < nt; ++t) {
@@ -329,33 +336,37 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
       // ===== fast body: a hand-ordered wave-level software pipeline.  Measured before it: the tile's
       // phases (QK^T MFMAs, softmax VALU, PV MFMAs, staging) cost their SUM -- hipcc issues all MFMAs
       // of a phase back to back and the in-order wave then does its VALU with the matrix pipe idle.
-      // Here every MFMA is followed by one slice of independent work, fenced so the order survives:
+      // Here every group of QB MFMAs (one K or V^T fragment against each 32-query block) is followed
+      // by one slice of independent work, fenced so the order survives:
       //   QK^T(b0)            | K fragment reads two k-steps ahead
       //   QK^T(b1)            | softmax of block 0 (its own online-softmax step: no wait for b1's max)
       //   PV(b0), k-steps 0,1 | softmax of block 1, V^T fragment reads
       //   PV(b1), k-steps 2,3 | staging: tile t+1 registers -> LDS, tile t+2 global loads
       // (tile t+1 may be written any time after barrier t: its buffer's last readers were tile t-1's)
-      f32x16 s0, s1;
-      u32x4 pk0[2], pk1[2];
+      f32x16 s0[QB], s1[QB];
+      u32x4 pk0[QB][2], pk1[QB][2];
       u32x4 vfa[DB], vfb[DB];
-      float ma, mb, m0, m1, alpha0, alpha1;
-      f32x2 ps0 = {0.f, 0.f}, ps1 = {0.f, 0.f};
-      // one slice of a block's softmax; j = 0..6
-      auto sm_slice = [&](int j, f32x16& sc, float m_prev, float& m_new, float& alpha, f32x2& ps, u32x4 (&pk)[2]) {
+      float ma[QB], mb_[QB], m0[QB], m1[QB], alpha0[QB], alpha1[QB];
+      float ps0[QB][2], ps1[QB][2];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) ps0[qb][0] = ps0[qb][1] = ps1[qb][0] = ps1[qb][1] = 0.f;
+      // one slice of a block's softmax for query block qb; j = 0..6
+      auto sm_slice = [&](int j, int qb, f32x16& sc, float m_prev, float& m_new, float& alpha, float (&ps)[2],
+                          u32x4 (&pk)[2]) {
         if (j == 0) {
-          ma = max3f(sc[0], sc[1], sc[2]);
-          mb = max3f(sc[3], sc[4], sc[5]);
-          ma = max3f(ma, sc[6], sc[7]);
-          mb = max3f(mb, sc[8], sc[9]);
-          asm volatile("" ::"v"(ma), "v"(mb));  // anchors: hipcc otherwise sinks a slice to its first use
+          ma[qb] = max3f(sc[0], sc[1], sc[2]);
+          mb_[qb] = max3f(sc[3], sc[4], sc[5]);
+          ma[qb] = max3f(ma[qb], sc[6], sc[7]);
+          mb_[qb] = max3f(mb_[qb], sc[8], sc[9]);
+          asm volatile("" ::"v"(ma[qb]), "v"(mb_[qb]));  // anchors: hipcc otherwise sinks a slice to its first use
         } else if (j == 1) {
-          ma = max3f(ma, sc[10], sc[11]);
-          mb = max3f(mb, sc[12], sc[13]);
-          ma = max3f(ma, sc[14], sc[15]);
-          ma = max2f(ma, mb);
-          asm volatile("" ::"v"(ma));
+          ma[qb] = max3f(ma[qb], sc[10], sc[11]);
+          mb_[qb] = max3f(mb_[qb], sc[12], sc[13]);
+          ma[qb] = max3f(ma[qb], sc[14], sc[15]);
+          ma[qb] = max2f(ma[qb], mb_[qb]);
+          asm volatile("" ::"v"(ma[qb]));
         } else if (j == 2) {
-          float mt = half_swap_max(ma) * c2;
+          float mt = half_swap_max(ma[qb]) * c2;
           mt = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
           m_new = max2f(m_prev, mt);
           alpha = fast_exp2(m_prev - m_new);
@@ -374,15 +385,7 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
           const int pi = 2 * (j - 3);
           pk[pi >> 2][pi & 3] = pack2<T>(v[0], v[1]);
           pk[(pi + 1) >> 2][(pi + 1) & 3] = pack2<T>(v[2], v[3]);
-          asm volatile("" ::"v"(pk[pi >> 2][pi & 3]), "v"(pk[(pi + 1) >> 2][(pi + 1) & 3]), "v"(ps));
-        }
-      };
-      auto load_v2 = [&](int step, int db0, u32x4 (&dst)[DB]) {  // two d blocks = 4 transposed reads
-#pragma unroll
-        for (int db = db0; db < db0 + 2; ++db) {
-          const u32x2 lo2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64);
-          const u32x2 hi2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64 + 8 * kVStride);
-          dst[db] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+          asm volatile("" ::"v"(pk[pi >> 2][pi & 3]), "v"(pk[(pi + 1) >> 2][(pi + 1) & 3]), "v"(ps[0]), "v"(ps[1]));
         }
       };
       {
@@ -391,38 +394,70 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
         kf[1] = load_k(tile, 0, 1);
 #pragma unroll
         for (int i = 0; i < 2 * KS; ++i) {
-          if (i + 2 < 2 * KS) kf[i + 2] = load_k(tile, (i + 2) >> 3, (i + 2) & 7);
-          else load_v2(0, 2 * (i + 2 - 2 * KS), vfa);
-          if (i < KS) {
-            s0 = mfma32<T>(__builtin_bit_cast(vec8, kf[i]), qf[i], i == 0 ? zero16 : s0);
-          } else {
-            s1 = mfma32<T>(__builtin_bit_cast(vec8, kf[i]), qf[i - KS], i == KS ? zero16 : s1);
-            if (i > KS) sm_slice(i - KS - 1, s0, m_run, m0, alpha0, ps0, pk0);
+          if (i + 2 < 2 * KS) {
+            kf[i + 2] = load_k(tile, (i + 2) >> 3, (i + 2) & 7);
+          } else {  // last two gaps: the first PV k-step's V^T fragments
+            vfa[2 * (i + 2 - 2 * KS)] = load_v1(tile, 0, 2 * (i + 2 - 2 * KS));
+            vfa[2 * (i + 2 - 2 * KS) + 1] = load_v1(tile, 0, 2 * (i + 2 - 2 * KS) + 1);
+          }
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            if (i < KS) s0[qb] = mfma32<T>(__builtin_bit_cast(vec8, kf[i]), qf[qb][i], i == 0 ? zero16 : s0[qb]);
+            else s1[qb] = mfma32<T>(__builtin_bit_cast(vec8, kf[i]), qf[qb][i - KS], i == KS ? zero16 : s1[qb]);
+          }
+          if (i > KS) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+              sm_slice(i - KS - 1, qb, s0[qb], m_run[qb], m0[qb], alpha0[qb], ps0[qb], pk0[qb]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
       RX_STAMP(1);
-      if (__builtin_amdgcn_ballot_w64(alpha0 != 1.0f) != 0) {
 #pragma unroll
-        for (int db = 0; db < DB; ++db) oacc[db] *= alpha0;
+      for (int qb = 0; qb < QB; ++qb) {
+        if (__builtin_amdgcn_ballot_w64(alpha0[qb] != 1.0f) != 0) {
+#pragma unroll
+          for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha0[qb];
+        }
       }
       // PV(b0): k-steps 0 (vfa), 1 (vfb) | softmax of block 1
 #pragma unroll
       for (int g = 0; g < 2 * DB; ++g) {
-        if (g < 2) load_v2(1, 2 * g, vfb);
-        if (g < DB) oacc[g] = mfma32<T>(__builtin_bit_cast(vec8, vfa[g]), __builtin_bit_cast(vec8, pk0[0]), oacc[g]);
-        else oacc[g - DB] = mfma32<T>(__builtin_bit_cast(vec8, vfb[g - DB]), __builtin_bit_cast(vec8, pk0[1]), oacc[g - DB]);
-        if (g >= DB && g < DB + 2) load_v2(2, 2 * (g - DB), vfa);
-        if (g < 7) sm_slice(g, s1, m0, m1, alpha1, ps1, pk1);
+        if (g < 2) {
+          vfb[2 * g] = load_v1(tile, 1, 2 * g);
+          vfb[2 * g + 1] = load_v1(tile, 1, 2 * g + 1);
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          if (g < DB)
+            oacc[qb][g] = mfma32<T>(__builtin_bit_cast(vec8, vfa[g]), __builtin_bit_cast(vec8, pk0[qb][0]), oacc[qb][g]);
+          else
+            oacc[qb][g - DB] = mfma32<T>(__builtin_bit_cast(vec8, vfb[g - DB]), __builtin_bit_cast(vec8, pk0[qb][1]),
+                                         oacc[qb][g - DB]);
+        }
+        if (g >= DB && g < DB + 2) {
+          vfa[2 * (g - DB)] = load_v1(tile, 2, 2 * (g - DB));
+          vfa[2 * (g - DB) + 1] = load_v1(tile, 2, 2 * (g - DB) + 1);
+        }
+        if (g < 7) {
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) sm_slice(g, qb, s1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      l_run = (l_run * alpha0 + (ps0[0] + ps0[1])) * alpha1 + (ps1[0] + ps1[1]);
-      m_run = m1;
-      RX_STAMP(2);
-      if (__builtin_amdgcn_ballot_w64(alpha1 != 1.0f) != 0) {
 #pragma unroll
-        for (int db = 0; db < DB; ++db) oacc[db] *= alpha1;
+      for (int qb = 0; qb < QB; ++qb) {
+        l_run[qb] = (l_run[qb] * alpha0[qb] + (ps0[qb][0] + ps0[qb][1])) * alpha1[qb] + (ps1[qb][0] + ps1[qb][1]);
+        m_run[qb] = m1[qb];
+      }
+      RX_STAMP(2);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        if (__builtin_amdgcn_ballot_w64(alpha1[qb] != 1.0f) != 0) {
+#pragma unroll
+          for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha1[qb];
+        }
       }
       // PV(b1): k-steps 2 (vfa), 3 (vfb) | staging
       {
@@ -433,28 +468,31 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
         const int64_t kts = pre ? a.k_tok_stride : a.k_stride_t, vts = pre ? a.v_tok_stride : a.v_stride_t;
         const int sh = (LINEAR || !pre) ? 31 : -a.page_size - 1;  // extend rows are never paged
         const uint32_t lo_mask = (1u << sh) - 1u;
+        auto reissue = [&](int i) {
+          const uint32_t sl = static_cast<uint32_t>(slot[i]);
+          stg_k[i] = *reinterpret_cast<const u32x4*>(kb + mul_u32(sl >> sh, a.k_page_stride) + mul_u32(sl & lo_mask, kts));
+          stg_v[i] = *reinterpret_cast<const u32x4*>(vb + mul_u32(sl >> sh, a.v_page_stride) + mul_u32(sl & lo_mask, vts));
+        };
 #pragma unroll
         for (int g = 0; g < 2 * DB; ++g) {
-          if (g < 2) load_v2(3, 2 * g, vfb);
-          if (g < DB) oacc[g] = mfma32<T>(__builtin_bit_cast(vec8, vfa[g]), __builtin_bit_cast(vec8, pk1[0]), oacc[g]);
-          else oacc[g - DB] = mfma32<T>(__builtin_bit_cast(vec8, vfb[g - DB]), __builtin_bit_cast(vec8, pk1[1]), oacc[g - DB]);
-          if (g == 2) write_lds((t + 1) & 1);
-          if (g >= 3 && g < 3 + NPASS && g - 3 < NPASS) {
-            const int i = g - 3;
-            const uint32_t sl = static_cast<uint32_t>(slot[i]);
-            stg_k[i] = *reinterpret_cast<const u32x4*>(kb + mul_u32(sl >> sh, a.k_page_stride) + mul_u32(sl & lo_mask, kts));
-            stg_v[i] = *reinterpret_cast<const u32x4*>(vb + mul_u32(sl >> sh, a.v_page_stride) + mul_u32(sl & lo_mask, vts));
+          if (g < 2) {
+            vfb[2 * g] = load_v1(tile, 3, 2 * g);
+            vfb[2 * g + 1] = load_v1(tile, 3, 2 * g + 1);
           }
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            if (g < DB)
+              oacc[qb][g] = mfma32<T>(__builtin_bit_cast(vec8, vfa[g]), __builtin_bit_cast(vec8, pk1[qb][0]), oacc[qb][g]);
+            else
+              oacc[qb][g - DB] = mfma32<T>(__builtin_bit_cast(vec8, vfb[g - DB]), __builtin_bit_cast(vec8, pk1[qb][1]),
+                                           oacc[qb][g - DB]);
+          }
+          if (g == 2) write_lds((t + 1) & 1);
+          if (g >= 3 && g - 3 < NPASS) reissue(g - 3);
           __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (NPASS > 2 * DB - 3) {
 #pragma unroll
-          for (int i = 2 * DB - 3; i < NPASS; ++i) {
-            const uint32_t sl = static_cast<uint32_t>(slot[i]);
-            stg_k[i] = *reinterpret_cast<const u32x4*>(kb + mul_u32(sl >> sh, a.k_page_stride) + mul_u32(sl & lo_mask, kts));
-            stg_v[i] = *reinterpret_cast<const u32x4*>(vb + mul_u32(sl >> sh, a.v_page_stride) + mul_u32(sl & lo_mask, vts));
-          }
-        }
+        for (int i = 2 * DB - 3; i < NPASS; ++i) reissue(i);
         load_idx_tile(t + 3);
       }
       RX_STAMP(3);
@@ -469,66 +507,68 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
       const bool prefix = ti.prefix, full = ti.full;
       const int tile_n0 = ti.tile_n0, nblk = ti.nblk;
       const float cs = ti.cs, c2 = ti.c2, vs = ti.vs;
-      // ===== boundary tiles: causal diagonal, ragged ends, window, logit cap =========================
-      f32x16 sacc[2];
+      // ===== boundary tiles: causal diagonal, ragged ends, window, logit cap; one query block at a time
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        if (b < nblk) {
+      for (int qb = 0; qb < QB; ++qb) {
+        f32x16 sacc[2];
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks)
-            sacc[b] = mfma32<T>(__builtin_bit_cast(vec8, load_k(tile, b, ks)), qf[ks], ks == 0 ? zero16 : sacc[b]);
-        }
-      }
-      float mt = -INFINITY;
+        for (int b = 0; b < 2; ++b) {
+          if (b < nblk) {
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        if (b < nblk) {
-          if (capped) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[b][i] = a.logit_cap * tanhf(sacc[b][i] * cs / a.logit_cap);
+            for (int ks = 0; ks < KS; ++ks)
+              sacc[b] = mfma32<T>(__builtin_bit_cast(vec8, load_k(tile, b, ks)), qf[qb][ks], ks == 0 ? zero16 : sacc[b]);
           }
-          if (!full) {
+        }
+        float mt = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const int n = tile_n0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
-              bool keep;
-              if (prefix) {
-                keep = n < p_len;
-                if (a.window > 0) keep = keep && (P + m <= n + a.window);
-              } else {
-                keep = n < n_end_w && (!a.causal || n <= m);
-                if (a.window > 0) keep = keep && (m <= n + a.window);
-              }
-              sacc[b][i] = keep ? sacc[b][i] : -INFINITY;
+        for (int b = 0; b < 2; ++b) {
+          if (b < nblk) {
+            if (capped) {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) sacc[b][i] = a.logit_cap * tanhf(sacc[b][i] * cs / a.logit_cap);
             }
+            if (!full) {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                const int n = tile_n0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
+                bool keep;
+                if (prefix) {
+                  keep = n < p_len;
+                  if (a.window > 0) keep = keep && (P + m[qb] <= n + a.window);
+                } else {
+                  keep = n < n_end_w && (!a.causal || n <= m[qb]);
+                  if (a.window > 0) keep = keep && (m[qb] <= n + a.window);
+                }
+                sacc[b][i] = keep ? sacc[b][i] : -INFINITY;
+              }
+            }
+            mt = fmaxf(mt, row_max16(sacc[b]));
           }
-          mt = fmaxf(mt, row_max16(sacc[b]));
         }
-      }
-      mt = half_swap_max(mt);
-      mt *= c2;
-      const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
-      const float m_new = fmaxf(m_run, mt_fixed);
-      const float alpha = fast_exp2(m_run - m_new);
-      m_run = m_new;
-      float psum = 0.f;
-      u32x4 pk[2][2];  // [block][k-step within block]: 8 bf16 = registers 8s..8s+7
+        mt = half_swap_max(mt);
+        mt *= c2;
+        const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
+        const float m_new = fmaxf(m_run[qb], mt_fixed);
+        const float alpha = fast_exp2(m_run[qb] - m_new);
+        m_run[qb] = m_new;
+        float psum = 0.f;
+        u32x4 pk[2][2];  // [block][k-step within block]: 8 bf16 = registers 8s..8s+7
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-        if (b < nblk) psum += exp_pack(sacc[b], c2, m_new, vs, pk[b]);
-      l_run = l_run * alpha + psum;
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+        for (int b = 0; b < 2; ++b)
+          if (b < nblk) psum += exp_pack(sacc[b], c2, m_new, vs, pk[b]);
+        l_run[qb] = l_run[qb] * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-        for (int db = 0; db < DB; ++db) oacc[db] *= alpha;
-      }
+          for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha;
+        }
 #pragma unroll
-      for (int step = 0; step < 4; ++step) {
-        if (step < 2 * nblk) {
-          u32x4 vf[DB];
-          load_v(tile, step, vf);
-          const vec8 pb = __builtin_bit_cast(vec8, pk[step >> 1][step & 1]);
+        for (int step = 0; step < 4; ++step) {
+          if (step < 2 * nblk) {
+            const vec8 pb = __builtin_bit_cast(vec8, pk[step >> 1][step & 1]);
 #pragma unroll
-          for (int db = 0; db < DB; ++db) oacc[db] = mfma32<T>(__builtin_bit_cast(vec8, vf[db]), pb, oacc[db]);
+            for (int db = 0; db < DB; ++db)
+              oacc[qb][db] = mfma32<T>(__builtin_bit_cast(vec8, load_v1(tile, step, db)), pb, oacc[qb][db]);
+          }
         }
       }
     }
@@ -537,28 +577,33 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
   RX_STAMP(4);
   // ---- epilogue -------------------------------------------------------------------------------------
   if (!active) return;
-  float l = l_run;
-  {
-    float a2 = l, b2 = l;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(a2), "+v"(b2));
-    l = a2;
-  }
-  if (m >= E) return;
-  float den = l;
-  if (a.sinks) den += fast_exp2(a.sinks[head] * kLog2e - m_run);
-  const float inv = 1.0f / den;
-  uint16_t* op = a.o + (qo0 + m) * a.o_stride_t + head * a.o_stride_h + 4 * h;
 #pragma unroll
-  for (int db = 0; db < DB; ++db) {
+  for (int qb = 0; qb < QB; ++qb) {
+    float l = l_run[qb];
+    {
+      float a2 = l, b2 = l;
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(a2), "+v"(b2));
+      l = a2;
+    }
+    if (m[qb] < E) {
+      float den = l;
+      if (a.sinks) den += fast_exp2(a.sinks[head] * kLog2e - m_run[qb]);
+      const float inv = 1.0f / den;
+      uint16_t* op = a.o + (qo0 + m[qb]) * a.o_stride_t + head * a.o_stride_h + 4 * h;
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {  // registers 4 gq .. 4 gq + 3 = d 32 db + 8 gq + 4 h + 0..3
-      u32x2 pk2;
-      pk2[0] = pack2<T>(oacc[db][4 * gq] * inv, oacc[db][4 * gq + 1] * inv);
-      pk2[1] = pack2<T>(oacc[db][4 * gq + 2] * inv, oacc[db][4 * gq + 3] * inv);
-      *reinterpret_cast<u32x2*>(op + 32 * db + 8 * gq) = pk2;
+      for (int db = 0; db < DB; ++db) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {  // registers 4 gq .. 4 gq + 3 = d 32 db + 8 gq + 4 h + 0..3
+          u32x2 pk2;
+          pk2[0] = pack2<T>(oacc[qb][db][4 * gq] * inv, oacc[qb][db][4 * gq + 1] * inv);
+          pk2[1] = pack2<T>(oacc[qb][db][4 * gq + 2] * inv, oacc[qb][db][4 * gq + 3] * inv);
+          *reinterpret_cast<u32x2*>(op + 32 * db + 8 * gq) = pk2;
+        }
+      }
+      if (a.lse && h == 0)
+        a.lse[(qo0 + m[qb]) * a.lse_stride_t + head * a.lse_stride_h] = m_run[qb] * kLn2 + __logf(l);
     }
   }
-  if (a.lse && h == 0) a.lse[(qo0 + m) * a.lse_stride_t + head * a.lse_stride_h] = m_run * kLn2 + __logf(l);
 #if RX_EXT32_STAMP
   if (lane == 0) {  // diagnostic build: the stamps REPLACE the first 24 bytes of the wave's first output row
     uint32_t* dbg = reinterpret_cast<uint32_t*>(a.o + (qo0 + qbase) * a.o_stride_t + head * a.o_stride_h);
@@ -568,13 +613,13 @@ __global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Ar
 }
 
 // launcher used by rx_extend.hip for head_dim == v_head_dim == 128
-template <int NW>
+template <int NW, int QB>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
   constexpr unsigned kLds = 2 * kBufBytes;  // 74 KiB: above the 64 KiB static limit, hence dynamic
 #define RX_E32(TT, IT, LIN, VS)                                                                        \
   do {                                                                                                 \
-    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW>;                                             \
+    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB>;                                         \
     static const hipError_t attr = hipFuncSetAttribute(                                                \
         reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);       \
     (void)attr;                                                                                        \
@@ -594,8 +639,13 @@ static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, 
 #undef RX_E32
 }
 
-#ifndef RX_EXT32_NW
-#define RX_EXT32_NW 8
+#ifndef RX_EXT32_QB
+// 32-query blocks per wave.  1 = eight waves x 32 queries, two waves per SIMD (default: 753 TFLOP/s at
+// config 3).  2 = four waves x 64 queries, one wave per SIMD with the 512-register file: halves the LDS
+// fragment traffic per FLOP, but as compiled by hipcc (accumulators shuffled between VGPRs and AGPRs,
+// no second wave to cover the in-order stalls) it measured 373 TFLOP/s -- kept for a hand-allocated
+// follow-up, not dispatched.
+#define RX_EXT32_QB 1
 #endif
 
 int launch_extend32(const rx_extend_params* p, hipStream_t s) {
@@ -625,9 +675,9 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
-  constexpr int NW = RX_EXT32_NW;
-  a.mblocks = (p->max_extend_len + NW * 32 - 1) / (NW * 32);
-  launch32_nw<NW>(a, p->dtype == RX_BF16, p->kv_indices_is_i64 != 0, linear, p->v_scale != 1.0f, s);
+  constexpr int QB = RX_EXT32_QB, NW = 8 / QB;  // 256 queries per workgroup either way
+  a.mblocks = (p->max_extend_len + 255) / 256;
+  launch32_nw<NW, QB>(a, p->dtype == RX_BF16, p->kv_indices_is_i64 != 0, linear, p->v_scale != 1.0f, s);
   return RX_OK;
 }
 

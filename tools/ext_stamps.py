@@ -27,7 +27,8 @@ for _ in range(3):
     ops.extend_attention_fwd(q, k_ext, v_ext, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True,
                              None, E, 1.0, 1.0, sm_scale=D ** -0.5, page_size=1)
 torch.cuda.synchronize()
-rows = o.view(chunk, E // 32, 32, HQ, D)[:, :, 0]          # first row of every wave: [req, wave, head, D]
+QPW = int(os.environ.get("QPW", "64"))
+rows = o.view(chunk, E // QPW, QPW, HQ, D)[:, :, 0]          # first row of every wave: [req, wave, head, D]
 st = rows.contiguous().view(torch.int32)[..., :6].to(torch.float64)  # [req, wave, head, 6]
 names = ["barrier", "QK+SM0", "PV0+SM1", "PV1+stage", "boundary+exit", "loop ovh"]
 tot = st.sum(-1, keepdim=True)
