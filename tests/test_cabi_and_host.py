@@ -56,6 +56,35 @@ def test_ops_refuse_cpu_tensors_loudly():
         ops.store_cache(k, k, k, k, torch.tensor([1, 0]))
 
 
+def test_torch_custom_ops_registered_with_fake_impls():
+    """torch.ops.radix_hip.* (the reference binds its kernels with register_custom_op,
+    srt/utils/custom_op.py): schemas mark the mutated tensors, fake impls trace, CPU tensors raise."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    from sglang_amd import custom_ops
+
+    names = {o._qualname.split("::")[1] for o in custom_ops.ALL_OPS}
+    assert names == {"store_cache", "build_kv_indices", "get_num_kv_splits", "decode_attention",
+                     "decode_attention_paged", "extend_attention", "alloc_extend", "alloc_decode",
+                     "write_req_to_token", "move_kv"}
+    sch = str(torch.ops.radix_hip.decode_attention.default._schema)
+    assert "Tensor(a3!) o" in sch and "attn_logits" in sch and sch.endswith("-> ()")
+    assert "!" in str(torch.ops.radix_hip.store_cache.default._schema)
+
+    def args():
+        q = torch.empty(4, 8, 128, dtype=torch.bfloat16)
+        kb = torch.empty(100, 2, 128, dtype=torch.bfloat16)
+        return (q, kb, kb, torch.empty_like(q), torch.empty(5, dtype=torch.int32),
+                torch.empty(64, dtype=torch.int64), torch.empty(4, 8, 8, 128), torch.empty(4, 8, 8),
+                torch.empty(4, dtype=torch.int32), 8, 0.088)
+
+    with FakeTensorMode():
+        assert torch.ops.radix_hip.decode_attention(*args()) is None
+    with pytest.raises(RuntimeError, match="GPU"):
+        torch.ops.radix_hip.decode_attention(*args())
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "sglang_amd")
     for dp, _, files in os.walk(pkg):

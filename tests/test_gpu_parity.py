@@ -573,3 +573,44 @@ def test_k_and_v_scales(ops):
     ops.extend_attention_fwd(qe.to(DEV), ke.to(DEV), ve.to(DEV), oe, kbe.to(DEV), vbe.to(DEV), _t(np.array([0, 40])),
                              _t(np.array([0, 20], dtype=np.int32)), _t(kvi), None, True, None, 40, 0.5, 2.0, sm_scale=0.2)
     assert np.abs(_np(oe.float()) - want_e).max() <= 6e-3
+
+
+def test_torch_custom_ops_match_direct_calls_and_capture(ops, golden_dir):
+    """torch.ops.radix_hip.* is the same code path as sglang_amd.ops, and replays under a HIP graph."""
+    from sglang_amd import custom_ops  # noqa: F401  (registers the ops)
+
+    cases = _cases(np.load(os.path.join(golden_dir, "decode.npz")))
+    name, c = next(iter(cases.items()))
+    o_ref, al_ref, lse_ref = _run_decode(ops, c, "split", None)
+    q, kb, vb = _t(c["q"]), _t(c["kb"]), _t(c["vb"])
+    S = int(c["max_splits"])
+    o = torch.zeros_like(o_ref)
+    al, lse = torch.zeros_like(al_ref), torch.zeros_like(lse_ref)
+    a = (q, kb, vb, o, _t(c["kv_indptr"]), _t(c["kv_indices"]), al, lse, _t(c["nsplit"]), S,
+         float(c["sm_scale"]))
+    torch.ops.radix_hip.decode_attention(*a)
+    assert torch.equal(o, o_ref)
+    # HIP graph capture through the dispatcher
+    o.zero_()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        torch.ops.radix_hip.decode_attention(*a)
+        s.synchronize()
+        o.zero_()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            torch.ops.radix_hip.decode_attention(*a)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o, o_ref)
+
+    ecases = _cases(np.load(os.path.join(golden_dir, "extend.npz")))
+    ename, e = next(iter(ecases.items()))
+    oe_ref, _ = _run_extend(ops, e, with_lse=False)
+    qe, ke, ve, kbe, vbe = (_t(e[k]) for k in ("q", "k_ext", "v_ext", "kb", "vb"))
+    oe = torch.zeros_like(qe)
+    torch.ops.radix_hip.extend_attention(qe, ke, ve, oe, kbe, vbe, _t(e["qo_indptr"]), _t(e["kv_indptr"]),
+                                         _t(e["kv_indices"]), bool(e["causal"]),
+                                         int(np.diff(e["qo_indptr"]).max()), 1.0, 1.0,
+                                         float(e["sm_scale"]), float(e["logit_cap"]))
+    assert torch.equal(oe, oe_ref)
