@@ -446,8 +446,56 @@ __global__ __launch_bounds__(64) void decode_generic_kernel(const DecodeArgs a, 
 }
 
 // ---- stage 2: merge the kv splits (decode_attention.py:731-805) --------------------------------
+// One thread = four consecutive output columns of one (request, head).  The split weights come from
+// the LSEs alone (m = max_s lse_s, w_s = exp(lse_s - m)), so the partial rows are read by
+// independent 16-byte loads with nothing but an FMA between them: HBM-bound instead of a dependent
+// load -> exp -> rescale chain per split.  Same value as the reference's running rescale up to fp32
+// rounding.
 template <typename T>
-__global__ __launch_bounds__(128) void decode_merge_kernel(const DecodeArgs a, int dv) {
+__global__ __launch_bounds__(256) void decode_merge_kernel(const DecodeArgs a, int dv) {
+  const int dv4 = dv >> 2;
+  const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t bh = gid / dv4;
+  if (bh >= static_cast<int64_t>(a.bs) * a.hq) return;
+  const int d = static_cast<int>(gid % dv4) * 4;
+  const int h = static_cast<int>(bh % a.hq);
+  const int b = static_cast<int>(bh / a.hq);
+  int32_t seq_len;
+  if (a.kv_indices) {
+    seq_len = a.kv_indptr[b + 1] - a.kv_indptr[b];
+  } else {
+    seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
+  }
+  const int32_t splits = a.num_kv_splits ? a.num_kv_splits[b] : 1;
+  // live splits are a prefix: split s covers [per s, min(per (s+1), seq_len))
+  const int32_t per = ((seq_len + splits - 1) / splits + kMinBlockKV - 1) / kMinBlockKV * kMinBlockKV;
+  int32_t live = per > 0 ? (seq_len + per - 1) / per : 0;
+  live = min(live, min(splits, a.max_kv_splits));
+  const int64_t row0 = bh * a.max_kv_splits;
+  const float* lse = a.attn_lse + row0;
+  float e_max = -INFINITY;
+  for (int s = 0; s < live; ++s) e_max = fmaxf(e_max, lse[s]);
+  float e_sum = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* lp = a.attn_logits + row0 * dv + d;
+#pragma unroll 4
+  for (int s = 0; s < live; ++s) {
+    const float w = __expf(lse[s] - e_max);
+    const f32x4 tv = *reinterpret_cast<const f32x4*>(lp + static_cast<int64_t>(s) * dv);
+    acc += w * tv;
+    e_sum += w;
+  }
+  if (a.sinks) e_sum += __expf(a.sinks[h] - e_max);
+  const float inv = a.v_scale / e_sum;
+  u32x2 pk;
+  pk[0] = pack2<T>(acc[0] * inv, acc[1] * inv);
+  pk[1] = pack2<T>(acc[2] * inv, acc[3] * inv);
+  *reinterpret_cast<u32x2*>(a.o + b * a.o_stride_t + h * a.o_stride_h + d) = pk;
+}
+
+// any v_head_dim / output alignment: one thread per column, the reference's running rescale as written
+template <typename T>
+__global__ __launch_bounds__(128) void decode_merge_scalar_kernel(const DecodeArgs a, int dv) {
   const int h = blockIdx.x % a.hq;
   const int b = blockIdx.x / a.hq;
   int32_t seq_len;
@@ -479,6 +527,18 @@ __global__ __launch_bounds__(128) void decode_merge_kernel(const DecodeArgs a, i
   }
 }
 
+template <typename T>
+static void launch_merge(const DecodeArgs& a, int dv, hipStream_t s) {
+  const bool vec = dv % 4 == 0 && ((a.o_stride_t | a.o_stride_h) & 3) == 0 &&
+                   (reinterpret_cast<uintptr_t>(a.o) & 7) == 0;
+  if (vec) {
+    const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(a.bs) * a.hq * (dv >> 2) + 255) / 256);
+    hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(grid), dim3(256), 0, s, a, dv);
+  } else {
+    hipLaunchKernelGGL((decode_merge_scalar_kernel<T>), dim3(a.bs * a.hq), dim3(128), 0, s, a, dv);
+  }
+}
+
 template <typename T, typename IdxT, bool LINEAR>
 static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
   const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
@@ -495,7 +555,7 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
                        dk * sizeof(float), s, a, dk, dv);
   }
   if (a.max_kv_splits > 1)
-    hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(a.bs * a.hq), dim3(128), 0, s, a, dv);
+    launch_merge<T>(a, dv, s);
   return check_launch("rx_decode_attn");
 }
 
@@ -517,7 +577,7 @@ static int run_mla(const rx_decode_params* p, const DecodeArgs& a, hipStream_t s
   const int rc = launch_decode_mla(p, s);
   if (rc != RX_OK) return rc;
   if (a.max_kv_splits > 1)
-    hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(a.bs * a.hq), dim3(128), 0, s, a, p->v_head_dim);
+    launch_merge<T>(a, p->v_head_dim, s);
   return check_launch("rx_decode_attn(mla)");
 }
 

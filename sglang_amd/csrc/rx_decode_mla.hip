@@ -48,6 +48,12 @@ struct MlaArgs {
   const float* sinks;
 };
 
+#ifndef RX_MLA_STAMP
+#define RX_MLA_STAMP 0  // 1: diagnostic build, s_memtime phase stamps overwrite the split's first partial row
+#endif
+#ifndef RX_MLA_PD
+#define RX_MLA_PD 8  // K-fragment prefetch distance (LDS reads in flight ahead of the MFMA)
+#endif
 constexpr int kMlaDk = 576, kMlaDv = 512;
 constexpr int kMlaTile = 32;
 constexpr int kMlaRowBytes = kMlaDk * 2;          // 1152
@@ -173,20 +179,49 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
   }
   __syncthreads();
 
+#if RX_MLA_STAMP
+  uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
+#define MLA_STAMP(i)                                               \
+  do {                                                             \
+    const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();  \
+    st_acc[i] += now_ - st_prev;                                   \
+    st_prev = now_;                                                \
+  } while (0)
+#else
+#define MLA_STAMP(i)
+#endif
+  MLA_STAMP(5);
   const int qd = r >> 2, pp = r & 3;
   for (int t = 0; t < ntiles; ++t) {
     const char* kt = smem + (t & 1) * kMlaTile * kMlaLdsRow;
     // ---- S^T = K Q^T over all 576 columns --------------------------------------------------------
+    // K fragments run RX_MLA_PD reads ahead of their MFMA: a ds_read_b128 round trip is ~100+ cycles,
+    // a 16x16x32 MFMA 16; hipcc left alone reads two ahead and the in-order wave then waits on LDS
+    // before nearly every one of the 36 MFMAs (measured: ~10k cycles per tile, every pipe < 25 % busy).
     f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    {
+      constexpr int NF = 2 * KS, PD = RX_MLA_PD;
+      u32x4 kf[NF];
+      const char* kb0 = kt + r * kMlaLdsRow + g * 16;
+      auto kload = [&](int i) {  // i = 2 s + bb
+        return *reinterpret_cast<const u32x4*>(kb0 + (i & 1) * 16 * kMlaLdsRow + (i >> 1) * 64);
+      };
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
+      for (int i = 0; i < PD; ++i) kf[i] = kload(i);
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const vec8 ka = __builtin_bit_cast(
-            vec8, *reinterpret_cast<const u32x4*>(kt + (16 * bb + r) * kMlaLdsRow + (4 * s + g) * 16));
-        sacc[bb] = T::mfma(ka, qf[s], sacc[bb]);
+      for (int i = 0; i < NF; ++i) {
+        if (i + PD < NF) kf[i + PD] = kload(i + PD);
+        sacc[i & 1] = T::mfma(__builtin_bit_cast(vec8, kf[i]), qf[i >> 1], sacc[i & 1]);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
+#pragma unroll
+      for (int i = 0; i < NF; ++i) {
+        if (i + PD < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
     }
+    MLA_STAMP(0);
     // ---- online softmax (identical in all four waves) -----------------------------------------------
     float sv[8];
     const int tok_base = lo + t * kMlaTile + 4 * g;
@@ -223,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) oacc[nb] *= alpha;
     }
+    MLA_STAMP(1);
     // ---- O^T[128w + ...] += V^T P^T, V = columns [0,512) of the staged rows -------------------------
     {
       const char* rp0 = kt + (4 * g + qd) * kMlaLdsRow + (128 * w) * 2 + 8 * pp;
@@ -235,6 +271,7 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
         oacc[nb] = T::mfma(av, pf, oacc[nb]);
       }
     }
+    MLA_STAMP(2);
     // ---- stage the next tile into the other buffer -------------------------------------------------
     if (t + 1 < ntiles) {
       write_lds((t + 1) & 1);
@@ -243,7 +280,9 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
         if (t + 3 < ntiles) load_slots(t + 3);
       }
     }
+    MLA_STAMP(3);
     __syncthreads();
+    MLA_STAMP(4);
   }
 
   // ---- epilogue: every wave holds the full statistics and its own 128 output columns -------------
@@ -269,6 +308,12 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) *reinterpret_cast<f32x4*>(lp + 16 * nb) = oacc[nb] * inv;
     if (w == 0 && g == 0) a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
+#if RX_MLA_STAMP
+    if (w == 0 && lane == 0) {
+      uint32_t* dbg = reinterpret_cast<uint32_t*>(a.attn_logits + row * kMlaDv);
+      for (int i = 0; i < 6; ++i) dbg[i] = st_acc[i];
+    }
+#endif
   }
 }
 
