@@ -51,6 +51,8 @@ def parse():
                     help="hnd = [pages, Hkv, page, D] (MI355X-native default: a head's 16 tokens of a page are one "
                          "contiguous 4 KiB run); nhd = [slots, Hkv, D] (the reference's default)")
     ap.add_argument("--max-kv-splits", type=int, default=8)
+    ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="dev: KV pool dtype (BASELINE's config is bf16; fp8 = --kv-cache-dtype fp8_e4m3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extend", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -99,15 +101,22 @@ def make_decode_state(args, tp, dev):
     pages_per_req = (ctx + ps - 1) // ps
     size = bs * pages_per_req * ps
     free_b, total_b = torch.cuda.mem_get_info()
-    per_layer = 2 * (size + ps) * hkv * D * 2
+    kv_dt = torch.float8_e4m3fn if args.kv_dtype == "fp8" else torch.bfloat16
+    kv_esz = 1 if args.kv_dtype == "fp8" else 2
+    per_layer = 2 * (size + ps) * hkv * D * kv_esz
     distinct = L
     while distinct > 1 and distinct * per_layer > free_b - (12 << 30):
         distinct //= 2
-    pool = MHATokenToKVPool(size, ps, torch.bfloat16, hkv, D, distinct, dev, use_hnd=(args.kv_layout == "hnd"))
+    pool = MHATokenToKVPool(size, ps, kv_dt, hkv, D, distinct, dev, use_hnd=(args.kv_layout == "hnd"))
     g = torch.Generator(device=dev).manual_seed(42)
     for l in range(distinct):
-        pool.k_buffer[l].normal_(generator=g)
-        pool.v_buffer[l].normal_(generator=g)
+        if args.kv_dtype == "fp8":  # random bytes with the NaN encodings (0x7f / 0xff) masked off
+            for b in (pool.k_buffer[l], pool.v_buffer[l]):
+                b.random_(0, 256, generator=g)
+                b.bitwise_and_(0x77)
+        else:
+            pool.k_buffer[l].normal_(generator=g)
+            pool.v_buffer[l].normal_(generator=g)
     r2t_pool = ReqToTokenPool(bs, ctx + ps, dev)
     rng = np.random.default_rng(0)
     perm = rng.permutation(np.arange(1, bs * pages_per_req + 1))  # shuffled pages, page 0 reserved
@@ -379,7 +388,7 @@ def main():
 
     # roofline of the dominant kernel (decode attention), per launch
     bs, ctx, L = args.bs, args.ctx, args.layers
-    b_kv = bs * ctx * (st.hkv * st.D + st.hkv * st.D) * 2
+    b_kv = bs * ctx * (st.hkv * st.D + st.hkv * st.D) * (1 if args.kv_dtype == "fp8" else 2)
     b_qo = 2 * bs * st.hq * st.D * 2
     bytes_per_launch = b_kv + b_qo
     dur_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
@@ -411,7 +420,7 @@ def main():
                                % (bs, ctx, L, args.page_size, args.kv_layout.upper(), world, st.hq, st.hkv,
                                   " + RCCL all-reduce (side stream)" if world > 1 else ""),
                    "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{world}",
-                   "index_mode": args.index_mode, "kv_layout": args.kv_layout, "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
+                   "index_mode": args.index_mode, "kv_layout": args.kv_layout, "kv_dtype": args.kv_dtype, "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
                    "kv_bytes_resident_per_gpu": int(sum(st.pool.get_kv_size_bytes()))},
         "roofline": roofline,
     }

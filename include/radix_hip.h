@@ -33,7 +33,7 @@ typedef enum rx_status {
   RX_ERR_LAUNCH = -3        /* hipLaunchKernel / hipGetLastError reported failure */
 } rx_status;
 
-typedef enum rx_dtype { RX_BF16 = 0, RX_F16 = 1 } rx_dtype;
+typedef enum rx_dtype { RX_BF16 = 0, RX_F16 = 1 } rx_dtype; /* dtype of q / o / new k, v */
 
 /* Device-side error word bits (optional `err_flag`, int32, caller-zeroed): the kernels OR
  * these in instead of the reference's always-on device assert (kvcache.cuh:209). */
@@ -88,6 +88,11 @@ typedef struct rx_kv_layout {
   int32_t page_size;
   int64_t k_page_stride, k_tok_stride, k_head_stride;
   int64_t v_page_stride, v_tok_stride, v_head_stride;
+  /* 0: the pool holds q's 16-bit dtype.  1: OCP fp8 e4m3fn bytes (--kv-cache-dtype fp8_e4m3:
+   * MHATokenToKVPool store_dtype uint8, srt/mem_cache/memory_pool.py:2043-2094,2305-2381; MLA
+   * latent rows :4046-4138): strides are in elements = bytes, kernels upcast to q's dtype on load
+   * (exact) and fold k_scale / v_scale as the reference does (decode_attention.py:499,603). */
+  int32_t kv_fp8;
 } rx_kv_layout;
 
 
@@ -98,6 +103,28 @@ int rx_store_kv_layout(const void* k, const void* v, const rx_kv_layout* lay /* 
                        const void* loc, int64_t n, int num_kv_heads, int head_dim, int v_head_dim,
                        int64_t k_stride_t, int64_t v_stride_t, int loc_is_i64, int64_t size_limit,
                        int64_t skip_index, int32_t* err_flag, void* stream);
+
+/* Quantising K1/K12: 16-bit k [n, Hkv*Dk] / v [n, Hkv*Dv] rows -> fp8 e4m3fn bytes at the
+ * rx_kv_layout addresses (lay->kv_fp8 must be 1).  Per element: t = x / scale rounded to the source
+ * dtype (the reference's in-place cache_k.div_(k_scale), memory_pool.py:2334-2343; skipped when
+ * scale == 1), then round-to-nearest-even to e4m3fn (.to(float8_e4m3fn)); |t| > 448 saturates
+ * where torch produces NaN.  The MLA two-tensor write (set_mla_kv_buffer_triton[_fp8_quant],
+ * kernels/ops/kvcache/mla_buffer.py; memory_pool.py:4046-4110) is the Hkv = 1 case with
+ * k = nope[n,512] -> row bytes [0,512) and v = rope[n,64] -> v_buf = k_buf + 512. */
+int rx_store_kv_fp8(const void* k, const void* v, const rx_kv_layout* lay /* HOST */,
+                    const void* loc, int64_t n, int num_kv_heads, int head_dim, int v_head_dim,
+                    int64_t k_stride_t, int64_t v_stride_t, int src_dtype /* rx_dtype */,
+                    float k_scale, float v_scale, int loc_is_i64, int64_t size_limit,
+                    int64_t skip_index, int32_t* err_flag, void* stream);
+
+/* K12 read side: get_mla_kv_buffer_triton (kernels/ops/kvcache/mla_buffer.py; caller
+ * MLATokenToKVPool.get_mla_kv_buffer, memory_pool.py:4117-4138).  Gathers latent rows
+ *   nope_out[i, :] = rows[loc[i], 0:nope_cols],  rope_out[i, :] = rows[loc[i], nope_cols:nope_cols+rope_cols]
+ * into dense [n, cols] outputs of dst_dtype (rx_dtype).  The pool is that same 16-bit dtype
+ * (pure copy) or fp8 e4m3fn (kv_fp8 = 1: exact upcast).  Column counts are multiples of 8. */
+int rx_get_mla_kv(const void* kv_buf, int64_t row_stride /* elements */, int kv_fp8, const void* loc,
+                  int loc_is_i64, int64_t n, int nope_cols, int rope_cols, void* nope_out,
+                  void* rope_out, int dst_dtype, int64_t size_limit, int32_t* err_flag, void* stream);
 
 /* ---- K4/K5/K6: decode attention ---------------------------------------------------------
  * decode_attention_fwd (kernels/ops/attention/decode_attention.py:968-1044): stage 1

@@ -44,6 +44,49 @@ def f32_to_bf16(x: np.ndarray) -> np.ndarray:
     return out
 
 
+# ---- OCP fp8 e4m3fn (torch.float8_e4m3fn; gfx950's native fp8) ----------------------------------
+# The reference's fp8 KV pools are plain casts: ``cache_k.to(torch.float8_e4m3fn)``
+# (srt/mem_cache/memory_pool.py:2334-2343 for MHA, :4022-4066 for MLA latent rows), i.e. torch's
+# round-to-nearest-even with NaN above the largest finite value 448.  Pinned against torch's own
+# CPU cast in tests/test_oracle_golden.py.
+def fp8_e4m3fn_decode(u8: np.ndarray) -> np.ndarray:
+    u = np.asarray(u8, dtype=np.uint8).astype(np.int32)
+    sign = np.where(u & 0x80, -1.0, 1.0)
+    e = (u >> 3) & 0xF
+    m = u & 0x7
+    val = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1.0 + m / 8.0) * np.exp2(e.astype(np.float64) - 7))
+    val = np.where((e == 15) & (m == 7), np.nan, val)
+    return (sign * val).astype(np.float32)
+
+
+_FP8_POS = fp8_e4m3fn_decode(np.arange(0, 0x7F, dtype=np.uint8)).astype(np.float64)  # 0 .. 448, ascending
+
+
+def fp8_e4m3fn_encode(x: np.ndarray) -> np.ndarray:
+    """float -> e4m3fn byte, round to nearest, ties to the even mantissa; |x| beyond the rounding
+    range of 448 and NaN give 0x7F | sign (torch); the gfx950 instruction saturates to 448 instead."""
+    x = np.asarray(x, dtype=np.float64)
+    a = np.abs(x)
+    hi = np.searchsorted(_FP8_POS, a, side="left").clip(1, len(_FP8_POS) - 1)
+    lo = hi - 1
+    dlo, dhi = a - _FP8_POS[lo], _FP8_POS[hi] - a
+    pick_hi = (dhi < dlo) | ((dhi == dlo) & (hi % 2 == 0))
+    code = np.where(pick_hi, hi, lo).astype(np.uint8)
+    code = np.where(a > 464.0, 0x7F, code)  # 464 = midpoint of 448 and the (absent) 480: the tie goes to 448
+    code = np.where(np.isnan(x), 0x7F, code)
+    return (code | np.where(np.signbit(x), 0x80, 0).astype(np.uint8)).astype(np.uint8)
+
+
+def quantize_kv_fp8(x: np.ndarray, scale: float, src_is_bf16: bool) -> np.ndarray:
+    """set_kv_buffer's fp8 write (memory_pool.py:2334-2343): in-place ``x.div_(scale)`` on the 16-bit
+    tensor (fp32 quotient rounded back to the source dtype), then ``.to(float8_e4m3fn)``."""
+    x = np.asarray(x, dtype=np.float32)
+    if scale != 1.0:
+        t = x / np.float32(scale)
+        x = bf16_to_f32(f32_to_bf16(t)) if src_is_bf16 else t.astype(np.float16).astype(np.float32)
+    return fp8_e4m3fn_encode(x)
+
+
 def to_f64(x: np.ndarray) -> np.ndarray:
     """Accept bf16-bits (uint16), float16, float32 -> float64."""
     if x.dtype == np.uint16:

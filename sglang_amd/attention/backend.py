@@ -241,7 +241,7 @@ class HipRadixAttnBackend:
                 k_buf, v_buf, self.page_size, layer.tp_q_head_num,
                 k_buf.shape[1] if hnd else k_buf.shape[-2], layer.qk_head_dim, layer.v_head_dim,
                 layer.scaling, k_descale, v_descale, layer.logit_cap,
-                kv_layout=ops.kv_layout_hnd(k_buf, v_buf) if hnd else None)
+                kv_layout=ops.kv_layout_hnd(k_buf, v_buf) if hnd else None, q_dtype=q.dtype)
         if ln.version != self._md_version:
             if self.decode_index_mode == "indices":
                 ln.set_metadata(self._md_version, q3.shape[0], kv_indptr=md.kv_indptr,

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <type_traits>
 
 #include "../../include/radix_hip.h"
 
@@ -85,6 +86,25 @@ struct F16 {
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// eight OCP fp8 e4m3fn bytes -> eight 16-bit floats of T (exact: both bf16 and f16 hold every e4m3
+// value).  One v_cvt_scalef32_pk_{bf16,f16}_fp8 per pair, scale 1.0.
+template <typename T>
+__device__ __forceinline__ u32x4 fp8x8_to_16(u32x2 raw) {
+  u32x4 out;
+  if constexpr (__is_same(typename T::scalar, __bf16)) {
+    out[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw[0], 1.0f, false));
+    out[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw[0], 1.0f, true));
+    out[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw[1], 1.0f, false));
+    out[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw[1], 1.0f, true));
+  } else {
+    out[0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(raw[0], 1.0f, false));
+    out[1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(raw[0], 1.0f, true));
+    out[2] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(raw[1], 1.0f, false));
+    out[3] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(raw[1], 1.0f, true));
+  }
+  return out;
+}
 
 // two fp32 -> one dword of two 16-bit floats (RNE).  The vector convert lets hipcc emit ONE
 // v_cvt_pk_bf16_f32 per pair (two scalar casts cost cvt + cvt + shift + or).

@@ -48,6 +48,7 @@ struct DecodeArgs {
   float sm_scale;  // sm_scale * k_scale
   float v_scale, logit_cap;
   const float* sinks;
+  int32_t kv_fp8;  // pool holds fp8 e4m3fn bytes (strides in bytes)
 };
 
 constexpr int kMinBlockKV = 32;  // decode_attention.py:36 (_MIN_BLOCK_KV)
@@ -111,17 +112,26 @@ __device__ __forceinline__ void split_range(int32_t seq_len, int32_t splits, int
 #define RX_DEC_NT 0  // 1: non-temporal K/V loads
 #endif
 
-__device__ __forceinline__ u32x4 kv_load16(const uint16_t* p) {
+// one K/V fragment chunk = 8 elements per lane: 16 B of a 16-bit pool, 8 B of an fp8 pool
+template <typename V, typename E>
+__device__ __forceinline__ V kv_load8(const E* p) {
 #if RX_DEC_NT
-  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
 #else
-  return *reinterpret_cast<const u32x4*>(p);
+  return *reinterpret_cast<const V*>(p);
 #endif
 }
+template <typename T, bool KV8, typename V>
+__device__ __forceinline__ u32x4 kv_frag16(V raw) {
+  if constexpr (KV8) return fp8x8_to_16<T>(raw);
+  else return raw;
+}
 
-template <typename T, int D, typename IdxT, bool LINEAR>
+template <typename T, int D, typename IdxT, bool LINEAR, bool KV8>
 __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const DecodeArgs a) {
   using vec8 = typename T::vec8;
+  using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;  // pool element
+  using KvV = std::conditional_t<KV8, u32x2, u32x4>;       // 8 pool elements
   constexpr int KS = D / 32;  // k-steps of the QK^T product
   constexpr int NB = D / 16;  // 16-wide d blocks of the output
   constexpr int ROW_BYTES = D * 2;
@@ -182,8 +192,8 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
   // state (Q loads possibly pending) into the loop header and would otherwise emit vmcnt(0) in front
   // of the first MFMA of EVERY iteration, i.e. wait for the next tile's prefetch before computing.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
-  const uint16_t* kbase = a.k_buf + kvh * a.k_head_stride + 8 * g;
-  const uint16_t* vbase = a.v_buf + kvh * a.v_head_stride + 8 * g;
+  const KvE* kbase = reinterpret_cast<const KvE*>(a.k_buf) + kvh * a.k_head_stride + 8 * g;
+  const KvE* vbase = reinterpret_cast<const KvE*>(a.v_buf) + kvh * a.v_head_stride + 8 * g;
   char* vt = smem + w * TILE_BYTES;  // this wave's V tile
 
   f32x4 oacc[NB];
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
     s0 = static_cast<int64_t>(idx[t0]);
     s1 = static_cast<int64_t>(idx[t1]);
   };
-  u32x4 kf[2][KS], vf[2][KS];
+  KvV kf[2][KS], vf[2][KS];  // fp8 pools: half the registers, upcast (exact) where consumed
   auto load_kv = [&](int64_t s0, int64_t s1) {
     const int64_t ko0 = slot_offset<LINEAR>(s0, a.page_size, a.k_page_stride, a.k_tok_stride);
     const int64_t ko1 = slot_offset<LINEAR>(s1, a.page_size, a.k_page_stride, a.k_tok_stride);
@@ -208,13 +218,13 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
     const int64_t vo1 = slot_offset<LINEAR>(s1, a.page_size, a.v_page_stride, a.v_tok_stride);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      kf[0][s] = kv_load16(kbase + ko0 + 32 * s);
-      kf[1][s] = kv_load16(kbase + ko1 + 32 * s);
+      kf[0][s] = kv_load8<KvV>(kbase + ko0 + 32 * s);
+      kf[1][s] = kv_load8<KvV>(kbase + ko1 + 32 * s);
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      vf[0][s] = kv_load16(vbase + vo0 + 32 * s);
-      vf[1][s] = kv_load16(vbase + vo1 + 32 * s);
+      vf[0][s] = kv_load8<KvV>(vbase + vo0 + 32 * s);
+      vf[1][s] = kv_load8<KvV>(vbase + vo1 + 32 * s);
     }
   };
 
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
       sacc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KS; ++s)
-        sacc[bb] = T::mfma(__builtin_bit_cast(vec8, kf[bb][s]), qf[s], sacc[bb]);
+        sacc[bb] = T::mfma(__builtin_bit_cast(vec8, kv_frag16<T, KV8>(kf[bb][s])), qf[s], sacc[bb]);
     }
     // ---- V tile -> LDS (row = token, swizzled 16-B chunks) -------------------------------
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int chunk = (4 * s + g) ^ v_swizzle<D>(row);
-        *reinterpret_cast<u32x4*>(vt + row * ROW_BYTES + chunk * 16) = vf[bb][s];
+        *reinterpret_cast<u32x4*>(vt + row * ROW_BYTES + chunk * 16) = kv_frag16<T, KV8>(vf[bb][s]);
       }
     }
     // ---- prefetch the next tile (registers of this tile are free again) ------------------
@@ -544,11 +554,20 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
   const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
   if (mfma_ok) {
     const unsigned grid = static_cast<unsigned>(a.bs) * a.hkv * a.qblocks * a.max_kv_splits;
-    if (dk == 64)
-      hipLaunchKernelGGL((decode_mfma_kernel<T, 64, IdxT, LINEAR>), dim3(grid), dim3(256), 0, s, a);
-    else
-      hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR>), dim3(grid), dim3(256), 0, s, a);
+#define RX_DEC(DD, K8) \
+  hipLaunchKernelGGL((decode_mfma_kernel<T, DD, IdxT, LINEAR, K8>), dim3(grid), dim3(256), 0, s, a)
+    if (a.kv_fp8) {
+      if (dk == 64) RX_DEC(64, true);
+      else RX_DEC(128, true);
+    } else {
+      if (dk == 64) RX_DEC(64, false);
+      else RX_DEC(128, false);
+    }
+#undef RX_DEC
   } else {
+    if (a.kv_fp8)
+      return fail(RX_ERR_UNSUPPORTED, "rx_decode_attn: fp8 KV pools need head_dim 64/128 (or the MLA shape), got %d/%d",
+                  dk, dv);
     if (dv > 512) return fail(RX_ERR_UNSUPPORTED, "rx_decode_attn: v_head_dim %d > 512", dv);
     const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.max_kv_splits;
     hipLaunchKernelGGL((decode_generic_kernel<T, IdxT, LINEAR>), dim3(grid), dim3(64),
@@ -596,6 +615,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   RX_REQUIRE(p->head_dim > 0 && p->v_head_dim > 0, "rx_decode_attn: bad head dims");
   RX_REQUIRE(p->kv.page_size >= 1, "rx_decode_attn: page_size < 1");
   RX_REQUIRE(p->dtype == RX_BF16 || p->dtype == RX_F16, "rx_decode_attn: dtype %d", p->dtype);
+  RX_REQUIRE(p->kv.kv_fp8 == 0 || p->kv.kv_fp8 == 1, "rx_decode_attn: kv_fp8 = %d", p->kv.kv_fp8);
   const bool mode_a = p->kv_indices != nullptr;
   if (mode_a) {
     RX_REQUIRE(p->kv_indptr, "rx_decode_attn: kv_indices given without kv_indptr");
@@ -616,8 +636,9 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
                         p->kv.k_head_stride | p->kv.v_page_stride | p->kv.v_tok_stride |
                         p->kv.v_head_stride;
     RX_REQUIRE(all % 8 == 0, "rx_decode_attn: q/kv strides must be multiples of 8 elements");
-    RX_REQUIRE((((uintptr_t)p->q | (uintptr_t)p->kv.k_buf | (uintptr_t)p->kv.v_buf) & 15) == 0,
-               "rx_decode_attn: q/k_buf/v_buf must be 16-byte aligned");
+    RX_REQUIRE((((uintptr_t)p->q | (uintptr_t)p->kv.k_buf | (uintptr_t)p->kv.v_buf) & (p->kv.kv_fp8 ? 7 : 15)) == 0 &&
+                   ((uintptr_t)p->q & 15) == 0,
+               "rx_decode_attn: q must be 16-byte aligned, k_buf/v_buf 16-byte (fp8 pools: 8-byte)");
   }
   DecodeArgs a;
   a.q = (const uint16_t*)p->q;
@@ -657,6 +678,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.v_scale = p->v_scale;
   a.logit_cap = p->logit_cap;
   a.sinks = p->sinks;
+  a.kv_fp8 = p->kv.kv_fp8;
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
@@ -666,7 +688,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   const bool mla = dk == 576 && dv == 512 && p->num_kv_heads == 1 && p->kv.v_buf == p->kv.k_buf &&
                    p->kv.v_tok_stride == p->kv.k_tok_stride && p->kv.v_page_stride == p->kv.k_page_stride &&
                    ((p->q_stride_t | p->q_stride_h | p->kv.k_tok_stride | p->kv.k_page_stride) % 8 == 0) &&
-                   (((uintptr_t)p->q | (uintptr_t)p->kv.k_buf) & 15) == 0 &&
+                   ((uintptr_t)p->q & 15) == 0 && ((uintptr_t)p->kv.k_buf & (p->kv.kv_fp8 ? 7 : 15)) == 0 &&
                    ((p->o_stride_t | p->o_stride_h) % 4 == 0) && ((uintptr_t)p->o & 7) == 0;
   if (mla) return p->dtype == RX_BF16 ? run_mla<BF16>(p, a, s) : run_mla<F16>(p, a, s);
   return p->dtype == RX_BF16 ? dispatch_decode<BF16>(a, dk, dv, idx64, linear, s)

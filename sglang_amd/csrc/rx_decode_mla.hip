@@ -72,9 +72,13 @@ __device__ __forceinline__ int64_t mla_slot_off(int64_t slot, int32_t page_size,
   return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
 }
 
-template <typename T, typename IdxT, bool LINEAR>
+// KV8: the latent rows are fp8 e4m3fn (576 B); they are upcast (exact) while being staged, so the LDS
+// image and everything after it is the 16-bit kernel's.
+template <typename T, typename IdxT, bool LINEAR, bool KV8>
 __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
   using vec8 = typename T::vec8;
+  using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;
+  using KvV = std::conditional_t<KV8, u32x2, u32x4>;
   constexpr int KS = kMlaDk / 32;       // 18 k-steps
   constexpr int NBW = kMlaDv / 16 / 4;  // 8 d-blocks of 16 per wave
   __shared__ __attribute__((aligned(16))) char smem[2 * kMlaTile * kMlaLdsRow];
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
     st_row[i] = c / kMlaChunks;
     st_col[i] = c % kMlaChunks;
   }
-  u32x4 stg[kMlaStage];
+  KvV stg[kMlaStage];
   int32_t slot_n[kMlaStage];  // slots of the tile whose loads are issued next (fetched a tile early)
   auto load_slots = [&](int t) {
 #pragma unroll
@@ -152,15 +156,20 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
   auto issue_loads = [&]() {
 #pragma unroll
     for (int i = 0; i < kMlaStage; ++i)
-      stg[i] = *reinterpret_cast<const u32x4*>(
-          a.kv_buf + mla_slot_off<LINEAR>(slot_n[i], a.page_size, a.page_stride, a.tok_stride) +
-          8 * st_col[i]);
+      stg[i] = *reinterpret_cast<const KvV*>(
+          reinterpret_cast<const KvE*>(a.kv_buf) +
+          mla_slot_off<LINEAR>(slot_n[i], a.page_size, a.page_stride, a.tok_stride) + 8 * st_col[i]);
   };
   auto write_lds = [&](int buf) {
     char* kt = smem + buf * kMlaTile * kMlaLdsRow;
 #pragma unroll
     for (int i = 0; i < kMlaStage; ++i)
-      *reinterpret_cast<u32x4*>(kt + st_row[i] * kMlaLdsRow + st_col[i] * 16) = stg[i];
+    {
+      u32x4 v16;
+      if constexpr (KV8) v16 = fp8x8_to_16<T>(stg[i]);
+      else v16 = stg[i];
+      *reinterpret_cast<u32x4*>(kt + st_row[i] * kMlaLdsRow + st_col[i] * 16) = v16;
+    }
   };
 
   f32x4 oacc[NBW];
@@ -358,18 +367,25 @@ int launch_decode_mla(const rx_decode_params* p, hipStream_t s) {
   const bool linear = p->kv.page_size == 1 || p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride;
   const bool idx64 = p->kv_indices != nullptr && p->kv_indices_is_i64;
   const unsigned grid = static_cast<unsigned>(a.bs) * a.qblocks * a.max_kv_splits;
-#define RX_MLA_GO(TT)                                                                                \
-  do {                                                                                               \
-    if (idx64) {                                                                                     \
-      if (linear) hipLaunchKernelGGL((decode_mla_kernel<TT, int64_t, true>), dim3(grid), dim3(256), 0, s, a);  \
-      else hipLaunchKernelGGL((decode_mla_kernel<TT, int64_t, false>), dim3(grid), dim3(256), 0, s, a);        \
-    } else {                                                                                         \
-      if (linear) hipLaunchKernelGGL((decode_mla_kernel<TT, int32_t, true>), dim3(grid), dim3(256), 0, s, a);  \
-      else hipLaunchKernelGGL((decode_mla_kernel<TT, int32_t, false>), dim3(grid), dim3(256), 0, s, a);        \
-    }                                                                                                \
+  const bool kv8 = p->kv.kv_fp8 != 0;
+#define RX_MLA_L(TT, IT, LIN)                                                                          \
+  do {                                                                                                 \
+    if (kv8) hipLaunchKernelGGL((decode_mla_kernel<TT, IT, LIN, true>), dim3(grid), dim3(256), 0, s, a); \
+    else hipLaunchKernelGGL((decode_mla_kernel<TT, IT, LIN, false>), dim3(grid), dim3(256), 0, s, a);  \
+  } while (0)
+#define RX_MLA_GO(TT)                                \
+  do {                                               \
+    if (idx64) {                                     \
+      if (linear) RX_MLA_L(TT, int64_t, true);       \
+      else RX_MLA_L(TT, int64_t, false);             \
+    } else {                                         \
+      if (linear) RX_MLA_L(TT, int32_t, true);       \
+      else RX_MLA_L(TT, int32_t, false);             \
+    }                                                \
   } while (0)
   if (p->dtype == RX_BF16) RX_MLA_GO(BF16);
   else RX_MLA_GO(F16);
+#undef RX_MLA_L
 #undef RX_MLA_GO
   return RX_OK;
 }

@@ -534,12 +534,15 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
     RX_REQUIRE(all % 8 == 0, "rx_extend_attn: q/k/v strides must be multiples of 8 elements");
     RX_REQUIRE((p->o_stride_t | p->o_stride_h) % 4 == 0,
                "rx_extend_attn: o strides must be multiples of 4 elements");
-    RX_REQUIRE((((uintptr_t)p->q | (uintptr_t)p->k_extend | (uintptr_t)p->v_extend |
-                 (uintptr_t)p->kv.k_buf | (uintptr_t)p->kv.v_buf) & 15) == 0 &&
+    RX_REQUIRE((((uintptr_t)p->q | (uintptr_t)p->k_extend | (uintptr_t)p->v_extend) & 15) == 0 &&
+                   (((uintptr_t)p->kv.k_buf | (uintptr_t)p->kv.v_buf) & (p->kv.kv_fp8 ? 7 : 15)) == 0 &&
                    ((uintptr_t)p->o & 7) == 0,
-               "rx_extend_attn: q/k/v/k_buf/v_buf must be 16-byte and o 8-byte aligned");
+               "rx_extend_attn: q/k/v/k_buf/v_buf must be 16-byte (fp8 pools: 8-byte) and o 8-byte aligned");
   }
-  if (mfma_ok && dk == 128 && !getenv("RX_EXTEND_16X16")) {  // 32x32x16 fast path
+  RX_REQUIRE(p->kv.kv_fp8 == 0 || p->kv.kv_fp8 == 1, "rx_extend_attn: kv_fp8 = %d", p->kv.kv_fp8);
+  if (p->kv.kv_fp8 && !p->skip_prefix && !(mfma_ok && dk == 128))
+    return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: an fp8 prefix pool needs head_dim 128, got %d/%d", dk, dv);
+  if (mfma_ok && dk == 128 && (p->kv.kv_fp8 || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
     const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }

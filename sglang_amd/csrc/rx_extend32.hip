@@ -36,6 +36,7 @@ struct Ext32Args {
   const uint16_t* k_buf;
   const uint16_t* v_buf;
   int32_t page_size;
+  int32_t kv_fp8;  // prefix pool holds fp8 e4m3fn bytes (strides in bytes)
   int64_t k_page_stride, k_tok_stride, k_head_stride;
   int64_t v_page_stride, v_tok_stride, v_head_stride;
   const void* qo_indptr;
@@ -96,9 +97,12 @@ __device__ __forceinline__ float half_swap_max(float x) {
   return a;
 }
 
-template <typename T, typename IdxT, bool LINEAR, bool VSCALE, int NW, int QB>
+// KV8: the cached prefix is an fp8 e4m3fn pool; its rows are upcast (exact) on the way into LDS, the
+// new tokens' K/V are 16-bit as always.
+template <typename T, typename IdxT, bool LINEAR, bool VSCALE, int NW, int QB, bool KV8>
 __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel(const Ext32Args a) {
   using vec8 = typename T::vec8;
+  using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;  // prefix pool element
   constexpr int KS = kD / 16;                  // 8 k-steps of the QK^T product
   constexpr int DB = kD / 32;                  // 4 output d blocks of 32
   constexpr int THREADS = 64 * NW;
@@ -160,8 +164,8 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 
   // ---- cooperative staging ------------------------------------------------------------------------
   const int st_row = tid >> 4, st_chunk = tid & 15;
-  const uint16_t* kbuf_h = a.k_buf + kvh * a.k_head_stride + 8 * st_chunk;
-  const uint16_t* vbuf_h = a.v_buf + kvh * a.v_head_stride + 8 * st_chunk;
+  const KvE* kbuf_h = reinterpret_cast<const KvE*>(a.k_buf) + kvh * a.k_head_stride + 8 * st_chunk;
+  const KvE* vbuf_h = reinterpret_cast<const KvE*>(a.v_buf) + kvh * a.v_head_stride + 8 * st_chunk;
   const uint16_t* kext_h = a.k_ext + qo0 * a.k_stride_t + kvh * a.k_stride_h + 8 * st_chunk;
   const uint16_t* vext_h = a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h + 8 * st_chunk;
   int32_t slot[NPASS];
@@ -176,14 +180,22 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     }
   };
   u32x4 stg_k[NPASS], stg_v[NPASS];
+  // 8 pool elements of one staged chunk: 16 B, or 8 B of an fp8 pool kept raw in the register's low
+  // half until write_lds upcasts them (converting here would wait for the load at once)
+  auto pool_load = [&](const KvE* p) {
+    if constexpr (KV8) {
+      const u32x2 raw = *reinterpret_cast<const u32x2*>(p);
+      return u32x4{raw[0], raw[1], 0u, 0u};
+    } else {
+      return *reinterpret_cast<const u32x4*>(p);
+    }
+  };
   auto issue_loads = [&](int t) {
     if (t < nt1) {
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
-        stg_k[i] = *reinterpret_cast<const u32x4*>(
-            kbuf_h + slot_off32<LINEAR>(slot[i], a.page_size, a.k_page_stride, a.k_tok_stride));
-        stg_v[i] = *reinterpret_cast<const u32x4*>(
-            vbuf_h + slot_off32<LINEAR>(slot[i], a.page_size, a.v_page_stride, a.v_tok_stride));
+        stg_k[i] = pool_load(kbuf_h + slot_off32<LINEAR>(slot[i], a.page_size, a.k_page_stride, a.k_tok_stride));
+        stg_v[i] = pool_load(vbuf_h + slot_off32<LINEAR>(slot[i], a.page_size, a.v_page_stride, a.v_tok_stride));
       }
     } else {
 #pragma unroll
@@ -193,13 +205,21 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       }
     }
   };
-  auto write_lds = [&](int buf) {
+  auto write_lds = [&](int buf, bool from_pool) {  // from_pool: the staged tile is a prefix tile
     char* kt = smem + buf * kBufBytes + st_row * kKStride + st_chunk * 16;
     char* vt = smem + buf * kBufBytes + kKTile + st_row * kVStride + st_chunk * 16;
+    if (KV8 && from_pool) {
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-      *reinterpret_cast<u32x4*>(kt + i * RPP * kKStride) = stg_k[i];
-      *reinterpret_cast<u32x4*>(vt + i * RPP * kVStride) = stg_v[i];
+      for (int i = 0; i < NPASS; ++i) {
+        *reinterpret_cast<u32x4*>(kt + i * RPP * kKStride) = fp8x8_to_16<T>(u32x2{stg_k[i][0], stg_k[i][1]});
+        *reinterpret_cast<u32x4*>(vt + i * RPP * kVStride) = fp8x8_to_16<T>(u32x2{stg_v[i][0], stg_v[i][1]});
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        *reinterpret_cast<u32x4*>(kt + i * RPP * kKStride) = stg_k[i];
+        *reinterpret_cast<u32x4*>(vt + i * RPP * kVStride) = stg_v[i];
+      }
     }
   };
 
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     load_idx_tile(0);
     issue_loads(0);
     if (nt > 1) load_idx_tile(1);
-    write_lds(0);
+    write_lds(0, 0 < nt1);
     if (nt > 1) {
       issue_loads(1);
       if (nt > 2) load_idx_tile(2);
@@ -299,7 +319,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   auto tile_sync_and_stage = [&](int t) {
     __syncthreads();
     if (t + 1 < nt) {
-      write_lds((t + 1) & 1);
+      write_lds((t + 1) & 1, t + 1 < nt1);
       if (t + 2 < nt) {
         issue_loads(t + 2);
         if (t + 3 < nt) load_idx_tile(t + 3);
@@ -463,15 +483,27 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       {
         const int t2 = t + 2;
         const bool pre = t2 < nt1;
-        const uint16_t* kb = pre ? kbuf_h : kext_h;
-        const uint16_t* vb = pre ? vbuf_h : vext_h;
-        const int64_t kts = pre ? a.k_tok_stride : a.k_stride_t, vts = pre ? a.v_tok_stride : a.v_stride_t;
+        // one address form for pool rows and new rows: (slot >> sh) * page_stride + (slot & mask) * tok_stride
+        // in BYTES (an fp8 pool's elements are bytes, everything else is 16-bit)
+        const int esz = (KV8 && pre) ? 1 : 2;
+        const char* kb = pre ? reinterpret_cast<const char*>(kbuf_h) : reinterpret_cast<const char*>(kext_h);
+        const char* vb = pre ? reinterpret_cast<const char*>(vbuf_h) : reinterpret_cast<const char*>(vext_h);
+        const int64_t kts = (pre ? a.k_tok_stride : a.k_stride_t) * esz, vts = (pre ? a.v_tok_stride : a.v_stride_t) * esz;
+        const int64_t kps = a.k_page_stride * esz, vps = a.v_page_stride * esz;
         const int sh = (LINEAR || !pre) ? 31 : -a.page_size - 1;  // extend rows are never paged
         const uint32_t lo_mask = (1u << sh) - 1u;
         auto reissue = [&](int i) {
           const uint32_t sl = static_cast<uint32_t>(slot[i]);
-          stg_k[i] = *reinterpret_cast<const u32x4*>(kb + mul_u32(sl >> sh, a.k_page_stride) + mul_u32(sl & lo_mask, kts));
-          stg_v[i] = *reinterpret_cast<const u32x4*>(vb + mul_u32(sl >> sh, a.v_page_stride) + mul_u32(sl & lo_mask, vts));
+          const char* kp = kb + mul_u32(sl >> sh, kps) + mul_u32(sl & lo_mask, kts);
+          const char* vp = vb + mul_u32(sl >> sh, vps) + mul_u32(sl & lo_mask, vts);
+          if (KV8 && pre) {
+            const u32x2 kr = *reinterpret_cast<const u32x2*>(kp), vr = *reinterpret_cast<const u32x2*>(vp);
+            stg_k[i] = u32x4{kr[0], kr[1], 0u, 0u};
+            stg_v[i] = u32x4{vr[0], vr[1], 0u, 0u};
+          } else {
+            stg_k[i] = *reinterpret_cast<const u32x4*>(kp);
+            stg_v[i] = *reinterpret_cast<const u32x4*>(vp);
+          }
         };
 #pragma unroll
         for (int g = 0; g < 2 * DB; ++g) {
@@ -487,7 +519,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
               oacc[qb][g - DB] = mfma32<T>(__builtin_bit_cast(vec8, vfb[g - DB]), __builtin_bit_cast(vec8, pk1[qb][1]),
                                            oacc[qb][g - DB]);
           }
-          if (g == 2) write_lds((t + 1) & 1);
+          if (g == 2) write_lds((t + 1) & 1, t + 1 < nt1);
           if (g >= 3 && g - 3 < NPASS) reissue(g - 3);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -613,13 +645,13 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 }
 
 // launcher used by rx_extend.hip for head_dim == v_head_dim == 128
-template <int NW, int QB>
+template <int NW, int QB, bool KV8>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
   constexpr unsigned kLds = 2 * kBufBytes;  // 74 KiB: above the 64 KiB static limit, hence dynamic
 #define RX_E32(TT, IT, LIN, VS)                                                                        \
   do {                                                                                                 \
-    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB>;                                         \
+    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB, KV8>;                                    \
     static const hipError_t attr = hipFuncSetAttribute(                                                \
         reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);       \
     (void)attr;                                                                                        \
@@ -677,7 +709,9 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
   constexpr int QB = RX_EXT32_QB, NW = 8 / QB;  // 256 queries per workgroup either way
   a.mblocks = (p->max_extend_len + 255) / 256;
-  launch32_nw<NW, QB>(a, p->dtype == RX_BF16, p->kv_indices_is_i64 != 0, linear, p->v_scale != 1.0f, s);
+  a.kv_fp8 = p->kv.kv_fp8;
+  if (a.kv_fp8) launch32_nw<NW, QB, true>(a, p->dtype == RX_BF16, p->kv_indices_is_i64 != 0, linear, p->v_scale != 1.0f, s);
+  else launch32_nw<NW, QB, false>(a, p->dtype == RX_BF16, p->kv_indices_is_i64 != 0, linear, p->v_scale != 1.0f, s);
   return RX_OK;
 }
 

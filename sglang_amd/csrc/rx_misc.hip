@@ -79,6 +79,82 @@ __global__ __launch_bounds__(256) void store_kv_layout_kernel(
   }
 }
 
+// Quantising store: one wave per token, 8 source elements (16 B) -> 8 fp8 bytes per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void store_kv_fp8_kernel(
+    const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, uint8_t* __restrict__ kc,
+    uint8_t* __restrict__ vc, const void* __restrict__ loc, int64_t n, int hkv, int dk, int dv,
+    int64_t k_stride_t, int64_t v_stride_t, int page_size, int64_t kps, int64_t kts, int64_t khs,
+    int64_t vps, int64_t vts, int64_t vhs, float k_scale, float v_scale, int loc64,
+    int64_t size_limit, int64_t skip_index, int32_t* err_flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t idx = load_idx(loc, row, loc64);
+  if (idx == skip_index) return;
+  if (idx < 0 || idx >= size_limit) {
+    if (lane == 0 && err_flag) atomicOr(err_flag, RX_DEVERR_SLOT_OOB);
+    return;
+  }
+  const int64_t pg = idx / page_size, off = idx % page_size;
+  auto quant8 = [](u32x4 raw, float scale) {
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = T::to_f32(static_cast<uint16_t>(raw[i] & 0xffffu));
+      f[2 * i + 1] = T::to_f32(static_cast<uint16_t>(raw[i] >> 16));
+    }
+    if (scale != 1.0f) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = T::to_f32(T::from_f32(f[i] / scale));  // div_ rounds to the source dtype
+    }
+    u32x2 out;
+    out[0] = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0u, false);
+    out[0] = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], out[0], true);
+    out[1] = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0u, false);
+    out[1] = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], out[1], true);
+    return out;
+  };
+  for (int e = lane * 8; e < hkv * dk; e += 64 * 8) {
+    const int h = e / dk, d = e % dk;
+    *reinterpret_cast<u32x2*>(kc + pg * kps + off * kts + h * khs + d) =
+        quant8(*reinterpret_cast<const u32x4*>(k + row * k_stride_t + e), k_scale);
+  }
+  for (int e = lane * 8; e < hkv * dv; e += 64 * 8) {
+    const int h = e / dv, d = e % dv;
+    *reinterpret_cast<u32x2*>(vc + pg * vps + off * vts + h * vhs + d) =
+        quant8(*reinterpret_cast<const u32x4*>(v + row * v_stride_t + e), v_scale);
+  }
+}
+
+// K12 read side: one wave per gathered row, 8 elements per lane per step.
+template <typename T, bool KV8>
+__global__ __launch_bounds__(256) void get_mla_kv_kernel(const void* __restrict__ buf, int64_t row_stride,
+                                                         const void* __restrict__ loc, int loc64, int64_t n,
+                                                         int nope_cols, int rope_cols,
+                                                         uint16_t* __restrict__ nope_out,
+                                                         uint16_t* __restrict__ rope_out,
+                                                         int64_t size_limit, int32_t* err_flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t idx = load_idx(loc, row, loc64);
+  if (idx < 0 || idx >= size_limit) {
+    if (lane == 0 && err_flag) atomicOr(err_flag, RX_DEVERR_SLOT_OOB);
+    return;
+  }
+  for (int e = lane * 8; e < nope_cols + rope_cols; e += 64 * 8) {
+    u32x4 v16;
+    if constexpr (KV8) {
+      v16 = fp8x8_to_16<T>(*reinterpret_cast<const u32x2*>(static_cast<const uint8_t*>(buf) + idx * row_stride + e));
+    } else {
+      v16 = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(buf) + idx * row_stride + e);
+    }
+    if (e < nope_cols) *reinterpret_cast<u32x4*>(nope_out + row * nope_cols + e) = v16;
+    else *reinterpret_cast<u32x4*>(rope_out + row * rope_cols + (e - nope_cols)) = v16;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // K2  kv_indptr scan + ragged gather of req_to_token rows.
 // Reference: create_flashinfer_kv_indices_triton (kv_indices.py:8-46), grid (bs,), 512-wide.
@@ -362,6 +438,7 @@ int rx_store_kv_layout(const void* k, const void* v, const rx_kv_layout* lay, co
   RX_REQUIRE(n >= 0, "rx_store_kv_layout: n < 0");
   if (n == 0) return RX_OK;
   RX_REQUIRE(k && v && lay && lay->k_buf && lay->v_buf && loc, "rx_store_kv_layout: null pointer");
+  RX_REQUIRE(lay->kv_fp8 == 0, "rx_store_kv_layout: fp8 pool -- use rx_store_kv_fp8");
   RX_REQUIRE(num_kv_heads > 0 && head_dim > 0 && v_head_dim > 0 && head_dim % 8 == 0 &&
                  v_head_dim % 8 == 0,
              "rx_store_kv_layout: head dims must be positive multiples of 8 (16-bit elements)");
@@ -376,6 +453,66 @@ int rx_store_kv_layout(const void* k, const void* v, const rx_kv_layout* lay, co
                      lay->k_tok_stride, lay->k_head_stride, lay->v_page_stride, lay->v_tok_stride,
                      lay->v_head_stride, loc_is_i64, size_limit, skip_index, err_flag);
   return check_launch("rx_store_kv_layout");
+}
+
+int rx_store_kv_fp8(const void* k, const void* v, const rx_kv_layout* lay, const void* loc, int64_t n,
+                    int num_kv_heads, int head_dim, int v_head_dim, int64_t k_stride_t,
+                    int64_t v_stride_t, int src_dtype, float k_scale, float v_scale, int loc_is_i64,
+                    int64_t size_limit, int64_t skip_index, int32_t* err_flag, void* stream) {
+  RX_REQUIRE(n >= 0, "rx_store_kv_fp8: n < 0");
+  if (n == 0) return RX_OK;
+  RX_REQUIRE(k && v && lay && lay->k_buf && lay->v_buf && loc, "rx_store_kv_fp8: null pointer");
+  RX_REQUIRE(lay->kv_fp8 == 1, "rx_store_kv_fp8: the layout is not an fp8 pool (kv_fp8 = %d)", lay->kv_fp8);
+  RX_REQUIRE(src_dtype == RX_BF16 || src_dtype == RX_F16, "rx_store_kv_fp8: src_dtype %d", src_dtype);
+  RX_REQUIRE(num_kv_heads > 0 && head_dim > 0 && v_head_dim > 0 && head_dim % 8 == 0 &&
+                 v_head_dim % 8 == 0,
+             "rx_store_kv_fp8: head dims must be positive multiples of 8");
+  RX_REQUIRE(k_scale > 0.f && v_scale > 0.f, "rx_store_kv_fp8: scales must be > 0");
+  const int64_t all = k_stride_t | v_stride_t | lay->k_page_stride | lay->k_tok_stride |
+                      lay->k_head_stride | lay->v_page_stride | lay->v_tok_stride | lay->v_head_stride;
+  RX_REQUIRE(all % 8 == 0 && lay->page_size >= 1 && size_limit > 0 &&
+                 (((uintptr_t)lay->k_buf | (uintptr_t)lay->v_buf) % 8 == 0) &&
+                 (((uintptr_t)k | (uintptr_t)v) % 16 == 0),
+             "rx_store_kv_fp8: strides must be multiples of 8 elements, sources 16-byte and pool 8-byte aligned");
+#define RX_SQ(TT)                                                                                      \
+  hipLaunchKernelGGL(store_kv_fp8_kernel<TT>, dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0, \
+                     static_cast<hipStream_t>(stream), (const uint16_t*)k, (const uint16_t*)v,         \
+                     (uint8_t*)lay->k_buf, (uint8_t*)lay->v_buf, loc, n, num_kv_heads, head_dim,       \
+                     v_head_dim, k_stride_t, v_stride_t, lay->page_size, lay->k_page_stride,           \
+                     lay->k_tok_stride, lay->k_head_stride, lay->v_page_stride, lay->v_tok_stride,     \
+                     lay->v_head_stride, k_scale, v_scale, loc_is_i64, size_limit, skip_index, err_flag)
+  if (src_dtype == RX_BF16) RX_SQ(BF16);
+  else RX_SQ(F16);
+#undef RX_SQ
+  return check_launch("rx_store_kv_fp8");
+}
+
+int rx_get_mla_kv(const void* kv_buf, int64_t row_stride, int kv_fp8, const void* loc, int loc_is_i64,
+                  int64_t n, int nope_cols, int rope_cols, void* nope_out, void* rope_out, int dst_dtype,
+                  int64_t size_limit, int32_t* err_flag, void* stream) {
+  RX_REQUIRE(n >= 0, "rx_get_mla_kv: n < 0");
+  if (n == 0) return RX_OK;
+  RX_REQUIRE(kv_buf && loc && nope_out && rope_out, "rx_get_mla_kv: null pointer");
+  RX_REQUIRE(dst_dtype == RX_BF16 || dst_dtype == RX_F16, "rx_get_mla_kv: dst_dtype %d", dst_dtype);
+  RX_REQUIRE(nope_cols > 0 && rope_cols > 0 && nope_cols % 8 == 0 && rope_cols % 8 == 0 && row_stride % 8 == 0 &&
+                 size_limit > 0,
+             "rx_get_mla_kv: column counts and the row stride must be positive multiples of 8");
+  RX_REQUIRE(((uintptr_t)kv_buf % (kv_fp8 ? 8 : 16)) == 0 && (((uintptr_t)nope_out | (uintptr_t)rope_out) % 16) == 0,
+             "rx_get_mla_kv: misaligned buffer");
+  const dim3 grid(static_cast<unsigned>((n + 3) / 4)), block(256);
+  auto s = static_cast<hipStream_t>(stream);
+#define RX_GM(TT, K8)                                                                                   \
+  hipLaunchKernelGGL((get_mla_kv_kernel<TT, K8>), grid, block, 0, s, kv_buf, row_stride, loc, loc_is_i64, n, \
+                     nope_cols, rope_cols, (uint16_t*)nope_out, (uint16_t*)rope_out, size_limit, err_flag)
+  if (dst_dtype == RX_BF16) {
+    if (kv_fp8) RX_GM(BF16, true);
+    else RX_GM(BF16, false);
+  } else {
+    if (kv_fp8) RX_GM(F16, true);
+    else RX_GM(F16, false);
+  }
+#undef RX_GM
+  return check_launch("rx_get_mla_kv");
 }
 
 int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,

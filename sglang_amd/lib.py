@@ -25,6 +25,7 @@ class RxKvLayout(C.Structure):
         ("k_buf", c_void_p), ("v_buf", c_void_p), ("page_size", c_int32),
         ("k_page_stride", c_int64), ("k_tok_stride", c_int64), ("k_head_stride", c_int64),
         ("v_page_stride", c_int64), ("v_tok_stride", c_int64), ("v_head_stride", c_int64),
+        ("kv_fp8", c_int32),
     ]
 
 
@@ -71,6 +72,11 @@ PROTOTYPES = {
     "rx_store_kv": (c_int, [c_void_p] * 5 + [c_int64] * 7 + [c_int, c_int64, c_int64, c_void_p, c_void_p]),
     "rx_store_kv_layout": (c_int, [c_void_p, c_void_p, C.POINTER(RxKvLayout), c_void_p, c_int64, c_int, c_int,
                                    c_int, c_int64, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "rx_get_mla_kv": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p,
+                              c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "rx_store_kv_fp8": (c_int, [c_void_p, c_void_p, C.POINTER(RxKvLayout), c_void_p, c_int64, c_int, c_int, c_int,
+                                c_int64, c_int64, c_int, C.c_float, C.c_float, c_int, c_int64, c_int64,
+                                c_void_p, c_void_p]),
     "rx_build_kv_indices": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                     c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rx_num_kv_splits": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -79,7 +79,11 @@ class MHATokenToKVPool:
         self.size = size
         self.page_size = page_size
         self.dtype = dtype
-        self.store_dtype = dtype
+        # fp8 pools are stored as uint8 and viewed as fp8 by the getters (memory_pool.py:1753-1760)
+        self.is_fp8 = dtype in ops.FP8_DTYPES
+        if not self.is_fp8 and dtype not in (torch.bfloat16, torch.float16):
+            raise NotImplementedError(f"MHATokenToKVPool: dtype {dtype} (bf16 / fp16 / float8_e4m3fn)")
+        self.store_dtype = torch.uint8 if self.is_fp8 else dtype
         self.head_num = head_num
         self.head_dim = head_dim
         self.v_head_dim = head_dim if v_head_dim is None else v_head_dim
@@ -123,10 +127,12 @@ class MHATokenToKVPool:
         return k, v
 
     def get_key_buffer(self, layer_id: int):
-        return self.k_buffer[layer_id - self.start_layer]
+        b = self.k_buffer[layer_id - self.start_layer]
+        return b.view(self.dtype) if self.is_fp8 else b
 
     def get_value_buffer(self, layer_id: int):
-        return self.v_buffer[layer_id - self.start_layer]
+        b = self.v_buffer[layer_id - self.start_layer]
+        return b.view(self.dtype) if self.is_fp8 else b
 
     def get_kv_buffer(self, layer_id: int):
         return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
@@ -145,14 +151,31 @@ class MHATokenToKVPool:
         """memory_pool.py:2305-2381 -> _store_kv_layer (:2383-2430) -> rx_store_kv."""
         loc, _, _ = unwrap_write_loc(loc_info)
         layer_id = layer_id_override if layer_id_override is not None else layer.layer_id
+        li = layer_id - self.start_layer
+        if self.is_fp8:
+            # quant-on-write in ONE kernel (the reference: in-place div_ + .to(fp8) + store,
+            # memory_pool.py:2334-2343): t = x / scale rounded to x's dtype, then RNE to e4m3fn
+            n = loc.shape[0]
+            if not (cache_k.is_cuda and cache_v.is_cuda and loc.is_cuda):
+                raise RuntimeError("set_kv_buffer: k, v and loc must be GPU tensors (there is no CPU fallback)")
+            lay = self._fp8_layouts[li] if hasattr(self, "_fp8_layouts") else None
+            if lay is None:
+                if not hasattr(self, "_fp8_layouts"):
+                    self._fp8_layouts = [None] * self.layer_num
+                kb, vb = self.k_buffer[li], self.v_buffer[li]
+                lay = ops.kv_layout_hnd(kb, vb) if self.use_hnd else ops._kv_layout(kb, vb, self.page_size)
+                self._fp8_layouts[li] = lay
+            ops.store_cache_fp8(cache_k.reshape(n, self.row_dim), cache_v.reshape(n, self.v_row_dim), lay,
+                                loc, self.head_num, self.head_dim, self.v_head_dim,
+                                size_limit=(self.num_pages * self.page_size if self.use_hnd
+                                            else self.size + self.page_size),
+                                k_scale=1.0 if k_scale is None else float(k_scale),
+                                v_scale=1.0 if v_scale is None else float(v_scale),
+                                err_flag=self.err_flag)
+            return
         if cache_k.dtype != self.dtype:
-            if k_scale is not None:
-                cache_k.div_(k_scale)
-            if v_scale is not None:
-                cache_v.div_(v_scale)
             cache_k = cache_k.to(self.dtype)
             cache_v = cache_v.to(self.dtype)
-        li = layer_id - self.start_layer
         n = loc.shape[0]
         k2 = cache_k.reshape(n, self.row_dim) if cache_k.dim() == 3 else cache_k
         v2 = cache_v.reshape(n, self.v_row_dim) if cache_v.dim() == 3 else cache_v
@@ -205,22 +228,25 @@ class MLATokenToKVPool:
     """Latent-KV pool for MLA models (memory_pool.py:3906-4179): ONE buffer per layer,
     [size + page_size, 1, kv_lora_rank + qk_rope_head_dim]; the value view is the first
     kv_lora_rank columns of the same rows (:4006-4014), so decode reads each row once for both
-    products.  bf16/fp16 rows only in this round (fp8 rows + the MFMA MLA decode kernel are the next
-    step; the generic HIP decode kernel serves Dk=576 / Dv=512 meanwhile)."""
+    products.  Rows are bf16 / fp16, or fp8 e4m3fn bytes (576-B rows: 16-bit -> fp8 cast fused into the
+    write, exact upcast inside the MLA decode kernel's staging)."""
 
     def __init__(self, size: int, page_size: int, dtype: torch.dtype, kv_lora_rank: int,
                  qk_rope_head_dim: int, layer_num: int, device: str, start_layer: int = 0):
-        if dtype not in (torch.bfloat16, torch.float16):
-            raise NotImplementedError(f"MLATokenToKVPool: dtype {dtype} (fp8 latent rows are not built yet)")
-        self.size, self.page_size, self.dtype, self.store_dtype = size, page_size, dtype, dtype
+        self.is_fp8 = dtype in ops.FP8_DTYPES
+        if not self.is_fp8 and dtype not in (torch.bfloat16, torch.float16):
+            raise NotImplementedError(f"MLATokenToKVPool: dtype {dtype} (bf16 / fp16 / float8_e4m3fn)")
+        self.size, self.page_size, self.dtype = size, page_size, dtype
+        self.store_dtype = torch.uint8 if self.is_fp8 else dtype
         self.kv_lora_rank, self.qk_rope_head_dim = kv_lora_rank, qk_rope_head_dim
         self.kv_cache_dim = kv_lora_rank + qk_rope_head_dim
         self.layer_num, self.device, self.start_layer = layer_num, device, start_layer
         self.use_hnd = False
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=device)
         # slot 0 absorbs the writes of padded tokens (:3967)
-        self.kv_buffer = [torch.zeros((size + page_size, 1, self.kv_cache_dim), dtype=dtype, device=device)
-                          for _ in range(layer_num)]
+        self.kv_buffer = [torch.zeros((size + page_size, 1, self.kv_cache_dim), dtype=self.store_dtype,
+                                      device=device) for _ in range(layer_num)]
+        self._fp8_layouts = [None] * layer_num
         self.data_ptrs = torch.tensor([b.data_ptr() for b in self.kv_buffer], dtype=torch.int64, device=device)
         self.data_strides = torch.tensor([b.stride(0) * b.element_size() for b in self.kv_buffer],
                                          dtype=torch.int64, device=device)
@@ -229,10 +255,11 @@ class MLATokenToKVPool:
         return sum(b.numel() * b.element_size() for b in self.kv_buffer)
 
     def get_key_buffer(self, layer_id: int):
-        return self.kv_buffer[layer_id - self.start_layer]
+        b = self.kv_buffer[layer_id - self.start_layer]
+        return b.view(self.dtype) if self.is_fp8 else b
 
     def get_value_buffer(self, layer_id: int):
-        return self.kv_buffer[layer_id - self.start_layer][..., : self.kv_lora_rank]
+        return self.get_key_buffer(layer_id)[..., : self.kv_lora_rank]
 
     def get_kv_buffer(self, layer_id: int):
         return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
@@ -242,9 +269,19 @@ class MLATokenToKVPool:
 
     def _write_two(self, layer_id, loc, a, b):
         """dst[loc, :a_cols] = a ; dst[loc, a_cols:] = b  in one rx_store_kv launch."""
-        buf = self.kv_buffer[layer_id - self.start_layer].view(-1, self.kv_cache_dim)
+        li = layer_id - self.start_layer
+        buf = self.kv_buffer[li].view(-1, self.kv_cache_dim)
         n = loc.shape[0]
         a2, b2 = a.reshape(n, -1), b.reshape(n, -1)
+        if self.is_fp8:  # fused 16-bit -> fp8 cast + paged write (set_mla_kv_buffer_triton_fp8_quant, :4046-4056)
+            lay = self._fp8_layouts[li]
+            if lay is None:
+                rows = self.kv_buffer[li]  # [slots, 1, 576] uint8
+                lay = self._fp8_layouts[li] = ops._kv_layout(rows[..., : a2.shape[1]], rows[..., a2.shape[1]:], 1)
+            ops.store_cache_fp8(a2, b2, lay, loc, 1, a2.shape[1], b2.shape[1],
+                                size_limit=self.size + self.page_size, reserved_skip_index=-1,
+                                err_flag=self.err_flag)
+            return
         ops.store_cache(a2, b2, buf[:, : a2.shape[1]], buf[:, a2.shape[1]:], loc,
                         size_limit=self.size + self.page_size, reserved_skip_index=-1,
                         err_flag=self.err_flag)
@@ -252,7 +289,7 @@ class MLATokenToKVPool:
     def set_kv_buffer(self, layer, loc_info, cache_k: torch.Tensor, cache_v: torch.Tensor = None, *_, **__):
         """memory_pool.py:4022-4044: the whole latent row comes in as cache_k; cache_v is unused."""
         loc, _, _ = unwrap_write_loc(loc_info)
-        if cache_k.dtype != self.dtype:
+        if not self.is_fp8 and cache_k.dtype != self.dtype:
             cache_k = cache_k.to(self.dtype)
         k2 = cache_k.reshape(loc.shape[0], self.kv_cache_dim)
         self._write_two(layer.layer_id, loc, k2[:, : self.kv_lora_rank], k2[:, self.kv_lora_rank:])
@@ -260,16 +297,16 @@ class MLATokenToKVPool:
     def set_mla_kv_buffer(self, layer, loc: torch.Tensor, cache_k_nope: torch.Tensor,
                           cache_k_rope: torch.Tensor):
         """memory_pool.py:4095-4115 (two-tensor write of [nope | rope])."""
-        if cache_k_nope.dtype != self.dtype:
+        if not self.is_fp8 and cache_k_nope.dtype != self.dtype:
             cache_k_nope, cache_k_rope = cache_k_nope.to(self.dtype), cache_k_rope.to(self.dtype)
         self._write_two(layer.layer_id, loc, cache_k_nope, cache_k_rope)
 
     def get_mla_kv_buffer(self, layer, loc: torch.Tensor, dst_dtype: Optional[torch.dtype] = None):
         """memory_pool.py:4117-4138."""
-        rows = self.get_key_buffer(layer.layer_id)[loc.long()]
-        dst_dtype = dst_dtype or self.dtype
-        return (rows[..., : self.kv_lora_rank].to(dst_dtype).contiguous(),
-                rows[..., self.kv_lora_rank:].to(dst_dtype).contiguous())
+        dst_dtype = dst_dtype or (torch.bfloat16 if self.is_fp8 else self.dtype)
+        return ops.get_mla_kv(self.kv_buffer[layer.layer_id - self.start_layer], loc, self.kv_lora_rank,
+                              self.qk_rope_head_dim, dst_dtype, size_limit=self.size + self.page_size,
+                              err_flag=self.err_flag)
 
     def move_kv_cache(self, tgt_loc: torch.Tensor, src_loc: torch.Tensor):
         if tgt_loc.numel():

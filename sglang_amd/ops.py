@@ -38,6 +38,15 @@ def _rx_dtype(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported dtype {t.dtype}: the HIP path computes in bf16/fp16")
 
 
+FP8_DTYPES = (torch.float8_e4m3fn,)  # gfx950 pools are OCP e4m3fn (MI300's fnuz encoding is not supported)
+
+
+def _is_fp8_pool(buf: torch.Tensor) -> bool:
+    """fp8 pools arrive as float8_e4m3fn views of the uint8 store (KVCache.get_key_buffer,
+    srt/mem_cache/memory_pool.py:2273-2290); a raw uint8 store buffer is accepted too."""
+    return buf.dtype in FP8_DTYPES or buf.dtype == torch.uint8
+
+
 def _require_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -93,6 +102,50 @@ def store_cache_layout(k, v, layout: "_L.RxKvLayout", indices, num_kv_heads, hea
                                       _is64(idx, "indices"), size_limit, reserved_skip_index,
                                       _ptr(err_flag), _stream(k2))
     _L.check(st, "rx_store_kv_layout")
+
+
+def store_cache_fp8(k, v, layout: "_L.RxKvLayout", indices, num_kv_heads, head_dim, v_head_dim, *,
+                    size_limit: int, k_scale: float = 1.0, v_scale: float = 1.0,
+                    reserved_skip_index: int = 0, err_flag=None) -> None:
+    """Quantising KV store into an fp8 e4m3fn pool (set_kv_buffer with an fp8 store dtype,
+    srt/mem_cache/memory_pool.py:2305-2381: ``cache_k.div_(k_scale)`` then ``.to(fp8)``; the MLA
+    two-tensor fp8 write, :4046-4066).  k [n, Hkv*Dk], v [n, Hkv*Dv] are 16-bit."""
+    _require_cuda(k, v, indices)
+    k2 = k.reshape(k.shape[0], -1)
+    v2 = v.reshape(v.shape[0], -1)
+    if k2.stride(-1) != 1 or v2.stride(-1) != 1:
+        raise ValueError("store_cache_fp8: innermost dimension must be contiguous")
+    if k2.dtype != v2.dtype:
+        raise TypeError("store_cache_fp8: k and v dtypes differ")
+    idx = indices if indices.is_contiguous() else indices.contiguous()
+    st = _L.load().rx_store_kv_fp8(_ptr(k2), _ptr(v2), C.byref(layout), _ptr(idx), k2.shape[0],
+                                   num_kv_heads, head_dim, v_head_dim, k2.stride(0), v2.stride(0),
+                                   _rx_dtype(k2), float(k_scale), float(v_scale), _is64(idx, "indices"),
+                                   size_limit, reserved_skip_index, _ptr(err_flag), _stream(k2))
+    _L.check(st, "rx_store_kv_fp8")
+
+
+def get_mla_kv(kv_buffer: torch.Tensor, loc: torch.Tensor, nope_cols: int, rope_cols: int,
+               dst_dtype: torch.dtype, *, size_limit: int, err_flag=None):
+    """get_mla_kv_buffer_triton (kernels/ops/kvcache/mla_buffer.py): gather latent rows into dense
+    (nope [n,1,nope_cols], rope [n,1,rope_cols]) of dst_dtype; fp8 rows are upcast exactly."""
+    _require_cuda(kv_buffer, loc)
+    if dst_dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError(f"get_mla_kv: dst_dtype {dst_dtype}")
+    fp8 = _is_fp8_pool(kv_buffer)
+    if not fp8 and kv_buffer.dtype != dst_dtype:
+        raise TypeError("get_mla_kv: a 16-bit pool is copied, not converted: dst_dtype must equal the pool dtype")
+    rows = kv_buffer.view(kv_buffer.shape[0], -1)
+    n = loc.shape[0]
+    nope = torch.empty((n, 1, nope_cols), dtype=dst_dtype, device=kv_buffer.device)
+    rope = torch.empty((n, 1, rope_cols), dtype=dst_dtype, device=kv_buffer.device)
+    idx = loc if loc.is_contiguous() else loc.contiguous()
+    st = _L.load().rx_get_mla_kv(_ptr(rows), rows.stride(0), int(fp8), _ptr(idx), _is64(idx, "loc"), n,
+                                 nope_cols, rope_cols, _ptr(nope), _ptr(rope),
+                                 _L.RX_BF16 if dst_dtype == torch.bfloat16 else _L.RX_F16,
+                                 size_limit, _ptr(err_flag), _stream(kv_buffer))
+    _L.check(st, "rx_get_mla_kv")
+    return nope, rope
 
 
 # --------------------------------------------------------------------------------------
@@ -159,6 +212,7 @@ def _kv_layout(k_buffer: torch.Tensor, v_buffer: torch.Tensor, page_size: int) -
     lay.v_page_stride, lay.v_tok_stride, lay.v_head_stride = strides(v_buffer)
     if k_buffer.stride(-1) != 1 or v_buffer.stride(-1) != 1:
         raise ValueError("KV buffers must be contiguous in head_dim")
+    lay.kv_fp8 = int(_is_fp8_pool(k_buffer))
     return lay
 
 
@@ -172,6 +226,7 @@ def kv_layout_hnd(k_buffer: torch.Tensor, v_buffer: torch.Tensor) -> _L.RxKvLayo
                                                               k_buffer.stride(2))
     lay.v_page_stride, lay.v_head_stride, lay.v_tok_stride = (v_buffer.stride(0), v_buffer.stride(1),
                                                               v_buffer.stride(2))
+    lay.kv_fp8 = int(_is_fp8_pool(k_buffer))
     return lay
 
 
@@ -258,8 +313,10 @@ def _fill_decode_common(p, q, k_buffer, v_buffer, o, attn_logits, attn_lse, num_
         p._keep = sinks
         p.sinks = sinks.data_ptr()
     p.dtype = _rx_dtype(q)
-    if k_buffer.dtype != q.dtype or v_buffer.dtype != q.dtype or o.dtype != q.dtype:
-        raise TypeError("q, k_buffer, v_buffer and o must share one 16-bit dtype")
+    fp8 = _is_fp8_pool(k_buffer)
+    if o.dtype != q.dtype or _is_fp8_pool(v_buffer) != fp8 or (not fp8 and (
+            k_buffer.dtype != q.dtype or v_buffer.dtype != q.dtype)):
+        raise TypeError("q and o must share one 16-bit dtype; k_buffer / v_buffer that dtype or fp8 e4m3fn")
 
 
 class DecodeLauncher:
@@ -269,7 +326,7 @@ class DecodeLauncher:
     microseconds (the generic ``decode_attention_fwd*`` wrappers re-derive everything per call)."""
 
     def __init__(self, k_buffer, v_buffer, page_size, num_q_heads, num_kv_heads, head_dim, v_head_dim,
-                 sm_scale, k_scale=1.0, v_scale=1.0, logit_cap=0.0, kv_layout=None):
+                 sm_scale, k_scale=1.0, v_scale=1.0, logit_cap=0.0, kv_layout=None, q_dtype=None):
         _require_cuda(k_buffer, v_buffer)
         self._lib = _L.load()
         p = self.p = _L.RxDecodeParams()
@@ -277,7 +334,12 @@ class DecodeLauncher:
         p.num_q_heads, p.num_kv_heads = num_q_heads, num_kv_heads
         p.head_dim, p.v_head_dim = head_dim, v_head_dim
         p.sm_scale, p.k_scale, p.v_scale, p.logit_cap = sm_scale, k_scale, v_scale, logit_cap
-        p.dtype = _rx_dtype(k_buffer)
+        if _is_fp8_pool(k_buffer):  # q / o dtype cannot be read off an fp8 pool
+            if q_dtype not in (torch.bfloat16, torch.float16):
+                raise TypeError("DecodeLauncher: an fp8 pool needs q_dtype = bfloat16 / float16")
+            p.dtype = _L.RX_BF16 if q_dtype == torch.bfloat16 else _L.RX_F16
+        else:
+            p.dtype = _rx_dtype(k_buffer)
         p.max_kv_splits = 1
         self._ref = C.byref(p)
         self._keep = ()

@@ -223,3 +223,29 @@ def test_cpu_native_golden_bf16(golden_dir):
         want = orc.bf16_to_f32(c["o"]).astype(np.float64)
         np.testing.assert_allclose(o, want, atol=1e-2, rtol=1e-2, err_msg=name)
         np.testing.assert_allclose(got_c, o, atol=1e-2, rtol=1e-2, err_msg=name + " (C oracle)")
+
+
+def test_fp8_e4m3fn_codec_matches_torch_cast():
+    """The reference's fp8 KV pools are torch casts (memory_pool.py:2334-2343, :4022-4066): pin the
+    oracle's e4m3fn decode / encode (RNE, ties to even, NaN above 464) against torch's CPU cast."""
+    import torch
+
+    u = np.arange(256, dtype=np.uint8)
+    want = torch.from_numpy(u).view(torch.float8_e4m3fn).float().numpy()
+    got = orc.fp8_e4m3fn_decode(u)
+    assert np.array_equal(np.isnan(want), np.isnan(got))
+    assert np.array_equal(np.nan_to_num(want), np.nan_to_num(got))
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(100000) * np.exp(rng.uniform(-12, 7, 100000))).astype(np.float32)
+    mid = ((orc._FP8_POS[:-1] + orc._FP8_POS[1:]) / 2).astype(np.float32)
+    x = np.concatenate([x, mid, -mid, np.array([0.0, -0.0, 448, 464, 464.5, 1e6, -1e6], np.float32)])
+    for cast in (torch.bfloat16, torch.float16):
+        xs = torch.from_numpy(x).to(cast)
+        want = xs.to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+        got = orc.fp8_e4m3fn_encode(xs.float().numpy())
+        assert np.array_equal(want, got), cast
+    # quant-on-write with a scale: in-place div_ on the 16-bit tensor, then the cast
+    xb = torch.from_numpy(x[:50000]).bfloat16()
+    want = xb.clone().div_(0.37).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    got = orc.quantize_kv_fp8(xb.float().numpy(), 0.37, True)
+    assert np.array_equal(want, got)

@@ -14,6 +14,9 @@ bs, ctx, hq, dk, dv, ps = 64, 8192, 16, 576, 512, int(os.environ.get("PS", "1"))
 dev = "cuda"
 pool = bs * ctx + ps
 kv = torch.empty(pool, 1, dk, dtype=torch.bfloat16, device=dev).normal_()
+FP8 = bool(os.environ.get("FP8"))
+if FP8:
+    kv = kv.to(torch.float8_e4m3fn)
 q = torch.randn(bs, hq, dk, device=dev).to(torch.bfloat16)
 o = torch.empty(bs, hq, dv, dtype=torch.bfloat16, device=dev)
 perm = torch.randperm(bs * ctx // ps, device=dev) + 1 if ps > 1 else torch.randperm(bs * ctx, device=dev) + 1
@@ -48,7 +51,7 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
-byt = bs * ctx * dk * 2
+byt = bs * ctx * dk * (1 if FP8 else 2)
 print(f"MLA decode bs={bs} ctx={ctx} Hq={hq}: {ms*1e3:.1f} us  {byt/ms/1e6:.0f} GB/s ({byt/ms/1e6/8000:.1%} of 8 TB/s)")
 
 if os.environ.get("STAMPS"):
