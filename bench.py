@@ -155,7 +155,12 @@ def make_decode_state(args, tp, dev):
     rank = int(os.environ.get("RANK", "0"))
     w_full = (torch.randn(HQ * D, HID, device=dev, generator=g) * 0.02).to(torch.bfloat16)
     st.shard = shard_heads(HQ, HKV, tp, rank)
-    st.o_proj = RowParallelOProj(w_full, st.shard, D, TPGroup())
+    custom_ar = None
+    if tp > 1 and os.environ.get("RX_CUSTOM_AR") == "1":  # opt-in: peer-to-peer two-shot kernel instead of RCCL
+        from sglang_amd.parallel import CustomAllReduce
+        custom_ar = CustomAllReduce(None, torch.device(dev), max_bytes=bs * HID * 2)
+    st.custom_ar = custom_ar
+    st.o_proj = RowParallelOProj(w_full, st.shard, D, TPGroup(custom_ar=custom_ar))
     del w_full
     st.slots = slots
     return st
@@ -420,7 +425,8 @@ def main():
                                % (bs, ctx, L, args.page_size, args.kv_layout.upper(), world, st.hq, st.hkv,
                                   " + RCCL all-reduce (side stream)" if world > 1 else ""),
                    "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{world}",
-                   "index_mode": args.index_mode, "kv_layout": args.kv_layout, "kv_dtype": args.kv_dtype, "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
+                   "index_mode": args.index_mode, "kv_layout": args.kv_layout, "kv_dtype": args.kv_dtype,
+                   "all_reduce": "p2p-two-shot" if getattr(st, "custom_ar", None) is not None else ("rccl" if world > 1 else "none"), "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
                    "kv_bytes_resident_per_gpu": int(sum(st.pool.get_kv_size_bytes()))},
         "roofline": roofline,
     }

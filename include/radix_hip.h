@@ -37,7 +37,8 @@ typedef enum rx_dtype { RX_BF16 = 0, RX_F16 = 1 } rx_dtype; /* dtype of q / o / 
 
 /* Device-side error word bits (optional `err_flag`, int32, caller-zeroed): the kernels OR
  * these in instead of the reference's always-on device assert (kvcache.cuh:209). */
-#define RX_DEVERR_SLOT_OOB 1 /* a KV slot index fell outside [0, size_limit) */
+#define RX_DEVERR_SLOT_OOB 1   /* a KV slot index fell outside [0, size_limit) */
+#define RX_DEVERR_AR_TIMEOUT 2 /* rx_allreduce gave up waiting for a peer's flag */
 
 int rx_version(void);
 const char* rx_last_error(void);
@@ -263,6 +264,30 @@ int64_t rx_radix_total_size(const rx_radix* t);
 int64_t rx_radix_num_nodes(const rx_radix* t);
 /* info6 = {parent id, key length, lock_ref, hit_count, #children, priority}; -1 if unknown id. */
 int rx_radix_node_info(const rx_radix* t, int64_t node_id, int64_t* info6);
+
+/* ---- C1: peer-to-peer all-reduce over xGMI (one process per GPU) ---------------------------------
+ * The sum all-reduce behind RowParallelLinear.forward (srt/layers/linear.py:1606-1627 ->
+ * GroupCoordinator.all_reduce, srt/distributed/parallel_state.py:622-732, whose small-message path is a
+ * custom IPC all-reduce).  Two-shot direct over the full mesh; see csrc/rx_allreduce.hip.
+ *
+ * Setup (host, once): every rank allocates one region of rx_ar_region_bytes(max_bytes) with
+ * rx_ar_alloc_region (uncached device memory, zeroed), exports it with rx_ipc_get_handle, the 64-byte
+ * handles are exchanged out of band (torch.distributed all_gather in sglang_amd/parallel.py), peers
+ * are mapped with rx_ipc_open_handle, and rx_ar_init receives the `world` region pointers (own region =
+ * the local pointer).  dev_err is a caller-owned, zeroed int32 device word (RX_DEVERR_AR_TIMEOUT).
+ * rx_allreduce is stream ordered, allocation free and must be called in the same order with the same
+ * count on every rank; in == out is allowed.  count is in elements (multiple of 8), dtype an rx_dtype. */
+typedef struct rx_ar_ctx rx_ar_ctx;
+int64_t rx_ar_region_bytes(int64_t max_bytes);
+int rx_ar_alloc_region(int64_t bytes, void** dev_ptr_out);
+int rx_ar_free_region(void* dev_ptr);
+int rx_ipc_get_handle(void* dev_ptr, void* handle_out_64b);
+int rx_ipc_open_handle(const void* handle_64b, void** dev_ptr_out);
+int rx_ipc_close_handle(void* dev_ptr);
+int rx_ar_init(rx_ar_ctx** ctx_out, int rank, int world, void* const* peer_regions, int64_t max_bytes,
+               int32_t* dev_err);
+int rx_allreduce(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int dtype, void* stream);
+int rx_ar_destroy(rx_ar_ctx* ctx);
 
 #ifdef __cplusplus
 }

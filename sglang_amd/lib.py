@@ -72,6 +72,15 @@ PROTOTYPES = {
     "rx_store_kv": (c_int, [c_void_p] * 5 + [c_int64] * 7 + [c_int, c_int64, c_int64, c_void_p, c_void_p]),
     "rx_store_kv_layout": (c_int, [c_void_p, c_void_p, C.POINTER(RxKvLayout), c_void_p, c_int64, c_int, c_int,
                                    c_int, c_int64, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "rx_ar_region_bytes": (c_int64, [c_int64]),
+    "rx_ar_alloc_region": (c_int, [c_int64, C.POINTER(c_void_p)]),
+    "rx_ar_free_region": (c_int, [c_void_p]),
+    "rx_ipc_get_handle": (c_int, [c_void_p, c_void_p]),
+    "rx_ipc_open_handle": (c_int, [c_void_p, C.POINTER(c_void_p)]),
+    "rx_ipc_close_handle": (c_int, [c_void_p]),
+    "rx_ar_init": (c_int, [C.POINTER(c_void_p), c_int, c_int, C.POINTER(c_void_p), c_int64, c_void_p]),
+    "rx_allreduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rx_ar_destroy": (c_int, [c_void_p]),
     "rx_get_mla_kv": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p,
                               c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "rx_store_kv_fp8": (c_int, [c_void_p, c_void_p, C.POINTER(RxKvLayout), c_void_p, c_int64, c_int, c_int, c_int,

@@ -51,11 +51,83 @@ def shard_heads(total_q_heads: int, total_kv_heads: int, tp_size: int, tp_rank: 
     return HeadShard(tp_size, tp_rank, nq, nkv, tp_rank * nq, kv_start, rep)
 
 
+class CustomAllReduce:
+    """Peer-to-peer two-shot all-reduce over IPC-mapped buffers (csrc/rx_allreduce.hip; the role of
+    the reference's custom all-reduce behind GroupCoordinator.all_reduce, parallel_state.py:622-732).
+    One instance per rank; the 64-byte IPC handles travel through the torch.distributed group.
+    Opt-in (``RX_CUSTOM_AR=1``): RCCL stays the default because this round could only exercise the
+    kernel with several processes on ONE GPU (the gpurun box), not across xGMI."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup], device: torch.device, max_bytes: int = 8 << 20):
+        import ctypes as C
+
+        from . import lib as _L
+
+        self._L, self._C = _L, C
+        lib = self._lib = _L.load()
+        self.group, self.device = group, device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.max_bytes = (int(max_bytes) + 255) // 256 * 256
+        region_bytes = lib.rx_ar_region_bytes(self.max_bytes)
+        with torch.cuda.device(device):
+            own = C.c_void_p()
+            _L.check(lib.rx_ar_alloc_region(region_bytes, C.byref(own)), "rx_ar_alloc_region")
+            self._own = own
+            handle = C.create_string_buffer(64)
+            _L.check(lib.rx_ipc_get_handle(own, handle), "rx_ipc_get_handle")
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(handle.raw), group=group)
+            ptrs = (C.c_void_p * self.world)()
+            self._opened = []
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    ptrs[r] = own.value
+                else:
+                    p = C.c_void_p()
+                    _L.check(lib.rx_ipc_open_handle(C.create_string_buffer(h, 64), C.byref(p)), "rx_ipc_open_handle")
+                    ptrs[r] = p.value
+                    self._opened.append(p)
+            self.err_flag = torch.zeros(1, dtype=torch.int32, device=device)
+            ctx = C.c_void_p()
+            _L.check(lib.rx_ar_init(C.byref(ctx), self.rank, self.world, ptrs, self.max_bytes,
+                                    C.c_void_p(self.err_flag.data_ptr())), "rx_ar_init")
+            self._ctx = ctx
+        dist.barrier(group=group)  # every region is mapped everywhere before the first call
+
+    def supports(self, x: torch.Tensor) -> bool:
+        return (x.is_cuda and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float16)
+                and x.numel() % 8 == 0 and x.numel() * 2 <= self.max_bytes and x.data_ptr() % 16 == 0)
+
+    def all_reduce(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = x if out is None else out
+        st = self._lib.rx_allreduce(self._ctx, self._C.c_void_p(x.data_ptr()), self._C.c_void_p(out.data_ptr()),
+                                    x.numel(), self._L.RX_BF16 if x.dtype == torch.bfloat16 else self._L.RX_F16,
+                                    self._C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        self._L.check(st, "rx_allreduce")
+        return out
+
+    def check_errors(self) -> int:
+        v = int(self.err_flag.item())
+        if v:
+            self.err_flag.zero_()
+        return v
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None:
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)  # nobody still reads a region that is about to go away
+            self._lib.rx_ar_destroy(self._ctx)
+            for p in self._opened:
+                self._lib.rx_ipc_close_handle(p)
+            self._lib.rx_ar_free_region(self._own)
+            self._ctx = None
+
+
 class TPGroup:
     """Thin coordinator over one torch.distributed process group (GroupCoordinator's all_reduce
     entry, parallel_state.py:622-732)."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, custom_ar: Optional[CustomAllReduce] = None):
         if not dist.is_initialized():
             self.rank, self.world_size, self.group = 0, 1, None
         else:
@@ -63,12 +135,19 @@ class TPGroup:
             self.rank = dist.get_rank(group)
             self.world_size = dist.get_world_size(group)
         self._comm_stream = None
+        self.custom_ar = custom_ar if self.world_size > 1 else None
+
+    def _reduce(self, x: torch.Tensor) -> None:
+        if self.custom_ar is not None and self.custom_ar.supports(x):
+            self.custom_ar.all_reduce(x)
+        else:
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         """In-place sum over the group; bypassed for world size 1 (parallel_state.py:640-642)."""
         if self.world_size == 1:
             return x
-        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        self._reduce(x)
         return x
 
     # ---- side-stream overlap (GPU only) ------------------------------------------------------
@@ -88,7 +167,7 @@ class TPGroup:
         ready.record(main)
         self._comm_stream.wait_event(ready)
         with torch.cuda.stream(self._comm_stream):
-            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+            self._reduce(x)
             x.record_stream(self._comm_stream)
             done = torch.cuda.Event()
             done.record(self._comm_stream)
