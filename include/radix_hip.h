@@ -165,6 +165,9 @@ typedef struct rx_decode_params {
   float sm_scale, k_scale, v_scale, logit_cap;
   const float* sinks; /* fp32[Hq] or NULL (stage 2, :796-798) */
   int32_t dtype;      /* rx_dtype of q / kv / o */
+  /* Grok temperature (decode_attention.py:156-160,212-213): L > 0 multiplies request b's scores by
+   * log2(seq_len_b - 1) / log2(L) when seq_len_b - 1 > L (after scale and cap); <= 0 = off */
+  int32_t xai_temperature_len;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);
@@ -195,6 +198,19 @@ typedef struct rx_extend_params {
   int32_t is_causal, skip_prefix, skip_extend, sliding_window_size; /* window <= 0: off */
   const float* sinks;
   int32_t dtype;
+  /* speculative-decoding tree mask (extend_attention.py:320-326,378-390,525-539; built by
+   * TritonAttnBackend.init_forward_metadata for TARGET_VERIFY / DRAFT_EXTEND, triton_backend.py:845-866):
+   * request i owns the bytes custom_mask[mask_indptr[i] ...], a row-major
+   * [E_i, woff_i + P_i + E_i] 0/1 matrix (woff_i = window_kv_offsets[i], 0 when NULL).  In the
+   * extend part the mask REPLACES the causal triangle; the prefix part is masked only when
+   * skip_prefix_custom_mask == 0.  NULL = no mask. */
+  const uint8_t* custom_mask;
+  const int64_t* mask_indptr; /* int64[bs+1] */
+  int32_t skip_prefix_custom_mask;
+  const int32_t* window_kv_offsets; /* int32[bs] or NULL */
+  /* Grok temperature (:336-343): L > 0 multiplies the scores of the query at absolute position
+   * a = P_i + m by log2(a) / log2(L) when a > L (after scale and cap); <= 0 = off */
+  int32_t xai_temperature_len;
 } rx_extend_params;
 
 int rx_extend_attn(const rx_extend_params* p /* HOST */, void* stream);

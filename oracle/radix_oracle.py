@@ -482,7 +482,7 @@ def _gather_kv(buf, slots, kv_head):
 
 def decode_attention(q, k_buffer, v_buffer, kv_indptr, kv_indices, sm_scale,
                      k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
-                     return_lse=False):
+                     return_lse=False, xai_temperature_len=-1):
     """Semantics of decode_attention_fwd (decode_attention.py:968-1044):
     o[b,h] = softmax(q[b,h]·K[idx]^T * sm_scale*k_scale [tanh cap]) · V[idx] * v_scale,
     idx = kv_indices[kv_indptr[b]:kv_indptr[b+1]], kv head = h // (Hq/Hkv).
@@ -499,11 +499,14 @@ def decode_attention(q, k_buffer, v_buffer, kv_indptr, kv_indices, sm_scale,
         idx = np.asarray(kv_indices[kv_indptr[b] : kv_indptr[b + 1]]).astype(np.int64)
         if idx.size == 0:
             continue
+        xai = 1.0  # Grok temperature (decode_attention.py:156-160,212-213): the query sits at seq_len - 1
+        if xai_temperature_len > 0 and idx.size - 1 > xai_temperature_len:
+            xai = math.log2(idx.size - 1) / math.log2(float(xai_temperature_len))
         for kvh in range(hkv):
             kk = _gather_kv(k_buffer, idx, kvh)
             vv = _gather_kv(v_buffer, idx, kvh)
             for h in range(kvh * group, (kvh + 1) * group):
-                s = _tanh_cap(kk @ qf[b, h] * (sm_scale * k_scale), logit_cap)
+                s = _tanh_cap(kk @ qf[b, h] * (sm_scale * k_scale), logit_cap) * xai
                 m = s.max()
                 p = np.exp(s - m)
                 den = p.sum()
@@ -573,7 +576,8 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
                      kv_indptr, kv_indices, is_causal=True, sm_scale=None,
                      k_scale=1.0, v_scale=1.0, logit_cap=0.0,
                      sliding_window_size=-1, sinks=None, skip_prefix=False,
-                     skip_extend=False, return_lse=False):
+                     skip_extend=False, return_lse=False, custom_mask=None, mask_indptr=None,
+                     skip_prefix_custom_mask=True, window_kv_offsets=None, xai_temperature_len=-1):
     """Semantics of extend_attention_fwd (extend_attention.py:664-812).  Request i
     has prefix tokens kv_indices[kv_indptr[i]:kv_indptr[i+1]] read from the cache
     (stage 1, :372-510; scaled by k_scale / v_scale) and E_i = qo_indptr[i+1]-
@@ -581,6 +585,12 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
     (stage 2, :512-631).  Query m (0-based inside the extend part) sees every
     prefix token and extend tokens n <= m when causal, all E_i otherwise.
     sliding window W>0: q_abs <= kv_abs + W (:385-390, :556-561).
+    custom_mask (speculative tree attention, :320-326, :378-390, :525-539): request i owns the flat
+    bytes mask[mask_indptr[i]:], a row-major [E_i, woff_i + P_i + E_i] matrix (woff = window_kv_offsets,
+    0 without SWA); in the extend part it REPLACES the causal mask, in the prefix part it applies
+    unless skip_prefix_custom_mask.  xai_temperature_len L>0 (:336-343, :460, :591): scores of the
+    query at absolute position a = P_i + m are multiplied by log2(a)/log2(L) when a > L, after scale
+    and cap.  Rows with nothing visible come out NaN in the reference (0/0); here they stay 0.
     Returns o float64 [T,Hq,Dv] (+ lse [T,Hq])."""
     t, hq, dq = q_extend.shape
     hkv = k_extend.shape[1]
@@ -597,6 +607,12 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
         e = q1 - q0
         idx = np.asarray(kv_indices[kv_indptr[i] : kv_indptr[i + 1]]).astype(np.int64)
         p_len = idx.size
+        cm = None
+        if custom_mask is not None:
+            woff = int(window_kv_offsets[i]) if window_kv_offsets is not None else 0
+            row = woff + p_len + e
+            m0 = int(mask_indptr[i])
+            cm = np.asarray(custom_mask[m0 : m0 + e * row]).astype(bool).reshape(e, row)[:, woff:]
         for kvh in range(hkv):
             if p_len and not skip_prefix:
                 kp = _gather_kv(k_buffer, idx, kvh)
@@ -608,15 +624,22 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
             for h in range(kvh * group, (kvh + 1) * group):
                 for m in range(e):
                     parts_s, parts_v = [], []
+                    xai = 1.0
+                    if xai_temperature_len > 0 and (p_len + m) > xai_temperature_len:
+                        xai = math.log2(p_len + m) / math.log2(float(xai_temperature_len))
                     if kp.shape[0]:
-                        s1 = _tanh_cap(kp @ qf[q0 + m, h] * (sm_scale * k_scale), logit_cap)
+                        s1 = _tanh_cap(kp @ qf[q0 + m, h] * (sm_scale * k_scale), logit_cap) * xai
+                        if cm is not None and not skip_prefix_custom_mask:
+                            s1 = np.where(cm[m, :p_len], s1, -np.inf)
                         if sliding_window_size > 0:
                             keep = (p_len + m) <= (np.arange(p_len) + sliding_window_size)
                             s1 = np.where(keep, s1, -np.inf)
                         parts_s.append(s1); parts_v.append(vp * v_scale)
                     if not skip_extend:
-                        n_end = (m + 1) if is_causal else e
-                        s2 = _tanh_cap(ke[:n_end] @ qf[q0 + m, h] * sm_scale, logit_cap)
+                        n_end = (m + 1) if (is_causal and cm is None) else e
+                        s2 = _tanh_cap(ke[:n_end] @ qf[q0 + m, h] * sm_scale, logit_cap) * xai
+                        if cm is not None:
+                            s2 = np.where(cm[m, p_len : p_len + n_end], s2, -np.inf)
                         if sliding_window_size > 0:
                             keep = m <= (np.arange(n_end) + sliding_window_size)
                             s2 = np.where(keep, s2, -np.inf)

@@ -49,7 +49,15 @@ struct DecodeArgs {
   float v_scale, logit_cap;
   const float* sinks;
   int32_t kv_fp8;  // pool holds fp8 e4m3fn bytes (strides in bytes)
+  int32_t xai_len; // Grok temperature length or <= 0
 };
+
+// Grok temperature factor of a request (decode_attention.py:156-160): the single query sits at seq_len-1
+__device__ __forceinline__ float xai_factor(int32_t xai_len, int32_t seq_len) {
+  const int32_t qidx = seq_len - 1;
+  if (xai_len <= 0 || qidx <= xai_len) return 1.0f;
+  return __log2f(static_cast<float>(qidx)) / __log2f(static_cast<float>(xai_len));
+}
 
 constexpr int kMinBlockKV = 32;  // decode_attention.py:36 (_MIN_BLOCK_KV)
 constexpr int kTile = 32;        // tokens per wave tile (K of the PV MFMA)
@@ -202,7 +210,8 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
   float m_run = -INFINITY;  // running max (log2 domain), identical in the 4 lanes of a q head
   float l_run = 0.f;        // this lane's partial row sum
 
-  const float scale_log2 = a.sm_scale * kLog2e;
+  const float xai = xai_factor(a.xai_len, si.seq_len);
+  const float scale_log2 = a.sm_scale * kLog2e * xai;
 
   auto load_slots = [&](int t, int64_t& s0, int64_t& s1) {
     const int32_t t0 = min(lo + t * kTile + r, hi - 1);
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
       for (int i = 0; i < 4; ++i) {
         float x = sacc[bb][i];
         if (a.logit_cap > 0.f) {
-          x = a.logit_cap * tanhf(x * a.sm_scale / a.logit_cap) * kLog2e;
+          x = a.logit_cap * tanhf(x * a.sm_scale / a.logit_cap) * (kLog2e * xai);
         } else {
           x *= scale_log2;
         }
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(64) void decode_generic_kernel(const DecodeArgs a, 
     for (int d = 0; d < dk; ++d) s += qs[d] * T::to_f32(kp[d]);
     s *= a.sm_scale;
     if (a.logit_cap > 0.f) s = a.logit_cap * tanhf(s / a.logit_cap);
-    s = valid ? s * kLog2e : -INFINITY;
+    s = valid ? s * (kLog2e * xai_factor(a.xai_len, si.seq_len)) : -INFINITY;
     float mt = s;
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) mt = fmaxf(mt, __shfl_xor(mt, dd));
@@ -679,6 +688,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.logit_cap = p->logit_cap;
   a.sinks = p->sinks;
   a.kv_fp8 = p->kv.kv_fp8;
+  a.xai_len = p->xai_temperature_len;
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);

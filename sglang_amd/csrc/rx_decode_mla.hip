@@ -46,6 +46,7 @@ struct MlaArgs {
   int32_t bs, hq, qblocks;
   float sm_scale, v_scale, logit_cap;
   const float* sinks;
+  int32_t xai_len;
 };
 
 #ifndef RX_MLA_STAMP
@@ -176,7 +177,10 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
-  const float c2 = (a.logit_cap > 0.f) ? kLog2e : a.sm_scale * kLog2e;
+  float xai = 1.0f;  // Grok temperature (decode_attention.py:156-160): the query sits at seq_len - 1
+  if (a.xai_len > 0 && seq_len - 1 > a.xai_len)
+    xai = __log2f(static_cast<float>(seq_len - 1)) / __log2f(static_cast<float>(a.xai_len));
+  const float c2 = ((a.logit_cap > 0.f) ? kLog2e : a.sm_scale * kLog2e) * xai;
 
   load_slots(0);
   issue_loads();
@@ -364,6 +368,7 @@ int launch_decode_mla(const rx_decode_params* p, hipStream_t s) {
   a.v_scale = p->v_scale;
   a.logit_cap = p->logit_cap;
   a.sinks = p->sinks;
+  a.xai_len = p->xai_temperature_len;
   const bool linear = p->kv.page_size == 1 || p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride;
   const bool idx64 = p->kv_indices != nullptr && p->kv_indices_is_i64;
   const unsigned grid = static_cast<unsigned>(a.bs) * a.qblocks * a.max_kv_splits;

@@ -39,6 +39,10 @@ struct ExtendArgs {
   int32_t bs, hq, hkv, group, mblocks;
   float sm_scale, k_scale, v_scale, logit_cap;
   int32_t causal, skip_prefix, skip_extend, window;
+  const uint8_t* custom_mask;  // generic kernel only (the D = 128 MFMA kernel has its own copy)
+  const int64_t* mask_indptr;
+  const int32_t* window_kv_offsets;
+  int32_t skip_prefix_mask, xai_len;
   const float* sinks;
 };
 
@@ -407,7 +411,14 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(const ExtendArgs a, 
   const int32_t P = a.kv_indptr[req + 1] - kv0;
   const IdxT* idx = reinterpret_cast<const IdxT*>(a.kv_indices) + kv0;
   const int32_t p_len = a.skip_prefix ? 0 : P;
-  const int32_t n_end = a.skip_extend ? 0 : (a.causal ? m + 1 : E);
+  const bool masked = a.custom_mask != nullptr;
+  const int32_t n_end = a.skip_extend ? 0 : ((a.causal && !masked) ? m + 1 : E);
+  const int32_t mask_woff = (masked && a.window_kv_offsets) ? a.window_kv_offsets[req] : 0;
+  const uint8_t* mask_row_p =
+      masked ? a.custom_mask + a.mask_indptr[req] + static_cast<int64_t>(m) * (mask_woff + P + E) + mask_woff : nullptr;
+  float xai = 1.0f;
+  if (a.xai_len > 0 && P + m > a.xai_len)
+    xai = __log2f(static_cast<float>(P + m)) / __log2f(static_cast<float>(a.xai_len));
   for (int d = lane; d < dk; d += 64) qs[d] = T::to_f32(a.q[tq * a.q_stride_t + h * a.q_stride_h + d]);
   __syncthreads();
   constexpr int MAXV = 8;
@@ -436,11 +447,14 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(const ExtendArgs a, 
     for (int d = 0; d < dk; ++d) s += qs[d] * T::to_f32(kp[d]);
     s *= prefix ? a.sm_scale * a.k_scale : a.sm_scale;
     if (a.logit_cap > 0.f) s = a.logit_cap * tanhf(s / a.logit_cap);
+    s *= xai;
     bool keep = inb;
     if (a.window > 0) {
       if (prefix) keep = keep && (P + m <= nn + a.window);
       else keep = keep && (m <= (nn - p_len) + a.window);
     }
+    if (masked && keep && (!prefix || !a.skip_prefix_mask))
+      keep = mask_row_p[prefix ? nn : P + (nn - p_len)] != 0;
     s = keep ? s * kLog2e : -INFINITY;
     float mt = s;
 #pragma unroll
@@ -482,7 +496,9 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(const ExtendArgs a, 
 
 template <typename T, typename IdxT, bool LINEAR>
 static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, hipStream_t s) {
-  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
+  // tree masks and the xai temperature live in the D = 128 kernel (rx_extend32.hip) and in the generic
+  // kernel; the 16x16x32 kernel below does not carry them
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128) && !a.custom_mask && a.xai_len <= 0;
   if (mfma_ok) {
     const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
     const bool vs = a.v_scale != 1.0f;
@@ -542,7 +558,9 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   RX_REQUIRE(p->kv.kv_fp8 == 0 || p->kv.kv_fp8 == 1, "rx_extend_attn: kv_fp8 = %d", p->kv.kv_fp8);
   if (p->kv.kv_fp8 && !p->skip_prefix && !(mfma_ok && dk == 128))
     return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: an fp8 prefix pool needs head_dim 128, got %d/%d", dk, dv);
-  if (mfma_ok && dk == 128 && (p->kv.kv_fp8 || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
+  if (p->custom_mask) RX_REQUIRE(p->mask_indptr, "rx_extend_attn: custom_mask given without mask_indptr");
+  const bool extras = p->custom_mask || p->xai_temperature_len > 0;
+  if (mfma_ok && dk == 128 && (p->kv.kv_fp8 || extras || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
     const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }
@@ -589,6 +607,11 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   a.skip_prefix = p->skip_prefix;
   a.skip_extend = p->skip_extend;
   a.window = p->sliding_window_size;
+  a.custom_mask = p->custom_mask;
+  a.mask_indptr = p->mask_indptr;
+  a.window_kv_offsets = p->window_kv_offsets;
+  a.skip_prefix_mask = p->skip_prefix_custom_mask;
+  a.xai_len = p->xai_temperature_len;
   a.sinks = p->sinks;
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&

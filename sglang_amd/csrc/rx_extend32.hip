@@ -48,6 +48,11 @@ struct Ext32Args {
   int32_t bs, hq, hkv, group, mblocks;
   float sm_scale, k_scale, v_scale, logit_cap;
   int32_t causal, skip_prefix, skip_extend, window;
+  const uint8_t* custom_mask;   // tree mask (speculative verify) or null
+  const int64_t* mask_indptr;
+  const int32_t* window_kv_offsets;
+  int32_t skip_prefix_mask;     // 1: the prefix part is not masked
+  int32_t xai_len;              // Grok temperature length or <= 0
   const float* sinks;
 };
 
@@ -140,6 +145,21 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   int m[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) m[qb] = qbase + 32 * qb + ql;
+
+  // speculative tree mask: row of query m = mask_base + m * mask_row (+ woff + kv position)
+  const bool masked = a.custom_mask != nullptr;
+  const int32_t mask_woff = (masked && a.window_kv_offsets) ? a.window_kv_offsets[req] : 0;
+  const int64_t mask_row = static_cast<int64_t>(mask_woff) + P + E;
+  const uint8_t* mask_base = masked ? a.custom_mask + a.mask_indptr[req] + mask_woff : nullptr;
+  const bool mask_prefix = masked && !a.skip_prefix_mask;
+  // Grok temperature: per-query multiplier of the scaled scores (1 when off)
+  float xai[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    xai[qb] = 1.0f;
+    if (a.xai_len > 0 && P + m[qb] > a.xai_len)
+      xai[qb] = __log2f(static_cast<float>(P + m[qb])) / __log2f(static_cast<float>(a.xai_len));
+  }
 
   // ---- Q^T fragments: lane (q, h) holds Q[q][16 ks + 8 h .. +8] ------------------------------------
   vec8 qf[QB][KS];
@@ -309,8 +329,8 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     ti.c2 = capped ? kLog2e : ti.cs * kLog2e;
     ti.vs = ti.prefix ? a.v_scale : 1.0f;
     const int n_hi = ti.tile_n0 + 32 * ti.nblk;
-    if (ti.prefix) ti.full = n_hi <= p_len && a.window <= 0;
-    else ti.full = n_hi <= E && (!a.causal || n_hi - 1 <= qbase) && a.window <= 0;
+    if (ti.prefix) ti.full = n_hi <= p_len && a.window <= 0 && !mask_prefix;
+    else ti.full = n_hi <= E && (!a.causal || n_hi - 1 <= qbase) && a.window <= 0 && !masked;
     ti.fast = ti.work && ti.full && ti.nblk == 2 && !capped && (LINEAR || a.page_size < 0);
     return ti;
   };
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       __syncthreads();
       RX_STAMP(0);
       const char* tile = smem + (t & 1) * kBufBytes;
-      const float c2 = ti.c2, vs = ti.vs;
+      const float c2u = ti.c2, vs = ti.vs;
       // ===== fast body: a hand-ordered wave-level software pipeline.  Measured before it: the tile's
       // phases (QK^T MFMAs, softmax VALU, PV MFMAs, staging) cost their SUM -- hipcc issues all MFMAs
       // of a phase back to back and the in-order wave then does its VALU with the matrix pipe idle.
@@ -373,6 +393,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       // one slice of a block's softmax for query block qb; j = 0..6
       auto sm_slice = [&](int j, int qb, f32x16& sc, float m_prev, float& m_new, float& alpha, float (&ps)[2],
                           u32x4 (&pk)[2]) {
+        const float c2 = c2u * xai[qb];
         if (j == 0) {
           ma[qb] = max3f(sc[0], sc[1], sc[2]);
           mb_[qb] = max3f(sc[3], sc[4], sc[5]);
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       const char* tile = smem + (t & 1) * kBufBytes;
       const bool prefix = ti.prefix, full = ti.full;
       const int tile_n0 = ti.tile_n0, nblk = ti.nblk;
-      const float cs = ti.cs, c2 = ti.c2, vs = ti.vs;
+      const float cs = ti.cs, c2u = ti.c2, vs = ti.vs;
       // ===== boundary tiles: causal diagonal, ragged ends, window, logit cap; one query block at a time
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
@@ -567,9 +588,11 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
                 if (prefix) {
                   keep = n < p_len;
                   if (a.window > 0) keep = keep && (P + m[qb] <= n + a.window);
+                  if (mask_prefix && keep && m[qb] < E) keep = mask_base[m[qb] * mask_row + n] != 0;
                 } else {
-                  keep = n < n_end_w && (!a.causal || n <= m[qb]);
+                  keep = n < n_end_w && (masked || !a.causal || n <= m[qb]);
                   if (a.window > 0) keep = keep && (m[qb] <= n + a.window);
+                  if (masked && keep && m[qb] < E) keep = mask_base[m[qb] * mask_row + P + n] != 0;
                 }
                 sacc[b][i] = keep ? sacc[b][i] : -INFINITY;
               }
@@ -577,6 +600,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
             mt = fmaxf(mt, row_max16(sacc[b]));
           }
         }
+        const float c2 = c2u * xai[qb];
         mt = half_swap_max(mt);
         mt *= c2;
         const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
@@ -704,6 +728,8 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.sm_scale = p->sm_scale; a.k_scale = p->k_scale; a.v_scale = p->v_scale; a.logit_cap = p->logit_cap;
   a.causal = p->is_causal; a.skip_prefix = p->skip_prefix; a.skip_extend = p->skip_extend;
   a.window = p->sliding_window_size; a.sinks = p->sinks;
+  a.custom_mask = p->custom_mask; a.mask_indptr = p->mask_indptr; a.window_kv_offsets = p->window_kv_offsets;
+  a.skip_prefix_mask = p->skip_prefix_custom_mask; a.xai_len = p->xai_temperature_len;
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);

@@ -37,7 +37,7 @@ def store_cache(k: Tensor, v: Tensor, k_cache: Tensor, v_cache: Tensor, indices:
 # K2 / K3 ----------------------------------------------------------------------------------------
 @_op("build_kv_indices", ("kv_indptr", "kv_indices"))
 def build_kv_indices(req_to_token: Tensor, req_pool_indices: Tensor, lens: Tensor, kv_indptr: Tensor,
-                     kv_indices: Optional[Tensor] = None, kv_start: Optional[Tensor] = None) -> None:
+                     kv_indices: Tensor, kv_start: Optional[Tensor] = None) -> None:
     ops.build_kv_indices(req_to_token, req_pool_indices, lens, kv_indptr, kv_indices, kv_start)
 
 
@@ -72,21 +72,50 @@ def decode_attention_paged(q: Tensor, k_buffer: Tensor, v_buffer: Tensor, o: Ten
 
 
 # K7 ---------------------------------------------------------------------------------------------
-@_op("extend_attention", ("o_extend", "lse_extend"))
+# (torch.library cannot take an OPTIONAL mutated argument that the caller omits, so the LSE output
+# has its own op)
+def _extend(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+            is_causal, max_len_extend, k_scale, v_scale, sm_scale, logit_cap, sliding_window_size, sinks,
+            lse_extend, skip_prefix, skip_extend, page_size, custom_mask, mask_indptr, skip_prefix_custom_mask,
+            window_kv_offsets, xai_temperature_len):
+    ops.extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
+                             kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend,
+                             k_scale, v_scale, sm_scale=sm_scale, logit_cap=logit_cap,
+                             skip_prefix_custom_mask=skip_prefix_custom_mask,
+                             sliding_window_size=sliding_window_size, sinks=sinks,
+                             window_kv_offsets=window_kv_offsets, xai_temperature_len=xai_temperature_len,
+                             lse_extend=lse_extend, skip_prefix=skip_prefix, skip_extend=skip_extend,
+                             page_size=page_size)
+
+
+@_op("extend_attention", ("o_extend",))
 def extend_attention(q_extend: Tensor, k_extend: Tensor, v_extend: Tensor, o_extend: Tensor,
                      k_buffer: Optional[Tensor], v_buffer: Optional[Tensor], qo_indptr: Tensor,
                      kv_indptr: Tensor, kv_indices: Optional[Tensor], is_causal: bool,
                      max_len_extend: int, k_scale: float = 1.0, v_scale: float = 1.0,
                      sm_scale: Optional[float] = None, logit_cap: float = 0.0,
                      sliding_window_size: int = -1, sinks: Optional[Tensor] = None,
-                     lse_extend: Optional[Tensor] = None, skip_prefix: bool = False,
-                     skip_extend: bool = False, page_size: int = 1) -> None:
-    ops.extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
-                             kv_indptr, kv_indices, None, is_causal, None, max_len_extend, k_scale,
-                             v_scale, sm_scale=sm_scale, logit_cap=logit_cap,
-                             sliding_window_size=sliding_window_size, sinks=sinks,
-                             lse_extend=lse_extend, skip_prefix=skip_prefix, skip_extend=skip_extend,
-                             page_size=page_size)
+                     skip_prefix: bool = False, skip_extend: bool = False, page_size: int = 1,
+                     custom_mask: Optional[Tensor] = None, mask_indptr: Optional[Tensor] = None,
+                     skip_prefix_custom_mask: bool = True, window_kv_offsets: Optional[Tensor] = None,
+                     xai_temperature_len: int = -1) -> None:
+    _extend(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+            is_causal, max_len_extend, k_scale, v_scale, sm_scale, logit_cap, sliding_window_size, sinks, None,
+            skip_prefix, skip_extend, page_size, custom_mask, mask_indptr, skip_prefix_custom_mask,
+            window_kv_offsets, xai_temperature_len)
+
+
+@_op("extend_attention_lse", ("o_extend", "lse_extend"))
+def extend_attention_lse(q_extend: Tensor, k_extend: Tensor, v_extend: Tensor, o_extend: Tensor,
+                         lse_extend: Tensor, k_buffer: Optional[Tensor], v_buffer: Optional[Tensor],
+                         qo_indptr: Tensor, kv_indptr: Tensor, kv_indices: Optional[Tensor], is_causal: bool,
+                         max_len_extend: int, k_scale: float = 1.0, v_scale: float = 1.0,
+                         sm_scale: Optional[float] = None, logit_cap: float = 0.0,
+                         sliding_window_size: int = -1, sinks: Optional[Tensor] = None,
+                         skip_prefix: bool = False, skip_extend: bool = False, page_size: int = 1) -> None:
+    _extend(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+            is_causal, max_len_extend, k_scale, v_scale, sm_scale, logit_cap, sliding_window_size, sinks,
+            lse_extend, skip_prefix, skip_extend, page_size, None, None, True, None, -1)
 
 
 # K9 / K10 / K11 ---------------------------------------------------------------------------------
@@ -119,7 +148,7 @@ def move_kv(data_ptrs: Tensor, row_bytes: Tensor, tgt_loc: Tensor, src_loc: Tens
 
 
 ALL_OPS = (store_cache, build_kv_indices, get_num_kv_splits, decode_attention, decode_attention_paged,
-           extend_attention, alloc_extend, alloc_decode, write_req_to_token, move_kv)
+           extend_attention, extend_attention_lse, alloc_extend, alloc_decode, write_req_to_token, move_kv)
 
 for _o in ALL_OPS:  # in-place ops: the fake implementation has nothing to compute
     _o.register_fake(lambda *a, **k: None)

@@ -44,6 +44,7 @@ class RxDecodeParams(C.Structure):
         ("head_dim", c_int32), ("v_head_dim", c_int32),
         ("sm_scale", c_float), ("k_scale", c_float), ("v_scale", c_float), ("logit_cap", c_float),
         ("sinks", c_void_p), ("dtype", c_int32),
+        ("xai_temperature_len", c_int32),
     ]
 
 
@@ -62,6 +63,8 @@ class RxExtendParams(C.Structure):
         ("is_causal", c_int32), ("skip_prefix", c_int32), ("skip_extend", c_int32),
         ("sliding_window_size", c_int32),
         ("sinks", c_void_p), ("dtype", c_int32),
+        ("custom_mask", c_void_p), ("mask_indptr", c_void_p), ("skip_prefix_custom_mask", c_int32),
+        ("window_kv_offsets", c_void_p), ("xai_temperature_len", c_int32),
     ]
 
 

@@ -240,8 +240,10 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     """Same contract as the reference.  q [bs,Hq,Dk], o [bs,Hq,Dv], kv_indptr int32[bs+1],
     kv_indices int32/int64, attn_logits fp32[bs,Hq,max_kv_splits,Dv], attn_lse fp32[bs,Hq,S].
     ``max_kv_splits == 1`` (or num_kv_splits None) runs the single-pass kernel."""
-    if xai_temperature_len > 0 or score_mod is not None or aux_tensors is not None or has_mla:
-        raise NotImplementedError("xai temperature / score_mod / MLA are outside the HIP path")
+    if score_mod is not None or aux_tensors is not None:
+        raise NotImplementedError("score_mod / aux_tensors: outside the HIP path")
+    # has_mla only selects a Triton block shape in the reference; here the MLA kernel is chosen from the
+    # tensor shapes (Dk 576 / Dv 512, one kv head, V aliasing K)
     _require_cuda(q, k_buffer, v_buffer, o, kv_indptr, kv_indices)
     if max_kv_splits > 1:
         assert max_kv_splits == attn_logits.shape[2]
@@ -256,13 +258,14 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     p.kv_indptr = kv_indptr.data_ptr()
     p.kv_indices = kv_indices.data_ptr()
     p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
+    p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
 def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
                                attn_logits, attn_lse, num_kv_splits, max_kv_splits, sm_scale,
                                k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
-                               page_size: int = 1, kv_layout=None):
+                               page_size: int = 1, kv_layout=None, xai_temperature_len=-1):
     """MI355X-native entry: the kernel walks req_to_token itself (as the reference's CPU kernel
     decode_attention_cpu does, aot/csrc/cpu/decode.cpp:1586), so no kv_indices are materialised."""
     _require_cuda(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens)
@@ -279,6 +282,7 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
     p.req_pool_indices_is_i64 = _is64(req_pool_indices, "req_pool_indices")
     p.seq_lens = seq_lens.data_ptr()
     p.seq_lens_is_i64 = _is64(seq_lens, "seq_lens")
+    p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -437,9 +441,10 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
                          window_kv_offsets=None, xai_temperature_len=-1, lse_extend=None,
                          skip_prefix=False, skip_extend=False, page_size: int = 1,
                          score_mod=None, aux_tensors=None, kv_layout=None):
-    if custom_mask is not None or xai_temperature_len > 0 or score_mod is not None:
-        raise NotImplementedError("custom_mask / xai temperature / score_mod: outside the HIP path")
-    _require_cuda(q_extend, k_extend, v_extend, o_extend, qo_indptr, kv_indptr)
+    if score_mod is not None or aux_tensors is not None:
+        raise NotImplementedError("score_mod / aux_tensors: outside the HIP path")
+    _require_cuda(q_extend, k_extend, v_extend, o_extend, qo_indptr, kv_indptr, custom_mask, mask_indptr,
+                  window_kv_offsets)
     for name, t in (("q", q_extend), ("k", k_extend), ("v", v_extend), ("o", o_extend)):
         if t.dim() != 3 or t.stride(-1) != 1:
             raise ValueError(f"{name}_extend must be [T, heads, dim] and contiguous in dim")
@@ -482,6 +487,23 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         p._keep = sinks
         p.sinks = sinks.data_ptr()
     p.dtype = _rx_dtype(q_extend)
+    keep = []
+    if custom_mask is not None:  # speculative tree mask (bool / uint8 bytes) + int64 offsets
+        if mask_indptr is None:
+            raise ValueError("custom_mask needs mask_indptr")
+        cm = custom_mask if custom_mask.dtype == torch.uint8 else custom_mask.to(torch.uint8)
+        mi = mask_indptr if mask_indptr.dtype == torch.int64 else mask_indptr.to(torch.int64)
+        cm, mi = cm.contiguous(), mi.contiguous()
+        keep += [cm, mi]
+        p.custom_mask, p.mask_indptr = cm.data_ptr(), mi.data_ptr()
+        p.skip_prefix_custom_mask = int(bool(skip_prefix_custom_mask))
+        if window_kv_offsets is not None:
+            wo = window_kv_offsets if window_kv_offsets.dtype == torch.int32 else window_kv_offsets.to(torch.int32)
+            wo = wo.contiguous()
+            keep.append(wo)
+            p.window_kv_offsets = wo.data_ptr()
+    p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
+    p._keep_mask = keep
     _L.check(_L.load().rx_extend_attn(C.byref(p), _stream(q_extend)), "rx_extend_attn")
 
 

@@ -16,6 +16,8 @@ Fixture families:
   F6 extend attention (Triton extend_attention_fwd) -> extend_*.npz
   F7 radix tree op sequences (reference RadixCache, recording allocator) -> radix_sequences.json
   F8 bf16 decode/extend from the compiled reference C++ CPU kernels -> cpu_native.npz
+  F10 decode with the xai temperature -> decode_xai.npz
+  F9 extend with custom (tree) masks, sliding window (+ window_kv_offsets), xai temperature -> extend_mask.npz
 """
 import json
 import os
@@ -561,7 +563,107 @@ def f8():
     save("cpu_native.npz", **out)
 
 
+def f9():
+    """F9 extend with the speculative-decoding tree mask (custom_mask / mask_indptr, with and without
+    the prefix part masked), sliding window + window_kv_offsets, and Grok's xai temperature ->
+    extend_mask.npz.  Reference kernel under TRITON_INTERPRET=1 (fp16)."""
+    torch.manual_seed(7)
+    dtype = torch.float16
+    rng = np.random.default_rng(19)
+    cfgs = [
+        # name, Hq, Hkv, D, prefix, extend, skip_prefix_mask, window, woff, xai_len
+        ("tree", 8, 2, 128, [40, 7], [6, 6], True, -1, None, -1),
+        ("tree_prefix", 4, 4, 64, [33, 5], [5, 9], False, -1, None, -1),
+        ("tree_swa", 8, 2, 128, [20, 12], [4, 4], True, 16, [3, 0], -1),
+        ("xai", 8, 2, 128, [50, 3], [9, 17], None, -1, None, 16),
+        ("swa", 4, 2, 128, [70, 10], [12, 40], None, 24, None, -1),
+    ]
+    flat = {}
+    for name, HQ, HKV, D, pre, ext, skipm, window, woff, xai in cfgs:
+        pre = np.array(pre, dtype=np.int32); ext = np.array(ext, dtype=np.int32)
+        B = len(pre)
+        T = int(ext.sum())
+        pool = int(pre.sum()) + 9
+        kb = torch.randn(pool, HKV, D).to(dtype)
+        vb = torch.randn(pool, HKV, D).to(dtype)
+        q = torch.randn(T, HQ, D).to(dtype)
+        k_ext = torch.randn(T, HKV, D).to(dtype)
+        v_ext = torch.randn(T, HKV, D).to(dtype)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.from_numpy(np.cumsum(pre))
+        qo_indptr = torch.zeros(B + 1, dtype=torch.int64)
+        qo_indptr[1:] = torch.from_numpy(np.cumsum(ext))
+        kv_indices = torch.from_numpy(rng.permutation(pool - 1)[: int(pre.sum())] + 1).to(torch.int64)
+        custom_mask = mask_indptr = wko = None
+        if skipm is not None:
+            wo = np.array(woff if woff is not None else [0] * B, dtype=np.int32)
+            rows = []
+            for i in range(B):
+                L = int(pre[i] + ext[i] + wo[i])
+                m = rng.random((int(ext[i]), L)) < 0.5
+                # a draft token always sees itself; tree masks never look ahead
+                for r in range(int(ext[i])):
+                    m[r, wo[i] + pre[i] + r] = True
+                    m[r, wo[i] + pre[i] + r + 1:] = False
+                    if skipm:
+                        m[r, : wo[i] + pre[i]] = True
+                    else:
+                        m[r, wo[i]] = True  # keep every row non-empty in the prefix part too
+                rows.append(m.reshape(-1))
+            custom_mask = torch.from_numpy(np.concatenate(rows))
+            mask_indptr = torch.zeros(B + 1, dtype=torch.int64)
+            mask_indptr[1:] = torch.from_numpy(np.cumsum([r.size for r in rows]))
+            if woff is not None:
+                wko = torch.from_numpy(wo)
+        o = torch.zeros(T, HQ, D, dtype=dtype)
+        extend_attention_fwd(q, k_ext, v_ext, o, kb, vb, qo_indptr, kv_indptr, kv_indices, custom_mask,
+                             True, mask_indptr, int(ext.max()), 1.0, 1.0, sm_scale=1.0 / D**0.5,
+                             skip_prefix_custom_mask=bool(skipm) if skipm is not None else True,
+                             sliding_window_size=window, window_kv_offsets=wko, xai_temperature_len=xai)
+        c = dict(q=q, k_ext=k_ext, v_ext=v_ext, kb=kb, vb=vb, qo_indptr=qo_indptr, kv_indptr=kv_indptr,
+                 kv_indices=kv_indices, sm_scale=1.0 / D**0.5, window=window, xai=xai,
+                 skip_prefix_mask=-1 if skipm is None else int(skipm), o=o)
+        if custom_mask is not None:
+            c["custom_mask"] = custom_mask.to(torch.uint8)
+            c["mask_indptr"] = mask_indptr
+        if wko is not None:
+            c["window_kv_offsets"] = wko
+        for k, v in c.items():
+            flat[f"{name}.{k}"] = bits(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+    save("extend_mask.npz", **flat)
+
+
+def f10():
+    """F10 decode with the xai temperature (grouped and MHA stage-1 kernels) -> decode_xai.npz."""
+    torch.manual_seed(3)
+    dtype = torch.float16
+    rng = np.random.default_rng(5)
+    flat = {}
+    for name, HQ, HKV, D, lens, xai in [("gqa", 8, 2, 128, [5, 40, 200, 17], 16), ("mha", 4, 4, 64, [100, 3], 8)]:
+        lens = np.array(lens, dtype=np.int32)
+        B = len(lens)
+        pool = int(lens.sum()) + 5
+        kb = torch.randn(pool, HKV, D).to(dtype)
+        vb = torch.randn(pool, HKV, D).to(dtype)
+        q = torch.randn(B, HQ, D).to(dtype)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.from_numpy(np.cumsum(lens))
+        kv_indices = torch.from_numpy(rng.permutation(pool - 1)[: int(lens.sum())] + 1).to(torch.int64)
+        S = 4
+        nsplit = torch.full((B,), 2, dtype=torch.int32)
+        o = torch.zeros(B, HQ, D, dtype=dtype)
+        al = torch.zeros(B, HQ, S, D, dtype=torch.float32)
+        lse = torch.zeros(B, HQ, S, dtype=torch.float32)
+        decode_attention_fwd(q, kb, vb, o, kv_indptr, kv_indices, al, lse, nsplit, S, 1.0 / D**0.5, 1.0, 1.0,
+                             xai_temperature_len=xai)
+        c = dict(q=q, kb=kb, vb=vb, kv_indptr=kv_indptr, kv_indices=kv_indices, nsplit=nsplit, max_splits=S,
+                 sm_scale=1.0 / D**0.5, xai=xai, o=o)
+        for k, v in c.items():
+            flat[f"{name}.{k}"] = bits(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+    save("decode_xai.npz", **flat)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10"]
     for w in which:
         globals()[w]()

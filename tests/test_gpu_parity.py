@@ -614,3 +614,89 @@ def test_torch_custom_ops_match_direct_calls_and_capture(ops, golden_dir):
                                          int(np.diff(e["qo_indptr"]).max()), 1.0, 1.0,
                                          float(e["sm_scale"]), float(e["logit_cap"]))
     assert torch.equal(oe, oe_ref)
+
+
+def test_extend_tree_mask_window_xai_golden(ops, golden_dir):
+    """F9 (reference Triton kernel, fp16): speculative tree masks with / without the prefix part,
+    sliding window + window_kv_offsets, xai temperature.  D = 128 runs the MFMA kernel (fast prefix
+    tiles, masked boundary path), D = 64 the generic kernel."""
+    cases = _cases(np.load(os.path.join(golden_dir, "extend_mask.npz")))
+    for name, c in cases.items():
+        q, ke, ve, kb, vb = (_t(c[k]) for k in ("q", "k_ext", "v_ext", "kb", "vb"))
+        o = torch.zeros_like(q)
+        cm = _t(c["custom_mask"]) if "custom_mask" in c else None
+        mi = _t(c["mask_indptr"]) if "mask_indptr" in c else None
+        wo = _t(c["window_kv_offsets"]) if "window_kv_offsets" in c else None
+        skipm = int(c["skip_prefix_mask"])
+        ops.extend_attention_fwd(q, ke, ve, o, kb, vb, _t(c["qo_indptr"]), _t(c["kv_indptr"]), _t(c["kv_indices"]),
+                                 cm, True, mi, int(np.diff(c["qo_indptr"]).max()), 1.0, 1.0,
+                                 sm_scale=float(c["sm_scale"]), skip_prefix_custom_mask=(skipm != 0),
+                                 sliding_window_size=int(c["window"]), window_kv_offsets=wo,
+                                 xai_temperature_len=int(c["xai"]))
+        got = _np(o).astype(np.float64)
+        want = c["o"].astype(np.float64)
+        ok = np.isfinite(want).all(axis=-1)  # rows that see nothing: 0/0 in the reference
+        assert np.abs(got[ok] - want[ok]).max() <= 1e-2, (name, "vs triton golden")
+        ref = orc.extend_attention(
+            c["q"], c["k_ext"], c["v_ext"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"],
+            is_causal=True, sm_scale=float(c["sm_scale"]), sliding_window_size=int(c["window"]),
+            custom_mask=c.get("custom_mask"), mask_indptr=c.get("mask_indptr"),
+            skip_prefix_custom_mask=(skipm != 0), window_kv_offsets=c.get("window_kv_offsets"),
+            xai_temperature_len=int(c["xai"]))
+        assert np.abs(got[ok] - ref[ok]).max() <= 3e-3, (name, np.abs(got[ok] - ref[ok]).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_extend_tree_mask_long_prefix_vs_oracle(ops, dtype):
+    """TARGET_VERIFY shape: long cached prefixes (fast unmasked tiles) + a few draft tokens under a tree
+    mask, bs 5, GQA, page 16."""
+    rng = np.random.default_rng(23)
+    hq, hkv, d, nd = 8, 2, 128, 7
+    prefix = np.array([700, 64, 1, 333, 128], dtype=np.int64)
+    bs = len(prefix)
+    pool = int(prefix.sum()) + 40
+    g = torch.Generator().manual_seed(9)
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    T_ = bs * nd
+    q = torch.randn(T_, hq, d, generator=g).to(dtype)
+    ke = torch.randn(T_, hkv, d, generator=g).to(dtype)
+    ve = torch.randn(T_, hkv, d, generator=g).to(dtype)
+    kv_indptr = np.concatenate([[0], np.cumsum(prefix)]).astype(np.int32)
+    kv_indices = (rng.permutation(pool - 1)[: int(prefix.sum())] + 1).astype(np.int64)
+    qo = (np.arange(bs + 1) * nd).astype(np.int64)
+    rows = []
+    for i in range(bs):
+        m = np.ones((nd, int(prefix[i]) + nd), dtype=bool)
+        tri = np.tril(rng.random((nd, nd)) < 0.6)
+        np.fill_diagonal(tri, True)
+        m[:, int(prefix[i]):] = tri
+        rows.append(m.reshape(-1))
+    cm = np.concatenate(rows).astype(np.uint8)
+    mi = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
+    sm = d ** -0.5
+    want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
+                                is_causal=True, sm_scale=sm, custom_mask=cm, mask_indptr=mi)
+    o = torch.zeros_like(q, device=DEV)
+    ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo), _t(kv_indptr),
+                             _t(kv_indices), _t(cm).bool(), True, _t(mi), nd, 1.0, 1.0, sm_scale=sm)
+    tol = 3e-3 if dtype == torch.float16 else 1e-2
+    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
+    assert err <= tol, err
+
+
+def test_decode_xai_temperature_golden(ops, golden_dir):
+    cases = _cases(np.load(os.path.join(golden_dir, "decode_xai.npz")))
+    for name, c in cases.items():
+        q, kb, vb = _t(c["q"]), _t(c["kb"]), _t(c["vb"])
+        bs, hq, d = q.shape
+        S = int(c["max_splits"])
+        al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
+        lse = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+        o = torch.zeros_like(q)
+        ops.decode_attention_fwd(q, kb, vb, o, _t(c["kv_indptr"]), _t(c["kv_indices"]), al, lse, _t(c["nsplit"]), S,
+                                 float(c["sm_scale"]), 1.0, 1.0, xai_temperature_len=int(c["xai"]))
+        assert np.abs(_np(o).astype(np.float64) - c["o"].astype(np.float64)).max() <= 1e-2, name
+        want = orc.decode_attention(c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"], float(c["sm_scale"]),
+                                    xai_temperature_len=int(c["xai"]))
+        assert np.abs(_np(o).astype(np.float64) - want).max() <= 2e-3, name

@@ -249,3 +249,41 @@ def test_fp8_e4m3fn_codec_matches_torch_cast():
     want = xb.clone().div_(0.37).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
     got = orc.quantize_kv_fp8(xb.float().numpy(), 0.37, True)
     assert np.array_equal(want, got)
+
+
+def test_extend_mask_window_xai_golden(golden_dir):
+    """F9: tree (custom) masks with / without the prefix part, sliding window + window_kv_offsets and
+    the xai temperature, produced by the reference's Triton extend kernel (fp16, interpreter)."""
+    z = np.load(os.path.join(golden_dir, "extend_mask.npz"))
+    cases = {}
+    for key in z.files:
+        c, f = key.split(".", 1)
+        cases.setdefault(c, {})[f] = z[key]
+    assert set(cases) == {"tree", "tree_prefix", "tree_swa", "xai", "swa"}
+    for name, c in cases.items():
+        skipm = int(c["skip_prefix_mask"])
+        got = orc.extend_attention(
+            c["q"], c["k_ext"], c["v_ext"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"],
+            is_causal=True, sm_scale=float(c["sm_scale"]), sliding_window_size=int(c["window"]),
+            custom_mask=c.get("custom_mask"), mask_indptr=c.get("mask_indptr"),
+            skip_prefix_custom_mask=(skipm != 0), window_kv_offsets=c.get("window_kv_offsets"),
+            xai_temperature_len=int(c["xai"]))
+        want = c["o"].astype(np.float64)
+        ok = np.isfinite(want).all(axis=-1)  # rows that see nothing are 0/0 in the reference
+        assert ok.mean() > 0.8, name
+        assert np.abs(got[ok] - want[ok]).max() <= 2e-3, (name, np.abs(got[ok] - want[ok]).max())
+
+
+def test_decode_xai_temperature_golden(golden_dir):
+    """F10: Grok's xai temperature in the reference's decode kernels (grouped + MHA, fp16)."""
+    z = np.load(os.path.join(golden_dir, "decode_xai.npz"))
+    cases = {}
+    for key in z.files:
+        c, f = key.split(".", 1)
+        cases.setdefault(c, {})[f] = z[key]
+    for name, c in cases.items():
+        got = orc.decode_attention(c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"], float(c["sm_scale"]),
+                                   xai_temperature_len=int(c["xai"]))
+        assert np.abs(got - c["o"].astype(np.float64)).max() <= 2e-3, name
+        off = orc.decode_attention(c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"], float(c["sm_scale"]))
+        assert np.abs(off - c["o"].astype(np.float64)).max() > 1e-2, "the case must exercise the factor"
