@@ -46,6 +46,14 @@ class ForwardMetadata:
     kv_indices: Optional[torch.Tensor]
     qo_indptr: Optional[torch.Tensor]
     max_kv_splits: int = 1
+    # speculative decoding (TARGET_VERIFY / DRAFT_EXTEND_V2): the draft tree's mask
+    custom_mask: Optional[torch.Tensor] = None
+    mask_indptr: Optional[torch.Tensor] = None
+    # sliding-window layers: the last min(len, W) tokens of every request
+    window_kv_indptr: Optional[torch.Tensor] = None
+    window_kv_indices: Optional[torch.Tensor] = None
+    window_num_kv_splits: Optional[torch.Tensor] = None
+    window_kv_offsets: Optional[torch.Tensor] = None
 
 
 def host_num_kv_splits(seq_lens: np.ndarray, num_head: int, num_kv_head: int, max_kv_splits: int,
@@ -101,6 +109,14 @@ class HipRadixAttnBackend:
         max_bs = self.req_to_token_pool.size
         self.kv_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
         self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int64, device=self.device)
+        self.mask_indptr = torch.zeros((max_bs + 1,), dtype=torch.int64, device=self.device)
+        # hybrid sliding-window models (triton_backend.py:259-276): a second set of window indices
+        self.sliding_window_size = getattr(model_runner, "sliding_window_size", None)
+        if self.sliding_window_size is not None and self.sliding_window_size > 0:
+            self.window_kv_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
+        else:
+            self.sliding_window_size, self.window_kv_indptr = None, None
+        self.num_draft_tokens = getattr(sa, "speculative_num_draft_tokens", None)
         self.forward_metadata: Optional[ForwardMetadata] = None
         self._scratch_logits = None
         self._scratch_lse = None
@@ -134,8 +150,25 @@ class HipRadixAttnBackend:
             return
         if mode.is_decode():
             self.forward_metadata = self._decode_metadata(forward_batch, bs, in_capture)
+        elif mode.is_target_verify():
+            self.forward_metadata = self._target_verify_metadata(forward_batch, bs)
+        elif mode.is_draft_extend_v2():
+            self.forward_metadata = self._draft_extend_metadata(forward_batch, bs)
         else:
             self.forward_metadata = self._extend_metadata(forward_batch, bs)
+
+    # ------------------------------------------------------------------ sliding window
+    def _window(self, lens: torch.Tensor, req_pool_indices: torch.Tensor, bs: int):
+        """update_sliding_window_buffer (triton_backend.py:2043-2110): the last min(len, W) slots of every
+        request -> (window_kv_indptr, window_kv_indices, window_kv_lens, window_kv_offsets)."""
+        w = self.sliding_window_size
+        window_lens = torch.clamp(lens, max=w)
+        start = (lens - window_lens).to(torch.int32)
+        total = min(bs * w, bs * self.max_context_len)
+        kv_indices = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+        kv_indptr = ops.build_kv_indices(self.req_to_token, req_pool_indices, window_lens,
+                                         self.window_kv_indptr, kv_indices, start)
+        return kv_indptr, kv_indices, window_lens, start
 
     def _decode_metadata(self, fb: ForwardBatch, bs: int, in_capture: bool) -> ForwardMetadata:
         use_graph_bufs = self._graph is not None and (in_capture or self._graph.get("active"))
@@ -155,8 +188,16 @@ class HipRadixAttnBackend:
                 kv_indices = torch.empty(total, dtype=torch.int64, device=self.device)
             kv_indptr = ops.build_kv_indices(self.req_to_token, fb.req_pool_indices, fb.seq_lens,
                                              self.kv_indptr, kv_indices)
+        win = {}
+        if self.sliding_window_size is not None:
+            wp, wi, wl, _ = self._window(fb.seq_lens, fb.req_pool_indices, bs)
+            wsplits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+            ops.get_num_kv_splits(wsplits, wl, self.num_head, self.num_kv_head, self.max_kv_splits,
+                                  self.device_core_count)
+            win = dict(window_kv_indptr=wp, window_kv_indices=wi, window_num_kv_splits=wsplits)
+            splits_needed = splits_needed or self.max_kv_splits > 1  # window launch uses the scratch too
         if not splits_needed:
-            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1)
+            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1, **win)
         if use_graph_bufs:
             num_kv_splits = self._graph["num_kv_splits"][:bs]
             attn_logits, attn_lse = self._graph["attn_logits"][:bs], self._graph["attn_lse"][:bs]
@@ -166,7 +207,7 @@ class HipRadixAttnBackend:
         ops.get_num_kv_splits(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head,
                               self.max_kv_splits, self.device_core_count)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices,
-                               None, self.max_kv_splits)
+                               None, self.max_kv_splits, **win)
 
     def _extend_metadata(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
         # prefix-only kv indices + qo_indptr (triton_backend.py:869-924)
@@ -183,7 +224,44 @@ class HipRadixAttnBackend:
             max_extend_len = max(fb.extend_seq_lens_cpu)
         else:
             max_extend_len = int(fb.extend_seq_lens.max())
-        return ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr)
+        win = {}
+        if self.sliding_window_size is not None:  # window over the cached prefix (triton_backend.py:891-905)
+            wp, wi, _, wo = self._window(fb.extend_prefix_lens, fb.req_pool_indices, bs)
+            win = dict(window_kv_indptr=wp, window_kv_indices=wi, window_kv_offsets=wo)
+        return ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr, **win)
+
+    def _target_verify_metadata(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
+        """TARGET_VERIFY (triton_backend.py:801-866): every request extends by its draft tokens over its
+        WHOLE cached sequence, under the draft tree's mask."""
+        spec = fb.spec_info
+        nd = self.num_draft_tokens
+        if spec is not None and getattr(spec, "draft_token_num", None) is not None:
+            nd = int(spec.draft_token_num)
+        if not nd:
+            raise ValueError("TARGET_VERIFY needs spec_info.draft_token_num or server_args.speculative_num_draft_tokens")
+        qo_indptr = torch.arange(0, (1 + bs) * nd, step=nd, dtype=torch.int64, device=self.device)
+        total = fb.seq_lens_sum if fb.seq_lens_sum is not None else bs * self.max_context_len
+        kv_indices = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+        kv_indptr = ops.build_kv_indices(self.req_to_token, fb.req_pool_indices, fb.seq_lens, self.kv_indptr,
+                                         kv_indices)
+        win = {}
+        if self.sliding_window_size is not None:
+            wp, wi, _, wo = self._window(fb.seq_lens, fb.req_pool_indices, bs)
+            win = dict(window_kv_indptr=wp, window_kv_indices=wi, window_kv_offsets=wo)
+        mask_indptr = self.mask_indptr[: bs + 1]
+        mask_indptr[1:] = torch.cumsum(nd * (fb.seq_lens[:bs].to(torch.int64) + nd), dim=0)
+        return ForwardMetadata(None, None, nd, None, kv_indptr, kv_indices, qo_indptr,
+                               custom_mask=spec.custom_mask, mask_indptr=mask_indptr, **win)
+
+    def _draft_extend_metadata(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
+        """DRAFT_EXTEND_V2 (triton_backend.py:907-924): spec_info produces the prefill arguments."""
+        kv_indices, kv_indptr, qo_indptr, custom_mask = fb.spec_info.generate_attn_arg_prefill(
+            fb.req_pool_indices, fb.seq_lens, None, self.req_to_token)
+        max_extend_len = int(getattr(fb.spec_info, "num_tokens_per_req", 0)) or int(
+            (qo_indptr[1:] - qo_indptr[:-1]).max())
+        return ForwardMetadata(None, None, max_extend_len, None, kv_indptr.to(torch.int32), kv_indices,
+                               qo_indptr, custom_mask=custom_mask,
+                               mask_indptr=self.mask_indptr[: bs + 1] if custom_mask is not None else None)
 
     # ------------------------------------------------------------------ graph support
     def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int):
@@ -242,8 +320,16 @@ class HipRadixAttnBackend:
                 k_buf.shape[1] if hnd else k_buf.shape[-2], layer.qk_head_dim, layer.v_head_dim,
                 layer.scaling, k_descale, v_descale, layer.logit_cap,
                 kv_layout=ops.kv_layout_hnd(k_buf, v_buf) if hnd else None, q_dtype=q.dtype)
+            ln.p.xai_temperature_len = max(0, int(getattr(layer, "xai_temperature_len", -1) or 0))
+        swa = (layer.sliding_window_size is not None and layer.sliding_window_size > -1
+               and md.window_kv_indptr is not None)
         if ln.version != self._md_version:
-            if self.decode_index_mode == "indices":
+            if swa:  # sliding-window layer: the window's own indices and split schedule (triton_backend.py:1770-1781)
+                ln.set_metadata(self._md_version, q3.shape[0], kv_indptr=md.window_kv_indptr,
+                                kv_indices=md.window_kv_indices, num_kv_splits=md.window_num_kv_splits,
+                                max_kv_splits=md.max_kv_splits if md.attn_logits is not None else 1,
+                                attn_logits=md.attn_logits, attn_lse=md.attn_lse)
+            elif self.decode_index_mode == "indices":
                 ln.set_metadata(self._md_version, q3.shape[0], kv_indptr=md.kv_indptr,
                                 kv_indices=md.kv_indices, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
@@ -274,16 +360,24 @@ class HipRadixAttnBackend:
         causal = not (layer.is_cross_attention or layer.attn_type.value == "encoder_only")
         k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
         lay = ops.kv_layout_hnd(k_buf, v_buf) if getattr(self.token_to_kv_pool, "use_hnd", False) else None
-        window = layer.sliding_window_size if (layer.sliding_window_size is not None
-                                               and layer.sliding_window_size > -1) else -1
+        # sliding-window layers read the window indices (triton_backend.py:1353-1365)
+        if (layer.sliding_window_size is not None and layer.sliding_window_size > -1
+                and md.window_kv_indptr is not None):
+            window = layer.sliding_window_size
+            kv_indptr, kv_indices, window_kv_offsets = md.window_kv_indptr, md.window_kv_indices, md.window_kv_offsets
+        else:
+            window = layer.sliding_window_size if (layer.sliding_window_size is not None
+                                                   and layer.sliding_window_size > -1) else -1
+            kv_indptr, kv_indices, window_kv_offsets = md.kv_indptr, md.kv_indices, None
         ops.extend_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
             k.view(-1, layer.tp_k_head_num, layer.qk_head_dim),
             v.view(-1, layer.tp_v_head_num, layer.v_head_dim),
             o.view(-1, layer.tp_q_head_num, layer.v_head_dim), k_buf, v_buf, md.qo_indptr,
-            md.kv_indptr, md.kv_indices, None, causal, None, md.max_extend_len, k_descale, v_descale,
-            sm_scale=layer.scaling, logit_cap=layer.logit_cap, sliding_window_size=window, sinks=sinks,
-            page_size=self.page_size, kv_layout=lay)
+            kv_indptr, kv_indices, md.custom_mask, causal, md.mask_indptr, md.max_extend_len, k_descale,
+            v_descale, sm_scale=layer.scaling, logit_cap=layer.logit_cap, sliding_window_size=window,
+            sinks=sinks, window_kv_offsets=window_kv_offsets if md.custom_mask is not None else None,
+            xai_temperature_len=layer.xai_temperature_len, page_size=self.page_size, kv_layout=lay)
         return o
 
     def support_triton(self):

@@ -15,12 +15,27 @@ class ForwardMode(IntEnum):
     DECODE = auto()
     MIXED = auto()
     IDLE = auto()
+    TARGET_VERIFY = auto()     # speculative decoding: verify the draft tree (extend under a custom mask)
+    DRAFT_EXTEND_V2 = auto()   # speculative decoding: draft model extends over the accepted tokens
 
-    def is_prefill(self):
-        return self.is_extend()
+    def is_prefill(self, include_draft_extend_v2: bool = False):
+        return self.is_extend(include_draft_extend_v2=include_draft_extend_v2)
 
-    def is_extend(self):
-        return self in (ForwardMode.EXTEND, ForwardMode.MIXED)
+    def is_extend(self, include_draft_extend_v2: bool = False):
+        return (self in (ForwardMode.EXTEND, ForwardMode.MIXED, ForwardMode.TARGET_VERIFY)
+                or (include_draft_extend_v2 and self == ForwardMode.DRAFT_EXTEND_V2))
+
+    def is_target_verify(self):
+        return self == ForwardMode.TARGET_VERIFY
+
+    def is_draft_extend_v2(self):
+        return self == ForwardMode.DRAFT_EXTEND_V2
+
+    def is_extend_without_speculative(self):
+        return self.is_extend() and not self.is_target_verify()
+
+    def is_cuda_graph(self):
+        return self in (ForwardMode.DECODE, ForwardMode.TARGET_VERIFY, ForwardMode.IDLE)
 
     def is_decode(self):
         return self == ForwardMode.DECODE

@@ -369,3 +369,128 @@ def test_hnd_pool_extend_with_prefix():
         outs.append(layer(q, k, v, fb, be))
         assert pool.check_errors() == 0
     assert torch.equal(outs[0], outs[1])
+
+
+def _swa_expected(q3, kb, vb, r2t, rows, seq_lens, prefix_lens, extend_lens, d, window, mask=None):
+    """Semantics of a sliding-window layer: the reference's window metadata (last min(prefix, W) prefix
+    tokens, triton_backend.py:2043-2110) + the in-kernel window mask (extend_attention.py:391-397,550-556)."""
+    bs = len(rows)
+    pre = np.array(prefix_lens)
+    wlen = np.minimum(pre, window)
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, np.array(rows), wlen, kv_start=pre - wlen)
+    T = int(sum(extend_lens))
+    qo = np.concatenate([[0], np.cumsum(extend_lens)]).astype(np.int64)
+    ke = np.zeros((T,) + kb.shape[1:], dtype=kb.dtype)
+    ve = np.zeros((T,) + vb.shape[1:], dtype=vb.dtype)
+    for i in range(bs):
+        sl = r2t[rows[i], prefix_lens[i]: seq_lens[i]]
+        ke[qo[i]: qo[i + 1]], ve[qo[i]: qo[i + 1]] = kb[sl], vb[sl]
+    kw = dict(custom_mask=mask[0], mask_indptr=mask[1], window_kv_offsets=pre - wlen) if mask else {}
+    return orc.extend_attention(q3, ke, ve, kb, vb, qo, kv_indptr, kv_indices, is_causal=True, sm_scale=d ** -0.5,
+                                sliding_window_size=window, **kw)
+
+
+@pytest.mark.parametrize("index_mode", ["paged", "indices"])
+def test_sliding_window_layers_decode_and_extend(index_mode):
+    """Hybrid SWA model: window metadata (window_kv_indptr / indices / num_kv_splits / offsets) is built
+    next to the full one and sliding-window layers read it (triton_backend.py:748-767,1353-1365,1770-1781)."""
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+
+    ps, hq, hkv, d, W = 16, 8, 2, 128, 48
+    hs = _Harness(ps, hq, hkv, d, torch.float16, "shuffled_pages", index_mode)
+    hs.backend.sliding_window_size = W
+    hs.backend.window_kv_indptr = torch.zeros_like(hs.backend.kv_indptr)
+    swa_layer = RadixAttention(hq, d, d ** -0.5, hkv, 0, sliding_window_size=W)
+    prefix_lens, extend_lens = (10, 100, 47, 300), (5, 70, 1, 33)
+    bs = len(prefix_lens)
+    rows = hs.r2t.alloc(bs)
+    hs.fill_prefix(rows, prefix_lens)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    seq_lens = [p + e for p, e in zip(prefix_lens, extend_lens)]
+    loc = hs.alloc_extend(rows, list(prefix_lens), seq_lens)
+    T = sum(extend_lens)
+    q, k, v = hs.rand(T, hq * d), hs.rand(T, hkv * d), hs.rand(T, hkv * d)
+    fb = ForwardBatch.for_extend(rpi, torch.tensor(seq_lens, device=DEV), loc, list(prefix_lens), list(extend_lens))
+    hs.backend.init_forward_metadata(fb)
+    assert hs.backend.forward_metadata.window_kv_indptr is not None
+    o_swa = swa_layer(q, k, v, fb, hs.backend)
+    o_full = hs.layer(q, k, v, fb, hs.backend, save_kv_cache=False)
+    kb, vb = hs.pool.get_kv_buffer(0)
+    r2t = _bits(hs.r2t.req_to_token)
+    want = _swa_expected(_bits(q.view(T, hq, d)), _bits(kb), _bits(vb), r2t, rows, seq_lens, prefix_lens,
+                         extend_lens, d, W)
+    assert np.abs(_bits(o_swa.view(T, hq, d)).astype(np.float64) - want).max() <= 3e-3
+    want_full = orc.sdpa_extend_req_to_token(_bits(q.view(T, hq, d)), _bits(kb), _bits(vb), r2t, np.array(rows),
+                                             np.array(seq_lens), np.array(prefix_lens), np.array(extend_lens),
+                                             d ** -0.5)
+    assert np.abs(_bits(o_full.view(T, hq, d)).astype(np.float64) - want_full).max() <= 3e-3
+    # ---- decode: the window layer sees the last min(seq, W) tokens
+    seq_t = torch.tensor([s + 1 for s in seq_lens], dtype=torch.int64)
+    last = torch.tensor([int(hs.r2t.req_to_token[r, s - 1]) for r, s in zip(rows, seq_lens)], dtype=torch.int64,
+                        device=DEV)
+    dloc = hs.alloc.alloc_decode(seq_t.to(DEV), seq_t, last)
+    hs.r2t.req_to_token[rpi, torch.tensor(seq_lens, device=DEV)] = dloc.to(torch.int32)
+    q1, k1, v1 = hs.rand(bs, hq * d), hs.rand(bs, hkv * d), hs.rand(bs, hkv * d)
+    fbd = ForwardBatch.for_decode(rpi, seq_t.to(DEV), dloc, seq_t)
+    hs.backend.init_forward_metadata(fbd)
+    o1 = swa_layer(q1, k1, v1, fbd, hs.backend)
+    kb, vb = hs.pool.get_kv_buffer(0)
+    sl = seq_t.numpy()
+    wl = np.minimum(sl, W)
+    kv_indptr, kv_indices = orc.build_kv_indices(_bits(hs.r2t.req_to_token), np.array(rows), wl, kv_start=sl - wl)
+    want1 = orc.decode_attention(_bits(q1.view(bs, hq, d)), _bits(kb), _bits(vb), kv_indptr, kv_indices, d ** -0.5)
+    assert np.abs(_bits(o1.view(bs, hq, d)).astype(np.float64) - want1).max() <= 3e-3
+    assert hs.pool.check_errors() == 0
+
+
+def test_target_verify_mode_with_tree_mask():
+    """TARGET_VERIFY (speculative decoding): every request extends by its draft tokens over its whole
+    cached sequence under the draft tree's mask; metadata as triton_backend.py:801-866."""
+    from sglang_amd.forward_batch import ForwardBatch, ForwardMode
+
+    ps, hq, hkv, d, nd = 16, 8, 2, 128, 5
+    hs = _Harness(ps, hq, hkv, d, torch.float16, "shuffled_pages", "paged")
+    seq_lens = (70, 16, 333)
+    bs = len(seq_lens)
+    rows = hs.r2t.alloc(bs)
+    hs.fill_prefix(rows, seq_lens)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    total = [s + nd for s in seq_lens]
+    loc = hs.alloc_extend(rows, list(seq_lens), total)
+    rng = np.random.default_rng(4)
+    masks = []
+    for s in seq_lens:
+        m = np.ones((nd, s + nd), dtype=bool)
+        tri = np.tril(rng.random((nd, nd)) < 0.5)
+        np.fill_diagonal(tri, True)
+        m[:, s:] = tri
+        masks.append(m.reshape(-1))
+    cm = np.concatenate(masks)
+
+    class Spec:
+        draft_token_num = nd
+        custom_mask = torch.from_numpy(cm).to(DEV)
+
+    T = bs * nd
+    q, k, v = hs.rand(T, hq * d), hs.rand(T, hkv * d), hs.rand(T, hkv * d)
+    seq_t = torch.tensor(seq_lens, dtype=torch.int64)
+    fb = ForwardBatch(forward_mode=ForwardMode.TARGET_VERIFY, batch_size=bs, req_pool_indices=rpi,
+                      seq_lens=seq_t.to(DEV), out_cache_loc=loc, seq_lens_sum=int(seq_t.sum()), seq_lens_cpu=seq_t,
+                      spec_info=Spec)
+    hs.backend.init_forward_metadata(fb)
+    md = hs.backend.forward_metadata
+    assert md.max_extend_len == nd and md.custom_mask is Spec.custom_mask
+    assert md.mask_indptr.tolist() == np.concatenate([[0], np.cumsum([nd * (s + nd) for s in seq_lens])]).tolist()
+    o = hs.layer(q, k, v, fb, hs.backend)
+    kb, vb = hs.pool.get_kv_buffer(0)
+    r2t = _bits(hs.r2t.req_to_token)
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, np.array(rows), np.array(seq_lens))
+    qo = (np.arange(bs + 1) * nd).astype(np.int64)
+    kbn, vbn = _bits(kb), _bits(vb)
+    ke = np.concatenate([kbn[r2t[rows[i], seq_lens[i]: total[i]]] for i in range(bs)])
+    ve = np.concatenate([vbn[r2t[rows[i], seq_lens[i]: total[i]]] for i in range(bs)])
+    mi = np.concatenate([[0], np.cumsum([m.size for m in masks])]).astype(np.int64)
+    want = orc.extend_attention(_bits(q.view(T, hq, d)), ke, ve, kbn, vbn, qo, kv_indptr, kv_indices, is_causal=True,
+                                sm_scale=d ** -0.5, custom_mask=cm, mask_indptr=mi)
+    assert np.abs(_bits(o.view(T, hq, d)).astype(np.float64) - want).max() <= 3e-3
