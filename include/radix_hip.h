@@ -215,6 +215,19 @@ typedef struct rx_extend_params {
 
 int rx_extend_attn(const rx_extend_params* p /* HOST */, void* stream);
 
+/* ---- merge of two partial attention states ----------------------------------------------------
+ * merge_state_triton (kernels/ops/attention/merge_state.py:8-96; CUDA twin
+ * kernels/aot/csrc/attention/merge_attn_states.cu): the building block of prefix-cascade / chunked
+ * prefix attention.  For every (token, head):
+ *   m = max(lse_a, lse_b); w_a = exp(lse_a - m); w_b = exp(lse_b - m)
+ *   out = (a * w_a + b * w_b) / (w_a + w_b);   out_lse = log(w_a + w_b) + m   (optional)
+ * A +inf LSE is read as -inf (an empty partial), as the reference does.  a, b, out are dense
+ * [num_tokens, num_heads, head_size] of dtype (rx_dtype), LSEs fp32 [num_tokens, num_heads];
+ * head_size is a multiple of 8.  out may alias a or b. */
+int rx_merge_state(const void* a, const float* lse_a, const void* b, const float* lse_b, void* out,
+                   float* out_lse /* or NULL */, int64_t num_tokens, int num_heads, int head_size,
+                   int dtype, void* stream);
+
 /* ---- K9: paged slot allocation -----------------------------------------------------------
  * alloc_extend_kernel / alloc_decode_kernel (kernels/ops/memory/allocator.py:16-135), called
  * by PagedTokenToKVPoolAllocator.alloc_extend / alloc_decode (allocator/paged.py:172-259).

@@ -660,6 +660,22 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
     return (o, lse) if return_lse else o
 
 
+def merge_state(a, lse_a, b, lse_b):
+    """merge_state_triton (kernels/ops/attention/merge_state.py:8-64): LSE-weighted blend of two partial
+    attention outputs; a +inf LSE is read as -inf.  Returns (out float64, out_lse float64)."""
+    a, b = to_f64(a), to_f64(b)
+    la = np.asarray(lse_a, dtype=np.float64).copy()
+    lb = np.asarray(lse_b, dtype=np.float64).copy()
+    la[la == np.inf] = -np.inf
+    lb[lb == np.inf] = -np.inf
+    m = np.maximum(la, lb)
+    with np.errstate(invalid="ignore"):
+        wa, wb = np.exp(la - m), np.exp(lb - m)
+    se = wa + wb
+    out = a * (wa / se)[..., None] + b * (wb / se)[..., None]
+    return out, np.log(se) + m
+
+
 # --------------------------------------------------------------------------
 # a14 torch-native semantics   srt/layers/attention/torch_native_backend.py:61-277
 # --------------------------------------------------------------------------

@@ -155,6 +155,39 @@ __global__ __launch_bounds__(256) void get_mla_kv_kernel(const void* __restrict_
   }
 }
 
+// merge_state: one thread = 8 consecutive columns of one (token, head)
+template <typename T>
+__global__ __launch_bounds__(256) void merge_state_kernel(const uint16_t* __restrict__ a,
+                                                          const float* __restrict__ lse_a,
+                                                          const uint16_t* __restrict__ b,
+                                                          const float* __restrict__ lse_b,
+                                                          uint16_t* __restrict__ out, float* __restrict__ out_lse,
+                                                          int64_t rows, int head_size) {
+  const int per_row = head_size >> 3;
+  const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t row = gid / per_row;
+  if (row >= rows) return;
+  const int c = static_cast<int>(gid % per_row) * 8;
+  float la = lse_a[row], lb = lse_b[row];
+  la = (la == INFINITY) ? -INFINITY : la;  // merge_state.py:28-29
+  lb = (lb == INFINITY) ? -INFINITY : lb;
+  const float m = fmaxf(la, lb);
+  const float wa = __expf(la - m), wb = __expf(lb - m);
+  const float se = wa + wb;
+  const float sa = wa / se, sb = wb / se;
+  const u32x4 va = *reinterpret_cast<const u32x4*>(a + row * head_size + c);
+  const u32x4 vb = *reinterpret_cast<const u32x4*>(b + row * head_size + c);
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a0 = T::to_f32(static_cast<uint16_t>(va[j] & 0xffffu)), a1 = T::to_f32(static_cast<uint16_t>(va[j] >> 16));
+    const float b0 = T::to_f32(static_cast<uint16_t>(vb[j] & 0xffffu)), b1 = T::to_f32(static_cast<uint16_t>(vb[j] >> 16));
+    o[j] = pack2<T>(a0 * sa + b0 * sb, a1 * sa + b1 * sb);
+  }
+  *reinterpret_cast<u32x4*>(out + row * head_size + c) = o;
+  if (out_lse && c == 0) out_lse[row] = __logf(se) + m;
+}
+
 // ---------------------------------------------------------------------------------------
 // K2  kv_indptr scan + ragged gather of req_to_token rows.
 // Reference: create_flashinfer_kv_indices_triton (kv_indices.py:8-46), grid (bs,), 512-wide.
@@ -513,6 +546,26 @@ int rx_get_mla_kv(const void* kv_buf, int64_t row_stride, int kv_fp8, const void
   }
 #undef RX_GM
   return check_launch("rx_get_mla_kv");
+}
+
+int rx_merge_state(const void* a, const float* lse_a, const void* b, const float* lse_b, void* out,
+                   float* out_lse, int64_t num_tokens, int num_heads, int head_size, int dtype, void* stream) {
+  RX_REQUIRE(num_tokens >= 0 && num_heads > 0, "rx_merge_state: bad sizes");
+  if (num_tokens == 0) return RX_OK;
+  RX_REQUIRE(a && b && lse_a && lse_b && out, "rx_merge_state: null pointer");
+  RX_REQUIRE(dtype == RX_BF16 || dtype == RX_F16, "rx_merge_state: dtype %d", dtype);
+  RX_REQUIRE(head_size > 0 && head_size % 8 == 0, "rx_merge_state: head_size %d must be a multiple of 8", head_size);
+  RX_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "rx_merge_state: 16-byte alignment");
+  const int64_t rows = num_tokens * num_heads;
+  const unsigned grid = static_cast<unsigned>((rows * (head_size >> 3) + 255) / 256);
+  auto s = static_cast<hipStream_t>(stream);
+  if (dtype == RX_BF16)
+    hipLaunchKernelGGL(merge_state_kernel<BF16>, dim3(grid), dim3(256), 0, s, (const uint16_t*)a, lse_a,
+                       (const uint16_t*)b, lse_b, (uint16_t*)out, out_lse, rows, head_size);
+  else
+    hipLaunchKernelGGL(merge_state_kernel<F16>, dim3(grid), dim3(256), 0, s, (const uint16_t*)a, lse_a,
+                       (const uint16_t*)b, lse_b, (uint16_t*)out, out_lse, rows, head_size);
+  return check_launch("rx_merge_state");
 }
 
 int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,

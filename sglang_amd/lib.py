@@ -84,6 +84,7 @@ PROTOTYPES = {
     "rx_ar_init": (c_int, [C.POINTER(c_void_p), c_int, c_int, C.POINTER(c_void_p), c_int64, c_void_p]),
     "rx_allreduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rx_ar_destroy": (c_int, [c_void_p]),
+    "rx_merge_state": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rx_get_mla_kv": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p,
                               c_void_p, c_int, c_int64, c_void_p, c_void_p]),
     "rx_store_kv_fp8": (c_int, [c_void_p, c_void_p, C.POINTER(RxKvLayout), c_void_p, c_int64, c_int, c_int, c_int,

@@ -508,6 +508,37 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
 
 
 # --------------------------------------------------------------------------------------
+# merge_state                kernels/ops/attention/merge_state.py:66-96
+# --------------------------------------------------------------------------------------
+def merge_state(prefix_output: torch.Tensor, prefix_lse: torch.Tensor, suffix_output: torch.Tensor,
+                suffix_lse: torch.Tensor, output: Optional[torch.Tensor] = None,
+                output_lse: Optional[torch.Tensor] = None):
+    """Same contract as merge_state_triton: returns (output, output_lse); buffers are created when not
+    given.  [T, H, D] 16-bit outputs, fp32 [T, H] LSEs."""
+    _require_cuda(prefix_output, prefix_lse, suffix_output, suffix_lse, output, output_lse)
+    if prefix_output.shape != suffix_output.shape or prefix_output.dim() != 3:
+        raise ValueError("merge_state: outputs must both be [num_tokens, num_heads, head_size]")
+    if prefix_output.dtype != suffix_output.dtype:
+        raise TypeError("merge_state: output dtypes differ")
+    for n, t in (("prefix_lse", prefix_lse), ("suffix_lse", suffix_lse)):
+        if t.dtype != torch.float32 or tuple(t.shape) != tuple(prefix_output.shape[:2]):
+            raise TypeError(f"merge_state: {n} must be float32 [num_tokens, num_heads]")
+    a, b = prefix_output.contiguous(), suffix_output.contiguous()
+    la, lb = prefix_lse.contiguous(), suffix_lse.contiguous()
+    if output is None:
+        output = torch.empty_like(a)
+    if output_lse is None:
+        output_lse = torch.empty_like(la)
+    if not output.is_contiguous() or not output_lse.is_contiguous():
+        raise ValueError("merge_state: output buffers must be contiguous")
+    T, H, D = a.shape
+    st = _L.load().rx_merge_state(_ptr(a), _ptr(la), _ptr(b), _ptr(lb), _ptr(output), _ptr(output_lse), T, H, D,
+                                  _rx_dtype(a), _stream(a))
+    _L.check(st, "rx_merge_state")
+    return output, output_lse
+
+
+# --------------------------------------------------------------------------------------
 # K9  paged allocation kernels   kernels/ops/memory/allocator.py:16-135
 # --------------------------------------------------------------------------------------
 def alloc_extend(prefix_lens, seq_lens, last_loc, free_pages, out_indices, page_size: int):

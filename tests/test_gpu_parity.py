@@ -700,3 +700,51 @@ def test_decode_xai_temperature_golden(ops, golden_dir):
         want = orc.decode_attention(c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"], float(c["sm_scale"]),
                                     xai_temperature_len=int(c["xai"]))
         assert np.abs(_np(o).astype(np.float64) - want).max() <= 2e-3, name
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_merge_state_and_prefix_cascade(ops, dtype):
+    """rx_merge_state vs the oracle, then the cascade it exists for: extend over (prefix only) and
+    (new tokens only) merged by LSE equals the one-pass extend (merge_state.py docstring use)."""
+    g = torch.Generator().manual_seed(2)
+    T, H, D = 37, 6, 128
+    a = torch.randn(T, H, D, generator=g).to(dtype).to(DEV)
+    b = torch.randn(T, H, D, generator=g).to(dtype).to(DEV)
+    la = torch.randn(T, H, generator=g).to(DEV) * 3
+    lb = torch.randn(T, H, generator=g).to(DEV) * 3
+    la[0, 0], lb[1, 1] = float("inf"), float("-inf")
+    out, lse = ops.merge_state(a, la, b, lb)
+    want, want_lse = orc.merge_state(_np(a), la.cpu().numpy(), _np(b), lb.cpu().numpy())
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    assert np.abs(orc.to_f64(_np(out)) - want).max() <= tol
+    np.testing.assert_allclose(lse.cpu().numpy(), want_lse, atol=1e-5, rtol=1e-5)
+
+    # cascade
+    rng = np.random.default_rng(1)
+    hq, hkv, d = 8, 2, 128
+    prefix = np.array([300, 17, 64], dtype=np.int64)
+    ext = np.array([33, 64, 5], dtype=np.int64)
+    pool = int(prefix.sum()) + 9
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype).to(DEV)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype).to(DEV)
+    Tq = int(ext.sum())
+    q = torch.randn(Tq, hq, d, generator=g).to(dtype).to(DEV)
+    ke = torch.randn(Tq, hkv, d, generator=g).to(dtype).to(DEV)
+    ve = torch.randn(Tq, hkv, d, generator=g).to(dtype).to(DEV)
+    kv_indptr = _t(np.concatenate([[0], np.cumsum(prefix)]).astype(np.int32))
+    kv_indices = _t((rng.permutation(pool - 1)[: int(prefix.sum())] + 1).astype(np.int64))
+    qo = _t(np.concatenate([[0], np.cumsum(ext)]).astype(np.int64))
+
+    def run(**kw):
+        o = torch.zeros_like(q)
+        l = torch.zeros(Tq, hq, dtype=torch.float32, device=DEV)
+        ops.extend_attention_fwd(q, ke, ve, o, kb, vb, qo, kv_indptr, kv_indices, None, True, None, int(ext.max()),
+                                 1.0, 1.0, sm_scale=d ** -0.5, lse_extend=l, **kw)
+        return o, l
+
+    o_full, l_full = run()
+    o_p, l_p = run(skip_extend=True)
+    o_e, l_e = run(skip_prefix=True)
+    o_m, l_m = ops.merge_state(o_p, l_p, o_e, l_e)
+    assert (o_m.float() - o_full.float()).abs().max().item() <= (4e-3 if dtype == torch.float16 else 3e-2)
+    np.testing.assert_allclose(l_m.cpu().numpy(), l_full.cpu().numpy(), atol=2e-3, rtol=1e-4)
