@@ -215,6 +215,22 @@ typedef struct rx_extend_params {
 
 int rx_extend_attn(const rx_extend_params* p /* HOST */, void* stream);
 
+/* ---- fused rotary embedding + KV store ---------------------------------------------------------
+ * q [n, Hq, D] and k [n, Hkv, D] are rotated IN PLACE (positions int64[n], cos_sin_cache fp32
+ * [max_pos, rotary_dim] = [cos(rot/2) | sin(rot/2)], neox or gptj pairing, fp32 math, one rounding) and,
+ * when lay != NULL, the rotated k rows and the v rows are written to the pool at loc in the same launch
+ * (16-bit pool, or kv_fp8 = 1 with the quant-on-write of rx_store_kv_fp8).  Replaces
+ * RotaryEmbedding.forward (srt/layers/rotary_embedding/base.py) + set_kv_buffer
+ * (srt/mem_cache/memory_pool.py:2305-2381); the reference's fused forms are
+ * kernels/ops/kvcache/rope_cache.py:101-… and kernels/jit/csrc/elementwise/rope.cuh.  Strides in elements. */
+int rx_rope_store_kv(void* q, void* k, const void* v, int64_t q_stride_t, int64_t q_stride_h,
+                     int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
+                     int64_t n, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim,
+                     int rotary_dim, const int64_t* positions, const float* cos_sin_cache,
+                     int64_t cos_sin_stride, int is_neox, const rx_kv_layout* lay /* HOST, or NULL */,
+                     const void* loc, int loc_is_i64, int64_t size_limit, int64_t skip_index, float k_scale,
+                     float v_scale, int dtype, int32_t* err_flag, void* stream);
+
 /* ---- merge of two partial attention states ----------------------------------------------------
  * merge_state_triton (kernels/ops/attention/merge_state.py:8-96; CUDA twin
  * kernels/aot/csrc/attention/merge_attn_states.cu): the building block of prefix-cascade / chunked

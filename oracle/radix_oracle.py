@@ -660,6 +660,24 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
     return (o, lse) if return_lse else o
 
 
+def rope(x, positions, cos_sin_cache, is_neox, rotary_dim=None):
+    """RotaryEmbedding._apply_rotary_emb semantics (srt/layers/rotary_embedding: cos_sin_cache[pos] =
+    [cos(rot/2) | sin(rot/2)]; neox pairs (i, i+rot/2), gptj pairs (2i, 2i+1)) in float64.
+    x [n, H, D] -> float64 [n, H, D]; columns >= rotary_dim pass through."""
+    x = to_f64(x).copy()
+    cs = np.asarray(cos_sin_cache, dtype=np.float64)[np.asarray(positions)]
+    rot = int(rotary_dim or cs.shape[-1])
+    half = rot // 2
+    cos, sin = cs[:, None, :half], cs[:, None, half:rot]
+    if is_neox:
+        x0, x1 = x[..., :half].copy(), x[..., half:rot].copy()
+        x[..., :half], x[..., half:rot] = x0 * cos - x1 * sin, x1 * cos + x0 * sin
+    else:
+        x0, x1 = x[..., 0:rot:2].copy(), x[..., 1:rot:2].copy()
+        x[..., 0:rot:2], x[..., 1:rot:2] = x0 * cos - x1 * sin, x1 * cos + x0 * sin
+    return x
+
+
 def merge_state(a, lse_a, b, lse_b):
     """merge_state_triton (kernels/ops/attention/merge_state.py:8-64): LSE-weighted blend of two partial
     attention outputs; a +inf LSE is read as -inf.  Returns (out float64, out_lse float64)."""

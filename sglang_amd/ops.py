@@ -508,6 +508,39 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
 
 
 # --------------------------------------------------------------------------------------
+# fused RoPE + KV store      RotaryEmbedding.forward + set_kv_buffer; kernels/ops/kvcache/rope_cache.py
+# --------------------------------------------------------------------------------------
+def rope_store_kv(q, k, v, positions, cos_sin_cache, is_neox: bool, *, rotary_dim: Optional[int] = None,
+                  layout: Optional["_L.RxKvLayout"] = None, loc=None, size_limit: int = 0,
+                  k_scale: float = 1.0, v_scale: float = 1.0, reserved_skip_index: int = 0, err_flag=None):
+    """Rotate q [n,Hq,D] and k [n,Hkv,D] in place; with ``layout`` + ``loc`` also write the rotated k and
+    v [n,Hkv,Dv] into the pool (16-bit or fp8) in the same launch.  cos_sin_cache: fp32 [max_pos, rot]."""
+    _require_cuda(q, k, v, positions, cos_sin_cache, loc)
+    if q.dim() != 3 or k.dim() != 3 or q.stride(-1) != 1 or k.stride(-1) != 1:
+        raise ValueError("rope_store_kv: q / k must be [n, heads, dim], contiguous in dim")
+    if cos_sin_cache.dtype != torch.float32 or cos_sin_cache.stride(-1) != 1:
+        raise TypeError("rope_store_kv: cos_sin_cache must be float32 [max_pos, rotary_dim]")
+    pos = positions if positions.dtype == torch.int64 else positions.to(torch.int64)
+    rot = int(rotary_dim or cos_sin_cache.shape[-1])
+    lay_ref, locp, l64 = None, None, 0
+    dv = 0
+    vs_t = vs_h = 0
+    if layout is not None:
+        if v is None or loc is None:
+            raise ValueError("rope_store_kv: the pool store needs v and loc")
+        if v.dim() != 3 or v.stride(-1) != 1:
+            raise ValueError("rope_store_kv: v must be [n, Hkv, Dv], contiguous in Dv")
+        lay_ref, locp, l64 = C.byref(layout), _ptr(loc.contiguous()), _is64(loc, "loc")
+        dv, vs_t, vs_h = v.shape[-1], v.stride(0), v.stride(1)
+    st = _L.load().rx_rope_store_kv(
+        _ptr(q), _ptr(k), _ptr(v), q.stride(0), q.stride(1), k.stride(0), k.stride(1), vs_t, vs_h, q.shape[0],
+        q.shape[1], k.shape[1], q.shape[2], dv, rot, _ptr(pos), _ptr(cos_sin_cache), cos_sin_cache.stride(0),
+        int(bool(is_neox)), lay_ref, locp, l64, size_limit, reserved_skip_index, float(k_scale), float(v_scale),
+        _rx_dtype(q), _ptr(err_flag), _stream(q))
+    _L.check(st, "rx_rope_store_kv")
+
+
+# --------------------------------------------------------------------------------------
 # merge_state                kernels/ops/attention/merge_state.py:66-96
 # --------------------------------------------------------------------------------------
 def merge_state(prefix_output: torch.Tensor, prefix_lse: torch.Tensor, suffix_output: torch.Tensor,

@@ -17,6 +17,7 @@ Fixture families:
   F7 radix tree op sequences (reference RadixCache, recording allocator) -> radix_sequences.json
   F8 bf16 decode/extend from the compiled reference C++ CPU kernels -> cpu_native.npz
   F10 decode with the xai temperature -> decode_xai.npz
+  F11 rotary embedding (torch-native apply_rotary_emb) -> rope.npz
   F9 extend with custom (tree) masks, sliding window (+ window_kv_offsets), xai temperature -> extend_mask.npz
 """
 import json
@@ -663,7 +664,39 @@ def f10():
     save("decode_xai.npz", **flat)
 
 
+def f11():
+    """F11 rotary embedding: the reference's torch-native apply_rotary_emb
+    (srt/layers/rotary_embedding/utils.py:36-62) on fp32 copies of fp16 q/k with the cos_sin_cache of
+    RotaryEmbedding._compute_cos_sin_cache (base.py:171-181) -> rope.npz."""
+    from sglang.srt.layers.rotary_embedding.utils import apply_rotary_emb
+
+    torch.manual_seed(13)
+    flat = {}
+    for name, D, rot, neox, base in [("neox128", 128, 128, True, 10000.0), ("gptj64", 64, 64, False, 10000.0),
+                                     ("partial", 128, 64, True, 500000.0)]:
+        n, HQ, HKV, max_pos = 9, 4, 2, 4096
+        inv_freq = 1.0 / (base ** (torch.arange(0, rot, 2, dtype=torch.float) / rot))
+        freqs = torch.einsum("i,j -> ij", torch.arange(max_pos, dtype=torch.float), inv_freq)
+        cache = torch.cat((freqs.cos(), freqs.sin()), dim=-1)
+        pos = torch.tensor([0, 1, 2, 77, 1000, 4095, 5, 5, 300])
+        q = torch.randn(n, HQ, D).half()
+        k = torch.randn(n, HKV, D).half()
+        cos, sin = cache.index_select(0, pos).chunk(2, dim=-1)
+        outs = []
+        for x in (q, k):
+            xr = apply_rotary_emb(x[..., :rot].float(), cos, sin, neox)
+            outs.append(torch.cat((xr, x[..., rot:].float()), dim=-1))
+        # the fixture keeps only the cache rows that are used (positions remapped to them): the values
+        # every consumer reads are unchanged, the file is 100x smaller
+        uniq, remap = torch.unique(pos, return_inverse=True)
+        c = dict(q=q, k=k, positions=remap, true_positions=pos, cos_sin_cache=cache.index_select(0, uniq),
+                 rotary_dim=rot, is_neox=int(neox), q_out=outs[0], k_out=outs[1])
+        for kk, v in c.items():
+            flat[f"{name}.{kk}"] = bits(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+    save("rope.npz", **flat)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11"]
     for w in which:
         globals()[w]()

@@ -748,3 +748,51 @@ def test_merge_state_and_prefix_cascade(ops, dtype):
     o_m, l_m = ops.merge_state(o_p, l_p, o_e, l_e)
     assert (o_m.float() - o_full.float()).abs().max().item() <= (4e-3 if dtype == torch.float16 else 3e-2)
     np.testing.assert_allclose(l_m.cpu().numpy(), l_full.cpu().numpy(), atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("pool", ["none", "nhd", "hnd_fp8"])
+def test_rope_store_kv_golden(ops, golden_dir, pool):
+    """Fused RoPE (+ KV store): q/k rotated in place match the reference's apply_rotary_emb to one
+    16-bit rounding; the pool receives exactly the rotated k (and v), or their fp8 quantisation."""
+    cases = _cases(np.load(os.path.join(golden_dir, "rope.npz")))
+    for name, c in cases.items():
+        for dtype in (torch.float16, torch.bfloat16):
+            q = torch.from_numpy(c["q"]).to(dtype).to(DEV)
+            k = torch.from_numpy(c["k"]).to(dtype).to(DEV)
+            n, hkv, d = k.shape
+            v = torch.randn(n, hkv, d, generator=torch.Generator().manual_seed(1)).to(dtype).to(DEV)
+            pos = _t(c["positions"])
+            cache = _t(c["cos_sin_cache"])
+            neox, rot = bool(c["is_neox"]), int(c["rotary_dim"])
+            want_q = orc.rope(_np(q) if dtype == torch.float16 else _np(q), c["positions"], c["cos_sin_cache"], neox, rot)
+            want_k = orc.rope(_np(k), c["positions"], c["cos_sin_cache"], neox, rot)
+            kw = {}
+            page, slots = 16, 64
+            loc = torch.tensor([3, 17, 18, 0, 40, 41, 63, 5, 9], device=DEV)
+            if pool == "nhd":
+                kb = torch.zeros(slots, hkv, d, dtype=dtype, device=DEV)
+                vb = torch.zeros_like(kb)
+                kw = dict(layout=ops._kv_layout(kb, vb, page), loc=loc, size_limit=slots)
+            elif pool == "hnd_fp8":
+                kb = torch.zeros(slots // page, hkv, page, d, dtype=torch.uint8, device=DEV)
+                vb = torch.zeros_like(kb)
+                kw = dict(layout=ops.kv_layout_hnd(kb, vb), loc=loc, size_limit=slots, k_scale=0.5, v_scale=2.0)
+            ops.rope_store_kv(q, k, v if pool != "none" else None, pos, cache, neox, rotary_dim=rot, **kw)
+            ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+            for got, want in ((q, want_q), (k, want_k)):
+                g = orc.to_f64(_np(got))
+                assert (np.abs(g - want) <= ulp * np.maximum(np.abs(want), 1.0) * 1.01).all(), (name, dtype)
+            if pool == "none":
+                continue
+            keep = (loc != 0).cpu().numpy()
+            locn = loc.cpu().numpy()[keep]
+            if pool == "nhd":
+                assert torch.equal(kb[loc[loc != 0]], k[torch.from_numpy(keep).to(DEV)])
+                assert torch.equal(vb[loc[loc != 0]], v[torch.from_numpy(keep).to(DEV)])
+                assert int(kb[0].abs().sum()) == 0  # reserved slot untouched
+            else:
+                gk = kb.cpu().numpy().transpose(0, 2, 1, 3).reshape(slots, hkv, d)[locn]
+                gv = vb.cpu().numpy().transpose(0, 2, 1, 3).reshape(slots, hkv, d)[locn]
+                is_bf = dtype == torch.bfloat16
+                assert np.array_equal(gk, orc.quantize_kv_fp8(k.float().cpu().numpy()[keep], 0.5, is_bf))
+                assert np.array_equal(gv, orc.quantize_kv_fp8(v.float().cpu().numpy()[keep], 2.0, is_bf))

@@ -287,3 +287,17 @@ def test_decode_xai_temperature_golden(golden_dir):
         assert np.abs(got - c["o"].astype(np.float64)).max() <= 2e-3, name
         off = orc.decode_attention(c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"], float(c["sm_scale"]))
         assert np.abs(off - c["o"].astype(np.float64)).max() > 1e-2, "the case must exercise the factor"
+
+
+def test_rope_golden(golden_dir):
+    """F11: the oracle's rope() vs the reference's torch-native apply_rotary_emb (fp32)."""
+    z = np.load(os.path.join(golden_dir, "rope.npz"))
+    cases = {}
+    for key in z.files:
+        c, f = key.split(".", 1)
+        cases.setdefault(c, {})[f] = z[key]
+    assert set(cases) == {"neox128", "gptj64", "partial"}
+    for name, c in cases.items():
+        for x, want in (("q", "q_out"), ("k", "k_out")):
+            got = orc.rope(c[x], c["positions"], c["cos_sin_cache"], bool(c["is_neox"]), int(c["rotary_dim"]))
+            assert np.abs(got - c[want].astype(np.float64)).max() <= 2e-6, (name, x)
