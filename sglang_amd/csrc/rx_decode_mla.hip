@@ -53,7 +53,7 @@ struct MlaArgs {
 #define RX_MLA_STAMP 0  // 1: diagnostic build, s_memtime phase stamps overwrite the split's first partial row
 #endif
 #ifndef RX_MLA_PD
-#define RX_MLA_PD 8  // K-fragment prefetch distance (LDS reads in flight ahead of the MFMA)
+#define RX_MLA_PD 4  // K-fragment prefetch distance (LDS reads in flight ahead of the MFMA)
 #endif
 constexpr int kMlaDk = 576, kMlaDv = 512;
 constexpr int kMlaTile = 32;
@@ -147,21 +147,28 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
     st_row[i] = c / kMlaChunks;
     st_col[i] = c % kMlaChunks;
   }
-  KvV stg[kMlaStage];
+  // Tiles in flight per workgroup (register sets).  2 was tried for fp8 rows (half the staging
+  // registers): 114.8 -> 120.9 us at the config-5 shape, i.e. the fp8 kernel is bound by the per-tile
+  // compute path (S^T, softmax, staging, barrier: ~5 k cycles), not by bytes in flight.
+#ifndef RX_MLA_DEPTH
+#define RX_MLA_DEPTH 1
+#endif
+  constexpr int DEPTH = RX_MLA_DEPTH;
+  KvV stg[DEPTH][kMlaStage];
   int32_t slot_n[kMlaStage];  // slots of the tile whose loads are issued next (fetched a tile early)
   auto load_slots = [&](int t) {
 #pragma unroll
     for (int i = 0; i < kMlaStage; ++i)
       slot_n[i] = static_cast<int32_t>(idx[min(lo + t * kMlaTile + st_row[i], hi - 1)]);
   };
-  auto issue_loads = [&]() {
+  auto issue_loads = [&](KvV (&stg)[kMlaStage]) {
 #pragma unroll
     for (int i = 0; i < kMlaStage; ++i)
       stg[i] = *reinterpret_cast<const KvV*>(
           reinterpret_cast<const KvE*>(a.kv_buf) +
           mla_slot_off<LINEAR>(slot_n[i], a.page_size, a.page_stride, a.tok_stride) + 8 * st_col[i]);
   };
-  auto write_lds = [&](int buf) {
+  auto write_lds = [&](int buf, const KvV (&stg)[kMlaStage]) {
     char* kt = smem + buf * kMlaTile * kMlaLdsRow;
 #pragma unroll
     for (int i = 0; i < kMlaStage; ++i)
@@ -182,13 +189,21 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
     xai = __log2f(static_cast<float>(seq_len - 1)) / __log2f(static_cast<float>(a.xai_len));
   const float c2 = ((a.logit_cap > 0.f) ? kLog2e : a.sm_scale * kLog2e) * xai;
 
+  // prologue: tiles 0 .. DEPTH-1 go to sets 0 .. DEPTH-1, tile 0 is written to LDS and its set refilled
+  // with tile DEPTH; invariant at iteration t: set (t+1) % DEPTH holds tile t+1, slot_n the slots of
+  // tile t+1+DEPTH
   load_slots(0);
-  issue_loads();
-  if (ntiles > 1) load_slots(1);
-  write_lds(0);
-  if (ntiles > 1) {
-    issue_loads();
-    if (ntiles > 2) load_slots(2);
+#pragma unroll
+  for (int dd = 0; dd < DEPTH; ++dd) {
+    if (dd < ntiles) {
+      issue_loads(stg[dd]);
+      if (dd + 1 < ntiles) load_slots(dd + 1);
+    }
+  }
+  write_lds(0, stg[0]);
+  if (DEPTH < ntiles) {
+    issue_loads(stg[0]);
+    if (DEPTH + 1 < ntiles) load_slots(DEPTH + 1);
   }
   __syncthreads();
 
@@ -206,7 +221,11 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
 #endif
   MLA_STAMP(5);
   const int qd = r >> 2, pp = r & 3;
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t0 = 0; t0 < ntiles; t0 += DEPTH) {
+#pragma unroll
+   for (int u = 0; u < DEPTH; ++u) {  // unrolled so that the register set is a compile-time index
+    const int t = t0 + u;
+    if (t >= ntiles) break;
     const char* kt = smem + (t & 1) * kMlaTile * kMlaLdsRow;
     // ---- S^T = K Q^T over all 576 columns --------------------------------------------------------
     // K fragments run RX_MLA_PD reads ahead of their MFMA: a ds_read_b128 round trip is ~100+ cycles,
@@ -287,15 +306,16 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
     MLA_STAMP(2);
     // ---- stage the next tile into the other buffer -------------------------------------------------
     if (t + 1 < ntiles) {
-      write_lds((t + 1) & 1);
-      if (t + 2 < ntiles) {
-        issue_loads();
-        if (t + 3 < ntiles) load_slots(t + 3);
+      write_lds((t + 1) & 1, stg[(u + 1) % DEPTH]);
+      if (t + 1 + DEPTH < ntiles) {
+        issue_loads(stg[(u + 1) % DEPTH]);
+        if (t + 2 + DEPTH < ntiles) load_slots(t + 2 + DEPTH);
       }
     }
     MLA_STAMP(3);
     __syncthreads();
     MLA_STAMP(4);
+   }
   }
 
   // ---- epilogue: every wave holds the full statistics and its own 128 output columns -------------
