@@ -616,8 +616,9 @@ int rx_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const i
                     void* stream) {
   RX_REQUIRE(bs >= 0 && page_size > 0, "rx_alloc_extend: bad sizes");
   if (bs == 0) return RX_OK;
-  RX_REQUIRE(prefix_lens && seq_lens && last_loc && free_pages && out_indices,
-             "rx_alloc_extend: null pointer");
+  // free_pages may be NULL when the free list is empty and no request needs a new page (the caller
+  // checks the page budget first, allocator/paged.py:190-196): the kernels read it only for new pages
+  RX_REQUIRE(prefix_lens && seq_lens && last_loc && out_indices, "rx_alloc_extend: null pointer");
   hipLaunchKernelGGL(alloc_extend_kernel, dim3(bs), dim3(256), 0,
                      static_cast<hipStream_t>(stream), prefix_lens, seq_lens, last_loc,
                      free_pages, out_indices, page_size);
@@ -628,7 +629,7 @@ int rx_alloc_decode(const int64_t* seq_lens, const int64_t* last_loc, const int6
                     int64_t* out_indices, int bs, int page_size, void* stream) {
   RX_REQUIRE(bs >= 0 && page_size > 0, "rx_alloc_decode: bad sizes");
   if (bs == 0) return RX_OK;
-  RX_REQUIRE(seq_lens && last_loc && free_pages && out_indices, "rx_alloc_decode: null pointer");
+  RX_REQUIRE(seq_lens && last_loc && out_indices, "rx_alloc_decode: null pointer");  // free_pages: see above
   hipLaunchKernelGGL(alloc_decode_kernel, dim3(bs), dim3(256), 0,
                      static_cast<hipStream_t>(stream), seq_lens, last_loc, free_pages,
                      out_indices, page_size);
