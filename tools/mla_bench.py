@@ -28,7 +28,7 @@ r2t = torch.zeros(bs + 1, ctx, dtype=torch.int32, device=dev)
 r2t[1:] = slots.int()
 rpi = torch.arange(1, bs + 1, device=dev)
 lens = torch.full((bs,), ctx, dtype=torch.int64, device=dev)
-S = 16
+S = int(os.environ.get("S", "8"))
 nsplit = torch.zeros(bs, dtype=torch.int32, device=dev)
 ops.get_num_kv_splits(nsplit, lens.int(), hq, 1, S, 256)
 print("splits", nsplit[:4].tolist())
