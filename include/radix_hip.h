@@ -211,6 +211,13 @@ typedef struct rx_extend_params {
   /* Grok temperature (:336-343): L > 0 multiplies the scores of the query at absolute position
    * a = P_i + m by log2(a) / log2(L) when a > L (after scale and cap); <= 0 = off */
   int32_t xai_temperature_len;
+  /* K8, the one-stage "unified" form used for deterministic inference (extend_attention_fwd_unified,
+   * extend_attention.py:1160-1300; _fwd_kernel_unified :852-1158): non-NULL unified_prefix_lens (int32[bs])
+   * means kv_indptr / kv_indices list prefix AND new tokens (already stored in the pool), k_extend /
+   * v_extend are ignored, and query m of request i sees list position n iff n < prefix_i or
+   * n - prefix_i <= m (causal); window: prefix_i + m <= n + W; a custom mask row is [kv_len_i] wide and
+   * replaces the causal rule; xai factor = L / (prefix_i + m + 1) once prefix_i + m >= L (:940-946). */
+  const int32_t* unified_prefix_lens;
 } rx_extend_params;
 
 int rx_extend_attn(const rx_extend_params* p /* HOST */, void* stream);

@@ -660,6 +660,59 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
     return (o, lse) if return_lse else o
 
 
+def extend_attention_unified(q, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, prefix_lens, sm_scale=None,
+                             k_scale=1.0, v_scale=1.0, logit_cap=0.0, is_causal=True, sliding_window_size=-1,
+                             sinks=None, custom_mask=None, mask_indptr=None, xai_temperature_len=-1):
+    """Semantics of extend_attention_fwd_unified / _fwd_kernel_unified (extend_attention.py:852-1158): one pass
+    over a kv list holding prefix + new tokens.  Query m of request i sees list position n iff n < prefix_i or
+    n - prefix_i <= m (causal, :993-1008), window prefix_i + m <= n + W (:1010-1027); a custom mask row is
+    kv_len wide and replaces the causal rule (:980-990); xai factor L / (prefix_i + m + 1) once
+    prefix_i + m >= L (:940-946)."""
+    t, hq, dq = q.shape
+    hkv = k_buffer.shape[-2]
+    dv = v_buffer.shape[-1]
+    group = hq // hkv
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(dq)
+    qf = to_f64(q)
+    o = np.zeros((t, hq, dv), dtype=np.float64)
+    for i in range(len(qo_indptr) - 1):
+        q0, q1 = int(qo_indptr[i]), int(qo_indptr[i + 1])
+        e = q1 - q0
+        idx = np.asarray(kv_indices[kv_indptr[i]: kv_indptr[i + 1]]).astype(np.int64)
+        n_kv, pre = idx.size, int(prefix_lens[i])
+        cm = None
+        if custom_mask is not None:
+            m0 = int(mask_indptr[i])
+            cm = np.asarray(custom_mask[m0: m0 + e * n_kv]).astype(bool).reshape(e, n_kv)
+        pos = np.arange(n_kv)
+        for kvh in range(hkv):
+            kk, vv = _gather_kv(k_buffer, idx, kvh), _gather_kv(v_buffer, idx, kvh)
+            for h in range(kvh * group, (kvh + 1) * group):
+                for m in range(e):
+                    xai = 1.0
+                    if xai_temperature_len > 0 and pre + m >= xai_temperature_len:
+                        xai = xai_temperature_len / (pre + m + 1.0)
+                    s = _tanh_cap(kk @ qf[q0 + m, h] * (sm_scale * k_scale), logit_cap) * xai
+                    keep = np.ones(n_kv, dtype=bool)
+                    if cm is not None:
+                        keep &= cm[m]
+                    elif is_causal:
+                        keep &= (pos < pre) | (pos - pre <= m)
+                    if sliding_window_size > 0:
+                        keep &= (pre + m) <= (pos + sliding_window_size)
+                    s = np.where(keep, s, -np.inf)
+                    mx = s.max() if n_kv else -np.inf
+                    if not np.isfinite(mx):
+                        continue
+                    p = np.exp(s - mx)
+                    den = p.sum()
+                    if sinks is not None:
+                        den = den + math.exp(float(sinks[h]) - mx)
+                    o[q0 + m, h] = (p @ vv) / den * v_scale
+    return o
+
+
 def rope(x, positions, cos_sin_cache, is_neox, rotary_dim=None):
     """RotaryEmbedding._apply_rotary_emb semantics (srt/layers/rotary_embedding: cos_sin_cache[pos] =
     [cos(rot/2) | sin(rot/2)]; neox pairs (i, i+rot/2), gptj pairs (2i, 2i+1)) in float64.

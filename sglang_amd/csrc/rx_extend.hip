@@ -43,6 +43,7 @@ struct ExtendArgs {
   const int64_t* mask_indptr;
   const int32_t* window_kv_offsets;
   int32_t skip_prefix_mask, xai_len;
+  const int32_t* unified_prefix;  // K8 unified form (see radix_hip.h), or null
   const float* sinks;
 };
 
@@ -412,13 +413,22 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(const ExtendArgs a, 
   const IdxT* idx = reinterpret_cast<const IdxT*>(a.kv_indices) + kv0;
   const int32_t p_len = a.skip_prefix ? 0 : P;
   const bool masked = a.custom_mask != nullptr;
-  const int32_t n_end = a.skip_extend ? 0 : ((a.causal && !masked) ? m + 1 : E);
-  const int32_t mask_woff = (masked && a.window_kv_offsets) ? a.window_kv_offsets[req] : 0;
-  const uint8_t* mask_row_p =
-      masked ? a.custom_mask + a.mask_indptr[req] + static_cast<int64_t>(m) * (mask_woff + P + E) + mask_woff : nullptr;
+  const bool unified = a.unified_prefix != nullptr;
+  const int32_t q_off = unified ? a.unified_prefix[req] : P;
+  const int32_t n_end = (a.skip_extend || unified) ? 0 : ((a.causal && !masked) ? m + 1 : E);
+  const int32_t mask_woff = (masked && !unified && a.window_kv_offsets) ? a.window_kv_offsets[req] : 0;
+  const int64_t mask_row = unified ? static_cast<int64_t>(P) : static_cast<int64_t>(mask_woff) + P + E;
+  const uint8_t* mask_row_p = masked ? a.custom_mask + a.mask_indptr[req] + m * mask_row + mask_woff : nullptr;
+  const bool mask_prefix = masked && (unified || !a.skip_prefix_mask);
+  const bool causal_in_list = unified && a.causal && !masked;
   float xai = 1.0f;
-  if (a.xai_len > 0 && P + m > a.xai_len)
-    xai = __log2f(static_cast<float>(P + m)) / __log2f(static_cast<float>(a.xai_len));
+  if (a.xai_len > 0) {
+    if (unified) {
+      if (q_off + m >= a.xai_len) xai = static_cast<float>(a.xai_len) / (static_cast<float>(q_off + m) + 1.0f);
+    } else if (P + m > a.xai_len) {
+      xai = __log2f(static_cast<float>(P + m)) / __log2f(static_cast<float>(a.xai_len));
+    }
+  }
   for (int d = lane; d < dk; d += 64) qs[d] = T::to_f32(a.q[tq * a.q_stride_t + h * a.q_stride_h + d]);
   __syncthreads();
   constexpr int MAXV = 8;
@@ -449,11 +459,12 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(const ExtendArgs a, 
     if (a.logit_cap > 0.f) s = a.logit_cap * tanhf(s / a.logit_cap);
     s *= xai;
     bool keep = inb;
+    if (prefix && causal_in_list) keep = keep && (nn <= q_off + m);
     if (a.window > 0) {
-      if (prefix) keep = keep && (P + m <= nn + a.window);
+      if (prefix) keep = keep && (q_off + m <= nn + a.window);
       else keep = keep && (m <= (nn - p_len) + a.window);
     }
-    if (masked && keep && (!prefix || !a.skip_prefix_mask))
+    if (masked && keep && (!prefix || mask_prefix))
       keep = mask_row_p[prefix ? nn : P + (nn - p_len)] != 0;
     s = keep ? s * kLog2e : -INFINITY;
     float mt = s;
@@ -498,7 +509,7 @@ template <typename T, typename IdxT, bool LINEAR>
 static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, hipStream_t s) {
   // tree masks and the xai temperature live in the D = 128 kernel (rx_extend32.hip) and in the generic
   // kernel; the 16x16x32 kernel below does not carry them
-  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128) && !a.custom_mask && a.xai_len <= 0;
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128) && !a.custom_mask && a.xai_len <= 0 && !a.unified_prefix;
   if (mfma_ok) {
     const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
     const bool vs = a.v_scale != 1.0f;
@@ -530,7 +541,11 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   RX_REQUIRE(p, "rx_extend_attn: params is null");
   RX_REQUIRE(p->bs >= 0 && p->max_extend_len >= 0, "rx_extend_attn: negative sizes");
   if (p->bs == 0 || p->max_extend_len == 0) return RX_OK;
-  RX_REQUIRE(p->q && p->o && p->k_extend && p->v_extend, "rx_extend_attn: null q/k/v/o");
+  RX_REQUIRE(p->q && p->o, "rx_extend_attn: null q/o");
+  RX_REQUIRE(p->unified_prefix_lens || (p->k_extend && p->v_extend), "rx_extend_attn: null k_extend/v_extend");
+  if (p->unified_prefix_lens)
+    RX_REQUIRE(!p->skip_prefix && p->kv.k_buf && p->kv.v_buf && p->kv_indices,
+               "rx_extend_attn: the unified form reads every key from the pool (k_buf, v_buf, kv_indices)");
   RX_REQUIRE(p->qo_indptr && p->kv_indptr, "rx_extend_attn: null indptr");
   RX_REQUIRE(p->num_q_heads > 0 && p->num_kv_heads > 0 && p->num_q_heads % p->num_kv_heads == 0,
              "rx_extend_attn: Hq=%d must be a positive multiple of Hkv=%d", p->num_q_heads,
@@ -559,7 +574,7 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   if (p->kv.kv_fp8 && !p->skip_prefix && !(mfma_ok && dk == 128))
     return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: an fp8 prefix pool needs head_dim 128, got %d/%d", dk, dv);
   if (p->custom_mask) RX_REQUIRE(p->mask_indptr, "rx_extend_attn: custom_mask given without mask_indptr");
-  const bool extras = p->custom_mask || p->xai_temperature_len > 0;
+  const bool extras = p->custom_mask || p->xai_temperature_len > 0 || p->unified_prefix_lens;
   if (mfma_ok && dk == 128 && (p->kv.kv_fp8 || extras || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
     const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
@@ -612,6 +627,7 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   a.window_kv_offsets = p->window_kv_offsets;
   a.skip_prefix_mask = p->skip_prefix_custom_mask;
   a.xai_len = p->xai_temperature_len;
+  a.unified_prefix = p->unified_prefix_lens;
   a.sinks = p->sinks;
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&

@@ -53,6 +53,7 @@ struct Ext32Args {
   const int32_t* window_kv_offsets;
   int32_t skip_prefix_mask;     // 1: the prefix part is not masked
   int32_t xai_len;              // Grok temperature length or <= 0
+  const int32_t* unified_prefix; // K8 unified form: per-request prefix length, or null
   const float* sinks;
 };
 
@@ -146,19 +147,29 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) m[qb] = qbase + 32 * qb + ql;
 
+  // K8 unified form: the kv list holds prefix + new tokens; q_off = the query's distance from list start
+  const bool unified = a.unified_prefix != nullptr;
+  const int32_t q_off = unified ? a.unified_prefix[req] : P;
   // speculative tree mask: row of query m = mask_base + m * mask_row (+ woff + kv position)
   const bool masked = a.custom_mask != nullptr;
-  const int32_t mask_woff = (masked && a.window_kv_offsets) ? a.window_kv_offsets[req] : 0;
-  const int64_t mask_row = static_cast<int64_t>(mask_woff) + P + E;
+  const int32_t mask_woff = (masked && !unified && a.window_kv_offsets) ? a.window_kv_offsets[req] : 0;
+  const int64_t mask_row = unified ? static_cast<int64_t>(P) : static_cast<int64_t>(mask_woff) + P + E;
   const uint8_t* mask_base = masked ? a.custom_mask + a.mask_indptr[req] + mask_woff : nullptr;
-  const bool mask_prefix = masked && !a.skip_prefix_mask;
+  const bool mask_prefix = masked && (unified || !a.skip_prefix_mask);
+  const bool causal_in_list = unified && a.causal && !masked;  // the causal rule applies inside the kv list
   // Grok temperature: per-query multiplier of the scaled scores (1 when off)
   float xai[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     xai[qb] = 1.0f;
-    if (a.xai_len > 0 && P + m[qb] > a.xai_len)
-      xai[qb] = __log2f(static_cast<float>(P + m[qb])) / __log2f(static_cast<float>(a.xai_len));
+    const int32_t qidx = q_off + m[qb];
+    if (a.xai_len > 0) {
+      if (unified) {  // extend_attention.py:940-946
+        if (qidx >= a.xai_len) xai[qb] = static_cast<float>(a.xai_len) / (static_cast<float>(qidx) + 1.0f);
+      } else if (qidx > a.xai_len) {  // :336-343
+        xai[qb] = __log2f(static_cast<float>(qidx)) / __log2f(static_cast<float>(a.xai_len));
+      }
+    }
   }
 
   // ---- Q^T fragments: lane (q, h) holds Q[q][16 ks + 8 h .. +8] ------------------------------------
@@ -175,9 +186,10 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // Q landed before the loop (see rx_extend.hip)
 
+  const bool no_ext = a.skip_extend || a.unified_prefix != nullptr;  // unified: every key comes from the pool
   const int32_t p_len = a.skip_prefix ? 0 : P;
-  const int32_t n_end_wg = a.skip_extend ? 0 : (a.causal ? min(E, qb0 + NW * QPW) : E);
-  const int32_t n_end_w = a.skip_extend ? 0 : (a.causal ? min(E, qbase + QPW) : E);
+  const int32_t n_end_wg = no_ext ? 0 : (a.causal ? min(E, qb0 + NW * QPW) : E);
+  const int32_t n_end_w = no_ext ? 0 : (a.causal ? min(E, qbase + QPW) : E);
   const int nt1 = (p_len + kTok - 1) / kTok;
   const int nt2 = (n_end_wg + kTok - 1) / kTok;
   const int nt = nt1 + nt2;
@@ -322,14 +334,15 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     TileInfo ti;
     ti.prefix = t < nt1;
     ti.tile_n0 = (ti.prefix ? t : t - nt1) * kTok;
-    const int32_t lim = ti.prefix ? p_len : n_end_w;
+    // list positions this wave can see at all (causal inside the list in the unified form)
+    const int32_t lim = ti.prefix ? (causal_in_list ? min(p_len, q_off + qbase + QPW) : p_len) : n_end_w;
     ti.work = active && ti.tile_n0 < lim;
     ti.nblk = (ti.tile_n0 + 32 < lim) ? 2 : 1;  // visible 32-token blocks of this tile
     ti.cs = ti.prefix ? a.sm_scale * a.k_scale : a.sm_scale;
     ti.c2 = capped ? kLog2e : ti.cs * kLog2e;
     ti.vs = ti.prefix ? a.v_scale : 1.0f;
     const int n_hi = ti.tile_n0 + 32 * ti.nblk;
-    if (ti.prefix) ti.full = n_hi <= p_len && a.window <= 0 && !mask_prefix;
+    if (ti.prefix) ti.full = n_hi <= p_len && a.window <= 0 && !mask_prefix && (!causal_in_list || n_hi - 1 <= q_off + qbase);
     else ti.full = n_hi <= E && (!a.causal || n_hi - 1 <= qbase) && a.window <= 0 && !masked;
     ti.fast = ti.work && ti.full && ti.nblk == 2 && !capped && (LINEAR || a.page_size < 0);
     return ti;
@@ -586,8 +599,8 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
                 const int n = tile_n0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
                 bool keep;
                 if (prefix) {
-                  keep = n < p_len;
-                  if (a.window > 0) keep = keep && (P + m[qb] <= n + a.window);
+                  keep = n < p_len && (!causal_in_list || n <= q_off + m[qb]);
+                  if (a.window > 0) keep = keep && (q_off + m[qb] <= n + a.window);
                   if (mask_prefix && keep && m[qb] < E) keep = mask_base[m[qb] * mask_row + n] != 0;
                 } else {
                   keep = n < n_end_w && (masked || !a.causal || n <= m[qb]);
@@ -730,6 +743,7 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.window = p->sliding_window_size; a.sinks = p->sinks;
   a.custom_mask = p->custom_mask; a.mask_indptr = p->mask_indptr; a.window_kv_offsets = p->window_kv_offsets;
   a.skip_prefix_mask = p->skip_prefix_custom_mask; a.xai_len = p->xai_temperature_len;
+  a.unified_prefix = p->unified_prefix_lens;
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);

@@ -440,22 +440,26 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
                          skip_prefix_custom_mask=True, sliding_window_size=-1, sinks=None,
                          window_kv_offsets=None, xai_temperature_len=-1, lse_extend=None,
                          skip_prefix=False, skip_extend=False, page_size: int = 1,
-                         score_mod=None, aux_tensors=None, kv_layout=None):
+                         score_mod=None, aux_tensors=None, kv_layout=None, unified_prefix_lens=None):
     if score_mod is not None or aux_tensors is not None:
         raise NotImplementedError("score_mod / aux_tensors: outside the HIP path")
     _require_cuda(q_extend, k_extend, v_extend, o_extend, qo_indptr, kv_indptr, custom_mask, mask_indptr,
-                  window_kv_offsets)
+                  window_kv_offsets, unified_prefix_lens)
+    unified = unified_prefix_lens is not None
     for name, t in (("q", q_extend), ("k", k_extend), ("v", v_extend), ("o", o_extend)):
+        if t is None and unified and name in ("k", "v"):
+            continue
         if t.dim() != 3 or t.stride(-1) != 1:
             raise ValueError(f"{name}_extend must be [T, heads, dim] and contiguous in dim")
     if kv_indptr.dtype != torch.int32:
         raise TypeError("kv_indptr must be int32")
     p = _L.RxExtendParams()
-    p.q, p.k_extend, p.v_extend, p.o = (q_extend.data_ptr(), k_extend.data_ptr(),
-                                        v_extend.data_ptr(), o_extend.data_ptr())
+    p.q, p.o = q_extend.data_ptr(), o_extend.data_ptr()
     p.q_stride_t, p.q_stride_h = q_extend.stride(0), q_extend.stride(1)
-    p.k_stride_t, p.k_stride_h = k_extend.stride(0), k_extend.stride(1)
-    p.v_stride_t, p.v_stride_h = v_extend.stride(0), v_extend.stride(1)
+    if k_extend is not None:
+        p.k_extend, p.v_extend = k_extend.data_ptr(), v_extend.data_ptr()
+        p.k_stride_t, p.k_stride_h = k_extend.stride(0), k_extend.stride(1)
+        p.v_stride_t, p.v_stride_h = v_extend.stride(0), v_extend.stride(1)
     p.o_stride_t, p.o_stride_h = o_extend.stride(0), o_extend.stride(1)
     if k_buffer is not None:
         p.kv = kv_layout if kv_layout is not None else _kv_layout(k_buffer, v_buffer, page_size)
@@ -475,8 +479,16 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         p.lse_stride_t, p.lse_stride_h = lse_extend.stride(0), lse_extend.stride(1)
     p.bs = qo_indptr.shape[0] - 1
     p.max_extend_len = int(max_len_extend)
-    p.num_q_heads, p.num_kv_heads = q_extend.shape[1], k_extend.shape[1]
-    p.head_dim, p.v_head_dim = q_extend.shape[-1], v_extend.shape[-1]
+    if unified:
+        hnd = kv_layout is not None
+        p.num_kv_heads = k_buffer.shape[1] if hnd else k_buffer.shape[-2]
+        p.v_head_dim = v_buffer.shape[-1]
+        upl = unified_prefix_lens if unified_prefix_lens.dtype == torch.int32 else unified_prefix_lens.to(torch.int32)
+        p._keep_unified = upl = upl.contiguous()
+        p.unified_prefix_lens = upl.data_ptr()
+    else:
+        p.num_kv_heads, p.v_head_dim = k_extend.shape[1], v_extend.shape[-1]
+    p.num_q_heads, p.head_dim = q_extend.shape[1], q_extend.shape[-1]
     p.sm_scale = sm_scale or 1.0 / (q_extend.shape[-1] ** 0.5)
     p.k_scale, p.v_scale, p.logit_cap = k_scale, v_scale, logit_cap
     p.is_causal, p.skip_prefix, p.skip_extend = int(bool(is_causal)), int(skip_prefix), int(skip_extend)
@@ -505,6 +517,22 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
     p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
     p._keep_mask = keep
     _L.check(_L.load().rx_extend_attn(C.byref(p), _stream(q_extend)), "rx_extend_attn")
+
+
+def extend_attention_fwd_unified(q, o, k_buffer, v_buffer, k_scale, v_scale, qo_indptr, kv_indptr, kv_indices,
+                                 prefix_lens, max_len_extend, custom_mask=None, mask_indptr=None, sm_scale=None,
+                                 logit_cap=0.0, is_causal=True, sliding_window_size=-1, sinks=None,
+                                 window_start_pos=None, xai_temperature_len=-1, page_size: int = 1,
+                                 score_mod=None, aux_tensors=None, kv_layout=None):
+    """K8: the one-stage extend of deterministic inference (extend_attention.py:1160-1300).  kv_indptr /
+    kv_indices list prefix AND new tokens (their K/V are already in the pool); prefix_lens int32[bs].
+    window_start_pos only shifts both sides of the window test and is accepted for signature parity."""
+    extend_attention_fwd(q, None, None, o, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, custom_mask,
+                         is_causal, mask_indptr, max_len_extend, k_scale, v_scale, sm_scale=sm_scale,
+                         logit_cap=logit_cap, skip_prefix_custom_mask=False,
+                         sliding_window_size=sliding_window_size, sinks=sinks,
+                         xai_temperature_len=xai_temperature_len, page_size=page_size, score_mod=score_mod,
+                         aux_tensors=aux_tensors, kv_layout=kv_layout, unified_prefix_lens=prefix_lens)
 
 
 # --------------------------------------------------------------------------------------

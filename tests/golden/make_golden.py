@@ -17,6 +17,7 @@ Fixture families:
   F7 radix tree op sequences (reference RadixCache, recording allocator) -> radix_sequences.json
   F8 bf16 decode/extend from the compiled reference C++ CPU kernels -> cpu_native.npz
   F10 decode with the xai temperature -> decode_xai.npz
+  F12 unified one-stage extend (deterministic inference) -> extend_unified.npz
   F11 rotary embedding (torch-native apply_rotary_emb) -> rope.npz
   F9 extend with custom (tree) masks, sliding window (+ window_kv_offsets), xai temperature -> extend_mask.npz
 """
@@ -696,7 +697,61 @@ def f11():
     save("rope.npz", **flat)
 
 
+def f12():
+    """F12 the unified one-stage extend of deterministic inference (extend_attention_fwd_unified): plain
+    causal, sliding window, tree mask, xai temperature -> extend_unified.npz (fp16, interpreter)."""
+    from sglang.kernels.ops.attention.extend_attention import extend_attention_fwd_unified
+
+    torch.manual_seed(21)
+    dtype = torch.float16
+    rng = np.random.default_rng(31)
+    flat = {}
+    for name, HQ, HKV, D, pre, ext, window, masked, xai in [
+            ("causal", 8, 2, 128, [40, 0, 7], [6, 20, 9], -1, False, -1),
+            ("mha64", 4, 4, 64, [33, 5], [5, 9], -1, False, -1),
+            ("swa", 8, 2, 128, [70, 10], [12, 40], 24, False, -1),
+            ("tree", 8, 2, 128, [50, 12], [6, 6], -1, True, -1),
+            ("xai", 8, 2, 128, [50, 3], [9, 17], -1, False, 16)]:
+        pre = np.array(pre, dtype=np.int32); ext = np.array(ext, dtype=np.int32)
+        B = len(pre)
+        T = int(ext.sum())
+        tot = pre + ext
+        pool = int(tot.sum()) + 9
+        kb = torch.randn(pool, HKV, D).to(dtype)
+        vb = torch.randn(pool, HKV, D).to(dtype)
+        q = torch.randn(T, HQ, D).to(dtype)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.from_numpy(np.cumsum(tot))
+        qo_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        qo_indptr[1:] = torch.from_numpy(np.cumsum(ext))
+        kv_indices = torch.from_numpy(rng.permutation(pool - 1)[: int(tot.sum())] + 1).to(torch.int64)
+        cm = mi = None
+        if masked:
+            rows = []
+            for i in range(B):
+                m = rng.random((int(ext[i]), int(tot[i]))) < 0.5
+                for r in range(int(ext[i])):
+                    m[r, pre[i] + r] = True
+                    m[r, pre[i] + r + 1:] = False
+                rows.append(m.reshape(-1))
+            cm = torch.from_numpy(np.concatenate(rows))
+            mi = torch.zeros(B + 1, dtype=torch.int64)
+            mi[1:] = torch.from_numpy(np.cumsum([r.size for r in rows]))
+        o = torch.zeros(T, HQ, D, dtype=dtype)
+        extend_attention_fwd_unified(q, o, kb, vb, 1.0, 1.0, qo_indptr, kv_indptr, kv_indices, torch.from_numpy(pre),
+                                     int(ext.max()), custom_mask=cm, mask_indptr=mi, sm_scale=1.0 / D**0.5,
+                                     is_causal=True, sliding_window_size=window, xai_temperature_len=xai)
+        c = dict(q=q, kb=kb, vb=vb, qo_indptr=qo_indptr, kv_indptr=kv_indptr, kv_indices=kv_indices,
+                 prefix_lens=torch.from_numpy(pre), sm_scale=1.0 / D**0.5, window=window, xai=xai, o=o)
+        if cm is not None:
+            c["custom_mask"] = cm.to(torch.uint8)
+            c["mask_indptr"] = mi
+        for k, v in c.items():
+            flat[f"{name}.{k}"] = bits(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+    save("extend_unified.npz", **flat)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
     for w in which:
         globals()[w]()

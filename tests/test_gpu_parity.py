@@ -796,3 +796,61 @@ def test_rope_store_kv_golden(ops, golden_dir, pool):
                 is_bf = dtype == torch.bfloat16
                 assert np.array_equal(gk, orc.quantize_kv_fp8(k.float().cpu().numpy()[keep], 0.5, is_bf))
                 assert np.array_equal(gv, orc.quantize_kv_fp8(v.float().cpu().numpy()[keep], 2.0, is_bf))
+
+
+def test_extend_unified_golden(ops, golden_dir):
+    """K8 (deterministic one-stage extend): D = 128 on the MFMA kernel, D = 64 on the generic kernel."""
+    cases = _cases(np.load(os.path.join(golden_dir, "extend_unified.npz")))
+    for name, c in cases.items():
+        q, kb, vb = _t(c["q"]), _t(c["kb"]), _t(c["vb"])
+        o = torch.zeros_like(q)
+        cm = _t(c["custom_mask"]) if "custom_mask" in c else None
+        mi = _t(c["mask_indptr"]) if "mask_indptr" in c else None
+        ops.extend_attention_fwd_unified(q, o, kb, vb, 1.0, 1.0, _t(c["qo_indptr"]), _t(c["kv_indptr"]),
+                                         _t(c["kv_indices"]), _t(c["prefix_lens"]),
+                                         int(np.diff(c["qo_indptr"]).max()), custom_mask=cm, mask_indptr=mi,
+                                         sm_scale=float(c["sm_scale"]), sliding_window_size=int(c["window"]),
+                                         xai_temperature_len=int(c["xai"]))
+        got = _np(o).astype(np.float64)
+        want = c["o"].astype(np.float64)
+        ok = np.isfinite(want).all(axis=-1)
+        assert np.abs(got[ok] - want[ok]).max() <= 1e-2, (name, "vs triton golden")
+        ref = orc.extend_attention_unified(
+            c["q"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"], c["prefix_lens"],
+            sm_scale=float(c["sm_scale"]), sliding_window_size=int(c["window"]), custom_mask=c.get("custom_mask"),
+            mask_indptr=c.get("mask_indptr"), xai_temperature_len=int(c["xai"]))
+        assert np.abs(got[ok] - ref[ok]).max() <= 3e-3, (name, np.abs(got[ok] - ref[ok]).max())
+
+
+def test_extend_unified_equals_two_stage_on_long_batch(ops):
+    """The unified form over (prefix + stored new tokens) equals the two-stage extend, incl. long prefixes
+    that take the fast unmasked tiles and the causal boundary inside the kv list."""
+    rng = np.random.default_rng(8)
+    hq, hkv, d = 8, 2, 128
+    prefix = np.array([300, 0, 129, 64], dtype=np.int64)
+    ext = np.array([70, 260, 33, 1], dtype=np.int64)
+    bs = len(ext)
+    tot = prefix + ext
+    pool = int(tot.sum()) + 9
+    g = torch.Generator().manual_seed(4)
+    kb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+    vb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+    T = int(ext.sum())
+    q = torch.randn(T, hq, d, generator=g).to(torch.bfloat16).to(DEV)
+    slots = rng.permutation(pool - 1)[: int(tot.sum())] + 1
+    u_indptr = np.concatenate([[0], np.cumsum(tot)]).astype(np.int32)
+    p_idx, e_idx = [], []
+    for i in range(bs):
+        s = slots[u_indptr[i]: u_indptr[i + 1]]
+        p_idx.append(s[: prefix[i]]); e_idx.append(s[prefix[i]:])
+    e_all = torch.from_numpy(np.concatenate(e_idx)).to(DEV)
+    ke, ve = kb[e_all].contiguous(), vb[e_all].contiguous()
+    qo = _t(np.concatenate([[0], np.cumsum(ext)]).astype(np.int64))
+    o2 = torch.zeros_like(q)
+    ops.extend_attention_fwd(q, ke, ve, o2, kb, vb, qo, _t(np.concatenate([[0], np.cumsum(prefix)]).astype(np.int32)),
+                             _t(np.concatenate(p_idx).astype(np.int64)), None, True, None, int(ext.max()), 1.0, 1.0,
+                             sm_scale=d ** -0.5)
+    o1 = torch.zeros_like(q)
+    ops.extend_attention_fwd_unified(q, o1, kb, vb, 1.0, 1.0, qo, _t(u_indptr), _t(slots.astype(np.int64)),
+                                     _t(prefix.astype(np.int32)), int(ext.max()), sm_scale=d ** -0.5)
+    assert (o1.float() - o2.float()).abs().max().item() <= 2e-2

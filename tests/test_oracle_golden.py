@@ -301,3 +301,27 @@ def test_rope_golden(golden_dir):
         for x, want in (("q", "q_out"), ("k", "k_out")):
             got = orc.rope(c[x], c["positions"], c["cos_sin_cache"], bool(c["is_neox"]), int(c["rotary_dim"]))
             assert np.abs(got - c[want].astype(np.float64)).max() <= 2e-6, (name, x)
+
+
+def _npz_cases(path):
+    z = np.load(path)
+    cases = {}
+    for key in z.files:
+        c, f = key.split(".", 1)
+        cases.setdefault(c, {})[f] = z[key]
+    return cases
+
+
+def test_extend_unified_golden(golden_dir):
+    """F12: the one-stage unified extend of deterministic inference (reference Triton kernel, fp16)."""
+    cases = _npz_cases(os.path.join(golden_dir, "extend_unified.npz"))
+    assert set(cases) == {"causal", "mha64", "swa", "tree", "xai"}
+    for name, c in cases.items():
+        got = orc.extend_attention_unified(
+            c["q"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"], c["prefix_lens"],
+            sm_scale=float(c["sm_scale"]), sliding_window_size=int(c["window"]), custom_mask=c.get("custom_mask"),
+            mask_indptr=c.get("mask_indptr"), xai_temperature_len=int(c["xai"]))
+        want = c["o"].astype(np.float64)
+        ok = np.isfinite(want).all(axis=-1)
+        assert ok.mean() > 0.8, name
+        assert np.abs(got[ok] - want[ok]).max() <= 2e-3, (name, np.abs(got[ok] - want[ok]).max())
