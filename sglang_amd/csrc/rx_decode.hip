@@ -116,6 +116,9 @@ __device__ __forceinline__ void split_range(int32_t seq_len, int32_t splits, int
 #ifndef RX_DEC_MINW
 #define RX_DEC_MINW 1  // min waves per SIMD requested from the register allocator
 #endif
+#ifndef RX_DEC_FP8_DEPTH
+#define RX_DEC_FP8_DEPTH 2  // K/V register sets (tiles in flight per wave) of the fp8-pool kernel
+#endif
 #ifndef RX_DEC_NT
 #define RX_DEC_NT 0  // 1: non-temporal K/V loads
 #endif
@@ -139,7 +142,12 @@ template <typename T, int D, typename IdxT, bool LINEAR, bool KV8>
 __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const DecodeArgs a) {
   using vec8 = typename T::vec8;
   using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;  // pool element
-  using KvV = std::conditional_t<KV8, u32x2, u32x4>;       // 8 pool elements
+  using KvV = u32x4;  // 16 B per lane and load: 8 elements of a 16-bit pool, 16 of an fp8 pool
+  // fp8 pools: a 16-B load is TWO 8-element k-groups.  The contraction index is free to permute (Q uses
+  // the same map), so lane g takes d = 64 j + 16 g + 8 e + (0..7) for k-step 2 j + e: its 16 bytes of
+  // load j are the operands of k-steps 2j and 2j+1.  (8-B loads touched 32 B of each 128-B row per
+  // instruction and ran at 4.5 TB/s.)
+  constexpr int NL = KV8 ? D / 64 : D / 32;  // loads per 16-token row block (KS = D / 32 k-steps)
   constexpr int KS = D / 32;  // k-steps of the QK^T product
   constexpr int NB = D / 16;  // 16-wide d blocks of the output
   constexpr int ROW_BYTES = D * 2;
@@ -191,7 +199,9 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
     const uint16_t* qp = a.q + b * a.q_stride_t + (q_valid ? h : 0) * a.q_stride_h + 8 * g;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      u32x4 raw = q_valid ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
+      // element offset of k-step s for this lane (qp already carries + 8 g)
+      const int qoff = KV8 ? 64 * (s >> 1) + 8 * g + 8 * (s & 1) : 32 * s;  // fp8: 64 j + 16 g + 8 e
+      u32x4 raw = q_valid ? *reinterpret_cast<const u32x4*>(qp + qoff) : u32x4{0, 0, 0, 0};
       qf[s] = __builtin_bit_cast(vec8, raw);
     }
   }
@@ -200,8 +210,8 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
   // state (Q loads possibly pending) into the loop header and would otherwise emit vmcnt(0) in front
   // of the first MFMA of EVERY iteration, i.e. wait for the next tile's prefetch before computing.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
-  const KvE* kbase = reinterpret_cast<const KvE*>(a.k_buf) + kvh * a.k_head_stride + 8 * g;
-  const KvE* vbase = reinterpret_cast<const KvE*>(a.v_buf) + kvh * a.v_head_stride + 8 * g;
+  const KvE* kbase = reinterpret_cast<const KvE*>(a.k_buf) + kvh * a.k_head_stride + (KV8 ? 16 : 8) * g;
+  const KvE* vbase = reinterpret_cast<const KvE*>(a.v_buf) + kvh * a.v_head_stride + (KV8 ? 16 : 8) * g;
   char* vt = smem + w * TILE_BYTES;  // this wave's V tile
 
   f32x4 oacc[NB];
@@ -219,34 +229,54 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
     s0 = static_cast<int64_t>(idx[t0]);
     s1 = static_cast<int64_t>(idx[t1]);
   };
-  KvV kf[2][KS], vf[2][KS];  // fp8 pools: half the registers, upcast (exact) where consumed
-  auto load_kv = [&](int64_t s0, int64_t s1) {
+  // Register sets of K/V tiles in flight per wave.  One 32-token tile is 16 KiB of a 16-bit pool but
+  // 8 KiB of an fp8 pool: with a single set the fp8 kernel has half the bytes in flight and ran at
+  // 4.55 TB/s; two sets restore the 128 KiB per CU of the 16-bit kernel in the same registers.
+  constexpr int DEPTH = KV8 ? RX_DEC_FP8_DEPTH : 1;
+  KvV kf[DEPTH][2][NL], vf[DEPTH][2][NL];  // fp8 pools: upcast (exact) where consumed
+  constexpr int LSTEP = KV8 ? 64 : 32;  // elements between a lane's consecutive loads
+  auto load_kv = [&](int64_t s0, int64_t s1, KvV (&kfs)[2][NL], KvV (&vfs)[2][NL]) {
     const int64_t ko0 = slot_offset<LINEAR>(s0, a.page_size, a.k_page_stride, a.k_tok_stride);
     const int64_t ko1 = slot_offset<LINEAR>(s1, a.page_size, a.k_page_stride, a.k_tok_stride);
     const int64_t vo0 = slot_offset<LINEAR>(s0, a.page_size, a.v_page_stride, a.v_tok_stride);
     const int64_t vo1 = slot_offset<LINEAR>(s1, a.page_size, a.v_page_stride, a.v_tok_stride);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      kf[0][s] = kv_load8<KvV>(kbase + ko0 + 32 * s);
-      kf[1][s] = kv_load8<KvV>(kbase + ko1 + 32 * s);
+    for (int s = 0; s < NL; ++s) {
+      kfs[0][s] = kv_load8<KvV>(kbase + ko0 + LSTEP * s);
+      kfs[1][s] = kv_load8<KvV>(kbase + ko1 + LSTEP * s);
     }
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      vf[0][s] = kv_load8<KvV>(vbase + vo0 + 32 * s);
-      vf[1][s] = kv_load8<KvV>(vbase + vo1 + 32 * s);
+    for (int s = 0; s < NL; ++s) {
+      vfs[0][s] = kv_load8<KvV>(vbase + vo0 + LSTEP * s);
+      vfs[1][s] = kv_load8<KvV>(vbase + vo1 + LSTEP * s);
     }
   };
+  // 8 pool elements of k-step s as a 16-bit MFMA operand / LDS chunk
+  auto frag16 = [&](const KvV (&fs)[NL], int s) -> u32x4 {
+    if constexpr (KV8) return fp8x8_to_16<T>(u32x2{fs[s >> 1][2 * (s & 1)], fs[s >> 1][2 * (s & 1) + 1]});
+    else return fs[s];
+  };
 
-  int t = w;
-  int64_t n0 = 0, n1 = 0;
-  if (t < ntiles) {
-    int64_t s0, s1;
-    load_slots(t, s0, s1);
-    load_kv(s0, s1);
-    if (t + kWavesPerWG < ntiles) load_slots(t + kWavesPerWG, n0, n1);
+  // set u holds tile w + 4 (u + DEPTH k); n0/n1[u] = the slots of the tile that will refill it
+  constexpr int STEP = kWavesPerWG * DEPTH;
+  int64_t n0[DEPTH], n1[DEPTH];
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) {
+    n0[u] = n1[u] = 0;
+    const int tt = w + kWavesPerWG * u;
+    if (tt < ntiles) {
+      int64_t s0, s1;
+      load_slots(tt, s0, s1);
+      load_kv(s0, s1, kf[u], vf[u]);
+      if (tt + STEP < ntiles) load_slots(tt + STEP, n0[u], n1[u]);
+    }
   }
 
-  for (; t < ntiles; t += kWavesPerWG) {
+  for (int t0 = w; t0 < ntiles; t0 += STEP) {
+#pragma unroll
+   for (int u = 0; u < DEPTH; ++u) {  // unrolled: the register set is a compile-time index
+    const int t = t0 + kWavesPerWG * u;
+    if (t >= ntiles) break;
     // ---- S^T[token][q] = K Q^T ---------------------------------------------------------
     f32x4 sacc[2];
 #pragma unroll
@@ -254,7 +284,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
       sacc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KS; ++s)
-        sacc[bb] = T::mfma(__builtin_bit_cast(vec8, kv_frag16<T, KV8>(kf[bb][s])), qf[s], sacc[bb]);
+        sacc[bb] = T::mfma(__builtin_bit_cast(vec8, frag16(kf[u][bb], s)), qf[s], sacc[bb]);
     }
     // ---- V tile -> LDS (row = token, swizzled 16-B chunks) -------------------------------
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -264,14 +294,16 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
       const int row = 16 * bb + r;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const int chunk = (4 * s + g) ^ v_swizzle<D>(row);
-        *reinterpret_cast<u32x4*>(vt + row * ROW_BYTES + chunk * 16) = kv_frag16<T, KV8>(vf[bb][s]);
+        // 16-byte chunk of V[row][d .. d+8): d = 32 s + 8 g, or the fp8 map 64 j + 16 g + 8 e
+        const int c = KV8 ? 8 * (s >> 1) + 2 * g + (s & 1) : 4 * s + g;
+        const int chunk = c ^ v_swizzle<D>(row);
+        *reinterpret_cast<u32x4*>(vt + row * ROW_BYTES + chunk * 16) = frag16(vf[u][bb], s);
       }
     }
     // ---- prefetch the next tile (registers of this tile are free again) ------------------
-    if (t + kWavesPerWG < ntiles) {
-      load_kv(n0, n1);
-      if (t + 2 * kWavesPerWG < ntiles) load_slots(t + 2 * kWavesPerWG, n0, n1);
+    if (t + STEP < ntiles) {
+      load_kv(n0[u], n1[u], kf[u], vf[u]);
+      if (t + 2 * STEP < ntiles) load_slots(t + 2 * STEP, n0[u], n1[u]);
     }
     // ---- online softmax on the lane ------------------------------------------------------
     float sv[8];
@@ -330,6 +362,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
         oacc[nb] = T::mfma(__builtin_bit_cast(vec8, av), pf, oacc[nb]);
       }
     }
+   }
   }
 
   // ---- merge the four waves through LDS ----------------------------------------------------
