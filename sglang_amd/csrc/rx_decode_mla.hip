@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
     // before nearly every one of the 36 MFMAs (measured: ~10k cycles per tile, every pipe < 25 % busy).
     f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     {
-      constexpr int NF = 2 * KS, PD = RX_MLA_PD;
+      constexpr int NF = 2 * KS, PD = KV8 ? 2 * RX_MLA_PD : RX_MLA_PD;  // fp8 rows leave 18 registers for it (+5 %)
       u32x4 kf[NF];
       const char* kb0 = kt + r * kMlaLdsRow + g * 16;
       auto kload = [&](int i) {  // i = 2 s + bb
