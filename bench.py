@@ -171,11 +171,12 @@ def decode_step(st, fb, world, ev_pairs=None):
     be = st.backend
     be.init_forward_metadata(fb)
     pending = None
-    for layer in st.layers:
-        if ev_pairs is not None:
-            # HIP events around the attention launch of this layer (the roofline kernel)
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
+    for li, layer in enumerate(st.layers):
+        if ev_pairs is not None and li % st.ev_stride == 0:
+            # HIP events around the attention launch of this layer (the roofline kernel); the event
+            # objects come from a pool created before the timed region (hipEventCreate is ~10 us of host
+            # time each, which matters once a TP shard's layer is only ~100 us of GPU work)
+            e0, e1 = st.ev_pool.pop(), st.ev_pool.pop()
             be.token_to_kv_pool.set_kv_buffer(layer, fb.out_cache_loc, st.k, st.v)
             e0.record()
             o = be.forward_decode(st.q, None, None, layer, fb, save_kv_cache=False)
@@ -374,11 +375,16 @@ def main():
     timed = {"on": False}
 
     def step():
-        decode_step(st, fb, world, ev_pairs if timed["on"] else None)
+        decode_step(st, fb, world, ev_pairs if (timed["on"] and not os.environ.get("RX_BENCH_NO_EVENTS")) else None)
 
     # warmup untimed, then EXACTLY K timed steps (events are recorded inside the timed region)
     for _ in range(args.warmup):
         step()
+    # A timed event pair costs ~40 us of host time: invisible next to a 700-us TP=1 layer, but a TP shard's
+    # layer is ~100 us of GPU work and 32 pairs per step would make the HOST the bottleneck (measured on a
+    # TP=8 shard: 3.7 ms/step without events, 5.7 with).  Sharded runs therefore time every 8th layer.
+    st.ev_stride = 1 if (world == 1 and not args.tp_sim) else 8
+    st.ev_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps * args.layers)]
     timed["on"] = True
     dt = time_steps(step, args.steps, 0, world)
     timed["on"] = False

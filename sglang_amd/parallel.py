@@ -162,14 +162,20 @@ class TPGroup:
             return _Done(x)
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=x.device)
+            # a ring of reusable events: creating two per call costs ~20 us of host time, a third of a
+            # TP=8 shard's per-layer GPU time.  A stream-wait refers to the record that precedes it, so an
+            # event may be re-recorded once its waiter has been enqueued; the ring is far longer than the
+            # one all-reduce a caller keeps pending.
+            self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(16)]
+            self._ev_i = 0
         main = torch.cuda.current_stream(x.device)
-        ready = torch.cuda.Event()
+        ready, done = self._events[self._ev_i]
+        self._ev_i = (self._ev_i + 1) % len(self._events)
         ready.record(main)
         self._comm_stream.wait_event(ready)
         with torch.cuda.stream(self._comm_stream):
             self._reduce(x)
             x.record_stream(self._comm_stream)
-            done = torch.cuda.Event()
             done.record(self._comm_stream)
         return _Pending(x, done)
 
