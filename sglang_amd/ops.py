@@ -469,9 +469,11 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
     p.qo_indptr = qo_indptr.data_ptr()
     p.qo_indptr_is_i64 = _is64(qo_indptr, "qo_indptr")
     p.kv_indptr = kv_indptr.data_ptr()
-    if kv_indices is not None:
+    if kv_indices is not None and kv_indices.numel() > 0:
         p.kv_indices = kv_indices.data_ptr()
         p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
+    else:
+        skip_prefix = True  # an empty index list: no request has a cached prefix (its data_ptr is null)
     if lse_extend is not None:
         if lse_extend.dtype != torch.float32:
             raise TypeError("lse_extend must be float32")
