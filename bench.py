@@ -54,6 +54,8 @@ def parse():
                     help="hnd = [pages, Hkv, page, D] (MI355X-native default: a head's 16 tokens of a page are one "
                          "contiguous 4 KiB run); nhd = [slots, Hkv, D] (the reference's default)")
     ap.add_argument("--max-kv-splits", type=int, default=8)
+    ap.add_argument("--split-policy", default="native", choices=["native", "reference"],
+                    help="kv-split schedule: MI355X-native (default) or the reference's K3 formula capped by --max-kv-splits")
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"],
                     help="dev: KV pool dtype (BASELINE's config is bf16; fp8 = --kv-cache-dtype fp8_e4m3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -141,7 +143,7 @@ def make_decode_state(args, tp, dev):
         class server_args:
             triton_attention_num_kv_splits = args.max_kv_splits
 
-    backend = HipRadixAttnBackend(MR, decode_index_mode=args.index_mode)
+    backend = HipRadixAttnBackend(MR, decode_index_mode=args.index_mode, split_policy=args.split_policy)
     layers = [RadixAttention(hq, D, D ** -0.5, hkv, l % distinct) for l in range(L)]
     st = _Cfg()
     st.backend, st.layers, st.pool, st.r2t = backend, layers, pool, r2t_pool
@@ -435,6 +437,7 @@ def main():
                                   " + RCCL all-reduce (side stream)" if world > 1 else ""),
                    "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{world}",
                    "index_mode": args.index_mode, "kv_layout": args.kv_layout, "kv_dtype": args.kv_dtype,
+                   "split_policy": args.split_policy,
                    "all_reduce": "p2p-two-shot" if getattr(st, "custom_ar", None) is not None else ("rccl" if world > 1 else "none"), "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
                    "kv_bytes_resident_per_gpu": int(sum(st.pool.get_kv_size_bytes()))},
         "roofline": roofline,

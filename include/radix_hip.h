@@ -75,6 +75,17 @@ int rx_num_kv_splits(const void* seq_lens, int seq_lens_is_i64, int num_seq, int
                      int num_head, int num_kv_head, int max_kv_splits, int device_core_count,
                      int32_t* out, void* stream);
 
+/* MI355X-native split schedule (not a reference kernel: the reference's K3 formula above stays available
+ * and bit-exact).  Measured on gfx950 (tools/decode_sweep.py): the decode kernel is fastest with one to two
+ * workgroups per CU in total, e.g. bs 1 x ctx 32k: 8 splits (K3's answer) 74 us, 32 splits 38 us;
+ * bs 64 x ctx 2k: 3 splits 110 us, 1 split 102 us.  Every request gets
+ *   S = clamp(ceil(cu_count / (bs * wg_per_request)), 1, max_kv_splits), further capped at
+ *   ceil(seq_len / min_tokens_per_split) so that short requests are not shredded;
+ * wg_per_request = num_kv_heads * ceil(group / 16) (the kernel's workgroups per request and split). */
+int rx_num_kv_splits_native(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request,
+                            int cu_count, int max_kv_splits, int min_tokens_per_split, int32_t* out,
+                            void* stream);
+
 /* ---- KV buffer addressing shared by decode / extend ------------------------------------
  * element offset of (slot, kv_head) = (slot / page_size) * page_stride
  *                                   + (slot % page_size) * tok_stride + kv_head * head_stride

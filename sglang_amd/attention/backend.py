@@ -86,7 +86,7 @@ class HipRadixAttnBackend:
     supports_ragged_verify_graph: bool = False
 
     def __init__(self, model_runner, decode_index_mode: str = "paged",
-                 max_kv_splits: Optional[int] = None):
+                 max_kv_splits: Optional[int] = None, split_policy: str = "native"):
         self.device = model_runner.device
         self.req_to_token_pool = model_runner.req_to_token_pool
         self.token_to_kv_pool = model_runner.token_to_kv_pool
@@ -103,6 +103,13 @@ class HipRadixAttnBackend:
         sa = getattr(model_runner, "server_args", None)
         self.max_kv_splits = max_kv_splits or getattr(sa, "triton_attention_num_kv_splits", 8)
         self.device_core_count = torch.cuda.get_device_properties(self.device).multi_processor_count
+        # "native": the MI355X schedule (one to two workgroups per CU in total, rx_num_kv_splits_native;
+        # up to native_split_cap splits) -- "reference": get_num_kv_splits_triton's formula (K3) with
+        # --triton-attention-num-kv-splits as the cap
+        if split_policy not in ("native", "reference"):
+            raise ValueError(f"split_policy must be 'native' or 'reference', got {split_policy}")
+        self.split_policy = split_policy
+        self.native_split_cap = 32
         if decode_index_mode not in ("paged", "indices"):
             raise ValueError(f"decode_index_mode must be 'paged' or 'indices', got {decode_index_mode}")
         self.decode_index_mode = decode_index_mode
@@ -126,12 +133,15 @@ class HipRadixAttnBackend:
         self._cur_fb = None
 
     # ------------------------------------------------------------------ scratch
-    def _scratch(self, bs: int):
-        need = (bs, self.num_head, self.max_kv_splits, self.v_head_dim)
-        if self._scratch_logits is None or self._scratch_logits.shape[0] < bs:
-            self._scratch_logits = torch.empty(need, dtype=torch.float32, device=self.device)
-            self._scratch_lse = torch.empty(need[:3], dtype=torch.float32, device=self.device)
-        return self._scratch_logits[:bs], self._scratch_lse[:bs]
+    def _scratch(self, bs: int, splits: Optional[int] = None):
+        """fp32 partials [bs, Hq, S, Dv] / [bs, Hq, S] carved out of flat, grow-only buffers."""
+        S = self.max_kv_splits if splits is None else splits
+        n = bs * self.num_head * S
+        if self._scratch_lse is None or self._scratch_lse.numel() < n:
+            self._scratch_logits = torch.empty(n * self.v_head_dim, dtype=torch.float32, device=self.device)
+            self._scratch_lse = torch.empty(n, dtype=torch.float32, device=self.device)
+        return (self._scratch_logits[: n * self.v_head_dim].view(bs, self.num_head, S, self.v_head_dim),
+                self._scratch_lse[:n].view(bs, self.num_head, S))
 
     # ------------------------------------------------------------------ metadata
     def init_forward_metadata(self, forward_batch: ForwardBatch):
@@ -172,6 +182,8 @@ class HipRadixAttnBackend:
 
     def _decode_metadata(self, fb: ForwardBatch, bs: int, in_capture: bool) -> ForwardMetadata:
         use_graph_bufs = self._graph is not None and (in_capture or self._graph.get("active"))
+        if self.split_policy == "native" and self.sliding_window_size is None:
+            return self._decode_metadata_native(fb, bs, use_graph_bufs)
         splits_needed = True
         if not use_graph_bufs and fb.seq_lens_cpu is not None and self.max_kv_splits > 1:
             host = host_num_kv_splits(np.asarray(fb.seq_lens_cpu), self.num_head, self.num_kv_head,
@@ -208,6 +220,34 @@ class HipRadixAttnBackend:
                               self.max_kv_splits, self.device_core_count)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices,
                                None, self.max_kv_splits, **win)
+
+    def _decode_metadata_native(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool) -> ForwardMetadata:
+        """Split schedule sized for the chip, not by the reference's formula: S depends on bs only, so it is
+        graph-stable; the per-request counts (short requests get fewer splits) are written on the device."""
+        kv_indptr = kv_indices = None
+        if self.decode_index_mode == "indices":
+            if use_graph_bufs:
+                kv_indices = self._graph["kv_indices"]
+            else:
+                total = fb.seq_lens_sum if fb.seq_lens_sum is not None else bs * self.max_context_len
+                kv_indices = torch.empty(total, dtype=torch.int64, device=self.device)
+            kv_indptr = ops.build_kv_indices(self.req_to_token, fb.req_pool_indices, fb.seq_lens,
+                                             self.kv_indptr, kv_indices)
+        S = ops.native_max_kv_splits(bs, self.num_head, self.num_kv_head, self.device_core_count,
+                                     self.native_split_cap)
+        if S <= 1:
+            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1)
+        if use_graph_bufs:
+            num_kv_splits = self._graph["num_kv_splits"][:bs]
+            n = bs * self.num_head * S
+            attn_logits = self._graph["native_logits"][: n * self.v_head_dim].view(bs, self.num_head, S, self.v_head_dim)
+            attn_lse = self._graph["native_lse"][:n].view(bs, self.num_head, S)
+        else:
+            num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+            attn_logits, attn_lse = self._scratch(bs, S)
+        ops.get_num_kv_splits_native(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S,
+                                     self.device_core_count)
+        return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S)
 
     def _extend_metadata(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
         # prefix-only kv indices + qo_indptr (triton_backend.py:869-924)
@@ -276,6 +316,11 @@ class HipRadixAttnBackend:
             "kv_indices": torch.zeros((max_bs * self.max_context_len,), dtype=torch.int64,
                                       device=self.device) if self.decode_index_mode == "indices" else None,
         }
+        # native schedule: bs * S(bs) <= cu_count / wg_per_request + bs rows of partials
+        group = max(1, self.num_head // self.num_kv_head)
+        rows = (self.device_core_count // (self.num_kv_head * ((group + 15) // 16)) + max_bs + 1) * self.num_head
+        self._graph["native_logits"] = torch.zeros(rows * self.v_head_dim, dtype=torch.float32, device=self.device)
+        self._graph["native_lse"] = torch.zeros(rows, dtype=torch.float32, device=self.device)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1  # triton_backend.py:1205-1206

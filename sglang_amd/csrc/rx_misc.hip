@@ -611,6 +611,33 @@ int rx_num_kv_splits(const void* seq_lens, int seq_lens_is_i64, int num_seq, int
   return check_launch("rx_num_kv_splits");
 }
 
+namespace rx {
+__global__ __launch_bounds__(256) void num_kv_splits_native_kernel(const void* __restrict__ seq_lens, int is64,
+                                                                   int bs, int uniform, int min_tokens,
+                                                                   int32_t* __restrict__ out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= bs) return;
+  const int32_t len = static_cast<int32_t>(load_idx(seq_lens, b, is64));
+  out[b] = max(1, min(uniform, cdiv32(len, min_tokens)));
+}
+}  // namespace rx
+
+int rx_num_kv_splits_native(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int cu_count,
+                            int max_kv_splits, int min_tokens_per_split, int32_t* out, void* stream) {
+  RX_REQUIRE(bs >= 0, "rx_num_kv_splits_native: bs < 0");
+  if (bs == 0) return RX_OK;
+  RX_REQUIRE(seq_lens && out, "rx_num_kv_splits_native: null pointer");
+  RX_REQUIRE(wg_per_request > 0 && cu_count > 0 && max_kv_splits > 0 && min_tokens_per_split > 0,
+             "rx_num_kv_splits_native: bad sizes");
+  const int64_t wgs = static_cast<int64_t>(bs) * wg_per_request;
+  int uniform = static_cast<int>((cu_count + wgs - 1) / wgs);
+  uniform = uniform < 1 ? 1 : (uniform > max_kv_splits ? max_kv_splits : uniform);
+  hipLaunchKernelGGL(rx::num_kv_splits_native_kernel, dim3((bs + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), seq_lens, seq_lens_is_i64, bs, uniform, min_tokens_per_split,
+                     out);
+  return check_launch("rx_num_kv_splits_native");
+}
+
 int rx_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const int64_t* last_loc,
                     const int64_t* free_pages, int64_t* out_indices, int bs, int page_size,
                     void* stream) {

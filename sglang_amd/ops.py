@@ -191,6 +191,25 @@ def get_num_kv_splits(num_kv_splits: torch.Tensor, seq_lens: torch.Tensor, num_h
     _L.check(st, "rx_num_kv_splits")
 
 
+def native_max_kv_splits(bs: int, num_head: int, num_kv_head: int, cu_count: int, cap: int) -> int:
+    """Uniform split count of the MI355X-native schedule (include/radix_hip.h, rx_num_kv_splits_native)."""
+    group = max(1, num_head // num_kv_head)
+    wgs = max(1, bs * num_kv_head * ((group + 15) // 16))
+    return max(1, min(cap, -(-cu_count // wgs)))
+
+
+def get_num_kv_splits_native(num_kv_splits: torch.Tensor, seq_lens: torch.Tensor, num_head: int, num_kv_head: int,
+                             max_kv_splits: int, device_core_count: int, min_tokens_per_split: int = 128) -> None:
+    _require_cuda(num_kv_splits, seq_lens)
+    if num_kv_splits.dtype != torch.int32:
+        raise TypeError("num_kv_splits must be int32")
+    group = max(1, num_head // num_kv_head)
+    st = _L.load().rx_num_kv_splits_native(_ptr(seq_lens), _is64(seq_lens, "seq_lens"), seq_lens.shape[0],
+                                           num_kv_head * ((group + 15) // 16), device_core_count, max_kv_splits,
+                                           min_tokens_per_split, _ptr(num_kv_splits), _stream(seq_lens))
+    _L.check(st, "rx_num_kv_splits_native")
+
+
 # --------------------------------------------------------------------------------------
 # KV buffer strides          _extract_kv_strides, kernels/ops/attention/decode_attention.py:39-88
 # --------------------------------------------------------------------------------------

@@ -42,7 +42,8 @@ def _bits(t):
 
 
 class _Harness:
-    def __init__(self, page_size, hq, hkv, d, dtype, layout, index_mode, max_ctx=4200, max_reqs=8):
+    def __init__(self, page_size, hq, hkv, d, dtype, layout, index_mode, max_ctx=4200, max_reqs=8,
+                 split_policy="native"):
         from sglang_amd.attention.backend import HipRadixAttnBackend
         from sglang_amd.attention.radix_attention import RadixAttention
         from sglang_amd.mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
@@ -78,7 +79,7 @@ class _Harness:
             class server_args:
                 triton_attention_num_kv_splits = 8
 
-        self.backend = HipRadixAttnBackend(MR, decode_index_mode=index_mode)
+        self.backend = HipRadixAttnBackend(MR, decode_index_mode=index_mode, split_policy=split_policy)
         self.layer = RadixAttention(hq, d, d ** -0.5, hkv, 0)
         self.gen = torch.Generator().manual_seed(11)
 
@@ -122,8 +123,11 @@ def test_dense_case_matrix(case, d, layout):
     if ps == 1 and layout != "contiguous":
         pytest.skip("page layouts need page_size > 1")
     dtype = torch.float16
-    for index_mode in (("paged", "indices") if mode == "decode" else ("paged",)):
-        hs = _Harness(ps, hq, hkv, d, dtype, layout, index_mode)
+    # decode: both index modes, and both split schedules (the MI355X-native one and the reference's K3)
+    variants = ([("paged", "native"), ("indices", "native"), ("paged", "reference")] if mode == "decode"
+                else [("paged", "native")])
+    for index_mode, policy in variants:
+        hs = _Harness(ps, hq, hkv, d, dtype, layout, index_mode, split_policy=policy)
         bs = len(prefix_lens)
         rows = hs.r2t.alloc(bs)
         hs.fill_prefix(rows, prefix_lens)
@@ -164,7 +168,7 @@ def test_dense_case_matrix(case, d, layout):
             got = _bits(o.view(bs, hq, d)).astype(np.float64)
         assert hs.pool.check_errors() == 0
         err = np.abs(got - want).max()
-        assert err <= 3e-3, (name, index_mode, err)  # kit tolerance is 3e-2 (dense_attention.py:35-36)
+        assert err <= 3e-3, (name, index_mode, policy, err)  # kit tolerance is 3e-2 (dense_attention.py:35-36)
 
 
 def test_idle_mode_and_graph_state():
@@ -494,3 +498,16 @@ def test_target_verify_mode_with_tree_mask():
     want = orc.extend_attention(_bits(q.view(T, hq, d)), ke, ve, kbn, vbn, qo, kv_indptr, kv_indices, is_causal=True,
                                 sm_scale=d ** -0.5, custom_mask=cm, mask_indptr=mi)
     assert np.abs(_bits(o.view(T, hq, d)).astype(np.float64) - want).max() <= 3e-3
+
+
+def test_native_split_schedule_values():
+    """rx_num_kv_splits_native: S = ceil(CUs / (bs * Hkv * ceil(G/16))) capped, short requests fewer."""
+    from sglang_amd import ops
+
+    lens = torch.tensor([1, 100, 128, 129, 5000, 40000], dtype=torch.int64, device=DEV)
+    out = torch.zeros(6, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits_native(out, lens, 32, 8, 32, 256)          # 6 * 8 = 48 workgroups -> ceil(256/48) = 6
+    assert ops.native_max_kv_splits(6, 32, 8, 256, 32) == 6
+    assert out.tolist() == [1, 1, 1, 2, 6, 6]
+    assert ops.native_max_kv_splits(1, 32, 8, 256, 32) == 32 and ops.native_max_kv_splits(256, 32, 8, 256, 32) == 1
+    assert ops.native_max_kv_splits(1, 128, 1, 256, 32) == 32      # MLA: 8 q-blocks of 16 heads

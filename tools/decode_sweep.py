@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Dev sweep: dense decode kernel time vs (batch, ctx, forced split count) at Llama-3-8B head geometry."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sglang_amd import ops
+
+dev = "cuda"
+HQ, HKV, D, PS = 32, 8, 128, 16
+def run(bs, ctx, splits_list):
+    pages = ctx // PS
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(np.arange(1, bs * pages + 1))
+    slots = (perm.reshape(bs, pages)[:, :, None] * PS + np.arange(PS)[None, None, :]).reshape(bs, -1)
+    r2t = torch.zeros(bs + 1, ctx, dtype=torch.int32, device=dev); r2t[1:] = torch.from_numpy(slots.astype(np.int32)).to(dev)
+    rpi = torch.arange(1, bs + 1, device=dev); lens = torch.full((bs,), ctx, dtype=torch.int64, device=dev)
+    pool = (bs * pages + 1) * PS
+    kb = torch.randn(pool // PS, HKV, PS, D, device=dev).to(torch.bfloat16); vb = torch.randn_like(kb)
+    lay = ops.kv_layout_hnd(kb, vb)
+    q = torch.randn(bs, HQ, D, device=dev).to(torch.bfloat16); o = torch.empty_like(q)
+    ref = torch.zeros(bs, dtype=torch.int32, device=dev)
+    ops.get_num_kv_splits(ref, lens.int(), HQ, HKV, 8, 256)
+    out = [f"bs={bs} ctx={ctx} reference schedule(max 8)={ref[0].item()}"]
+    byt = bs * ctx * HKV * D * 2 * 2
+    for S in splits_list:
+        ns = torch.full((bs,), S, dtype=torch.int32, device=dev)
+        al = torch.empty(bs, HQ, max(S, 1), D, dtype=torch.float32, device=dev); lse = torch.empty(bs, HQ, max(S, 1), device=dev)
+        def f():
+            if S == 1: ops.decode_attention_fwd_paged(q, kb, vb, o, r2t, rpi, lens, None, None, None, 1, D ** -0.5, page_size=PS, kv_layout=lay)
+            else: ops.decode_attention_fwd_paged(q, kb, vb, o, r2t, rpi, lens, al, lse, ns, S, D ** -0.5, page_size=PS, kv_layout=lay)
+        for _ in range(3): f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): f()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        out.append(f"S={S}: {us:.0f} us {byt/us/1e6:.2f} TB/s")
+    print(" | ".join(out))
+for bs, ctx in [(64, 2048), (16, 4096), (8, 16384), (1, 32768), (1, 131072), (4, 8192), (32, 1024), (256, 4096)]:
+    run(bs, ctx, [int(x) for x in os.environ.get("SPLITS", "1,2,4,8,16,32,64").split(",")])
