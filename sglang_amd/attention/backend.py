@@ -110,6 +110,10 @@ class HipRadixAttnBackend:
             raise ValueError(f"split_policy must be 'native' or 'reference', got {split_policy}")
         self.split_policy = split_policy
         self.native_split_cap = 32
+        # workgroups the native schedule aims for: one per CU for the dense kernel (four independent waves
+        # each); two per CU for the MLA kernel, whose four waves share one staged tile (config-5 shape:
+        # 256 workgroups 157 us, 512 workgroups 134 us)
+        self._is_mla_pool = hasattr(self.token_to_kv_pool, "kv_lora_rank")
         if decode_index_mode not in ("paged", "indices"):
             raise ValueError(f"decode_index_mode must be 'paged' or 'indices', got {decode_index_mode}")
         self.decode_index_mode = decode_index_mode
@@ -233,8 +237,8 @@ class HipRadixAttnBackend:
                 kv_indices = torch.empty(total, dtype=torch.int64, device=self.device)
             kv_indptr = ops.build_kv_indices(self.req_to_token, fb.req_pool_indices, fb.seq_lens,
                                              self.kv_indptr, kv_indices)
-        S = ops.native_max_kv_splits(bs, self.num_head, self.num_kv_head, self.device_core_count,
-                                     self.native_split_cap)
+        wg_target = self.device_core_count * (2 if self._is_mla_pool else 1)
+        S = ops.native_max_kv_splits(bs, self.num_head, self.num_kv_head, wg_target, self.native_split_cap)
         if S <= 1:
             return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1)
         if use_graph_bufs:
@@ -245,8 +249,7 @@ class HipRadixAttnBackend:
         else:
             num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
             attn_logits, attn_lse = self._scratch(bs, S)
-        ops.get_num_kv_splits_native(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S,
-                                     self.device_core_count)
+        ops.get_num_kv_splits_native(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S, wg_target)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S)
 
     def _extend_metadata(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
@@ -318,7 +321,7 @@ class HipRadixAttnBackend:
         }
         # native schedule: bs * S(bs) <= cu_count / wg_per_request + bs rows of partials
         group = max(1, self.num_head // self.num_kv_head)
-        rows = (self.device_core_count // (self.num_kv_head * ((group + 15) // 16)) + max_bs + 1) * self.num_head
+        rows = (2 * self.device_core_count // (self.num_kv_head * ((group + 15) // 16)) + max_bs + 1) * self.num_head
         self._graph["native_logits"] = torch.zeros(rows * self.v_head_dim, dtype=torch.float32, device=self.device)
         self._graph["native_lse"] = torch.zeros(rows, dtype=torch.float32, device=self.device)
 
