@@ -326,6 +326,8 @@ def extend_bench(args, dev, tp):
 
     HQ, HKV, D = 32 // tp, max(1, 8 // tp), 128
     P, E, chunk, nchunks = 3584, 512, 32, 8
+    if os.environ.get("RX_EXTEND_SHAPE"):  # dev: "P,E,chunk", e.g. config 2's 2k prompts without a prefix: 0,2048,8
+        P, E, chunk = (int(x) for x in os.environ["RX_EXTEND_SHAPE"].split(","))
     g = torch.Generator(device=dev).manual_seed(1)
     pool = P + chunk * E + 16
     kb = torch.randn(pool, HKV, D, device=dev, generator=g).to(torch.bfloat16)
@@ -356,7 +358,7 @@ def extend_bench(args, dev, tp):
     ms = e0.elapsed_time(e1) / nchunks
     flops = 4.0 * HQ * D * chunk * (E * P + E * (E + 1) / 2)
     tflops = flops / (ms * 1e-3) / 1e12
-    return {"metric": "extend attention TFLOP/s (config 3: 3584-token shared prefix + 512 new, bf16)",
+    return {"metric": f"extend attention TFLOP/s (config 3: {P}-token shared prefix + {E} new, bf16)",
             "tflops": tflops, "ms_per_chunk": ms, "chunk_requests": chunk, "flops_per_chunk": flops,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": None}}

@@ -229,6 +229,10 @@ typedef struct rx_extend_params {
    * n - prefix_i <= m (causal); window: prefix_i + m <= n + W; a custom mask row is [kv_len_i] wide and
    * replaces the causal rule; xai factor = L / (prefix_i + m + 1) once prefix_i + m >= L (:940-946). */
   const int32_t* unified_prefix_lens;
+  /* launch-shape hint, 0 = unknown: mean number of kv_indices entries per request (the host knows the
+   * tensor's length; the per-request lengths live on the device).  Short work per (request, head, query
+   * block) runs better as two 128-query workgroups per CU than as one 256-query workgroup. */
+  int32_t avg_kv_len_hint;
 } rx_extend_params;
 
 int rx_extend_attn(const rx_extend_params* p /* HOST */, void* stream);

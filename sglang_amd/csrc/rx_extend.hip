@@ -575,7 +575,11 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
     return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: an fp8 prefix pool needs head_dim 128, got %d/%d", dk, dv);
   if (p->custom_mask) RX_REQUIRE(p->mask_indptr, "rx_extend_attn: custom_mask given without mask_indptr");
   const bool extras = p->custom_mask || p->xai_temperature_len > 0 || p->unified_prefix_lens;
-  if (mfma_ok && dk == 128 && (p->kv.kv_fp8 || extras || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
+  // the D = 128 kernel stores whole 16-byte row chunks of o
+  const bool o16 = ((p->o_stride_t | p->o_stride_h) % 8 == 0) && ((uintptr_t)p->o & 15) == 0;
+  if (mfma_ok && dk == 128 && !o16 && (p->kv.kv_fp8 || extras))
+    return fail(RX_ERR_INVALID_ARG, "rx_extend_attn: o must be 16-byte aligned with strides that are multiples of 8");
+  if (mfma_ok && dk == 128 && o16 && (p->kv.kv_fp8 || extras || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
     const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }

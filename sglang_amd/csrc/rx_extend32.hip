@@ -21,6 +21,9 @@
 // one block under the softmax VALU of the other); boundary tiles take a plain masked path.
 #include "rx_common.h"
 
+#ifndef RX_EXT32_SMALL_WG_TILES
+#define RX_EXT32_SMALL_WG_TILES 28  // below this many estimated tiles per workgroup: 128-query workgroups
+#endif
 #ifndef RX_EXT32_STAMP
 #define RX_EXT32_STAMP 0  // 1: diagnostic build with s_memtime phase stamps (tools/ext_stamps.py); outputs are clobbered
 #endif
@@ -128,7 +131,9 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   int bid = blockIdx.x;
   const int kvh = bid % a.hkv;
   bid /= a.hkv;
-  const int mb = bid % a.mblocks;
+  // query blocks are dealt heaviest first: under the causal mask block mb walks mb+1 times as many new-token
+  // tiles as block 0, and a late heavy block is the kernel's tail
+  const int mb = a.mblocks - 1 - bid % a.mblocks;
   bid /= a.mblocks;
   const int head = kvh * a.group + bid % a.group;
   const int req = bid / a.group;
@@ -645,7 +650,14 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 
   RX_STAMP(4);
   // ---- epilogue -------------------------------------------------------------------------------------
+  // The accumulator has one query ROW per lane: stored as it stands, every store instruction touches 32
+  // different rows (8 bytes each, sixteen of them per lane) and the tail is store-issue bound (~4 us per
+  // workgroup).  Each wave therefore transposes its 32 x 128 block through a private LDS region (the K/V
+  // tiles are dead after one more barrier) and writes whole 256-byte rows, 16 lanes x 16 B per row.
+  __syncthreads();
   if (!active) return;
+  constexpr int kORow = 272;  // 256 + 16: keeps ds_read_b128 aligned, spreads the row-per-lane writes
+  char* obuf = smem + w * (32 * kORow);
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     float l = l_run[qb];
@@ -654,23 +666,35 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(a2), "+v"(b2));
       l = a2;
     }
-    if (m[qb] < E) {
-      float den = l;
-      if (a.sinks) den += fast_exp2(a.sinks[head] * kLog2e - m_run[qb]);
-      const float inv = 1.0f / den;
-      uint16_t* op = a.o + (qo0 + m[qb]) * a.o_stride_t + head * a.o_stride_h + 4 * h;
+    float den = l;
+    if (a.sinks) den += fast_exp2(a.sinks[head] * kLog2e - m_run[qb]);
+    const float inv = 1.0f / den;
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
+    for (int db = 0; db < DB; ++db) {
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {  // registers 4 gq .. 4 gq + 3 = d 32 db + 8 gq + 4 h + 0..3
-          u32x2 pk2;
-          pk2[0] = pack2<T>(oacc[qb][db][4 * gq] * inv, oacc[qb][db][4 * gq + 1] * inv);
-          pk2[1] = pack2<T>(oacc[qb][db][4 * gq + 2] * inv, oacc[qb][db][4 * gq + 3] * inv);
-          *reinterpret_cast<u32x2*>(op + 32 * db + 8 * gq) = pk2;
-        }
+      for (int gq = 0; gq < 4; ++gq) {  // registers 4 gq .. 4 gq + 3 = d 32 db + 8 gq + 4 h + 0..3
+        u32x2 pk2;
+        pk2[0] = pack2<T>(oacc[qb][db][4 * gq] * inv, oacc[qb][db][4 * gq + 1] * inv);
+        pk2[1] = pack2<T>(oacc[qb][db][4 * gq + 2] * inv, oacc[qb][db][4 * gq + 3] * inv);
+        *reinterpret_cast<u32x2*>(obuf + ql * kORow + (32 * db + 8 * gq + 4 * h) * 2) = pk2;
       }
-      if (a.lse && h == 0)
-        a.lse[(qo0 + m[qb]) * a.lse_stride_t + head * a.lse_stride_h] = m_run[qb] * kLn2 + __logf(l);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int32_t row0 = qbase + 32 * qb;  // first query of this block
+#pragma unroll
+    for (int pss = 0; pss < 8; ++pss) {
+      const int row = 4 * pss + (lane >> 4), chunk = lane & 15;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(obuf + row * kORow + chunk * 16);
+      if (row0 + row < E)
+        *reinterpret_cast<u32x4*>(a.o + (qo0 + row0 + row) * a.o_stride_t + head * a.o_stride_h + 8 * chunk) = v;
+    }
+    if (a.lse && h == 0 && m[qb] < E)
+      a.lse[(qo0 + m[qb]) * a.lse_stride_t + head * a.lse_stride_h] = m_run[qb] * kLn2 + __logf(l);
+    if (qb + 1 < QB) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 #if RX_EXT32_STAMP
@@ -747,11 +771,25 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
-  constexpr int QB = RX_EXT32_QB, NW = 8 / QB;  // 256 queries per workgroup either way
-  a.mblocks = (p->max_extend_len + 255) / 256;
+  constexpr int QB = RX_EXT32_QB;
+  // Workgroup size.  One 256-query workgroup per CU (8 waves) is best when a (request, head, query block)
+  // walks many tiles (config 3: 60 tiles, 739 vs 706 TFLOP/s); with few tiles the per-workgroup
+  // prologue / epilogue and the launch itself dominate and two 128-query workgroups per CU overlap them
+  // (no prefix, 2 Ki new tokens: 452 -> 512; 512 + 128: 356 -> 493).  Estimated tiles per workgroup from
+  // the host-side hints: (mean prefix + half the longest extend) / 64.
+  const int est_tiles = (p->avg_kv_len_hint + p->max_extend_len / 2) / kTok;
+  const bool small_wg = QB == 1 && est_tiles < RX_EXT32_SMALL_WG_TILES && !getenv("RX_EXT32_FORCE_NW8");
+  const int nw = small_wg ? 4 : 8 / QB;
+  a.mblocks = (p->max_extend_len + nw * QB * 32 - 1) / (nw * QB * 32);
   a.kv_fp8 = p->kv.kv_fp8;
-  if (a.kv_fp8) launch32_nw<NW, QB, true>(a, p->dtype == RX_BF16, p->kv_indices_is_i64 != 0, linear, p->v_scale != 1.0f, s);
-  else launch32_nw<NW, QB, false>(a, p->dtype == RX_BF16, p->kv_indices_is_i64 != 0, linear, p->v_scale != 1.0f, s);
+  const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0, vsc = p->v_scale != 1.0f;
+  if (small_wg) {
+    if (a.kv_fp8) launch32_nw<4, 1, true>(a, bf, i64, linear, vsc, s);
+    else launch32_nw<4, 1, false>(a, bf, i64, linear, vsc, s);
+  } else {
+    if (a.kv_fp8) launch32_nw<8 / QB, QB, true>(a, bf, i64, linear, vsc, s);
+    else launch32_nw<8 / QB, QB, false>(a, bf, i64, linear, vsc, s);
+  }
   return RX_OK;
 }
 

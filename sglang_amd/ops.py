@@ -500,6 +500,8 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         p.lse_stride_t, p.lse_stride_h = lse_extend.stride(0), lse_extend.stride(1)
     p.bs = qo_indptr.shape[0] - 1
     p.max_extend_len = int(max_len_extend)
+    if kv_indices is not None and p.bs > 0:
+        p.avg_kv_len_hint = min(int(kv_indices.numel() // p.bs), 2 ** 31 - 1)
     if unified:
         hnd = kv_layout is not None
         p.num_kv_heads = k_buffer.shape[1] if hnd else k_buffer.shape[-2]
