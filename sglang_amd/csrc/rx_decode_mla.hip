@@ -307,6 +307,9 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
     // ---- stage the next tile into the other buffer -------------------------------------------------
     if (t + 1 < ntiles) {
       write_lds((t + 1) & 1, stg[(u + 1) % DEPTH]);
+#if RX_MLA_STAMP == 2
+      MLA_STAMP(5);  // finer diagnostic: slot 5 = the LDS write (incl. its vmcnt waits), 3 = the re-issue
+#endif
       if (t + 1 + DEPTH < ntiles) {
         issue_loads(stg[(u + 1) % DEPTH]);
         if (t + 2 + DEPTH < ntiles) load_slots(t + 2 + DEPTH);
