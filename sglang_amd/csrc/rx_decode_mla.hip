@@ -89,11 +89,22 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
 
-  int bid = blockIdx.x;  // split slowest (XCD balance, see rx_decode.hip)
-  const int qb = bid % a.qblocks;
-  bid /= a.qblocks;
-  const int b = bid % a.bs;
-  const int split = bid / a.bs;
+  // Block index -> (request, split, 16-head q block).  The q blocks of one (request, split) read the SAME
+  // latent rows; workgroups are dealt round-robin to the 8 XCDs, so with the q block as the fastest index
+  // (the plain order) the up-to-8 blocks that share rows land on 8 different L2s and the rows are fetched
+  // from HBM up to 8 times (TP=1 DeepSeek: 128 heads = 8 q blocks).  Here the XCD is bid % 8, the
+  // (request, split) pair is bound to that XCD and its q blocks follow each other on it.  Split slowest
+  // (see rx_decode.hip).
+  int qb, b, split;
+  {
+    const int G = a.qblocks;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    qb = j % G;
+    const int r = (j / G) * 8 + xcd;  // (request, split) pair
+    if (r >= a.bs * a.max_kv_splits) return;
+    b = r % a.bs;
+    split = r / a.bs;
+  }
 
   int32_t seq_len;
   const IdxT* idx;
@@ -394,7 +405,8 @@ int launch_decode_mla(const rx_decode_params* p, hipStream_t s) {
   a.xai_len = p->xai_temperature_len;
   const bool linear = p->kv.page_size == 1 || p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride;
   const bool idx64 = p->kv_indices != nullptr && p->kv_indices_is_i64;
-  const unsigned grid = static_cast<unsigned>(a.bs) * a.qblocks * a.max_kv_splits;
+  const unsigned pairs = static_cast<unsigned>(a.bs) * a.max_kv_splits;
+  const unsigned grid = (pairs + 7) / 8 * 8 * a.qblocks;  // whole groups of 8 pairs (one per XCD)
   const bool kv8 = p->kv.kv_fp8 != 0;
 #define RX_MLA_L(TT, IT, LIN)                                                                          \
   do {                                                                                                 \

@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sglang_amd import ops  # noqa: E402
 
-bs, ctx, hq, dk, dv, ps = 64, 8192, 16, 576, 512, int(os.environ.get("PS", "1"))
+bs, ctx, hq, dk, dv, ps = int(os.environ.get("BS", "64")), int(os.environ.get("CTX", "8192")), int(os.environ.get("HQ", "16")), 576, 512, int(os.environ.get("PS", "1"))
 dev = "cuda"
 pool = bs * ctx + ps
 kv = torch.empty(pool, 1, dk, dtype=torch.bfloat16, device=dev).normal_()
