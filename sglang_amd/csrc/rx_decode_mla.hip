@@ -52,6 +52,9 @@ struct MlaArgs {
 #ifndef RX_MLA_STAMP
 #define RX_MLA_STAMP 0  // 1: diagnostic build, s_memtime phase stamps overwrite the split's first partial row
 #endif
+#ifndef RX_MLA_SPLIT_S
+#define RX_MLA_SPLIT_S 1  // 1: the four waves split the score block and exchange partial sums; 0: each wave computes all of it
+#endif
 #ifndef RX_MLA_PD
 #define RX_MLA_PD 4  // K-fragment prefetch distance (LDS reads in flight ahead of the MFMA)
 #endif
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
   using KvV = std::conditional_t<KV8, u32x2, u32x4>;
   constexpr int KS = kMlaDk / 32;       // 18 k-steps
   constexpr int NBW = kMlaDv / 16 / 4;  // 8 d-blocks of 16 per wave
-  __shared__ __attribute__((aligned(16))) char smem[2 * kMlaTile * kMlaLdsRow];
+  // two staged tiles + (split-S form) the 4 x 1 KiB exchange of partial score blocks
+  __shared__ __attribute__((aligned(16))) char smem[2 * kMlaTile * kMlaLdsRow + (RX_MLA_SPLIT_S ? 4 * 64 * 16 : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -135,12 +139,18 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
   }
   const int ntiles = (hi - lo + kMlaTile - 1) / kMlaTile;
 
-  // ---- Q^T fragments for all 18 k-steps (72 VGPRs) ------------------------------------------------
-  vec8 qf[KS];
+  // ---- Q^T fragments ------------------------------------------------------------------------------
+  // split-S form (default): the score block S^T[32 tokens][16 heads] is cut four ways -- wave w computes
+  // token block (w & 1) over k-steps [9 (w >> 1), +9) -- and the partial sums are exchanged through LDS, so
+  // a wave issues 9 MFMAs (and keeps 9 Q fragments) instead of the 36 / 18 of the redundant form.  The sum
+  // is taken in one fixed order, so every wave still holds bitwise-identical scores.
+  constexpr int KSW = RX_MLA_SPLIT_S ? KS / 2 : KS;  // k-steps whose Q fragments this wave keeps
+  const int ks0 = RX_MLA_SPLIT_S ? KSW * (w >> 1) : 0;
+  vec8 qf[KSW];
   {
-    const uint16_t* qp = a.q + b * a.q_stride_t + (q_valid ? h : 0) * a.q_stride_h + 8 * g;
+    const uint16_t* qp = a.q + b * a.q_stride_t + (q_valid ? h : 0) * a.q_stride_h + 8 * g + 32 * ks0;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
+    for (int s = 0; s < KSW; ++s) {
       u32x4 raw = q_valid ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
       qf[s] = __builtin_bit_cast(vec8, raw);
     }
@@ -243,6 +253,26 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
     // a 16x16x32 MFMA 16; hipcc left alone reads two ahead and the in-order wave then waits on LDS
     // before nearly every one of the 36 MFMAs (measured: ~10k cycles per tile, every pipe < 25 % busy).
     f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#if RX_MLA_SPLIT_S
+    {
+      constexpr int PD = KSW < RX_MLA_PD ? KSW : RX_MLA_PD;
+      u32x4 kf[KSW];
+      const char* kb0 = kt + ((w & 1) * 16 + r) * kMlaLdsRow + g * 16 + ks0 * 64;
+#pragma unroll
+      for (int i = 0; i < PD; ++i) kf[i] = *reinterpret_cast<const u32x4*>(kb0 + i * 64);
+      f32x4 part = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KSW; ++i) {
+        if (i + PD < KSW) kf[i + PD] = *reinterpret_cast<const u32x4*>(kb0 + (i + PD) * 64);
+        part = T::mfma(__builtin_bit_cast(vec8, kf[i]), qf[i], part);
+      }
+      f32x4* xch = reinterpret_cast<f32x4*>(smem + 2 * kMlaTile * kMlaLdsRow);
+      xch[w * 64 + lane] = part;
+      __syncthreads();
+      sacc[0] = xch[0 * 64 + lane] + xch[2 * 64 + lane];
+      sacc[1] = xch[1 * 64 + lane] + xch[3 * 64 + lane];
+    }
+#else
     {
       constexpr int NF = 2 * KS, PD = KV8 ? 2 * RX_MLA_PD : RX_MLA_PD;  // fp8 rows leave 18 registers for it (+5 %)
       u32x4 kf[NF];
@@ -264,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
     }
+#endif
     MLA_STAMP(0);
     // ---- online softmax (identical in all four waves) -----------------------------------------------
     float sv[8];
