@@ -82,7 +82,7 @@ template <typename T, typename IdxT, bool LINEAR, bool KV8>
 __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
   using vec8 = typename T::vec8;
   using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;
-  using KvV = std::conditional_t<KV8, u32x2, u32x4>;
+  using KvV = u32x4;  // 16 B per lane and load: 8 elements of a 16-bit row, 16 of an fp8 row
   constexpr int KS = kMlaDk / 32;       // 18 k-steps
   constexpr int NBW = kMlaDv / 16 / 4;  // 8 d-blocks of 16 per wave
   // two staged tiles + (split-S form) the 4 x 1 KiB exchange of partial score blocks
@@ -160,14 +160,19 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
   // state (Q loads possibly pending) into the loop header and would otherwise emit vmcnt(0) in front
   // of the first MFMA of EVERY iteration, i.e. wait for the next tile's prefetch before computing.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
-  // ---- cooperative staging: thread handles chunks c = tid + 256 i, row = c / 72, col = c % 72 ------
-  int st_row[kMlaStage], st_col[kMlaStage];
+  // ---- cooperative staging: thread handles 16-byte global chunks c = tid + 256 i of the tile --------
+  // 16-bit rows: 72 chunks per row, 9 per thread.  fp8 rows: 36 chunks per row = 1152 per tile = 4.5 per
+  // thread (the fifth pass is taken by the first 128 threads); one chunk becomes two 16-byte LDS chunks.
+  constexpr int CPRG = KV8 ? kMlaChunks / 2 : kMlaChunks;                      // global chunks per row
+  constexpr int NST = (kMlaTile * CPRG + 255) / 256;                           // passes: 9 or 5
+  int st_row[NST], st_col[NST];
 #pragma unroll
-  for (int i = 0; i < kMlaStage; ++i) {
-    const int c = tid + 256 * i;
-    st_row[i] = c / kMlaChunks;
-    st_col[i] = c % kMlaChunks;
+  for (int i = 0; i < NST; ++i) {
+    const int c = min(tid + 256 * i, kMlaTile * CPRG - 1);  // the partial last pass re-reads the last chunk
+    st_row[i] = c / CPRG;
+    st_col[i] = c % CPRG;
   }
+  const bool last_pass_on = tid + 256 * (NST - 1) < kMlaTile * CPRG;
   // Tiles in flight per workgroup (register sets).  2 was tried for fp8 rows (half the staging
   // registers): 114.8 -> 120.9 us at the config-5 shape, i.e. the fp8 kernel is bound by the per-tile
   // compute path (S^T, softmax, staging, barrier: ~5 k cycles), not by bytes in flight.
@@ -175,29 +180,32 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
 #define RX_MLA_DEPTH 1
 #endif
   constexpr int DEPTH = RX_MLA_DEPTH;
-  KvV stg[DEPTH][kMlaStage];
-  int32_t slot_n[kMlaStage];  // slots of the tile whose loads are issued next (fetched a tile early)
+  KvV stg[DEPTH][NST];
+  int32_t slot_n[NST];  // slots of the tile whose loads are issued next (fetched a tile early)
   auto load_slots = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < kMlaStage; ++i)
+    for (int i = 0; i < NST; ++i)
       slot_n[i] = static_cast<int32_t>(idx[min(lo + t * kMlaTile + st_row[i], hi - 1)]);
   };
-  auto issue_loads = [&](KvV (&stg)[kMlaStage]) {
+  auto issue_loads = [&](KvV (&stg)[NST]) {
 #pragma unroll
-    for (int i = 0; i < kMlaStage; ++i)
+    for (int i = 0; i < NST; ++i)
       stg[i] = *reinterpret_cast<const KvV*>(
           reinterpret_cast<const KvE*>(a.kv_buf) +
-          mla_slot_off<LINEAR>(slot_n[i], a.page_size, a.page_stride, a.tok_stride) + 8 * st_col[i]);
+          mla_slot_off<LINEAR>(slot_n[i], a.page_size, a.page_stride, a.tok_stride) + (KV8 ? 16 : 8) * st_col[i]);
   };
-  auto write_lds = [&](int buf, const KvV (&stg)[kMlaStage]) {
+  auto write_lds = [&](int buf, const KvV (&stg)[NST]) {
     char* kt = smem + buf * kMlaTile * kMlaLdsRow;
 #pragma unroll
-    for (int i = 0; i < kMlaStage; ++i)
-    {
-      u32x4 v16;
-      if constexpr (KV8) v16 = fp8x8_to_16<T>(stg[i]);
-      else v16 = stg[i];
-      *reinterpret_cast<u32x4*>(kt + st_row[i] * kMlaLdsRow + st_col[i] * 16) = v16;
+    for (int i = 0; i < NST; ++i) {
+      if (i == NST - 1 && !last_pass_on) break;
+      char* dst = kt + st_row[i] * kMlaLdsRow + st_col[i] * (KV8 ? 32 : 16);
+      if constexpr (KV8) {
+        *reinterpret_cast<u32x4*>(dst) = fp8x8_to_16<T>(u32x2{stg[i][0], stg[i][1]});
+        *reinterpret_cast<u32x4*>(dst + 16) = fp8x8_to_16<T>(u32x2{stg[i][2], stg[i][3]});
+      } else {
+        *reinterpret_cast<u32x4*>(dst) = stg[i];
+      }
     }
   };
 
