@@ -24,6 +24,9 @@
 #ifndef RX_EXT32_SMALL_WG_TILES
 #define RX_EXT32_SMALL_WG_TILES 28  // below this many estimated tiles per workgroup: 128-query workgroups
 #endif
+#ifndef RX_EXT32_PRIO
+#define RX_EXT32_PRIO 0
+#endif
 #ifndef RX_EXT32_STAMP
 #define RX_EXT32_STAMP 0  // 1: diagnostic build with s_memtime phase stamps (tools/ext_stamps.py); outputs are clobbered
 #endif
@@ -381,6 +384,10 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   // The two tile bodies live in two separate inner loops (runs of fast tiles, runs of boundary
   // tiles): with both bodies inside one loop hipcc's allocator spills 147 registers, each alone fits.
   // Waves of one workgroup may be in different loops at the same t; every tile is one barrier either way.
+#if RX_EXT32_PRIO
+  // static priority for the second-dispatched half (MI355X_MICROARCH.md, Two waves per SIMD, item 4)
+  if (w >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   int t = 0;
   while (t < nt) {
     for (; t + 3 < nt; ++t) {
