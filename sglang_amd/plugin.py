@@ -50,6 +50,8 @@ class _RunnerView:
         self.page_size = getattr(mr, "page_size", 1)
         self.server_args = mr.server_args
         self.tp_size = getattr(mr, "tp_size", 1)
+        # hybrid sliding-window models: window metadata is built next to the full one (triton_backend.py:259-276)
+        self.sliding_window_size = getattr(mr, "sliding_window_size", None)
 
         class _MC:
             num_attention_heads = mr.model_config.num_attention_heads
