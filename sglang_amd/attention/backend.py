@@ -331,6 +331,17 @@ class HipRadixAttnBackend:
     def on_after_cuda_graph_warmup(self):
         pass
 
+    def draft_extend_metadata_captured_in_graph(self) -> bool:
+        return False  # base_attn_backend.py:94-99: replay metadata is rebuilt eagerly, out of graph
+
+    def update_verify_buffers_to_fill_after_draft(self, spec_info, cuda_graph_bs):
+        pass  # triton_backend.py:1212-1215: the tree mask is read in place, nothing derived from it
+
+    def forward_mixed(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache: bool = True):
+        # base_attn_backend.py:259-269 (NPU-only hook in the reference's dispatch); MIXED batches take the
+        # extend kernels here, as in forward().
+        return self.forward_extend(q, k, v, layer, forward_batch, save_kv_cache)
+
     # ------------------------------------------------------------------ forward
     def forward(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache: bool = True, **kwargs):
         mode = forward_batch.forward_mode

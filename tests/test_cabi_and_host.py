@@ -182,3 +182,47 @@ def test_forward_batch_constructors():
     fd = ForwardBatch.for_decode(torch.tensor([1, 2]), torch.tensor([10, 7]), torch.tensor([5, 6]))
     assert fd.forward_mode == ForwardMode.DECODE and fd.positions.tolist() == [9, 6]
     assert fd.seq_lens_sum == 17
+
+
+REF_ABC = "/root/reference/python/sglang/srt/layers/attention/base_attn_backend.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_ABC), reason="reference tree not mounted (GPU box)")
+def test_backend_satisfies_reference_attention_backend_abc():
+    """Drop-in check against the reference's own plugin interface: load its AttentionBackend ABC
+    (base_attn_backend.py:30-290) stand-alone and check that HipRadixAttnBackend overrides every hook the
+    model runner / graph runner calls, with call-compatible signatures."""
+    import importlib.util
+    import inspect
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import _ref_import
+
+    _ref_import.install()
+    spec = importlib.util.spec_from_file_location("_ref_base_attn_backend", REF_ABC)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ref = mod.AttentionBackend
+    from sglang_amd.attention.backend import HipRadixAttnBackend as mine
+
+    glued = type("Glued", (mine, ref), {})
+    assert not getattr(glued, "__abstractmethods__", None)
+    # hooks whose base implementation raises NotImplementedError must be overridden ...
+    must = ["init_forward_metadata", "init_forward_metadata_out_graph", "init_forward_metadata_in_graph",
+            "init_cuda_graph_state", "get_cuda_graph_seq_len_fill_value", "forward", "forward_decode",
+            "forward_extend", "forward_mixed", "update_verify_buffers_to_fill_after_draft",
+            "on_after_cuda_graph_warmup", "draft_extend_metadata_captured_in_graph", "support_triton"]
+    for name in must:
+        assert name in vars(mine), name
+        ref_params = inspect.signature(getattr(ref, name)).parameters
+        my_sig = inspect.signature(getattr(mine, name))
+        # ... and accept every positional / keyword the reference passes
+        takes_kwargs = any(p.kind is p.VAR_KEYWORD for p in my_sig.parameters.values())
+        for pname, p in ref_params.items():
+            if p.kind in (p.VAR_KEYWORD, p.VAR_POSITIONAL):
+                continue
+            assert pname in my_sig.parameters or takes_kwargs, f"{name}: missing parameter {pname}"
+    # the breakable-graph / chunked-prefix paths are opt-in flags on the ABC; we leave them off
+    assert ref.use_captured_forward_metadata_for_breakable_cuda_graph is False
+    assert ref.supports_full_cuda_graph_chunked_prefix is False
