@@ -179,9 +179,47 @@ typedef struct rx_decode_params {
   /* Grok temperature (decode_attention.py:156-160,212-213): L > 0 multiplies request b's scores by
    * log2(seq_len_b - 1) / log2(L) when seq_len_b - 1 > L (after scale and cap); <= 0 = off */
   int32_t xai_temperature_len;
+  /* Shared-prefix (cascade) decode, see rx_shared_prefix_plan.  kv_start (int32[bs] or NULL, lookup mode
+   * (b) only): request b attends tokens [kv_start[b], seq_len_b) of its req_to_token row; split sizes and
+   * the stage-2 merge use that suffix length, the Grok temperature still uses seq_len_b.
+   * extra_o / extra_lse: num_extra_partials more partial results per (request, head) -- dense
+   * [num_extra, bs, Hq, Dv] of dtype (already divided by their own softmax sums, NOT multiplied by v_scale)
+   * and natural-log LSEs fp32 [num_extra, bs, Hq] (-inf = empty partial, row ignored) -- that stage 2
+   * merges with the kv splits.  Needs max_kv_splits > 1 (there is no merge in the single-pass form). */
+  const int32_t* kv_start;
+  const void* extra_o;
+  const float* extra_lse;
+  int32_t num_extra_partials;
+  /* 0 = stage 1 then stage 2 (default); 1 = stage 1 only (partials to attn_logits / attn_lse);
+   * 2 = stage 2 only.  Lets a caller produce the extra partials on another stream while stage 1 runs
+   * and join before the merge.  1 / 2 need max_kv_splits > 1. */
+  int32_t stages;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);
+
+/* ---- shared-prefix (cascade) decode plan ----------------------------------------------------------
+ * SURVEY 8f-2.  The reference has only the building block (merge_state); with RadixAttention every request
+ * of a batch that hit the same radix-tree path carries the SAME leading slots in its req_to_token row
+ * (radix_cache.py:352-430 match_prefix -> allocation.py:55-101 write_cache_indices), and its decode
+ * kernel re-reads those rows once per request.  This plan finds the batch-wide common prefix ON DEVICE
+ * (no host sync; graph-replay safe) so that the caller can
+ *   1. run rx_extend_attn once over the shared rows with all bs decode queries as the M dimension
+ *      (num_chunks pseudo-requests, one per chunk of the prefix; skip_extend, not causal, LSE out),
+ *   2. run rx_decode_attn over the per-request suffixes (kv_start) and let its stage 2 merge the
+ *      chunk partials (extra_o / extra_lse).
+ * Outputs (all int32, device):
+ *   plan[0] = L = largest t <= min(min_b seq_len_b, max_shared) with
+ *             req_to_token[rpi[b], 0:t] == req_to_token[rpi[0], 0:t] for every b; 0 if that is < min_shared
+ *   plan[1]   scratch
+ *   chunk_indptr[0..num_chunks] = min(i * per, L), per = ceil(ceil(L / num_chunks) / chunk_align) * chunk_align
+ *   shared_indices[0:L] = req_to_token[rpi[0], 0:L]      (capacity max_shared)
+ *   kv_start[b] = L,  suffix_lens[b] = seq_len_b - L. */
+int rx_shared_prefix_plan(const int32_t* req_to_token, int64_t req_row_stride, const void* req_pool_indices,
+                          int req_pool_indices_is_i64, const void* seq_lens, int seq_lens_is_i64, int bs,
+                          int32_t max_shared, int32_t min_shared, int num_chunks, int chunk_align,
+                          int32_t* plan, int32_t* chunk_indptr, int32_t* shared_indices, int32_t* kv_start,
+                          int32_t* suffix_lens, void* stream);
 
 /* ---- K7: extend attention ---------------------------------------------------------------
  * extend_attention_fwd (kernels/ops/attention/extend_attention.py:664-812) -> _fwd_kernel

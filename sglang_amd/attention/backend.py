@@ -86,7 +86,8 @@ class HipRadixAttnBackend:
     supports_ragged_verify_graph: bool = False
 
     def __init__(self, model_runner, decode_index_mode: str = "paged",
-                 max_kv_splits: Optional[int] = None, split_policy: str = "native"):
+                 max_kv_splits: Optional[int] = None, split_policy: str = "native",
+                 cascade_decode: bool = False, cascade_min_bs: int = 8, cascade_min_shared: int = 256):
         self.device = model_runner.device
         self.req_to_token_pool = model_runner.req_to_token_pool
         self.token_to_kv_pool = model_runner.token_to_kv_pool
@@ -135,6 +136,20 @@ class HipRadixAttnBackend:
         self._md_version = 0  # bumped by every init_forward_metadata_out_graph
         self._decode_launchers = {}  # layer_id -> ops.DecodeLauncher
         self._cur_fb = None
+        # shared-prefix (cascade) decode, SURVEY 8f-2: opt-in (a batch without a common prefix pays two empty
+        # launches per layer); the common prefix itself is found on the device every forward
+        self.cascade_decode = bool(cascade_decode) and not self._is_mla_pool and self.sliding_window_size is None
+        self.cascade_min_bs, self.cascade_min_shared = int(cascade_min_bs), int(cascade_min_shared)
+        self._cascade = None
+        self._cascade_on = False
+        self._model_dtype = getattr(model_runner, "dtype", None)
+
+    def _q_dtype(self, k_buffer: torch.Tensor):
+        """dtype of q / o: the runner's model dtype, else the pool's if that is a 16-bit float."""
+        dt = getattr(self, "_model_dtype", None)
+        if dt in (torch.bfloat16, torch.float16):
+            return dt
+        return k_buffer.dtype if k_buffer.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
 
     # ------------------------------------------------------------------ scratch
     def _scratch(self, bs: int, splits: Optional[int] = None):
@@ -186,6 +201,21 @@ class HipRadixAttnBackend:
 
     def _decode_metadata(self, fb: ForwardBatch, bs: int, in_capture: bool) -> ForwardMetadata:
         use_graph_bufs = self._graph is not None and (in_capture or self._graph.get("active"))
+        self._cascade_on = self.cascade_decode and bs >= self.cascade_min_bs
+        if self._cascade_on:
+            if self._cascade is None:
+                kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
+                if kb.shape[-1] not in (64, 128) or kb.shape[-1] != self.v_head_dim:
+                    self.cascade_decode = self._cascade_on = False
+                else:
+                    self._cascade = ops.CascadeDecode(
+                        self.req_to_token_pool.size, self.num_head, self.num_kv_head, self.v_head_dim,
+                        self._q_dtype(kb), self.device,
+                        max_shared=self.req_to_token.shape[1], cu_count=self.device_core_count,
+                        min_shared=self.cascade_min_shared, max_kv_splits=self.native_split_cap)
+            if self._cascade_on:
+                self._cascade.plan(self.req_to_token, fb.req_pool_indices, fb.seq_lens)
+                return ForwardMetadata(None, None, None, None, None, None, None, 1)
         if self.split_policy == "native" and self.sliding_window_size is None:
             return self._decode_metadata_native(fb, bs, use_graph_bufs)
         splits_needed = True
@@ -369,6 +399,14 @@ class HipRadixAttnBackend:
         md = self.forward_metadata
         q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
+        if self._cascade_on and not (getattr(layer, "xai_temperature_len", -1) or 0) > 0:
+            k_descale, v_descale = self._scales(layer)
+            k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+            hnd = getattr(self.token_to_kv_pool, "use_hnd", False)
+            self._cascade(q3, k_buf, v_buf, o3, layer.scaling, k_descale, v_descale, layer.logit_cap,
+                          sinks if sinks is None or sinks.dtype == torch.float32 else sinks.float(),
+                          page_size=self.page_size, kv_layout=ops.kv_layout_hnd(k_buf, v_buf) if hnd else None)
+            return o
         ln = self._decode_launchers.get(layer.layer_id)
         if ln is None:
             k_descale, v_descale = self._scales(layer)

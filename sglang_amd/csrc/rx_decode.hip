@@ -50,6 +50,11 @@ struct DecodeArgs {
   const float* sinks;
   int32_t kv_fp8;  // pool holds fp8 e4m3fn bytes (strides in bytes)
   int32_t xai_len; // Grok temperature length or <= 0
+  const int32_t* kv_start;   // mode (b): request b attends tokens [kv_start[b], seq_len_b) only (or NULL)
+  const uint16_t* extra_o;   // [num_extra, bs, hq, dv] partial outputs merged by stage 2 (or NULL)
+  const float* extra_lse;    // [num_extra, bs, hq]
+  int32_t num_extra;
+  int32_t stages;  // 0 both, 1 stage 1 only, 2 stage 2 only
 };
 
 // Grok temperature factor of a request (decode_attention.py:156-160): the single query sits at seq_len-1
@@ -85,21 +90,33 @@ __device__ __forceinline__ int64_t slot_offset(int64_t slot, int32_t page_size,
 }
 
 struct SeqInfo {
-  int32_t seq_len;
-  const void* idx;  // token -> slot list of this request
+  int32_t seq_len;   // tokens this launch attends
+  int32_t full_len;  // the request's sequence length (position of the query + 1)
+  const void* idx;   // token -> slot list of this request
 };
+
+// attended / full length of request b (mode (b) with kv_start: the suffix only)
+__device__ __forceinline__ int32_t attended_len(const DecodeArgs& a, int b, int32_t& start) {
+  start = 0;
+  if (a.kv_indices) return a.kv_indptr[b + 1] - a.kv_indptr[b];
+  const int32_t full = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
+  if (a.kv_start) start = min(max(a.kv_start[b], 0), full);
+  return full - start;
+}
 
 template <typename IdxT>
 __device__ __forceinline__ SeqInfo seq_info(const DecodeArgs& a, int b) {
   SeqInfo s;
   if (a.kv_indices) {
     const int32_t beg = a.kv_indptr[b];
-    s.seq_len = a.kv_indptr[b + 1] - beg;
+    s.seq_len = s.full_len = a.kv_indptr[b + 1] - beg;
     s.idx = reinterpret_cast<const IdxT*>(a.kv_indices) + beg;
   } else {
     const int64_t req = load_idx(a.req_pool_indices, b, a.rpi64);
-    s.seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
-    s.idx = a.req_to_token + req * a.req_row_stride;  // IdxT == int32_t in this mode
+    int32_t start;
+    s.seq_len = attended_len(a, b, start);
+    s.full_len = s.seq_len + start;
+    s.idx = a.req_to_token + req * a.req_row_stride + start;  // IdxT == int32_t in this mode
   }
   return s;
 }
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
   float m_run = -INFINITY;  // running max (log2 domain), identical in the 4 lanes of a q head
   float l_run = 0.f;        // this lane's partial row sum
 
-  const float xai = xai_factor(a.xai_len, si.seq_len);
+  const float xai = xai_factor(a.xai_len, si.full_len);
   const float scale_log2 = a.sm_scale * kLog2e * xai;
 
   auto load_slots = [&](int t, int64_t& s0, int64_t& s1) {
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(64) void decode_generic_kernel(const DecodeArgs a, 
     for (int d = 0; d < dk; ++d) s += qs[d] * T::to_f32(kp[d]);
     s *= a.sm_scale;
     if (a.logit_cap > 0.f) s = a.logit_cap * tanhf(s / a.logit_cap);
-    s = valid ? s * (kLog2e * xai_factor(a.xai_len, si.seq_len)) : -INFINITY;
+    s = valid ? s * (kLog2e * xai_factor(a.xai_len, si.full_len)) : -INFINITY;
     float mt = s;
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) mt = fmaxf(mt, __shfl_xor(mt, dd));
@@ -512,12 +529,8 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const DecodeArgs a, i
   const int d = static_cast<int>(gid % dv4) * 4;
   const int h = static_cast<int>(bh % a.hq);
   const int b = static_cast<int>(bh / a.hq);
-  int32_t seq_len;
-  if (a.kv_indices) {
-    seq_len = a.kv_indptr[b + 1] - a.kv_indptr[b];
-  } else {
-    seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
-  }
+  int32_t kv_begin;
+  const int32_t seq_len = attended_len(a, b, kv_begin);
   const int32_t splits = a.num_kv_splits ? a.num_kv_splits[b] : 1;
   // live splits are a prefix: split s covers [per s, min(per (s+1), seq_len))
   const int32_t per = ((seq_len + splits - 1) / splits + kMinBlockKV - 1) / kMinBlockKV * kMinBlockKV;
@@ -527,6 +540,8 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const DecodeArgs a, i
   const float* lse = a.attn_lse + row0;
   float e_max = -INFINITY;
   for (int s = 0; s < live; ++s) e_max = fmaxf(e_max, lse[s]);
+  const int64_t xstride = static_cast<int64_t>(a.bs) * a.hq;  // one extra partial = [bs, hq] rows
+  for (int x = 0; x < a.num_extra; ++x) e_max = fmaxf(e_max, a.extra_lse[x * xstride + bh]);
   float e_sum = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float* lp = a.attn_logits + row0 * dv + d;
@@ -535,6 +550,15 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const DecodeArgs a, i
     const float w = __expf(lse[s] - e_max);
     const f32x4 tv = *reinterpret_cast<const f32x4*>(lp + static_cast<int64_t>(s) * dv);
     acc += w * tv;
+    e_sum += w;
+  }
+  for (int x = 0; x < a.num_extra; ++x) {  // 16-bit partials of another pass (shared-prefix phase)
+    const float xl = a.extra_lse[x * xstride + bh];
+    if (!(xl > -INFINITY)) continue;  // empty partial: its row is undefined
+    const float w = __expf(xl - e_max);
+    const u32x2 raw = *reinterpret_cast<const u32x2*>(a.extra_o + (x * xstride + bh) * dv + d);
+    acc += w * f32x4{T::to_f32(static_cast<uint16_t>(raw[0] & 0xffff)), T::to_f32(static_cast<uint16_t>(raw[0] >> 16)),
+                     T::to_f32(static_cast<uint16_t>(raw[1] & 0xffff)), T::to_f32(static_cast<uint16_t>(raw[1] >> 16))};
     e_sum += w;
   }
   if (a.sinks) e_sum += __expf(a.sinks[h] - e_max);
@@ -550,12 +574,8 @@ template <typename T>
 __global__ __launch_bounds__(128) void decode_merge_scalar_kernel(const DecodeArgs a, int dv) {
   const int h = blockIdx.x % a.hq;
   const int b = blockIdx.x / a.hq;
-  int32_t seq_len;
-  if (a.kv_indices) {
-    seq_len = a.kv_indptr[b + 1] - a.kv_indptr[b];
-  } else {
-    seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
-  }
+  int32_t kv_begin;
+  const int32_t seq_len = attended_len(a, b, kv_begin);
   const int32_t splits = a.num_kv_splits ? a.num_kv_splits[b] : 1;
   const int64_t row0 = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits;
   for (int d = threadIdx.x; d < dv; d += 128) {
@@ -574,6 +594,18 @@ __global__ __launch_bounds__(128) void decode_merge_scalar_kernel(const DecodeAr
         e_max = n_max;
       }
     }
+    for (int x = 0; x < a.num_extra; ++x) {
+      const int64_t xrow = (static_cast<int64_t>(x) * a.bs + b) * a.hq + h;
+      const float tl = a.extra_lse[xrow];
+      if (!(tl > -INFINITY)) continue;
+      const float tv = T::to_f32(a.extra_o[xrow * dv + d]);
+      const float n_max = fmaxf(tl, e_max);
+      const float old_scale = __expf(e_max - n_max);
+      const float w = __expf(tl - n_max);
+      acc = acc * old_scale + w * tv;
+      e_sum = e_sum * old_scale + w;
+      e_max = n_max;
+    }
     if (a.sinks) e_sum += __expf(a.sinks[h] - e_max);
     a.o[b * a.o_stride_t + h * a.o_stride_h + d] = T::from_f32(acc / e_sum * a.v_scale);
   }
@@ -582,7 +614,7 @@ __global__ __launch_bounds__(128) void decode_merge_scalar_kernel(const DecodeAr
 template <typename T>
 static void launch_merge(const DecodeArgs& a, int dv, hipStream_t s) {
   const bool vec = dv % 4 == 0 && ((a.o_stride_t | a.o_stride_h) & 3) == 0 &&
-                   (reinterpret_cast<uintptr_t>(a.o) & 7) == 0;
+                   (reinterpret_cast<uintptr_t>(a.o) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.extra_o) & 7) == 0;
   if (vec) {
     const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(a.bs) * a.hq * (dv >> 2) + 255) / 256);
     hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(grid), dim3(256), 0, s, a, dv);
@@ -594,6 +626,10 @@ static void launch_merge(const DecodeArgs& a, int dv, hipStream_t s) {
 template <typename T, typename IdxT, bool LINEAR>
 static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
   const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
+  if (a.stages == 2) {
+    launch_merge<T>(a, dv, s);
+    return check_launch("rx_decode_attn");
+  }
   if (mfma_ok) {
     const unsigned grid = static_cast<unsigned>(a.bs) * a.hkv * a.qblocks * a.max_kv_splits;
 #define RX_DEC(DD, K8) \
@@ -615,7 +651,7 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
     hipLaunchKernelGGL((decode_generic_kernel<T, IdxT, LINEAR>), dim3(grid), dim3(64),
                        dk * sizeof(float), s, a, dk, dv);
   }
-  if (a.max_kv_splits > 1)
+  if (a.max_kv_splits > 1 && a.stages != 1)
     launch_merge<T>(a, dv, s);
   return check_launch("rx_decode_attn");
 }
@@ -635,9 +671,11 @@ int launch_decode_mla(const rx_decode_params* p, hipStream_t s);  // rx_decode_m
 
 template <typename T>
 static int run_mla(const rx_decode_params* p, const DecodeArgs& a, hipStream_t s) {
-  const int rc = launch_decode_mla(p, s);
-  if (rc != RX_OK) return rc;
-  if (a.max_kv_splits > 1)
+  if (a.stages != 2) {
+    const int rc = launch_decode_mla(p, s);
+    if (rc != RX_OK) return rc;
+  }
+  if (a.max_kv_splits > 1 && a.stages != 1)
     launch_merge<T>(a, p->v_head_dim, s);
   return check_launch("rx_decode_attn(mla)");
 }
@@ -722,6 +760,18 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.sinks = p->sinks;
   a.kv_fp8 = p->kv.kv_fp8;
   a.xai_len = p->xai_temperature_len;
+  RX_REQUIRE(p->stages >= 0 && p->stages <= 2 && (p->stages == 0 || max_splits > 1),
+             "rx_decode_attn: stages = %d (1 / 2 need max_kv_splits > 1)", p->stages);
+  a.stages = p->stages;
+  a.kv_start = mode_a ? nullptr : p->kv_start;
+  a.num_extra = p->num_extra_partials > 0 ? p->num_extra_partials : 0;
+  a.extra_o = a.num_extra ? (const uint16_t*)p->extra_o : nullptr;
+  a.extra_lse = a.num_extra ? p->extra_lse : nullptr;
+  if (a.num_extra)
+    RX_REQUIRE(p->extra_o && p->extra_lse && max_splits > 1,
+               "rx_decode_attn: extra partials need extra_o, extra_lse and max_kv_splits > 1 (stage 2 merges them)");
+  RX_REQUIRE(!(mode_a && p->kv_start), "rx_decode_attn: kv_start applies to the req_to_token lookup only "
+             "(with kv_indices, build the list with rx_build_kv_indices' kv_start)");
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
@@ -733,6 +783,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
                    ((p->q_stride_t | p->q_stride_h | p->kv.k_tok_stride | p->kv.k_page_stride) % 8 == 0) &&
                    ((uintptr_t)p->q & 15) == 0 && ((uintptr_t)p->kv.k_buf & (p->kv.kv_fp8 ? 7 : 15)) == 0 &&
                    ((p->o_stride_t | p->o_stride_h) % 4 == 0) && ((uintptr_t)p->o & 7) == 0;
+  if (mla) RX_REQUIRE(!p->kv_start, "rx_decode_attn: kv_start is not supported on the MLA kernel");
   if (mla) return p->dtype == RX_BF16 ? run_mla<BF16>(p, a, s) : run_mla<F16>(p, a, s);
   return p->dtype == RX_BF16 ? dispatch_decode<BF16>(a, dk, dv, idx64, linear, s)
                              : dispatch_decode<F16>(a, dk, dv, idx64, linear, s);

@@ -690,4 +690,95 @@ int rx_move_kv(const uint64_t* data_ptrs, const int64_t* row_bytes, int num_bufs
   return check_launch("rx_move_kv");
 }
 
+namespace rx {
+// ---- shared-prefix (cascade) decode plan --------------------------------------------------------------
+// Three stream-ordered launches, all integer work on the 4-byte req_to_token table:
+//   init    : plan[1] = min(min_b seq_len_b, max_shared)
+//   compare : column t of every row against row rpi[0]; a mismatch lowers plan[1] to t (atomicMin)
+//   emit    : threshold, chunk boundaries, the shared slot list, kv_start / suffix_lens
+__global__ __launch_bounds__(256) void shared_prefix_init_kernel(const void* __restrict__ seq_lens, int sl64, int bs,
+                                                                 int32_t max_shared, int32_t* __restrict__ plan) {
+  __shared__ int32_t red[4];
+  int32_t m = max_shared;
+  for (int b = threadIdx.x; b < bs; b += 256) m = min(m, static_cast<int32_t>(load_idx(seq_lens, b, sl64)));
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = min(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) plan[1] = max(0, min(min(red[0], red[1]), min(red[2], red[3])));
+}
+
+constexpr int kPlanRows = 16;  // rows of the table one workgroup compares
+__global__ __launch_bounds__(256) void shared_prefix_compare_kernel(const int32_t* __restrict__ req_to_token,
+                                                                    int64_t row_stride,
+                                                                    const void* __restrict__ rpi, int rpi64, int bs,
+                                                                    int32_t* __restrict__ plan) {
+  const int32_t t = blockIdx.x * 256 + threadIdx.x;
+  // plan[1] only ever decreases while this kernel runs; a stale (larger) bound costs extra compares only
+  const int32_t bound = __atomic_load_n(plan + 1, __ATOMIC_RELAXED);
+  if (blockIdx.x * 256 >= bound) return;
+  const int b0 = 1 + blockIdx.y * kPlanRows;
+  const int32_t want = t < bound ? req_to_token[load_idx(rpi, 0, rpi64) * row_stride + t] : 0;
+  bool diff = false;
+#pragma unroll 4
+  for (int i = 0; i < kPlanRows; ++i) {
+    const int b = b0 + i;
+    if (b < bs && t < bound) diff |= req_to_token[load_idx(rpi, b, rpi64) * row_stride + t] != want;
+  }
+  // first differing column of this wave, one atomic per wave
+  const uint64_t mask = __ballot(diff);
+  if (mask != 0 && (threadIdx.x & 63) == 0)
+    atomicMin(plan + 1, (t & ~63) + static_cast<int32_t>(__builtin_ctzll(mask)));
+}
+
+__global__ __launch_bounds__(256) void shared_prefix_emit_kernel(
+    const int32_t* __restrict__ req_to_token, int64_t row_stride, const void* __restrict__ rpi, int rpi64,
+    const void* __restrict__ seq_lens, int sl64, int bs, int32_t min_shared, int num_chunks, int chunk_align,
+    int32_t* __restrict__ plan, int32_t* __restrict__ chunk_indptr, int32_t* __restrict__ shared_indices,
+    int32_t* __restrict__ kv_start, int32_t* __restrict__ suffix_lens) {
+  int32_t L = plan[1];
+  if (L < min_shared) L = 0;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid == 0) plan[0] = L;
+  if (gid <= num_chunks) {
+    const int32_t per = cdiv32(cdiv32(L, num_chunks), chunk_align) * chunk_align;
+    chunk_indptr[gid] = static_cast<int32_t>(min(static_cast<int64_t>(gid) * per, static_cast<int64_t>(L)));
+  }
+  if (gid < bs) {
+    kv_start[gid] = L;
+    suffix_lens[gid] = static_cast<int32_t>(load_idx(seq_lens, gid, sl64)) - L;
+  }
+  if (gid < L) shared_indices[gid] = req_to_token[load_idx(rpi, 0, rpi64) * row_stride + gid];
+}
+}  // namespace rx
+
+int rx_shared_prefix_plan(const int32_t* req_to_token, int64_t req_row_stride, const void* req_pool_indices,
+                          int req_pool_indices_is_i64, const void* seq_lens, int seq_lens_is_i64, int bs,
+                          int32_t max_shared, int32_t min_shared, int num_chunks, int chunk_align,
+                          int32_t* plan, int32_t* chunk_indptr, int32_t* shared_indices, int32_t* kv_start,
+                          int32_t* suffix_lens, void* stream) {
+  RX_REQUIRE(bs >= 0, "rx_shared_prefix_plan: bs < 0");
+  if (bs == 0) return RX_OK;
+  RX_REQUIRE(req_to_token && req_pool_indices && seq_lens && plan && chunk_indptr && shared_indices && kv_start &&
+                 suffix_lens,
+             "rx_shared_prefix_plan: null pointer");
+  RX_REQUIRE(max_shared >= 0 && min_shared >= 0 && num_chunks >= 1 && chunk_align >= 1 &&
+                 max_shared <= req_row_stride,
+             "rx_shared_prefix_plan: bad sizes (max_shared=%d min_shared=%d num_chunks=%d chunk_align=%d)",
+             max_shared, min_shared, num_chunks, chunk_align);
+  auto s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(rx::shared_prefix_init_kernel, dim3(1), dim3(256), 0, s, seq_lens, seq_lens_is_i64, bs,
+                     max_shared, plan);
+  if (bs > 1 && max_shared > 0)
+    hipLaunchKernelGGL(rx::shared_prefix_compare_kernel,
+                       dim3((max_shared + 255) / 256, (bs - 1 + rx::kPlanRows - 1) / rx::kPlanRows), dim3(256), 0, s,
+                       req_to_token, req_row_stride, req_pool_indices, req_pool_indices_is_i64, bs, plan);
+  const int n = max_shared > bs ? (max_shared > num_chunks + 1 ? max_shared : num_chunks + 1)
+                                : (bs > num_chunks + 1 ? bs : num_chunks + 1);
+  hipLaunchKernelGGL(rx::shared_prefix_emit_kernel, dim3((n + 255) / 256), dim3(256), 0, s, req_to_token,
+                     req_row_stride, req_pool_indices, req_pool_indices_is_i64, seq_lens, seq_lens_is_i64, bs,
+                     min_shared, num_chunks, chunk_align, plan, chunk_indptr, shared_indices, kv_start, suffix_lens);
+  return check_launch("rx_shared_prefix_plan");
+}
+
 }  // extern "C"

@@ -45,6 +45,8 @@ class RxDecodeParams(C.Structure):
         ("sm_scale", c_float), ("k_scale", c_float), ("v_scale", c_float), ("logit_cap", c_float),
         ("sinks", c_void_p), ("dtype", c_int32),
         ("xai_temperature_len", c_int32),
+        ("kv_start", c_void_p), ("extra_o", c_void_p), ("extra_lse", c_void_p), ("num_extra_partials", c_int32),
+        ("stages", c_int32),
     ]
 
 
@@ -88,6 +90,8 @@ PROTOTYPES = {
     "rx_rope_store_kv": (c_int, [c_void_p] * 3 + [c_int64] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_int64, c_int,
                                  C.POINTER(RxKvLayout), c_void_p, c_int, c_int64, c_int64, c_float, c_float, c_int,
                                  c_void_p, c_void_p]),
+    "rx_shared_prefix_plan": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_int32, c_int32,
+                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rx_num_kv_splits_native": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rx_merge_state": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rx_get_mla_kv": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p,

@@ -284,10 +284,13 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
 def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
                                attn_logits, attn_lse, num_kv_splits, max_kv_splits, sm_scale,
                                k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
-                               page_size: int = 1, kv_layout=None, xai_temperature_len=-1):
+                               page_size: int = 1, kv_layout=None, xai_temperature_len=-1,
+                               kv_start=None, extra_o=None, extra_lse=None, stages: int = 0):
     """MI355X-native entry: the kernel walks req_to_token itself (as the reference's CPU kernel
-    decode_attention_cpu does, aot/csrc/cpu/decode.cpp:1586), so no kv_indices are materialised."""
-    _require_cuda(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens)
+    decode_attention_cpu does, aot/csrc/cpu/decode.cpp:1586), so no kv_indices are materialised.
+    ``kv_start`` int32[bs]: attend tokens [kv_start[b], seq_len_b) only; ``extra_o`` [P,bs,Hq,Dv] +
+    ``extra_lse`` fp32[P,bs,Hq]: more partial results for stage 2 to merge (shared-prefix decode)."""
+    _require_cuda(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, kv_start, extra_o, extra_lse)
     if req_to_token.dtype != torch.int32:
         raise TypeError("req_to_token must be int32")
     p = _L.RxDecodeParams()
@@ -302,7 +305,24 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
     p.seq_lens = seq_lens.data_ptr()
     p.seq_lens_is_i64 = _is64(seq_lens, "seq_lens")
     p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
+    if kv_start is not None:
+        if kv_start.dtype != torch.int32:
+            raise TypeError("kv_start must be int32")
+        p.kv_start = kv_start.data_ptr()
+    if extra_o is not None:
+        _set_extra_partials(p, extra_o, extra_lse, q)
+    p.stages = int(stages)
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
+
+
+def _set_extra_partials(p, extra_o, extra_lse, q):
+    bs, hq = q.shape[0], q.shape[1]
+    if extra_o.dtype != q.dtype or extra_lse.dtype != torch.float32:
+        raise TypeError("extra_o must have q's dtype, extra_lse float32")
+    if (extra_o.dim() != 4 or tuple(extra_o.shape[1:3]) != (bs, hq) or not extra_o.is_contiguous()
+            or tuple(extra_lse.shape) != tuple(extra_o.shape[:3]) or not extra_lse.is_contiguous()):
+        raise ValueError("extra_o must be contiguous [P, bs, Hq, Dv], extra_lse contiguous [P, bs, Hq]")
+    p.extra_o, p.extra_lse, p.num_extra_partials = extra_o.data_ptr(), extra_lse.data_ptr(), extra_o.shape[0]
 
 
 def _fill_decode_common(p, q, k_buffer, v_buffer, o, attn_logits, attn_lse, num_kv_splits,
@@ -402,6 +422,139 @@ class DecodeLauncher:
             _L.check(st, "rx_decode_attn")
 
 
+def shared_prefix_plan(req_to_token, req_pool_indices, seq_lens, plan, chunk_indptr, shared_indices, kv_start,
+                       suffix_lens, *, min_shared: int = 0, chunk_align: int = 64) -> None:
+    """rx_shared_prefix_plan: batch-wide common prefix of the req_to_token rows, found on the device.
+    All outputs int32: plan[2], chunk_indptr[num_chunks+1], shared_indices[max_shared], kv_start[bs],
+    suffix_lens[bs] (include/radix_hip.h)."""
+    _require_cuda(req_to_token, req_pool_indices, seq_lens, plan, chunk_indptr, shared_indices, kv_start, suffix_lens)
+    for name, t in (("req_to_token", req_to_token), ("plan", plan), ("chunk_indptr", chunk_indptr),
+                    ("shared_indices", shared_indices), ("kv_start", kv_start), ("suffix_lens", suffix_lens)):
+        if t.dtype != torch.int32:
+            raise TypeError(f"{name} must be int32")
+    bs = req_pool_indices.shape[0]
+    if plan.numel() < 2 or kv_start.numel() < bs or suffix_lens.numel() < bs or chunk_indptr.numel() < 2:
+        raise ValueError("shared_prefix_plan: output too small")
+    max_shared = min(shared_indices.numel(), req_to_token.shape[1])
+    st = _L.load().rx_shared_prefix_plan(_ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices),
+                                         _is64(req_pool_indices, "req_pool_indices"), _ptr(seq_lens),
+                                         _is64(seq_lens, "seq_lens"), bs, max_shared, int(min_shared),
+                                         chunk_indptr.numel() - 1, int(chunk_align), _ptr(plan), _ptr(chunk_indptr),
+                                         _ptr(shared_indices), _ptr(kv_start), _ptr(suffix_lens),
+                                         _stream(req_to_token))
+    _L.check(st, "rx_shared_prefix_plan")
+
+
+class CascadeDecode:
+    """Shared-prefix (cascade) decode attention for one batch geometry (the reference only has the
+    merge building block, kernels/ops/attention/merge_state.py:8-96).
+
+    When the requests of a decode batch carry the same leading slots in their ``req_to_token`` rows (a radix
+    hit), the per-request decode kernel reads those K/V rows bs times.  Here they are read once:
+
+    * ``plan`` (once per forward, shared by all layers; no host sync): common prefix length L on the device,
+      the prefix cut into ``num_chunks`` pieces, per-request suffix starts / lengths and suffix kv splits;
+    * ``__call__`` (per layer): (1) the extend MFMA kernel over the shared rows with all bs decode queries as
+      its M dimension -- one pseudo-request per chunk, so the launch still fills the chip; (2) the decode
+      kernel over the suffixes ``[L, seq_len_b)``; its stage 2 merges the chunk partials with the kv splits.
+
+    The result equals plain decode attention up to the partials' 16-bit rounding.  Not available with
+    sliding windows or the Grok temperature (position dependent per request)."""
+
+    def __init__(self, max_bs: int, num_q_heads: int, num_kv_heads: int, head_dim: int, dtype, device,
+                 max_shared: int, cu_count: int = 256, min_shared: int = 256, max_kv_splits: int = 16,
+                 num_chunks: Optional[int] = None, overlap: bool = False):
+        if head_dim not in (64, 128):
+            raise ValueError("CascadeDecode: head_dim 64 / 128 (the MFMA extend kernels)")
+        self.max_bs, self.hq, self.hkv, self.d = max_bs, num_q_heads, num_kv_heads, head_dim
+        self.cu_count, self.min_shared, self.max_shared = cu_count, int(min_shared), int(max_shared)
+        if num_chunks is None:  # workgroups of phase 1 = chunks * ceil(bs / 128) * Hq: cover every CU once
+            num_chunks = max(1, min(16, -(-cu_count // (-(-max_bs // 128) * num_q_heads))))
+        self.num_chunks = S = int(num_chunks)
+        self.split_cap = max(2, int(max_kv_splits))
+        i32 = dict(dtype=torch.int32, device=device)
+        self.plan_buf = torch.zeros(2, **i32)
+        self.chunk_indptr = torch.zeros(S + 1, **i32)
+        self.shared_indices = torch.zeros(max(1, self.max_shared), **i32)
+        self.kv_start = torch.zeros(max_bs, **i32)
+        self.suffix_lens = torch.zeros(max_bs, **i32)
+        self.num_kv_splits = torch.ones(max_bs, **i32)
+        self.q_rep = torch.zeros(S, max_bs, num_q_heads, head_dim, dtype=dtype, device=device)
+        self.o_parts = torch.zeros(S, max_bs, num_q_heads, head_dim, dtype=dtype, device=device)
+        self.lse_parts = torch.zeros(S, max_bs, num_q_heads, dtype=torch.float32, device=device)
+        self.bs = 0
+        # overlap: phase 1 (MFMA-bound) on a side stream next to phase 2's stage 1 (HBM-bound), joined before
+        # stage 2.  Measured at bs=256 / 3584 shared / 512 private: 166 -> 156 us per layer, but the two extra
+        # stream waits cost more host time than that on small batches -- off by default.
+        self._side = torch.cuda.Stream(device=device) if overlap else None
+
+    def plan(self, req_to_token, req_pool_indices, seq_lens) -> None:
+        bs = self.bs = req_pool_indices.shape[0]
+        if bs > self.max_bs:
+            raise ValueError(f"CascadeDecode: bs {bs} > max_bs {self.max_bs}")
+        self._tabs = (req_to_token, req_pool_indices, seq_lens)
+        shared_prefix_plan(req_to_token, req_pool_indices, seq_lens, self.plan_buf, self.chunk_indptr,
+                           self.shared_indices, self.kv_start[:bs], self.suffix_lens[:bs],
+                           min_shared=self.min_shared)
+        # suffix kv splits: the native schedule on the suffix lengths; >= 2 slots so that stage 2 runs
+        self.max_kv_splits = max(2, native_max_kv_splits(bs, self.hq, self.hkv, self.cu_count, self.split_cap))
+        get_num_kv_splits_native(self.num_kv_splits[:bs], self.suffix_lens[:bs], self.hq, self.hkv,
+                                 self.max_kv_splits, self.cu_count)
+        S = self.num_chunks
+        self.qo_indptr = torch.arange(0, (S + 1) * bs, bs, dtype=torch.int32, device=seq_lens.device)
+        rows = bs * self.hq * self.max_kv_splits
+        if getattr(self, "_rows", 0) < rows:
+            self.attn_logits = torch.empty(rows * self.d, dtype=torch.float32, device=seq_lens.device)
+            self.attn_lse = torch.empty(rows, dtype=torch.float32, device=seq_lens.device)
+            self._rows = rows
+
+    def shared_len(self) -> int:
+        """Host copy of L (synchronises; diagnostics / tests only)."""
+        return int(self.plan_buf[0].item())
+
+    def __call__(self, q, k_buffer, v_buffer, o, sm_scale, k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
+                 page_size: int = 1, kv_layout=None) -> None:
+        bs, S = self.bs, self.num_chunks
+        if q.shape != (bs, self.hq, self.d):
+            raise ValueError(f"CascadeDecode: q {tuple(q.shape)} != {(bs, self.hq, self.d)}")
+        req_to_token, req_pool_indices, seq_lens = self._tabs
+        # phase 1: every chunk of the shared prefix against all bs queries (M = bs per head)
+        q_rep = self.q_rep[:, :bs] if bs == self.max_bs else self.q_rep.view(-1)[: S * bs * self.hq * self.d].view(
+            S, bs, self.hq, self.d)
+        o_parts = self.o_parts.view(-1)[: S * bs * self.hq * self.d].view(S, bs, self.hq, self.d)
+        lse_parts = self.lse_parts.view(-1)[: S * bs * self.hq].view(S, bs, self.hq)
+        attn_logits = self.attn_logits[: bs * self.hq * self.max_kv_splits * self.d].view(
+            bs, self.hq, self.max_kv_splits, self.d)
+        attn_lse = self.attn_lse[: bs * self.hq * self.max_kv_splits].view(bs, self.hq, self.max_kv_splits)
+        qf, of = q_rep.view(S * bs, self.hq, self.d), o_parts.view(S * bs, self.hq, self.d)
+
+        def phase1():
+            q_rep.copy_(q.unsqueeze(0).expand(S, -1, -1, -1))
+            extend_attention_fwd(qf, qf, qf, of, k_buffer, v_buffer, self.qo_indptr, self.chunk_indptr,
+                                 self.shared_indices, None, False, None, bs, k_scale, 1.0, sm_scale=sm_scale,
+                                 logit_cap=logit_cap, lse_extend=lse_parts.view(S * bs, self.hq), skip_extend=True,
+                                 page_size=page_size, kv_layout=kv_layout, _num_kv_heads=self.hkv, avg_kv_len_hint=0)
+
+        def phase2(stages):  # suffixes [L, seq_len_b); stage 2 merges everything (sinks join once, there)
+            decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
+                                       attn_logits, attn_lse, self.num_kv_splits[:bs], self.max_kv_splits, sm_scale,
+                                       k_scale, v_scale, logit_cap, sinks, page_size, kv_layout,
+                                       kv_start=self.kv_start[:bs], extra_o=o_parts, extra_lse=lse_parts,
+                                       stages=stages)
+
+        if self._side is None:
+            phase1()
+            phase2(0)
+            return
+        cur = torch.cuda.current_stream(q.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            phase1()
+        phase2(1)
+        cur.wait_stream(self._side)
+        phase2(2)
+
+
 class StoreLayoutLauncher:
     """rx_store_kv_layout with the pool-side arguments of one layer pre-computed (HND pools)."""
 
@@ -459,7 +612,8 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
                          skip_prefix_custom_mask=True, sliding_window_size=-1, sinks=None,
                          window_kv_offsets=None, xai_temperature_len=-1, lse_extend=None,
                          skip_prefix=False, skip_extend=False, page_size: int = 1,
-                         score_mod=None, aux_tensors=None, kv_layout=None, unified_prefix_lens=None):
+                         score_mod=None, aux_tensors=None, kv_layout=None, unified_prefix_lens=None,
+                         _num_kv_heads=None, avg_kv_len_hint=None):
     if score_mod is not None or aux_tensors is not None:
         raise NotImplementedError("score_mod / aux_tensors: outside the HIP path")
     _require_cuda(q_extend, k_extend, v_extend, o_extend, qo_indptr, kv_indptr, custom_mask, mask_indptr,
@@ -500,7 +654,9 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         p.lse_stride_t, p.lse_stride_h = lse_extend.stride(0), lse_extend.stride(1)
     p.bs = qo_indptr.shape[0] - 1
     p.max_extend_len = int(max_len_extend)
-    if kv_indices is not None and p.bs > 0:
+    if avg_kv_len_hint is not None:
+        p.avg_kv_len_hint = int(avg_kv_len_hint)
+    elif kv_indices is not None and p.bs > 0:
         p.avg_kv_len_hint = min(int(kv_indices.numel() // p.bs), 2 ** 31 - 1)
     if unified:
         hnd = kv_layout is not None
@@ -511,6 +667,8 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         p.unified_prefix_lens = upl.data_ptr()
     else:
         p.num_kv_heads, p.v_head_dim = k_extend.shape[1], v_extend.shape[-1]
+        if _num_kv_heads is not None:  # skip_extend callers without new K/V (k_extend / v_extend are not read)
+            p.num_kv_heads = int(_num_kv_heads)
     p.num_q_heads, p.head_dim = q_extend.shape[1], q_extend.shape[-1]
     p.sm_scale = sm_scale or 1.0 / (q_extend.shape[-1] ** 0.5)
     p.k_scale, p.v_scale, p.logit_cap = k_scale, v_scale, logit_cap

@@ -1,0 +1,199 @@
+"""Shared-prefix (cascade) decode: rx_shared_prefix_plan + extend-over-shared-rows + suffix decode
++ stage-2 merge must equal plain decode attention (fp64 oracle) for any batch, whatever the common prefix is."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import radix_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sglang_amd import ops as _ops
+
+    return _ops
+
+
+def _bits(t):
+    if t.dtype == torch.bfloat16:
+        return t.detach().cpu().contiguous().view(torch.uint16).numpy()
+    return t.detach().cpu().numpy()
+
+
+def _table(rng, shared, lens, page_size, ctx):
+    """req_to_token rows (row 0 = padding) whose first `shared` slots are identical; the rest private pages."""
+    bs = len(lens)
+    npages_shared = -(-shared // page_size)
+    pages_priv = [max(0, -(-int(n) // page_size) - shared // page_size) for n in lens]
+    n_pages = npages_shared + sum(pages_priv) + 2
+    ids = rng.permutation(np.arange(1, n_pages))
+    sh = np.concatenate([np.arange(p * page_size, (p + 1) * page_size) for p in ids[:npages_shared]] or
+                        [np.zeros(0, np.int64)])[:shared]
+    r2t = np.zeros((bs + 1, ctx), dtype=np.int32)
+    pi = npages_shared
+    for i, n in enumerate(lens):
+        priv = np.concatenate([np.arange(p * page_size, (p + 1) * page_size)
+                               for p in ids[pi: pi + pages_priv[i]]] or [np.zeros(0, np.int64)])
+        pi += pages_priv[i]
+        # a shared prefix that ends inside a page: the private part starts on a fresh page, like a
+        # radix split at a page boundary would; the tail of the shared page is simply unused here
+        row = np.concatenate([sh, priv])[: int(n)]
+        r2t[i + 1, : len(row)] = row
+    return r2t, n_pages * page_size
+
+
+def _oracle_plan(r2t, rpi, lens, max_shared, min_shared):
+    rows = r2t[rpi]
+    m = int(min(int(lens.min()), max_shared))
+    L = 0
+    while L < m and np.all(rows[:, L] == rows[0, L]):
+        L += 1
+    return 0 if L < min_shared else L
+
+
+CASES = [
+    # bs, hq, hkv, d, page, shared(target), lens, min_shared
+    (8, 8, 2, 128, 16, 512, [600, 513, 700, 640, 1000, 512 + 17, 530, 800], 64),
+    (5, 4, 4, 128, 1, 100, [101, 150, 333, 100, 129], 1),          # one request is the prefix itself
+    (3, 16, 2, 64, 32, 256, [300, 257, 512], 64),
+    (4, 8, 1, 128, 16, 0, [100, 200, 300, 64], 64),                # nothing shared -> plain decode
+    (6, 8, 2, 128, 16, 48, [100, 200, 300, 64, 90, 77], 64),       # shared but below min_shared -> L = 0
+    (1, 8, 2, 128, 16, 0, [777], 16),                              # bs 1: everything is "shared"
+    (130, 4, 1, 128, 64, 1024, None, 256),                         # > 128 queries per head (two M blocks)
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_cascade_decode_matches_oracle(ops, case, dtype):
+    bs, hq, hkv, d, page, shared, lens, min_shared = CASES[case]
+    rng = np.random.default_rng(500 + case)
+    if lens is None:
+        lens = shared + rng.integers(1, 200, size=bs)
+    lens = np.asarray(lens, dtype=np.int64)
+    ctx = int(lens.max()) + page
+    r2t, pool = _table(rng, shared, lens, page, ctx)
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    g = torch.Generator().manual_seed(case)
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    q = torch.randn(bs, hq, d, generator=g).to(dtype)
+    sinks = torch.randn(hq, generator=g) if case % 2 else None
+    cap = 30.0 if case == 2 else 0.0
+    ks, vs = (0.9, 1.1) if case % 3 == 0 else (1.0, 1.0)
+    sm = d ** -0.5
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
+    want = orc.decode_attention(_bits(q), _bits(kb), _bits(vb), kv_indptr, kv_indices, sm, k_scale=ks, v_scale=vs,
+                                logit_cap=cap, sinks=None if sinks is None else sinks.numpy())
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    cd = ops.CascadeDecode(bs, hq, hkv, d, dtype, DEV, max_shared=ctx, min_shared=min_shared,
+                           num_chunks=[None, 1, 3][case % 3], overlap=bool(case % 2 == 0))
+    r2t_d, rpi_d, lens_d = T(r2t), T(rpi if case % 2 else rpi.astype(np.int32)), T(lens if case % 2 else lens.astype(np.int32))
+    cd.plan(r2t_d, rpi_d, lens_d)
+    L = _oracle_plan(r2t, rpi, lens, ctx, min_shared)
+    assert cd.shared_len() == L
+    if case not in (3, 4):
+        assert L >= shared
+    ci = cd.chunk_indptr.cpu().numpy()
+    assert ci[0] == 0 and ci[-1] == L and np.all(np.diff(ci) >= 0)
+    assert np.array_equal(cd.shared_indices.cpu().numpy()[:L], r2t[1, :L])
+    assert np.array_equal(cd.kv_start[:bs].cpu().numpy(), np.full(bs, L))
+    assert np.array_equal(cd.suffix_lens[:bs].cpu().numpy(), lens - L)
+    o = torch.zeros(bs, hq, d, dtype=dtype, device=DEV)
+    cd(q.to(DEV), kb.to(DEV), vb.to(DEV), o, sm, ks, vs, cap, None if sinks is None else sinks.to(DEV),
+       page_size=page)
+    tol = 3e-3 if dtype == torch.float16 else 1.5e-2
+    err = np.abs(o.float().cpu().numpy().astype(np.float64) - want).max()
+    assert err <= tol, err
+
+
+def test_cascade_decode_fp8_pool(ops):
+    """fp8 e4m3fn pool: both phases read the same bytes as plain decode."""
+    bs, hq, hkv, d, page, shared = 16, 8, 2, 128, 16, 768
+    rng = np.random.default_rng(9)
+    lens = (shared + rng.integers(1, 300, size=bs)).astype(np.int64)
+    ctx = int(lens.max()) + page
+    r2t, pool = _table(rng, shared, lens, page, ctx)
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    g = torch.Generator().manual_seed(3)
+    kb = torch.randn(pool, hkv, d, generator=g).to(torch.float8_e4m3fn)
+    vb = torch.randn(pool, hkv, d, generator=g).to(torch.float8_e4m3fn)
+    q = torch.randn(bs, hq, d, generator=g).to(torch.bfloat16)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    sm, ks, vs = d ** -0.5, 0.5, 2.0
+    qd, kbd, vbd = q.to(DEV), kb.view(torch.uint8).to(DEV), vb.view(torch.uint8).to(DEV)
+    ref = torch.zeros(bs, hq, d, dtype=torch.bfloat16, device=DEV)
+    ops.decode_attention_fwd_paged(qd, kbd, vbd, ref, T(r2t), T(rpi), T(lens), None, None, None, 1, sm, ks, vs,
+                                   page_size=page)
+    cd = ops.CascadeDecode(bs, hq, hkv, d, torch.bfloat16, DEV, max_shared=ctx, min_shared=64)
+    cd.plan(T(r2t), T(rpi), T(lens))
+    assert cd.shared_len() >= shared
+    o = torch.zeros_like(ref)
+    cd(qd, kbd, vbd, o, sm, ks, vs, page_size=page)
+    assert (o.float() - ref.float()).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("page_size", [1, 16])
+def test_backend_cascade_decode_on_radix_hit_batch(page_size):
+    """HipRadixAttnBackend(cascade_decode=True) driven like the runner drives a backend: requests whose
+    req_to_token rows start with the same slots (a radix hit), private suffixes, one decode step with the KV
+    store -- against the torch-native semantics of the oracle."""
+    from sglang_amd.attention.backend import HipRadixAttnBackend
+    from sglang_amd.forward_batch import ForwardBatch
+    from tests.test_gpu_backend import _Harness
+
+    hq, hkv, d, bs, shared = 8, 2, 128, 9, 512
+    hs = _Harness(page_size, hq, hkv, d, torch.bfloat16, "shuffled_pages" if page_size > 1 else "contiguous",
+                  "paged", max_ctx=1200, max_reqs=16)
+    hs.backend = HipRadixAttnBackend(_runner_of(hs), cascade_decode=True, cascade_min_bs=2, cascade_min_shared=64)
+    rows = hs.r2t.alloc(bs)
+    hs.fill_prefix(rows[:1], [shared])
+    for r in rows[1:]:  # radix hit: the cached prefix's slots are written into the new request's row
+        hs.r2t.req_to_token[r, :shared] = hs.r2t.req_to_token[rows[0], :shared]
+    priv = [1, 40, 129, 16, 300, 77, 5, 250, 64]
+    prefix_lens = [shared + p for p in priv]
+    loc = hs.alloc_extend(rows, [shared] * bs, prefix_lens)
+    hs.pool.set_kv_buffer(hs.layer, loc, hs.rand(sum(priv), hkv, d), hs.rand(sum(priv), hkv, d))
+    seq_lens = [p + 1 for p in prefix_lens]
+    seq_t = torch.tensor(seq_lens, dtype=torch.int64)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    if page_size == 1:
+        loc = hs.alloc.alloc(bs)
+    else:
+        last = torch.tensor([int(hs.r2t.req_to_token[r, p - 1]) for r, p in zip(rows, prefix_lens)],
+                            dtype=torch.int64, device=DEV)
+        loc = hs.alloc.alloc_decode(seq_t.to(DEV), seq_t, last)
+    hs.r2t.req_to_token[rpi, torch.tensor(prefix_lens, device=DEV)] = loc.to(torch.int32)
+    q, k, v = hs.rand(bs, hq * d), hs.rand(bs, hkv * d), hs.rand(bs, hkv * d)
+    fb = ForwardBatch.for_decode(rpi, seq_t.to(DEV), loc, seq_t)
+    hs.backend.init_forward_metadata(fb)
+    o = hs.layer(q, k, v, fb, hs.backend)
+    assert hs.backend._cascade is not None and hs.backend._cascade.shared_len() == shared
+    kb, vb = hs.pool.get_kv_buffer(0)
+    want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, d)), _bits(kb), _bits(vb), _bits(hs.r2t.req_to_token),
+                                        np.array(rows), np.array(seq_lens), d ** -0.5)
+    got = o.view(bs, hq, d).float().cpu().numpy().astype(np.float64)
+    assert hs.pool.check_errors() == 0
+    assert np.abs(got - want).max() <= 1.5e-2
+
+
+def _runner_of(hs):
+    class MC:
+        num_attention_heads, num_key_value_heads, context_len = hs.hq, hs.hkv, hs.r2t.req_to_token.shape[1]
+
+    class MR:
+        device = DEV
+        req_to_token_pool = hs.r2t
+        token_to_kv_pool = hs.pool
+        token_to_kv_pool_allocator = hs.alloc
+        model_config = MC
+        page_size = hs.ps
+        dtype = hs.dtype
+
+        class server_args:
+            triton_attention_num_kv_splits = 8
+
+    return MR
