@@ -60,6 +60,7 @@ def parse():
                     help="dev: KV pool dtype (BASELINE's config is bf16; fp8 = --kv-cache-dtype fp8_e4m3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extend", action="store_true")
+    ap.add_argument("--no-radix-hit", action="store_true", help="skip the shared-prefix (radix-hit) decode leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-worker", default=None, choices=["reference", "port"])
     ap.add_argument("--extend-only", action="store_true", help="dev: run only the extend leg")
@@ -94,8 +95,10 @@ def build_world(args):
     return rank, world, local_rank
 
 
-def make_decode_state(args, tp, dev):
-    """Pools, page table and per-layer synthetic q/k/v for one rank."""
+def make_decode_state(args, tp, dev, shared_prefix=0, cascade=False):
+    """Pools, page table and per-layer synthetic q/k/v for one rank.  shared_prefix > 0: every request's
+    first shared_prefix tokens are the SAME pages (a radix hit on one cached prefix); cascade: backend with
+    shared-prefix decode on."""
     from sglang_amd.attention.backend import HipRadixAttnBackend
     from sglang_amd.attention.radix_attention import RadixAttention
     from sglang_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
@@ -104,7 +107,9 @@ def make_decode_state(args, tp, dev):
     hq, hkv = HQ // tp, max(1, HKV // tp)
     bs, ctx, ps, L = args.bs, args.ctx, args.page_size, args.layers
     pages_per_req = (ctx + ps - 1) // ps
-    size = bs * pages_per_req * ps
+    shared_pages = shared_prefix // ps
+    n_pages = shared_pages + bs * (pages_per_req - shared_pages)
+    size = n_pages * ps
     free_b, total_b = torch.cuda.mem_get_info()
     kv_dt = torch.float8_e4m3fn if args.kv_dtype == "fp8" else torch.bfloat16
     kv_esz = 1 if args.kv_dtype == "fp8" else 2
@@ -124,8 +129,10 @@ def make_decode_state(args, tp, dev):
             pool.v_buffer[l].normal_(generator=g)
     r2t_pool = ReqToTokenPool(bs, ctx + ps, dev)
     rng = np.random.default_rng(0)
-    perm = rng.permutation(np.arange(1, bs * pages_per_req + 1))  # shuffled pages, page 0 reserved
-    slots = (perm.reshape(bs, pages_per_req)[:, :, None] * ps + np.arange(ps)[None, None, :]).reshape(bs, -1)
+    perm = rng.permutation(np.arange(1, n_pages + 1))  # shuffled pages, page 0 reserved
+    pages = np.concatenate([np.broadcast_to(perm[:shared_pages], (bs, shared_pages)),
+                            perm[shared_pages:].reshape(bs, pages_per_req - shared_pages)], axis=1)
+    slots = (pages[:, :, None] * ps + np.arange(ps)[None, None, :]).reshape(bs, -1)
     rows = r2t_pool.alloc(bs)
     r2t_pool.req_to_token[rows, : slots.shape[1]] = torch.from_numpy(slots.astype(np.int32)).to(dev)
 
@@ -143,7 +150,8 @@ def make_decode_state(args, tp, dev):
         class server_args:
             triton_attention_num_kv_splits = args.max_kv_splits
 
-    backend = HipRadixAttnBackend(MR, decode_index_mode=args.index_mode, split_policy=args.split_policy)
+    backend = HipRadixAttnBackend(MR, decode_index_mode=args.index_mode, split_policy=args.split_policy,
+                                  cascade_decode=cascade)
     layers = [RadixAttention(hq, D, D ** -0.5, hkv, l % distinct) for l in range(L)]
     st = _Cfg()
     st.backend, st.layers, st.pool, st.r2t = backend, layers, pool, r2t_pool
@@ -194,6 +202,29 @@ def decode_step(st, fb, world, ev_pairs=None):
         pending = st.o_proj.forward(o, overlap=world > 1)
     if pending is not None:
         pending.wait()
+
+
+def radix_hit_bench(args, dev):
+    """Secondary figure: the same decode step on a radix-hit batch -- config 3's 256 requests
+    sharing one cached 3584-token prefix, 512 private tokens each -- with the per-request decode kernel and
+    with shared-prefix (cascade) decode.  Not `value`: the headline workload has no shared pages."""
+    from sglang_amd.forward_batch import ForwardBatch
+
+    shared = (args.ctx * 7 // 8) // args.page_size * args.page_size
+    res = {"workload": "bs=%d, ctx=%d of which the first %d tokens are one shared cached prefix (same pages in "
+                       "every req_to_token row), %d layers, store + decode attention + o_proj per layer"
+                       % (args.bs, args.ctx, shared, args.layers)}
+    for name, cascade in (("per_request_decode", False), ("cascade_decode", True)):
+        st = make_decode_state(args, 1, dev, shared_prefix=shared, cascade=cascade)
+        fb = ForwardBatch.for_decode(st.req_pool_indices, st.seq_lens, st.out_cache_loc, st.seq_lens_cpu)
+        dt = time_steps(lambda: decode_step(st, fb, 1), args.steps, args.warmup, 1)
+        res[name] = {"tokens_per_s": args.bs / (dt / args.steps), "ms_per_step": dt / args.steps * 1e3}
+        if cascade:
+            res["shared_prefix_len_found_on_device"] = st.backend._cascade.shared_len()
+        del st, fb
+        torch.cuda.empty_cache()
+    res["speedup"] = res["cascade_decode"]["tokens_per_s"] / res["per_request_decode"]["tokens_per_s"]
+    return res
 
 
 def time_steps(fn, steps, warmup, world):
@@ -449,6 +480,13 @@ def main():
             out["extend"] = extend_bench(args, dev, world)
         except Exception as e:
             out["extend"] = {"error": str(e)}
+    if rank == 0 and world == 1 and not args.no_radix_hit:
+        try:
+            del st, fb
+            torch.cuda.empty_cache()
+            out["radix_hit_decode"] = radix_hit_bench(args, dev)
+        except Exception as e:
+            out["radix_hit_decode"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

@@ -37,5 +37,8 @@ def run(bs, ctx, splits_list):
         us = e0.elapsed_time(e1) / 20 * 1e3
         out.append(f"S={S}: {us:.0f} us {byt/us/1e6:.2f} TB/s")
     print(" | ".join(out))
-for bs, ctx in [(64, 2048), (16, 4096), (8, 16384), (1, 32768), (1, 131072), (4, 8192), (32, 1024), (256, 4096)]:
+SHAPES = [(64, 2048), (16, 4096), (8, 16384), (1, 32768), (1, 131072), (4, 8192), (32, 1024), (256, 4096)]
+if os.environ.get("SHAPES"):  # e.g. SHAPES=256x512,256x1024
+    SHAPES = [tuple(int(v) for v in x.split("x")) for x in os.environ["SHAPES"].split(",")]
+for bs, ctx in SHAPES:
     run(bs, ctx, [int(x) for x in os.environ.get("SPLITS", "1,2,4,8,16,32,64").split(",")])
