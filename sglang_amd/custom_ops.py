@@ -147,7 +147,23 @@ def move_kv(data_ptrs: Tensor, row_bytes: Tensor, tgt_loc: Tensor, src_loc: Tens
     ops.move_kv(data_ptrs, row_bytes, tgt_loc, src_loc)
 
 
-ALL_OPS = (store_cache, build_kv_indices, get_num_kv_splits, decode_attention, decode_attention_paged,
+# merge_state_triton (kernels/ops/attention/merge_state.py:66-96) as an out-variant op
+@_op("merge_state", ("output", "output_lse"))
+def merge_state(prefix_output: Tensor, prefix_lse: Tensor, suffix_output: Tensor, suffix_lse: Tensor,
+                output: Tensor, output_lse: Tensor) -> None:
+    ops.merge_state(prefix_output, prefix_lse, suffix_output, suffix_lse, output, output_lse)
+
+
+# shared-prefix decode plan (include/radix_hip.h: rx_shared_prefix_plan); all outputs int32
+@_op("shared_prefix_plan", ("plan", "chunk_indptr", "shared_indices", "kv_start", "suffix_lens"))
+def shared_prefix_plan(req_to_token: Tensor, req_pool_indices: Tensor, seq_lens: Tensor, plan: Tensor,
+                       chunk_indptr: Tensor, shared_indices: Tensor, kv_start: Tensor, suffix_lens: Tensor,
+                       min_shared: int = 0, chunk_align: int = 64) -> None:
+    ops.shared_prefix_plan(req_to_token, req_pool_indices, seq_lens, plan, chunk_indptr, shared_indices,
+                           kv_start, suffix_lens, min_shared=min_shared, chunk_align=chunk_align)
+
+
+ALL_OPS = (merge_state, shared_prefix_plan, store_cache, build_kv_indices, get_num_kv_splits, decode_attention, decode_attention_paged,
            extend_attention, extend_attention_lse, alloc_extend, alloc_decode, write_req_to_token, move_kv)
 
 for _o in ALL_OPS:  # in-place ops: the fake implementation has nothing to compute

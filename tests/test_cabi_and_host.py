@@ -67,7 +67,7 @@ def test_torch_custom_ops_registered_with_fake_impls():
     names = {o._qualname.split("::")[1] for o in custom_ops.ALL_OPS}
     assert names == {"store_cache", "build_kv_indices", "get_num_kv_splits", "decode_attention",
                      "decode_attention_paged", "extend_attention", "extend_attention_lse", "alloc_extend", "alloc_decode",
-                     "write_req_to_token", "move_kv"}
+                     "write_req_to_token", "move_kv", "merge_state", "shared_prefix_plan"}
     sch = str(torch.ops.radix_hip.decode_attention.default._schema)
     assert "Tensor(a3!) o" in sch and "attn_logits" in sch and sch.endswith("-> ()")
     assert "!" in str(torch.ops.radix_hip.store_cache.default._schema)

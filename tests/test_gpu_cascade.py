@@ -197,3 +197,48 @@ def _runner_of(hs):
             triton_attention_num_kv_splits = 8
 
     return MR
+
+
+def test_cascade_plan_and_layer_replay_under_hip_graph(ops):
+    """The plan reads the page table on the device: a captured {plan, layer} graph must follow a CHANGED
+    common prefix (and changed lengths) on replay, with no host involvement."""
+    bs, hq, hkv, d, page = 12, 8, 2, 128, 16
+    rng = np.random.default_rng(77)
+    ctx = 1024
+    lens_a = (512 + rng.integers(1, 200, size=bs)).astype(np.int64)
+    lens_b = (256 + rng.integers(1, 600, size=bs)).astype(np.int64)
+    r2t_a, pool_a = _table(rng, 512, lens_a, page, ctx)
+    r2t_b, pool_b = _table(rng, 256, lens_b, page, ctx)
+    pool = max(pool_a, pool_b)
+    g = torch.Generator().manual_seed(1)
+    kb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+    vb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+    q = torch.randn(bs, hq, d, generator=g).to(torch.bfloat16).to(DEV)
+    o = torch.zeros_like(q)
+    r2t = torch.from_numpy(r2t_a).to(DEV)
+    lens = torch.from_numpy(lens_a).to(DEV)
+    rpi = torch.arange(1, bs + 1, dtype=torch.int64, device=DEV)
+    sm = d ** -0.5
+    cd = ops.CascadeDecode(bs, hq, hkv, d, torch.bfloat16, DEV, max_shared=ctx, min_shared=64)
+
+    def step():
+        cd.plan(r2t, rpi, lens)
+        cd(q, kb, vb, o, sm, page_size=page)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()  # warm the allocator and the scratch buffers
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for r2t_np, lens_np, want_shared in ((r2t_b, lens_b, 256), (r2t_a, lens_a, 512)):
+        r2t.copy_(torch.from_numpy(r2t_np).to(DEV))
+        lens.copy_(torch.from_numpy(lens_np).to(DEV))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert cd.shared_len() >= want_shared
+        ref = torch.zeros_like(q)
+        ops.decode_attention_fwd_paged(q, kb, vb, ref, r2t, rpi, lens, None, None, None, 1, sm, page_size=page)
+        assert (o.float() - ref.float()).abs().max().item() <= 1.5e-2
