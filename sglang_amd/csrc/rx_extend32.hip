@@ -64,6 +64,10 @@ struct Ext32Args {
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+#ifndef RX_EXT32_MAX_SLACK
+#define RX_EXT32_MAX_SLACK 8.0f
+#endif
+constexpr float kMaxSlack = RX_EXT32_MAX_SLACK;  // see sm_slice: how far (log2 units) a tile max may exceed a row's reference max
 
 constexpr int kD = 128, kRow = 256, kTok = 64;  // head dim, bytes per row, tokens per tile
 // LDS images: padded rows instead of an XOR swizzle, so that fragment addresses are lane constant +
@@ -96,6 +100,47 @@ __device__ __forceinline__ f32x16 mfma32<F16>(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// O^T accumulators held in AGPRs (the 64-queries-per-wave form, QB == 2): at one wave per SIMD a wave owns 512
+// registers, but VALU instructions only address v0..v255.  hipcc given 128 accumulator registers on top of
+// the Q fragments and score tiles keeps shuffling them through v_accvgpr moves (755 in the loop); here the PV
+// MFMAs are written as inline asm with the accumulator pinned to the "a" class, so it never leaves the AGPR
+// half and only the (rare) rescale and the epilogue read it.  hipcc's hazard recogniser does not see through
+// inline asm: acc_settle() supplies the wait states of "XDL write -> VALU read" (and back) by hand.
+template <typename T, bool AG>
+__device__ __forceinline__ void pv_mfma(u32x4 a, u32x4 b, f32x16& c) {
+  if constexpr (AG) {
+    if constexpr (std::is_same_v<T, BF16>)
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  } else {
+    c = mfma32<T>(__builtin_bit_cast(typename T::vec8, a), __builtin_bit_cast(typename T::vec8, b), c);
+  }
+}
+// QK^T step: S^T (+)= K fragment x Q fragment.  AG: the Q fragments live in AGPRs as well (MFMA reads its B
+// operand from either half; they are loaded once and never touched by VALU), the score tile stays in VGPRs.
+template <typename T, bool AG, bool FIRST>
+__device__ __forceinline__ void qk_mfma(u32x4 k, const typename T::vec8& q, f32x16& sc) {
+  if constexpr (AG) {
+    const u32x4 qr = __builtin_bit_cast(u32x4, q);
+    if constexpr (std::is_same_v<T, BF16>) {
+      if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sc) : "v"(k), "a"(qr));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sc) : "v"(k), "a"(qr));
+    } else {
+      if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sc) : "v"(k), "a"(qr));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sc) : "v"(k), "a"(qr));
+    }
+  } else {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    sc = mfma32<T>(__builtin_bit_cast(typename T::vec8, k), q, FIRST ? zero16 : sc);
+  }
+}
+template <bool AG, int N>
+__device__ __forceinline__ void acc_settle(f32x16 (&o)[N]) {
+  static_assert(N == 4, "one 128-wide O^T block row");
+  if constexpr (AG) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0]), "+a"(o[1]), "+a"(o[2]), "+a"(o[3]));
+}
+
 // This file is compiled with -fno-honor-nans (sglang_amd/build.py): with NaNs honoured hipcc
 // canonicalises every MFMA result before fmaxf (v_max_f32 x, x, x -- one extra VALU per score).
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }  // v_max3_f32
@@ -117,6 +162,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;  // prefix pool element
   constexpr int KS = kD / 16;                  // 8 k-steps of the QK^T product
   constexpr int DB = kD / 32;                  // 4 output d blocks of 32
+  constexpr bool AG = QB > 1;                  // O^T accumulators pinned to AGPRs (pv_mfma)
   constexpr int THREADS = 64 * NW;
   constexpr int RPP = THREADS / 16;            // rows staged per pass
   constexpr int NPASS = kTok / RPP;            // 2 (NW=8) or 4 (NW=4)
@@ -193,6 +239,18 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // Q landed before the loop (see rx_extend.hip)
+  if constexpr (AG) {
+    // re-define every Q fragment as an AGPR-class value: with the loads' VGPR-class definitions hipcc copies a
+    // fragment into a fresh AGPR tuple in front of EVERY asm use (4 v_accvgpr_write per QK^T MFMA, in the loop)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        u32x4 t = __builtin_bit_cast(u32x4, qf[qb][ks]);
+        asm volatile("" : "+a"(t));
+        qf[qb][ks] = __builtin_bit_cast(vec8, t);
+      }
+  }
 
   const bool no_ext = a.skip_extend || a.unified_prefix != nullptr;  // unified: every key comes from the pool
   const int32_t p_len = a.skip_prefix ? 0 : P;
@@ -295,11 +353,16 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   // K fragment (block b, k-step ks): lane (ql, h) <- K[32 b + ql][16 ks + 8 h .. +8]
+#ifndef RX_EXT32_ABL
+#define RX_EXT32_ABL 0  // dev ablations of the fast loop (results are garbage): 1 no softmax slices, 2 no LDS fragment reads, 4 no staging
+#endif
   auto load_k = [&](const char* tile, int b, int ks) {
+    if constexpr ((RX_EXT32_ABL & 2) != 0) return u32x4{(uint32_t)b, (uint32_t)ks, 0x3c003c00u, 0x3c003c00u};
     return *reinterpret_cast<const u32x4*>(tile + kaddr + b * 32 * kKStride + ks * 32);
   };
   // V^T fragments of k-step `step` (16 tokens): rows 16 step + 4 h + qd (+8), d block db
   auto load_v1 = [&](const char* tile, int step, int db) {
+    if constexpr ((RX_EXT32_ABL & 2) != 0) return u32x4{(uint32_t)step, (uint32_t)db, 0x3c003c00u, 0x3c003c00u};
     const u32x2 lo2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64);
     const u32x2 hi2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64 + 8 * kVStride);
     return u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
@@ -415,6 +478,14 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       float ps0[QB][2], ps1[QB][2];
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) ps0[qb][0] = ps0[qb][1] = ps1[qb][0] = ps1[qb][1] = 0.f;
+      if constexpr ((RX_EXT32_ABL & 25) != 0) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          alpha0[qb] = alpha1[qb] = 1.f;
+          m0[qb] = m1[qb] = m_run[qb];
+          pk0[qb][0] = pk0[qb][1] = pk1[qb][0] = pk1[qb][1] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        }
+      }
       // one slice of a block's softmax for query block qb; j = 0..6
       auto sm_slice = [&](int j, int qb, f32x16& sc, float m_prev, float& m_new, float& alpha, float (&ps)[2],
                           u32x4 (&pk)[2]) {
@@ -434,12 +505,21 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
         } else if (j == 2) {
           float mt = half_swap_max(ma[qb]) * c2;
           mt = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
-          m_new = max2f(m_prev, mt);
+          // thresholded running max: a row moves its reference max only when the tile's max exceeds it by more
+          // than kMaxSlack (log2 units).  exp2(s - m) then reaches 2^kMaxSlack at most -- exact algebra (l uses
+          // the same m), fp32 sums and 16-bit P have the range -- and the O^T rescale, which costs 64 (VGPR) or
+          // 192 + wait states (AGPR) instructions per block, runs on the first tile and almost never again;
+          // with the plain rule some row of a 32-row block sets a new max in ~70 % of 56 random tiles.
+          const float m_cand = max2f(m_prev, mt);
+          m_new = (m_cand - m_prev > kMaxSlack) ? m_cand : m_prev;
           alpha = fast_exp2(m_prev - m_new);
           asm volatile("" ::"v"(m_new), "v"(alpha));
         } else {
           const int e = 4 * (j - 3);
           float v[4];
+          // AG build: without an input-side anchor hipcc hoists all four exp slices up to where m_new is
+          // first known (one 100-instruction VALU lump behind a single MFMA pair)
+          if constexpr (AG) asm volatile("" : "+v"(m_new));
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = fast_exp2(__builtin_fmaf(sc[e + i], c2, -m_new));
           ps[0] += v[0] + v[2];
@@ -468,10 +548,12 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
           }
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) {
-            if (i < KS) s0[qb] = mfma32<T>(__builtin_bit_cast(vec8, kf[i]), qf[qb][i], i == 0 ? zero16 : s0[qb]);
-            else s1[qb] = mfma32<T>(__builtin_bit_cast(vec8, kf[i]), qf[qb][i - KS], i == KS ? zero16 : s1[qb]);
+            if (i == 0) qk_mfma<T, AG, true>(kf[i], qf[qb][0], s0[qb]);
+            else if (i < KS) qk_mfma<T, AG, false>(kf[i], qf[qb][i], s0[qb]);
+            else if (i == KS) qk_mfma<T, AG, true>(kf[i], qf[qb][0], s1[qb]);
+            else qk_mfma<T, AG, false>(kf[i], qf[qb][i - KS], s1[qb]);
           }
-          if (i > KS) {
+          if (i > KS && !(RX_EXT32_ABL & 9)) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
               sm_slice(i - KS - 1, qb, s0[qb], m_run[qb], m0[qb], alpha0[qb], ps0[qb], pk0[qb]);
@@ -483,8 +565,10 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         if (__builtin_amdgcn_ballot_w64(alpha0[qb] != 1.0f) != 0) {
+          acc_settle<AG>(oacc[qb]);
 #pragma unroll
           for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha0[qb];
+          acc_settle<AG>(oacc[qb]);
         }
       }
       // PV(b0): k-steps 0 (vfa), 1 (vfb) | softmax of block 1
@@ -497,18 +581,20 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
           if (g < DB)
-            oacc[qb][g] = mfma32<T>(__builtin_bit_cast(vec8, vfa[g]), __builtin_bit_cast(vec8, pk0[qb][0]), oacc[qb][g]);
+            pv_mfma<T, AG>(vfa[g], pk0[qb][0], oacc[qb][g]);
           else
-            oacc[qb][g - DB] = mfma32<T>(__builtin_bit_cast(vec8, vfb[g - DB]), __builtin_bit_cast(vec8, pk0[qb][1]),
-                                         oacc[qb][g - DB]);
+            pv_mfma<T, AG>(vfb[g - DB], pk0[qb][1], oacc[qb][g - DB]);
         }
         if (g >= DB && g < DB + 2) {
           vfa[2 * (g - DB)] = load_v1(tile, 2, 2 * (g - DB));
           vfa[2 * (g - DB) + 1] = load_v1(tile, 2, 2 * (g - DB) + 1);
         }
-        if (g < 7) {
+        // AG: the score MFMAs are inline asm, so hipcc does not pad "XDL write -> VALU read" itself; block 1's
+        // softmax starts one group later, behind four more MFMAs (>= 96 cycles of matrix pipe)
+        constexpr int SH = AG ? 1 : 0;
+        if (g >= SH && g < 7 + SH && !(RX_EXT32_ABL & 17)) {
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb) sm_slice(g, qb, s1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb]);
+          for (int qb = 0; qb < QB; ++qb) sm_slice(g - SH, qb, s1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -521,8 +607,10 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         if (__builtin_amdgcn_ballot_w64(alpha1[qb] != 1.0f) != 0) {
+          acc_settle<AG>(oacc[qb]);
 #pragma unroll
           for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha1[qb];
+          acc_settle<AG>(oacc[qb]);
         }
       }
       // PV(b1): k-steps 2 (vfa), 3 (vfb) | staging
@@ -560,17 +648,17 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) {
             if (g < DB)
-              oacc[qb][g] = mfma32<T>(__builtin_bit_cast(vec8, vfa[g]), __builtin_bit_cast(vec8, pk1[qb][0]), oacc[qb][g]);
+              pv_mfma<T, AG>(vfa[g], pk1[qb][0], oacc[qb][g]);
             else
-              oacc[qb][g - DB] = mfma32<T>(__builtin_bit_cast(vec8, vfb[g - DB]), __builtin_bit_cast(vec8, pk1[qb][1]),
-                                           oacc[qb][g - DB]);
+              pv_mfma<T, AG>(vfb[g - DB], pk1[qb][1], oacc[qb][g - DB]);
           }
-          if (g == 2) write_lds((t + 1) & 1, t + 1 < nt1);
-          if (g >= 3 && g - 3 < NPASS) reissue(g - 3);
+          if (g == 2 && !(RX_EXT32_ABL & 4)) write_lds((t + 1) & 1, t + 1 < nt1);
+          if (g >= 3 && g - 3 < NPASS && !(RX_EXT32_ABL & 4)) reissue(g - 3);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int i = 2 * DB - 3; i < NPASS; ++i) reissue(i);
+        for (int i = 2 * DB - 3; i < NPASS; ++i)
+          if (!(RX_EXT32_ABL & 4)) reissue(i);
         load_idx_tile(t + 3);
       }
       RX_STAMP(3);
@@ -594,9 +682,11 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
           if (b < nblk) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-              sacc[b] = mfma32<T>(__builtin_bit_cast(vec8, load_k(tile, b, ks)), qf[qb][ks], ks == 0 ? zero16 : sacc[b]);
+              if (ks == 0) qk_mfma<T, AG, true>(load_k(tile, b, ks), qf[qb][ks], sacc[b]);
+              else qk_mfma<T, AG, false>(load_k(tile, b, ks), qf[qb][ks], sacc[b]);
           }
         }
+        if constexpr (AG) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(sacc[0]), "+v"(sacc[1]));  // XDL write -> VALU read
         float mt = -INFINITY;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -629,7 +719,8 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
         mt = half_swap_max(mt);
         mt *= c2;
         const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
-        const float m_new = fmaxf(m_run[qb], mt_fixed);
+        const float m_cand = fmaxf(m_run[qb], mt_fixed);
+        const float m_new = (m_cand - m_run[qb] > kMaxSlack) ? m_cand : m_run[qb];
         const float alpha = fast_exp2(m_run[qb] - m_new);
         m_run[qb] = m_new;
         float psum = 0.f;
@@ -639,16 +730,16 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
           if (b < nblk) psum += exp_pack(sacc[b], c2, m_new, vs, pk[b]);
         l_run[qb] = l_run[qb] * alpha + psum;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+          acc_settle<AG>(oacc[qb]);
 #pragma unroll
           for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha;
+          acc_settle<AG>(oacc[qb]);
         }
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
           if (step < 2 * nblk) {
-            const vec8 pb = __builtin_bit_cast(vec8, pk[step >> 1][step & 1]);
 #pragma unroll
-            for (int db = 0; db < DB; ++db)
-              oacc[qb][db] = mfma32<T>(__builtin_bit_cast(vec8, load_v1(tile, step, db)), pb, oacc[qb][db]);
+            for (int db = 0; db < DB; ++db) pv_mfma<T, AG>(load_v1(tile, step, db), pk[step >> 1][step & 1], oacc[qb][db]);
           }
         }
       }
@@ -676,6 +767,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     float den = l;
     if (a.sinks) den += fast_exp2(a.sinks[head] * kLog2e - m_run[qb]);
     const float inv = 1.0f / den;
+    acc_settle<AG>(oacc[qb]);
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
 #pragma unroll
