@@ -167,6 +167,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   constexpr int RPP = THREADS / 16;            // rows staged per pass
   constexpr int NPASS = kTok / RPP;            // 2 (NW=8) or 4 (NW=4)
   constexpr int QPW = 32 * QB;                 // queries per wave: QB blocks of 32
+  constexpr int RING = AG ? 3 : 2;             // LDS tile ring (the AG pipeline reads tile t-1's V after barrier t)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
 
   const int tid = threadIdx.x;
@@ -303,6 +304,16 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       }
     }
   };
+  // one staged chunk (piece i < NPASS: K row chunk i; else V row chunk i - NPASS) -> LDS
+  auto write_lds_piece = [&](int buf, bool from_pool, int piece) {
+    const bool is_v = piece >= NPASS;
+    const int i = is_v ? piece - NPASS : piece;
+    char* dst = smem + buf * kBufBytes + (is_v ? kKTile + st_row * kVStride : st_row * kKStride) + st_chunk * 16 +
+                i * RPP * (is_v ? kVStride : kKStride);
+    const u32x4 raw = is_v ? stg_v[i] : stg_k[i];
+    if (KV8 && from_pool) *reinterpret_cast<u32x4*>(dst) = fp8x8_to_16<T>(u32x2{raw[0], raw[1]});
+    else *reinterpret_cast<u32x4*>(dst) = raw;
+  };
   auto write_lds = [&](int buf, bool from_pool) {  // from_pool: the staged tile is a prefix tile
     char* kt = smem + buf * kBufBytes + st_row * kKStride + st_chunk * 16;
     char* vt = smem + buf * kBufBytes + kKTile + st_row * kVStride + st_chunk * 16;
@@ -423,7 +434,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   auto tile_sync_and_stage = [&](int t) {
     __syncthreads();
     if (t + 1 < nt) {
-      write_lds((t + 1) & 1, t + 1 < nt1);
+      write_lds((t + 1) % RING, t + 1 < nt1);
       if (t + 2 < nt) {
         issue_loads(t + 2);
         if (t + 3 < nt) load_idx_tile(t + 3);
@@ -453,13 +464,273 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 #endif
   int t = 0;
   while (t < nt) {
-    for (; t + 3 < nt; ++t) {
+
+    if constexpr (AG) {
+      // ===== one wave per SIMD (QB = 2): a two-tile-deep pipeline with ONE small filler behind EVERY MFMA.
+      // A single in-order wave hides VALU work only inside the 32-cycle shadow of the MFMA it follows (about
+      // 24 cycles of issue; MI355X_MICROARCH.md 'vector-instruction ISSUE cost'): two MFMAs back to back just
+      // wait out the first, and a VALU lump behind the second overflows its gap.  So the softmax of one
+      // (query block, 32-key block) is cut into 16 units -- two of row max, two for the reference max, twelve
+      // with one or two exp each -- and dealt over the 16 MFMAs of that query block in the two following groups:
+      //   G1  QK^T block 0 of tile t    | units 8-15 of block 1, tile t-1
+      //   G2  QK^T block 1 of tile t    | units 0-7  of block 0, tile t   (+ V^T reads of tile t-1)
+      //   G3  PV   block 1 of tile t-1  | units 8-15 of block 0, tile t   (+ tile t+1 registers -> LDS)
+      //   G4  PV   block 0 of tile t    | units 0-7  of block 1, tile t   (+ tile t+2 global loads)
+      // Tile t-1's V rows are read after barrier t, hence the ring of three tiles.  A run of fast tiles starts
+      // from a DUMMY predecessor (scores -inf: P = 0, max and sum unchanged; its PV multiplies this tile's V
+      // rows by zero) instead of a peeled iteration and ends with a drain (units 8-15 + PV of the last block 1).
+      f32x16 s0[QB], s1[QB];
+      u32x4 pk0[QB][2], pk1[QB][2];
+      u32x4 vfa[DB], vfb[DB];
+      float ma0[QB], mb0[QB], ma1[QB], mb1[QB], m0[QB], m1[QB], alpha0[QB], alpha1[QB];
+      float ps0[QB][2], ps1[QB][2];
+      // elements (of the 16 per lane) finished by unit u >= 4:  2 1 1 2 1 1 2 1 1 2 1 1
+      auto sm_unit = [&](int u, int qb, f32x16& sc, float& ma, float& mb, float m_prev, float& m_new, float& alpha,
+                         float (&ps)[2], u32x4 (&pk)[2], float c2u, float vs) {
+        const float c2 = c2u * xai[qb];
+        if (u == 0) {
+          ma = max3f(sc[0], sc[1], sc[2]);
+          mb = max3f(sc[3], sc[4], sc[5]);
+          ma = max3f(ma, sc[6], sc[7]);
+          mb = max3f(mb, sc[8], sc[9]);
+          asm volatile("" ::"v"(ma), "v"(mb));
+        } else if (u == 1) {
+          ma = max3f(ma, sc[10], sc[11]);
+          mb = max3f(mb, sc[12], sc[13]);
+          ma = max3f(ma, sc[14], sc[15]);
+          ma = max2f(ma, mb);
+          asm volatile("" ::"v"(ma));
+        } else if (u == 2) {
+          float mt = half_swap_max(ma) * c2;
+          ma = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
+          asm volatile("" ::"v"(ma));
+        } else if (u == 3) {
+          const float m_cand = max2f(m_prev, ma);
+          m_new = (m_cand - m_prev > kMaxSlack) ? m_cand : m_prev;  // thresholded running max, see the QB = 1 body
+          alpha = fast_exp2(m_prev - m_new);
+          ps[0] = ps[1] = 0.f;
+          asm volatile("" ::"v"(m_new), "v"(alpha));
+        } else {
+          const int k3 = (u - 4) / 3, r3 = (u - 4) % 3;
+          const int e0 = 4 * k3 + (r3 == 0 ? 0 : r3 + 1), ne = r3 == 0 ? 2 : 1;
+          asm volatile("" : "+v"(m_new));  // input-side anchor: keeps the unit where it is written
+          float v[2];
+#pragma unroll
+          for (int i = 0; i < ne; ++i) {
+            v[i] = fast_exp2(__builtin_fmaf(sc[e0 + i], c2, -m_new));
+            ps[(e0 + i) & 1] += v[i];
+            if constexpr (VSCALE) v[i] *= vs;
+          }
+          // scores become P in place (the score registers are dead after this unit); pairs (2p, 2p+1) are packed
+          // by the unit that finishes the odd element
+#pragma unroll
+          for (int i = 0; i < ne; ++i) sc[e0 + i] = v[i];
+          const int elast = e0 + ne - 1;
+          if (elast & 1) {
+            const int pi = elast >> 1;
+            pk[pi >> 2][pi & 3] = pack2<T>(sc[elast - 1], sc[elast]);
+            asm volatile("" ::"v"(pk[pi >> 2][pi & 3]), "v"(ps[0]), "v"(ps[1]));
+          } else {
+            asm volatile("" ::"v"(sc[elast]), "v"(ps[0]), "v"(ps[1]));
+          }
+        }
+      };
+      auto rescale = [&](int qb, float alpha) {
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+          acc_settle<AG>(oacc[qb]);
+#pragma unroll
+          for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha;
+          acc_settle<AG>(oacc[qb]);
+        }
+      };
+      // first tile >= t that is not fast, inside t's segment (prefix or new tokens); tile t itself is fast.
+      // Closed form of tile_info().fast: the tile-independent conditions hold (tile t passed them), the rest is
+      // "both blocks inside the visible range".
+      auto fast_run_end = [&](int t0) {
+        int lim, base;
+        if (t0 < nt1) {
+          lim = causal_in_list ? min(p_len, q_off + qbase + 1) : p_len;
+          base = 0;
+        } else {
+          lim = a.causal ? min(E, qbase + 1) : E;
+          base = nt1;
+        }
+        const int end = base + lim / kTok;
+        return min(min(end, t0 < nt1 ? nt1 : nt), nt - 3);
+      };
+      while (t + 3 < nt) {
+        const TileInfo ti0 = tile_info(t);
+        if (!ti0.fast) break;
+        const int run_end = max(fast_run_end(t), t + 1);  // tile t itself is fast by tile_info
+        const float c2r = ti0.c2, vsr = ti0.vs;
+        // dummy predecessor: block 1 of "tile t-1" with every score -inf, units 0-7 done
+        const char* tile_p = smem + (t % RING) * kBufBytes;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s1[qb][i] = -INFINITY;
+          m0[qb] = m_run[qb];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            sm_unit(u, qb, s1[qb], ma1[qb], mb1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], c2r, vsr);
+        }
+        for (; t < run_end; ++t) {
+          RX_STAMP(5);
+          __syncthreads();
+          RX_STAMP(0);
+          const char* tile = smem + (t % RING) * kBufBytes;
+          // ---- G1: QK^T(b0, t) | units 8-15 of (b1, t-1)
+          {
+            u32x4 kf[KS];
+            kf[0] = load_k(tile, 0, 0);
+            kf[1] = load_k(tile, 0, 1);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+              if (i + 2 < KS) kf[i + 2] = load_k(tile, 0, i + 2);
+#pragma unroll
+              for (int qb = 0; qb < QB; ++qb) {
+                if (i == 0) qk_mfma<T, AG, true>(kf[i], qf[qb][0], s0[qb]);
+                else qk_mfma<T, AG, false>(kf[i], qf[qb][i], s0[qb]);
+                sm_unit(8 + i, qb, s1[qb], ma1[qb], mb1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], c2r, vsr);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+          RX_STAMP(1);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) l_run[qb] = l_run[qb] * alpha1[qb] + (ps1[qb][0] + ps1[qb][1]);
+          // ---- G2: QK^T(b1, t) | units 0-7 of (b0, t), V^T fragments of tile t-1's rows 32..47
+          {
+            u32x4 kf[KS];
+            kf[0] = load_k(tile, 1, 0);
+            kf[1] = load_k(tile, 1, 1);
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+              if (i + 2 < KS) kf[i + 2] = load_k(tile, 1, i + 2);
+              else {
+                vfa[2 * (i + 2 - KS)] = load_v1(tile_p, 2, 2 * (i + 2 - KS));
+                vfa[2 * (i + 2 - KS) + 1] = load_v1(tile_p, 2, 2 * (i + 2 - KS) + 1);
+              }
+#pragma unroll
+              for (int qb = 0; qb < QB; ++qb) {
+                if (i == 0) qk_mfma<T, AG, true>(kf[i], qf[qb][0], s1[qb]);
+                else qk_mfma<T, AG, false>(kf[i], qf[qb][i], s1[qb]);
+                // (s0's last MFMA is >= 12 issued instructions back: XDL write -> VALU read needs no pad here)
+                sm_unit(i, qb, s0[qb], ma0[qb], mb0[qb], m1[qb], m0[qb], alpha0[qb], ps0[qb], pk0[qb], c2r, vsr);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }
+          RX_STAMP(2);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) rescale(qb, alpha1[qb]);
+          // ---- G3: PV(b1, t-1) | units 8-15 of (b0, t), tile t+1 registers -> LDS
+#pragma unroll
+          for (int g = 0; g < 2 * DB; ++g) {
+            if (g < 2) {
+              vfb[2 * g] = load_v1(tile_p, 3, 2 * g);
+              vfb[2 * g + 1] = load_v1(tile_p, 3, 2 * g + 1);
+            }
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+              if (g < DB) pv_mfma<T, AG>(vfa[g], pk1[qb][0], oacc[qb][g]);
+              else pv_mfma<T, AG>(vfb[g - DB], pk1[qb][1], oacc[qb][g - DB]);
+              sm_unit(8 + g, qb, s0[qb], ma0[qb], mb0[qb], m1[qb], m0[qb], alpha0[qb], ps0[qb], pk0[qb], c2r, vsr);
+              if (qb == 1 && !(RX_EXT32_ABL & (4 | 32))) write_lds_piece((t + 1) % RING, t + 1 < nt1, g);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g >= DB && g < DB + 2) {  // tile t's rows 0..15 for G4
+              vfa[2 * (g - DB)] = load_v1(tile, 0, 2 * (g - DB));
+              vfa[2 * (g - DB) + 1] = load_v1(tile, 0, 2 * (g - DB) + 1);
+            }
+          }
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            l_run[qb] = l_run[qb] * alpha0[qb] + (ps0[qb][0] + ps0[qb][1]);
+            rescale(qb, alpha0[qb]);
+          }
+          // ---- G4: PV(b0, t) | units 0-7 of (b1, t), tile t+2 global loads
+          {
+            const int t2 = t + 2;
+            const bool pre = t2 < nt1;
+            const int esz = (KV8 && pre) ? 1 : 2;
+            const char* kb = pre ? reinterpret_cast<const char*>(kbuf_h) : reinterpret_cast<const char*>(kext_h);
+            const char* vb = pre ? reinterpret_cast<const char*>(vbuf_h) : reinterpret_cast<const char*>(vext_h);
+            const int64_t kts = (pre ? a.k_tok_stride : a.k_stride_t) * esz, vts = (pre ? a.v_tok_stride : a.v_stride_t) * esz;
+            const int64_t kps = a.k_page_stride * esz, vps = a.v_page_stride * esz;
+            const int sh = (LINEAR || !pre) ? 31 : -a.page_size - 1;
+            const uint32_t lo_mask = (1u << sh) - 1u;
+            auto reissue = [&](int i, int which) {  // which: 0 the K row, 1 the V row (one per MFMA gap)
+              const uint32_t sl = static_cast<uint32_t>(slot[i]);
+              if (which == 0) {
+                const char* kp = kb + mul_u32(sl >> sh, kps) + mul_u32(sl & lo_mask, kts);
+                if (KV8 && pre) {
+                  const u32x2 kr = *reinterpret_cast<const u32x2*>(kp);
+                  stg_k[i] = u32x4{kr[0], kr[1], 0u, 0u};
+                } else {
+                  stg_k[i] = *reinterpret_cast<const u32x4*>(kp);
+                }
+              } else {
+                const char* vp = vb + mul_u32(sl >> sh, vps) + mul_u32(sl & lo_mask, vts);
+                if (KV8 && pre) {
+                  const u32x2 vr = *reinterpret_cast<const u32x2*>(vp);
+                  stg_v[i] = u32x4{vr[0], vr[1], 0u, 0u};
+                } else {
+                  stg_v[i] = *reinterpret_cast<const u32x4*>(vp);
+                }
+              }
+            };
+#pragma unroll
+            for (int g = 0; g < 2 * DB; ++g) {
+              if (g < 2) {
+                vfb[2 * g] = load_v1(tile, 1, 2 * g);
+                vfb[2 * g + 1] = load_v1(tile, 1, 2 * g + 1);
+              }
+#pragma unroll
+              for (int qb = 0; qb < QB; ++qb) {
+                if (g < DB) pv_mfma<T, AG>(vfa[g], pk0[qb][0], oacc[qb][g]);
+                else pv_mfma<T, AG>(vfb[g - DB], pk0[qb][1], oacc[qb][g - DB]);
+                sm_unit(g, qb, s1[qb], ma1[qb], mb1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], c2r, vsr);
+                if (g < NPASS && !(RX_EXT32_ABL & (4 | 64))) reissue(g, qb);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+            static_assert(2 * NPASS == 2 * DB && QB == 2, "staging pieces fit the PV groups");
+          }
+          load_idx_tile(t + 3);
+          tile_p = tile;
+          RX_STAMP(3);
+        }
+        // drain: units 8-15 and the PV of the last fast tile's block 1
+#pragma unroll
+        for (int u = 8; u < 16; ++u)
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            sm_unit(u, qb, s1[qb], ma1[qb], mb1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], c2r, vsr);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          l_run[qb] = l_run[qb] * alpha1[qb] + (ps1[qb][0] + ps1[qb][1]);
+          m_run[qb] = m1[qb];
+          rescale(qb, alpha1[qb]);
+        }
+#pragma unroll
+        for (int step = 2; step < 4; ++step)
+#pragma unroll
+          for (int db = 0; db < DB; ++db) {
+            const u32x4 vf = load_v1(tile_p, step, db);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) pv_mfma<T, AG>(vf, pk1[qb][step - 2], oacc[qb][db]);
+          }
+        break;  // the boundary loop below takes over (it re-enters this pipeline at the next run)
+      }
+    }
+    for (; !AG && t + 3 < nt; ++t) {
       const TileInfo ti = tile_info(t);
       if (!ti.fast) break;
       RX_STAMP(5);
       __syncthreads();
       RX_STAMP(0);
-      const char* tile = smem + (t & 1) * kBufBytes;
+      const char* tile = smem + (t % RING) * kBufBytes;
       const float c2u = ti.c2, vs = ti.vs;
       // ===== fast body: a hand-ordered wave-level software pipeline.  Measured before it: the tile's
       // phases (QK^T MFMAs, softmax VALU, PV MFMAs, staging) cost their SUM -- hipcc issues all MFMAs
@@ -652,7 +923,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
             else
               pv_mfma<T, AG>(vfb[g - DB], pk1[qb][1], oacc[qb][g - DB]);
           }
-          if (g == 2 && !(RX_EXT32_ABL & 4)) write_lds((t + 1) & 1, t + 1 < nt1);
+          if (g == 2 && !(RX_EXT32_ABL & 4)) write_lds((t + 1) % RING, t + 1 < nt1);
           if (g >= 3 && g - 3 < NPASS && !(RX_EXT32_ABL & 4)) reissue(g - 3);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -669,7 +940,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       if (ti.fast && t + 3 < nt) break;
       tile_sync_and_stage(t);
       if (!ti.work) continue;
-      const char* tile = smem + (t & 1) * kBufBytes;
+      const char* tile = smem + (t % RING) * kBufBytes;
       const bool prefix = ti.prefix, full = ti.full;
       const int tile_n0 = ti.tile_n0, nblk = ti.nblk;
       const float cs = ti.cs, c2u = ti.c2, vs = ti.vs;
@@ -808,7 +1079,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 template <int NW, int QB, bool KV8>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
-  constexpr unsigned kLds = 2 * kBufBytes;  // 74 KiB: above the 64 KiB static limit, hence dynamic
+  constexpr unsigned kLds = (QB > 1 ? 3 : 2) * kBufBytes;  // 74 KiB: above the 64 KiB static limit, hence dynamic
 #define RX_E32(TT, IT, LIN, VS)                                                                        \
   do {                                                                                                 \
     auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB, KV8>;                                    \
