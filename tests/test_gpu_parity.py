@@ -854,3 +854,52 @@ def test_extend_unified_equals_two_stage_on_long_batch(ops):
     ops.extend_attention_fwd_unified(q, o1, kb, vb, 1.0, 1.0, qo, _t(u_indptr), _t(slots.astype(np.int64)),
                                      _t(prefix.astype(np.int32)), int(ext.max()), sm_scale=d ** -0.5)
     assert (o1.float() - o2.float()).abs().max().item() <= 2e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("pattern", ["ramp", "spikes", "plateau"])
+def test_extend_thresholded_max_adversarial_scores(ops, dtype, pattern):
+    """The D = 128 MFMA kernel moves a row's reference max only when a tile's max exceeds it by > 2^8
+    (kMaxSlack, rx_extend32.hip).  Score sequences built to stress that rule -- a slow ramp that stays inside
+    the slack tile after tile, rare huge spikes, a long flat plateau after one early peak -- must still match
+    the fp64 oracle (output and LSE)."""
+    hq, hkv, d, P, E = 2, 1, 128, 1024 + 37, 192
+    rng = np.random.default_rng({"ramp": 1, "spikes": 2, "plateau": 3}[pattern])
+    g = torch.Generator().manual_seed(3)
+    # q = e0 * sqrt(d) so that score(position n) = k[n][0]; the other coordinates add gaussian noise
+    q = torch.randn(E, hq, d, generator=g) * 0.05
+    q[:, :, 0] = d ** 0.5
+    n = P + E
+    if pattern == "ramp":        # +0.02 per token: ~1.8 log2 units per 64-token tile, never > 8 in one step
+        base = torch.arange(n, dtype=torch.float32) * 0.02
+    elif pattern == "spikes":    # flat, with a +40 spike every ~300 tokens, each higher than the last
+        base = torch.zeros(n)
+        for j, pos in enumerate(range(50, n, 300)):
+            base[pos] = 40.0 + 7.0 * j
+    else:                        # early peak at token 3, then a plateau 5.5 below it (inside the slack)
+        base = torch.full((n,), 4.0)
+        base[3] = 9.5
+    kfull = torch.randn(n, hkv, d, generator=g) * 0.3
+    kfull[:, :, 0] = base[:, None]
+    vfull = torch.randn(n, hkv, d, generator=g)
+    q, kfull, vfull = q.to(dtype), kfull.to(dtype), vfull.to(dtype)
+    pool = n + 3
+    slots = rng.permutation(pool - 1)[:n] + 1
+    kb = torch.zeros(pool, hkv, d, dtype=dtype)
+    vb = torch.zeros(pool, hkv, d, dtype=dtype)
+    kb[slots] = kfull
+    vb[slots] = vfull
+    kv_indptr = np.array([0, P], dtype=np.int32)
+    kv_indices = slots[:P].astype(np.int64)
+    qo = np.array([0, E], dtype=np.int64)
+    ke, ve = kfull[P:].contiguous(), vfull[P:].contiguous()
+    want, want_lse = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
+                                          sm_scale=1.0 / d ** 0.5, return_lse=True)
+    o = torch.zeros(E, hq, d, dtype=dtype, device=DEV)
+    lse = torch.zeros(E, hq, dtype=torch.float32, device=DEV)
+    ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo), _t(kv_indptr),
+                             _t(kv_indices), None, True, None, E, 1.0, 1.0, lse_extend=lse)
+    tol = 4e-3 if dtype == torch.float16 else 2e-2
+    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
+    assert err <= tol, (pattern, err)
+    np.testing.assert_allclose(_np(lse), want_lse, atol=5e-3, rtol=2e-3)
