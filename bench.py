@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle", type=int, default=5, help="untimed steps run before the warmup steps (state bring-up)")
     ap.add_argument("--bs", type=int, default=256)
     ap.add_argument("--ctx", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=32)
@@ -230,16 +231,25 @@ def radix_hit_bench(args, dev):
 def time_steps(fn, steps, warmup, world):
     import torch.distributed as dist
 
+    import gc
+
     for _ in range(warmup):
         fn()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        fn()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # no cyclic-GC pass inside the timed region: right after the sync the GPU queue is empty, so a 20-30 ms
+    # gen-2 collection on the host (seen once per few runs as ONE 26-ms "launch") idles the GPU for its length
+    gc.collect()
+    gc.disable()
+    try:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
     if world > 1:
         dist.barrier()
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -416,6 +426,10 @@ def main():
         decode_step(st, fb, world, ev_pairs if (timed["on"] and not os.environ.get("RX_BENCH_NO_EVENTS")) else None)
 
     # warmup untimed, then EXACTLY K timed steps (events are recorded inside the timed region)
+    # untimed settle steps before the W warmup steps: the first steps after a 128-GiB allocation run 2-3x long
+    # (first touch of the pools, clock ramp); they are part of bringing the state up, not of the measurement
+    for _ in range(args.settle):
+        step()
     for _ in range(args.warmup):
         step()
     # A timed event pair costs ~40 us of host time: invisible next to a 700-us TP=1 layer, but a TP shard's
@@ -440,7 +454,8 @@ def main():
     b_kv = bs * ctx * (st.hkv * st.D + st.hkv * st.D) * (1 if args.kv_dtype == "fp8" else 2)
     b_qo = 2 * bs * st.hq * st.D * 2
     bytes_per_launch = b_kv + b_qo
-    dur_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_pairs])) if ev_pairs else float("nan")
+    durs = np.array([a.elapsed_time(b) for a, b in ev_pairs]) if ev_pairs else np.array([float("nan")])
+    dur_ms = float(durs.mean())
     achieved = bytes_per_launch / (dur_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
     try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
@@ -455,7 +470,11 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "rx::decode_mfma_kernel",
-                "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dur_ms, "launches": len(ev_pairs)}
+                "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dur_ms, "launches": len(ev_pairs),
+                # spread of the same launches (the mean above is what `achieved` uses): a box in its slow state
+                # shows up here as min ~= median ~= mean, one-off stalls as a max far above the median
+                "launch_ms_min": float(durs.min()), "launch_ms_median": float(np.median(durs)),
+                "launch_ms_max": float(durs.max())}
 
     out = {
         "metric": "decode tokens/sec + extend TFLOPS, Llama-3-8B bs=256 ctx=4k (value = decode tokens/s of the "
@@ -470,7 +489,7 @@ def main():
                                   " + RCCL all-reduce (side stream)" if world > 1 else ""),
                    "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{world}",
                    "index_mode": args.index_mode, "kv_layout": args.kv_layout, "kv_dtype": args.kv_dtype,
-                   "split_policy": args.split_policy,
+                   "split_policy": args.split_policy, "settle_steps_untimed": args.settle,
                    "all_reduce": "p2p-two-shot" if getattr(st, "custom_ar", None) is not None else ("rccl" if world > 1 else "none"), "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
                    "kv_bytes_resident_per_gpu": int(sum(st.pool.get_kv_size_bytes()))},
         "roofline": roofline,
