@@ -178,3 +178,47 @@ def test_allocator_and_store_full_size_properties(ops):
     assert torch.equal(kb[loc], k) and torch.equal(vb[loc], v)
     assert int(kb.view(torch.int16).to(torch.int64).sum()) == int(k.view(torch.int16).to(torch.int64).sum())
     assert pool.check_errors() == 0
+
+
+def test_cascade_decode_full_size_properties(ops):
+    """Config 3's radix-hit batch at full size (256 requests, 3584 shared + 512 private tokens, page 16):
+    shared-prefix decode == per-request decode; the plan finds exactly the shared length; a one-hot V row inside
+    the shared prefix comes back with the weight the per-request kernel gives it; ragged private lengths."""
+    shared, uniq = 3584, 512
+    rng = np.random.default_rng(5)
+    n_pages = shared // PS + BS * (uniq // PS) + 1
+    ids = rng.permutation(np.arange(1, n_pages))
+    sh = (ids[: shared // PS, None] * PS + np.arange(PS)[None]).reshape(-1)
+    priv = (ids[shared // PS:].reshape(BS, uniq // PS)[:, :, None] * PS + np.arange(PS)[None, None]).reshape(BS, -1)
+    r2t_np = np.zeros((BS + 1, CTX), dtype=np.int32)
+    r2t_np[1:, :shared] = sh[None]
+    r2t_np[1:, shared:] = priv
+    r2t = torch.from_numpy(r2t_np).to(DEV)
+    rpi = torch.arange(1, BS + 1, dtype=torch.int64, device=DEV)
+    lens_np = shared + rng.integers(1, uniq + 1, size=BS)
+    lens_np[:4] = [shared + 1, shared + uniq, shared + 17, shared + 256]
+    lens = torch.from_numpy(lens_np.astype(np.int64)).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    pool = n_pages * PS
+    kb = torch.randn(pool, HKV, D, device=DEV, generator=g).to(torch.bfloat16)
+    vb = torch.randn(pool, HKV, D, device=DEV, generator=g).to(torch.bfloat16)
+    q = torch.randn(BS, HQ, D, device=DEV, generator=g).to(torch.bfloat16)
+    sm = D ** -0.5
+    ref = torch.empty_like(q)
+    ops.decode_attention_fwd_paged(q, kb, vb, ref, r2t, rpi, lens, None, None, None, 1, sm, page_size=PS)
+    cd = ops.CascadeDecode(BS, HQ, HKV, D, torch.bfloat16, DEV, max_shared=CTX)
+    cd.plan(r2t, rpi, lens)
+    assert cd.shared_len() == shared
+    assert torch.equal(cd.suffix_lens[:BS].cpu(), torch.from_numpy((lens_np - shared).astype(np.int32)))
+    o = torch.empty_like(q)
+    cd(q, kb, vb, o, sm, page_size=PS)
+    assert (o.float() - ref.float()).abs().max().item() <= 1.5e-2
+    # one-hot V at a shared token: every request reads the same row, with its own softmax weight
+    vb2 = torch.zeros_like(vb)
+    tok = 1234
+    vb2[int(sh[tok]), :, 7] = 1.0
+    ops.decode_attention_fwd_paged(q, kb, vb2, ref, r2t, rpi, lens, None, None, None, 1, sm, page_size=PS)
+    cd(q, kb, vb2, o, sm, page_size=PS)
+    assert ref[:, :, 7].float().abs().max().item() > 0
+    assert (o.float() - ref.float()).abs().max().item() <= 2e-3
+    assert o[:, :, :7].abs().max().item() == 0 and o[:, :, 8:].abs().max().item() == 0
