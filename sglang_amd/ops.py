@@ -281,7 +281,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
-def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
+def _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
                                attn_logits, attn_lse, num_kv_splits, max_kv_splits, sm_scale,
                                k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
                                page_size: int = 1, kv_layout=None, xai_temperature_len=-1,
@@ -312,6 +312,17 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
     if extra_o is not None:
         _set_extra_partials(p, extra_o, extra_lse, q)
     p.stages = int(stages)
+    return p
+
+
+def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
+                               attn_logits, attn_lse, num_kv_splits, max_kv_splits, sm_scale,
+                               k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
+                               page_size: int = 1, kv_layout=None, xai_temperature_len=-1,
+                               kv_start=None, extra_o=None, extra_lse=None, stages: int = 0):
+    p = _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse,
+                             num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap, sinks, page_size,
+                             kv_layout, xai_temperature_len, kv_start, extra_o, extra_lse, stages)
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -482,7 +493,15 @@ class CascadeDecode:
         self.q_rep = torch.zeros(S, max_bs, num_q_heads, head_dim, dtype=dtype, device=device)
         self.o_parts = torch.zeros(S, max_bs, num_q_heads, head_dim, dtype=dtype, device=device)
         self.lse_parts = torch.zeros(S, max_bs, num_q_heads, dtype=torch.float32, device=device)
+        self.qo_indptr = torch.zeros(S + 1, **i32)
+        # suffix partials: bs * S(bs) <= cu / (Hkv * ceil(G / 16)) + bs rows per head (native schedule), >= 2 slots
+        group = max(1, num_q_heads // num_kv_heads)
+        rows = (max(2 * max_bs, cu_count // (num_kv_heads * ((group + 15) // 16)) + max_bs) + 1) * num_q_heads
+        self.attn_logits = torch.empty(rows * head_dim, dtype=torch.float32, device=device)
+        self.attn_lse = torch.empty(rows, dtype=torch.float32, device=device)
         self.bs = 0
+        self._params = {}  # (k ptr, v ptr, bs, scalars) -> filled rx_extend_params / rx_decode_params
+        self._lib = _L.load()
         # overlap: phase 1 (MFMA-bound) on a side stream next to phase 2's stage 1 (HBM-bound), joined before
         # stage 2.  Measured at bs=256 / 3584 shared / 512 private: 166 -> 156 us per layer, but the two extra
         # stream waits cost more host time than that on small batches -- off by default.
@@ -501,12 +520,9 @@ class CascadeDecode:
         get_num_kv_splits_native(self.num_kv_splits[:bs], self.suffix_lens[:bs], self.hq, self.hkv,
                                  self.max_kv_splits, self.cu_count)
         S = self.num_chunks
-        self.qo_indptr = torch.arange(0, (S + 1) * bs, bs, dtype=torch.int32, device=seq_lens.device)
-        rows = bs * self.hq * self.max_kv_splits
-        if getattr(self, "_rows", 0) < rows:
-            self.attn_logits = torch.empty(rows * self.d, dtype=torch.float32, device=seq_lens.device)
-            self.attn_lse = torch.empty(rows, dtype=torch.float32, device=seq_lens.device)
-            self._rows = rows
+        torch.arange(0, (S + 1) * bs, bs, out=self.qo_indptr)
+        if bs * self.hq * self.max_kv_splits > self.attn_lse.numel():
+            raise RuntimeError("CascadeDecode: partials scratch too small")  # sized for every bs <= max_bs
 
     def shared_len(self) -> int:
         """Host copy of L (synchronises; diagnostics / tests only)."""
@@ -528,19 +544,48 @@ class CascadeDecode:
         attn_lse = self.attn_lse[: bs * self.hq * self.max_kv_splits].view(bs, self.hq, self.max_kv_splits)
         qf, of = q_rep.view(S * bs, self.hq, self.d), o_parts.view(S * bs, self.hq, self.d)
 
+        # the two parameter blocks depend on the layer's buffers, bs and a few scalars only: filled once, then
+        # just q / o / sinks are patched (per-layer host cost: one copy + two ctypes calls)
+        key = (k_buffer.data_ptr(), v_buffer.data_ptr(), bs, self.max_kv_splits, float(sm_scale), float(k_scale),
+               float(v_scale), float(logit_cap), page_size, req_to_token.data_ptr())
+        ent = self._params.get(key)
+        if ent is None:
+            if len(self._params) > 4096:
+                self._params.clear()
+            pe = _extend_params(qf, qf, qf, of, k_buffer, v_buffer, self.qo_indptr, self.chunk_indptr,
+                                self.shared_indices, None, False, None, bs, k_scale, 1.0, sm_scale=sm_scale,
+                                logit_cap=logit_cap, lse_extend=lse_parts.view(S * bs, self.hq), skip_extend=True,
+                                page_size=page_size, kv_layout=kv_layout, _num_kv_heads=self.hkv, avg_kv_len_hint=0)
+            pd = _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
+                                      attn_lse, self.num_kv_splits[:bs], self.max_kv_splits, sm_scale, k_scale,
+                                      v_scale, logit_cap, None, page_size, kv_layout, kv_start=self.kv_start[:bs],
+                                      extra_o=o_parts, extra_lse=lse_parts)
+            ent = self._params[key] = (pe, C.byref(pe), pd, C.byref(pd), (k_buffer, v_buffer, req_to_token))
+        pe, pe_ref, pd, pd_ref, _ = ent
+        # per-forward tensors of the caller (fresh every step in eager serving): patched, not part of the key
+        pd.req_pool_indices, pd.req_pool_indices_is_i64 = req_pool_indices.data_ptr(), _is64(req_pool_indices, "req_pool_indices")
+        pd.seq_lens, pd.seq_lens_is_i64 = seq_lens.data_ptr(), _is64(seq_lens, "seq_lens")
+        if q.stride(-1) != 1 or o.stride(-1) != 1 or q.dtype != self.q_rep.dtype or o.dtype != q.dtype:
+            raise ValueError("CascadeDecode: q / o must be contiguous in head_dim and of the planned dtype")
+        pd.q, pd.o = q.data_ptr(), o.data_ptr()
+        pd.q_stride_t, pd.q_stride_h, pd.o_stride_t, pd.o_stride_h = q.stride(0), q.stride(1), o.stride(0), o.stride(1)
+        if sinks is not None and sinks.dtype != torch.float32:
+            sinks = sinks.float()
+        pd.sinks = None if sinks is None else sinks.data_ptr()
+        self._sinks_keep = sinks
+        lib = self._lib
+
         def phase1():
             q_rep.copy_(q.unsqueeze(0).expand(S, -1, -1, -1))
-            extend_attention_fwd(qf, qf, qf, of, k_buffer, v_buffer, self.qo_indptr, self.chunk_indptr,
-                                 self.shared_indices, None, False, None, bs, k_scale, 1.0, sm_scale=sm_scale,
-                                 logit_cap=logit_cap, lse_extend=lse_parts.view(S * bs, self.hq), skip_extend=True,
-                                 page_size=page_size, kv_layout=kv_layout, _num_kv_heads=self.hkv, avg_kv_len_hint=0)
+            st = lib.rx_extend_attn(pe_ref, _stream(q))
+            if st:
+                _L.check(st, "rx_extend_attn")
 
         def phase2(stages):  # suffixes [L, seq_len_b); stage 2 merges everything (sinks join once, there)
-            decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
-                                       attn_logits, attn_lse, self.num_kv_splits[:bs], self.max_kv_splits, sm_scale,
-                                       k_scale, v_scale, logit_cap, sinks, page_size, kv_layout,
-                                       kv_start=self.kv_start[:bs], extra_o=o_parts, extra_lse=lse_parts,
-                                       stages=stages)
+            pd.stages = stages
+            st = lib.rx_decode_attn(pd_ref, _stream(q))
+            if st:
+                _L.check(st, "rx_decode_attn")
 
         if self._side is None:
             phase1()
@@ -606,7 +651,7 @@ class StoreLauncher:
 # --------------------------------------------------------------------------------------
 # K7  extend_attention_fwd      kernels/ops/attention/extend_attention.py:664-812
 # --------------------------------------------------------------------------------------
-def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
+def _extend_params(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
                          kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr,
                          max_len_extend, k_scale, v_scale, sm_scale=None, logit_cap=0.0,
                          skip_prefix_custom_mask=True, sliding_window_size=-1, sinks=None,
@@ -697,6 +742,25 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
             p.window_kv_offsets = wo.data_ptr()
     p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
     p._keep_mask = keep
+    return p
+
+
+def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
+                         kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr,
+                         max_len_extend, k_scale, v_scale, sm_scale=None, logit_cap=0.0,
+                         skip_prefix_custom_mask=True, sliding_window_size=-1, sinks=None,
+                         window_kv_offsets=None, xai_temperature_len=-1, lse_extend=None,
+                         skip_prefix=False, skip_extend=False, page_size: int = 1,
+                         score_mod=None, aux_tensors=None, kv_layout=None, unified_prefix_lens=None,
+                         _num_kv_heads=None, avg_kv_len_hint=None):
+    p = _extend_params(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                       custom_mask, is_causal, mask_indptr, max_len_extend, k_scale, v_scale, sm_scale=sm_scale,
+                       logit_cap=logit_cap, skip_prefix_custom_mask=skip_prefix_custom_mask,
+                       sliding_window_size=sliding_window_size, sinks=sinks, window_kv_offsets=window_kv_offsets,
+                       xai_temperature_len=xai_temperature_len, lse_extend=lse_extend, skip_prefix=skip_prefix,
+                       skip_extend=skip_extend, page_size=page_size, score_mod=score_mod, aux_tensors=aux_tensors,
+                       kv_layout=kv_layout, unified_prefix_lens=unified_prefix_lens, _num_kv_heads=_num_kv_heads,
+                       avg_kv_len_hint=avg_kv_len_hint)
     _L.check(_L.load().rx_extend_attn(C.byref(p), _stream(q_extend)), "rx_extend_attn")
 
 
