@@ -13,14 +13,32 @@ Wire-up on the reference side (nothing in SGLang itself changes):
 """
 from __future__ import annotations
 
+import os
+
 BACKEND_NAME = "hip_radix"
+
+
+def backend_options() -> dict:
+    """Backend knobs SGLang's ServerArgs has no field for, read from the environment:
+    SGLANG_HIP_RADIX_INDEX_MODE = paged | indices, SGLANG_HIP_RADIX_SPLIT_POLICY = native | reference,
+    SGLANG_HIP_RADIX_CASCADE = 1 (shared-prefix decode) with
+    SGLANG_HIP_RADIX_CASCADE_MIN_BS / _MIN_SHARED."""
+    env = os.environ
+    opts = {"decode_index_mode": env.get("SGLANG_HIP_RADIX_INDEX_MODE", "paged"),
+            "split_policy": env.get("SGLANG_HIP_RADIX_SPLIT_POLICY", "native"),
+            "cascade_decode": env.get("SGLANG_HIP_RADIX_CASCADE", "0") not in ("", "0", "false", "False")}
+    if "SGLANG_HIP_RADIX_CASCADE_MIN_BS" in env:
+        opts["cascade_min_bs"] = int(env["SGLANG_HIP_RADIX_CASCADE_MIN_BS"])
+    if "SGLANG_HIP_RADIX_CASCADE_MIN_SHARED" in env:
+        opts["cascade_min_shared"] = int(env["SGLANG_HIP_RADIX_CASCADE_MIN_SHARED"])
+    return opts
 
 
 def make_backend(model_runner):
     """Factory with the signature ATTENTION_BACKENDS expects: fn(model_runner) -> backend."""
     from .attention.backend import HipRadixAttnBackend
 
-    return HipRadixAttnBackend(model_runner)
+    return HipRadixAttnBackend(model_runner, **backend_options())
 
 
 def make_sglang_backend_class():
@@ -33,7 +51,7 @@ def make_sglang_backend_class():
     class SGLangHipRadixAttnBackend(HipRadixAttnBackend, AttentionBackend):
         def __init__(self, model_runner):
             AttentionBackend.__init__(self)
-            HipRadixAttnBackend.__init__(self, _RunnerView(model_runner))
+            HipRadixAttnBackend.__init__(self, _RunnerView(model_runner), **backend_options())
 
     return SGLangHipRadixAttnBackend
 
@@ -52,6 +70,7 @@ class _RunnerView:
         self.tp_size = getattr(mr, "tp_size", 1)
         # hybrid sliding-window models: window metadata is built next to the full one (triton_backend.py:259-276)
         self.sliding_window_size = getattr(mr, "sliding_window_size", None)
+        self.dtype = getattr(mr, "dtype", None)  # q / o dtype (an fp8 pool cannot tell)
 
         class _MC:
             num_attention_heads = mr.model_config.num_attention_heads

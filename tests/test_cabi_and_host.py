@@ -226,3 +226,17 @@ def test_backend_satisfies_reference_attention_backend_abc():
     # the breakable-graph / chunked-prefix paths are opt-in flags on the ABC; we leave them off
     assert ref.use_captured_forward_metadata_for_breakable_cuda_graph is False
     assert ref.supports_full_cuda_graph_chunked_prefix is False
+
+
+def test_plugin_backend_options_from_environment(monkeypatch):
+    from sglang_amd import plugin
+
+    for k in list(os.environ):
+        if k.startswith("SGLANG_HIP_RADIX_"):
+            monkeypatch.delenv(k)
+    assert plugin.backend_options() == {"decode_index_mode": "paged", "split_policy": "native", "cascade_decode": False}
+    monkeypatch.setenv("SGLANG_HIP_RADIX_CASCADE", "1")
+    monkeypatch.setenv("SGLANG_HIP_RADIX_CASCADE_MIN_BS", "4")
+    monkeypatch.setenv("SGLANG_HIP_RADIX_SPLIT_POLICY", "reference")
+    o = plugin.backend_options()
+    assert o["cascade_decode"] is True and o["cascade_min_bs"] == 4 and o["split_policy"] == "reference"
