@@ -210,11 +210,17 @@ class RowParallelOProj:
     def __init__(self, full_weight: torch.Tensor, shard: HeadShard, head_dim: int, group: TPGroup):
         lo = shard.q_head_start * head_dim
         hi = lo + shard.num_q_heads * head_dim
-        self.weight = full_weight[lo:hi].contiguous()
+        # stored [hidden, Hq_local*D] (the nn.Linear layout): hipBLASLt's NT kernel runs the TP=1 shape
+        # [256, 4096] x [4096, 4096] in 19-20 us against 24-25 us for the row-major weight
+        self.weight_t = full_weight[lo:hi].t().contiguous()
         self.group = group
 
+    @property
+    def weight(self) -> torch.Tensor:
+        return self.weight_t.t()
+
     def forward(self, attn_out: torch.Tensor, overlap: bool = False):
-        y = torch.matmul(attn_out, self.weight)
+        y = torch.nn.functional.linear(attn_out, self.weight_t)
         if overlap:
             return self.group.all_reduce_async(y)
         return _Done(self.group.all_reduce(y))
