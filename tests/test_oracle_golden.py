@@ -325,3 +325,16 @@ def test_extend_unified_golden(golden_dir):
         ok = np.isfinite(want).all(axis=-1)
         assert ok.mean() > 0.8, name
         assert np.abs(got[ok] - want[ok]).max() <= 2e-3, (name, np.abs(got[ok] - want[ok]).max())
+
+
+def test_cpu_baseline_container_fixture(golden_dir):
+    """SURVEY 8(d) CPU-baseline item (1): the reference's compiled CPU kernel and the C restatement timed in
+    the build container on identical inputs (oracle/time_cpu_container.py) -- fixture present and consistent."""
+    import json
+    import os
+
+    d = json.load(open(os.path.join(golden_dir, "cpu_baseline_container.json")))
+    assert d["reference"]["kind"] == "reference" and d["port"]["kind"] == "port"
+    for k in ("reference", "port"):
+        assert d[k]["ms_per_layer"] > 0 and abs(d[k]["value"] - 256 / (32 * d[k]["ms_per_layer"] * 1e-3)) < 1e-6
+    assert d["parity_max_abs_reference_vs_port_small_case"] <= 2e-3  # bf16 outputs of two summation orders
