@@ -1,0 +1,186 @@
+"""One parity case per BASELINE.json config, at that config's own head geometry and context length (batch cut to
+what the fp64 oracle finishes in seconds).  configs[2] -- the metric's shape -- also has the full-size property
+tests (test_gpu_fullsize.py) and is what bench.py runs.
+
+  0  OPT-125m, bs 4, ctx 512 (MHA 12 x 64)                       extend of the prompts + one decode step
+  1  Llama-3-8B, bs 64, 2k prompt / 128 gen                      2k-token extend without prefix + decode at 2k+
+  2  Llama-3-8B, bs 256, one shared 3584-token prefix + 512 new  extend over a shared (radix-hit) prefix
+  3  Llama-3-70B TP 8 shard (Hq 8, Hkv 1), bs 128, ctx 4k        decode, split-KV
+  4  DeepSeek-V3-style MLA fp8, TP 8 (Hq 16, 576 / 512), ctx 8k  decode over fp8 latent rows
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import radix_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FP8 = torch.float8_e4m3fn
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sglang_amd import ops as _ops
+
+    return _ops
+
+
+def _bits(t):
+    if t.dtype == torch.bfloat16:
+        return t.detach().cpu().contiguous().view(torch.uint16).numpy()
+    return t.detach().cpu().numpy()
+
+
+def _T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _pages(rng, n_tokens_per_req, page):
+    """shuffled pages (page 0 reserved) -> req_to_token rows (row 0 = padding) and the pool size in slots"""
+    per = [-(-int(n) // page) for n in n_tokens_per_req]
+    ids = rng.permutation(np.arange(1, sum(per) + 1))
+    r2t = np.zeros((len(per) + 1, max(per) * page), dtype=np.int32)
+    pi = 0
+    for i, k in enumerate(per):
+        r2t[i + 1, : k * page] = (ids[pi: pi + k, None] * page + np.arange(page)[None]).reshape(-1)
+        pi += k
+    return r2t, (sum(per) + 1) * page
+
+
+def _extend_then_decode(ops, dtype, hq, hkv, d, page, prefix, ext, tol_o):
+    """prompts (prefix cached + ext new tokens) through store + extend, then one decode step; vs the oracle"""
+    rng = np.random.default_rng(hq * 1000 + d + len(ext))
+    bs = len(ext)
+    seq = [p + e + 1 for p, e in zip(prefix, ext)]  # +1: the decode step's token
+    r2t, pool = _pages(rng, seq, page)
+    g = torch.Generator().manual_seed(hq + d)
+    kb = torch.zeros(pool, hkv, d, dtype=dtype, device=DEV)
+    vb = torch.zeros(pool, hkv, d, dtype=dtype, device=DEV)
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    # cached prefix rows
+    for i, p in enumerate(prefix):
+        if p:
+            loc = _T(r2t[i + 1, :p].astype(np.int64))
+            ops.store_cache(torch.randn(p, hkv * d, generator=g).to(dtype).to(DEV),
+                            torch.randn(p, hkv * d, generator=g).to(dtype).to(DEV),
+                            kb.view(pool, -1), vb.view(pool, -1), loc)
+    T_ = int(sum(ext))
+    q = torch.randn(T_, hq, d, generator=g).to(dtype)
+    ke = torch.randn(T_, hkv, d, generator=g).to(dtype)
+    ve = torch.randn(T_, hkv, d, generator=g).to(dtype)
+    ext_loc = np.concatenate([r2t[i + 1, p: p + e] for i, (p, e) in enumerate(zip(prefix, ext))]).astype(np.int64)
+    ops.store_cache(ke.view(T_, -1).to(DEV), ve.view(T_, -1).to(DEV), kb.view(pool, -1), vb.view(pool, -1), _T(ext_loc))
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, np.asarray(prefix, dtype=np.int64))
+    qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
+    sm = d ** -0.5
+    o = torch.zeros(T_, hq, d, dtype=dtype, device=DEV)
+    ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb, vb, _T(qo), _T(kv_indptr), _T(kv_indices),
+                             None, True, None, int(max(ext)), 1.0, 1.0, sm_scale=sm, page_size=page)
+    want = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr, kv_indices,
+                                sm_scale=sm)
+    err = np.abs(o.float().cpu().numpy().astype(np.float64) - want).max()
+    assert err <= tol_o, ("extend", err)
+    # one decode step on top
+    lens = np.asarray(seq, dtype=np.int64)
+    new_loc = np.array([r2t[i + 1, s - 1] for i, s in enumerate(seq)], dtype=np.int64)
+    kd = torch.randn(bs, hkv * d, generator=g).to(dtype).to(DEV)
+    vd = torch.randn(bs, hkv * d, generator=g).to(dtype).to(DEV)
+    ops.store_cache(kd, vd, kb.view(pool, -1), vb.view(pool, -1), _T(new_loc))
+    qd = torch.randn(bs, hq, d, generator=g).to(dtype)
+    od = torch.zeros(bs, hq, d, dtype=dtype, device=DEV)
+    ops.decode_attention_fwd_paged(qd.to(DEV), kb, vb, od, _T(r2t), _T(rpi), _T(lens), None, None, None, 1, sm,
+                                   page_size=page)
+    ip, ii = orc.build_kv_indices(r2t, rpi, lens)
+    want_d = orc.decode_attention(_bits(qd), _bits(kb), _bits(vb), ip, ii, sm)
+    err = np.abs(od.float().cpu().numpy().astype(np.float64) - want_d).max()
+    assert err <= tol_o, ("decode", err)
+
+
+def test_config0_opt125m_bs4_ctx512(ops):
+    # OPT-125m: 12 heads x 64, MHA, fp16; prompts that end at ctx 512 after the decode step
+    _extend_then_decode(ops, torch.float16, 12, 12, 64, 1, prefix=[0, 0, 0, 0], ext=[511, 300, 128, 17], tol_o=3e-3)
+
+
+def test_config1_llama8b_2k_prompt(ops):
+    # Llama-3-8B geometry (GQA 4:1, D 128), one TP-4 slice of the heads (Hq 8 / Hkv 2), a 2048-token prompt
+    _extend_then_decode(ops, torch.bfloat16, 8, 2, 128, 16, prefix=[0, 0], ext=[2048, 777], tol_o=1.5e-2)
+
+
+def test_config2_shared_prefix_extend(ops):
+    # config 2/3 of the survey: every request hits the same 3584-token cached prefix and adds 512 new tokens
+    dtype, hq, hkv, d, page, P, E, bs = torch.bfloat16, 4, 1, 128, 16, 3584, 512, 2
+    rng = np.random.default_rng(2)
+    r2t_p, pool_p = _pages(rng, [P], page)
+    g = torch.Generator().manual_seed(2)
+    pool = pool_p
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    q = torch.randn(bs * E, hq, d, generator=g).to(dtype)
+    ke = torch.randn(bs * E, hkv, d, generator=g).to(dtype)
+    ve = torch.randn(bs * E, hkv, d, generator=g).to(dtype)
+    kv_indices = np.tile(r2t_p[1, :P].astype(np.int64), bs)          # identical rows: the radix hit
+    kv_indptr = (np.arange(bs + 1) * P).astype(np.int32)
+    qo = (np.arange(bs + 1) * E).astype(np.int64)
+    sm = d ** -0.5
+    o = torch.zeros_like(q, device=DEV)
+    lse = torch.zeros(bs * E, hq, dtype=torch.float32, device=DEV)
+    ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _T(qo), _T(kv_indptr),
+                             _T(kv_indices), None, True, None, E, 1.0, 1.0, sm_scale=sm, lse_extend=lse, page_size=page)
+    want, want_lse = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr,
+                                          kv_indices, sm_scale=sm, return_lse=True)
+    assert np.abs(o.float().cpu().numpy().astype(np.float64) - want).max() <= 1.5e-2
+    np.testing.assert_allclose(lse.cpu().numpy(), want_lse, atol=5e-3, rtol=2e-3)
+
+
+def test_config3_llama70b_tp8_shard_decode(ops):
+    # Llama-3-70B under TP 8: 64 / 8 = 8 q heads and 8 / 8 = 1 kv head per GPU, D 128, ctx 4k
+    dtype, hq, hkv, d, page = torch.bfloat16, 8, 1, 128, 16
+    rng = np.random.default_rng(3)
+    lens = np.array([4096, 4095, 4000, 2049, 4096, 33, 1, 3000], dtype=np.int64)
+    bs = len(lens)
+    r2t, pool = _pages(rng, lens, page)
+    g = torch.Generator().manual_seed(3)
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    q = torch.randn(bs, hq, d, generator=g).to(dtype)
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    sm = d ** -0.5
+    ip, ii = orc.build_kv_indices(r2t, rpi, lens)
+    want = orc.decode_attention(_bits(q), _bits(kb), _bits(vb), ip, ii, sm)
+    qd, kbd, vbd = q.to(DEV), kb.to(DEV), vb.to(DEV)
+    for S in (1, 8):  # single pass and the split-KV schedule a small TP shard batch gets
+        o = torch.zeros(bs, hq, d, dtype=dtype, device=DEV)
+        if S == 1:
+            ops.decode_attention_fwd_paged(qd, kbd, vbd, o, _T(r2t), _T(rpi), _T(lens), None, None, None, 1, sm,
+                                           page_size=page)
+        else:
+            ns = torch.zeros(bs, dtype=torch.int32, device=DEV)
+            ops.get_num_kv_splits_native(ns, _T(lens), hq, hkv, S, 256)
+            al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
+            ls = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+            ops.decode_attention_fwd_paged(qd, kbd, vbd, o, _T(r2t), _T(rpi), _T(lens), al, ls, ns, S, sm,
+                                           page_size=page)
+        assert np.abs(o.float().cpu().numpy().astype(np.float64) - want).max() <= 1e-2, S
+
+
+def test_config4_mla_fp8_tp8_decode(ops):
+    # DeepSeek-V3 MLA under TP 8: 128 / 8 = 16 q heads, latent rows 512 + 64 in fp8 e4m3fn, ctx 8k
+    dtype, hq, page = torch.bfloat16, 16, 64
+    rng = np.random.default_rng(4)
+    lens = np.array([8192, 8191, 4097, 64], dtype=np.int64)
+    bs = len(lens)
+    r2t, pool = _pages(rng, lens, page)
+    g = torch.Generator().manual_seed(4)
+    kv = torch.randn(pool, 1, 576, generator=g).to(FP8)
+    q = torch.randn(bs, hq, 576, generator=g).to(dtype)
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    sm = (128 + 64) ** -0.5
+    ip, ii = orc.build_kv_indices(r2t, rpi, lens)
+    kvn = orc.fp8_e4m3fn_decode(kv.view(torch.uint8).numpy())
+    want = orc.decode_attention(_bits(q), kvn, kvn[..., :512], ip, ii, sm)
+    kvd = kv.to(DEV)
+    o = torch.zeros(bs, hq, 512, dtype=dtype, device=DEV)
+    ops.decode_attention_fwd_paged(q.to(DEV), kvd, kvd[..., :512], o, _T(r2t), _T(rpi), _T(lens), None, None, None, 1,
+                                   sm, page_size=page)
+    assert np.abs(o.float().cpu().numpy().astype(np.float64) - want).max() <= 1e-2
