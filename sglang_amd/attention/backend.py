@@ -87,7 +87,7 @@ class HipRadixAttnBackend:
 
     def __init__(self, model_runner, decode_index_mode: str = "paged",
                  max_kv_splits: Optional[int] = None, split_policy: str = "native",
-                 cascade_decode: bool = False, cascade_min_bs: int = 8, cascade_min_shared: int = 256):
+                 cascade_decode: bool = False, cascade_min_bs: int = 16, cascade_min_shared: int = 1024):
         self.device = model_runner.device
         self.req_to_token_pool = model_runner.req_to_token_pool
         self.token_to_kv_pool = model_runner.token_to_kv_pool

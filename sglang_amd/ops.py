@@ -473,7 +473,7 @@ class CascadeDecode:
     sliding windows or the Grok temperature (position dependent per request)."""
 
     def __init__(self, max_bs: int, num_q_heads: int, num_kv_heads: int, head_dim: int, dtype, device,
-                 max_shared: int, cu_count: int = 256, min_shared: int = 256, max_kv_splits: int = 16,
+                 max_shared: int, cu_count: int = 256, min_shared: int = 1024, max_kv_splits: int = 16,
                  num_chunks: Optional[int] = None, overlap: bool = False):
         if head_dim not in (64, 128):
             raise ValueError("CascadeDecode: head_dim 64 / 128 (the MFMA extend kernels)")
