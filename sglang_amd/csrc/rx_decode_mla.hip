@@ -63,7 +63,6 @@ constexpr int kMlaTile = 32;
 constexpr int kMlaRowBytes = kMlaDk * 2;          // 1152
 constexpr int kMlaLdsRow = kMlaRowBytes + 16;     // 1168: padded LDS row stride
 constexpr int kMlaChunks = kMlaRowBytes / 16;     // 72 16-byte chunks per row
-constexpr int kMlaStage = kMlaTile * kMlaChunks / 256;  // 9 chunks per thread per tile
 
 template <bool LINEAR>
 __device__ __forceinline__ int64_t mla_slot_off(int64_t slot, int32_t page_size, int64_t page_stride,

@@ -51,7 +51,6 @@ struct ExtendArgs {
 #define RX_EXT_CB 2
 #endif
 constexpr int kQPerWave = 16 * RX_EXT_CB;
-constexpr int kETile = 32;
 
 template <int D>
 __device__ __forceinline__ int v_swz(int row) {

@@ -361,7 +361,6 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const int kaddr = ql * kKStride + h * 16;                                        // K row 32 b + ql
   const int vaddr = kKTile + (4 * h + qd) * kVStride + (2 * dg + (pp >> 1)) * 16 + 8 * (pp & 1);
   const bool capped = a.logit_cap > 0.f;
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   // K fragment (block b, k-step ks): lane (ql, h) <- K[32 b + ql][16 ks + 8 h .. +8]
 #ifndef RX_EXT32_ABL
