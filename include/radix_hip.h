@@ -185,7 +185,8 @@ typedef struct rx_decode_params {
    * extra_o / extra_lse: num_extra_partials more partial results per (request, head) -- dense
    * [num_extra, bs, Hq, Dv] of dtype (already divided by their own softmax sums, NOT multiplied by v_scale)
    * and natural-log LSEs fp32 [num_extra, bs, Hq] (-inf = empty partial, row ignored) -- that stage 2
-   * merges with the kv splits.  Needs max_kv_splits > 1 (there is no merge in the single-pass form). */
+   * merges with the kv splits; with max_kv_splits == 1 the D = 64 / 128 kernel folds them into its own
+   * epilogue (no fp32 partials, no second launch), the other kernels need max_kv_splits > 1. */
   const int32_t* kv_start;
   const void* extra_o;
   const float* extra_lse;

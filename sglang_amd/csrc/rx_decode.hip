@@ -64,6 +64,35 @@ __device__ __forceinline__ float xai_factor(int32_t xai_len, int32_t seq_len) {
   return __log2f(static_cast<float>(qidx)) / __log2f(static_cast<float>(xai_len));
 }
 
+// Single-pass epilogue with extra partials (shared-prefix decode): folds the extras of (request b, head h),
+// column d, into the running (max in log2 units, sum, weighted value) of this workgroup's own pass -- what
+// stage 2 would do, without the fp32 partial round trip and the second launch.
+template <typename T>
+__device__ __forceinline__ void fold_extras(const DecodeArgs& a, int b, int h, int d, int dv, float& mx, float& lsum,
+                                            float& acc) {
+  constexpr int kBatch = 4;  // loads of a batch are issued together: one memory latency per batch, not per partial
+  for (int x0 = 0; x0 < a.num_extra; x0 += kBatch) {
+    float xl[kBatch], xv[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      const int x = min(x0 + j, a.num_extra - 1);
+      const int64_t xrow = (static_cast<int64_t>(x) * a.bs + b) * a.hq + h;
+      xl[j] = a.extra_lse[xrow];
+      xv[j] = T::to_f32(a.extra_o[xrow * dv + d]);
+    }
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      if (x0 + j >= a.num_extra || !(xl[j] > -INFINITY)) continue;  // past the end / empty partial (row undefined)
+      const float m2 = xl[j] * kLog2e;
+      const float nm = fmaxf(mx, m2);
+      const float so = fast_exp2(mx - nm), w = fast_exp2(m2 - nm);
+      acc = acc * so + w * xv[j];
+      lsum = lsum * so + w;
+      mx = nm;
+    }
+  }
+}
+
 constexpr int kMinBlockKV = 32;  // decode_attention.py:36 (_MIN_BLOCK_KV)
 constexpr int kTile = 32;        // tokens per wave tile (K of the PV MFMA)
 constexpr int kWavesPerWG = 4;
@@ -202,8 +231,17 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
     if (single && si.seq_len == 0) {  // empty request: define the output (reference: 0/0)
       for (int i = tid; i < 16 * D; i += 256) {
         const int q = i / D, d = i % D;
-        if (qb * 16 + q < a.group)
-          a.o[b * a.o_stride_t + (kvh * a.group + qb * 16 + q) * a.o_stride_h + d] = 0;
+        if (qb * 16 + q >= a.group) continue;
+        const int hh = kvh * a.group + qb * 16 + q;
+        float out = 0.f;
+        if (a.num_extra) {  // nothing of its own to attend: the extra partials are the whole result
+          float mx = -INFINITY, lsum = 0.f, acc = 0.f;
+          fold_extras<T>(a, b, hh, d, D, mx, lsum, acc);
+          float den = lsum;
+          if (a.sinks) den += fast_exp2(a.sinks[hh] * kLog2e - mx);
+          out = acc / den * a.v_scale;
+        }
+        a.o[b * a.o_stride_t + hh * a.o_stride_h + d] = T::from_f32(out);
       }
     }
     return;
@@ -415,6 +453,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
       acc += reinterpret_cast<const float*>(smem + ww * TILE_BYTES)[q * D + d] * sc;
     }
     if (single) {
+      if (a.num_extra) fold_extras<T>(a, b, hh, d, D, mx, lsum, acc);
       float den = lsum;
       if (a.sinks) den += fast_exp2(a.sinks[hh] * kLog2e - mx);
       a.o[b * a.o_stride_t + hh * a.o_stride_h + d] = T::from_f32(acc / den * a.v_scale);
@@ -768,8 +807,9 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.extra_o = a.num_extra ? (const uint16_t*)p->extra_o : nullptr;
   a.extra_lse = a.num_extra ? p->extra_lse : nullptr;
   if (a.num_extra)
-    RX_REQUIRE(p->extra_o && p->extra_lse && max_splits > 1,
-               "rx_decode_attn: extra partials need extra_o, extra_lse and max_kv_splits > 1 (stage 2 merges them)");
+    RX_REQUIRE(p->extra_o && p->extra_lse && (max_splits > 1 || mfma_ok),
+               "rx_decode_attn: extra partials need extra_o, extra_lse and either max_kv_splits > 1 (stage 2 merges "
+               "them) or the D = 64 / 128 kernel (its single-pass epilogue folds them in)");
   RX_REQUIRE(!(mode_a && p->kv_start), "rx_decode_attn: kv_start applies to the req_to_token lookup only "
              "(with kv_indices, build the list with rx_build_kv_indices' kv_start)");
   const bool linear = p->kv.page_size == 1 ||

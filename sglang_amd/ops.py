@@ -515,10 +515,15 @@ class CascadeDecode:
         shared_prefix_plan(req_to_token, req_pool_indices, seq_lens, self.plan_buf, self.chunk_indptr,
                            self.shared_indices, self.kv_start[:bs], self.suffix_lens[:bs],
                            min_shared=self.min_shared)
-        # suffix kv splits: the native schedule on the suffix lengths; >= 2 slots so that stage 2 runs
-        self.max_kv_splits = max(2, native_max_kv_splits(bs, self.hq, self.hkv, self.cu_count, self.split_cap))
-        get_num_kv_splits_native(self.num_kv_splits[:bs], self.suffix_lens[:bs], self.hq, self.hkv,
-                                 self.max_kv_splits, self.cu_count)
+        # suffix kv splits: the native schedule on the suffix lengths.  One split (a batch that fills the chip by
+        # itself): the decode kernel's single-pass epilogue folds the chunk partials in -- no fp32 partials, no
+        # stage-2 launch.  (The side-stream overlap joins before stage 2, so it keeps >= 2 slots.)
+        self.max_kv_splits = native_max_kv_splits(bs, self.hq, self.hkv, self.cu_count, self.split_cap)
+        if self._side is not None:
+            self.max_kv_splits = max(2, self.max_kv_splits)
+        if self.max_kv_splits > 1:
+            get_num_kv_splits_native(self.num_kv_splits[:bs], self.suffix_lens[:bs], self.hq, self.hkv,
+                                     self.max_kv_splits, self.cu_count)
         S = self.num_chunks
         torch.arange(0, (S + 1) * bs, bs, out=self.qo_indptr)
         if bs * self.hq * self.max_kv_splits > self.attn_lse.numel():
@@ -557,7 +562,8 @@ class CascadeDecode:
                                 logit_cap=logit_cap, lse_extend=lse_parts.view(S * bs, self.hq), skip_extend=True,
                                 page_size=page_size, kv_layout=kv_layout, _num_kv_heads=self.hkv, avg_kv_len_hint=0)
             pd = _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits,
-                                      attn_lse, self.num_kv_splits[:bs], self.max_kv_splits, sm_scale, k_scale,
+                                      attn_lse, self.num_kv_splits[:bs] if self.max_kv_splits > 1 else None,
+                                      self.max_kv_splits, sm_scale, k_scale,
                                       v_scale, logit_cap, None, page_size, kv_layout, kv_start=self.kv_start[:bs],
                                       extra_o=o_parts, extra_lse=lse_parts)
             ent = self._params[key] = (pe, C.byref(pe), pd, C.byref(pd), (k_buffer, v_buffer, req_to_token))
