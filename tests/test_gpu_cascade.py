@@ -242,3 +242,30 @@ def test_cascade_plan_and_layer_replay_under_hip_graph(ops):
         ref = torch.zeros_like(q)
         ops.decode_attention_fwd_paged(q, kb, vb, ref, r2t, rpi, lens, None, None, None, 1, sm, page_size=page)
         assert (o.float() - ref.float()).abs().max().item() <= 1.5e-2
+
+
+def test_cascade_decode_hnd_pool(ops):
+    """HND pool ([pages, Hkv, page, D], the bench's default layout): both phases address it through rx_kv_layout."""
+    bs, hq, hkv, d, page, shared = 24, 8, 2, 128, 16, 1024
+    rng = np.random.default_rng(21)
+    lens = (shared + rng.integers(1, 400, size=bs)).astype(np.int64)
+    ctx = int(lens.max()) + page
+    r2t, pool = _table(rng, shared, lens, page, ctx)
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    g = torch.Generator().manual_seed(8)
+    kb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16)      # NHD data ...
+    vb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16)
+    q = torch.randn(bs, hq, d, generator=g).to(torch.bfloat16)
+    kh = kb.view(pool // page, page, hkv, d).permute(0, 2, 1, 3).contiguous().to(DEV)   # ... re-laid as HND
+    vh = vb.view(pool // page, page, hkv, d).permute(0, 2, 1, 3).contiguous().to(DEV)
+    lay = ops.kv_layout_hnd(kh, vh)
+    sm = d ** -0.5
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
+    want = orc.decode_attention(_bits(q), _bits(kb), _bits(vb), kv_indptr, kv_indices, sm)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    cd = ops.CascadeDecode(bs, hq, hkv, d, torch.bfloat16, DEV, max_shared=ctx, min_shared=64)
+    cd.plan(T(r2t), T(rpi), T(lens))
+    assert cd.shared_len() >= shared
+    o = torch.zeros(bs, hq, d, dtype=torch.bfloat16, device=DEV)
+    cd(q.to(DEV), kh, vh, o, sm, page_size=page, kv_layout=lay)
+    assert np.abs(o.float().cpu().numpy().astype(np.float64) - want).max() <= 1.5e-2
