@@ -59,7 +59,8 @@ struct Ext32Args {
   const int32_t* window_kv_offsets;
   int32_t skip_prefix_mask;     // 1: the prefix part is not masked
   int32_t xai_len;              // Grok temperature length or <= 0
-  const int32_t* unified_prefix; // K8 unified form: per-request prefix length, or null
+  const int32_t* unified_prefix;
+  int32_t q_pack;  // GQA-packed query rows: row m is token m / q_pack (1 = off) // K8 unified form: per-request prefix length, or null
   const float* sinks;
 };
 
@@ -193,6 +194,11 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const int32_t kv0 = a.kv_indptr[req];
   const int32_t P = a.kv_indptr[req + 1] - kv0;
   const int32_t qb0 = mb * NW * QPW;
+  // GQA packing (q_pack = G > 1): the caller laid the G q heads of a kv head out as consecutive query ROWS of one
+  // "head" (row = token * G + g), so a request with few new tokens still fills a 32-row block and its K/V tiles
+  // are staged once for the whole group.  E counts rows; keys, positions and mask rows go by token = row / pack.
+  const int32_t pack = a.q_pack;
+  const int32_t Ek = E / pack;
   if (qb0 >= E) return;
   const int32_t qbase = qb0 + w * QPW;
   const bool active = qbase < E;
@@ -201,6 +207,9 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   int m[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) m[qb] = qbase + 32 * qb + ql;
+  int mp[QB];  // token index (position inside the extend part) of the lane's query row
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) mp[qb] = pack == 1 ? m[qb] : m[qb] / pack;
 
   // K8 unified form: the kv list holds prefix + new tokens; q_off = the query's distance from list start
   const bool unified = a.unified_prefix != nullptr;
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   // speculative tree mask: row of query m = mask_base + m * mask_row (+ woff + kv position)
   const bool masked = a.custom_mask != nullptr;
   const int32_t mask_woff = (masked && !unified && a.window_kv_offsets) ? a.window_kv_offsets[req] : 0;
-  const int64_t mask_row = unified ? static_cast<int64_t>(P) : static_cast<int64_t>(mask_woff) + P + E;
+  const int64_t mask_row = unified ? static_cast<int64_t>(P) : static_cast<int64_t>(mask_woff) + P + Ek;
   const uint8_t* mask_base = masked ? a.custom_mask + a.mask_indptr[req] + mask_woff : nullptr;
   const bool mask_prefix = masked && (unified || !a.skip_prefix_mask);
   const bool causal_in_list = unified && a.causal && !masked;  // the causal rule applies inside the kv list
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     xai[qb] = 1.0f;
-    const int32_t qidx = q_off + m[qb];
+    const int32_t qidx = q_off + mp[qb];
     if (a.xai_len > 0) {
       if (unified) {  // extend_attention.py:940-946
         if (qidx >= a.xai_len) xai[qb] = static_cast<float>(a.xai_len) / (static_cast<float>(qidx) + 1.0f);
@@ -255,8 +264,8 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 
   const bool no_ext = a.skip_extend || a.unified_prefix != nullptr;  // unified: every key comes from the pool
   const int32_t p_len = a.skip_prefix ? 0 : P;
-  const int32_t n_end_wg = no_ext ? 0 : (a.causal ? min(E, qb0 + NW * QPW) : E);
-  const int32_t n_end_w = no_ext ? 0 : (a.causal ? min(E, qbase + QPW) : E);
+  const int32_t n_end_wg = no_ext ? 0 : (a.causal ? min(Ek, (qb0 + NW * QPW - 1) / pack + 1) : Ek);
+  const int32_t n_end_w = no_ext ? 0 : (a.causal ? min(Ek, (qbase + QPW - 1) / pack + 1) : Ek);
   const int nt1 = (p_len + kTok - 1) / kTok;
   const int nt2 = (n_end_wg + kTok - 1) / kTok;
   const int nt = nt1 + nt2;
@@ -265,8 +274,8 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const int st_row = tid >> 4, st_chunk = tid & 15;
   const KvE* kbuf_h = reinterpret_cast<const KvE*>(a.k_buf) + kvh * a.k_head_stride + 8 * st_chunk;
   const KvE* vbuf_h = reinterpret_cast<const KvE*>(a.v_buf) + kvh * a.v_head_stride + 8 * st_chunk;
-  const uint16_t* kext_h = a.k_ext + qo0 * a.k_stride_t + kvh * a.k_stride_h + 8 * st_chunk;
-  const uint16_t* vext_h = a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h + 8 * st_chunk;
+  const uint16_t* kext_h = a.k_ext + (qo0 / pack) * a.k_stride_t + kvh * a.k_stride_h + 8 * st_chunk;
+  const uint16_t* vext_h = a.v_ext + (qo0 / pack) * a.v_stride_t + kvh * a.v_stride_h + 8 * st_chunk;
   int32_t slot[NPASS];
   auto load_idx_tile = [&](int t) {
     if (t < nt1) {
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     ti.vs = ti.prefix ? a.v_scale : 1.0f;
     const int n_hi = ti.tile_n0 + 32 * ti.nblk;
     if (ti.prefix) ti.full = n_hi <= p_len && a.window <= 0 && !mask_prefix && (!causal_in_list || n_hi - 1 <= q_off + qbase);
-    else ti.full = n_hi <= E && (!a.causal || n_hi - 1 <= qbase) && a.window <= 0 && !masked;
+    else ti.full = n_hi <= Ek && (!a.causal || n_hi - 1 <= qbase / pack) && a.window <= 0 && !masked;
     ti.fast = ti.work && ti.full && ti.nblk == 2 && !capped && (LINEAR || a.page_size < 0);
     return ti;
   };
@@ -551,7 +560,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
           lim = causal_in_list ? min(p_len, q_off + qbase + 1) : p_len;
           base = 0;
         } else {
-          lim = a.causal ? min(E, qbase + 1) : E;
+          lim = a.causal ? min(Ek, qbase / pack + 1) : Ek;
           base = nt1;
         }
         const int end = base + lim / kTok;
@@ -971,13 +980,13 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
                 const int n = tile_n0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
                 bool keep;
                 if (prefix) {
-                  keep = n < p_len && (!causal_in_list || n <= q_off + m[qb]);
-                  if (a.window > 0) keep = keep && (q_off + m[qb] <= n + a.window);
-                  if (mask_prefix && keep && m[qb] < E) keep = mask_base[m[qb] * mask_row + n] != 0;
+                  keep = n < p_len && (!causal_in_list || n <= q_off + mp[qb]);
+                  if (a.window > 0) keep = keep && (q_off + mp[qb] <= n + a.window);
+                  if (mask_prefix && keep && m[qb] < E) keep = mask_base[mp[qb] * mask_row + n] != 0;
                 } else {
-                  keep = n < n_end_w && (masked || !a.causal || n <= m[qb]);
-                  if (a.window > 0) keep = keep && (m[qb] <= n + a.window);
-                  if (masked && keep && m[qb] < E) keep = mask_base[m[qb] * mask_row + P + n] != 0;
+                  keep = n < n_end_w && (masked || !a.causal || n <= mp[qb]);
+                  if (a.window > 0) keep = keep && (mp[qb] <= n + a.window);
+                  if (masked && keep && m[qb] < E) keep = mask_base[mp[qb] * mask_row + P + n] != 0;
                 }
                 sacc[b][i] = keep ? sacc[b][i] : -INFINITY;
               }
@@ -1137,6 +1146,7 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.custom_mask = p->custom_mask; a.mask_indptr = p->mask_indptr; a.window_kv_offsets = p->window_kv_offsets;
   a.skip_prefix_mask = p->skip_prefix_custom_mask; a.xai_len = p->xai_temperature_len;
   a.unified_prefix = p->unified_prefix_lens;
+  a.q_pack = p->q_pack > 1 ? p->q_pack : 1;
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);

@@ -67,7 +67,7 @@ class RxExtendParams(C.Structure):
         ("sinks", c_void_p), ("dtype", c_int32),
         ("custom_mask", c_void_p), ("mask_indptr", c_void_p), ("skip_prefix_custom_mask", c_int32),
         ("window_kv_offsets", c_void_p), ("xai_temperature_len", c_int32),
-        ("unified_prefix_lens", c_void_p), ("avg_kv_len_hint", c_int32),
+        ("unified_prefix_lens", c_void_p), ("avg_kv_len_hint", c_int32), ("q_pack", c_int32),
     ]
 
 

@@ -664,7 +664,7 @@ def _extend_params(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, q
                          window_kv_offsets=None, xai_temperature_len=-1, lse_extend=None,
                          skip_prefix=False, skip_extend=False, page_size: int = 1,
                          score_mod=None, aux_tensors=None, kv_layout=None, unified_prefix_lens=None,
-                         _num_kv_heads=None, avg_kv_len_hint=None):
+                         _num_kv_heads=None, avg_kv_len_hint=None, q_pack: int = 1):
     if score_mod is not None or aux_tensors is not None:
         raise NotImplementedError("score_mod / aux_tensors: outside the HIP path")
     _require_cuda(q_extend, k_extend, v_extend, o_extend, qo_indptr, kv_indptr, custom_mask, mask_indptr,
@@ -748,6 +748,7 @@ def _extend_params(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, q
             p.window_kv_offsets = wo.data_ptr()
     p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
     p._keep_mask = keep
+    p.q_pack = int(q_pack)
     return p
 
 
@@ -758,7 +759,7 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
                          window_kv_offsets=None, xai_temperature_len=-1, lse_extend=None,
                          skip_prefix=False, skip_extend=False, page_size: int = 1,
                          score_mod=None, aux_tensors=None, kv_layout=None, unified_prefix_lens=None,
-                         _num_kv_heads=None, avg_kv_len_hint=None):
+                         _num_kv_heads=None, avg_kv_len_hint=None, q_pack: int = 1):
     p = _extend_params(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
                        custom_mask, is_causal, mask_indptr, max_len_extend, k_scale, v_scale, sm_scale=sm_scale,
                        logit_cap=logit_cap, skip_prefix_custom_mask=skip_prefix_custom_mask,
@@ -766,8 +767,31 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
                        xai_temperature_len=xai_temperature_len, lse_extend=lse_extend, skip_prefix=skip_prefix,
                        skip_extend=skip_extend, page_size=page_size, score_mod=score_mod, aux_tensors=aux_tensors,
                        kv_layout=kv_layout, unified_prefix_lens=unified_prefix_lens, _num_kv_heads=_num_kv_heads,
-                       avg_kv_len_hint=avg_kv_len_hint)
+                       avg_kv_len_hint=avg_kv_len_hint, q_pack=q_pack)
     _L.check(_L.load().rx_extend_attn(C.byref(p), _stream(q_extend)), "rx_extend_attn")
+
+
+def extend_attention_fwd_gqa_packed(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
+                                    kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend,
+                                    k_scale, v_scale, **kw):
+    """extend_attention_fwd for requests with FEW new tokens (speculative verify, short chunks) under GQA: the
+    G q heads of a kv head are laid out as consecutive query rows of one head (``q_pack = G``,
+    include/radix_hip.h), so a request's 4-16 new tokens x G heads fill the kernel's 32-row query blocks and its
+    K/V tiles are staged once per kv head instead of once per q head.  Same arguments and result as
+    extend_attention_fwd (two small re-layout copies around the launch); head_dim 128 only, no sinks, no LSE."""
+    T, hq, d = q_extend.shape
+    hkv = k_extend.shape[1]
+    g = hq // hkv
+    if g <= 1 or d != 128 or kw.get("sinks") is not None or kw.get("lse_extend") is not None or \
+            kw.get("unified_prefix_lens") is not None:
+        return extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr,
+                                    kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend, k_scale, v_scale,
+                                    **kw)
+    qp = q_extend.reshape(T, hkv, g, d).permute(0, 2, 1, 3).reshape(T * g, hkv, d)   # row = token * G + g
+    op = torch.empty_like(qp)
+    extend_attention_fwd(qp, k_extend, v_extend, op, k_buffer, v_buffer, qo_indptr * g, kv_indptr, kv_indices,
+                         custom_mask, is_causal, mask_indptr, int(max_len_extend) * g, k_scale, v_scale, q_pack=g, **kw)
+    o_extend.view(T, hkv, g, d).copy_(op.view(T, g, hkv, d).permute(0, 2, 1, 3))
 
 
 def extend_attention_fwd_unified(q, o, k_buffer, v_buffer, k_scale, v_scale, qo_indptr, kv_indptr, kv_indices,

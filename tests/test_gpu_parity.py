@@ -903,3 +903,58 @@ def test_extend_thresholded_max_adversarial_scores(ops, dtype, pattern):
     err = np.abs(_np(o.float()).astype(np.float64) - want).max()
     assert err <= tol, (pattern, err)
     np.testing.assert_allclose(_np(lse), want_lse, atol=5e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (16, 2), (4, 1)])
+@pytest.mark.parametrize("mode", ["tree", "causal", "window"])
+def test_extend_gqa_packed_rows_match_oracle(ops, dtype, hq, hkv, mode):
+    """q_pack (GQA-packed query rows, the speculative-verify shape: few new tokens per request over a long
+    prefix): same results as the oracle for tree masks, plain causal extends and a sliding window."""
+    d, page = 128, 16
+    rng = np.random.default_rng(hq * 10 + hkv + len(mode))
+    pre = np.array([300, 0, 1023, 64, 17], dtype=np.int32)
+    ext = np.array([8, 5, 16, 1, 33], dtype=np.int32)
+    bs, T = len(pre), int(ext.sum())
+    total = int((pre + ext).sum())
+    pool = total + 7
+    slots = rng.permutation(pool - 1)[:total] + 1
+    g = torch.Generator().manual_seed(hq + len(mode))
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    q = torch.randn(T, hq, d, generator=g).to(dtype)
+    kv_indptr = np.concatenate([[0], np.cumsum(pre)]).astype(np.int32)
+    qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
+    kv_indices = np.empty(int(pre.sum()), dtype=np.int64)
+    ext_slots = np.empty(T, dtype=np.int64)
+    so = 0
+    for i in range(bs):
+        s = slots[so: so + pre[i] + ext[i]]; so += pre[i] + ext[i]
+        kv_indices[kv_indptr[i]: kv_indptr[i + 1]] = s[: pre[i]]
+        ext_slots[qo[i]: qo[i + 1]] = s[pre[i]:]
+    ke, ve = kb[ext_slots], vb[ext_slots]
+    mask = mask_indptr = None
+    kw = {}
+    if mode == "tree":  # random draft tree: every new token sees the whole prefix, itself, and a random subset
+        rows = []
+        for i in range(bs):
+            mm = np.ones((ext[i], pre[i] + ext[i]), dtype=np.uint8)
+            tri = np.tril(rng.integers(0, 2, size=(ext[i], ext[i]))).astype(np.uint8)  # ancestors only
+            np.fill_diagonal(tri, 1)
+            mm[:, pre[i]:] = tri
+            rows.append(mm.reshape(-1))
+        mask = np.concatenate(rows)
+        mask_indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    window = 40 if mode == "window" else -1
+    want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
+                                sm_scale=1.0 / d ** 0.5, custom_mask=mask, mask_indptr=mask_indptr,
+                                sliding_window_size=window)
+    o = torch.zeros(T, hq, d, dtype=dtype, device=DEV)
+    ops.extend_attention_fwd_gqa_packed(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo),
+                                        _t(kv_indptr), _t(kv_indices), None if mask is None else _t(mask), True,
+                                        None if mask is None else _t(mask_indptr), int(ext.max()), 1.0, 1.0,
+                                        sliding_window_size=window)
+    got = _np(o.float()).astype(np.float64)
+    ok = np.isfinite(want).all(axis=(1, 2))  # a window / mask can hide everything from a row (0/0 in the reference)
+    tol = 3e-3 if dtype == torch.float16 else 1.5e-2
+    assert np.abs(got[ok] - want[ok]).max() <= tol
