@@ -221,6 +221,12 @@ def test_extend_fp8_prefix_pool_vs_oracle(ops, dtype, page_size):
     tol = 3e-3 if dtype == torch.float16 else 1e-2
     err = np.abs(_f32(o).astype(np.float64) - want).max()
     assert err <= tol, err
+    # GQA-packed query rows over the same fp8 prefix pool: the same result
+    o2 = torch.zeros_like(o)
+    ops.extend_attention_fwd_gqa_packed(q.to(DEV), ke.to(DEV), ve.to(DEV), o2, kb.to(DEV), vb.to(DEV), T(qo),
+                                        T(kv_indptr), T(kv_indices), None, True, None, int(ext.max()), ks, vs,
+                                        sm_scale=sm, page_size=page_size)
+    assert np.abs(_f32(o2).astype(np.float64) - want).max() <= tol
 
 
 def test_fp8_pools_roundtrip_through_the_pool_classes(ops):
