@@ -228,6 +228,55 @@ def radix_hit_bench(args, dev):
     return res
 
 
+def verify_bench(dev):
+    """Secondary figure: speculative-verify shaped extend (64 requests x 4096 cached + 8 draft tokens under a
+    lower-triangular tree mask, Llama-3-8B heads), one layer: per-q-head launch vs GQA-packed query rows."""
+    from sglang_amd import ops
+
+    bs, P, nd, hq, hkv, d = 64, 4096, 8, 32, 8, 128
+    g = torch.Generator(device=dev).manual_seed(0)
+    pool = bs * P + 16
+    kb = torch.randn(pool, hkv, d, device=dev, generator=g).to(torch.bfloat16)
+    vb = torch.randn(pool, hkv, d, device=dev, generator=g).to(torch.bfloat16)
+    T = bs * nd
+    q = torch.randn(T, hq, d, device=dev, generator=g).to(torch.bfloat16)
+    ke = torch.randn(T, hkv, d, device=dev, generator=g).to(torch.bfloat16)
+    ve = torch.randn(T, hkv, d, device=dev, generator=g).to(torch.bfloat16)
+    kv_indices = (torch.randperm(bs * P, device=dev, generator=g) + 8).to(torch.int64)
+    kv_indptr = (torch.arange(bs + 1, device=dev) * P).to(torch.int32)
+    qo = (torch.arange(bs + 1, device=dev) * nd).to(torch.int64)
+    rng = np.random.default_rng(0)
+    rows = []
+    for _ in range(bs):
+        m = np.ones((nd, P + nd), dtype=np.uint8)
+        m[:, P:] = np.tril(rng.integers(0, 2, size=(nd, nd))) | np.eye(nd, dtype=np.int64)
+        rows.append(m.reshape(-1))
+    mask = torch.from_numpy(np.concatenate(rows)).to(dev)
+    mi = torch.from_numpy(np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)).to(dev)
+    o = torch.zeros_like(q)
+    args = (kb, vb, qo, kv_indptr, kv_indices, mask, True, mi, nd, 1.0, 1.0)
+
+    def timed(fn, n=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n * 1e3
+
+    t_head = timed(lambda: ops.extend_attention_fwd(q, ke, ve, o, *args))
+    t_pack = timed(lambda: ops.extend_attention_fwd_gqa_packed(q, ke, ve, o, *args))
+    kv_bytes = bs * P * hkv * d * 2 * 2
+    return {"workload": "TARGET_VERIFY shape: 64 requests x 4096 cached tokens + 8 draft tokens, tree mask, Hq 32 / "
+                        "Hkv 8 / D 128 bf16, one layer",
+            "per_q_head_us": t_head, "gqa_packed_us": t_pack, "speedup": t_head / t_pack,
+            "kv_bytes_once": kv_bytes, "gqa_packed_kv_TBps": kv_bytes / t_pack / 1e6}
+
+
 def time_steps(fn, steps, warmup, world):
     import torch.distributed as dist
 
@@ -506,6 +555,10 @@ def main():
             out["radix_hit_decode"] = radix_hit_bench(args, dev)
         except Exception as e:
             out["radix_hit_decode"] = {"error": str(e)}
+        try:
+            out["spec_verify"] = verify_bench(dev)
+        except Exception as e:
+            out["spec_verify"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
