@@ -479,21 +479,28 @@ class CascadeDecode:
             raise ValueError("CascadeDecode: head_dim 64 / 128 (the MFMA extend kernels)")
         self.max_bs, self.hq, self.hkv, self.d = max_bs, num_q_heads, num_kv_heads, head_dim
         self.cu_count, self.min_shared, self.max_shared = cu_count, int(min_shared), int(max_shared)
-        if num_chunks is None:  # workgroups of phase 1 = chunks * ceil(bs / 128) * Hq: cover every CU once
-            num_chunks = max(1, min(16, -(-cu_count // (-(-max_bs // 128) * num_q_heads))))
-        self.num_chunks = S = int(num_chunks)
+        # chunks of the shared prefix = pseudo-requests of phase 1.  Its workgroups = chunks * ceil(bs / 128) * Hq
+        # should cover every CU once, so the count follows the ACTUAL batch (a pool sized for thousands of requests
+        # usually runs batches far smaller): chosen per plan(), buffers sized for the worst bs <= max_bs
+        self._fixed_chunks = None if num_chunks is None else int(num_chunks)
+        self.num_chunks = self._chunks_for(max_bs)
+        cands = list(range(1, min(max_bs, 2048) + 1)) + [max_bs]
+        rows_max = max(self._chunks_for(b) * b for b in cands)
+        S_max = max(self._chunks_for(b) for b in cands)
         self.split_cap = max(2, int(max_kv_splits))
         i32 = dict(dtype=torch.int32, device=device)
         self.plan_buf = torch.zeros(2, **i32)
-        self.chunk_indptr = torch.zeros(S + 1, **i32)
+        self._chunk_indptr_buf = torch.zeros(S_max + 1, **i32)
+        self.chunk_indptr = self._chunk_indptr_buf[: self.num_chunks + 1]
         self.shared_indices = torch.zeros(max(1, self.max_shared), **i32)
         self.kv_start = torch.zeros(max_bs, **i32)
         self.suffix_lens = torch.zeros(max_bs, **i32)
         self.num_kv_splits = torch.ones(max_bs, **i32)
-        self.q_rep = torch.zeros(S, max_bs, num_q_heads, head_dim, dtype=dtype, device=device)
-        self.o_parts = torch.zeros(S, max_bs, num_q_heads, head_dim, dtype=dtype, device=device)
-        self.lse_parts = torch.zeros(S, max_bs, num_q_heads, dtype=torch.float32, device=device)
-        self.qo_indptr = torch.zeros(S + 1, **i32)
+        self.q_rep = torch.zeros(rows_max * num_q_heads * head_dim, dtype=dtype, device=device)
+        self.o_parts = torch.zeros(rows_max * num_q_heads * head_dim, dtype=dtype, device=device)
+        self.lse_parts = torch.zeros(rows_max * num_q_heads, dtype=torch.float32, device=device)
+        self._qo_indptr_buf = torch.zeros(S_max + 1, **i32)
+        self.qo_indptr = self._qo_indptr_buf[: self.num_chunks + 1]
         # suffix partials: bs * S(bs) <= cu / (Hkv * ceil(G / 16)) + bs rows per head (native schedule), >= 2 slots
         group = max(1, num_q_heads // num_kv_heads)
         rows = (max(2 * max_bs, cu_count // (num_kv_heads * ((group + 15) // 16)) + max_bs) + 1) * num_q_heads
@@ -507,11 +514,19 @@ class CascadeDecode:
         # stream waits cost more host time than that on small batches -- off by default.
         self._side = torch.cuda.Stream(device=device) if overlap else None
 
+    def _chunks_for(self, bs: int) -> int:
+        if self._fixed_chunks is not None:
+            return self._fixed_chunks
+        return max(1, min(16, -(-self.cu_count // (-(-bs // 128) * self.hq))))
+
     def plan(self, req_to_token, req_pool_indices, seq_lens) -> None:
         bs = self.bs = req_pool_indices.shape[0]
         if bs > self.max_bs:
             raise ValueError(f"CascadeDecode: bs {bs} > max_bs {self.max_bs}")
         self._tabs = (req_to_token, req_pool_indices, seq_lens)
+        self.num_chunks = self._chunks_for(bs)
+        self.chunk_indptr = self._chunk_indptr_buf[: self.num_chunks + 1]
+        self.qo_indptr = self._qo_indptr_buf[: self.num_chunks + 1]
         shared_prefix_plan(req_to_token, req_pool_indices, seq_lens, self.plan_buf, self.chunk_indptr,
                            self.shared_indices, self.kv_start[:bs], self.suffix_lens[:bs],
                            min_shared=self.min_shared)
@@ -540,10 +555,9 @@ class CascadeDecode:
             raise ValueError(f"CascadeDecode: q {tuple(q.shape)} != {(bs, self.hq, self.d)}")
         req_to_token, req_pool_indices, seq_lens = self._tabs
         # phase 1: every chunk of the shared prefix against all bs queries (M = bs per head)
-        q_rep = self.q_rep[:, :bs] if bs == self.max_bs else self.q_rep.view(-1)[: S * bs * self.hq * self.d].view(
-            S, bs, self.hq, self.d)
-        o_parts = self.o_parts.view(-1)[: S * bs * self.hq * self.d].view(S, bs, self.hq, self.d)
-        lse_parts = self.lse_parts.view(-1)[: S * bs * self.hq].view(S, bs, self.hq)
+        q_rep = self.q_rep[: S * bs * self.hq * self.d].view(S, bs, self.hq, self.d)
+        o_parts = self.o_parts[: S * bs * self.hq * self.d].view(S, bs, self.hq, self.d)
+        lse_parts = self.lse_parts[: S * bs * self.hq].view(S, bs, self.hq)
         attn_logits = self.attn_logits[: bs * self.hq * self.max_kv_splits * self.d].view(
             bs, self.hq, self.max_kv_splits, self.d)
         attn_lse = self.attn_lse[: bs * self.hq * self.max_kv_splits].view(bs, self.hq, self.max_kv_splits)

@@ -269,3 +269,32 @@ def test_cascade_decode_hnd_pool(ops):
     o = torch.zeros(bs, hq, d, dtype=torch.bfloat16, device=DEV)
     cd(q.to(DEV), kh, vh, o, sm, page_size=page, kv_layout=lay)
     assert np.abs(o.float().cpu().numpy().astype(np.float64) - want).max() <= 1.5e-2
+
+
+def test_cascade_chunk_count_follows_the_batch(ops):
+    """A CascadeDecode sized for a large pool (max_bs 512) planning a small batch picks the chunk count of THAT
+    batch (phase 1 must still fill the chip) and stays correct; then a large batch on the same object."""
+    hq, hkv, d, page, shared = 8, 2, 128, 16, 2048
+    cd = ops.CascadeDecode(512, hq, hkv, d, torch.bfloat16, DEV, max_shared=4096, min_shared=64)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    seen = []
+    for bs in (6, 300):
+        rng = np.random.default_rng(bs)
+        lens = (shared + rng.integers(1, 200, size=bs)).astype(np.int64)
+        ctx = int(lens.max()) + page
+        r2t, pool = _table(rng, shared, lens, page, ctx)
+        rpi = np.arange(1, bs + 1, dtype=np.int64)
+        g = torch.Generator().manual_seed(bs)
+        kb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+        vb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+        q = torch.randn(bs, hq, d, generator=g).to(torch.bfloat16).to(DEV)
+        sm = d ** -0.5
+        ref = torch.zeros_like(q)
+        ops.decode_attention_fwd_paged(q, kb, vb, ref, T(r2t), T(rpi), T(lens), None, None, None, 1, sm, page_size=page)
+        cd.plan(T(r2t), T(rpi), T(lens))
+        seen.append(cd.num_chunks)
+        assert cd.shared_len() >= shared and cd.chunk_indptr.numel() == cd.num_chunks + 1
+        o = torch.zeros_like(q)
+        cd(q, kb, vb, o, sm, page_size=page)
+        assert (o.float() - ref.float()).abs().max().item() <= 1.5e-2
+    assert seen[0] > seen[1] >= 1   # 16 chunks for 6 requests, fewer for 300
