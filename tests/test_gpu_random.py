@@ -126,6 +126,15 @@ def test_random_extend(ops, seed):
                              T(kv_indices if seed % 2 else kv_indices.astype(np.int32)), None, causal, None,
                              int(ext.max()), ks, vs, sm_scale=sm, logit_cap=cap, sliding_window_size=window,
                              sinks=None if sinks is None else sinks.to(DEV), lse_extend=lse, page_size=page_size)
+    if d == 128 and hq > hkv and sinks is None:  # GQA-packed query rows: the same numbers, row for row
+        o2 = torch.zeros_like(o)
+        ops.extend_attention_fwd_gqa_packed(q.to(DEV), ke.to(DEV), ve.to(DEV), o2, kb.to(DEV), vb.to(DEV),
+                                            T(qo if seed % 2 else qo.astype(np.int32)), T(kv_indptr),
+                                            T(kv_indices if seed % 2 else kv_indices.astype(np.int32)), None, causal,
+                                            None, int(ext.max()), ks, vs, sm_scale=sm, logit_cap=cap,
+                                            sliding_window_size=window, page_size=page_size)
+        ok = torch.isfinite(o.float()).all(dim=-1) & torch.isfinite(o2.float()).all(dim=-1)
+        assert (o.float()[ok] - o2.float()[ok]).abs().max().item() <= 2e-2
     got = o.float().cpu().numpy().astype(np.float64)
     seen = np.isfinite(want_lse)  # a window can hide everything from a row: 0/0 in the reference
     tol = 4e-3 if dtype == torch.float16 else 2e-2
