@@ -271,7 +271,18 @@ def verify_bench(dev):
     t_head = timed(lambda: ops.extend_attention_fwd(q, ke, ve, o, *args))
     t_pack = timed(lambda: ops.extend_attention_fwd_gqa_packed(q, ke, ve, o, *args))
     kv_bytes = bs * P * hkv * d * 2 * 2
-    return {"workload": "TARGET_VERIFY shape: 64 requests x 4096 cached tokens + 8 draft tokens, tree mask, Hq 32 / "
+    # latency case: 2 requests of the same batch (one workgroup per (request, kv head) would use 16 of 256 CUs)
+    b2 = 2
+    sub = (kb, vb, qo[: b2 + 1], kv_indptr[: b2 + 1], kv_indices, mask, True, mi[: b2 + 1], nd, 1.0, 1.0)
+    q2, ke2, ve2, o2 = q[: b2 * nd], ke[: b2 * nd], ve[: b2 * nd], o[: b2 * nd]
+    t_head2 = timed(lambda: ops.extend_attention_fwd(q2, ke2, ve2, o2, *sub))
+    vs = ops.VerifySplitKV(hq, hkv, torch.bfloat16, dev)
+    vs.plan(qo[: b2 + 1], kv_indptr[: b2 + 1], kv_indices, mask, mi[: b2 + 1], nd)
+    t_split2 = timed(lambda: vs(q2, ke2, ve2, o2, kb, vb, 1.0, 1.0))
+    small = {"workload": "2 requests x 4096 cached + 8 draft tokens", "per_q_head_us": t_head2,
+             "split_kv_us": t_split2, "chunks": vs.num_chunks(b2), "speedup": t_head2 / t_split2}
+    return {"small_batch": small,
+            "workload": "TARGET_VERIFY shape: 64 requests x 4096 cached tokens + 8 draft tokens, tree mask, Hq 32 / "
                         "Hkv 8 / D 128 bf16, one layer",
             "per_q_head_us": t_head, "gqa_packed_us": t_pack, "speedup": t_head / t_pack,
             "kv_bytes_once": kv_bytes, "gqa_packed_kv_TBps": kv_bytes / t_pack / 1e6}

@@ -312,6 +312,16 @@ int rx_merge_state(const void* a, const float* lse_a, const void* b, const float
                    float* out_lse /* or NULL */, int64_t num_tokens, int num_heads, int head_size,
                    int dtype, void* stream);
 
+/* n-way merge for a split pass (speculative verify over a long cached sequence, split into chunks so that a small
+ * batch still fills the chip -- the job of kernels/ops/attention/verify_splitkv.py in the reference).  Group g
+ * (one request) has num_chunks partials o_chunks [groups, num_chunks, rows_per_group, heads, head_size] with LSEs
+ * [groups, num_chunks, rows_per_group, heads], plus optionally one more partial o_last [groups, rows_per_group,
+ * heads, head_size] / lse_last (the new tokens' own block).  out [groups, rows_per_group, heads, head_size],
+ * out_lse optional.  Same weights as rx_merge_state; empty partials (lse = -inf or +inf) are skipped. */
+int rx_merge_chunks(const void* o_chunks, const float* lse_chunks, int num_chunks, const void* o_last,
+                    const float* lse_last, void* out, float* out_lse, int64_t groups, int rows_per_group,
+                    int num_heads, int head_size, int dtype, void* stream);
+
 /* ---- K9: paged slot allocation -----------------------------------------------------------
  * alloc_extend_kernel / alloc_decode_kernel (kernels/ops/memory/allocator.py:16-135), called
  * by PagedTokenToKVPoolAllocator.alloc_extend / alloc_decode (allocator/paged.py:172-259).

@@ -142,6 +142,8 @@ class HipRadixAttnBackend:
         self.cascade_min_bs, self.cascade_min_shared = int(cascade_min_bs), int(cascade_min_shared)
         self._cascade = None
         self._cascade_on = False
+        self._verify_split = None      # ops.VerifySplitKV, built on the first TARGET_VERIFY forward
+        self._verify_split_on = False
         self._model_dtype = getattr(model_runner, "dtype", None)
 
     def _q_dtype(self, k_buffer: torch.Tensor):
@@ -323,6 +325,19 @@ class HipRadixAttnBackend:
             win = dict(window_kv_indptr=wp, window_kv_indices=wi, window_kv_offsets=wo)
         mask_indptr = self.mask_indptr[: bs + 1]
         mask_indptr[1:] = torch.cumsum(nd * (fb.seq_lens[:bs].to(torch.int64) + nd), dim=0)
+        # small verify batches: one workgroup per (request, kv head) would leave the chip idle -- cut the cached
+        # part into chunks (ops.VerifySplitKV, the reference's verify_splitkv case)
+        self._verify_split_on = False
+        if (self.sliding_window_size is None and not self._is_mla_pool and self.v_head_dim == 128
+                and spec.custom_mask is not None):
+            if self._verify_split is None:
+                kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
+                self._verify_split = ops.VerifySplitKV(self.num_head, self.num_kv_head, self._q_dtype(kb), self.device,
+                                                       cu_count=self.device_core_count)
+            if self._verify_split.num_chunks(bs) >= 2:
+                cm = spec.custom_mask if spec.custom_mask.dtype == torch.uint8 else spec.custom_mask.to(torch.uint8)
+                self._verify_split.plan(qo_indptr, kv_indptr, kv_indices, cm, mask_indptr, nd)
+                self._verify_split_on = True
         return ForwardMetadata(None, None, nd, None, kv_indptr, kv_indices, qo_indptr,
                                custom_mask=spec.custom_mask, mask_indptr=mask_indptr, **win)
 
@@ -466,6 +481,15 @@ class HipRadixAttnBackend:
             window = layer.sliding_window_size if (layer.sliding_window_size is not None
                                                    and layer.sliding_window_size > -1) else -1
             kv_indptr, kv_indices, window_kv_offsets = md.kv_indptr, md.kv_indices, None
+        if (self._verify_split_on and forward_batch.forward_mode.is_target_verify() and sinks is None
+                and layer.qk_head_dim == 128 == layer.v_head_dim and not (getattr(layer, "xai_temperature_len", -1) or 0) > 0
+                and not (layer.sliding_window_size is not None and layer.sliding_window_size > -1)
+                and layer.tp_q_head_num == self.num_head):
+            self._verify_split(q.view(-1, layer.tp_q_head_num, 128), k.view(-1, layer.tp_k_head_num, 128),
+                               v.view(-1, layer.tp_v_head_num, 128), o.view(-1, layer.tp_q_head_num, 128), k_buf, v_buf,
+                               k_descale, v_descale, sm_scale=layer.scaling, logit_cap=layer.logit_cap,
+                               page_size=self.page_size, kv_layout=lay)
+            return o
         # few new tokens per request (speculative verify / draft extend, short chunks): GQA-packed query rows -- the
         # G q heads of a kv head share one pass over the request's K/V (3.1-3.4x at 4-16 draft tokens over 4-8k)
         packed = (md.max_extend_len is not None and md.max_extend_len <= 64 and sinks is None

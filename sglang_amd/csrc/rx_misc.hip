@@ -188,6 +188,73 @@ __global__ __launch_bounds__(256) void merge_state_kernel(const uint16_t* __rest
   if (out_lse && c == 0) out_lse[row] = __logf(se) + m;
 }
 
+// merge_chunks: n-way form of merge_state for a split pass.  Group g (= one request) has S chunk partials
+// [S][R rows] (chunk-major inside the group) and optionally one more partial [R rows] from another tensor;
+// one thread = 8 consecutive columns of one (row, head).  Empty partials (lse -inf / +inf) are skipped.
+template <typename T>
+__global__ __launch_bounds__(256) void merge_chunks_kernel(const uint16_t* __restrict__ oc, const float* __restrict__ lc,
+                                                           int S, const uint16_t* __restrict__ ol,
+                                                           const float* __restrict__ ll, uint16_t* __restrict__ out,
+                                                           float* __restrict__ out_lse, int64_t groups, int R, int heads,
+                                                           int head_size) {
+  const int per_row = head_size >> 3;
+  const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t rh = gid / per_row;  // (group, row, head) flattened
+  if (rh >= groups * R * heads) return;
+  const int c = static_cast<int>(gid % per_row) * 8;
+  const int64_t g = rh / (static_cast<int64_t>(R) * heads);
+  const int64_t in_g = rh % (static_cast<int64_t>(R) * heads);  // row * heads + head
+  const int64_t base = g * S * R * heads + in_g;               // chunk 0 of this (row, head); + x * R * heads
+  // loads in independent batches of 8 (one memory latency per batch, not per chunk); an empty partial gets weight 0
+  const int64_t cstride = static_cast<int64_t>(R) * heads;
+  auto clean = [](float l) { return (l < INFINITY) ? l : -INFINITY; };  // +inf / NaN -> empty
+  float m = -INFINITY;
+  for (int x0 = 0; x0 < S; x0 += 8) {
+    float l8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l8[j] = lc[base + static_cast<int64_t>(min(x0 + j, S - 1)) * cstride];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, clean(l8[j]));
+  }
+  float l_last = -INFINITY;
+  if (ol) {
+    l_last = clean(ll[rh]);
+    m = fmaxf(m, l_last);
+  }
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float se = 0.f;
+  auto add = [&](u32x4 v, float w) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[2 * j] += w * T::to_f32(static_cast<uint16_t>(v[j] & 0xffffu));
+      acc[2 * j + 1] += w * T::to_f32(static_cast<uint16_t>(v[j] >> 16));
+    }
+    se += w;
+  };
+  for (int x0 = 0; x0 < S; x0 += 8) {
+    float l8[8];
+    u32x4 v8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t r = base + static_cast<int64_t>(min(x0 + j, S - 1)) * cstride;
+      l8[j] = lc[r];
+      v8[j] = *reinterpret_cast<const u32x4*>(oc + r * head_size + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float l = clean(l8[j]);
+      if (x0 + j < S && l > -INFINITY) add(v8[j], __expf(l - m));  // (an empty partial's row may hold NaN)
+    }
+  }
+  if (ol && l_last > -INFINITY) add(*reinterpret_cast<const u32x4*>(ol + rh * head_size + c), __expf(l_last - m));
+  const float inv = 1.0f / se;
+  u32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = pack2<T>(acc[2 * j] * inv, acc[2 * j + 1] * inv);
+  *reinterpret_cast<u32x4*>(out + rh * head_size + c) = o;
+  if (out_lse && c == 0) out_lse[rh] = __logf(se) + m;
+}
+
 // ---------------------------------------------------------------------------------------
 // K2  kv_indptr scan + ragged gather of req_to_token rows.
 // Reference: create_flashinfer_kv_indices_triton (kv_indices.py:8-46), grid (bs,), 512-wide.
@@ -566,6 +633,29 @@ int rx_merge_state(const void* a, const float* lse_a, const void* b, const float
     hipLaunchKernelGGL(merge_state_kernel<F16>, dim3(grid), dim3(256), 0, s, (const uint16_t*)a, lse_a,
                        (const uint16_t*)b, lse_b, (uint16_t*)out, out_lse, rows, head_size);
   return check_launch("rx_merge_state");
+}
+
+int rx_merge_chunks(const void* o_chunks, const float* lse_chunks, int num_chunks, const void* o_last,
+                    const float* lse_last, void* out, float* out_lse, int64_t groups, int rows_per_group,
+                    int num_heads, int head_size, int dtype, void* stream) {
+  RX_REQUIRE(groups >= 0 && rows_per_group > 0 && num_heads > 0 && num_chunks >= 1, "rx_merge_chunks: bad sizes");
+  if (groups == 0) return RX_OK;
+  RX_REQUIRE(o_chunks && lse_chunks && out && (!o_last || lse_last), "rx_merge_chunks: null pointer");
+  RX_REQUIRE(dtype == RX_BF16 || dtype == RX_F16, "rx_merge_chunks: dtype %d", dtype);
+  RX_REQUIRE(head_size > 0 && head_size % 8 == 0, "rx_merge_chunks: head_size %d must be a multiple of 8", head_size);
+  RX_REQUIRE((((uintptr_t)o_chunks | (uintptr_t)o_last | (uintptr_t)out) & 15) == 0, "rx_merge_chunks: 16-byte alignment");
+  const int64_t n = groups * rows_per_group * num_heads * (head_size >> 3);
+  const unsigned grid = static_cast<unsigned>((n + 255) / 256);
+  auto s = static_cast<hipStream_t>(stream);
+  if (dtype == RX_BF16)
+    hipLaunchKernelGGL(merge_chunks_kernel<BF16>, dim3(grid), dim3(256), 0, s, (const uint16_t*)o_chunks, lse_chunks,
+                       num_chunks, (const uint16_t*)o_last, lse_last, (uint16_t*)out, out_lse, groups, rows_per_group,
+                       num_heads, head_size);
+  else
+    hipLaunchKernelGGL(merge_chunks_kernel<F16>, dim3(grid), dim3(256), 0, s, (const uint16_t*)o_chunks, lse_chunks,
+                       num_chunks, (const uint16_t*)o_last, lse_last, (uint16_t*)out, out_lse, groups, rows_per_group,
+                       num_heads, head_size);
+  return check_launch("rx_merge_chunks");
 }
 
 int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,

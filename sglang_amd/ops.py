@@ -808,6 +808,121 @@ def extend_attention_fwd_gqa_packed(q_extend, k_extend, v_extend, o_extend, k_bu
     o_extend.view(T, hkv, g, d).copy_(op.view(T, g, hkv, d).permute(0, 2, 1, 3))
 
 
+def merge_chunks(o_chunks, lse_chunks, o_last, lse_last, out):
+    """rx_merge_chunks: o_chunks [groups, S, R, H, D] + lse [groups, S, R, H] (+ o_last [groups, R, H, D], lse_last)
+    -> out [groups, R, H, D]."""
+    _require_cuda(o_chunks, lse_chunks, o_last, lse_last, out)
+    G_, S, R, H, D = o_chunks.shape
+    for t in (o_chunks, lse_chunks, out) + ((o_last, lse_last) if o_last is not None else ()):
+        if not t.is_contiguous():
+            raise ValueError("merge_chunks: tensors must be contiguous")
+    st = _L.load().rx_merge_chunks(_ptr(o_chunks), _ptr(lse_chunks), S, _ptr(o_last), _ptr(lse_last), _ptr(out), None,
+                                   G_, R, H, D, _rx_dtype(o_chunks), _stream(o_chunks))
+    _L.check(st, "rx_merge_chunks")
+
+
+class VerifySplitKV:
+    """Speculative verify (TARGET_VERIFY) for SMALL batches: every request has ``nd`` new tokens under a tree mask
+    over a long cached sequence.  One workgroup per (request, kv head) leaves the chip idle (1 request x 32k cached
+    tokens: 650 us per layer), so -- as the reference's verify_splitkv does (kernels/ops/attention/verify_splitkv.py)
+    -- the cached part is cut into chunks that run as pseudo-requests of ONE GQA-packed extend launch (no mask: every
+    draft token sees the whole cache), the draft tokens' own block (tree mask) is a second, tiny launch, and
+    rx_merge_chunks joins the partials.
+
+    ``plan`` (once per forward, shared by all layers, no host sync): chunk boundaries inside every request's cached
+    list (multiples of 64 tokens) and the row offsets; ``__call__`` (per layer): two re-layout copies, the two
+    launches and the merge, with parameter blocks filled once per (layer buffers, batch geometry).
+    head_dim 128; no sliding window, Grok temperature or sinks (use extend_attention_fwd_gqa_packed)."""
+
+    def __init__(self, num_q_heads: int, num_kv_heads: int, dtype, device, cu_count: int = 256, max_chunks: int = 32):
+        self.hq, self.hkv, self.g, self.d = num_q_heads, num_kv_heads, max(1, num_q_heads // num_kv_heads), 128
+        self.dtype, self.device, self.cu_count, self.max_chunks = dtype, device, cu_count, max_chunks
+        self._geo = None
+        self._params = {}
+        self._lib = _L.load()
+
+    def num_chunks(self, bs: int) -> int:
+        """Chunks per request: enough workgroups (bs * Hkv * chunks) to cover every CU."""
+        return max(1, min(self.max_chunks, -(-self.cu_count // max(1, bs * self.hkv))))
+
+    def plan(self, qo_indptr, kv_indptr, kv_indices, custom_mask, mask_indptr, nd: int) -> None:
+        bs = qo_indptr.shape[0] - 1
+        S, R, dev = self.num_chunks(bs), int(nd) * self.g, self.device
+        if self._geo != (bs, S, R):
+            self._geo = (bs, S, R)
+            n = bs * S * R
+            self.q_rep = torch.empty(n, self.hkv, self.d, dtype=self.dtype, device=dev)
+            self.o_c = torch.empty(n, self.hkv, self.d, dtype=self.dtype, device=dev)
+            self.lse_c = torch.empty(n, self.hkv, dtype=torch.float32, device=dev)
+            self.qp = torch.empty(bs * R, self.hkv, self.d, dtype=self.dtype, device=dev)
+            self.o_l = torch.empty_like(self.qp)
+            self.lse_l = torch.empty(bs * R, self.hkv, dtype=torch.float32, device=dev)
+            self.out = torch.empty_like(self.qp)
+            self.qo_c = torch.arange(0, (bs * S + 1) * R, R, dtype=torch.int32, device=dev)
+            self.qo_g = torch.arange(0, (bs + 1) * R, R, dtype=torch.int32, device=dev)
+            self.chunk_indptr = torch.empty(bs * S + 1, dtype=torch.int32, device=dev)
+            self._arange_s = torch.arange(S, device=dev, dtype=torch.int32)[None, :]
+            self._params.clear()
+        P = (kv_indptr[1:] - kv_indptr[:-1]).to(torch.int32)
+        per = ((P + (S - 1)) // S + 63) // 64 * 64
+        offs = torch.minimum(self._arange_s * per[:, None], P[:, None]) + kv_indptr[:-1, None]
+        self.chunk_indptr[:-1] = offs.reshape(-1)
+        self.chunk_indptr[-1:] = kv_indptr[-1:]
+        self._tabs = (kv_indptr, kv_indices, custom_mask, mask_indptr)
+        self.nd = int(nd)
+
+    def __call__(self, q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, k_scale, v_scale, sm_scale=None,
+                 logit_cap=0.0, page_size: int = 1, kv_layout=None) -> None:
+        bs, S, R = self._geo
+        nd, g, hkv, d = self.nd, self.g, self.hkv, self.d
+        kv_indptr, kv_indices, custom_mask, mask_indptr = self._tabs
+        if q_extend.shape != (bs * nd, self.hq, d):
+            raise ValueError(f"VerifySplitKV: q {tuple(q_extend.shape)} != {(bs * nd, self.hq, d)}")
+        key = (k_buffer.data_ptr(), v_buffer.data_ptr(), k_extend.data_ptr(), v_extend.data_ptr(), kv_indices.data_ptr(),
+               kv_indptr.data_ptr(), 0 if custom_mask is None else custom_mask.data_ptr(), float(sm_scale or 0.0),
+               float(k_scale), float(v_scale), float(logit_cap), page_size)
+        ent = self._params.get(key)
+        if ent is None:
+            if len(self._params) > 1024:
+                self._params.clear()
+            pc = _extend_params(self.q_rep, self.q_rep, self.q_rep, self.o_c, k_buffer, v_buffer, self.qo_c,
+                                self.chunk_indptr, kv_indices, None, False, None, R, k_scale, v_scale,
+                                sm_scale=sm_scale, logit_cap=logit_cap, lse_extend=self.lse_c, skip_extend=True,
+                                page_size=page_size, kv_layout=kv_layout, _num_kv_heads=hkv, q_pack=g,
+                                avg_kv_len_hint=0)
+            pl = _extend_params(self.qp, k_extend, v_extend, self.o_l, k_buffer, v_buffer, self.qo_g, kv_indptr,
+                                kv_indices, custom_mask, True, mask_indptr, R, k_scale, v_scale, sm_scale=sm_scale,
+                                logit_cap=logit_cap, lse_extend=self.lse_l, skip_prefix=True, page_size=page_size,
+                                kv_layout=kv_layout, q_pack=g, avg_kv_len_hint=0)
+            ent = self._params[key] = (pc, C.byref(pc), pl, C.byref(pl), (k_buffer, v_buffer, k_extend, v_extend))
+        _, pc_ref, _, pl_ref, _ = ent
+        stream = _stream(q_extend)
+        # row = token * G + g of "head" kvh
+        self.qp.view(bs, nd, g, hkv, d).copy_(q_extend.view(bs, nd, hkv, g, d).permute(0, 1, 3, 2, 4))
+        self.q_rep.view(bs, S, R, hkv, d).copy_(self.qp.view(bs, 1, R, hkv, d).expand(bs, S, R, hkv, d))
+        lib = self._lib
+        for ref in (pc_ref, pl_ref):
+            st = lib.rx_extend_attn(ref, stream)
+            if st:
+                _L.check(st, "rx_extend_attn")
+        st = lib.rx_merge_chunks(_ptr(self.o_c), _ptr(self.lse_c), S, _ptr(self.o_l), _ptr(self.lse_l), _ptr(self.out),
+                                 None, bs, R, hkv, d, _rx_dtype(self.qp), stream)
+        if st:
+            _L.check(st, "rx_merge_chunks")
+        o_extend.view(bs, nd, hkv, g, d).copy_(self.out.view(bs, nd, g, hkv, d).permute(0, 1, 3, 2, 4))
+
+
+def verify_attention_splitkv(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr,
+                             kv_indices, custom_mask, mask_indptr, num_draft_tokens: int, num_chunks: int, k_scale,
+                             v_scale, sm_scale=None, logit_cap=0.0, page_size: int = 1, kv_layout=None):
+    """One-shot form of VerifySplitKV (plan + call) with an explicit chunk count; see the class."""
+    vs = VerifySplitKV(q_extend.shape[1], k_extend.shape[1], q_extend.dtype, q_extend.device, max_chunks=num_chunks,
+                       cu_count=1 << 30)
+    vs.plan(qo_indptr, kv_indptr, kv_indices, custom_mask, mask_indptr, num_draft_tokens)
+    vs(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, k_scale, v_scale, sm_scale=sm_scale,
+       logit_cap=logit_cap, page_size=page_size, kv_layout=kv_layout)
+
+
 def extend_attention_fwd_unified(q, o, k_buffer, v_buffer, k_scale, v_scale, qo_indptr, kv_indptr, kv_indices,
                                  prefix_lens, max_len_extend, custom_mask=None, mask_indptr=None, sm_scale=None,
                                  logit_cap=0.0, is_causal=True, sliding_window_size=-1, sinks=None,

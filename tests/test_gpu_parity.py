@@ -958,3 +958,43 @@ def test_extend_gqa_packed_rows_match_oracle(ops, dtype, hq, hkv, mode):
     ok = np.isfinite(want).all(axis=(1, 2))  # a window / mask can hide everything from a row (0/0 in the reference)
     tol = 3e-3 if dtype == torch.float16 else 1.5e-2
     assert np.abs(got[ok] - want[ok]).max() <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("chunks", [1, 3, 8])
+def test_verify_attention_splitkv_vs_oracle(ops, dtype, chunks):
+    """Small-batch speculative verify, cached part split into chunks (the reference's verify_splitkv case):
+    GQA-packed chunk launch + draft-block launch + rx_merge_chunks == the oracle's masked extend."""
+    rng = np.random.default_rng(31 + chunks)
+    hq, hkv, d, nd = 8, 2, 128, 6
+    prefix = np.array([900, 64, 1, 333, 4097], dtype=np.int64)   # incl. fewer tokens than chunks * 64
+    bs = len(prefix)
+    pool = int(prefix.sum()) + 40
+    g = torch.Generator().manual_seed(5)
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    T_ = bs * nd
+    q = torch.randn(T_, hq, d, generator=g).to(dtype)
+    ke = torch.randn(T_, hkv, d, generator=g).to(dtype)
+    ve = torch.randn(T_, hkv, d, generator=g).to(dtype)
+    kv_indptr = np.concatenate([[0], np.cumsum(prefix)]).astype(np.int32)
+    kv_indices = (rng.permutation(pool - 1)[: int(prefix.sum())] + 1).astype(np.int64)
+    qo = (np.arange(bs + 1) * nd).astype(np.int64)
+    rows = []
+    for i in range(bs):
+        m = np.ones((nd, int(prefix[i]) + nd), dtype=bool)
+        tri = np.tril(rng.random((nd, nd)) < 0.6)
+        np.fill_diagonal(tri, True)
+        m[:, int(prefix[i]):] = tri
+        rows.append(m.reshape(-1))
+    cm = np.concatenate(rows).astype(np.uint8)
+    mi = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
+    sm = d ** -0.5
+    want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
+                                is_causal=True, sm_scale=sm, custom_mask=cm, mask_indptr=mi)
+    o = torch.zeros_like(q, device=DEV)
+    ops.verify_attention_splitkv(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo), _t(kv_indptr),
+                                 _t(kv_indices), _t(cm), _t(mi), nd, chunks, 1.0, 1.0, sm_scale=sm)
+    tol = 4e-3 if dtype == torch.float16 else 1.5e-2
+    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
+    assert err <= tol, err

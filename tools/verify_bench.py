@@ -46,6 +46,13 @@ def timed(fn, n=20):
 args = (kb, vb, qo, kv_indptr, kv_indices, mask, True, mi, nd, 1.0, 1.0)
 t1 = timed(lambda: ops.extend_attention_fwd(q, ke, ve, o1, *args))
 t2 = timed(lambda: ops.extend_attention_fwd_gqa_packed(q, ke, ve, o2, *args))
+vsk = ops.VerifySplitKV(hq, hkv, torch.bfloat16, dev)
+S = vsk.num_chunks(bs)
+o3 = torch.zeros_like(q)
+vsk.plan(qo, kv_indptr, kv_indices, mask, mi, nd)
+t3 = timed(lambda: vsk(q, ke, ve, o3, kb, vb, 1.0, 1.0))
+t_plan = timed(lambda: vsk.plan(qo, kv_indptr, kv_indices, mask, mi, nd))
+print(f"split-KV verify ({S} chunks): {t3:.0f} us ({t1 / t3:.2f}x the per-head launch); max |diff| vs packed {(o3.float() - o2.float()).abs().max().item():.4f}; plan {t_plan:.0f} us per forward")
 byt = bs * P * hkv * d * 2 * 2
 print(f"bs={bs} P={P} nd={nd}: per-head {t1:.0f} us, GQA-packed {t2:.0f} us ({t1 / t2:.2f}x); KV bytes once = "
       f"{byt / 1e6:.0f} MB -> {byt / t2 / 1e6:.2f} TB/s packed; max |diff| {(o1.float() - o2.float()).abs().max().item():.4f}")
