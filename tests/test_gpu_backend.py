@@ -487,6 +487,7 @@ def test_target_verify_mode_with_tree_mask():
     assert md.max_extend_len == nd and md.custom_mask is Spec.custom_mask
     assert md.mask_indptr.tolist() == np.concatenate([[0], np.cumsum([nd * (s + nd) for s in seq_lens])]).tolist()
     o = hs.layer(q, k, v, fb, hs.backend)
+    assert hs.backend._verify_split_on and hs.backend._verify_split.num_chunks(bs) >= 2  # small batch: split-KV verify
     kb, vb = hs.pool.get_kv_buffer(0)
     r2t = _bits(hs.r2t.req_to_token)
     kv_indptr, kv_indices = orc.build_kv_indices(r2t, np.array(rows), np.array(seq_lens))
