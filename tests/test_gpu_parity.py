@@ -998,3 +998,63 @@ def test_verify_attention_splitkv_vs_oracle(ops, dtype, chunks):
     tol = 4e-3 if dtype == torch.float16 else 1.5e-2
     err = np.abs(_np(o.float()).astype(np.float64) - want).max()
     assert err <= tol, err
+
+
+def test_verify_splitkv_replays_under_hip_graph(ops):
+    """plan() and the layer call use device data only: a captured {plan, call} graph follows changed cached lengths
+    (different chunk boundaries) and a changed tree mask on replay."""
+    hq, hkv, d, nd, bs = 8, 2, 128, 4, 2
+    rng = np.random.default_rng(12)
+    cap = 3000
+    pool = bs * cap + 64
+    g = torch.Generator().manual_seed(2)
+    kb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+    vb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+    q = torch.randn(bs * nd, hq, d, generator=g).to(torch.bfloat16).to(DEV)
+    ke = torch.randn(bs * nd, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+    ve = torch.randn(bs * nd, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+    kv_indices = torch.from_numpy((rng.permutation(pool - 1)[: bs * cap] + 1).astype(np.int64)).to(DEV)
+    kv_indptr = torch.zeros(bs + 1, dtype=torch.int32, device=DEV)
+    qo = torch.arange(0, (bs + 1) * nd, nd, dtype=torch.int64, device=DEV)
+    mask = torch.ones(bs * nd * (cap + nd), dtype=torch.uint8, device=DEV)
+    mi = torch.zeros(bs + 1, dtype=torch.int64, device=DEV)
+    o = torch.zeros_like(q)
+    vs = ops.VerifySplitKV(hq, hkv, torch.bfloat16, DEV)
+
+    def set_case(prefix, seed):
+        prefix = np.asarray(prefix, dtype=np.int64)
+        kv_indptr.copy_(torch.from_numpy(np.concatenate([[0], np.cumsum(prefix)]).astype(np.int32)))
+        r = np.random.default_rng(seed)
+        rows = []
+        for p in prefix:
+            m = np.ones((nd, int(p) + nd), dtype=np.uint8)
+            tri = np.tril(r.integers(0, 2, size=(nd, nd))) | np.eye(nd, dtype=np.int64)
+            m[:, int(p):] = tri
+            rows.append(m.reshape(-1))
+        cm = np.concatenate(rows)
+        mask[: cm.size] = torch.from_numpy(cm).to(DEV)
+        mi.copy_(torch.from_numpy(np.concatenate([[0], np.cumsum([x.size for x in rows])]).astype(np.int64)))
+        return prefix, cm
+
+    def step():
+        vs.plan(qo, kv_indptr, kv_indices, mask, mi, nd)
+        vs(q, ke, ve, o, kb, vb, 1.0, 1.0)
+
+    set_case([1000, 2500], 1)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    for prefix, seed in (([2999, 65], 7), ([700, 1500], 9)):
+        prefix, cm = set_case(prefix, seed)
+        graph.replay()
+        torch.cuda.synchronize()
+        ip = np.concatenate([[0], np.cumsum(prefix)]).astype(np.int32)
+        want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo.cpu().numpy(), ip,
+                                    kv_indices.cpu().numpy()[: int(prefix.sum())], is_causal=True, sm_scale=d ** -0.5,
+                                    custom_mask=cm, mask_indptr=mi.cpu().numpy())
+        assert np.abs(_np(o.float()).astype(np.float64) - want).max() <= 1.5e-2
