@@ -272,12 +272,11 @@ typedef struct rx_extend_params {
    * tensor's length; the per-request lengths live on the device).  Short work per (request, head, query
    * block) runs better as two 128-query workgroups per CU than as one 256-query workgroup. */
   int32_t avg_kv_len_hint;
-  /* GQA-packed queries (0 / 1 = off; D = 128 kernel only, not with unified_prefix_lens).  With q_pack = G the
-   * caller passes num_q_heads = num_kv_heads and lays q / o / lse out so that query ROW token * G + g of "head"
-   * kvh is q head kvh * G + g of that token: qo_indptr and max_extend_len count rows (G per new token), k_extend /
-   * v_extend, causal positions, custom_mask rows, window and xai positions go by token = row / G.  A request with
-   * few new tokens (speculative verify, short chunks) then fills the kernel's 32-row query blocks and stages its
-   * K/V tiles once per kv head instead of once per q head. */
+  /* GQA-packed query rows (0 / 1 = off; q_pack = Hq / Hkv; D = 128 kernel only, not with unified_prefix_lens).
+   * Same tensors and index arrays as without it.  The kernel then runs one workgroup "head" per KV head whose
+   * query rows are (new token, q head of the group) pairs, row = token * G + g: a request with few new tokens
+   * (speculative verify, short chunks) fills the 32-row query blocks and stages its K/V tiles once per kv head
+   * instead of once per q head.  Bit-identical results. */
   int32_t q_pack;
 } rx_extend_params;
 

@@ -581,7 +581,8 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   if (p->q_pack > 1) {
     if (!(mfma_ok && dk == 128 && o16) || p->unified_prefix_lens)
       return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: q_pack needs head_dim 128, 16-byte aligned o and no unified_prefix_lens");
-    RX_REQUIRE(p->num_q_heads == p->num_kv_heads, "rx_extend_attn: q_pack = %d with num_q_heads != num_kv_heads", p->q_pack);
+    RX_REQUIRE(p->num_q_heads == p->num_kv_heads * p->q_pack, "rx_extend_attn: q_pack = %d must be Hq / Hkv = %d / %d",
+               p->q_pack, p->num_q_heads, p->num_kv_heads);
   }
   if (mfma_ok && dk == 128 && o16 && (p->q_pack > 1 || p->kv.kv_fp8 || extras || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
     const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));

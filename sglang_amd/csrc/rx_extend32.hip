@@ -190,14 +190,16 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const int req = bid / a.group;
 
   const int64_t qo0 = load_idx(a.qo_indptr, req, a.qo64);
-  const int32_t E = static_cast<int32_t>(load_idx(a.qo_indptr, req + 1, a.qo64) - qo0);
+  const int32_t pack = a.q_pack;
+  // queries of this request as ROWS: one per new token, or (q_pack = G) one per (new token, q head of the group)
+  const int32_t E = static_cast<int32_t>(load_idx(a.qo_indptr, req + 1, a.qo64) - qo0) * pack;
   const int32_t kv0 = a.kv_indptr[req];
   const int32_t P = a.kv_indptr[req + 1] - kv0;
   const int32_t qb0 = mb * NW * QPW;
-  // GQA packing (q_pack = G > 1): the caller laid the G q heads of a kv head out as consecutive query ROWS of one
-  // "head" (row = token * G + g), so a request with few new tokens still fills a 32-row block and its K/V tiles
-  // are staged once for the whole group.  E counts rows; keys, positions and mask rows go by token = row / pack.
-  const int32_t pack = a.q_pack;
+  // GQA packing (q_pack = G > 1): the workgroup's "head" is a KV head and its query rows are (token, q head of
+  // the group) pairs, row = token * G + g, so a request with few new tokens still fills a 32-row block and its K/V
+  // tiles are staged once for the whole group.  E counts rows; keys, positions and mask rows go by token = row / G;
+  // q, o and lse are addressed as (token, kv head * G + g) of the caller's ordinary [tokens, Hq, D] tensors.
   const int32_t Ek = E / pack;
   if (qb0 >= E) return;
   const int32_t qbase = qb0 + w * QPW;
@@ -241,7 +243,8 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const bool ok = m[qb] < E;
-    const uint16_t* qp = a.q + (qo0 + (ok ? m[qb] : 0)) * a.q_stride_t + head * a.q_stride_h + 8 * h;
+    const int32_t tk = ok ? mp[qb] : 0, gq = ok ? m[qb] - mp[qb] * pack : 0;
+    const uint16_t* qp = a.q + (qo0 + tk) * a.q_stride_t + (head * pack + gq) * a.q_stride_h + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 16 * ks) : u32x4{0, 0, 0, 0};
@@ -274,8 +277,8 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const int st_row = tid >> 4, st_chunk = tid & 15;
   const KvE* kbuf_h = reinterpret_cast<const KvE*>(a.k_buf) + kvh * a.k_head_stride + 8 * st_chunk;
   const KvE* vbuf_h = reinterpret_cast<const KvE*>(a.v_buf) + kvh * a.v_head_stride + 8 * st_chunk;
-  const uint16_t* kext_h = a.k_ext + (qo0 / pack) * a.k_stride_t + kvh * a.k_stride_h + 8 * st_chunk;
-  const uint16_t* vext_h = a.v_ext + (qo0 / pack) * a.v_stride_t + kvh * a.v_stride_h + 8 * st_chunk;
+  const uint16_t* kext_h = a.k_ext + qo0 * a.k_stride_t + kvh * a.k_stride_h + 8 * st_chunk;
+  const uint16_t* vext_h = a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h + 8 * st_chunk;
   int32_t slot[NPASS];
   auto load_idx_tile = [&](int t) {
     if (t < nt1) {
@@ -1044,7 +1047,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       l = a2;
     }
     float den = l;
-    if (a.sinks) den += fast_exp2(a.sinks[head] * kLog2e - m_run[qb]);
+    if (a.sinks) den += fast_exp2(a.sinks[head * pack + (m[qb] < E ? m[qb] - mp[qb] * pack : 0)] * kLog2e - m_run[qb]);
     const float inv = 1.0f / den;
     acc_settle<AG>(oacc[qb]);
 #pragma unroll
@@ -1065,11 +1068,14 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     for (int pss = 0; pss < 8; ++pss) {
       const int row = 4 * pss + (lane >> 4), chunk = lane & 15;
       const u32x4 v = *reinterpret_cast<const u32x4*>(obuf + row * kORow + chunk * 16);
-      if (row0 + row < E)
-        *reinterpret_cast<u32x4*>(a.o + (qo0 + row0 + row) * a.o_stride_t + head * a.o_stride_h + 8 * chunk) = v;
+      if (row0 + row < E) {
+        const int32_t r = row0 + row, tk = pack == 1 ? r : r / pack, gq = r - tk * pack;
+        *reinterpret_cast<u32x4*>(a.o + (qo0 + tk) * a.o_stride_t + (head * pack + gq) * a.o_stride_h + 8 * chunk) = v;
+      }
     }
     if (a.lse && h == 0 && m[qb] < E)
-      a.lse[(qo0 + m[qb]) * a.lse_stride_t + head * a.lse_stride_h] = m_run[qb] * kLn2 + __logf(l);
+      a.lse[(qo0 + mp[qb]) * a.lse_stride_t + (head * pack + (m[qb] - mp[qb] * pack)) * a.lse_stride_h] =
+          m_run[qb] * kLn2 + __logf(l);
     if (qb + 1 < QB) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1147,6 +1153,10 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.skip_prefix_mask = p->skip_prefix_custom_mask; a.xai_len = p->xai_temperature_len;
   a.unified_prefix = p->unified_prefix_lens;
   a.q_pack = p->q_pack > 1 ? p->q_pack : 1;
+  if (a.q_pack > 1) {  // the grid's heads are KV heads; their rows carry the q heads of the group
+    a.hq = p->num_kv_heads;
+    a.group = 1;
+  }
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
@@ -1159,7 +1169,7 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const int est_tiles = (p->avg_kv_len_hint + p->max_extend_len / 2) / kTok;
   const bool small_wg = QB == 1 && est_tiles < RX_EXT32_SMALL_WG_TILES && !getenv("RX_EXT32_FORCE_NW8");
   const int nw = small_wg ? 4 : 8 / QB;
-  a.mblocks = (p->max_extend_len + nw * QB * 32 - 1) / (nw * QB * 32);
+  a.mblocks = (p->max_extend_len * a.q_pack + nw * QB * 32 - 1) / (nw * QB * 32);
   a.kv_fp8 = p->kv.kv_fp8;
   const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0, vsc = p->v_scale != 1.0f;
   if (small_wg) {

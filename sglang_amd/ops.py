@@ -788,24 +788,18 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
 def extend_attention_fwd_gqa_packed(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
                                     kv_indptr, kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend,
                                     k_scale, v_scale, **kw):
-    """extend_attention_fwd for requests with FEW new tokens (speculative verify, short chunks) under GQA: the
-    G q heads of a kv head are laid out as consecutive query rows of one head (``q_pack = G``,
-    include/radix_hip.h), so a request's 4-16 new tokens x G heads fill the kernel's 32-row query blocks and its
-    K/V tiles are staged once per kv head instead of once per q head.  Same arguments and result as
-    extend_attention_fwd (two small re-layout copies around the launch); head_dim 128 only, no sinks, no LSE."""
-    T, hq, d = q_extend.shape
-    hkv = k_extend.shape[1]
-    g = hq // hkv
-    if g <= 1 or d != 128 or kw.get("sinks") is not None or kw.get("lse_extend") is not None or \
-            kw.get("unified_prefix_lens") is not None:
-        return extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr,
-                                    kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend, k_scale, v_scale,
-                                    **kw)
-    qp = q_extend.reshape(T, hkv, g, d).permute(0, 2, 1, 3).reshape(T * g, hkv, d)   # row = token * G + g
-    op = torch.empty_like(qp)
-    extend_attention_fwd(qp, k_extend, v_extend, op, k_buffer, v_buffer, qo_indptr * g, kv_indptr, kv_indices,
-                         custom_mask, is_causal, mask_indptr, int(max_len_extend) * g, k_scale, v_scale, q_pack=g, **kw)
-    o_extend.view(T, hkv, g, d).copy_(op.view(T, g, hkv, d).permute(0, 2, 1, 3))
+    """extend_attention_fwd for requests with FEW new tokens (speculative verify, short chunks) under GQA: with
+    ``q_pack = G`` (include/radix_hip.h) the kernel runs one workgroup head per KV head whose query rows are (token,
+    q head of the group) pairs, so a request's 4-16 new tokens x G heads fill the 32-row query blocks and its K/V
+    tiles are staged once per kv head instead of once per q head.  Same arguments, same (bit-identical) result;
+    head_dim 128 only, otherwise the ordinary launch."""
+    hq, d = q_extend.shape[1], q_extend.shape[2]
+    g = hq // k_extend.shape[1]
+    if g <= 1 or d != 128 or kw.get("unified_prefix_lens") is not None:
+        g = 1
+    return extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr,
+                                kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend, k_scale, v_scale,
+                                q_pack=g, **kw)
 
 
 def merge_chunks(o_chunks, lse_chunks, o_last, lse_last, out):
@@ -847,17 +841,15 @@ class VerifySplitKV:
 
     def plan(self, qo_indptr, kv_indptr, kv_indices, custom_mask, mask_indptr, nd: int) -> None:
         bs = qo_indptr.shape[0] - 1
-        S, R, dev = self.num_chunks(bs), int(nd) * self.g, self.device
+        S, R, dev = self.num_chunks(bs), int(nd), self.device   # R = new tokens per request
         if self._geo != (bs, S, R):
             self._geo = (bs, S, R)
             n = bs * S * R
-            self.q_rep = torch.empty(n, self.hkv, self.d, dtype=self.dtype, device=dev)
-            self.o_c = torch.empty(n, self.hkv, self.d, dtype=self.dtype, device=dev)
-            self.lse_c = torch.empty(n, self.hkv, dtype=torch.float32, device=dev)
-            self.qp = torch.empty(bs * R, self.hkv, self.d, dtype=self.dtype, device=dev)
-            self.o_l = torch.empty_like(self.qp)
-            self.lse_l = torch.empty(bs * R, self.hkv, dtype=torch.float32, device=dev)
-            self.out = torch.empty_like(self.qp)
+            self.q_rep = torch.empty(n, self.hq, self.d, dtype=self.dtype, device=dev)
+            self.o_c = torch.empty(n, self.hq, self.d, dtype=self.dtype, device=dev)
+            self.lse_c = torch.empty(n, self.hq, dtype=torch.float32, device=dev)
+            self.o_l = torch.empty(bs * R, self.hq, self.d, dtype=self.dtype, device=dev)
+            self.lse_l = torch.empty(bs * R, self.hq, dtype=torch.float32, device=dev)
             self.qo_c = torch.arange(0, (bs * S + 1) * R, R, dtype=torch.int32, device=dev)
             self.qo_g = torch.arange(0, (bs + 1) * R, R, dtype=torch.int32, device=dev)
             self.chunk_indptr = torch.empty(bs * S + 1, dtype=torch.int32, device=dev)
@@ -868,19 +860,25 @@ class VerifySplitKV:
         offs = torch.minimum(self._arange_s * per[:, None], P[:, None]) + kv_indptr[:-1, None]
         self.chunk_indptr[:-1] = offs.reshape(-1)
         self.chunk_indptr[-1:] = kv_indptr[-1:]
+        if custom_mask is not None:  # the forms the C ABI takes: uint8 bytes, int64 offsets
+            custom_mask = (custom_mask if custom_mask.dtype == torch.uint8 else custom_mask.to(torch.uint8)).contiguous()
+            mask_indptr = (mask_indptr if mask_indptr.dtype == torch.int64 else mask_indptr.to(torch.int64)).contiguous()
+        if kv_indptr.dtype != torch.int32:
+            raise TypeError("kv_indptr must be int32")
         self._tabs = (kv_indptr, kv_indices, custom_mask, mask_indptr)
         self.nd = int(nd)
 
     def __call__(self, q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, k_scale, v_scale, sm_scale=None,
                  logit_cap=0.0, page_size: int = 1, kv_layout=None) -> None:
         bs, S, R = self._geo
-        nd, g, hkv, d = self.nd, self.g, self.hkv, self.d
+        nd, g, hkv, hq, d = self.nd, self.g, self.hkv, self.hq, self.d
         kv_indptr, kv_indices, custom_mask, mask_indptr = self._tabs
-        if q_extend.shape != (bs * nd, self.hq, d):
-            raise ValueError(f"VerifySplitKV: q {tuple(q_extend.shape)} != {(bs * nd, self.hq, d)}")
-        key = (k_buffer.data_ptr(), v_buffer.data_ptr(), k_extend.data_ptr(), v_extend.data_ptr(), kv_indices.data_ptr(),
-               kv_indptr.data_ptr(), 0 if custom_mask is None else custom_mask.data_ptr(), float(sm_scale or 0.0),
-               float(k_scale), float(v_scale), float(logit_cap), page_size)
+        if q_extend.shape != (bs * nd, hq, d) or not q_extend.is_contiguous() or not o_extend.is_contiguous():
+            raise ValueError(f"VerifySplitKV: q / o must be contiguous {(bs * nd, hq, d)}")
+        # parameter blocks per (layer buffers, scalars); everything that changes per forward or per layer -- the
+        # activations q / k / v, the index lists, the mask -- is patched in
+        key = (k_buffer.data_ptr(), v_buffer.data_ptr(), float(sm_scale or 0.0), float(k_scale), float(v_scale),
+               float(logit_cap), page_size, custom_mask is None)
         ent = self._params.get(key)
         if ent is None:
             if len(self._params) > 1024:
@@ -890,26 +888,31 @@ class VerifySplitKV:
                                 sm_scale=sm_scale, logit_cap=logit_cap, lse_extend=self.lse_c, skip_extend=True,
                                 page_size=page_size, kv_layout=kv_layout, _num_kv_heads=hkv, q_pack=g,
                                 avg_kv_len_hint=0)
-            pl = _extend_params(self.qp, k_extend, v_extend, self.o_l, k_buffer, v_buffer, self.qo_g, kv_indptr,
+            pl = _extend_params(q_extend, k_extend, v_extend, self.o_l, k_buffer, v_buffer, self.qo_g, kv_indptr,
                                 kv_indices, custom_mask, True, mask_indptr, R, k_scale, v_scale, sm_scale=sm_scale,
                                 logit_cap=logit_cap, lse_extend=self.lse_l, skip_prefix=True, page_size=page_size,
                                 kv_layout=kv_layout, q_pack=g, avg_kv_len_hint=0)
-            ent = self._params[key] = (pc, C.byref(pc), pl, C.byref(pl), (k_buffer, v_buffer, k_extend, v_extend))
-        _, pc_ref, _, pl_ref, _ = ent
+            ent = self._params[key] = (pc, C.byref(pc), pl, C.byref(pl), (k_buffer, v_buffer))
+        pc, pc_ref, pl, pl_ref, _ = ent
+        i64 = _is64(kv_indices, "kv_indices")
+        pc.kv_indices, pc.kv_indices_is_i64 = kv_indices.data_ptr(), i64
+        pl.kv_indices, pl.kv_indices_is_i64, pl.kv_indptr = kv_indices.data_ptr(), i64, kv_indptr.data_ptr()
+        pl.q, pl.q_stride_t, pl.q_stride_h = q_extend.data_ptr(), q_extend.stride(0), q_extend.stride(1)
+        pl.k_extend, pl.k_stride_t, pl.k_stride_h = k_extend.data_ptr(), k_extend.stride(0), k_extend.stride(1)
+        pl.v_extend, pl.v_stride_t, pl.v_stride_h = v_extend.data_ptr(), v_extend.stride(0), v_extend.stride(1)
+        if custom_mask is not None:
+            pl.custom_mask, pl.mask_indptr = custom_mask.data_ptr(), mask_indptr.data_ptr()
         stream = _stream(q_extend)
-        # row = token * G + g of "head" kvh
-        self.qp.view(bs, nd, g, hkv, d).copy_(q_extend.view(bs, nd, hkv, g, d).permute(0, 1, 3, 2, 4))
-        self.q_rep.view(bs, S, R, hkv, d).copy_(self.qp.view(bs, 1, R, hkv, d).expand(bs, S, R, hkv, d))
+        self.q_rep.view(bs, S, R, hq, d).copy_(q_extend.view(bs, 1, R, hq, d).expand(bs, S, R, hq, d))
         lib = self._lib
         for ref in (pc_ref, pl_ref):
             st = lib.rx_extend_attn(ref, stream)
             if st:
                 _L.check(st, "rx_extend_attn")
-        st = lib.rx_merge_chunks(_ptr(self.o_c), _ptr(self.lse_c), S, _ptr(self.o_l), _ptr(self.lse_l), _ptr(self.out),
-                                 None, bs, R, hkv, d, _rx_dtype(self.qp), stream)
+        st = lib.rx_merge_chunks(_ptr(self.o_c), _ptr(self.lse_c), S, _ptr(self.o_l), _ptr(self.lse_l), _ptr(o_extend),
+                                 None, bs, R, hq, d, _rx_dtype(q_extend), stream)
         if st:
             _L.check(st, "rx_merge_chunks")
-        o_extend.view(bs, nd, hkv, g, d).copy_(self.out.view(bs, nd, g, hkv, d).permute(0, 1, 3, 2, 4))
 
 
 def verify_attention_splitkv(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr,
