@@ -317,6 +317,11 @@ int rx_merge_state(const void* a, const float* lse_a, const void* b, const float
  * [groups, num_chunks, rows_per_group, heads], plus optionally one more partial o_last [groups, rows_per_group,
  * heads, head_size] / lse_last (the new tokens' own block).  out [groups, rows_per_group, heads, head_size],
  * out_lse optional.  Same weights as rx_merge_state; empty partials (lse = -inf or +inf) are skipped. */
+/* chunk boundaries for such a split pass, as an indptr into the SAME kv_indices: out[b * num_chunks + x] =
+ * kv_indptr[b] + min(x * per_b, P_b) with P_b = kv_indptr[b+1] - kv_indptr[b] and per_b = ceil(P_b / num_chunks)
+ * rounded up to chunk_align tokens; out[bs * num_chunks] = kv_indptr[bs].  int32[bs * num_chunks + 1]. */
+int rx_chunk_indptr(const int32_t* kv_indptr, int bs, int num_chunks, int chunk_align, int32_t* out, void* stream);
+
 int rx_merge_chunks(const void* o_chunks, const float* lse_chunks, int num_chunks, const void* o_last,
                     const float* lse_last, void* out, float* out_lse, int64_t groups, int rows_per_group,
                     int num_heads, int head_size, int dtype, void* stream);

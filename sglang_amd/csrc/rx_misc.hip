@@ -871,4 +871,31 @@ int rx_shared_prefix_plan(const int32_t* req_to_token, int64_t req_row_stride, c
   return check_launch("rx_shared_prefix_plan");
 }
 
+namespace rx {
+// chunk boundaries of every request's kv list for a split pass: out[b * S + x] = indptr[b] + min(x * per_b, P_b),
+// per_b = ceil(ceil(P_b / S) / align) * align, out[bs * S] = indptr[bs]
+__global__ __launch_bounds__(256) void chunk_indptr_kernel(const int32_t* __restrict__ indptr, int bs, int S, int align,
+                                                           int32_t* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > bs * S) return;
+  if (i == bs * S) {
+    out[i] = indptr[bs];
+    return;
+  }
+  const int b = i / S, x = i % S;
+  const int32_t beg = indptr[b], P = indptr[b + 1] - beg;
+  const int32_t per = cdiv32(cdiv32(P, S), align) * align;
+  out[i] = beg + static_cast<int32_t>(min(static_cast<int64_t>(x) * per, static_cast<int64_t>(P)));
+}
+}  // namespace rx
+
+int rx_chunk_indptr(const int32_t* kv_indptr, int bs, int num_chunks, int chunk_align, int32_t* out, void* stream) {
+  RX_REQUIRE(bs >= 0 && num_chunks >= 1 && chunk_align >= 1, "rx_chunk_indptr: bad sizes");
+  RX_REQUIRE(kv_indptr && out, "rx_chunk_indptr: null pointer");
+  const int n = bs * num_chunks + 1;
+  hipLaunchKernelGGL(rx::chunk_indptr_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     kv_indptr, bs, num_chunks, chunk_align, out);
+  return check_launch("rx_chunk_indptr");
+}
+
 }  // extern "C"

@@ -90,6 +90,7 @@ PROTOTYPES = {
     "rx_rope_store_kv": (c_int, [c_void_p] * 3 + [c_int64] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_int64, c_int,
                                  C.POINTER(RxKvLayout), c_void_p, c_int, c_int64, c_int64, c_float, c_float, c_int,
                                  c_void_p, c_void_p]),
+    "rx_chunk_indptr": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rx_merge_chunks": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                 c_int, c_int, c_void_p]),
     "rx_shared_prefix_plan": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_int32, c_int32,

@@ -853,18 +853,14 @@ class VerifySplitKV:
             self.qo_c = torch.arange(0, (bs * S + 1) * R, R, dtype=torch.int32, device=dev)
             self.qo_g = torch.arange(0, (bs + 1) * R, R, dtype=torch.int32, device=dev)
             self.chunk_indptr = torch.empty(bs * S + 1, dtype=torch.int32, device=dev)
-            self._arange_s = torch.arange(S, device=dev, dtype=torch.int32)[None, :]
             self._params.clear()
-        P = (kv_indptr[1:] - kv_indptr[:-1]).to(torch.int32)
-        per = ((P + (S - 1)) // S + 63) // 64 * 64
-        offs = torch.minimum(self._arange_s * per[:, None], P[:, None]) + kv_indptr[:-1, None]
-        self.chunk_indptr[:-1] = offs.reshape(-1)
-        self.chunk_indptr[-1:] = kv_indptr[-1:]
+        if kv_indptr.dtype != torch.int32:
+            raise TypeError("kv_indptr must be int32")
+        _L.check(self._lib.rx_chunk_indptr(_ptr(kv_indptr), bs, S, 64, _ptr(self.chunk_indptr), _stream(kv_indptr)),
+                 "rx_chunk_indptr")
         if custom_mask is not None:  # the forms the C ABI takes: uint8 bytes, int64 offsets
             custom_mask = (custom_mask if custom_mask.dtype == torch.uint8 else custom_mask.to(torch.uint8)).contiguous()
             mask_indptr = (mask_indptr if mask_indptr.dtype == torch.int64 else mask_indptr.to(torch.int64)).contiguous()
-        if kv_indptr.dtype != torch.int32:
-            raise TypeError("kv_indptr must be int32")
         self._tabs = (kv_indptr, kv_indices, custom_mask, mask_indptr)
         self.nd = int(nd)
 

@@ -79,7 +79,9 @@ for it in range(N):
         if g > 1 or True:
             S = int(rng.choice([1, 2, 5, 32]))
             ops.verify_attention_splitkv(q, ke, ve, o2, kb, vb, qo, kv_indptr, kv_indices, mask, mi, nd, S, 1.0, 1.0)
-            e2 = (o2.float() - ref.float()).abs().max().item()
+            # partials are rounded to 16 bits before the merge: compare relative to the output's magnitude
+            e2 = ((o2.float() - ref.float()).abs() / ref.float().abs().clamp(min=1.0)).max().item()
             worst["split"] = max(worst["split"], e2)
-            assert e2 <= 2e-2, ("split", it, bs, nd, hq, hkv, S, prefix.tolist(), e2)
+            # (two roundings: the 16-bit partial and the merged output -- up to ~1.5 ulp of the output)
+            assert e2 <= (1.6e-2 if dtype == torch.bfloat16 else 3e-3), ("split", it, bs, nd, hq, hkv, S, prefix.tolist(), e2)
 print("fuzz ok", N, "cases; worst |diff| vs the plain HIP path:", worst)
