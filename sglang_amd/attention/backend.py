@@ -144,6 +144,7 @@ class HipRadixAttnBackend:
         self._cascade_on = False
         self._verify_split = None      # ops.VerifySplitKV, built on the first TARGET_VERIFY forward
         self._verify_split_on = False
+        self._extend_split_on = False
         self._model_dtype = getattr(model_runner, "dtype", None)
 
     def _q_dtype(self, k_buffer: torch.Tensor):
@@ -303,6 +304,21 @@ class HipRadixAttnBackend:
         if self.sliding_window_size is not None:  # window over the cached prefix (triton_backend.py:891-905)
             wp, wi, _, wo = self._window(fb.extend_prefix_lens, fb.req_pool_indices, bs)
             win = dict(window_kv_indptr=wp, window_kv_indices=wi, window_kv_offsets=wo)
+        # a small batch of SHORT extends over LONG cached prefixes (a follow-up turn on a long conversation): one
+        # workgroup per (request, kv head, query block) leaves most CUs idle and each walks the whole prefix -- the
+        # split-KV form of the verify path, with the causal rule in place of a tree mask
+        self._extend_split_on = False
+        ext, pre = fb.extend_seq_lens_cpu, fb.extend_prefix_lens_cpu
+        if (self.sliding_window_size is None and not self._is_mla_pool and self.v_head_dim == 128 and ext is not None
+                and pre is not None and len(set(int(e) for e in ext)) == 1 and 0 < int(ext[0]) <= 512
+                and min(int(p) for p in pre) >= 1024):
+            if self._verify_split is None:
+                kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
+                self._verify_split = ops.VerifySplitKV(self.num_head, self.num_kv_head, self._q_dtype(kb), self.device,
+                                                       cu_count=self.device_core_count)
+            if self._verify_split.num_chunks(bs, int(ext[0])) >= 2:
+                self._verify_split.plan(qo_indptr, kv_indptr, kv_indices, None, None, int(ext[0]))
+                self._extend_split_on = True
         return ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr, **win)
 
     def _target_verify_metadata(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
@@ -334,7 +350,7 @@ class HipRadixAttnBackend:
                 kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
                 self._verify_split = ops.VerifySplitKV(self.num_head, self.num_kv_head, self._q_dtype(kb), self.device,
                                                        cu_count=self.device_core_count)
-            if self._verify_split.num_chunks(bs) >= 2:
+            if self._verify_split.num_chunks(bs, nd) >= 2:
                 cm = spec.custom_mask if spec.custom_mask.dtype == torch.uint8 else spec.custom_mask.to(torch.uint8)
                 self._verify_split.plan(qo_indptr, kv_indptr, kv_indices, cm, mask_indptr, nd)
                 self._verify_split_on = True
@@ -481,7 +497,10 @@ class HipRadixAttnBackend:
             window = layer.sliding_window_size if (layer.sliding_window_size is not None
                                                    and layer.sliding_window_size > -1) else -1
             kv_indptr, kv_indices, window_kv_offsets = md.kv_indptr, md.kv_indices, None
-        if (self._verify_split_on and forward_batch.forward_mode.is_target_verify() and sinks is None
+        split = ((self._verify_split_on and forward_batch.forward_mode.is_target_verify())
+                 or (self._extend_split_on and forward_batch.forward_mode.is_extend() and causal
+                     and not forward_batch.forward_mode.is_target_verify() and md.custom_mask is None))
+        if (split and sinks is None
                 and layer.qk_head_dim == 128 == layer.v_head_dim and not (getattr(layer, "xai_temperature_len", -1) or 0) > 0
                 and not (layer.sliding_window_size is not None and layer.sliding_window_size > -1)
                 and layer.tp_q_head_num == self.num_head):
@@ -492,8 +511,12 @@ class HipRadixAttnBackend:
             return o
         # few new tokens per request (speculative verify / draft extend, short chunks): GQA-packed query rows -- the
         # G q heads of a kv head share one pass over the request's K/V (3.1-3.4x at 4-16 draft tokens over 4-8k)
+        # (only when the per-head launch would over-subscribe the chip: packing trades workgroups for work, and a tiny
+        # batch needs the parallelism more -- 1 request x 32k + 64 tokens: per head 636 us, packed 993 us)
+        n_req = md.qo_indptr.shape[0] - 1
         packed = (md.max_extend_len is not None and md.max_extend_len <= 64 and sinks is None
-                  and layer.tp_q_head_num > layer.tp_k_head_num and layer.qk_head_dim == 128 == layer.v_head_dim)
+                  and layer.tp_q_head_num > layer.tp_k_head_num and layer.qk_head_dim == 128 == layer.v_head_dim
+                  and n_req * layer.tp_q_head_num >= 2 * self.device_core_count)
         (ops.extend_attention_fwd_gqa_packed if packed else ops.extend_attention_fwd)(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
             k.view(-1, layer.tp_k_head_num, layer.qk_head_dim),

@@ -835,13 +835,14 @@ class VerifySplitKV:
         self._params = {}
         self._lib = _L.load()
 
-    def num_chunks(self, bs: int) -> int:
-        """Chunks per request: enough workgroups (bs * Hkv * chunks) to cover every CU."""
-        return max(1, min(self.max_chunks, -(-self.cu_count // max(1, bs * self.hkv))))
+    def num_chunks(self, bs: int, nd: int = 1) -> int:
+        """Chunks per request: enough workgroups (bs * Hkv * query blocks * chunks) to cover every CU."""
+        mblocks = -(-(max(1, int(nd)) * self.g) // 128)
+        return max(1, min(self.max_chunks, -(-self.cu_count // max(1, bs * self.hkv * mblocks))))
 
     def plan(self, qo_indptr, kv_indptr, kv_indices, custom_mask, mask_indptr, nd: int) -> None:
         bs = qo_indptr.shape[0] - 1
-        S, R, dev = self.num_chunks(bs), int(nd), self.device   # R = new tokens per request
+        S, R, dev = self.num_chunks(bs, nd), int(nd), self.device   # R = new tokens per request
         if self._geo != (bs, S, R):
             self._geo = (bs, S, R)
             n = bs * S * R

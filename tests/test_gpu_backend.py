@@ -512,3 +512,32 @@ def test_native_split_schedule_values():
     assert out.tolist() == [1, 1, 1, 2, 6, 6]
     assert ops.native_max_kv_splits(1, 32, 8, 256, 32) == 32 and ops.native_max_kv_splits(256, 32, 8, 256, 32) == 1
     assert ops.native_max_kv_splits(1, 128, 1, 256, 32) == 32      # MLA: 8 q-blocks of 16 heads
+
+
+def test_short_extend_over_long_prefix_takes_split_kv_path():
+    """A small batch of short extends over long cached prefixes (a follow-up turn on a long conversation): the
+    backend cuts the prefix into chunks (ops.VerifySplitKV with the causal rule) -- same result as the oracle."""
+    from sglang_amd.forward_batch import ForwardBatch
+
+    ps, hq, hkv, d = 16, 8, 2, 128
+    hs = _Harness(ps, hq, hkv, d, torch.bfloat16, "shuffled_pages", "paged")
+    prefix_lens, extend_lens = (2048, 1500), (40, 40)
+    bs = len(prefix_lens)
+    rows = hs.r2t.alloc(bs)
+    hs.fill_prefix(rows, prefix_lens)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    seq_lens = [p + e for p, e in zip(prefix_lens, extend_lens)]
+    loc = hs.alloc_extend(rows, list(prefix_lens), seq_lens)
+    T = sum(extend_lens)
+    q, k, v = hs.rand(T, hq * d), hs.rand(T, hkv * d), hs.rand(T, hkv * d)
+    fb = ForwardBatch.for_extend(rpi, torch.tensor(seq_lens, device=DEV), loc, list(prefix_lens), list(extend_lens))
+    hs.backend.init_forward_metadata(fb)
+    assert hs.backend._extend_split_on and hs.backend._verify_split.num_chunks(bs, 40) >= 2
+    o = hs.layer(q, k, v, fb, hs.backend)
+    kb, vb = hs.pool.get_kv_buffer(0)
+    want = orc.sdpa_extend_req_to_token(_bits(q.view(T, hq, d)), _bits(kb), _bits(vb), _bits(hs.r2t.req_to_token),
+                                        np.array(rows), np.array(seq_lens), np.array(prefix_lens),
+                                        np.array(extend_lens), d ** -0.5)
+    got = o.view(T, hq, d).float().cpu().numpy().astype(np.float64)
+    assert hs.pool.check_errors() == 0
+    assert np.abs(got - want).max() <= 1.5e-2

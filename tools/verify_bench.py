@@ -53,6 +53,13 @@ vsk.plan(qo, kv_indptr, kv_indices, mask, mi, nd)
 t3 = timed(lambda: vsk(q, ke, ve, o3, kb, vb, 1.0, 1.0))
 t_plan = timed(lambda: vsk.plan(qo, kv_indptr, kv_indices, mask, mi, nd))
 print(f"split-KV verify ({S} chunks): {t3:.0f} us ({t1 / t3:.2f}x the per-head launch); max |diff| vs packed {(o3.float() - o2.float()).abs().max().item():.4f}; plan {t_plan:.0f} us per forward")
+# the same split with the causal rule instead of a tree mask: a short follow-up turn over a long conversation
+vsk.plan(qo, kv_indptr, kv_indices, None, None, nd)
+o4, o5 = torch.zeros_like(q), torch.zeros_like(q)
+argc = (kb, vb, qo, kv_indptr, kv_indices, None, True, None, nd, 1.0, 1.0)
+t4 = timed(lambda: ops.extend_attention_fwd_gqa_packed(q, ke, ve, o4, *argc))
+t5 = timed(lambda: vsk(q, ke, ve, o5, kb, vb, 1.0, 1.0))
+print(f"causal extend of {nd} tokens: packed {t4:.0f} us, split-KV {t5:.0f} us ({t4 / t5:.2f}x); max |diff| {(o4.float() - o5.float()).abs().max().item():.4f}")
 byt = bs * P * hkv * d * 2 * 2
 print(f"bs={bs} P={P} nd={nd}: per-head {t1:.0f} us, GQA-packed {t2:.0f} us ({t1 / t2:.2f}x); KV bytes once = "
       f"{byt / 1e6:.0f} MB -> {byt / t2 / 1e6:.2f} TB/s packed; max |diff| {(o1.float() - o2.float()).abs().max().item():.4f}")
