@@ -2,7 +2,9 @@
 """RadixAttention hot-path bench on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+    --gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the env), or bare -- `python bench.py --gpus N`
+    starts the N ranks itself as a child torch.distributed.run before making any GPU call.
 
 A step = one decode step of the attention path of Llama-3-8B (bf16, 32 layers, Hq=32, Hkv=8,
 D=128) at bs=256 / ctx=4096 / page_size=16 with shuffled pages: per layer
@@ -66,7 +68,30 @@ def parse():
     ap.add_argument("--cpu-worker", default=None, choices=["reference", "port"])
     ap.add_argument("--extend-only", action="store_true", help="dev: run only the extend leg")
     ap.add_argument("--tp-sim", type=int, default=0, help="dev: run ONE rank's shard of a TP=N job on one GPU (no collective)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel of the decode step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N fresh ranks with torch.distributed.run as a
+    CHILD process (this parent has made no GPU call and never will: a process that has touched the GPU must not
+    exec or re-launch itself on this pool) and hand its exit code back."""
+    import socket
+    import subprocess
+
+    port = args.master_port
+    if not port:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
 
 
 class _Cfg:
@@ -77,7 +102,7 @@ def build_world(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # dev dry-run of the multi-rank control flow on a 1-GPU box: RX_BENCH_BACKEND=gloo puts every
     # rank on device 0 and reduces through the host (never used for reported numbers)
@@ -177,19 +202,26 @@ def make_decode_state(args, tp, dev, shared_prefix=0, cascade=False):
     st.o_proj = RowParallelOProj(w_full, st.shard, D, TPGroup(custom_ar=custom_ar))
     del w_full
     st.slots = slots
+    st.overlap, st.ev_stride = True, 1
     return st
 
 
-def decode_step(st, fb, world, ev_pairs=None):
-    """One decode step of the attention path over all layers."""
+def decode_layers(st, fb, world, lo, hi, ev_pairs=None, attn_only_first=False, skip_attn_first=False):
+    """Layers [lo, hi) of one decode step of the attention path: per layer KV store of the new token -> paged
+    decode attention -> row-parallel o_proj GEMM -> (N > 1) sum all-reduce on the side stream.  ONE all-reduce is
+    in flight at a time: layer i's o_proj waits for layer i-1's reduce, which therefore overlaps layer i's store +
+    attention (in the model, the residual stream of layer i+1 needs it no earlier).  The segment joins the side
+    stream before it returns, so a segment can be captured into a HIP graph.
+    ev_pairs: HIP events around every ev_stride-th attention launch (eager mode's roofline samples)."""
     be = st.backend
-    be.init_forward_metadata(fb)
     pending = None
-    for li, layer in enumerate(st.layers):
-        if ev_pairs is not None and li % st.ev_stride == 0:
-            # HIP events around the attention launch of this layer (the roofline kernel); the event
-            # objects come from a pool created before the timed region (hipEventCreate is ~10 us of host
-            # time each, which matters once a TP shard's layer is only ~100 us of GPU work)
+    for li in range(lo, hi):
+        layer = st.layers[li]
+        first = li == lo
+        if first and skip_attn_first:      # the probe layer: its store ran in the previous segment and its
+            o = st.probe_o                 # attention was launched eagerly between two events
+        elif ev_pairs is not None and li % st.ev_stride == 0:
+            # event objects come from a pool created before the timed region (hipEventCreate is ~10 us of host time)
             e0, e1 = st.ev_pool.pop(), st.ev_pool.pop()
             be.token_to_kv_pool.set_kv_buffer(layer, fb.out_cache_loc, st.k, st.v)
             e0.record()
@@ -198,11 +230,76 @@ def decode_step(st, fb, world, ev_pairs=None):
             ev_pairs.append((e0, e1))
         else:
             o = layer(st.q, st.k, st.v, fb, be)
-        # row-parallel o_proj + (N>1) sum all-reduce on the side stream: it overlaps the next
-        # layer's KV store + attention on the main stream
-        pending = st.o_proj.forward(o, overlap=world > 1)
+        if pending is not None:
+            pending.wait()
+        pending = st.o_proj.forward(o, overlap=world > 1 and st.overlap)
     if pending is not None:
         pending.wait()
+
+
+def decode_step(st, fb, world, ev_pairs=None):
+    """One eager decode step of the attention path over all layers."""
+    st.backend.init_forward_metadata(fb)
+    decode_layers(st, fb, world, 0, len(st.layers), ev_pairs)
+
+
+class GraphStep:
+    """The decode step as HIP-graph replays (the reference replays its decode step the same way:
+    decode_cuda_graph_runner.py:318-323,1168).  A TP shard's layer is ~100 us of GPU work against ~60 us of host
+    launch cost, so an eager TP=8 step is host-bound; replayed, the host does three calls per step.
+
+    The step is cut at ONE probe layer so that the roofline kernel can still be timed live with HIP events on
+    the launch stream:  graph A = layers [0, p) + the KV store of layer p;  eager, between two events: layer p's
+    decode attention;  graph B = layer p's o_proj (+ all-reduce) + layers (p, L).  Before every replay the
+    backend refills its static metadata (init_forward_metadata_out_graph), as the runner does."""
+
+    def __init__(self, st, fb, world):
+        self.st, self.fb, self.world = st, fb, world
+        L = len(st.layers)
+        p = self.p = L // 2
+        be = st.backend
+        be.init_cuda_graph_state(fb.batch_size, fb.batch_size)
+        be.init_forward_metadata_out_graph(fb, in_capture=True)
+        layer_p = st.layers[p]
+        st.probe_o = be.forward_decode(st.q, None, None, layer_p, fb, save_kv_cache=False)  # address-stable output
+
+        def seg_a():
+            decode_layers(st, fb, world, 0, p)
+            be.token_to_kv_pool.set_kv_buffer(layer_p, fb.out_cache_loc, st.k, st.v)
+
+        def seg_b():
+            decode_layers(st, fb, world, p, L, skip_attn_first=True)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # warm-up off the default stream: lazy launchers, GEMM workspaces
+            seg_a()
+            self._probe()
+            seg_b()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.ga, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.ga):
+            seg_a()
+        with torch.cuda.graph(self.gb, pool=self.ga.pool()):
+            seg_b()
+
+    def _probe(self, ev_pairs=None):
+        st = self.st
+        if ev_pairs is not None:
+            e0, e1 = st.ev_pool.pop(), st.ev_pool.pop()
+            e0.record()
+        o = st.backend.forward_decode(st.q, None, None, st.layers[self.p], self.fb, save_kv_cache=False)
+        if ev_pairs is not None:
+            e1.record()
+            ev_pairs.append((e0, e1))
+        st.probe_o.copy_(o)  # 2 MiB device copy into the buffer graph B reads (outside the event pair)
+
+    def __call__(self, ev_pairs=None):
+        self.st.backend.init_forward_metadata_out_graph(self.fb)
+        self.ga.replay()
+        self._probe(ev_pairs)
+        self.gb.replay()
 
 
 def radix_hit_bench(args, dev):
@@ -420,32 +517,42 @@ def cpu_baseline(args):
     return {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": "; ".join(errors)}
 
 
-def extend_bench(args, dev, tp):
-    """Config 3: bs=256 sharing one 3584-token prefix (radix hit) + 512 new tokens each,
-    chunked to 32 requests (16 Ki tokens) per forward; one layer."""
+def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=8):
+    """Config 3: bs=256 sharing one 3584-token prefix (radix hit) + 512 new tokens each, chunked to 32 requests
+    (16 Ki tokens) per forward; one layer.  The cached prefix sits where the decode leg's KV sits: page_size-16
+    pages in SHUFFLED order (page 0 reserved) of a pool in the bench's --kv-layout (HND by default), and every
+    request's kv_indices row lists the same slots -- the radix hit."""
     from sglang_amd import ops
 
-    HQ, HKV, D = 32 // tp, max(1, 8 // tp), 128
-    P, E, chunk, nchunks = 3584, 512, 32, 8
+    D = head_dim
+    Dv = v_head_dim or D
+    HQ, HKV = 32 // tp, max(1, 8 // tp)
+    P, E, chunk = 3584, 512, 32
     if os.environ.get("RX_EXTEND_SHAPE"):  # dev: "P,E,chunk", e.g. config 2's 2k prompts without a prefix: 0,2048,8
         P, E, chunk = (int(x) for x in os.environ["RX_EXTEND_SHAPE"].split(","))
+    ps = args.page_size
     g = torch.Generator(device=dev).manual_seed(1)
-    pool = P + chunk * E + 16
-    kb = torch.randn(pool, HKV, D, device=dev, generator=g).to(torch.bfloat16)
-    vb = torch.randn(pool, HKV, D, device=dev, generator=g).to(torch.bfloat16)
+    n_pages = (P + ps - 1) // ps + chunk * ((E + ps - 1) // ps) + 1   # prefix pages + the new tokens' + page 0
+    hnd = args.kv_layout == "hnd"
+    kshape = (n_pages, HKV, ps, D) if hnd else (n_pages * ps, HKV, D)
+    vshape = (n_pages, HKV, ps, Dv) if hnd else (n_pages * ps, HKV, Dv)
+    kb = torch.randn(kshape, device=dev, generator=g).to(torch.bfloat16)
+    vb = torch.randn(vshape, device=dev, generator=g).to(torch.bfloat16)
+    lay = ops.kv_layout_hnd(kb, vb) if hnd else None
     T = chunk * E
     q = torch.randn(T, HQ, D, device=dev, generator=g).to(torch.bfloat16)
     k_ext = torch.randn(T, HKV, D, device=dev, generator=g).to(torch.bfloat16)
-    v_ext = torch.randn(T, HKV, D, device=dev, generator=g).to(torch.bfloat16)
-    o = torch.empty_like(q)
-    prefix_slots = torch.arange(16, 16 + P, device=dev, dtype=torch.int64)
+    v_ext = torch.randn(T, HKV, Dv, device=dev, generator=g).to(torch.bfloat16)
+    o = torch.empty(T, HQ, Dv, device=dev, dtype=torch.bfloat16)
+    pages = torch.randperm(n_pages - 1, device=dev, generator=g)[: (P + ps - 1) // ps] + 1
+    prefix_slots = (pages[:, None] * ps + torch.arange(ps, device=dev)[None, :]).reshape(-1)[:P].to(torch.int64)
     kv_indices = prefix_slots.repeat(chunk)  # identical rows: every request hits the same pages
     kv_indptr = (torch.arange(chunk + 1, device=dev) * P).to(torch.int32)
     qo_indptr = (torch.arange(chunk + 1, device=dev) * E).to(torch.int64)
 
     def run():
         ops.extend_attention_fwd(q, k_ext, v_ext, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True,
-                                 None, E, 1.0, 1.0, sm_scale=D ** -0.5, page_size=1)
+                                 None, E, 1.0, 1.0, sm_scale=D ** -0.5, page_size=ps, kv_layout=lay)
 
     for _ in range(2):
         run()
@@ -457,46 +564,135 @@ def extend_bench(args, dev, tp):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / nchunks
-    flops = 4.0 * HQ * D * chunk * (E * P + E * (E + 1) / 2)
+    flops = 2.0 * HQ * (D + Dv) * chunk * (E * P + E * (E + 1) / 2)
     tflops = flops / (ms * 1e-3) / 1e12
-    return {"metric": f"extend attention TFLOP/s (config 3: {P}-token shared prefix + {E} new, bf16)",
+    return {"metric": f"extend attention TFLOP/s (config 3: {P}-token shared prefix + {E} new, bf16, head_dim {D}"
+                      + (f"/{Dv}" if Dv != D else "") + ")",
             "tflops": tflops, "ms_per_chunk": ms, "chunk_requests": chunk, "flops_per_chunk": flops,
+            "prefix_layout": f"page_size {ps}, shuffled pages, {args.kv_layout.upper()} pool",
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": None}}
+
+
+def extend_head_dims(args, dev):
+    """The same config-3 chunk at the other head dims the reference tunes for gfx950 (extend_attention.py:66-77):
+    64, 256, and the MLA prefill shape 192 / 128."""
+    res = {}
+    for name, d, dv in (("d64", 64, 64), ("d256", 256, 256), ("d192_v128", 192, 128)):
+        try:
+            r = extend_bench(args, dev, 1, d, dv, nchunks=3)
+            res[name] = {"tflops": r["tflops"], "ms_per_chunk": r["ms_per_chunk"], "frac": r["roofline"]["frac"]}
+        except Exception as e:  # noqa: BLE001
+            res[name] = {"error": f"{type(e).__name__}: {e}"}
+    return res
+
+
+def rccl_capturable(dev) -> bool:
+    """Can this stack capture an RCCL all-reduce into a HIP graph and replay it?  Probed on a tiny tensor before
+    the step is captured, so that a refusal costs nothing but the eager fallback."""
+    import torch.distributed as dist
+
+    try:
+        x = torch.ones(1024, device=dev, dtype=torch.bfloat16)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dist.all_reduce(x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        x.fill_(1.0)
+        with torch.cuda.graph(g):
+            dist.all_reduce(x)
+        g.replay()
+        torch.cuda.synchronize()
+        ok = bool(torch.isfinite(x.float()).all().item())
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] RCCL all-reduce not capturable here ({type(e).__name__}: {e}); eager step", file=sys.stderr)
+        ok = False
+    t = torch.tensor([1 if ok else 0], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def allreduce_figures(st, fb, world, args, step_fn_factory):
+    """SURVEY 8d 'TP scaling': the o_proj all-reduce alone, and the step with / without the side-stream overlap."""
+    import torch.distributed as dist
+
+    HID = st.hid
+    x = torch.zeros(args.bs, HID, device=st.q.device, dtype=torch.bfloat16)
+    grp = st.o_proj.group
+    for _ in range(5):
+        grp.all_reduce(x)
+    dist.barrier()
+    torch.cuda.synchronize()
+    n = 50
+    t0 = time.perf_counter()
+    for _ in range(n):
+        grp.all_reduce(x)
+    torch.cuda.synchronize()
+    alone_us = (time.perf_counter() - t0) / n * 1e6
+    res = {"bytes": x.numel() * 2, "per_step": len(st.layers), "alone_us": alone_us}
+    for name, ov in (("step_ms_no_overlap", False), ("step_ms_overlap", True)):
+        st.overlap = ov
+        fn = step_fn_factory()
+        dt = time_steps(fn, max(3, args.steps // 2), 2, world)
+        res[name] = dt / max(3, args.steps // 2) * 1e3
+    st.overlap = True
+    return res
 
 
 def main():
     args = parse()
     if args.cpu_worker:
         return cpu_worker(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.tp_sim:
+        sys.exit(self_launch(args))
     rank, world, local_rank = build_world(args)
+    if world != args.gpus and not args.tp_sim:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     dev = torch.device("cuda", local_rank)
     if args.extend_only:
         print(json.dumps(extend_bench(args, dev, world)))
         return
     from sglang_amd.forward_batch import ForwardBatch
 
-    st = make_decode_state(args, args.tp_sim or world, dev)
+    tp = args.tp_sim or world
+    st = make_decode_state(args, tp, dev)
+    st.overlap = True
     fb = ForwardBatch.for_decode(st.req_pool_indices, st.seq_lens, st.out_cache_loc, st.seq_lens_cpu)
+    comm_backend = os.environ.get("RX_BENCH_BACKEND", "nccl") if world > 1 else "none"
 
+    # ---- the step: HIP-graph replay (default) or eager launches
+    use_graph, graph_note = not args.no_graph, None
+    if use_graph and world > 1:
+        if comm_backend != "nccl":
+            use_graph, graph_note = False, f"{comm_backend} reduces through the host: not capturable"
+        elif getattr(st, "custom_ar", None) is None and not rccl_capturable(dev):
+            use_graph, graph_note = False, "RCCL all-reduce refused HIP-graph capture on this stack"
     ev_pairs = []
     timed = {"on": False}
+    no_events = bool(os.environ.get("RX_BENCH_NO_EVENTS"))
 
-    def step():
-        decode_step(st, fb, world, ev_pairs if (timed["on"] and not os.environ.get("RX_BENCH_NO_EVENTS")) else None)
+    def make_step():
+        if use_graph:
+            gs = GraphStep(st, fb, world)
+            return lambda: gs(ev_pairs if (timed["on"] and not no_events) else None)
+        return lambda: decode_step(st, fb, world, ev_pairs if (timed["on"] and not no_events) else None)
 
-    # warmup untimed, then EXACTLY K timed steps (events are recorded inside the timed region)
+    # A timed event pair costs ~40 us of host time: invisible next to a 700-us TP=1 layer, but a TP shard's
+    # layer is ~100 us of GPU work; eager sharded runs therefore time every 8th layer (graph mode: one probe
+    # layer per step).
+    st.ev_stride = 1 if (tp == 1) else 8
+    st.ev_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + 8) * args.layers)]
+    step = make_step()
     # untimed settle steps before the W warmup steps: the first steps after a 128-GiB allocation run 2-3x long
     # (first touch of the pools, clock ramp); they are part of bringing the state up, not of the measurement
     for _ in range(args.settle):
         step()
     for _ in range(args.warmup):
         step()
-    # A timed event pair costs ~40 us of host time: invisible next to a 700-us TP=1 layer, but a TP shard's
-    # layer is ~100 us of GPU work and 32 pairs per step would make the HOST the bottleneck (measured on a
-    # TP=8 shard: 3.7 ms/step without events, 5.7 with).  Sharded runs therefore time every 8th layer.
-    st.ev_stride = 1 if (world == 1 and not args.tp_sim) else 8
-    st.ev_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps * args.layers)]
+    # warmup untimed, then EXACTLY K timed steps (events are recorded inside the timed region)
     timed["on"] = True
     dt = time_steps(step, args.steps, 0, world)
     timed["on"] = False
@@ -517,14 +713,22 @@ def main():
     durs = np.array([a.elapsed_time(b) for a, b in ev_pairs]) if ev_pairs else np.array([float("nan")])
     dur_ms = float(durs.mean())
     achieved = bytes_per_launch / (dur_ms * 1e-3) / 1e9
+    # HBM bytes per launch are a PMC figure: they cannot be collected inside this run (counters need their own
+    # rocprofv3 --pmc passes).  The committed summary of those passes is quoted WITH its provenance, and only when
+    # it was measured for this very workload; otherwise null.
     traffic, traffic_src = None, None
-    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+    try:
         import glob
-        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-        if cand and world == 1 and (bs, ctx) == (256, 4096):
-            for k, v in json.load(open(cand[-1]))["kernels"].items():
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_summary.json")))
+        if cand and tp == 1 and (bs, ctx) == (256, 4096) and args.kv_dtype == "bf16" and args.kv_layout == "hnd":
+            doc = json.load(open(cand[-1]))
+            for k, v in doc["kernels"].items():
                 if "decode_mfma_kernel" in k and "hbm_traffic_bytes_per_launch" in v:
-                    traffic, traffic_src = v["hbm_traffic_bytes_per_launch"], os.path.basename(cand[-1])
+                    traffic = v["hbm_traffic_bytes_per_launch"]
+                    traffic_src = {"file": "profiles/" + os.path.basename(cand[-1]),
+                                   "measured_in": doc.get("round", os.path.basename(cand[-1])[:3]),
+                                   "note": "separate rocprofv3 --pmc passes of this command on another box, "
+                                           "not this run"}
     except Exception:
         pass
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -535,6 +739,19 @@ def main():
                 # shows up here as min ~= median ~= mean, one-off stalls as a max far above the median
                 "launch_ms_min": float(durs.min()), "launch_ms_median": float(np.median(durs)),
                 "launch_ms_max": float(durs.max())}
+    ar = None
+    if world > 1:
+        import torch.distributed as dist
+
+        # every rank's own roofline fraction (the shards are identical work; a slow link or GPU shows here)
+        fr = torch.tensor([roofline["frac"]], device=dev, dtype=torch.float64)
+        allf = [torch.zeros_like(fr) for _ in range(world)]
+        dist.all_gather(allf, fr)
+        roofline["per_rank_frac"] = [float(x.item()) for x in allf]
+        try:
+            ar = allreduce_figures(st, fb, world, args, make_step)
+        except Exception as e:  # noqa: BLE001
+            ar = {"error": f"{type(e).__name__}: {e}"}
 
     out = {
         "metric": "decode tokens/sec + extend TFLOPS, Llama-3-8B bs=256 ctx=4k (value = decode tokens/s of the "
@@ -545,23 +762,34 @@ def main():
         "config": {"workload": "configs[2]-shaped decode: Llama-3-8B bf16 attention path, bs=%d, ctx=%d, "
                                "%d layers, page_size=%d shuffled pages, %s KV layout, TP=%d (Hq=%d,Hkv=%d per GPU), "
                                "per layer: KV store + paged decode attention + o_proj GEMM%s"
-                               % (bs, ctx, L, args.page_size, args.kv_layout.upper(), world, st.hq, st.hkv,
-                                  " + RCCL all-reduce (side stream)" if world > 1 else ""),
-                   "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{world}",
+                               % (bs, ctx, L, args.page_size, args.kv_layout.upper(), tp, st.hq, st.hkv,
+                                  " + all-reduce (side stream, one in flight)" if world > 1 else ""),
+                   "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{tp}",
                    "index_mode": args.index_mode, "kv_layout": args.kv_layout, "kv_dtype": args.kv_dtype,
                    "split_policy": args.split_policy, "settle_steps_untimed": args.settle,
-                   "all_reduce": "p2p-two-shot" if getattr(st, "custom_ar", None) is not None else ("rccl" if world > 1 else "none"), "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
+                   "step_launch": "hip-graph replay (2 graphs + 1 eager probe launch per step)" if use_graph else "eager",
+                   "step_launch_note": graph_note,
+                   "all_reduce": ("p2p-two-shot" if getattr(st, "custom_ar", None) is not None else
+                                  ("rccl" if comm_backend == "nccl" else comm_backend)) if world > 1 else "none",
+                   "distinct_layer_buffers": st.distinct, "host_enqueue_ms_per_step": host_enqueue_ms,
                    "kv_bytes_resident_per_gpu": int(sum(st.pool.get_kv_size_bytes()))},
         "roofline": roofline,
     }
+    if ar is not None:
+        out["all_reduce"] = ar
+    if args.tp_sim:
+        out["config"]["tp_sim"] = ("ONE rank's shard of a TP=%d job on one GPU, no collective: not a %d-GPU number"
+                                   % (tp, tp))
     if rank == 0 and world == 1 and not args.no_extend:
         try:
             out["extend"] = extend_bench(args, dev, world)
+            out["extend"]["other_head_dims"] = extend_head_dims(args, dev)
         except Exception as e:
             out["extend"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_radix_hit:
         try:
-            del st, fb
+            del st, fb, step
+            ev_pairs.clear()
             torch.cuda.empty_cache()
             out["radix_hit_decode"] = radix_hit_bench(args, dev)
         except Exception as e:

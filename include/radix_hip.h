@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 1
+#define RX_ABI_VERSION 2
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -41,6 +41,10 @@ typedef enum rx_dtype { RX_BF16 = 0, RX_F16 = 1 } rx_dtype; /* dtype of q / o / 
 #define RX_DEVERR_AR_TIMEOUT 2 /* rx_allreduce gave up waiting for a peer's flag */
 
 int rx_version(void);
+/* sizeof of the parameter structs this library was built with: which = 0 rx_kv_layout, 1 rx_decode_params,
+ * 2 rx_extend_params (-1 otherwise).  A binding compares them with its own struct definitions at load time, so a
+ * stale library next to newer host code (or the reverse) fails loudly instead of reading a shifted layout. */
+int64_t rx_abi_sizeof(int which);
 const char* rx_last_error(void);
 
 /* ---- K1: KV store -------------------------------------------------------------------
@@ -358,6 +362,13 @@ int rx_write_req_to_token(int32_t* req_to_token, int64_t row_stride,
  * (the pool's data_ptrs / data_strides tables, memory_pool.py:2005-2028). */
 int rx_move_kv(const uint64_t* data_ptrs, const int64_t* row_bytes, int num_bufs,
                const int64_t* tgt_loc, const int64_t* src_loc, int64_t n, void* stream);
+
+/* The same move on a paged pool layout (the HND pools [pages, Hkv, page, D] of memory_pool.py:2032-2036, where a
+ * slot's row is num_heads pieces): slot s lives at page s / page_size, offset s % page_size.
+ * geom: device int64[num_bufs][4] = {page_stride, head_stride, tok_stride, piece_bytes} per buffer, in BYTES
+ * (piece_bytes = head_dim * element size; a multiple of 4). */
+int rx_move_kv_layout(const uint64_t* data_ptrs, const int64_t* geom, int num_bufs, int page_size, int num_heads,
+                      const int64_t* tgt_loc, const int64_t* src_loc, int64_t n, void* stream);
 
 /* ---- a16: native radix tree of cached KV prefixes (HOST side; no GPU work) -----------------------
  * RadixCache (srt/mem_cache/radix_cache.py:279-812): match_prefix :352-410, insert :412-432 /

@@ -167,43 +167,58 @@ class HipRadixAttnBackend:
 
     # ------------------------------------------------------------------ metadata
     def init_forward_metadata(self, forward_batch: ForwardBatch):
-        self.init_forward_metadata_out_graph(forward_batch)
-        self.init_forward_metadata_in_graph(forward_batch)
+        """Eager entry point (triton_backend.py:714-960): per-call tensors, host-side launch-shape decisions."""
+        self._build_metadata(forward_batch, graph=False)
 
     def init_forward_metadata_in_graph(self, forward_batch: ForwardBatch):
         """Graph-recordable part: nothing -- the kernels read seq_lens / req_to_token directly."""
 
     def init_forward_metadata_out_graph(self, forward_batch: ForwardBatch, in_capture: bool = False):
+        """Graph entry point (triton_backend.py:572-632), called by the runner before capture
+        (``in_capture=True``) AND before every ``graph.replay()`` (decode_cuda_graph_runner.py:1168): it
+        always (re)fills the address-stable buffers of ``init_cuda_graph_state`` -- num_kv_splits, the fp32
+        partials, kv_indices / kv_indptr, the verify qo / mask indptr -- because those are what the captured
+        kernels read.  Every launch-shape decision here depends on ``bs`` only, never on the lengths.  A
+        runner that never built graph state gets the eager body (base_attn_backend.py:55-56)."""
+        self._build_metadata(forward_batch, graph=self._graph is not None)
+
+    def _build_metadata(self, forward_batch: ForwardBatch, graph: bool):
         bs = forward_batch.batch_size
         mode = forward_batch.forward_mode
         self._md_version += 1
         if mode.is_idle():
             self.forward_metadata = ForwardMetadata(None, None, None, None, None, None, None)
             return
+        if graph and bs > self._graph["max_bs"]:
+            raise ValueError(f"batch size {bs} exceeds init_cuda_graph_state's max_bs {self._graph['max_bs']}")
         if mode.is_decode():
-            self.forward_metadata = self._decode_metadata(forward_batch, bs, in_capture)
+            self.forward_metadata = self._decode_metadata(forward_batch, bs, graph)
         elif mode.is_target_verify():
-            self.forward_metadata = self._target_verify_metadata(forward_batch, bs)
+            self.forward_metadata = self._target_verify_metadata(forward_batch, bs, graph)
         elif mode.is_draft_extend_v2():
             self.forward_metadata = self._draft_extend_metadata(forward_batch, bs)
         else:
             self.forward_metadata = self._extend_metadata(forward_batch, bs)
 
     # ------------------------------------------------------------------ sliding window
-    def _window(self, lens: torch.Tensor, req_pool_indices: torch.Tensor, bs: int):
+    def _window(self, lens: torch.Tensor, req_pool_indices: torch.Tensor, bs: int, graph: bool = False):
         """update_sliding_window_buffer (triton_backend.py:2043-2110): the last min(len, W) slots of every
         request -> (window_kv_indptr, window_kv_indices, window_kv_lens, window_kv_offsets)."""
         w = self.sliding_window_size
         window_lens = torch.clamp(lens, max=w)
         start = (lens - window_lens).to(torch.int32)
         total = min(bs * w, bs * self.max_context_len)
-        kv_indices = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+        if graph:
+            kv_indices = self._graph["window_kv_indices"]
+            self._graph["window_kv_offsets"][:bs].copy_(start)
+            start = self._graph["window_kv_offsets"][:bs]
+        else:
+            kv_indices = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
         kv_indptr = ops.build_kv_indices(self.req_to_token, req_pool_indices, window_lens,
                                          self.window_kv_indptr, kv_indices, start)
         return kv_indptr, kv_indices, window_lens, start
 
-    def _decode_metadata(self, fb: ForwardBatch, bs: int, in_capture: bool) -> ForwardMetadata:
-        use_graph_bufs = self._graph is not None and (in_capture or self._graph.get("active"))
+    def _decode_metadata(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool) -> ForwardMetadata:
         self._cascade_on = self.cascade_decode and bs >= self.cascade_min_bs
         if self._cascade_on:
             if self._cascade is None:
@@ -231,7 +246,7 @@ class HipRadixAttnBackend:
         kv_indptr = kv_indices = None
         if self.decode_index_mode == "indices":
             if use_graph_bufs:
-                kv_indices = self._graph["kv_indices"]
+                kv_indices = self._graph_kv_indices()
             else:
                 total = fb.seq_lens_sum if fb.seq_lens_sum is not None else bs * self.max_context_len
                 kv_indices = torch.empty(total, dtype=torch.int64, device=self.device)
@@ -239,8 +254,9 @@ class HipRadixAttnBackend:
                                              self.kv_indptr, kv_indices)
         win = {}
         if self.sliding_window_size is not None:
-            wp, wi, wl, _ = self._window(fb.seq_lens, fb.req_pool_indices, bs)
-            wsplits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+            wp, wi, wl, _ = self._window(fb.seq_lens, fb.req_pool_indices, bs, use_graph_bufs)
+            wsplits = (self._graph["window_num_kv_splits"][:bs] if use_graph_bufs
+                       else torch.empty((bs,), dtype=torch.int32, device=self.device))
             ops.get_num_kv_splits(wsplits, wl, self.num_head, self.num_kv_head, self.max_kv_splits,
                                   self.device_core_count)
             win = dict(window_kv_indptr=wp, window_kv_indices=wi, window_num_kv_splits=wsplits)
@@ -264,7 +280,7 @@ class HipRadixAttnBackend:
         kv_indptr = kv_indices = None
         if self.decode_index_mode == "indices":
             if use_graph_bufs:
-                kv_indices = self._graph["kv_indices"]
+                kv_indices = self._graph_kv_indices()
             else:
                 total = fb.seq_lens_sum if fb.seq_lens_sum is not None else bs * self.max_context_len
                 kv_indices = torch.empty(total, dtype=torch.int64, device=self.device)
@@ -321,70 +337,108 @@ class HipRadixAttnBackend:
                 self._extend_split_on = True
         return ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr, **win)
 
-    def _target_verify_metadata(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
+    def _target_verify_metadata(self, fb: ForwardBatch, bs: int, graph: bool = False) -> ForwardMetadata:
         """TARGET_VERIFY (triton_backend.py:801-866): every request extends by its draft tokens over its
-        WHOLE cached sequence, under the draft tree's mask."""
+        WHOLE cached sequence, under the draft tree's mask.  ``graph``: qo_indptr / kv_indices / mask_indptr
+        live in the address-stable buffers (triton_backend.py:1016-1063), refilled before every replay."""
         spec = fb.spec_info
         nd = self.num_draft_tokens
         if spec is not None and getattr(spec, "draft_token_num", None) is not None:
             nd = int(spec.draft_token_num)
         if not nd:
             raise ValueError("TARGET_VERIFY needs spec_info.draft_token_num or server_args.speculative_num_draft_tokens")
-        qo_indptr = torch.arange(0, (1 + bs) * nd, step=nd, dtype=torch.int64, device=self.device)
-        total = fb.seq_lens_sum if fb.seq_lens_sum is not None else bs * self.max_context_len
-        kv_indices = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
+        custom_mask = getattr(spec, "custom_mask", None)
+        if custom_mask is None:
+            raise ValueError("TARGET_VERIFY needs spec_info.custom_mask (the draft tree's visibility mask)")
+        qo_indptr = self.qo_indptr[: bs + 1]
+        torch.arange(0, (1 + bs) * nd, step=nd, dtype=torch.int64, device=self.device, out=qo_indptr)
+        if graph:
+            kv_indices = self._graph_kv_indices()
+        else:
+            total = fb.seq_lens_sum if fb.seq_lens_sum is not None else bs * self.max_context_len
+            kv_indices = torch.empty(max(total, 1), dtype=torch.int64, device=self.device)
         kv_indptr = ops.build_kv_indices(self.req_to_token, fb.req_pool_indices, fb.seq_lens, self.kv_indptr,
                                          kv_indices)
         win = {}
         if self.sliding_window_size is not None:
-            wp, wi, _, wo = self._window(fb.seq_lens, fb.req_pool_indices, bs)
+            wp, wi, _, wo = self._window(fb.seq_lens, fb.req_pool_indices, bs, graph)
             win = dict(window_kv_indptr=wp, window_kv_indices=wi, window_kv_offsets=wo)
         mask_indptr = self.mask_indptr[: bs + 1]
         mask_indptr[1:] = torch.cumsum(nd * (fb.seq_lens[:bs].to(torch.int64) + nd), dim=0)
+        if graph:
+            # the captured kernels read the mask bytes in place: keep them at one address (a runner's bool mask
+            # would be re-cast into a fresh uint8 tensor on every forward)
+            g = self._graph
+            need = g["max_bs"] * nd * (self.max_context_len + nd)
+            if g.get("custom_mask") is None or g["custom_mask"].numel() < need:
+                g["custom_mask"] = torch.zeros(need, dtype=torch.uint8, device=self.device)
+            if custom_mask.numel() > need:
+                raise ValueError("TARGET_VERIFY mask larger than max_bs * nd * (context_len + nd)")
+            g["custom_mask"][: custom_mask.numel()].copy_(custom_mask.reshape(-1))
+            custom_mask = g["custom_mask"]
         # small verify batches: one workgroup per (request, kv head) would leave the chip idle -- cut the cached
         # part into chunks (ops.VerifySplitKV, the reference's verify_splitkv case)
         self._verify_split_on = False
-        if (self.sliding_window_size is None and not self._is_mla_pool and self.v_head_dim == 128
-                and spec.custom_mask is not None):
+        if self.sliding_window_size is None and not self._is_mla_pool and self.v_head_dim == 128:
             if self._verify_split is None:
                 kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
                 self._verify_split = ops.VerifySplitKV(self.num_head, self.num_kv_head, self._q_dtype(kb), self.device,
                                                        cu_count=self.device_core_count)
             if self._verify_split.num_chunks(bs, nd) >= 2:
-                cm = spec.custom_mask if spec.custom_mask.dtype == torch.uint8 else spec.custom_mask.to(torch.uint8)
+                cm = custom_mask if custom_mask.dtype == torch.uint8 else custom_mask.to(torch.uint8)
                 self._verify_split.plan(qo_indptr, kv_indptr, kv_indices, cm, mask_indptr, nd)
                 self._verify_split_on = True
         return ForwardMetadata(None, None, nd, None, kv_indptr, kv_indices, qo_indptr,
-                               custom_mask=spec.custom_mask, mask_indptr=mask_indptr, **win)
+                               custom_mask=custom_mask, mask_indptr=mask_indptr, **win)
 
     def _draft_extend_metadata(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
-        """DRAFT_EXTEND_V2 (triton_backend.py:907-924): spec_info produces the prefill arguments."""
+        """DRAFT_EXTEND_V2 (triton_backend.py:907-924): spec_info produces the prefill arguments; a mask, when
+        one comes back, is addressed through mask_indptr = cumsum(extend_len * (cached_len + extend_len))."""
         kv_indices, kv_indptr, qo_indptr, custom_mask = fb.spec_info.generate_attn_arg_prefill(
             fb.req_pool_indices, fb.seq_lens, None, self.req_to_token)
-        max_extend_len = int(getattr(fb.spec_info, "num_tokens_per_req", 0)) or int(
-            (qo_indptr[1:] - qo_indptr[:-1]).max())
+        ext = qo_indptr[1:] - qo_indptr[:-1]
+        max_extend_len = int(getattr(fb.spec_info, "num_tokens_per_req", 0)) or int(ext.max())
+        mask_indptr = None
+        if custom_mask is not None:
+            mask_indptr = self.mask_indptr[: bs + 1]
+            cached = (kv_indptr[1:] - kv_indptr[:-1]).to(torch.int64)
+            mask_indptr[1:] = torch.cumsum(ext.to(torch.int64) * (cached + ext.to(torch.int64)), dim=0)
         return ForwardMetadata(None, None, max_extend_len, None, kv_indptr.to(torch.int32), kv_indices,
-                               qo_indptr, custom_mask=custom_mask,
-                               mask_indptr=self.mask_indptr[: bs + 1] if custom_mask is not None else None)
+                               qo_indptr, custom_mask=custom_mask, mask_indptr=mask_indptr)
 
     # ------------------------------------------------------------------ graph support
     def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int):
-        """Address-stable buffers (triton_backend.py:962-1063)."""
+        """Address-stable buffers (triton_backend.py:962-1063).  Everything a captured kernel reads that
+        init_forward_metadata_out_graph rewrites before a replay lives here."""
+        dev = self.device
         self._graph = {
-            "active": False,
-            "num_kv_splits": torch.full((max_bs,), 1, dtype=torch.int32, device=self.device),
+            "max_bs": int(max_bs),
+            "num_kv_splits": torch.full((max_bs,), 1, dtype=torch.int32, device=dev),
             "attn_logits": torch.zeros((max_bs, self.num_head, self.max_kv_splits, self.v_head_dim),
-                                       dtype=torch.float32, device=self.device),
-            "attn_lse": torch.zeros((max_bs, self.num_head, self.max_kv_splits),
-                                    dtype=torch.float32, device=self.device),
-            "kv_indices": torch.zeros((max_bs * self.max_context_len,), dtype=torch.int64,
-                                      device=self.device) if self.decode_index_mode == "indices" else None,
+                                       dtype=torch.float32, device=dev),
+            "attn_lse": torch.zeros((max_bs, self.num_head, self.max_kv_splits), dtype=torch.float32, device=dev),
+            # int64 slot list of the "indices" contract and of TARGET_VERIFY: built on first use (the paged decode
+            # mode never materialises it)
+            "kv_indices": None,
         }
         # native schedule: bs * S(bs) <= cu_count / wg_per_request + bs rows of partials
         group = max(1, self.num_head // self.num_kv_head)
         rows = (2 * self.device_core_count // (self.num_kv_head * ((group + 15) // 16)) + max_bs + 1) * self.num_head
-        self._graph["native_logits"] = torch.zeros(rows * self.v_head_dim, dtype=torch.float32, device=self.device)
-        self._graph["native_lse"] = torch.zeros(rows, dtype=torch.float32, device=self.device)
+        self._graph["native_logits"] = torch.zeros(rows * self.v_head_dim, dtype=torch.float32, device=dev)
+        self._graph["native_lse"] = torch.zeros(rows, dtype=torch.float32, device=dev)
+        if self.decode_index_mode == "indices":
+            self._graph_kv_indices()
+        if self.sliding_window_size is not None:
+            w = min(self.sliding_window_size, self.max_context_len)
+            self._graph["window_kv_indices"] = torch.zeros(max(1, max_bs * w), dtype=torch.int64, device=dev)
+            self._graph["window_kv_offsets"] = torch.zeros(max_bs, dtype=torch.int32, device=dev)
+            self._graph["window_num_kv_splits"] = torch.ones(max_bs, dtype=torch.int32, device=dev)
+
+    def _graph_kv_indices(self) -> torch.Tensor:
+        g = self._graph
+        if g["kv_indices"] is None:
+            g["kv_indices"] = torch.zeros((g["max_bs"] * self.max_context_len,), dtype=torch.int64, device=self.device)
+        return g["kv_indices"]
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1  # triton_backend.py:1205-1206

@@ -41,6 +41,7 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
+    force = force or bool(os.environ.get("RX_BUILD_FORCE"))
     hipcc = _hipcc()
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
@@ -53,10 +54,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
                "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-c", sp, "-o", obj]
         cmd[1:1] = EXTRA_FLAGS.get(src, []) + os.environ.get("RX_CFLAGS", "").split()
+        objs.append(obj)
+        # per-object incremental build: recompile only what is older than its source, the headers or its flags
+        stamp = obj + ".cmd"
+        deps = [sp] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+        if (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+                and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps)):
+            continue
+        with open(stamp, "w") as f:
+            f.write(" ".join(cmd))
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
     for src, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:

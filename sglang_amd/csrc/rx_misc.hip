@@ -487,6 +487,36 @@ __global__ __launch_bounds__(256) void move_kv_kernel(const uint64_t* __restrict
   }
 }
 
+// K10 on a paged layout (HND pools: a slot's row is Hkv pieces, one per head, page_stride / head_stride /
+// tok_stride apart): same contract, the row address comes from rx_kv_layout-style strides.  geom[b] =
+// {page_stride, head_stride, tok_stride, piece_bytes} of buffer b, all in BYTES.  One wave per (slot, buffer).
+__global__ __launch_bounds__(256) void move_kv_layout_kernel(const uint64_t* __restrict__ data_ptrs,
+                                                             const int64_t* __restrict__ geom, int32_t page_size,
+                                                             int32_t num_heads, const int64_t* __restrict__ tgt,
+                                                             const int64_t* __restrict__ src, int64_t n) {
+  const int buf = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  char* base = reinterpret_cast<char*>(data_ptrs[buf]);
+  const int64_t ps = geom[4 * buf], hs = geom[4 * buf + 1], ts = geom[4 * buf + 2], piece = geom[4 * buf + 3];
+  const int64_t s_slot = src[i], t_slot = tgt[i];
+  const char* s = base + (s_slot / page_size) * ps + (s_slot % page_size) * ts;
+  char* d = base + (t_slot / page_size) * ps + (t_slot % page_size) * ts;
+  const int64_t total = piece * num_heads;
+  if ((piece & 15) == 0) {
+    for (int64_t off = lane * 16; off < total; off += 64 * 16) {
+      const int64_t h = off / piece, w = off - h * piece;
+      *reinterpret_cast<u32x4*>(d + h * hs + w) = *reinterpret_cast<const u32x4*>(s + h * hs + w);
+    }
+  } else {
+    for (int64_t off = lane * 4; off < total; off += 64 * 4) {
+      const int64_t h = off / piece, w = off - h * piece;
+      *reinterpret_cast<uint32_t*>(d + h * hs + w) = *reinterpret_cast<const uint32_t*>(s + h * hs + w);
+    }
+  }
+}
+
 }  // namespace rx
 
 using namespace rx;
@@ -494,6 +524,14 @@ using namespace rx;
 extern "C" {
 
 int rx_version(void) { return RX_ABI_VERSION; }
+int64_t rx_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(rx_kv_layout);
+    case 1: return sizeof(rx_decode_params);
+    case 2: return sizeof(rx_extend_params);
+    default: return -1;
+  }
+}
 const char* rx_last_error(void) { return rx::err_buf(); }
 
 int rx_store_kv(const void* k, const void* v, void* k_cache, void* v_cache, const void* loc,
@@ -778,6 +816,16 @@ int rx_move_kv(const uint64_t* data_ptrs, const int64_t* row_bytes, int num_bufs
                      dim3(256), 0, static_cast<hipStream_t>(stream), data_ptrs, row_bytes,
                      tgt_loc, src_loc, n);
   return check_launch("rx_move_kv");
+}
+
+int rx_move_kv_layout(const uint64_t* data_ptrs, const int64_t* geom, int num_bufs, int page_size, int num_heads,
+                      const int64_t* tgt_loc, const int64_t* src_loc, int64_t n, void* stream) {
+  RX_REQUIRE(num_bufs >= 0 && n >= 0 && page_size >= 1 && num_heads >= 1, "rx_move_kv_layout: bad sizes");
+  if (num_bufs == 0 || n == 0) return RX_OK;
+  RX_REQUIRE(data_ptrs && geom && tgt_loc && src_loc, "rx_move_kv_layout: null pointer");
+  hipLaunchKernelGGL(move_kv_layout_kernel, dim3(static_cast<unsigned>((n + 3) / 4), num_bufs), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), data_ptrs, geom, page_size, num_heads, tgt_loc, src_loc, n);
+  return check_launch("rx_move_kv_layout");
 }
 
 namespace rx {

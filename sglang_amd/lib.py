@@ -16,6 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
+RX_ABI_VERSION = 2  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -74,6 +75,7 @@ class RxExtendParams(C.Structure):
 # symbol -> (restype, argtypes); every prototype of include/radix_hip.h
 PROTOTYPES = {
     "rx_version": (c_int, []),
+    "rx_abi_sizeof": (c_int64, [c_int]),
     "rx_last_error": (C.c_char_p, []),
     "rx_store_kv": (c_int, [c_void_p] * 5 + [c_int64] * 7 + [c_int, c_int64, c_int64, c_void_p, c_void_p]),
     "rx_store_kv_layout": (c_int, [c_void_p, c_void_p, C.POINTER(RxKvLayout), c_void_p, c_int64, c_int, c_int,
@@ -112,6 +114,7 @@ PROTOTYPES = {
     "rx_alloc_decode": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "rx_write_req_to_token": (c_int, [c_void_p, c_int64] + [c_void_p] * 6 + [c_int, c_void_p]),
     "rx_move_kv": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rx_move_kv_layout": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     # host-side radix tree
     "rx_radix_create": (c_void_p, [c_int, c_int]),
     "rx_radix_destroy": (None, [c_void_p]),
@@ -151,9 +154,12 @@ def load(build_if_missing: bool = True):
         if build_if_missing and _build.needs_build():
             try:
                 _build.build()
-            except Exception as e:  # stale-but-present lib is still usable on a GPU box w/o sources
+            except Exception as e:  # stale-but-present lib: usable only if the ABI checks below pass
                 if not os.path.exists(path):
                     raise RadixHipError(f"libradix_hip.so missing and build failed: {e}") from e
+                import warnings
+                warnings.warn(f"libradix_hip.so is older than its sources and the rebuild failed ({e}); "
+                              f"loading the stale library", RuntimeWarning)
         if not os.path.exists(path):
             raise RadixHipError(f"{path} not found: run `python -m sglang_amd.build`")
         lib = C.CDLL(path)
@@ -161,8 +167,13 @@ def load(build_if_missing: bool = True):
             fn = getattr(lib, name)  # AttributeError if the header and the .so disagree
             fn.restype = res
             fn.argtypes = args
-        if lib.rx_version() != 1:
-            raise RadixHipError(f"ABI version mismatch: {lib.rx_version()}")
+        if lib.rx_version() != RX_ABI_VERSION:
+            raise RadixHipError(f"ABI version mismatch: library {lib.rx_version()}, binding {RX_ABI_VERSION} "
+                                f"(rebuild: python -m sglang_amd.build --force)")
+        for which, st in enumerate((RxKvLayout, RxDecodeParams, RxExtendParams)):
+            if lib.rx_abi_sizeof(which) != C.sizeof(st):
+                raise RadixHipError(f"{path}: sizeof({st.__name__}) is {lib.rx_abi_sizeof(which)} in the library, "
+                                    f"{C.sizeof(st)} in the binding -- stale build (python -m sglang_amd.build --force)")
         _lib = lib
         return _lib
 

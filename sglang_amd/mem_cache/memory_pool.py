@@ -120,6 +120,10 @@ class MHATokenToKVPool:
                                       device=self.device)
         self.data_strides = torch.tensor(
             [b.stride(0) * b.element_size() for b in bufs], dtype=torch.int64, device=self.device)
+        if self.use_hnd:  # [pages, Hkv, page, D]: {page, head, token} strides and one head's piece, in bytes
+            self.data_geom = torch.tensor(
+                [[b.stride(0) * b.element_size(), b.stride(1) * b.element_size(), b.stride(2) * b.element_size(),
+                  b.shape[3] * b.element_size()] for b in bufs], dtype=torch.int64, device=self.device)
 
     def get_kv_size_bytes(self):
         k = sum(b.numel() * b.element_size() for b in self.k_buffer)
@@ -212,7 +216,9 @@ class MHATokenToKVPool:
         if tgt_loc.numel() == 0:
             return
         if self.use_hnd:
-            raise NotImplementedError("move_kv_cache on the HND layout")
+            ops.move_kv_layout(self.data_ptrs, self.data_geom, self.page_size, self.head_num,
+                               tgt_loc.to(torch.int64), src_loc.to(torch.int64))
+            return
         ops.move_kv(self.data_ptrs, self.data_strides, tgt_loc.to(torch.int64),
                     src_loc.to(torch.int64))
 

@@ -1056,3 +1056,19 @@ def move_kv(data_ptrs: torch.Tensor, row_bytes: torch.Tensor, tgt_loc: torch.Ten
     st = _L.load().rx_move_kv(_ptr(data_ptrs), _ptr(row_bytes), data_ptrs.shape[0], _ptr(tgt_loc),
                               _ptr(src_loc), tgt_loc.shape[0], _stream(tgt_loc))
     _L.check(st, "rx_move_kv")
+
+
+def move_kv_layout(data_ptrs: torch.Tensor, geom: torch.Tensor, page_size: int, num_heads: int,
+                   tgt_loc: torch.Tensor, src_loc: torch.Tensor):
+    """rx_move_kv_layout: move_kv_cache on a paged (HND) pool; geom int64[num_bufs, 4] =
+    {page_stride, head_stride, tok_stride, piece_bytes} in bytes per buffer."""
+    _require_cuda(data_ptrs, geom, tgt_loc, src_loc)
+    if data_ptrs.dtype not in (torch.uint64, torch.int64) or geom.dtype != torch.int64:
+        raise TypeError("data_ptrs must be (u)int64 and geom int64")
+    if tuple(geom.shape) != (data_ptrs.shape[0], 4) or not geom.is_contiguous():
+        raise ValueError("geom must be contiguous [num_bufs, 4]")
+    if tgt_loc.dtype != torch.int64 or src_loc.dtype != torch.int64:
+        raise TypeError("tgt_loc / src_loc must be int64")
+    st = _L.load().rx_move_kv_layout(_ptr(data_ptrs), _ptr(geom), data_ptrs.shape[0], int(page_size), int(num_heads),
+                                     _ptr(tgt_loc), _ptr(src_loc), tgt_loc.shape[0], _stream(tgt_loc))
+    _L.check(st, "rx_move_kv_layout")

@@ -175,7 +175,8 @@ class TPGroup:
         self._comm_stream.wait_event(ready)
         with torch.cuda.stream(self._comm_stream):
             self._reduce(x)
-            x.record_stream(self._comm_stream)
+            if not torch.cuda.is_current_stream_capturing():  # a captured graph owns its memory pool
+                x.record_stream(self._comm_stream)
             done.record(self._comm_stream)
         return _Pending(x, done)
 

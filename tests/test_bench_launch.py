@@ -1,0 +1,91 @@
+"""bench.py's N-rank launch path: `python bench.py --gpus N` without a launcher around it must start N ranks
+itself (as a child torch.distributed.run, before any GPU call) and print ONE JSON line with n_gpus = N."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_bench():
+    spec = importlib.util.spec_from_file_location("rx_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_self_launch_starts_torchrun_child_with_same_arguments(monkeypatch):
+    bench = _load_bench()
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    args = bench.parse()
+    assert bench.self_launch(args) == 7  # the child's exit code is handed back
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+
+
+def test_main_self_launches_only_without_a_launcher(monkeypatch):
+    """--gpus N with WORLD_SIZE unset -> self_launch and exit with its code; the parent makes no GPU call."""
+    bench = _load_bench()
+    calls = []
+    monkeypatch.setattr(bench, "self_launch", lambda a: calls.append(a.gpus) or 0)
+    monkeypatch.setattr(bench, "build_world", lambda a: (_ for _ in ()).throw(AssertionError("GPU path reached")))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and calls == [2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--no-graph"]], ids=["default", "eager"])
+def test_bench_gpus_2_runs_two_ranks_on_one_gpu(extra):
+    """The whole multi-rank control flow on the single GPU of a test box: RX_BENCH_BACKEND=gloo puts both ranks on
+    device 0 and reduces through the host (never a reported number); rank 0 prints one line with n_gpus == 2."""
+    env = dict(os.environ, RX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--settle", "1", "--bs", "16", "--ctx", "512", "--layers", "4", "--no-cpu-baseline"] + extra,
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "tp2"
+    assert out["config"]["all_reduce"] == "gloo" and out["steps"] == 2
+    assert len(out["roofline"]["per_rank_frac"]) == 2
+    assert {"alone_us", "step_ms_overlap", "step_ms_no_overlap"} <= set(out["all_reduce"])
+
+
+@pytest.mark.gpu
+def test_bench_tp_sim_shard_replays_from_hip_graphs():
+    """One rank's shard of a TP=8 job (no collective) under graph replay: the step is launched as HIP-graph replays
+    and the roofline kernel is still timed live."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tp-sim", "8", "--steps", "3", "--warmup", "1",
+                        "--settle", "1", "--bs", "64", "--ctx", "1024", "--layers", "8", "--no-cpu-baseline",
+                        "--no-extend", "--no-radix-hit"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["step_launch"].startswith("hip-graph")
+    assert out["roofline"]["launches"] == 3 and out["roofline"]["avg_launch_ms"] > 0

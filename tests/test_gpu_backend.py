@@ -326,6 +326,40 @@ def test_hnd_pool_store_and_decode():
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("dtype,vd", [(torch.bfloat16, 128), (torch.float16, 64), (torch.float8_e4m3fn, 128)])
+def test_move_kv_cache_on_hnd_and_nhd_pools_agree(dtype, vd):
+    """move_kv_cache (memory_pool.py:2775-2842) on the HND layout [pages, Hkv, page, D] -- the pool layout the
+    backend and the bench default to: every layer's K and V rows src -> tgt, identical to the NHD pool's move."""
+    from sglang_amd.mem_cache.memory_pool import MHATokenToKVPool
+
+    hkv, d, ps, layers, size = 4, 128, 16, 3, 1024
+    g = torch.Generator().manual_seed(3)
+    src = (torch.randperm(size - 1, generator=g)[:200] + 1).to(DEV)
+    tgt = (torch.randperm(size - 1, generator=g)[:200] + 1).to(DEV)
+    tgt = tgt[~torch.isin(tgt, src)]              # a move never reads what it writes
+    src = src[: tgt.numel()]
+    pools = {}
+    for use_hnd in (False, True):
+        pool = pools[use_hnd] = MHATokenToKVPool(size, ps, dtype, hkv, d, layers, DEV, v_head_dim=vd, use_hnd=use_hnd)
+        gg = torch.Generator(device=DEV).manual_seed(7)
+        for l in range(layers):
+            for bufs, hd in ((pool.k_buffer, d), (pool.v_buffer, vd)):
+                rows = torch.randint(0, 120, (size + ps, hkv, hd), generator=gg, device=DEV, dtype=torch.uint8)
+                rows = rows if pool.is_fp8 else rows.to(dtype)
+                if use_hnd:
+                    bufs[l].copy_(rows.view(-1, ps, hkv, hd).permute(0, 2, 1, 3))
+                else:
+                    bufs[l].copy_(rows)
+        pool.move_kv_cache(tgt, src)
+    torch.cuda.synchronize()
+    for l in range(layers):
+        for a, b in ((pools[False].k_buffer[l], pools[True].k_buffer[l]), (pools[False].v_buffer[l], pools[True].v_buffer[l])):
+            hd = a.shape[-1]
+            assert torch.equal(a.view(-1, ps, hkv, hd).permute(0, 2, 1, 3), b)
+        kb = pools[True].k_buffer[l]
+        assert torch.equal(kb[tgt // ps, :, tgt % ps, :], kb[src // ps, :, src % ps, :])
+
+
 def test_hnd_pool_extend_with_prefix():
     """Extend (prefix gathered from an HND pool through the shift/mask page addressing)."""
     from sglang_amd.attention.backend import HipRadixAttnBackend
@@ -541,3 +575,136 @@ def test_short_extend_over_long_prefix_takes_split_kv_path():
     got = o.view(T, hq, d).float().cpu().numpy().astype(np.float64)
     assert hs.pool.check_errors() == 0
     assert np.abs(got - want).max() <= 1.5e-2
+
+
+def _capture(fn):
+    """Warm on a side stream (allocator, lazy launchers), then capture fn() into a HIP graph."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fn()
+    return graph, out
+
+
+@pytest.mark.parametrize("index_mode,policy", [("paged", "native"), ("indices", "native"), ("paged", "reference"),
+                                               ("indices", "reference")])
+def test_graph_replay_refreshes_static_metadata(index_mode, policy):
+    """The runner's contract (decode_cuda_graph_runner.py:946-953,1168): capture once with seq_lens = the fill
+    value in address-stable input buffers, then before EVERY replay copy the live batch into those buffers and call
+    init_forward_metadata_out_graph(fb) -- which must refill the static num_kv_splits / partials / kv_indices the
+    captured kernels read (triton_backend.py:572-632).  Replay == eager on the same live batch."""
+    from sglang_amd.forward_batch import ForwardBatch
+
+    hs = _Harness(16, 32, 8, 128, torch.bfloat16, "shuffled_pages", index_mode, split_policy=policy)
+    be = hs.backend
+    bs = 3
+    be.init_cuda_graph_state(4, 4)
+    fill = be.get_cuda_graph_seq_len_fill_value()
+    s_rpi = torch.zeros(bs, dtype=torch.int64, device=DEV)           # padding row 0
+    s_seq = torch.full((bs,), fill, dtype=torch.int64, device=DEV)
+    s_loc = torch.zeros(bs, dtype=torch.int64, device=DEV)           # padding slot 0
+    q, k, v = hs.rand(bs, 32 * 128), hs.rand(bs, 8 * 128), hs.rand(bs, 8 * 128)
+    fb_g = ForwardBatch.for_decode(s_rpi, s_seq, s_loc, torch.full((bs,), fill, dtype=torch.int64))
+    be.init_forward_metadata_out_graph(fb_g, in_capture=True)
+    graph, out = _capture(lambda: hs.layer(q, k, v, fb_g, be))
+
+    # two different live batches replayed through the SAME graph
+    rows = hs.r2t.alloc(bs)
+    for prefix in ((600, 33, 1024), (1, 2047, 130)):
+        hs.fill_prefix(rows, prefix)
+        rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+        seq = torch.tensor([p + 1 for p in prefix], dtype=torch.int64)
+        last = torch.tensor([int(hs.r2t.req_to_token[r, p - 1]) for r, p in zip(rows, prefix)],
+                            dtype=torch.int64, device=DEV)
+        loc = hs.alloc.alloc_decode(seq.to(DEV), seq, last)
+        hs.r2t.req_to_token[rpi, torch.tensor(prefix, device=DEV)] = loc.to(torch.int32)
+        q.copy_(hs.rand(bs, 32 * 128)); k.copy_(hs.rand(bs, 8 * 128)); v.copy_(hs.rand(bs, 8 * 128))
+        s_rpi.copy_(rpi); s_seq.copy_(seq.to(DEV)); s_loc.copy_(loc)
+        fb_r = ForwardBatch.for_decode(s_rpi, s_seq, s_loc, seq)
+        be.init_forward_metadata_out_graph(fb_r)
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = out.clone()
+        fb_e = ForwardBatch.for_decode(rpi, seq.to(DEV), loc, seq)
+        be.init_forward_metadata(fb_e)
+        eager = hs.layer(q, k, v, fb_e, be)
+        kb, vb = hs.pool.get_kv_buffer(0)
+        want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, 32, 128)), _bits(kb), _bits(vb),
+                                            _bits(hs.r2t.req_to_token), np.array(rows), seq.numpy(), 128 ** -0.5)
+        err = np.abs(replayed.view(bs, 32, 128).float().cpu().numpy().astype(np.float64) - want).max()
+        assert err <= 1e-2, (index_mode, policy, prefix, err)
+        assert torch.equal(replayed, eager), (index_mode, policy, prefix)
+        # free the batch's pages so that the next one starts from empty rows
+        for r, p in zip(rows, prefix):
+            hs.alloc.free(hs.r2t.req_to_token[r, : p + 1].to(torch.int64))
+    assert hs.pool.check_errors() == 0
+
+
+def test_target_verify_graph_replay_refreshes_indices_and_mask():
+    """TARGET_VERIFY under a HIP graph: qo_indptr / kv_indices / mask_indptr / the mask bytes are address-stable
+    and refilled by init_forward_metadata_out_graph before each replay (triton_backend.py:1016-1063)."""
+    from sglang_amd.forward_batch import ForwardBatch, ForwardMode
+
+    ps, hq, hkv, d, nd = 16, 8, 2, 128, 4
+    hs = _Harness(ps, hq, hkv, d, torch.float16, "shuffled_pages", "paged")
+    be = hs.backend
+    bs = 2
+    be.init_cuda_graph_state(2, 2 * nd)
+    T = bs * nd
+    s_rpi = torch.zeros(bs, dtype=torch.int64, device=DEV)
+    s_seq = torch.full((bs,), 1, dtype=torch.int64, device=DEV)
+    s_loc = torch.zeros(T, dtype=torch.int64, device=DEV)
+    s_mask = torch.ones(bs * nd * (hs.backend.max_context_len + nd), dtype=torch.bool, device=DEV)
+    q, k, v = hs.rand(T, hq * d), hs.rand(T, hkv * d), hs.rand(T, hkv * d)
+
+    class Spec:
+        draft_token_num = nd
+        custom_mask = s_mask
+
+    def make_fb(seq_cpu):
+        return ForwardBatch(forward_mode=ForwardMode.TARGET_VERIFY, batch_size=bs, req_pool_indices=s_rpi,
+                            seq_lens=s_seq, out_cache_loc=s_loc, seq_lens_sum=int(seq_cpu.sum()),
+                            seq_lens_cpu=seq_cpu, spec_info=Spec)
+
+    fb_g = make_fb(torch.ones(bs, dtype=torch.int64))
+    be.init_forward_metadata_out_graph(fb_g, in_capture=True)
+    graph, out = _capture(lambda: hs.layer(q, k, v, fb_g, be))
+    rows = hs.r2t.alloc(bs)
+    rng = np.random.default_rng(9)
+    for seq_lens in ((300, 77), (64, 1500)):
+        hs.fill_prefix(rows, seq_lens)
+        total = [s + nd for s in seq_lens]
+        loc = hs.alloc_extend(rows, list(seq_lens), total)
+        masks = []
+        for s in seq_lens:
+            m = np.ones((nd, s + nd), dtype=bool)
+            tri = np.tril(rng.random((nd, nd)) < 0.5)
+            np.fill_diagonal(tri, True)
+            m[:, s:] = tri
+            masks.append(m.reshape(-1))
+        cm = np.concatenate(masks)
+        s_mask[: cm.size].copy_(torch.from_numpy(cm).to(DEV))
+        s_rpi.copy_(torch.tensor(rows, device=DEV)); s_seq.copy_(torch.tensor(seq_lens, device=DEV)); s_loc.copy_(loc)
+        q.copy_(hs.rand(T, hq * d)); k.copy_(hs.rand(T, hkv * d)); v.copy_(hs.rand(T, hkv * d))
+        be.init_forward_metadata_out_graph(make_fb(torch.tensor(seq_lens, dtype=torch.int64)))
+        graph.replay()
+        torch.cuda.synchronize()
+        kb, vb = hs.pool.get_kv_buffer(0)
+        r2t = _bits(hs.r2t.req_to_token)
+        kv_indptr, kv_indices = orc.build_kv_indices(r2t, np.array(rows), np.array(seq_lens))
+        qo = (np.arange(bs + 1) * nd).astype(np.int64)
+        kbn, vbn = _bits(kb), _bits(vb)
+        ke = np.concatenate([kbn[r2t[rows[i], seq_lens[i]: total[i]]] for i in range(bs)])
+        ve = np.concatenate([vbn[r2t[rows[i], seq_lens[i]: total[i]]] for i in range(bs)])
+        mi = np.concatenate([[0], np.cumsum([m.size for m in masks])]).astype(np.int64)
+        want = orc.extend_attention(_bits(q.view(T, hq, d)), ke, ve, kbn, vbn, qo, kv_indptr, kv_indices,
+                                    is_causal=True, sm_scale=d ** -0.5, custom_mask=cm, mask_indptr=mi)
+        err = np.abs(_bits(out.view(T, hq, d)).astype(np.float64) - want).max()
+        assert err <= 3e-3, (seq_lens, err)
+        for r, t in zip(rows, total):
+            hs.alloc.free(hs.r2t.req_to_token[r, :t].to(torch.int64))
+    assert hs.pool.check_errors() == 0
