@@ -354,6 +354,65 @@ int rx_write_req_to_token(int32_t* req_to_token, int64_t row_stride,
                           const int64_t* extend_lens, const int64_t* out_cache_loc, int bs,
                           void* stream);
 
+/* ---- a5 / 8f-1: device-resident free list of the slot / page allocators ------------------------------------
+ * Replaces the torch-tensor free list of TokenToKVPoolAllocator (srt/mem_cache/allocator/token.py:27-84) and
+ * PagedTokenToKVPoolAllocator (allocator/paged.py:105-345; merge_and_sort_free allocator/base.py:70-76) with a
+ * ring in HBM that kernels update in place -- same list ORDER after every operation (it decides the KV page indices
+ * a request gets, which must be bit-exact), no torch.cat / torch.unique, no host sync.
+ * All pointers are device pointers owned by the caller:
+ *   free_ring / release_ring  int64[capacity]   the two lists (release_ring may be NULL without need_sort)
+ *   flags                     uint8[num_ids+1]  zero between calls; marks ids during sorted inserts
+ *   tile_scratch              int64[rx_pool_tile_scratch_len(num_ids)]
+ *   state                     int64[rx_pool_state_words()]: [0] free head, [1] free count, [2] release head,
+ *                             [3] release count, [4] refused allocations (count check failed on the device)
+ * capacity >= the largest number of ids a list can hold.  `which`: 0 = free list, 1 = release list. */
+typedef struct rx_pool_desc {
+  int64_t* free_ring;
+  int64_t* release_ring;
+  int64_t capacity;
+  uint8_t* flags;
+  int64_t num_ids;
+  int64_t* tile_scratch;
+  int64_t* state;
+} rx_pool_desc;
+
+int64_t rx_pool_tile_scratch_len(int64_t num_ids);
+int rx_pool_state_words(void);
+/* clear(): free = [first_id, first_id + n), release empty (token.py:42-49, paged.py:329-337) */
+int rx_pool_reset(const rx_pool_desc* d, int64_t first_id, int64_t n, void* stream);
+/* list := ids (restore / tests);  out[0..min(count, out_cap)) := list in order */
+int rx_pool_load(const rx_pool_desc* d, int which, const int64_t* ids, int64_t n, void* stream);
+int rx_pool_snapshot(const rx_pool_desc* d, int which, int64_t* out, int64_t out_cap, void* stream);
+/* alloc (token.py:55-64, paged.py:149-170): num_pages ids off the head, expanded to page_size slots each */
+int rx_pool_alloc(const rx_pool_desc* d, int64_t num_pages, int page_size, int64_t* out, void* stream);
+/* alloc_extend / alloc_decode (paged.py:172-259; kernels/ops/memory/allocator.py:16-135) against the ring;
+ * num_new_pages (known on the host from the CPU lens) ids leave the head afterwards */
+int rx_pool_alloc_extend(const rx_pool_desc* d, const int64_t* prefix_lens, const int64_t* seq_lens,
+                         const int64_t* last_loc, int64_t* out_indices, int bs, int page_size,
+                         int64_t num_new_pages, void* stream);
+int rx_pool_alloc_decode(const rx_pool_desc* d, const int64_t* seq_lens, const int64_t* last_loc,
+                         int64_t* out_indices, int bs, int page_size, int64_t num_new_pages, void* stream);
+/* alloc_for_decode as ONE launch (srt/mem_cache/allocation.py:539-593): for request i with seq_lens[i] tokens so far
+ * (int64, BEFORE the new one) and row req_pool_indices[i] of req_to_token (int32, row_stride elements apart):
+ * loc = row[seq-1] + 1 inside a page, or the first slot of the next free page when seq % page_size == 0 (page_size
+ * 1: always) -- alloc_decode_kernel's rule (allocator.py:98-135); out_indices[i] = loc and row[seq] = loc.
+ * num_new_pages = #{i : seq_lens[i] % page_size == 0}, known on the host. */
+int rx_pool_alloc_decode_rows(const rx_pool_desc* d, int32_t* req_to_token, int64_t row_stride,
+                              const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t* out_indices, int bs,
+                              int page_size, int64_t num_new_pages, void* stream);
+/* list := list + ids (token.py:66-76) */
+int rx_pool_append(const rx_pool_desc* d, int which, const int64_t* ids, int64_t n, void* stream);
+/* list := reps + list, reps = ([idx[0]] if has_first) + idx[start::stride], each / page_size  (free_segment's
+ * stride-slice page representatives, paged.py:273-301) */
+int rx_pool_prepend_strided(const rx_pool_desc* d, int which, const int64_t* idx, int64_t n_idx, int has_first,
+                            int64_t start, int64_t stride, int page_size, void* stream);
+/* free (paged.py:261-271): mark idx / page_size (several calls may accumulate: free_group), then
+ * list := sorted(unique(marked)) + list -- what torch.unique + cat compute, without the host sync */
+int rx_pool_mark(const rx_pool_desc* d, const int64_t* idx, int64_t n, int page_size, void* stream);
+int rx_pool_flush_marks(const rx_pool_desc* d, int which, void* stream);
+/* merge_and_sort_free (base.py:70-76): free := sort(free + release), release := empty */
+int rx_pool_merge_sort(const rx_pool_desc* d, void* stream);
+
 /* ---- K10: KV move (all layers) ---------------------------------------------------------------
  * copy_all_layer_kv_cache_tiled (kernels/ops/kvcache/cache_move.py:60-133) used by
  * MHATokenToKVPool.move_kv_cache (memory_pool.py:2775-2842):
@@ -402,6 +461,19 @@ int64_t rx_radix_total_size(const rx_radix* t);
 int64_t rx_radix_num_nodes(const rx_radix* t);
 /* info6 = {parent id, key length, lock_ref, hit_count, #children, priority}; -1 if unknown id. */
 int rx_radix_node_info(const rx_radix* t, int64_t node_id, int64_t* info6);
+
+/* One request's cache bookkeeping in one call (RadixCache.cache_finished_req radix_cache.py:434-486 and
+ * cache_unfinished_req :488-553): insert the request's page-aligned key with the slots of its req_to_token row,
+ * move the locks, and report which row ranges go back to the allocator.
+ * token_ids / slots: host int64[n] (slots = the row's first n entries).  flags: bit 0 finished, bit 1 insert
+ * (finished only), bit 2 chunked (unfinished only).  last_node: node the request holds a lock on, < 0 for none.
+ * out8 (host int64[8]): [0],[1] first range to free [begin, end) (free_segment with start_pos = begin);
+ * [2],[3] second range (finished: the unaligned tail [key_len, n)); [4] page-aligned key length; [5] unfinished:
+ * slots written to out_slots (the row's cached prefix as the tree now holds it); [6] unfinished: node now locked;
+ * [7] prefix length the insert found cached.  Returns 0, -1 on bad arguments / out_slots too small. */
+int rx_radix_cache_req(rx_radix* t, const int64_t* token_ids, const int64_t* slots, int64_t n, const char* extra_key,
+                       int priority, int flags, int64_t protected_len, int64_t last_node, int64_t* out_slots,
+                       int64_t out_cap, int64_t* out8);
 
 /* ---- C1: peer-to-peer all-reduce over xGMI (one process per GPU) ---------------------------------
  * The sum all-reduce behind RowParallelLinear.forward (srt/layers/linear.py:1606-1627 ->

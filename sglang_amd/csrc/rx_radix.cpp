@@ -328,4 +328,58 @@ int rx_radix_node_info(const rx_radix* t, int64_t node_id, int64_t* info6) {
   return 0;
 }
 
+// One request's cache bookkeeping in ONE call: what RadixCache.cache_finished_req (:434-486) and
+// cache_unfinished_req (:488-553) spread over insert / match_prefix / dec_lock_ref / inc_lock_ref plus the slot-range
+// arithmetic between them.  The caller passes the request's tokens and the KV slots of its req_to_token row (host
+// copies); the tree is updated and the caller gets back WHICH PARTS OF THE ROW to hand to the allocator and (for an
+// unfinished request) the row's new contents.
+//   flags: bit 0 finished, bit 1 insert (finished only: 0 = free everything past the protected prefix),
+//          bit 2 chunked (unfinished only)
+//   out8:  [0],[1] first range to free  [begin, end) as offsets into the row  (duplicates of pages the tree
+//                  already held, or the whole uninserted run)           -- free_segment(start_pos = begin)
+//          [2],[3] second range (finished only): the tail past the last whole page [key_len, n)
+//          [4]     length of the page-aligned key
+//          [5]     unfinished: number of slots written to out_slots (the row's cached prefix as the tree now
+//                  holds it -- possibly pages shared with an earlier request)
+//          [6]     unfinished: id of the node the request is now locked on
+//          [7]     prefix length the insert found already cached
+// last_node: the node the request held a lock on (< 0: none); it is released here, and for an unfinished request
+// the new last node is locked.  Returns 0, or -1 on bad arguments / a too-small out_slots.
+int rx_radix_cache_req(rx_radix* t, const int64_t* token_ids, const int64_t* slots, int64_t n, const char* extra_key,
+                       int priority, int flags, int64_t protected_len, int64_t last_node, int64_t* out_slots,
+                       int64_t out_cap, int64_t* out8) {
+  if (!t || !out8 || n < 0 || (n > 0 && (!token_ids || !slots)) || protected_len < 0) return -1;
+  const bool finished = flags & 1, do_insert = flags & 2, chunked = flags & 4;
+  const int64_t key_len = n / t->page_size * t->page_size;
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  out8[4] = key_len;
+  int64_t node_id = t->root->id;
+  if (finished) {
+    int64_t freed_end = key_len;
+    if (do_insert) {
+      freed_end = rx_radix_insert(t, token_ids, slots, key_len, extra_key, priority, 0, &node_id);
+      out8[7] = freed_end;
+    }
+    out8[0] = protected_len;
+    out8[1] = freed_end > protected_len ? freed_end : protected_len;
+    out8[2] = key_len;
+    out8[3] = n;
+    if (last_node >= 0) rx_radix_dec_lock_ref(t, last_node);
+    return 0;
+  }
+  const int64_t pre = rx_radix_insert(t, token_ids, slots, key_len, extra_key, priority, chunked ? 1 : 0, &node_id);
+  out8[7] = pre;
+  out8[0] = protected_len;
+  out8[1] = pre > protected_len ? pre : protected_len;
+  if (out_cap < key_len || (key_len > 0 && !out_slots)) return -1;
+  int64_t new_last = t->root->id;
+  const int64_t m = key_len ? rx_radix_match_prefix(t, token_ids, key_len, extra_key, out_slots, out_cap, &new_last) : 0;
+  if (m != key_len) return -1;  // everything just inserted must match (radix_cache.py:527)
+  out8[5] = m;
+  out8[6] = new_last;
+  if (last_node >= 0) rx_radix_dec_lock_ref(t, last_node);
+  rx_radix_inc_lock_ref(t, new_last);
+  return 0;
+}
+
 }  // extern "C"

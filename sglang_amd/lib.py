@@ -30,6 +30,11 @@ class RxKvLayout(C.Structure):
     ]
 
 
+class RxPoolDesc(C.Structure):
+    _fields_ = [("free_ring", c_void_p), ("release_ring", c_void_p), ("capacity", c_int64), ("flags", c_void_p),
+                ("num_ids", c_int64), ("tile_scratch", c_void_p), ("state", c_void_p)]
+
+
 class RxDecodeParams(C.Structure):
     _fields_ = [
         ("q", c_void_p), ("o", c_void_p),
@@ -114,6 +119,25 @@ PROTOTYPES = {
     "rx_alloc_decode": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "rx_write_req_to_token": (c_int, [c_void_p, c_int64] + [c_void_p] * 6 + [c_int, c_void_p]),
     "rx_move_kv": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    # device-resident allocator free list
+    "rx_pool_tile_scratch_len": (c_int64, [c_int64]),
+    "rx_pool_state_words": (c_int, []),
+    "rx_pool_reset": (c_int, [C.POINTER(RxPoolDesc), c_int64, c_int64, c_void_p]),
+    "rx_pool_load": (c_int, [C.POINTER(RxPoolDesc), c_int, c_void_p, c_int64, c_void_p]),
+    "rx_pool_snapshot": (c_int, [C.POINTER(RxPoolDesc), c_int, c_void_p, c_int64, c_void_p]),
+    "rx_pool_alloc": (c_int, [C.POINTER(RxPoolDesc), c_int64, c_int, c_void_p, c_void_p]),
+    "rx_pool_alloc_extend": (c_int, [C.POINTER(RxPoolDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                     c_int64, c_void_p]),
+    "rx_pool_alloc_decode": (c_int, [C.POINTER(RxPoolDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                     c_void_p]),
+    "rx_pool_alloc_decode_rows": (c_int, [C.POINTER(RxPoolDesc), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_int, c_int64, c_void_p]),
+    "rx_pool_append": (c_int, [C.POINTER(RxPoolDesc), c_int, c_void_p, c_int64, c_void_p]),
+    "rx_pool_prepend_strided": (c_int, [C.POINTER(RxPoolDesc), c_int, c_void_p, c_int64, c_int, c_int64, c_int64,
+                                        c_int, c_void_p]),
+    "rx_pool_mark": (c_int, [C.POINTER(RxPoolDesc), c_void_p, c_int64, c_int, c_void_p]),
+    "rx_pool_flush_marks": (c_int, [C.POINTER(RxPoolDesc), c_int, c_void_p]),
+    "rx_pool_merge_sort": (c_int, [C.POINTER(RxPoolDesc), c_void_p]),
     "rx_move_kv_layout": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     # host-side radix tree
     "rx_radix_create": (c_void_p, [c_int, c_int]),
@@ -133,6 +157,8 @@ PROTOTYPES = {
     "rx_radix_total_size": (c_int64, [c_void_p]),
     "rx_radix_num_nodes": (c_int64, [c_void_p]),
     "rx_radix_node_info": (c_int, [c_void_p, c_int64, c_void_p]),
+    "rx_radix_cache_req": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, C.c_char_p, c_int, c_int, c_int64, c_int64,
+                                   c_void_p, c_int64, c_void_p]),
 }
 
 

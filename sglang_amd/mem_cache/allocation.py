@@ -77,16 +77,13 @@ def alloc_for_extend(reqs: Sequence[Req], prefix_lens: Sequence[int], seq_lens: 
 def alloc_for_decode(req_pool_indices: torch.Tensor, seq_lens: torch.Tensor, seq_lens_cpu: torch.Tensor,
                      req_to_token_pool, allocator, tree_cache=None, token_per_req: int = 1):
     """seq_lens are the lengths BEFORE the new token; returns out_cache_loc int64[bs] and writes
-    req_to_token[req, seq_len] = loc (allocation.py:578-580)."""
+    req_to_token[req, seq_len] = loc (allocation.py:578-580).  The last-slot gather, the allocation and the row
+    write are one kernel on the device-resident free list (rx_pool_alloc_decode_rows)."""
     assert token_per_req == 1
     bs = seq_lens.shape[0]
-    if allocator.page_size == 1:
-        out_cache_loc = alloc_token_slots(tree_cache, allocator, bs)
-    else:
-        last_loc = req_to_token_pool.req_to_token[req_pool_indices, seq_lens - 1].to(torch.int64)
-        evict_from_tree_cache(tree_cache, allocator, bs * allocator.page_size)
-        out_cache_loc = allocator.alloc_decode(seq_lens + 1, seq_lens_cpu + 1, last_loc)
-        if out_cache_loc is None:
-            raise RuntimeError(f"Decode out of memory: available {allocator.available_size()}")
-    req_to_token_pool.req_to_token[req_pool_indices, seq_lens] = out_cache_loc.to(torch.int32)
+    evict_from_tree_cache(tree_cache, allocator, bs * allocator.page_size)
+    out_cache_loc = allocator.alloc_decode_rows(req_to_token_pool.req_to_token, req_pool_indices, seq_lens,
+                                                seq_lens_cpu)
+    if out_cache_loc is None:
+        raise RuntimeError(f"Decode out of memory: available {allocator.available_size()}")
     return out_cache_loc

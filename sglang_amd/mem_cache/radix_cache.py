@@ -287,60 +287,52 @@ class RadixCache:
         return int(self._lib.rx_radix_num_nodes(self._h))
 
     # ------------------------------------------------------------------ request hooks
+    # Both hooks are ONE call into the native tree (rx_radix_cache_req): it inserts the request's page-aligned key
+    # with the slots of its req_to_token row, moves the locks and answers with the row ranges that go back to the
+    # allocator (and, for a request that keeps running, the row's new cached prefix).  Python only moves the data:
+    # row -> host, freed ranges -> allocator, new prefix -> row.
+    _FINISHED, _INSERT, _CHUNKED = 1, 2, 4
+
+    def _book(self, req: Req, token_ids, flags: int):
+        n = len(token_ids)
+        row = self.req_to_token_pool.req_to_token[req.req_pool_idx, :n].to(torch.int64)
+        toks = RadixKey(token_ids, req.extra_key).as_int64()
+        slots = row.cpu().numpy()
+        new_slots = np.empty(n if not flags & self._FINISHED else 0, dtype=np.int64)
+        out8 = (C.c_int64 * 8)()
+        st = self._lib.rx_radix_cache_req(
+            self._h, toks.ctypes.data, slots.ctypes.data, n,
+            None if req.extra_key is None else req.extra_key.encode(), int(req.priority or 0), flags,
+            int(req.cache_protected_len), -1 if req.last_node is None else req.last_node.id,
+            new_slots.ctypes.data, len(new_slots), out8)
+        if st != 0:
+            raise _L.RadixHipError("rx_radix_cache_req failed (row shorter than the key, or a stale last_node)")
+        return row, new_slots, list(out8)
+
     def cache_finished_req(self, req: Req, is_insert: bool = True, *, kv_len_to_handle: int):
-        """radix_cache.py:434-486."""
-        if self.disable_finished_insert:
-            is_insert = False
-        r2t = self.req_to_token_pool.req_to_token
+        """radix_cache.py:434-486: the finished request's pages join the tree (or are all released), the duplicates
+        and the unaligned tail go back to the allocator, its lock is dropped."""
+        alloc = self.token_to_kv_pool_allocator
         if self.disable:
-            kv_indices = r2t[req.req_pool_idx, req.cache_protected_len: kv_len_to_handle]
-            self.token_to_kv_pool_allocator.free_segment(kv_indices.to(torch.int64),
-                                                         start_pos=req.cache_protected_len)
+            lo = req.cache_protected_len
+            row = self.req_to_token_pool.req_to_token[req.req_pool_idx, lo:kv_len_to_handle]
+            alloc.free_segment(row.to(torch.int64), start_pos=lo)
             return
-        token_ids = (req.origin_input_ids + req.output_ids)[:kv_len_to_handle]
-        kv_indices = r2t[req.req_pool_idx, : len(token_ids)].to(torch.int64)
-        radix_key = RadixKey(token_ids, req.extra_key).page_aligned(self.page_size)
-        key_len = len(radix_key)
-        values = kv_indices[:key_len].clone()
-        if is_insert:
-            result = self.insert(InsertParams(key=radix_key, value=values, priority=req.priority or 0))
-            freed_end = result.prefix_len
-        else:
-            freed_end = key_len
-        # duplicates / uninserted range, then the unaligned tail
-        self.token_to_kv_pool_allocator.free_segments([
-            (kv_indices[req.cache_protected_len: freed_end], req.cache_protected_len),
-            (kv_indices[key_len:], key_len),
-        ])
-        if req.last_node is not None:
-            self.dec_lock_ref(req.last_node)
+        flags = self._FINISHED | (self._INSERT if is_insert and not self.disable_finished_insert else 0)
+        row, _, out = self._book(req, (req.origin_input_ids + req.output_ids)[:kv_len_to_handle], flags)
+        alloc.free_segments([(row[out[0]: out[1]], out[0]), (row[out[2]: out[3]], out[2])])
 
     def cache_unfinished_req(self, req: Req, chunked: bool = False):
-        """radix_cache.py:488-553."""
+        """radix_cache.py:488-553: a request that keeps running (chunked prefill, or between decode batches) parks
+        its whole pages in the tree, takes over the tree's copy of that prefix and re-locks the deeper node."""
         if self.disable:
             return
-        token_ids = req.get_fill_ids()
-        r2t = self.req_to_token_pool.req_to_token
-        kv_indices = r2t[req.req_pool_idx, : len(token_ids)].to(torch.int64)
-        radix_key = RadixKey(token_ids, req.extra_key).page_aligned(self.page_size)
-        values = kv_indices[: len(radix_key)].clone()
-        result = self.insert(InsertParams(key=radix_key, value=values, chunked=chunked,
-                                          priority=req.priority or 0))
-        new_prefix_len = result.prefix_len
-        self.token_to_kv_pool_allocator.free_segment(
-            kv_indices[req.cache_protected_len: new_prefix_len], start_pos=req.cache_protected_len)
-        match = self.match_prefix(MatchPrefixParams(key=radix_key))
-        new_indices, new_last_node = match.device_indices, match.last_device_node
-        assert len(new_indices) == len(radix_key), f"{len(new_indices)=}, {len(radix_key)=}"
-        # the prefix may now point at pages shared with an earlier request
-        r2t[req.req_pool_idx, req.cache_protected_len: len(new_indices)] = \
-            new_indices[req.cache_protected_len:].to(torch.int32)
-        req.cache_protected_len = len(new_indices)
-        if req.last_node is not None:
-            self.dec_lock_ref(req.last_node)
-        self.inc_lock_ref(new_last_node)
-        if len(new_indices) < len(kv_indices):
-            req.prefix_indices = torch.cat([new_indices, kv_indices[len(new_indices):]])
-        else:
-            req.prefix_indices = new_indices
-        req.last_node = new_last_node
+        row, new_slots, out = self._book(req, req.get_fill_ids(), self._CHUNKED if chunked else 0)
+        self.token_to_kv_pool_allocator.free_segment(row[out[0]: out[1]], start_pos=out[0])
+        m, lo = out[5], req.cache_protected_len
+        cached = torch.from_numpy(new_slots[:m]).to(self.device) if m else self._empty
+        if m > lo:  # the prefix may now be pages another request cached first
+            self.req_to_token_pool.req_to_token[req.req_pool_idx, lo:m] = cached[lo:].to(torch.int32)
+        req.cache_protected_len = m
+        req.last_node = TreeNode(self, out[6])
+        req.prefix_indices = cached if m == row.numel() else torch.cat([cached, row[m:]])

@@ -107,70 +107,24 @@ def test_host_split_schedule_matches_reference_golden(golden_dir):
         assert got.tolist() == r["out"]
 
 
-def test_token_allocator_host_logic_matches_golden(golden_dir):
-    """page_size == 1 allocator is pure list bookkeeping: replay the reference's op log on CPU."""
-    from sglang_amd.mem_cache.allocator import TokenToKVPoolAllocator
+def test_allocators_live_on_the_gpu_and_refuse_a_cpu_device():
+    """The free list is a device-resident ring (csrc/rx_pool.hip): there is no CPU variant to fall back to.  Its
+    replay against the reference's op logs is tests/test_gpu_allocator.py."""
+    from sglang_amd.mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
 
-    cases = json.load(open(os.path.join(golden_dir, "alloc_sequences.json")))
-    n = 0
-    for case in cases:
-        if case["page_size"] != 1:
-            continue
-        a = TokenToKVPoolAllocator(case["size"], torch.bfloat16, "cpu", None, case["need_sort"])
-        for ent in case["log"]:
-            if ent["op"] == "alloc":
-                out = a.alloc(ent["need"])
-                assert (out is None) == (ent["out"] is None)
-                if out is not None:
-                    assert out.tolist() == ent["out"]
-            elif ent["op"] == "free":
-                a.free(torch.tensor(ent["idx"], dtype=torch.int64))
-            elif ent["op"] == "merge_and_sort_free":
-                a.merge_and_sort_free()
-            elif ent["op"] == "free_group":
-                a.free_group_begin()
-                for idx in ent["idx"]:
-                    a.free(torch.tensor(idx, dtype=torch.int64))
-                a.free_group_end()
-            assert a.free_pages.tolist() == ent["free"][0]
-            assert a.release_pages.tolist() == ent["free"][1]
-            n += 1
-    assert n > 50
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        TokenToKVPoolAllocator(64, torch.bfloat16, "cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        PagedTokenToKVPoolAllocator(64, 16, torch.bfloat16, "cpu")
 
 
-def test_paged_allocator_free_paths_match_golden(golden_dir):
-    """free / free_segment / free_group / merge_and_sort need no kernel: replay them on CPU,
-    resetting the free list from the log after each (GPU-only) alloc_* entry."""
-    from sglang_amd.mem_cache.allocator import PagedTokenToKVPoolAllocator
+def test_num_new_pages_matches_reference_formula():
+    """get_num_new_pages (srt/utils/common.py:4298-4321) on CPU lens."""
+    from sglang_amd.mem_cache.allocator import get_num_new_pages
 
-    cases = json.load(open(os.path.join(golden_dir, "alloc_sequences.json")))
-    n = 0
-    for case in cases:
-        ps = case["page_size"]
-        if ps == 1:
-            continue
-        a = PagedTokenToKVPoolAllocator(case["size"], ps, torch.bfloat16, "cpu", None, case["need_sort"])
-        for ent in case["log"]:
-            op = ent["op"]
-            if op in ("alloc_extend", "alloc_decode"):
-                a.free_pages = torch.tensor(ent["free"][0], dtype=torch.int64)
-                a.release_pages = torch.tensor(ent["free"][1], dtype=torch.int64)
-                continue
-            if op == "free":
-                a.free(torch.tensor(ent["idx"], dtype=torch.int64))
-            elif op == "free_segment":
-                a.free_segment(torch.tensor(ent["idx"], dtype=torch.int64), start_pos=ent["start_pos"])
-            elif op == "merge_and_sort_free":
-                a.merge_and_sort_free()
-            elif op == "free_group":
-                a.free_group_begin()
-                for idx in ent["idx"]:
-                    a.free(torch.tensor(idx, dtype=torch.int64))
-                a.free_group_end()
-            assert a.free_pages.tolist() == ent["free"][0], (ps, op)
-            assert a.release_pages.tolist() == ent["free"][1], (ps, op)
-            n += 1
-    assert n > 40
+    seq, pre = torch.tensor([1, 16, 17, 33, 5]), torch.tensor([0, 16, 16, 1, 5])
+    assert get_num_new_pages(seq, 16, pre) == 1 + 0 + 1 + 2 + 0
+    assert get_num_new_pages(torch.tensor([1, 16, 17, 33, 49]), 16, decode=True) == 4
 
 
 def test_forward_batch_constructors():
