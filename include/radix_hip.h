@@ -497,6 +497,17 @@ int rx_ipc_close_handle(void* dev_ptr);
 int rx_ar_init(rx_ar_ctx** ctx_out, int rank, int world, void* const* peer_regions, int64_t max_bytes,
                int32_t* dev_err);
 int rx_allreduce(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int dtype, void* stream);
+
+/* Fused all-reduce + residual add + RMSNorm (GroupCoordinator.fused_allreduce_rmsnorm, srt/distributed/
+ * parallel_state.py:748-878; the split path it replaces: benchmark/kernels/all_reduce/benchmark_fused_ar_rms_amd.py
+ * :171-182):
+ *   residual_out = all_reduce_sum(in) + residual_in          (both rounded to the 16-bit dtype, as the split path)
+ *   out          = residual_out * rsqrt(mean(residual_out^2) + eps) * weight     (fp32 math, one rounding)
+ * in / residual_in / out / residual_out: [rows, hidden] contiguous, weight [hidden], all of `dtype`; hidden a multiple
+ * of 8 and <= 16384; rows * hidden * 2 <= the context's max_bytes.  residual_out may alias residual_in (in-place
+ * residual stream); out must be a buffer of its own.  Same context / stream rules as rx_allreduce. */
+int rx_allreduce_rmsnorm(rx_ar_ctx* ctx, const void* in, const void* residual_in, const void* weight, void* out,
+                         void* residual_out, int64_t rows, int64_t hidden, float eps, int dtype, void* stream);
 int rx_ar_destroy(rx_ar_ctx* ctx);
 
 #ifdef __cplusplus

@@ -21,6 +21,20 @@
 // alternate by call parity, so a rank may start call g+1 while a slow peer still reads call g's data
 // (a buffer is reused at g+2, after the peer's "ready" of g+1 proved it finished g).  Spins are
 // bounded: on timeout the kernel raises RX_DEVERR_AR_TIMEOUT in the context's error word and returns.
+//
+// HIP-graph safe: the call number lives in DEVICE memory (one counter per block index in the rank's own
+// region, read and bumped by that block), not in the launch arguments -- a captured launch replays with the
+// same arguments and still sees call numbers 1, 2, 3, ... (the reference's custom all-reduce keeps its signal
+// counters on the device for the same reason, parallel_state.py:560-620).  One context serves ONE stream of
+// ordered launches; a caller that reduces on two streams (sglang_amd/parallel.py: main + side stream) uses one
+// context per stream.
+//
+// allreduce_rmsnorm_kernel (GroupCoordinator.fused_allreduce_rmsnorm, parallel_state.py:748-878):
+//   residual_out = all_reduce(x) + residual ;  out = rmsnorm(residual_out) * weight
+// in the same two-shot schedule, chunked by ROWS so that a rank owns whole rows: phase 1 reduces its rows,
+// adds the residual and normalises them; phase 2 gathers the other ranks' residual_out rows and normalises
+// them locally while they pass through registers -- the normalised rows never cross xGMI (a separate
+// RMSNorm launch would re-read 2 x T x H bytes from HBM; shipping `out` as well would double the gather).
 #include "rx_common.h"
 
 #include <cstring>
@@ -37,13 +51,13 @@ struct ArFlags {
   // ready[b][src]: src's block b has staged its input of call `value`; done[b][src]: ... reduced its chunk
   uint32_t ready[kArBlocks][kArMaxWorld];
   uint32_t done[kArBlocks][kArMaxWorld];
+  uint32_t calls[kArBlocks];  // this rank's own call counter, one per block index (written by that block only)
 };
 
 struct ArCtx {
   int rank, world;
   int64_t max_bytes;       // per-call message limit (bytes)
   char* peers[kArMaxWorld];  // every rank's region mapped into this process (own = local pointer)
-  uint32_t call;             // host-side call counter
   int32_t* dev_err;          // device error word (RX_DEVERR_*)
 };
 
@@ -59,8 +73,13 @@ struct ArArgs {
   const uint16_t* in;
   uint16_t* out;
   int64_t n;  // elements
-  uint32_t call;
   int32_t* dev_err;
+  // fused residual-add + RMSNorm form: x = in [rows, hidden]; out = normalised, out_res = residual stream
+  const uint16_t* residual;
+  const uint16_t* weight;
+  uint16_t* out_res;
+  int32_t rows, hidden;
+  float eps;
 };
 
 __device__ __forceinline__ void ar_signal(uint32_t* p, uint32_t v) {
@@ -75,16 +94,30 @@ __device__ __forceinline__ bool ar_wait(const uint32_t* p, uint32_t v) {
   return false;
 }
 
+// call number of this launch for block b: previous + 1, kept in the rank's own region
+__device__ __forceinline__ uint32_t ar_next_call(const ArArgs& a, int b, uint32_t* sh) {
+  if (threadIdx.x == 0) {
+    uint32_t* c = &reinterpret_cast<ArFlags*>(a.peers[a.rank])->calls[b];
+    const uint32_t g = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __hip_atomic_store(c, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *sh = g;
+  }
+  __syncthreads();
+  return *sh;
+}
+
 // 8 elements (16 B) per thread step; chunk c = elements [c * per, min((c+1) * per, n)), per % 8 == 0
 template <typename T>
 __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const ArArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x, W = a.world, r = a.rank;
-  const int64_t stage_off = ar_align(sizeof(ArFlags)) + (a.call & 1) * ar_align(a.max_bytes);
-  const int64_t result_off = ar_align(sizeof(ArFlags)) + (2 + (a.call & 1)) * ar_align(a.max_bytes);
-  const int64_t nv = a.n / 8;                     // 16-byte vectors
-  const int64_t per = (nv + W - 1) / W;           // vectors per chunk
+  __shared__ uint32_t call_s;
   __shared__ int timeout_s;
   if (tid == 0) timeout_s = 0;
+  const uint32_t call = ar_next_call(a, b, &call_s);
+  const int64_t stage_off = ar_align(sizeof(ArFlags)) + (call & 1) * ar_align(a.max_bytes);
+  const int64_t result_off = ar_align(sizeof(ArFlags)) + (2 + (call & 1)) * ar_align(a.max_bytes);
+  const int64_t nv = a.n / 8;                     // 16-byte vectors
+  const int64_t per = (nv + W - 1) / W;           // vectors per chunk
 
   // ---- phase 0: stage my input (block b takes every kArBlocks-th group of 256 vectors of each chunk)
   u32x4* my_stage = reinterpret_cast<u32x4*>(a.peers[r] + stage_off);
@@ -96,9 +129,9 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
   __threadfence_system();
   __syncthreads();
   if (tid < W && tid != r)
-    ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->ready[b][r], a.call);
+    ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->ready[b][r], call);
   if (tid < W && tid != r) {
-    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->ready[b][tid], a.call)) timeout_s = 1;
+    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->ready[b][tid], call)) timeout_s = 1;
   }
   __syncthreads();
   if (timeout_s) {
@@ -132,9 +165,9 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
   __threadfence_system();
   __syncthreads();
   if (tid < W && tid != r)
-    ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->done[b][r], a.call);
+    ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->done[b][r], call);
   if (tid < W && tid != r) {
-    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->done[b][tid], a.call)) timeout_s = 1;
+    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->done[b][tid], call)) timeout_s = 1;
   }
   __syncthreads();
   if (timeout_s) {
@@ -151,6 +184,171 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
       const u32x4* res = reinterpret_cast<const u32x4*>(a.peers[c] + result_off);
       for (int64_t i = lo + b * kArThreads + tid; i < hi; i += kArBlocks * kArThreads)
         out_v[i] = __builtin_nontemporal_load(res + i);
+    }
+  }
+}
+
+// ---- fused all-reduce + residual add + RMSNorm ----------------------------------------------------------------
+// Rows [c * per, (c + 1) * per) are rank c's chunk; row j of a chunk (local index l) belongs to block l % kArBlocks
+// in every phase on every rank, so block b still only depends on block b of its peers.  A row is H / 8 16-byte
+// vectors, thread t takes vectors t, t + 256, ... (at most kArVpt of them: H <= 16384).
+constexpr int kArVpt = 8;
+
+__device__ __forceinline__ float ar_block_sum(float x, float* sh) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+  __syncthreads();  // sh may still be read by the previous row
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// one residual_out row held in registers as rounded 16-bit values `ro`: out[row] = ro * rstd * weight
+template <typename T>
+__device__ __forceinline__ void ar_norm_row(const ArArgs& a, const u32x4 (&ro)[kArVpt], int nvec, int64_t row,
+                                            float* sh) {
+  const int tid = threadIdx.x;
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < kArVpt; ++k) {
+    const int v = tid + k * kArThreads;
+    if (v < nvec) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = T::to_f32(static_cast<uint16_t>(ro[k][j] & 0xffffu));
+        const float hi = T::to_f32(static_cast<uint16_t>(ro[k][j] >> 16));
+        ss += lo * lo + hi * hi;
+      }
+    }
+  }
+  const float rstd = rsqrtf(ar_block_sum(ss, sh) / static_cast<float>(a.hidden) + a.eps);
+  u32x4* out_v = reinterpret_cast<u32x4*>(a.out) + row * nvec;
+  const u32x4* w_v = reinterpret_cast<const u32x4*>(a.weight);
+#pragma unroll
+  for (int k = 0; k < kArVpt; ++k) {
+    const int v = tid + k * kArThreads;
+    if (v < nvec) {
+      const u32x4 w = w_v[v];
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lo = T::to_f32(static_cast<uint16_t>(ro[k][j] & 0xffffu)) * rstd *
+                         T::to_f32(static_cast<uint16_t>(w[j] & 0xffffu));
+        const float hi = T::to_f32(static_cast<uint16_t>(ro[k][j] >> 16)) * rstd *
+                         T::to_f32(static_cast<uint16_t>(w[j] >> 16));
+        o[j] = pack2<T>(lo, hi);
+      }
+      out_v[v] = o;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x, W = a.world, r = a.rank;
+  __shared__ uint32_t call_s;
+  __shared__ int timeout_s;
+  __shared__ float red_s[4];
+  if (tid == 0) timeout_s = 0;
+  const uint32_t call = ar_next_call(a, b, &call_s);
+  const int64_t stage_off = ar_align(sizeof(ArFlags)) + (call & 1) * ar_align(a.max_bytes);
+  const int64_t result_off = ar_align(sizeof(ArFlags)) + (2 + (call & 1)) * ar_align(a.max_bytes);
+  const int nvec = a.hidden / 8;
+  const int64_t per = (a.rows + W - 1) / W;  // rows per chunk
+
+  // ---- phase 0: stage my rows
+  {
+    u32x4* my_stage = reinterpret_cast<u32x4*>(a.peers[r] + stage_off);
+    const u32x4* in_v = reinterpret_cast<const u32x4*>(a.in);
+    for (int c = 0; c < W; ++c) {
+      const int64_t lo = c * per, hi = min(lo + per, static_cast<int64_t>(a.rows));
+      for (int64_t row = lo + b; row < hi; row += kArBlocks)
+        for (int v = tid; v < nvec; v += kArThreads) my_stage[row * nvec + v] = in_v[row * nvec + v];
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < W && tid != r) ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->ready[b][r], call);
+  if (tid < W && tid != r) {
+    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->ready[b][tid], call)) timeout_s = 1;
+  }
+  __syncthreads();
+  if (timeout_s) {
+    if (tid == 0) atomicOr(a.dev_err, RX_DEVERR_AR_TIMEOUT);
+    return;
+  }
+
+  // ---- phase 1: my rows = sum over ranks (fp32, fixed order) -> 16-bit, + residual -> 16-bit, normalise
+  {
+    const int64_t lo = r * per, hi = min(lo + per, static_cast<int64_t>(a.rows));
+    u32x4* my_res = reinterpret_cast<u32x4*>(a.peers[r] + result_off);
+    u32x4* res_out = reinterpret_cast<u32x4*>(a.out_res);
+    const u32x4* resid = reinterpret_cast<const u32x4*>(a.residual);
+    for (int64_t row = lo + b; row < hi; row += kArBlocks) {
+      u32x4 ro[kArVpt];
+#pragma unroll
+      for (int k = 0; k < kArVpt; ++k) {
+        const int v = tid + k * kArThreads;
+        if (v < nvec) {
+          float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          for (int p = 0; p < W; ++p) {
+            const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.peers[p] + stage_off) +
+                                                       row * nvec + v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[2 * j] += T::to_f32(static_cast<uint16_t>(x[j] & 0xffffu));
+              acc[2 * j + 1] += T::to_f32(static_cast<uint16_t>(x[j] >> 16));
+            }
+          }
+          const u32x4 rs = resid[row * nvec + v];
+          u32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // the split path's two roundings: all_reduce output in 16 bits, then the residual add in 16 bits
+            const uint32_t s2 = pack2<T>(acc[2 * j], acc[2 * j + 1]);
+            o[j] = pack2<T>(
+                T::to_f32(static_cast<uint16_t>(s2 & 0xffffu)) + T::to_f32(static_cast<uint16_t>(rs[j] & 0xffffu)),
+                T::to_f32(static_cast<uint16_t>(s2 >> 16)) + T::to_f32(static_cast<uint16_t>(rs[j] >> 16)));
+          }
+          ro[k] = o;
+          my_res[row * nvec + v] = o;
+          res_out[row * nvec + v] = o;
+        }
+      }
+      ar_norm_row<T>(a, ro, nvec, row, red_s);
+    }
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid < W && tid != r) ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->done[b][r], call);
+  if (tid < W && tid != r) {
+    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->done[b][tid], call)) timeout_s = 1;
+  }
+  __syncthreads();
+  if (timeout_s) {
+    if (tid == 0) atomicOr(a.dev_err, RX_DEVERR_AR_TIMEOUT);
+    return;
+  }
+
+  // ---- phase 2: the other ranks' residual_out rows: copy and normalise on the way through
+  {
+    u32x4* res_out = reinterpret_cast<u32x4*>(a.out_res);
+    for (int c = 0; c < W; ++c) {
+      if (c == r) continue;
+      const int64_t lo = c * per, hi = min(lo + per, static_cast<int64_t>(a.rows));
+      const u32x4* src = reinterpret_cast<const u32x4*>(a.peers[c] + result_off);
+      for (int64_t row = lo + b; row < hi; row += kArBlocks) {
+        u32x4 ro[kArVpt];
+#pragma unroll
+        for (int k = 0; k < kArVpt; ++k) {
+          const int v = tid + k * kArThreads;
+          if (v < nvec) {
+            ro[k] = __builtin_nontemporal_load(src + row * nvec + v);
+            res_out[row * nvec + v] = ro[k];
+          }
+        }
+        ar_norm_row<T>(a, ro, nvec, row, red_s);
+      }
     }
   }
 }
@@ -214,7 +412,6 @@ int rx_ar_init(rx_ar_ctx** ctx_out, int rank, int world, void* const* peer_regio
   c->rank = rank;
   c->world = world;
   c->max_bytes = max_bytes;
-  c->call = 0;
   c->dev_err = dev_err;
   for (int i = 0; i < world; ++i) {
     if (!peer_regions[i]) {
@@ -227,6 +424,16 @@ int rx_ar_init(rx_ar_ctx** ctx_out, int rank, int world, void* const* peer_regio
   return RX_OK;
 }
 
+static ArArgs ar_args(const ArCtx* c) {
+  ArArgs a{};
+  for (int i = 0; i < c->world; ++i) a.peers[i] = c->peers[i];
+  a.rank = c->rank;
+  a.world = c->world;
+  a.max_bytes = c->max_bytes;
+  a.dev_err = c->dev_err;
+  return a;
+}
+
 int rx_allreduce(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int dtype, void* stream) {
   RX_REQUIRE(ctx && in && out, "rx_allreduce: null pointer");
   auto* c = reinterpret_cast<ArCtx*>(ctx);
@@ -236,22 +443,48 @@ int rx_allreduce(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int d
              (long long)c->max_bytes);
   RX_REQUIRE((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "rx_allreduce: in/out must be 16-byte aligned");
   if (count == 0) return RX_OK;
-  ArArgs a;
-  for (int i = 0; i < c->world; ++i) a.peers[i] = c->peers[i];
-  a.rank = c->rank;
-  a.world = c->world;
-  a.max_bytes = c->max_bytes;
+  ArArgs a = ar_args(c);
   a.in = static_cast<const uint16_t*>(in);
   a.out = static_cast<uint16_t*>(out);
   a.n = count;
-  a.call = ++c->call;  // every rank issues the same sequence of calls, so the counters agree
-  a.dev_err = c->dev_err;
   auto s = static_cast<hipStream_t>(stream);
   if (dtype == RX_BF16)
     hipLaunchKernelGGL(allreduce_two_shot_kernel<BF16>, dim3(kArBlocks), dim3(kArThreads), 0, s, a);
   else
     hipLaunchKernelGGL(allreduce_two_shot_kernel<F16>, dim3(kArBlocks), dim3(kArThreads), 0, s, a);
   return check_launch("rx_allreduce");
+}
+
+int rx_allreduce_rmsnorm(rx_ar_ctx* ctx, const void* in, const void* residual_in, const void* weight, void* out,
+                         void* residual_out, int64_t rows, int64_t hidden, float eps, int dtype, void* stream) {
+  RX_REQUIRE(ctx && in && residual_in && weight && out && residual_out, "rx_allreduce_rmsnorm: null pointer");
+  auto* c = reinterpret_cast<ArCtx*>(ctx);
+  RX_REQUIRE(dtype == RX_BF16 || dtype == RX_F16, "rx_allreduce_rmsnorm: dtype %d", dtype);
+  RX_REQUIRE(rows >= 0 && hidden > 0 && hidden % 8 == 0 && hidden <= 8 * kArThreads * kArVpt,
+             "rx_allreduce_rmsnorm: hidden %lld must be a multiple of 8, at most %d", (long long)hidden,
+             8 * kArThreads * kArVpt);
+  RX_REQUIRE(rows * hidden * 2 <= c->max_bytes, "rx_allreduce_rmsnorm: %lld bytes exceed the context's %lld",
+             (long long)(rows * hidden * 2), (long long)c->max_bytes);
+  RX_REQUIRE((((uintptr_t)in | (uintptr_t)residual_in | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)residual_out) & 15) == 0,
+             "rx_allreduce_rmsnorm: pointers must be 16-byte aligned");
+  RX_REQUIRE(out != in && out != residual_in && out != residual_out, "rx_allreduce_rmsnorm: out must not alias an input");
+  if (rows == 0) return RX_OK;
+  ArArgs a = ar_args(c);
+  a.in = static_cast<const uint16_t*>(in);
+  a.residual = static_cast<const uint16_t*>(residual_in);
+  a.weight = static_cast<const uint16_t*>(weight);
+  a.out = static_cast<uint16_t*>(out);
+  a.out_res = static_cast<uint16_t*>(residual_out);
+  a.rows = static_cast<int32_t>(rows);
+  a.hidden = static_cast<int32_t>(hidden);
+  a.eps = eps;
+  a.n = rows * hidden;
+  auto s = static_cast<hipStream_t>(stream);
+  if (dtype == RX_BF16)
+    hipLaunchKernelGGL(allreduce_rmsnorm_kernel<BF16>, dim3(kArBlocks), dim3(kArThreads), 0, s, a);
+  else
+    hipLaunchKernelGGL(allreduce_rmsnorm_kernel<F16>, dim3(kArBlocks), dim3(kArThreads), 0, s, a);
+  return check_launch("rx_allreduce_rmsnorm");
 }
 
 int rx_ar_destroy(rx_ar_ctx* ctx) {

@@ -366,7 +366,8 @@ int rx_pool_load(const rx_pool_desc* d, int which, const int64_t* ids, int64_t n
 
 int rx_pool_snapshot(const rx_pool_desc* d, int which, int64_t* out, int64_t out_cap, void* stream) {
   RX_POOL_CHECK(d);
-  RX_REQUIRE((which == 0 || (which == 1 && d->release_ring)) && out && out_cap >= 0, "rx_pool_snapshot: bad arguments");
+  RX_REQUIRE((which == 0 || (which == 1 && d->release_ring)) && out_cap >= 0 && (out || out_cap == 0),
+             "rx_pool_snapshot: bad arguments");
   if (out_cap == 0) return RX_OK;
   hipLaunchKernelGGL(pool_snapshot_kernel, dim3(blocks_for(out_cap)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      pool_args(d), which, out, out_cap);

@@ -93,6 +93,8 @@ PROTOTYPES = {
     "rx_ipc_close_handle": (c_int, [c_void_p]),
     "rx_ar_init": (c_int, [C.POINTER(c_void_p), c_int, c_int, C.POINTER(c_void_p), c_int64, c_void_p]),
     "rx_allreduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rx_allreduce_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                     c_float, c_int, c_void_p]),
     "rx_ar_destroy": (c_int, [c_void_p]),
     "rx_rope_store_kv": (c_int, [c_void_p] * 3 + [c_int64] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_int64, c_int,
                                  C.POINTER(RxKvLayout), c_void_p, c_int, c_int64, c_int64, c_float, c_float, c_int,

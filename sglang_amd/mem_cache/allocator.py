@@ -71,7 +71,8 @@ class DeviceFreeList:
 
     def snapshot(self, which: int, count: int) -> torch.Tensor:
         out = torch.empty(count, dtype=torch.int64, device=self.device)
-        self._call("rx_pool_snapshot", which, C.c_void_p(out.data_ptr()), count)
+        if count:
+            self._call("rx_pool_snapshot", which, C.c_void_p(out.data_ptr()), count)
         return out
 
     def counts(self) -> Tuple[int, int, int]:

@@ -53,12 +53,20 @@ def shard_heads(total_q_heads: int, total_kv_heads: int, tp_size: int, tp_rank: 
 
 class CustomAllReduce:
     """Peer-to-peer two-shot all-reduce over IPC-mapped buffers (csrc/rx_allreduce.hip; the role of
-    the reference's custom all-reduce behind GroupCoordinator.all_reduce, parallel_state.py:622-732).
+    the reference's custom all-reduce behind GroupCoordinator.all_reduce, parallel_state.py:622-732) and its
+    fused all-reduce + residual add + RMSNorm form (fused_allreduce_rmsnorm, :748-878).
     One instance per rank; the 64-byte IPC handles travel through the torch.distributed group.
-    Opt-in (``RX_CUSTOM_AR=1``): RCCL stays the default because this round could only exercise the
-    kernel with several processes on ONE GPU (the gpurun box), not across xGMI."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup], device: torch.device, max_bytes: int = 8 << 20):
+    A context's kernels count their calls in device memory, so captured launches replay correctly under HIP
+    graphs, but the calls of ONE context must be ordered (one stream, or one chain of graph dependencies).  This
+    object therefore owns ``lanes`` contexts with a region each: lane 0 for the caller's main stream, lane 1 for
+    the side (communication) stream of TPGroup.all_reduce_async.
+
+    Opt-in (``RX_CUSTOM_AR=1``): RCCL stays the default because the kernels have only been exercised with several
+    processes on ONE GPU (the gpurun box), not across xGMI."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup], device: torch.device, max_bytes: int = 8 << 20,
+                 lanes: int = 2):
         import ctypes as C
 
         from . import lib as _L
@@ -69,42 +77,68 @@ class CustomAllReduce:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.max_bytes = (int(max_bytes) + 255) // 256 * 256
         region_bytes = lib.rx_ar_region_bytes(self.max_bytes)
+        self._own, self._opened, self._ctxs = [], [], []
         with torch.cuda.device(device):
-            own = C.c_void_p()
-            _L.check(lib.rx_ar_alloc_region(region_bytes, C.byref(own)), "rx_ar_alloc_region")
-            self._own = own
-            handle = C.create_string_buffer(64)
-            _L.check(lib.rx_ipc_get_handle(own, handle), "rx_ipc_get_handle")
-            handles = [None] * self.world
-            dist.all_gather_object(handles, bytes(handle.raw), group=group)
-            ptrs = (C.c_void_p * self.world)()
-            self._opened = []
-            for r, h in enumerate(handles):
-                if r == self.rank:
-                    ptrs[r] = own.value
-                else:
-                    p = C.c_void_p()
-                    _L.check(lib.rx_ipc_open_handle(C.create_string_buffer(h, 64), C.byref(p)), "rx_ipc_open_handle")
-                    ptrs[r] = p.value
-                    self._opened.append(p)
             self.err_flag = torch.zeros(1, dtype=torch.int32, device=device)
-            ctx = C.c_void_p()
-            _L.check(lib.rx_ar_init(C.byref(ctx), self.rank, self.world, ptrs, self.max_bytes,
-                                    C.c_void_p(self.err_flag.data_ptr())), "rx_ar_init")
-            self._ctx = ctx
+            for _ in range(lanes):
+                own = C.c_void_p()
+                _L.check(lib.rx_ar_alloc_region(region_bytes, C.byref(own)), "rx_ar_alloc_region")
+                self._own.append(own)
+                handle = C.create_string_buffer(64)
+                _L.check(lib.rx_ipc_get_handle(own, handle), "rx_ipc_get_handle")
+                handles = [None] * self.world
+                dist.all_gather_object(handles, bytes(handle.raw), group=group)
+                ptrs = (C.c_void_p * self.world)()
+                for r, h in enumerate(handles):
+                    if r == self.rank:
+                        ptrs[r] = own.value
+                    else:
+                        p = C.c_void_p()
+                        _L.check(lib.rx_ipc_open_handle(C.create_string_buffer(h, 64), C.byref(p)), "rx_ipc_open_handle")
+                        ptrs[r] = p.value
+                        self._opened.append(p)
+                ctx = C.c_void_p()
+                _L.check(lib.rx_ar_init(C.byref(ctx), self.rank, self.world, ptrs, self.max_bytes,
+                                        C.c_void_p(self.err_flag.data_ptr())), "rx_ar_init")
+                self._ctxs.append(ctx)
+        self._ctx = self._ctxs[0]
         dist.barrier(group=group)  # every region is mapped everywhere before the first call
 
     def supports(self, x: torch.Tensor) -> bool:
         return (x.is_cuda and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float16)
                 and x.numel() % 8 == 0 and x.numel() * 2 <= self.max_bytes and x.data_ptr() % 16 == 0)
 
-    def all_reduce(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def _dt(self, x):
+        return self._L.RX_BF16 if x.dtype == torch.bfloat16 else self._L.RX_F16
+
+    def all_reduce(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, lane: int = 0) -> torch.Tensor:
         out = x if out is None else out
-        st = self._lib.rx_allreduce(self._ctx, self._C.c_void_p(x.data_ptr()), self._C.c_void_p(out.data_ptr()),
-                                    x.numel(), self._L.RX_BF16 if x.dtype == torch.bfloat16 else self._L.RX_F16,
+        st = self._lib.rx_allreduce(self._ctxs[lane], self._C.c_void_p(x.data_ptr()), self._C.c_void_p(out.data_ptr()),
+                                    x.numel(), self._dt(x),
                                     self._C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
         self._L.check(st, "rx_allreduce")
         return out
+
+    def supports_fused_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor) -> bool:
+        return (x.dim() == 2 and self.supports(x) and residual.shape == x.shape and residual.dtype == x.dtype
+                and residual.is_contiguous() and weight.dtype == x.dtype and weight.is_contiguous()
+                and weight.numel() == x.shape[1] and x.shape[1] % 8 == 0 and x.shape[1] <= 16384
+                and residual.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0)
+
+    def fused_allreduce_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                                lane: int = 0):
+        """(out, residual_out): residual_out = all_reduce(x) + residual, out = rmsnorm(residual_out) * weight
+        (parallel_state.py:748-878), one kernel.  residual_out is written IN PLACE over ``residual``."""
+        if not self.supports_fused_rmsnorm(x, residual, weight):
+            raise ValueError("fused_allreduce_rmsnorm: unsupported shapes / dtypes (see supports_fused_rmsnorm)")
+        out = torch.empty_like(x)
+        cp = self._C.c_void_p
+        st = self._lib.rx_allreduce_rmsnorm(self._ctxs[lane], cp(x.data_ptr()), cp(residual.data_ptr()),
+                                            cp(weight.data_ptr()), cp(out.data_ptr()), cp(residual.data_ptr()),
+                                            x.shape[0], x.shape[1], float(eps), self._dt(x),
+                                            cp(torch.cuda.current_stream(x.device).cuda_stream))
+        self._L.check(st, "rx_allreduce_rmsnorm")
+        return out, residual
 
     def check_errors(self) -> int:
         v = int(self.err_flag.item())
@@ -113,14 +147,16 @@ class CustomAllReduce:
         return v
 
     def close(self):
-        if getattr(self, "_ctx", None) is not None:
+        if getattr(self, "_ctxs", None):
             torch.cuda.synchronize(self.device)
             dist.barrier(group=self.group)  # nobody still reads a region that is about to go away
-            self._lib.rx_ar_destroy(self._ctx)
+            for ctx in self._ctxs:
+                self._lib.rx_ar_destroy(ctx)
             for p in self._opened:
                 self._lib.rx_ipc_close_handle(p)
-            self._lib.rx_ar_free_region(self._own)
-            self._ctx = None
+            for own in self._own:
+                self._lib.rx_ar_free_region(own)
+            self._ctxs, self._ctx = [], None
 
 
 class TPGroup:
@@ -137,11 +173,26 @@ class TPGroup:
         self._comm_stream = None
         self.custom_ar = custom_ar if self.world_size > 1 else None
 
-    def _reduce(self, x: torch.Tensor) -> None:
-        if self.custom_ar is not None and self.custom_ar.supports(x):
-            self.custom_ar.all_reduce(x)
+    def _reduce(self, x: torch.Tensor, lane: int = 0) -> None:
+        # ONE implementation per group: mixing the peer-to-peer kernel (fp32 sums in rank order) with RCCL (its own
+        # order) inside a run would make results depend on tensor shapes.  A tensor the custom kernel cannot take
+        # is an error when it is selected, not a silent switch.
+        if self.custom_ar is not None:
+            if not self.custom_ar.supports(x):
+                raise ValueError("custom all-reduce selected but the tensor is not contiguous 16-bit, 16-byte "
+                                 f"aligned, a multiple of 8 elements and <= {self.custom_ar.max_bytes} bytes")
+            self.custom_ar.all_reduce(x, lane=lane)
         else:
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+
+    def fused_allreduce_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float):
+        """tensor_model_parallel_fused_allreduce_rmsnorm (communication_op.py -> parallel_state.py:748-878):
+        (out, residual_out) or None when no fused path applies (the caller then runs all_reduce + add + norm)."""
+        if self.world_size == 1 or self.custom_ar is None:
+            return None
+        if not self.custom_ar.supports_fused_rmsnorm(x, residual, weight):
+            return None
+        return self.custom_ar.fused_allreduce_rmsnorm(x, residual, weight, eps)
 
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         """In-place sum over the group; bypassed for world size 1 (parallel_state.py:640-642)."""
@@ -174,7 +225,7 @@ class TPGroup:
         ready.record(main)
         self._comm_stream.wait_event(ready)
         with torch.cuda.stream(self._comm_stream):
-            self._reduce(x)
+            self._reduce(x, lane=1)
             if not torch.cuda.is_current_stream_capturing():  # a captured graph owns its memory pool
                 x.record_stream(self._comm_stream)
             done.record(self._comm_stream)

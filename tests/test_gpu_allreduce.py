@@ -1,5 +1,5 @@
-"""C1: the peer-to-peer two-shot all-reduce (csrc/rx_allreduce.hip) across PROCESSES through IPC-mapped
-regions.  The gpurun box has one GPU, so the ranks share cuda:0 -- that exercises the handle exchange,
+"""C1: the peer-to-peer two-shot all-reduce (csrc/rx_allreduce.hip) and its fused all-reduce + residual + RMSNorm
+form across PROCESSES through IPC-mapped regions, eagerly and under HIP-graph replay.  The gpurun box has one GPU, so the ranks share cuda:0 -- that exercises the handle exchange,
 the flag protocol, buffer alternation and the arithmetic, not xGMI coherence (DESIGN.md says so).
 gloo carries the 64-byte handles."""
 import os
@@ -23,23 +23,119 @@ dev = torch.device("cuda:0")
 ar = CustomAllReduce(None, dev, max_bytes=4 << 20)
 tp = TPGroup(None, custom_ar=ar)
 ok = True
+
+def parts_for(seed, n, dt):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(n, generator=g).to(dt) for _ in range(world)]   # same on every rank
+
 for it, (n, dt) in enumerate([(8, torch.bfloat16), (256 * 4096, torch.bfloat16), (1000 * 8, torch.float16),
                               (2 << 20, torch.bfloat16), (4096, torch.float16)] * 3):
-    g = torch.Generator().manual_seed(100 * it)
-    parts = [torch.randn(n, generator=g).to(dt) for _ in range(world)]   # same on every rank
+    parts = parts_for(100 * it, n, dt)
     x = parts[rank].to(dev)
     want = sum(p.float() for p in parts).to(dt)                          # fp32 sum in rank order, one rounding
     if it % 2 == 0:
-        tp.all_reduce(x)                      # in place, current stream
+        tp.all_reduce(x)                      # in place, current stream (lane 0)
         got = x
     else:
-        got = tp.all_reduce_async(x).wait()   # side stream + events
+        got = tp.all_reduce_async(x).wait()   # side stream + events (lane 1)
     torch.cuda.synchronize()
     if not torch.equal(got.cpu(), want):
         ok = False
         print(f"rank {rank} it {it} n {n}: max diff", (got.cpu().float() - want.float()).abs().max().item(), flush=True)
+
+# ---- HIP-graph capture: THREE consecutive calls in one graph, replayed three times with fresh inputs.  The call
+# numbers live on the device, so every replay is calls g+1, g+2, g+3 -- with a host-side counter the replays
+# would resend the capture-time numbers and read stale (or not yet written) peer buffers.
+n = 64 * 4096
+bufs = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for b_ in bufs:
+        ar.all_reduce(b_)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+dist.barrier()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    for b_ in bufs:
+        ar.all_reduce(b_)
+for rep in range(3):
+    wants = []
+    for j, b_ in enumerate(bufs):
+        parts = parts_for(1000 + 10 * rep + j, n, torch.bfloat16)
+        b_.copy_(parts[rank])
+        wants.append(sum(p.float() for p in parts).to(torch.bfloat16))
+    graph.replay()
+    torch.cuda.synchronize()
+    for j, (b_, w_) in enumerate(zip(bufs, wants)):
+        if not torch.equal(b_.cpu(), w_):
+            ok = False
+            print(f"rank {rank} graph replay {rep} call {j}: max diff", (b_.cpu().float() - w_.float()).abs().max().item(), flush=True)
+# an eager call after the replays continues the same counters
+parts = parts_for(7, n, torch.bfloat16)
+x = parts[rank].to(dev)
+ar.all_reduce(x)
+torch.cuda.synchronize()
+ok = ok and torch.equal(x.cpu(), sum(p.float() for p in parts).to(torch.bfloat16))
+
+# ---- fused all-reduce + residual add + RMSNorm vs the split path in fp32 torch (parallel_state.py:748-878)
+for (T, H, dt, tol) in [(256, 4096, torch.bfloat16, 2e-2), (7, 8192, torch.float16, 2e-3), (33, 1024, torch.bfloat16, 2e-2),
+                        (1, 4096, torch.bfloat16, 2e-2)]:
+    parts = [p.view(T, H) for p in parts_for(T + H, T * H, dt)]
+    g = torch.Generator().manual_seed(5)
+    residual = torch.randn(T, H, generator=g).to(dt)
+    weight = (1 + 0.1 * torch.randn(H, generator=g)).to(dt)
+    eps = 1e-5
+    ar_out = sum(p.float() for p in parts).to(dt)                        # the all-reduce's 16-bit result
+    res_want = (ar_out.float() + residual.float()).to(dt)                # residual add in 16 bits
+    xf = res_want.float()
+    out_want = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * weight.float()
+    res_dev = residual.to(dev)
+    fused = tp.fused_allreduce_rmsnorm(parts[rank].to(dev).contiguous(), res_dev, weight.to(dev), eps)
+    assert fused is not None
+    out, res_out = fused
+    torch.cuda.synchronize()
+    assert res_out.data_ptr() == res_dev.data_ptr()
+    if not torch.equal(res_out.cpu(), res_want):
+        ok = False
+        print(f"rank {rank} fused residual {T}x{H}: max diff", (res_out.cpu().float() - res_want.float()).abs().max().item(), flush=True)
+    err = (out.cpu().float() - out_want).abs().max().item()
+    if not err <= tol:
+        ok = False
+        print(f"rank {rank} fused norm {T}x{H}: max err {err}", flush=True)
+# fused under graph replay as well (same device-side counters)
+T, H = 64, 4096
+xg = torch.zeros(T, H, dtype=torch.bfloat16, device=dev)
+rg = torch.zeros(T, H, dtype=torch.bfloat16, device=dev)
+wg = torch.ones(H, dtype=torch.bfloat16, device=dev)
+with torch.cuda.stream(side):
+    ar.fused_allreduce_rmsnorm(xg, rg, wg, 1e-6)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+dist.barrier()
+g2 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g2):
+    og, _ = ar.fused_allreduce_rmsnorm(xg, rg, wg, 1e-6)
+for rep in range(2):
+    parts = [p.view(T, H) for p in parts_for(50 + rep, T * H, torch.bfloat16)]
+    xg.copy_(parts[rank]); rg.zero_()
+    g2.replay()
+    torch.cuda.synchronize()
+    xf = sum(p.float() for p in parts).to(torch.bfloat16).float()
+    want = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    err = (og.cpu().float() - want).abs().max().item()
+    if not err <= 2e-2:
+        ok = False
+        print(f"rank {rank} fused graph replay {rep}: max err {err}", flush=True)
+
 assert ar.check_errors() == 0
-assert not ar.supports(torch.zeros(7, device=dev, dtype=torch.bfloat16))   # falls back to the group
+assert not ar.supports(torch.zeros(7, device=dev, dtype=torch.bfloat16))
+try:
+    tp.all_reduce(torch.zeros(7, device=dev, dtype=torch.bfloat16))   # no silent switch to another implementation
+    ok = False
+except ValueError:
+    pass
 ar.close()
 dist.destroy_process_group()
 print("RANK_OK" if ok else "RANK_FAIL", flush=True)
