@@ -529,6 +529,8 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
 }
 
 int launch_extend32(const rx_extend_params* p, hipStream_t s);  // rx_extend32.hip (D = 128)
+bool extend_nd_supports(int dk, int dv);                          // rx_extend_nd.hip (256/256, 192/128, ...)
+int launch_extend_nd(const rx_extend_params* p, hipStream_t s);
 
 }  // namespace rx
 
@@ -587,6 +589,19 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   if (mfma_ok && dk == 128 && o16 && (p->q_pack > 1 || p->kv.kv_fp8 || extras || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
     const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
+  }
+  if (!extras && !p->kv.kv_fp8 && p->q_pack <= 1 && extend_nd_supports(dk, dv) && !getenv("RX_EXTEND_NO_ND")) {
+    // MFMA 16x16x32 kernel for the other head dims, when the tensors allow 16-byte row chunks
+    const int64_t all = p->q_stride_t | p->q_stride_h | p->k_stride_t | p->k_stride_h | p->v_stride_t | p->v_stride_h |
+                        p->kv.k_page_stride | p->kv.k_tok_stride | p->kv.k_head_stride | p->kv.v_page_stride |
+                        p->kv.v_tok_stride | p->kv.v_head_stride;
+    const bool aligned = all % 8 == 0 && (p->o_stride_t | p->o_stride_h) % 4 == 0 &&
+                         (((uintptr_t)p->q | (uintptr_t)p->k_extend | (uintptr_t)p->v_extend | (uintptr_t)p->kv.k_buf |
+                           (uintptr_t)p->kv.v_buf) & 15) == 0 && ((uintptr_t)p->o & 7) == 0;
+    if (aligned) {
+      const int rc = launch_extend_nd(p, static_cast<hipStream_t>(stream));
+      return rc != RX_OK ? rc : check_launch("rx_extend_attn");
+    }
   }
   ExtendArgs a;
   a.q = (const uint16_t*)p->q;

@@ -157,8 +157,25 @@ __device__ __forceinline__ float half_swap_max(float x) {
 
 // KV8: the cached prefix is an fp8 e4m3fn pool; its rows are upcast (exact) on the way into LDS, the
 // new tokens' K/V are 16-bit as always.
-template <typename T, typename IdxT, bool LINEAR, bool VSCALE, int NW, int QB, bool KV8>
-__global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel(const Ext32Args a) {
+// PLAIN: the launch uses none of the per-request extras (tree mask, unified list, sliding window, Grok
+// temperature, logit cap, GQA packing, window offsets) -- plain prefill / extend over a cached prefix.  Their
+// fields are then compile-time constants: the fast loop of the general instance keeps ~30 more scalars alive and
+// hipcc spills SGPRs into VGPR lanes, reading 26 of them back with v_readlane EVERY tile (VALU issue slots in a
+// VALU-issue-bound loop).
+template <typename T, typename IdxT, bool LINEAR, bool VSCALE, int NW, int QB, bool KV8, bool PLAIN>
+__global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel(const Ext32Args a_in) {
+  Ext32Args a = a_in;
+  if constexpr (PLAIN) {
+    a.q_pack = 1;
+    a.unified_prefix = nullptr;
+    a.custom_mask = nullptr;
+    a.mask_indptr = nullptr;
+    a.window_kv_offsets = nullptr;
+    a.skip_prefix_mask = 1;
+    a.window = 0;
+    a.xai_len = 0;
+    a.logit_cap = 0.f;
+  }
   using vec8 = typename T::vec8;
   using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;  // prefix pool element
   constexpr int KS = kD / 16;                  // 8 k-steps of the QK^T product
@@ -1090,20 +1107,24 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 }
 
 // launcher used by rx_extend.hip for head_dim == v_head_dim == 128
-template <int NW, int QB, bool KV8>
+template <int NW, int QB, bool KV8, bool PLAIN>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
   constexpr unsigned kLds = (QB > 1 ? 3 : 2) * kBufBytes;  // 74 KiB: above the 64 KiB static limit, hence dynamic
 #define RX_E32(TT, IT, LIN, VS)                                                                        \
   do {                                                                                                 \
-    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB, KV8>;                                    \
+    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB, KV8, PLAIN>;                             \
     static const hipError_t attr = hipFuncSetAttribute(                                                \
         reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);       \
     (void)attr;                                                                                        \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), kLds, s, a);                                   \
   } while (0)
-#define RX_E32_VS(TT, IT, LIN) \
-  do { if (vs) RX_E32(TT, IT, LIN, true); else RX_E32(TT, IT, LIN, false); } while (0)
+#define RX_E32_VS(TT, IT, LIN)                                          \
+  do {                                                                  \
+    if constexpr (PLAIN) RX_E32(TT, IT, LIN, false);                    \
+    else if (vs) RX_E32(TT, IT, LIN, true);                             \
+    else RX_E32(TT, IT, LIN, false);                                    \
+  } while (0)
 #define RX_E32_LIN(TT, IT) \
   do { if (linear) RX_E32_VS(TT, IT, true); else RX_E32_VS(TT, IT, false); } while (0)
 #define RX_E32_IDX(TT) \
@@ -1172,12 +1193,16 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.mblocks = (p->max_extend_len * a.q_pack + nw * QB * 32 - 1) / (nw * QB * 32);
   a.kv_fp8 = p->kv.kv_fp8;
   const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0, vsc = p->v_scale != 1.0f;
+  const bool plain = !a.kv_fp8 && !vsc && a.q_pack == 1 && !a.unified_prefix && !a.custom_mask && a.window <= 0 &&
+                     a.xai_len <= 0 && !(a.logit_cap > 0.f) && !getenv("RX_EXT32_NO_PLAIN");
   if (small_wg) {
-    if (a.kv_fp8) launch32_nw<4, 1, true>(a, bf, i64, linear, vsc, s);
-    else launch32_nw<4, 1, false>(a, bf, i64, linear, vsc, s);
+    if (plain) launch32_nw<4, 1, false, true>(a, bf, i64, linear, false, s);
+    else if (a.kv_fp8) launch32_nw<4, 1, true, false>(a, bf, i64, linear, vsc, s);
+    else launch32_nw<4, 1, false, false>(a, bf, i64, linear, vsc, s);
   } else {
-    if (a.kv_fp8) launch32_nw<8 / QB, QB, true>(a, bf, i64, linear, vsc, s);
-    else launch32_nw<8 / QB, QB, false>(a, bf, i64, linear, vsc, s);
+    if (plain) launch32_nw<8 / QB, QB, false, true>(a, bf, i64, linear, false, s);
+    else if (a.kv_fp8) launch32_nw<8 / QB, QB, true, false>(a, bf, i64, linear, vsc, s);
+    else launch32_nw<8 / QB, QB, false, false>(a, bf, i64, linear, vsc, s);
   }
   return RX_OK;
 }

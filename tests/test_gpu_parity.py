@@ -404,6 +404,65 @@ def test_extend_generic_head_dims(ops, d):
     np.testing.assert_allclose(_np(o.float()), want, atol=1.5e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dk,dv", [(256, 256), (192, 128), (192, 192), (96, 96)])
+@pytest.mark.parametrize("variant", ["plain", "window", "cap_sinks_noncausal", "hnd_pool"])
+def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
+    """rx::extend_nd_kernel (MFMA 16x16x32 for head dims 256 / 192+128 / 192 / 96 -- the shapes the reference retunes
+    for gfx950, extend_attention.py:66-77, and the MLA prefill shape) vs the fp64 oracle: ragged batch with zero /
+    tile-crossing prefixes and extends, GQA, LSE; sliding window; logit cap + sinks + non-causal; a paged HND pool."""
+    rng = np.random.default_rng(dk + dv)
+    hq, hkv = 8, 2
+    pre = np.array([0, 16, 33, 200, 5, 64], dtype=np.int32)
+    ext = np.array([1, 32, 50, 140, 129, 64], dtype=np.int32)
+    bs, T = len(pre), int(ext.sum())
+    total = int((pre + ext).sum())
+    ps = 16
+    n_pages = (total + ps - 1) // ps + 3
+    pool = n_pages * ps
+    slots = rng.permutation(pool - ps)[:total] + ps          # page 0 reserved
+    g = torch.Generator().manual_seed(7)
+    kb = torch.randn(pool, hkv, dk, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, dv, generator=g).to(dtype)
+    q = torch.randn(T, hq, dk, generator=g).to(dtype)
+    kv_indptr = np.concatenate([[0], np.cumsum(pre)]).astype(np.int32)
+    qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
+    kv_indices = np.empty(int(pre.sum()), dtype=np.int64)
+    ext_slots = np.empty(T, dtype=np.int64)
+    so = 0
+    for i in range(bs):
+        s_ = slots[so: so + pre[i] + ext[i]]; so += pre[i] + ext[i]
+        kv_indices[kv_indptr[i]: kv_indptr[i + 1]] = s_[: pre[i]]
+        ext_slots[qo[i]: qo[i + 1]] = s_[pre[i]:]
+    ke, ve = kb[ext_slots], vb[ext_slots]
+    kw, okw = {}, {}
+    causal = True
+    if variant == "window":
+        kw = okw = dict(sliding_window_size=9)
+    elif variant == "cap_sinks_noncausal":
+        sinks = torch.randn(hq, generator=g)
+        causal = False
+        kw = dict(logit_cap=20.0, sinks=sinks.to(DEV))
+        okw = dict(logit_cap=20.0, sinks=sinks.numpy())
+    want, want_lse = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
+                                          is_causal=causal, sm_scale=1.0 / dk ** 0.5, return_lse=True, **okw)
+    o = torch.zeros(T, hq, dv, dtype=dtype, device=DEV)
+    lse = torch.zeros(T, hq, dtype=torch.float32, device=DEV)
+    kbd, vbd, lay = kb.to(DEV), vb.to(DEV), None
+    if variant == "hnd_pool":     # [pages, Hkv, page, D]: same slots, page / offset addressing
+        kbd = kbd.view(n_pages, ps, hkv, dk).permute(0, 2, 1, 3).contiguous()
+        vbd = vbd.view(n_pages, ps, hkv, dv).permute(0, 2, 1, 3).contiguous()
+        lay = ops.kv_layout_hnd(kbd, vbd)
+    ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kbd, vbd, _t(qo), _t(kv_indptr), _t(kv_indices),
+                             None, causal, None, int(ext.max()), 1.0, 1.0, lse_extend=lse,
+                             page_size=ps if variant == "hnd_pool" else 1, kv_layout=lay, **kw)
+    tol = 3e-3 if dtype == torch.float16 else 1.5e-2
+    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
+    assert err <= tol, (dk, dv, variant, err)
+    if variant != "cap_sinks_noncausal":  # (the LSE output leaves the sink out, as the reference's does)
+        np.testing.assert_allclose(_np(lse), want_lse, atol=5e-3, rtol=2e-3)
+
+
 # ---------------------------------------------------------------------------- K10 / K11
 def test_move_kv_and_write_req_to_token(ops):
     rng = np.random.default_rng(0)
