@@ -27,6 +27,13 @@
 #ifndef RX_EXT32_PRIO
 #define RX_EXT32_PRIO 0
 #endif
+#ifndef RX_EXT32_DEEP
+// Deeper-pipeline experiments of round 2, all measured SLOWER than the default at config 3 and therefore off (same box,
+// TFLOP/s): 0 default 784-815 | 2 ring of three tiles written two ahead 793-802 | 1 the same + the next tile's first
+// K fragments read before its barrier 781-792 | 3 the ring + waves 4-7 taking their barrier after the QK^T group
+// (half-tile stagger of the SIMD partners) 763-770: QK^T group 1779 -> 1130 cycles, but the PV groups grow by more.
+#define RX_EXT32_DEEP 0
+#endif
 #ifndef RX_EXT32_STAMP
 #define RX_EXT32_STAMP 0  // 1: diagnostic build with s_memtime phase stamps (tools/ext_stamps.py); outputs are clobbered
 #endif
@@ -185,7 +192,21 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   constexpr int RPP = THREADS / 16;            // rows staged per pass
   constexpr int NPASS = kTok / RPP;            // 2 (NW=8) or 4 (NW=4)
   constexpr int QPW = 32 * QB;                 // queries per wave: QB blocks of 32
-  constexpr int RING = AG ? 3 : 2;             // LDS tile ring (the AG pipeline reads tile t-1's V after barrier t)
+  // DEEP (eight-wave form): tiles are written TWO ahead into a ring of three, so tile t+1 is complete one barrier
+  // early and a wave reads its first K fragments of tile t+1 BEFORE barrier t+1 -- the QK^T group then starts on
+  // registers instead of waiting out an LDS round trip with both waves of the SIMD stalled the same way.
+  constexpr bool RING3 = !AG && NW == 8 && RX_EXT32_DEEP >= 1;
+  constexpr bool DEEP = RING3 && RX_EXT32_DEEP == 1;   // cross-barrier K prefetch on top of the deeper ring
+  // STAGGER: with tiles complete one barrier early, the second-dispatched half of the workgroup (waves 4-7, the
+  // SIMD partners of waves 0-3) takes its one barrier per tile AFTER the QK^T group instead of before it.  Same
+  // code, same barrier count -- but after every release one wave of a SIMD is in its matrix-heavy group while its
+  // partner is in a softmax-heavy one, instead of both queueing on the matrix pipe and then both on VALU issue
+  // (MI355X_MICROARCH.md, Two waves per SIMD, item 9).  Legal because tile t is complete at barrier t-1 (written
+  // during tile t-2) and tile t-1's last reads (the late half's PV groups) precede barrier t, after which tile
+  // t+2 overwrites its buffer.
+  constexpr bool STAGGER = RING3 && RX_EXT32_DEEP == 3;
+  constexpr int AHEAD = RING3 ? 2 : 1;         // tile t + AHEAD is written during tile t
+  constexpr int RING = (AG || RING3) ? 3 : 2;   // LDS tile ring (the AG pipeline reads tile t-1's V after barrier t)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
 
   const int tid = threadIdx.x;
@@ -294,8 +315,16 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const int st_row = tid >> 4, st_chunk = tid & 15;
   const KvE* kbuf_h = reinterpret_cast<const KvE*>(a.k_buf) + kvh * a.k_head_stride + 8 * st_chunk;
   const KvE* vbuf_h = reinterpret_cast<const KvE*>(a.v_buf) + kvh * a.v_head_stride + 8 * st_chunk;
-  const uint16_t* kext_h = a.k_ext + qo0 * a.k_stride_t + kvh * a.k_stride_h + 8 * st_chunk;
-  const uint16_t* vext_h = a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h + 8 * st_chunk;
+  // The fast loop stages tiles t+1 / t+2 and fetches the indices of t+3 WITHOUT asking whether they exist (a guard
+  // inside the fenced MFMA groups costs +1.6 k cycles per tile: hipcc's wait-count pass merges pessimistically at
+  // every join).  Tiles past the end therefore resolve to rows that are always readable: extend rows are clamped to
+  // [0, n_end_wg), and a launch without an extend part reads pool slot 0 (the padding slot) through a zero stride.
+  const bool has_ext = nt2 > 0;
+  const uint16_t* kext_h = has_ext ? a.k_ext + qo0 * a.k_stride_t + kvh * a.k_stride_h + 8 * st_chunk
+                                   : reinterpret_cast<const uint16_t*>(kbuf_h);
+  const uint16_t* vext_h = has_ext ? a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h + 8 * st_chunk
+                                   : reinterpret_cast<const uint16_t*>(vbuf_h);
+  const int64_t k_ext_stride = has_ext ? a.k_stride_t : 0, v_ext_stride = has_ext ? a.v_stride_t : 0;
   int32_t slot[NPASS];
   auto load_idx_tile = [&](int t) {
     if (t < nt1) {
@@ -304,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
         slot[i] = static_cast<int32_t>(idx[min(t * kTok + i * RPP + st_row, p_len - 1)]);
     } else {
 #pragma unroll
-      for (int i = 0; i < NPASS; ++i) slot[i] = min((t - nt1) * kTok + i * RPP + st_row, n_end_wg - 1);
+      for (int i = 0; i < NPASS; ++i) slot[i] = max(0, min((t - nt1) * kTok + i * RPP + st_row, n_end_wg - 1));
     }
   };
   u32x4 stg_k[NPASS], stg_v[NPASS];
@@ -328,8 +357,8 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     } else {
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
-        stg_k[i] = *reinterpret_cast<const u32x4*>(kext_h + mul_u32(slot[i], a.k_stride_t));
-        stg_v[i] = *reinterpret_cast<const u32x4*>(vext_h + mul_u32(slot[i], a.v_stride_t));
+        stg_k[i] = *reinterpret_cast<const u32x4*>(kext_h + mul_u32(slot[i], k_ext_stride));
+        stg_v[i] = *reinterpret_cast<const u32x4*>(vext_h + mul_u32(slot[i], v_ext_stride));
       }
     }
   };
@@ -381,6 +410,16 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     if (nt > 1) {
       issue_loads(1);
       if (nt > 2) load_idx_tile(2);
+    }
+    if constexpr (RING3) {  // one more tile in the ring, one more in flight
+      if (nt > 1) {
+        write_lds(1, 1 < nt1);
+        if (nt > 2) {
+          issue_loads(2);
+          if (nt > 3) load_idx_tile(3);
+        }
+      }
+      __syncthreads();  // tiles 0 and 1 are complete: from here on tile t is readable after barrier t - 1
     }
   }
 
@@ -461,11 +500,11 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   // and tile t+2's global loads are re-issued at once, so they have this whole tile to land
   auto tile_sync_and_stage = [&](int t) {
     __syncthreads();
-    if (t + 1 < nt) {
-      write_lds((t + 1) % RING, t + 1 < nt1);
-      if (t + 2 < nt) {
-        issue_loads(t + 2);
-        if (t + 3 < nt) load_idx_tile(t + 3);
+    if (t + AHEAD < nt) {
+      write_lds((t + AHEAD) % RING, t + AHEAD < nt1);
+      if (t + AHEAD + 1 < nt) {
+        issue_loads(t + AHEAD + 1);
+        if (t + AHEAD + 2 < nt) load_idx_tile(t + AHEAD + 2);
       }
     }
   };
@@ -684,7 +723,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
             const int esz = (KV8 && pre) ? 1 : 2;
             const char* kb = pre ? reinterpret_cast<const char*>(kbuf_h) : reinterpret_cast<const char*>(kext_h);
             const char* vb = pre ? reinterpret_cast<const char*>(vbuf_h) : reinterpret_cast<const char*>(vext_h);
-            const int64_t kts = (pre ? a.k_tok_stride : a.k_stride_t) * esz, vts = (pre ? a.v_tok_stride : a.v_stride_t) * esz;
+            const int64_t kts = (pre ? a.k_tok_stride : k_ext_stride) * esz, vts = (pre ? a.v_tok_stride : v_ext_stride) * esz;
             const int64_t kps = a.k_page_stride * esz, vps = a.v_page_stride * esz;
             const int sh = (LINEAR || !pre) ? 31 : -a.page_size - 1;
             const uint32_t lo_mask = (1u << sh) - 1u;
@@ -752,14 +791,33 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
         break;  // the boundary loop below takes over (it re-enters this pipeline at the next run)
       }
     }
-    for (; !AG && t + 3 < nt; ++t) {
-      const TileInfo ti = tile_info(t);
-      if (!ti.fast) break;
+    // A run of fast tiles [t, fe): found ONCE per run in closed form (tile_info per tile cost ~310 cycles of scalar
+    // work between the end of a tile and its barrier), and it may reach the very last tile: staging past the end is
+    // harmless (see has_ext above).
+    int fe = t;
+    if constexpr (!AG) {
+      const TileInfo ti0 = tile_info(t);
+      if (ti0.fast) {  // the tile-independent conditions hold; the rest is "both blocks inside the visible range"
+        if (t < nt1) fe = min(nt1, (causal_in_list ? min(p_len, q_off + qbase + 1) : p_len) / kTok);
+        else fe = min(nt, nt1 + (a.causal ? min(Ek, qbase / pack + 1) : Ek) / kTok);
+        fe = max(fe, t + 1);
+      }
+    }
+    const float c2u = tile_info(t).c2, vs = tile_info(t).vs;  // constant inside a run (prefix or new tokens)
+    u32x4 kpre[3];  // DEEP: the next tile's first K fragments, read before its barrier
+    if constexpr (DEEP) {
+      if (t < fe) {
+        const char* tile0 = smem + (t % RING) * kBufBytes;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) kpre[i] = load_k(tile0, 0, i);
+      }
+    }
+    const bool late = STAGGER && w >= NW / 2;  // wave-uniform
+    for (; !AG && t < fe; ++t) {
       RX_STAMP(5);
-      __syncthreads();
+      if (!late) __syncthreads();
       RX_STAMP(0);
       const char* tile = smem + (t % RING) * kBufBytes;
-      const float c2u = ti.c2, vs = ti.vs;
       // ===== fast body: a hand-ordered wave-level software pipeline.  Measured before it: the tile's
       // phases (QK^T MFMAs, softmax VALU, PV MFMAs, staging) cost their SUM -- hipcc issues all MFMAs
       // of a phase back to back and the in-order wave then does its VALU with the matrix pipe idle.
@@ -834,14 +892,19 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
         }
       };
       {
-        u32x4 kf[2 * KS];
-        kf[0] = load_k(tile, 0, 0);
-        kf[1] = load_k(tile, 0, 1);
+        u32x4 kf[2 * KS + 1];
+        constexpr int KA = DEEP ? 3 : 2;  // K fragments in flight ahead of the MFMA that consumes them
+        if constexpr (DEEP) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) kf[i] = kpre[i];
+        } else {
+          kf[0] = load_k(tile, 0, 0);
+          kf[1] = load_k(tile, 0, 1);
+        }
 #pragma unroll
         for (int i = 0; i < 2 * KS; ++i) {
-          if (i + 2 < 2 * KS) {
-            kf[i + 2] = load_k(tile, (i + 2) >> 3, (i + 2) & 7);
-          } else {  // last two gaps: the first PV k-step's V^T fragments
+          if (i + KA < 2 * KS) kf[i + KA] = load_k(tile, (i + KA) >> 3, (i + KA) & 7);
+          if (i + 2 >= 2 * KS) {  // last two gaps: the first PV k-step's V^T fragments
             vfa[2 * (i + 2 - 2 * KS)] = load_v1(tile, 0, 2 * (i + 2 - 2 * KS));
             vfa[2 * (i + 2 - 2 * KS) + 1] = load_v1(tile, 0, 2 * (i + 2 - 2 * KS) + 1);
           }
@@ -861,6 +924,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
         }
       }
       RX_STAMP(1);
+      if (late) __syncthreads();
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         if (__builtin_amdgcn_ballot_w64(alpha0[qb] != 1.0f) != 0) {
@@ -914,14 +978,14 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       }
       // PV(b1): k-steps 2 (vfa), 3 (vfb) | staging
       {
-        const int t2 = t + 2;
+        const int t2 = t + AHEAD + 1;
         const bool pre = t2 < nt1;
         // one address form for pool rows and new rows: (slot >> sh) * page_stride + (slot & mask) * tok_stride
         // in BYTES (an fp8 pool's elements are bytes, everything else is 16-bit)
         const int esz = (KV8 && pre) ? 1 : 2;
         const char* kb = pre ? reinterpret_cast<const char*>(kbuf_h) : reinterpret_cast<const char*>(kext_h);
         const char* vb = pre ? reinterpret_cast<const char*>(vbuf_h) : reinterpret_cast<const char*>(vext_h);
-        const int64_t kts = (pre ? a.k_tok_stride : a.k_stride_t) * esz, vts = (pre ? a.v_tok_stride : a.v_stride_t) * esz;
+        const int64_t kts = (pre ? a.k_tok_stride : k_ext_stride) * esz, vts = (pre ? a.v_tok_stride : v_ext_stride) * esz;
         const int64_t kps = a.k_page_stride * esz, vps = a.v_page_stride * esz;
         const int sh = (LINEAR || !pre) ? 31 : -a.page_size - 1;  // extend rows are never paged
         const uint32_t lo_mask = (1u << sh) - 1u;
@@ -951,21 +1015,24 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
             else
               pv_mfma<T, AG>(vfb[g - DB], pk1[qb][1], oacc[qb][g - DB]);
           }
-          if (g == 2 && !(RX_EXT32_ABL & 4)) write_lds((t + 1) % RING, t + 1 < nt1);
+          if (g == 2 && !(RX_EXT32_ABL & 4)) write_lds((t + AHEAD) % RING, t + AHEAD < nt1);
           if (g >= 3 && g - 3 < NPASS && !(RX_EXT32_ABL & 4)) reissue(g - 3);
+          if constexpr (DEEP) {  // tile t+1 has been complete since barrier t: its first K fragments, now
+            if (g >= 2 * DB - 3) kpre[g - (2 * DB - 3)] = load_k(smem + ((t + 1) % RING) * kBufBytes, 0, g - (2 * DB - 3));
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 2 * DB - 3; i < NPASS; ++i)
           if (!(RX_EXT32_ABL & 4)) reissue(i);
-        load_idx_tile(t + 3);
+        load_idx_tile(t + AHEAD + 2);
       }
       RX_STAMP(3);
     }
     RX_STAMP(5);
     for (; t < nt; ++t) {
       const TileInfo ti = tile_info(t);
-      if (ti.fast && t + 3 < nt) break;
+      if (ti.fast && (!AG || t + 3 < nt)) break;
       tile_sync_and_stage(t);
       if (!ti.work) continue;
       const char* tile = smem + (t % RING) * kBufBytes;
@@ -1110,7 +1177,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 template <int NW, int QB, bool KV8, bool PLAIN>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
-  constexpr unsigned kLds = (QB > 1 ? 3 : 2) * kBufBytes;  // 74 KiB: above the 64 KiB static limit, hence dynamic
+  constexpr unsigned kLds = ((QB > 1 || (NW == 8 && RX_EXT32_DEEP >= 1)) ? 3 : 2) * kBufBytes;  // 74 / 111 KiB: above the 64 KiB static limit, hence dynamic
 #define RX_E32(TT, IT, LIN, VS)                                                                        \
   do {                                                                                                 \
     auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB, KV8, PLAIN>;                             \
