@@ -77,15 +77,30 @@ __device__ __forceinline__ int64_t mla_slot_off(int64_t slot, int32_t page_size,
 
 // KV8: the latent rows are fp8 e4m3fn (576 B); they are upcast (exact) while being staged, so the LDS
 // image and everything after it is the 16-bit kernel's.
+#ifndef RX_MLA_FP8_SINGLE_BUF
+#define RX_MLA_FP8_SINGLE_BUF 1
+#endif
+// fp8 rows carry half the bytes per tile through the same per-tile compute path, so that path -- a chain of
+// latency-bound steps (LDS round trips, the score exchange, the softmax dependency chain) at two waves per SIMD --
+// sets the rate, not HBM (round 1: 4.0-4.3 TB/s against 5.1 for 16-bit rows).  The fp8 instance therefore keeps ONE
+// staged tile in LDS instead of two (41 KB per workgroup) and runs THREE workgroups per CU: 50 % more rows in
+// flight and a third wave per SIMD to fill the bubbles, for one more barrier per tile.
+template <bool KV8>
+struct MlaBuf {
+  static constexpr int NBUF = (KV8 && RX_MLA_FP8_SINGLE_BUF) ? 1 : 2;
+  static constexpr int WGS = NBUF == 1 ? 3 : 2;  // workgroups per CU (= waves per SIMD) to allocate registers for
+};
+
 template <typename T, typename IdxT, bool LINEAR, bool KV8>
-__global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
+__global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const MlaArgs a) {
+  constexpr int NBUF = MlaBuf<KV8>::NBUF;
   using vec8 = typename T::vec8;
   using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;
   using KvV = u32x4;  // 16 B per lane and load: 8 elements of a 16-bit row, 16 of an fp8 row
   constexpr int KS = kMlaDk / 32;       // 18 k-steps
   constexpr int NBW = kMlaDv / 16 / 4;  // 8 d-blocks of 16 per wave
   // two staged tiles + (split-S form) the 4 x 1 KiB exchange of partial score blocks
-  __shared__ __attribute__((aligned(16))) char smem[2 * kMlaTile * kMlaLdsRow + (RX_MLA_SPLIT_S ? 4 * 64 * 16 : 0)];
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * kMlaTile * kMlaLdsRow + (RX_MLA_SPLIT_S ? 4 * 64 * 16 : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -215,7 +230,8 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
   float xai = 1.0f;  // Grok temperature (decode_attention.py:156-160): the query sits at seq_len - 1
   if (a.xai_len > 0 && seq_len - 1 > a.xai_len)
     xai = __log2f(static_cast<float>(seq_len - 1)) / __log2f(static_cast<float>(a.xai_len));
-  const float c2 = ((a.logit_cap > 0.f) ? kLog2e : a.sm_scale * kLog2e) * xai;
+  const bool capped = a.logit_cap > 0.f;
+  const float c2 = (capped ? kLog2e : a.sm_scale * kLog2e) * xai;
 
   // prologue: tiles 0 .. DEPTH-1 go to sets 0 .. DEPTH-1, tile 0 is written to LDS and its set refilled
   // with tile DEPTH; invariant at iteration t: set (t+1) % DEPTH holds tile t+1, slot_n the slots of
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
    for (int u = 0; u < DEPTH; ++u) {  // unrolled so that the register set is a compile-time index
     const int t = t0 + u;
     if (t >= ntiles) break;
-    const char* kt = smem + (t & 1) * kMlaTile * kMlaLdsRow;
+    const char* kt = smem + (t % NBUF) * kMlaTile * kMlaLdsRow;
     // ---- S^T = K Q^T over all 576 columns --------------------------------------------------------
     // K fragments run RX_MLA_PD reads ahead of their MFMA: a ds_read_b128 round trip is ~100+ cycles,
     // a 16x16x32 MFMA 16; hipcc left alone reads two ahead and the in-order wave then waits on LDS
@@ -273,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
         if (i + PD < KSW) kf[i + PD] = *reinterpret_cast<const u32x4*>(kb0 + (i + PD) * 64);
         part = T::mfma(__builtin_bit_cast(vec8, kf[i]), qf[i], part);
       }
-      f32x4* xch = reinterpret_cast<f32x4*>(smem + 2 * kMlaTile * kMlaLdsRow);
+      f32x4* xch = reinterpret_cast<f32x4*>(smem + NBUF * kMlaTile * kMlaLdsRow);
       xch[w * 64 + lane] = part;
       __syncthreads();
       sacc[0] = xch[0 * 64 + lane] + xch[2 * 64 + lane];
@@ -310,10 +326,18 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
+      for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[bb][i];
+    // ONE wave-uniform branch around all eight scores: written per element, hipcc emits eight branches (and the
+    // tanh expansion eight times) inside the tile loop and serialises the score exchange around them
+    if (capped) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * a.sm_scale / a.logit_cap);
+    }
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float x = sacc[bb][i];
-        if (a.logit_cap > 0.f) x = a.logit_cap * tanhf(x * a.sm_scale / a.logit_cap);
-        x = (tok_base + 16 * bb + i < hi) ? x : -INFINITY;
+        const float x = (tok_base + 16 * bb + i < hi) ? sv[bb * 4 + i] : -INFINITY;
         sv[bb * 4 + i] = x;
         mt = fmaxf(mt, x);
       }
@@ -354,8 +378,9 @@ __global__ __launch_bounds__(256, 2) void decode_mla_kernel(const MlaArgs a) {
     }
     MLA_STAMP(2);
     // ---- stage the next tile into the other buffer -------------------------------------------------
+    if constexpr (NBUF == 1) __syncthreads();  // every wave has read tile t: its buffer may be overwritten
     if (t + 1 < ntiles) {
-      write_lds((t + 1) & 1, stg[(u + 1) % DEPTH]);
+      write_lds((t + 1) % NBUF, stg[(u + 1) % DEPTH]);
 #if RX_MLA_STAMP == 2
       MLA_STAMP(5);  // finer diagnostic: slot 5 = the LDS write (incl. its vmcnt waits), 3 = the re-issue
 #endif

@@ -10,6 +10,8 @@ tests (test_gpu_fullsize.py) and is what bench.py runs.
 """
 import numpy as np
 import pytest
+
+import parity_util as parity
 import torch
 
 from oracle import radix_oracle as orc
@@ -79,8 +81,7 @@ def _extend_then_decode(ops, dtype, hq, hkv, d, page, prefix, ext, tol_o):
                              None, True, None, int(max(ext)), 1.0, 1.0, sm_scale=sm, page_size=page)
     want = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr, kv_indices,
                                 sm_scale=sm)
-    err = np.abs(o.float().cpu().numpy().astype(np.float64) - want).max()
-    assert err <= tol_o, ("extend", err)
+    parity.check_out(o.float().cpu().numpy(), want, dtype, "extend")
     # one decode step on top
     lens = np.asarray(seq, dtype=np.int64)
     new_loc = np.array([r2t[i + 1, s - 1] for i, s in enumerate(seq)], dtype=np.int64)
@@ -93,8 +94,7 @@ def _extend_then_decode(ops, dtype, hq, hkv, d, page, prefix, ext, tol_o):
                                    page_size=page)
     ip, ii = orc.build_kv_indices(r2t, rpi, lens)
     want_d = orc.decode_attention(_bits(qd), _bits(kb), _bits(vb), ip, ii, sm)
-    err = np.abs(od.float().cpu().numpy().astype(np.float64) - want_d).max()
-    assert err <= tol_o, ("decode", err)
+    parity.check_out(od.float().cpu().numpy(), want_d, dtype, "decode")
 
 
 def test_config0_opt125m_bs4_ctx512(ops):
@@ -129,7 +129,7 @@ def test_config2_shared_prefix_extend(ops):
                              _T(kv_indices), None, True, None, E, 1.0, 1.0, sm_scale=sm, lse_extend=lse, page_size=page)
     want, want_lse = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr,
                                           kv_indices, sm_scale=sm, return_lse=True)
-    assert np.abs(o.float().cpu().numpy().astype(np.float64) - want).max() <= 1.5e-2
+    parity.check(np.abs(o.float().cpu().numpy().astype(np.float64) - want).max(), 1.5e-2, None)
     np.testing.assert_allclose(lse.cpu().numpy(), want_lse, atol=5e-3, rtol=2e-3)
 
 
@@ -161,7 +161,7 @@ def test_config3_llama70b_tp8_shard_decode(ops):
             ls = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
             ops.decode_attention_fwd_paged(qd, kbd, vbd, o, _T(r2t), _T(rpi), _T(lens), al, ls, ns, S, sm,
                                            page_size=page)
-        assert np.abs(o.float().cpu().numpy().astype(np.float64) - want).max() <= 1e-2, S
+        parity.check(np.abs(o.float().cpu().numpy().astype(np.float64) - want).max(), 1e-2, S)
 
 
 def test_config4_mla_fp8_tp8_decode(ops):
@@ -183,4 +183,4 @@ def test_config4_mla_fp8_tp8_decode(ops):
     o = torch.zeros(bs, hq, 512, dtype=dtype, device=DEV)
     ops.decode_attention_fwd_paged(q.to(DEV), kvd, kvd[..., :512], o, _T(r2t), _T(rpi), _T(lens), None, None, None, 1,
                                    sm, page_size=page)
-    assert np.abs(o.float().cpu().numpy().astype(np.float64) - want).max() <= 1e-2
+    parity.check(np.abs(o.float().cpu().numpy().astype(np.float64) - want).max(), 1e-2, None)

@@ -5,6 +5,8 @@ are compared with the fp64 oracle run on the dequantised pool.
 """
 import numpy as np
 import pytest
+
+import parity_util as parity
 import torch
 
 from oracle import radix_oracle as orc
@@ -36,7 +38,7 @@ def _dq(u8):  # pool bytes -> float32 values (oracle decode)
     return orc.fp8_e4m3fn_decode(u8.detach().cpu().numpy())
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("layout", ["nhd", "hnd", "mla"])
 @pytest.mark.parametrize("scales", [(1.0, 1.0), (0.37, 2.5)])
 def test_store_fp8_bit_exact(ops, dtype, layout, scales):
@@ -119,7 +121,7 @@ def _paged(rng, lens, page_size, max_extra=0):
     return r2t, n_pages * page_size
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("hq,hkv,d,page_size", [(32, 8, 128, 16), (8, 1, 128, 1), (4, 4, 64, 32)])
 def test_decode_fp8_pool_vs_oracle(ops, dtype, hq, hkv, d, page_size):
     rng = np.random.default_rng(hq + d)
@@ -142,7 +144,7 @@ def test_decode_fp8_pool_vs_oracle(ops, dtype, hq, hkv, d, page_size):
     ops.decode_attention_fwd_paged(qd, kbd, vbd, o, T(r2t), T(rpi), T(lens), None, None, None, 1, sm, ks, vs,
                                    page_size=page_size)
     err = np.abs(_f32(o).astype(np.float64) - want).max()
-    assert err <= tol, ("single", err)
+    parity.check(err, tol, ("single", err))
     S = 8
     nsplit = torch.zeros(bs, dtype=torch.int32, device=DEV)
     ops.get_num_kv_splits(nsplit, T(lens).int(), hq, hkv, S, 256)
@@ -152,10 +154,10 @@ def test_decode_fp8_pool_vs_oracle(ops, dtype, hq, hkv, d, page_size):
     ops.decode_attention_fwd(qd, kbd.view(torch.uint8), vbd.view(torch.uint8), o2, T(kv_indptr), T(kv_indices),
                              al, lse, nsplit, S, sm, ks, vs, page_size=page_size)
     err2 = np.abs(_f32(o2).astype(np.float64) - want).max()
-    assert err2 <= tol, ("split", err2)
+    parity.check(err2, tol, ("split", err2))
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("hq,page_size", [(16, 1), (128, 16)])
 def test_decode_mla_fp8_rows_vs_oracle(ops, dtype, hq, page_size):
     rng = np.random.default_rng(hq)
@@ -177,7 +179,7 @@ def test_decode_mla_fp8_rows_vs_oracle(ops, dtype, hq, page_size):
     ops.decode_attention_fwd_paged(qd, kvd, kvd[..., :512], o, T(r2t), T(rpi), T(lens), None, None, None, 1, sm,
                                    page_size=page_size)
     err = np.abs(_f32(o).astype(np.float64) - want).max()
-    assert err <= tol, ("single", err)
+    parity.check(err, tol, ("single", err))
     S = 8
     nsplit = torch.zeros(bs, dtype=torch.int32, device=DEV)
     ops.get_num_kv_splits(nsplit, T(lens).int(), hq, 1, S, 256)
@@ -187,10 +189,10 @@ def test_decode_mla_fp8_rows_vs_oracle(ops, dtype, hq, page_size):
     ops.decode_attention_fwd(qd, kvd, kvd[..., :512], o2, T(kv_indptr), T(kv_indices), al, lse, nsplit, S, sm,
                              1.0, 1.0, page_size=page_size)
     err2 = np.abs(_f32(o2).astype(np.float64) - want).max()
-    assert err2 <= tol, ("split", err2)
+    parity.check(err2, tol, ("split", err2))
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("page_size", [1, 16])
 def test_extend_fp8_prefix_pool_vs_oracle(ops, dtype, page_size):
     rng = np.random.default_rng(page_size)
@@ -220,13 +222,13 @@ def test_extend_fp8_prefix_pool_vs_oracle(ops, dtype, page_size):
                              page_size=page_size)
     tol = 3e-3 if dtype == torch.float16 else 1e-2
     err = np.abs(_f32(o).astype(np.float64) - want).max()
-    assert err <= tol, err
+    parity.check(err, tol, err)
     # GQA-packed query rows over the same fp8 prefix pool: the same result
     o2 = torch.zeros_like(o)
     ops.extend_attention_fwd_gqa_packed(q.to(DEV), ke.to(DEV), ve.to(DEV), o2, kb.to(DEV), vb.to(DEV), T(qo),
                                         T(kv_indptr), T(kv_indices), None, True, None, int(ext.max()), ks, vs,
                                         sm_scale=sm, page_size=page_size)
-    assert np.abs(_f32(o2).astype(np.float64) - want).max() <= tol
+    parity.check(np.abs(_f32(o2).astype(np.float64) - want).max(), tol, None)
 
 
 def test_fp8_pools_roundtrip_through_the_pool_classes(ops):

@@ -10,6 +10,8 @@ import os
 
 import numpy as np
 import pytest
+
+import parity_util as parity
 import torch
 
 from oracle import radix_oracle as orc
@@ -201,7 +203,7 @@ def test_decode_golden_fp16(ops, golden_dir):
             np.testing.assert_allclose(got, c["o"].astype(np.float64), atol=1e-2, rtol=1e-2,
                                        err_msg=f"{name}/{mode} vs triton golden")
             # vs the fp64 oracle, north-star bar
-            assert np.abs(got - want).max() <= 2e-3, (name, mode, np.abs(got - want).max())
+            parity.check_out(got, want, torch.float16, (name, mode))
             if mode == "split":
                 logits, lse_s, _ = orc.decode_attention_split(
                     c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"], c["nsplit"],
@@ -238,7 +240,7 @@ def _make_paged_case(rng, bs, hq, hkv, d, lens, page_size, dtype, layout="shuffl
     return q, kb, vb, r2t, rpi
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (8, 1, 128), (4, 4, 64), (12, 12, 64), (16, 1, 128), (40, 2, 128)])
 @pytest.mark.parametrize("page_size,layout", [(1, "shuffled"), (16, "shuffled"), (16, "interleaved"), (32, "contiguous")])
 def test_decode_paged_vs_oracle(ops, dtype, hq, hkv, d, page_size, layout):
@@ -249,15 +251,13 @@ def test_decode_paged_vs_oracle(ops, dtype, hq, hkv, d, page_size, layout):
     sm = 1.0 / d ** 0.5
     kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
     want = orc.decode_attention(_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, sm)
-    tol = 2e-3 if dtype == torch.float16 else 1e-2
     qd, kbd, vbd = q.to(DEV), kb.to(DEV), vb.to(DEV)
     r2td, rpid, lensd = _t(r2t), _t(rpi), _t(lens)
     # (b) native mode: in-kernel req_to_token walk, single pass
     o = torch.zeros(bs, hq, d, dtype=dtype, device=DEV)
     ops.decode_attention_fwd_paged(qd, kbd, vbd, o, r2td, rpid, lensd, None, None, None, 1, sm,
                                    page_size=page_size)
-    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    assert err <= tol, ("paged/single", err)
+    parity.check_out(_np(o.float()), want, dtype, "paged/single")
     # (a) reference contract: kv_indices + K3-chosen splits + stage 2
     S = 8
     nsplit = torch.zeros(bs, dtype=torch.int32, device=DEV)
@@ -270,8 +270,7 @@ def test_decode_paged_vs_oracle(ops, dtype, hq, hkv, d, page_size, layout):
     o2 = torch.zeros_like(o)
     ops.decode_attention_fwd(qd, kbd, vbd, o2, kvp, kvi, al, lse, nsplit, S, sm, 1.0, 1.0,
                              page_size=page_size)
-    err2 = np.abs(_np(o2.float()).astype(np.float64) - want).max()
-    assert err2 <= tol, ("indices/split", err2)
+    parity.check_out(_np(o2.float()), want, dtype, "indices/split")
 
 
 def test_decode_hnd_layout_and_sinks(ops):
@@ -290,7 +289,7 @@ def test_decode_hnd_layout_and_sinks(ops):
     o = torch.zeros(bs, hq, d, dtype=torch.float16, device=DEV)
     ops.decode_attention_fwd_paged(q.to(DEV), k_hnd, v_hnd, o, _t(r2t), _t(rpi), _t(lens), None, None,
                                    None, 1, 0.1, sinks=sinks.to(DEV), kv_layout=lay)
-    assert np.abs(_np(o.float()) - want).max() <= 2e-3
+    parity.check(np.abs(_np(o.float()) - want).max(), 2e-3, None)
 
 
 @pytest.mark.parametrize("hq,hkv,dk,dv", [(4, 4, 80, 80), (4, 4, 13, 13), (16, 1, 96, 96), (16, 1, 576, 512)])
@@ -338,11 +337,11 @@ def test_extend_golden_fp16(ops, golden_dir):
             c["q"], c["k_ext"], c["v_ext"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"],
             c["kv_indices"], is_causal=bool(c["causal"]), sm_scale=float(c["sm_scale"]),
             logit_cap=float(c["logit_cap"]), return_lse=True)
-        assert np.abs(got - want).max() <= 3e-3, (name, np.abs(got - want).max())
+        parity.check_out(got, want, torch.float16, name)
         np.testing.assert_allclose(_np(lse), want_lse, atol=2e-3, rtol=1e-3, err_msg=name)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("hq,hkv,d", [(8, 2, 128), (4, 4, 64), (4, 1, 128)])
 @pytest.mark.parametrize("window", [-1, 7])
 def test_extend_ragged_vs_oracle(ops, dtype, hq, hkv, d, window):
@@ -376,9 +375,9 @@ def test_extend_ragged_vs_oracle(ops, dtype, hq, hkv, d, window):
     ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo),
                              _t(kv_indptr), _t(kv_indices), None, True, None, int(ext.max()), 1.0, 1.0,
                              sliding_window_size=window, lse_extend=lse)
-    tol = 3e-3 if dtype == torch.float16 else 1.5e-2
-    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    assert err <= tol, err
+    absw = orc.extend_attention(_np(q), _np(ke), parity.abs_values(_np(ve)), _np(kb), parity.abs_values(_np(vb)), qo,
+                                kv_indptr, kv_indices, sm_scale=1.0 / d ** 0.5, sliding_window_size=window)
+    parity.check_out(_np(o.float()), want, dtype, (hq, hkv, d, window), absw=absw)
     np.testing.assert_allclose(_np(lse), want_lse, atol=5e-3, rtol=2e-3)
 
 
@@ -404,7 +403,7 @@ def test_extend_generic_head_dims(ops, d):
     np.testing.assert_allclose(_np(o.float()), want, atol=1.5e-2, rtol=1e-2)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("dk,dv", [(256, 256), (192, 128), (192, 192), (96, 96)])
 @pytest.mark.parametrize("variant", ["plain", "window", "cap_sinks_noncausal", "hnd_pool"])
 def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
@@ -456,9 +455,9 @@ def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
     ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kbd, vbd, _t(qo), _t(kv_indptr), _t(kv_indices),
                              None, causal, None, int(ext.max()), 1.0, 1.0, lse_extend=lse,
                              page_size=ps if variant == "hnd_pool" else 1, kv_layout=lay, **kw)
-    tol = 3e-3 if dtype == torch.float16 else 1.5e-2
-    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    assert err <= tol, (dk, dv, variant, err)
+    absw = orc.extend_attention(_np(q), _np(ke), parity.abs_values(_np(ve)), _np(kb), parity.abs_values(_np(vb)), qo,
+                                kv_indptr, kv_indices, is_causal=causal, sm_scale=1.0 / dk ** 0.5, **okw)
+    parity.check_out(_np(o.float()), want, dtype, (dk, dv, variant), absw=absw)
     if variant != "cap_sinks_noncausal":  # (the LSE output leaves the sink out, as the reference's does)
         np.testing.assert_allclose(_np(lse), want_lse, atol=5e-3, rtol=2e-3)
 
@@ -491,7 +490,7 @@ def test_move_kv_and_write_req_to_token(ops):
 
 
 # ---------------------------------------------------------------------------- MLA decode kernel
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("hq,page_size", [(16, 1), (128, 16), (5, 64)])
 def test_decode_mla_kernel(ops, dtype, hq, page_size):
     """rx::decode_mla_kernel (Dk 576 / Dv 512, V = first 512 columns of the latent rows): single pass
@@ -523,7 +522,7 @@ def test_decode_mla_kernel(ops, dtype, hq, page_size):
     ops.decode_attention_fwd_paged(qd, kvd, kvd[..., :512], o, _t(r2t), _t(rpi), _t(lens), None, None, None, 1, sm,
                                    page_size=page_size)
     err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    assert err <= tol, ("single", err)
+    parity.check(err, tol, ("single", err))
     S = 8
     nsplit = torch.zeros(bs, dtype=torch.int32, device=DEV)
     ops.get_num_kv_splits(nsplit, _t(lens).int(), hq, 1, S, 256)
@@ -533,7 +532,7 @@ def test_decode_mla_kernel(ops, dtype, hq, page_size):
     ops.decode_attention_fwd(qd, kvd, kvd[..., :512], o2, _t(kv_indptr), _t(kv_indices), al, lse, nsplit, S, sm,
                              1.0, 1.0, page_size=page_size)
     err2 = np.abs(_np(o2.float()).astype(np.float64) - want).max()
-    assert err2 <= tol, ("split", err2)
+    parity.check(err2, tol, ("split", err2))
 
 
 # ---------------------------------------------------------------------------- edge cases
@@ -564,7 +563,7 @@ def test_decode_edge_cases(ops):
                                    S, d ** -0.5, page_size=ps)
     got = _np(o.float()).astype(np.float64)
     live = lens > 0
-    assert np.abs(got[live] - want[live]).max() <= 1e-2
+    parity.check(np.abs(got[live] - want[live]).max(), 1e-2, None)
     # single pass: the empty request gets a defined (zero) output
     o1 = torch.full((bs, hq, d), 7.0, dtype=torch.bfloat16, device=DEV)
     ops.decode_attention_fwd_paged(q_view, kbd, vbd, o1, _t(r2t), _t(rpi), _t(lens), None, None, None, 1,
@@ -603,7 +602,7 @@ def test_extend_edge_cases(ops):
     ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo).to(torch.int32),
                              _t(kv_indptr), _t(kv_indices).to(torch.int32), None, True, None, int(ext.max()),
                              1.0, 1.0)
-    assert np.abs(_np(o.float()).astype(np.float64) - want).max() <= 3e-3
+    parity.check(np.abs(_np(o.float()).astype(np.float64) - want).max(), 3e-3, None)
 
 
 def test_k_and_v_scales(ops):
@@ -618,7 +617,7 @@ def test_k_and_v_scales(ops):
     o = torch.zeros(2, hq, d, dtype=torch.float16, device=DEV)
     ops.decode_attention_fwd(q.to(DEV), kb.to(DEV), vb.to(DEV), o, _t(kv_indptr), _t(kv_indices), None, None, None,
                              1, 0.2, 0.5, 2.0)
-    assert np.abs(_np(o.float()) - want).max() <= 4e-3
+    parity.check(np.abs(_np(o.float()) - want).max(), 4e-3, None)
     # extend: scales apply to the cached prefix only
     pre, ext = np.array([20], dtype=np.int32), np.array([40], dtype=np.int32)
     g = torch.Generator().manual_seed(4)
@@ -631,7 +630,7 @@ def test_k_and_v_scales(ops):
     oe = torch.zeros(40, hq, d, dtype=torch.float16, device=DEV)
     ops.extend_attention_fwd(qe.to(DEV), ke.to(DEV), ve.to(DEV), oe, kbe.to(DEV), vbe.to(DEV), _t(np.array([0, 40])),
                              _t(np.array([0, 20], dtype=np.int32)), _t(kvi), None, True, None, 40, 0.5, 2.0, sm_scale=0.2)
-    assert np.abs(_np(oe.float()) - want_e).max() <= 6e-3
+    parity.check(np.abs(_np(oe.float()) - want_e).max(), 6e-3, None)
 
 
 def test_torch_custom_ops_match_direct_calls_and_capture(ops, golden_dir):
@@ -695,17 +694,17 @@ def test_extend_tree_mask_window_xai_golden(ops, golden_dir):
         got = _np(o).astype(np.float64)
         want = c["o"].astype(np.float64)
         ok = np.isfinite(want).all(axis=-1)  # rows that see nothing: 0/0 in the reference
-        assert np.abs(got[ok] - want[ok]).max() <= 1e-2, (name, "vs triton golden")
+        parity.check(np.abs(got[ok] - want[ok]).max(), 1e-2, (name, "vs triton golden"))
         ref = orc.extend_attention(
             c["q"], c["k_ext"], c["v_ext"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"],
             is_causal=True, sm_scale=float(c["sm_scale"]), sliding_window_size=int(c["window"]),
             custom_mask=c.get("custom_mask"), mask_indptr=c.get("mask_indptr"),
             skip_prefix_custom_mask=(skipm != 0), window_kv_offsets=c.get("window_kv_offsets"),
             xai_temperature_len=int(c["xai"]))
-        assert np.abs(got[ok] - ref[ok]).max() <= 3e-3, (name, np.abs(got[ok] - ref[ok]).max())
+        parity.check(np.abs(got[ok] - ref[ok]).max(), 3e-3, (name, np.abs(got[ok] - ref[ok]).max()))
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_extend_tree_mask_long_prefix_vs_oracle(ops, dtype):
     """TARGET_VERIFY shape: long cached prefixes (fast unmasked tiles) + a few draft tokens under a tree
     mask, bs 5, GQA, page 16."""
@@ -741,7 +740,7 @@ def test_extend_tree_mask_long_prefix_vs_oracle(ops, dtype):
                              _t(kv_indices), _t(cm).bool(), True, _t(mi), nd, 1.0, 1.0, sm_scale=sm)
     tol = 3e-3 if dtype == torch.float16 else 1e-2
     err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    assert err <= tol, err
+    parity.check(err, tol, err)
 
 
 def test_decode_xai_temperature_golden(ops, golden_dir):
@@ -755,13 +754,13 @@ def test_decode_xai_temperature_golden(ops, golden_dir):
         o = torch.zeros_like(q)
         ops.decode_attention_fwd(q, kb, vb, o, _t(c["kv_indptr"]), _t(c["kv_indices"]), al, lse, _t(c["nsplit"]), S,
                                  float(c["sm_scale"]), 1.0, 1.0, xai_temperature_len=int(c["xai"]))
-        assert np.abs(_np(o).astype(np.float64) - c["o"].astype(np.float64)).max() <= 1e-2, name
+        parity.check(np.abs(_np(o).astype(np.float64) - c["o"].astype(np.float64)).max(), 1e-2, name)
         want = orc.decode_attention(c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"], float(c["sm_scale"]),
                                     xai_temperature_len=int(c["xai"]))
-        assert np.abs(_np(o).astype(np.float64) - want).max() <= 2e-3, name
+        parity.check(np.abs(_np(o).astype(np.float64) - want).max(), 2e-3, name)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 def test_merge_state_and_prefix_cascade(ops, dtype):
     """rx_merge_state vs the oracle, then the cascade it exists for: extend over (prefix only) and
     (new tokens only) merged by LSE equals the one-pass extend (merge_state.py docstring use)."""
@@ -775,7 +774,7 @@ def test_merge_state_and_prefix_cascade(ops, dtype):
     out, lse = ops.merge_state(a, la, b, lb)
     want, want_lse = orc.merge_state(_np(a), la.cpu().numpy(), _np(b), lb.cpu().numpy())
     tol = 2e-3 if dtype == torch.float16 else 1.6e-2
-    assert np.abs(orc.to_f64(_np(out)) - want).max() <= tol
+    parity.check(np.abs(orc.to_f64(_np(out)) - want).max(), tol, None)
     np.testing.assert_allclose(lse.cpu().numpy(), want_lse, atol=1e-5, rtol=1e-5)
 
     # cascade
@@ -873,12 +872,12 @@ def test_extend_unified_golden(ops, golden_dir):
         got = _np(o).astype(np.float64)
         want = c["o"].astype(np.float64)
         ok = np.isfinite(want).all(axis=-1)
-        assert np.abs(got[ok] - want[ok]).max() <= 1e-2, (name, "vs triton golden")
+        parity.check(np.abs(got[ok] - want[ok]).max(), 1e-2, (name, "vs triton golden"))
         ref = orc.extend_attention_unified(
             c["q"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"], c["prefix_lens"],
             sm_scale=float(c["sm_scale"]), sliding_window_size=int(c["window"]), custom_mask=c.get("custom_mask"),
             mask_indptr=c.get("mask_indptr"), xai_temperature_len=int(c["xai"]))
-        assert np.abs(got[ok] - ref[ok]).max() <= 3e-3, (name, np.abs(got[ok] - ref[ok]).max())
+        parity.check(np.abs(got[ok] - ref[ok]).max(), 3e-3, (name, np.abs(got[ok] - ref[ok]).max()))
 
 
 def test_extend_unified_equals_two_stage_on_long_batch(ops):
@@ -915,7 +914,7 @@ def test_extend_unified_equals_two_stage_on_long_batch(ops):
     assert (o1.float() - o2.float()).abs().max().item() <= 2e-2
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("pattern", ["ramp", "spikes", "plateau"])
 def test_extend_thresholded_max_adversarial_scores(ops, dtype, pattern):
     """The D = 128 MFMA kernel moves a row's reference max only when a tile's max exceeds it by > 2^8
@@ -960,11 +959,11 @@ def test_extend_thresholded_max_adversarial_scores(ops, dtype, pattern):
                              _t(kv_indices), None, True, None, E, 1.0, 1.0, lse_extend=lse)
     tol = 4e-3 if dtype == torch.float16 else 2e-2
     err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    assert err <= tol, (pattern, err)
+    parity.check(err, tol, (pattern, err))
     np.testing.assert_allclose(_np(lse), want_lse, atol=5e-3, rtol=2e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("hq,hkv", [(8, 2), (16, 2), (4, 1)])
 @pytest.mark.parametrize("mode", ["tree", "causal", "window"])
 def test_extend_gqa_packed_rows_match_oracle(ops, dtype, hq, hkv, mode):
@@ -1016,10 +1015,10 @@ def test_extend_gqa_packed_rows_match_oracle(ops, dtype, hq, hkv, mode):
     got = _np(o.float()).astype(np.float64)
     ok = np.isfinite(want).all(axis=(1, 2))  # a window / mask can hide everything from a row (0/0 in the reference)
     tol = 3e-3 if dtype == torch.float16 else 1.5e-2
-    assert np.abs(got[ok] - want[ok]).max() <= tol
+    parity.check(np.abs(got[ok] - want[ok]).max(), tol, None)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("chunks", [1, 3, 8])
 def test_verify_attention_splitkv_vs_oracle(ops, dtype, chunks):
     """Small-batch speculative verify, cached part split into chunks (the reference's verify_splitkv case):
@@ -1056,7 +1055,7 @@ def test_verify_attention_splitkv_vs_oracle(ops, dtype, chunks):
                                  _t(kv_indices), _t(cm), _t(mi), nd, chunks, 1.0, 1.0, sm_scale=sm)
     tol = 4e-3 if dtype == torch.float16 else 1.5e-2
     err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    assert err <= tol, err
+    parity.check(err, tol, err)
 
 
 def test_verify_splitkv_replays_under_hip_graph(ops):
@@ -1116,4 +1115,4 @@ def test_verify_splitkv_replays_under_hip_graph(ops):
         want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo.cpu().numpy(), ip,
                                     kv_indices.cpu().numpy()[: int(prefix.sum())], is_causal=True, sm_scale=d ** -0.5,
                                     custom_mask=cm, mask_indptr=mi.cpu().numpy())
-        assert np.abs(_np(o.float()).astype(np.float64) - want).max() <= 1.5e-2
+        parity.check(np.abs(_np(o.float()).astype(np.float64) - want).max(), 1.5e-2, None)
