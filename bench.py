@@ -587,6 +587,55 @@ def extend_head_dims(args, dev):
     return res
 
 
+def mla_decode_bench(dev):
+    """configs[4]-shaped MLA decode (one TP=8 rank: 16 q heads, Hkv = 1, Dk 576 = 512 latent + 64 rope, Dv 512; bs 64,
+    ctx 8192, page_size 64 pages in shuffled order), latent rows bf16 and fp8 e4m3: time of rx_decode_attn (MLA stage 1
+    + stage-2 merge), HBM-bound -- algorithmic bytes = sum seq * row bytes + Q + O."""
+    from sglang_amd import ops
+
+    bs, ctx, hq, dk, dv, ps, S = 64, 8192, 16, 576, 512, 64, 8
+    g = torch.Generator(device=dev).manual_seed(3)
+    pool = bs * ctx + ps
+    perm = torch.randperm(bs * ctx // ps, device=dev, generator=g) + 1
+    slots = (perm.view(bs, -1, 1) * ps + torch.arange(ps, device=dev)).view(bs, -1)[:, :ctx]
+    r2t = torch.zeros(bs + 1, ctx, dtype=torch.int32, device=dev)
+    r2t[1:] = slots.int()
+    rpi = torch.arange(1, bs + 1, device=dev)
+    lens = torch.full((bs,), ctx, dtype=torch.int64, device=dev)
+    nsplit = torch.zeros(bs, dtype=torch.int32, device=dev)
+    ops.get_num_kv_splits(nsplit, lens.int(), hq, 1, S, 256)
+    al = torch.empty(bs, hq, S, dv, dtype=torch.float32, device=dev)
+    lse = torch.empty(bs, hq, S, dtype=torch.float32, device=dev)
+    q = torch.randn(bs, hq, dk, device=dev, generator=g).to(torch.bfloat16)
+    o = torch.empty(bs, hq, dv, dtype=torch.bfloat16, device=dev)
+    res = {"workload": "DeepSeek-V3-style MLA decode, one TP=8 rank: bs=64, ctx=8192, 16 q heads, latent rows 576 "
+                       "(512 + 64 rope), page_size 64 shuffled pages, 8 kv splits; whole op (stage 1 + merge)"}
+    for name, fp8 in (("bf16_rows", False), ("fp8_rows", True)):
+        kv = torch.empty(pool, 1, dk, dtype=torch.bfloat16, device=dev).normal_(generator=g)
+        if fp8:
+            kv = kv.to(torch.float8_e4m3fn)
+
+        def run():
+            ops.decode_attention_fwd_paged(q, kv, kv[..., :dv], o, r2t, rpi, lens, al, lse, nsplit, S, dk ** -0.5,
+                                           page_size=ps)
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        byt = bs * ctx * dk * (1 if fp8 else 2) + bs * hq * (dk + dv) * 2
+        res[name] = {"us": ms * 1e3, "bytes": byt,
+                     "roofline": {"bound": "hbm", "achieved": byt / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": byt / ms / 1e6 / HBM_PEAK_GBS, "traffic": None}}
+        del kv
+    return res
+
+
 def rccl_capturable(dev) -> bool:
     """Can this stack capture an RCCL all-reduce into a HIP graph and replay it?  Probed on a tiny tensor before
     the step is captured, so that a refusal costs nothing but the eager fallback."""
@@ -798,6 +847,10 @@ def main():
             out["spec_verify"] = verify_bench(dev)
         except Exception as e:
             out["spec_verify"] = {"error": str(e)}
+        try:
+            out["mla_decode"] = mla_decode_bench(dev)
+        except Exception as e:
+            out["mla_decode"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

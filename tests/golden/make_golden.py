@@ -15,6 +15,7 @@ Fixture families:
   F5 decode attention (Triton decode_attention_fwd) -> decode_*.npz
   F6 extend attention (Triton extend_attention_fwd) -> extend_*.npz
   F7 radix tree op sequences (reference RadixCache, recording allocator) -> radix_sequences.json
+  F13 scheduler flow (reference RadixCache request hooks + allocators + req_to_token rows) -> scheduler_flow.json
   F8 bf16 decode/extend from the compiled reference C++ CPU kernels -> cpu_native.npz
   F10 decode with the xai temperature -> decode_xai.npz
   F12 unified one-stage extend (deterministic inference) -> extend_unified.npz
@@ -751,7 +752,122 @@ def f12():
     save("extend_unified.npz", **flat)
 
 
+# ------------------------------------------------------------------ F13
+def gen_flow(page_size, seed):
+    """A small scheduler loop on the REFERENCE's RadixCache + its CPU allocator + a req_to_token table: admit a
+    request (match_prefix, lock, allocate the new tokens' slots, write its row, cache_unfinished_req), decode steps
+    (alloc_decode / alloc + row write), re-caching between batches, finishing (cache_finished_req), explicit evictions.
+    After every op: the request's row, its cache_protected_len / prefix_indices, both allocator lists and the tree
+    sizes.  This pins the ORCHESTRATION (SURVEY a6 + the request hooks of a16): tests/test_gpu_radix_flow.py replays it
+    through sglang_amd.mem_cache.{allocation, radix_cache, allocator} on the GPU."""
+    from array import array
+
+    from sglang.srt.mem_cache.allocator.paged import PagedTokenToKVPoolAllocator
+    from sglang.srt.mem_cache.allocator.token import TokenToKVPoolAllocator
+
+    rc, bpc, CacheInitParams = _import_ref_radix()
+    rng = np.random.default_rng(seed)
+    size, rows, ctx = 96 * max(page_size, 4), 12, 160
+    alloc = (TokenToKVPoolAllocator(size, torch.bfloat16, "cpu", None, False) if page_size == 1 else
+             PagedTokenToKVPoolAllocator(size, page_size, torch.bfloat16, "cpu", None, False))
+
+    class Pool:
+        def __init__(self):
+            self.req_to_token = torch.zeros((rows, ctx), dtype=torch.int32)
+
+        def write(self, indices, values):
+            self.req_to_token[indices] = values.to(torch.int32)
+
+    pool = Pool()
+    cache = rc.RadixCache(CacheInitParams(disable=False, req_to_token_pool=pool, token_to_kv_pool_allocator=alloc,
+                                          page_size=page_size, eviction_policy="lru"))
+
+    class Req:
+        def __init__(self, rid, toks, row):
+            self.rid, self.origin_input_ids, self.output_ids = rid, list(toks), []
+            self.req_pool_idx, self.extra_key, self.priority = row, None, 0
+            self.prefix_indices, self.last_node, self.cache_protected_len = None, None, 0
+
+        def get_fill_ids(self):
+            return self.origin_input_ids + self.output_ids
+
+    live, free_rows, log, next_rid = {}, list(range(1, rows)), [], [0]
+    stems = [[int(x) for x in rng.integers(0, 50, size=3 * page_size + 5)] for _ in range(3)]
+
+    def snap(req=None):
+        d = dict(free=alloc.free_pages.tolist(), release=alloc.release_pages.tolist(),
+                 sizes=[cache.evictable_size(), cache.protected_size(), cache.total_size()])
+        if req is not None:
+            n = len(req.get_fill_ids())
+            d.update(row=pool.req_to_token[req.req_pool_idx, :n].tolist(), protected=req.cache_protected_len,
+                     prefix_indices=None if req.prefix_indices is None else req.prefix_indices.tolist())
+        return d
+
+    for _ in range(70):
+        op = rng.choice(["new", "decode", "recache", "finish", "evict"], p=[0.3, 0.35, 0.1, 0.17, 0.08])
+        if op == "new" and free_rows:
+            stem = stems[int(rng.integers(0, len(stems)))]
+            toks = stem[: int(rng.integers(1, len(stem) + 1))] + [int(x) for x in rng.integers(50, 60, size=int(rng.integers(1, 2 * page_size + 3)))]
+            req = Req(next_rid[0], toks, free_rows.pop(0))
+            next_rid[0] += 1
+            m = cache.match_prefix(bpc.MatchPrefixParams(key=rc.RadixKey(list(toks), None)))
+            req.prefix_indices, req.last_node = m.device_indices, m.last_device_node
+            cache.inc_lock_ref(req.last_node)
+            pre = len(req.prefix_indices)
+            req.cache_protected_len = pre
+            pool.req_to_token[req.req_pool_idx, :pre] = req.prefix_indices.to(torch.int32)
+            ext = len(toks) - pre
+            if page_size == 1:
+                out = alloc.alloc(ext)
+            else:
+                pl, sl = torch.tensor([pre]), torch.tensor([len(toks)])
+                last = torch.tensor([int(req.prefix_indices[-1]) if pre else -1])
+                out = alloc.alloc_extend(pl, pl, sl, sl, last, ext)
+            assert out is not None
+            pool.req_to_token[req.req_pool_idx, pre: len(toks)] = out.to(torch.int32)
+            cache.cache_unfinished_req(req)
+            live[req.rid] = req
+            log.append(dict(op="new", rid=req.rid, row=req.req_pool_idx, tokens=toks, matched=pre, out=out.tolist(),
+                            after=snap(req)))
+        elif op == "decode" and live:
+            req = live[int(rng.choice(list(live)))]
+            n = len(req.get_fill_ids())
+            if n + 1 >= ctx:
+                continue
+            if page_size == 1:
+                loc = alloc.alloc(1)
+            else:
+                sl = torch.tensor([n + 1])
+                loc = alloc.alloc_decode(sl, sl, torch.tensor([int(pool.req_to_token[req.req_pool_idx, n - 1])]))
+            assert loc is not None
+            pool.req_to_token[req.req_pool_idx, n] = int(loc[0])
+            req.output_ids.append(int(rng.integers(60, 70)))
+            log.append(dict(op="decode", rid=req.rid, loc=loc.tolist(), token=req.output_ids[-1], after=snap(req)))
+        elif op == "recache" and live:
+            req = live[int(rng.choice(list(live)))]
+            cache.cache_unfinished_req(req)
+            log.append(dict(op="recache", rid=req.rid, after=snap(req)))
+        elif op == "finish" and live:
+            req = live.pop(int(rng.choice(list(live))))
+            insert = bool(rng.random() < 0.8)
+            cache.cache_finished_req(req, is_insert=insert, kv_len_to_handle=len(req.get_fill_ids()))
+            free_rows.append(req.req_pool_idx)
+            log.append(dict(op="finish", rid=req.rid, insert=insert, after=snap()))
+        elif op == "evict":
+            n = int(rng.integers(1, 6 * page_size))
+            r = cache.evict(bpc.EvictParams(num_tokens=n))
+            log.append(dict(op="evict", num_tokens=n, evicted=r.num_tokens_evicted, after=snap()))
+    return dict(page_size=page_size, size=size, rows=rows, ctx=ctx, log=log)
+
+
+def f13():
+    cases = [gen_flow(ps, seed) for ps, seed in [(1, 1), (4, 2), (16, 3), (16, 4)]]
+    with open(os.path.join(HERE, "scheduler_flow.json"), "w") as f:
+        json.dump(cases, f)
+    print("wrote scheduler_flow.json", [len(c["log"]) for c in cases])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
     for w in which:
         globals()[w]()

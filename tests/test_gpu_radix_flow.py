@@ -160,3 +160,81 @@ def test_eviction_frees_pages_under_pressure():
         w.r2t.free(r.req_pool_idx)
         assert w.conservation() == total
     assert w.tree.evictable_size() <= 512 and w.pool.check_errors() == 0
+
+
+def test_scheduler_flow_replays_reference_log_bit_exact(golden_dir):
+    """SURVEY a6 + a16's request hooks against a log RECORDED FROM THE REFERENCE (tests/golden/make_golden.py::gen_flow:
+    its RadixCache.cache_unfinished_req / cache_finished_req / match_prefix / evict, its CPU allocators and a
+    req_to_token table driven like the scheduler drives them).  Replayed here through alloc_for_extend /
+    alloc_for_decode (one fused kernel), the native radix tree's rx_radix_cache_req and the device-resident allocator:
+    after EVERY op the request's row, its cache_protected_len / prefix_indices, both allocator lists and the tree's
+    evictable / protected / total sizes are identical."""
+    import json
+    import os
+
+    from sglang_amd.mem_cache.allocation import alloc_for_decode, alloc_for_extend
+    from sglang_amd.mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
+    from sglang_amd.mem_cache.memory_pool import ReqToTokenPool
+    from sglang_amd.mem_cache.radix_cache import EvictParams, MatchPrefixParams, RadixCache, RadixKey, Req
+
+    cases = json.load(open(os.path.join(golden_dir, "scheduler_flow.json")))
+    n_ops = 0
+    for case in cases:
+        ps = case["page_size"]
+        alloc = (TokenToKVPoolAllocator(case["size"], torch.bfloat16, DEV) if ps == 1 else
+                 PagedTokenToKVPoolAllocator(case["size"], ps, torch.bfloat16, DEV))
+        pool = ReqToTokenPool(case["rows"], case["ctx"], DEV)
+        tree = RadixCache(pool, alloc, ps)
+        live = {}
+
+        def check(ent, req=None):
+            a = ent["after"]
+            tag = (ps, ent["op"], ent.get("rid"))
+            assert alloc.free_pages.tolist() == a["free"], tag
+            assert alloc.release_pages.tolist() == a["release"], tag
+            assert [tree.evictable_size(), tree.protected_size(), tree.total_size()] == a["sizes"], tag
+            if req is not None:
+                n = len(req.get_fill_ids())
+                assert pool.req_to_token[req.req_pool_idx, :n].tolist() == a["row"], tag
+                assert req.cache_protected_len == a["protected"], tag
+                assert (None if req.prefix_indices is None else req.prefix_indices.tolist()) == a["prefix_indices"], tag
+
+        for ent in case["log"]:
+            op = ent["op"]
+            if op == "new":
+                toks = ent["tokens"]
+                req = Req(origin_input_ids=list(toks), output_ids=[], req_pool_idx=ent["row"])
+                m = tree.match_prefix(MatchPrefixParams(key=RadixKey(toks, None)))
+                req.prefix_indices, req.last_node = m.device_indices, m.last_device_node
+                tree.inc_lock_ref(req.last_node)
+                pre = len(req.prefix_indices)
+                assert pre == ent["matched"]
+                req.cache_protected_len = pre
+                out, _ = alloc_for_extend([req], [pre], [len(toks)], pool, alloc, tree)
+                assert out.tolist() == ent["out"], (ps, "new", ent["rid"])
+                tree.cache_unfinished_req(req)
+                live[ent["rid"]] = req
+                check(ent, req)
+            elif op == "decode":
+                req = live[ent["rid"]]
+                n = len(req.get_fill_ids())
+                rpi = torch.tensor([req.req_pool_idx], dtype=torch.int64, device=DEV)
+                seq = torch.tensor([n], dtype=torch.int64)
+                loc = alloc_for_decode(rpi, seq.to(DEV), seq, pool, alloc, tree)
+                assert loc.tolist() == ent["loc"], (ps, "decode", ent["rid"])
+                req.output_ids.append(ent["token"])
+                check(ent, req)
+            elif op == "recache":
+                req = live[ent["rid"]]
+                tree.cache_unfinished_req(req)
+                check(ent, req)
+            elif op == "finish":
+                req = live.pop(ent["rid"])
+                tree.cache_finished_req(req, is_insert=ent["insert"], kv_len_to_handle=len(req.get_fill_ids()))
+                check(ent)
+            elif op == "evict":
+                r = tree.evict(EvictParams(num_tokens=ent["num_tokens"]))
+                assert r.num_tokens_evicted == ent["evicted"]
+                check(ent)
+            n_ops += 1
+    assert n_ops > 200
