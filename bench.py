@@ -618,16 +618,29 @@ def mla_decode_bench(dev):
         def run():
             ops.decode_attention_fwd_paged(q, kv, kv[..., :dv], o, r2t, rpi, lens, al, lse, nsplit, S, dk ** -0.5,
                                            page_size=ps)
-        for _ in range(3):
-            run()
+        # 10 calls captured into one HIP graph: the op is ~75-125 us of GPU work and the generic Python wrapper costs
+        # about as much per call, so eager timing would measure the host
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(10):
+                run()
+        gr.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20):
-            run()
+        for _ in range(3):
+            gr.replay()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 20
+        ms = e0.elapsed_time(e1) / 30
+        del gr
         byt = bs * ctx * dk * (1 if fp8 else 2) + bs * hq * (dk + dv) * 2
         res[name] = {"us": ms * 1e3, "bytes": byt,
                      "roofline": {"bound": "hbm", "achieved": byt / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,19 +1,25 @@
 #!/bin/bash
 # Reproduces the committed profiles/ set on an MI355X box:  bash tools/profile_round.sh <tag>
 # (run through gpurun; then `python profiles/summarize.py gpurun_out/prof <tag>` condenses the CSVs)
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-radix-hit --steps 2 --warmup 1 > $OUT/${TAG}_bench_under_kernel_trace.json 2> $OUT/kt.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pf --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pf.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pw --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pw.err
+# counter passes: eager launches (--no-graph), one counter family per pass, nothing but --pmc on the command line
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pf --output-format csv -- python3 $R/bench.py --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pf.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pw --output-format csv -- python3 $R/bench.py --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pw.err
 python3 $R/profiles/summarize.py $OUT $TAG
+# MLA decode (config 5 shape): kernel traces for 16-bit and fp8 latent rows
+rocprofv3 --kernel-trace --stats -d $OUT/mla16 -o m --output-format csv -- python3 $R/tools/mla_bench.py > $OUT/mla16.txt 2> $OUT/mla16.err
+FP8=1 rocprofv3 --kernel-trace --stats -d $OUT/mla8 -o m --output-format csv -- python3 $R/tools/mla_bench.py > $OUT/mla8.txt 2> $OUT/mla8.err
+cp $(find $OUT/mla16 -name "*_kernel_stats.csv" | head -1) $R/profiles/${TAG}_mla_bf16_kernel_stats.csv 2>/dev/null
+cp $(find $OUT/mla8 -name "*_kernel_stats.csv" | head -1) $R/profiles/${TAG}_mla_fp8_kernel_stats.csv 2>/dev/null
 # shared-prefix (cascade) decode: per-kernel times of the radix-hit batch (plain vs cascade, 4 layer buffers)
 rocprofv3 --kernel-trace --stats -d $OUT/casc -o casc --output-format csv -- python3 $R/tools/cascade_bench.py > $OUT/${TAG}_cascade_bench.txt 2> $OUT/casc.err
 cp $OUT/casc/casc_kernel_stats.csv $R/profiles/${TAG}_cascade_kernel_stats.csv 2>/dev/null
 cp $OUT/${TAG}_bench_default.json $OUT/${TAG}_bench_under_kernel_trace.json $R/gpurun_out/ 2>/dev/null
-mkdir -p $R/gpurun_out/profiles_new && cp $R/profiles/${TAG}_kernel_stats.csv $R/profiles/${TAG}_pmc_summary.json $R/profiles/${TAG}_cascade_kernel_stats.csv $OUT/${TAG}_cascade_bench.txt $R/gpurun_out/profiles_new/ 2>/dev/null
+mkdir -p $R/gpurun_out/profiles_new && cp $R/profiles/${TAG}_kernel_stats.csv $R/profiles/${TAG}_pmc_summary.json $R/profiles/${TAG}_cascade_kernel_stats.csv $R/profiles/${TAG}_mla_bf16_kernel_stats.csv $R/profiles/${TAG}_mla_fp8_kernel_stats.csv $OUT/${TAG}_cascade_bench.txt $OUT/mla16.txt $OUT/mla8.txt $R/gpurun_out/profiles_new/ 2>/dev/null
 tail -c 1500 $OUT/${TAG}_bench_default.json
