@@ -44,7 +44,11 @@ struct ExtNdArgs {
 
 template <int DK, int DV>
 struct NdGeom {
-  static constexpr int CB = (DV > 128) ? 1 : 2;        // 16-query blocks per wave
+#ifndef RX_ND_WIDE256
+#define RX_ND_WIDE256 0
+#endif
+  static constexpr int CB = (DV > 128 && !RX_ND_WIDE256) ? 1 : 2;  // 16-query blocks per wave
+  static constexpr int MINW = (DV > 128 && RX_ND_WIDE256) ? 1 : 2;  // waves per SIMD to allocate registers for
   static constexpr int TT = (DK > 128) ? 32 : 64;      // tokens per staged tile
   static constexpr int KROW = DK * 2, VROW = DV * 2;   // bytes per row
   // padded LDS rows: K rows step an odd number of 16-B chunks (the 16 rows of one ds_read_b128 pass land on 16
@@ -63,7 +67,7 @@ __device__ __forceinline__ int64_t nd_slot_off(int64_t slot, int32_t shift, int3
 }
 
 template <typename T, int DK, int DV>
-__global__ __launch_bounds__(256, 2) void extend_nd_kernel(const ExtNdArgs a) {
+__global__ __launch_bounds__(256, (NdGeom<DK, DV>::MINW)) void extend_nd_kernel(const ExtNdArgs a) {
   using G = NdGeom<DK, DV>;
   using vec8 = typename T::vec8;
   constexpr int CB = G::CB, TT = G::TT;
