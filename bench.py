@@ -279,9 +279,10 @@ class GraphStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.ga, self.gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.ga):
+        # thread_local: the process group's watchdog thread may make HIP calls while this thread captures
+        with torch.cuda.graph(self.ga, capture_error_mode="thread_local"):
             seg_a()
-        with torch.cuda.graph(self.gb, pool=self.ga.pool()):
+        with torch.cuda.graph(self.gb, pool=self.ga.pool(), capture_error_mode="thread_local"):
             seg_b()
 
     def _probe(self, ev_pairs=None):
@@ -544,6 +545,9 @@ def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=8):
     k_ext = torch.randn(T, HKV, D, device=dev, generator=g).to(torch.bfloat16)
     v_ext = torch.randn(T, HKV, Dv, device=dev, generator=g).to(torch.bfloat16)
     o = torch.empty(T, HQ, Dv, device=dev, dtype=torch.bfloat16)
+    if os.environ.get("RX_EXTEND_ZERO"):  # dev: all-zero operands -- same instruction stream, minimal switching power:
+        for t_ in (kb, vb, q, k_ext, v_ext):  # separates "cycles" from "clock held under load" (DVFS)
+            t_.zero_()
     pages = torch.randperm(n_pages - 1, device=dev, generator=g)[: (P + ps - 1) // ps] + 1
     prefix_slots = (pages[:, None] * ps + torch.arange(ps, device=dev)[None, :]).reshape(-1)[:P].to(torch.int64)
     kv_indices = prefix_slots.repeat(chunk)  # identical rows: every request hits the same pages
@@ -664,7 +668,7 @@ def rccl_capturable(dev) -> bool:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         x.fill_(1.0)
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             dist.all_reduce(x)
         g.replay()
         torch.cuda.synchronize()

@@ -24,6 +24,12 @@
 #ifndef RX_EXT32_SMALL_WG_TILES
 #define RX_EXT32_SMALL_WG_TILES 28  // below this many estimated tiles per workgroup: 128-query workgroups
 #endif
+#ifndef RX_EXT32_FINE
+#define RX_EXT32_FINE 0  // 1: eight-wave form on the fine-grained (one softmax unit per MFMA) two-tile-deep pipeline
+#endif
+#ifndef RX_EXT32_KA
+#define RX_EXT32_KA 2  // K fragments (ds_read_b128) in flight ahead of their QK^T MFMA in the eight-wave fast loop
+#endif
 #ifndef RX_EXT32_PRIO
 #define RX_EXT32_PRIO 0
 #endif
@@ -188,6 +194,10 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   constexpr int KS = kD / 16;                  // 8 k-steps of the QK^T product
   constexpr int DB = kD / 32;                  // 4 output d blocks of 32
   constexpr bool AG = QB > 1;                  // O^T accumulators pinned to AGPRs (pv_mfma)
+  // FINE: the two-tile-deep pipeline with ONE softmax unit behind EVERY MFMA (written for the AGPR form) also for the
+  // eight-wave form: its 7 slices of ~13 VALU behind the MFMAs of two of the four groups overflow a 32-cycle MFMA gap
+  // (the other two groups' gaps stay empty), 16 units of 1-2 exp spread the same work over all 32 gaps
+  constexpr bool FINE = AG || (RX_EXT32_FINE && NW == 8);
   constexpr int THREADS = 64 * NW;
   constexpr int RPP = THREADS / 16;            // rows staged per pass
   constexpr int NPASS = kTok / RPP;            // 2 (NW=8) or 4 (NW=4)
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   // DEEP (eight-wave form): tiles are written TWO ahead into a ring of three, so tile t+1 is complete one barrier
   // early and a wave reads its first K fragments of tile t+1 BEFORE barrier t+1 -- the QK^T group then starts on
   // registers instead of waiting out an LDS round trip with both waves of the SIMD stalled the same way.
-  constexpr bool RING3 = !AG && NW == 8 && RX_EXT32_DEEP >= 1;
+  constexpr bool RING3 = !FINE && NW == 8 && RX_EXT32_DEEP >= 1;
   constexpr bool DEEP = RING3 && RX_EXT32_DEEP == 1;   // cross-barrier K prefetch on top of the deeper ring
   // STAGGER: with tiles complete one barrier early, the second-dispatched half of the workgroup (waves 4-7, the
   // SIMD partners of waves 0-3) takes its one barrier per tile AFTER the QK^T group instead of before it.  Same
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   // t+2 overwrites its buffer.
   constexpr bool STAGGER = RING3 && RX_EXT32_DEEP == 3;
   constexpr int AHEAD = RING3 ? 2 : 1;         // tile t + AHEAD is written during tile t
-  constexpr int RING = (AG || RING3) ? 3 : 2;   // LDS tile ring (the AG pipeline reads tile t-1's V after barrier t)
+  constexpr int RING = (FINE || RING3) ? 3 : 2;   // LDS tile ring (the AG pipeline reads tile t-1's V after barrier t)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
 
   const int tid = threadIdx.x;
@@ -532,7 +542,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   int t = 0;
   while (t < nt) {
 
-    if constexpr (AG) {
+    if constexpr (FINE) {
       // ===== one wave per SIMD (QB = 2): a two-tile-deep pipeline with ONE small filler behind EVERY MFMA.
       // A single in-order wave hides VALU work only inside the 32-cycle shadow of the MFMA it follows (about
       // 24 cycles of issue; MI355X_MICROARCH.md 'vector-instruction ISSUE cost'): two MFMAs back to back just
@@ -703,7 +713,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
               if (g < DB) pv_mfma<T, AG>(vfa[g], pk1[qb][0], oacc[qb][g]);
               else pv_mfma<T, AG>(vfb[g - DB], pk1[qb][1], oacc[qb][g - DB]);
               sm_unit(8 + g, qb, s0[qb], ma0[qb], mb0[qb], m1[qb], m0[qb], alpha0[qb], ps0[qb], pk0[qb], c2r, vsr);
-              if (qb == 1 && !(RX_EXT32_ABL & (4 | 32))) write_lds_piece((t + 1) % RING, t + 1 < nt1, g);
+              if (qb == QB - 1 && g < 2 * NPASS && !(RX_EXT32_ABL & (4 | 32))) write_lds_piece((t + 1) % RING, t + 1 < nt1, g);
               __builtin_amdgcn_sched_barrier(0);
             }
             if (g >= DB && g < DB + 2) {  // tile t's rows 0..15 for G4
@@ -758,11 +768,11 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
                 if (g < DB) pv_mfma<T, AG>(vfa[g], pk0[qb][0], oacc[qb][g]);
                 else pv_mfma<T, AG>(vfb[g - DB], pk0[qb][1], oacc[qb][g - DB]);
                 sm_unit(g, qb, s1[qb], ma1[qb], mb1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], c2r, vsr);
-                if (g < NPASS && !(RX_EXT32_ABL & (4 | 64))) reissue(g, qb);
+                if (g * QB + qb < 2 * NPASS && !(RX_EXT32_ABL & (4 | 64))) reissue((g * QB + qb) >> 1, (g * QB + qb) & 1);
                 __builtin_amdgcn_sched_barrier(0);
               }
             }
-            static_assert(2 * NPASS == 2 * DB && QB == 2, "staging pieces fit the PV groups");
+            static_assert(2 * NPASS <= 2 * DB * QB, "staging pieces fit the PV groups");
           }
           load_idx_tile(t + 3);
           tile_p = tile;
@@ -795,7 +805,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     // work between the end of a tile and its barrier), and it may reach the very last tile: staging past the end is
     // harmless (see has_ext above).
     int fe = t;
-    if constexpr (!AG) {
+    if constexpr (!FINE) {
       const TileInfo ti0 = tile_info(t);
       if (ti0.fast) {  // the tile-independent conditions hold; the rest is "both blocks inside the visible range"
         if (t < nt1) fe = min(nt1, (causal_in_list ? min(p_len, q_off + qbase + 1) : p_len) / kTok);
@@ -813,7 +823,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       }
     }
     const bool late = STAGGER && w >= NW / 2;  // wave-uniform
-    for (; !AG && t < fe; ++t) {
+    for (; !FINE && t < fe; ++t) {
       RX_STAMP(5);
       if (!late) __syncthreads();
       RX_STAMP(0);
@@ -892,14 +902,14 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
         }
       };
       {
-        u32x4 kf[2 * KS + 1];
-        constexpr int KA = DEEP ? 3 : 2;  // K fragments in flight ahead of the MFMA that consumes them
+        u32x4 kf[2 * KS + 8];
+        constexpr int KA = DEEP ? 3 : RX_EXT32_KA;  // K fragments in flight ahead of the MFMA that consumes them
         if constexpr (DEEP) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) kf[i] = kpre[i];
         } else {
-          kf[0] = load_k(tile, 0, 0);
-          kf[1] = load_k(tile, 0, 1);
+#pragma unroll
+          for (int i = 0; i < KA; ++i) kf[i] = load_k(tile, i >> 3, i & 7);
         }
 #pragma unroll
         for (int i = 0; i < 2 * KS; ++i) {
@@ -1032,7 +1042,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     RX_STAMP(5);
     for (; t < nt; ++t) {
       const TileInfo ti = tile_info(t);
-      if (ti.fast && (!AG || t + 3 < nt)) break;
+      if (ti.fast && (!FINE || t + 3 < nt)) break;
       tile_sync_and_stage(t);
       if (!ti.work) continue;
       const char* tile = smem + (t % RING) * kBufBytes;
@@ -1177,7 +1187,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 template <int NW, int QB, bool KV8, bool PLAIN>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
-  constexpr unsigned kLds = ((QB > 1 || (NW == 8 && RX_EXT32_DEEP >= 1)) ? 3 : 2) * kBufBytes;  // 74 / 111 KiB: above the 64 KiB static limit, hence dynamic
+  constexpr unsigned kLds = ((QB > 1 || (NW == 8 && (RX_EXT32_DEEP >= 1 || RX_EXT32_FINE))) ? 3 : 2) * kBufBytes;  // 74 / 111 KiB: above the 64 KiB static limit, hence dynamic
 #define RX_E32(TT, IT, LIN, VS)                                                                        \
   do {                                                                                                 \
     auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB, KV8, PLAIN>;                             \
