@@ -753,25 +753,33 @@ def merge_state(a, lse_a, b, lse_b):
 
 
 def sdpa_decode_req_to_token(q, k_cache, v_cache, req_to_token, req_pool_indices,
-                             seq_lens, scaling):
+                             seq_lens, scaling, sliding_window_size=-1):
     """_run_sdpa_forward_decode (:176-277): per request, K/V =
-    cache[req_to_token[req_pool_idx, :seq_len]], one query token, no mask."""
-    kv_indptr, kv_indices = build_kv_indices(req_to_token, req_pool_indices, seq_lens)
+    cache[req_to_token[req_pool_idx, :seq_len]], one query token at position seq_len - 1, no mask; with a sliding
+    window W the mask of _make_sliding_window_mask (:36-48): keys q_pos - W .. q_pos (W + 1 of them)."""
+    seq_lens = np.asarray(seq_lens, dtype=np.int64)
+    if sliding_window_size is None or sliding_window_size < 0:
+        kv_indptr, kv_indices = build_kv_indices(req_to_token, req_pool_indices, seq_lens)
+    else:
+        wl = np.minimum(seq_lens, sliding_window_size + 1)
+        kv_indptr, kv_indices = build_kv_indices(req_to_token, req_pool_indices, wl, kv_start=seq_lens - wl)
     return decode_attention(q, k_cache, v_cache, kv_indptr, kv_indices, scaling)
 
 
 def sdpa_extend_req_to_token(q, k_cache, v_cache, req_to_token, req_pool_indices,
                              seq_lens, extend_prefix_lens, extend_seq_lens, scaling,
-                             causal=True):
+                             causal=True, sliding_window_size=-1):
     """_run_sdpa_forward_extend (:61-174): the new tokens' K/V are read back from
     the cache (they were stored before the call), queries sit at positions
-    prefix..seq-1 of a causal mask over the whole sequence."""
+    prefix..seq-1 of a causal mask over the whole sequence; with a sliding window W the mask
+    (k_pos <= q_pos) & (k_pos >= q_pos - W) replaces the causal one (:147-157)."""
     t, hq, _ = q.shape
     hkv = k_cache.shape[-2]
     group = hq // hkv
     dv = v_cache.shape[-1]
     qf = to_f64(q)
     o = np.zeros((t, hq, dv), dtype=np.float64)
+    windowed = sliding_window_size is not None and sliding_window_size >= 0
     start = 0
     for i in range(len(seq_lens)):
         e, pre, seq = int(extend_seq_lens[i]), int(extend_prefix_lens[i]), int(seq_lens[i])
@@ -781,10 +789,11 @@ def sdpa_extend_req_to_token(q, k_cache, v_cache, req_to_token, req_pool_indices
             vv = _gather_kv(v_cache, idx, kvh)
             for h in range(kvh * group, (kvh + 1) * group):
                 for m in range(e):
-                    n_end = pre + m + 1 if causal else seq
-                    s = kk[:n_end] @ qf[start + m, h] * scaling
+                    n_end = pre + m + 1 if (causal or windowed) else seq
+                    n_lo = max(0, pre + m - sliding_window_size) if windowed else 0
+                    s = kk[n_lo:n_end] @ qf[start + m, h] * scaling
                     p = np.exp(s - s.max())
-                    o[start + m, h] = (p @ vv[:n_end]) / p.sum()
+                    o[start + m, h] = (p @ vv[n_lo:n_end]) / p.sum()
         start += e
     return o
 

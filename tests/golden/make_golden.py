@@ -15,6 +15,7 @@ Fixture families:
   F5 decode attention (Triton decode_attention_fwd) -> decode_*.npz
   F6 extend attention (Triton extend_attention_fwd) -> extend_*.npz
   F7 radix tree op sequences (reference RadixCache, recording allocator) -> radix_sequences.json
+  F14 the reference's torch-native SDPA helpers (a14) on fp32 tensors -> torch_native.npz
   F13 scheduler flow (reference RadixCache request hooks + allocators + req_to_token rows) -> scheduler_flow.json
   F8 bf16 decode/extend from the compiled reference C++ CPU kernels -> cpu_native.npz
   F10 decode with the xai temperature -> decode_xai.npz
@@ -867,7 +868,67 @@ def f13():
     print("wrote scheduler_flow.json", [len(c["log"]) for c in cases])
 
 
+# ------------------------------------------------------------------ F14
+def _ref_torch_native():
+    """The two SDPA helpers of the reference's TorchNativeAttnBackend (torch_native_backend.py:36-277) as a class that
+    can be instantiated here: the module itself does not import (forward_batch_info -> configs -> torchvision), but the
+    three methods are torch-only, so they are cut out of the reference FILE with ast at generation time and executed --
+    nothing of their text is stored, only the vectors they produce."""
+    import ast
+    import typing
+
+    path = os.path.join(_ref_import.REF_PY, "sglang/srt/layers/attention/torch_native_backend.py")
+    tree = ast.parse(open(path).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "TorchNativeAttnBackend")
+    keep = [n for n in cls.body if isinstance(n, ast.FunctionDef) and
+            n.name in ("_make_sliding_window_mask", "_run_sdpa_forward_extend", "_run_sdpa_forward_decode")]
+    assert len(keep) == 3, [n.name for n in keep]
+    mod = ast.Module(body=[ast.ClassDef(name="RefTorchNative", bases=[], keywords=[], body=keep, decorator_list=[])],
+                     type_ignores=[])
+    ns = {"torch": torch, "Optional": typing.Optional,
+          "scaled_dot_product_attention": torch.nn.functional.scaled_dot_product_attention}
+    exec(compile(ast.fix_missing_locations(mod), path, "exec"), ns)
+    return ns["RefTorchNative"]()
+
+
+def f14():
+    """a14: outputs of the reference's torch-native SDPA helpers on fp32 CPU tensors (so that the comparison with the
+    fp64 oracle is tight): ragged extend over cached prefixes with GQA, decode, and both under a sliding window."""
+    ref = _ref_torch_native()
+    g = torch.Generator().manual_seed(14)
+    flat = {}
+    for name, hq, hkv, d, window in (("gqa", 8, 2, 64, None), ("mha", 4, 4, 32, None), ("mqa_window", 4, 1, 64, 5),
+                                     ("gqa_window", 8, 2, 64, 17)):
+        prefix = [0, 7, 33, 16]
+        ext = [5, 1, 20, 16]
+        seq = [p + e for p, e in zip(prefix, ext)]
+        pool = sum(seq) + 9
+        perm = torch.randperm(pool - 1, generator=g) + 1
+        r2t = torch.zeros(6, 64, dtype=torch.int64)
+        rows, o = [3, 1, 4, 2], 0
+        for r, n in zip(rows, seq):
+            r2t[r, :n] = perm[o: o + n]
+            o += n
+        kc = torch.randn(pool, hkv, d, generator=g)
+        vc = torch.randn(pool, hkv, d, generator=g)
+        T = sum(ext)
+        q = torch.randn(T, hq, d, generator=g)
+        rpi = torch.tensor(rows)
+        out = ref._run_sdpa_forward_extend(q, torch.zeros(T, hq, d), kc, vc, r2t, rpi, torch.tensor(seq),
+                                           torch.tensor(prefix), torch.tensor(ext), scaling=d ** -0.5,
+                                           enable_gqa=hq != hkv, causal=True, sliding_window_size=window)
+        qd = torch.randn(len(seq), hq, d, generator=g)
+        outd = ref._run_sdpa_forward_decode(qd, torch.zeros(len(seq), hq, d), kc, vc, r2t, rpi, torch.tensor(seq),
+                                            scaling=d ** -0.5, enable_gqa=hq != hkv, causal=False,
+                                            sliding_window_size=window)
+        c = dict(q=q, qd=qd, kc=kc, vc=vc, r2t=r2t, rpi=rpi, seq=torch.tensor(seq), prefix=torch.tensor(prefix),
+                 ext=torch.tensor(ext), window=-1 if window is None else window, o_extend=out, o_decode=outd)
+        for k, v in c.items():
+            flat[f"{name}.{k}"] = v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    save("torch_native.npz", **flat)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14"]
     for w in which:
         globals()[w]()

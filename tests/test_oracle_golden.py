@@ -338,3 +338,25 @@ def test_cpu_baseline_container_fixture(golden_dir):
     for k in ("reference", "port"):
         assert d[k]["ms_per_layer"] > 0 and abs(d[k]["value"] - 256 / (32 * d[k]["ms_per_layer"] * 1e-3)) < 1e-6
     assert d["parity_max_abs_reference_vs_port_small_case"] <= 2e-3  # bf16 outputs of two summation orders
+
+
+def test_a14_torch_native_semantics_pinned_to_the_reference(golden_dir):
+    """a14, pinned DIRECTLY: outputs of the reference's own TorchNativeAttnBackend._run_sdpa_forward_extend /
+    _run_sdpa_forward_decode (torch_native_backend.py:61-277; executed from the reference file by
+    tests/golden/make_golden.py::f14 on fp32 tensors) vs the oracle's restatement -- ragged extend over cached
+    prefixes, decode, GQA / MHA / MQA, and both under a sliding window (_make_sliding_window_mask :36-48)."""
+    npz = np.load(os.path.join(golden_dir, "torch_native.npz"))
+    cases = {}
+    for key in npz.files:
+        case, field = key.split(".", 1)
+        cases.setdefault(case, {})[field] = npz[key]
+    assert set(cases) == {"gqa", "mha", "mqa_window", "gqa_window"}
+    for name, c in cases.items():
+        d = c["q"].shape[-1]
+        w = int(c["window"])
+        got = orc.sdpa_extend_req_to_token(c["q"], c["kc"], c["vc"], c["r2t"], c["rpi"], c["seq"], c["prefix"], c["ext"],
+                                           d ** -0.5, causal=True, sliding_window_size=w)
+        assert np.abs(got - c["o_extend"].astype(np.float64)).max() < 5e-6, name
+        gotd = orc.sdpa_decode_req_to_token(c["qd"], c["kc"], c["vc"], c["r2t"], c["rpi"], c["seq"], d ** -0.5,
+                                            sliding_window_size=w)
+        assert np.abs(gotd - c["o_decode"].astype(np.float64)).max() < 5e-6, name
