@@ -416,5 +416,8 @@ class PagedTokenToKVPoolAllocator(BaseTokenToKVPoolAllocator):
             self._debug_check_no_duplicate_pages()
 
     def _debug_check_no_duplicate_pages(self):
-        pages = torch.cat((self.free_pages, self.release_pages))
-        assert pages.unique().numel() == pages.numel(), "a page sits in the free lists twice"
+        """debug_mode only (synchronises): after sorting, no two neighbours of free + release may be equal."""
+        ids, _ = torch.sort(torch.cat((self._list.snapshot(FREE, self._free_count()),
+                                       self._list.snapshot(RELEASE, self._release_count()))))
+        if ids.numel() > 1 and bool((ids[1:] == ids[:-1]).any()):
+            raise AssertionError("a page sits in the free lists twice")
