@@ -741,10 +741,27 @@ def main():
     no_events = bool(os.environ.get("RX_BENCH_NO_EVENTS"))
 
     def make_step():
-        if use_graph:
+        nonlocal use_graph, graph_note
+        eager = lambda: decode_step(st, fb, world, ev_pairs if (timed["on"] and not no_events) else None)  # noqa: E731
+        if not use_graph:
+            return eager
+        gs, err = None, None
+        try:
             gs = GraphStep(st, fb, world)
-            return lambda: gs(ev_pairs if (timed["on"] and not no_events) else None)
-        return lambda: decode_step(st, fb, world, ev_pairs if (timed["on"] and not no_events) else None)
+        except Exception as e:  # noqa: BLE001 -- a stack that cannot capture this step still gets measured, eagerly
+            err = f"{type(e).__name__}: {e}"
+            print(f"[bench] HIP-graph capture of the decode step failed ({err}); eager step", file=sys.stderr)
+        if world > 1:  # every rank takes the same path
+            import torch.distributed as dist
+
+            ok = torch.tensor([0 if gs is None else 1], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not bool(ok.item()):
+                gs = None
+        if gs is None:
+            use_graph, graph_note = False, "capture of the decode step failed: " + (err or "on another rank")
+            return eager
+        return lambda: gs(ev_pairs if (timed["on"] and not no_events) else None)
 
     # A timed event pair costs ~40 us of host time: invisible next to a 700-us TP=1 layer, but a TP shard's
     # layer is ~100 us of GPU work; eager sharded runs therefore time every 8th layer (graph mode: one probe

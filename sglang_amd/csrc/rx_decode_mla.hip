@@ -58,6 +58,7 @@ struct MlaArgs {
 #ifndef RX_MLA_PD
 #define RX_MLA_PD 4  // K-fragment prefetch distance (LDS reads in flight ahead of the MFMA)
 #endif
+typedef int v2i_t __attribute__((ext_vector_type(2)));
 constexpr int kMlaDk = 576, kMlaDv = 512;
 constexpr int kMlaTile = 32;
 constexpr int kMlaRowBytes = kMlaDk * 2;          // 1152
@@ -427,6 +428,309 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp8 latent rows, second form (round 2): the LDS image STAYS fp8 and the rows arrive by LDS-DMA.
+//
+// The first form above upcasts while staging (global -> registers -> 16-bit LDS image); with fp8 rows it moves half
+// the bytes through the same per-tile path and spends its largest phase ("staging": wait for the rows, 36 converts and
+// 9 ds_write_b128 per thread, re-issue) off the memory system: 4.0-4.4 TB/s.  Here
+//   * a tile of 32 rows is 32 x 592 B in LDS (576 data + 16 pad) -- three tiles in a ring are 60 KB, two workgroups
+//     per CU -- and is filled by `global_load_lds_dwordx4` (1 KiB per wave instruction, per-lane source address =
+//     row gather): no staging registers, no ds_write, no convert on the way in, and TWO tiles in flight per workgroup;
+//   * the upcast moves to the fragment reads and costs the same number of converts as before because the four-way
+//     score split reads every K element exactly once: K fragments by ds_read_b64 (8 fp8 -> one 16-bit MFMA operand),
+//     V^T fragments by ONE ds_read_b64_tr_b8 each (per 16 lanes: lane 2q + p supplies the address of row q, bytes
+//     8p .. 8p+7; lane i receives byte column i of the 8 rows -- measured, tools/probe/tr8_probe.hip).  S^T row
+//     rho = 4 g + i of token block bb is mapped to tile row 8 g + 4 bb + i, so that the eight k-slots of a lane
+//     group's P fragment are the CONTIGUOUS rows 8 g .. 8 g + 7 the transposed read delivers;
+//   * the rows' slot ids come from LDS (1024 tokens staged at a time), so the steady-state loop issues no VMEM
+//     instruction but the DMA pieces and `s_waitcnt vmcnt(5)` means exactly "tile t has landed, tile t+1 may fly".
+// hipcc neither counts nor orders the asm DMA: every wait on it is written out below.
+constexpr int kM8Row = 592;                    // LDS row stride of the fp8 image
+constexpr int kM8Cpr = kM8Row / 16;            // 37 chunks per row (36 data + 1 pad)
+constexpr int kM8Pieces = 20;                  // 1-KiB DMA pieces per tile buffer: 5 per wave (18.5 carry data)
+constexpr int kM8Buf = kM8Pieces * 1024;       // 20 KB
+#ifndef RX_M8_DBG
+#define RX_M8_DBG 0  // dev: 1 = DMA and waits only, 2 = compute only (no DMA in the loop); results are wrong
+#endif
+#ifndef RX_M8_RING
+#define RX_M8_RING 3  // tile buffers; RING - 1 tiles are in flight or resident ahead of the one being read
+#endif
+constexpr int kM8Ring = RX_M8_RING;
+constexpr int kM8Ahead = kM8Ring - 1;
+constexpr int kM8SlotBlock = 1024;             // tokens whose slot ids are staged in LDS at a time
+constexpr int kM8Lds = kM8Ring * kM8Buf + 4 * 64 * 16 + 2 * kM8SlotBlock * 4;
+
+// one 1-KiB LDS-DMA piece: lane l's 16 bytes land at lds_dst + 16 l (recipe: cdna_hip_programming.md 5.7)
+__device__ __forceinline__ void m8_dma16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <typename T, typename IdxT, bool LINEAR>
+__global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_kernel(const MlaArgs a) {
+  using vec8 = typename T::vec8;
+  constexpr int KS = kMlaDk / 32;       // 18 k-steps
+  constexpr int NBW = kMlaDv / 16 / 4;  // 8 d-blocks of 16 per wave
+  constexpr int KSW = KS / 2;           // k-steps of this wave's score part
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 tiles][exchange][2 slot blocks]
+  char* const xch_base = smem + kM8Ring * kM8Buf;
+  int32_t* const slots_lds = reinterpret_cast<int32_t*>(xch_base + 4 * 64 * 16);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  int qb, b, split;
+  {
+    const int G = a.qblocks;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    qb = j % G;
+    const int pr = (j / G) * 8 + xcd;  // (request, split) pair, bound to one XCD (see the first form)
+    if (pr >= a.bs * a.max_kv_splits) return;
+    b = pr % a.bs;
+    split = pr / a.bs;
+  }
+  int32_t seq_len;
+  const IdxT* idx;
+  if (a.kv_indices) {
+    const int32_t beg = a.kv_indptr[b];
+    seq_len = a.kv_indptr[b + 1] - beg;
+    idx = reinterpret_cast<const IdxT*>(a.kv_indices) + beg;
+  } else {
+    const int64_t req = load_idx(a.req_pool_indices, b, a.rpi64);
+    seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
+    idx = reinterpret_cast<const IdxT*>(a.req_to_token + req * a.req_row_stride);
+  }
+  const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
+  const bool single = (a.max_kv_splits == 1);
+  const int h = qb * 16 + r;
+  const bool q_valid = h < a.hq;
+  if (split >= splits) return;
+  const int32_t per = ((seq_len + splits - 1) / splits + 31) / 32 * 32;
+  const int32_t lo = per * split;
+  const int32_t hi = min(lo + per, seq_len);
+  if (hi <= lo) {
+    if (single && seq_len == 0)
+      for (int i = tid; i < 16 * kMlaDv; i += 256) {
+        const int q = i / kMlaDv, d = i % kMlaDv;
+        if (qb * 16 + q < a.hq) a.o[b * a.o_stride_t + (qb * 16 + q) * a.o_stride_h + d] = 0;
+      }
+    return;
+  }
+  const int ntiles = (hi - lo + kMlaTile - 1) / kMlaTile;
+
+  // ---- Q^T fragments of this wave's k-steps
+  const int ks0 = KSW * (w >> 1);
+  vec8 qf[KSW];
+  {
+    const uint16_t* qp = a.q + b * a.q_stride_t + (q_valid ? h : 0) * a.q_stride_h + 8 * g + 32 * ks0;
+#pragma unroll
+    for (int s = 0; s < KSW; ++s) {
+      u32x4 raw = q_valid ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
+      qf[s] = __builtin_bit_cast(vec8, raw);
+    }
+  }
+  // ---- slot ids of the first block of tokens -> LDS
+  auto stage_slots = [&](int blk) {  // tokens [blk * 1024, +1024) of this split -> slot block blk & 1
+    int32_t* dst = slots_lds + (blk & 1) * kM8SlotBlock;
+#pragma unroll
+    for (int i = 0; i < kM8SlotBlock / 256; ++i) {
+      const int tok = blk * kM8SlotBlock + tid + 256 * i;
+      dst[tid + 256 * i] = static_cast<int32_t>(idx[min(lo + tok, hi - 1)]);
+    }
+  };
+  stage_slots(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q and the slot ids have landed; nothing of ours is in flight yet
+  __syncthreads();
+
+  // ---- DMA of one tile: wave w issues pieces w, w + 4, ..., 5 per wave (the last ones carry padding only)
+  // The five slot ids a lane needs for a tile are read from LDS ONE iteration before the tile is issued, so the issue
+  // is five address computations and five DMA instructions with no LDS round trip between them.
+  const uint8_t* kvb = reinterpret_cast<const uint8_t*>(a.kv_buf);
+  constexpr int NP = kM8Pieces / 4;
+  int prow[NP], pcol[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = min((w + 4 * i) * 64 + lane, kMlaTile * kM8Cpr - 1);  // chunk of the padded image; the tail repeats the last
+    prow[i] = c / kM8Cpr;
+    pcol[i] = 16 * min(c % kM8Cpr, kM8Cpr - 2);  // pad chunk: re-reads the row's last data chunk
+  }
+  int32_t pslot[NP];
+  auto read_slots = [&](int t) {
+    const int32_t* sl = slots_lds + ((t * kMlaTile / kM8SlotBlock) & 1) * kM8SlotBlock + (t * kMlaTile) % kM8SlotBlock;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pslot[i] = sl[prow[i]];
+  };
+  auto dma_tile = [&](int t) {  // uses pslot (tile t's)
+    const uint32_t buf = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)) + (t % kM8Ring) * kM8Buf;
+    const uint8_t* src[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      src[i] = kvb + mla_slot_off<LINEAR>(static_cast<int64_t>(pslot[i]), a.page_size, a.page_stride, a.tok_stride) + pcol[i];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) m8_dma16(src[i], __builtin_amdgcn_readfirstlane(buf + (w + 4 * i) * 1024));
+  };
+  // tiles past the end are "loaded" as well (their rows clamp to the last token): the counted waits stay uniform
+#pragma unroll
+  for (int tt = 0; tt < kM8Ahead; ++tt) {
+    read_slots(tt);
+    dma_tile(tt);
+  }
+  read_slots(kM8Ahead);
+
+  f32x4 oacc[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  float xai = 1.0f;
+  if (a.xai_len > 0 && seq_len - 1 > a.xai_len)
+    xai = __log2f(static_cast<float>(seq_len - 1)) / __log2f(static_cast<float>(a.xai_len));
+  const bool capped = a.logit_cap > 0.f;
+  const float c2 = (capped ? kLog2e : a.sm_scale * kLog2e) * xai;
+  const int bb_w = w & 1;
+  const int i16 = lane & 15;
+#if RX_MLA_STAMP
+  uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+
+  for (int t = 0; t < ntiles; ++t) {
+    // tile t has landed (ours: all but the 5 youngest pieces = tile t+1's; everybody's: the barrier)
+    if constexpr (kM8Ahead == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (kM8Ahead == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    __syncthreads();
+    MLA_STAMP(0);  // landing wait + barrier
+    const char* kt = smem + (t % kM8Ring) * kM8Buf;
+    // next slot block, one block ahead of the DMA that will read it (rare: every 32 tiles)
+    if ((t & 31) == 0 && (t / 32 + 1) * kM8SlotBlock < hi - lo + (kM8Ahead + 2) * kMlaTile) {
+      stage_slots(t / 32 + 1);  // published by the exchange barrier below; first read at iteration 32 k + 31 - kM8Ahead - 1
+    }
+    // tile t+2 -> the buffer tile t-1 was read from (every wave is past this iteration's barrier, i.e. done with t-1)
+#if RX_M8_DBG != 2
+    dma_tile(t + kM8Ahead);
+    read_slots(t + kM8Ahead + 1);  // for the next iteration's issue
+#endif
+#if RX_M8_DBG == 1
+    continue;
+#endif
+    MLA_STAMP(1);  // DMA issue
+
+    // ---- partial S^T of this wave: token block bb_w, k-steps [ks0, ks0 + 9)
+    f32x4 sacc[2];
+    {
+      const char* kb0 = kt + (8 * (r >> 2) + 4 * bb_w + (r & 3)) * kM8Row + 8 * g + 32 * ks0;
+      constexpr int PD = 4;
+      u32x2 kf[KSW];
+#pragma unroll
+      for (int i = 0; i < PD; ++i) kf[i] = *reinterpret_cast<const u32x2*>(kb0 + i * 32);
+      f32x4 part = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KSW; ++i) {
+        if (i + PD < KSW) kf[i + PD] = *reinterpret_cast<const u32x2*>(kb0 + (i + PD) * 32);
+        part = T::mfma(__builtin_bit_cast(vec8, fp8x8_to_16<T>(kf[i])), qf[i], part);
+      }
+      f32x4* xch = reinterpret_cast<f32x4*>(xch_base);
+      xch[w * 64 + lane] = part;
+      MLA_STAMP(2);  // K fragments, upcast, score MFMAs
+      __syncthreads();
+      sacc[0] = xch[0 * 64 + lane] + xch[2 * 64 + lane];
+      sacc[1] = xch[1 * 64 + lane] + xch[3 * 64 + lane];
+      MLA_STAMP(3);  // exchange barrier
+    }
+    // ---- online softmax (identical in all four waves); score (bb, i) of this lane is token 8 g + 4 bb + i
+    float sv[8];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[bb][i];
+    if (capped) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * a.sm_scale / a.logit_cap);
+    }
+    const int tok_base = lo + t * kMlaTile + 8 * g;
+    float mt = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sv[j] = (tok_base + j < hi) ? sv[j] : -INFINITY;
+      mt = fmaxf(mt, sv[j]);
+    }
+    mt = quad_row_max(mt) * c2;
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+      psum += sv[j];
+    }
+    l_run = l_run * alpha + psum;
+    u32x4 praw;
+    praw[0] = pack2<T>(sv[0], sv[1]);
+    praw[1] = pack2<T>(sv[2], sv[3]);
+    praw[2] = pack2<T>(sv[4], sv[5]);
+    praw[3] = pack2<T>(sv[6], sv[7]);
+    const vec8 pf = __builtin_bit_cast(vec8, praw);
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) oacc[nb] *= alpha;
+    }
+    MLA_STAMP(4);  // softmax
+    // ---- O^T[128 w + ...] += V^T P^T: one transposed byte read per fragment (rows 8 g .. 8 g + 7), upcast, MFMA
+    {
+      const char* vp = kt + (8 * g + (i16 >> 1)) * kM8Row + 128 * w + 8 * (i16 & 1);
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        auto lp = (__attribute__((address_space(3))) v2i_t*)(uintptr_t)(uint32_t)(uintptr_t)(vp + 16 * nb);
+        const v2i_t raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32(lp);
+        const vec8 av = __builtin_bit_cast(vec8, fp8x8_to_16<T>(u32x2{static_cast<uint32_t>(raw[0]), static_cast<uint32_t>(raw[1])}));
+        oacc[nb] = T::mfma(av, pf, oacc[nb]);
+      }
+    }
+    MLA_STAMP(5);  // PV
+  }
+  // nothing of this workgroup may still be landing in LDS when the block retires
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue (as the first form)
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  if (!q_valid) return;
+  if (single) {
+    float den = l_run;
+    if (a.sinks) den += fast_exp2(a.sinks[h] * kLog2e - m_run);
+    const float inv = a.v_scale / den;
+    uint16_t* op = a.o + b * a.o_stride_t + h * a.o_stride_h + 128 * w + 4 * g;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      u32x2 pk;
+      pk[0] = pack2<T>(oacc[nb][0] * inv, oacc[nb][1] * inv);
+      pk[1] = pack2<T>(oacc[nb][2] * inv, oacc[nb][3] * inv);
+      *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
+    }
+  } else {
+    const int64_t row = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits + split;
+    const float inv = 1.0f / l_run;
+    float* lp = a.attn_logits + row * kMlaDv + 128 * w + 4 * g;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) *reinterpret_cast<f32x4*>(lp + 16 * nb) = oacc[nb] * inv;
+    if (w == 0 && g == 0) a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
+#if RX_MLA_STAMP
+    if (w == 0 && lane == 0) {
+      uint32_t* dbg = reinterpret_cast<uint32_t*>(a.attn_logits + row * kMlaDv);
+      for (int i = 0; i < 6; ++i) dbg[i] = st_acc[i];
+    }
+#endif
+  }
+}
+
 }  // namespace rx
 
 namespace rx {
@@ -471,10 +775,20 @@ int launch_decode_mla(const rx_decode_params* p, hipStream_t s) {
   const unsigned pairs = static_cast<unsigned>(a.bs) * a.max_kv_splits;
   const unsigned grid = (pairs + 7) / 8 * 8 * a.qblocks;  // whole groups of 8 pairs (one per XCD)
   const bool kv8 = p->kv.kv_fp8 != 0;
+  static const bool old8 = getenv("RX_MLA8_OLD") != nullptr;  // dev: the upcast-while-staging form for fp8 rows
 #define RX_MLA_L(TT, IT, LIN)                                                                          \
   do {                                                                                                 \
-    if (kv8) hipLaunchKernelGGL((decode_mla_kernel<TT, IT, LIN, true>), dim3(grid), dim3(256), 0, s, a); \
-    else hipLaunchKernelGGL((decode_mla_kernel<TT, IT, LIN, false>), dim3(grid), dim3(256), 0, s, a);  \
+    if (kv8 && !old8) {                                                                                \
+      auto kern = decode_mla8_dma_kernel<TT, IT, LIN>;                                                 \
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),          \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kM8Lds); \
+      (void)attr;                                                                                      \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kM8Lds, s, a);                                   \
+    } else if (kv8) {                                                                                  \
+      hipLaunchKernelGGL((decode_mla_kernel<TT, IT, LIN, true>), dim3(grid), dim3(256), 0, s, a);      \
+    } else {                                                                                           \
+      hipLaunchKernelGGL((decode_mla_kernel<TT, IT, LIN, false>), dim3(grid), dim3(256), 0, s, a);     \
+    }                                                                                                  \
   } while (0)
 #define RX_MLA_GO(TT)                                \
   do {                                               \

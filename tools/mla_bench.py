@@ -57,6 +57,7 @@ print(f"MLA decode bs={bs} ctx={ctx} Hq={hq}: {ms*1e3:.1f} us  {byt/ms/1e6:.0f} 
 if os.environ.get("STAMPS"):
     run(); torch.cuda.synchronize()
     st = al[:, 0].contiguous().view(torch.int32)[..., :6].double()   # [bs, S, 6] (head 0 = lane 0 of wave 0)
-    names = ["S=KQ^T", "softmax", "PV", "stage", "barrier", "prologue"]
+    names = (["landing", "dma issue", "S=KQ^T", "xch barrier", "softmax", "PV"] if FP8 and not os.environ.get("RX_MLA8_OLD")
+             else ["S=KQ^T", "softmax", "PV", "stage", "barrier", "prologue"])
     print("mean cycles per WG:", {n: round(v) for n, v in zip(names, st.mean((0, 1)).tolist())})
     print("per tile:", {n: round(v / (ctx / S / 32)) for n, v in zip(names, st.mean((0, 1)).tolist())})
