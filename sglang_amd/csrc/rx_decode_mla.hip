@@ -454,6 +454,9 @@ constexpr int kM8Buf = kM8Pieces * 1024;       // 20 KB
 #ifndef RX_M8_DBG
 #define RX_M8_DBG 0  // dev: 1 = DMA and waits only, 2 = compute only (no DMA in the loop); results are wrong
 #endif
+#ifndef RX_M8_SPREAD
+#define RX_M8_SPREAD 1  // the five DMA pieces of a tile are issued in three places of the iteration (0: in one) -- the issue stalls on the full memory queue, and three short stalls overlap the partner workgroup better than one long one
+#endif
 #ifndef RX_M8_RING
 #define RX_M8_RING 3  // tile buffers; RING - 1 tiles are in flight or resident ahead of the one being read
 #endif
@@ -567,14 +570,20 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
 #pragma unroll
     for (int i = 0; i < NP; ++i) pslot[i] = sl[prow[i]];
   };
-  auto dma_tile = [&](int t) {  // uses pslot (tile t's)
-    const uint32_t buf = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)) + (t % kM8Ring) * kM8Buf;
-    const uint8_t* src[NP];
+  const uint8_t* psrc[NP];
+  auto dma_addr = [&]() {  // pslot -> source addresses
 #pragma unroll
     for (int i = 0; i < NP; ++i)
-      src[i] = kvb + mla_slot_off<LINEAR>(static_cast<int64_t>(pslot[i]), a.page_size, a.page_stride, a.tok_stride) + pcol[i];
+      psrc[i] = kvb + mla_slot_off<LINEAR>(static_cast<int64_t>(pslot[i]), a.page_size, a.page_stride, a.tok_stride) + pcol[i];
+  };
+  auto dma_pieces = [&](int t, int i0, int i1) {  // pieces [i0, i1) of tile t from psrc
+    const uint32_t buf = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)) + (t % kM8Ring) * kM8Buf;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) m8_dma16(src[i], __builtin_amdgcn_readfirstlane(buf + (w + 4 * i) * 1024));
+    for (int i = i0; i < i1; ++i) m8_dma16(psrc[i], __builtin_amdgcn_readfirstlane(buf + (w + 4 * i) * 1024));
+  };
+  auto dma_tile = [&](int t) {  // uses pslot (tile t's)
+    dma_addr();
+    dma_pieces(t, 0, NP);
   };
   // tiles past the end are "loaded" as well (their rows clamp to the last token): the counted waits stay uniform
 #pragma unroll
@@ -614,7 +623,12 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
     }
     // tile t+2 -> the buffer tile t-1 was read from (every wave is past this iteration's barrier, i.e. done with t-1)
 #if RX_M8_DBG != 2
+#if RX_M8_SPREAD
+    dma_addr();
+    dma_pieces(t + kM8Ahead, 0, 2);
+#else
     dma_tile(t + kM8Ahead);
+#endif
     read_slots(t + kM8Ahead + 1);  // for the next iteration's issue
 #endif
 #if RX_M8_DBG == 1
@@ -630,12 +644,15 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
       u32x2 kf[KSW];
 #pragma unroll
       for (int i = 0; i < PD; ++i) kf[i] = *reinterpret_cast<const u32x2*>(kb0 + i * 32);
-      f32x4 part = {0.f, 0.f, 0.f, 0.f};
+      f32x4 part3[3];  // three independent chains: a dependent 16x16x32 waits out its predecessor
+#pragma unroll
+      for (int c = 0; c < 3; ++c) part3[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < KSW; ++i) {
         if (i + PD < KSW) kf[i + PD] = *reinterpret_cast<const u32x2*>(kb0 + (i + PD) * 32);
-        part = T::mfma(__builtin_bit_cast(vec8, fp8x8_to_16<T>(kf[i])), qf[i], part);
+        part3[i % 3] = T::mfma(__builtin_bit_cast(vec8, fp8x8_to_16<T>(kf[i])), qf[i], part3[i % 3]);
       }
+      const f32x4 part = part3[0] + part3[1] + part3[2];
       f32x4* xch = reinterpret_cast<f32x4*>(xch_base);
       xch[w * 64 + lane] = part;
       MLA_STAMP(2);  // K fragments, upcast, score MFMAs
@@ -644,6 +661,9 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
       sacc[1] = xch[1 * 64 + lane] + xch[3 * 64 + lane];
       MLA_STAMP(3);  // exchange barrier
     }
+#if RX_M8_SPREAD && RX_M8_DBG != 2
+    dma_pieces(t + kM8Ahead, 2, 4);
+#endif
     // ---- online softmax (identical in all four waves); score (bb, i) of this lane is token 8 g + 4 bb + i
     float sv[8];
 #pragma unroll
@@ -654,13 +674,12 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
 #pragma unroll
       for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * a.sm_scale / a.logit_cap);
     }
-    const int tok_base = lo + t * kMlaTile + 8 * g;
-    float mt = -INFINITY;
+    if (t == ntiles - 1) {  // only the split's last tile can reach past its end
+      const int tok_base = lo + t * kMlaTile + 8 * g;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      sv[j] = (tok_base + j < hi) ? sv[j] : -INFINITY;
-      mt = fmaxf(mt, sv[j]);
+      for (int j = 0; j < 8; ++j) sv[j] = (tok_base + j < hi) ? sv[j] : -INFINITY;
     }
+    float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
     mt = quad_row_max(mt) * c2;
     const float m_new = fmaxf(m_run, mt);
     const float alpha = fast_exp2(m_run - m_new);
@@ -682,6 +701,9 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) oacc[nb] *= alpha;
     }
+#if RX_M8_SPREAD && RX_M8_DBG != 2
+    dma_pieces(t + kM8Ahead, 4, NP);
+#endif
     MLA_STAMP(4);  // softmax
     // ---- O^T[128 w + ...] += V^T P^T: one transposed byte read per fragment (rows 8 g .. 8 g + 7), upcast, MFMA
     {
