@@ -869,6 +869,27 @@ def main():
             out["extend"]["other_head_dims"] = extend_head_dims(args, dev)
         except Exception as e:
             out["extend"] = {"error": str(e)}
+    if world > 1 and not args.no_extend:
+        # the extend half of the metric at N GPUs: every rank runs ITS head shard of the same config-3 chunk (heads are
+        # independent: no exchange inside attention); whole-job TFLOP/s = all ranks' FLOPs / the slowest rank's time
+        import torch.distributed as dist
+
+        try:
+            dist.barrier()
+            ext = extend_bench(args, dev, world)
+            t_ms = torch.tensor([ext["ms_per_chunk"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_ms, op=dist.ReduceOp.MAX)
+            ms_max = float(t_ms.item())
+            total = ext["flops_per_chunk"] * world
+            ext.update({"ms_per_chunk_rank0": ext["ms_per_chunk"], "ms_per_chunk": ms_max,
+                        "flops_per_chunk": total, "tflops": total / (ms_max * 1e-3) / 1e12,
+                        "sharding": f"tp{world}: {32 // world} q heads / {max(1, 8 // world)} kv head(s) per GPU, "
+                                    "no collective in the attention path"})
+            ext["roofline"].update({"achieved": ext["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS * world,
+                                    "frac": ext["tflops"] / (MFMA_BF16_PEAK_TFLOPS * world)})
+            out["extend"] = ext
+        except Exception as e:  # noqa: BLE001
+            out["extend"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_radix_hit:
         try:
             del st, fb, step

@@ -76,6 +76,9 @@ def test_bench_gpus_2_runs_two_ranks_on_one_gpu(extra):
     assert out["config"]["all_reduce"] == "gloo" and out["steps"] == 2
     assert len(out["roofline"]["per_rank_frac"]) == 2
     assert {"alone_us", "step_ms_overlap", "step_ms_no_overlap"} <= set(out["all_reduce"])
+    # the extend half of the metric is reported at N > 1 too: every rank's head shard, slowest rank's time
+    assert "error" not in out["extend"], out["extend"]
+    assert out["extend"]["tflops"] > 0 and out["extend"]["sharding"].startswith("tp2")
 
 
 @pytest.mark.gpu
