@@ -8,8 +8,8 @@
 //
 // Why 16x16x32 here: at Dv = 256 a 32-query block's O^T accumulator alone is 128 registers per lane on the
 // 32x32 shape; on 16x16 tiles a wave carries 16 (CB = 1) or 32 (CB = 2) queries with 64 accumulator registers and
-// two waves per SIMD still fit.  One workgroup = 4 waves = 64 * CB queries of one (request, q head); K/V tiles of
-// TT tokens are staged once per workgroup (global -> registers, in flight for a whole tile -> padded LDS rows,
+// two waves per SIMD still fit.  One workgroup = 4 or 8 waves (NdGeom::NW) of 16 * CB queries of one (request,
+// q head); K/V tiles of TT tokens are staged once per workgroup (global -> registers, in flight for a whole tile -> padded LDS rows,
 // double buffered, one barrier per tile); S^T = K Q^T puts one query on lane & 15 with 8 scores of a 32-token
 // half in the lane, so the softmax is lane-local up to one quad reduction, and packed P is the B operand of
 // O^T += V^T P^T with V^T read by ds_read_b64_tr_b16.
@@ -42,14 +42,18 @@ struct ExtNdArgs {
   const float* sinks;
 };
 
-template <int DK, int DV>
+template <int DK, int DV, bool BIG>
 struct NdGeom {
 #ifndef RX_ND_WIDE256
 #define RX_ND_WIDE256 0
 #endif
   static constexpr int CB = (DV > 128 && !RX_ND_WIDE256) ? 1 : 2;  // 16-query blocks per wave
-  static constexpr int MINW = (DV > 128 && RX_ND_WIDE256) ? 1 : 2;  // waves per SIMD to allocate registers for
-  static constexpr int TT = (DK > 128) ? 32 : 64;      // tokens per staged tile
+#ifndef RX_ND_MINW_WIDE
+#define RX_ND_MINW_WIDE 1
+#endif
+  static constexpr int MINW = (DV > 128 && RX_ND_WIDE256) ? RX_ND_MINW_WIDE : 2;  // waves per SIMD to allocate registers for
+  // tokens per staged tile: 64, or 32 for the long rows of the four-wave form (two workgroups per CU keep their LDS)
+  static constexpr int TT = (DK > 128 && !BIG) ? 32 : 64;
   static constexpr int KROW = DK * 2, VROW = DV * 2;   // bytes per row
   // padded LDS rows: K rows step an odd number of 16-B chunks (the 16 rows of one ds_read_b128 pass land on 16
   // different chunk positions), V rows step 64 B past a multiple of 256 (the 4 rows of a transposed read land on
@@ -57,7 +61,13 @@ struct NdGeom {
   static constexpr int KSTRIDE = KROW + 16;
   static constexpr int VSTRIDE = ((VROW + 64) % 256 == 0) ? VROW + 32 : VROW + 64;
   static constexpr int KTILE = TT * KSTRIDE, VTILE = TT * VSTRIDE, BUF = KTILE + VTILE;
-  static constexpr int QPW = 16 * CB, QPWG = 4 * QPW;
+  // waves per workgroup: a staged tile serves NW * QPW queries.  With four waves of 16 queries (Dv > 128) every tile
+  // is re-staged for 64 queries only and the kernel is bound by L2 -> LDS staging and its one barrier per 32 tokens,
+  // not by the matrix pipe: the BIG form (eight waves, 64-token tiles, one workgroup per CU) serves Dk > 128 whenever
+  // the extends are long enough to fill it (D = 256: 448 -> 558 TFLOP/s, 192/128: 575 -> 715 at config 3's chunk)
+  static constexpr int NW = BIG ? 8 : 4;
+  static constexpr int NT = 64 * NW;
+  static constexpr int QPW = 16 * CB, QPWG = NW * QPW;
 };
 
 __device__ __forceinline__ int64_t nd_slot_off(int64_t slot, int32_t shift, int32_t page_size, int64_t page_stride,
@@ -66,15 +76,16 @@ __device__ __forceinline__ int64_t nd_slot_off(int64_t slot, int32_t shift, int3
   return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
 }
 
-template <typename T, int DK, int DV>
-__global__ __launch_bounds__(256, (NdGeom<DK, DV>::MINW)) void extend_nd_kernel(const ExtNdArgs a) {
-  using G = NdGeom<DK, DV>;
+template <typename T, int DK, int DV, bool BIG>
+__global__ __launch_bounds__((NdGeom<DK, DV, BIG>::NT), (NdGeom<DK, DV, BIG>::MINW * 4 / NdGeom<DK, DV, BIG>::NW)) void extend_nd_kernel(const ExtNdArgs a) {
+  using G = NdGeom<DK, DV, BIG>;
   using vec8 = typename T::vec8;
   constexpr int CB = G::CB, TT = G::TT;
   constexpr int KS = DK / 32, NB = DV / 16;
   constexpr int CPRK = G::KROW / 16, CPRV = G::VROW / 16;          // 16-byte chunks per row
   constexpr int NCHK = TT * CPRK, NCHV = TT * CPRV;                // chunks per tile
-  constexpr int NPK = (NCHK + 255) / 256, NPV = (NCHV + 255) / 256;  // chunks per thread
+  constexpr int NT = G::NT;
+  constexpr int NPK = (NCHK + NT - 1) / NT, NPV = (NCHV + NT - 1) / NT;  // chunks per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][K tile | V tile]
 
   const int tid = threadIdx.x;
@@ -134,17 +145,17 @@ __global__ __launch_bounds__(256, (NdGeom<DK, DV>::MINW)) void extend_nd_kernel(
   };
   auto load_idx_tile = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < NPK; ++i) slot_k[i] = tile_row(t, min((tid + 256 * i) / CPRK, TT - 1));
+    for (int i = 0; i < NPK; ++i) slot_k[i] = tile_row(t, min((tid + NT * i) / CPRK, TT - 1));
 #pragma unroll
-    for (int i = 0; i < NPV; ++i) slot_v[i] = tile_row(t, min((tid + 256 * i) / CPRV, TT - 1));
+    for (int i = 0; i < NPV; ++i) slot_v[i] = tile_row(t, min((tid + NT * i) / CPRV, TT - 1));
   };
   u32x4 stg_k[NPK], stg_v[NPV];
   auto issue_loads = [&](int t) {
     const bool pre = t < nt1;
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
-      const int id = tid + 256 * i, ch = id % CPRK;
-      if (NCHK % 256 == 0 || id < NCHK) {
+      const int id = tid + NT * i, ch = id % CPRK;
+      if (NCHK % NT == 0 || id < NCHK) {
         const uint16_t* p = pre ? kbuf_h + nd_slot_off(slot_k[i], a.page_shift, a.page_size, a.k_page_stride, a.k_tok_stride)
                                 : kext_h + static_cast<int64_t>(slot_k[i]) * a.k_stride_t;
         stg_k[i] = *reinterpret_cast<const u32x4*>(p + 8 * ch);
@@ -152,8 +163,8 @@ __global__ __launch_bounds__(256, (NdGeom<DK, DV>::MINW)) void extend_nd_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-      const int id = tid + 256 * i, ch = id % CPRV;
-      if (NCHV % 256 == 0 || id < NCHV) {
+      const int id = tid + NT * i, ch = id % CPRV;
+      if (NCHV % NT == 0 || id < NCHV) {
         const uint16_t* p = pre ? vbuf_h + nd_slot_off(slot_v[i], a.page_shift, a.page_size, a.v_page_stride, a.v_tok_stride)
                                 : vext_h + static_cast<int64_t>(slot_v[i]) * a.v_stride_t;
         stg_v[i] = *reinterpret_cast<const u32x4*>(p + 8 * ch);
@@ -165,14 +176,14 @@ __global__ __launch_bounds__(256, (NdGeom<DK, DV>::MINW)) void extend_nd_kernel(
     char* vt = kt + G::KTILE;
 #pragma unroll
     for (int i = 0; i < NPK; ++i) {
-      const int id = tid + 256 * i;
-      if (NCHK % 256 == 0 || id < NCHK)
+      const int id = tid + NT * i;
+      if (NCHK % NT == 0 || id < NCHK)
         *reinterpret_cast<u32x4*>(kt + (id / CPRK) * G::KSTRIDE + (id % CPRK) * 16) = stg_k[i];
     }
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
-      const int id = tid + 256 * i;
-      if (NCHV % 256 == 0 || id < NCHV)
+      const int id = tid + NT * i;
+      if (NCHV % NT == 0 || id < NCHV)
         *reinterpret_cast<u32x4*>(vt + (id / CPRV) * G::VSTRIDE + (id % CPRV) * 16) = stg_v[i];
     }
   };
@@ -352,18 +363,18 @@ __global__ __launch_bounds__(256, (NdGeom<DK, DV>::MINW)) void extend_nd_kernel(
   }
 }
 
-template <typename T, int DK, int DV>
+template <typename T, int DK, int DV, bool BIG>
 static void launch_nd_one(const ExtNdArgs& a0, int max_extend_len, hipStream_t s) {
-  using G = NdGeom<DK, DV>;
+  using G = NdGeom<DK, DV, BIG>;
   ExtNdArgs a = a0;
   a.mblocks = (max_extend_len + G::QPWG - 1) / G::QPWG;
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
   constexpr unsigned kLds = 2 * G::BUF;
-  auto kern = extend_nd_kernel<T, DK, DV>;
+  auto kern = extend_nd_kernel<T, DK, DV, BIG>;
   static const hipError_t attr =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
   (void)attr;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLds, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), kLds, s, a);
 }
 
 bool extend_nd_supports(int dk, int dv) {
@@ -398,11 +409,19 @@ int launch_extend_nd(const rx_extend_params* p, hipStream_t s) {
   a.window = p->sliding_window_size; a.sinks = p->sinks;
   const int dk = p->head_dim, dv = p->v_head_dim, mel = p->max_extend_len;
   const bool bf = p->dtype == RX_BF16;
-#define RX_ND(DK_, DV_)                                        \
-  if (dk == DK_ && dv == DV_) {                                \
-    if (bf) launch_nd_one<BF16, DK_, DV_>(a, mel, s);          \
-    else launch_nd_one<F16, DK_, DV_>(a, mel, s);              \
-    return RX_OK;                                              \
+  static const bool no_big = getenv("RX_ND_NO_BIG") != nullptr;  // dev: four-wave form only
+  // the eight-wave form when the longest extend fills more than a four-wave workgroup's query rows
+#define RX_ND(DK_, DV_)                                                           \
+  if (dk == DK_ && dv == DV_) {                                                   \
+    const bool big = DK_ > 128 && mel > NdGeom<DK_, DV_, false>::QPWG && !no_big; \
+    if (bf) {                                                                     \
+      if (big) launch_nd_one<BF16, DK_, DV_, (DK_ > 128)>(a, mel, s);             \
+      else launch_nd_one<BF16, DK_, DV_, false>(a, mel, s);                       \
+    } else {                                                                      \
+      if (big) launch_nd_one<F16, DK_, DV_, (DK_ > 128)>(a, mel, s);              \
+      else launch_nd_one<F16, DK_, DV_, false>(a, mel, s);                        \
+    }                                                                             \
+    return RX_OK;                                                                 \
   }
   RX_ND(256, 256)
   RX_ND(192, 128)

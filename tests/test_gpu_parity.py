@@ -405,7 +405,7 @@ def test_extend_generic_head_dims(ops, d):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("dk,dv", [(256, 256), (192, 128), (192, 192), (96, 96)])
-@pytest.mark.parametrize("variant", ["plain", "window", "cap_sinks_noncausal", "hnd_pool"])
+@pytest.mark.parametrize("variant", ["plain", "window", "cap_sinks_noncausal", "hnd_pool", "short_extends"])
 def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
     """rx::extend_nd_kernel (MFMA 16x16x32 for head dims 256 / 192+128 / 192 / 96 -- the shapes the reference retunes
     for gfx950, extend_attention.py:66-77, and the MLA prefill shape) vs the fp64 oracle: ragged batch with zero /
@@ -413,7 +413,9 @@ def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
     rng = np.random.default_rng(dk + dv)
     hq, hkv = 8, 2
     pre = np.array([0, 16, 33, 200, 5, 64], dtype=np.int32)
-    ext = np.array([1, 32, 50, 140, 129, 64], dtype=np.int32)
+    # the longest extend picks the kernel form: > 64 (Dv > 128) / > 128 rows -> eight waves and 64-token tiles for
+    # Dk > 128, else the four-wave form ("short_extends" runs every head dim through that one)
+    ext = np.array([1, 32, 50, 140, 129, 64] if variant != "short_extends" else [1, 32, 50, 40, 29, 64], dtype=np.int32)
     bs, T = len(pre), int(ext.sum())
     total = int((pre + ext).sum())
     ps = 16
