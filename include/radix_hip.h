@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 2
+#define RX_ABI_VERSION 3
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -329,6 +329,50 @@ int rx_chunk_indptr(const int32_t* kv_indptr, int bs, int num_chunks, int chunk_
 int rx_merge_chunks(const void* o_chunks, const float* lse_chunks, int num_chunks, const void* o_last,
                     const float* lse_last, void* out, float* out_lse, int64_t groups, int rows_per_group,
                     int num_heads, int head_size, int dtype, void* stream);
+
+/* ---- decode context parallel (DCP) ------------------------------------------------------------------
+ * SURVEY 8e "alternative shardings".  The KV of one request is spread over the dcp_size ranks of a group by the owner
+ * rule  position % dcp_size == dcp_rank;  a rank's pool holds virtual slot v at local slot v / dcp_size.  Each rank
+ * attends its own tokens with the group's gathered q heads; the partial results are joined by their LSEs
+ * (TritonAttnBackend.forward_decode, triton_backend.py:1797-1839; _forward_extend_dcp :1439-1569).  The exchanges are
+ * the caller's (torch.distributed); these are the index math and the fp32 LSE arithmetic either side of them.
+ *
+ * rx_dcp_kv_indices = get_dcp_lens (srt/layers/dcp/layout.py:23-41) + the cumsum + create_triton_kv_indices_for_dcp_triton
+ * (kernels/ops/attention/dcp_kernels.py:34-76), i.e. TritonAttnBackend._dcp_kv_indices (triton_backend.py:356-384):
+ *   first_i = start_i + (dcp_rank - start_i) mod dcp_size;   n_i = max(0, ceil((start_i + lens_i - first_i) / dcp_size))
+ *   kv_indptr[0] = 0, kv_indptr[i+1] = kv_indptr[i] + n_i;   dcp_lens_out[i] = n_i   (optional)
+ *   kv_indices[kv_indptr[i] + j] = req_to_token[req_pool_indices[i]][first_i + j * dcp_size] / dcp_size
+ * kv_start (int32[bs]) may be NULL (= 0). */
+int rx_dcp_kv_indices(const int32_t* req_to_token, int64_t row_stride, const void* req_pool_indices,
+                      int pool_idx_is_i64, const void* lens, int lens_is_i64, const int32_t* kv_start, int dcp_size,
+                      int dcp_rank, int32_t* kv_indptr_out, void* kv_indices_out, int out_is_i64, int32_t* dcp_lens_out,
+                      int bs, void* stream);
+/* Write locations of new tokens under DCP (TritonAttnBackend._set_kv_buffer, triton_backend.py:1227-1239 +
+ * masked_set_kv_buffer_kernel, memory_pool.py:4609-4650): loc_out[i] = out_cache_loc[i] / dcp_size when
+ * positions[i] % dcp_size == dcp_rank, else skip_index (the value rx_store_kv* is told to leave unwritten). */
+int rx_dcp_store_loc(const void* out_cache_loc, int loc_is_i64, const void* positions, int pos_is_i64, int64_t n,
+                     int dcp_size, int dcp_rank, int64_t skip_index, int64_t* loc_out, void* stream);
+/* One rank's kv-split partials (rx_decode_attn stages = 1; attn_lse filled with -inf beforehand, as
+ * triton_backend.py:1816 does) -> its normalised fp32 output [rows, head_size] and natural-log LSE [rows]
+ * (rows = bs * heads): o_for_decode / local_lse of triton_backend.py:1806-1837.  A row with no live split gets 0 / -inf.
+ * v_scale: the V descale stage 2 would have applied (stage-1 partials carry none). */
+int rx_dcp_local_merge(const float* attn_logits, const float* attn_lse, int64_t rows, int num_splits, int head_size,
+                       float v_scale, float* o32, float* lse_out, void* stream);
+/* 16-bit partial (an extend kernel's output) -> fp32 for the same exchange; n elements, a multiple of 4 */
+int rx_dcp_widen(const void* in, int64_t n, int dtype, float* out, void* stream);
+/* cp_lse_ag_out_rs_mha (srt/layers/dcp/comm.py:82-108), the part before the all-reduce: with lses_all the all-gathered
+ * fp32 [dcp_size, rows], o32[row] *= exp(lses_all[dcp_rank][row] - logsumexp_r lses_all[r][row]), NaN / inf in either
+ * factor -> 0; global_lse [rows] (optional) receives the logsumexp. */
+int rx_dcp_scale(float* o32, const float* lses_all, int64_t rows, int dcp_size, int dcp_rank, int head_size,
+                 float* global_lse, void* stream);
+/* ... and the part after it: this rank's heads [head_start, head_start + heads_local) of the summed fp32
+ * [num_tokens, heads_all, head_size] -> out [num_tokens, heads_local, head_size] of dtype.  With cur_o / cur_lse (the
+ * extend path's own-chunk partial, dtype [num_tokens, heads_local, head_size] + fp32 [num_tokens, heads_local]) the two
+ * are first joined by their LSEs, global_lse [num_tokens, heads_all] being the prefix part's
+ * (triton_backend.py:1560-1569). */
+int rx_dcp_finish(const float* o32, const float* global_lse, const void* cur_o, const float* cur_lse, void* out,
+                  int64_t num_tokens, int heads_all, int head_start, int heads_local, int head_size, int dtype,
+                  void* stream);
 
 /* ---- K9: paged slot allocation -----------------------------------------------------------
  * alloc_extend_kernel / alloc_decode_kernel (kernels/ops/memory/allocator.py:16-135), called

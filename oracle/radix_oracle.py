@@ -748,6 +748,63 @@ def merge_state(a, lse_a, b, lse_b):
 
 
 # --------------------------------------------------------------------------
+# decode context parallel (8e)   srt/layers/dcp/layout.py, kernels/ops/attention/dcp_kernels.py, srt/layers/dcp/comm.py
+# --------------------------------------------------------------------------
+def dcp_lens(lens, dcp_size, dcp_rank, start=None):
+    """get_dcp_lens (layout.py:23-41): tokens of [start, start + lens) at positions p with p % dcp_size == dcp_rank."""
+    lens = np.asarray(lens, dtype=np.int64)
+    if dcp_size == 1:
+        return lens
+    if start is None:
+        return lens // dcp_size + (dcp_rank < lens % dcp_size)
+    start = np.asarray(start, dtype=np.int64)
+    first = start + np.remainder(dcp_rank - start, dcp_size)
+    remaining = start + lens - first
+    return np.maximum((remaining + dcp_size - 1) // dcp_size, 0)
+
+
+def dcp_kv_indices(req_to_token, req_pool_indices, lens, dcp_size, dcp_rank, kv_start=None, out_dtype=np.int64):
+    """TritonAttnBackend._dcp_kv_indices (triton_backend.py:356-384) = dcp_lens + cumsum + the strided gather of
+    create_triton_kv_indices_for_dcp_triton (dcp_kernels.py:34-76): the rank's tokens of every request as LOCAL slots
+    (virtual slot // dcp_size).  Returns (kv_indptr int32, kv_indices, dcp_lens)."""
+    req_to_token = np.asarray(req_to_token)
+    dl = dcp_lens(lens, dcp_size, dcp_rank, kv_start)
+    bs = len(dl)
+    kv_indptr = np.zeros((bs + 1,), dtype=np.int32)
+    kv_indptr[1:] = np.cumsum(dl)
+    kv_indices = np.empty((int(kv_indptr[-1]),), dtype=out_dtype)
+    for i in range(bs):
+        s = 0 if kv_start is None else int(kv_start[i])
+        first = s + (dcp_rank - s) % dcp_size
+        pos = first + np.arange(int(dl[i]), dtype=np.int64) * dcp_size
+        kv_indices[kv_indptr[i]: kv_indptr[i + 1]] = req_to_token[int(req_pool_indices[i]), pos] // dcp_size
+    return kv_indptr, kv_indices, dl.astype(np.int32)
+
+
+def dcp_store_loc(out_cache_loc, positions, dcp_size, dcp_rank, skip_index=0):
+    """_set_kv_buffer's DCP branch (triton_backend.py:1227-1239): local slot for owned tokens, skip_index otherwise."""
+    loc = np.asarray(out_cache_loc, dtype=np.int64)
+    pos = np.asarray(positions, dtype=np.int64)
+    return np.where(pos % dcp_size == dcp_rank, loc // dcp_size, skip_index).astype(np.int64)
+
+
+def dcp_merge(outs, lses):
+    """cp_lse_ag_out_rs_mha (comm.py:82-108) for all ranks at once: outs [dcp, T, H, D], lses [dcp, T, H] (natural log;
+    -inf = the rank saw no token; NaN / inf outputs of such rows count as 0).  Returns (scaled [dcp, T, H, D] -- what
+    each rank contributes to the all-reduce --, summed [T, H, D], global_lse [T, H]); rank r keeps heads
+    [r * H / dcp, (r + 1) * H / dcp)."""
+    outs = np.asarray(outs, dtype=np.float64)
+    lses = np.asarray(lses, dtype=np.float64)
+    m = lses.max(axis=0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        g = np.where(np.isfinite(m), m + np.log(np.exp(lses - np.where(np.isfinite(m), m, 0.0)).sum(axis=0)), m)
+        scale = np.exp(lses - g)
+    scale = np.where(np.isfinite(scale), scale, 0.0)
+    scaled = np.where(np.isfinite(outs), outs, 0.0) * scale[..., None]
+    return scaled, scaled.sum(axis=0), g
+
+
+# --------------------------------------------------------------------------
 # a14 torch-native semantics   srt/layers/attention/torch_native_backend.py:61-277
 # --------------------------------------------------------------------------
 

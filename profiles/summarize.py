@@ -56,5 +56,31 @@ def main(src, tag):
                        "kernels": pmc}, f, indent=1)
 
 
+def mla(src, tag):
+    """FETCH_SIZE of the MLA decode kernels (tools/mla_bench.py under --pmc, 16-bit and fp8 latent rows) against the
+    algorithmic bytes of the shape (bs 64 x ctx 8192 x 576 elements)."""
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for sub, name, row_bytes in (("mla16_pmc", "bf16_rows", 1152), ("mla8_pmc", "fp8_rows", 576)):
+        files = glob.glob(os.path.join(src, sub, "**", "*_counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(files[0])):
+            if r["Counter_Name"] == "FETCH_SIZE" and "decode_mla" in r["Kernel_Name"]:
+                acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        alg = 64 * 8192 * row_bytes
+        for k, v in acc.items():
+            kib = sum(v) / len(v)
+            res[name] = {"kernel": k, "launches": len(v), "FETCH_SIZE_mean_KiB": kib,
+                         "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)": 2 * kib * 1024,
+                         "algorithmic_kv_bytes": alg, "read_over_algorithmic": 2 * kib * 1024 / alg}
+    if res:
+        with open(os.path.join(out_dir, f"{tag}_mla_pmc_summary.json"), "w") as f:
+            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE -- python3 tools/mla_bench.py (FP8=1 for fp8 rows); same "
+                                 "gfx950 correction as the decode summary", "kernels": res}, f, indent=1)
+
+
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
+    mla(sys.argv[1], sys.argv[2])

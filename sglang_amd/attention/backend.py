@@ -81,13 +81,18 @@ def host_num_kv_splits(seq_lens: np.ndarray, num_head: int, num_kv_head: int, ma
     return np.maximum(-(-seq_lens // c1), -(-seq_lens // c2)).astype(np.int32)
 
 
+def md_has_mask(md) -> bool:
+    return md is not None and getattr(md, "custom_mask", None) is not None
+
+
 class HipRadixAttnBackend:
     needs_cpu_seq_lens: bool = True
     supports_ragged_verify_graph: bool = False
 
     def __init__(self, model_runner, decode_index_mode: str = "paged",
                  max_kv_splits: Optional[int] = None, split_policy: str = "native",
-                 cascade_decode: bool = False, cascade_min_bs: int = 16, cascade_min_shared: int = 1024):
+                 cascade_decode: bool = False, cascade_min_bs: int = 16, cascade_min_shared: int = 1024,
+                 dcp=None):
         self.device = model_runner.device
         self.req_to_token_pool = model_runner.req_to_token_pool
         self.token_to_kv_pool = model_runner.token_to_kv_pool
@@ -98,6 +103,18 @@ class HipRadixAttnBackend:
         tp = getattr(model_runner, "tp_size", 1)
         self.num_head = mc.num_attention_heads // tp
         self.num_kv_head = max(1, mc.num_key_value_heads // tp)
+        # decode context parallel (attention/dcp.py): a request's KV is spread over the group's ranks; every rank runs
+        # the group's gathered q heads over its own tokens (triton_backend.py:182-190: num_head is the gathered count)
+        self.dcp = dcp if (dcp is not None and dcp.size > 1) else None
+        self.local_num_head = self.num_head
+        if self.dcp is not None:
+            # DCP spreads the tokens over the TP ranks that would otherwise hold COPIES of one kv head (tp_size > kv
+            # heads): the gathered q heads are that head's GQA group.  With several kv heads per rank the GQA mapping
+            # of the local heads (new tokens' block) and of the gathered heads (cached part) would disagree.
+            if self.num_kv_head != 1:
+                raise ValueError(f"DCP needs one kv head per rank (the replicated-kv-head case), got {self.num_kv_head}")
+            self.num_head *= self.dcp.size
+            decode_index_mode = "indices"  # the rank's share of a request is a strided subset of its row
         self.v_head_dim = self.token_to_kv_pool.get_value_buffer(
             getattr(self.token_to_kv_pool, "start_layer", 0)).shape[-1]
         self.max_context_len = mc.context_len
@@ -138,7 +155,10 @@ class HipRadixAttnBackend:
         self._cur_fb = None
         # shared-prefix (cascade) decode, SURVEY 8f-2: opt-in (a batch without a common prefix pays two empty
         # launches per layer); the common prefix itself is found on the device every forward
-        self.cascade_decode = bool(cascade_decode) and not self._is_mla_pool and self.sliding_window_size is None
+        if self.dcp is not None and (self._is_mla_pool or self.sliding_window_size is not None):
+            raise NotImplementedError("DCP here covers MHA / GQA pools without sliding-window layers")
+        self.cascade_decode = (bool(cascade_decode) and not self._is_mla_pool and self.sliding_window_size is None
+                               and self.dcp is None)
         self.cascade_min_bs, self.cascade_min_shared = int(cascade_min_bs), int(cascade_min_shared)
         self._cascade = None
         self._cascade_on = False
@@ -191,6 +211,14 @@ class HipRadixAttnBackend:
             return
         if graph and bs > self._graph["max_bs"]:
             raise ValueError(f"batch size {bs} exceeds init_cuda_graph_state's max_bs {self._graph['max_bs']}")
+        if self.dcp is not None:
+            if mode.is_decode():
+                self.forward_metadata = self._decode_metadata_dcp(forward_batch, bs, graph)
+            elif mode.is_target_verify() or mode.is_draft_extend_v2():
+                raise NotImplementedError("speculative modes under DCP")
+            else:
+                self.forward_metadata = self._extend_metadata_dcp(forward_batch, bs)
+            return
         if mode.is_decode():
             self.forward_metadata = self._decode_metadata(forward_batch, bs, graph)
         elif mode.is_target_verify():
@@ -300,6 +328,121 @@ class HipRadixAttnBackend:
             attn_logits, attn_lse = self._scratch(bs, S)
         ops.get_num_kv_splits_native(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S, wg_target)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S)
+
+    # ------------------------------------------------------------------ decode context parallel
+    def _decode_metadata_dcp(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool) -> ForwardMetadata:
+        """_update_decode_kv_buffers' DCP branch (triton_backend.py:422-433): the rank's local kv_indices, and the
+        split schedule from the per-rank lengths (clamped to >= 1).  Always two stages: the cross-rank join works on
+        the fp32 partials."""
+        d = self.dcp
+        if use_graph_bufs:
+            kv_indices = self._graph_kv_indices()
+        else:
+            total = fb.seq_lens_sum if fb.seq_lens_sum is not None else bs * self.max_context_len
+            kv_indices = torch.empty(total // d.size + bs + 1, dtype=torch.int64, device=self.device)
+        dcp_lens = torch.empty((bs,), dtype=torch.int32, device=self.device)
+        kv_indptr = ops.dcp_kv_indices(self.req_to_token, fb.req_pool_indices, fb.seq_lens, self.kv_indptr, kv_indices,
+                                       d.size, d.rank, dcp_lens=dcp_lens)
+        S = max(2, self.max_kv_splits)
+        if use_graph_bufs:
+            num_kv_splits = self._graph["num_kv_splits"][:bs]
+            n = bs * self.num_head * S
+            attn_logits = self._graph["native_logits"][: n * self.v_head_dim].view(bs, self.num_head, S, self.v_head_dim)
+            attn_lse = self._graph["native_lse"][:n].view(bs, self.num_head, S)
+        else:
+            num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+            attn_logits, attn_lse = self._scratch(bs, S)
+        ops.get_num_kv_splits(num_kv_splits, dcp_lens.clamp_(min=1), self.num_head, self.num_kv_head, S,
+                              self.device_core_count)
+        return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S)
+
+    def _extend_metadata_dcp(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
+        """The cached prefix through the rank's local kv_indices (triton_backend.py:728-737); qo_indptr as ever."""
+        d = self.dcp
+        if fb.extend_prefix_lens_cpu is not None:
+            total = int(sum(fb.extend_prefix_lens_cpu))
+        else:
+            total = bs * self.max_context_len
+        kv_indices = torch.empty(total // d.size + bs + 1, dtype=torch.int64, device=self.device)
+        kv_indptr = ops.dcp_kv_indices(self.req_to_token, fb.req_pool_indices, fb.extend_prefix_lens, self.kv_indptr,
+                                       kv_indices, d.size, d.rank)
+        qo_indptr = self.qo_indptr[: bs + 1]
+        qo_indptr[1:] = torch.cumsum(fb.extend_seq_lens, dim=0)
+        if fb.extend_seq_lens_cpu is not None:
+            max_extend_len = max(fb.extend_seq_lens_cpu)
+        else:
+            max_extend_len = int(fb.extend_seq_lens.max())
+        self._extend_split_on = False
+        md = ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr)
+        md.dcp_prefix_total = total  # the WHOLE prefix, known to every rank alike: decides the collective path
+        return md
+
+    def _dcp_store(self, layer, fb: ForwardBatch, k, v):
+        """_set_kv_buffer's DCP branch (triton_backend.py:1227-1239): the rank stores the tokens it owns, at the
+        local slot; the other rows carry the pool's skip index."""
+        if fb.positions is None or fb.positions.numel() != fb.out_cache_loc.numel():
+            raise ValueError("DCP needs forward_batch.positions for the new tokens")
+        loc = ops.dcp_store_loc(fb.out_cache_loc, fb.positions, self.dcp.size, self.dcp.rank, skip_index=0)
+        self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(loc), k, v, layer.k_scale, layer.v_scale)
+
+    def _forward_decode_dcp(self, q3, o3, layer, fb: ForwardBatch, sinks):
+        """triton_backend.py:1797-1839: gathered q heads over the local tokens (kv-split partials only), the rank's
+        fp32 result and LSE, then cp_lse_ag_out_rs_mha."""
+        if sinks is not None or (getattr(layer, "xai_temperature_len", -1) or 0) > 0:
+            raise NotImplementedError("DCP decode: sinks and the Grok temperature need the whole sequence on one rank")
+        md = self.forward_metadata
+        bs = q3.shape[0]
+        q_all = self.dcp.all_gather_heads(q3.contiguous())
+        k_descale, v_descale = self._scales(layer)
+        k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+        hnd = getattr(self.token_to_kv_pool, "use_hnd", False)
+        attn_logits, attn_lse = md.attn_logits[:bs], md.attn_lse[:bs]
+        attn_lse.fill_(float("-inf"))  # splits that do not run (and ranks without tokens) stay empty
+        o_unused = q_all.new_empty(bs, q_all.shape[1], layer.v_head_dim)
+        ops.decode_attention_fwd(q_all, k_buf, v_buf, o_unused, md.kv_indptr, md.kv_indices, attn_logits, attn_lse,
+                                 md.num_kv_splits, md.max_kv_splits, layer.scaling, k_descale, v_descale,
+                                 logit_cap=layer.logit_cap, page_size=self.page_size,
+                                 kv_layout=ops.kv_layout_hnd(k_buf, v_buf) if hnd else None, stages=1)
+        o32, lse = ops.dcp_local_merge(attn_logits, attn_lse, v_scale=v_descale)
+        self.dcp.merge_partials(o32, lse, o3)
+
+    def _forward_extend_dcp(self, q3, k3, v3, o3, layer, fb: ForwardBatch, causal: bool, sinks):
+        """_forward_extend_dcp (triton_backend.py:1439-1569): the new tokens' own block with the local heads (their
+        K/V are whole on every rank), the cached prefix with the gathered heads over the local tokens, joined across
+        the ranks by LSE and then with the first part.  Partials are 16-bit (what the extend kernels write, as every
+        merge_state input in the reference is)."""
+        if sinks is not None or md_has_mask(self.forward_metadata):
+            raise NotImplementedError("DCP extend: no sinks / custom masks (as the reference)")
+        if layer.sliding_window_size is not None and layer.sliding_window_size > -1:
+            raise NotImplementedError("DCP extend: no sliding window (as the reference)")
+        md = self.forward_metadata
+        T, h_loc = q3.shape[0], q3.shape[1]
+        k_descale, v_descale = self._scales(layer)
+        k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+        lay = ops.kv_layout_hnd(k_buf, v_buf) if getattr(self.token_to_kv_pool, "use_hnd", False) else None
+        xai = layer.xai_temperature_len
+        empty_indptr = torch.zeros_like(md.kv_indptr)
+        has_prefix = md.dcp_prefix_total > 0
+        cur_o = torch.empty_like(o3) if has_prefix else o3
+        cur_lse = torch.full((T, h_loc), float("-inf"), dtype=torch.float32, device=q3.device)
+        ops.extend_attention_fwd(q3, k3, v3, cur_o, k_buf, v_buf, md.qo_indptr, empty_indptr, md.kv_indices[:0], None,
+                                 causal, None, md.max_extend_len, 1.0, 1.0, sm_scale=layer.scaling,
+                                 logit_cap=layer.logit_cap, xai_temperature_len=xai, lse_extend=cur_lse,
+                                 skip_prefix=True, page_size=self.page_size, kv_layout=lay)
+        if not has_prefix:
+            return
+        q_all = self.dcp.all_gather_heads(q3.contiguous())
+        h_all = q_all.shape[1]
+        pre_o = torch.empty(T, h_all, layer.v_head_dim, dtype=q3.dtype, device=q3.device)
+        pre_lse = torch.full((T, h_all), float("-inf"), dtype=torch.float32, device=q3.device)
+        # skip_extend: the new tokens' K/V are not read (one-row stand-ins carry the head count and dims)
+        k_none = q3.new_empty(1, layer.tp_k_head_num, layer.qk_head_dim)
+        v_none = q3.new_empty(1, layer.tp_v_head_num, layer.v_head_dim)
+        ops.extend_attention_fwd(q_all, k_none, v_none, pre_o, k_buf, v_buf, md.qo_indptr, md.kv_indptr, md.kv_indices,
+                                 None, False, None, md.max_extend_len, k_descale, v_descale, sm_scale=layer.scaling,
+                                 logit_cap=layer.logit_cap, xai_temperature_len=xai, lse_extend=pre_lse,
+                                 skip_extend=True, page_size=self.page_size, kv_layout=lay)
+        self.dcp.merge_partials(ops.dcp_widen(pre_o), pre_lse, o3, cur_o, cur_lse)
 
     def _extend_metadata(self, fb: ForwardBatch, bs: int) -> ForwardMetadata:
         # prefix-only kv indices + qo_indptr (triton_backend.py:869-924)
@@ -479,11 +622,17 @@ class HipRadixAttnBackend:
         else:
             o = torch.empty_like(q)
         if save_kv_cache and k is not None:
-            self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(forward_batch.out_cache_loc), k, v,
-                                                layer.k_scale, layer.v_scale)
+            if self.dcp is not None:
+                self._dcp_store(layer, forward_batch, k, v)
+            else:
+                self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(forward_batch.out_cache_loc), k, v,
+                                                    layer.k_scale, layer.v_scale)
         md = self.forward_metadata
         q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
+        if self.dcp is not None:
+            self._forward_decode_dcp(q3, o3, layer, forward_batch, sinks)
+            return o
         if self._cascade_on and not (getattr(layer, "xai_temperature_len", -1) or 0) > 0:
             k_descale, v_descale = self._scales(layer)
             k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
@@ -534,12 +683,21 @@ class HipRadixAttnBackend:
             o = torch.empty_like(q)
         if k is None or v is None:
             raise ValueError("forward_extend needs the new tokens' k and v")
+        causal = not (layer.is_cross_attention or layer.attn_type.value == "encoder_only")
+        if self.dcp is not None:
+            # attention first: the new tokens' K/V are read from k / v, the cache holds the prefix only
+            self._forward_extend_dcp(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
+                                     k.view(-1, layer.tp_k_head_num, layer.qk_head_dim),
+                                     v.view(-1, layer.tp_v_head_num, layer.v_head_dim),
+                                     o.view(-1, layer.tp_q_head_num, layer.v_head_dim), layer, forward_batch, causal, sinks)
+            if save_kv_cache:
+                self._dcp_store(layer, forward_batch, k, v)
+            return o
         if save_kv_cache:
             self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(forward_batch.out_cache_loc), k, v,
                                                 layer.k_scale, layer.v_scale)
         md = self.forward_metadata
         k_descale, v_descale = self._scales(layer)
-        causal = not (layer.is_cross_attention or layer.attn_type.value == "encoder_only")
         k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
         lay = ops.kv_layout_hnd(k_buf, v_buf) if getattr(self.token_to_kv_pool, "use_hnd", False) else None
         # sliding-window layers read the window indices (triton_backend.py:1353-1365)

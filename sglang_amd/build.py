@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 # RX_LIB_NAME / RX_CFLAGS: developer knobs for A/B-ing kernel variants built side by side
 LIB_PATH = os.path.join(HERE, os.environ.get("RX_LIB_NAME", "libradix_hip.so"))
 SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_decode_mla.hip", "rx_extend.hip", "rx_extend32.hip", "rx_extend_nd.hip",
-           "rx_allreduce.hip", "rx_rope.hip", "rx_pool.hip", "rx_radix.cpp"]
+           "rx_allreduce.hip", "rx_rope.hip", "rx_pool.hip", "rx_dcp.hip", "rx_radix.cpp"]
 # rx_extend32: without -fno-honor-nans every fmaxf on an MFMA result is preceded by a canonicalising
 # v_max_f32 x, x, x (one extra VALU per score in a VALU-issue-bound loop).  The kernel creates no NaN.
 # -amdgpu-mfma-vgpr-form: at one wave per SIMD hipcc otherwise puts every MFMA result in AGPRs and

@@ -90,7 +90,11 @@ class ForwardBatch:
         start = torch.zeros_like(ext)
         start[1:] = torch.cumsum(ext[:-1], dim=0)
         seq_cpu = seq_lens.cpu()
-        return cls(forward_mode=ForwardMode.EXTEND, batch_size=len(seq_lens),
+        # compute_position (forward_batch_info.py:923, 1689-...): prefix_len + 0 .. extend_len - 1 per request
+        positions = torch.cat([torch.arange(p_, p_ + e_, dtype=torch.int64)
+                               for p_, e_ in zip(extend_prefix_lens_cpu, extend_seq_lens_cpu)]
+                              or [torch.zeros(0, dtype=torch.int64)]).to(dev)
+        return cls(forward_mode=ForwardMode.EXTEND, batch_size=len(seq_lens), positions=positions,
                    req_pool_indices=req_pool_indices, seq_lens=seq_lens,
                    out_cache_loc=out_cache_loc, seq_lens_sum=int(seq_cpu.sum()),
                    seq_lens_cpu=seq_cpu, extend_num_tokens=int(sum(extend_seq_lens_cpu)),

@@ -16,7 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
-RX_ABI_VERSION = 2  # include/radix_hip.h
+RX_ABI_VERSION = 3  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -140,6 +140,15 @@ PROTOTYPES = {
     "rx_pool_mark": (c_int, [C.POINTER(RxPoolDesc), c_void_p, c_int64, c_int, c_void_p]),
     "rx_pool_flush_marks": (c_int, [C.POINTER(RxPoolDesc), c_int, c_void_p]),
     "rx_pool_merge_sort": (c_int, [C.POINTER(RxPoolDesc), c_void_p]),
+    # decode context parallel
+    "rx_dcp_kv_indices": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
+                                  c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "rx_dcp_store_loc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "rx_dcp_local_merge": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "rx_dcp_widen": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "rx_dcp_scale": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rx_dcp_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                              c_int, c_void_p]),
     "rx_move_kv_layout": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     # host-side radix tree
     "rx_radix_create": (c_void_p, [c_int, c_int]),

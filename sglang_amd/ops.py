@@ -255,10 +255,11 @@ def kv_layout_hnd(k_buffer: torch.Tensor, v_buffer: torch.Tensor) -> _L.RxKvLayo
 def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
                          num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap=0.0,
                          sinks=None, xai_temperature_len=-1, has_mla=False, use_pdl=False,
-                         page_size: int = 1, score_mod=None, aux_tensors=None, kv_layout=None):
+                         page_size: int = 1, score_mod=None, aux_tensors=None, kv_layout=None, stages: int = 0):
     """Same contract as the reference.  q [bs,Hq,Dk], o [bs,Hq,Dv], kv_indptr int32[bs+1],
     kv_indices int32/int64, attn_logits fp32[bs,Hq,max_kv_splits,Dv], attn_lse fp32[bs,Hq,S].
-    ``max_kv_splits == 1`` (or num_kv_splits None) runs the single-pass kernel."""
+    ``max_kv_splits == 1`` (or num_kv_splits None) runs the single-pass kernel.  ``stages`` as in
+    rx_decode_params (1 = the kv-split partials only)."""
     if score_mod is not None or aux_tensors is not None:
         raise NotImplementedError("score_mod / aux_tensors: outside the HIP path")
     # has_mla only selects a Triton block shape in the reference; here the MLA kernel is chosen from the
@@ -278,6 +279,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     p.kv_indices = kv_indices.data_ptr()
     p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
     p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
+    p.stages = int(stages)
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -1072,3 +1074,112 @@ def move_kv_layout(data_ptrs: torch.Tensor, geom: torch.Tensor, page_size: int, 
     st = _L.load().rx_move_kv_layout(_ptr(data_ptrs), _ptr(geom), data_ptrs.shape[0], int(page_size), int(num_heads),
                                      _ptr(tgt_loc), _ptr(src_loc), tgt_loc.shape[0], _stream(tgt_loc))
     _L.check(st, "rx_move_kv_layout")
+
+
+# --------------------------------------------------------------------------------------
+# decode context parallel (DCP)   srt/layers/dcp/{layout,comm}.py, kernels/ops/attention/dcp_kernels.py
+# --------------------------------------------------------------------------------------
+def dcp_kv_indices(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor, lens: torch.Tensor,
+                   kv_indptr: torch.Tensor, kv_indices: Optional[torch.Tensor], dcp_size: int, dcp_rank: int,
+                   kv_start: Optional[torch.Tensor] = None, dcp_lens: Optional[torch.Tensor] = None):
+    """TritonAttnBackend._dcp_kv_indices (triton_backend.py:356-384) in one call: this rank's share of every request
+    (owner rule position % dcp_size == dcp_rank) as kv_indptr[:bs+1] (int32), its LOCAL slots (virtual slot //
+    dcp_size) in kv_indices when given, and the per-request counts in dcp_lens (int32[bs]) when given."""
+    _require_cuda(req_to_token, req_pool_indices, lens, kv_indptr, kv_indices, kv_start, dcp_lens)
+    bs = lens.shape[0]
+    if req_to_token.dtype != torch.int32 or kv_indptr.dtype != torch.int32:
+        raise TypeError("req_to_token and kv_indptr must be int32")
+    if kv_indptr.numel() < bs + 1:
+        raise ValueError("kv_indptr too small")
+    if dcp_lens is not None and (dcp_lens.dtype != torch.int32 or dcp_lens.numel() < bs):
+        raise TypeError("dcp_lens must be int32[bs]")
+    if kv_start is not None and kv_start.dtype != torch.int32:
+        kv_start = kv_start.to(torch.int32)
+    st = _L.load().rx_dcp_kv_indices(
+        _ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices),
+        _is64(req_pool_indices, "req_pool_indices"), _ptr(lens), _is64(lens, "lens"), _ptr(kv_start), int(dcp_size),
+        int(dcp_rank), _ptr(kv_indptr), _ptr(kv_indices),
+        0 if kv_indices is None else _is64(kv_indices, "kv_indices"), _ptr(dcp_lens), bs, _stream(req_to_token))
+    _L.check(st, "rx_dcp_kv_indices")
+    return kv_indptr[: bs + 1]
+
+
+def dcp_store_loc(out_cache_loc: torch.Tensor, positions: torch.Tensor, dcp_size: int, dcp_rank: int,
+                  skip_index: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Local write slots of the new tokens: out_cache_loc // dcp_size for the tokens this rank owns
+    (positions % dcp_size == dcp_rank), ``skip_index`` (left unwritten by the store kernels) for the rest."""
+    _require_cuda(out_cache_loc, positions, out)
+    n = out_cache_loc.numel()
+    if positions.numel() != n:
+        raise ValueError("positions and out_cache_loc differ in length")
+    if out is None:
+        out = torch.empty(n, dtype=torch.int64, device=out_cache_loc.device)
+    elif out.dtype != torch.int64 or out.numel() < n:
+        raise TypeError("out must be int64[n]")
+    st = _L.load().rx_dcp_store_loc(_ptr(out_cache_loc), _is64(out_cache_loc, "out_cache_loc"), _ptr(positions),
+                                    _is64(positions, "positions"), n, int(dcp_size), int(dcp_rank), int(skip_index),
+                                    _ptr(out), _stream(out_cache_loc))
+    _L.check(st, "rx_dcp_store_loc")
+    return out[:n]
+
+
+def dcp_local_merge(attn_logits: torch.Tensor, attn_lse: torch.Tensor, o32: Optional[torch.Tensor] = None,
+                    lse: Optional[torch.Tensor] = None, v_scale: float = 1.0):
+    """kv-split partials [bs, H, S, Dv] / [bs, H, S] (dead splits -inf) -> (fp32 [bs, H, Dv], natural-log LSE [bs, H])."""
+    _require_cuda(attn_logits, attn_lse, o32, lse)
+    if attn_logits.dtype != torch.float32 or attn_lse.dtype != torch.float32 or attn_logits.dim() != 4:
+        raise TypeError("dcp_local_merge: fp32 [bs, H, S, Dv] partials and [bs, H, S] LSEs")
+    if not attn_logits.is_contiguous() or not attn_lse.is_contiguous():
+        raise ValueError("dcp_local_merge: partials must be contiguous")
+    bs, H, S, Dv = attn_logits.shape
+    if o32 is None:
+        o32 = torch.empty(bs, H, Dv, dtype=torch.float32, device=attn_logits.device)
+    if lse is None:
+        lse = torch.empty(bs, H, dtype=torch.float32, device=attn_logits.device)
+    st = _L.load().rx_dcp_local_merge(_ptr(attn_logits), _ptr(attn_lse), bs * H, S, Dv, float(v_scale), _ptr(o32), _ptr(lse),
+                                      _stream(attn_logits))
+    _L.check(st, "rx_dcp_local_merge")
+    return o32, lse
+
+
+def dcp_widen(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """16-bit partial -> fp32 (same shape)."""
+    _require_cuda(x, out)
+    if not x.is_contiguous():
+        raise ValueError("dcp_widen: contiguous input")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().rx_dcp_widen(_ptr(x), x.numel(), _rx_dtype(x), _ptr(out), _stream(x)), "rx_dcp_widen")
+    return out
+
+
+def dcp_scale(o32: torch.Tensor, lses_all: torch.Tensor, dcp_rank: int, global_lse: Optional[torch.Tensor] = None):
+    """In place: o32 [T, H, Dv] *= exp(lses_all[rank] - logsumexp over ranks); lses_all fp32 [dcp, T, H] (all-gathered)."""
+    _require_cuda(o32, lses_all, global_lse)
+    if o32.dtype != torch.float32 or lses_all.dtype != torch.float32 or not o32.is_contiguous() or not lses_all.is_contiguous():
+        raise TypeError("dcp_scale: contiguous fp32 tensors")
+    dcp, rows = lses_all.shape[0], o32.shape[0] * o32.shape[1]
+    if lses_all.numel() != dcp * rows:
+        raise ValueError("dcp_scale: lses_all must be [dcp, T, H]")
+    st = _L.load().rx_dcp_scale(_ptr(o32), _ptr(lses_all), rows, dcp, int(dcp_rank), o32.shape[2], _ptr(global_lse),
+                                _stream(o32))
+    _L.check(st, "rx_dcp_scale")
+    return o32
+
+
+def dcp_finish(o32: torch.Tensor, out: torch.Tensor, head_start: int, global_lse: Optional[torch.Tensor] = None,
+               cur_o: Optional[torch.Tensor] = None, cur_lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """This rank's heads of the all-reduced fp32 [T, H_all, Dv] -> out [T, H_loc, Dv] (16-bit), joined with the
+    extend path's own-chunk partial (cur_o 16-bit [T, H_loc, Dv], cur_lse fp32 [T, H_loc]) when given."""
+    _require_cuda(o32, out, global_lse, cur_o, cur_lse)
+    T, Hall, Dv = o32.shape
+    Hloc = out.shape[1]
+    if tuple(out.shape) != (T, Hloc, Dv) or not out.is_contiguous() or not o32.is_contiguous():
+        raise ValueError("dcp_finish: out must be contiguous [T, H_loc, Dv]")
+    if cur_o is not None and (tuple(cur_o.shape) != tuple(out.shape) or cur_o.dtype != out.dtype or not cur_o.is_contiguous()
+                              or not cur_lse.is_contiguous() or not global_lse.is_contiguous()):
+        raise ValueError("dcp_finish: cur_o must match out; LSEs contiguous")
+    st = _L.load().rx_dcp_finish(_ptr(o32), _ptr(global_lse), _ptr(cur_o), _ptr(cur_lse), _ptr(out), T, Hall,
+                                 int(head_start), Hloc, Dv, _rx_dtype(out), _stream(o32))
+    _L.check(st, "rx_dcp_finish")
+    return out

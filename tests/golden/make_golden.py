@@ -15,6 +15,7 @@ Fixture families:
   F5 decode attention (Triton decode_attention_fwd) -> decode_*.npz
   F6 extend attention (Triton extend_attention_fwd) -> extend_*.npz
   F7 radix tree op sequences (reference RadixCache, recording allocator) -> radix_sequences.json
+  F15 decode context parallel: per-rank lengths, local kv indices, the cross-rank LSE merge -> dcp.npz
   F14 the reference's torch-native SDPA helpers (a14) on fp32 tensors -> torch_native.npz
   F13 scheduler flow (reference RadixCache request hooks + allocators + req_to_token rows) -> scheduler_flow.json
   F8 bf16 decode/extend from the compiled reference C++ CPU kernels -> cpu_native.npz
@@ -928,7 +929,100 @@ def f14():
     save("torch_native.npz", **flat)
 
 
+# ------------------------------------------------------------------ F15
+def _ref_funcs(rel_path, names, ns):
+    """Functions cut out of a reference FILE with ast at generation time and executed (the module around them does not
+    import here); only the vectors they produce are stored."""
+    import ast
+
+    path = os.path.join(_ref_import.REF_PY, rel_path)
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(keep) == len(names), [n.name for n in keep]
+    exec(compile(ast.fix_missing_locations(ast.Module(body=keep, type_ignores=[])), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def f15():
+    """F15 decode context parallel: get_dcp_lens (srt/layers/dcp/layout.py), the per-rank kv-index kernel
+    (create_triton_kv_indices_for_dcp_triton, under the Triton interpreter) and cp_lse_ag_out_rs_mha
+    (srt/layers/dcp/comm.py) run rank by rank against a recording stand-in for the process group -> dcp.npz."""
+    import typing
+
+    from sglang.kernels.ops.attention.dcp_kernels import create_triton_kv_indices_for_dcp_triton
+
+    (get_dcp_lens,) = _ref_funcs("sglang/srt/layers/dcp/layout.py", ["get_dcp_lens"], {"torch": torch})
+    rng = np.random.default_rng(15)
+    out = {}
+    ci = 0
+    for dcp in (2, 3, 8):
+        batch, max_batch, ctx = 9, 16, 400
+        r2t = torch.from_numpy(rng.integers(0, 1 << 20, size=(max_batch, ctx)).astype(np.int32))
+        rpi = torch.from_numpy(rng.choice(max_batch, size=batch, replace=False).astype(np.int32))
+        lens = torch.from_numpy(np.concatenate([[0, 1, dcp - 1, dcp, dcp + 1],
+                                                rng.integers(0, ctx // 2, size=batch - 5)]).astype(np.int32))
+        start = torch.from_numpy(rng.integers(0, ctx // 2, size=batch).astype(np.int32))
+        for use_start in (False, True):
+            for rank in range(dcp):
+                dl = get_dcp_lens(lens, dcp, rank, start if use_start else None).to(torch.int32)
+                kv_indptr = torch.zeros((batch + 1,), dtype=torch.int32)
+                kv_indptr[1:] = torch.cumsum(dl, 0)
+                kv_indices = torch.full((int(kv_indptr[-1]),), -1, dtype=torch.int64)
+                create_triton_kv_indices_for_dcp_triton[(batch,)](
+                    r2t, rpi, dl, kv_indptr, start if use_start else None, kv_indices, r2t.stride(0), dcp, rank)
+                tag = f"idx{ci}"
+                ci += 1
+                out.update({f"{tag}.req_to_token": r2t.numpy(), f"{tag}.req_pool_indices": rpi.numpy(),
+                            f"{tag}.lens": lens.numpy(), f"{tag}.start": start.numpy(),
+                            f"{tag}.use_start": np.int32(use_start), f"{tag}.dcp": np.int32(dcp),
+                            f"{tag}.rank": np.int32(rank), f"{tag}.dcp_lens": dl.numpy(),
+                            f"{tag}.kv_indptr": kv_indptr.numpy(), f"{tag}.kv_indices": kv_indices.numpy()})
+    out["idx.count"] = np.int32(ci)
+
+    # cp_lse_ag_out_rs_mha: every rank's call sees the same all-gathered LSEs; the stand-in's all_reduce records the
+    # rank's scaled output and returns the sum over ALL ranks (computed from the recorded ones on a second pass)
+    class Group:
+        def __init__(self, world, rank, lses, summed):
+            self.world_size, self.rank_in_group, self._lses, self._summed, self.scaled = world, rank, lses, summed, None
+
+        def all_gather(self, x, dim=0):
+            assert dim == 0
+            return torch.cat(list(self._lses), dim=0)
+
+        def all_reduce(self, x):
+            self.scaled = x.clone()
+            return self._summed if self._summed is not None else x
+
+    ns = {"torch": torch, "GroupCoordinator": object, "Optional": typing.Optional}
+    _ag_lse, merge = _ref_funcs("sglang/srt/layers/dcp/comm.py", ["_ag_lse", "cp_lse_ag_out_rs_mha"], ns)
+    g = torch.Generator().manual_seed(15)
+    for mi, (world, T, H, D) in enumerate([(2, 5, 4, 16), (4, 3, 8, 32)]):
+        outs = [torch.randn(T, H, D, generator=g) for _ in range(world)]
+        lses = [torch.randn(T, H, generator=g) * 3 for _ in range(world)]
+        lses[0][0, :] = float("-inf")            # a rank without tokens for one request
+        outs[0][0, :] = float("nan")             # ... whose output row is undefined
+        for r in range(world):
+            lses[r][1, 0] = float("-inf")        # a row empty on every rank
+        scaled = []
+        for r in range(world):
+            grp = Group(world, r, lses, None)
+            merge(outs[r].clone(), lses[r].clone(), grp)
+            scaled.append(grp.scaled)
+        summed = torch.stack(scaled).sum(0)
+        finals, glses = [], []
+        for r in range(world):
+            o, l = merge(outs[r].clone(), lses[r].clone(), Group(world, r, lses, summed.clone()), return_lse=True)
+            finals.append(o)
+            glses.append(l)
+        out.update({f"merge{mi}.outs": torch.stack(outs).numpy(), f"merge{mi}.lses": torch.stack(lses).numpy(),
+                    f"merge{mi}.scaled": torch.stack(scaled).numpy(), f"merge{mi}.final": torch.stack(finals).numpy(),
+                    f"merge{mi}.global_lse": torch.stack(glses).numpy()})
+    out["merge.count"] = np.int32(2)
+    save("dcp.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14",
+                             "f15"]
     for w in which:
         globals()[w]()

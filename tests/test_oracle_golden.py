@@ -360,3 +360,61 @@ def test_a14_torch_native_semantics_pinned_to_the_reference(golden_dir):
         gotd = orc.sdpa_decode_req_to_token(c["qd"], c["kc"], c["vc"], c["r2t"], c["rpi"], c["seq"], d ** -0.5,
                                             sliding_window_size=w)
         assert np.abs(gotd - c["o_decode"].astype(np.float64)).max() < 5e-6, name
+
+
+def _dcp_golden(golden_dir):
+    npz = np.load(os.path.join(golden_dir, "dcp.npz"))
+    cases = {}
+    for key in npz.files:
+        case, field = key.split(".", 1)
+        cases.setdefault(case, {})[field] = npz[key]
+    return cases
+
+
+def test_dcp_lens_and_local_kv_indices_bit_exact(golden_dir):
+    """8e (decode context parallel), F15: the reference's get_dcp_lens (srt/layers/dcp/layout.py:23-41) and its
+    create_triton_kv_indices_for_dcp_triton (kernels/ops/attention/dcp_kernels.py:34-76, run under the Triton
+    interpreter) for dcp 2 / 3 / 8, every rank, with and without a start offset, lengths 0 / 1 / dcp-1 / dcp / dcp+1."""
+    cases = _dcp_golden(golden_dir)
+    n = int(cases["idx"]["count"])
+    assert n == 26
+    for i in range(n):
+        c = cases[f"idx{i}"]
+        start = c["start"] if int(c["use_start"]) else None
+        dl = orc.dcp_lens(c["lens"], int(c["dcp"]), int(c["rank"]), start)
+        assert np.array_equal(dl, c["dcp_lens"]), i
+        indptr, idx, dl2 = orc.dcp_kv_indices(c["req_to_token"], c["req_pool_indices"], c["lens"], int(c["dcp"]),
+                                              int(c["rank"]), start)
+        assert np.array_equal(indptr, c["kv_indptr"]) and np.array_equal(idx, c["kv_indices"]), i
+        assert np.array_equal(dl2, c["dcp_lens"])
+    # the shares of all ranks partition the request
+    c = cases["idx0"]
+    tot = sum(orc.dcp_lens(c["lens"], 3, r) for r in range(3))
+    assert np.array_equal(tot, c["lens"])
+
+
+def test_dcp_lse_merge_matches_the_reference(golden_dir):
+    """F15: cp_lse_ag_out_rs_mha (srt/layers/dcp/comm.py:82-108) executed from the reference file rank by rank:
+    the scaled contribution of every rank, the head slice of the sum each rank keeps and the global LSE -- with a
+    rank that saw no token for one request (LSE -inf, NaN output row) and a row that is empty on every rank."""
+    cases = _dcp_golden(golden_dir)
+    for mi in range(int(cases["merge"]["count"])):
+        c = cases[f"merge{mi}"]
+        world, T, H, D = c["outs"].shape
+        scaled, summed, g = orc.dcp_merge(c["outs"], c["lses"])
+        assert np.abs(scaled - c["scaled"]).max() < 2e-6
+        hl = H // world
+        for r in range(world):
+            assert np.abs(summed[:, r * hl:(r + 1) * hl] - c["final"][r]).max() < 5e-6
+            want_l = c["global_lse"][r].astype(np.float64)
+            got_l = g[:, r * hl:(r + 1) * hl]
+            both_inf = np.isneginf(want_l) & np.isneginf(got_l)
+            with np.errstate(invalid="ignore"):
+                assert np.all(both_inf | (np.abs(got_l - want_l) < 5e-6))
+
+
+def test_dcp_store_loc_restatement():
+    loc = np.array([10, 11, 12, 13, 25, 7], dtype=np.int64)
+    pos = np.array([0, 1, 2, 3, 9, 4], dtype=np.int64)
+    assert orc.dcp_store_loc(loc, pos, 2, 1).tolist() == [0, 5, 0, 6, 12, 0]
+    assert orc.dcp_store_loc(loc, pos, 2, 0, skip_index=-1).tolist() == [5, -1, 6, -1, -1, 3]

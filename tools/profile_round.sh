@@ -11,6 +11,9 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3
 # counter passes: eager launches (--no-graph), one counter family per pass, nothing but --pmc on the command line
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pf --output-format csv -- python3 $R/bench.py --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pf.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pw --output-format csv -- python3 $R/bench.py --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pw.err
+# MLA decode kernels: HBM read bytes per launch (one --pmc pass each, nothing else on the command line)
+rocprofv3 --pmc FETCH_SIZE -d $OUT/mla16_pmc -o p --output-format csv -- python3 $R/tools/mla_bench.py > /dev/null 2> $OUT/mla16_pmc.err
+FP8=1 rocprofv3 --pmc FETCH_SIZE -d $OUT/mla8_pmc -o p --output-format csv -- python3 $R/tools/mla_bench.py > /dev/null 2> $OUT/mla8_pmc.err
 python3 $R/profiles/summarize.py $OUT $TAG
 # MLA decode (config 5 shape): kernel traces for 16-bit and fp8 latent rows
 rocprofv3 --kernel-trace --stats -d $OUT/mla16 -o m --output-format csv -- python3 $R/tools/mla_bench.py > $OUT/mla16.txt 2> $OUT/mla16.err
@@ -21,5 +24,5 @@ cp $(find $OUT/mla8 -name "*_kernel_stats.csv" | head -1) $R/profiles/${TAG}_mla
 rocprofv3 --kernel-trace --stats -d $OUT/casc -o casc --output-format csv -- python3 $R/tools/cascade_bench.py > $OUT/${TAG}_cascade_bench.txt 2> $OUT/casc.err
 cp $OUT/casc/casc_kernel_stats.csv $R/profiles/${TAG}_cascade_kernel_stats.csv 2>/dev/null
 cp $OUT/${TAG}_bench_default.json $OUT/${TAG}_bench_under_kernel_trace.json $R/gpurun_out/ 2>/dev/null
-mkdir -p $R/gpurun_out/profiles_new && cp $R/profiles/${TAG}_kernel_stats.csv $R/profiles/${TAG}_pmc_summary.json $R/profiles/${TAG}_cascade_kernel_stats.csv $R/profiles/${TAG}_mla_bf16_kernel_stats.csv $R/profiles/${TAG}_mla_fp8_kernel_stats.csv $OUT/${TAG}_cascade_bench.txt $OUT/mla16.txt $OUT/mla8.txt $R/gpurun_out/profiles_new/ 2>/dev/null
+mkdir -p $R/gpurun_out/profiles_new && cp $R/profiles/${TAG}_kernel_stats.csv $R/profiles/${TAG}_pmc_summary.json $R/profiles/${TAG}_cascade_kernel_stats.csv $R/profiles/${TAG}_mla_bf16_kernel_stats.csv $R/profiles/${TAG}_mla_fp8_kernel_stats.csv $R/profiles/${TAG}_mla_pmc_summary.json $OUT/${TAG}_cascade_bench.txt $OUT/mla16.txt $OUT/mla8.txt $R/gpurun_out/profiles_new/ 2>/dev/null
 tail -c 1500 $OUT/${TAG}_bench_default.json
