@@ -619,9 +619,9 @@ def mla_decode_bench(dev):
         if fp8:
             kv = kv.to(torch.float8_e4m3fn)
 
-        def run():
+        def run(stages=0):
             ops.decode_attention_fwd_paged(q, kv, kv[..., :dv], o, r2t, rpi, lens, al, lse, nsplit, S, dk ** -0.5,
-                                           page_size=ps)
+                                           page_size=ps, stages=stages)
         # 10 calls captured into one HIP graph: the op is ~75-125 us of GPU work and the generic Python wrapper costs
         # about as much per call, so eager timing would measure the host
         side = torch.cuda.Stream()
@@ -631,25 +631,47 @@ def mla_decode_bench(dev):
                 run()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
-            for _ in range(10):
-                run()
-        gr.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
+        def timed(stages):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(10):
+                    run(stages)
             gr.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 30
-        del gr
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 30
+
+        ms = timed(0)       # the whole op: stage 1 + the stage-2 merge of the 8 kv-split partials
+        ms_k = timed(1)     # the dominant kernel alone (stage 1), launch to launch inside the graph
         byt = bs * ctx * dk * (1 if fp8 else 2) + bs * hq * (dk + dv) * 2
-        res[name] = {"us": ms * 1e3, "bytes": byt,
-                     "roofline": {"bound": "hbm", "achieved": byt / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": byt / ms / 1e6 / HBM_PEAK_GBS, "traffic": None}}
+        res[name] = {"us": ms * 1e3, "kernel_us": ms_k * 1e3, "bytes": byt,
+                     "op_frac_of_hbm_peak": byt / ms / 1e6 / HBM_PEAK_GBS,
+                     # as for the decode leg: the roofline is the dominant kernel's (profiles/rNN_mla_*_kernel_stats.csv
+                     # hold its rocprofv3 duration)
+                     "roofline": {"bound": "hbm", "kernel": "rx::decode_mla8_dma_kernel" if fp8 else "rx::decode_mla_kernel",
+                                  "achieved": byt / ms_k / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": byt / ms_k / 1e6 / HBM_PEAK_GBS, "traffic": None}}
         del kv
+    try:  # HBM read bytes per launch of the two kernels: a PMC figure from its own rocprofv3 passes, quoted with provenance
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_mla_pmc_summary.json")))
+        if cand:
+            doc = json.load(open(cand[-1]))
+            for name in ("bf16_rows", "fp8_rows"):
+                k = doc["kernels"].get(name)
+                if k and name in res:
+                    res[name]["roofline"]["traffic"] = k["hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)"]
+                    res[name]["roofline"]["traffic_source"] = {
+                        "file": "profiles/" + os.path.basename(cand[-1]),
+                        "note": "separate rocprofv3 --pmc FETCH_SIZE pass of tools/mla_bench.py (same shape, page_size 1 "
+                                "random slots) on another box, not this run"}
+    except Exception:  # noqa: BLE001
+        pass
     return res
 
 
