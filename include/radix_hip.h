@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 3
+#define RX_ABI_VERSION 4
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -199,6 +199,13 @@ typedef struct rx_decode_params {
    * 2 = stage 2 only.  Lets a caller produce the extra partials on another stream while stage 1 runs
    * and join before the merge.  1 / 2 need max_kv_splits > 1. */
   int32_t stages;
+  /* Optional: stage 2 inside the stage-1 kernel.  int32[>= bs * num_q_heads], device memory, ZERO before the first
+   * call; the kernels leave it zero.  With it (and stages == 0, no extra partials, max_kv_splits a multiple of 8, 16-byte
+   * aligned attn_logits / attn_lse, at most 4 MiB of partials, the D = 64 / 128 or MLA kernel) the last workgroup of a (request, head block) to finish merges that block's kv-split partials
+   * itself and no second kernel is launched -- the same arithmetic as stage 2 (_decode_softmax_reducev_fwd,
+   * decode_attention.py:731-805).  One buffer serves one stream of calls (not two concurrent ones); after a faulted
+   * launch the caller zeroes it again.  NULL: stage 2 is its own launch, as in the reference. */
+  int32_t* merge_counters;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);

@@ -26,6 +26,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -149,6 +151,12 @@ class HipRadixAttnBackend:
         self.forward_metadata: Optional[ForwardMetadata] = None
         self._scratch_logits = None
         self._scratch_lse = None
+        # stage 2 inside the stage-1 kernel (rx_decode_params.merge_counters): one zeroed word per (request, head);
+        # the kernels leave it zero, so one buffer serves every layer and every replay of a captured step
+        self._merge_counters = torch.zeros(max(1, self.req_to_token_pool.size) * self.num_head, dtype=torch.int32,
+                                           device=self.device)
+        if os.environ.get("RX_NO_INKERNEL_MERGE"):  # dev A/B: stage 2 as its own launch
+            self._merge_counters = None
         self._graph = None  # static buffers of init_cuda_graph_state
         self._md_version = 0  # bumped by every init_forward_metadata_out_graph
         self._decode_launchers = {}  # layer_id -> ops.DecodeLauncher
@@ -659,18 +667,19 @@ class HipRadixAttnBackend:
                 ln.set_metadata(self._md_version, q3.shape[0], kv_indptr=md.window_kv_indptr,
                                 kv_indices=md.window_kv_indices, num_kv_splits=md.window_num_kv_splits,
                                 max_kv_splits=md.max_kv_splits if md.attn_logits is not None else 1,
-                                attn_logits=md.attn_logits, attn_lse=md.attn_lse)
+                                attn_logits=md.attn_logits, attn_lse=md.attn_lse,
+                                merge_counters=self._merge_counters)
             elif self.decode_index_mode == "indices":
                 ln.set_metadata(self._md_version, q3.shape[0], kv_indptr=md.kv_indptr,
                                 kv_indices=md.kv_indices, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
-                                attn_lse=md.attn_lse)
+                                attn_lse=md.attn_lse, merge_counters=self._merge_counters)
             else:
                 ln.set_metadata(self._md_version, q3.shape[0], req_to_token=self.req_to_token,
                                 req_pool_indices=forward_batch.req_pool_indices,
                                 seq_lens=forward_batch.seq_lens, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
-                                attn_lse=md.attn_lse)
+                                attn_lse=md.attn_lse, merge_counters=self._merge_counters)
         if sinks is not None and sinks.dtype != torch.float32:
             sinks = sinks.float()
         ln(q3, o3, torch.cuda.current_stream(q.device).cuda_stream, sinks)

@@ -127,6 +127,114 @@ __device__ __forceinline__ int64_t mul_u32(int64_t slot, int64_t stride) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// ---- stage 2 inside the stage-1 kernel ("the last workgroup to arrive merges") --------------------------------
+// With rx_decode_params.merge_counters the kv-split kernels do not need the stage-2 launch: every workgroup of a
+// (request, head block) publishes its partial, bumps the block's counter, and the one that sees `live - 1` resets the
+// counter for the next launch and merges all `live` partials of its head block.  The partials cross XCDs, whose L2s
+// are not coherent with each other.  Agent-scope release / acquire FENCES would do (buffer_wbl2 + buffer_inv), but
+// they write back and invalidate a whole L2 per workgroup: measured 67 -> 142 us on the MLA shape and 121 -> 750 us
+// at bs 64 x 2 k.  Instead only the partials themselves take the slow path: device-scope (sc0 sc1) write-through
+// stores and device-scope loads, plus the counter's device-scope atomic; everything else keeps its cached accesses.
+__device__ __forceinline__ void store_dev(float* p, float v) {
+  asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_dev(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+// One round trip for a chunk of 8 splits: the 8 LSEs (two 16-B loads) and the 8 partial rows' 16 B of this thread, all
+// device-scope, issued together and waited for once.  (One asm statement: between a load and its wait hipcc must not
+// touch the destination registers, and it cannot know that.)
+__device__ __forceinline__ void load_dev_chunk8(const float* lse8, const float* const (&row)[8], f32x4& la, f32x4& lb,
+                                                f32x4 (&x)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %10, off sc0 sc1\n\tglobal_load_dwordx4 %1, %10, off offset:16 sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %11, off sc0 sc1\n\tglobal_load_dwordx4 %3, %12, off sc0 sc1\n\t"
+      "global_load_dwordx4 %4, %13, off sc0 sc1\n\tglobal_load_dwordx4 %5, %14, off sc0 sc1\n\t"
+      "global_load_dwordx4 %6, %15, off sc0 sc1\n\tglobal_load_dwordx4 %7, %16, off sc0 sc1\n\t"
+      "global_load_dwordx4 %8, %17, off sc0 sc1\n\tglobal_load_dwordx4 %9, %18, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(la), "=&v"(lb), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]),
+        "=&v"(x[7])
+      : "v"(lse8), "v"(row[0]), "v"(row[1]), "v"(row[2]), "v"(row[3]), "v"(row[4]), "v"(row[5]), "v"(row[6]), "v"(row[7])
+      : "memory");
+}
+__device__ __forceinline__ void load_dev_lse8(const float* lse8, f32x4& la, f32x4& lb) {
+  asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(la), "=&v"(lb)
+               : "v"(lse8)
+               : "memory");
+}
+// Returns true in the workgroup that has to merge (workgroup-uniform; contains two barriers).
+__device__ __forceinline__ bool split_arrive_is_last(int32_t* counter, int live) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through partial stores have completed ...
+  __syncthreads();                                  // ... and so have every other thread's, before the count moves
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (old == live - 1);
+    if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
+// _decode_softmax_reducev_fwd (decode_attention.py:731-805) for ONE block of `nheads` (<= 16) consecutive q heads of
+// one request, by the 256 threads of the calling workgroup; same arithmetic as decode_merge_kernel (rx_decode.hip).
+// logits / lse point at the block's first head: partial (q, s) is logits[(q * max_splits + s) * dv ...], lse[q *
+// max_splits + s]; o at the block's first head of the request.
+template <typename T>
+__device__ __forceinline__ void merge_splits_in_kernel(const float* logits, const float* lse, int nheads, int dv, int live,
+                                                       int max_splits, const float* sinks /* block's first head, or NULL */,
+                                                       float v_scale, uint16_t* o, int64_t o_stride_h) {
+  // requires max_splits % 8 == 0 and 16-byte aligned buffers (the host enables the in-kernel form only then)
+  const int dv4 = dv >> 2;
+  for (int i = threadIdx.x; i < nheads * dv4; i += 256) {
+    const int q = i / dv4, d = (i % dv4) * 4;
+    const float* l = lse + q * max_splits;
+    const float* lp = logits + static_cast<int64_t>(q) * max_splits * dv + d;
+    float e_max = -INFINITY;
+    if (live > 8) {  // two passes, as stage 2: the maximum over ALL live splits first
+      for (int s0 = 0; s0 < live; s0 += 8) {
+        f32x4 la, lb;
+        load_dev_lse8(l + s0, la, lb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (s0 + j < live) e_max = fmaxf(e_max, j < 4 ? la[j] : lb[j - 4]);
+      }
+    }
+    float e_sum = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < live; s0 += 8) {
+      const float* row[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row[j] = lp + static_cast<int64_t>(min(s0 + j, live - 1)) * dv;
+      f32x4 la, lb, x[8];
+      load_dev_chunk8(l + s0, row, la, lb, x);
+      if (live <= 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < live) e_max = fmaxf(e_max, j < 4 ? la[j] : lb[j - 4]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (s0 + j < live) {  // in stage 2's order
+          const float w = __expf((j < 4 ? la[j] : lb[j - 4]) - e_max);
+          acc += w * x[j];
+          e_sum += w;
+        }
+      }
+    }
+    if (sinks) e_sum += __expf(sinks[q] - e_max);
+    const float inv = v_scale / e_sum;
+    u32x2 pk;
+    pk[0] = pack2<T>(acc[0] * inv, acc[1] * inv);
+    pk[1] = pack2<T>(acc[2] * inv, acc[3] * inv);
+    *reinterpret_cast<u32x2*>(o + q * o_stride_h + d) = pk;
+  }
+}
+
 // max over the four lanes {l, l^16, l^32, l^48} that hold one query's scores in the S^T accumulator
 // layout.  gfx950 half/row swaps (v_permlane16_swap / v_permlane32_swap) instead of two ds_bpermute
 // round trips through the LDS crossbar: no lgkmcnt wait on the softmax critical path.  Inline asm

@@ -55,6 +55,7 @@ struct DecodeArgs {
   const float* extra_lse;    // [num_extra, bs, hq]
   int32_t num_extra;
   int32_t stages;  // 0 both, 1 stage 1 only, 2 stage 2 only
+  int32_t* merge_counters;  // in-kernel stage 2 (rx_common.h split_arrive_is_last), or NULL: stage-2 launch
 };
 
 // Grok temperature factor of a request (decode_attention.py:156-160): the single query sits at seq_len-1
@@ -224,6 +225,19 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
   const bool q_valid = gq < a.group;
   const int h = kvh * a.group + gq;      // global q head
 
+  if (!single && a.merge_counters && si.seq_len == 0) {
+    // no workgroup of this request will ever arrive (its split count may even be 0): split 0's workgroup writes
+    // what the stage-2 kernel writes for zero live splits
+    if (split == 0)
+      for (int i = tid; i < 16 * D; i += 256) {
+        const int q = i / D, d = i % D;
+        if (qb * 16 + q >= a.group) continue;
+        const int hh = kvh * a.group + qb * 16 + q;
+        const float e_sum = a.sinks ? INFINITY : 0.f;  // exp(sink - (-inf))
+        a.o[b * a.o_stride_t + hh * a.o_stride_h + d] = T::from_f32(0.f * (a.v_scale / e_sum));
+      }
+    return;
+  }
   if (split >= splits) return;
   int32_t lo, hi;
   split_range(si.seq_len, splits, split, lo, hi);
@@ -459,9 +473,24 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
       a.o[b * a.o_stride_t + hh * a.o_stride_h + d] = T::from_f32(acc / den * a.v_scale);
     } else {
       const int64_t row = (static_cast<int64_t>(b) * a.hq + hh) * a.max_kv_splits + split;
-      a.attn_logits[row * D + d] = acc / lsum;
-      if (d == 0) a.attn_lse[row] = mx * kLn2 + __logf(lsum);
+      if (a.merge_counters) {  // partials that another XCD's workgroup may merge: device-scope write-through stores
+        store_dev(a.attn_logits + row * D + d, acc / lsum);
+        if (d == 0) store_dev(a.attn_lse + row, mx * kLn2 + __logf(lsum));
+      } else {
+        a.attn_logits[row * D + d] = acc / lsum;
+        if (d == 0) a.attn_lse[row] = mx * kLn2 + __logf(lsum);
+      }
     }
+  }
+  if (!single && a.merge_counters) {  // stage 2 here: the last of this head block's live splits merges them
+    const int32_t per = ((si.seq_len + splits - 1) / splits + kMinBlockKV - 1) / kMinBlockKV * kMinBlockKV;
+    const int32_t live = min((si.seq_len + per - 1) / per, min(splits, a.max_kv_splits));
+    if (!split_arrive_is_last(a.merge_counters + (b * a.hkv + kvh) * a.qblocks + qb, live)) return;
+    const int h0 = kvh * a.group + qb * 16;
+    const int64_t row0 = (static_cast<int64_t>(b) * a.hq + h0) * a.max_kv_splits;
+    merge_splits_in_kernel<T>(a.attn_logits + row0 * D, a.attn_lse + row0, min(16, a.group - qb * 16), D, live,
+                              a.max_kv_splits, a.sinks ? a.sinks + h0 : nullptr, a.v_scale,
+                              a.o + b * a.o_stride_t + h0 * a.o_stride_h, a.o_stride_h);
   }
 }
 
@@ -690,7 +719,7 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
     hipLaunchKernelGGL((decode_generic_kernel<T, IdxT, LINEAR>), dim3(grid), dim3(64),
                        dk * sizeof(float), s, a, dk, dv);
   }
-  if (a.max_kv_splits > 1 && a.stages != 1)
+  if (a.max_kv_splits > 1 && a.stages != 1 && !(a.merge_counters && mfma_ok))
     launch_merge<T>(a, dv, s);
   return check_launch("rx_decode_attn");
 }
@@ -706,15 +735,15 @@ static int dispatch_decode(const DecodeArgs& a, int dk, int dv, bool idx64, bool
                 : launch_decode<T, int32_t, false>(a, dk, dv, s);
 }
 
-int launch_decode_mla(const rx_decode_params* p, hipStream_t s);  // rx_decode_mla.hip
+int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, hipStream_t s);  // rx_decode_mla.hip
 
 template <typename T>
 static int run_mla(const rx_decode_params* p, const DecodeArgs& a, hipStream_t s) {
   if (a.stages != 2) {
-    const int rc = launch_decode_mla(p, s);
+    const int rc = launch_decode_mla(p, a.merge_counters, s);
     if (rc != RX_OK) return rc;
   }
-  if (a.max_kv_splits > 1 && a.stages != 1)
+  if (a.max_kv_splits > 1 && a.stages != 1 && !a.merge_counters)
     launch_merge<T>(a, p->v_head_dim, s);
   return check_launch("rx_decode_attn(mla)");
 }
@@ -824,6 +853,17 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
                    ((uintptr_t)p->q & 15) == 0 && ((uintptr_t)p->kv.k_buf & (p->kv.kv_fp8 ? 7 : 15)) == 0 &&
                    ((p->o_stride_t | p->o_stride_h) % 4 == 0) && ((uintptr_t)p->o & 7) == 0;
   if (mla) RX_REQUIRE(!p->kv_start, "rx_decode_attn: kv_start is not supported on the MLA kernel");
+  // stage 2 inside the stage-1 kernel: the kernels that have the epilogue, both stages wanted, nothing else to merge,
+  // and the vector stores of the merge possible
+  const bool merge_in_kernel = p->merge_counters && p->stages == 0 && a.num_extra == 0 && max_splits > 1 &&
+                               (mfma_ok || mla) && p->o_stride_t % 4 == 0 && p->o_stride_h % 4 == 0 &&
+                               ((uintptr_t)p->o & 7) == 0 && ((uintptr_t)p->attn_logits & 15) == 0 &&
+                               max_splits % 8 == 0 && ((uintptr_t)p->attn_lse & 15) == 0 &&  // 8 LSEs = two 16-B loads
+                               // the partials take device-scope (write-through) stores in this form: a win while they
+                               // are small (bs 1 x 32 k: 39 -> 36 us per layer, 16 x 4 k: 56 -> 53), a loss once they
+                               // are many MB (MLA 64 x 16 heads x 8 splits = 17 MB: 67.6 -> 69.5 us)
+                               static_cast<int64_t>(p->bs) * p->num_q_heads * max_splits * dv * 4 <= (4ll << 20);
+  a.merge_counters = merge_in_kernel ? p->merge_counters : nullptr;
   if (mla) return p->dtype == RX_BF16 ? run_mla<BF16>(p, a, s) : run_mla<F16>(p, a, s);
   return p->dtype == RX_BF16 ? dispatch_decode<BF16>(a, dk, dv, idx64, linear, s)
                              : dispatch_decode<F16>(a, dk, dv, idx64, linear, s);

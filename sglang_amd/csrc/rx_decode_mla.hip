@@ -47,6 +47,7 @@ struct MlaArgs {
   float sm_scale, v_scale, logit_cap;
   const float* sinks;
   int32_t xai_len;
+  int32_t* merge_counters;  // in-kernel stage 2 (rx_common.h split_arrive_is_last), or NULL
 };
 
 #ifndef RX_MLA_STAMP
@@ -61,6 +62,20 @@ struct MlaArgs {
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 constexpr int kMlaDk = 576, kMlaDv = 512;
 constexpr int kMlaTile = 32;
+
+// stage 2 inside the kernel: called by every thread of a workgroup that wrote a partial of (request b, q block qb)
+template <typename T>
+__device__ __forceinline__ void mla_merge_if_last(const MlaArgs& a, int b, int qb, int32_t seq_len, int32_t splits) {
+  const int32_t per = ((seq_len + splits - 1) / splits + 31) / 32 * 32;
+  const int32_t live = min((seq_len + per - 1) / per, min(splits, a.max_kv_splits));
+  if (!split_arrive_is_last(a.merge_counters + b * a.qblocks + qb, live)) return;
+  const int h0 = qb * 16;
+  const int64_t row0 = (static_cast<int64_t>(b) * a.hq + h0) * a.max_kv_splits;
+  merge_splits_in_kernel<T>(a.attn_logits + row0 * kMlaDv, a.attn_lse + row0, min(16, a.hq - h0), kMlaDv, live,
+                            a.max_kv_splits, a.sinks ? a.sinks + h0 : nullptr, a.v_scale,
+                            a.o + b * a.o_stride_t + h0 * a.o_stride_h, a.o_stride_h);
+}
+
 constexpr int kMlaRowBytes = kMlaDk * 2;          // 1152
 constexpr int kMlaLdsRow = kMlaRowBytes + 16;     // 1168: padded LDS row stride
 constexpr int kMlaChunks = kMlaRowBytes / 16;     // 72 16-byte chunks per row
@@ -140,6 +155,16 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
   const bool single = (a.max_kv_splits == 1);
   const int h = qb * 16 + r;
   const bool q_valid = h < a.hq;
+  if (!single && a.merge_counters && seq_len == 0) {  // nobody will arrive: stage 2's zero-split result, by split 0
+    if (split == 0)
+      for (int i = tid; i < 16 * kMlaDv; i += 256) {
+        const int q = i / kMlaDv, d = i % kMlaDv;
+        if (qb * 16 + q < a.hq)
+          a.o[b * a.o_stride_t + (qb * 16 + q) * a.o_stride_h + d] =
+              T::from_f32(0.f * (a.v_scale / (a.sinks ? INFINITY : 0.f)));
+      }
+    return;
+  }
   if (split >= splits) return;
   const int32_t per = ((seq_len + splits - 1) / splits + 31) / 32 * 32;  // decode_attention.py:466-472
   const int32_t lo = per * split;
@@ -399,8 +424,8 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
   // ---- epilogue: every wave holds the full statistics and its own 128 output columns -------------
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
-  if (!q_valid) return;
   if (single) {
+    if (!q_valid) return;
     float den = l_run;
     if (a.sinks) den += fast_exp2(a.sinks[h] * kLog2e - m_run);
     const float inv = a.v_scale / den;
@@ -413,18 +438,27 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
       *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
     }
   } else {
-    const int64_t row = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits + split;
-    const float inv = 1.0f / l_run;
-    float* lp = a.attn_logits + row * kMlaDv + 128 * w + 4 * g;
+    if (q_valid) {
+      const int64_t row = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits + split;
+      const float inv = 1.0f / l_run;
+      float* lp = a.attn_logits + row * kMlaDv + 128 * w + 4 * g;
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) *reinterpret_cast<f32x4*>(lp + 16 * nb) = oacc[nb] * inv;
-    if (w == 0 && g == 0) a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
+      for (int nb = 0; nb < NBW; ++nb) {
+        if (a.merge_counters) store_dev(lp + 16 * nb, oacc[nb] * inv);  // may be merged from another XCD
+        else *reinterpret_cast<f32x4*>(lp + 16 * nb) = oacc[nb] * inv;
+      }
+      if (w == 0 && g == 0) {
+        if (a.merge_counters) store_dev(a.attn_lse + row, m_run * kLn2 + __logf(l_run));
+        else a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
+      }
 #if RX_MLA_STAMP
-    if (w == 0 && lane == 0) {
-      uint32_t* dbg = reinterpret_cast<uint32_t*>(a.attn_logits + row * kMlaDv);
-      for (int i = 0; i < 6; ++i) dbg[i] = st_acc[i];
-    }
+      if (w == 0 && lane == 0) {
+        uint32_t* dbg = reinterpret_cast<uint32_t*>(a.attn_logits + row * kMlaDv);
+        for (int i = 0; i < 6; ++i) dbg[i] = st_acc[i];
+      }
 #endif
+    }
+    if (a.merge_counters) mla_merge_if_last<T>(a, b, qb, seq_len, splits);
   }
 }
 
@@ -514,6 +548,16 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
   const bool single = (a.max_kv_splits == 1);
   const int h = qb * 16 + r;
   const bool q_valid = h < a.hq;
+  if (!single && a.merge_counters && seq_len == 0) {  // nobody will arrive: stage 2's zero-split result, by split 0
+    if (split == 0)
+      for (int i = tid; i < 16 * kMlaDv; i += 256) {
+        const int q = i / kMlaDv, d = i % kMlaDv;
+        if (qb * 16 + q < a.hq)
+          a.o[b * a.o_stride_t + (qb * 16 + q) * a.o_stride_h + d] =
+              T::from_f32(0.f * (a.v_scale / (a.sinks ? INFINITY : 0.f)));
+      }
+    return;
+  }
   if (split >= splits) return;
   const int32_t per = ((seq_len + splits - 1) / splits + 31) / 32 * 32;
   const int32_t lo = per * split;
@@ -724,8 +768,8 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
   // ---- epilogue (as the first form)
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
-  if (!q_valid) return;
   if (single) {
+    if (!q_valid) return;
     float den = l_run;
     if (a.sinks) den += fast_exp2(a.sinks[h] * kLog2e - m_run);
     const float inv = a.v_scale / den;
@@ -738,18 +782,27 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
       *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
     }
   } else {
-    const int64_t row = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits + split;
-    const float inv = 1.0f / l_run;
-    float* lp = a.attn_logits + row * kMlaDv + 128 * w + 4 * g;
+    if (q_valid) {
+      const int64_t row = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits + split;
+      const float inv = 1.0f / l_run;
+      float* lp = a.attn_logits + row * kMlaDv + 128 * w + 4 * g;
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) *reinterpret_cast<f32x4*>(lp + 16 * nb) = oacc[nb] * inv;
-    if (w == 0 && g == 0) a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
+      for (int nb = 0; nb < NBW; ++nb) {
+        if (a.merge_counters) store_dev(lp + 16 * nb, oacc[nb] * inv);  // may be merged from another XCD
+        else *reinterpret_cast<f32x4*>(lp + 16 * nb) = oacc[nb] * inv;
+      }
+      if (w == 0 && g == 0) {
+        if (a.merge_counters) store_dev(a.attn_lse + row, m_run * kLn2 + __logf(l_run));
+        else a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
+      }
 #if RX_MLA_STAMP
-    if (w == 0 && lane == 0) {
-      uint32_t* dbg = reinterpret_cast<uint32_t*>(a.attn_logits + row * kMlaDv);
-      for (int i = 0; i < 6; ++i) dbg[i] = st_acc[i];
-    }
+      if (w == 0 && lane == 0) {
+        uint32_t* dbg = reinterpret_cast<uint32_t*>(a.attn_logits + row * kMlaDv);
+        for (int i = 0; i < 6; ++i) dbg[i] = st_acc[i];
+      }
 #endif
+    }
+    if (a.merge_counters) mla_merge_if_last<T>(a, b, qb, seq_len, splits);
   }
 }
 
@@ -758,8 +811,9 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
 namespace rx {
 // called from rx_decode_attn (rx_decode.hip) when head_dim == 576 and v_head_dim == 512, Hkv == 1
 // and V aliases K's first 512 columns
-int launch_decode_mla(const rx_decode_params* p, hipStream_t s) {
+int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, hipStream_t s) {
   MlaArgs a;
+  a.merge_counters = merge_counters;
   a.q = (const uint16_t*)p->q;
   a.o = (uint16_t*)p->o;
   a.q_stride_t = p->q_stride_t;

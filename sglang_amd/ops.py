@@ -255,7 +255,8 @@ def kv_layout_hnd(k_buffer: torch.Tensor, v_buffer: torch.Tensor) -> _L.RxKvLayo
 def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
                          num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap=0.0,
                          sinks=None, xai_temperature_len=-1, has_mla=False, use_pdl=False,
-                         page_size: int = 1, score_mod=None, aux_tensors=None, kv_layout=None, stages: int = 0):
+                         page_size: int = 1, score_mod=None, aux_tensors=None, kv_layout=None, stages: int = 0,
+                         merge_counters=None):
     """Same contract as the reference.  q [bs,Hq,Dk], o [bs,Hq,Dv], kv_indptr int32[bs+1],
     kv_indices int32/int64, attn_logits fp32[bs,Hq,max_kv_splits,Dv], attn_lse fp32[bs,Hq,S].
     ``max_kv_splits == 1`` (or num_kv_splits None) runs the single-pass kernel.  ``stages`` as in
@@ -280,6 +281,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
     p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
     p.stages = int(stages)
+    p.merge_counters = _merge_counters_ptr(merge_counters, q.shape[0], q.shape[1])
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -321,10 +323,11 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
                                attn_logits, attn_lse, num_kv_splits, max_kv_splits, sm_scale,
                                k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
                                page_size: int = 1, kv_layout=None, xai_temperature_len=-1,
-                               kv_start=None, extra_o=None, extra_lse=None, stages: int = 0):
+                               kv_start=None, extra_o=None, extra_lse=None, stages: int = 0, merge_counters=None):
     p = _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse,
                              num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap, sinks, page_size,
                              kv_layout, xai_temperature_len, kv_start, extra_o, extra_lse, stages)
+    p.merge_counters = _merge_counters_ptr(merge_counters, q.shape[0], q.shape[1])
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -375,6 +378,17 @@ def _fill_decode_common(p, q, k_buffer, v_buffer, o, attn_logits, attn_lse, num_
         raise TypeError("q and o must share one 16-bit dtype; k_buffer / v_buffer that dtype or fp8 e4m3fn")
 
 
+def _merge_counters_ptr(merge_counters, bs: int, num_q_heads: int):
+    """rx_decode_params.merge_counters: zeroed int32 device memory of at least bs * Hq words (the kernels leave it
+    zero), or None for the separate stage-2 launch."""
+    if merge_counters is None:
+        return None
+    if (not merge_counters.is_cuda or merge_counters.dtype != torch.int32 or not merge_counters.is_contiguous()
+            or merge_counters.numel() < bs * num_q_heads):
+        raise ValueError("merge_counters must be a contiguous int32 GPU tensor of at least bs * num_q_heads words")
+    return merge_counters.data_ptr()
+
+
 class DecodeLauncher:
     """rx_decode_params pre-filled for one layer: the KV layout, head geometry and scales are set
     once; ``set_metadata`` writes the per-forward fields (shared by all layers of a forward) and
@@ -403,9 +417,10 @@ class DecodeLauncher:
 
     def set_metadata(self, version, bs, *, kv_indptr=None, kv_indices=None, req_to_token=None,
                      req_pool_indices=None, seq_lens=None, num_kv_splits=None, max_kv_splits=1,
-                     attn_logits=None, attn_lse=None):
+                     attn_logits=None, attn_lse=None, merge_counters=None):
         p = self.p
         p.bs = bs
+        p.merge_counters = _merge_counters_ptr(merge_counters, bs, p.num_q_heads)
         if kv_indices is not None:
             p.kv_indptr, p.kv_indices = kv_indptr.data_ptr(), kv_indices.data_ptr()
             p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
@@ -421,7 +436,7 @@ class DecodeLauncher:
         else:
             p.num_kv_splits, p.max_kv_splits = None, 1
         self._keep = (kv_indptr, kv_indices, req_to_token, req_pool_indices, seq_lens, num_kv_splits,
-                      attn_logits, attn_lse)
+                      attn_logits, attn_lse, merge_counters)
         self.version = version
 
     def __call__(self, q3, o3, stream_ptr, sinks=None):

@@ -271,6 +271,19 @@ def test_decode_paged_vs_oracle(ops, dtype, hq, hkv, d, page_size, layout):
     ops.decode_attention_fwd(qd, kbd, vbd, o2, kvp, kvi, al, lse, nsplit, S, sm, 1.0, 1.0,
                              page_size=page_size)
     parity.check_out(_np(o2.float()), want, dtype, "indices/split")
+    # stage 2 inside the stage-1 kernel (merge_counters): the last workgroup of a head block merges -- the SAME
+    # arithmetic, so the same bits; three calls in a row prove the counters come back to zero
+    cnt = torch.zeros(bs * hq, dtype=torch.int32, device=DEV)
+    for rep in range(3):
+        o3 = torch.full_like(o, float("nan"))
+        ops.decode_attention_fwd(qd, kbd, vbd, o3, kvp, kvi, al, lse, nsplit, S, sm, 1.0, 1.0,
+                                 page_size=page_size, merge_counters=cnt)
+        assert torch.equal(o3, o2), (rep, (o3.float() - o2.float()).abs().max().item())
+        assert int(cnt.abs().sum()) == 0
+    o4 = torch.full_like(o, float("nan"))
+    ops.decode_attention_fwd_paged(qd, kbd, vbd, o4, r2td, rpid, lensd, al, lse, nsplit, S, sm,
+                                   page_size=page_size, merge_counters=cnt)
+    assert torch.equal(o4, o2) and int(cnt.abs().sum()) == 0
 
 
 def test_decode_hnd_layout_and_sinks(ops):
@@ -535,6 +548,21 @@ def test_decode_mla_kernel(ops, dtype, hq, page_size):
                              1.0, 1.0, page_size=page_size)
     err2 = np.abs(_np(o2.float()).astype(np.float64) - want).max()
     parity.check(err2, tol, ("split", err2))
+    # in-kernel stage 2 (merge_counters): same bits as the two-launch form, counters back at zero, call after call
+    cnt = torch.zeros(bs * hq, dtype=torch.int32, device=DEV)
+    for rep in range(3):
+        o3 = torch.full_like(o, float("nan"))
+        ops.decode_attention_fwd(qd, kvd, kvd[..., :512], o3, _t(kv_indptr), _t(kv_indices), al, lse, nsplit, S, sm,
+                                 1.0, 1.0, page_size=page_size, merge_counters=cnt)
+        assert torch.equal(o3, o2), (rep, (o3.float() - o2.float()).abs().max().item())
+        assert int(cnt.abs().sum()) == 0
+    kv8 = kvd.to(torch.float8_e4m3fn)                     # the LDS-DMA kernel of fp8 latent rows
+    o5, o6 = torch.zeros_like(o), torch.full_like(o, float("nan"))
+    ops.decode_attention_fwd(qd, kv8, kv8[..., :512], o5, _t(kv_indptr), _t(kv_indices), al, lse, nsplit, S, sm,
+                             1.0, 1.0, page_size=page_size)
+    ops.decode_attention_fwd(qd, kv8, kv8[..., :512], o6, _t(kv_indptr), _t(kv_indices), al, lse, nsplit, S, sm,
+                             1.0, 1.0, page_size=page_size, merge_counters=cnt)
+    assert torch.equal(o5, o6) and int(cnt.abs().sum()) == 0
 
 
 # ---------------------------------------------------------------------------- edge cases
@@ -1118,3 +1146,68 @@ def test_verify_splitkv_replays_under_hip_graph(ops):
                                     kv_indices.cpu().numpy()[: int(prefix.sum())], is_causal=True, sm_scale=d ** -0.5,
                                     custom_mask=cm, mask_indptr=mi.cpu().numpy())
         parity.check(np.abs(_np(o.float()).astype(np.float64) - want).max(), 1.5e-2, None)
+
+
+def test_decode_in_kernel_merge_edges_and_graph_replay(ops):
+    """rx_decode_params.merge_counters: a zero-length request (no workgroup ever arrives), requests shorter than one
+    split (one live split), sinks and a V scale in the merge, fp8 pool; then the call captured in a HIP graph and
+    replayed with NEW lengths -- the counters are reset by the kernels themselves."""
+    rng = np.random.default_rng(77)
+    hq, hkv, d, ps, S = 16, 2, 128, 16, 8
+    lens = np.array([0, 1, 40, 300, 1000, 17, 256], dtype=np.int64)
+    bs = len(lens)
+    q, kb, vb, r2t, rpi = _make_paged_case(rng, bs, hq, hkv, d, np.maximum(lens, 1200), ps, torch.bfloat16, "shuffled")
+    qd, kbd, vbd, r2td, rpid = q.to(DEV), kb.to(DEV), vb.to(DEV), _t(r2t), _t(rpi)
+    sinks = torch.randn(hq, device=DEV)
+    al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
+    lse = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+    cnt = torch.zeros(bs * hq, dtype=torch.int32, device=DEV)
+    lens_d = _t(lens)
+    nsplit = torch.zeros(bs, dtype=torch.int32, device=DEV)
+
+    def both(kbuf, vbuf, lens_t, **kw):
+        ops.get_num_kv_splits(nsplit, lens_t.to(torch.int32), hq, hkv, S, 256)
+        a = torch.full((bs, hq, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+        b = torch.full_like(a, float("nan"))
+        ops.decode_attention_fwd_paged(qd, kbuf, vbuf, a, r2td, rpid, lens_t, al, lse, nsplit, S, d ** -0.5, page_size=ps, **kw)
+        ops.decode_attention_fwd_paged(qd, kbuf, vbuf, b, r2td, rpid, lens_t, al, lse, nsplit, S, d ** -0.5, page_size=ps,
+                                       merge_counters=cnt, **kw)
+        torch.cuda.synchronize()
+        same = (a == b) | (torch.isnan(a) & torch.isnan(b))      # the empty request is 0/0 in both forms
+        assert bool(same.all()) and int(cnt.abs().sum()) == 0
+        return b
+
+    both(kbd, vbd, lens_d)
+    both(kbd, vbd, lens_d, sinks=sinks, v_scale=0.5, logit_cap=30.0)
+    both(kbd.to(torch.float8_e4m3fn), vbd.to(torch.float8_e4m3fn), lens_d, k_scale=1.0, v_scale=1.0)
+    # stale-line hunt: the SAME buffers, fresh queries and lengths every call, merged by whichever workgroup arrives
+    # last (any XCD) -- a partial read from a stale cache line would differ from the two-launch result
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for it in range(40):
+        qd.copy_(torch.randn(qd.shape, device=DEV, generator=g).to(qd.dtype))
+        lens_i = torch.randint(1, 1200, (bs,), device=DEV, generator=g)
+        both(kbd, vbd, lens_i)
+    # graph capture + replay with other lengths
+    lens_g = lens_d.clone()
+    ops.get_num_kv_splits(nsplit, lens_g.to(torch.int32), hq, hkv, S, 256)
+    og = torch.zeros(bs, hq, d, dtype=torch.bfloat16, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.decode_attention_fwd_paged(qd, kbd, vbd, og, r2td, rpid, lens_g, al, lse, nsplit, S, d ** -0.5, page_size=ps,
+                                       merge_counters=cnt)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        ops.decode_attention_fwd_paged(qd, kbd, vbd, og, r2td, rpid, lens_g, al, lse, nsplit, S, d ** -0.5, page_size=ps,
+                                       merge_counters=cnt)
+    for new in ([5, 1200, 64, 31, 999, 2, 513], [1200] * bs, [33, 1, 1, 700, 8, 1100, 90]):
+        new_t = torch.tensor(new, dtype=torch.int64, device=DEV)
+        lens_g.copy_(new_t)
+        ops.get_num_kv_splits(nsplit, lens_g.to(torch.int32), hq, hkv, S, 256)
+        gr.replay()
+        ref = torch.zeros_like(og)
+        ops.decode_attention_fwd_paged(qd, kbd, vbd, ref, r2td, rpid, new_t, al, lse, nsplit, S, d ** -0.5, page_size=ps)
+        torch.cuda.synchronize()
+        assert torch.equal(og, ref) and int(cnt.abs().sum()) == 0, new

@@ -21,18 +21,31 @@ def run(bs, ctx, splits_list):
     ref = torch.zeros(bs, dtype=torch.int32, device=dev)
     ops.get_num_kv_splits(ref, lens.int(), HQ, HKV, 8, 256)
     out = [f"bs={bs} ctx={ctx} reference schedule(max 8)={ref[0].item()}"]
+    cnt = torch.zeros(bs * HQ, dtype=torch.int32, device=dev) if os.environ.get("MC") else None  # in-kernel stage 2
     byt = bs * ctx * HKV * D * 2 * 2
     for S in splits_list:
         ns = torch.full((bs,), S, dtype=torch.int32, device=dev)
         al = torch.empty(bs, HQ, max(S, 1), D, dtype=torch.float32, device=dev); lse = torch.empty(bs, HQ, max(S, 1), device=dev)
         def f():
             if S == 1: ops.decode_attention_fwd_paged(q, kb, vb, o, r2t, rpi, lens, None, None, None, 1, D ** -0.5, page_size=PS, kv_layout=lay)
-            else: ops.decode_attention_fwd_paged(q, kb, vb, o, r2t, rpi, lens, al, lse, ns, S, D ** -0.5, page_size=PS, kv_layout=lay)
+            else: ops.decode_attention_fwd_paged(q, kb, vb, o, r2t, rpi, lens, al, lse, ns, S, D ** -0.5, page_size=PS, kv_layout=lay, merge_counters=cnt)
         for _ in range(3): f()
         torch.cuda.synchronize()
+        if os.environ.get("GRAPH"):  # 20 calls captured once: launch-to-launch time on the GPU, no host in the way
+            side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side): f()
+            torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(20): f()
+            gr.replay(); torch.cuda.synchronize()
+            run20 = gr.replay
+        else:
+            def run20():
+                for _ in range(20): f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20): f()
+        run20()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
         out.append(f"S={S}: {us:.0f} us {byt/us/1e6:.2f} TB/s")

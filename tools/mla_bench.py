@@ -36,9 +36,12 @@ al = torch.empty(bs, hq, S, dv, dtype=torch.float32, device=dev)
 lse = torch.empty(bs, hq, S, dtype=torch.float32, device=dev)
 
 
+cnt = torch.zeros(bs * hq, dtype=torch.int32, device=dev) if os.environ.get("MC") else None  # in-kernel stage 2
+
+
 def run():
     ops.decode_attention_fwd_paged(q, kv, kv[..., :dv], o, r2t, rpi, lens, al, lse, nsplit, S, dk ** -0.5,
-                                   page_size=ps)
+                                   page_size=ps, merge_counters=cnt)
 
 
 for _ in range(3):
