@@ -322,7 +322,22 @@ class HipRadixAttnBackend:
                 kv_indices = torch.empty(total, dtype=torch.int64, device=self.device)
             kv_indptr = ops.build_kv_indices(self.req_to_token, fb.req_pool_indices, fb.seq_lens,
                                              self.kv_indptr, kv_indices)
-        wg_target = self.device_core_count * (2 if self._is_mla_pool else 1)
+        # workgroups aimed for in total.  Dense kernel: one per CU is four waves per CU, one per SIMD -- with bs * Hkv
+        # head blocks <= CUs a second workgroup per CU pays (TP=8 shard, 256 x 4 k: 113 -> 106 us per layer; 128 x 4 k:
+        # 58 -> 52; TP=1 16 x 4 k: 57 -> 55; 8 x 8 k: 56 -> 51), above that every split only costs (64 x 2 k: 102 us
+        # at 1 split, 107 at 2).  In the 2-4 split regime a split under ~1 k tokens is all prologue (32 x 1 k: 31 us at 1
+        # split, 33 at 2), so short requests take fewer; tiny batches keep the 128-token floor, they need the parallelism.
+        group = max(1, self.num_head // self.num_kv_head)
+        blocks = bs * self.num_kv_head * ((group + 15) // 16)
+        min_tokens = 128
+        if self._is_mla_pool:
+            wg_target = self.device_core_count * 2
+        elif blocks <= self.device_core_count:
+            wg_target = self.device_core_count * 2
+            if 2 * blocks >= self.device_core_count:
+                min_tokens = 1024
+        else:
+            wg_target = self.device_core_count
         S = ops.native_max_kv_splits(bs, self.num_head, self.num_kv_head, wg_target, self.native_split_cap)
         if S <= 1:
             return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1)
@@ -334,7 +349,8 @@ class HipRadixAttnBackend:
         else:
             num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
             attn_logits, attn_lse = self._scratch(bs, S)
-        ops.get_num_kv_splits_native(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S, wg_target)
+        ops.get_num_kv_splits_native(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S, wg_target,
+                                     min_tokens_per_split=min_tokens)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S)
 
     # ------------------------------------------------------------------ decode context parallel
