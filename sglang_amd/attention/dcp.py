@@ -21,15 +21,15 @@ from sglang_amd import ops
 
 
 def get_dcp_lens(lens: torch.Tensor, dcp_size: int, dcp_rank: int, start: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Tokens of [start, start + lens) owned by ``dcp_rank`` (layout.py:23-41) -- host / torch form for planning code;
-    the kernels' copy is in rx_dcp_kv_indices."""
+    """Tokens of [start, start + lens) that ``dcp_rank`` owns (layout.py:23-41), for host-side planning code (the kernels'
+    copy is in rx_dcp_kv_indices): positions p with p % dcp_size == dcp_rank below an end e number
+    floor((e - 1 - rank) / size) + 1, so the count in a range is a difference of two floor divisions."""
     if dcp_size == 1:
         return lens
-    if start is None:
-        return lens // dcp_size + (dcp_rank < lens % dcp_size)
-    first = start + torch.remainder(dcp_rank - start, dcp_size)
-    remaining = start + lens - first
-    return torch.clamp((remaining + dcp_size - 1) // dcp_size, min=0)
+    first = 0 if start is None else start
+    below_end = torch.div(first + lens - 1 - dcp_rank, dcp_size, rounding_mode="floor")
+    below_start = torch.div(first - 1 - dcp_rank + torch.zeros_like(lens), dcp_size, rounding_mode="floor")
+    return below_end - below_start
 
 
 class DcpGroup:

@@ -231,6 +231,13 @@ class BaseTokenToKVPoolAllocator:
         pending, self._group_pending = self._group_pending, []
         self._flush_group(pending)
 
+    def _release(self, piece) -> None:
+        """Every give-back goes through here: queued while a group is open, applied to the device list otherwise."""
+        if self._grouping:
+            self._group_pending.append(piece)
+        else:
+            self._flush_group([piece])
+
     def alloc_extend(self, *args, **kwargs):
         raise NotImplementedError("alloc_extend is only for paged allocator")
 
@@ -275,18 +282,13 @@ class TokenToKVPoolAllocator(BaseTokenToKVPoolAllocator):
         return out
 
     def free(self, free_index: torch.Tensor):
-        n = free_index.numel()
-        if n == 0:
-            return
-        if self._grouping:
-            self._group_pending.append(free_index)
-            return
-        self._list.append(self._target, free_index)
-        self._bump(self._target, n)
+        if free_index.numel():
+            self._release(free_index)
 
     def _flush_group(self, pending):
         for idx in pending:  # cat(free_group) appended = the pieces appended in order
-            self.free(idx)
+            self._list.append(self._target, idx)
+            self._bump(self._target, idx.numel())
 
 
 def get_num_new_pages(seq_lens: torch.Tensor, page_size: int, prefix_lens: Optional[torch.Tensor] = None,
@@ -367,32 +369,16 @@ class PagedTokenToKVPoolAllocator(BaseTokenToKVPoolAllocator):
         """Slots of arbitrary pages: the SORTED SET of their pages goes to the front (paged.py:261-271).  The set
         is formed on the device (flag per page + ordered compaction); its size is not known here, so the mirror
         of that list's length becomes unknown until somebody needs it."""
-        if free_index.numel() == 0:
-            return
-        if self._grouping:
-            self._group_pending.append(("slots", free_index))
-            return
-        self._list.mark(free_index, self.page_size)
-        self._list.flush_marks(self._target)
-        self._bump(self._target, None)
-        if self.debug_mode:
-            self._debug_check_no_duplicate_pages()
+        if free_index.numel():
+            self._release(("slots", free_index))
 
     def free_segment(self, free_index: torch.Tensor, *, start_pos: int):
         """A run of consecutive positions starting at start_pos (paged.py:273-301): one representative slot per page
         at fixed strides -- the first slot, then every page_size-th from the next page boundary -- so the page
         count is known on the host and the pages go to the front in run order."""
-        n = free_index.numel()
-        if n == 0:
-            return
-        off = start_pos % self.page_size
-        piece = (free_index, bool(off), (self.page_size - off) if off else 0)
-        if self._grouping:
-            self._group_pending.append(("segment",) + piece)
-            return
-        self._prepend_segment(*piece)
-        if self.debug_mode:
-            self._debug_check_no_duplicate_pages()
+        if free_index.numel():
+            off = start_pos % self.page_size
+            self._release(("segment", free_index, bool(off), (self.page_size - off) if off else 0))
 
     def _prepend_segment(self, idx: torch.Tensor, has_first: bool, start: int):
         ps, n = self.page_size, idx.numel()

@@ -9,6 +9,7 @@ resident at the metric shape.  Writes go through rx_store_kv, moves through rx_m
 """
 from __future__ import annotations
 
+import collections
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -37,13 +38,10 @@ class ReqToTokenPool:
     graph-padded batches read (memory_pool.py:273-281)."""
 
     def __init__(self, size: int, max_context_len: int, device: str):
-        self.size = size
-        self._alloc_size = size + 1
-        self.max_context_len = max_context_len
-        self.device = device
-        self.req_to_token = torch.zeros((self._alloc_size, max_context_len), dtype=torch.int32,
-                                        device=device)
-        self.free_slots = list(range(1, self._alloc_size))
+        self.size, self.max_context_len, self.device = size, max_context_len, device
+        self._alloc_size = size + 1  # + the padding row
+        self.req_to_token = torch.zeros((self._alloc_size, max_context_len), dtype=torch.int32, device=device)
+        self.clear()
 
     def write(self, indices, values):
         self.req_to_token[indices] = values
@@ -56,18 +54,15 @@ class ReqToTokenPool:
         req.req_pool_idx; the id order is the same, memory_pool.py:306-314)."""
         if need_size > len(self.free_slots):
             return None
-        select_index = self.free_slots[:need_size]
-        self.free_slots = self.free_slots[need_size:]
-        return select_index
+        return [self.free_slots.popleft() for _ in range(need_size)]
 
     def free(self, free_index):
         if isinstance(free_index, int):
-            self.free_slots.append(free_index)
-        else:
-            self.free_slots.extend(free_index)
+            free_index = (free_index,)
+        self.free_slots.extend(free_index)
 
     def clear(self):
-        self.free_slots = list(range(1, self._alloc_size))
+        self.free_slots = collections.deque(range(1, self._alloc_size))
 
 
 class MHATokenToKVPool:

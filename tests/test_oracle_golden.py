@@ -418,3 +418,17 @@ def test_dcp_store_loc_restatement():
     pos = np.array([0, 1, 2, 3, 9, 4], dtype=np.int64)
     assert orc.dcp_store_loc(loc, pos, 2, 1).tolist() == [0, 5, 0, 6, 12, 0]
     assert orc.dcp_store_loc(loc, pos, 2, 0, skip_index=-1).tolist() == [5, -1, 6, -1, -1, 3]
+
+
+def test_dcp_host_lens_match_the_reference(golden_dir):
+    """sglang_amd.attention.dcp.get_dcp_lens (the host-side form planning code uses) against F15's get_dcp_lens rows."""
+    import torch
+
+    from sglang_amd.attention.dcp import get_dcp_lens
+
+    cases = _dcp_golden(golden_dir)
+    for i in range(int(cases["idx"]["count"])):
+        c = cases[f"idx{i}"]
+        start = torch.from_numpy(c["start"]) if int(c["use_start"]) else None
+        got = get_dcp_lens(torch.from_numpy(c["lens"]), int(c["dcp"]), int(c["rank"]), start)
+        assert np.array_equal(got.numpy(), c["dcp_lens"]), i
