@@ -341,6 +341,14 @@ class HipRadixAttnBackend:
         S = ops.native_max_kv_splits(bs, self.num_head, self.num_kv_head, wg_target, self.native_split_cap)
         if S <= 1:
             return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1)
+        # The in-kernel stage 2 (merge_counters) wants the partial rows of a head in chunks of 8: allocate 8 (16, ...) split
+        # slots while a request still runs `S_live` of them -- the surplus workgroups exit at once, and the second launch
+        # goes (TP=8 shard 256 x 4 k at 2 live splits: 107 us with the stage-2 launch, 101 with 8 slots and none).
+        S_live = S
+        if self._merge_counters is not None and S % 8:
+            S8 = (S + 7) // 8 * 8
+            if bs * self.num_head * S8 * self.v_head_dim * 4 <= (4 << 20):  # the library's bound for that form
+                S = S8
         if use_graph_bufs:
             num_kv_splits = self._graph["num_kv_splits"][:bs]
             n = bs * self.num_head * S
@@ -349,7 +357,7 @@ class HipRadixAttnBackend:
         else:
             num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
             attn_logits, attn_lse = self._scratch(bs, S)
-        ops.get_num_kv_splits_native(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S, wg_target,
+        ops.get_num_kv_splits_native(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S_live, wg_target,
                                      min_tokens_per_split=min_tokens)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S)
 
@@ -591,6 +599,7 @@ class HipRadixAttnBackend:
         # native schedule: bs * S(bs) <= cu_count / wg_per_request + bs rows of partials
         group = max(1, self.num_head // self.num_kv_head)
         rows = (2 * self.device_core_count // (self.num_kv_head * ((group + 15) // 16)) + max_bs + 1) * self.num_head
+        rows = max(rows, (1 << 20) // self.v_head_dim + 8)  # split slots rounded up to 8 while the partials fit 4 MiB
         self._graph["native_logits"] = torch.zeros(rows * self.v_head_dim, dtype=torch.float32, device=dev)
         self._graph["native_lse"] = torch.zeros(rows, dtype=torch.float32, device=dev)
         if self.decode_index_mode == "indices":

@@ -24,7 +24,7 @@ def run(bs, ctx, splits_list):
     cnt = torch.zeros(bs * HQ, dtype=torch.int32, device=dev) if os.environ.get("MC") else None  # in-kernel stage 2
     byt = bs * ctx * HKV * D * 2 * 2
     for S in splits_list:
-        ns = torch.full((bs,), S, dtype=torch.int32, device=dev)
+        ns = torch.full((bs,), int(os.environ.get("NS") or S), dtype=torch.int32, device=dev)  # NS: live splits of S allocated
         al = torch.empty(bs, HQ, max(S, 1), D, dtype=torch.float32, device=dev); lse = torch.empty(bs, HQ, max(S, 1), device=dev)
         def f():
             if S == 1: ops.decode_attention_fwd_paged(q, kb, vb, o, r2t, rpi, lens, None, None, None, 1, D ** -0.5, page_size=PS, kv_layout=lay)
