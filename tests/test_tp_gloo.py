@@ -90,3 +90,64 @@ def test_tp2_row_parallel_allreduce_matches_unsharded(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def _dcp_worker(rank, world, port, out_dir):
+    """Decode context parallel on CPU: the three exchanges of sglang_amd.attention.dcp.DcpGroup (all-gather of the q
+    heads, of the LSEs, the all-reduce) carry ORACLE partials -- every rank attends the tokens it owns (position %
+    world == rank) with the gathered heads -- and the joined result must be the attention over the whole sequence."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sglang_amd.attention.dcp import DcpGroup, get_dcp_lens
+
+        grp = DcpGroup(world, rank)
+        rng = np.random.default_rng(1)  # same data on every rank
+        bs, H_ALL, D = 3, 4, 16
+        hl = H_ALL // world
+        lens = np.array([7, 1, 12])
+        pool = 40
+        kb = rng.standard_normal((pool, 1, D)).astype(np.float32)       # virtual cache, one kv head
+        vb = rng.standard_normal((pool, 1, D)).astype(np.float32)
+        q = rng.standard_normal((bs, H_ALL, D)).astype(np.float32)
+        r2t = np.zeros((bs + 1, 16), dtype=np.int32)
+        perm = rng.permutation(pool - 1) + 1
+        o = 0
+        for i, n in enumerate(lens):
+            r2t[i + 1, :n] = perm[o:o + n]; o += n
+        rpi = np.arange(1, bs + 1)
+        kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
+        want = orc.decode_attention(q, kb, vb, kv_indptr, kv_indices, D ** -0.5)
+        # 1. gather the q heads: rank r contributes heads [r * hl, (r + 1) * hl)
+        q_all = grp.all_gather_heads(torch.from_numpy(q[:, rank * hl:(rank + 1) * hl].copy()))
+        assert torch.equal(q_all, torch.from_numpy(q))
+        # 2. local attention over the tokens this rank owns (the oracle here; rx_decode_attn on the GPU)
+        assert np.array_equal(get_dcp_lens(torch.from_numpy(lens), world, rank).numpy(), orc.dcp_lens(lens, world, rank))
+        o_loc = np.zeros((bs, H_ALL, D))
+        lse_loc = np.full((bs, H_ALL), -np.inf)
+        for b in range(bs):
+            mine = [int(r2t[b + 1, p]) for p in range(lens[b]) if p % world == rank]
+            if not mine:
+                continue
+            s = np.einsum("hd,td->ht", q[b].astype(np.float64), kb[mine, 0].astype(np.float64)) * D ** -0.5
+            m = s.max(-1, keepdims=True)
+            p = np.exp(s - m)
+            o_loc[b] = (p / p.sum(-1, keepdims=True)) @ vb[mine, 0].astype(np.float64)
+            lse_loc[b] = (m + np.log(p.sum(-1, keepdims=True)))[:, 0]
+        # 3. cp_lse_ag_out_rs_mha: all-gather the LSEs, scale, all-reduce, keep the local heads
+        lses = grp.all_gather_lse(torch.from_numpy(lse_loc))
+        assert lses.shape == (world, bs, H_ALL) and torch.equal(lses[rank], torch.from_numpy(lse_loc))
+        scaled, _, _ = orc.dcp_merge(np.stack([o_loc] * world), lses.numpy())   # row `rank` is this rank's contribution
+        total = grp.all_reduce(torch.from_numpy(scaled[rank].copy()))
+        np.testing.assert_allclose(total.numpy()[:, rank * hl:(rank + 1) * hl], want[:, rank * hl:(rank + 1) * hl],
+                                   atol=1e-9)
+        open(os.path.join(out_dir, f"dcp_ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dcp2_exchanges_reproduce_whole_sequence_attention(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_dcp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"dcp_ok{r}") for r in range(world))
