@@ -570,8 +570,23 @@ def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=8):
     ms = e0.elapsed_time(e1) / nchunks
     flops = 2.0 * HQ * (D + Dv) * chunk * (E * P + E * (E + 1) / 2)
     tflops = flops / (ms * 1e-3) / 1e12
+    # MFMA-pipe busy fraction: an SQ-counter figure (SQ_VALU_MFMA_BUSY_CYCLES) that needs its own rocprofv3 --pmc passes;
+    # the committed summary of those passes is quoted with its provenance, for the shape it was measured on only
+    mfma_busy = None
+    try:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_extend32_sq_counters.json")))
+        if cand and (D, Dv, tp, P, E, chunk) == (128, 128, 1, 3584, 512, 32):
+            doc = json.load(open(cand[-1]))
+            key = next(k for k in doc["derived"] if k.startswith("mfma_pipe_busy_frac"))
+            mfma_busy = {"frac_of_simd_cycles": doc["derived"][key], "valu_per_mfma": doc["derived"].get("valu_per_mfma"),
+                         "file": "profiles/" + os.path.basename(cand[-1]),
+                         "note": "three rocprofv3 --pmc passes of `bench.py --extend-only` on another box, not this run"}
+    except Exception:  # noqa: BLE001
+        pass
     return {"metric": f"extend attention TFLOP/s (config 3: {P}-token shared prefix + {E} new, bf16, head_dim {D}"
                       + (f"/{Dv}" if Dv != D else "") + ")",
+            "mfma_busy": mfma_busy,
             "tflops": tflops, "ms_per_chunk": ms, "chunk_requests": chunk, "flops_per_chunk": flops,
             "prefix_layout": f"page_size {ps}, shuffled pages, {args.kv_layout.upper()} pool",
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
