@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 4
+#define RX_ABI_VERSION 5
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -206,6 +206,16 @@ typedef struct rx_decode_params {
    * decode_attention.py:731-805).  One buffer serves one stream of calls (not two concurrent ones); after a faulted
    * launch the caller zeroes it again.  NULL: stage 2 is its own launch, as in the reference. */
   int32_t* merge_counters;
+  /* Optional: the step's KV store fused into the kernel.  k_new / v_new = the new token's rows of every request,
+   * dtype [bs, Hkv, D] with element strides (token, head); request b's newest position (seq_len_b - 1, whose slot the
+   * req_to_token row / kv_indices already names) is then READ from them and WRITTEN to that slot by the kernel -- K1
+   * (store_cache, memory_pool.py:2383-2430) without its own launch, as the reference's CPU kernel does
+   * (decode_attention_cpu, aot/csrc/cpu/decode.cpp).  Needs the D = 64 / 128 kernel on a 16-bit pool, at most 16 q heads
+   * per kv head (one workgroup per row), stages == 0, no kv_start / extra partials; anything else is an error (store
+   * with rx_store_kv* first).  NULL: the pool already holds the token. */
+  const void* k_new;
+  const void* v_new;
+  int64_t k_new_stride_t, k_new_stride_h, v_new_stride_t, v_new_stride_h;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);

@@ -157,6 +157,7 @@ class HipRadixAttnBackend:
                                            device=self.device)
         if os.environ.get("RX_NO_INKERNEL_MERGE"):  # dev A/B: stage 2 as its own launch
             self._merge_counters = None
+        self._no_fused_store = bool(os.environ.get("RX_NO_FUSED_STORE"))  # dev A/B: the store as its own launch
         self._graph = None  # static buffers of init_cuda_graph_state
         self._md_version = 0  # bumped by every init_forward_metadata_out_graph
         self._decode_launchers = {}  # layer_id -> ops.DecodeLauncher
@@ -648,13 +649,34 @@ class HipRadixAttnBackend:
             return layer.k_scale_float, layer.v_scale_float
         return 1.0, 1.0
 
+    def _fused_store_ok(self, layer, k, v) -> bool:
+        """rx_decode_params.k_new: the new token's rows are read from k / v and written to their slots by the decode
+        kernel itself -- a 16-bit pool of k's dtype, D = 64 / 128, at most 16 q heads per kv head, the plain (not
+        cascade / DCP / sliding-window / scaled-store) path, 16-byte aligned rows."""
+        if self._no_fused_store or self.dcp is not None or self._cascade_on or self._is_mla_pool:
+            return False
+        pool = self.token_to_kv_pool
+        if getattr(pool, "is_fp8", False) or k.dtype != pool.dtype or v.dtype != pool.dtype:
+            return False
+        if layer.k_scale is not None or layer.v_scale is not None:
+            return False
+        if layer.sliding_window_size is not None and layer.sliding_window_size > -1:
+            return False
+        d = layer.qk_head_dim
+        if d != layer.v_head_dim or d not in (64, 128) or layer.tp_q_head_num > 16 * layer.tp_k_head_num:
+            return False
+        return (k.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0 and k.stride(-1) == 1 and v.stride(-1) == 1
+                and (layer.tp_k_head_num * d) % 8 == 0)
+
     def forward_decode(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, sinks=None):
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
         if layer.qk_head_dim != layer.v_head_dim:
             o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         else:
             o = torch.empty_like(q)
-        if save_kv_cache and k is not None:
+        # the KV store of the step rides in the decode launch when the kernel can take it (see _fused_store_ok)
+        fuse = save_kv_cache and k is not None and self._fused_store_ok(layer, k, v)
+        if save_kv_cache and k is not None and not fuse:
             if self.dcp is not None:
                 self._dcp_store(layer, forward_batch, k, v)
             else:
@@ -707,7 +729,11 @@ class HipRadixAttnBackend:
                                 attn_lse=md.attn_lse, merge_counters=self._merge_counters)
         if sinks is not None and sinks.dtype != torch.float32:
             sinks = sinks.float()
-        ln(q3, o3, torch.cuda.current_stream(q.device).cuda_stream, sinks)
+        if fuse:
+            ln(q3, o3, torch.cuda.current_stream(q.device).cuda_stream, sinks,
+               k_new=k.view(-1, layer.tp_k_head_num, layer.qk_head_dim), v_new=v.view(-1, layer.tp_v_head_num, layer.v_head_dim))
+        else:
+            ln(q3, o3, torch.cuda.current_stream(q.device).cuda_stream, sinks)
         return o
 
     def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, sinks=None):

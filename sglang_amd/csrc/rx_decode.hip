@@ -56,6 +56,10 @@ struct DecodeArgs {
   int32_t num_extra;
   int32_t stages;  // 0 both, 1 stage 1 only, 2 stage 2 only
   int32_t* merge_counters;  // in-kernel stage 2 (rx_common.h split_arrive_is_last), or NULL: stage-2 launch
+  // fused store of the new token (16-bit pools, one q block per kv head): its K / V rows [bs, Hkv, D], or NULL
+  const uint16_t* k_new;
+  const uint16_t* v_new;
+  int64_t kn_stride_t, kn_stride_h, vn_stride_t, vn_stride_h;
 };
 
 // Grok temperature factor of a request (decode_attention.py:156-160): the single query sits at seq_len-1
@@ -185,8 +189,13 @@ __device__ __forceinline__ u32x4 kv_frag16(V raw) {
   else return raw;
 }
 
-template <typename T, int D, typename IdxT, bool LINEAR, bool KV8>
+// FUSE: the request's NEWEST token (position seq_len - 1, the one this decode step produced) is read from k_new /
+// v_new instead of the pool, and the lanes that hold its 16-byte chunks write them to its pool slot on the way -- the
+// KV store of the step (K1) without its own launch (a small-batch or TP-shard layer is 35-100 us, the store launch
+// ~5).  Only with ONE q block per kv head: then exactly one workgroup ever touches that row.
+template <typename T, int D, typename IdxT, bool LINEAR, bool KV8, bool FUSE = false>
 __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const DecodeArgs a) {
+  static_assert(!(FUSE && KV8), "the fused store writes 16-bit rows");
   using vec8 = typename T::vec8;
   using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;  // pool element
   using KvV = u32x4;  // 16 B per lane and load: 8 elements of a 16-bit pool, 16 of an fp8 pool
@@ -298,26 +307,51 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
     s0 = static_cast<int64_t>(idx[t0]);
     s1 = static_cast<int64_t>(idx[t1]);
   };
+  // FUSE: this workgroup's range ends at the request's newest token, whose rows are not in the pool yet
+  const bool has_new = FUSE && hi == si.seq_len;
+  const uint16_t* knew = nullptr;
+  const uint16_t* vnew = nullptr;
+  if constexpr (FUSE) {
+    knew = a.k_new + b * a.kn_stride_t + kvh * a.kn_stride_h + 8 * g;
+    vnew = a.v_new + b * a.vn_stride_t + kvh * a.vn_stride_h + 8 * g;
+  }
   // Register sets of K/V tiles in flight per wave.  One 32-token tile is 16 KiB of a 16-bit pool but
   // 8 KiB of an fp8 pool: with a single set the fp8 kernel has half the bytes in flight and ran at
   // 4.55 TB/s; two sets restore the 128 KiB per CU of the 16-bit kernel in the same registers.
   constexpr int DEPTH = KV8 ? RX_DEC_FP8_DEPTH : 1;
   KvV kf[DEPTH][2][NL], vf[DEPTH][2][NL];  // fp8 pools: upcast (exact) where consumed
   constexpr int LSTEP = KV8 ? 64 : 32;  // elements between a lane's consecutive loads
-  auto load_kv = [&](int64_t s0, int64_t s1, KvV (&kfs)[2][NL], KvV (&vfs)[2][NL]) {
+  auto load_kv = [&](int t, int64_t s0, int64_t s1, KvV (&kfs)[2][NL], KvV (&vfs)[2][NL]) {
     const int64_t ko0 = slot_offset<LINEAR>(s0, a.page_size, a.k_page_stride, a.k_tok_stride);
     const int64_t ko1 = slot_offset<LINEAR>(s1, a.page_size, a.k_page_stride, a.k_tok_stride);
     const int64_t vo0 = slot_offset<LINEAR>(s0, a.page_size, a.v_page_stride, a.v_tok_stride);
     const int64_t vo1 = slot_offset<LINEAR>(s1, a.page_size, a.v_page_stride, a.v_tok_stride);
-#pragma unroll
-    for (int s = 0; s < NL; ++s) {
-      kfs[0][s] = kv_load8<KvV>(kbase + ko0 + LSTEP * s);
-      kfs[1][s] = kv_load8<KvV>(kbase + ko1 + LSTEP * s);
+    const KvE* kp0 = kbase + ko0;
+    const KvE* kp1 = kbase + ko1;
+    const KvE* vp0 = vbase + vo0;
+    const KvE* vp1 = vbase + vo1;
+    if constexpr (FUSE) {
+      // rows that are (or clamp to) the newest token come from k_new / v_new; only the last tile can hold it
+      if (has_new && t == ntiles - 1) {
+        if (lo + t * kTile + r >= hi - 1) {
+          kp0 = reinterpret_cast<const KvE*>(knew);
+          vp0 = reinterpret_cast<const KvE*>(vnew);
+        }
+        if (lo + t * kTile + 16 + r >= hi - 1) {
+          kp1 = reinterpret_cast<const KvE*>(knew);
+          vp1 = reinterpret_cast<const KvE*>(vnew);
+        }
+      }
     }
 #pragma unroll
     for (int s = 0; s < NL; ++s) {
-      vfs[0][s] = kv_load8<KvV>(vbase + vo0 + LSTEP * s);
-      vfs[1][s] = kv_load8<KvV>(vbase + vo1 + LSTEP * s);
+      kfs[0][s] = kv_load8<KvV>(kp0 + LSTEP * s);
+      kfs[1][s] = kv_load8<KvV>(kp1 + LSTEP * s);
+    }
+#pragma unroll
+    for (int s = 0; s < NL; ++s) {
+      vfs[0][s] = kv_load8<KvV>(vp0 + LSTEP * s);
+      vfs[1][s] = kv_load8<KvV>(vp1 + LSTEP * s);
     }
   };
   // 8 pool elements of k-step s as a 16-bit MFMA operand / LDS chunk
@@ -336,7 +370,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
     if (tt < ntiles) {
       int64_t s0, s1;
       load_slots(tt, s0, s1);
-      load_kv(s0, s1, kf[u], vf[u]);
+      load_kv(tt, s0, s1, kf[u], vf[u]);
       if (tt + STEP < ntiles) load_slots(tt + STEP, n0[u], n1[u]);
     }
   }
@@ -370,8 +404,26 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
       }
     }
     // ---- prefetch the next tile (registers of this tile are free again) ------------------
+    if constexpr (FUSE) {
+      // the newest token's chunks, still in this tile's registers, go to its pool slot (the lane that holds the
+      // token itself, not the clamped copies): the step's KV store
+      if (has_new && t == ntiles - 1) {
+        const int32_t tn = hi - 1 - (lo + t * kTile);  // row of the newest token in this tile
+        if (r == (tn & 15)) {
+          const int bb = tn >> 4;
+          const int64_t slot = static_cast<int64_t>(idx[hi - 1]);
+          KvE* kd = const_cast<KvE*>(kbase) + slot_offset<LINEAR>(slot, a.page_size, a.k_page_stride, a.k_tok_stride);
+          KvE* vd = const_cast<KvE*>(vbase) + slot_offset<LINEAR>(slot, a.page_size, a.v_page_stride, a.v_tok_stride);
+#pragma unroll
+          for (int s = 0; s < NL; ++s) {
+            *reinterpret_cast<KvV*>(kd + LSTEP * s) = bb ? kf[u][1][s] : kf[u][0][s];
+            *reinterpret_cast<KvV*>(vd + LSTEP * s) = bb ? vf[u][1][s] : vf[u][0][s];
+          }
+        }
+      }
+    }
     if (t + STEP < ntiles) {
-      load_kv(n0[u], n1[u], kf[u], vf[u]);
+      load_kv(t + STEP, n0[u], n1[u], kf[u], vf[u]);
       if (t + 2 * STEP < ntiles) load_slots(t + 2 * STEP, n0[u], n1[u]);
     }
     // ---- online softmax on the lane ------------------------------------------------------
@@ -700,14 +752,17 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
   }
   if (mfma_ok) {
     const unsigned grid = static_cast<unsigned>(a.bs) * a.hkv * a.qblocks * a.max_kv_splits;
-#define RX_DEC(DD, K8) \
-  hipLaunchKernelGGL((decode_mfma_kernel<T, DD, IdxT, LINEAR, K8>), dim3(grid), dim3(256), 0, s, a)
+#define RX_DEC(DD, K8, FU) \
+  hipLaunchKernelGGL((decode_mfma_kernel<T, DD, IdxT, LINEAR, K8, FU>), dim3(grid), dim3(256), 0, s, a)
     if (a.kv_fp8) {
-      if (dk == 64) RX_DEC(64, true);
-      else RX_DEC(128, true);
+      if (dk == 64) RX_DEC(64, true, false);
+      else RX_DEC(128, true, false);
+    } else if (a.k_new) {  // fused store of the new token
+      if (dk == 64) RX_DEC(64, false, true);
+      else RX_DEC(128, false, true);
     } else {
-      if (dk == 64) RX_DEC(64, false);
-      else RX_DEC(128, false);
+      if (dk == 64) RX_DEC(64, false, false);
+      else RX_DEC(128, false, false);
     }
 #undef RX_DEC
   } else {
@@ -864,6 +919,22 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
                                // are many MB (MLA 64 x 16 heads x 8 splits = 17 MB: 67.6 -> 69.5 us)
                                static_cast<int64_t>(p->bs) * p->num_q_heads * max_splits * dv * 4 <= (4ll << 20);
   a.merge_counters = merge_in_kernel ? p->merge_counters : nullptr;
+  // fused store of the new token: one q block per kv head (one workgroup touches the row), a 16-bit pool, the whole
+  // request attended in one pass of the MFMA kernel, 16-byte chunks
+  a.k_new = a.v_new = nullptr;
+  if (p->k_new || p->v_new) {
+    RX_REQUIRE(p->k_new && p->v_new, "rx_decode_attn: k_new and v_new come together");
+    RX_REQUIRE(mfma_ok && !mla && !p->kv.kv_fp8 && a.qblocks == 1 && p->stages == 0 && !a.kv_start && a.num_extra == 0,
+               "rx_decode_attn: the fused store needs the D = 64 / 128 kernel on a 16-bit pool with at most 16 q heads "
+               "per kv head, stages = 0 and no kv_start / extra partials (store with rx_store_kv* instead)");
+    RX_REQUIRE((((uintptr_t)p->k_new | (uintptr_t)p->v_new) & 15) == 0 &&
+                   (p->k_new_stride_t | p->k_new_stride_h | p->v_new_stride_t | p->v_new_stride_h) % 8 == 0,
+               "rx_decode_attn: k_new / v_new need 16-byte aligned rows");
+    a.k_new = (const uint16_t*)p->k_new;
+    a.v_new = (const uint16_t*)p->v_new;
+    a.kn_stride_t = p->k_new_stride_t; a.kn_stride_h = p->k_new_stride_h;
+    a.vn_stride_t = p->v_new_stride_t; a.vn_stride_h = p->v_new_stride_h;
+  }
   if (mla) return p->dtype == RX_BF16 ? run_mla<BF16>(p, a, s) : run_mla<F16>(p, a, s);
   return p->dtype == RX_BF16 ? dispatch_decode<BF16>(a, dk, dv, idx64, linear, s)
                              : dispatch_decode<F16>(a, dk, dv, idx64, linear, s);

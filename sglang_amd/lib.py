@@ -16,7 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
-RX_ABI_VERSION = 4  # include/radix_hip.h
+RX_ABI_VERSION = 5  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -53,6 +53,8 @@ class RxDecodeParams(C.Structure):
         ("xai_temperature_len", c_int32),
         ("kv_start", c_void_p), ("extra_o", c_void_p), ("extra_lse", c_void_p), ("num_extra_partials", c_int32),
         ("stages", c_int32), ("merge_counters", c_void_p),
+        ("k_new", c_void_p), ("v_new", c_void_p),
+        ("k_new_stride_t", c_int64), ("k_new_stride_h", c_int64), ("v_new_stride_t", c_int64), ("v_new_stride_h", c_int64),
     ]
 
 

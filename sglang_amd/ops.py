@@ -256,7 +256,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
                          num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap=0.0,
                          sinks=None, xai_temperature_len=-1, has_mla=False, use_pdl=False,
                          page_size: int = 1, score_mod=None, aux_tensors=None, kv_layout=None, stages: int = 0,
-                         merge_counters=None):
+                         merge_counters=None, k_new=None, v_new=None):
     """Same contract as the reference.  q [bs,Hq,Dk], o [bs,Hq,Dv], kv_indptr int32[bs+1],
     kv_indices int32/int64, attn_logits fp32[bs,Hq,max_kv_splits,Dv], attn_lse fp32[bs,Hq,S].
     ``max_kv_splits == 1`` (or num_kv_splits None) runs the single-pass kernel.  ``stages`` as in
@@ -282,6 +282,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
     p.stages = int(stages)
     p.merge_counters = _merge_counters_ptr(merge_counters, q.shape[0], q.shape[1])
+    _set_new_kv(p, k_new, v_new, q.shape[0])
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -323,11 +324,13 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
                                attn_logits, attn_lse, num_kv_splits, max_kv_splits, sm_scale,
                                k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
                                page_size: int = 1, kv_layout=None, xai_temperature_len=-1,
-                               kv_start=None, extra_o=None, extra_lse=None, stages: int = 0, merge_counters=None):
+                               kv_start=None, extra_o=None, extra_lse=None, stages: int = 0, merge_counters=None,
+                               k_new=None, v_new=None):
     p = _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse,
                              num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap, sinks, page_size,
                              kv_layout, xai_temperature_len, kv_start, extra_o, extra_lse, stages)
     p.merge_counters = _merge_counters_ptr(merge_counters, q.shape[0], q.shape[1])
+    _set_new_kv(p, k_new, v_new, q.shape[0])
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -376,6 +379,20 @@ def _fill_decode_common(p, q, k_buffer, v_buffer, o, attn_logits, attn_lse, num_
     if o.dtype != q.dtype or _is_fp8_pool(v_buffer) != fp8 or (not fp8 and (
             k_buffer.dtype != q.dtype or v_buffer.dtype != q.dtype)):
         raise TypeError("q and o must share one 16-bit dtype; k_buffer / v_buffer that dtype or fp8 e4m3fn")
+
+
+def _set_new_kv(p, k_new, v_new, bs: int) -> None:
+    """rx_decode_params.k_new / v_new: the step's KV store fused into the decode kernel ([bs, Hkv, D] rows)."""
+    if k_new is None and v_new is None:
+        p.k_new = p.v_new = None
+        return
+    if k_new is None or v_new is None or k_new.dim() != 3 or v_new.dim() != 3 or k_new.shape[0] != bs or v_new.shape[0] != bs:
+        raise ValueError("k_new / v_new must both be [bs, Hkv, D]")
+    if not (k_new.is_cuda and v_new.is_cuda) or k_new.stride(-1) != 1 or v_new.stride(-1) != 1:
+        raise ValueError("k_new / v_new must be GPU tensors, contiguous in head_dim")
+    p.k_new, p.v_new = k_new.data_ptr(), v_new.data_ptr()
+    p.k_new_stride_t, p.k_new_stride_h = k_new.stride(0), k_new.stride(1)
+    p.v_new_stride_t, p.v_new_stride_h = v_new.stride(0), v_new.stride(1)
 
 
 def _merge_counters_ptr(merge_counters, bs: int, num_q_heads: int):
@@ -439,8 +456,16 @@ class DecodeLauncher:
                       attn_logits, attn_lse, merge_counters)
         self.version = version
 
-    def __call__(self, q3, o3, stream_ptr, sinks=None):
+    def can_fuse_store(self) -> bool:
+        """The new token's KV store can ride in the decode launch (rx_decode_params.k_new): D = 64 / 128 on a 16-bit
+        pool with at most 16 q heads per kv head."""
         p = self.p
+        return (not p.kv.kv_fp8 and p.head_dim == p.v_head_dim and p.head_dim in (64, 128)
+                and p.num_q_heads <= 16 * p.num_kv_heads)
+
+    def __call__(self, q3, o3, stream_ptr, sinks=None, k_new=None, v_new=None):
+        p = self.p
+        _set_new_kv(p, k_new, v_new, q3.shape[0])
         p.q, p.o = q3.data_ptr(), o3.data_ptr()
         p.q_stride_t, p.q_stride_h = q3.stride(0), q3.stride(1)
         p.o_stride_t, p.o_stride_h = o3.stride(0), o3.stride(1)

@@ -1211,3 +1211,93 @@ def test_decode_in_kernel_merge_edges_and_graph_replay(ops):
         ops.decode_attention_fwd_paged(qd, kbd, vbd, ref, r2td, rpid, new_t, al, lse, nsplit, S, d ** -0.5, page_size=ps)
         torch.cuda.synchronize()
         assert torch.equal(og, ref) and int(cnt.abs().sum()) == 0, new
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (4, 1, 128), (16, 1, 128), (8, 8, 64), (12, 4, 64)])
+@pytest.mark.parametrize("page_size,hnd", [(1, False), (16, False), (16, True), (64, True)])
+def test_decode_fused_store_of_the_new_token(ops, dtype, hq, hkv, d, page_size, hnd):
+    """rx_decode_params.k_new / v_new: the step's KV store inside the decode launch.  The pool holds every token BUT the
+    newest of each request; the fused call must (a) give the bits of store-then-decode and (b) leave the new rows in
+    their slots -- lengths put the new token on every position class of a 32-token tile (first / 16th / last row, a
+    tile of its own), in the single-pass and the split form, both lookup modes."""
+    rng = np.random.default_rng(hq * 7 + d + page_size)
+    lens = np.array([1, 2, 16, 17, 32, 33, 48, 64, 65, 500, 1000], dtype=np.int64)
+    bs = len(lens)
+    q, kb, vb, r2t, rpi = _make_paged_case(rng, bs, hq, hkv, d, lens, page_size, dtype, "shuffled")
+    g = torch.Generator().manual_seed(3)
+    k_new = torch.randn(bs, hkv, d, generator=g).to(dtype).to(DEV)
+    v_new = torch.randn(bs, hkv, d, generator=g).to(dtype).to(DEV)
+    new_slots = torch.tensor([int(r2t[i + 1, n - 1]) for i, n in enumerate(lens)], dtype=torch.int64, device=DEV)
+    sm = d ** -0.5
+    qd, r2td, rpid, lensd = q.to(DEV), _t(r2t), _t(rpi), _t(lens)
+
+    def pools():  # fresh pools without the new tokens (their slots hold garbage)
+        k0, v0 = kb.to(DEV).clone(), vb.to(DEV).clone()
+        k0[new_slots] = 7.0
+        v0[new_slots] = -7.0
+        if not hnd:
+            return k0, v0, None, (k0, v0)
+        n_pages = k0.shape[0] // page_size
+        kh = k0.view(n_pages, page_size, hkv, d).permute(0, 2, 1, 3).contiguous()
+        vh = v0.view(n_pages, page_size, hkv, d).permute(0, 2, 1, 3).contiguous()
+        return kh, vh, ops.kv_layout_hnd(kh, vh), (kh, vh)
+
+    def rows(buf):  # the new tokens' rows of a pool, [bs, hkv, d]
+        if not hnd:
+            return buf[new_slots]
+        return buf[new_slots // page_size, :, new_slots % page_size, :]
+
+    S = 8
+    nsplit = torch.zeros(bs, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits(nsplit, lensd.to(torch.int32), hq, hkv, S, 256)
+    al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
+    lse = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+    kvi = torch.empty(int(lens.sum()), dtype=torch.int64, device=DEV)
+    kvp = torch.zeros(bs + 1, dtype=torch.int32, device=DEV)
+    ops.build_kv_indices(r2td, rpid, lensd, kvp, kvi)
+    for mode in ("paged_single", "paged_split", "indices_split"):
+        outs = []
+        for fused in (False, True):
+            kbuf, vbuf, lay, (kraw, vraw) = pools()
+            if not fused:  # the store as its own step
+                if hnd:
+                    kraw[new_slots // page_size, :, new_slots % page_size, :] = k_new
+                    vraw[new_slots // page_size, :, new_slots % page_size, :] = v_new
+                else:
+                    kraw[new_slots] = k_new
+                    vraw[new_slots] = v_new
+            kw = dict(k_new=k_new, v_new=v_new) if fused else {}
+            o = torch.full((bs, hq, d), float("nan"), dtype=dtype, device=DEV)
+            if mode == "paged_single":
+                ops.decode_attention_fwd_paged(qd, kbuf, vbuf, o, r2td, rpid, lensd, None, None, None, 1, sm,
+                                               page_size=page_size, kv_layout=lay, **kw)
+            elif mode == "paged_split":
+                ops.decode_attention_fwd_paged(qd, kbuf, vbuf, o, r2td, rpid, lensd, al, lse, nsplit, S, sm,
+                                               page_size=page_size, kv_layout=lay, **kw)
+            else:
+                ops.decode_attention_fwd(qd, kbuf, vbuf, o, kvp, kvi, al, lse, nsplit, S, sm, 1.0, 1.0,
+                                         page_size=page_size, kv_layout=lay, **kw)
+            torch.cuda.synchronize()
+            outs.append(o)
+            if fused:
+                assert torch.equal(rows(kraw), k_new) and torch.equal(rows(vraw), v_new), mode
+        assert torch.equal(outs[0], outs[1]), (mode, (outs[0].float() - outs[1].float()).abs().max().item())
+
+
+def test_decode_fused_store_rejects_what_it_cannot_do(ops):
+    from sglang_amd.lib import RadixHipError
+
+    bs, d = 2, 128
+    q = torch.randn(bs, 32, d, device=DEV).to(torch.bfloat16)          # 32 q heads on ONE kv head: two q blocks
+    kb = torch.randn(64, 1, d, device=DEV).to(torch.bfloat16)
+    r2t = torch.arange(64, dtype=torch.int32, device=DEV).repeat(bs + 1, 1)
+    lens = torch.tensor([5, 9], device=DEV)
+    o = torch.empty_like(q)
+    kn = torch.randn(bs, 1, d, device=DEV).to(torch.bfloat16)
+    with pytest.raises(RadixHipError):
+        ops.decode_attention_fwd_paged(q, kb, kb, o, r2t, torch.tensor([1, 2], device=DEV), lens, None, None, None, 1,
+                                       d ** -0.5, k_new=kn, v_new=kn)
+    with pytest.raises(ValueError):
+        ops.decode_attention_fwd_paged(q[:, :4], kb, kb, o[:, :4], r2t, torch.tensor([1, 2], device=DEV), lens, None, None,
+                                       None, 1, d ** -0.5, k_new=kn, v_new=None)
