@@ -749,6 +749,11 @@ def main():
     args = parse()
     if args.cpu_worker:
         return cpu_worker(args)
+    # a wedged collective (or GPU) must not hold the launcher forever: after 30 minutes dump every thread's stack and
+    # leave with a non-zero code (the default run takes about a minute per N)
+    import faulthandler
+
+    faulthandler.dump_traceback_later(int(os.environ.get("RX_BENCH_WATCHDOG_S", "1800")), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.tp_sim:
         sys.exit(self_launch(args))
     rank, world, local_rank = build_world(args)
