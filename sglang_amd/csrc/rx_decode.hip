@@ -309,18 +309,13 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
   };
   // FUSE: this workgroup's range ends at the request's newest token, whose rows are not in the pool yet
   const bool has_new = FUSE && hi == si.seq_len;
-  const uint16_t* knew = nullptr;
-  const uint16_t* vnew = nullptr;
-  if constexpr (FUSE) {
-    knew = a.k_new + b * a.kn_stride_t + kvh * a.kn_stride_h + 8 * g;
-    vnew = a.v_new + b * a.vn_stride_t + kvh * a.vn_stride_h + 8 * g;
-  }
   // Register sets of K/V tiles in flight per wave.  One 32-token tile is 16 KiB of a 16-bit pool but
   // 8 KiB of an fp8 pool: with a single set the fp8 kernel has half the bytes in flight and ran at
   // 4.55 TB/s; two sets restore the 128 KiB per CU of the 16-bit kernel in the same registers.
   constexpr int DEPTH = KV8 ? RX_DEC_FP8_DEPTH : 1;
   KvV kf[DEPTH][2][NL], vf[DEPTH][2][NL];  // fp8 pools: upcast (exact) where consumed
   constexpr int LSTEP = KV8 ? 64 : 32;  // elements between a lane's consecutive loads
+  int64_t new_slot = 0;  // FUSE: pool slot of the newest token, kept from the slot list (no dependent load at the tail)
   auto load_kv = [&](int t, int64_t s0, int64_t s1, KvV (&kfs)[2][NL], KvV (&vfs)[2][NL]) {
     const int64_t ko0 = slot_offset<LINEAR>(s0, a.page_size, a.k_page_stride, a.k_tok_stride);
     const int64_t ko1 = slot_offset<LINEAR>(s1, a.page_size, a.k_page_stride, a.k_tok_stride);
@@ -333,13 +328,18 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
     if constexpr (FUSE) {
       // rows that are (or clamp to) the newest token come from k_new / v_new; only the last tile can hold it
       if (has_new && t == ntiles - 1) {
+        // (computed here, not hoisted: the pointers would otherwise sit in registers through the whole loop)
+        const uint16_t* knew = a.k_new + b * a.kn_stride_t + kvh * a.kn_stride_h + 8 * g;
+        const uint16_t* vnew = a.v_new + b * a.vn_stride_t + kvh * a.vn_stride_h + 8 * g;
         if (lo + t * kTile + r >= hi - 1) {
           kp0 = reinterpret_cast<const KvE*>(knew);
           vp0 = reinterpret_cast<const KvE*>(vnew);
+          new_slot = s0;  // (clamped rows carry the same slot)
         }
         if (lo + t * kTile + 16 + r >= hi - 1) {
           kp1 = reinterpret_cast<const KvE*>(knew);
           vp1 = reinterpret_cast<const KvE*>(vnew);
+          new_slot = s1;
         }
       }
     }
@@ -411,9 +411,8 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
         const int32_t tn = hi - 1 - (lo + t * kTile);  // row of the newest token in this tile
         if (r == (tn & 15)) {
           const int bb = tn >> 4;
-          const int64_t slot = static_cast<int64_t>(idx[hi - 1]);
-          KvE* kd = const_cast<KvE*>(kbase) + slot_offset<LINEAR>(slot, a.page_size, a.k_page_stride, a.k_tok_stride);
-          KvE* vd = const_cast<KvE*>(vbase) + slot_offset<LINEAR>(slot, a.page_size, a.v_page_stride, a.v_tok_stride);
+          KvE* kd = const_cast<KvE*>(kbase) + slot_offset<LINEAR>(new_slot, a.page_size, a.k_page_stride, a.k_tok_stride);
+          KvE* vd = const_cast<KvE*>(vbase) + slot_offset<LINEAR>(new_slot, a.page_size, a.v_page_stride, a.v_tok_stride);
 #pragma unroll
           for (int s = 0; s < NL; ++s) {
             *reinterpret_cast<KvV*>(kd + LSTEP * s) = bb ? kf[u][1][s] : kf[u][0][s];
