@@ -10,12 +10,19 @@ HQ, HKV, D, PS = int(os.environ.get("HQ", "32")), int(os.environ.get("HKV", "8")
 def run(bs, ctx, splits_list):
     pages = ctx // PS
     rng = np.random.default_rng(0)
-    perm = rng.permutation(np.arange(1, bs * pages + 1))
+    perm = np.arange(1, bs * pages + 1) if os.environ.get("CONTIG") else rng.permutation(np.arange(1, bs * pages + 1))
     slots = (perm.reshape(bs, pages)[:, :, None] * PS + np.arange(PS)[None, None, :]).reshape(bs, -1)
     r2t = torch.zeros(bs + 1, ctx, dtype=torch.int32, device=dev); r2t[1:] = torch.from_numpy(slots.astype(np.int32)).to(dev)
     rpi = torch.arange(1, bs + 1, device=dev); lens = torch.full((bs,), ctx, dtype=torch.int64, device=dev)
     pool = (bs * pages + 1) * PS
-    kb = torch.randn(pool // PS, HKV, PS, D, device=dev).to(torch.bfloat16); vb = torch.randn_like(kb)
+    kb = torch.randn(pool // PS, HKV, PS, D, device=dev).to(torch.bfloat16)
+    if os.environ.get("VPAD"):  # K and V in ONE allocation, V displaced by VPAD bytes past K's end (DRAM channel / bank aliasing probe)
+        pad = int(os.environ["VPAD"]) // 2
+        big = torch.empty(2 * kb.numel() + pad + 64, dtype=torch.bfloat16, device=dev)
+        big[: kb.numel()].copy_(kb.view(-1)); kb = big[: kb.numel()].view(kb.shape)
+        vb = big[kb.numel() + pad: 2 * kb.numel() + pad].view(kb.shape); vb.normal_()
+    else:
+        vb = torch.randn_like(kb)
     lay = ops.kv_layout_hnd(kb, vb)
     q = torch.randn(bs, HQ, D, device=dev).to(torch.bfloat16); o = torch.empty_like(q)
     ref = torch.zeros(bs, dtype=torch.int32, device=dev)
