@@ -146,9 +146,13 @@ class MHATokenToKVPool:
 
     def set_kv_buffer(self, layer, loc_info, cache_k: torch.Tensor, cache_v: torch.Tensor,
                       k_scale: Optional[float] = None, v_scale: Optional[float] = None,
-                      layer_id_override: Optional[int] = None):
-        """memory_pool.py:2305-2381 -> _store_kv_layer (:2383-2430) -> rx_store_kv."""
+                      layer_id_override: Optional[int] = None, dcp_kv_mask: Optional[torch.Tensor] = None):
+        """memory_pool.py:2305-2381 -> _store_kv_layer (:2383-2430) -> rx_store_kv.  ``dcp_kv_mask`` (decode context
+        parallel, :2351-2369 masked_set_kv_buffer_kernel): rows whose mask is 0 are not written -- they take the
+        reserved slot 0, which the store kernels skip."""
         loc, _, _ = unwrap_write_loc(loc_info)
+        if dcp_kv_mask is not None:
+            loc = torch.where(dcp_kv_mask.to(torch.bool), loc, torch.zeros_like(loc))
         layer_id = layer_id_override if layer_id_override is not None else layer.layer_id
         li = layer_id - self.start_layer
         if self.is_fp8:
