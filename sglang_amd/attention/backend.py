@@ -164,8 +164,8 @@ class HipRadixAttnBackend:
         self._cur_fb = None
         # shared-prefix (cascade) decode, SURVEY 8f-2: opt-in (a batch without a common prefix pays two empty
         # launches per layer); the common prefix itself is found on the device every forward
-        if self.dcp is not None and (self._is_mla_pool or self.sliding_window_size is not None):
-            raise NotImplementedError("DCP here covers MHA / GQA pools without sliding-window layers")
+        if self.dcp is not None and self.sliding_window_size is not None:
+            raise NotImplementedError("DCP here covers pools without sliding-window layers")
         self.cascade_decode = (bool(cascade_decode) and not self._is_mla_pool and self.sliding_window_size is None
                                and self.dcp is None)
         self.cascade_min_bs, self.cascade_min_shared = int(cascade_min_bs), int(cascade_min_shared)

@@ -150,9 +150,15 @@ dtype = torch.bfloat16 if os.environ["RX_DTYPE"] == "bf16" else torch.float16
 # the ranks of a DCP group are the TP ranks that would otherwise REPLICATE one kv head: one kv head per rank, and the
 # group's gathered q heads are that head's whole GQA group
 H_ALL, HKV, D, PS = 8, 1, int(os.environ["RX_D"]), 16
+MLA = D == 576                                 # the latent-row pool (one "kv head" of 576, V = its first 512 columns):
+DV = 512 if MLA else D                         # replicated over TP in the reference, i.e. the case DCP exists for
 HL = H_ALL // world
 VSIZE = 4096                                   # virtual slots (page 16, pages aligned so that slot % dcp == position % dcp)
-pool = MHATokenToKVPool(VSIZE // world + PS, 1, dtype, HKV, D, 1, DEV)        # this rank's share
+if MLA:
+    from sglang_amd.mem_cache.memory_pool import MLATokenToKVPool
+    pool = MLATokenToKVPool(VSIZE // world + PS, 1, dtype, 512, 64, 1, DEV)
+else:
+    pool = MHATokenToKVPool(VSIZE // world + PS, 1, dtype, HKV, D, 1, DEV)    # this rank's share
 r2t = ReqToTokenPool(8, 1024, DEV)
 alloc = PagedTokenToKVPoolAllocator(VSIZE, PS, dtype, DEV, pool)               # same decisions on every rank
 g0 = torch.Generator().manual_seed(5)
@@ -165,11 +171,11 @@ class MR:
     class server_args: triton_attention_num_kv_splits = 4
 backend = HipRadixAttnBackend(MR, dcp=DcpGroup(world, rank))
 assert backend.num_head == H_ALL and backend.local_num_head == HL and backend.decode_index_mode == "indices"
-layer = RadixAttention(HL, D, D ** -0.5, HKV, 0)
+layer = RadixAttention(HL, D, D ** -0.5, HKV, 0, v_head_dim=DV)
 gen = torch.Generator().manual_seed(11)        # same stream on every rank
 rows = [3, 1, 5]
 kc = np.zeros((VSIZE + PS, HKV, D), dtype=np.float64)      # the virtual cache, for the oracle
-vc = np.zeros_like(kc)
+vc = np.zeros((VSIZE + PS, HKV, DV), dtype=np.float64)
 seq = [0, 0, 0]
 ok = True
 
@@ -193,19 +199,21 @@ def extend_step(ext):
     ops.write_req_to_token(r2t.req_to_token, torch.tensor(rows, dtype=torch.int64, device=DEV), None, pre_t.to(DEV),
                            new_t.to(DEV), (new_t - pre_t).to(DEV), loc)
     T = sum(ext)
-    q, k, v = rnd(T, H_ALL, D), rnd(T, HKV, D), rnd(T, HKV, D)
+    q, k = rnd(T, H_ALL, D), rnd(T, HKV, D)
+    v = k[..., :DV] if MLA else rnd(T, HKV, D)
     kc[loc.cpu().numpy()] = k.double().numpy(); vc[loc.cpu().numpy()] = v.double().numpy()
     fb = ForwardBatch.for_extend(torch.tensor(rows, dtype=torch.int64, device=DEV), new_t.to(DEV), loc, pre, ext)
     # slot % dcp == position % dcp: what makes (virtual slot // dcp) collision-free on a rank
     assert torch.equal(loc % world, fb.positions % world)
     backend.init_forward_metadata(fb)
     ql = q[:, rank * HL:(rank + 1) * HL].contiguous().to(DEV)
-    out = layer(ql.view(T, -1), k.to(DEV).view(T, -1), v.to(DEV).view(T, -1), fb, backend)
+    kd = k.to(DEV)
+    out = layer(ql.view(T, -1), kd, kd[..., :DV] if MLA else v.to(DEV), fb, backend)
     args = (r2t.req_to_token.cpu().numpy(), np.array(rows), np.array(new), np.array(pre), np.array(ext), D ** -0.5)
     want = orc.sdpa_extend_req_to_token(q.double().numpy(), kc, vc, *args, causal=True)
     absw = orc.sdpa_extend_req_to_token(q.double().numpy(), kc, np.abs(vc), *args, causal=True)
     # two 16-bit roundings where a prefix exists: the extend kernels' partials are 16-bit (as merge_state's inputs are)
-    check(out.view(T, HL, D), want[:, rank * HL:(rank + 1) * HL], f"extend {pre}+{ext}",
+    check(out.view(T, HL, DV), want[:, rank * HL:(rank + 1) * HL], f"extend {pre}+{ext}",
           absw[:, rank * HL:(rank + 1) * HL], 2.0 if sum(pre) else 1.0)
     seq = new
 
@@ -218,17 +226,19 @@ def decode_step():
     for r, s, l in zip(rows, seq, loc.tolist()):
         r2t.req_to_token[r, s] = l
     bs = len(rows)
-    q, k, v = rnd(bs, H_ALL, D), rnd(bs, HKV, D), rnd(bs, HKV, D)
+    q, k = rnd(bs, H_ALL, D), rnd(bs, HKV, D)
+    v = k[..., :DV] if MLA else rnd(bs, HKV, D)
     kc[loc.cpu().numpy()] = k.double().numpy(); vc[loc.cpu().numpy()] = v.double().numpy()
     fb = ForwardBatch.for_decode(torch.tensor(rows, dtype=torch.int64, device=DEV), new_t.to(DEV), loc)
     backend.init_forward_metadata(fb)
     ql = q[:, rank * HL:(rank + 1) * HL].contiguous().to(DEV)
-    out = layer(ql.view(bs, -1), k.to(DEV).view(bs, -1), v.to(DEV).view(bs, -1), fb, backend)
+    kd = k.to(DEV)
+    out = layer(ql.view(bs, -1), kd, kd[..., :DV] if MLA else v.to(DEV), fb, backend)
     args = (r2t.req_to_token.cpu().numpy(), np.array(rows), np.array(new), D ** -0.5)
     want = orc.sdpa_decode_req_to_token(q.double().numpy(), kc, vc, *args)
     absw = orc.sdpa_decode_req_to_token(q.double().numpy(), kc, np.abs(vc), *args)
     # fp32 partials end to end (as the reference): one output rounding
-    check(out.view(bs, HL, D), want[:, rank * HL:(rank + 1) * HL], f"decode {new}", absw[:, rank * HL:(rank + 1) * HL], 1.0)
+    check(out.view(bs, HL, DV), want[:, rank * HL:(rank + 1) * HL], f"decode {new}", absw[:, rank * HL:(rank + 1) * HL], 1.0)
     seq = new
 
 extend_step([37, 64, 5])          # prefill: no prefix anywhere, no collective on the data path
@@ -255,11 +265,11 @@ sys.exit(0 if ok else 1)
 
 
 @pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("dt,d", [("bf16", 128), ("fp16", 64)])
+@pytest.mark.parametrize("dt,d", [("bf16", 128), ("fp16", 64), ("bf16", 576)], ids=["bf16-128", "fp16-64", "mla-bf16"])
 def test_dcp_prefill_and_decode_across_processes(world, dt, d, tmp_path):
     script = tmp_path / "dcp_worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, RX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + world + (d == 64)),
+    env = dict(os.environ, RX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + world + (d == 64) + 20 * (d == 576)),
                WORLD_SIZE=str(world), RX_DTYPE=dt, RX_D=str(d), HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
