@@ -129,7 +129,9 @@ def test_config2_shared_prefix_extend(ops):
                              _T(kv_indices), None, True, None, E, 1.0, 1.0, sm_scale=sm, lse_extend=lse, page_size=page)
     want, want_lse = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr,
                                           kv_indices, sm_scale=sm, return_lse=True)
-    parity.check(np.abs(o.float().cpu().numpy().astype(np.float64) - want).max(), 1.5e-2, None)
+    absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve)), _bits(kb), parity.abs_values(_bits(vb)),
+                                qo, kv_indptr, kv_indices, sm_scale=sm)
+    parity.check_out(o.float().cpu().numpy(), want, dtype, "config 2/3 chunk", absw=absw)   # north star, element-wise
     np.testing.assert_allclose(lse.cpu().numpy(), want_lse, atol=5e-3, rtol=2e-3)
 
 
@@ -148,6 +150,7 @@ def test_config3_llama70b_tp8_shard_decode(ops):
     sm = d ** -0.5
     ip, ii = orc.build_kv_indices(r2t, rpi, lens)
     want = orc.decode_attention(_bits(q), _bits(kb), _bits(vb), ip, ii, sm)
+    absw = orc.decode_attention(_bits(q), _bits(kb), parity.abs_values(_bits(vb)), ip, ii, sm)
     qd, kbd, vbd = q.to(DEV), kb.to(DEV), vb.to(DEV)
     for S in (1, 8):  # single pass and the split-KV schedule a small TP shard batch gets
         o = torch.zeros(bs, hq, d, dtype=dtype, device=DEV)
@@ -161,7 +164,7 @@ def test_config3_llama70b_tp8_shard_decode(ops):
             ls = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
             ops.decode_attention_fwd_paged(qd, kbd, vbd, o, _T(r2t), _T(rpi), _T(lens), al, ls, ns, S, sm,
                                            page_size=page)
-        parity.check(np.abs(o.float().cpu().numpy().astype(np.float64) - want).max(), 1e-2, S)
+        parity.check_out(o.float().cpu().numpy(), want, dtype, ("config 3 shard", S), absw=absw)   # north star
 
 
 def test_config4_mla_fp8_tp8_decode(ops):
@@ -179,8 +182,9 @@ def test_config4_mla_fp8_tp8_decode(ops):
     ip, ii = orc.build_kv_indices(r2t, rpi, lens)
     kvn = orc.fp8_e4m3fn_decode(kv.view(torch.uint8).numpy())
     want = orc.decode_attention(_bits(q), kvn, kvn[..., :512], ip, ii, sm)
+    absw = orc.decode_attention(_bits(q), kvn, np.abs(kvn[..., :512]), ip, ii, sm)
     kvd = kv.to(DEV)
     o = torch.zeros(bs, hq, 512, dtype=dtype, device=DEV)
     ops.decode_attention_fwd_paged(q.to(DEV), kvd, kvd[..., :512], o, _T(r2t), _T(rpi), _T(lens), None, None, None, 1,
                                    sm, page_size=page)
-    parity.check(np.abs(o.float().cpu().numpy().astype(np.float64) - want).max(), 1e-2, None)
+    parity.check_out(o.float().cpu().numpy(), want, dtype, "config 4 MLA fp8 shard", absw=absw)   # north star
