@@ -211,8 +211,9 @@ typedef struct rx_decode_params {
    * req_to_token row / kv_indices already names) is then READ from them and WRITTEN to that slot by the kernel -- K1
    * (store_cache, memory_pool.py:2383-2430) without its own launch, as the reference's CPU kernel does
    * (decode_attention_cpu, aot/csrc/cpu/decode.cpp).  Needs the D = 64 / 128 kernel on a 16-bit pool, at most 16 q heads
-   * per kv head (one workgroup per row), stages == 0, no kv_start / extra partials; anything else is an error (store
-   * with rx_store_kv* first).  NULL: the pool already holds the token. */
+   * per kv head (one workgroup per row) and a call that runs stage 1 (stages 0 or 1; kv_start and extra partials are
+   * fine: the newest token is the last of the attended suffix); anything else is an error (store with rx_store_kv*
+   * first).  NULL: the pool already holds the token. */
   const void* k_new;
   const void* v_new;
   int64_t k_new_stride_t, k_new_stride_h, v_new_stride_t, v_new_stride_h;

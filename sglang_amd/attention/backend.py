@@ -651,9 +651,9 @@ class HipRadixAttnBackend:
 
     def _fused_store_ok(self, layer, k, v) -> bool:
         """rx_decode_params.k_new: the new token's rows are read from k / v and written to their slots by the decode
-        kernel itself -- a 16-bit pool of k's dtype, D = 64 / 128, at most 16 q heads per kv head, the plain (not
-        cascade / DCP / sliding-window / scaled-store) path, 16-byte aligned rows."""
-        if self._no_fused_store or self.dcp is not None or self._cascade_on or self._is_mla_pool:
+        kernel itself -- a 16-bit pool of k's dtype, D = 64 / 128, at most 16 q heads per kv head, the plain or
+        shared-prefix path (not DCP / sliding-window / scaled-store), 16-byte aligned rows."""
+        if self._no_fused_store or self.dcp is not None or self._is_mla_pool:
             return False
         pool = self.token_to_kv_pool
         if getattr(pool, "is_fp8", False) or k.dtype != pool.dtype or v.dtype != pool.dtype:
@@ -692,9 +692,12 @@ class HipRadixAttnBackend:
             k_descale, v_descale = self._scales(layer)
             k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
             hnd = getattr(self.token_to_kv_pool, "use_hnd", False)
+            kn = k.view(-1, layer.tp_k_head_num, layer.qk_head_dim) if fuse else None
+            vn = v.view(-1, layer.tp_v_head_num, layer.v_head_dim) if fuse else None
             self._cascade(q3, k_buf, v_buf, o3, layer.scaling, k_descale, v_descale, layer.logit_cap,
                           sinks if sinks is None or sinks.dtype == torch.float32 else sinks.float(),
-                          page_size=self.page_size, kv_layout=ops.kv_layout_hnd(k_buf, v_buf) if hnd else None)
+                          page_size=self.page_size, kv_layout=ops.kv_layout_hnd(k_buf, v_buf) if hnd else None,
+                          k_new=kn, v_new=vn)
             return o
         ln = self._decode_launchers.get(layer.layer_id)
         if ln is None:

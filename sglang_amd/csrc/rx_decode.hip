@@ -923,9 +923,9 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.k_new = a.v_new = nullptr;
   if (p->k_new || p->v_new) {
     RX_REQUIRE(p->k_new && p->v_new, "rx_decode_attn: k_new and v_new come together");
-    RX_REQUIRE(mfma_ok && !mla && !p->kv.kv_fp8 && a.qblocks == 1 && p->stages == 0 && !a.kv_start && a.num_extra == 0,
+    RX_REQUIRE(mfma_ok && !mla && !p->kv.kv_fp8 && a.qblocks == 1 && p->stages != 2,
                "rx_decode_attn: the fused store needs the D = 64 / 128 kernel on a 16-bit pool with at most 16 q heads "
-               "per kv head, stages = 0 and no kv_start / extra partials (store with rx_store_kv* instead)");
+               "per kv head, in a call that runs stage 1 (store with rx_store_kv* instead)");
     RX_REQUIRE((((uintptr_t)p->k_new | (uintptr_t)p->v_new) & 15) == 0 &&
                    (p->k_new_stride_t | p->k_new_stride_h | p->v_new_stride_t | p->v_new_stride_h) % 8 == 0,
                "rx_decode_attn: k_new / v_new need 16-byte aligned rows");

@@ -591,7 +591,9 @@ class CascadeDecode:
         return int(self.plan_buf[0].item())
 
     def __call__(self, q, k_buffer, v_buffer, o, sm_scale, k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
-                 page_size: int = 1, kv_layout=None) -> None:
+                 page_size: int = 1, kv_layout=None, k_new=None, v_new=None) -> None:
+        """k_new / v_new: the step's KV store rides in the suffix launch (rx_decode_params.k_new): the newest token of
+        every request is the last of its suffix."""
         bs, S = self.bs, self.num_chunks
         if q.shape != (bs, self.hq, self.d):
             raise ValueError(f"CascadeDecode: q {tuple(q.shape)} != {(bs, self.hq, self.d)}")
@@ -635,6 +637,7 @@ class CascadeDecode:
             sinks = sinks.float()
         pd.sinks = None if sinks is None else sinks.data_ptr()
         self._sinks_keep = sinks
+        _set_new_kv(pd, k_new, v_new, bs)
         lib = self._lib
 
         def phase1():
