@@ -61,6 +61,9 @@ def parse():
                     help="kv-split schedule: MI355X-native (default) or the reference's K3 formula capped by --max-kv-splits")
     ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp8"],
                     help="dev: KV pool dtype (BASELINE's config is bf16; fp8 = --kv-cache-dtype fp8_e4m3)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="SURVEY 8d's second input: seq_lens uniform in [ctx/2, ctx] (torch.manual_seed(0)) instead of all "
+                         "= ctx; the roofline's bytes follow the sum of the lengths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extend", action="store_true")
     ap.add_argument("--no-radix-hit", action="store_true", help="skip the shared-prefix (radix-hit) decode leg")
@@ -183,9 +186,12 @@ def make_decode_state(args, tp, dev, shared_prefix=0, cascade=False):
     st.backend, st.layers, st.pool, st.r2t = backend, layers, pool, r2t_pool
     st.hq, st.hkv, st.D, st.hid, st.distinct = hq, hkv, D, HID, distinct
     st.req_pool_indices = torch.tensor(rows, dtype=torch.int64, device=dev)
-    st.seq_lens = torch.full((bs,), ctx, dtype=torch.int64, device=dev)
-    st.seq_lens_cpu = torch.full((bs,), ctx, dtype=torch.int64)
-    st.out_cache_loc = r2t_pool.req_to_token[rows, ctx - 1].to(torch.int64)
+    if getattr(args, "ragged", False) and not shared_prefix:
+        st.seq_lens_cpu = torch.randint(ctx // 2, ctx + 1, (bs,), generator=torch.Generator().manual_seed(0), dtype=torch.int64)
+    else:
+        st.seq_lens_cpu = torch.full((bs,), ctx, dtype=torch.int64)
+    st.seq_lens = st.seq_lens_cpu.to(dev)
+    st.out_cache_loc = r2t_pool.req_to_token[st.req_pool_indices, st.seq_lens - 1].to(torch.int64)
     st.q = torch.randn(bs, hq * D, device=dev, generator=g).to(torch.bfloat16)
     st.k = torch.randn(bs, hkv * D, device=dev, generator=g).to(torch.bfloat16)
     st.v = torch.randn(bs, hkv * D, device=dev, generator=g).to(torch.bfloat16)
@@ -832,7 +838,7 @@ def main():
 
     # roofline of the dominant kernel (decode attention), per launch
     bs, ctx, L = args.bs, args.ctx, args.layers
-    b_kv = bs * ctx * (st.hkv * st.D + st.hkv * st.D) * (1 if args.kv_dtype == "fp8" else 2)
+    b_kv = int(st.seq_lens_cpu.sum()) * (st.hkv * st.D + st.hkv * st.D) * (1 if args.kv_dtype == "fp8" else 2)
     b_qo = 2 * bs * st.hq * st.D * 2
     bytes_per_launch = b_kv + b_qo
     durs = np.array([a.elapsed_time(b) for a, b in ev_pairs]) if ev_pairs else np.array([float("nan")])
@@ -890,6 +896,8 @@ def main():
                                % (bs, ctx, L, args.page_size, args.kv_layout.upper(), tp, st.hq, st.hkv,
                                   " + all-reduce (side stream, one in flight)" if world > 1 else ""),
                    "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{tp}",
+                   "seq_lens": ("uniform int in [%d, %d], seed 0 (mean %.0f)" % (ctx // 2, ctx, float(st.seq_lens_cpu.float().mean()))
+                                if args.ragged else "all = ctx"),
                    "index_mode": args.index_mode, "kv_layout": args.kv_layout, "kv_dtype": args.kv_dtype,
                    "split_policy": args.split_policy, "settle_steps_untimed": args.settle,
                    "step_launch": "hip-graph replay (2 graphs + 1 eager probe launch per step)" if use_graph else "eager",

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 5
+#define RX_ABI_VERSION 6
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -217,6 +217,10 @@ typedef struct rx_decode_params {
   const void* k_new;
   const void* v_new;
   int64_t k_new_stride_t, k_new_stride_h, v_new_stride_t, v_new_stride_h;
+  /* Optional: int32[bs], a permutation of 0..bs-1 -- the order in which the D = 64 / 128 kernel's workgroups take the
+   * requests (e.g. argsort of the lengths, descending: the last round of workgroups of a ragged batch is then its short
+   * requests).  Results do not depend on it.  NULL: request b is block b. */
+  const int32_t* request_order;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);

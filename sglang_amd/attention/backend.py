@@ -56,6 +56,8 @@ class ForwardMetadata:
     window_kv_indices: Optional[torch.Tensor] = None
     window_num_kv_splits: Optional[torch.Tensor] = None
     window_kv_offsets: Optional[torch.Tensor] = None
+    # decode: launch order of the requests (longest first) for batches that take more than one round of workgroups
+    request_order: Optional[torch.Tensor] = None
 
 
 def host_num_kv_splits(seq_lens: np.ndarray, num_head: int, num_kv_head: int, max_kv_splits: int,
@@ -255,6 +257,25 @@ class HipRadixAttnBackend:
                                          self.window_kv_indptr, kv_indices, start)
         return kv_indptr, kv_indices, window_lens, start
 
+    def _request_order(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool) -> Optional[torch.Tensor]:
+        """rx_decode_params.request_order: the batch's requests by descending length, when the launch has more
+        workgroups than the chip holds at once (two per CU) -- a ragged batch's longest requests then start first and
+        its last round is the short ones (bs 256, lengths uniform in [2 k, 4 k]: decode kernel 0.73 -> 0.76 of HBM peak)."""
+        group = max(1, self.num_head // self.num_kv_head)
+        if bs * self.num_kv_head * ((group + 15) // 16) <= 2 * self.device_core_count:
+            return None
+        if not use_graph_bufs and fb.seq_lens_cpu is not None:
+            cpu = fb.seq_lens_cpu
+            if int(cpu.max()) == int(cpu.min()):
+                return None
+        order = torch.argsort(fb.seq_lens[:bs], descending=True).to(torch.int32)
+        if use_graph_bufs:
+            buf = self._graph.setdefault("request_order", torch.zeros(self._graph["max_bs"], dtype=torch.int32,
+                                                                      device=self.device))
+            buf[:bs].copy_(order)
+            return buf[:bs]
+        return order
+
     def _decode_metadata(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool) -> ForwardMetadata:
         self._cascade_on = self.cascade_decode and bs >= self.cascade_min_bs
         if self._cascade_on:
@@ -299,7 +320,8 @@ class HipRadixAttnBackend:
             win = dict(window_kv_indptr=wp, window_kv_indices=wi, window_num_kv_splits=wsplits)
             splits_needed = splits_needed or self.max_kv_splits > 1  # window launch uses the scratch too
         if not splits_needed:
-            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1, **win)
+            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1, **win,
+                                   request_order=None if win else self._request_order(fb, bs, use_graph_bufs))
         if use_graph_bufs:
             num_kv_splits = self._graph["num_kv_splits"][:bs]
             attn_logits, attn_lse = self._graph["attn_logits"][:bs], self._graph["attn_lse"][:bs]
@@ -341,7 +363,8 @@ class HipRadixAttnBackend:
             wg_target = self.device_core_count
         S = ops.native_max_kv_splits(bs, self.num_head, self.num_kv_head, wg_target, self.native_split_cap)
         if S <= 1:
-            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1)
+            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1,
+                                   request_order=self._request_order(fb, bs, use_graph_bufs))
         # The in-kernel stage 2 (merge_counters) wants the partial rows of a head in chunks of 8: allocate 8 (16, ...) split
         # slots while a request still runs `S_live` of them -- the surplus workgroups exit at once, and the second launch
         # goes (TP=8 shard 256 x 4 k at 2 live splits: 107 us with the stage-2 launch, 101 with 8 slots and none).
@@ -723,13 +746,15 @@ class HipRadixAttnBackend:
                 ln.set_metadata(self._md_version, q3.shape[0], kv_indptr=md.kv_indptr,
                                 kv_indices=md.kv_indices, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
-                                attn_lse=md.attn_lse, merge_counters=self._merge_counters)
+                                attn_lse=md.attn_lse, merge_counters=self._merge_counters,
+                                request_order=md.request_order)
             else:
                 ln.set_metadata(self._md_version, q3.shape[0], req_to_token=self.req_to_token,
                                 req_pool_indices=forward_batch.req_pool_indices,
                                 seq_lens=forward_batch.seq_lens, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
-                                attn_lse=md.attn_lse, merge_counters=self._merge_counters)
+                                attn_lse=md.attn_lse, merge_counters=self._merge_counters,
+                                request_order=md.request_order)
         if sinks is not None and sinks.dtype != torch.float32:
             sinks = sinks.float()
         if fuse:

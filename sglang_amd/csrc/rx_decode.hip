@@ -60,6 +60,7 @@ struct DecodeArgs {
   const uint16_t* k_new;
   const uint16_t* v_new;
   int64_t kn_stride_t, kn_stride_h, vn_stride_t, vn_stride_h;
+  const int32_t* order;  // launch order of the requests (a permutation of 0..bs-1, longest first), or NULL
 };
 
 // Grok temperature factor of a request (decode_attention.py:156-160): the single query sits at seq_len-1
@@ -223,7 +224,9 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
   bid /= a.qblocks;
   const int kvh = bid % a.hkv;
   bid /= a.hkv;
-  const int b = bid % a.bs;
+  // a ragged batch is dealt longest request first (a.order): the chip's last round of workgroups is then the
+  // short requests, not a 4 k-token one that starts when the others are finishing
+  const int b = a.order ? a.order[bid % a.bs] : bid % a.bs;
   const int split = bid / a.bs;
 
   const SeqInfo si = seq_info<IdxT>(a, b);
@@ -920,6 +923,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.merge_counters = merge_in_kernel ? p->merge_counters : nullptr;
   // fused store of the new token: one q block per kv head (one workgroup touches the row), a 16-bit pool, the whole
   // request attended in one pass of the MFMA kernel, 16-byte chunks
+  a.order = p->request_order;
   a.k_new = a.v_new = nullptr;
   if (p->k_new || p->v_new) {
     RX_REQUIRE(p->k_new && p->v_new, "rx_decode_attn: k_new and v_new come together");

@@ -256,7 +256,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
                          num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap=0.0,
                          sinks=None, xai_temperature_len=-1, has_mla=False, use_pdl=False,
                          page_size: int = 1, score_mod=None, aux_tensors=None, kv_layout=None, stages: int = 0,
-                         merge_counters=None, k_new=None, v_new=None):
+                         merge_counters=None, k_new=None, v_new=None, request_order=None):
     """Same contract as the reference.  q [bs,Hq,Dk], o [bs,Hq,Dv], kv_indptr int32[bs+1],
     kv_indices int32/int64, attn_logits fp32[bs,Hq,max_kv_splits,Dv], attn_lse fp32[bs,Hq,S].
     ``max_kv_splits == 1`` (or num_kv_splits None) runs the single-pass kernel.  ``stages`` as in
@@ -283,6 +283,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     p.stages = int(stages)
     p.merge_counters = _merge_counters_ptr(merge_counters, q.shape[0], q.shape[1])
     _set_new_kv(p, k_new, v_new, q.shape[0])
+    p.request_order = _request_order_ptr(request_order, q.shape[0])
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -325,12 +326,13 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
                                k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
                                page_size: int = 1, kv_layout=None, xai_temperature_len=-1,
                                kv_start=None, extra_o=None, extra_lse=None, stages: int = 0, merge_counters=None,
-                               k_new=None, v_new=None):
+                               k_new=None, v_new=None, request_order=None):
     p = _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse,
                              num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap, sinks, page_size,
                              kv_layout, xai_temperature_len, kv_start, extra_o, extra_lse, stages)
     p.merge_counters = _merge_counters_ptr(merge_counters, q.shape[0], q.shape[1])
     _set_new_kv(p, k_new, v_new, q.shape[0])
+    p.request_order = _request_order_ptr(request_order, q.shape[0])
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -395,6 +397,16 @@ def _set_new_kv(p, k_new, v_new, bs: int) -> None:
     p.v_new_stride_t, p.v_new_stride_h = v_new.stride(0), v_new.stride(1)
 
 
+def _request_order_ptr(request_order, bs: int):
+    """rx_decode_params.request_order: int32[bs] permutation (launch order of the requests), or None."""
+    if request_order is None:
+        return None
+    if (not request_order.is_cuda or request_order.dtype != torch.int32 or not request_order.is_contiguous()
+            or request_order.numel() < bs):
+        raise ValueError("request_order must be a contiguous int32 GPU tensor of bs entries")
+    return request_order.data_ptr()
+
+
 def _merge_counters_ptr(merge_counters, bs: int, num_q_heads: int):
     """rx_decode_params.merge_counters: zeroed int32 device memory of at least bs * Hq words (the kernels leave it
     zero), or None for the separate stage-2 launch."""
@@ -434,10 +446,11 @@ class DecodeLauncher:
 
     def set_metadata(self, version, bs, *, kv_indptr=None, kv_indices=None, req_to_token=None,
                      req_pool_indices=None, seq_lens=None, num_kv_splits=None, max_kv_splits=1,
-                     attn_logits=None, attn_lse=None, merge_counters=None):
+                     attn_logits=None, attn_lse=None, merge_counters=None, request_order=None):
         p = self.p
         p.bs = bs
         p.merge_counters = _merge_counters_ptr(merge_counters, bs, p.num_q_heads)
+        p.request_order = _request_order_ptr(request_order, bs)
         if kv_indices is not None:
             p.kv_indptr, p.kv_indices = kv_indptr.data_ptr(), kv_indices.data_ptr()
             p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
@@ -453,7 +466,7 @@ class DecodeLauncher:
         else:
             p.num_kv_splits, p.max_kv_splits = None, 1
         self._keep = (kv_indptr, kv_indices, req_to_token, req_pool_indices, seq_lens, num_kv_splits,
-                      attn_logits, attn_lse, merge_counters)
+                      attn_logits, attn_lse, merge_counters, request_order)
         self.version = version
 
     def can_fuse_store(self) -> bool:

@@ -1299,3 +1299,32 @@ def test_decode_fused_store_rejects_what_it_cannot_do(ops):
     with pytest.raises(ValueError):
         ops.decode_attention_fwd_paged(q[:, :4], kb, kb, o[:, :4], r2t, torch.tensor([1, 2], device=DEV), lens, None, None,
                                        None, 1, d ** -0.5, k_new=kn, v_new=None)
+
+
+def test_decode_request_order_changes_nothing_but_the_launch_order(ops):
+    """rx_decode_params.request_order (longest request first): same bits as the natural order, single pass and split."""
+    rng = np.random.default_rng(12)
+    hq, hkv, d, ps = 8, 2, 128, 16
+    lens = rng.integers(1, 900, size=40).astype(np.int64)
+    bs = len(lens)
+    q, kb, vb, r2t, rpi = _make_paged_case(rng, bs, hq, hkv, d, lens, ps, torch.bfloat16, "shuffled")
+    qd, kbd, vbd, r2td, rpid, lensd = q.to(DEV), kb.to(DEV), vb.to(DEV), _t(r2t), _t(rpi), _t(lens)
+    order = torch.argsort(lensd, descending=True).to(torch.int32)
+    assert sorted(order.tolist()) == list(range(bs))
+    S = 8
+    nsplit = torch.zeros(bs, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits(nsplit, lensd.to(torch.int32), hq, hkv, S, 64)
+    al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
+    lse = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+    for split in (False, True):
+        outs = []
+        for ro in (None, order):
+            o = torch.full((bs, hq, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+            if split:
+                ops.decode_attention_fwd_paged(qd, kbd, vbd, o, r2td, rpid, lensd, al, lse, nsplit, S, d ** -0.5,
+                                               page_size=ps, request_order=ro)
+            else:
+                ops.decode_attention_fwd_paged(qd, kbd, vbd, o, r2td, rpid, lensd, None, None, None, 1, d ** -0.5,
+                                               page_size=ps, request_order=ro)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1])
