@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Dev sweep: dense decode kernel time vs (batch, ctx, forced split count) at Llama-3-8B head geometry."""
+"""Dev sweep: dense decode kernel time vs (batch, ctx, forced split count) at Llama-3-8B head geometry.
+env: HQ / HKV (head counts, default 32 / 8), SHAPES (e.g. 256x4096,1x32768), SPLITS (e.g. 1,2,8), NS (live splits of the
+S allocated), GRAPH=1 (20 calls captured once: GPU time without the host), MC=1 (in-kernel stage 2: merge_counters),
+CONTIG=1 (pages in order instead of shuffled), VPAD=<bytes> (K and V in one allocation, V displaced)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
