@@ -90,6 +90,16 @@ int rx_num_kv_splits_native(const void* seq_lens, int seq_lens_is_i64, int bs, i
                             int cu_count, int max_kv_splits, int min_tokens_per_split, int32_t* out,
                             void* stream);
 
+/* Length-aware form of the native schedule (round 2): a batch is rarely uniform, and ONE long request in a batch of
+ * short ones is the whole kernel's tail when every request gets the same split count (64 requests, one of 32 k tokens
+ * and 63 of 1 k: 516 us unsplit, 139 us with the long one cut 16 ways).  With total = sum of the lengths,
+ *   t* = max(min_tokens_per_split, ceil(total * wg_per_request / wg_target))      (an even share of the batch)
+ *   out[b] = 1 if 2 * len_b <= 3 * t*,  else min(max_kv_splits, ceil(len_b / t*)).
+ * One launch, no host sync; max_kv_splits (the scratch's split slots) caps the count, so a host-side guess of the
+ * largest count can never be overrun. */
+int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int wg_target,
+                              int max_kv_splits, int min_tokens_per_split, int32_t* out, void* stream);
+
 /* ---- KV buffer addressing shared by decode / extend ------------------------------------
  * element offset of (slot, kv_head) = (slot / page_size) * page_stride
  *                                   + (slot % page_size) * tok_stride + kv_head * head_stride

@@ -345,29 +345,68 @@ class HipRadixAttnBackend:
                 kv_indices = torch.empty(total, dtype=torch.int64, device=self.device)
             kv_indptr = ops.build_kv_indices(self.req_to_token, fb.req_pool_indices, fb.seq_lens,
                                              self.kv_indptr, kv_indices)
-        # workgroups aimed for in total.  Dense kernel: one per CU is four waves per CU, one per SIMD -- with bs * Hkv
-        # head blocks <= CUs a second workgroup per CU pays (TP=8 shard, 256 x 4 k: 113 -> 106 us per layer; 128 x 4 k:
-        # 58 -> 52; TP=1 16 x 4 k: 57 -> 55; 8 x 8 k: 56 -> 51), above that every split only costs (64 x 2 k: 102 us
-        # at 1 split, 107 at 2).  In the 2-4 split regime a split under ~1 k tokens is all prologue (32 x 1 k: 31 us at 1
-        # split, 33 at 2), so short requests take fewer; tiny batches keep the 128-token floor, they need the parallelism.
         group = max(1, self.num_head // self.num_kv_head)
         blocks = bs * self.num_kv_head * ((group + 15) // 16)
-        min_tokens = 128
+        wg_target = self.device_core_count * 2
         if self._is_mla_pool:
-            wg_target = self.device_core_count * 2
-        elif blocks <= self.device_core_count:
-            wg_target = self.device_core_count * 2
-            if 2 * blocks >= self.device_core_count:
-                min_tokens = 1024
-        else:
-            wg_target = self.device_core_count
-        S = ops.native_max_kv_splits(bs, self.num_head, self.num_kv_head, wg_target, self.native_split_cap)
+            return self._decode_metadata_uniform(fb, bs, use_graph_bufs, kv_indptr, kv_indices, wg_target, 128)
+        # Dense kernel: the LENGTH-AWARE schedule (rx_num_kv_splits_balanced).  Two workgroups per CU in total is where
+        # the kernel is fastest (one per CU is one wave per SIMD: TP=8 shard 256 x 4 k 113 -> 106 us per layer at 2
+        # splits; 16 x 4 k 57 -> 55; 8 x 8 k 56 -> 51; beyond that every split only costs), and a request takes
+        # ceil(len / t*) splits, t* = the batch's even share per workgroup -- but ONLY if it is well above that share:
+        # in a uniform batch nobody is split (bs 256 x 4 k: one pass each), while one 32 k-token request among 63 of 1 k
+        # is cut ~20 ways instead of being the kernel's tail (516 -> 139 us per layer).  Requests with one split write
+        # their output straight from stage 1 (rx_decode_params: direct_single).  In the 2-4 split regime a split under
+        # ~1 k tokens is all prologue (32 x 1 k: 31 us at 1 split, 33 at 2): t* has a 1 k floor there, 128 for tiny batches.
+        min_tokens = 1024 if 2 * blocks >= self.device_core_count else 128
+        cap = self.native_split_cap
+        if not use_graph_bufs and fb.seq_lens_cpu is not None:
+            S = int(ops.balanced_kv_splits_host(fb.seq_lens_cpu.numpy()[:bs], self.num_head, self.num_kv_head, cap,
+                                                wg_target, min_tokens).max())
+        else:  # lengths unknown here (graph replay refills the counts on the device): slots by batch size alone
+            S = self._graph_split_slots(bs)
         if S <= 1:
             return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1,
                                    request_order=self._request_order(fb, bs, use_graph_bufs))
-        # The in-kernel stage 2 (merge_counters) wants the partial rows of a head in chunks of 8: allocate 8 (16, ...) split
-        # slots while a request still runs `S_live` of them -- the surplus workgroups exit at once, and the second launch
-        # goes (TP=8 shard 256 x 4 k at 2 live splits: 107 us with the stage-2 launch, 101 with 8 slots and none).
+        S_cap = S
+        # the in-kernel stage 2 (merge_counters) wants the partial rows of a head in chunks of 8: round the slots up while
+        # the partials fit its bound -- the surplus workgroups exit at once, and the second launch goes
+        if self._merge_counters is not None and S % 8:
+            S8 = (S + 7) // 8 * 8
+            if bs * self.num_head * S8 * self.v_head_dim * 4 <= (4 << 20):
+                S = S8
+        if use_graph_bufs:
+            num_kv_splits = self._graph["num_kv_splits"][:bs]
+            n = bs * self.num_head * S
+            attn_logits = self._graph["native_logits"][: n * self.v_head_dim].view(bs, self.num_head, S, self.v_head_dim)
+            attn_lse = self._graph["native_lse"][:n].view(bs, self.num_head, S)
+        else:
+            num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+            attn_logits, attn_lse = self._scratch(bs, S)
+        ops.get_num_kv_splits_balanced(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S_cap, wg_target,
+                                       min_tokens_per_split=min_tokens)
+        return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S,
+                               request_order=self._request_order(fb, bs, use_graph_bufs))
+
+    def _graph_split_slots(self, bs: int) -> int:
+        """Split slots of a graph-replayed dense decode step: enough for a small batch to fill the chip, and at least 8
+        so that a long request in a large batch can still be cut (the counts themselves are refilled on the device
+        before every replay; a request with one split costs nothing, see direct_single)."""
+        group = max(1, self.num_head // self.num_kv_head)
+        blocks = max(1, bs * self.num_kv_head * ((group + 15) // 16))
+        S = max(8, min(self.native_split_cap, -(-2 * self.device_core_count // blocks)))
+        if self._merge_counters is not None and S % 8 and bs * self.num_head * ((S + 7) // 8 * 8) * self.v_head_dim * 4 <= (4 << 20):
+            S = (S + 7) // 8 * 8
+        return S
+
+    def _decode_metadata_uniform(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool, kv_indptr, kv_indices,
+                                 wg_target: int, min_tokens: int) -> ForwardMetadata:
+        """MLA pools: the same split count for every request (fewer for short ones), S from the batch size alone -- the
+        MLA kernels have no direct single-split output, and two workgroups per CU is their optimum (config-5 shape:
+        256 workgroups 157 us, 512 workgroups 134 us)."""
+        S = ops.native_max_kv_splits(bs, self.num_head, self.num_kv_head, wg_target, self.native_split_cap)
+        if S <= 1:
+            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1)
         S_live = S
         if self._merge_counters is not None and S % 8:
             S8 = (S + 7) // 8 * 8
@@ -624,6 +663,8 @@ class HipRadixAttnBackend:
         group = max(1, self.num_head // self.num_kv_head)
         rows = (2 * self.device_core_count // (self.num_kv_head * ((group + 15) // 16)) + max_bs + 1) * self.num_head
         rows = max(rows, (1 << 20) // self.v_head_dim + 8)  # split slots rounded up to 8 while the partials fit 4 MiB
+        if not self._is_mla_pool:  # the length-aware schedule's slots: _graph_split_slots(bs) per request
+            rows = max(rows, max(b * self._graph_split_slots(b) for b in range(1, max_bs + 1)) * self.num_head)
         self._graph["native_logits"] = torch.zeros(rows * self.v_head_dim, dtype=torch.float32, device=dev)
         self._graph["native_lse"] = torch.zeros(rows, dtype=torch.float32, device=dev)
         if self.decode_index_mode == "indices":

@@ -61,6 +61,9 @@ struct DecodeArgs {
   const uint16_t* v_new;
   int64_t kn_stride_t, kn_stride_h, vn_stride_t, vn_stride_h;
   const int32_t* order;  // launch order of the requests (a permutation of 0..bs-1, longest first), or NULL
+  // a request with ONE kv split writes its final output from stage 1 and stage 2 leaves it alone (MFMA kernel, no
+  // extra partials): a length-aware schedule then costs the unsplit majority of a batch nothing
+  int32_t direct_single;
 };
 
 // Grok temperature factor of a request (decode_attention.py:156-160): the single query sits at seq_len-1
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
   const SeqInfo si = seq_info<IdxT>(a, b);
   const IdxT* idx = reinterpret_cast<const IdxT*>(si.idx);
   const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
-  const bool single = (a.max_kv_splits == 1);
+  const bool single = (a.max_kv_splits == 1) || (a.direct_single && splits == 1);
   const int gq = qb * 16 + r;            // q head inside the GQA group handled by this lane
   const bool q_valid = gq < a.group;
   const int h = kvh * a.group + gq;      // global q head
@@ -654,6 +657,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const DecodeArgs a, i
   int32_t kv_begin;
   const int32_t seq_len = attended_len(a, b, kv_begin);
   const int32_t splits = a.num_kv_splits ? a.num_kv_splits[b] : 1;
+  if (a.direct_single && splits == 1) return;  // stage 1 wrote this request's final output
   // live splits are a prefix: split s covers [per s, min(per (s+1), seq_len))
   const int32_t per = ((seq_len + splits - 1) / splits + kMinBlockKV - 1) / kMinBlockKV * kMinBlockKV;
   int32_t live = per > 0 ? (seq_len + per - 1) / per : 0;
@@ -699,6 +703,7 @@ __global__ __launch_bounds__(128) void decode_merge_scalar_kernel(const DecodeAr
   int32_t kv_begin;
   const int32_t seq_len = attended_len(a, b, kv_begin);
   const int32_t splits = a.num_kv_splits ? a.num_kv_splits[b] : 1;
+  if (a.direct_single && splits == 1) return;  // stage 1 wrote this request's final output
   const int64_t row0 = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits;
   for (int d = threadIdx.x; d < dv; d += 128) {
     float e_sum = 0.f, e_max = -INFINITY, acc = 0.f;
@@ -924,6 +929,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   // fused store of the new token: one q block per kv head (one workgroup touches the row), a 16-bit pool, the whole
   // request attended in one pass of the MFMA kernel, 16-byte chunks
   a.order = p->request_order;
+  a.direct_single = (mfma_ok && !mla && a.num_extra == 0 && max_splits > 1 && p->stages == 0) ? 1 : 0;
   a.k_new = a.v_new = nullptr;
   if (p->k_new || p->v_new) {
     RX_REQUIRE(p->k_new && p->v_new, "rx_decode_attn: k_new and v_new come together");

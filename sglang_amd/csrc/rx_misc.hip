@@ -766,6 +766,51 @@ int rx_num_kv_splits_native(const void* seq_lens, int seq_lens_is_i64, int bs, i
   return check_launch("rx_num_kv_splits_native");
 }
 
+namespace rx {
+// one block: the batch's token total, then every request's count
+__global__ __launch_bounds__(1024) void num_kv_splits_balanced_kernel(const void* __restrict__ seq_lens, int is64, int bs,
+                                                                      int wg_per_request, int wg_target, int cap,
+                                                                      int min_tokens, int32_t* __restrict__ out) {
+  __shared__ unsigned long long part[16];
+  __shared__ unsigned long long total_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  unsigned long long acc = 0;
+  for (int i = tid; i < bs; i += 1024) acc += static_cast<unsigned long long>(max<int64_t>(load_idx(seq_lens, i, is64), 0));
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+  if (lane == 0) part[wid] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    total_s = t;
+  }
+  __syncthreads();
+  // tokens one workgroup should carry so that wg_target workgroups share the batch evenly
+  const unsigned long long work = total_s * static_cast<unsigned long long>(wg_per_request);
+  const int64_t even = static_cast<int64_t>((work + wg_target - 1) / wg_target);
+  const int64_t tstar = max<int64_t>(min_tokens, even);
+  for (int i = tid; i < bs; i += 1024) {
+    const int64_t len = max<int64_t>(load_idx(seq_lens, i, is64), 0);
+    int64_t n = 1;
+    if (2 * len > 3 * tstar) n = min<int64_t>(cap, (len + tstar - 1) / tstar);  // only what is well above an even share
+    out[i] = static_cast<int32_t>(max<int64_t>(n, 1));
+  }
+}
+}  // namespace rx
+
+int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int wg_target,
+                              int max_kv_splits, int min_tokens_per_split, int32_t* out, void* stream) {
+  RX_REQUIRE(bs >= 0, "rx_num_kv_splits_balanced: bs < 0");
+  if (bs == 0) return RX_OK;
+  RX_REQUIRE(seq_lens && out, "rx_num_kv_splits_balanced: null pointer");
+  RX_REQUIRE(wg_per_request > 0 && wg_target > 0 && max_kv_splits > 0 && min_tokens_per_split > 0,
+             "rx_num_kv_splits_balanced: bad sizes");
+  hipLaunchKernelGGL(rx::num_kv_splits_balanced_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), seq_lens,
+                     seq_lens_is_i64, bs, wg_per_request, wg_target, max_kv_splits, min_tokens_per_split, out);
+  return check_launch("rx_num_kv_splits_balanced");
+}
+
 int rx_alloc_extend(const int64_t* prefix_lens, const int64_t* seq_lens, const int64_t* last_loc,
                     const int64_t* free_pages, int64_t* out_indices, int bs, int page_size,
                     void* stream) {

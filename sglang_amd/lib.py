@@ -108,6 +108,7 @@ PROTOTYPES = {
     "rx_shared_prefix_plan": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_int32, c_int32,
                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rx_num_kv_splits_native": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rx_num_kv_splits_balanced": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rx_merge_state": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rx_get_mla_kv": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p,
                               c_void_p, c_int, c_int64, c_void_p, c_void_p]),

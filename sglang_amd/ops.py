@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import lib as _L
@@ -208,6 +209,31 @@ def get_num_kv_splits_native(num_kv_splits: torch.Tensor, seq_lens: torch.Tensor
                                            num_kv_head * ((group + 15) // 16), device_core_count, max_kv_splits,
                                            min_tokens_per_split, _ptr(num_kv_splits), _stream(seq_lens))
     _L.check(st, "rx_num_kv_splits_native")
+
+
+def balanced_kv_splits_host(lens, num_head: int, num_kv_head: int, max_kv_splits: int, wg_target: int,
+                            min_tokens_per_split: int = 128) -> np.ndarray:
+    """Host mirror of rx_num_kv_splits_balanced (include/radix_hip.h) on the CPU copy of the lengths: what the eager
+    metadata path uses to size the split slots (the device kernel clamps to them, so a mismatch is harmless)."""
+    lens = np.maximum(np.asarray(lens, dtype=np.int64), 0)
+    group = max(1, num_head // num_kv_head)
+    wgpr = num_kv_head * ((group + 15) // 16)
+    even = -(-int(lens.sum()) * wgpr // wg_target)
+    tstar = max(int(min_tokens_per_split), even)
+    n = np.where(2 * lens > 3 * tstar, np.minimum(max_kv_splits, -(-lens // tstar)), 1)
+    return np.maximum(n, 1).astype(np.int32)
+
+
+def get_num_kv_splits_balanced(num_kv_splits: torch.Tensor, seq_lens: torch.Tensor, num_head: int, num_kv_head: int,
+                               max_kv_splits: int, wg_target: int, min_tokens_per_split: int = 128) -> None:
+    _require_cuda(num_kv_splits, seq_lens)
+    if num_kv_splits.dtype != torch.int32:
+        raise TypeError("num_kv_splits must be int32")
+    group = max(1, num_head // num_kv_head)
+    st = _L.load().rx_num_kv_splits_balanced(_ptr(seq_lens), _is64(seq_lens, "seq_lens"), seq_lens.shape[0],
+                                             num_kv_head * ((group + 15) // 16), int(wg_target), int(max_kv_splits),
+                                             int(min_tokens_per_split), _ptr(num_kv_splits), _stream(seq_lens))
+    _L.check(st, "rx_num_kv_splits_balanced")
 
 
 # --------------------------------------------------------------------------------------

@@ -551,6 +551,54 @@ def test_native_split_schedule_values():
     assert ops.native_max_kv_splits(1, 128, 1, 256, 32) == 32      # MLA: 8 q-blocks of 16 heads
 
 
+def test_balanced_split_schedule_kernel_matches_its_host_mirror_and_heterogeneous_batch_decodes():
+    """rx_num_kv_splits_balanced (the length-aware native schedule): device counts == ops.balanced_kv_splits_host on
+    uniform, outlier and ragged batches; a uniform batch is not split at all, an outlier is; then a heterogeneous batch
+    (one long request among short ones) through the backend against the oracle."""
+    from sglang_amd import ops
+    from sglang_amd.forward_batch import ForwardBatch
+
+    rng = np.random.default_rng(5)
+    for lens, hq, hkv in ([[4096] * 256, 32, 8], [[32768] + [1024] * 63, 32, 8], [[8192] * 4 + [512] * 124, 32, 8],
+                          [rng.integers(0, 6000, size=96).tolist(), 32, 8], [[4096] * 256, 4, 1], [[32768], 32, 8],
+                          [[0, 5, 70000], 8, 8]):
+        lt = torch.tensor(lens, dtype=torch.int64, device=DEV)
+        for mt in (128, 1024):
+            out = torch.zeros(len(lens), dtype=torch.int32, device=DEV)
+            ops.get_num_kv_splits_balanced(out, lt, hq, hkv, 32, 512, mt)
+            want = ops.balanced_kv_splits_host(lens, hq, hkv, 32, 512, mt)
+            assert out.tolist() == want.tolist(), (lens[:4], hq, hkv, mt)
+    assert ops.balanced_kv_splits_host([4096] * 256, 32, 8, 32, 512, 1024).max() == 1          # the headline batch: one pass
+    out = ops.balanced_kv_splits_host([32768] + [1024] * 63, 32, 8, 32, 512, 1024)
+    assert out[0] >= 16 and out[1:].max() == 1                                                  # only the outlier is cut
+    assert ops.balanced_kv_splits_host([4096] * 256, 4, 1, 32, 512, 1024).max() == 2            # TP=8 shard: two per CU
+
+    ps, hq, hkv, d = 16, 8, 2, 128
+    hs = _Harness(ps, hq, hkv, d, torch.bfloat16, "shuffled_pages", "paged", max_ctx=4200, max_reqs=40)
+    lens = [4000] + [64, 33, 17, 200, 129] * 6 + [1]
+    bs = len(lens)
+    rows = hs.r2t.alloc(bs)
+    hs.fill_prefix(rows, [n - 1 for n in lens[:-1]] + [0])
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    seq = torch.tensor(lens, dtype=torch.int64)
+    last = torch.tensor([int(hs.r2t.req_to_token[r, n - 2]) if n > 1 else -1 for r, n in zip(rows, lens)], dtype=torch.int64,
+                        device=DEV)
+    loc = hs.alloc.alloc_decode(seq.to(DEV), seq, last)
+    hs.r2t.req_to_token[rpi, torch.tensor([n - 1 for n in lens], device=DEV)] = loc.to(torch.int32)
+    q, k, v = hs.rand(bs, hq * d), hs.rand(bs, hkv * d), hs.rand(bs, hkv * d)
+    fb = ForwardBatch.for_decode(rpi, seq.to(DEV), loc, seq)
+    hs.backend.init_forward_metadata(fb)
+    md = hs.backend.forward_metadata
+    # a tiny batch (64 head blocks on 256 CUs): the long request takes every slot, a 200-token one two, the rest one
+    assert md.num_kv_splits is not None and int(md.num_kv_splits[0]) >= 16 and int(md.num_kv_splits[1:].max()) <= 2
+    o = hs.layer(q, k, v, fb, hs.backend)
+    kb, vb = hs.pool.get_kv_buffer(0)
+    args = (_bits(hs.r2t.req_to_token), np.array(rows), np.array(lens), d ** -0.5)
+    want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, d)), _bits(kb), _bits(vb), *args)
+    absw = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, d)), _bits(kb), parity.abs_values(_bits(vb)), *args)
+    parity.check_out(o.view(bs, hq, d).float().cpu().numpy(), want, torch.bfloat16, "heterogeneous batch", absw=absw)
+
+
 def test_short_extend_over_long_prefix_takes_split_kv_path():
     """A small batch of short extends over long cached prefixes (a follow-up turn on a long conversation): the
     backend cuts the prefix into chunks (ops.VerifySplitKV with the causal rule) -- same result as the oracle."""

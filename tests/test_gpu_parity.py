@@ -184,6 +184,11 @@ def _run_decode(ops, c, mode, dtype_t):
         lse = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
         ops.decode_attention_fwd(q, kb, vb, o, kv_indptr, _t(c["kv_indices"]), al, lse,
                                  _t(c["nsplit"]), S, float(c["sm_scale"]), 1.0, 1.0, logit_cap=cap)
+        # the stage-1 partials for inspection: a request with ONE split writes its output straight from stage 1 in the
+        # two-stage call (no partial row), so they come from an explicit stage-1-only call
+        al.zero_(); lse.zero_()
+        ops.decode_attention_fwd(q, kb, vb, torch.empty_like(o), kv_indptr, _t(c["kv_indices"]), al, lse,
+                                 _t(c["nsplit"]), S, float(c["sm_scale"]), 1.0, 1.0, logit_cap=cap, stages=1)
         return o, al, lse
     ops.decode_attention_fwd(q, kb, vb, o, kv_indptr, _t(c["kv_indices"]).to(torch.int32), None, None,
                              None, 1, float(c["sm_scale"]), 1.0, 1.0, logit_cap=cap)
