@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 6
+#define RX_ABI_VERSION 7
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -231,6 +231,11 @@ typedef struct rx_decode_params {
    * requests (e.g. argsort of the lengths, descending: the last round of workgroups of a ragged batch is then its short
    * requests).  Results do not depend on it.  NULL: request b is block b. */
   const int32_t* request_order;
+  /* Optional (0 = bs * max_kv_splits): an upper estimate of the (request, split) pairs that really write a partial.
+   * With the length-aware schedule most requests of a large batch have ONE split and write none (direct output), so
+   * the 4-MiB bound of the in-kernel stage 2 is taken on this count instead of on the split slots.  A performance
+   * hint only: results do not depend on it. */
+  int32_t partial_pairs_hint;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);

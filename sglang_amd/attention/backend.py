@@ -58,6 +58,8 @@ class ForwardMetadata:
     window_kv_offsets: Optional[torch.Tensor] = None
     # decode: launch order of the requests (longest first) for batches that take more than one round of workgroups
     request_order: Optional[torch.Tensor] = None
+    # decode, length-aware schedule: upper estimate of the (request, split) pairs that write a partial
+    partial_pairs_hint: int = 0
 
 
 def host_num_kv_splits(seq_lens: np.ndarray, num_head: int, num_kv_head: int, max_kv_splits: int,
@@ -385,8 +387,12 @@ class HipRadixAttnBackend:
             attn_logits, attn_lse = self._scratch(bs, S)
         ops.get_num_kv_splits_balanced(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S_cap, wg_target,
                                        min_tokens_per_split=min_tokens)
+        # split requests share ~wg_target workgroups: (request, split) pairs with a partial <= that / blocks per request,
+        # with slack for rounding up -- what the in-kernel stage 2's size bound should look at, not bs * slots
+        wgpr = self.num_kv_head * ((group + 15) // 16)
+        pairs = min(bs * S, 2 * wg_target // wgpr + 8)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S,
-                               request_order=self._request_order(fb, bs, use_graph_bufs))
+                               request_order=self._request_order(fb, bs, use_graph_bufs), partial_pairs_hint=pairs)
 
     def _graph_split_slots(self, bs: int) -> int:
         """Split slots of a graph-replayed dense decode step: enough for a small batch to fill the chip, and at least 8
@@ -788,14 +794,14 @@ class HipRadixAttnBackend:
                                 kv_indices=md.kv_indices, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
                                 attn_lse=md.attn_lse, merge_counters=self._merge_counters,
-                                request_order=md.request_order)
+                                request_order=md.request_order, partial_pairs_hint=md.partial_pairs_hint)
             else:
                 ln.set_metadata(self._md_version, q3.shape[0], req_to_token=self.req_to_token,
                                 req_pool_indices=forward_batch.req_pool_indices,
                                 seq_lens=forward_batch.seq_lens, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
                                 attn_lse=md.attn_lse, merge_counters=self._merge_counters,
-                                request_order=md.request_order)
+                                request_order=md.request_order, partial_pairs_hint=md.partial_pairs_hint)
         if sinks is not None and sinks.dtype != torch.float32:
             sinks = sinks.float()
         if fuse:

@@ -924,7 +924,13 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
                                // the partials take device-scope (write-through) stores in this form: a win while they
                                // are small (bs 1 x 32 k: 39 -> 36 us per layer, 16 x 4 k: 56 -> 53), a loss once they
                                // are many MB (MLA 64 x 16 heads x 8 splits = 17 MB: 67.6 -> 69.5 us)
-                               static_cast<int64_t>(p->bs) * p->num_q_heads * max_splits * dv * 4 <= (4ll << 20);
+                               // (partial_pairs_hint: how many (request, split) pairs really write a partial, when
+                               // the caller's schedule knows better than bs * max_kv_splits)
+                               static_cast<int64_t>(p->partial_pairs_hint > 0
+                                                        ? min(static_cast<int64_t>(p->partial_pairs_hint),
+                                                              static_cast<int64_t>(p->bs) * max_splits)
+                                                        : static_cast<int64_t>(p->bs) * max_splits) *
+                                       p->num_q_heads * dv * 4 <= (4ll << 20);
   a.merge_counters = merge_in_kernel ? p->merge_counters : nullptr;
   // fused store of the new token: one q block per kv head (one workgroup touches the row), a 16-bit pool, the whole
   // request attended in one pass of the MFMA kernel, 16-byte chunks

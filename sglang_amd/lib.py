@@ -16,7 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
-RX_ABI_VERSION = 6  # include/radix_hip.h
+RX_ABI_VERSION = 7  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -55,7 +55,7 @@ class RxDecodeParams(C.Structure):
         ("stages", c_int32), ("merge_counters", c_void_p),
         ("k_new", c_void_p), ("v_new", c_void_p),
         ("k_new_stride_t", c_int64), ("k_new_stride_h", c_int64), ("v_new_stride_t", c_int64), ("v_new_stride_h", c_int64),
-        ("request_order", c_void_p),
+        ("request_order", c_void_p), ("partial_pairs_hint", c_int32),
     ]
 
 

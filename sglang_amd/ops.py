@@ -472,9 +472,11 @@ class DecodeLauncher:
 
     def set_metadata(self, version, bs, *, kv_indptr=None, kv_indices=None, req_to_token=None,
                      req_pool_indices=None, seq_lens=None, num_kv_splits=None, max_kv_splits=1,
-                     attn_logits=None, attn_lse=None, merge_counters=None, request_order=None):
+                     attn_logits=None, attn_lse=None, merge_counters=None, request_order=None,
+                     partial_pairs_hint: int = 0):
         p = self.p
         p.bs = bs
+        p.partial_pairs_hint = int(partial_pairs_hint)
         p.merge_counters = _merge_counters_ptr(merge_counters, bs, p.num_q_heads)
         p.request_order = _request_order_ptr(request_order, bs)
         if kv_indices is not None:
