@@ -350,8 +350,6 @@ class HipRadixAttnBackend:
         group = max(1, self.num_head // self.num_kv_head)
         blocks = bs * self.num_kv_head * ((group + 15) // 16)
         wg_target = self.device_core_count * 2
-        if self._is_mla_pool:
-            return self._decode_metadata_uniform(fb, bs, use_graph_bufs, kv_indptr, kv_indices, wg_target, 128)
         # Dense kernel: the LENGTH-AWARE schedule (rx_num_kv_splits_balanced).  Two workgroups per CU in total is where
         # the kernel is fastest (one per CU is one wave per SIMD: TP=8 shard 256 x 4 k 113 -> 106 us per layer at 2
         # splits; 16 x 4 k 57 -> 55; 8 x 8 k 56 -> 51; beyond that every split only costs), and a request takes
@@ -360,7 +358,7 @@ class HipRadixAttnBackend:
         # is cut ~20 ways instead of being the kernel's tail (516 -> 139 us per layer).  Requests with one split write
         # their output straight from stage 1 (rx_decode_params: direct_single).  In the 2-4 split regime a split under
         # ~1 k tokens is all prologue (32 x 1 k: 31 us at 1 split, 33 at 2): t* has a 1 k floor there, 128 for tiny batches.
-        min_tokens = 1024 if 2 * blocks >= self.device_core_count else 128
+        min_tokens = 1024 if (2 * blocks >= self.device_core_count and not self._is_mla_pool) else 128
         cap = self.native_split_cap
         if not use_graph_bufs and fb.seq_lens_cpu is not None:
             S = int(ops.balanced_kv_splits_host(fb.seq_lens_cpu.numpy()[:bs], self.num_head, self.num_kv_head, cap,
@@ -404,31 +402,6 @@ class HipRadixAttnBackend:
         if self._merge_counters is not None and S % 8 and bs * self.num_head * ((S + 7) // 8 * 8) * self.v_head_dim * 4 <= (4 << 20):
             S = (S + 7) // 8 * 8
         return S
-
-    def _decode_metadata_uniform(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool, kv_indptr, kv_indices,
-                                 wg_target: int, min_tokens: int) -> ForwardMetadata:
-        """MLA pools: the same split count for every request (fewer for short ones), S from the batch size alone -- the
-        MLA kernels have no direct single-split output, and two workgroups per CU is their optimum (config-5 shape:
-        256 workgroups 157 us, 512 workgroups 134 us)."""
-        S = ops.native_max_kv_splits(bs, self.num_head, self.num_kv_head, wg_target, self.native_split_cap)
-        if S <= 1:
-            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1)
-        S_live = S
-        if self._merge_counters is not None and S % 8:
-            S8 = (S + 7) // 8 * 8
-            if bs * self.num_head * S8 * self.v_head_dim * 4 <= (4 << 20):  # the library's bound for that form
-                S = S8
-        if use_graph_bufs:
-            num_kv_splits = self._graph["num_kv_splits"][:bs]
-            n = bs * self.num_head * S
-            attn_logits = self._graph["native_logits"][: n * self.v_head_dim].view(bs, self.num_head, S, self.v_head_dim)
-            attn_lse = self._graph["native_lse"][:n].view(bs, self.num_head, S)
-        else:
-            num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
-            attn_logits, attn_lse = self._scratch(bs, S)
-        ops.get_num_kv_splits_native(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S_live, wg_target,
-                                     min_tokens_per_split=min_tokens)
-        return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S)
 
     # ------------------------------------------------------------------ decode context parallel
     def _decode_metadata_dcp(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool) -> ForwardMetadata:
@@ -669,8 +642,8 @@ class HipRadixAttnBackend:
         group = max(1, self.num_head // self.num_kv_head)
         rows = (2 * self.device_core_count // (self.num_kv_head * ((group + 15) // 16)) + max_bs + 1) * self.num_head
         rows = max(rows, (1 << 20) // self.v_head_dim + 8)  # split slots rounded up to 8 while the partials fit 4 MiB
-        if not self._is_mla_pool:  # the length-aware schedule's slots: _graph_split_slots(bs) per request
-            rows = max(rows, max(b * self._graph_split_slots(b) for b in range(1, max_bs + 1)) * self.num_head)
+        # the length-aware schedule's slots: _graph_split_slots(bs) per request
+        rows = max(rows, max(b * self._graph_split_slots(b) for b in range(1, max_bs + 1)) * self.num_head)
         self._graph["native_logits"] = torch.zeros(rows * self.v_head_dim, dtype=torch.float32, device=dev)
         self._graph["native_lse"] = torch.zeros(rows, dtype=torch.float32, device=dev)
         if self.decode_index_mode == "indices":

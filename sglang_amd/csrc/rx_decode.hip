@@ -797,12 +797,12 @@ static int dispatch_decode(const DecodeArgs& a, int dk, int dv, bool idx64, bool
                 : launch_decode<T, int32_t, false>(a, dk, dv, s);
 }
 
-int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, hipStream_t s);  // rx_decode_mla.hip
+int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, int direct_single, hipStream_t s);  // rx_decode_mla.hip
 
 template <typename T>
 static int run_mla(const rx_decode_params* p, const DecodeArgs& a, hipStream_t s) {
   if (a.stages != 2) {
-    const int rc = launch_decode_mla(p, a.merge_counters, s);
+    const int rc = launch_decode_mla(p, a.merge_counters, a.direct_single, s);
     if (rc != RX_OK) return rc;
   }
   if (a.max_kv_splits > 1 && a.stages != 1 && !a.merge_counters)
@@ -935,7 +935,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   // fused store of the new token: one q block per kv head (one workgroup touches the row), a 16-bit pool, the whole
   // request attended in one pass of the MFMA kernel, 16-byte chunks
   a.order = p->request_order;
-  a.direct_single = (mfma_ok && !mla && a.num_extra == 0 && max_splits > 1 && p->stages == 0) ? 1 : 0;
+  a.direct_single = ((mfma_ok || mla) && a.num_extra == 0 && max_splits > 1 && p->stages == 0) ? 1 : 0;
   a.k_new = a.v_new = nullptr;
   if (p->k_new || p->v_new) {
     RX_REQUIRE(p->k_new && p->v_new, "rx_decode_attn: k_new and v_new come together");

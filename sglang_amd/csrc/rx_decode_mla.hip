@@ -48,6 +48,7 @@ struct MlaArgs {
   const float* sinks;
   int32_t xai_len;
   int32_t* merge_counters;  // in-kernel stage 2 (rx_common.h split_arrive_is_last), or NULL
+  int32_t direct_single;    // a request with one kv split writes its final output from stage 1 (see rx_decode.hip)
 };
 
 #ifndef RX_MLA_STAMP
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
     idx = reinterpret_cast<const IdxT*>(a.req_to_token + req * a.req_row_stride);
   }
   const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
-  const bool single = (a.max_kv_splits == 1);
+  const bool single = (a.max_kv_splits == 1) || (a.direct_single && splits == 1);
   const int h = qb * 16 + r;
   const bool q_valid = h < a.hq;
   if (!single && a.merge_counters && seq_len == 0) {  // nobody will arrive: stage 2's zero-split result, by split 0
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
     idx = reinterpret_cast<const IdxT*>(a.req_to_token + req * a.req_row_stride);
   }
   const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
-  const bool single = (a.max_kv_splits == 1);
+  const bool single = (a.max_kv_splits == 1) || (a.direct_single && splits == 1);
   const int h = qb * 16 + r;
   const bool q_valid = h < a.hq;
   if (!single && a.merge_counters && seq_len == 0) {  // nobody will arrive: stage 2's zero-split result, by split 0
@@ -811,9 +812,10 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
 namespace rx {
 // called from rx_decode_attn (rx_decode.hip) when head_dim == 576 and v_head_dim == 512, Hkv == 1
 // and V aliases K's first 512 columns
-int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, hipStream_t s) {
+int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, int direct_single, hipStream_t s) {
   MlaArgs a;
   a.merge_counters = merge_counters;
+  a.direct_single = direct_single;
   a.q = (const uint16_t*)p->q;
   a.o = (uint16_t*)p->o;
   a.q_stride_t = p->q_stride_t;
