@@ -696,6 +696,82 @@ def mla_decode_bench(dev):
     return res
 
 
+def hetero_decode_bench(dev):
+    """A batch with an outlier -- 64 requests, one of 32 k tokens and 63 of 1 k (Llama-3-8B heads, page-16 shuffled pages,
+    HND pool): per-layer decode time with one pass per request, with the reference's split formula at its default cap
+    (get_num_kv_splits_triton, 8) and with the length-aware native schedule (rx_num_kv_splits_balanced).  Ten calls
+    captured in a HIP graph each."""
+    from sglang_amd import ops
+
+    HQ, HKV, D, PS = 32, 8, 128, 16
+    lens = [32768] + [1024] * 63
+    bs, ctx = len(lens), max(lens)
+    pages = [(n + PS - 1) // PS for n in lens]
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(np.arange(1, sum(pages) + 1))
+    r2t = np.zeros((bs + 1, ctx + PS), dtype=np.int32)
+    pi = 0
+    for i, n in enumerate(lens):
+        r2t[i + 1, :n] = (perm[pi: pi + pages[i], None] * PS + np.arange(PS)[None]).reshape(-1)[:n]
+        pi += pages[i]
+    g = torch.Generator(device=dev).manual_seed(7)
+    kb = torch.randn(sum(pages) + 1, HKV, PS, D, device=dev, generator=g).to(torch.bfloat16)
+    vb = torch.randn(sum(pages) + 1, HKV, PS, D, device=dev, generator=g).to(torch.bfloat16)
+    lay = ops.kv_layout_hnd(kb, vb)
+    q = torch.randn(bs, HQ, D, device=dev, generator=g).to(torch.bfloat16)
+    o = torch.empty_like(q)
+    r2td = torch.from_numpy(r2t).to(dev)
+    rpi = torch.arange(1, bs + 1, device=dev)
+    lens_d = torch.tensor(lens, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(bs * HQ, dtype=torch.int32, device=dev)
+    order = torch.argsort(lens_d, descending=True).to(torch.int32)
+
+    def timed(ns, S):
+        al = torch.empty(bs, HQ, max(S, 1), D, dtype=torch.float32, device=dev)
+        lse = torch.empty(bs, HQ, max(S, 1), dtype=torch.float32, device=dev)
+
+        def run():
+            if S == 1:
+                ops.decode_attention_fwd_paged(q, kb, vb, o, r2td, rpi, lens_d, None, None, None, 1, D ** -0.5, page_size=PS,
+                                               kv_layout=lay, request_order=order)
+            else:
+                ops.decode_attention_fwd_paged(q, kb, vb, o, r2td, rpi, lens_d, al, lse, ns, S, D ** -0.5, page_size=PS,
+                                               kv_layout=lay, merge_counters=cnt, request_order=order)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(10):
+                run()
+        gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        gr.replay()
+        gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 20 * 1e3
+
+    k3 = torch.zeros(bs, dtype=torch.int32, device=dev)
+    ops.get_num_kv_splits(k3, lens_d.int(), HQ, HKV, 8, 256)
+    S_bal = int(ops.balanced_kv_splits_host(lens, HQ, HKV, 32, 512, 128).max())
+    S_slots = (S_bal + 7) // 8 * 8
+    bal = torch.zeros(bs, dtype=torch.int32, device=dev)
+    ops.get_num_kv_splits_balanced(bal, lens_d, HQ, HKV, S_bal, 512, 128)
+    byt = sum(lens) * HKV * D * 2 * 2
+    res = {"workload": "64 requests: one of 32768 tokens, 63 of 1024 (Hq 32 / Hkv 8 / D 128 bf16, page 16 shuffled, one layer)",
+           "kv_bytes": byt}
+    for name, ns, S in (("one_pass_per_request", None, 1), ("reference_formula_max8", k3, 8), ("length_aware_native", bal, S_slots)):
+        us = timed(ns, S)
+        res[name] = {"us_per_layer": us, "TBps": byt / us / 1e6, "splits_of_the_long_request": 1 if ns is None else int(ns[0])}
+    return res
+
+
 def rccl_capturable(dev) -> bool:
     """Can this stack capture an RCCL all-reduce into a HIP graph and replay it?  Probed on a tiny tensor before
     the step is captured, so that a refusal costs nothing but the eager fallback."""
@@ -956,6 +1032,10 @@ def main():
             out["mla_decode"] = mla_decode_bench(dev)
         except Exception as e:
             out["mla_decode"] = {"error": str(e)}
+        try:
+            out["heterogeneous_decode"] = hetero_decode_bench(dev)
+        except Exception as e:
+            out["heterogeneous_decode"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
