@@ -531,6 +531,8 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
 int launch_extend32(const rx_extend_params* p, hipStream_t s);  // rx_extend32.hip (D = 128)
 bool extend_nd_supports(int dk, int dv);                          // rx_extend_nd.hip (256/256, 192/128, ...)
 int launch_extend_nd(const rx_extend_params* p, hipStream_t s);
+bool extend_mla_supports(const rx_extend_params* p);               // rx_extend_mla.hip (576 / 512 over one latent kv head)
+int launch_extend_mla(const rx_extend_params* p, hipStream_t s);
 
 }  // namespace rx
 
@@ -602,6 +604,10 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
       const int rc = launch_extend_nd(p, static_cast<hipStream_t>(stream));
       return rc != RX_OK ? rc : check_launch("rx_extend_attn");
     }
+  }
+  if (extend_mla_supports(p) && !getenv("RX_EXTEND_NO_MLA")) {
+    const int rc = launch_extend_mla(p, static_cast<hipStream_t>(stream));
+    return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }
   ExtendArgs a;
   a.q = (const uint16_t*)p->q;

@@ -1,0 +1,477 @@
+// K7 for the latent (absorbed) MLA shape: q [T, Hq, 576] against ONE kv head whose rows are the 576-wide latent
+// (kv_lora_rank 512 + rope 64) and whose values are the first 512 columns of the same row.  This is what an extend
+// over a cached prefix runs at for DeepSeek-class models on the reference's backend (forward_absorb_core ->
+// attn_mqa -> TritonAttnBackend.forward_extend, triton_backend.py:1290-1437; kernel extend_attention.py:241-661
+// with Lq = 576, Lv = 512): every radix-cache hit of an MLA model takes it.  Until round 2 it ran the scalar
+// generic kernel here.
+//
+// Shape of the problem on gfx950: 2176 FLOP per (query row, token) and only 8 + 8 softmax values per lane per
+// 32 x 32 block, so VALU does not matter; what does is registers and LDS bandwidth.  With 16x16x32 MFMAs an O^T
+// block of 16 rows x 512 columns is 128 accumulator registers, and every K / V^T fragment read from LDS (1 KiB
+// per wave instruction) feeds as many MFMAs as the wave has 16-row blocks.  Two blocks per wave (32 rows) make
+// LDS time equal to matrix time; that needs 256 accumulator registers, i.e. ONE wave per SIMD with the
+// accumulators in the AGPR half (pinned by inline-asm MFMAs: hipcc left alone moves them through v_accvgpr
+// copies), the Q fragments (144 registers) in the VGPR half and NO staging registers:
+//   * a workgroup is 4 waves x 32 query rows; rows are (token, q head) pairs, row = token * Hq + head -- all
+//     heads share the one kv head, so packing costs nothing and a request with 8 new tokens still fills a block;
+//   * tiles of 32 tokens go global -> LDS by `global_load_lds_dwordx4` (lane l's 16 bytes land at base + 16 l, the
+//     per-lane source address does the row gather), into rows padded to 73 chunks: K fragments by ds_read_b128,
+//     V^T fragments by ds_read_b64_tr_b16 FROM THE SAME IMAGE when v aliases k[..., :512] (the pool always does:
+//     get_value_buffer is a view of the latent buffer, memory_pool.py MLATokenToKVPool), from a second image
+//     otherwise (the new tokens' k is a fresh concat in the reference's model code);
+//   * two stages: tile t + 1 flies while tile t is computed; `s_waitcnt vmcnt(0)` + one barrier per tile;
+//   * slot ids of 1024 tokens at a time sit in LDS, so the loop has no compiler-visible VMEM;
+//   * the running max moves only when a tile's max exceeds it by 2^8 (exact algebra, see rx_extend32.hip): the
+//     256-register rescale runs on the first tile and almost never again.
+// Causal / non-causal, skip_prefix / skip_extend, LSE, k / v scales.  Windows, caps, sinks, masks: generic kernel.
+#include <type_traits>
+
+#include "rx_common.h"
+
+namespace rx {
+
+constexpr int kXDk = 576, kXDv = 512, kXTT = 32;
+constexpr int kXCpr = kXDk * 2 / 16 + 1;        // 73 chunks per LDS row (72 data + 1 pad)
+constexpr int kXRow = kXCpr * 16;               // 1168 B: 9 (odd) chunks past a multiple of 256
+constexpr int kXPieces = 37;                    // 1-KiB DMA pieces per image (36.5 carry rows)
+constexpr int kXImg = kXPieces * 1024;
+// SHARED (v aliases k[..., :512] for the pool AND the new tokens): a ring of four one-image stages, three tiles in
+// flight.  Otherwise two stages of K image | V image, one tile in flight.  Both: the Q fragments of the last k-step
+// parked in LDS (8 VGPRs the wave does not have: with them in registers hipcc spills a Q fragment and reloads it every
+// tile, and a scratch reload waits for every DMA issued before it), slot ids of 256 tokens at a time.
+template <bool SHARED>
+struct XGeom {
+  static constexpr int NSTAGE = SHARED ? 4 : 2;
+  static constexpr int AHEAD = NSTAGE - 1;
+  static constexpr int STAGE = SHARED ? kXImg : 2 * kXImg;
+  static constexpr int SLOTBLK = 256;                   // tokens whose slot ids are staged in LDS at a time
+  static constexpr int NQL = 1;                         // k-steps of Q kept in LDS
+  static constexpr int SLOTS_AT = NSTAGE * STAGE;
+  static constexpr int QTAIL_AT = SLOTS_AT + 2 * SLOTBLK * 4;
+  static constexpr int LDS = QTAIL_AT + 4 * 2 * NQL * 1024;  // 161792 B of 163840
+};
+constexpr int kXRows = 128;                     // query rows per workgroup
+constexpr float kXSlack = 8.0f;                 // log2 units a row's max may run ahead of its reference
+
+struct ExtMlaArgs {
+  const uint16_t* q;
+  const uint16_t* k_ext;
+  const uint16_t* v_ext;
+  uint16_t* o;
+  int64_t q_stride_t, q_stride_h, k_stride_t, v_stride_t, o_stride_t, o_stride_h;
+  const uint16_t* k_buf;
+  const uint16_t* v_buf;
+  int32_t page_shift;  // log2(page_size), or -1 for a pool that is linear in the slot
+  int64_t k_page_stride, k_tok_stride, v_page_stride, v_tok_stride;
+  const void* qo_indptr;
+  int32_t qo64;
+  const int32_t* kv_indptr;
+  const void* kv_indices;
+  int32_t idx64;
+  float* lse;
+  int64_t lse_stride_t, lse_stride_h;
+  int32_t bs, hq, mblocks, xcd_bind;
+  float sm_scale, k_scale, v_scale;
+  int32_t causal, skip_prefix, skip_extend;
+  int32_t share_p, share_e;  // v aliases k[..., :512] in the pool / in the new tokens
+};
+
+// 64 slot ids (4 B per lane) global -> LDS
+__device__ __forceinline__ void x_dma4(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void x_dma16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+// LDS by 32-bit address: the loop keeps no 64-bit generic pointers alive
+typedef __attribute__((address_space(3))) const u32x4* x_lds_u32x4;
+typedef __attribute__((address_space(3))) const int32_t* x_lds_i32;
+__device__ __forceinline__ u32x4 x_lds_read16(uint32_t addr) { return *reinterpret_cast<x_lds_u32x4>(addr); }
+__device__ __forceinline__ int32_t x_lds_read4(uint32_t addr) { return *reinterpret_cast<x_lds_i32>(addr); }
+
+template <typename T>
+__device__ __forceinline__ void x_pv_mfma(u32x4 a, u32x4 b, f32x4& c) {
+  if constexpr (std::is_same_v<T, BF16>) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// hipcc's hazard recogniser does not see the asm MFMAs: the wait states between an XDL write of the accumulators
+// and a VALU read of them (and back) are supplied here
+// (asm volatile statements keep their order: the accumulators are re-defined AFTER the nops, so no read of one can
+// be scheduled in front of them)
+template <int N>
+__device__ __forceinline__ void x_settle(f32x4 (&o)[N]) {
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+a"(o[i]));
+}
+// element offset of a KV slot; page_shift < 0: the pool is linear in the slot (page_stride == page_size * tok_stride)
+__device__ __forceinline__ int64_t x_slot_off(int32_t slot, int32_t shift, int64_t page_stride, int64_t tok_stride) {
+  if (shift < 0) return mul_u32(slot, tok_stride);
+  return mul_u32(slot >> shift, page_stride) + mul_u32(slot & ((1 << shift) - 1), tok_stride);
+}
+
+template <typename T, bool SHARED>
+__global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) {
+  using vec8 = typename T::vec8;
+  using G = XGeom<SHARED>;
+  constexpr int KS = kXDk / 32, NB = kXDv / 16;
+  constexpr int KSR = KS - G::NQL;  // k-steps of Q held in registers
+  constexpr int kXSlotBlock = G::SLOTBLK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [stages][2 slot blocks][Q tails of the 4 waves]
+  const uint32_t smem_u = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  // all workgroups of a request read the same rows: with 8 or more requests a request is bound to one XCD's L2
+  int req, mb;
+  if (a.xcd_bind) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    req = (j / a.mblocks) * 8 + xcd;
+    mb = a.mblocks - 1 - j % a.mblocks;  // heaviest query blocks first under the causal mask
+    if (req >= a.bs) return;
+  } else {
+    req = blockIdx.x / a.mblocks;
+    mb = a.mblocks - 1 - blockIdx.x % a.mblocks;
+  }
+  const int64_t qo0 = load_idx(a.qo_indptr, req, a.qo64);
+  const int32_t E = static_cast<int32_t>(load_idx(a.qo_indptr, req + 1, a.qo64) - qo0);
+  const int32_t kv0 = a.kv_indptr[req];
+  const int32_t P = a.kv_indptr[req + 1] - kv0;
+  const int32_t R = E * a.hq;            // query rows of the request: row = token * Hq + head
+  const int32_t row0 = mb * kXRows;
+  if (row0 >= R) return;                 // workgroup-uniform
+  const int32_t rbase = row0 + 32 * w;
+  const bool active = rbase < R;         // inactive waves still issue their DMA pieces and hit the barriers
+
+  // ---- Q^T fragments: block c, lane (r, g) holds Q[row rbase + 16 c + r][32 s + 8 g .. +8]
+  vec8 qf[2][KSR];
+  const uint32_t qtail = smem_u + G::QTAIL_AT + (w * 2 * G::NQL * 64 + lane) * 16;  // this wave's; fragment j at + j KiB
+  int32_t tok[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int m = rbase + 16 * c + r;
+    const bool ok = m < R;
+    tok[c] = (ok ? m : 0) / a.hq;
+    const int32_t hd = (ok ? m : 0) - tok[c] * a.hq;
+    const uint16_t* qp = a.q + (qo0 + tok[c]) * a.q_stride_t + hd * a.q_stride_h + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
+      if (s < KSR) qf[c][s] = __builtin_bit_cast(vec8, raw);
+      else *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(qtail + (c * G::NQL + s - KSR) * 1024) = raw;
+    }
+    if (!ok) tok[c] = E;  // sees everything the wave's limit allows; never stored
+  }
+
+  const int32_t p_len = a.skip_prefix ? 0 : P;
+  const int32_t tok_hi_wg = (min(R, row0 + kXRows) - 1) / a.hq + 1;  // one past the last token of the workgroup's rows
+  const int32_t tok_hi_w = active ? (min(R, rbase + 32) - 1) / a.hq + 1 : 0;
+  const int32_t n_end_wg = a.skip_extend ? 0 : (a.causal ? tok_hi_wg : E);
+  const int32_t n_end_w = a.skip_extend ? 0 : (a.causal ? tok_hi_w : E);
+  const int nt1 = (p_len + kXTT - 1) / kXTT;
+  const int nt2 = (n_end_wg + kXTT - 1) / kXTT;
+  const int nt = nt1 + nt2;
+
+  // ---- slot ids of 256 prefix tokens at a time -> LDS, by DMA as well: the loop has no compiler-visible VMEM, so no
+  // wait of hipcc's drains the ring (the new tokens' rows are consecutive: no ids needed)
+  const char* const idx_b = reinterpret_cast<const char*>(a.kv_indices);
+  const int idx_sh = a.idx64 ? 3 : 2;  // int64 ids: the low dword
+  auto stage_slots = [&](int blk) {
+    const int v = blk * kXSlotBlock + tid;
+    const int64_t e = kv0 + max(min(v, p_len - 1), 0);
+    x_dma4(idx_b + (e << idx_sh), __builtin_amdgcn_readfirstlane(smem_u + G::SLOTS_AT + ((blk & 1) * kXSlotBlock + 64 * w) * 4));
+  };
+  if (nt1 > 0) stage_slots(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q and the slot ids have landed; nothing of ours is in flight
+  __syncthreads();
+
+  // ---- DMA of tile t into stage t & 1: wave w issues pieces w, w + 4, ... of the K image (and of the V image when
+  // the tile's v rows are their own tensor).  Piece p, lane l = chunk 64 p + l of the padded image.
+  const char* const kbuf_b = reinterpret_cast<const char*>(a.k_buf);
+  const char* const vbuf_b = reinterpret_cast<const char*>(a.v_buf);
+  const char* const kext_b = reinterpret_cast<const char*>(a.k_ext + qo0 * a.k_stride_t);
+  const char* const vext_b = reinterpret_cast<const char*>(a.v_ext + qo0 * a.v_stride_t);
+  constexpr int NP = (kXPieces + 3) / 4;  // 10
+  // per-kind constants of the address arithmetic, branch-free: offset = (slot >> shift) * pstride + (slot & mask) * tstride
+  // (a pool that is linear in the slot and the new tokens' tensors: shift 31, i.e. page 0 and the whole slot as "in-page")
+  const int32_t sh_p = a.page_shift < 0 ? 31 : a.page_shift;
+  auto dma_tile = [&](int t, int ring) {  // tile t -> stage ring % NSTAGE
+    const bool pre = t < nt1;
+    const uint32_t sl = smem_u + G::SLOTS_AT + 4 * (((t * kXTT / kXSlotBlock) & 1) * kXSlotBlock + (t * kXTT) % kXSlotBlock);
+    const bool own_v = !SHARED && (pre ? !a.share_p : !a.share_e);
+    const uint32_t kimg = smem_u + (ring % G::NSTAGE) * G::STAGE;
+    const char* const kb = pre ? kbuf_b : kext_b;
+    const char* const vb = pre ? vbuf_b : vext_b;
+    const int32_t sh = pre ? sh_p : 31;
+    const uint32_t mask = sh == 31 ? 0x7fffffffu : (1u << sh) - 1u;
+    const uint32_t k_ps = pre ? static_cast<uint32_t>(a.k_page_stride) : 0u, k_ts = static_cast<uint32_t>(pre ? a.k_tok_stride : a.k_stride_t);
+    const uint32_t v_ps = pre ? static_cast<uint32_t>(a.v_page_stride) : 0u, v_ts = static_cast<uint32_t>(pre ? a.v_tok_stride : a.v_stride_t);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // opaque: keeps the per-piece chunk arithmetic inside the loop (hoisted, it costs 30 registers)
+    int32_t slot[NP];             // all LDS reads first: one round trip, not ten
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int row = min((w + 4 * i) * 64 + ln, kXTT * kXCpr - 1) / kXCpr;
+      slot[i] = pre ? x_lds_read4(sl + 4 * row) : max(min((t - nt1) * kXTT + row, n_end_wg - 1), 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (w + 4 * i < kXPieces) {  // wave-uniform
+        const int c = min((w + 4 * i) * 64 + ln, kXTT * kXCpr - 1);
+        const int col = min(c - (c / kXCpr) * kXCpr, kXCpr - 2);  // the pad chunk re-reads the row's last data chunk
+        const uint32_t pg = static_cast<uint32_t>(slot[i]) >> sh, in = static_cast<uint32_t>(slot[i]) & mask;
+        const uint64_t ko = static_cast<uint64_t>(pg) * k_ps + static_cast<uint64_t>(in) * k_ts;
+        x_dma16(kb + 2 * ko + 16 * col, __builtin_amdgcn_readfirstlane(kimg + (w + 4 * i) * 1024));
+        if (own_v) {
+          const uint64_t vo = static_cast<uint64_t>(pg) * v_ps + static_cast<uint64_t>(in) * v_ts;
+          x_dma16(vb + 2 * vo + 16 * min(col, kXDv * 2 / 16 - 1), __builtin_amdgcn_readfirstlane(kimg + kXImg + (w + 4 * i) * 1024));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one piece's address arithmetic at a time (interleaved, ten of them cost 60 registers)
+    }
+  };
+  if (nt > 0) {
+#pragma unroll
+    for (int i = 0; i < G::AHEAD; ++i) dma_tile(min(i, nt - 1), i);
+  }
+
+  f32x4 oacc[2][NB];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    m_run[c] = -INFINITY;
+    l_run[c] = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) oacc[c][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int qd = r >> 2, pp = r & 3;
+  const int vrow0 = 4 * g + qd;  // V^T read: row inside a 16-token block
+  const uint32_t k_lane = r * kXRow + g * 16;
+  const uint32_t v_lane = vrow0 * kXRow + 8 * (pp & 1) + (pp >> 1) * 16;
+
+  for (int t = 0; t < nt; ++t) {
+    // this wave's pieces of tile t have landed: everything but the two youngest tiles' 2 x 9 (wave 0: 2 x 10, so it
+    // waits for two pieces more than it must; a slot-block DMA in between only makes the wait stricter)
+    if constexpr (!SHARED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    __syncthreads();                                   // everybody's have; everybody is done with tile t - 1
+    constexpr int TPB = kXSlotBlock / kXTT;  // tiles per slot block
+    if (t % TPB == 0 && (t / TPB + 1) * kXSlotBlock < nt1 * kXTT) stage_slots(t / TPB + 1);
+    if constexpr (SHARED) dma_tile(min(t + G::AHEAD, nt - 1), t + G::AHEAD);  // past the end: the last tile again (uniform counts)
+    else if (t + 1 < nt) dma_tile(t + 1, t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool prefix = t < nt1;
+    const int n0 = (prefix ? t : t - nt1) * kXTT;
+    const int32_t lim = prefix ? p_len : n_end_w;
+    if (!active || n0 >= lim) continue;  // nothing visible to this wave (wave-uniform)
+    const uint32_t kt = smem_u + (t % G::NSTAGE) * G::STAGE;
+    const uint32_t vt = kt + ((SHARED || (prefix ? a.share_p : a.share_e)) ? 0 : kXImg);
+
+    // ---- S^T = K Q^T: tokens 16 bb + 4 g + i of the tile on the lane, query row r of block c
+    f32x4 sacc[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) sacc[c][0] = sacc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      // a single wave per SIMD: the K fragments are read PD steps ahead of the MFMAs that use them
+      constexpr int PD = 4;
+      const uint32_t krow = kt + k_lane;
+      auto kfrag = [&](int i) { return x_lds_read16(krow + (i / KS) * 16 * kXRow + (i % KS) * 64); };
+      u32x4 qt[2][G::NQL];  // parked Q fragments: temporaries of this phase only
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < G::NQL; ++j) qt[c][j] = x_lds_read16(qtail + (c * G::NQL + j) * 1024);
+      u32x4 kf[PD];
+#pragma unroll
+      for (int i = 0; i < PD; ++i) kf[i] = kfrag(i);
+#pragma unroll
+      for (int i = 0; i < 2 * KS; ++i) {
+        const vec8 ka = __builtin_bit_cast(vec8, kf[i % PD]);
+        if (i + PD < 2 * KS) kf[i % PD] = kfrag(i + PD);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const vec8 qb = (i % KS < KSR) ? qf[c][i % KS < KSR ? i % KS : 0] : __builtin_bit_cast(vec8, qt[c][i % KS < KSR ? 0 : i % KS - KSR]);
+          sacc[c][i / KS] = T::mfma(ka, qb, sacc[c][i / KS]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t rp0 = vt + v_lane;
+    const uint32_t rp1 = rp0 + 16 * kXRow;
+    const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
+    const float c2 = cs * kLog2e;
+    u32x4 pf[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float sv[8];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
+      {
+        // the mask is one compare + select per score on every tile (16 per lane against 136 MFMAs): no second body
+        const int32_t vis = (prefix ? p_len : min(n_end_w, a.causal ? tok[c] + 1 : E)) - n0 - 4 * g;  // visible: index < vis
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i < vis) ? sv[bb * 4 + i] : -INFINITY;
+      }
+      float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+      mt = quad_row_max(mt) * c2;  // c2 > 0: max commutes with the scale
+      const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
+      const float m_new = (mt_fixed > m_run[c] + kXSlack) ? mt_fixed : m_run[c];
+      const float alpha = fast_exp2(m_run[c] - m_new);
+      m_run[c] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+        psum += sv[j];
+      }
+      l_run[c] = l_run[c] * alpha + psum;
+      if (prefix && a.v_scale != 1.0f) {  // per-tensor V scale of the cached part (wave-uniform branch)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[j] *= a.v_scale;
+      }
+      pf[c][0] = pack2<T>(sv[0], sv[1]);
+      pf[c][1] = pack2<T>(sv[2], sv[3]);
+      pf[c][2] = pack2<T>(sv[4], sv[5]);
+      pf[c][3] = pack2<T>(sv[6], sv[7]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // first tile; then only on a 2^8 jump
+        x_settle(oacc[c]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          oacc[c][nb] *= alpha;
+          asm volatile("" : "+a"(oacc[c][nb]));  // back in its AGPRs before the next one is read
+        }
+        x_settle(oacc[c]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O^T += V^T P^T (the first V^T reads are issued here, not above the softmax: 16 registers the wave does not have)
+    constexpr int NPRE = 4;  // V^T fragments read ahead of their MFMA
+    u32x2 vlo[NPRE], vhi[NPRE];
+#pragma unroll
+    for (int nb = 0; nb < NPRE; ++nb) {
+      vlo[nb] = T::ds_read_tr((const void*)(uintptr_t)(rp0 + nb * 32));
+      vhi[nb] = T::ds_read_tr((const void*)(uintptr_t)(rp1 + nb * 32));
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const u32x2 lo = vlo[nb % NPRE], hi = vhi[nb % NPRE];
+      if (nb + NPRE < NB) {
+        vlo[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp0 + (nb + NPRE) * 32));
+        vhi[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp1 + (nb + NPRE) * 32));
+      }
+      const u32x4 av = u32x4{lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+      for (int c = 0; c < 2; ++c) x_pv_mfma<T>(av, pf[c], oacc[c][nb]);
+    }
+  }
+
+  if (!active) return;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    x_settle(oacc[c]);
+    float l = l_run[c];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const int m = rbase + 16 * c + r;
+    if (m >= R) continue;
+    const float inv = 1.0f / l;
+    const int32_t tk = m / a.hq, hd = m - tk * a.hq;
+    uint16_t* op = a.o + (qo0 + tk) * a.o_stride_t + hd * a.o_stride_h + 4 * g;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      u32x2 pk;
+      pk[0] = pack2<T>(oacc[c][nb][0] * inv, oacc[c][nb][1] * inv);
+      pk[1] = pack2<T>(oacc[c][nb][2] * inv, oacc[c][nb][3] * inv);
+      *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
+      __builtin_amdgcn_sched_barrier(0);  // one accumulator at a time through the VGPR half
+    }
+    if (a.lse && g == 0) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run[c] * kLn2 + __logf(l);
+  }
+}
+
+bool extend_mla_supports(const rx_extend_params* p) {
+  if (p->head_dim != kXDk || p->v_head_dim != kXDv || p->num_kv_heads != 1 || p->kv.kv_fp8) return false;
+  if (p->sliding_window_size > 0 || p->logit_cap > 0.f || p->sinks || p->custom_mask || p->xai_temperature_len > 0 ||
+      p->unified_prefix_lens || p->q_pack > 1)
+    return false;
+  const int64_t all = p->q_stride_t | p->q_stride_h | p->k_stride_t | p->v_stride_t | p->kv.k_page_stride |
+                      p->kv.k_tok_stride | p->kv.v_page_stride | p->kv.v_tok_stride;
+  if (all % 8 != 0 || (p->o_stride_t | p->o_stride_h) % 4 != 0) return false;
+  if ((((uintptr_t)p->q | (uintptr_t)p->k_extend | (uintptr_t)p->v_extend | (uintptr_t)p->kv.k_buf | (uintptr_t)p->kv.v_buf) & 15) != 0 ||
+      ((uintptr_t)p->o & 7) != 0)
+    return false;
+  const bool linear = p->kv.page_size == 1 || (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
+                                               p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
+  if (!linear && (p->kv.page_size & (p->kv.page_size - 1)) != 0) return false;
+  return static_cast<int64_t>(p->max_extend_len) * p->num_q_heads < (1ll << 30);
+}
+
+int launch_extend_mla(const rx_extend_params* p, hipStream_t s) {
+  ExtMlaArgs a;
+  a.q = (const uint16_t*)p->q;
+  a.k_ext = (const uint16_t*)p->k_extend;
+  a.v_ext = (const uint16_t*)p->v_extend;
+  a.o = (uint16_t*)p->o;
+  a.q_stride_t = p->q_stride_t; a.q_stride_h = p->q_stride_h;
+  a.k_stride_t = p->k_stride_t; a.v_stride_t = p->v_stride_t;
+  a.o_stride_t = p->o_stride_t; a.o_stride_h = p->o_stride_h;
+  a.k_buf = (const uint16_t*)p->kv.k_buf;
+  a.v_buf = (const uint16_t*)p->kv.v_buf;
+  const bool linear = p->kv.page_size == 1 || (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
+                                               p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
+  a.page_shift = linear ? -1 : __builtin_ctz(p->kv.page_size);
+  a.k_page_stride = p->kv.k_page_stride; a.k_tok_stride = p->kv.k_tok_stride;
+  a.v_page_stride = p->kv.v_page_stride; a.v_tok_stride = p->kv.v_tok_stride;
+  a.qo_indptr = p->qo_indptr; a.qo64 = p->qo_indptr_is_i64;
+  a.kv_indptr = p->kv_indptr; a.kv_indices = p->kv_indices; a.idx64 = p->kv_indices_is_i64;
+  a.lse = p->lse; a.lse_stride_t = p->lse_stride_t; a.lse_stride_h = p->lse_stride_h;
+  a.bs = p->bs; a.hq = p->num_q_heads;
+  a.mblocks = static_cast<int32_t>((static_cast<int64_t>(p->max_extend_len) * p->num_q_heads + kXRows - 1) / kXRows);
+  a.xcd_bind = p->bs >= 8;
+  a.sm_scale = p->sm_scale; a.k_scale = p->k_scale; a.v_scale = p->v_scale;
+  a.causal = p->is_causal; a.skip_prefix = p->skip_prefix; a.skip_extend = p->skip_extend;
+  a.share_p = p->kv.v_buf == p->kv.k_buf && p->kv.v_page_stride == p->kv.k_page_stride && p->kv.v_tok_stride == p->kv.k_tok_stride;
+  a.share_e = p->v_extend == p->k_extend && p->v_stride_t == p->k_stride_t;
+  const unsigned groups = a.xcd_bind ? static_cast<unsigned>((a.bs + 7) / 8) * 8 : static_cast<unsigned>(a.bs);
+  const unsigned grid = groups * a.mblocks;
+  const bool bf = p->dtype == RX_BF16;
+  static const bool no_shared = getenv("RX_XMLA_NO_SHARED") != nullptr;  // dev: the two-image form for aliased tensors too
+  const bool shared = a.share_p && a.share_e && !no_shared;
+  if (no_shared) a.share_p = a.share_e = 0;
+#define RX_XMLA(TT, SH)                                                                                              \
+  do {                                                                                                               \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_mla_kernel<TT, SH>),     \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, XGeom<SH>::LDS);  \
+    (void)attr;                                                                                                      \
+    hipLaunchKernelGGL((extend_mla_kernel<TT, SH>), dim3(grid), dim3(256), XGeom<SH>::LDS, s, a);                    \
+  } while (0)
+  if (bf) {
+    if (shared) RX_XMLA(BF16, true);
+    else RX_XMLA(BF16, false);
+  } else {
+    if (shared) RX_XMLA(F16, true);
+    else RX_XMLA(F16, false);
+  }
+#undef RX_XMLA
+  return RX_OK;
+}
+
+}  // namespace rx

@@ -482,6 +482,83 @@ def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
         np.testing.assert_allclose(_np(lse), want_lse, atol=5e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("variant", ["aliased", "own_v", "own_v_new_tokens", "noncausal", "skip_prefix", "skip_extend",
+                                     "many_requests_int32", "paged_pool"])
+def test_extend_mla_latent_shape(ops, dtype, variant):
+    """rx::extend_mla_kernel (q 576 against one latent kv head, v = the first 512 columns: the absorbed-MLA extend of
+    triton_backend.py:1290-1437 / extend_attention.py:241-661 at Lq 576, Lv 512) vs the fp64 oracle.  Ragged batch:
+    zero / one-tile / slot-block-crossing prefixes (256-token id blocks, a ring of four tiles), extends from 1 token
+    (16 packed rows) to several workgroups, an empty request.  'aliased' is how the pool always looks (v_buffer a view
+    of the latent rows) with the new tokens' v a view of their k; the own_v variants give v tensors of their own (the
+    kernel's two-image form), with DIFFERENT values so that a kernel reading k for v would fail."""
+    rng = np.random.default_rng(576)
+    hq, dk, dv = 16, 576, 512
+    if variant == "many_requests_int32":   # >= 8 requests: requests bound to XCDs, a partial last group
+        pre = np.array([0, 16, 33, 290, 5, 64, 31, 32, 100, 7, 0], dtype=np.int32)
+        ext = np.array([1, 32, 5, 40, 9, 17, 0, 3, 64, 2, 8], dtype=np.int32)
+    else:
+        pre = np.array([0, 16, 33, 700, 5, 300], dtype=np.int32)
+        ext = np.array([1, 32, 50, 140, 0, 64], dtype=np.int32)
+    bs, T = len(pre), int(ext.sum())
+    total = int((pre + ext).sum())
+    ps = 16 if variant == "paged_pool" else 1
+    n_pages = (total + ps - 1) // ps + 3
+    pool = n_pages * ps
+    slots = rng.permutation(pool - ps)[:total] + ps
+    g = torch.Generator().manual_seed(11)
+    kb = (torch.randn(pool, 1, dk, generator=g) * 0.5).to(dtype)
+    own_pool_v = variant == "own_v"
+    vb = (torch.randn(pool, 1, dv, generator=g).to(dtype)) if own_pool_v else kb[..., :dv]
+    q = torch.randn(T, hq, dk, generator=g).to(dtype)
+    kv_indptr = np.concatenate([[0], np.cumsum(pre)]).astype(np.int32)
+    qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
+    kv_indices = np.empty(int(pre.sum()), dtype=np.int64)
+    ext_slots = np.empty(T, dtype=np.int64)
+    so = 0
+    for i in range(bs):
+        s_ = slots[so: so + pre[i] + ext[i]]; so += pre[i] + ext[i]
+        kv_indices[kv_indptr[i]: kv_indptr[i + 1]] = s_[: pre[i]]
+        ext_slots[qo[i]: qo[i + 1]] = s_[pre[i]:]
+    ke = kb[ext_slots].contiguous()
+    if variant in ("own_v", "own_v_new_tokens"):
+        ve = torch.randn(T, 1, dv, generator=g).to(dtype)
+    else:
+        ve = ke[..., :dv]
+    causal = variant != "noncausal"
+    okw = dict(skip_prefix=True) if variant == "skip_prefix" else dict(skip_extend=True) if variant == "skip_extend" else {}
+    sm = 1.0 / (128 + 64) ** 0.5
+    want, want_lse = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
+                                          is_causal=causal, sm_scale=sm, return_lse=True, **okw)
+    kbd = kb.to(DEV)
+    vbd = vb.to(DEV) if own_pool_v else kbd[..., :dv]
+    ked = ke.to(DEV)
+    ved = ve.to(DEV) if variant in ("own_v", "own_v_new_tokens") else ked[..., :dv]
+    lay = None
+    if variant == "paged_pool":    # [pages, 1, page, 576] with a padded page stride: page / offset addressing
+        big = torch.zeros(n_pages, ps * dk + 64, dtype=dtype, device=DEV)
+        big[:, : ps * dk] = kbd.view(n_pages, ps * dk)
+        kbd = big[:, : ps * dk].view(n_pages, 1, ps, dk)
+        vbd = kbd[..., :dv]
+        lay = ops.kv_layout_hnd(kbd, vbd)
+    o = torch.zeros(T, hq, dv, dtype=dtype, device=DEV)
+    lse = torch.zeros(T, hq, dtype=torch.float32, device=DEV)
+    idx_dt = torch.int32 if variant == "many_requests_int32" else torch.int64
+    ops.extend_attention_fwd(q.to(DEV), ked, ved, o, kbd, vbd, _t(qo), _t(kv_indptr), _t(kv_indices).to(idx_dt),
+                             None, causal, None, int(ext.max()), 1.0, 1.0, lse_extend=lse, sm_scale=sm,
+                             page_size=ps, kv_layout=lay, **okw)
+    absw = orc.extend_attention(_np(q), _np(ke), parity.abs_values(_np(ve)), _np(kb), parity.abs_values(_np(vb)), qo,
+                                kv_indptr, kv_indices, is_causal=causal, sm_scale=sm, **okw)
+    live = np.repeat(np.arange(bs), ext)
+    rows = np.ones(T, dtype=bool)
+    if variant == "skip_prefix":
+        pass
+    if variant == "skip_extend":   # requests without a prefix see nothing: the reference leaves 0 / -inf-like rows
+        rows = pre[live] > 0
+    parity.check_out(_np(o.float())[rows], want[rows], dtype, ("mla_extend", variant), absw=absw[rows])
+    np.testing.assert_allclose(_np(lse)[rows], want_lse[rows], atol=5e-3, rtol=2e-3)
+
+
 # ---------------------------------------------------------------------------- K10 / K11
 def test_move_kv_and_write_req_to_token(ops):
     rng = np.random.default_rng(0)
