@@ -612,6 +612,45 @@ def extend_head_dims(args, dev):
     return res
 
 
+def mla_extend_bench(dev):
+    """The absorbed-MLA extend over a cached prefix (what a radix-cache hit of a DeepSeek-class model runs on the
+    reference's backend: forward_absorb_core -> attn_mqa -> forward_extend at Lq 576 / Lv 512 over ONE latent kv head):
+    config-3's chunk shape on one TP=8 rank -- 32 requests x (3584 cached + 512 new tokens), 16 q heads, shuffled slots.
+    MFMA-bound: FLOPs = 2 (576 + 512) Hq sum_i (E_i P_i + E_i (E_i + 1) / 2).  'v_view_of_k' passes the new tokens'
+    v as a view of their k rows, 'v_own_tensor' as the reference's model code does (k is a fresh concat)."""
+    from sglang_amd import ops
+
+    bs, P, E, hq, dk, dv = 32, 3584, 512, 16, 576, 512
+    g = torch.Generator(device=dev).manual_seed(5)
+    pool = bs * (P + E) + 64
+    latent = (torch.randn(pool, 1, dk, device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    perm = (torch.randperm(pool - 1, device=dev, generator=g)[: bs * (P + E)] + 1).view(bs, P + E)
+    kv_indices = perm[:, :P].reshape(-1).contiguous()
+    kv_indptr = (torch.arange(bs + 1, device=dev, dtype=torch.int32) * P).contiguous()
+    qo = (torch.arange(bs + 1, device=dev, dtype=torch.int64) * E).contiguous()
+    q = torch.randn(bs * E, hq, dk, device=dev, generator=g).to(torch.bfloat16)
+    ke = latent[perm[:, P:].reshape(-1)].contiguous()
+    o = torch.empty(bs * E, hq, dv, device=dev, dtype=torch.bfloat16)
+    flops = 2.0 * (dk + dv) * hq * bs * (E * P + E * (E + 1) / 2)
+    res = {"workload": "absorbed-MLA extend, one TP=8 rank: 32 requests x (3584 cached + 512 new), 16 q heads, q 576 / v 512 "
+                       "over one latent kv head, bf16, shuffled slots", "flops_per_call": flops}
+    for name, ve in (("v_view_of_k", ke[..., :dv]), ("v_own_tensor", ke[..., :dv].contiguous())):
+        def call():
+            ops.extend_attention_fwd(q, ke, ve, o, latent, latent[..., :dv], qo, kv_indptr, kv_indices, None, True, None, E,
+                                     1.0, 1.0, sm_scale=192 ** -0.5)
+        call()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(5):
+            call()
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / 5
+        res[name] = {"ms": round(ms, 3), "tflops": round(flops / ms / 1e9, 1), "frac_of_mfma_peak": round(flops / ms / 1e9 / 2500.0, 3)}
+    return res
+
+
 def mla_decode_bench(dev):
     """configs[4]-shaped MLA decode (one TP=8 rank: 16 q heads, Hkv = 1, Dk 576 = 512 latent + 64 rope, Dv 512; bs 64,
     ctx 8192, page_size 64 pages in shuffled order), latent rows bf16 and fp8 e4m3: time of rx_decode_attn (MLA stage 1
@@ -993,6 +1032,7 @@ def main():
         try:
             out["extend"] = extend_bench(args, dev, world)
             out["extend"]["other_head_dims"] = extend_head_dims(args, dev)
+            out["extend"]["mla_latent"] = mla_extend_bench(dev)
         except Exception as e:
             out["extend"] = {"error": str(e)}
     if world > 1 and not args.no_extend:

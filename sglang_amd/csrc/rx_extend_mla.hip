@@ -30,6 +30,16 @@
 
 namespace rx {
 
+#ifndef RX_XMLA_DBG
+#define RX_XMLA_DBG 0  // dev: 1 = DMA and waits only, 2 = compute only (no DMA in the loop); results are wrong
+#endif
+#ifndef RX_XMLA_SPREAD
+#define RX_XMLA_SPREAD 1  // the DMA pieces of a tile are issued between the MFMAs of the whole iteration (0: all at its top; 2: inside the softmax, the phase without LDS reads)
+#endif
+#ifndef RX_XMLA_NSTAGE
+#define RX_XMLA_NSTAGE 4
+#endif
+
 constexpr int kXDk = 576, kXDv = 512, kXTT = 32;
 constexpr int kXCpr = kXDk * 2 / 16 + 1;        // 73 chunks per LDS row (72 data + 1 pad)
 constexpr int kXRow = kXCpr * 16;               // 1168 B: 9 (odd) chunks past a multiple of 256
@@ -41,7 +51,7 @@ constexpr int kXImg = kXPieces * 1024;
 // tile, and a scratch reload waits for every DMA issued before it), slot ids of 256 tokens at a time.
 template <bool SHARED>
 struct XGeom {
-  static constexpr int NSTAGE = SHARED ? 4 : 2;
+  static constexpr int NSTAGE = SHARED ? RX_XMLA_NSTAGE : 2;
   static constexpr int AHEAD = NSTAGE - 1;
   static constexpr int STAGE = SHARED ? kXImg : 2 * kXImg;
   static constexpr int SLOTBLK = 256;                   // tokens whose slot ids are staged in LDS at a time
@@ -77,19 +87,15 @@ struct ExtMlaArgs {
 };
 
 // 64 slot ids (4 B per lane) global -> LDS
+// M0 is set and NOT restored: a restore right behind the DMA waits until the DMA has consumed M0 and keeps costing the
+// wave 60-100 cycles per piece however far apart the pieces are (tools/probe/dma_issue.hip: forms 0 / 1).  hipcc uses
+// M0 for nothing else in this kernel (checked in the ISA: no m0 operand outside these statements; a kernel with
+// dynamically indexed register arrays or ds_gws would).
 __device__ __forceinline__ void x_dma4(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void x_dma16(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 // LDS by 32-bit address: the loop keeps no 64-bit generic pointers alive
@@ -118,6 +124,10 @@ __device__ __forceinline__ int64_t x_slot_off(int32_t slot, int32_t shift, int64
   if (shift < 0) return mul_u32(slot, tok_stride);
   return mul_u32(slot >> shift, page_stride) + mul_u32(slot & ((1 << shift) - 1), tok_stride);
 }
+
+#ifndef RX_XMLA_STAMP
+#define RX_XMLA_STAMP 0  // 1: diagnostic build, s_memtime phase stamps of wave 0 go to lse[8 * block ...] (tools/mla_extend_bench.py STAMPS=1)
+#endif
 
 template <typename T, bool SHARED>
 __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) {
@@ -158,21 +168,23 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   // ---- Q^T fragments: block c, lane (r, g) holds Q[row rbase + 16 c + r][32 s + 8 g .. +8]
   vec8 qf[2][KSR];
   const uint32_t qtail = smem_u + G::QTAIL_AT + (w * 2 * G::NQL * 64 + lane) * 16;  // this wave's; fragment j at + j KiB
-  int32_t tok[2];
+  // row -> token by a multiply-high (exact for rows < 2^32 / Hq, checked by the launcher): the causal mask then
+  // needs no per-lane token registers
+  const uint32_t hq_magic = static_cast<uint32_t>(0x100000000ull / static_cast<uint32_t>(a.hq)) + 1u;
+  auto row_tok = [&](int m) { return static_cast<int32_t>(__umulhi(static_cast<uint32_t>(m), hq_magic)); };
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int m = rbase + 16 * c + r;
     const bool ok = m < R;
-    tok[c] = (ok ? m : 0) / a.hq;
-    const int32_t hd = (ok ? m : 0) - tok[c] * a.hq;
-    const uint16_t* qp = a.q + (qo0 + tok[c]) * a.q_stride_t + hd * a.q_stride_h + 8 * g;
+    const int32_t tk = row_tok(ok ? m : 0);
+    const int32_t hd = (ok ? m : 0) - tk * a.hq;
+    const uint16_t* qp = a.q + (qo0 + tk) * a.q_stride_t + hd * a.q_stride_h + 8 * g;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
       if (s < KSR) qf[c][s] = __builtin_bit_cast(vec8, raw);
       else *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(qtail + (c * G::NQL + s - KSR) * 1024) = raw;
     }
-    if (!ok) tok[c] = E;  // sees everything the wave's limit allows; never stored
   }
 
   const int32_t p_len = a.skip_prefix ? 0 : P;
@@ -220,32 +232,93 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
     const uint32_t v_ps = pre ? static_cast<uint32_t>(a.v_page_stride) : 0u, v_ts = static_cast<uint32_t>(pre ? a.v_tok_stride : a.v_stride_t);
     int ln = lane;
     asm volatile("" : "+v"(ln));  // opaque: keeps the per-piece chunk arithmetic inside the loop (hoisted, it costs 30 registers)
-    int32_t slot[NP];             // all LDS reads first: one round trip, not ten
+    // piece w + 4 i, lane l = chunk 64 w + l + 256 i of the padded image: (row, col) step by (3, 37) mod 73 chunks per
+    // row -- three VALU per piece instead of a division
+    const int c0 = 64 * w + ln;  // < 256
+    int row = (c0 >= kXCpr) + (c0 >= 2 * kXCpr) + (c0 >= 3 * kXCpr);
+    int col = c0 - kXCpr * row;
+    int32_t slot[NP], col16[NP];  // all LDS reads first: one round trip, not ten
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int row = min((w + 4 * i) * 64 + ln, kXTT * kXCpr - 1) / kXCpr;
-      slot[i] = pre ? x_lds_read4(sl + 4 * row) : max(min((t - nt1) * kXTT + row, n_end_wg - 1), 0);
+      const bool past = row >= kXTT;                                    // the last piece's tail: repeats the last chunk
+      const int rw = past ? kXTT - 1 : row;
+      col16[i] = 16 * ((past || col == kXCpr - 1) ? kXCpr - 2 : col);  // the pad chunk re-reads the row's last data chunk
+      slot[i] = pre ? x_lds_read4(sl + 4 * rw) : max(min((t - nt1) * kXTT + rw, n_end_wg - 1), 0);
+      col += 256 % kXCpr;
+      row += 256 / kXCpr;
+      if (col >= kXCpr) {
+        col -= kXCpr;
+        row += 1;
+      }
     }
+    const bool paged = pre && sh != 31;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       if (w + 4 * i < kXPieces) {  // wave-uniform
-        const int c = min((w + 4 * i) * 64 + ln, kXTT * kXCpr - 1);
-        const int col = min(c - (c / kXCpr) * kXCpr, kXCpr - 2);  // the pad chunk re-reads the row's last data chunk
-        const uint32_t pg = static_cast<uint32_t>(slot[i]) >> sh, in = static_cast<uint32_t>(slot[i]) & mask;
-        const uint64_t ko = static_cast<uint64_t>(pg) * k_ps + static_cast<uint64_t>(in) * k_ts;
-        x_dma16(kb + 2 * ko + 16 * col, __builtin_amdgcn_readfirstlane(kimg + (w + 4 * i) * 1024));
+        const uint32_t in = static_cast<uint32_t>(slot[i]) & mask;
+        uint64_t ko = static_cast<uint64_t>(in) * (2 * k_ts) + static_cast<uint32_t>(col16[i]);
+        if (paged) ko += static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) >> sh) * (2 * k_ps);
+        x_dma16(kb + ko, __builtin_amdgcn_readfirstlane(kimg + (w + 4 * i) * 1024));
         if (own_v) {
-          const uint64_t vo = static_cast<uint64_t>(pg) * v_ps + static_cast<uint64_t>(in) * v_ts;
-          x_dma16(vb + 2 * vo + 16 * min(col, kXDv * 2 / 16 - 1), __builtin_amdgcn_readfirstlane(kimg + kXImg + (w + 4 * i) * 1024));
+          uint64_t vo = static_cast<uint64_t>(in) * (2 * v_ts) + static_cast<uint32_t>(min(col16[i], kXDv * 2 - 16));
+          if (paged) vo += static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) >> sh) * (2 * v_ps);
+          x_dma16(vb + vo, __builtin_amdgcn_readfirstlane(kimg + kXImg + (w + 4 * i) * 1024));
         }
       }
-      __builtin_amdgcn_sched_barrier(0);  // one piece's address arithmetic at a time (interleaved, ten of them cost 60 registers)
     }
   };
   if (nt > 0) {
 #pragma unroll
     for (int i = 0; i < G::AHEAD; ++i) dma_tile(min(i, nt - 1), i);
   }
+  // The LDS-DMA path takes in ~12 B per cycle and CU (a tile's 37 KB: ~3.2 k cycles -- MORE than its 2.2 k cycles of
+  // MFMA), and a wave that issues into the full queue stalls: ten pieces at the top of an iteration cost 2.9 k cycles
+  // in which the SIMD does nothing else.  The SHARED form therefore issues ONE piece every ~14 MFMAs: state carried
+  // between the issue points = the lane's (row, col) in the padded image and the NEXT piece's slot id (read from LDS
+  // one issue point ahead), the tile's constants are scalars.
+  struct {
+    uint32_t sl, img, mask, ts2, ps2;
+    int32_t sh, ext0;
+    const char* base;
+    bool pre, paged;
+  } pc;
+  int p_rc = 0;  // row * 128 + col
+  int32_t p_slot = 0;
+  auto piece_slot = [&]() {
+    const int rw = min(p_rc >> 7, kXTT - 1);
+    p_slot = pc.pre ? x_lds_read4(pc.sl + 4 * rw) : max(min(pc.ext0 + rw, n_end_wg - 1), 0);
+  };
+  auto piece_begin = [&](int t, int ring) {
+    pc.pre = t < nt1;
+    pc.sl = smem_u + G::SLOTS_AT + 4 * (((t * kXTT / kXSlotBlock) & 1) * kXSlotBlock + (t * kXTT) % kXSlotBlock);
+    pc.img = smem_u + (ring % G::NSTAGE) * G::STAGE;
+    pc.base = pc.pre ? kbuf_b : kext_b;
+    pc.sh = pc.pre ? sh_p : 31;
+    pc.mask = pc.sh == 31 ? 0x7fffffffu : (1u << pc.sh) - 1u;
+    pc.ts2 = 2u * static_cast<uint32_t>(pc.pre ? a.k_tok_stride : a.k_stride_t);
+    pc.ps2 = pc.pre ? 2u * static_cast<uint32_t>(a.k_page_stride) : 0u;
+    pc.paged = pc.pre && pc.sh != 31;
+    pc.ext0 = (t - nt1) * kXTT;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int c0 = 64 * w + ln;  // < 256
+    const int row0 = (c0 >= kXCpr) + (c0 >= 2 * kXCpr) + (c0 >= 3 * kXCpr);
+    p_rc = c0 + (128 - kXCpr) * row0;
+    piece_slot();
+  };
+  auto piece_issue = [&](int k) {  // piece w + 4 k of the tile piece_begin() named; then the next piece's (row, col, slot)
+    if (w + 4 * k < kXPieces) {   // wave-uniform
+      const int p_col = p_rc & 127;
+      const uint32_t col16 = 16u * ((p_rc >= kXTT * 128 || p_col == kXCpr - 1) ? kXCpr - 2 : p_col);
+      uint64_t ko = static_cast<uint64_t>(static_cast<uint32_t>(p_slot) & pc.mask) * pc.ts2 + col16;
+      if (pc.paged) ko += static_cast<uint64_t>(static_cast<uint32_t>(p_slot) >> pc.sh) * pc.ps2;
+      x_dma16(pc.base + ko, __builtin_amdgcn_readfirstlane(pc.img + (w + 4 * k) * 1024));
+    }
+    p_rc += 128 * (256 / kXCpr) + 256 % kXCpr;
+    if ((p_rc & 127) >= kXCpr) p_rc += 128 - kXCpr;
+    if (k + 1 < NP) piece_slot();
+  };
+  constexpr bool SPREAD = SHARED && RX_XMLA_SPREAD && RX_XMLA_DBG == 0;
 
   f32x4 oacc[2][NB];
   float m_run[2], l_run[2];
@@ -262,21 +335,49 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   const uint32_t k_lane = r * kXRow + g * 16;
   const uint32_t v_lane = vrow0 * kXRow + 8 * (pp & 1) + (pp >> 1) * 16;
 
+#if RX_XMLA_STAMP
+  uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
+#define X_STAMP(i)                                                 \
+  do {                                                             \
+    const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();  \
+    st_acc[i] += now_ - st_prev;                                   \
+    st_prev = now_;                                                \
+  } while (0)
+#else
+#define X_STAMP(i)
+#endif
   for (int t = 0; t < nt; ++t) {
     // this wave's pieces of tile t have landed: everything but the two youngest tiles' 2 x 9 (wave 0: 2 x 10, so it
     // waits for two pieces more than it must; a slot-block DMA in between only makes the wait stricter)
     if constexpr (!SHARED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (G::AHEAD == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (G::AHEAD == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                   // everybody's have; everybody is done with tile t - 1
+    X_STAMP(0);  // landing wait + barrier
     constexpr int TPB = kXSlotBlock / kXTT;  // tiles per slot block
     if (t % TPB == 0 && (t / TPB + 1) * kXSlotBlock < nt1 * kXTT) stage_slots(t / TPB + 1);
-    if constexpr (SHARED) dma_tile(min(t + G::AHEAD, nt - 1), t + G::AHEAD);  // past the end: the last tile again (uniform counts)
+#if RX_XMLA_DBG != 2
+    if constexpr (SPREAD) piece_begin(min(t + G::AHEAD, nt - 1), t + G::AHEAD);
+    else if constexpr (SHARED) dma_tile(min(t + G::AHEAD, nt - 1), t + G::AHEAD);  // past the end: the last tile again (uniform counts)
     else if (t + 1 < nt) dma_tile(t + 1, t + 1);
+#endif
     __builtin_amdgcn_sched_barrier(0);
+    X_STAMP(1);  // DMA issue
+#if RX_XMLA_DBG == 1
+    continue;
+#endif
     const bool prefix = t < nt1;
     const int n0 = (prefix ? t : t - nt1) * kXTT;
     const int32_t lim = prefix ? p_len : n_end_w;
-    if (!active || n0 >= lim) continue;  // nothing visible to this wave (wave-uniform)
+    if (!active || n0 >= lim) {  // nothing visible to this wave (wave-uniform)
+      if constexpr (SPREAD) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) piece_issue(k);
+      }
+      continue;
+    }
     const uint32_t kt = smem_u + (t % G::NSTAGE) * G::STAGE;
     const uint32_t vt = kt + ((SHARED || (prefix ? a.share_p : a.share_e)) ? 0 : kXImg);
 
@@ -301,6 +402,9 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       for (int i = 0; i < 2 * KS; ++i) {
         const vec8 ka = __builtin_bit_cast(vec8, kf[i % PD]);
         if (i + PD < 2 * KS) kf[i % PD] = kfrag(i + PD);
+        if constexpr (SPREAD) {
+          if (RX_XMLA_SPREAD == 1 && i % 9 == 3) piece_issue(i / 9);  // pieces 0 .. 3
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const vec8 qb = (i % KS < KSR) ? qf[c][i % KS < KSR ? i % KS : 0] : __builtin_bit_cast(vec8, qt[c][i % KS < KSR ? 0 : i % KS - KSR]);
@@ -309,6 +413,7 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    X_STAMP(2);  // QK^T
     const uint32_t rp0 = vt + v_lane;
     const uint32_t rp1 = rp0 + 16 * kXRow;
     const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
@@ -323,14 +428,27 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
         for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
       {
         // the mask is one compare + select per score on every tile (16 per lane against 136 MFMAs): no second body
-        const int32_t vis = (prefix ? p_len : min(n_end_w, a.causal ? tok[c] + 1 : E)) - n0 - 4 * g;  // visible: index < vis
+        int lnm = lane;
+        asm volatile("" : "+v"(lnm));  // (opaque: the row arithmetic stays inside the loop)
+        const int32_t tk1 = row_tok(rbase + 16 * c + (lnm & 15)) + 1;  // rows past the request's end: masked by n_end_w only, never stored
+        const int32_t vis = (prefix ? p_len : min(n_end_w, a.causal ? tk1 : E)) - n0 - 4 * (lnm >> 4);  // visible: index < vis
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
           for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i < vis) ? sv[bb * 4 + i] : -INFINITY;
       }
+#define XP(k_)                                    \
+  do {                                            \
+    if constexpr (SPREAD && RX_XMLA_SPREAD == 2) { \
+      __builtin_amdgcn_sched_barrier(0);          \
+      piece_issue(5 * c + (k_));                  \
+      __builtin_amdgcn_sched_barrier(0);          \
+    }                                             \
+  } while (0)
+      XP(0);
       float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
       mt = quad_row_max(mt) * c2;  // c2 > 0: max commutes with the scale
+      XP(1);
       const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
       const float m_new = (mt_fixed > m_run[c] + kXSlack) ? mt_fixed : m_run[c];
       const float alpha = fast_exp2(m_run[c] - m_new);
@@ -340,6 +458,8 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       for (int j = 0; j < 8; ++j) {
         sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
         psum += sv[j];
+        if (j == 2) XP(2);
+        if (j == 5) XP(3);
       }
       l_run[c] = l_run[c] * alpha + psum;
       if (prefix && a.v_scale != 1.0f) {  // per-tensor V scale of the cached part (wave-uniform branch)
@@ -350,6 +470,8 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       pf[c][1] = pack2<T>(sv[2], sv[3]);
       pf[c][2] = pack2<T>(sv[4], sv[5]);
       pf[c][3] = pack2<T>(sv[6], sv[7]);
+      if constexpr (SPREAD && RX_XMLA_SPREAD == 1) piece_issue(4 + c);  // pieces 4, 5
+      if constexpr (SPREAD && RX_XMLA_SPREAD == 2) XP(4);
       __builtin_amdgcn_sched_barrier(0);
       if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // first tile; then only on a 2^8 jump
         x_settle(oacc[c]);
@@ -362,6 +484,7 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    X_STAMP(3);  // softmax
     // ---- O^T += V^T P^T (the first V^T reads are issued here, not above the softmax: 16 registers the wave does not have)
     constexpr int NPRE = 4;  // V^T fragments read ahead of their MFMA
     u32x2 vlo[NPRE], vhi[NPRE];
@@ -377,11 +500,22 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
         vlo[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp0 + (nb + NPRE) * 32));
         vhi[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp1 + (nb + NPRE) * 32));
       }
+      if constexpr (SPREAD) {
+        if (RX_XMLA_SPREAD == 1 && nb % 8 == 3) piece_issue(6 + nb / 8);  // pieces 6 .. 9
+      }
       const u32x4 av = u32x4{lo[0], lo[1], hi[0], hi[1]};
 #pragma unroll
       for (int c = 0; c < 2; ++c) x_pv_mfma<T>(av, pf[c], oacc[c][nb]);
     }
+    X_STAMP(4);  // PV
   }
+#if RX_XMLA_STAMP
+  if (w == 0 && lane == 0 && a.lse) {
+    uint32_t* dbg = reinterpret_cast<uint32_t*>(a.lse) + 8 * blockIdx.x;
+    for (int i = 0; i < 5; ++i) dbg[i] = st_acc[i];
+    dbg[5] = nt;
+  }
+#endif
 
   if (!active) return;
 #pragma unroll
@@ -403,7 +537,7 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
       __builtin_amdgcn_sched_barrier(0);  // one accumulator at a time through the VGPR half
     }
-    if (a.lse && g == 0) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run[c] * kLn2 + __logf(l);
+    if (a.lse && g == 0 && !RX_XMLA_STAMP) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run[c] * kLn2 + __logf(l);
   }
 }
 
@@ -421,7 +555,7 @@ bool extend_mla_supports(const rx_extend_params* p) {
   const bool linear = p->kv.page_size == 1 || (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                                                p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
   if (!linear && (p->kv.page_size & (p->kv.page_size - 1)) != 0) return false;
-  return static_cast<int64_t>(p->max_extend_len) * p->num_q_heads < (1ll << 30);
+  return static_cast<int64_t>(p->max_extend_len + 1) * p->num_q_heads * p->num_q_heads < (1ll << 31);  // row -> token by multiply-high
 }
 
 int launch_extend_mla(const rx_extend_params* p, hipStream_t s) {

@@ -278,6 +278,71 @@ def test_mla_latent_pool_and_decode():
     parity.check(np.abs(got - want).max(), 1e-2, None)
 
 
+@pytest.mark.parametrize("own_v", [False, True], ids=["v_view_of_k", "v_own_tensor"])
+def test_mla_latent_radix_hit_extend(own_v):
+    """A radix-cache hit of an MLA model: cached latent prefix + new tokens through HipRadixAttnBackend.forward_extend
+    (absorbed form, q 576 / v 512 over ONE kv head: forward_absorb_core -> attn_mqa -> forward_extend,
+    triton_backend.py:1290-1437) -- rx::extend_mla_kernel.  The new tokens' v is either a view of their k rows or, as in
+    the reference's model code, a tensor of its own (k is a fresh concat of k_nope and k_pe there)."""
+    from sglang_amd.attention.backend import HipRadixAttnBackend
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+    from sglang_amd.mem_cache.memory_pool import MLATokenToKVPool, ReqToTokenPool
+
+    hq, rank, rope = 16, 512, 64
+    pre, ext = [70, 0, 300], [9, 40, 130]
+    bs = len(pre)
+    pool = MLATokenToKVPool(1024, 1, torch.bfloat16, rank, rope, 1, DEV)
+    r2t = ReqToTokenPool(4, 512, DEV)
+    g = torch.Generator().manual_seed(3)
+    perm = torch.randperm(1023, generator=g) + 1
+    rows = r2t.alloc(bs)
+    layer = RadixAttention(hq, rank + rope, (128 + 64) ** -0.5, 1, 0, v_head_dim=rank)
+    off = 0
+    new_loc = []
+    for r, p_, e_ in zip(rows, pre, ext):
+        slots = perm[off: off + p_ + e_].to(DEV); off += p_ + e_
+        r2t.req_to_token[r, : p_ + e_] = slots.int()
+        if p_:
+            pool.set_mla_kv_buffer(layer, slots[:p_], (torch.randn(p_, 1, rank, generator=g) * 0.5).to(torch.bfloat16).to(DEV),
+                                   (torch.randn(p_, 1, rope, generator=g) * 0.5).to(torch.bfloat16).to(DEV))
+        new_loc.append(slots[p_:])
+    loc = torch.cat(new_loc)
+
+    class MC:
+        num_attention_heads, num_key_value_heads, context_len = hq, 1, 512
+
+    class MR:
+        device = DEV
+        req_to_token_pool = r2t
+        token_to_kv_pool = pool
+        model_config = MC
+        page_size = 1
+
+    be = HipRadixAttnBackend(MR)
+    T = sum(ext)
+    k_new = (torch.randn(T, 1, rank + rope, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    v_new = k_new[..., :rank].contiguous() if own_v else k_new[..., :rank]
+    q = torch.randn(T, hq * (rank + rope), generator=g).to(torch.bfloat16).to(DEV)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    fb = ForwardBatch.for_extend(rpi, torch.tensor([p_ + e_ for p_, e_ in zip(pre, ext)], device=DEV), loc, pre, ext)
+    be.init_forward_metadata(fb)
+    o = layer(q, k_new, v_new, fb, be)
+    assert o.shape == (T, hq * rank)
+    # the new tokens were stored as well
+    assert torch.equal(pool.get_key_buffer(0)[loc], k_new)
+    kb = pool.get_key_buffer(0)
+    kv_indptr = np.concatenate([[0], np.cumsum(pre)]).astype(np.int32)
+    qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
+    kv_indices = np.concatenate([_bits(r2t.req_to_token[r, :p_]).astype(np.int64) for r, p_ in zip(rows, pre)])
+    kbn = kb.float().cpu().numpy()
+    want = orc.extend_attention(q.view(T, hq, rank + rope).float().cpu().numpy(), k_new.float().cpu().numpy(),
+                                k_new[..., :rank].float().cpu().numpy(), kbn, kbn[..., :rank], qo, kv_indptr, kv_indices,
+                                sm_scale=layer.scaling)
+    got = o.view(T, hq, rank).float().cpu().numpy()
+    parity.check_out(got, want, torch.bfloat16, ("mla_radix_hit_extend", own_v))
+
+
 def test_hnd_pool_store_and_decode():
     """HND pool [pages, Hkv, page, D] (memory_pool.py:2032-2036): rx_store_kv_layout scatter +
     paged decode through the backend equal the NHD result bit for bit."""

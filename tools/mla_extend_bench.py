@@ -4,6 +4,7 @@
     python tools/mla_extend_bench.py                 # bs 32 x (3584 cached + 512 new), 16 q heads (DeepSeek TP8 shard)
     SHAPES=32x3584+512,8x8192+2048 HQ=16,128 python tools/mla_extend_bench.py
     OWNV=1  ... the new tokens' v is its own tensor (the kernel's two-image form)
+    STAMPS=1 ... with a library built with RX_CFLAGS=-DRX_XMLA_STAMP=1: phase times per tile
     GENERIC=1 ... also time the scalar generic kernel (RX_EXTEND_NO_MLA=1 in a child process) on the first shape
 
 FLOPs = 2 * (576 + 512) * Hq * sum_i (E_i * P_i + E_i (E_i + 1) / 2)   (causal)."""
@@ -27,6 +28,8 @@ def run(bs, P, E, hq, own_v, iters):
     pool = bs * (P + E) + 64
     latent = (torch.randn(pool, 1, DK, device=DEV, generator=g) * 0.5).to(torch.bfloat16)
     perm = torch.randperm(pool - 1, device=DEV, generator=g)[: bs * (P + E)] + 1
+    if os.environ.get("CONTIG"):
+        perm = torch.arange(1, bs * (P + E) + 1, device=DEV)
     perm = perm.view(bs, P + E)
     kv_indices = perm[:, :P].reshape(-1).contiguous()
     ext_slots = perm[:, P:].reshape(-1)
@@ -36,11 +39,12 @@ def run(bs, P, E, hq, own_v, iters):
     ke = latent[ext_slots].contiguous()
     ve = ke[..., :DV].contiguous() if own_v else ke[..., :DV]
     o = torch.empty(bs * E, hq, DV, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(bs * E, hq, device=DEV, dtype=torch.float32) if os.environ.get("STAMPS") else None
     sm = 1.0 / (192 ** 0.5)
 
     def call():
         ops.extend_attention_fwd(q, ke, ve, o, latent, latent[..., :DV], qo, kv_indptr, kv_indices, None, True, None, E,
-                                 1.0, 1.0, sm_scale=sm)
+                                 1.0, 1.0, sm_scale=sm, lse_extend=lse)
 
     call()
     torch.cuda.synchronize()
@@ -52,6 +56,13 @@ def run(bs, P, E, hq, own_v, iters):
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / iters
     flops = 2.0 * (DK + DV) * hq * bs * (E * P + E * (E + 1) / 2)
+    if lse is not None:  # a build with -DRX_XMLA_STAMP=1: per-workgroup phase cycles of wave 0 (s_memtime, 100 MHz ticks)
+        nwg = ((bs + 7) // 8 * 8 if bs >= 8 else bs) * ((E * hq + 127) // 128)
+        st = lse.view(torch.int32).flatten()[: 8 * nwg].view(nwg, 8).double()
+        st = st[st[:, 5] > 0]
+        names = ["wait+barrier", "dma issue", "QK", "softmax", "PV"]
+        per = (st[:, :5] / st[:, 5:6]).mean(0).tolist()
+        print("ticks per tile (wave 0):", {n: round(v, 1) for n, v in zip(names, per)}, "tiles/wg", st[:, 5].mean().item())
     return ms, flops / ms / 1e9, o
 
 
