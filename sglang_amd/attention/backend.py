@@ -180,6 +180,17 @@ class HipRadixAttnBackend:
         self._extend_split_on = False
         self._model_dtype = getattr(model_runner, "dtype", None)
 
+    def _split_dims(self):
+        """(Dk, Dv) the split-KV extend forms serve for this pool, or None: head dim 128, or 16-bit latent MLA rows
+        (576 / 512 over one kv head)."""
+        if self._is_mla_pool:
+            pool = self.token_to_kv_pool
+            kb = pool.get_key_buffer(getattr(pool, "start_layer", 0))
+            if kb.dtype in (torch.bfloat16, torch.float16) and kb.shape[-1] == 576 and self.v_head_dim == 512:
+                return 576, 512
+            return None
+        return (128, 128) if self.v_head_dim == 128 else None
+
     def _q_dtype(self, k_buffer: torch.Tensor):
         """dtype of q / o: the runner's model dtype, else the pool's if that is a 16-bit float."""
         dt = getattr(self, "_model_dtype", None)
@@ -542,13 +553,14 @@ class HipRadixAttnBackend:
         # split-KV form of the verify path, with the causal rule in place of a tree mask
         self._extend_split_on = False
         ext, pre = fb.extend_seq_lens_cpu, fb.extend_prefix_lens_cpu
-        if (self.sliding_window_size is None and not self._is_mla_pool and self.v_head_dim == 128 and ext is not None
+        if (self.sliding_window_size is None and self._split_dims() is not None and ext is not None
                 and pre is not None and len(set(int(e) for e in ext)) == 1 and 0 < int(ext[0]) <= 512
                 and min(int(p) for p in pre) >= 1024):
             if self._verify_split is None:
                 kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
+                dk, dv = self._split_dims()
                 self._verify_split = ops.VerifySplitKV(self.num_head, self.num_kv_head, self._q_dtype(kb), self.device,
-                                                       cu_count=self.device_core_count)
+                                                       cu_count=self.device_core_count, head_dim=dk, v_head_dim=dv)
             if self._verify_split.num_chunks(bs, int(ext[0])) >= 2:
                 self._verify_split.plan(qo_indptr, kv_indptr, kv_indices, None, None, int(ext[0]))
                 self._extend_split_on = True
@@ -596,11 +608,12 @@ class HipRadixAttnBackend:
         # small verify batches: one workgroup per (request, kv head) would leave the chip idle -- cut the cached
         # part into chunks (ops.VerifySplitKV, the reference's verify_splitkv case)
         self._verify_split_on = False
-        if self.sliding_window_size is None and not self._is_mla_pool and self.v_head_dim == 128:
+        if self.sliding_window_size is None and self._split_dims() is not None:
             if self._verify_split is None:
                 kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
+                dk, dv = self._split_dims()
                 self._verify_split = ops.VerifySplitKV(self.num_head, self.num_kv_head, self._q_dtype(kb), self.device,
-                                                       cu_count=self.device_core_count)
+                                                       cu_count=self.device_core_count, head_dim=dk, v_head_dim=dv)
             if self._verify_split.num_chunks(bs, nd) >= 2:
                 cm = custom_mask if custom_mask.dtype == torch.uint8 else custom_mask.to(torch.uint8)
                 self._verify_split.plan(qo_indptr, kv_indptr, kv_indices, cm, mask_indptr, nd)
@@ -821,11 +834,14 @@ class HipRadixAttnBackend:
                  or (self._extend_split_on and forward_batch.forward_mode.is_extend() and causal
                      and not forward_batch.forward_mode.is_target_verify() and md.custom_mask is None))
         if (split and sinks is None
-                and layer.qk_head_dim == 128 == layer.v_head_dim and not (getattr(layer, "xai_temperature_len", -1) or 0) > 0
+                and (layer.qk_head_dim, layer.v_head_dim) == (self._verify_split.d, self._verify_split.dv)
+                and not (getattr(layer, "xai_temperature_len", -1) or 0) > 0
                 and not (layer.sliding_window_size is not None and layer.sliding_window_size > -1)
+                and not (layer.logit_cap and layer.logit_cap > 0 and layer.qk_head_dim != 128)
                 and layer.tp_q_head_num == self.num_head):
-            self._verify_split(q.view(-1, layer.tp_q_head_num, 128), k.view(-1, layer.tp_k_head_num, 128),
-                               v.view(-1, layer.tp_v_head_num, 128), o.view(-1, layer.tp_q_head_num, 128), k_buf, v_buf,
+            dk_, dv_ = layer.qk_head_dim, layer.v_head_dim
+            self._verify_split(q.view(-1, layer.tp_q_head_num, dk_), k.view(-1, layer.tp_k_head_num, dk_),
+                               v.view(-1, layer.tp_v_head_num, dv_), o.view(-1, layer.tp_q_head_num, dv_), k_buf, v_buf,
                                k_descale, v_descale, sm_scale=layer.scaling, logit_cap=layer.logit_cap,
                                page_size=self.page_size, kv_layout=lay)
             return o

@@ -912,10 +912,17 @@ class VerifySplitKV:
     ``plan`` (once per forward, shared by all layers, no host sync): chunk boundaries inside every request's cached
     list (multiples of 64 tokens) and the row offsets; ``__call__`` (per layer): two re-layout copies, the two
     launches and the merge, with parameter blocks filled once per (layer buffers, batch geometry).
-    head_dim 128; no sliding window, Grok temperature or sinks (use extend_attention_fwd_gqa_packed)."""
+    head_dim 128 (GQA-packed launches), or the latent MLA shape 576 / 512 over one kv head (rx::extend_mla_kernel packs
+    the heads itself; a tree mask's own-block launch runs the generic kernel there); no sliding window, Grok
+    temperature or sinks (use extend_attention_fwd_gqa_packed)."""
 
-    def __init__(self, num_q_heads: int, num_kv_heads: int, dtype, device, cu_count: int = 256, max_chunks: int = 32):
-        self.hq, self.hkv, self.g, self.d = num_q_heads, num_kv_heads, max(1, num_q_heads // num_kv_heads), 128
+    def __init__(self, num_q_heads: int, num_kv_heads: int, dtype, device, cu_count: int = 256, max_chunks: int = 32,
+                 head_dim: int = 128, v_head_dim: Optional[int] = None):
+        self.hq, self.hkv, self.g, self.d = num_q_heads, num_kv_heads, max(1, num_q_heads // num_kv_heads), int(head_dim)
+        self.dv = int(v_head_dim) if v_head_dim is not None else self.d
+        if (self.d, self.dv) != (128, 128) and not ((self.d, self.dv) == (576, 512) and num_kv_heads == 1):
+            raise ValueError(f"VerifySplitKV: head dims {self.d} / {self.dv} with {num_kv_heads} kv heads")
+        self.pack = self.g if self.d == 128 else 0
         self.dtype, self.device, self.cu_count, self.max_chunks = dtype, device, cu_count, max_chunks
         self._geo = None
         self._params = {}
@@ -933,9 +940,9 @@ class VerifySplitKV:
             self._geo = (bs, S, R)
             n = bs * S * R
             self.q_rep = torch.empty(n, self.hq, self.d, dtype=self.dtype, device=dev)
-            self.o_c = torch.empty(n, self.hq, self.d, dtype=self.dtype, device=dev)
+            self.o_c = torch.empty(n, self.hq, self.dv, dtype=self.dtype, device=dev)
             self.lse_c = torch.empty(n, self.hq, dtype=torch.float32, device=dev)
-            self.o_l = torch.empty(bs * R, self.hq, self.d, dtype=self.dtype, device=dev)
+            self.o_l = torch.empty(bs * R, self.hq, self.dv, dtype=self.dtype, device=dev)
             self.lse_l = torch.empty(bs * R, self.hq, dtype=torch.float32, device=dev)
             self.qo_c = torch.arange(0, (bs * S + 1) * R, R, dtype=torch.int32, device=dev)
             self.qo_g = torch.arange(0, (bs + 1) * R, R, dtype=torch.int32, device=dev)
@@ -966,15 +973,15 @@ class VerifySplitKV:
         if ent is None:
             if len(self._params) > 1024:
                 self._params.clear()
-            pc = _extend_params(self.q_rep, self.q_rep, self.q_rep, self.o_c, k_buffer, v_buffer, self.qo_c,
+            pc = _extend_params(self.q_rep, self.q_rep, self.q_rep[..., :self.dv], self.o_c, k_buffer, v_buffer, self.qo_c,
                                 self.chunk_indptr, kv_indices, None, False, None, R, k_scale, v_scale,
                                 sm_scale=sm_scale, logit_cap=logit_cap, lse_extend=self.lse_c, skip_extend=True,
-                                page_size=page_size, kv_layout=kv_layout, _num_kv_heads=hkv, q_pack=g,
+                                page_size=page_size, kv_layout=kv_layout, _num_kv_heads=hkv, q_pack=self.pack,
                                 avg_kv_len_hint=0)
             pl = _extend_params(q_extend, k_extend, v_extend, self.o_l, k_buffer, v_buffer, self.qo_g, kv_indptr,
                                 kv_indices, custom_mask, True, mask_indptr, R, k_scale, v_scale, sm_scale=sm_scale,
                                 logit_cap=logit_cap, lse_extend=self.lse_l, skip_prefix=True, page_size=page_size,
-                                kv_layout=kv_layout, q_pack=g, avg_kv_len_hint=0)
+                                kv_layout=kv_layout, q_pack=self.pack, avg_kv_len_hint=0)
             ent = self._params[key] = (pc, C.byref(pc), pl, C.byref(pl), (k_buffer, v_buffer))
         pc, pc_ref, pl, pl_ref, _ = ent
         i64 = _is64(kv_indices, "kv_indices")
@@ -993,7 +1000,7 @@ class VerifySplitKV:
             if st:
                 _L.check(st, "rx_extend_attn")
         st = lib.rx_merge_chunks(_ptr(self.o_c), _ptr(self.lse_c), S, _ptr(self.o_l), _ptr(self.lse_l), _ptr(o_extend),
-                                 None, bs, R, hq, d, _rx_dtype(q_extend), stream)
+                                 None, bs, R, hq, self.dv, _rx_dtype(q_extend), stream)
         if st:
             _L.check(st, "rx_merge_chunks")
 
@@ -1003,7 +1010,7 @@ def verify_attention_splitkv(q_extend, k_extend, v_extend, o_extend, k_buffer, v
                              v_scale, sm_scale=None, logit_cap=0.0, page_size: int = 1, kv_layout=None):
     """One-shot form of VerifySplitKV (plan + call) with an explicit chunk count; see the class."""
     vs = VerifySplitKV(q_extend.shape[1], k_extend.shape[1], q_extend.dtype, q_extend.device, max_chunks=num_chunks,
-                       cu_count=1 << 30)
+                       cu_count=1 << 30, head_dim=q_extend.shape[2], v_head_dim=o_extend.shape[2])
     vs.plan(qo_indptr, kv_indptr, kv_indices, custom_mask, mask_indptr, num_draft_tokens)
     vs(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, k_scale, v_scale, sm_scale=sm_scale,
        logit_cap=logit_cap, page_size=page_size, kv_layout=kv_layout)

@@ -693,6 +693,62 @@ def test_short_extend_over_long_prefix_takes_split_kv_path():
     parity.check(np.abs(got - want).max(), 1.5e-2, None)
 
 
+def test_short_mla_extend_over_long_prefix_takes_split_kv_path():
+    """The same follow-up-turn shape on an MLA pool (latent rows 576 / 512, one kv head): the backend's split-KV extend
+    runs rx::extend_mla_kernel over chunks of the prefix and merges -- same result as the oracle."""
+    from sglang_amd.attention.backend import HipRadixAttnBackend
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+    from sglang_amd.mem_cache.memory_pool import MLATokenToKVPool, ReqToTokenPool
+
+    hq, rank, rope = 16, 512, 64
+    pre, ext = [2048, 1500], [24, 24]
+    bs = len(pre)
+    pool = MLATokenToKVPool(4096, 1, torch.bfloat16, rank, rope, 1, DEV)
+    r2t = ReqToTokenPool(4, 4096, DEV)
+    g = torch.Generator().manual_seed(4)
+    perm = torch.randperm(4095, generator=g) + 1
+    rows = r2t.alloc(bs)
+    layer = RadixAttention(hq, rank + rope, (128 + 64) ** -0.5, 1, 0, v_head_dim=rank)
+    off, new_loc = 0, []
+    for r, p_, e_ in zip(rows, pre, ext):
+        slots = perm[off: off + p_ + e_].to(DEV); off += p_ + e_
+        r2t.req_to_token[r, : p_ + e_] = slots.int()
+        pool.set_mla_kv_buffer(layer, slots[:p_], (torch.randn(p_, 1, rank, generator=g) * 0.5).to(torch.bfloat16).to(DEV),
+                               (torch.randn(p_, 1, rope, generator=g) * 0.5).to(torch.bfloat16).to(DEV))
+        new_loc.append(slots[p_:])
+    loc = torch.cat(new_loc)
+
+    class MC:
+        num_attention_heads, num_key_value_heads, context_len = hq, 1, 4096
+
+    class MR:
+        device = DEV
+        req_to_token_pool = r2t
+        token_to_kv_pool = pool
+        model_config = MC
+        page_size = 1
+
+    be = HipRadixAttnBackend(MR)
+    T = sum(ext)
+    k_new = (torch.randn(T, 1, rank + rope, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    q = torch.randn(T, hq * (rank + rope), generator=g).to(torch.bfloat16).to(DEV)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    fb = ForwardBatch.for_extend(rpi, torch.tensor([p_ + e_ for p_, e_ in zip(pre, ext)], device=DEV), loc, pre, ext)
+    be.init_forward_metadata(fb)
+    assert be._extend_split_on and be._verify_split.num_chunks(bs, 24) >= 2 and be._verify_split.dv == 512
+    o = layer(q, k_new, k_new[..., :rank], fb, be)
+    kbn = pool.get_key_buffer(0).float().cpu().numpy()
+    kv_indptr = np.concatenate([[0], np.cumsum(pre)]).astype(np.int32)
+    qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
+    kv_indices = np.concatenate([_bits(r2t.req_to_token[r, :p_]).astype(np.int64) for r, p_ in zip(rows, pre)])
+    want = orc.extend_attention(q.view(T, hq, rank + rope).float().cpu().numpy(), k_new.float().cpu().numpy(),
+                                k_new[..., :rank].float().cpu().numpy(), kbn, kbn[..., :rank], qo, kv_indptr, kv_indices,
+                                sm_scale=layer.scaling)
+    got = o.view(T, hq, rank).float().cpu().numpy().astype(np.float64)
+    parity.check(np.abs(got - want).max(), 1.5e-2, None)
+
+
 def _capture(fn):
     """Warm on a side stream (allocator, lazy launchers), then capture fn() into a HIP graph."""
     s = torch.cuda.Stream()

@@ -1168,6 +1168,51 @@ def test_verify_attention_splitkv_vs_oracle(ops, dtype, chunks):
     parity.check(err, tol, err)
 
 
+@pytest.mark.parametrize("masked", [False, True], ids=["causal", "tree_mask"])
+@pytest.mark.parametrize("chunks", [1, 5])
+def test_verify_attention_splitkv_latent_mla(ops, masked, chunks):
+    """The split-KV form at the latent MLA shape (q 576 / v 512 over one kv head): the cached part cut into chunks
+    that run as pseudo-requests of ONE rx::extend_mla_kernel launch, the new tokens' own block as a second launch
+    (causal rule: the same kernel; a draft tree's mask: the generic kernel), rx_merge_chunks at Dv = 512 -- vs the
+    fp64 oracle's masked extend."""
+    rng = np.random.default_rng(77 + chunks)
+    dtype = torch.bfloat16
+    hq, dk, dv, nd = 16, 576, 512, 6
+    prefix = np.array([700, 64, 1, 1300], dtype=np.int64)
+    bs = len(prefix)
+    pool = int(prefix.sum()) + 40
+    g = torch.Generator().manual_seed(9)
+    kb = (torch.randn(pool, 1, dk, generator=g) * 0.5).to(dtype)
+    T_ = bs * nd
+    q = torch.randn(T_, hq, dk, generator=g).to(dtype)
+    ke = (torch.randn(T_, 1, dk, generator=g) * 0.5).to(dtype)
+    kv_indptr = np.concatenate([[0], np.cumsum(prefix)]).astype(np.int32)
+    kv_indices = (rng.permutation(pool - 1)[: int(prefix.sum())] + 1).astype(np.int64)
+    qo = (np.arange(bs + 1) * nd).astype(np.int64)
+    cm = mi = None
+    if masked:
+        rows = []
+        for i in range(bs):
+            m = np.ones((nd, int(prefix[i]) + nd), dtype=bool)
+            tri = np.tril(rng.random((nd, nd)) < 0.6)
+            np.fill_diagonal(tri, True)
+            m[:, int(prefix[i]):] = tri
+            rows.append(m.reshape(-1))
+        cm = np.concatenate(rows).astype(np.uint8)
+        mi = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
+    sm = 192 ** -0.5
+    okw = dict(custom_mask=cm, mask_indptr=mi) if masked else {}
+    want = orc.extend_attention(_np(q), _np(ke), _np(ke[..., :dv]), _np(kb), _np(kb[..., :dv]), qo, kv_indptr, kv_indices,
+                                is_causal=True, sm_scale=sm, **okw)
+    o = torch.zeros(T_, hq, dv, dtype=dtype, device=DEV)
+    kbd, ked = kb.to(DEV), ke.to(DEV)
+    ops.verify_attention_splitkv(q.to(DEV), ked, ked[..., :dv], o, kbd, kbd[..., :dv], _t(qo), _t(kv_indptr),
+                                 _t(kv_indices), _t(cm) if masked else None, _t(mi) if masked else None, nd, chunks,
+                                 1.0, 1.0, sm_scale=sm)
+    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
+    parity.check(err, 1.5e-2, err)
+
+
 def test_verify_splitkv_replays_under_hip_graph(ops):
     """plan() and the layer call use device data only: a captured {plan, call} graph follows changed cached lengths
     (different chunk boundaries) and a changed tree mask on replay."""

@@ -46,6 +46,14 @@ def run(bs, P, E, hq, own_v, iters):
         ops.extend_attention_fwd(q, ke, ve, o, latent, latent[..., :DV], qo, kv_indptr, kv_indices, None, True, None, E,
                                  1.0, 1.0, sm_scale=sm, lse_extend=lse)
 
+    if os.environ.get("SPLIT"):  # the split-KV form (ops.VerifySplitKV, causal rule) for small batches of short extends
+        vs = ops.VerifySplitKV(hq, 1, torch.bfloat16, DEV, head_dim=DK, v_head_dim=DV)
+        vs.plan(qo, kv_indptr, kv_indices, None, None, E)
+        print("chunks per request:", vs.num_chunks(bs, E))
+
+        def call():  # noqa: F811
+            vs(q, ke, ve, o, latent, latent[..., :DV], 1.0, 1.0, sm_scale=sm)
+
     call()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
