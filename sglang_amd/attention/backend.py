@@ -830,6 +830,17 @@ class HipRadixAttnBackend:
             window = layer.sliding_window_size if (layer.sliding_window_size is not None
                                                    and layer.sliding_window_size > -1) else -1
             kv_indptr, kv_indices, window_kv_offsets = md.kv_indptr, md.kv_indices, None
+        page_size = self.page_size
+        if (self._is_mla_pool and ops._is_fp8_pool(k_buf) and kv_indices is not None and kv_indices.numel() > 0
+                and layer.qk_head_dim == 576):
+            # fp8 latent rows under an extend: the cached rows this batch reads are upcast (exactly) into a dense
+            # 16-bit copy first (rx_get_mla_kv: ~1.7 KB of traffic per row against ~2 MFLOP of attention per row and
+            # query) and the 16-bit MFMA kernel runs on that copy; k_scale / v_scale apply as they do on the pool
+            nope, rope = self.token_to_kv_pool.get_mla_kv_buffer(layer, kv_indices, dst_dtype=q.dtype)
+            k_buf = torch.cat([nope, rope], dim=-1)
+            v_buf = k_buf[..., : layer.v_head_dim]
+            kv_indices = torch.arange(k_buf.shape[0], dtype=torch.int64, device=k_buf.device)
+            lay, page_size = None, 1
         split = ((self._verify_split_on and forward_batch.forward_mode.is_target_verify())
                  or (self._extend_split_on and forward_batch.forward_mode.is_extend() and causal
                      and not forward_batch.forward_mode.is_target_verify() and md.custom_mask is None))
@@ -861,7 +872,7 @@ class HipRadixAttnBackend:
             kv_indptr, kv_indices, md.custom_mask, causal, md.mask_indptr, md.max_extend_len, k_descale,
             v_descale, sm_scale=layer.scaling, logit_cap=layer.logit_cap, sliding_window_size=window,
             sinks=sinks, window_kv_offsets=window_kv_offsets if md.custom_mask is not None else None,
-            xai_temperature_len=layer.xai_temperature_len, page_size=self.page_size, kv_layout=lay)
+            xai_temperature_len=layer.xai_temperature_len, page_size=page_size, kv_layout=lay)
         return o
 
     def support_triton(self):

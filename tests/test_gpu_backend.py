@@ -693,6 +693,63 @@ def test_short_extend_over_long_prefix_takes_split_kv_path():
     parity.check(np.abs(got - want).max(), 1.5e-2, None)
 
 
+def test_mla_fp8_latent_pool_radix_hit_extend():
+    """An fp8 e4m3 latent pool under an extend over its cached rows: the backend upcasts the rows the batch reads
+    (exactly) and runs the 16-bit MFMA kernel on the copy -- vs the oracle on the pool's dequantised values; the new
+    tokens take part in 16 bits (as in the reference: k / v of the extend part are the layer's tensors)."""
+    from sglang_amd.attention.backend import HipRadixAttnBackend
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+    from sglang_amd.mem_cache.memory_pool import MLATokenToKVPool, ReqToTokenPool
+
+    hq, rank, rope = 16, 512, 64
+    pre, ext = [70, 0, 300], [9, 40, 130]
+    bs = len(pre)
+    pool = MLATokenToKVPool(1024, 1, torch.float8_e4m3fn, rank, rope, 1, DEV)
+    r2t = ReqToTokenPool(4, 512, DEV)
+    g = torch.Generator().manual_seed(8)
+    perm = torch.randperm(1023, generator=g) + 1
+    rows = r2t.alloc(bs)
+    layer = RadixAttention(hq, rank + rope, (128 + 64) ** -0.5, 1, 0, v_head_dim=rank)
+    off, new_loc = 0, []
+    for r, p_, e_ in zip(rows, pre, ext):
+        slots = perm[off: off + p_ + e_].to(DEV); off += p_ + e_
+        r2t.req_to_token[r, : p_ + e_] = slots.int()
+        if p_:
+            pool.set_mla_kv_buffer(layer, slots[:p_], (torch.randn(p_, 1, rank, generator=g) * 0.5).to(torch.bfloat16).to(DEV),
+                                   (torch.randn(p_, 1, rope, generator=g) * 0.5).to(torch.bfloat16).to(DEV))
+        new_loc.append(slots[p_:])
+    loc = torch.cat(new_loc)
+
+    class MC:
+        num_attention_heads, num_key_value_heads, context_len = hq, 1, 512
+
+    class MR:
+        device = DEV
+        req_to_token_pool = r2t
+        token_to_kv_pool = pool
+        model_config = MC
+        page_size = 1
+
+    be = HipRadixAttnBackend(MR)
+    T = sum(ext)
+    k_new = (torch.randn(T, 1, rank + rope, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    q = torch.randn(T, hq * (rank + rope), generator=g).to(torch.bfloat16).to(DEV)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    fb = ForwardBatch.for_extend(rpi, torch.tensor([p_ + e_ for p_, e_ in zip(pre, ext)], device=DEV), loc, pre, ext)
+    be.init_forward_metadata(fb)
+    o = layer(q, k_new, k_new[..., :rank], fb, be)
+    kbn = pool.get_key_buffer(0).float().cpu().numpy()  # dequantised rows
+    kv_indptr = np.concatenate([[0], np.cumsum(pre)]).astype(np.int32)
+    qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
+    kv_indices = np.concatenate([_bits(r2t.req_to_token[r, :p_]).astype(np.int64) for r, p_ in zip(rows, pre)])
+    want = orc.extend_attention(q.view(T, hq, rank + rope).float().cpu().numpy(), k_new.float().cpu().numpy(),
+                                k_new[..., :rank].float().cpu().numpy(), kbn, kbn[..., :rank], qo, kv_indptr, kv_indices,
+                                sm_scale=layer.scaling)
+    got = o.view(T, hq, rank).float().cpu().numpy()
+    parity.check_out(got, want, torch.bfloat16, ("mla_fp8_radix_hit_extend",))
+
+
 def test_short_mla_extend_over_long_prefix_takes_split_kv_path():
     """The same follow-up-turn shape on an MLA pool (latent rows 576 / 512, one kv head): the backend's split-KV extend
     runs rx::extend_mla_kernel over chunks of the prefix and merges -- same result as the oracle."""
