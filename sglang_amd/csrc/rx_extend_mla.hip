@@ -541,6 +541,302 @@ __global__ __launch_bounds__(256, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The eight-wave form (SHARED tensors only): 16 rows per wave, two waves per SIMD.  A wave's vector-memory path moves
+// ~3.6 B per cycle (tools/probe/dma_issue.hip), so with four waves per CU every tile's DMA costs each wave 2.7 k
+// cycles that nothing hides; here a wave issues 5 pieces and its SIMD partner computes meanwhile (waves 0-3 issue at
+// the top of the iteration, waves 4-7 behind their QK^T).  Price: a K / V^T fragment feeds ONE MFMA, i.e. twice the
+// LDS reads per FLOP, and 256 registers per wave: 128 AGPR accumulators, and of the 18 Q fragments only 18 - NQL8
+// stay in VGPRs -- the others are parked in LDS and read once per tile (the QK^T loop runs k-step-outer for that).
+#ifndef RX_XMLA_NQL8
+#define RX_XMLA_NQL8 10
+#endif
+struct XGeom8 {
+  static constexpr int NW = 8;
+  static constexpr int NQL = RX_XMLA_NQL8;
+  static constexpr int STAGE = kXImg;
+  static constexpr int SLOTS_AT = 2 * STAGE;
+  static constexpr int SLOTBLK = 256;
+  static constexpr int QTAIL_AT = SLOTS_AT + 2 * SLOTBLK * 4;
+  static constexpr int LDS = QTAIL_AT + NW * NQL * 1024;
+};
+static_assert(XGeom8::LDS <= 160 * 1024, "LDS budget of the eight-wave form");
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void extend_mla8w_kernel(const ExtMlaArgs a) {
+  using vec8 = typename T::vec8;
+  using G = XGeom8;
+  constexpr int KS = kXDk / 32, NB = kXDv / 16;
+  constexpr int KSR = KS - G::NQL;
+  constexpr int kXSlotBlock = G::SLOTBLK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][2 slot blocks][parked Q of the 8 waves]
+  const uint32_t smem_u = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  int req, mb;
+  if (a.xcd_bind) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    req = (j / a.mblocks) * 8 + xcd;
+    mb = a.mblocks - 1 - j % a.mblocks;
+    if (req >= a.bs) return;
+  } else {
+    req = blockIdx.x / a.mblocks;
+    mb = a.mblocks - 1 - blockIdx.x % a.mblocks;
+  }
+  const int64_t qo0 = load_idx(a.qo_indptr, req, a.qo64);
+  const int32_t E = static_cast<int32_t>(load_idx(a.qo_indptr, req + 1, a.qo64) - qo0);
+  const int32_t kv0 = a.kv_indptr[req];
+  const int32_t P = a.kv_indptr[req + 1] - kv0;
+  const int32_t R = E * a.hq;
+  const int32_t row0 = mb * kXRows;
+  if (row0 >= R) return;
+  const int32_t rbase = row0 + 16 * w;
+  const bool active = rbase < R;
+
+  vec8 qf[KSR];
+  const uint32_t qtail = smem_u + G::QTAIL_AT + (w * G::NQL * 64 + lane) * 16;
+  const uint32_t hq_magic = static_cast<uint32_t>(0x100000000ull / static_cast<uint32_t>(a.hq)) + 1u;
+  auto row_tok = [&](int m) { return static_cast<int32_t>(__umulhi(static_cast<uint32_t>(m), hq_magic)); };
+  {
+    const int m = rbase + r;
+    const bool ok = m < R;
+    const int32_t tk = row_tok(ok ? m : 0);
+    const int32_t hd = (ok ? m : 0) - tk * a.hq;
+    const uint16_t* qp = a.q + (qo0 + tk) * a.q_stride_t + hd * a.q_stride_h + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
+      if (s < KSR) qf[s] = __builtin_bit_cast(vec8, raw);
+      else *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(qtail + (s - KSR) * 1024) = raw;
+    }
+  }
+
+  const int32_t p_len = a.skip_prefix ? 0 : P;
+  const int32_t tok_hi_wg = (min(R, row0 + kXRows) - 1) / a.hq + 1;
+  const int32_t tok_hi_w = active ? (min(R, rbase + 16) - 1) / a.hq + 1 : 0;
+  const int32_t n_end_wg = a.skip_extend ? 0 : (a.causal ? tok_hi_wg : E);
+  const int32_t n_end_w = a.skip_extend ? 0 : (a.causal ? tok_hi_w : E);
+  const int nt1 = (p_len + kXTT - 1) / kXTT;
+  const int nt2 = (n_end_wg + kXTT - 1) / kXTT;
+  const int nt = nt1 + nt2;
+
+  const char* const idx_b = reinterpret_cast<const char*>(a.kv_indices);
+  const int idx_sh = a.idx64 ? 3 : 2;
+  auto stage_slots = [&](int blk) {  // waves 0-3: 256 slot ids
+    if (w < 4) {
+      const int v = blk * kXSlotBlock + tid;
+      const int64_t e = kv0 + max(min(v, p_len - 1), 0);
+      x_dma4(idx_b + (e << idx_sh), __builtin_amdgcn_readfirstlane(smem_u + G::SLOTS_AT + ((blk & 1) * kXSlotBlock + 64 * w) * 4));
+    }
+  };
+  if (nt1 > 0) stage_slots(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+
+  const char* const kbuf_b = reinterpret_cast<const char*>(a.k_buf);
+  const char* const kext_b = reinterpret_cast<const char*>(a.k_ext + qo0 * a.k_stride_t);
+  const int32_t sh_p = a.page_shift < 0 ? 31 : a.page_shift;
+  constexpr int kPieces = 37;
+  constexpr int NP = (kPieces + G::NW - 1) / G::NW;  // 5
+  // all pieces of tile t (this wave's: w, w + 8, ...) -> stage t & 1
+  auto dma_tile = [&](int t) {
+    const bool pre = t < nt1;
+    const uint32_t sl = smem_u + G::SLOTS_AT + 4 * (((t * kXTT / kXSlotBlock) & 1) * kXSlotBlock + (t * kXTT) % kXSlotBlock);
+    const uint32_t img = smem_u + (t & 1) * G::STAGE;
+    const char* const base = pre ? kbuf_b : kext_b;
+    const int32_t sh = pre ? sh_p : 31;
+    const uint32_t mask = sh == 31 ? 0x7fffffffu : (1u << sh) - 1u;
+    const uint32_t ts2 = 2u * static_cast<uint32_t>(pre ? a.k_tok_stride : a.k_stride_t);
+    const uint32_t ps2 = pre ? 2u * static_cast<uint32_t>(a.k_page_stride) : 0u;
+    const bool paged = pre && sh != 31;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int c0 = 64 * w + ln;  // < 512
+    int row = c0 / (kXCpr), col = c0 - row * kXCpr;
+    int32_t slot[NP], col16[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool past = row >= kXTT;
+      const int rw = past ? kXTT - 1 : row;
+      col16[i] = 16 * ((past || col == kXCpr - 1) ? kXCpr - 2 : col);
+      slot[i] = pre ? x_lds_read4(sl + 4 * rw) : max(min((t - nt1) * kXTT + rw, n_end_wg - 1), 0);
+      row += 512 / kXCpr;
+      col += 512 % kXCpr;
+      if (col >= kXCpr) {
+        col -= kXCpr;
+        row += 1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (w + G::NW * i < kPieces) {
+        uint64_t ko = static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) & mask) * ts2 + static_cast<uint32_t>(col16[i]);
+        if (paged) ko += static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) >> sh) * ps2;
+        x_dma16(base + ko, __builtin_amdgcn_readfirstlane(img + (w + G::NW * i) * 1024));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (nt > 0) dma_tile(0);
+
+  f32x4 oacc[NB];
+  float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int qd = r >> 2, pp = r & 3;
+  const int vrow0 = 4 * g + qd;
+  const uint32_t k_lane = r * kXRow + g * 16;
+  const uint32_t v_lane = vrow0 * kXRow + 8 * (pp & 1) + (pp >> 1) * 16;
+  const bool late = w >= 4;  // the SIMD partner of an early wave: issues its pieces behind its QK^T
+
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    constexpr int TPB = kXSlotBlock / kXTT;
+    if (t % TPB == 0 && (t / TPB + 1) * kXSlotBlock < nt1 * kXTT) stage_slots(t / TPB + 1);
+    const bool more = t + 1 < nt;
+    if (more && !late) dma_tile(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool prefix = t < nt1;
+    const int n0 = (prefix ? t : t - nt1) * kXTT;
+    const int32_t lim = prefix ? p_len : n_end_w;
+    if (!active || n0 >= lim) {
+      if (more && late) dma_tile(t + 1);
+      continue;
+    }
+    const uint32_t kt = smem_u + (t & 1) * G::STAGE;
+
+    // ---- S^T = K Q^T, k-step-outer: a parked Q fragment is read once per tile
+    f32x4 sacc[2];
+    sacc[0] = sacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int PD = 4;
+      const uint32_t krow = kt + k_lane;
+      auto kfrag = [&](int j) { return x_lds_read16(krow + (j & 1) * 16 * kXRow + (j >> 1) * 64); };  // j = 2 s + bb
+      u32x4 kf[PD];
+#pragma unroll
+      for (int j = 0; j < PD; ++j) kf[j] = kfrag(j);
+      u32x4 qq[2] = {};
+      if (KSR < 2) {
+#pragma unroll
+        for (int s = KSR; s < 2; ++s) qq[s & 1] = x_lds_read16(qtail + (s - KSR) * 1024);
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const vec8 qb = (s < KSR) ? qf[s < KSR ? s : 0] : __builtin_bit_cast(vec8, qq[s & 1]);
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const int j = 2 * s + bb;
+          const vec8 ka = __builtin_bit_cast(vec8, kf[j % PD]);
+          if (j + PD < 2 * KS) kf[j % PD] = kfrag(j + PD);
+          sacc[bb] = T::mfma(ka, qb, sacc[bb]);
+        }
+        if (s + 2 < KS && s + 2 >= KSR) qq[s & 1] = x_lds_read16(qtail + (s + 2 - KSR) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (more && late) dma_tile(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t rp0 = kt + v_lane;
+    const uint32_t rp1 = rp0 + 16 * kXRow;
+    const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
+    const float c2 = cs * kLog2e;
+    u32x4 pf;
+    {
+      float sv[8];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[bb][i];
+      {
+        int lnm = lane;
+        asm volatile("" : "+v"(lnm));
+        const int32_t tk1 = row_tok(rbase + (lnm & 15)) + 1;
+        const int32_t vis = (prefix ? p_len : min(n_end_w, a.causal ? tk1 : E)) - n0 - 4 * (lnm >> 4);
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i < vis) ? sv[bb * 4 + i] : -INFINITY;
+      }
+      float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+      mt = quad_row_max(mt) * c2;
+      const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
+      const float m_new = (mt_fixed > m_run + kXSlack) ? mt_fixed : m_run;
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+        psum += sv[j];
+      }
+      l_run = l_run * alpha + psum;
+      if (prefix && a.v_scale != 1.0f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[j] *= a.v_scale;
+      }
+      pf[0] = pack2<T>(sv[0], sv[1]);
+      pf[1] = pack2<T>(sv[2], sv[3]);
+      pf[2] = pack2<T>(sv[4], sv[5]);
+      pf[3] = pack2<T>(sv[6], sv[7]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+        x_settle(oacc);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          oacc[nb] *= alpha;
+          asm volatile("" : "+a"(oacc[nb]));
+        }
+        x_settle(oacc);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NPRE = 4;
+    u32x2 vlo[NPRE], vhi[NPRE];
+#pragma unroll
+    for (int nb = 0; nb < NPRE; ++nb) {
+      vlo[nb] = T::ds_read_tr((const void*)(uintptr_t)(rp0 + nb * 32));
+      vhi[nb] = T::ds_read_tr((const void*)(uintptr_t)(rp1 + nb * 32));
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const u32x2 lo = vlo[nb % NPRE], hi = vhi[nb % NPRE];
+      if (nb + NPRE < NB) {
+        vlo[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp0 + (nb + NPRE) * 32));
+        vhi[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp1 + (nb + NPRE) * 32));
+      }
+      const u32x4 av = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      x_pv_mfma<T>(av, pf, oacc[nb]);
+    }
+  }
+
+  if (!active) return;
+  x_settle(oacc);
+  float l = l_run;
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  const int m = rbase + r;
+  if (m >= R) return;
+  const float inv = 1.0f / l;
+  const int32_t tk = m / a.hq, hd = m - tk * a.hq;
+  uint16_t* op = a.o + (qo0 + tk) * a.o_stride_t + hd * a.o_stride_h + 4 * g;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    u32x2 pk;
+    pk[0] = pack2<T>(oacc[nb][0] * inv, oacc[nb][1] * inv);
+    pk[1] = pack2<T>(oacc[nb][2] * inv, oacc[nb][3] * inv);
+    *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (a.lse && g == 0) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run * kLn2 + __logf(l);
+}
+
 bool extend_mla_supports(const rx_extend_params* p) {
   if (p->head_dim != kXDk || p->v_head_dim != kXDv || p->num_kv_heads != 1 || p->kv.kv_fp8) return false;
   if (p->sliding_window_size > 0 || p->logit_cap > 0.f || p->sinks || p->custom_mask || p->xai_temperature_len > 0 ||
@@ -597,6 +893,18 @@ int launch_extend_mla(const rx_extend_params* p, hipStream_t s) {
     (void)attr;                                                                                                      \
     hipLaunchKernelGGL((extend_mla_kernel<TT, SH>), dim3(grid), dim3(256), XGeom<SH>::LDS, s, a);                    \
   } while (0)
+  static const bool eight = getenv("RX_XMLA_8W") != nullptr;  // dev: the eight-wave form for aliased tensors
+  if (eight && shared) {
+    static const hipError_t a8b = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_mla8w_kernel<BF16>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, XGeom8::LDS);
+    static const hipError_t a8h = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_mla8w_kernel<F16>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, XGeom8::LDS);
+    (void)a8b;
+    (void)a8h;
+    if (bf) hipLaunchKernelGGL(extend_mla8w_kernel<BF16>, dim3(grid), dim3(512), XGeom8::LDS, s, a);
+    else hipLaunchKernelGGL(extend_mla8w_kernel<F16>, dim3(grid), dim3(512), XGeom8::LDS, s, a);
+    return RX_OK;
+  }
   if (bf) {
     if (shared) RX_XMLA(BF16, true);
     else RX_XMLA(BF16, false);
