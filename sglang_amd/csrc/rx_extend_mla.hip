@@ -24,6 +24,12 @@
 //   * the running max moves only when a tile's max exceeds it by 2^8 (exact algebra, see rx_extend32.hip): the
 //     256-register rescale runs on the first tile and almost never again.
 // Causal / non-causal, skip_prefix / skip_extend, LSE, k / v scales.  Windows, caps, sinks, masks: generic kernel.
+//
+// Two forms.  The one described above (extend_mla_kernel, four waves) is bound by what its DMA costs the issuing wave
+// (~270 cycles per 1-KiB piece, 10 per tile, nothing on the SIMD to hide them: DESIGN 4.2b); it serves tensors whose v
+// is a tensor of its own.  Aliased tensors -- the common case -- take extend_mla8w_kernel further down: 16 rows per
+// wave, TWO waves per SIMD, so that a SIMD partner computes while a wave issues its 5 pieces; it pays with twice the
+// LDS reads per FLOP and is LDS-bound instead (650 -> 720-730 TFLOP/s at the bench shape, 712 -> 865 at larger ones).
 #include <type_traits>
 
 #include "rx_common.h"
@@ -694,15 +700,30 @@ __global__ __launch_bounds__(512, 1) void extend_mla8w_kernel(const ExtMlaArgs a
   const uint32_t k_lane = r * kXRow + g * 16;
   const uint32_t v_lane = vrow0 * kXRow + 8 * (pp & 1) + (pp >> 1) * 16;
   const bool late = w >= 4;  // the SIMD partner of an early wave: issues its pieces behind its QK^T
+#undef X_STAMP
+#if RX_XMLA_STAMP
+  uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
+#define X_STAMP(i)                                                 \
+  do {                                                             \
+    const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();  \
+    st_acc[i] += now_ - st_prev;                                   \
+    st_prev = now_;                                                \
+  } while (0)
+#else
+#define X_STAMP(i)
+#endif
 
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    X_STAMP(0);
     constexpr int TPB = kXSlotBlock / kXTT;
     if (t % TPB == 0 && (t / TPB + 1) * kXSlotBlock < nt1 * kXTT) stage_slots(t / TPB + 1);
     const bool more = t + 1 < nt;
     if (more && !late) dma_tile(t + 1);
     __builtin_amdgcn_sched_barrier(0);
+    X_STAMP(1);
     const bool prefix = t < nt1;
     const int n0 = (prefix ? t : t - nt1) * kXTT;
     const int32_t lim = prefix ? p_len : n_end_w;
@@ -741,8 +762,13 @@ __global__ __launch_bounds__(512, 1) void extend_mla8w_kernel(const ExtMlaArgs a
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (more && late) dma_tile(t + 1);
+    X_STAMP(2);
+#ifndef RX_XMLA_LATE_AT
+#define RX_XMLA_LATE_AT 1  // where waves 4-7 issue their pieces: 1 behind QK^T, 2 behind the softmax
+#endif
+    if (RX_XMLA_LATE_AT == 1 && more && late) dma_tile(t + 1);
     __builtin_amdgcn_sched_barrier(0);
+    X_STAMP(1);
     const uint32_t rp0 = kt + v_lane;
     const uint32_t rp1 = rp0 + 16 * kXRow;
     const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
@@ -797,6 +823,10 @@ __global__ __launch_bounds__(512, 1) void extend_mla8w_kernel(const ExtMlaArgs a
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    X_STAMP(3);
+    if (RX_XMLA_LATE_AT == 2 && more && late) dma_tile(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    X_STAMP(1);
     constexpr int NPRE = 4;
     u32x2 vlo[NPRE], vhi[NPRE];
 #pragma unroll
@@ -814,7 +844,15 @@ __global__ __launch_bounds__(512, 1) void extend_mla8w_kernel(const ExtMlaArgs a
       const u32x4 av = u32x4{lo[0], lo[1], hi[0], hi[1]};
       x_pv_mfma<T>(av, pf, oacc[nb]);
     }
+    X_STAMP(4);
   }
+#if RX_XMLA_STAMP
+  if ((w == 0 || w == 4) && lane == 0 && a.lse) {
+    uint32_t* dbg = reinterpret_cast<uint32_t*>(a.lse) + 16 * blockIdx.x + 2 * w;  // wave 0 at +0, wave 4 at +8
+    for (int i = 0; i < 5; ++i) dbg[i] = st_acc[i];
+    dbg[5] = nt;
+  }
+#endif
 
   if (!active) return;
   x_settle(oacc);
@@ -834,7 +872,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla8w_kernel(const ExtMlaArgs a
     *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (a.lse && g == 0) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run * kLn2 + __logf(l);
+  if (a.lse && g == 0 && !RX_XMLA_STAMP) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run * kLn2 + __logf(l);
 }
 
 bool extend_mla_supports(const rx_extend_params* p) {
@@ -893,7 +931,7 @@ int launch_extend_mla(const rx_extend_params* p, hipStream_t s) {
     (void)attr;                                                                                                      \
     hipLaunchKernelGGL((extend_mla_kernel<TT, SH>), dim3(grid), dim3(256), XGeom<SH>::LDS, s, a);                    \
   } while (0)
-  static const bool eight = getenv("RX_XMLA_8W") != nullptr;  // dev: the eight-wave form for aliased tensors
+  static const bool eight = getenv("RX_XMLA_4W") == nullptr;  // (dev: RX_XMLA_4W keeps the four-wave form for aliased tensors too)
   if (eight && shared) {
     static const hipError_t a8b = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_mla8w_kernel<BF16>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, XGeom8::LDS);
