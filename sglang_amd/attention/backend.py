@@ -98,8 +98,14 @@ class HipRadixAttnBackend:
     def __init__(self, model_runner, decode_index_mode: str = "paged",
                  max_kv_splits: Optional[int] = None, split_policy: str = "native",
                  cascade_decode: bool = False, cascade_min_bs: int = 16, cascade_min_shared: int = 1024,
-                 dcp=None):
+                 dcp=None, mla_v_is_latent_prefix: bool = False):
         self.device = model_runner.device
+        # MLA pools keep ONE latent row per token and serve v as its first kv_lora_rank columns (the reference's
+        # MLATokenToKVPool.set_kv_buffer drops cache_v); the model hands forward_extend v = k_nope, a tensor of its own
+        # with the same values.  With this flag the extend reads the new tokens' v from their k rows as well -- the
+        # kernel's one-image form -- instead of from v.  Off by default: it is the caller's statement that
+        # v == k[..., :kv_lora_rank] for the new tokens, which the absorbed formulation guarantees and the API does not.
+        self.mla_v_is_latent_prefix = bool(mla_v_is_latent_prefix)
         self.req_to_token_pool = model_runner.req_to_token_pool
         self.token_to_kv_pool = model_runner.token_to_kv_pool
         self.token_to_kv_pool_allocator = getattr(model_runner, "token_to_kv_pool_allocator", None)
@@ -831,6 +837,9 @@ class HipRadixAttnBackend:
                                                    and layer.sliding_window_size > -1) else -1
             kv_indptr, kv_indices, window_kv_offsets = md.kv_indptr, md.kv_indices, None
         page_size = self.page_size
+        if (self.mla_v_is_latent_prefix and self._is_mla_pool and layer.qk_head_dim > layer.v_head_dim
+                and k.shape[-1] == layer.tp_k_head_num * layer.qk_head_dim):
+            v = k.view(-1, layer.tp_k_head_num, layer.qk_head_dim)[..., : layer.v_head_dim]
         if (self._is_mla_pool and ops._is_fp8_pool(k_buf) and kv_indices is not None and kv_indices.numel() > 0
                 and layer.qk_head_dim == 576):
             # fp8 latent rows under an extend: the cached rows this batch reads are upcast (exactly) into a dense

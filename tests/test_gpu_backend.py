@@ -278,7 +278,7 @@ def test_mla_latent_pool_and_decode():
     parity.check(np.abs(got - want).max(), 1e-2, None)
 
 
-@pytest.mark.parametrize("own_v", [False, True], ids=["v_view_of_k", "v_own_tensor"])
+@pytest.mark.parametrize("own_v", [False, True, "flag"], ids=["v_view_of_k", "v_own_tensor", "v_own_tensor_flagged_as_latent_prefix"])
 def test_mla_latent_radix_hit_extend(own_v):
     """A radix-cache hit of an MLA model: cached latent prefix + new tokens through HipRadixAttnBackend.forward_extend
     (absorbed form, q 576 / v 512 over ONE kv head: forward_absorb_core -> attn_mqa -> forward_extend,
@@ -319,7 +319,7 @@ def test_mla_latent_radix_hit_extend(own_v):
         model_config = MC
         page_size = 1
 
-    be = HipRadixAttnBackend(MR)
+    be = HipRadixAttnBackend(MR, mla_v_is_latent_prefix=(own_v == "flag"))
     T = sum(ext)
     k_new = (torch.randn(T, 1, rank + rope, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
     v_new = k_new[..., :rank].contiguous() if own_v else k_new[..., :rank]
