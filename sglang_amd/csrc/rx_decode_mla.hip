@@ -501,12 +501,19 @@ constexpr int kM8SlotBlock = 1024;             // tokens whose slot ids are stag
 constexpr int kM8Lds = kM8Ring * kM8Buf + 4 * 64 * 16 + 2 * kM8SlotBlock * 4;
 
 // one 1-KiB LDS-DMA piece: lane l's 16 bytes land at lds_dst + 16 l (recipe: cdna_hip_programming.md 5.7)
+#ifndef RX_M8_M0_RESTORE
+#define RX_M8_M0_RESTORE 0  // 1: save / restore M0 around every piece (the guide's recipe).  The restore waits until the DMA has consumed M0: tools/probe/dma_issue.hip, +60-100 cycles per piece.  hipcc uses M0 for nothing else in this kernel (checked in the ISA).
+#endif
 __device__ __forceinline__ void m8_dma16(const void* gsrc, uint32_t lds_dst) {
+#if RX_M8_M0_RESTORE
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
+#else
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+#endif
 }
 
 template <typename T, typename IdxT, bool LINEAR>
