@@ -176,8 +176,7 @@ class HipRadixAttnBackend:
         # launches per layer); the common prefix itself is found on the device every forward
         if self.dcp is not None and self.sliding_window_size is not None:
             raise NotImplementedError("DCP here covers pools without sliding-window layers")
-        self.cascade_decode = (bool(cascade_decode) and not self._is_mla_pool and self.sliding_window_size is None
-                               and self.dcp is None)
+        self.cascade_decode = bool(cascade_decode) and self.sliding_window_size is None and self.dcp is None
         self.cascade_min_bs, self.cascade_min_shared = int(cascade_min_bs), int(cascade_min_shared)
         self._cascade = None
         self._cascade_on = False
@@ -300,14 +299,17 @@ class HipRadixAttnBackend:
         if self._cascade_on:
             if self._cascade is None:
                 kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
-                if kb.shape[-1] not in (64, 128) or kb.shape[-1] != self.v_head_dim:
+                mla = (self._is_mla_pool and kb.shape[-1] == 576 and self.v_head_dim == 512
+                       and kb.dtype in (torch.bfloat16, torch.float16))   # 16-bit latent rows (phase 1 reads them)
+                if not mla and (self._is_mla_pool or kb.shape[-1] not in (64, 128) or kb.shape[-1] != self.v_head_dim):
                     self.cascade_decode = self._cascade_on = False
                 else:
                     self._cascade = ops.CascadeDecode(
-                        self.req_to_token_pool.size, self.num_head, self.num_kv_head, self.v_head_dim,
+                        self.req_to_token_pool.size, self.num_head, self.num_kv_head, kb.shape[-1],
                         self._q_dtype(kb), self.device,
                         max_shared=self.req_to_token.shape[1], cu_count=self.device_core_count,
-                        min_shared=self.cascade_min_shared, max_kv_splits=self.native_split_cap)
+                        min_shared=self.cascade_min_shared, max_kv_splits=self.native_split_cap,
+                        v_head_dim=self.v_head_dim)
             if self._cascade_on:
                 self._cascade.plan(self.req_to_token, fb.req_pool_indices, fb.seq_lens)
                 return ForwardMetadata(None, None, None, None, None, None, None, 1)

@@ -914,7 +914,6 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
                    ((p->q_stride_t | p->q_stride_h | p->kv.k_tok_stride | p->kv.k_page_stride) % 8 == 0) &&
                    ((uintptr_t)p->q & 15) == 0 && ((uintptr_t)p->kv.k_buf & (p->kv.kv_fp8 ? 7 : 15)) == 0 &&
                    ((p->o_stride_t | p->o_stride_h) % 4 == 0) && ((uintptr_t)p->o & 7) == 0;
-  if (mla) RX_REQUIRE(!p->kv_start, "rx_decode_attn: kv_start is not supported on the MLA kernel");
   // stage 2 inside the stage-1 kernel: the kernels that have the epilogue, both stages wanted, nothing else to merge,
   // and the vector stores of the merge possible
   const bool merge_in_kernel = p->merge_counters && p->stages == 0 && a.num_extra == 0 && max_splits > 1 &&

@@ -34,6 +34,7 @@ struct MlaArgs {
   const int32_t* kv_indptr;
   const void* kv_indices;
   const int32_t* req_to_token;
+  const int32_t* kv_start;  // req_to_token lookup only: request b attends [kv_start[b], seq_len_b) (or NULL)
   int64_t req_row_stride;
   const void* req_pool_indices;
   int32_t rpi64;
@@ -152,6 +153,12 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
     seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
     idx = reinterpret_cast<const IdxT*>(a.req_to_token + req * a.req_row_stride);
   }
+  const int32_t full_len = seq_len;  // the query's position + 1 (Grok temperature)
+  if (a.kv_start && !a.kv_indices) {  // the suffix [kv_start[b], seq_len) only (shared-prefix cascade, phase 2)
+    const int32_t st = min(max(a.kv_start[b], 0), seq_len);
+    idx += st;
+    seq_len -= st;
+  }
   const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
   const bool single = (a.max_kv_splits == 1) || (a.direct_single && splits == 1);
   const int h = qb * 16 + r;
@@ -255,8 +262,8 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
   for (int nb = 0; nb < NBW; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
   float xai = 1.0f;  // Grok temperature (decode_attention.py:156-160): the query sits at seq_len - 1
-  if (a.xai_len > 0 && seq_len - 1 > a.xai_len)
-    xai = __log2f(static_cast<float>(seq_len - 1)) / __log2f(static_cast<float>(a.xai_len));
+  if (a.xai_len > 0 && full_len - 1 > a.xai_len)
+    xai = __log2f(static_cast<float>(full_len - 1)) / __log2f(static_cast<float>(a.xai_len));
   const bool capped = a.logit_cap > 0.f;
   const float c2 = (capped ? kLog2e : a.sm_scale * kLog2e) * xai;
 
@@ -552,6 +559,12 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
     seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
     idx = reinterpret_cast<const IdxT*>(a.req_to_token + req * a.req_row_stride);
   }
+  const int32_t full_len = seq_len;  // the query's position + 1 (Grok temperature)
+  if (a.kv_start && !a.kv_indices) {  // the suffix [kv_start[b], seq_len) only (shared-prefix cascade, phase 2)
+    const int32_t st = min(max(a.kv_start[b], 0), seq_len);
+    idx += st;
+    seq_len -= st;
+  }
   const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
   const bool single = (a.max_kv_splits == 1) || (a.direct_single && splits == 1);
   const int h = qb * 16 + r;
@@ -650,8 +663,8 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
   for (int nb = 0; nb < NBW; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
   float xai = 1.0f;
-  if (a.xai_len > 0 && seq_len - 1 > a.xai_len)
-    xai = __log2f(static_cast<float>(seq_len - 1)) / __log2f(static_cast<float>(a.xai_len));
+  if (a.xai_len > 0 && full_len - 1 > a.xai_len)
+    xai = __log2f(static_cast<float>(full_len - 1)) / __log2f(static_cast<float>(a.xai_len));
   const bool capped = a.logit_cap > 0.f;
   const float c2 = (capped ? kLog2e : a.sm_scale * kLog2e) * xai;
   const int bb_w = w & 1;
@@ -837,6 +850,7 @@ int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, int di
   a.kv_indptr = p->kv_indptr;
   a.kv_indices = p->kv_indices;
   a.req_to_token = p->req_to_token;
+  a.kv_start = p->kv_indices ? nullptr : p->kv_start;
   a.req_row_stride = p->req_row_stride;
   a.req_pool_indices = p->req_pool_indices;
   a.rpi64 = p->req_pool_indices_is_i64;

@@ -557,10 +557,13 @@ class CascadeDecode:
 
     def __init__(self, max_bs: int, num_q_heads: int, num_kv_heads: int, head_dim: int, dtype, device,
                  max_shared: int, cu_count: int = 256, min_shared: int = 1024, max_kv_splits: int = 16,
-                 num_chunks: Optional[int] = None, overlap: bool = False):
-        if head_dim not in (64, 128):
-            raise ValueError("CascadeDecode: head_dim 64 / 128 (the MFMA extend kernels)")
-        self.max_bs, self.hq, self.hkv, self.d = max_bs, num_q_heads, num_kv_heads, head_dim
+                 num_chunks: Optional[int] = None, overlap: bool = False, v_head_dim: Optional[int] = None):
+        v_head_dim = head_dim if v_head_dim is None else int(v_head_dim)
+        self.mla = (head_dim, v_head_dim) == (576, 512) and num_kv_heads == 1   # latent rows: rx::extend_mla_kernel
+        if not self.mla and (head_dim not in (64, 128) or v_head_dim != head_dim):
+            raise ValueError("CascadeDecode: head_dim 64 / 128, or the latent MLA shape 576 / 512 over one kv head "
+                             "(the MFMA extend kernels)")
+        self.max_bs, self.hq, self.hkv, self.d, self.dv = max_bs, num_q_heads, num_kv_heads, head_dim, v_head_dim
         self.cu_count, self.min_shared, self.max_shared = cu_count, int(min_shared), int(max_shared)
         # chunks of the shared prefix = pseudo-requests of phase 1.  Its workgroups = chunks * ceil(bs / 128) * Hq
         # should cover every CU once, so the count follows the ACTUAL batch (a pool sized for thousands of requests
@@ -580,14 +583,14 @@ class CascadeDecode:
         self.suffix_lens = torch.zeros(max_bs, **i32)
         self.num_kv_splits = torch.ones(max_bs, **i32)
         self.q_rep = torch.zeros(rows_max * num_q_heads * head_dim, dtype=dtype, device=device)
-        self.o_parts = torch.zeros(rows_max * num_q_heads * head_dim, dtype=dtype, device=device)
+        self.o_parts = torch.zeros(rows_max * num_q_heads * v_head_dim, dtype=dtype, device=device)
         self.lse_parts = torch.zeros(rows_max * num_q_heads, dtype=torch.float32, device=device)
         self._qo_indptr_buf = torch.zeros(S_max + 1, **i32)
         self.qo_indptr = self._qo_indptr_buf[: self.num_chunks + 1]
         # suffix partials: bs * S(bs) <= cu / (Hkv * ceil(G / 16)) + bs rows per head (native schedule), >= 2 slots
         group = max(1, num_q_heads // num_kv_heads)
         rows = (max(2 * max_bs, cu_count // (num_kv_heads * ((group + 15) // 16)) + max_bs) + 1) * num_q_heads
-        self.attn_logits = torch.empty(rows * head_dim, dtype=torch.float32, device=device)
+        self.attn_logits = torch.empty(rows * v_head_dim, dtype=torch.float32, device=device)
         self.attn_lse = torch.empty(rows, dtype=torch.float32, device=device)
         self.bs = 0
         self._params = {}  # (k ptr, v ptr, bs, scalars) -> filled rx_extend_params / rx_decode_params
@@ -600,6 +603,8 @@ class CascadeDecode:
     def _chunks_for(self, bs: int) -> int:
         if self._fixed_chunks is not None:
             return self._fixed_chunks
+        if self.mla:  # rows are (query, head) pairs there: ceil(bs * Hq / 128) workgroups per chunk
+            return max(1, min(16, -(-self.cu_count // -(-bs * self.hq // 128))))
         return max(1, min(16, -(-self.cu_count // (-(-bs // 128) * self.hq))))
 
     def plan(self, req_to_token, req_pool_indices, seq_lens) -> None:
@@ -641,12 +646,12 @@ class CascadeDecode:
         req_to_token, req_pool_indices, seq_lens = self._tabs
         # phase 1: every chunk of the shared prefix against all bs queries (M = bs per head)
         q_rep = self.q_rep[: S * bs * self.hq * self.d].view(S, bs, self.hq, self.d)
-        o_parts = self.o_parts[: S * bs * self.hq * self.d].view(S, bs, self.hq, self.d)
+        o_parts = self.o_parts[: S * bs * self.hq * self.dv].view(S, bs, self.hq, self.dv)
         lse_parts = self.lse_parts[: S * bs * self.hq].view(S, bs, self.hq)
-        attn_logits = self.attn_logits[: bs * self.hq * self.max_kv_splits * self.d].view(
-            bs, self.hq, self.max_kv_splits, self.d)
+        attn_logits = self.attn_logits[: bs * self.hq * self.max_kv_splits * self.dv].view(
+            bs, self.hq, self.max_kv_splits, self.dv)
         attn_lse = self.attn_lse[: bs * self.hq * self.max_kv_splits].view(bs, self.hq, self.max_kv_splits)
-        qf, of = q_rep.view(S * bs, self.hq, self.d), o_parts.view(S * bs, self.hq, self.d)
+        qf, of = q_rep.view(S * bs, self.hq, self.d), o_parts.view(S * bs, self.hq, self.dv)
 
         # the two parameter blocks depend on the layer's buffers, bs and a few scalars only: filled once, then
         # just q / o / sinks are patched (per-layer host cost: one copy + two ctypes calls)
@@ -656,7 +661,7 @@ class CascadeDecode:
         if ent is None:
             if len(self._params) > 4096:
                 self._params.clear()
-            pe = _extend_params(qf, qf, qf, of, k_buffer, v_buffer, self.qo_indptr, self.chunk_indptr,
+            pe = _extend_params(qf, qf, qf[..., : self.dv], of, k_buffer, v_buffer, self.qo_indptr, self.chunk_indptr,
                                 self.shared_indices, None, False, None, bs, k_scale, 1.0, sm_scale=sm_scale,
                                 logit_cap=logit_cap, lse_extend=lse_parts.view(S * bs, self.hq), skip_extend=True,
                                 page_size=page_size, kv_layout=kv_layout, _num_kv_heads=self.hkv, avg_kv_len_hint=0)

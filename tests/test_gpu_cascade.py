@@ -112,6 +112,53 @@ def test_cascade_decode_matches_oracle(ops, case, dtype):
     parity.check(err, tol, err)
 
 
+MLA_CASES = [
+    # bs, hq, page, shared(target), lens, min_shared
+    (8, 16, 16, 512, [600, 513, 700, 640, 1000, 512 + 17, 530, 800], 64),
+    (5, 16, 1, 100, [101, 150, 333, 100, 129], 1),       # one request is the prefix itself (empty suffix)
+    (4, 16, 16, 0, [100, 200, 300, 64], 64),             # nothing shared -> plain MLA decode
+    (20, 8, 64, 1500, None, 256),                        # 160 (query, head) rows per chunk: two workgroups each
+]
+
+
+@pytest.mark.parametrize("case", range(len(MLA_CASES)))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_cascade_decode_latent_mla(ops, case, dtype):
+    """The cascade on latent MLA rows (q 576 / v 512 over one kv head): phase 1 = rx::extend_mla_kernel over the shared
+    rows with all (query, head) pairs as its rows, phase 2 = the MLA decode kernel over the suffixes (kv_start on the
+    req_to_token lookup), stage 2 merges -- equals plain decode attention (fp64 oracle)."""
+    bs, hq, page, shared, lens, min_shared = MLA_CASES[case]
+    dk, dv = 576, 512
+    rng = np.random.default_rng(900 + case)
+    if lens is None:
+        lens = shared + rng.integers(1, 200, size=bs)
+    lens = np.asarray(lens, dtype=np.int64)
+    ctx = int(lens.max()) + page
+    r2t, pool = _table(rng, shared, lens, page, ctx)
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    g = torch.Generator().manual_seed(case)
+    kb = (torch.randn(pool, 1, dk, generator=g) * 0.5).to(dtype)
+    q = torch.randn(bs, hq, dk, generator=g).to(dtype)
+    sinks = torch.randn(hq, generator=g) if case % 2 else None
+    ks, vs = (0.9, 1.1) if case == 0 else (1.0, 1.0)
+    sm = 192 ** -0.5
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
+    want = orc.decode_attention(_bits(q), _bits(kb), _bits(kb[..., :dv].contiguous()), kv_indptr, kv_indices, sm,
+                                k_scale=ks, v_scale=vs, sinks=None if sinks is None else sinks.numpy())
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    cd = ops.CascadeDecode(bs, hq, 1, dk, dtype, DEV, max_shared=ctx, min_shared=min_shared, v_head_dim=dv,
+                           num_chunks=[None, 1, 3, None][case])
+    cd.plan(T(r2t), T(rpi), T(lens))
+    L = _oracle_plan(r2t, rpi, lens, ctx, min_shared)
+    assert cd.shared_len() == L
+    o = torch.zeros(bs, hq, dv, dtype=dtype, device=DEV)
+    kbd = kb.to(DEV)
+    cd(q.to(DEV), kbd, kbd[..., :dv], o, sm, ks, vs, 0.0, None if sinks is None else sinks.to(DEV), page_size=page)
+    tol = 3e-3 if dtype == torch.float16 else 1.5e-2
+    err = np.abs(o.float().cpu().numpy().astype(np.float64) - want).max()
+    parity.check(err, tol, err)
+
+
 def test_cascade_decode_fp8_pool(ops):
     """fp8 e4m3fn pool: both phases read the same bytes as plain decode."""
     bs, hq, hkv, d, page, shared = 16, 8, 2, 128, 16, 768
