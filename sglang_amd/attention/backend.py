@@ -295,7 +295,10 @@ class HipRadixAttnBackend:
         return order
 
     def _decode_metadata(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool) -> ForwardMetadata:
-        self._cascade_on = self.cascade_decode and bs >= self.cascade_min_bs
+        # (latent MLA rows are shared by all heads already: the cascade pays from ~128 requests on -- 64 x (3584 shared +
+        # 512 own): 54 -> 78 us per layer, 256: 194 -> 122, 256 x (8192 + 256): 348 -> 158; tools/cascade_bench.py MLA=1)
+        self._cascade_on = self.cascade_decode and bs >= (max(self.cascade_min_bs, 128) if self._is_mla_pool
+                                                          else self.cascade_min_bs)
         if self._cascade_on:
             if self._cascade is None:
                 kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))

@@ -622,7 +622,7 @@ class CascadeDecode:
         # itself): the decode kernel's single-pass epilogue folds the chunk partials in -- no fp32 partials, no
         # stage-2 launch.  (The side-stream overlap joins before stage 2, so it keeps >= 2 slots.)
         self.max_kv_splits = native_max_kv_splits(bs, self.hq, self.hkv, self.cu_count, self.split_cap)
-        if self._side is not None:
+        if self._side is not None or self.mla:  # (the MLA decode kernel has no single-pass fold: stage 2 merges)
             self.max_kv_splits = max(2, self.max_kv_splits)
         if self.max_kv_splits > 1:
             get_num_kv_splits_native(self.num_kv_splits[:bs], self.suffix_lens[:bs], self.hq, self.hkv,

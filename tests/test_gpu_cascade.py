@@ -118,6 +118,7 @@ MLA_CASES = [
     (5, 16, 1, 100, [101, 150, 333, 100, 129], 1),       # one request is the prefix itself (empty suffix)
     (4, 16, 16, 0, [100, 200, 300, 64], 64),             # nothing shared -> plain MLA decode
     (20, 8, 64, 1500, None, 256),                        # 160 (query, head) rows per chunk: two workgroups each
+    (300, 16, 16, 256, None, 64),                        # a batch that fills the chip: one suffix split per request
 ]
 
 
@@ -147,7 +148,7 @@ def test_cascade_decode_latent_mla(ops, case, dtype):
                                 k_scale=ks, v_scale=vs, sinks=None if sinks is None else sinks.numpy())
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
     cd = ops.CascadeDecode(bs, hq, 1, dk, dtype, DEV, max_shared=ctx, min_shared=min_shared, v_head_dim=dv,
-                           num_chunks=[None, 1, 3, None][case])
+                           num_chunks=[None, 1, 3, None, None][case])
     cd.plan(T(r2t), T(rpi), T(lens))
     L = _oracle_plan(r2t, rpi, lens, ctx, min_shared)
     assert cd.shared_len() == L
