@@ -531,6 +531,8 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
 int launch_extend32(const rx_extend_params* p, hipStream_t s);  // rx_extend32.hip (D = 128)
 bool extend_nd_supports(int dk, int dv);                          // rx_extend_nd.hip (256/256, 192/128, ...)
 int launch_extend_nd(const rx_extend_params* p, hipStream_t s);
+bool extend_d256_supports(const rx_extend_params* p);              // rx_extend_d256.hip (256 / 256, AGPR accumulators, LDS-DMA tiles)
+int launch_extend_d256(const rx_extend_params* p, hipStream_t s);
 bool extend_mla_supports(const rx_extend_params* p);               // rx_extend_mla.hip (576 / 512 over one latent kv head)
 int launch_extend_mla(const rx_extend_params* p, hipStream_t s);
 
@@ -590,6 +592,10 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   }
   if (mfma_ok && dk == 128 && o16 && (p->q_pack > 1 || p->kv.kv_fp8 || extras || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
     const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));
+    return rc != RX_OK ? rc : check_launch("rx_extend_attn");
+  }
+  if (extend_d256_supports(p) && !getenv("RX_EXTEND_NO_D256")) {
+    const int rc = launch_extend_d256(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }
   if (!extras && !p->kv.kv_fp8 && p->q_pack <= 1 && extend_nd_supports(dk, dv) && !getenv("RX_EXTEND_NO_ND")) {

@@ -1,0 +1,434 @@
+// K7 at head dim 256 (Gemma-class heads; the reference retunes its Triton kernel for 128 < D <= 256 on gfx950,
+// kernels/ops/attention/extend_attention.py:66-77) in the form rx_extend_mla.hip arrived at: the 16x16x32 kernel of
+// rx_extend_nd.hip holds 16 query rows per wave at Dv = 256 (64 accumulator registers; 32 rows spill 142 registers
+// there), so one K / V^T fragment read feeds ONE MFMA and the kernel is LDS-bound at 0.22 of the MFMA peak.  Here
+//   * a wave holds 32 rows: 128 accumulator registers pinned in the AGPR half by inline-asm MFMAs, Q (64 registers)
+//     and everything else in the 128 VGPRs, two waves per SIMD, eight waves = 256 rows per workgroup;
+//   * rows are (token, q head of the kv head's group) pairs, row = token * G + g (GQA packing: short extends still
+//     fill the block and a kv head's K / V tiles are staged once for its whole group);
+//   * 64-token K and V tiles come by LDS-DMA (no staging registers) into two stages of padded images (K rows 33
+//     chunks, V rows 36: conflict-free ds_read_b128 / ds_read_b64_tr_b16); waves 0-3 issue their pieces at the top
+//     of an iteration, their SIMD partners 4-7 behind their first QK^T, so one computes while the other sits in the
+//     memory queue; slot ids of 256 tokens at a time come into LDS by DMA as well;
+//   * thresholded running max (2^8 slack, exact algebra): the 128-register rescale runs on the first tile and almost
+//     never again; the mask is one compare + select per score on every tile.
+// Causal / non-causal, skip_prefix / skip_extend, LSE, k / v scales, 16-bit pools.  Everything else (windows, caps,
+// sinks, masks, short rows) stays with rx_extend_nd.hip / the generic kernel.
+#include <type_traits>
+
+#include "rx_common.h"
+
+namespace rx {
+
+constexpr int kYD = 256, kYTT = 64;
+constexpr int kYCpr = kYD * 2 / 16;          // 32 data chunks per row
+constexpr int kYKc = kYCpr + 1;              // K image row: 33 chunks (odd: 16 rows of a b128 pass on 16 chunk columns)
+constexpr int kYVc = kYCpr + 4;              // V image row: 36 chunks (64 B past a multiple of 256: transposed reads)
+constexpr int kYKrow = kYKc * 16, kYVrow = kYVc * 16;
+constexpr int kYKpieces = (kYTT * kYKc + 63) / 64;   // 33
+constexpr int kYVpieces = (kYTT * kYVc + 63) / 64;   // 36
+constexpr int kYKimg = kYKpieces * 1024, kYVimg = kYVpieces * 1024;
+constexpr int kYStage = kYKimg + kYVimg;     // 70656
+constexpr int kYSlotBlock = 256;
+constexpr int kYSlotsAt = 2 * kYStage;
+constexpr int kYLds = kYSlotsAt + 2 * kYSlotBlock * 4;  // 143360 B
+constexpr int kYRows = 256;                  // query rows per workgroup
+constexpr float kYSlack = 8.0f;
+
+struct ExtD256Args {
+  const uint16_t* q;
+  const uint16_t* k_ext;
+  const uint16_t* v_ext;
+  uint16_t* o;
+  int64_t q_stride_t, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_t, o_stride_h;
+  const uint16_t* k_buf;
+  const uint16_t* v_buf;
+  int32_t page_shift;  // log2(page_size), or -1 for a pool that is linear in the slot
+  int64_t k_page_stride, k_tok_stride, k_head_stride, v_page_stride, v_tok_stride, v_head_stride;
+  const void* qo_indptr;
+  int32_t qo64;
+  const int32_t* kv_indptr;
+  const void* kv_indices;
+  int32_t idx64;
+  float* lse;
+  int64_t lse_stride_t, lse_stride_h;
+  int32_t bs, hkv, group, mblocks;
+  float sm_scale, k_scale, v_scale;
+  int32_t causal, skip_prefix, skip_extend;
+};
+
+typedef __attribute__((address_space(3))) const u32x4* y_lds_u32x4;
+typedef __attribute__((address_space(3))) const int32_t* y_lds_i32;
+__device__ __forceinline__ u32x4 y_lds_read16(uint32_t addr) { return *reinterpret_cast<y_lds_u32x4>(addr); }
+__device__ __forceinline__ int32_t y_lds_read4(uint32_t addr) { return *reinterpret_cast<y_lds_i32>(addr); }
+// M0 is set and not restored (see rx_extend_mla.hip: hipcc uses M0 for nothing else in this kernel)
+__device__ __forceinline__ void y_dma4(const void* gsrc, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void y_dma16(const void* gsrc, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <typename T>
+__device__ __forceinline__ void y_pv_mfma(u32x4 a, u32x4 b, f32x4& c) {
+  if constexpr (std::is_same_v<T, BF16>) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+template <int N>
+__device__ __forceinline__ void y_settle(f32x4 (&o)[N]) {
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+a"(o[i]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a) {
+  using vec8 = typename T::vec8;
+  constexpr int KS = kYD / 32, NB = kYD / 16;  // 8 k-steps, 16 d-blocks
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages: K image | V image][2 slot blocks]
+  const uint32_t smem_u = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  // kv head = block mod Hkv: a kv head's prefix rows stay in one XCD's L2 (blocks go to the XCDs round robin)
+  int bid = blockIdx.x;
+  const int kvh = bid % a.hkv;
+  bid /= a.hkv;
+  const int mb = a.mblocks - 1 - bid % a.mblocks;  // heaviest query blocks first under the causal mask
+  const int req = bid / a.mblocks;
+
+  const int64_t qo0 = load_idx(a.qo_indptr, req, a.qo64);
+  const int32_t E = static_cast<int32_t>(load_idx(a.qo_indptr, req + 1, a.qo64) - qo0);
+  const int32_t kv0 = a.kv_indptr[req];
+  const int32_t P = a.kv_indptr[req + 1] - kv0;
+  const int32_t G = a.group;
+  const int32_t R = E * G;  // query rows of (request, kv head): row = token * G + g
+  const int32_t row0 = mb * kYRows;
+  if (row0 >= R) return;    // workgroup-uniform
+  const int32_t rbase = row0 + 32 * w;
+  const bool active = rbase < R;
+
+  const uint32_t g_magic = static_cast<uint32_t>(0x100000000ull / static_cast<uint32_t>(G)) + 1u;
+  auto row_tok = [&](int m) { return static_cast<int32_t>(__umulhi(static_cast<uint32_t>(m), g_magic)); };
+
+  // ---- Q^T fragments: block c, lane (r, g) holds Q[row rbase + 16 c + r][32 s + 8 g .. +8]
+  vec8 qf[2][KS];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int m = rbase + 16 * c + r;
+    const bool ok = m < R;
+    const int32_t tk = row_tok(ok ? m : 0);
+    const int32_t hd = kvh * G + ((ok ? m : 0) - tk * G);
+    const uint16_t* qp = a.q + (qo0 + tk) * a.q_stride_t + hd * a.q_stride_h + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
+      qf[c][s] = __builtin_bit_cast(vec8, raw);
+    }
+  }
+
+  const int32_t p_len = a.skip_prefix ? 0 : P;
+  const int32_t tok_hi_wg = (min(R, row0 + kYRows) - 1) / G + 1;
+  const int32_t tok_hi_w = active ? (min(R, rbase + 32) - 1) / G + 1 : 0;
+  const int32_t n_end_wg = a.skip_extend ? 0 : (a.causal ? tok_hi_wg : E);
+  const int32_t n_end_w = a.skip_extend ? 0 : (a.causal ? tok_hi_w : E);
+  const int nt1 = (p_len + kYTT - 1) / kYTT;
+  const int nt2 = (n_end_wg + kYTT - 1) / kYTT;
+  const int nt = nt1 + nt2;
+
+  const char* const idx_b = reinterpret_cast<const char*>(a.kv_indices);
+  const int idx_sh = a.idx64 ? 3 : 2;
+  auto stage_slots = [&](int blk) {  // waves 0-3: 256 slot ids by DMA (no compiler-visible VMEM in the loop)
+    if (w < 4) {
+      const int v = blk * kYSlotBlock + tid;
+      const int64_t e = kv0 + max(min(v, p_len - 1), 0);
+      y_dma4(idx_b + (e << idx_sh), __builtin_amdgcn_readfirstlane(smem_u + kYSlotsAt + ((blk & 1) * kYSlotBlock + 64 * w) * 4));
+    }
+  };
+  if (nt1 > 0) stage_slots(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q and the slot ids have landed
+  __syncthreads();
+
+  const char* const kbuf_b = reinterpret_cast<const char*>(a.k_buf + kvh * a.k_head_stride);
+  const char* const vbuf_b = reinterpret_cast<const char*>(a.v_buf + kvh * a.v_head_stride);
+  const char* const kext_b = reinterpret_cast<const char*>(a.k_ext + qo0 * a.k_stride_t + kvh * a.k_stride_h);
+  const char* const vext_b = reinterpret_cast<const char*>(a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h);
+  const int32_t sh_p = a.page_shift < 0 ? 31 : a.page_shift;
+  // this wave's pieces of an image: w, w + 8, ... (CPR chunks per padded row, NPIECES 1-KiB pieces)
+  auto dma_image = [&](int t, auto cpr_c, auto np_c, bool vside) {
+    constexpr int CPR = decltype(cpr_c)::value, NPIECES = decltype(np_c)::value;
+    constexpr int NP = (NPIECES + 7) / 8;  // 5
+    const bool pre = t < nt1;
+    const uint32_t sl = smem_u + kYSlotsAt + 4 * (((t * kYTT / kYSlotBlock) & 1) * kYSlotBlock + (t * kYTT) % kYSlotBlock);
+    const uint32_t img = smem_u + (t & 1) * kYStage + (vside ? kYKimg : 0);
+    const char* const base = pre ? (vside ? vbuf_b : kbuf_b) : (vside ? vext_b : kext_b);
+    const int32_t sh = pre ? sh_p : 31;
+    const uint32_t mask = sh == 31 ? 0x7fffffffu : (1u << sh) - 1u;
+    const uint32_t ts2 = 2u * static_cast<uint32_t>(pre ? (vside ? a.v_tok_stride : a.k_tok_stride) : (vside ? a.v_stride_t : a.k_stride_t));
+    const uint32_t ps2 = pre ? 2u * static_cast<uint32_t>(vside ? a.v_page_stride : a.k_page_stride) : 0u;
+    const bool paged = pre && sh != 31;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));  // opaque: the per-piece chunk arithmetic stays inside the loop
+    const int c0 = 64 * w + ln;   // < 512
+    int row = c0 / CPR, col = c0 - row * CPR;
+    int32_t slot[NP], col16[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool past = row >= kYTT;  // the last piece's tail: repeats a valid chunk
+      const int rw = past ? kYTT - 1 : row;
+      col16[i] = 16 * ((past || col >= kYCpr) ? kYCpr - 1 : col);  // pad chunks re-read the row's last data chunk
+      slot[i] = pre ? y_lds_read4(sl + 4 * rw) : max(min((t - nt1) * kYTT + rw, n_end_wg - 1), 0);
+      row += 512 / CPR;
+      col += 512 % CPR;
+      if (col >= CPR) {
+        col -= CPR;
+        row += 1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (w + 8 * i < NPIECES) {  // wave-uniform
+        uint64_t off = static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) & mask) * ts2 + static_cast<uint32_t>(col16[i]);
+        if (paged) off += static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) >> sh) * ps2;
+        y_dma16(base + off, __builtin_amdgcn_readfirstlane(img + (w + 8 * i) * 1024));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using KC = std::integral_constant<int, kYKc>;
+  using VC = std::integral_constant<int, kYVc>;
+  using KP = std::integral_constant<int, kYKpieces>;
+  using VP = std::integral_constant<int, kYVpieces>;
+  auto dma_tile = [&](int t) {
+    dma_image(t, KC{}, KP{}, false);
+    dma_image(t, VC{}, VP{}, true);
+  };
+  if (nt > 0) dma_tile(0);
+
+  f32x4 oacc[2][NB];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    m_run[c] = -INFINITY;
+    l_run[c] = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) oacc[c][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int qd = r >> 2, pp = r & 3;
+  const uint32_t k_lane = r * kYKrow + g * 16;
+  const uint32_t v_lane = (4 * g + qd) * kYVrow + 8 * (pp & 1) + (pp >> 1) * 16;
+  const bool late = w >= 4;  // the SIMD partner of an early wave: issues its pieces behind its first QK^T
+
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
+    __syncthreads();                                   // everybody's have; everybody is done with tile t - 1
+    constexpr int TPB = kYSlotBlock / kYTT;
+    if (t % TPB == 0 && (t / TPB + 1) * kYSlotBlock < nt1 * kYTT) stage_slots(t / TPB + 1);
+    const bool more = t + 1 < nt;
+    if (more && !late) dma_tile(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool prefix = t < nt1;
+    const int tile_n0 = (prefix ? t : t - nt1) * kYTT;
+    const int32_t lim = prefix ? p_len : n_end_w;
+    bool late_pending = more && late;
+    if (!active || tile_n0 >= lim) {
+      if (late_pending) dma_tile(t + 1);
+      continue;
+    }
+    const uint32_t kt = smem_u + (t & 1) * kYStage;
+    const uint32_t vt = kt + kYKimg;
+    const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
+    const float c2 = cs * kLog2e;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int n0 = tile_n0 + 32 * hh;
+      if (n0 >= lim) continue;  // nothing visible to this wave in this half (wave-uniform)
+      // ---- S^T = K Q^T: tokens 16 bb + 4 g + i of the half on the lane, query row r of block c
+      f32x4 sacc[2][2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) sacc[c][0] = sacc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        constexpr int PD = 4;
+        const uint32_t krow = kt + k_lane + 32 * hh * kYKrow;
+        auto kfrag = [&](int i) { return y_lds_read16(krow + (i / KS) * 16 * kYKrow + (i % KS) * 64); };
+        u32x4 kf[PD];
+#pragma unroll
+        for (int i = 0; i < PD; ++i) kf[i] = kfrag(i);
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) {
+          const vec8 ka = __builtin_bit_cast(vec8, kf[i % PD]);
+          if (i + PD < 2 * KS) kf[i % PD] = kfrag(i + PD);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) sacc[c][i / KS] = T::mfma(ka, qf[c][i % KS], sacc[c][i / KS]);
+          __builtin_amdgcn_sched_barrier(0);  // source order is the pipeline
+        }
+      }
+      if (hh == 0 && late_pending) {
+        dma_tile(t + 1);
+        late_pending = false;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      u32x4 pf[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float sv[8];
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
+        {
+          int lnm = lane;
+          asm volatile("" : "+v"(lnm));
+          const int32_t tk1 = row_tok(rbase + 16 * c + (lnm & 15)) + 1;
+          const int32_t vis = (prefix ? p_len : min(n_end_w, a.causal ? tk1 : E)) - n0 - 4 * (lnm >> 4);  // visible: index < vis
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i < vis) ? sv[bb * 4 + i] : -INFINITY;
+        }
+        float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+        mt = quad_row_max(mt) * c2;
+        const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
+        const float m_new = (mt_fixed > m_run[c] + kYSlack) ? mt_fixed : m_run[c];
+        const float alpha = fast_exp2(m_run[c] - m_new);
+        m_run[c] = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+          psum += sv[j];
+        }
+        l_run[c] = l_run[c] * alpha + psum;
+        if (prefix && a.v_scale != 1.0f) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sv[j] *= a.v_scale;
+        }
+        pf[c][0] = pack2<T>(sv[0], sv[1]);
+        pf[c][1] = pack2<T>(sv[2], sv[3]);
+        pf[c][2] = pack2<T>(sv[4], sv[5]);
+        pf[c][3] = pack2<T>(sv[6], sv[7]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // first tile; then only on a 2^8 jump
+          y_settle(oacc[c]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            oacc[c][nb] *= alpha;
+            asm volatile("" : "+a"(oacc[c][nb]));
+          }
+          y_settle(oacc[c]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- O^T += V^T P^T
+      const uint32_t rp0 = vt + v_lane + 32 * hh * kYVrow;
+      const uint32_t rp1 = rp0 + 16 * kYVrow;
+      constexpr int NPRE = 4;
+      u32x2 vlo[NPRE], vhi[NPRE];
+#pragma unroll
+      for (int nb = 0; nb < NPRE; ++nb) {
+        vlo[nb] = T::ds_read_tr((const void*)(uintptr_t)(rp0 + nb * 32));
+        vhi[nb] = T::ds_read_tr((const void*)(uintptr_t)(rp1 + nb * 32));
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const u32x2 lo = vlo[nb % NPRE], hi = vhi[nb % NPRE];
+        if (nb + NPRE < NB) {
+          vlo[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp0 + (nb + NPRE) * 32));
+          vhi[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp1 + (nb + NPRE) * 32));
+        }
+        const u32x4 av = u32x4{lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) y_pv_mfma<T>(av, pf[c], oacc[c][nb]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (late_pending) dma_tile(t + 1);  // (the first half had nothing visible)
+  }
+
+  if (!active) return;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    y_settle(oacc[c]);
+    float l = l_run[c];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const int m = rbase + 16 * c + r;
+    if (m >= R) continue;
+    const float inv = 1.0f / l;
+    const int32_t tk = m / G, hd = kvh * G + (m - tk * G);
+    uint16_t* op = a.o + (qo0 + tk) * a.o_stride_t + hd * a.o_stride_h + 4 * g;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      u32x2 pk;
+      pk[0] = pack2<T>(oacc[c][nb][0] * inv, oacc[c][nb][1] * inv);
+      pk[1] = pack2<T>(oacc[c][nb][2] * inv, oacc[c][nb][3] * inv);
+      *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (a.lse && g == 0) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run[c] * kLn2 + __logf(l);
+  }
+}
+
+// what the kernel serves: head dims 256 / 256 on a 16-bit pool, no window / cap / sinks / mask / unified form, aligned
+// tensors, and extends long enough to fill 256-row workgroups (short ones: rx_extend_nd.hip's smaller blocks)
+bool extend_d256_supports(const rx_extend_params* p) {
+  if (p->head_dim != kYD || p->v_head_dim != kYD || p->kv.kv_fp8) return false;
+  if (p->sliding_window_size > 0 || p->logit_cap > 0.f || p->sinks || p->custom_mask || p->xai_temperature_len > 0 ||
+      p->unified_prefix_lens || p->q_pack > 1)
+    return false;
+  const int64_t all = p->q_stride_t | p->q_stride_h | p->k_stride_t | p->k_stride_h | p->v_stride_t | p->v_stride_h |
+                      p->kv.k_page_stride | p->kv.k_tok_stride | p->kv.k_head_stride | p->kv.v_page_stride |
+                      p->kv.v_tok_stride | p->kv.v_head_stride;
+  if (all % 8 != 0 || (p->o_stride_t | p->o_stride_h) % 4 != 0) return false;
+  if ((((uintptr_t)p->q | (uintptr_t)p->k_extend | (uintptr_t)p->v_extend | (uintptr_t)p->kv.k_buf | (uintptr_t)p->kv.v_buf) & 15) != 0 ||
+      ((uintptr_t)p->o & 7) != 0)
+    return false;
+  const bool linear = p->kv.page_size == 1 || (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
+                                               p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
+  if (!linear && (p->kv.page_size & (p->kv.page_size - 1)) != 0) return false;
+  const int64_t group = p->num_q_heads / p->num_kv_heads;
+  if (static_cast<int64_t>(p->max_extend_len + 1) * group * group >= (1ll << 31)) return false;  // row -> token by multiply-high
+  return static_cast<int64_t>(p->max_extend_len) * group > 128;  // more than half a workgroup's rows
+}
+
+int launch_extend_d256(const rx_extend_params* p, hipStream_t s) {
+  ExtD256Args a;
+  a.q = (const uint16_t*)p->q;
+  a.k_ext = (const uint16_t*)p->k_extend;
+  a.v_ext = (const uint16_t*)p->v_extend;
+  a.o = (uint16_t*)p->o;
+  a.q_stride_t = p->q_stride_t; a.q_stride_h = p->q_stride_h;
+  a.k_stride_t = p->k_stride_t; a.k_stride_h = p->k_stride_h;
+  a.v_stride_t = p->v_stride_t; a.v_stride_h = p->v_stride_h;
+  a.o_stride_t = p->o_stride_t; a.o_stride_h = p->o_stride_h;
+  a.k_buf = (const uint16_t*)p->kv.k_buf;
+  a.v_buf = (const uint16_t*)p->kv.v_buf;
+  const bool linear = p->kv.page_size == 1 || (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
+                                               p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
+  a.page_shift = linear ? -1 : __builtin_ctz(p->kv.page_size);
+  a.k_page_stride = p->kv.k_page_stride; a.k_tok_stride = p->kv.k_tok_stride; a.k_head_stride = p->kv.k_head_stride;
+  a.v_page_stride = p->kv.v_page_stride; a.v_tok_stride = p->kv.v_tok_stride; a.v_head_stride = p->kv.v_head_stride;
+  a.qo_indptr = p->qo_indptr; a.qo64 = p->qo_indptr_is_i64;
+  a.kv_indptr = p->kv_indptr; a.kv_indices = p->kv_indices; a.idx64 = p->kv_indices_is_i64;
+  a.lse = p->lse; a.lse_stride_t = p->lse_stride_t; a.lse_stride_h = p->lse_stride_h;
+  a.bs = p->bs; a.hkv = p->num_kv_heads;
+  a.group = p->num_q_heads / p->num_kv_heads;
+  a.mblocks = static_cast<int32_t>((static_cast<int64_t>(p->max_extend_len) * a.group + kYRows - 1) / kYRows);
+  a.sm_scale = p->sm_scale; a.k_scale = p->k_scale; a.v_scale = p->v_scale;
+  a.causal = p->is_causal; a.skip_prefix = p->skip_prefix; a.skip_extend = p->skip_extend;
+  const unsigned grid = static_cast<unsigned>(a.bs) * a.hkv * a.mblocks;
+  static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_d256_kernel<BF16>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kYLds);
+  static const hipError_t attr_h = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_d256_kernel<F16>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kYLds);
+  (void)attr_b;
+  (void)attr_h;
+  if (p->dtype == RX_BF16) hipLaunchKernelGGL(extend_d256_kernel<BF16>, dim3(grid), dim3(512), kYLds, s, a);
+  else hipLaunchKernelGGL(extend_d256_kernel<F16>, dim3(grid), dim3(512), kYLds, s, a);
+  return RX_OK;
+}
+
+}  // namespace rx
