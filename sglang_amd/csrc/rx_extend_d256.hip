@@ -31,7 +31,14 @@ constexpr int kYKimg = kYKpieces * 1024, kYVimg = kYVpieces * 1024;
 constexpr int kYStage = kYKimg + kYVimg;     // 70656
 constexpr int kYSlotBlock = 256;
 constexpr int kYSlotsAt = 2 * kYStage;
-constexpr int kYLds = kYSlotsAt + 2 * kYSlotBlock * 4;  // 143360 B
+#ifndef RX_D256_NQL
+#define RX_D256_NQL 0  // k-steps of Q parked in LDS (per wave 2 x NQL KiB; read at the head of every QK^T pass)
+#endif
+constexpr int kYNql = RX_D256_NQL;
+constexpr int kYQtailAt = kYSlotsAt + 2 * kYSlotBlock * 4;
+constexpr int kYBounceAt = kYQtailAt + 8 * 2 * kYNql * 1024;
+constexpr int kYLds = kYBounceAt + 8 * 1024;  // 143360 + NQL * 16384 + 8192 B
+static_assert(kYLds <= 160 * 1024, "LDS budget");
 constexpr int kYRows = 256;                  // query rows per workgroup
 constexpr float kYSlack = 8.0f;
 
@@ -114,7 +121,9 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   auto row_tok = [&](int m) { return static_cast<int32_t>(__umulhi(static_cast<uint32_t>(m), g_magic)); };
 
   // ---- Q^T fragments: block c, lane (r, g) holds Q[row rbase + 16 c + r][32 s + 8 g .. +8]
-  vec8 qf[2][KS];
+  constexpr int KSR = KS - kYNql;
+  vec8 qf[2][KSR];
+  const uint32_t qtail = smem_u + kYQtailAt + (w * 2 * kYNql * 64 + lane) * 16;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int m = rbase + 16 * c + r;
@@ -125,7 +134,8 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
-      qf[c][s] = __builtin_bit_cast(vec8, raw);
+      if (s < KSR) qf[c][s] = __builtin_bit_cast(vec8, raw);
+      else *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(qtail + (c * kYNql + s - KSR) * 1024) = raw;
     }
   }
 
@@ -220,6 +230,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   const int qd = r >> 2, pp = r & 3;
   const uint32_t k_lane = r * kYKrow + g * 16;
   const uint32_t v_lane = (4 * g + qd) * kYVrow + 8 * (pp & 1) + (pp >> 1) * 16;
+  const uint32_t bounce = smem_u + kYBounceAt + (w * 64 + lane) * 16;  // this lane's 16 bytes of the rescale bounce
   const bool late = w >= 4;  // the SIMD partner of an early wave: issues its pieces behind its first QK^T
 
   for (int t = 0; t < nt; ++t) {
@@ -254,6 +265,11 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
         constexpr int PD = 4;
         const uint32_t krow = kt + k_lane + 32 * hh * kYKrow;
         auto kfrag = [&](int i) { return y_lds_read16(krow + (i / KS) * 16 * kYKrow + (i % KS) * 64); };
+        u32x4 qt[2][kYNql];  // parked Q fragments: temporaries of this pass
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int j = 0; j < kYNql; ++j) qt[c][j] = y_lds_read16(qtail + (c * kYNql + j) * 1024);
         u32x4 kf[PD];
 #pragma unroll
         for (int i = 0; i < PD; ++i) kf[i] = kfrag(i);
@@ -262,7 +278,10 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
           const vec8 ka = __builtin_bit_cast(vec8, kf[i % PD]);
           if (i + PD < 2 * KS) kf[i % PD] = kfrag(i + PD);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) sacc[c][i / KS] = T::mfma(ka, qf[c][i % KS], sacc[c][i / KS]);
+          for (int c = 0; c < 2; ++c) {
+            const vec8 qb = (i % KS < KSR) ? qf[c][i % KS < KSR ? i % KS : 0] : __builtin_bit_cast(vec8, qt[c][i % KS < KSR ? 0 : i % KS - KSR]);
+            sacc[c][i / KS] = T::mfma(ka, qb, sacc[c][i / KS]);
+          }
           __builtin_amdgcn_sched_barrier(0);  // source order is the pipeline
         }
       }
@@ -272,6 +291,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
       }
       __builtin_amdgcn_sched_barrier(0);
       u32x4 pf[2];
+      float alpha_c[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         float sv[8];
@@ -310,15 +330,26 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
         pf[c][1] = pack2<T>(sv[2], sv[3]);
         pf[c][2] = pack2<T>(sv[4], sv[5]);
         pf[c][3] = pack2<T>(sv[6], sv[7]);
+        alpha_c[c] = alpha;
         __builtin_amdgcn_sched_barrier(0);
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // first tile; then only on a 2^8 jump
-          y_settle(oacc[c]);
+      }
+      // ONE rescale branch behind both blocks' softmax (first tile; then only on a 2^8 jump): inside the block loop
+      // the branch is the kernel's register peak (53 spilled registers)
+      if (__builtin_amdgcn_ballot_w64(alpha_c[0] != 1.0f || alpha_c[1] != 1.0f) != 0) {
+        // The accumulators never pass through compiler-visible code: any C++ access makes hipcc route their live ranges
+        // through the VGPR half (53 spilled registers, Q fragments reloaded every half tile).  They bounce through one
+        // KiB of LDS instead -- ds_write from / ds_read into the AGPRs in asm, the multiply on a VGPR copy in between.
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // XDL write -> LDS read of the accumulators
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
-            oacc[c][nb] *= alpha;
-            asm volatile("" : "+a"(oacc[c][nb]));
+            asm volatile("ds_write_b128 %0, %1" : : "v"(bounce), "a"(oacc[c][nb]) : "memory");
+            f32x4 tv = *reinterpret_cast<__attribute__((address_space(3))) const f32x4*>(bounce);
+            tv *= alpha_c[c];
+            *reinterpret_cast<__attribute__((address_space(3))) f32x4*>(bounce) = tv;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=a"(oacc[c][nb]) : "v"(bounce) : "memory");
           }
-          y_settle(oacc[c]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);

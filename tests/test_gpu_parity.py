@@ -423,7 +423,7 @@ def test_extend_generic_head_dims(ops, d):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("dk,dv", [(256, 256), (192, 128), (192, 192), (96, 96)])
-@pytest.mark.parametrize("variant", ["plain", "window", "cap_sinks_noncausal", "hnd_pool", "short_extends"])
+@pytest.mark.parametrize("variant", ["plain", "window", "cap_sinks_noncausal", "hnd_pool", "short_extends", "max_jumps"])
 def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
     """rx::extend_nd_kernel (MFMA 16x16x32 for head dims 256 / 192+128 / 192 / 96 -- the shapes the reference retunes
     for gfx950, extend_attention.py:66-77, and the MLA prefill shape) vs the fp64 oracle: ragged batch with zero /
@@ -453,6 +453,9 @@ def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
         s_ = slots[so: so + pre[i] + ext[i]]; so += pre[i] + ext[i]
         kv_indices[kv_indptr[i]: kv_indptr[i + 1]] = s_[: pre[i]]
         ext_slots[qo[i]: qo[i + 1]] = s_[pre[i]:]
+        if variant == "max_jumps":   # keys that grow along the sequence: the running max jumps by far more than 2^8 several
+            n = len(s_)              # times per row (the kernels with AGPR accumulators rescale only on such jumps)
+            kb[torch.from_numpy(s_.copy())] *= torch.linspace(0.05, 3.0, n).pow(3).view(n, 1, 1).to(dtype)
     ke, ve = kb[ext_slots], vb[ext_slots]
     kw, okw = {}, {}
     causal = True
@@ -484,7 +487,7 @@ def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("variant", ["aliased", "own_v", "own_v_new_tokens", "noncausal", "skip_prefix", "skip_extend",
-                                     "many_requests_int32", "paged_pool"])
+                                     "many_requests_int32", "paged_pool", "max_jumps", "max_jumps_own_v"])
 def test_extend_mla_latent_shape(ops, dtype, variant):
     """rx::extend_mla_kernel (q 576 against one latent kv head, v = the first 512 columns: the absorbed-MLA extend of
     triton_backend.py:1290-1437 / extend_attention.py:241-661 at Lq 576, Lv 512) vs the fp64 oracle.  Ragged batch:
@@ -508,6 +511,9 @@ def test_extend_mla_latent_shape(ops, dtype, variant):
     slots = rng.permutation(pool - ps)[:total] + ps
     g = torch.Generator().manual_seed(11)
     kb = (torch.randn(pool, 1, dk, generator=g) * 0.5).to(dtype)
+    if variant.startswith("max_jumps"):  # keys that grow along the pool: the running max jumps by far more than 2^8
+        kb *= torch.linspace(0.05, 2.5, pool).pow(3).view(pool, 1, 1).to(dtype)
+        slots = np.sort(slots[: int((pre + ext).sum())])  # ascending slots = ascending key norms along every sequence
     own_pool_v = variant == "own_v"
     vb = (torch.randn(pool, 1, dv, generator=g).to(dtype)) if own_pool_v else kb[..., :dv]
     q = torch.randn(T, hq, dk, generator=g).to(dtype)
@@ -521,7 +527,7 @@ def test_extend_mla_latent_shape(ops, dtype, variant):
         kv_indices[kv_indptr[i]: kv_indptr[i + 1]] = s_[: pre[i]]
         ext_slots[qo[i]: qo[i + 1]] = s_[pre[i]:]
     ke = kb[ext_slots].contiguous()
-    if variant in ("own_v", "own_v_new_tokens"):
+    if variant in ("own_v", "own_v_new_tokens", "max_jumps_own_v"):
         ve = torch.randn(T, 1, dv, generator=g).to(dtype)
     else:
         ve = ke[..., :dv]
@@ -533,7 +539,7 @@ def test_extend_mla_latent_shape(ops, dtype, variant):
     kbd = kb.to(DEV)
     vbd = vb.to(DEV) if own_pool_v else kbd[..., :dv]
     ked = ke.to(DEV)
-    ved = ve.to(DEV) if variant in ("own_v", "own_v_new_tokens") else ked[..., :dv]
+    ved = ve.to(DEV) if variant in ("own_v", "own_v_new_tokens", "max_jumps_own_v") else ked[..., :dv]
     lay = None
     if variant == "paged_pool":    # [pages, 1, page, 576] with a padded page stride: page / offset addressing
         big = torch.zeros(n_pages, ps * dk + 64, dtype=dtype, device=DEV)
