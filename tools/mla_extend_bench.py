@@ -66,7 +66,7 @@ def run(bs, P, E, hq, own_v, iters):
     flops = 2.0 * (DK + DV) * hq * bs * (E * P + E * (E + 1) / 2)
     if lse is not None:  # a build with -DRX_XMLA_STAMP=1: per-workgroup phase cycles of wave 0 (s_memtime, 100 MHz ticks)
         nwg = ((bs + 7) // 8 * 8 if bs >= 8 else bs) * ((E * hq + 127) // 128)
-        if not os.environ.get("RX_XMLA_4W") and not own_v:  # the eight-wave form writes two records per workgroup: wave 0 (early DMA) and wave 4 (late)
+        if True:  # the eight-wave form writes two records per workgroup: wave 0 (early DMA) and wave 4 (late)
             rec = lse.view(torch.int32).flatten()[: 16 * nwg].view(nwg, 2, 8).double()
             for nm, st in (("wave 0", rec[:, 0]), ("wave 4", rec[:, 1])):
                 st = st[st[:, 5] > 0]
