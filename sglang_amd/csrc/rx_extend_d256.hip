@@ -1,4 +1,4 @@
-// K7 at head dim 256 (Gemma-class heads; the reference retunes its Triton kernel for 128 < D <= 256 on gfx950,
+// K7 at head dims 256 / 256, 192 / 192 and 192 / 128 (Gemma-class heads and the MLA prefill shape; the reference retunes its Triton kernel for 128 < D <= 256 on gfx950,
 // kernels/ops/attention/extend_attention.py:66-77) in the form rx_extend_mla.hip arrived at: the 16x16x32 kernel of
 // rx_extend_nd.hip holds 16 query rows per wave at Dv = 256 (64 accumulator registers; 32 rows spill 142 registers
 // there), so one K / V^T fragment read feeds ONE MFMA and the kernel is LDS-bound at 0.22 of the MFMA peak.  Here
@@ -20,27 +20,26 @@
 
 namespace rx {
 
-constexpr int kYD = 256, kYTT = 64;
-constexpr int kYCpr = kYD * 2 / 16;          // 32 data chunks per row
-constexpr int kYKc = kYCpr + 1;              // K image row: 33 chunks (odd: 16 rows of a b128 pass on 16 chunk columns)
-constexpr int kYVc = kYCpr + 4;              // V image row: 36 chunks (64 B past a multiple of 256: transposed reads)
-constexpr int kYKrow = kYKc * 16, kYVrow = kYVc * 16;
-constexpr int kYKpieces = (kYTT * kYKc + 63) / 64;   // 33
-constexpr int kYVpieces = (kYTT * kYVc + 63) / 64;   // 36
-constexpr int kYKimg = kYKpieces * 1024, kYVimg = kYVpieces * 1024;
-constexpr int kYStage = kYKimg + kYVimg;     // 70656
+constexpr int kYTT = 64;
 constexpr int kYSlotBlock = 256;
-constexpr int kYSlotsAt = 2 * kYStage;
-#ifndef RX_D256_NQL
-#define RX_D256_NQL 0  // k-steps of Q parked in LDS (per wave 2 x NQL KiB; read at the head of every QK^T pass)
-#endif
-constexpr int kYNql = RX_D256_NQL;
-constexpr int kYQtailAt = kYSlotsAt + 2 * kYSlotBlock * 4;
-constexpr int kYBounceAt = kYQtailAt + 8 * 2 * kYNql * 1024;
-constexpr int kYLds = kYBounceAt + 8 * 1024;  // 143360 + NQL * 16384 + 8192 B
-static_assert(kYLds <= 160 * 1024, "LDS budget");
 constexpr int kYRows = 256;                  // query rows per workgroup
 constexpr float kYSlack = 8.0f;
+
+// (Dk, Dv): 256 / 256, and the MLA prefill shape 192 / 128 (qk_nope 128 + rope 64 against v 128) and 192 / 192
+template <int DK, int DV>
+struct YGeom {
+  static constexpr int KCPR = DK * 2 / 16, VCPR = DV * 2 / 16;  // data chunks per row
+  static constexpr int KC = KCPR + 1;   // K image row: an odd number of chunks (16 rows of a b128 pass on 16 chunk columns)
+  static constexpr int VC = VCPR + (((DV * 2 + 64) % 256 == 0) ? 2 : 4);  // V image row: 64 B past a multiple of 256 (transposed reads)
+  static constexpr int KROW = KC * 16, VROW = VC * 16;
+  static constexpr int KPIECES = (kYTT * KC + 63) / 64, VPIECES = (kYTT * VC + 63) / 64;
+  static constexpr int KIMG = KPIECES * 1024, VIMG = VPIECES * 1024;
+  static constexpr int STAGE = KIMG + VIMG;
+  static constexpr int SLOTS_AT = 2 * STAGE;
+  static constexpr int BOUNCE_AT = SLOTS_AT + 2 * kYSlotBlock * 4;
+  static constexpr int LDS = BOUNCE_AT + 8 * 1024;  // 256 / 256: 151552 B
+  static_assert(KC % 2 == 1 && LDS <= 160 * 1024, "image geometry");
+};
 
 struct ExtD256Args {
   const uint16_t* q;
@@ -87,10 +86,13 @@ __device__ __forceinline__ void y_settle(f32x4 (&o)[N]) {
   for (int i = 0; i < N; ++i) asm volatile("" : "+a"(o[i]));
 }
 
-template <typename T>
+template <typename T, int DK, int DV>
 __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a) {
   using vec8 = typename T::vec8;
-  constexpr int KS = kYD / 32, NB = kYD / 16;  // 8 k-steps, 16 d-blocks
+  using Y = YGeom<DK, DV>;
+  constexpr int KS = DK / 32, NB = DV / 16;  // k-steps, d-blocks
+  constexpr int kYKrow = Y::KROW, kYVrow = Y::VROW, kYKimg = Y::KIMG, kYStage = Y::STAGE, kYSlotsAt = Y::SLOTS_AT,
+                kYBounceAt = Y::BOUNCE_AT, kYKc = Y::KC, kYVc = Y::VC, kYKpieces = Y::KPIECES, kYVpieces = Y::VPIECES;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages: K image | V image][2 slot blocks]
   const uint32_t smem_u = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
 
@@ -121,9 +123,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   auto row_tok = [&](int m) { return static_cast<int32_t>(__umulhi(static_cast<uint32_t>(m), g_magic)); };
 
   // ---- Q^T fragments: block c, lane (r, g) holds Q[row rbase + 16 c + r][32 s + 8 g .. +8]
-  constexpr int KSR = KS - kYNql;
-  vec8 qf[2][KSR];
-  const uint32_t qtail = smem_u + kYQtailAt + (w * 2 * kYNql * 64 + lane) * 16;
+  vec8 qf[2][KS];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int m = rbase + 16 * c + r;
@@ -134,8 +134,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
-      if (s < KSR) qf[c][s] = __builtin_bit_cast(vec8, raw);
-      else *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(qtail + (c * kYNql + s - KSR) * 1024) = raw;
+      qf[c][s] = __builtin_bit_cast(vec8, raw);
     }
   }
 
@@ -167,8 +166,8 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   const char* const vext_b = reinterpret_cast<const char*>(a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h);
   const int32_t sh_p = a.page_shift < 0 ? 31 : a.page_shift;
   // this wave's pieces of an image: w, w + 8, ... (CPR chunks per padded row, NPIECES 1-KiB pieces)
-  auto dma_image = [&](int t, auto cpr_c, auto np_c, bool vside) {
-    constexpr int CPR = decltype(cpr_c)::value, NPIECES = decltype(np_c)::value;
+  auto dma_image = [&](int t, auto cpr_c, auto np_c, auto data_c, bool vside) {
+    constexpr int CPR = decltype(cpr_c)::value, NPIECES = decltype(np_c)::value, DATA = decltype(data_c)::value;
     constexpr int NP = (NPIECES + 7) / 8;  // 5
     const bool pre = t < nt1;
     const uint32_t sl = smem_u + kYSlotsAt + 4 * (((t * kYTT / kYSlotBlock) & 1) * kYSlotBlock + (t * kYTT) % kYSlotBlock);
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
     for (int i = 0; i < NP; ++i) {
       const bool past = row >= kYTT;  // the last piece's tail: repeats a valid chunk
       const int rw = past ? kYTT - 1 : row;
-      col16[i] = 16 * ((past || col >= kYCpr) ? kYCpr - 1 : col);  // pad chunks re-read the row's last data chunk
+      col16[i] = 16 * ((past || col >= DATA) ? DATA - 1 : col);  // pad chunks re-read the row's last data chunk
       slot[i] = pre ? y_lds_read4(sl + 4 * rw) : max(min((t - nt1) * kYTT + rw, n_end_wg - 1), 0);
       row += 512 / CPR;
       col += 512 % CPR;
@@ -211,9 +210,11 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   using VC = std::integral_constant<int, kYVc>;
   using KP = std::integral_constant<int, kYKpieces>;
   using VP = std::integral_constant<int, kYVpieces>;
+  using KD = std::integral_constant<int, Y::KCPR>;
+  using VD = std::integral_constant<int, Y::VCPR>;
   auto dma_tile = [&](int t) {
-    dma_image(t, KC{}, KP{}, false);
-    dma_image(t, VC{}, VP{}, true);
+    dma_image(t, KC{}, KP{}, KD{}, false);
+    dma_image(t, VC{}, VP{}, VD{}, true);
   };
   if (nt > 0) dma_tile(0);
 
@@ -265,11 +266,6 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
         constexpr int PD = 4;
         const uint32_t krow = kt + k_lane + 32 * hh * kYKrow;
         auto kfrag = [&](int i) { return y_lds_read16(krow + (i / KS) * 16 * kYKrow + (i % KS) * 64); };
-        u32x4 qt[2][kYNql];  // parked Q fragments: temporaries of this pass
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int j = 0; j < kYNql; ++j) qt[c][j] = y_lds_read16(qtail + (c * kYNql + j) * 1024);
         u32x4 kf[PD];
 #pragma unroll
         for (int i = 0; i < PD; ++i) kf[i] = kfrag(i);
@@ -278,10 +274,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
           const vec8 ka = __builtin_bit_cast(vec8, kf[i % PD]);
           if (i + PD < 2 * KS) kf[i % PD] = kfrag(i + PD);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const vec8 qb = (i % KS < KSR) ? qf[c][i % KS < KSR ? i % KS : 0] : __builtin_bit_cast(vec8, qt[c][i % KS < KSR ? 0 : i % KS - KSR]);
-            sacc[c][i / KS] = T::mfma(ka, qb, sacc[c][i / KS]);
-          }
+          for (int c = 0; c < 2; ++c) sacc[c][i / KS] = T::mfma(ka, qf[c][i % KS], sacc[c][i / KS]);
           __builtin_amdgcn_sched_barrier(0);  // source order is the pipeline
         }
       }
@@ -406,7 +399,8 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
 // what the kernel serves: head dims 256 / 256 on a 16-bit pool, no window / cap / sinks / mask / unified form, aligned
 // tensors, and extends long enough to fill 256-row workgroups (short ones: rx_extend_nd.hip's smaller blocks)
 bool extend_d256_supports(const rx_extend_params* p) {
-  if (p->head_dim != kYD || p->v_head_dim != kYD || p->kv.kv_fp8) return false;
+  const int dk = p->head_dim, dv = p->v_head_dim;
+  if (!((dk == 256 && dv == 256) || (dk == 192 && (dv == 128 || dv == 192))) || p->kv.kv_fp8) return false;
   if (p->sliding_window_size > 0 || p->logit_cap > 0.f || p->sinks || p->custom_mask || p->xai_temperature_len > 0 ||
       p->unified_prefix_lens || p->q_pack > 1)
     return false;
@@ -451,14 +445,27 @@ int launch_extend_d256(const rx_extend_params* p, hipStream_t s) {
   a.sm_scale = p->sm_scale; a.k_scale = p->k_scale; a.v_scale = p->v_scale;
   a.causal = p->is_causal; a.skip_prefix = p->skip_prefix; a.skip_extend = p->skip_extend;
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hkv * a.mblocks;
-  static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_d256_kernel<BF16>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kYLds);
-  static const hipError_t attr_h = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_d256_kernel<F16>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kYLds);
-  (void)attr_b;
-  (void)attr_h;
-  if (p->dtype == RX_BF16) hipLaunchKernelGGL(extend_d256_kernel<BF16>, dim3(grid), dim3(512), kYLds, s, a);
-  else hipLaunchKernelGGL(extend_d256_kernel<F16>, dim3(grid), dim3(512), kYLds, s, a);
+#define RX_D256(TT, DK_, DV_)                                                                                          \
+  do {                                                                                                               \
+    constexpr int lds_ = YGeom<DK_, DV_>::LDS;                                                                       \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_d256_kernel<TT, DK_, DV_>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_);            \
+    (void)attr;                                                                                                      \
+    hipLaunchKernelGGL((extend_d256_kernel<TT, DK_, DV_>), dim3(grid), dim3(512), lds_, s, a);                        \
+  } while (0)
+  const bool bf = p->dtype == RX_BF16;
+  const int dk = p->head_dim, dv = p->v_head_dim;
+  if (dk == 256) {
+    if (bf) RX_D256(BF16, 256, 256);
+    else RX_D256(F16, 256, 256);
+  } else if (dv == 128) {
+    if (bf) RX_D256(BF16, 192, 128);
+    else RX_D256(F16, 192, 128);
+  } else {
+    if (bf) RX_D256(BF16, 192, 192);
+    else RX_D256(F16, 192, 192);
+  }
+#undef RX_D256
   return RX_OK;
 }
 
