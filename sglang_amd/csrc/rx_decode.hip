@@ -752,7 +752,7 @@ static void launch_merge(const DecodeArgs& a, int dv, hipStream_t s) {
 
 template <typename T, typename IdxT, bool LINEAR>
 static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
-  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128 || (dk == 256 && !a.kv_fp8));
   if (a.stages == 2) {
     launch_merge<T>(a, dv, s);
     return check_launch("rx_decode_attn");
@@ -769,7 +769,8 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
       else RX_DEC(128, false, true);
     } else {
       if (dk == 64) RX_DEC(64, false, false);
-      else RX_DEC(128, false, false);
+      else if (dk == 128) RX_DEC(128, false, false);
+      else RX_DEC(256, false, false);  // Gemma-class heads: the same kernel, 64 accumulator registers per wave
     }
 #undef RX_DEC
   } else {
@@ -839,7 +840,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
                "rx_decode_attn: max_kv_splits=%d needs attn_logits, attn_lse and num_kv_splits",
                max_splits);
   const int dk = p->head_dim, dv = p->v_head_dim;
-  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128);
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128 || (dk == 256 && !p->kv.kv_fp8));
   if (mfma_ok) {
     // 16-byte vector loads: every stride a multiple of 8 elements, bases 16-byte aligned
     const int64_t all = p->q_stride_t | p->q_stride_h | p->kv.k_page_stride | p->kv.k_tok_stride |
@@ -938,7 +939,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.k_new = a.v_new = nullptr;
   if (p->k_new || p->v_new) {
     RX_REQUIRE(p->k_new && p->v_new, "rx_decode_attn: k_new and v_new come together");
-    RX_REQUIRE(mfma_ok && !mla && !p->kv.kv_fp8 && a.qblocks == 1 && p->stages != 2,
+    RX_REQUIRE(mfma_ok && dk != 256 && !mla && !p->kv.kv_fp8 && a.qblocks == 1 && p->stages != 2,
                "rx_decode_attn: the fused store needs the D = 64 / 128 kernel on a 16-bit pool with at most 16 q heads "
                "per kv head, in a call that runs stage 1 (store with rx_store_kv* instead)");
     RX_REQUIRE((((uintptr_t)p->k_new | (uintptr_t)p->v_new) & 15) == 0 &&

@@ -331,6 +331,54 @@ def test_decode_generic_head_dims(ops, hq, hkv, dk, dv):
     np.testing.assert_allclose(_np(o.float()), want, atol=1e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("mode", ["indices_splits", "paged_single", "paged_hnd_splits"])
+def test_decode_head_dim_256(ops, dtype, mode):
+    """D = 256 (Gemma-class heads) on the MFMA split-KV decode kernel (the reference's kernel takes any Lk; here
+    head dims other than 64 / 128 ran the scalar generic kernel until round 2): ragged lengths incl. 1 and tile
+    crossings, GQA 8 / 2 and 16 q heads per kv head, kv splits, paged HND pool -- vs the fp64 oracle."""
+    rng = np.random.default_rng(256)
+    hq, hkv, d, ps = 16, 2, 256, 16
+    lens = np.array([1, 31, 32, 33, 200, 517], dtype=np.int64)
+    bs = len(lens)
+    n_pages = int(sum(-(-int(n) // ps) for n in lens)) + 2
+    pool = n_pages * ps
+    ids = rng.permutation(np.arange(1, n_pages))
+    ctx = int(lens.max()) + ps
+    r2t = np.zeros((bs + 1, ctx), dtype=np.int32)
+    pi = 0
+    for i, n in enumerate(lens):
+        k_ = -(-int(n) // ps)
+        row = (ids[pi: pi + k_, None] * ps + np.arange(ps)[None]).reshape(-1)[: int(n)]
+        pi += k_
+        r2t[i + 1, : len(row)] = row
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    g = torch.Generator().manual_seed(6)
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    q = torch.randn(bs, hq, d, generator=g).to(dtype)
+    sm = d ** -0.5
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
+    want = orc.decode_attention(_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, sm)
+    o = torch.zeros(bs, hq, d, dtype=dtype, device=DEV)
+    S = 8
+    nsplit = torch.tensor([1, 1, 2, 2, 4, 8], dtype=torch.int32, device=DEV)
+    al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
+    lse = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+    if mode == "indices_splits":
+        ops.decode_attention_fwd(q.to(DEV), kb.to(DEV), vb.to(DEV), o, _t(kv_indptr), _t(kv_indices), al, lse, nsplit, S,
+                                 sm, 1.0, 1.0, page_size=1)
+    elif mode == "paged_single":
+        ops.decode_attention_fwd_paged(q.to(DEV), kb.to(DEV), vb.to(DEV), o, _t(r2t), _t(rpi), _t(lens), None, None, None,
+                                       1, sm, page_size=ps)
+    else:
+        k_hnd = kb.to(DEV).view(n_pages, ps, hkv, d).permute(0, 2, 1, 3).contiguous()
+        v_hnd = vb.to(DEV).view(n_pages, ps, hkv, d).permute(0, 2, 1, 3).contiguous()
+        ops.decode_attention_fwd_paged(q.to(DEV), k_hnd, v_hnd, o, _t(r2t), _t(rpi), _t(lens), al, lse, nsplit, S, sm,
+                                       page_size=ps, kv_layout=ops.kv_layout_hnd(k_hnd, v_hnd))
+    parity.check_out(_np(o.float()), want, dtype, ("decode_d256", mode))
+
+
 # ---------------------------------------------------------------------------- K7 extend
 def _run_extend(ops, c, with_lse=True):
     q, ke, ve, kb, vb = (_t(c[k]) for k in ("q", "k_ext", "v_ext", "kb", "vb"))

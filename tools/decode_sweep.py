@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sglang_amd import ops
 
 dev = "cuda"
-HQ, HKV, D, PS = int(os.environ.get("HQ", "32")), int(os.environ.get("HKV", "8")), 128, 16
+HQ, HKV, D, PS = int(os.environ.get("HQ", "32")), int(os.environ.get("HKV", "8")), int(os.environ.get("D", "128")), 16
 def run(bs, ctx, splits_list):
     pages = ctx // PS
     rng = np.random.default_rng(0)
