@@ -377,6 +377,14 @@ def test_decode_head_dim_256(ops, dtype, mode):
         ops.decode_attention_fwd_paged(q.to(DEV), k_hnd, v_hnd, o, _t(r2t), _t(rpi), _t(lens), al, lse, nsplit, S, sm,
                                        page_size=ps, kv_layout=ops.kv_layout_hnd(k_hnd, v_hnd))
     parity.check_out(_np(o.float()), want, dtype, ("decode_d256", mode))
+    if mode == "indices_splits":   # stage 2 inside the stage-1 kernel: the same bits, counters back at zero
+        cnt = torch.zeros(bs * hq, dtype=torch.int32, device=DEV)
+        for rep in range(2):
+            o2 = torch.full_like(o, float("nan"))
+            ops.decode_attention_fwd(q.to(DEV), kb.to(DEV), vb.to(DEV), o2, _t(kv_indptr), _t(kv_indices), al, lse, nsplit,
+                                     S, sm, 1.0, 1.0, page_size=1, merge_counters=cnt)
+            assert torch.equal(o2, o), (rep, (o2.float() - o.float()).abs().max().item())
+            assert int(cnt.abs().sum()) == 0
 
 
 # ---------------------------------------------------------------------------- K7 extend
