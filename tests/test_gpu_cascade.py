@@ -65,6 +65,8 @@ CASES = [
     (6, 8, 2, 128, 16, 48, [100, 200, 300, 64, 90, 77], 64),       # shared but below min_shared -> L = 0
     (1, 8, 2, 128, 16, 0, [777], 16),                              # bs 1: everything is "shared"
     (130, 4, 1, 128, 64, 1024, None, 256),                         # > 128 queries per head (two M blocks)
+    (40, 8, 2, 256, 16, 600, None, 64),                            # head dim 256: extend_d256_kernel + the MFMA decode kernel
+    (6, 16, 2, 256, 16, 300, [301, 420, 333, 300, 512, 400], 64),  # (few rows per kv head: extend_nd_kernel in phase 1)
 ]
 
 
