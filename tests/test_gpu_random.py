@@ -147,6 +147,52 @@ def test_random_extend(ops, seed):
     np.testing.assert_allclose(lse.cpu().numpy()[seen], want_lse[seen], atol=3e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_extend_wide_heads(ops, seed):
+    """Random ragged batches on the AGPR-accumulator extend kernels (rx_extend_d256.hip at 256 / 256, 192 / 192,
+    192 / 128 and rx_extend_mla.hip at the latent shape 576 / 512): random page sizes, GQA groups, causal or not,
+    k / v scales, int32 / int64 indices, long and short extends, the new tokens' v aliased or not (latent shape)."""
+    rng = np.random.default_rng(7000 + seed)
+    dtype = [torch.bfloat16, torch.float16][seed % 2]
+    dk, dv, mla = [(256, 256, False), (192, 128, False), (192, 192, False), (576, 512, True)][seed % 4]
+    hkv = 1 if mla else int(rng.choice([1, 2]))
+    hq = hkv * int(rng.choice([8, 16] if mla else [2, 4, 8]))
+    page_size = int(rng.choice([1, 16, 32]))
+    bs = int(rng.integers(1, 10))
+    prefix = rng.choice([0, 0, 1, 17, 64, 65, 130, 300, 700], size=bs).astype(np.int64)
+    ext = rng.choice([1, 2, 31, 64, 100, 129, 257], size=bs).astype(np.int64)
+    r2t, pool = _paged(rng, np.maximum(prefix, 1), page_size)
+    g = torch.Generator().manual_seed(seed)
+    kb = (torch.randn(pool, hkv, dk, generator=g) * 0.6).to(dtype)
+    vb = kb[..., :dv] if mla else torch.randn(pool, hkv, dv, generator=g).to(dtype)
+    T_ = int(ext.sum())
+    q = torch.randn(T_, hq, dk, generator=g).to(dtype)
+    ke = (torch.randn(T_, hkv, dk, generator=g) * 0.6).to(dtype)
+    own_v = (not mla) or bool(rng.integers(0, 2))
+    ve = torch.randn(T_, hkv, dv, generator=g).to(dtype) if own_v else ke[..., :dv]
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, prefix)
+    qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
+    causal = bool(seed % 5 != 4)
+    ks, vs = float(rng.choice([1.0, 0.8])), float(rng.choice([1.0, 1.2]))
+    sm = (192 if mla else dk) ** -0.5
+    want, want_lse = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb.contiguous()), qo, kv_indptr,
+                                          kv_indices, is_causal=causal, sm_scale=sm, k_scale=ks, v_scale=vs, return_lse=True)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    o = torch.zeros(T_, hq, dv, dtype=dtype, device=DEV)
+    lse = torch.zeros(T_, hq, dtype=torch.float32, device=DEV)
+    kbd, ked = kb.to(DEV), ke.to(DEV)
+    vbd = kbd[..., :dv] if mla else vb.to(DEV)
+    ved = ve.to(DEV) if own_v else ked[..., :dv]
+    ops.extend_attention_fwd(q.to(DEV), ked, ved, o, kbd, vbd, T(qo if seed % 2 else qo.astype(np.int32)), T(kv_indptr),
+                             T(kv_indices if seed % 3 else kv_indices.astype(np.int32)), None, causal, None,
+                             int(ext.max()), ks, vs, sm_scale=sm, lse_extend=lse, page_size=page_size)
+    absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve)), _bits(kb), parity.abs_values(_bits(vb.contiguous())),
+                                qo, kv_indptr, kv_indices, is_causal=causal, sm_scale=sm, k_scale=ks, v_scale=vs)
+    parity.check_out(o.float().cpu().numpy().astype(np.float64), want, dtype, ("random wide heads", dk, dv), absw=absw)
+    np.testing.assert_allclose(lse.cpu().numpy(), want_lse, atol=3e-3, rtol=1e-3)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_byte_and_index_kernels(ops, seed):
     """store / kv-index build / move: bit-exact vs the oracle on random shapes and dtypes."""
