@@ -210,8 +210,10 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
   constexpr int NL = KV8 ? D / 64 : D / 32;  // loads per 16-token row block (KS = D / 32 k-steps)
   constexpr int KS = D / 32;  // k-steps of the QK^T product
   constexpr int NB = D / 16;  // 16-wide d blocks of the output
-  constexpr int ROW_BYTES = D * 2;
-  constexpr int TILE_BYTES = kTile * ROW_BYTES;  // == 16 * D * 4 (fp32 O^T of one wave)
+  // LDS row of the V tile: the row itself, or 256 B for D = 96 (the chunk swizzle permutes 16 chunk positions: a
+  // 12-chunk row is stored in a 16-chunk slot, four positions stay empty)
+  constexpr int ROW_BYTES = (D == 96) ? 256 : D * 2;
+  constexpr int TILE_BYTES = kTile * ROW_BYTES;  // >= 16 * D * 4 (fp32 O^T of one wave)
   __shared__ __attribute__((aligned(16))) char smem[kWavesPerWG * TILE_BYTES + 2 * 4 * 16 * 4];
 
   const int tid = threadIdx.x;
@@ -752,7 +754,7 @@ static void launch_merge(const DecodeArgs& a, int dv, hipStream_t s) {
 
 template <typename T, typename IdxT, bool LINEAR>
 static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
-  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128 || (dk == 256 && !a.kv_fp8));
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128 || ((dk == 256 || dk == 96) && !a.kv_fp8));
   if (a.stages == 2) {
     launch_merge<T>(a, dv, s);
     return check_launch("rx_decode_attn");
@@ -770,6 +772,7 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
     } else {
       if (dk == 64) RX_DEC(64, false, false);
       else if (dk == 128) RX_DEC(128, false, false);
+      else if (dk == 96) RX_DEC(96, false, false);  // Phi-3-class heads
       else RX_DEC(256, false, false);  // Gemma-class heads: the same kernel, 64 accumulator registers per wave
     }
 #undef RX_DEC
@@ -840,7 +843,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
                "rx_decode_attn: max_kv_splits=%d needs attn_logits, attn_lse and num_kv_splits",
                max_splits);
   const int dk = p->head_dim, dv = p->v_head_dim;
-  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128 || (dk == 256 && !p->kv.kv_fp8));
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128 || ((dk == 256 || dk == 96) && !p->kv.kv_fp8));
   if (mfma_ok) {
     // 16-byte vector loads: every stride a multiple of 8 elements, bases 16-byte aligned
     const int64_t all = p->q_stride_t | p->q_stride_h | p->kv.k_page_stride | p->kv.k_tok_stride |
@@ -939,7 +942,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.k_new = a.v_new = nullptr;
   if (p->k_new || p->v_new) {
     RX_REQUIRE(p->k_new && p->v_new, "rx_decode_attn: k_new and v_new come together");
-    RX_REQUIRE(mfma_ok && dk != 256 && !mla && !p->kv.kv_fp8 && a.qblocks == 1 && p->stages != 2,
+    RX_REQUIRE(mfma_ok && dk <= 128 && dk != 96 && !mla && !p->kv.kv_fp8 && a.qblocks == 1 && p->stages != 2,
                "rx_decode_attn: the fused store needs the D = 64 / 128 kernel on a 16-bit pool with at most 16 q heads "
                "per kv head, in a call that runs stage 1 (store with rx_store_kv* instead)");
     RX_REQUIRE((((uintptr_t)p->k_new | (uintptr_t)p->v_new) & 15) == 0 &&

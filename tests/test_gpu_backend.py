@@ -116,7 +116,7 @@ class _Harness:
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-@pytest.mark.parametrize("d", [16, 128, 256])
+@pytest.mark.parametrize("d", [16, 96, 128, 256])
 @pytest.mark.parametrize("layout", ["contiguous", "shuffled_pages", "interleaved_pages"])
 def test_dense_case_matrix(case, d, layout):
     from sglang_amd.forward_batch import ForwardBatch

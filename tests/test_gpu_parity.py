@@ -333,12 +333,13 @@ def test_decode_generic_head_dims(ops, hq, hkv, dk, dv):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("mode", ["indices_splits", "paged_single", "paged_hnd_splits"])
-def test_decode_head_dim_256(ops, dtype, mode):
-    """D = 256 (Gemma-class heads) on the MFMA split-KV decode kernel (the reference's kernel takes any Lk; here
+@pytest.mark.parametrize("d", [256, 96])
+def test_decode_head_dim_256(ops, dtype, mode, d):
+    """D = 256 (Gemma-class heads) and D = 96 (Phi-3-class) on the MFMA split-KV decode kernel (the reference's kernel takes any Lk; here
     head dims other than 64 / 128 ran the scalar generic kernel until round 2): ragged lengths incl. 1 and tile
     crossings, GQA 8 / 2 and 16 q heads per kv head, kv splits, paged HND pool -- vs the fp64 oracle."""
     rng = np.random.default_rng(256)
-    hq, hkv, d, ps = 16, 2, 256, 16
+    hq, hkv, ps = 16, 2, 16
     lens = np.array([1, 31, 32, 33, 200, 517], dtype=np.int64)
     bs = len(lens)
     n_pages = int(sum(-(-int(n) // ps) for n in lens)) + 2
@@ -376,7 +377,7 @@ def test_decode_head_dim_256(ops, dtype, mode):
         v_hnd = vb.to(DEV).view(n_pages, ps, hkv, d).permute(0, 2, 1, 3).contiguous()
         ops.decode_attention_fwd_paged(q.to(DEV), k_hnd, v_hnd, o, _t(r2t), _t(rpi), _t(lens), al, lse, nsplit, S, sm,
                                        page_size=ps, kv_layout=ops.kv_layout_hnd(k_hnd, v_hnd))
-    parity.check_out(_np(o.float()), want, dtype, ("decode_d256", mode))
+    parity.check_out(_np(o.float()), want, dtype, ("decode_d256", d, mode))
     if mode == "indices_splits":   # stage 2 inside the stage-1 kernel: the same bits, counters back at zero
         cnt = torch.zeros(bs * hq, dtype=torch.int32, device=DEV)
         for rep in range(2):
