@@ -106,14 +106,9 @@ __device__ __forceinline__ void x_settle(f32x4 (&o)[N]) {
 #define RX_XMLA_STAMP 0  // 1: diagnostic build, s_memtime phase stamps of wave 0 go to lse[8 * block ...] (tools/mla_extend_bench.py STAMPS=1)
 #endif
 
-// NQL8 > 0 parks that many of the 18 Q fragments in LDS (read once per tile: the QK^T loop runs k-step-outer for
-// that); with the rescale's LDS bounce all 18 fit in registers and parking only costs LDS reads (737 vs 757 TFLOP/s).
-#ifndef RX_XMLA_NQL8
-#define RX_XMLA_NQL8 0
-#endif
+// LDS: the stages | two blocks of slot ids | 1 KiB per wave for the rescale's way through LDS
 struct XGeom8 {
   static constexpr int NW = 8;
-  static constexpr int NQL = RX_XMLA_NQL8;
   static constexpr int STAGE = 2 * kXImg;  // K image | V image (the second one only for tiles whose v is a tensor of its own)
 #ifndef RX_XMLA_NSTAGE8
 #define RX_XMLA_NSTAGE8 2  // (four one-image stages, three tiles in flight: no faster -- the landing wait is not what costs)
@@ -122,9 +117,8 @@ struct XGeom8 {
   static constexpr int AHEAD = NSTAGE - 1;
   static constexpr int SLOTS_AT = NSTAGE * STAGE;
   static constexpr int SLOTBLK = 256;
-  static constexpr int QTAIL_AT = SLOTS_AT + 2 * SLOTBLK * 4;
-  static constexpr int BOUNCE_AT = QTAIL_AT + NW * NQL * 1024;  // 1 KiB per wave: the rescale's way through LDS
-  static constexpr int LDS = BOUNCE_AT + NW * 1024;
+  static constexpr int BOUNCE_AT = SLOTS_AT + 2 * SLOTBLK * 4;
+  static constexpr int LDS = BOUNCE_AT + NW * 1024;  // 161792 B
 };
 static_assert(XGeom8::LDS <= 160 * 1024, "LDS budget");
 
@@ -133,7 +127,6 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   using vec8 = typename T::vec8;
   using G = XGeom8;
   constexpr int KS = kXDk / 32, NB = kXDv / 16;
-  constexpr int KSR = KS - G::NQL;
   constexpr int kXSlotBlock = G::SLOTBLK;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][2 slot blocks][parked Q of the 8 waves]
   const uint32_t smem_u = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
@@ -163,8 +156,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   const int32_t rbase = row0 + 16 * w;
   const bool active = rbase < R;
 
-  vec8 qf[KSR];
-  const uint32_t qtail = smem_u + G::QTAIL_AT + (w * G::NQL * 64 + lane) * 16;
+  vec8 qf[KS];
   const uint32_t hq_magic = static_cast<uint32_t>(0x100000000ull / static_cast<uint32_t>(a.hq)) + 1u;
   auto row_tok = [&](int m) { return static_cast<int32_t>(__umulhi(static_cast<uint32_t>(m), hq_magic)); };
   {
@@ -176,8 +168,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
-      if (s < KSR) qf[s] = __builtin_bit_cast(vec8, raw);
-      else *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(qtail + (s - KSR) * 1024) = raw;
+      qf[s] = __builtin_bit_cast(vec8, raw);
     }
   }
 
@@ -314,7 +305,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
     }
     const uint32_t kt = smem_u + (t & (G::NSTAGE - 1)) * G::STAGE;
 
-    // ---- S^T = K Q^T, k-step-outer: a parked Q fragment is read once per tile
+    // ---- S^T = K Q^T: tokens 16 bb + 4 g + i of the tile on the lane, query row r
     f32x4 sacc[2];
     sacc[0] = sacc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
@@ -324,14 +315,9 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       u32x4 kf[PD];
 #pragma unroll
       for (int j = 0; j < PD; ++j) kf[j] = kfrag(j);
-      u32x4 qq[2] = {};
-      if (KSR < 2) {
-#pragma unroll
-        for (int s = KSR; s < 2; ++s) qq[s & 1] = x_lds_read16(qtail + (s - KSR) * 1024);
-      }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const vec8 qb = (s < KSR) ? qf[s < KSR ? s : 0] : __builtin_bit_cast(vec8, qq[s & 1]);
+        const vec8 qb = qf[s];
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
           const int j = 2 * s + bb;
@@ -339,8 +325,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
           if (j + PD < 2 * KS) kf[j % PD] = kfrag(j + PD);
           sacc[bb] = T::mfma(ka, qb, sacc[bb]);
         }
-        if (s + 2 < KS && s + 2 >= KSR) qq[s & 1] = x_lds_read16(qtail + (s + 2 - KSR) * 1024);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);  // source order IS the pipeline (hipcc left alone hoists the reads and serialises them)
       }
     }
     X_STAMP(2);
