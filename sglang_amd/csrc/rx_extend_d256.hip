@@ -12,8 +12,9 @@
 //     memory queue; slot ids of 256 tokens at a time come into LDS by DMA as well;
 //   * thresholded running max (2^8 slack, exact algebra): the 128-register rescale runs on the first tile and almost
 //     never again; the mask is one compare + select per score on every tile.
-// Causal / non-causal, skip_prefix / skip_extend, LSE, k / v scales, 16-bit pools.  Everything else (windows, caps,
-// sinks, masks, short rows) stays with rx_extend_nd.hip / the generic kernel.
+// Causal / non-causal, skip_prefix / skip_extend, LSE, k / v scales, logit cap, sliding window (tiles wholly below a
+// workgroup's window are never loaded), 16-bit pools.  Sinks, masks and short rows stay with rx_extend_nd.hip / the
+// generic kernel.
 #include <type_traits>
 
 #include "rx_common.h"
@@ -59,8 +60,8 @@ struct ExtD256Args {
   float* lse;
   int64_t lse_stride_t, lse_stride_h;
   int32_t bs, hkv, group, mblocks;
-  float sm_scale, k_scale, v_scale;
-  int32_t causal, skip_prefix, skip_extend;
+  float sm_scale, k_scale, v_scale, logit_cap;
+  int32_t causal, skip_prefix, skip_extend, window;  // window <= 0: off
 };
 
 typedef __attribute__((address_space(3))) const u32x4* y_lds_u32x4;
@@ -146,6 +147,16 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   const int nt1 = (p_len + kYTT - 1) / kYTT;
   const int nt2 = (n_end_wg + kYTT - 1) / kYTT;
   const int nt = nt1 + nt2;
+  // sliding window (extend_attention.py:385-390, 556-561): query token m sees cached token n iff P + m <= n + W and
+  // new token n iff m <= n + W.  Tiles wholly below the workgroup's first row's bound are never loaded.
+  const bool windowed = a.window > 0;
+  const int32_t tok_lo_wg = row0 / G, tok_lo_w = rbase / G;
+  int t_begin = 0;
+  if (windowed) {
+    t_begin = min(nt1, max(0, P + tok_lo_wg - a.window) / kYTT);
+    if (t_begin == nt1) t_begin += min(nt2, max(0, tok_lo_wg - a.window) / kYTT);
+  }
+  const bool capped = a.logit_cap > 0.f;
 
   const char* const idx_b = reinterpret_cast<const char*>(a.kv_indices);
   const int idx_sh = a.idx64 ? 3 : 2;
@@ -156,7 +167,11 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
       y_dma4(idx_b + (e << idx_sh), __builtin_amdgcn_readfirstlane(smem_u + kYSlotsAt + ((blk & 1) * kYSlotBlock + 64 * w) * 4));
     }
   };
-  if (nt1 > 0) stage_slots(0);
+  constexpr int TPB = kYSlotBlock / kYTT;
+  if (t_begin < nt1) {  // the slot block of the first tile (and the next one: the loop stages block b + 1 at tile b * TPB)
+    stage_slots(t_begin / TPB);
+    if (t_begin % TPB != 0 && (t_begin / TPB + 1) * kYSlotBlock < nt1 * kYTT) stage_slots(t_begin / TPB + 1);
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q and the slot ids have landed
   __syncthreads();
 
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
     dma_image(t, KC{}, KP{}, KD{}, false);
     dma_image(t, VC{}, VP{}, VD{}, true);
   };
-  if (nt > 0) dma_tile(0);
+  if (t_begin < nt) dma_tile(t_begin);
 
   f32x4 oacc[2][NB];
   float m_run[2], l_run[2];
@@ -234,10 +249,9 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   const uint32_t bounce = smem_u + kYBounceAt + (w * 64 + lane) * 16;  // this lane's 16 bytes of the rescale bounce
   const bool late = w >= 4;  // the SIMD partner of an early wave: issues its pieces behind its first QK^T
 
-  for (int t = 0; t < nt; ++t) {
+  for (int t = t_begin; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
     __syncthreads();                                   // everybody's have; everybody is done with tile t - 1
-    constexpr int TPB = kYSlotBlock / kYTT;
     if (t % TPB == 0 && (t / TPB + 1) * kYSlotBlock < nt1 * kYTT) stage_slots(t / TPB + 1);
     const bool more = t + 1 < nt;
     if (more && !late) dma_tile(t + 1);
@@ -246,18 +260,20 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
     const int tile_n0 = (prefix ? t : t - nt1) * kYTT;
     const int32_t lim = prefix ? p_len : n_end_w;
     bool late_pending = more && late;
-    if (!active || tile_n0 >= lim) {
+    // (a window: the tile may lie wholly below this wave's first row's bound)
+    const int32_t win_lo_w = windowed ? (prefix ? P : 0) + tok_lo_w - a.window : INT32_MIN;
+    if (!active || tile_n0 >= lim || tile_n0 + kYTT <= win_lo_w) {
       if (late_pending) dma_tile(t + 1);
       continue;
     }
     const uint32_t kt = smem_u + (t & 1) * kYStage;
     const uint32_t vt = kt + kYKimg;
     const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
-    const float c2 = cs * kLog2e;
+    const float c2 = capped ? kLog2e : cs * kLog2e;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int n0 = tile_n0 + 32 * hh;
-      if (n0 >= lim) continue;  // nothing visible to this wave in this half (wave-uniform)
+      if (n0 >= lim || n0 + 32 <= win_lo_w) continue;  // nothing visible to this wave in this half (wave-uniform)
       // ---- S^T = K Q^T: tokens 16 bb + 4 g + i of the half on the lane, query row r of block c
       f32x4 sacc[2][2];
 #pragma unroll
@@ -292,6 +308,10 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
           for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
+        if (capped) {  // logit cap (wave-uniform branch): cap * tanh(s * scale / cap)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * cs / a.logit_cap);
+        }
         {
           int lnm = lane;
           asm volatile("" : "+v"(lnm));
@@ -301,6 +321,13 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
           for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i < vis) ? sv[bb * 4 + i] : -INFINITY;
+          if (windowed) {  // ... and index >= the row's window bound (wave-uniform branch)
+            const int32_t wlo = (prefix ? P : 0) + tk1 - 1 - a.window - n0 - 4 * (lnm >> 4);
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i >= wlo) ? sv[bb * 4 + i] : -INFINITY;
+          }
         }
         float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
         mt = quad_row_max(mt) * c2;
@@ -401,8 +428,8 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
 bool extend_d256_supports(const rx_extend_params* p) {
   const int dk = p->head_dim, dv = p->v_head_dim;
   if (!((dk == 256 && dv == 256) || (dk == 192 && (dv == 128 || dv == 192))) || p->kv.kv_fp8) return false;
-  if (p->sliding_window_size > 0 || p->logit_cap > 0.f || p->sinks || p->custom_mask || p->xai_temperature_len > 0 ||
-      p->unified_prefix_lens || p->q_pack > 1)
+  if (p->sinks || p->custom_mask || p->xai_temperature_len > 0 || p->unified_prefix_lens || p->q_pack > 1 ||
+      p->window_kv_offsets)
     return false;
   const int64_t all = p->q_stride_t | p->q_stride_h | p->k_stride_t | p->k_stride_h | p->v_stride_t | p->v_stride_h |
                       p->kv.k_page_stride | p->kv.k_tok_stride | p->kv.k_head_stride | p->kv.v_page_stride |
@@ -442,8 +469,9 @@ int launch_extend_d256(const rx_extend_params* p, hipStream_t s) {
   a.bs = p->bs; a.hkv = p->num_kv_heads;
   a.group = p->num_q_heads / p->num_kv_heads;
   a.mblocks = static_cast<int32_t>((static_cast<int64_t>(p->max_extend_len) * a.group + kYRows - 1) / kYRows);
-  a.sm_scale = p->sm_scale; a.k_scale = p->k_scale; a.v_scale = p->v_scale;
+  a.sm_scale = p->sm_scale; a.k_scale = p->k_scale; a.v_scale = p->v_scale; a.logit_cap = p->logit_cap;
   a.causal = p->is_causal; a.skip_prefix = p->skip_prefix; a.skip_extend = p->skip_extend;
+  a.window = p->sliding_window_size;
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hkv * a.mblocks;
 #define RX_D256(TT, DK_, DV_)                                                                                          \
   do {                                                                                                               \

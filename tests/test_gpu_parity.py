@@ -480,7 +480,8 @@ def test_extend_generic_head_dims(ops, d):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("dk,dv", [(256, 256), (192, 128), (192, 192), (96, 96)])
-@pytest.mark.parametrize("variant", ["plain", "window", "cap_sinks_noncausal", "hnd_pool", "short_extends", "max_jumps"])
+@pytest.mark.parametrize("variant", ["plain", "window", "window_100_noncausal", "cap", "cap_sinks_noncausal", "hnd_pool",
+                                     "short_extends", "max_jumps"])
 def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
     """rx::extend_nd_kernel (MFMA 16x16x32 for head dims 256 / 192+128 / 192 / 96 -- the shapes the reference retunes
     for gfx950, extend_attention.py:66-77, and the MLA prefill shape) vs the fp64 oracle: ragged batch with zero /
@@ -518,6 +519,11 @@ def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
     causal = True
     if variant == "window":
         kw = okw = dict(sliding_window_size=9)
+    elif variant == "window_100_noncausal":
+        kw = okw = dict(sliding_window_size=100)
+        causal = False
+    elif variant == "cap":
+        kw = okw = dict(logit_cap=20.0)
     elif variant == "cap_sinks_noncausal":
         sinks = torch.randn(hq, generator=g)
         causal = False
