@@ -122,7 +122,8 @@ struct XGeom8 {
 };
 static_assert(XGeom8::LDS <= 160 * 1024, "LDS budget");
 
-template <typename T>
+// OWNV: the code for tiles whose v is a tensor of its own compiled in (instance picked by the launcher)
+template <typename T, bool OWNV>
 __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) {
   using vec8 = typename T::vec8;
   using G = XGeom8;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   const char* const kext_b = reinterpret_cast<const char*>(a.k_ext + qo0 * a.k_stride_t);
   const char* const vbuf_b = reinterpret_cast<const char*>(a.v_buf);
   const char* const vext_b = reinterpret_cast<const char*>(a.v_ext + qo0 * a.v_stride_t);
-  auto own_v = [&](int t) { return (t < nt1) ? !a.share_p : !a.share_e; };  // tile t's v rows are a tensor of their own
+  auto own_v = [&](int t) { return OWNV && ((t < nt1) ? !a.share_p : !a.share_e); };  // tile t's v rows are a tensor of their own
   const int32_t sh_p = a.page_shift < 0 ? 31 : a.page_shift;
   constexpr int kPieces = 37;
   constexpr int NP = (kPieces + G::NW - 1) / G::NW;  // 5
@@ -494,14 +495,22 @@ int launch_extend_mla(const rx_extend_params* p, hipStream_t s) {
   const bool bf = p->dtype == RX_BF16;
   static const bool no_shared = getenv("RX_XMLA_NO_SHARED") != nullptr;  // dev: the own-v-image path for aliased tensors too
   if (no_shared) a.share_p = a.share_e = 0;
-  static const hipError_t attr_b = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_mla_kernel<BF16>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, XGeom8::LDS);
-  static const hipError_t attr_h = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_mla_kernel<F16>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, XGeom8::LDS);
-  (void)attr_b;
-  (void)attr_h;
-  if (bf) hipLaunchKernelGGL(extend_mla_kernel<BF16>, dim3(grid), dim3(512), XGeom8::LDS, s, a);
-  else hipLaunchKernelGGL(extend_mla_kernel<F16>, dim3(grid), dim3(512), XGeom8::LDS, s, a);
+#define RX_XMLA(TT, OV)                                                                                       \
+  do {                                                                                                        \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_mla_kernel<TT, OV>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, XGeom8::LDS); \
+    (void)attr;                                                                                               \
+    hipLaunchKernelGGL((extend_mla_kernel<TT, OV>), dim3(grid), dim3(512), XGeom8::LDS, s, a);                \
+  } while (0)
+  const bool ownv = !(a.share_p && a.share_e);
+  if (bf) {
+    if (ownv) RX_XMLA(BF16, true);
+    else RX_XMLA(BF16, false);
+  } else {
+    if (ownv) RX_XMLA(F16, true);
+    else RX_XMLA(F16, false);
+  }
+#undef RX_XMLA
   return RX_OK;
 }
 
