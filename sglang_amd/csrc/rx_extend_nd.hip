@@ -76,8 +76,15 @@ __device__ __forceinline__ int64_t nd_slot_off(int64_t slot, int32_t shift, int3
   return (slot / page_size) * page_stride + (slot % page_size) * tok_stride;
 }
 
-template <typename T, int DK, int DV, bool BIG>
-__global__ __launch_bounds__((NdGeom<DK, DV, BIG>::NT), (NdGeom<DK, DV, BIG>::MINW * 4 / NdGeom<DK, DV, BIG>::NW)) void extend_nd_kernel(const ExtNdArgs a) {
+// PLAIN: no sliding window and no logit cap in this instance (their scalars and branches cost the plain call several
+// per cent even when both are off: rx_extend_d256.hip measured 8-9 %); the launcher picks it when the call uses neither
+template <typename T, int DK, int DV, bool BIG, bool PLAIN>
+__global__ __launch_bounds__((NdGeom<DK, DV, BIG>::NT), (NdGeom<DK, DV, BIG>::MINW * 4 / NdGeom<DK, DV, BIG>::NW)) void extend_nd_kernel(const ExtNdArgs a0) {
+  ExtNdArgs a = a0;
+  if constexpr (PLAIN) {
+    a.window = 0;
+    a.logit_cap = 0.f;
+  }
   using G = NdGeom<DK, DV, BIG>;
   using vec8 = typename T::vec8;
   constexpr int CB = G::CB, TT = G::TT;
@@ -363,18 +370,24 @@ __global__ __launch_bounds__((NdGeom<DK, DV, BIG>::NT), (NdGeom<DK, DV, BIG>::MI
   }
 }
 
-template <typename T, int DK, int DV, bool BIG>
-static void launch_nd_one(const ExtNdArgs& a0, int max_extend_len, hipStream_t s) {
+template <typename T, int DK, int DV, bool BIG, bool PLAIN>
+static void launch_nd_one_(const ExtNdArgs& a0, int max_extend_len, hipStream_t s) {
   using G = NdGeom<DK, DV, BIG>;
   ExtNdArgs a = a0;
   a.mblocks = (max_extend_len + G::QPWG - 1) / G::QPWG;
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
   constexpr unsigned kLds = 2 * G::BUF;
-  auto kern = extend_nd_kernel<T, DK, DV, BIG>;
+  auto kern = extend_nd_kernel<T, DK, DV, BIG, PLAIN>;
   static const hipError_t attr =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
   (void)attr;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), kLds, s, a);
+}
+
+template <typename T, int DK, int DV, bool BIG>
+static void launch_nd_one(const ExtNdArgs& a0, int max_extend_len, hipStream_t s) {
+  if (a0.window > 0 || a0.logit_cap > 0.f) launch_nd_one_<T, DK, DV, BIG, false>(a0, max_extend_len, s);
+  else launch_nd_one_<T, DK, DV, BIG, true>(a0, max_extend_len, s);
 }
 
 bool extend_nd_supports(int dk, int dv) {
