@@ -90,8 +90,15 @@ constexpr int kTT = RX_EXT_TT;  // tokens per LDS tile
 #endif
 constexpr int kCB = RX_EXT_CB;
 
-template <typename T, int D, typename IdxT, bool LINEAR, bool VSCALE>
-__global__ __launch_bounds__(256, RX_EXT_MINW) void extend_mfma_kernel(const ExtendArgs a) {
+// PLAIN: no sliding window and no logit cap in this instance (their scalars and branches cost a plain call several per
+// cent even when both are off); picked by the launcher
+template <typename T, int D, typename IdxT, bool LINEAR, bool VSCALE, bool PLAIN = false>
+__global__ __launch_bounds__(256, RX_EXT_MINW) void extend_mfma_kernel(const ExtendArgs a0) {
+  ExtendArgs a = a0;
+  if constexpr (PLAIN) {
+    a.window = 0;
+    a.logit_cap = 0.f;
+  }
   using vec8 = typename T::vec8;
   constexpr int KS = D / 32;
   constexpr int NB = D / 16;
@@ -512,9 +519,15 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
   if (mfma_ok) {
     const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
     const bool vs = a.v_scale != 1.0f;
+    const bool plain = a.window <= 0 && a.logit_cap <= 0.f;
     if (dk == 64) {
-      if (vs) hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, true>), dim3(grid), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, false>), dim3(grid), dim3(256), 0, s, a);
+      if (plain) {
+        if (vs) hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, true, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, false, true>), dim3(grid), dim3(256), 0, s, a);
+      } else {
+        if (vs) hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, false>), dim3(grid), dim3(256), 0, s, a);
+      }
     } else {
       if (vs) hipLaunchKernelGGL((extend_mfma_kernel<T, 128, IdxT, LINEAR, true>), dim3(grid), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((extend_mfma_kernel<T, 128, IdxT, LINEAR, false>), dim3(grid), dim3(256), 0, s, a);
