@@ -304,7 +304,7 @@ class HipRadixAttnBackend:
                 kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
                 mla = (self._is_mla_pool and kb.shape[-1] == 576 and self.v_head_dim == 512
                        and kb.dtype in (torch.bfloat16, torch.float16))   # 16-bit latent rows (phase 1 reads them)
-                d256 = kb.shape[-1] == 256 and kb.dtype in (torch.bfloat16, torch.float16)   # (no fp8 kernels at 256)
+                d256 = kb.shape[-1] in (96, 256) and kb.dtype in (torch.bfloat16, torch.float16)   # (no fp8 kernels at 96 / 256)
                 if not mla and (self._is_mla_pool or not (kb.shape[-1] in (64, 128) or d256) or kb.shape[-1] != self.v_head_dim):
                     self.cascade_decode = self._cascade_on = False
                 else:

@@ -560,8 +560,8 @@ class CascadeDecode:
                  num_chunks: Optional[int] = None, overlap: bool = False, v_head_dim: Optional[int] = None):
         v_head_dim = head_dim if v_head_dim is None else int(v_head_dim)
         self.mla = (head_dim, v_head_dim) == (576, 512) and num_kv_heads == 1   # latent rows: rx::extend_mla_kernel
-        if not self.mla and (head_dim not in (64, 128, 256) or v_head_dim != head_dim):
-            raise ValueError("CascadeDecode: head_dim 64 / 128 / 256, or the latent MLA shape 576 / 512 over one kv head "
+        if not self.mla and (head_dim not in (64, 96, 128, 256) or v_head_dim != head_dim):
+            raise ValueError("CascadeDecode: head_dim 64 / 96 / 128 / 256, or the latent MLA shape 576 / 512 over one kv head "
                              "(the MFMA extend and decode kernels)")
         self.max_bs, self.hq, self.hkv, self.d, self.dv = max_bs, num_q_heads, num_kv_heads, head_dim, v_head_dim
         self.cu_count, self.min_shared, self.max_shared = cu_count, int(min_shared), int(max_shared)

@@ -67,6 +67,7 @@ CASES = [
     (130, 4, 1, 128, 64, 1024, None, 256),                         # > 128 queries per head (two M blocks)
     (40, 8, 2, 256, 16, 600, None, 64),                            # head dim 256: extend_d256_kernel + the MFMA decode kernel
     (6, 16, 2, 256, 16, 300, [301, 420, 333, 300, 512, 400], 64),  # (few rows per kv head: extend_nd_kernel in phase 1)
+    (24, 8, 8, 96, 16, 400, None, 64),                             # head dim 96 (Phi-3-class)
 ]
 
 
