@@ -101,13 +101,12 @@ __device__ __forceinline__ void x_settle(f32x4 (&o)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) asm volatile("" : "+a"(o[i]));
 }
-// element offset of a KV slot; page_shift < 0: the pool is linear in the slot (page_stride == page_size * tok_stride)
 #ifndef RX_XMLA_STAMP
-#define RX_XMLA_STAMP 0  // 1: diagnostic build, s_memtime phase stamps of wave 0 go to lse[8 * block ...] (tools/mla_extend_bench.py STAMPS=1)
+#define RX_XMLA_STAMP 0  // 1: diagnostic build, s_memtime phase stamps of waves 0 and 4 go to lse[16 * block ...] (tools/mla_extend_bench.py STAMPS=1)
 #endif
 
 // LDS: the stages | two blocks of slot ids | 1 KiB per wave for the rescale's way through LDS
-struct XGeom8 {
+struct XGeom8 {  // (the eight-wave form's geometry; the four-wave first form is in the history and DESIGN 4.2b)
   static constexpr int NW = 8;
   static constexpr int STAGE = 2 * kXImg;  // K image | V image (the second one only for tiles whose v is a tensor of its own)
 #ifndef RX_XMLA_NSTAGE8
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   using G = XGeom8;
   constexpr int KS = kXDk / 32, NB = kXDv / 16;
   constexpr int kXSlotBlock = G::SLOTBLK;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][2 slot blocks][parked Q of the 8 waves]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [stages: K image | V image][2 slot blocks][rescale bounce of the 8 waves]
   const uint32_t smem_u = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem));
 
   const int tid = threadIdx.x;
