@@ -195,3 +195,25 @@ def test_plugin_backend_options_from_environment(monkeypatch):
     monkeypatch.setenv("SGLANG_HIP_RADIX_SPLIT_POLICY", "reference")
     o = plugin.backend_options()
     assert o["cascade_decode"] is True and o["cascade_min_bs"] == 4 and o["split_policy"] == "reference"
+
+
+def test_split_kv_planner_accepts_the_head_dims_its_kernels_serve():
+    """ops.VerifySplitKV (host side only: no launch): head dim 128 runs GQA-packed, the latent MLA shape 576 / 512 over one
+    kv head lets rx::extend_mla_kernel pack the heads itself, anything else is refused up front."""
+    import pytest
+    import torch
+
+    from sglang_amd import ops
+
+    vs = ops.VerifySplitKV(32, 8, torch.bfloat16, "cpu")
+    assert (vs.d, vs.dv, vs.pack) == (128, 128, 4)
+    assert vs.num_chunks(1, 8) == 32 and vs.num_chunks(1024, 8) == 1
+    mla = ops.VerifySplitKV(16, 1, torch.bfloat16, "cpu", head_dim=576, v_head_dim=512)
+    assert (mla.d, mla.dv, mla.pack) == (576, 512, 0)
+    assert mla.num_chunks(4, 64) == 8      # 4 requests x ceil(64 * 16 / 128) = 32 workgroups per chunk -> 8 chunks on 256 CUs
+    for bad in (dict(head_dim=96), dict(head_dim=576, v_head_dim=576), dict(head_dim=256)):
+        with pytest.raises(ValueError):
+            ops.VerifySplitKV(16, 1, torch.bfloat16, "cpu", **bad)
+    with pytest.raises(ValueError):        # the latent shape is one kv head
+        ops.VerifySplitKV(16, 2, torch.bfloat16, "cpu", head_dim=576, v_head_dim=512)
+
