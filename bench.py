@@ -617,8 +617,8 @@ def mla_extend_bench(dev):
     reference's backend: forward_absorb_core -> attn_mqa -> forward_extend at Lq 576 / Lv 512 over ONE latent kv head):
     config-3's chunk shape on one TP=8 rank -- 32 requests x (3584 cached + 512 new tokens), 16 q heads, shuffled slots.
     MFMA-bound: FLOPs = 2 (576 + 512) Hq sum_i (E_i P_i + E_i (E_i + 1) / 2).  'v_view_of_k' passes the new tokens'
-    v as a view of their k rows, 'v_own_tensor' as the reference's model code does (k is a fresh concat): the eight-wave and the four-wave form of
-    rx::extend_mla_kernel (DESIGN 4.2b)."""
+    v as a view of their k rows, 'v_own_tensor' as the reference's model code does (k is a fresh concat): the one-image and the
+    two-image instance of rx::extend_mla_kernel (DESIGN 4.2b)."""
     from sglang_amd import ops
 
     bs, P, E, hq, dk, dv = 32, 3584, 512, 16, 576, 512
