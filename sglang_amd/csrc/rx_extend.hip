@@ -217,15 +217,23 @@ __global__ __launch_bounds__(256, RX_EXT_MINW) void extend_mfma_kernel(const Ext
     l_run[c] = 0.f;
   }
 
+  // sliding window: tiles wholly below the workgroup's first query's bound (cached token n is visible to query m iff
+  // P + m <= n + W, new token n iff m <= n + W) are never staged -- a long chunk under a short window (gpt-oss: W = 128)
+  // otherwise computes and masks its whole causal triangle
+  int t0 = 0;
+  if (a.window > 0) {
+    t0 = min(nt1, max(0, P + qb0 - a.window) / kTT);
+    if (t0 == nt1) t0 += min(nt2, max(0, qb0 - a.window) / kTT);
+  }
   // ---- prologue -----------------------------------------------------------------------------------
-  if (nt > 0) {
-    load_idx_tile(0);
-    issue_loads(0);
-    if (nt > 1) load_idx_tile(1);
-    write_lds(0);
-    if (nt > 1) {
-      issue_loads(1);
-      if (nt > 2) load_idx_tile(2);
+  if (nt > t0) {
+    load_idx_tile(t0);
+    issue_loads(t0);
+    if (nt > t0 + 1) load_idx_tile(t0 + 1);
+    write_lds(t0 & 1);
+    if (nt > t0 + 1) {
+      issue_loads(t0 + 1);
+      if (nt > t0 + 2) load_idx_tile(t0 + 2);
     }
   }
   __syncthreads();
@@ -235,17 +243,18 @@ __global__ __launch_bounds__(256, RX_EXT_MINW) void extend_mfma_kernel(const Ext
   const int vrow0 = 4 * g + qd;  // V^T read: row inside a 16-token block
   const int swv = v_swz<D>(vrow0);
 
-  for (int t = 0; t < nt; ++t) {
+  for (int t = t0; t < nt; ++t) {
     const char* kt = smem + (t & 1) * 2 * TILE_BYTES;
     const char* vt = kt + TILE_BYTES;
     const bool prefix = t < nt1;
     const int tile_n0 = (prefix ? t : t - nt1) * kTT;
     const int32_t lim = prefix ? p_len : n_end_w;
+    const int32_t win_lo = a.window > 0 ? (prefix ? P : 0) + qbase - a.window : INT32_MIN;  // below it: hidden from the whole wave
     if (active) {
 #pragma unroll
       for (int hh = 0; hh < kTT / 32; ++hh) {
         const int n0 = tile_n0 + 32 * hh;  // first token of this 32-token half
-        if (n0 >= lim) continue;           // nothing visible to this wave (wave-uniform)
+        if (n0 >= lim || n0 + 32 <= win_lo) continue;  // nothing visible to this wave (wave-uniform)
         const float cs = (prefix ? a.sm_scale * a.k_scale : a.sm_scale);
         // ---- S^T = K Q^T ---------------------------------------------------------------------------
         f32x4 sacc[kCB][2];

@@ -205,14 +205,20 @@ __global__ __launch_bounds__((NdGeom<DK, DV, BIG>::NT), (NdGeom<DK, DV, BIG>::MI
     for (int nb = 0; nb < NB; ++nb) oacc[c][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  if (nt > 0) {
-    load_idx_tile(0);
-    issue_loads(0);
-    if (nt > 1) load_idx_tile(1);
-    write_lds(0);
-    if (nt > 1) {
-      issue_loads(1);
-      if (nt > 2) load_idx_tile(2);
+  // sliding window: tiles wholly below the workgroup's first query's bound are never staged (rx_extend.hip)
+  int t0 = 0;
+  if (a.window > 0) {
+    t0 = min(nt1, max(0, P + qb0 - a.window) / TT);
+    if (t0 == nt1) t0 += min(nt2, max(0, qb0 - a.window) / TT);
+  }
+  if (nt > t0) {
+    load_idx_tile(t0);
+    issue_loads(t0);
+    if (nt > t0 + 1) load_idx_tile(t0 + 1);
+    write_lds(t0 & 1);
+    if (nt > t0 + 1) {
+      issue_loads(t0 + 1);
+      if (nt > t0 + 2) load_idx_tile(t0 + 2);
     }
   }
   __syncthreads();
@@ -221,17 +227,18 @@ __global__ __launch_bounds__((NdGeom<DK, DV, BIG>::NT), (NdGeom<DK, DV, BIG>::MI
   const int vrow0 = 4 * g + qd;  // V^T read: row inside a 16-token block
   const bool capped = a.logit_cap > 0.f;
 
-  for (int t = 0; t < nt; ++t) {
+  for (int t = t0; t < nt; ++t) {
     const char* kt = smem + (t & 1) * G::BUF;
     const char* vt = kt + G::KTILE;
     const bool prefix = t < nt1;
     const int tile_n0 = (prefix ? t : t - nt1) * TT;
     const int32_t lim = prefix ? p_len : n_end_w;
+    const int32_t win_lo = a.window > 0 ? (prefix ? P : 0) + qbase - a.window : INT32_MIN;  // below it: hidden from the whole wave
     if (active) {
 #pragma unroll
       for (int hh = 0; hh < TT / 32; ++hh) {
         const int n0 = tile_n0 + 32 * hh;  // first token of this 32-token half
-        if (n0 >= lim) continue;           // nothing visible to this wave (wave-uniform)
+        if (n0 >= lim || n0 + 32 <= win_lo) continue;  // nothing visible to this wave (wave-uniform)
         const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
         // ---- S^T = K Q^T: tokens 16 bb + 4 g + i of the half on the lane, query r
         f32x4 sacc[CB][2];
