@@ -412,21 +412,29 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       for (int i = 0; i < 16; ++i) oacc[qb][db][i] = 0.f;
   }
 
-  if (nt > 0) {
-    load_idx_tile(0);
-    issue_loads(0);
-    if (nt > 1) load_idx_tile(1);
-    write_lds(0, 0 < nt1);
-    if (nt > 1) {
-      issue_loads(1);
-      if (nt > 2) load_idx_tile(2);
+  // sliding window (plain lists only: no tree mask, unified list or window offsets): tiles wholly below the
+  // workgroup's first row's bound are never staged (rx_extend.hip)
+  int t0 = 0;
+  if (a.window > 0 && !a.custom_mask && !a.unified_prefix && !a.window_kv_offsets) {
+    const int32_t tok0 = qb0 / pack;
+    t0 = min(nt1, max(0, P + tok0 - a.window) / kTok);
+    if (t0 == nt1) t0 += min(nt2, max(0, tok0 - a.window) / kTok);
+  }
+  if (nt > t0) {
+    load_idx_tile(t0);
+    issue_loads(t0);
+    if (nt > t0 + 1) load_idx_tile(t0 + 1);
+    write_lds(t0 % RING, t0 < nt1);
+    if (nt > t0 + 1) {
+      issue_loads(t0 + 1);
+      if (nt > t0 + 2) load_idx_tile(t0 + 2);
     }
     if constexpr (RING3) {  // one more tile in the ring, one more in flight
-      if (nt > 1) {
-        write_lds(1, 1 < nt1);
-        if (nt > 2) {
-          issue_loads(2);
-          if (nt > 3) load_idx_tile(3);
+      if (nt > t0 + 1) {
+        write_lds((t0 + 1) % RING, t0 + 1 < nt1);
+        if (nt > t0 + 2) {
+          issue_loads(t0 + 2);
+          if (nt > t0 + 3) load_idx_tile(t0 + 3);
         }
       }
       __syncthreads();  // tiles 0 and 1 are complete: from here on tile t is readable after barrier t - 1
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   // static priority for the second-dispatched half (MI355X_MICROARCH.md, Two waves per SIMD, item 4)
   if (w >= NW / 2) __builtin_amdgcn_s_setprio(1);
 #endif
-  int t = 0;
+  int t = t0;
   while (t < nt) {
 
     if constexpr (FINE) {
