@@ -286,8 +286,9 @@ __global__ __launch_bounds__(256, RX_EXT_MINW) void extend_mfma_kernel(const Ext
         }
         // ---- masks + online softmax (lane = one query per block c, 8 tokens) -------------------------
         bool full;  // every (query, token) pair of this half is visible: skip the mask code
-        if (prefix) full = (n0 + 32 <= p_len) && a.window <= 0;
-        else full = (n0 + 32 <= E) && (!a.causal || n0 + 31 <= qbase) && a.window <= 0;
+        // (a window: also every row of the wave within W of the half's first token -- the interior of the band needs no mask)
+        if (prefix) full = (n0 + 32 <= p_len) && (a.window <= 0 || P + qbase + kQPerWave - 1 <= n0 + a.window);
+        else full = (n0 + 32 <= E) && (!a.causal || n0 + 31 <= qbase) && (a.window <= 0 || qbase + kQPerWave - 1 <= n0 + a.window);
         const bool capped = a.logit_cap > 0.f;
         const float c2 = capped ? kLog2e : cs * kLog2e;
         vec8 pf[kCB];

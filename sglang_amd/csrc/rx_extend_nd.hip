@@ -265,8 +265,9 @@ __global__ __launch_bounds__((NdGeom<DK, DV, BIG>::NT), (NdGeom<DK, DV, BIG>::MI
           vhi[nb] = T::ds_read_tr(rp1 + nb * 32);
         }
         bool full;  // every (query, token) pair of this half is visible: no mask code
-        if (prefix) full = (n0 + 32 <= p_len) && a.window <= 0;
-        else full = (n0 + 32 <= E) && (!a.causal || n0 + 31 <= qbase) && a.window <= 0;
+        // (a window: also every row of the wave within W of the half's first token -- the interior of the band needs no mask)
+        if (prefix) full = (n0 + 32 <= p_len) && (a.window <= 0 || P + qbase + G::QPW - 1 <= n0 + a.window);
+        else full = (n0 + 32 <= E) && (!a.causal || n0 + 31 <= qbase) && (a.window <= 0 || qbase + G::QPW - 1 <= n0 + a.window);
         const float c2 = capped ? kLog2e : cs * kLog2e;
         vec8 pf[CB];
 #pragma unroll
