@@ -33,7 +33,7 @@ import torch
 
 from .. import ops
 from ..forward_batch import ForwardBatch
-from ..mem_cache.memory_pool import KVWriteLoc
+from ..mem_cache import memory_pool as _own_pools
 
 
 @dataclass
@@ -85,6 +85,29 @@ def host_num_kv_splits(seq_lens: np.ndarray, num_head: int, num_kv_head: int, ma
     s2 = max(1, min(-(-cores // token_grid), max_kv_splits))
     c2 = -(-mx // s2)
     return np.maximum(-(-seq_lens // c1), -(-seq_lens // c2)).astype(np.int32)
+
+
+def resolve_write_loc_cls(pool):
+    """The KVWriteLoc class ``pool.set_kv_buffer`` unwraps -- the one defined next to the POOL, never ours for a
+    foreign pool.  The reference's pools test ``isinstance(loc_info, KVWriteLoc)`` against THEIR dataclass
+    (unwrap_write_loc, srt/mem_cache/memory_pool.py:1566-1570; built by the Triton backend at
+    triton_backend.py:1287-1293,1750-1753): an instance of another class of the same name falls through as the
+    "bare loc" and the store dies on a dataclass where it wants a tensor.  Order: our own pools -> our class; a
+    foreign pool -> ``KVWriteLoc`` of the module (or a base class's module) that defines the pool; then of
+    sglang's memory_pool module if that is ALREADY imported (never imported from here); else None = hand the
+    bare ``out_cache_loc`` tensor over, which unwrap_write_loc accepts as it stands."""
+    import sys
+
+    if isinstance(pool, (_own_pools.MHATokenToKVPool, _own_pools.MLATokenToKVPool)):
+        return _own_pools.KVWriteLoc
+    for cls in type(pool).__mro__:
+        mod = sys.modules.get(getattr(cls, "__module__", None) or "")
+        cand = getattr(mod, "KVWriteLoc", None)
+        if isinstance(cand, type) and cand is not _own_pools.KVWriteLoc:
+            return cand
+    mod = sys.modules.get("sglang.srt.mem_cache.memory_pool")
+    cand = getattr(mod, "KVWriteLoc", None)
+    return cand if isinstance(cand, type) else None
 
 
 def md_has_mask(md) -> bool:
@@ -144,6 +167,14 @@ class HipRadixAttnBackend:
         # each); two per CU for the MLA kernel, whose four waves share one staged tile (config-5 shape:
         # 256 workgroups 157 us, 512 workgroups 134 us)
         self._is_mla_pool = hasattr(self.token_to_kv_pool, "kv_lora_rank")
+        # the write-location wrapper of THIS pool's module (a foreign pool unwraps its own class only) and whether
+        # the decode kernel may write the step's new K/V row itself: our pools, or a pool that says so -- a foreign
+        # set_kv_buffer may carry side effects the fused store would skip (layer-transfer sync memory_pool.py:
+        # 2273-2279, the OOB probe :2319, canaries)
+        self._own_pool = isinstance(self.token_to_kv_pool, (_own_pools.MHATokenToKVPool, _own_pools.MLATokenToKVPool))
+        self._write_loc_cls = resolve_write_loc_cls(self.token_to_kv_pool)
+        self._pool_allows_fused_store = self._own_pool or bool(
+            getattr(self.token_to_kv_pool, "supports_fused_decode_store", False))
         if decode_index_mode not in ("paged", "indices"):
             raise ValueError(f"decode_index_mode must be 'paged' or 'indices', got {decode_index_mode}")
         self.decode_index_mode = decode_index_mode
@@ -168,6 +199,8 @@ class HipRadixAttnBackend:
         if os.environ.get("RX_NO_INKERNEL_MERGE"):  # dev A/B: stage 2 as its own launch
             self._merge_counters = None
         self._no_fused_store = bool(os.environ.get("RX_NO_FUSED_STORE"))  # dev A/B: the store as its own launch
+        # RX_DEBUG_CHECKS=1: host-synchronising assertions of the backend's preconditions (see forward_decode)
+        self._debug_checks = os.environ.get("RX_DEBUG_CHECKS", "0") not in ("", "0")
         self._graph = None  # static buffers of init_cuda_graph_state
         self._md_version = 0  # bumped by every init_forward_metadata_out_graph
         self._decode_launchers = {}  # layer_id -> ops.DecodeLauncher
@@ -474,13 +507,18 @@ class HipRadixAttnBackend:
         md.dcp_prefix_total = total  # the WHOLE prefix, known to every rank alike: decides the collective path
         return md
 
+    def _loc_info(self, loc: torch.Tensor):
+        """What set_kv_buffer gets as its write location (triton_backend.py:1287-1293): the pool's own KVWriteLoc
+        around the out_cache_loc tensor, or the bare tensor when the pool's module has no such class."""
+        return self._write_loc_cls(loc) if self._write_loc_cls is not None else loc
+
     def _dcp_store(self, layer, fb: ForwardBatch, k, v):
         """_set_kv_buffer's DCP branch (triton_backend.py:1227-1239): the rank stores the tokens it owns, at the
         local slot; the other rows carry the pool's skip index."""
         if fb.positions is None or fb.positions.numel() != fb.out_cache_loc.numel():
             raise ValueError("DCP needs forward_batch.positions for the new tokens")
         loc = ops.dcp_store_loc(fb.out_cache_loc, fb.positions, self.dcp.size, self.dcp.rank, skip_index=0)
-        self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(loc), k, v, layer.k_scale, layer.v_scale)
+        self.token_to_kv_pool.set_kv_buffer(layer, self._loc_info(loc), k, v, layer.k_scale, layer.v_scale)
 
     def _forward_decode_dcp(self, q3, o3, layer, fb: ForwardBatch, sinks):
         """triton_backend.py:1797-1839: gathered q heads over the local tokens (kv-split partials only), the rank's
@@ -719,9 +757,10 @@ class HipRadixAttnBackend:
 
     def _fused_store_ok(self, layer, k, v) -> bool:
         """rx_decode_params.k_new: the new token's rows are read from k / v and written to their slots by the decode
-        kernel itself -- a 16-bit pool of k's dtype, D = 64 / 128, at most 16 q heads per kv head, the plain or
+        kernel itself -- one of OUR pools (or a foreign one that declares ``supports_fused_decode_store``: the fused
+        store never calls its set_kv_buffer), a 16-bit pool of k's dtype, D = 64 / 128, at most 16 q heads per kv head, the plain or
         shared-prefix path (not DCP / sliding-window / scaled-store), 16-byte aligned rows."""
-        if self._no_fused_store or self.dcp is not None or self._is_mla_pool:
+        if self._no_fused_store or self.dcp is not None or self._is_mla_pool or not self._pool_allows_fused_store:
             return False
         pool = self.token_to_kv_pool
         if getattr(pool, "is_fp8", False) or k.dtype != pool.dtype or v.dtype != pool.dtype:
@@ -737,6 +776,11 @@ class HipRadixAttnBackend:
                 and (layer.tp_k_head_num * d) % 8 == 0)
 
     def forward_decode(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, sinks=None):
+        """triton_backend.py:1714-1864.  PRECONDITION of the fused store (`_fused_store_ok`): the step's slot is
+        already in the page table, ``req_to_token[req_pool_indices, seq_lens - 1] == out_cache_loc`` -- what
+        alloc_for_decode leaves behind (allocation.py:578-580) -- because the kernel writes the new row to the slot it
+        READS for position seq_len - 1; the separate store (every foreign pool, fp8 / scaled / windowed layers) goes
+        by out_cache_loc like the reference.  RX_DEBUG_CHECKS=1 asserts the equality (a host sync) before fusing."""
         q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
         if layer.qk_head_dim != layer.v_head_dim:
             o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
@@ -744,11 +788,16 @@ class HipRadixAttnBackend:
             o = torch.empty_like(q)
         # the KV store of the step rides in the decode launch when the kernel can take it (see _fused_store_ok)
         fuse = save_kv_cache and k is not None and self._fused_store_ok(layer, k, v)
+        if fuse and self._debug_checks and forward_batch.out_cache_loc is not None:
+            slot = self.req_to_token[forward_batch.req_pool_indices.long(), forward_batch.seq_lens.long() - 1]
+            if not torch.equal(slot.long(), forward_batch.out_cache_loc.long().view(-1)):
+                raise AssertionError("fused decode store: req_to_token[req, seq_len - 1] != out_cache_loc "
+                                     "(write_cache_indices / alloc_for_decode must run before the forward)")
         if save_kv_cache and k is not None and not fuse:
             if self.dcp is not None:
                 self._dcp_store(layer, forward_batch, k, v)
             else:
-                self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(forward_batch.out_cache_loc), k, v,
+                self.token_to_kv_pool.set_kv_buffer(layer, self._loc_info(forward_batch.out_cache_loc), k, v,
                                                     layer.k_scale, layer.v_scale)
         md = self.forward_metadata
         q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
@@ -827,7 +876,7 @@ class HipRadixAttnBackend:
                 self._dcp_store(layer, forward_batch, k, v)
             return o
         if save_kv_cache:
-            self.token_to_kv_pool.set_kv_buffer(layer, KVWriteLoc(forward_batch.out_cache_loc), k, v,
+            self.token_to_kv_pool.set_kv_buffer(layer, self._loc_info(forward_batch.out_cache_loc), k, v,
                                                 layer.k_scale, layer.v_scale)
         md = self.forward_metadata
         k_descale, v_descale = self._scales(layer)
