@@ -263,6 +263,9 @@ class HipRadixAttnBackend:
         kernels read.  Every launch-shape decision here depends on ``bs`` only, never on the lengths.  A
         runner that never built graph state gets the eager body (base_attn_backend.py:55-56)."""
         self._build_metadata(forward_batch, graph=self._graph is not None)
+        if self._graph is not None:
+            # from here on a captured graph may hold the static buffers' addresses: nothing may be (re)allocated
+            self._graph["captured"] = True
 
     def _build_metadata(self, forward_batch: ForwardBatch, graph: bool):
         bs = forward_batch.batch_size
@@ -321,8 +324,7 @@ class HipRadixAttnBackend:
                 return None
         order = torch.argsort(fb.seq_lens[:bs], descending=True).to(torch.int32)
         if use_graph_bufs:
-            buf = self._graph.setdefault("request_order", torch.zeros(self._graph["max_bs"], dtype=torch.int32,
-                                                                      device=self.device))
+            buf = self._graph["request_order"]  # address-stable: allocated by init_cuda_graph_state
             buf[:bs].copy_(order)
             return buf[:bs]
         return order
@@ -649,10 +651,14 @@ class HipRadixAttnBackend:
             # would be re-cast into a fresh uint8 tensor on every forward)
             g = self._graph
             need = g["max_bs"] * nd * (self.max_context_len + nd)
-            if g.get("custom_mask") is None or g["custom_mask"].numel() < need:
+            if g.get("custom_mask") is None:
+                if g.get("captured"):
+                    raise RuntimeError("TARGET_VERIFY under graph replay needs server_args.speculative_num_draft_tokens "
+                                       "at init_cuda_graph_state time (the mask buffer must exist before capture)")
                 g["custom_mask"] = torch.zeros(need, dtype=torch.uint8, device=self.device)
-            if custom_mask.numel() > need:
-                raise ValueError("TARGET_VERIFY mask larger than max_bs * nd * (context_len + nd)")
+            if custom_mask.numel() > g["custom_mask"].numel() or need > g["custom_mask"].numel():
+                # never re-allocated: captured kernels hold the address
+                raise ValueError("TARGET_VERIFY mask larger than the graph state's max_bs * nd * (context_len + nd)")
             g["custom_mask"][: custom_mask.numel()].copy_(custom_mask.reshape(-1))
             custom_mask = g["custom_mask"]
         # small verify batches: one workgroup per (request, kv head) would leave the chip idle -- cut the cached
@@ -709,6 +715,14 @@ class HipRadixAttnBackend:
         rows = max(rows, max(b * self._graph_split_slots(b) for b in range(1, max_bs + 1)) * self.num_head)
         self._graph["native_logits"] = torch.zeros(rows * self.v_head_dim, dtype=torch.float32, device=dev)
         self._graph["native_lse"] = torch.zeros(rows, dtype=torch.float32, device=dev)
+        # every buffer a captured kernel reads lives here from the start (a buffer created lazily and re-allocated
+        # after capture would leave the graph reading the old address): the launch order of ragged batches ...
+        self._graph["request_order"] = torch.zeros(max_bs, dtype=torch.int32, device=dev)
+        # ... and the draft tree's mask bytes of TARGET_VERIFY, sized from speculative_num_draft_tokens
+        nd = int(self.num_draft_tokens or 0)
+        if nd > 0:
+            self._graph["custom_mask"] = torch.zeros(max_bs * nd * (self.max_context_len + nd), dtype=torch.uint8,
+                                                     device=dev)
         if self.decode_index_mode == "indices":
             self._graph_kv_indices()
         if self.sliding_window_size is not None:

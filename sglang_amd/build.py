@@ -45,9 +45,9 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    force = force or bool(os.environ.get("RX_BUILD_FORCE"))
     if not force and not needs_build():
         return LIB_PATH
-    force = force or bool(os.environ.get("RX_BUILD_FORCE"))
     hipcc = _hipcc()
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
@@ -67,17 +67,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
                 and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps)):
             continue
-        with open(stamp, "w") as f:
-            f.write(" ".join(cmd))
+        # the stamp is written only AFTER a successful compile, and the stale object goes first: a failed or
+        # interrupted compile must not leave an old .o behind a stamp that now matches the new flags
+        for stale in (obj, stamp):
+            if os.path.exists(stale):
+                os.remove(stale)
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, pr in procs:
+        procs.append((src, stamp, " ".join(cmd), subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = []
+    for src, stamp, line, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+            failed.append(f"hipcc failed on {src}:\n{out.decode()}")
+            continue
+        with open(stamp, "w") as f:
+            f.write(line)
         if verbose and out:
             print(out.decode(), file=sys.stderr)
+    if failed:
+        raise RuntimeError("\n".join(failed))
     tmp = LIB_PATH + ".tmp"
     link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

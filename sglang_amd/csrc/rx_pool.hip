@@ -22,7 +22,7 @@
 namespace rx {
 
 // state words (int64) of a pool
-enum { kFreeHead = 0, kFreeCount = 1, kRelHead = 2, kRelCount = 3, kOom = 4, kBase = 5, kTotal = 6, kStateWords = 8 };
+enum { kFreeHead = 0, kFreeCount = 1, kRelHead = 2, kRelCount = 3, kOom = 4, kBase = 5, kTotal = 6, kOverflow = 7, kStateWords = 8 };
 constexpr int kTile = 2048;  // ids per compaction tile: 256 threads x 8 flags
 
 struct PoolArgs {
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void pool_reset_kernel(PoolArgs p, int64_t fir
     p.state[kRelHead] = 0;
     p.state[kRelCount] = 0;
     p.state[kOom] = 0;
+    p.state[kOverflow] = 0;
   }
 }
 
@@ -192,7 +193,12 @@ __global__ __launch_bounds__(256) void pool_append_kernel(PoolArgs p, int which,
   const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   if (i < n) p.ring[which][wrap(tail + i, p.cap)] = ids[i];
 }
+// kOverflow: the two lists together never hold more than the pool's num_ids ids (ring capacity num_ids + 1).  A double free, or a
+// free_segment whose page was also passed to free(), pushes count + n past it: the ring wraps over live entries and
+// the same page would be handed out twice.  The writes have happened by the time the count moves, so this is a
+// detector, not a guard: the word is surfaced by the host's next read-back (allocator._sync_counts raises).
 __global__ void pool_grow_kernel(PoolArgs p, int which, int64_t n, int front) {
+  if (p.state[kFreeCount] + p.state[kRelCount] + n > p.num_ids) p.state[kOverflow] += 1;
   if (front) p.state[2 * which] = wrap(p.state[2 * which] - n, p.cap);
   p.state[2 * which + 1] += n;
 }
@@ -279,6 +285,7 @@ __global__ __launch_bounds__(256) void pool_tile_scan_kernel(PoolArgs p, int64_t
     const int64_t total = carry_s;
     p.state[kTotal] = total;
     if (mode == 0) {
+      if (p.state[kFreeCount] + p.state[kRelCount] + total > p.num_ids) p.state[kOverflow] += 1;
       const int64_t nh = wrap(p.state[2 * which] - total, p.cap);
       p.state[2 * which] = nh;
       p.state[2 * which + 1] += total;

@@ -76,9 +76,10 @@ class DeviceFreeList:
         return out
 
     def counts(self) -> Tuple[int, int, int]:
-        """(free count, release count, refused allocations): a device -> host read of the state words."""
+        """(free count, release count, refused allocations, list overflows): a device -> host read of the state
+        words."""
         s = self.state.tolist()
-        return int(s[1]), int(s[3]), int(s[4])
+        return int(s[1]), int(s[3]), int(s[4]), int(s[7])
 
     def take(self, num_pages: int, page_size: int) -> torch.Tensor:
         out = torch.empty(num_pages * page_size, dtype=torch.int64, device=self.device)
@@ -124,7 +125,10 @@ class BaseTokenToKVPoolAllocator:
 
     # ---- host mirror -------------------------------------------------------------------------------------------
     def _sync_counts(self) -> None:
-        nf, nr, refused = self._list.counts()
+        nf, nr, refused, overflow = self._list.counts()
+        if overflow:
+            raise RuntimeError(f"allocator: {overflow} free(s) pushed the free + release lists past the pool's "
+                               f"{self.num_ids} pages (a double free, or a page freed both by free() and free_segment())")
         if refused:
             raise RuntimeError(f"allocator: {refused} allocation(s) reached the device without enough free pages "
                                f"(host mirror out of step with the device list)")

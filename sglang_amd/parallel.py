@@ -104,9 +104,14 @@ class CustomAllReduce:
         self._ctx = self._ctxs[0]
         dist.barrier(group=group)  # every region is mapped everywhere before the first call
 
+    def shape_ok(self, x: torch.Tensor) -> bool:
+        """The rank-independent half of ``supports``: dtype and element count only (every rank of a group sees the
+        same answer for the same logical tensor)."""
+        return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.numel() > 0
+                and x.numel() % 8 == 0 and x.numel() * 2 <= self.max_bytes)
+
     def supports(self, x: torch.Tensor) -> bool:
-        return (x.is_cuda and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float16)
-                and x.numel() % 8 == 0 and x.numel() * 2 <= self.max_bytes and x.data_ptr() % 16 == 0)
+        return self.shape_ok(x) and x.is_contiguous() and x.data_ptr() % 16 == 0
 
     def _dt(self, x):
         return self._L.RX_BF16 if x.dtype == torch.bfloat16 else self._L.RX_F16
@@ -172,18 +177,32 @@ class TPGroup:
             self.world_size = dist.get_world_size(group)
         self._comm_stream = None
         self.custom_ar = custom_ar if self.world_size > 1 else None
+        import os
+
+        self._strict = os.environ.get("RX_CUSTOM_AR_STRICT", "0") not in ("", "0")
 
     def _reduce(self, x: torch.Tensor, lane: int = 0) -> None:
-        # ONE implementation per group: mixing the peer-to-peer kernel (fp32 sums in rank order) with RCCL (its own
-        # order) inside a run would make results depend on tensor shapes.  A tensor the custom kernel cannot take
-        # is an error when it is selected, not a silent switch.
-        if self.custom_ar is not None:
-            if not self.custom_ar.supports(x):
-                raise ValueError("custom all-reduce selected but the tensor is not contiguous 16-bit, 16-byte "
-                                 f"aligned, a multiple of 8 elements and <= {self.custom_ar.max_bytes} bytes")
-            self.custom_ar.all_reduce(x, lane=lane)
-        else:
-            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        # Per tensor, like GroupCoordinator.all_reduce's should_custom_ar test (parallel_state.py:672-700): the
+        # peer-to-peer kernel takes what it can (decode-sized 16-bit activations), everything else -- prefill-sized
+        # activations above max_bytes, fp32, odd element counts -- goes to RCCL.  The choice depends on dtype and
+        # element count ONLY, never on addresses or strides, so every rank makes the same one (a rank-dependent
+        # choice would deadlock: half the group in the kernel's flag exchange, half in RCCL); a tensor the shape
+        # rule sends to the kernel but whose memory it cannot take (a strided or misaligned view) is reduced
+        # through a contiguous copy.  RX_CUSTOM_AR_STRICT=1 raises instead of falling back (debugging: "which of my
+        # tensors are missing the fast path").
+        ar = self.custom_ar
+        if ar is not None and ar.shape_ok(x):
+            if ar.supports(x):
+                ar.all_reduce(x, lane=lane)
+            else:
+                tmp = x.contiguous().clone() if x.is_contiguous() else x.contiguous()
+                ar.all_reduce(tmp, lane=lane)
+                x.copy_(tmp)
+            return
+        if ar is not None and self._strict:
+            raise ValueError("custom all-reduce selected (RX_CUSTOM_AR_STRICT) but the tensor is not 16-bit, a "
+                             f"multiple of 8 elements and <= {ar.max_bytes} bytes: {x.dtype} x {x.numel()}")
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
 
     def fused_allreduce_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float):
         """tensor_model_parallel_fused_allreduce_rmsnorm (communication_op.py -> parallel_state.py:748-878):

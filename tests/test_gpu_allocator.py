@@ -115,7 +115,32 @@ def test_out_of_pages_is_decided_on_the_host_before_any_launch():
     assert got.tolist() == list(range(ps, 5 * ps))
     one = torch.tensor([4 * ps + 1])
     assert a.alloc_decode(one.to(DEV), one, got[-1:]) is None    # needs a fifth page
-    assert a._list.counts() == (0, 0, 0)                        # nothing was refused ON the device
+    assert a._list.counts() == (0, 0, 0, 0)                     # nothing was refused ON the device
+
+
+def test_double_free_is_detected_on_the_device():
+    """the rings hold num_ids + 1 entries; a double free (or a page freed by free() AND free_segment())
+    would wrap a list over live entries and hand a page out twice.  The grow / sorted-insert kernels count the
+    event in a state word and the host's next read-back raises."""
+    from sglang_amd.mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
+
+    a = TokenToKVPoolAllocator(64, torch.bfloat16, DEV, None)
+    x = a.alloc(10)
+    a.free(x)
+    assert a.available_size() == 64
+    a.free(x[:3])                                              # again: 67 ids in a pool of 64
+    a._n_free = None
+    with pytest.raises(RuntimeError, match="double free"):
+        a.available_size()
+    ps = 16
+    b = PagedTokenToKVPoolAllocator(8 * ps, ps, torch.bfloat16, DEV, None)
+    y = b.alloc(8 * ps)
+    b.free(y)                                                  # sorted insert of 8 pages: the pool is whole again
+    assert b.available_size() == 8 * ps
+    b.free(y[: 2 * ps])                                        # the same pages once more
+    b._n_free = None
+    with pytest.raises(RuntimeError, match="double free"):
+        b.available_size()
 
 
 def test_large_pool_sorted_insert_and_merge_use_many_tiles():

@@ -131,11 +131,37 @@ for rep in range(2):
 
 assert ar.check_errors() == 0
 assert not ar.supports(torch.zeros(7, device=dev, dtype=torch.bfloat16))
+# per-tensor routing (GroupCoordinator.all_reduce's should_custom_ar, parallel_state.py:672-700): what the kernel cannot
+# take -- odd counts, fp32, messages above max_bytes -- is reduced by the group's backend; a strided view the shape
+# rule accepts goes through a contiguous copy.  The rule reads dtype and element count only (same on every rank).
+for n, dt in [(7, torch.bfloat16), (1024, torch.float32), ((4 << 20) // 2 + 8, torch.bfloat16)]:
+    parts = parts_for(n, n, dt)
+    x = parts[rank].to(dev)
+    assert not ar.shape_ok(x)
+    tp.all_reduce(x)
+    torch.cuda.synchronize()
+    want = sum(p.float() for p in parts)
+    if not torch.allclose(x.cpu().float(), want, rtol=2e-2, atol=2e-2):
+        ok = False
+        print(f"rank {rank} fallback n {n} {dt}: max diff", (x.cpu().float() - want).abs().max().item(), flush=True)
+parts = parts_for(99, 2 * 4096, torch.bfloat16)
+base = parts[rank].to(dev).view(4096, 2)
+view = base[:, 0]                                   # strided: shape_ok, not supports
+assert ar.shape_ok(view) and not ar.supports(view)
+tp.all_reduce(view)
+torch.cuda.synchronize()
+want = sum(p.view(4096, 2)[:, 0].float() for p in parts).to(torch.bfloat16)
+if not torch.equal(view.cpu(), want) or not torch.equal(base[:, 1].cpu(), parts[rank].view(4096, 2)[:, 1]):
+    ok = False
+    print(f"rank {rank} strided view through the kernel: mismatch", flush=True)
+tp._strict = True                                   # RX_CUSTOM_AR_STRICT=1: no fallback, an error
 try:
-    tp.all_reduce(torch.zeros(7, device=dev, dtype=torch.bfloat16))   # no silent switch to another implementation
+    tp.all_reduce(torch.zeros(7, device=dev, dtype=torch.bfloat16))
     ok = False
 except ValueError:
     pass
+tp._strict = False
+assert ar.check_errors() == 0
 ar.close()
 dist.destroy_process_group()
 print("RANK_OK" if ok else "RANK_FAIL", flush=True)
