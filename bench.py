@@ -68,7 +68,9 @@ def parse():
     ap.add_argument("--no-extend", action="store_true")
     ap.add_argument("--no-radix-hit", action="store_true", help="skip the shared-prefix (radix-hit) decode leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--cpu-worker", default=None, choices=["reference", "port"])
+    ap.add_argument("--cpu-chunk", type=int, default=8,
+                    help="requests of the config-3 chunk the extend CPU baseline runs (the GPU leg runs 32)")
+    ap.add_argument("--cpu-worker", default=None, choices=["reference", "port", "reference-extend", "port-extend"])
     ap.add_argument("--extend-only", action="store_true", help="dev: run only the extend leg")
     ap.add_argument("--tp-sim", type=int, default=0, help="dev: run ONE rank's shard of a TP=N job on one GPU (no collective)")
     ap.add_argument("--no-graph", action="store_true",
@@ -440,6 +442,8 @@ def cpu_worker(args):
     """Runs in a child process that never touches the GPU: times one layer of the decode path on
     the host cores with synthetic data of the bench's shapes and prints one JSON line."""
     kind = args.cpu_worker
+    if kind.endswith("-extend"):
+        return cpu_extend_worker(args, kind[: -len("-extend")])
     bs, ctx, ps = args.bs, args.ctx, args.page_size
     HQ, HKV, D = 32, 8, 128
     pages = bs * ((ctx + ps - 1) // ps)
@@ -499,19 +503,92 @@ def cpu_worker(args):
                                 f"bs/({args.layers}*t_layer); host: {_cpu_model()}"}))
 
 
-def cpu_baseline(args):
+def cpu_extend_worker(args, kind):
+    """The extend half of the metric on the host cores (`extend_attention_cpu`, aot/csrc/cpu/extend.cpp:425):
+    one layer of a config-3 chunk -- requests sharing one 3584-token cached prefix (identical req_to_token prefixes:
+    the radix hit) + 512 new tokens each, Hq 32 / Hkv 8 / D 128, bf16, page-16 shuffled pages.  The sample is
+    bounded: `--cpu-chunk` requests (default 8, a quarter of the GPU leg's 32-request chunk); FLOPs counted with
+    the GPU leg's formula, so the two TFLOP/s figures are the same quantity."""
+    HQ, HKV, D, P, E, ps = 32, 8, 128, 3584, 512, args.page_size
+    chunk = args.cpu_chunk
+    torch.set_num_threads(os.cpu_count())
+    g = torch.Generator().manual_seed(7)
+    n_pages = (P + ps - 1) // ps + chunk * ((E + ps - 1) // ps) + 1
+    kb = torch.empty(n_pages * ps, HKV, D, dtype=torch.bfloat16).normal_(generator=g)
+    vb = torch.empty(n_pages * ps, HKV, D, dtype=torch.bfloat16).normal_(generator=g)
+    T = chunk * E
+    q = torch.randn(T, HQ, D, generator=g).to(torch.bfloat16)
+    k_ext = torch.randn(T, HKV, D, generator=g).to(torch.bfloat16)
+    v_ext = torch.randn(T, HKV, D, generator=g).to(torch.bfloat16)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(np.arange(1, n_pages))
+    npp, npe = (P + ps - 1) // ps, (E + ps - 1) // ps
+    pre_slots = (perm[:npp, None] * ps + np.arange(ps)[None]).reshape(-1)[:P]
+    r2t = torch.zeros(chunk + 1, P + E + ps, dtype=torch.int32)
+    for i in range(chunk):
+        own = (perm[npp + i * npe: npp + (i + 1) * npe, None] * ps + np.arange(ps)[None]).reshape(-1)[:E]
+        r2t[i + 1, :P] = torch.from_numpy(pre_slots.astype(np.int32))
+        r2t[i + 1, P: P + E] = torch.from_numpy(own.astype(np.int32))
+    rpi = torch.arange(1, chunk + 1, dtype=torch.int64)
+    seq = torch.full((chunk,), P + E, dtype=torch.int64)
+    ext = torch.full((chunk,), E, dtype=torch.int32)
+    start = (torch.arange(chunk, dtype=torch.int32) * E)
+    if kind == "reference":
+        from oracle import build_ref
+
+        m = build_ref.load()
+        if m is None:
+            raise SystemExit("oracle/_ref not built")
+        out = torch.zeros(T, HQ, D, dtype=torch.bfloat16)
+
+        def run():
+            m.extend_attention_cpu(q, k_ext, v_ext, out, kb, vb, r2t, rpi, seq, ext, start, E, D ** -0.5, 0.0, False,
+                                   0, None, None, None)
+        threads = torch.get_num_threads()
+        what = "extend_attention_cpu, the reference's own aot/csrc/cpu/extend.cpp built by oracle/build_ref.py"
+    else:
+        from oracle import c_oracle
+
+        bits = lambda t: t.contiguous().view(torch.uint16).numpy()  # noqa: E731
+        qo = (np.arange(chunk + 1) * E).astype(np.int64)
+        kvp = (np.arange(chunk + 1) * P).astype(np.int32)
+        kvi = np.tile(pre_slots.astype(np.int64), chunk)
+        qb, keb, veb, kbb, vbb = bits(q), bits(k_ext), bits(v_ext), bits(kb), bits(vb)
+
+        def run():
+            c_oracle.extend_bf16(qb, keb, veb, kbb, vbb, qo, kvp, kvi, D ** -0.5)
+        threads = c_oracle.num_threads()
+        what = "oracle/rx_oracle.c extend (C restatement, OpenMP)"
+    run()
+    ts = []
+    t_end = time.perf_counter() + args.cpu_seconds
+    while len(ts) < 2 or (time.perf_counter() < t_end and len(ts) < 50):
+        t0 = time.perf_counter(); run(); ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    flops = 2.0 * HQ * (D + D) * chunk * (E * P + E * (E + 1) / 2)
+    print(json.dumps({"value": flops / t / 1e12, "unit": "TFLOP/s", "cores": threads, "kind": kind,
+                      "ms_per_chunk": t * 1e3, "chunk_requests": chunk, "flops_per_chunk": flops,
+                      "sample": f"{what}; ONE layer of a config-3 chunk cut to {chunk} requests x ({P} shared cached + "
+                                f"{E} new tokens), Hq=32, Hkv=8, D=128, bf16, page_size={ps} shuffled pages; median "
+                                f"of {len(ts)} runs = {t*1e3:.1f} ms; FLOPs = 4*Hq*D*sum(E*P + E*(E+1)/2) as the GPU "
+                                f"leg counts them; host: {_cpu_model()}"}))
+
+
+def cpu_baseline(args, leg="decode"):
     """Spawn the CPU worker as a child (a reference build using ISA this host lacks would die with
     SIGILL; the child isolates that) -- reference kernel first, C port as the fallback."""
     import subprocess
 
     base = [sys.executable, os.path.abspath(__file__), "--bs", str(args.bs), "--ctx", str(args.ctx),
             "--layers", str(args.layers), "--page-size", str(args.page_size),
-            "--cpu-seconds", str(args.cpu_seconds)]
+            "--cpu-seconds", str(args.cpu_seconds), "--cpu-chunk", str(args.cpu_chunk)]
+    suffix = "-extend" if leg == "extend" else ""
+    unit = "TFLOP/s" if leg == "extend" else "tokens/s"
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(os.cpu_count()), OMP_WAIT_POLICY="passive")
     errors = []
     for kind in ("reference", "port"):
         try:
-            r = subprocess.run(base + ["--cpu-worker", kind], capture_output=True, text=True, env=env,
+            r = subprocess.run(base + ["--cpu-worker", kind + suffix], capture_output=True, text=True, env=env,
                                timeout=args.cpu_seconds * 6 + 240)
             if r.returncode == 0:
                 res = json.loads(r.stdout.strip().splitlines()[-1])
@@ -521,7 +598,7 @@ def cpu_baseline(args):
             errors.append(f"{kind}: rc={r.returncode} {r.stderr.strip()[-200:]}")
         except Exception as e:
             errors.append(f"{kind}: {e}")
-    return {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": "; ".join(errors)}
+    return {"value": None, "unit": unit, "cores": 0, "kind": "port", "sample": "; ".join(errors)}
 
 
 def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=8):
@@ -1079,6 +1156,9 @@ def main():
             out["heterogeneous_decode"] = {"error": str(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
+        if isinstance(out.get("extend"), dict) and "error" not in out["extend"]:
+            # the extend half of the metric beside its own CPU figure (SURVEY 8d names both CPU kernels)
+            out["extend"]["cpu_baseline"] = cpu_baseline(args, leg="extend")
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -74,8 +74,13 @@ def check_out(got, want, dtype, tag=None, ulps=1.0, absw=None):
     diff = np.abs(got - want)
     ratio = float((diff / bound).max()) if diff.size else 0.0
     err = float(diff.max()) if diff.size else 0.0
+    # reported, not asserted (profiles/rNN_parity_errors.json): the same check against the fp16 bar
+    # max(1e-3, ulps * ulp(|want|)) with no absw term -- for bf16 "would it pass without the 4e-3 floor"
+    strict = np.maximum(1e-3, ulps * _ulp(want, 10 if name == "fp16" else 7))
+    ratio_strict = float((diff / strict).max()) if diff.size else 0.0
     rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "err": err,
-           "tol": float(bound.min()) if diff.size else 0.0, "ratio": ratio, "dtype": name, "ulps": ulps}
+           "tol": float(bound.min()) if diff.size else 0.0, "ratio": ratio, "dtype": name, "ulps": ulps,
+           "ratio_floor_1e-3_no_absw": ratio_strict, "absw": absw is not None}
     if tag is not None:
         rec["tag"] = str(tag)
     try:

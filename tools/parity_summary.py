@@ -19,15 +19,26 @@ for line in open(src):
     params = t[t.index("[") + 1: -1] if "[" in t else ""
     dt = r.get("dtype") or ("fp16" if re.search(r"float16|fp16", params) else ("bf16" if re.search(r"bfloat16|bf16", params) else ""))
     key = (os.path.basename(t.split("::")[0]), fn, dt)
-    g = groups.setdefault(key, {"checks": 0, "max_err": 0.0, "tol": 0.0, "max_err_over_bound": None, "worst": None})
+    g = groups.setdefault(key, {"checks": 0, "max_err": 0.0, "tol": 0.0, "max_err_over_bound": None, "worst": None,
+                                "checks_with_strict_ratio": 0, "pass_at_floor_1e-3_1ulp_no_absw": 0,
+                                "max_err_over_strict_bound": None})
     g["checks"] += 1
     g["tol"] = max(g["tol"], r["tol"])
     if "ratio" in r:  # element-wise bound (parity_util.check_out): worst |err| / bound over all elements
         g["max_err_over_bound"] = max(g["max_err_over_bound"] or 0.0, r["ratio"])
+    if "ratio_floor_1e-3_no_absw" in r:  # the fp16 bar max(1e-3, ulps * ulp) without the |V| term, reported only
+        g["checks_with_strict_ratio"] += 1
+        g["pass_at_floor_1e-3_1ulp_no_absw"] += int(r["ratio_floor_1e-3_no_absw"] <= 1.0)
+        g["max_err_over_strict_bound"] = max(g["max_err_over_strict_bound"] or 0.0, r["ratio_floor_1e-3_no_absw"])
     if r["err"] >= g["max_err"]:
         g["max_err"], g["worst"] = r["err"], (params + (" | " + r["tag"] if r.get("tag") else ""))[:160]
 out = [{"file": k[0], "test": k[1], "dtype": k[2], **v} for k, v in groups.items()]
+bf = [o for o in out if o["dtype"] == "bf16" and o["checks_with_strict_ratio"]]
 doc = {"source": os.path.relpath(src, ROOT), "north_star_bar_fp16": 1e-3,
+       "bf16_checks_at_1ulp_without_the_4e-3_floor": {
+           "checks": sum(o["checks_with_strict_ratio"] for o in bf),
+           "pass": sum(o["pass_at_floor_1e-3_1ulp_no_absw"] for o in bf),
+           "bound": "max(1e-3, ulps * ulp_bf16(|want|)), no |V| term"},
        "fp16_checks_over_1e-3": [o for o in out if o["dtype"] == "fp16" and o["max_err"] > 1e-3], "groups": out}
 text = json.dumps(doc, indent=1)
 if dst:
