@@ -338,6 +338,12 @@ def test_cpu_baseline_container_fixture(golden_dir):
     for k in ("reference", "port"):
         assert d[k]["ms_per_layer"] > 0 and abs(d[k]["value"] - 256 / (32 * d[k]["ms_per_layer"] * 1e-3)) < 1e-6
     assert d["parity_max_abs_reference_vs_port_small_case"] <= 2e-3  # bf16 outputs of two summation orders
+    # round 3: the extend half of the metric (extend_attention_cpu, extend.cpp:425) beside it
+    for k in ("extend_reference", "extend_port"):
+        e = d[k]
+        assert e["unit"] == "TFLOP/s" and e["kind"] == k.split("_")[1]
+        assert abs(e["value"] - e["flops_per_chunk"] / (e["ms_per_chunk"] * 1e-3) / 1e12) < 1e-6
+    assert d["extend_parity_max_abs_reference_vs_port_small_case"] <= 8e-3  # one bf16 ulp at |o| in [1, 2)
 
 
 def test_a14_torch_native_semantics_pinned_to_the_reference(golden_dir):
