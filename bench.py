@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel of the decode step eagerly instead of replaying HIP graphs")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
+    ap.add_argument("--ar-leg", action="store_true",
+                    help="internal: the peer-to-peer all-reduce leg of an N > 1 run (started by rank 0 of the main run as "
+                         "a fresh child job with RX_CUSTOM_AR=1; prints its own JSON line)")
+    ap.add_argument("--no-custom-ar-leg", action="store_true", help="N > 1: skip the peer-to-peer all-reduce child leg")
     return ap.parse_args()
 
 
@@ -917,6 +921,100 @@ def rccl_capturable(dev) -> bool:
     return bool(t.item())
 
 
+def first_contact(grp, world, rank, local_rank, dev, impl):
+    """Before anything is timed at N > 1: (1) who is here -- every rank's device, and its hipDeviceCanAccessPeer row;
+    (2) ONE all-reduce through the group the step will use, checked on every rank against a locally computed fp32
+    sum of seeded per-rank tensors (every rank can regenerate every rank's input).  Bound: inputs are bf16 in
+    [-1, 1); a ring rounds to bf16 after each of its W - 1 adds, so |got - want| <= (W - 1) 2^-8 sum_r |x_r| + 2^-10
+    element-wise holds for ANY correct implementation and order (the two-shot kernel sums in fp32: one rounding).
+    A wrong or hung reduce must not become a throughput number: every rank exits non-zero.  Mirrors the reference's
+    own bring-up (custom_all_reduce.py:260-307 checks peer access and falls back; parallel_state.py:622-732)."""
+    import torch.distributed as dist
+
+    ndev = torch.cuda.device_count()
+    peers = []
+    for j in range(ndev):
+        try:
+            peers.append(1 if j == local_rank else int(torch.cuda.can_device_access_peer(local_rank, j)))
+        except Exception:  # noqa: BLE001
+            peers.append(-1)
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(dev),
+          "can_access_peer": peers, "pid": os.getpid()}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    n = 256 * 4096  # the step's message: bs x hidden bf16 = 2 MiB
+    parts = [torch.rand(n, generator=torch.Generator().manual_seed(1000 + r)).mul_(2).sub_(1).to(torch.bfloat16)
+             for r in range(world)]
+    want = torch.stack([p.float() for p in parts]).sum(0)
+    x = parts[rank].to(dev)
+    t0 = time.perf_counter()
+    grp.all_reduce(x)
+    torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    got = x.float().cpu()
+    # any summation order with a bf16 rounding after every add (a ring does W - 1 of them) stays within
+    # (W - 1) * 2^-8 * sum_r |x_r|; a dropped or doubled rank is off by |x_r| ~ 0.5, far outside it
+    abs_sum = torch.stack([p.float().abs() for p in parts]).sum(0)
+    err = (got - want).abs()
+    bound = max(1, world - 1) * 2.0 ** -8 * abs_sum + 2.0 ** -10
+    bad = int((err > bound).sum())
+    ok = torch.tensor([0 if (bad or not torch.isfinite(got).all()) else 1], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    res = {"ranks_seen": sorted(e["rank"] for e in everyone), "world": world, "implementation": impl,
+           "devices": [e["device"] for e in everyone], "can_access_peer": [e["can_access_peer"] for e in everyone],
+           "all_reduce_check": {"elements": n, "dtype": "bf16", "max_abs_err": float(err.max()),
+                                "bound": "(W-1) * 2^-8 * sum_r|x_r| + 2^-10, element-wise", "elements_out_of_bound_rank0": bad,
+                                "first_call_ms": first_ms, "ok_on_every_rank": bool(ok.item())}}
+    if rank == 0:
+        print("[bench] first contact: " + json.dumps(res), file=sys.stderr, flush=True)
+    if not bool(ok.item()):
+        raise SystemExit(f"[bench] rank {rank}: the all-reduce ({impl}) disagrees with the fp32 sum of the seeded "
+                         f"inputs ({bad} elements out of bound here); refusing to time it")
+    return res
+
+
+def custom_ar_child_leg(args, world):
+    """Rank 0 of an N > 1 run: the same decode step with the peer-to-peer two-shot all-reduce (RX_CUSTOM_AR=1) as
+    a FRESH child job -- its own torch.distributed.run, N new processes on the same N GPUs, never a re-exec of a
+    process that touched the GPU -- so that a kernel that times out or faults across xGMI (it has only ever run as
+    N processes on ONE GPU) costs this leg, not the run: the child is bounded by a timeout, its process group is
+    the one started here and is the only thing killed, and its non-zero exit becomes an "error" entry."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(world), "--ar-leg", "--steps", str(max(3, args.steps // 2)), "--warmup", "2", "--settle", "2",
+           "--bs", str(args.bs), "--ctx", str(args.ctx), "--layers", str(args.layers), "--page-size", str(args.page_size),
+           "--kv-layout", args.kv_layout, "--index-mode", args.index_mode, "--split-policy", args.split_policy,
+           "--max-kv-splits", str(args.max_kv_splits)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RX_CUSTOM_AR="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
+              "GROUP_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+              "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
+        env.pop(k, None)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    limit = float(os.environ.get("RX_BENCH_AR_LEG_TIMEOUT_S", "300"))
+    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = pr.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)  # exactly the process group started above
+        except OSError:
+            pass
+        out, err = pr.communicate()
+        return {"error": f"child job exceeded {limit:.0f} s and was stopped", "stderr_tail": err[-400:]}
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if pr.returncode != 0 or not lines:
+        return {"error": f"child job rc={pr.returncode}", "stderr_tail": err[-600:]}
+    return json.loads(lines[-1])
+
+
 def allreduce_figures(st, fb, world, args, step_fn_factory):
     """SURVEY 8d 'TP scaling': the o_proj all-reduce alone, and the step with / without the side-stream overlap."""
     import torch.distributed as dist
@@ -944,6 +1042,46 @@ def allreduce_figures(st, fb, world, args, step_fn_factory):
     return res
 
 
+def ar_leg_main(args, st, fb, world, rank, dev, contact):
+    """--ar-leg (child job of custom_ar_child_leg): the decode step with the peer-to-peer all-reduce -- first
+    contact already passed -- timed alone and inside the step with / without the side-stream overlap."""
+    import torch.distributed as dist
+
+    st.ev_stride, st.ev_pool = 8, []
+
+    def make_step():
+        gs = None
+        try:
+            gs = GraphStep(st, fb, world)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench --ar-leg] capture failed ({type(e).__name__}: {e}); eager step", file=sys.stderr)
+        ok = torch.tensor([0 if gs is None else 1], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if bool(ok.item()):
+            return lambda: gs(None)
+        return lambda: decode_step(st, fb, world, None)
+
+    step = make_step()
+    for _ in range(args.settle + args.warmup):
+        step()
+    dt = time_steps(step, args.steps, 0, world)
+    res = allreduce_figures(st, fb, world, args, make_step)
+    err = st.custom_ar.check_errors() if st.custom_ar is not None else 0
+    flag = torch.tensor([err], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    res.update({"implementation": contact["implementation"], "n_gpus": world, "ms_per_step": dt / args.steps * 1e3,
+                "tokens_per_s": args.bs / (dt / args.steps), "first_contact": contact["all_reduce_check"],
+                "device_side_timeouts": int(flag.item())})
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if st.custom_ar is not None:
+        st.custom_ar.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    if int(flag.item()):
+        raise SystemExit(3)
+
+
 def main():
     args = parse()
     if args.cpu_worker:
@@ -965,10 +1103,21 @@ def main():
     from sglang_amd.forward_batch import ForwardBatch
 
     tp = args.tp_sim or world
+    if args.ar_leg:
+        os.environ["RX_CUSTOM_AR"] = "1"
     st = make_decode_state(args, tp, dev)
     st.overlap = True
     fb = ForwardBatch.for_decode(st.req_pool_indices, st.seq_lens, st.out_cache_loc, st.seq_lens_cpu)
     comm_backend = os.environ.get("RX_BENCH_BACKEND", "nccl") if world > 1 else "none"
+    contact = None
+    if world > 1:
+        impl = ("p2p-two-shot (rx_allreduce over IPC regions)" if getattr(st, "custom_ar", None) is not None
+                else ("rccl" if comm_backend == "nccl" else comm_backend))
+        contact = first_contact(st.o_proj.group, world, rank, local_rank, dev, impl)
+        if getattr(st, "custom_ar", None) is not None and st.custom_ar.check_errors():
+            raise SystemExit("[bench] the peer-to-peer all-reduce reported a device-side timeout on first contact")
+    if args.ar_leg:
+        return ar_leg_main(args, st, fb, world, rank, dev, contact)
 
     # ---- the step: HIP-graph replay (default) or eager launches
     use_graph, graph_note = not args.no_graph, None
@@ -1076,6 +1225,17 @@ def main():
             ar = allreduce_figures(st, fb, world, args, make_step)
         except Exception as e:  # noqa: BLE001
             ar = {"error": f"{type(e).__name__}: {e}"}
+        ar["implementation"] = contact["implementation"] if contact else None
+        # the other implementation's timing leg, as a fresh child job (see custom_ar_child_leg); the other ranks wait
+        if getattr(st, "custom_ar", None) is None and not args.no_custom_ar_leg:
+            leg = [None]
+            if rank == 0:
+                try:
+                    leg[0] = custom_ar_child_leg(args, world)
+                except Exception as e:  # noqa: BLE001
+                    leg[0] = {"error": f"{type(e).__name__}: {e}"}
+            dist.broadcast_object_list(leg, src=0)
+            ar["p2p_two_shot_leg"] = leg[0]
 
     out = {
         "metric": "decode tokens/sec + extend TFLOPS, Llama-3-8B bs=256 ctx=4k (value = decode tokens/s of the "
@@ -1103,6 +1263,8 @@ def main():
     }
     if ar is not None:
         out["all_reduce"] = ar
+    if contact is not None:
+        out["first_contact"] = contact
     if args.tp_sim:
         out["config"]["tp_sim"] = ("ONE rank's shard of a TP=%d job on one GPU, no collective: not a %d-GPU number"
                                    % (tp, tp))

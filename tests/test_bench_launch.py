@@ -76,6 +76,15 @@ def test_bench_gpus_2_runs_two_ranks_on_one_gpu(extra):
     assert out["config"]["all_reduce"] == "gloo" and out["steps"] == 2
     assert len(out["roofline"]["per_rank_frac"]) == 2
     assert {"alone_us", "step_ms_overlap", "step_ms_no_overlap"} <= set(out["all_reduce"])
+    # first contact: both ranks seen, the reduce checked against the fp32 sum before anything was timed
+    fc = out["first_contact"]
+    assert fc["ranks_seen"] == [0, 1] and fc["implementation"] == "gloo" and fc["all_reduce_check"]["ok_on_every_rank"]
+    assert len(fc["can_access_peer"]) == 2
+    # the other implementation (peer-to-peer two-shot kernel) ran as a fresh child job and reported its own timings
+    leg = out["all_reduce"]["p2p_two_shot_leg"]
+    assert "error" not in leg, leg
+    assert leg["implementation"].startswith("p2p-two-shot") and leg["device_side_timeouts"] == 0
+    assert leg["first_contact"]["ok_on_every_rank"] and {"alone_us", "step_ms_overlap", "step_ms_no_overlap"} <= set(leg)
     # the extend half of the metric is reported at N > 1 too: every rank's head shard, slowest rank's time
     assert "error" not in out["extend"], out["extend"]
     assert out["extend"]["tflops"] > 0 and out["extend"]["sharding"].startswith("tp2")
