@@ -87,7 +87,13 @@ def _extend_then_decode(ops, dtype, hq, hkv, d, page, prefix, ext, tol_o):
                              None, True, None, int(max(ext)), 1.0, 1.0, sm_scale=sm, page_size=page)
     want = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr, kv_indices,
                                 sm_scale=sm)
-    parity.check_out(o.float().cpu().numpy(), want, dtype, "extend", ulps=1)
+    # bf16 P carries 8 bits: on the first causal rows (few visible keys, cancelling values) its rounding exceeds an ulp
+    # of |o| -- the u * sum p|v| term (parity_util.check_out) covers exactly that; fp16 is held to the bar as written
+    absw = None
+    if dtype == torch.bfloat16:
+        absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve)), _bits(kb),
+                                    parity.abs_values(_bits(vb)), qo, kv_indptr, kv_indices, sm_scale=sm)
+    parity.check_out(o.float().cpu().numpy(), want, dtype, "extend", ulps=1, absw=absw)
     # one decode step on top
     lens = np.asarray(seq, dtype=np.int64)
     new_loc = np.array([r2t[i + 1, s - 1] for i, s in enumerate(seq)], dtype=np.int64)
