@@ -552,6 +552,8 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
 }
 
 int launch_extend32(const rx_extend_params* p, hipStream_t s);  // rx_extend32.hip (D = 128)
+bool extend_pw_supports(const rx_extend_params* p);               // rx_extend_pw.hip (D = 128 plain call, 4 waves x 64 rows)
+int launch_extend_pw(const rx_extend_params* p, hipStream_t s);
 bool extend_nd_supports(int dk, int dv);                          // rx_extend_nd.hip (256/256, 192/128, ...)
 int launch_extend_nd(const rx_extend_params* p, hipStream_t s);
 bool extend_d256_supports(const rx_extend_params* p);              // rx_extend_d256.hip (256 / 256, AGPR accumulators, LDS-DMA tiles)
@@ -562,6 +564,10 @@ int launch_extend_mla(const rx_extend_params* p, hipStream_t s);
 }  // namespace rx
 
 using namespace rx;
+
+#ifndef RX_EXT_PW_DEFAULT
+#define RX_EXT_PW_DEFAULT 0  // until the four-wave kernel is parity-green and faster on the GPU: opt-in
+#endif
 
 // total_q for the generic path is bs * max_extend_len (an upper bound); blocks past the real
 // token count exit early.
@@ -612,6 +618,16 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
       return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: q_pack needs head_dim 128, 16-byte aligned o and no unified_prefix_lens");
     RX_REQUIRE(p->num_q_heads == p->num_kv_heads * p->q_pack, "rx_extend_attn: q_pack = %d must be Hq / Hkv = %d / %d",
                p->q_pack, p->num_q_heads, p->num_kv_heads);
+  }
+  // D = 128, the plain call, enough tiles per workgroup to amortise a 256-row workgroup's prologue: four waves x 64 rows
+  // (rx_extend_pw.hip).  RX_EXT_PW: 0 never, 2 whenever the kernel supports the call (tests), default = by the estimate.
+  if (mfma_ok && dk == 128 && o16 && extend_pw_supports(p)) {
+    static const int pw_mode = getenv("RX_EXT_PW") ? atoi(getenv("RX_EXT_PW")) : RX_EXT_PW_DEFAULT;
+    const int est_tiles = (p->avg_kv_len_hint + p->max_extend_len / 2) / 64;
+    if (pw_mode == 2 || (pw_mode == 1 && est_tiles >= 28 && p->max_extend_len > 128)) {
+      const int rc = launch_extend_pw(p, static_cast<hipStream_t>(stream));
+      return rc != RX_OK ? rc : check_launch("rx_extend_attn");
+    }
   }
   if (mfma_ok && dk == 128 && o16 && (p->q_pack > 1 || p->kv.kv_fp8 || extras || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
     const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));
