@@ -622,7 +622,8 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   // D = 128, the plain call, enough tiles per workgroup to amortise a 256-row workgroup's prologue: four waves x 64 rows
   // (rx_extend_pw.hip).  RX_EXT_PW: 0 never, 2 whenever the kernel supports the call (tests), default = by the estimate.
   if (mfma_ok && dk == 128 && o16 && extend_pw_supports(p)) {
-    static const int pw_mode = getenv("RX_EXT_PW") ? atoi(getenv("RX_EXT_PW")) : RX_EXT_PW_DEFAULT;
+    const char* pw_env = getenv("RX_EXT_PW");  // read per call: tests flip it inside one process
+    const int pw_mode = pw_env ? atoi(pw_env) : RX_EXT_PW_DEFAULT;
     const int est_tiles = (p->avg_kv_len_hint + p->max_extend_len / 2) / 64;
     if (pw_mode == 2 || (pw_mode == 1 && est_tiles >= 28 && p->max_extend_len > 128)) {
       const int rc = launch_extend_pw(p, static_cast<hipStream_t>(stream));

@@ -100,6 +100,10 @@ def _bits(t):
     return t.detach().cpu().numpy()
 
 
+def _f64(t):  # a kernel OUTPUT as float64 values (not bit patterns)
+    return t.detach().float().cpu().numpy().astype(np.float64)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("page_size", [1, 16])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -176,7 +180,7 @@ def test_extend_and_decode_through_a_foreign_reference_shaped_pool(page_size, dt
         absw = orc.sdpa_extend_req_to_token(_bits(q.view(T, hq, d)), _bits(kb), parity.abs_values(_bits(vb)),
                                             _bits(r2t.req_to_token), np.array(rows), np.array(seq), np.array(prefix),
                                             np.array(extend), d ** -0.5)
-    parity.check_out(_bits(o.view(T, hq, d)).astype(np.float64), want, dtype, ("foreign_pool_extend", ps), absw=absw)
+    parity.check_out(_f64(o.view(T, hq, d)), want, dtype, ("foreign_pool_extend", ps), absw=absw)
 
     # ---- two decode steps: each store must go through the pool's set_kv_buffer (no fused store on a foreign pool)
     for step in range(2):
@@ -194,7 +198,7 @@ def test_extend_and_decode_through_a_foreign_reference_shaped_pool(page_size, dt
         assert torch.equal(kb[loc], k.view(bs, hkv, d)) and torch.equal(vb[loc], v.view(bs, hkv, d))
         want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, d)), _bits(kb), _bits(vb), _bits(r2t.req_to_token),
                                             np.array(rows), np.array(seq), d ** -0.5)
-        parity.check_out(_bits(o.view(bs, hq, d)).astype(np.float64), want, dtype, ("foreign_pool_decode", ps, step))
+        parity.check_out(_f64(o.view(bs, hq, d)), want, dtype, ("foreign_pool_decode", ps, step))
     assert pool.loc_types == {"foreign_kv_pool.KVWriteLoc"}
 
     # a foreign pool that opts in gets the fused store (and then its set_kv_buffer is NOT called on decode)
@@ -215,4 +219,4 @@ def test_extend_and_decode_through_a_foreign_reference_shaped_pool(page_size, dt
     assert torch.equal(kb[loc], k.view(bs, hkv, d)) and torch.equal(vb[loc], v.view(bs, hkv, d))
     want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, d)), _bits(kb), _bits(vb), _bits(r2t.req_to_token),
                                         np.array(rows), np.array(seq), d ** -0.5)
-    parity.check_out(_bits(o.view(bs, hq, d)).astype(np.float64), want, dtype, ("foreign_pool_decode_fused", ps))
+    parity.check_out(_f64(o.view(bs, hq, d)), want, dtype, ("foreign_pool_decode_fused", ps))
