@@ -53,14 +53,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = []
+    # RX_VARIANT_SOURCES (dev): with RX_LIB_NAME / RX_CFLAGS set, only these sources are built as the variant; every
+    # other object is the default build's (a kernel A/B library then costs one compile, not fourteen)
+    only = [x for x in os.environ.get("RX_VARIANT_SOURCES", "").split(",") if x]
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        obj = os.path.join(HERE, "build", os.path.splitext(src)[0] + os.environ.get("RX_LIB_NAME", "") + ".o")
+        variant = not only or src in only
+        obj = os.path.join(HERE, "build", os.path.splitext(src)[0] + (os.environ.get("RX_LIB_NAME", "") if variant else "") + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
                "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-c", sp, "-o", obj]
-        cmd[1:1] = EXTRA_FLAGS.get(src, []) + os.environ.get("RX_CFLAGS", "").split()
+        cmd[1:1] = EXTRA_FLAGS.get(src, []) + (os.environ.get("RX_CFLAGS", "").split() if variant else [])
         objs.append(obj)
         # per-object incremental build: recompile only what is older than its source, the headers or its flags
         stamp = obj + ".cmd"
@@ -98,4 +102,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
