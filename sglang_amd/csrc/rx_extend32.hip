@@ -40,6 +40,9 @@
 // (half-tile stagger of the SIMD partners) 763-770: QK^T group 1779 -> 1130 cycles, but the PV groups grow by more.
 #define RX_EXT32_DEEP 0
 #endif
+#ifndef RX_EXT32_JUMPT
+#define RX_EXT32_JUMPT 1  // 1: jump test instead of the per-block max exchange in the plain eight-wave fast loop (see sm_slice)
+#endif
 #ifndef RX_EXT32_STAMP
 #define RX_EXT32_STAMP 0  // 1: diagnostic build with s_memtime phase stamps (tools/ext_stamps.py); outputs are clobbered
 #endif
@@ -822,6 +825,11 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       }
     }
     const float c2u = tile_info(t).c2, vs = tile_info(t).vs;  // constant inside a run (prefix or new tokens)
+    // JUMPT: the jump test of sm_slice (plain eight-wave instance only: one scale per run, no per-query temperature)
+    constexpr bool JUMPT = PLAIN && !FINE && RX_EXT32_JUMPT;
+    float thr[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) thr[qb] = (m_run[qb] + kMaxSlack) / (c2u * xai[qb]);
     u32x4 kpre[3];  // DEEP: the next tile's first K fragments, read before its barrier
     if constexpr (DEEP) {
       if (t < fe) {
@@ -851,6 +859,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       u32x4 vfa[DB], vfb[DB];
       float ma[QB], mb_[QB], m0[QB], m1[QB], alpha0[QB], alpha1[QB];
       float ps0[QB][2], ps1[QB][2];
+      bool jumped0 = false, jumped1 = false;  // wave-uniform: slice j == 2 of block 0 / 1 moved a reference max (JUMPT)
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) ps0[qb][0] = ps0[qb][1] = ps1[qb][0] = ps1[qb][1] = 0.f;
       if constexpr ((RX_EXT32_ABL & 25) != 0) {
@@ -863,7 +872,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       }
       // one slice of a block's softmax for query block qb; j = 0..6
       auto sm_slice = [&](int j, int qb, f32x16& sc, float m_prev, float& m_new, float& alpha, float (&ps)[2],
-                          u32x4 (&pk)[2]) {
+                          u32x4 (&pk)[2], bool& jumped) {
         const float c2 = c2u * xai[qb];
         if (j == 0) {
           ma[qb] = max3f(sc[0], sc[1], sc[2]);
@@ -878,16 +887,36 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
           ma[qb] = max2f(ma[qb], mb_[qb]);
           asm volatile("" ::"v"(ma[qb]));
         } else if (j == 2) {
-          float mt = half_swap_max(ma[qb]) * c2;
-          mt = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
           // thresholded running max: a row moves its reference max only when the tile's max exceeds it by more
           // than kMaxSlack (log2 units).  exp2(s - m) then reaches 2^kMaxSlack at most -- exact algebra (l uses
           // the same m), fp32 sums and 16-bit P have the range -- and the O^T rescale, which costs 64 (VGPR) or
           // 192 + wait states (AGPR) instructions per block, runs on the first tile and almost never again;
           // with the plain rule some row of a 32-row block sets a new max in ~70 % of 56 random tiles.
+          // Round 3 (JUMPT): in a VALU-issue-bound loop even the TEST was 12 instructions per block (half swap, scale,
+          // compare, select, exp2 of the difference).  Now one compare of the lane's raw maximum against a per-lane
+          // threshold thr = (m + slack) / c2 and a wave-uniform branch: no lane above it means m_new = m_prev and
+          // alpha = 1 for every row (a half row below the threshold cannot lift the row's maximum above it); only a
+          // wave with a jumping row takes the old code, which also moves the threshold.
+          if constexpr (JUMPT) {
+            if (__builtin_amdgcn_ballot_w64(ma[qb] > thr[qb]) != 0) {
+              float mt = half_swap_max(ma[qb]) * c2;
+              mt = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
+              const float m_cand = max2f(m_prev, mt);
+              m_new = (m_cand - m_prev > kMaxSlack) ? m_cand : m_prev;
+              alpha = fast_exp2(m_prev - m_new);
+              thr[qb] = (m_new + kMaxSlack) / c2;
+              jumped = true;
+            } else {
+              m_new = m_prev;
+              alpha = 1.0f;
+            }
+          } else {
+          float mt = half_swap_max(ma[qb]) * c2;
+          mt = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
           const float m_cand = max2f(m_prev, mt);
           m_new = (m_cand - m_prev > kMaxSlack) ? m_cand : m_prev;
           alpha = fast_exp2(m_prev - m_new);
+          }
           asm volatile("" ::"v"(m_new), "v"(alpha));
         } else {
           const int e = 4 * (j - 3);
@@ -936,7 +965,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
           if (i > KS && !(RX_EXT32_ABL & 9)) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
-              sm_slice(i - KS - 1, qb, s0[qb], m_run[qb], m0[qb], alpha0[qb], ps0[qb], pk0[qb]);
+              sm_slice(i - KS - 1, qb, s0[qb], m_run[qb], m0[qb], alpha0[qb], ps0[qb], pk0[qb], jumped0);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -945,7 +974,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       if (late) __syncthreads();
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        if (__builtin_amdgcn_ballot_w64(alpha0[qb] != 1.0f) != 0) {
+        if (JUMPT ? jumped0 : (__builtin_amdgcn_ballot_w64(alpha0[qb] != 1.0f) != 0)) {
           acc_settle<AG>(oacc[qb]);
 #pragma unroll
           for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha0[qb];
@@ -975,7 +1004,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
         constexpr int SH = AG ? 1 : 0;
         if (g >= SH && g < 7 + SH && !(RX_EXT32_ABL & 17)) {
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb) sm_slice(g - SH, qb, s1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb]);
+          for (int qb = 0; qb < QB; ++qb) sm_slice(g - SH, qb, s1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], jumped1);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -987,7 +1016,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       RX_STAMP(2);
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
-        if (__builtin_amdgcn_ballot_w64(alpha1[qb] != 1.0f) != 0) {
+        if (JUMPT ? jumped1 : (__builtin_amdgcn_ballot_w64(alpha1[qb] != 1.0f) != 0)) {
           acc_settle<AG>(oacc[qb]);
 #pragma unroll
           for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha1[qb];

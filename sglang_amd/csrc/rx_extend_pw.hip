@@ -21,6 +21,12 @@
 #ifndef RX_PW_BODY_INC
 #define RX_PW_BODY_INC "rx_extend_pw_body.inc"  // dev: alternative schedules from tools/gen_extend_pw.py (PW_GEN_TAG)
 #endif
+#ifndef RX_PW_RK
+#define RX_PW_RK 4  // fragment rings of the generated body (PW_GEN_RK / PW_GEN_RV)
+#endif
+#ifndef RX_PW_RV
+#define RX_PW_RV 4
+#endif
 #ifndef RX_PW_DMA32
 // dev experiment: 1 = the tile DMA with a scalar base and 32-bit lane offsets (global_load_lds ... saddr form); valid only
 // while every row offset of the K / V tensors fits 32 bits
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(256, 1) void extend_pw_kernel(const ExtPwArgs a) {
       const float c2inv = 1.0f / c2r;
       pw_f32x16 s0[2], s1[2];
       u32x4 pk0[2][2], pk1[2][2];
-      u32x4 kf[4], vfa[4];
+      u32x4 kf[RX_PW_RK], vfa[RX_PW_RV];
       float ma0[2], mb0[2], ma1[2], mb1[2], mref[2], thr[2], alpha0[2], alpha1[2], psa0[2], psb0[2], psa1[2], psb1[2];
       bool jump0 = false, jump1 = false;   // wave-uniform: a stream of block 0 / 1 moved a reference maximum
 #define PW_TV(b, q) float tv##b##_##q##_0, tv##b##_##q##_1, tv##b##_##q##_2, tv##b##_##q##_3, tv##b##_##q##_4, tv##b##_##q##_5, \

@@ -33,7 +33,9 @@ NO_FENCE = int(os.environ.get("PW_GEN_NO_FENCE", "0"))     # 1: no sched_barrier
 NO_SOFTMAX = int(os.environ.get("PW_GEN_NO_SOFTMAX", "0"))  # 1: MFMA + LDS + DMA skeleton only (garbage results)
 KA = int(os.environ.get("PW_GEN_KA", "2"))                 # K fragments read this many steps ahead (ring of 4: <= 3)
 LSUM_VALU = int(os.environ.get("PW_GEN_LSUM_VALU", "1"))   # 1: row sums by 64 VALU adds per tile (else by 8 extra MFMAs against a ones fragment)
-VA = int(os.environ.get("PW_GEN_VA", "2"))                 # V^T fragments read this many steps ahead (ring of 4: <= 3)
+VA = int(os.environ.get("PW_GEN_VA", "2"))
+RK = int(os.environ.get("PW_GEN_RK", "4"))                 # registers rings of the K / V^T fragments (fragments): > steps ahead
+RV = int(os.environ.get("PW_GEN_RV", "4"))                 # V^T fragments read this many steps ahead (ring of 4: <= 3)
 
 # ---- the softmax stream of one (block, query block): 16 slots + a tail -----------------------------------------
 # slots 0, 1: the lane's maximum over its 16 raw scores; slot 2: jump test (PW_JUMP: one compare + a wave-uniform
@@ -166,8 +168,8 @@ def gen_body():
             pre = []
             if qb == 0:
                 nxt = i + KA
-                pre.append(f"kf[{nxt % 4}] = PW_LDK({nxt // 8}, {nxt % 8});")
-            mf = f"PW_QK({'true' if i == 0 else 'false'}, s0[{qb}], kf[{i % 4}], {qb}, {i});"
+                pre.append(f"kf[{nxt % RK}] = PW_LDK({nxt // 8}, {nxt % 8});")
+            mf = f"PW_QK({'true' if i == 0 else 'false'}, s0[{qb}], kf[{i % RK}], {qb}, {i});"
             gap(f"G1 step {i} qb {qb}", pre, mf, stream_slot(1, qb, 8 + i), dma_post(1, i, qb))
     for qb in range(2):
         for x in stream_tail(1, qb):
@@ -181,10 +183,10 @@ def gen_body():
             pre = []
             if qb == 0 and i + KA < 8:
                 nxt = 8 + i + KA
-                pre.append(f"kf[{nxt % 4}] = PW_LDK(1, {nxt % 8});")
+                pre.append(f"kf[{nxt % RK}] = PW_LDK(1, {nxt % 8});")
             if qb == 0 and i >= 8 - VA:   # the first V^T fragments of PV(b1, t-1): tile t-1, k-step 2, db 0 ..
-                pre.append(f"vfa[{i - (8 - VA)}] = PW_LDVP(2, {i - (8 - VA)});")
-            mf = f"PW_QK({'true' if i == 0 else 'false'}, s1[{qb}], kf[{(8 + i) % 4}], {qb}, {i});"
+                pre.append(f"vfa[{(i - (8 - VA)) % RV}] = PW_LDVP(2, {i - (8 - VA)});")
+            mf = f"PW_QK({'true' if i == 0 else 'false'}, s1[{qb}], kf[{(8 + i) % RK}], {qb}, {i});"
             gap(f"G2 step {i} qb {qb}", pre, mf, stream_slot(0, qb, i), dma_post(2, i, qb))
     add("  PW_STAMP(2);")
     if not NO_SOFTMAX:
@@ -197,10 +199,10 @@ def gen_body():
             if qb == 0:
                 f2 = g2 + VA
                 if f2 < 8:    # PV(b1, t-1) fragment f2: tile t-1, k-step 2 + f2 / 4, db f2 % 4 (VA steps ahead)
-                    pre.append(f"vfa[{f2 % 4}] = PW_LDVP({2 + f2 // 4}, {f2 % 4});")
+                    pre.append(f"vfa[{f2 % RV}] = PW_LDVP({2 + f2 // 4}, {f2 % 4});")
                 else:         # the first V^T fragments of tile t for G4 (k-step 0, db 0 ..)
-                    pre.append(f"vfa[{(f2 - 8) % 4}] = PW_LDV(0, {f2 - 8});")
-            mf = f"PW_PV(vfa[{g2 % 4}], pk1[{qb}][{g2 // 4}], {qb}, {g2 % 4});"
+                    pre.append(f"vfa[{f2 % RV}] = PW_LDV(0, {f2 - 8});")
+            mf = f"PW_PV(vfa[{g2 % RV}], pk1[{qb}][{g2 // 4}], {qb}, {g2 % 4});"
             post = dma_post(3, g2, qb)
             if qb == 0 and g2 < 4:   # the K addresses move to the other ring slot (all K reads of tile t are done)
                 post = post + [f"PW_TOGGLE(ka[{2 * g2}]); PW_TOGGLE(ka[{2 * g2 + 1}]);"]
@@ -222,8 +224,8 @@ def gen_body():
             pre = []
             if qb == 0 and g2 + VA < 8:   # PV fragment g2 + VA (k-step (g2 + VA) / 4, db (g2 + VA) % 4) into the ring of four
                 f2 = g2 + VA
-                pre.append(f"vfa[{f2 % 4}] = PW_LDV({f2 // 4}, {f2 % 4});")
-            src = f"vfa[{g2 % 4}]"
+                pre.append(f"vfa[{(8 + f2) % RV}] = PW_LDV({f2 // 4}, {f2 % 4});")
+            src = f"vfa[{(8 + g2) % RV}]"
             mf = f"PW_PV({src}, pk0[{qb}][{g2 // 4}], {qb}, {g2 % 4});"
             post = dma_post(4, g2, qb)
             if qb == 1 and g2 == 7:       # after the last V read of tile t
