@@ -847,9 +847,11 @@ def hetero_decode_bench(dev):
     cnt = torch.zeros(bs * HQ, dtype=torch.int32, device=dev)
     order = torch.argsort(lens_d, descending=True).to(torch.int32)
 
-    def timed(ns, S):
+    def timed(ns, S, items=False):
         al = torch.empty(bs, HQ, max(S, 1), D, dtype=torch.float32, device=dev)
         lse = torch.empty(bs, HQ, max(S, 1), dtype=torch.float32, device=dev)
+        # items: the grid = the live (request, split) pairs, longest request first (rx_decode_params.split_items)
+        si = ops.SplitItems(int(ns.clamp_min(1).sum()), dev).build(ns, order) if items else None
 
         def run():
             if S == 1:
@@ -857,7 +859,7 @@ def hetero_decode_bench(dev):
                                                kv_layout=lay, request_order=order)
             else:
                 ops.decode_attention_fwd_paged(q, kb, vb, o, r2td, rpi, lens_d, al, lse, ns, S, D ** -0.5, page_size=PS,
-                                               kv_layout=lay, merge_counters=cnt, request_order=order)
+                                               kv_layout=lay, merge_counters=cnt, request_order=order, split_items=si)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -880,16 +882,23 @@ def hetero_decode_bench(dev):
 
     k3 = torch.zeros(bs, dtype=torch.int32, device=dev)
     ops.get_num_kv_splits(k3, lens_d.int(), HQ, HKV, 8, 256)
-    S_bal = int(ops.balanced_kv_splits_host(lens, HQ, HKV, 32, 512, 128).max())
-    S_slots = (S_bal + 7) // 8 * 8
+    # the backend's schedule (attention/backend.py: _decode_metadata_native): 2 workgroups per CU, 3 for a mixed batch
+    S_old = int(ops.balanced_kv_splits_host(lens, HQ, HKV, 64, 512, 1024).max())
+    old = torch.zeros(bs, dtype=torch.int32, device=dev)
+    ops.get_num_kv_splits_balanced(old, lens_d, HQ, HKV, S_old, 512, 1024)
+    S_bal = int(ops.balanced_kv_splits_host(lens, HQ, HKV, 64, 512, 1024, 768).max())
     bal = torch.zeros(bs, dtype=torch.int32, device=dev)
-    ops.get_num_kv_splits_balanced(bal, lens_d, HQ, HKV, S_bal, 512, 128)
+    ops.get_num_kv_splits_balanced(bal, lens_d, HQ, HKV, S_bal, 512, 1024, 768)
+    r8 = lambda x: (x + 7) // 8 * 8
     byt = sum(lens) * HKV * D * 2 * 2
     res = {"workload": "64 requests: one of 32768 tokens, 63 of 1024 (Hq 32 / Hkv 8 / D 128 bf16, page 16 shuffled, one layer)",
            "kv_bytes": byt}
-    for name, ns, S in (("one_pass_per_request", None, 1), ("reference_formula_max8", k3, 8), ("length_aware_native", bal, S_slots)):
-        us = timed(ns, S)
-        res[name] = {"us_per_layer": us, "TBps": byt / us / 1e6, "splits_of_the_long_request": 1 if ns is None else int(ns[0])}
+    for name, ns, S, items in (("one_pass_per_request", None, 1, False), ("reference_formula_max8", k3, 8, False),
+                               ("length_aware_split_slots", old, r8(S_old), False), ("length_aware_native", bal, r8(S_bal), True)):
+        us = timed(ns, S, items)
+        res[name] = {"us_per_layer": us, "TBps": byt / us / 1e6, "frac_of_hbm_peak": byt / us / 1e6 / 8.0,
+                     "splits_of_the_long_request": 1 if ns is None else int(ns[0]),
+                     "grid": "live (request, split) pairs, longest first" if items else "bs x split slots"}
     return res
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RX_ABI_VERSION 7
+#define RX_ABI_VERSION 8
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -96,9 +96,23 @@ int rx_num_kv_splits_native(const void* seq_lens, int seq_lens_is_i64, int bs, i
  *   t* = max(min_tokens_per_split, ceil(total * wg_per_request / wg_target))      (an even share of the batch)
  *   out[b] = 1 if 2 * len_b <= 3 * t*,  else min(max_kv_splits, ceil(len_b / t*)).
  * One launch, no host sync; max_kv_splits (the scratch's split slots) caps the count, so a host-side guess of the
- * largest count can never be overrun. */
+ * largest count can never be overrun.
+ * wg_target_mixed (round 3; 0 or <= wg_target: off): when that first pass leaves the batch MIXED -- some requests
+ * cut, some whole, i.e. workgroups of different sizes -- the counts are re-derived with wg_target_mixed in place of
+ * wg_target (the budget of the live-pairs grid: three workgroups per CU, all resident at once), and if rounding up
+ * overshoots it (pairs * wg_per_request > wg_target_mixed) t* is scaled up by that ratio once.  A uniform batch keeps
+ * the first pass: fewer, larger workgroups are faster there (4 x 16 k: 54 us at 512 workgroups, 56 at 768). */
 int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int wg_target,
-                              int max_kv_splits, int min_tokens_per_split, int32_t* out, void* stream);
+                              int max_kv_splits, int min_tokens_per_split, int wg_target_mixed, int32_t* out,
+                              void* stream);
+
+/* The work-item table of a split schedule (rx_decode_params.split_items): for i over the requests in `order` (a
+ * permutation, e.g. longest first; NULL = identity) and s < num_kv_splits[order[i]]: items[2 k] = order[i],
+ * items[2 k + 1] = s, k counting up; count[0] = number of pairs written (clamped to cap: pairs beyond it are NOT
+ * written and count[0] still says how many there would be -- the caller sizes cap from bs * max slots or from its host
+ * copy of the lengths).  One launch of one block, no host sync. */
+int rx_split_items(const int32_t* num_kv_splits, const int32_t* order, int bs, int32_t* items, int32_t* count, int cap,
+                   void* stream);
 
 /* ---- KV buffer addressing shared by decode / extend ------------------------------------
  * element offset of (slot, kv_head) = (slot / page_size) * page_stride
@@ -233,9 +247,20 @@ typedef struct rx_decode_params {
   const int32_t* request_order;
   /* Optional (0 = bs * max_kv_splits): an upper estimate of the (request, split) pairs that really write a partial.
    * With the length-aware schedule most requests of a large batch have ONE split and write none (direct output), so
-   * the 4-MiB bound of the in-kernel stage 2 is taken on this count instead of on the split slots.  A performance
-   * hint only: results do not depend on it. */
+   * the 4-MiB bound of the in-kernel stage 2 is taken on this count instead of on the split slots (with split_items
+   * below and no hint, on split_items_cap).  A performance hint only: results do not depend on it. */
   int32_t partial_pairs_hint;
+  /* Optional (round 3; D = 64 / 96 / 128 / 256 kernel): the LIVE (request, split) pairs of the split schedule,
+   * compacted by rx_split_items: int32 pairs {request, split}.  Without it the grid is bs x max_kv_splits split slots
+   * with the split the slowest block dimension, and a request whose count is below the slots leaves dead workgroups
+   * behind -- in a batch with ONE long request (64 requests: one of 32 k tokens cut 22 ways, 63 of 1 k with one split)
+   * every live workgroup of split s >= 1 sits behind 504 dead ones in dispatch order, and the long request's last
+   * splits start tens of microseconds late.  With the table, block (q block, kv head, item i) takes pair i: live work
+   * only, longest requests first; split_items_cap sizes the grid (>= the device-side count; pairs beyond the count
+   * exit at once -- they are at the END of the grid, which is what a graph-replayed step with an upper bound needs). */
+  const int32_t* split_items;       /* int32[2 * split_items_cap], device */
+  const int32_t* split_items_count; /* int32[1], device: live pairs */
+  int32_t split_items_cap;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);

@@ -60,6 +60,8 @@ class ForwardMetadata:
     request_order: Optional[torch.Tensor] = None
     # decode, length-aware schedule: upper estimate of the (request, split) pairs that write a partial
     partial_pairs_hint: int = 0
+    # decode, length-aware schedule: the live (request, split) pairs, compacted (ops.SplitItems)
+    split_items: Optional[object] = None
 
 
 def host_num_kv_splits(seq_lens: np.ndarray, num_head: int, num_kv_head: int, max_kv_splits: int,
@@ -199,6 +201,7 @@ class HipRadixAttnBackend:
         if os.environ.get("RX_NO_INKERNEL_MERGE"):  # dev A/B: stage 2 as its own launch
             self._merge_counters = None
         self._no_fused_store = bool(os.environ.get("RX_NO_FUSED_STORE"))  # dev A/B: the store as its own launch
+        self._no_split_items = bool(os.environ.get("RX_NO_SPLIT_ITEMS"))  # dev A/B: split slots instead of compacted pairs
         # RX_DEBUG_CHECKS=1: host-synchronising assertions of the backend's preconditions (see forward_decode)
         self._debug_checks = os.environ.get("RX_DEBUG_CHECKS", "0") not in ("", "0")
         self._graph = None  # static buffers of init_cuda_graph_state
@@ -311,13 +314,13 @@ class HipRadixAttnBackend:
                                          self.window_kv_indptr, kv_indices, start)
         return kv_indptr, kv_indices, window_lens, start
 
-    def _request_order(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool) -> Optional[torch.Tensor]:
+    def _request_order(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool, force: bool = False) -> Optional[torch.Tensor]:
         """rx_decode_params.request_order: the batch's requests by descending length, when the launch has more
         workgroups than the chip holds at once (two per CU) -- a ragged batch's longest requests then start first and
         its last round is the short ones (bs 256, lengths uniform in [2 k, 4 k]: decode kernel 0.73 -> 0.76 of HBM peak)."""
         group = max(1, self.num_head // self.num_kv_head)
-        if bs * self.num_kv_head * ((group + 15) // 16) <= 2 * self.device_core_count:
-            return None
+        if not force and bs * self.num_kv_head * ((group + 15) // 16) <= 2 * self.device_core_count:
+            return None   # (force: a split schedule's work items are dealt longest request first whatever the batch size)
         if not use_graph_bufs and fb.seq_lens_cpu is not None:
             cpu = fb.seq_lens_cpu
             if int(cpu.max()) == int(cpu.min()):
@@ -418,9 +421,16 @@ class HipRadixAttnBackend:
         # ~1 k tokens is all prologue (32 x 1 k: 31 us at 1 split, 33 at 2): t* has a 1 k floor there, 128 for tiny batches.
         min_tokens = 1024 if (2 * blocks >= self.device_core_count and not self._is_mla_pool) else 128
         cap = self.native_split_cap
+        # a MIXED batch (some requests cut, some whole) runs on the live-pairs grid, whose kernel form holds three
+        # workgroups per CU: its schedule aims at that many near-equal pieces (rx_num_kv_splits_balanced, wg_target_mixed)
+        use_items = not self._is_mla_pool and not self._no_split_items
+        wg_mixed = self.device_core_count * 3 if use_items else 0
+        host_pairs = None
         if not use_graph_bufs and fb.seq_lens_cpu is not None:
-            S = int(ops.balanced_kv_splits_host(fb.seq_lens_cpu.numpy()[:bs], self.num_head, self.num_kv_head, cap,
-                                                wg_target, min_tokens).max())
+            host_counts = ops.balanced_kv_splits_host(fb.seq_lens_cpu.numpy()[:bs], self.num_head, self.num_kv_head, cap,
+                                                      wg_target, min_tokens, wg_mixed)
+            S = int(host_counts.max())
+            host_pairs = int(host_counts.sum())
         else:  # lengths unknown here (graph replay refills the counts on the device): slots by batch size alone
             S = self._graph_split_slots(bs)
         if S <= 1:
@@ -429,10 +439,15 @@ class HipRadixAttnBackend:
         S_cap = S
         # the in-kernel stage 2 (merge_counters) wants the partial rows of a head in chunks of 8: round the slots up while
         # the partials fit its bound -- the surplus workgroups exit at once, and the second launch goes
+        wgpr = self.num_kv_head * ((group + 15) // 16)
+        # split requests share ~wg_target workgroups: (request, split) pairs with a partial <= that / blocks per request,
+        # with slack for rounding up -- what the in-kernel stage 2's size bound looks at, not bs * slots
+        pairs = 2 * max(wg_target, wg_mixed) // wgpr + 8
         if self._merge_counters is not None and S % 8:
             S8 = (S + 7) // 8 * 8
-            if bs * self.num_head * S8 * self.v_head_dim * 4 <= (4 << 20):
+            if min(bs * S8, pairs) * self.num_head * self.v_head_dim * 4 <= (4 << 20):
                 S = S8
+        pairs = min(bs * S, pairs)
         if use_graph_bufs:
             num_kv_splits = self._graph["num_kv_splits"][:bs]
             n = bs * self.num_head * S
@@ -442,13 +457,27 @@ class HipRadixAttnBackend:
             num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
             attn_logits, attn_lse = self._scratch(bs, S)
         ops.get_num_kv_splits_balanced(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S_cap, wg_target,
-                                       min_tokens_per_split=min_tokens)
-        # split requests share ~wg_target workgroups: (request, split) pairs with a partial <= that / blocks per request,
-        # with slack for rounding up -- what the in-kernel stage 2's size bound should look at, not bs * slots
-        wgpr = self.num_kv_head * ((group + 15) // 16)
-        pairs = min(bs * S, 2 * wg_target // wgpr + 8)
+                                       min_tokens_per_split=min_tokens, wg_target_mixed=wg_mixed)
+        order = self._request_order(fb, bs, use_graph_bufs, force=True)
+        # the grid holds the LIVE (request, split) pairs only, longest requests first (rx_decode_params.split_items): with
+        # split slots the long request's later splits sit behind hundreds of dead workgroups in dispatch order
+        items = None
+        if use_items:
+            if use_graph_bufs:
+                items = self._graph["split_items"].build(num_kv_splits, order, cap=self._split_pairs_bound(bs, S_cap))
+            else:
+                items = ops.SplitItems(host_pairs if host_pairs is not None else bs * S_cap, self.device).build(
+                    num_kv_splits, order)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S,
-                               request_order=self._request_order(fb, bs, use_graph_bufs), partial_pairs_hint=pairs)
+                               request_order=order, partial_pairs_hint=pairs, split_items=items)
+
+    def _split_pairs_bound(self, bs: int, slots: int) -> int:
+        """An upper bound of the (request, split) pairs rx_num_kv_splits_balanced can hand out: every request takes at
+        most ceil(len / t*) <= len / t* + 1 pieces and sum(len) / t* <= workgroup budget / workgroups per pair (t* >= the
+        even share of the LARGER budget; the overshoot step only raises it)."""
+        group = max(1, self.num_head // self.num_kv_head)
+        wgpr = self.num_kv_head * ((group + 15) // 16)
+        return min(bs * slots, bs + -(-3 * self.device_core_count // wgpr) + 1)
 
     def _graph_split_slots(self, bs: int) -> int:
         """Split slots of a graph-replayed dense decode step: enough for a small batch to fill the chip, and at least 8
@@ -457,6 +486,10 @@ class HipRadixAttnBackend:
         group = max(1, self.num_head // self.num_kv_head)
         blocks = max(1, bs * self.num_kv_head * ((group + 15) // 16))
         S = max(8, min(self.native_split_cap, -(-2 * self.device_core_count // blocks)))
+        if not self._is_mla_pool and not self._no_split_items:
+            # the live-pairs grid: a slot nobody uses costs nothing (no dead workgroup), so every batch size keeps the
+            # full cap -- the long request of a mixed batch is cut as finely under graph replay as in an eager step
+            S = max(S, self.native_split_cap)
         if self._merge_counters is not None and S % 8 and bs * self.num_head * ((S + 7) // 8 * 8) * self.v_head_dim * 4 <= (4 << 20):
             S = (S + 7) // 8 * 8
         return S
@@ -718,6 +751,9 @@ class HipRadixAttnBackend:
         # every buffer a captured kernel reads lives here from the start (a buffer created lazily and re-allocated
         # after capture would leave the graph reading the old address): the launch order of ragged batches ...
         self._graph["request_order"] = torch.zeros(max_bs, dtype=torch.int32, device=dev)
+        # ... the (request, split) pairs of the length-aware schedule
+        self._graph["split_items"] = ops.SplitItems(
+            max(self._split_pairs_bound(b, self._graph_split_slots(b)) for b in range(1, max_bs + 1)), dev)
         # ... and the draft tree's mask bytes of TARGET_VERIFY, sized from speculative_num_draft_tokens
         nd = int(self.num_draft_tokens or 0)
         if nd > 0:
@@ -855,14 +891,16 @@ class HipRadixAttnBackend:
                                 kv_indices=md.kv_indices, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
                                 attn_lse=md.attn_lse, merge_counters=self._merge_counters,
-                                request_order=md.request_order, partial_pairs_hint=md.partial_pairs_hint)
+                                request_order=md.request_order, partial_pairs_hint=md.partial_pairs_hint,
+                                split_items=md.split_items)
             else:
                 ln.set_metadata(self._md_version, q3.shape[0], req_to_token=self.req_to_token,
                                 req_pool_indices=forward_batch.req_pool_indices,
                                 seq_lens=forward_batch.seq_lens, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
                                 attn_lse=md.attn_lse, merge_counters=self._merge_counters,
-                                request_order=md.request_order, partial_pairs_hint=md.partial_pairs_hint)
+                                request_order=md.request_order, partial_pairs_hint=md.partial_pairs_hint,
+                                split_items=md.split_items)
         if sinks is not None and sinks.dtype != torch.float32:
             sinks = sinks.float()
         if fuse:

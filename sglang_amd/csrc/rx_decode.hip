@@ -64,6 +64,10 @@ struct DecodeArgs {
   // a request with ONE kv split writes its final output from stage 1 and stage 2 leaves it alone (MFMA kernel, no
   // extra partials): a length-aware schedule then costs the unsplit majority of a batch nothing
   int32_t direct_single;
+  // compacted (request, split) pairs of the split schedule (rx_split_items), or NULL: bs x max_kv_splits slots
+  const int32_t* items;
+  const int32_t* items_count;
+  int32_t items_cap;
 };
 
 // Grok temperature factor of a request (decode_attention.py:156-160): the single query sits at seq_len-1
@@ -197,8 +201,13 @@ __device__ __forceinline__ u32x4 kv_frag16(V raw) {
 // v_new instead of the pool, and the lanes that hold its 16-byte chunks write them to its pool slot on the way -- the
 // KV store of the step (K1) without its own launch (a small-batch or TP-shard layer is 35-100 us, the store launch
 // ~5).  Only with ONE q block per kv head: then exactly one workgroup ever touches that row.
-template <typename T, int D, typename IdxT, bool LINEAR, bool KV8, bool FUSE = false>
-__global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const DecodeArgs a) {
+//
+// OCC3: the register budget of THREE workgroups per CU (168 VGPRs: no spills in the plain D = 128 form, 7-14 dwords in
+// the fused-store one).  The split-items grid takes it: its schedule cuts the batch into ~3 x CUs near-equal
+// workgroups that are all resident at once, so nothing waits for a second round (one 32 k request among 63 of 1 k:
+// 87 us per layer at two per CU -> 76 at three); a uniform batch of one-pass requests is ~0.5 % faster at two.
+template <typename T, int D, typename IdxT, bool LINEAR, bool KV8, bool FUSE = false, bool OCC3 = false>
+__global__ __launch_bounds__(256, OCC3 ? 3 : RX_DEC_MINW) void decode_mfma_kernel(const DecodeArgs a) {
   static_assert(!(FUSE && KV8), "the fused store writes 16-bit rows");
   using vec8 = typename T::vec8;
   using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;  // pool element
@@ -231,8 +240,15 @@ __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_kernel(const Dec
   bid /= a.hkv;
   // a ragged batch is dealt longest request first (a.order): the chip's last round of workgroups is then the
   // short requests, not a 4 k-token one that starts when the others are finishing
-  const int b = a.order ? a.order[bid % a.bs] : bid % a.bs;
-  const int split = bid / a.bs;
+  int b, split;
+  if (a.items) {  // live (request, split) pairs only, longest requests first (rx_decode_params.split_items)
+    if (bid >= a.items_count[0]) return;
+    b = a.items[2 * bid];
+    split = a.items[2 * bid + 1];
+  } else {
+    b = a.order ? a.order[bid % a.bs] : bid % a.bs;
+    split = bid / a.bs;
+  }
 
   const SeqInfo si = seq_info<IdxT>(a, b);
   const IdxT* idx = reinterpret_cast<const IdxT*>(si.idx);
@@ -760,10 +776,15 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
     return check_launch("rx_decode_attn");
   }
   if (mfma_ok) {
-    const unsigned grid = static_cast<unsigned>(a.bs) * a.hkv * a.qblocks * a.max_kv_splits;
+    const unsigned grid = a.items ? static_cast<unsigned>(a.items_cap) * a.hkv * a.qblocks
+                                  : static_cast<unsigned>(a.bs) * a.hkv * a.qblocks * a.max_kv_splits;
+    if (grid == 0) return RX_OK;
 #define RX_DEC(DD, K8, FU) \
   hipLaunchKernelGGL((decode_mfma_kernel<T, DD, IdxT, LINEAR, K8, FU>), dim3(grid), dim3(256), 0, s, a)
-    if (a.kv_fp8) {
+    if (a.items && dk == 128 && !a.kv_fp8) {  // the split-items schedule: three workgroups per CU (OCC3)
+      if (a.k_new) hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR, false, true, true>), dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR, false, false, true>), dim3(grid), dim3(256), 0, s, a);
+    } else if (a.kv_fp8) {
       if (dk == 64) RX_DEC(64, true, false);
       else RX_DEC(128, true, false);
     } else if (a.k_new) {  // fused store of the new token
@@ -929,8 +950,10 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
                                // are many MB (MLA 64 x 16 heads x 8 splits = 17 MB: 67.6 -> 69.5 us)
                                // (partial_pairs_hint: how many (request, split) pairs really write a partial, when
                                // the caller's schedule knows better than bs * max_kv_splits)
-                               static_cast<int64_t>(p->partial_pairs_hint > 0
-                                                        ? min(static_cast<int64_t>(p->partial_pairs_hint),
+                               // (a split-items table bounds them the same way: its capacity >= the live pairs)
+                               static_cast<int64_t>((p->partial_pairs_hint > 0 || p->split_items)
+                                                        ? min(static_cast<int64_t>(p->partial_pairs_hint > 0 ? p->partial_pairs_hint
+                                                                                                           : p->split_items_cap),
                                                               static_cast<int64_t>(p->bs) * max_splits)
                                                         : static_cast<int64_t>(p->bs) * max_splits) *
                                        p->num_q_heads * dv * 4 <= (4ll << 20);
@@ -938,6 +961,13 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   // fused store of the new token: one q block per kv head (one workgroup touches the row), a 16-bit pool, the whole
   // request attended in one pass of the MFMA kernel, 16-byte chunks
   a.order = p->request_order;
+  a.items = p->split_items;
+  a.items_count = p->split_items_count;
+  a.items_cap = p->split_items_cap;
+  if (a.items) {
+    RX_REQUIRE(a.items_count && a.items_cap >= 0, "rx_decode_attn: split_items without its count / cap");
+    RX_REQUIRE(p->num_kv_splits && p->max_kv_splits > 1, "rx_decode_attn: split_items go with a split schedule (num_kv_splits, max_kv_splits > 1)");
+  }
   a.direct_single = ((mfma_ok || mla) && a.num_extra == 0 && max_splits > 1 && p->stages == 0) ? 1 : 0;
   a.k_new = a.v_new = nullptr;
   if (p->k_new || p->v_new) {

@@ -767,47 +767,130 @@ int rx_num_kv_splits_native(const void* seq_lens, int seq_lens_is_i64, int bs, i
 }
 
 namespace rx {
-// one block: the batch's token total, then every request's count
+// one block: the batch's token total, then every request's count (and, for a mixed batch, the same again on the
+// larger workgroup budget)
+__device__ __forceinline__ int64_t balanced_count(int64_t len, int64_t tstar, int cap) {
+  int64_t n = 1;
+  if (2 * len > 3 * tstar) n = min<int64_t>(cap, (len + tstar - 1) / tstar);  // only what is well above an even share
+  return max<int64_t>(n, 1);
+}
+
 __global__ __launch_bounds__(1024) void num_kv_splits_balanced_kernel(const void* __restrict__ seq_lens, int is64, int bs,
                                                                       int wg_per_request, int wg_target, int cap,
-                                                                      int min_tokens, int32_t* __restrict__ out) {
+                                                                      int min_tokens, int wg_mixed, int32_t* __restrict__ out) {
   __shared__ unsigned long long part[16];
   __shared__ unsigned long long total_s;
+  __shared__ int flags_s[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  auto block_sum = [&](unsigned long long acc) {  // every thread gets the block's total
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+    __syncthreads();  // part / total_s of the previous use are read by now
+    if (lane == 0) part[wid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long t = 0;
+      for (int w = 0; w < 16; ++w) t += part[w];
+      total_s = t;
+    }
+    __syncthreads();
+    return total_s;
+  };
+  if (tid < 2) flags_s[tid] = 0;
   unsigned long long acc = 0;
   for (int i = tid; i < bs; i += 1024) acc += static_cast<unsigned long long>(max<int64_t>(load_idx(seq_lens, i, is64), 0));
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
-  if (lane == 0) part[wid] = acc;
-  __syncthreads();
-  if (tid == 0) {
-    unsigned long long t = 0;
-    for (int w = 0; w < 16; ++w) t += part[w];
-    total_s = t;
-  }
-  __syncthreads();
   // tokens one workgroup should carry so that wg_target workgroups share the batch evenly
-  const unsigned long long work = total_s * static_cast<unsigned long long>(wg_per_request);
-  const int64_t even = static_cast<int64_t>((work + wg_target - 1) / wg_target);
-  const int64_t tstar = max<int64_t>(min_tokens, even);
+  const unsigned long long work = block_sum(acc) * static_cast<unsigned long long>(wg_per_request);
+  int64_t tstar = max<int64_t>(min_tokens, static_cast<int64_t>((work + wg_target - 1) / wg_target));
+  bool any_split = false, any_whole = false;
   for (int i = tid; i < bs; i += 1024) {
-    const int64_t len = max<int64_t>(load_idx(seq_lens, i, is64), 0);
-    int64_t n = 1;
-    if (2 * len > 3 * tstar) n = min<int64_t>(cap, (len + tstar - 1) / tstar);  // only what is well above an even share
-    out[i] = static_cast<int32_t>(max<int64_t>(n, 1));
+    const int64_t n = balanced_count(max<int64_t>(load_idx(seq_lens, i, is64), 0), tstar, cap);
+    out[i] = static_cast<int32_t>(n);
+    any_split |= n > 1;
+    any_whole |= n == 1;
   }
+  if (wg_mixed <= wg_target) return;
+  if (any_split) flags_s[0] = 1;
+  if (any_whole) flags_s[1] = 1;
+  __syncthreads();
+  if (!(flags_s[0] && flags_s[1])) return;
+  // a MIXED batch (some requests cut, some not) is where workgroups differ in size: re-derive the schedule for the
+  // budget of the live-pairs grid (three workgroups per CU, all resident: rx_decode_params.split_items), and scale t*
+  // up once if rounding up overshoots that budget (a second round of workgroups costs more than coarser pieces)
+  tstar = max<int64_t>(min_tokens, static_cast<int64_t>((work + wg_mixed - 1) / wg_mixed));
+  unsigned long long pairs = 0;
+  for (int i = tid; i < bs; i += 1024)
+    pairs += static_cast<unsigned long long>(balanced_count(max<int64_t>(load_idx(seq_lens, i, is64), 0), tstar, cap));
+  const unsigned long long wgs = block_sum(pairs) * static_cast<unsigned long long>(wg_per_request);
+  if (wgs > static_cast<unsigned long long>(wg_mixed))
+    tstar = static_cast<int64_t>((static_cast<unsigned long long>(tstar) * wgs + wg_mixed - 1) / wg_mixed);
+  for (int i = tid; i < bs; i += 1024)
+    out[i] = static_cast<int32_t>(balanced_count(max<int64_t>(load_idx(seq_lens, i, is64), 0), tstar, cap));
 }
 }  // namespace rx
 
+namespace rx {
+// one block: exclusive scan of the split counts in launch order, then the pairs (rx_decode_params.split_items)
+__global__ __launch_bounds__(1024) void split_items_kernel(const int32_t* __restrict__ splits, const int32_t* __restrict__ order,
+                                                           int bs, int32_t* __restrict__ items, int32_t* __restrict__ count, int cap) {
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < bs; c0 += 1024) {
+    const int i = c0 + tid;
+    const int b = i < bs ? (order ? order[i] : i) : 0;
+    const int32_t n = i < bs ? max(splits[b], 1) : 0;
+    int32_t x = n;  // inclusive scan inside the wave, then across the 16 waves
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    int32_t off = carry_s;
+    for (int w = 0; w < wid; ++w) off += wsum[w];
+    const int32_t first = off + x - n;
+    for (int32_t s = 0; s < n; ++s) {
+      if (first + s < cap) {
+        items[2 * (first + s)] = b;
+        items[2 * (first + s) + 1] = s;
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = off + x;
+    __syncthreads();
+  }
+  if (tid == 0) count[0] = carry_s;
+}
+}  // namespace rx
+
+int rx_split_items(const int32_t* num_kv_splits, const int32_t* order, int bs, int32_t* items, int32_t* count, int cap,
+                   void* stream) {
+  RX_REQUIRE(bs >= 0 && cap >= 0, "rx_split_items: negative sizes");
+  RX_REQUIRE(count, "rx_split_items: null count");
+  if (bs == 0) {
+    hipMemsetAsync(count, 0, sizeof(int32_t), static_cast<hipStream_t>(stream));
+    return check_launch("rx_split_items");
+  }
+  RX_REQUIRE(num_kv_splits && (items || cap == 0), "rx_split_items: null pointer");
+  hipLaunchKernelGGL(rx::split_items_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), num_kv_splits, order, bs,
+                     items, count, cap);
+  return check_launch("rx_split_items");
+}
+
 int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int wg_target,
-                              int max_kv_splits, int min_tokens_per_split, int32_t* out, void* stream) {
+                              int max_kv_splits, int min_tokens_per_split, int wg_target_mixed, int32_t* out,
+                              void* stream) {
   RX_REQUIRE(bs >= 0, "rx_num_kv_splits_balanced: bs < 0");
   if (bs == 0) return RX_OK;
   RX_REQUIRE(seq_lens && out, "rx_num_kv_splits_balanced: null pointer");
-  RX_REQUIRE(wg_per_request > 0 && wg_target > 0 && max_kv_splits > 0 && min_tokens_per_split > 0,
+  RX_REQUIRE(wg_per_request > 0 && wg_target > 0 && max_kv_splits > 0 && min_tokens_per_split > 0 && wg_target_mixed >= 0,
              "rx_num_kv_splits_balanced: bad sizes");
   hipLaunchKernelGGL(rx::num_kv_splits_balanced_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), seq_lens,
-                     seq_lens_is_i64, bs, wg_per_request, wg_target, max_kv_splits, min_tokens_per_split, out);
+                     seq_lens_is_i64, bs, wg_per_request, wg_target, max_kv_splits, min_tokens_per_split, wg_target_mixed, out);
   return check_launch("rx_num_kv_splits_balanced");
 }
 

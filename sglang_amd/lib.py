@@ -16,7 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
-RX_ABI_VERSION = 7  # include/radix_hip.h
+RX_ABI_VERSION = 8  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -56,6 +56,7 @@ class RxDecodeParams(C.Structure):
         ("k_new", c_void_p), ("v_new", c_void_p),
         ("k_new_stride_t", c_int64), ("k_new_stride_h", c_int64), ("v_new_stride_t", c_int64), ("v_new_stride_h", c_int64),
         ("request_order", c_void_p), ("partial_pairs_hint", c_int32),
+        ("split_items", c_void_p), ("split_items_count", c_void_p), ("split_items_cap", c_int32),
     ]
 
 
@@ -108,7 +109,8 @@ PROTOTYPES = {
     "rx_shared_prefix_plan": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_int, c_int32, c_int32,
                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rx_num_kv_splits_native": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "rx_num_kv_splits_balanced": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rx_split_items": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "rx_num_kv_splits_balanced": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rx_merge_state": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_void_p]),
     "rx_get_mla_kv": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p,
                               c_void_p, c_int, c_int64, c_void_p, c_void_p]),

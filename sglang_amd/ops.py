@@ -212,27 +212,39 @@ def get_num_kv_splits_native(num_kv_splits: torch.Tensor, seq_lens: torch.Tensor
 
 
 def balanced_kv_splits_host(lens, num_head: int, num_kv_head: int, max_kv_splits: int, wg_target: int,
-                            min_tokens_per_split: int = 128) -> np.ndarray:
+                            min_tokens_per_split: int = 128, wg_target_mixed: int = 0) -> np.ndarray:
     """Host mirror of rx_num_kv_splits_balanced (include/radix_hip.h) on the CPU copy of the lengths: what the eager
     metadata path uses to size the split slots (the device kernel clamps to them, so a mismatch is harmless)."""
     lens = np.maximum(np.asarray(lens, dtype=np.int64), 0)
     group = max(1, num_head // num_kv_head)
     wgpr = num_kv_head * ((group + 15) // 16)
-    even = -(-int(lens.sum()) * wgpr // wg_target)
-    tstar = max(int(min_tokens_per_split), even)
-    n = np.where(2 * lens > 3 * tstar, np.minimum(max_kv_splits, -(-lens // tstar)), 1)
-    return np.maximum(n, 1).astype(np.int32)
+    work = int(lens.sum()) * wgpr
+
+    def counts(tstar):
+        n = np.where(2 * lens > 3 * tstar, np.minimum(max_kv_splits, -(-lens // tstar)), 1)
+        return np.maximum(n, 1).astype(np.int32)
+
+    n = counts(max(int(min_tokens_per_split), -(-work // wg_target)))
+    if wg_target_mixed > wg_target and (n > 1).any() and (n == 1).any():  # a mixed batch: the live-pairs grid's budget
+        tstar = max(int(min_tokens_per_split), -(-work // wg_target_mixed))
+        wgs = int(counts(tstar).sum()) * wgpr
+        if wgs > wg_target_mixed:
+            tstar = -(-tstar * wgs // wg_target_mixed)
+        n = counts(tstar)
+    return n
 
 
 def get_num_kv_splits_balanced(num_kv_splits: torch.Tensor, seq_lens: torch.Tensor, num_head: int, num_kv_head: int,
-                               max_kv_splits: int, wg_target: int, min_tokens_per_split: int = 128) -> None:
+                               max_kv_splits: int, wg_target: int, min_tokens_per_split: int = 128,
+                               wg_target_mixed: int = 0) -> None:
     _require_cuda(num_kv_splits, seq_lens)
     if num_kv_splits.dtype != torch.int32:
         raise TypeError("num_kv_splits must be int32")
     group = max(1, num_head // num_kv_head)
     st = _L.load().rx_num_kv_splits_balanced(_ptr(seq_lens), _is64(seq_lens, "seq_lens"), seq_lens.shape[0],
                                              num_kv_head * ((group + 15) // 16), int(wg_target), int(max_kv_splits),
-                                             int(min_tokens_per_split), _ptr(num_kv_splits), _stream(seq_lens))
+                                             int(min_tokens_per_split), int(wg_target_mixed), _ptr(num_kv_splits),
+                                             _stream(seq_lens))
     _L.check(st, "rx_num_kv_splits_balanced")
 
 
@@ -282,7 +294,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
                          num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap=0.0,
                          sinks=None, xai_temperature_len=-1, has_mla=False, use_pdl=False,
                          page_size: int = 1, score_mod=None, aux_tensors=None, kv_layout=None, stages: int = 0,
-                         merge_counters=None, k_new=None, v_new=None, request_order=None):
+                         merge_counters=None, k_new=None, v_new=None, request_order=None, split_items=None):
     """Same contract as the reference.  q [bs,Hq,Dk], o [bs,Hq,Dv], kv_indptr int32[bs+1],
     kv_indices int32/int64, attn_logits fp32[bs,Hq,max_kv_splits,Dv], attn_lse fp32[bs,Hq,S].
     ``max_kv_splits == 1`` (or num_kv_splits None) runs the single-pass kernel.  ``stages`` as in
@@ -310,6 +322,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     p.merge_counters = _merge_counters_ptr(merge_counters, q.shape[0], q.shape[1])
     _set_new_kv(p, k_new, v_new, q.shape[0])
     p.request_order = _request_order_ptr(request_order, q.shape[0])
+    _set_split_items(p, split_items if p.max_kv_splits > 1 else None)
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -347,18 +360,57 @@ def _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indice
     return p
 
 
+class SplitItems:
+    """The live (request, split) pairs of a split schedule, compacted on the device (rx_split_items ->
+    rx_decode_params.split_items): the decode kernel's grid then holds live work only, longest requests first, instead of
+    bs x max_kv_splits split slots whose dead workgroups sit in front of a long request's later splits.
+
+    ``cap`` sizes the grid: the exact pair count when the caller knows the counts on the host (eager forwards), an upper
+    bound otherwise (graph replay: the surplus workgroups are at the END of the grid and exit at once)."""
+
+    def __init__(self, max_items: int, device):
+        self.items = torch.zeros(max(1, int(max_items)) * 2, dtype=torch.int32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.cap = 0
+
+    def build(self, num_kv_splits, request_order=None, cap: Optional[int] = None):
+        """num_kv_splits int32[bs] (device), request_order int32[bs] or None; cap defaults to the table's size."""
+        _require_cuda(num_kv_splits, request_order)
+        bs = num_kv_splits.shape[0]
+        if num_kv_splits.dtype != torch.int32 or (request_order is not None and request_order.dtype != torch.int32):
+            raise TypeError("SplitItems.build: num_kv_splits / request_order must be int32")
+        if request_order is not None and request_order.numel() < bs:
+            raise ValueError("SplitItems.build: request_order shorter than the batch")
+        self.cap = self.items.numel() // 2 if cap is None else int(cap)
+        if self.cap > self.items.numel() // 2:
+            raise ValueError(f"SplitItems.build: cap {self.cap} exceeds the table ({self.items.numel() // 2} pairs)")
+        st = _L.load().rx_split_items(_ptr(num_kv_splits), _ptr(request_order), bs, _ptr(self.items), _ptr(self.count),
+                                      self.cap, _stream(num_kv_splits))
+        _L.check(st, "rx_split_items")
+        return self
+
+
+def _set_split_items(p, split_items):
+    if split_items is None:
+        p.split_items, p.split_items_count, p.split_items_cap = None, None, 0
+    else:
+        p.split_items, p.split_items_count = split_items.items.data_ptr(), split_items.count.data_ptr()
+        p.split_items_cap = int(split_items.cap)
+
+
 def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
                                attn_logits, attn_lse, num_kv_splits, max_kv_splits, sm_scale,
                                k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
                                page_size: int = 1, kv_layout=None, xai_temperature_len=-1,
                                kv_start=None, extra_o=None, extra_lse=None, stages: int = 0, merge_counters=None,
-                               k_new=None, v_new=None, request_order=None):
+                               k_new=None, v_new=None, request_order=None, split_items=None):
     p = _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse,
                              num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap, sinks, page_size,
                              kv_layout, xai_temperature_len, kv_start, extra_o, extra_lse, stages)
     p.merge_counters = _merge_counters_ptr(merge_counters, q.shape[0], q.shape[1])
     _set_new_kv(p, k_new, v_new, q.shape[0])
     p.request_order = _request_order_ptr(request_order, q.shape[0])
+    _set_split_items(p, split_items if p.max_kv_splits > 1 else None)
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -473,7 +525,7 @@ class DecodeLauncher:
     def set_metadata(self, version, bs, *, kv_indptr=None, kv_indices=None, req_to_token=None,
                      req_pool_indices=None, seq_lens=None, num_kv_splits=None, max_kv_splits=1,
                      attn_logits=None, attn_lse=None, merge_counters=None, request_order=None,
-                     partial_pairs_hint: int = 0):
+                     partial_pairs_hint: int = 0, split_items=None):
         p = self.p
         p.bs = bs
         p.partial_pairs_hint = int(partial_pairs_hint)
@@ -493,8 +545,9 @@ class DecodeLauncher:
             p.attn_logits, p.attn_lse = attn_logits.data_ptr(), attn_lse.data_ptr()
         else:
             p.num_kv_splits, p.max_kv_splits = None, 1
+        _set_split_items(p, split_items if p.max_kv_splits > 1 else None)
         self._keep = (kv_indptr, kv_indices, req_to_token, req_pool_indices, seq_lens, num_kv_splits,
-                      attn_logits, attn_lse, merge_counters, request_order)
+                      attn_logits, attn_lse, merge_counters, request_order, split_items)
         self.version = version
 
     def can_fuse_store(self) -> bool:

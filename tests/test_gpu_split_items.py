@@ -1,0 +1,93 @@
+"""rx_split_items + rx_decode_params.split_items (round 3): the decode kernel's grid as the compacted list of live
+(request, split) pairs, longest requests first, instead of bs x max_kv_splits split slots.  The table is checked
+against its definition, the decode outputs must be BIT-identical to the slot form (same workgroups, same arithmetic,
+another dispatch order), and the whole thing against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import parity_util as parity
+from oracle import radix_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_split_items_table_matches_its_definition():
+    from sglang_amd import ops
+
+    rng = np.random.default_rng(0)
+    for bs in (1, 7, 64, 1500, 3000):
+        splits = rng.integers(0, 6, size=bs).astype(np.int32)   # 0 counts as 1 (a request always has its workgroup)
+        order = rng.permutation(bs).astype(np.int32)
+        for use_order in (False, True):
+            want = [(int(b), s) for b in (order if use_order else range(bs)) for s in range(max(int(splits[b]), 1))]
+            for cap in (len(want), len(want) + 5, max(1, len(want) // 2)):
+                si = ops.SplitItems(max(cap, 1), DEV)
+                si.items.fill_(-7)
+                si.build(torch.from_numpy(splits).to(DEV), torch.from_numpy(order).to(DEV) if use_order else None, cap=cap)
+                torch.cuda.synchronize()
+                assert int(si.count.item()) == len(want)              # the count says how many there WOULD be
+                got = si.items.cpu().numpy().reshape(-1, 2)
+                n = min(cap, len(want))
+                assert got[:n].tolist() == [list(x) for x in want[:n]]
+                assert (got[n:] == -7).all()                           # nothing written past cap
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("lookup", ["paged", "indices"])
+def test_decode_with_split_items_is_bit_identical_to_split_slots(dtype, lookup):
+    from sglang_amd import ops
+
+    hq, hkv, d, ps = 32, 8, 128, 16
+    lens = np.array([9000, 1, 0, 700, 2049, 33, 4096, 128, 5000, 17], dtype=np.int64)
+    bs = len(lens)
+    rng = np.random.default_rng(3)
+    pages = [-(-int(n) // ps) for n in lens]
+    perm = rng.permutation(np.arange(1, sum(pages) + 1))
+    r2t = np.zeros((bs + 1, int(lens.max()) + ps), dtype=np.int32)
+    pi = 0
+    for i, n in enumerate(lens):
+        r2t[i + 1, :n] = (perm[pi: pi + pages[i], None] * ps + np.arange(ps)[None]).reshape(-1)[:n]
+        pi += pages[i]
+    pool = (sum(pages) + 1) * ps
+    g = torch.Generator().manual_seed(1)
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    q = torch.randn(bs, hq, d, generator=g).to(dtype)
+    rpi = np.arange(1, bs + 1, dtype=np.int64)
+    S = 16
+    splits = torch.zeros(bs, dtype=torch.int32, device=DEV)
+    lens_d = torch.from_numpy(lens).to(DEV)
+    ops.get_num_kv_splits_balanced(splits, lens_d, hq, hkv, S, 512, 128)
+    order = torch.argsort(lens_d, descending=True).to(torch.int32)
+    kbd, vbd, qd = kb.to(DEV), vb.to(DEV), q.to(DEV)
+    ip, ii = orc.build_kv_indices(r2t, rpi, lens)
+    outs = []
+    for items in (None, "exact", "upper"):
+        o = torch.full((bs, hq, d), float("nan"), dtype=dtype, device=DEV)
+        al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
+        ls = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+        cnt = torch.zeros(bs * hq, dtype=torch.int32, device=DEV)
+        si = None
+        if items:
+            n_live = int(splits.clamp_min(1).sum())
+            si = ops.SplitItems(n_live if items == "exact" else bs * S, DEV).build(splits, order)
+        if lookup == "paged":
+            ops.decode_attention_fwd_paged(qd, kbd, vbd, o, torch.from_numpy(r2t).to(DEV), torch.from_numpy(rpi).to(DEV),
+                                           lens_d, al, ls, splits, S, d ** -0.5, page_size=ps, merge_counters=cnt,
+                                           request_order=order, split_items=si)
+        else:
+            ops.decode_attention_fwd(qd, kbd, vbd, o, torch.from_numpy(ip).to(DEV), torch.from_numpy(ii).to(DEV), al, ls, splits,
+                                     S, d ** -0.5, 1.0, 1.0, page_size=ps, merge_counters=cnt, request_order=order,
+                                     split_items=si)
+        torch.cuda.synchronize()
+        assert int(cnt.abs().sum()) == 0            # the in-kernel merge left its counters at zero
+        outs.append(o)
+    a, b, c = (x.view(torch.int16).cpu().numpy() for x in outs)
+    assert (a == b).all() and (a == c).all()
+    live = lens > 0
+    want = orc.decode_attention(q.view(torch.uint16).numpy() if dtype == torch.bfloat16 else q.numpy(),
+                                kb.view(torch.uint16).numpy() if dtype == torch.bfloat16 else kb.numpy(),
+                                vb.view(torch.uint16).numpy() if dtype == torch.bfloat16 else vb.numpy(), ip, ii, d ** -0.5)
+    parity.check_out(outs[1].float().cpu().numpy()[live], want[live], dtype, ("split items", lookup), ulps=1)

@@ -18,12 +18,13 @@ def case(lens):
     q=torch.randn(bs,HQ,D,device=dev).to(torch.bfloat16); o=torch.empty_like(q)
     r2td=torch.from_numpy(r2t).to(dev); rpi=torch.arange(1,bs+1,device=dev); lens_d=torch.tensor(lens,dtype=torch.int64,device=dev)
     byt=sum(lens)*HKV*D*2*2
-    def t(ns, S, order=None):
+    def t(ns, S, order=None, items=False):
         cnt=torch.zeros(bs*HQ,dtype=torch.int32,device=dev)
+        si=ops.SplitItems(int(ns.clamp_min(1).sum()),dev).build(ns,order) if items else None
         al=torch.empty(bs,HQ,S,D,dtype=torch.float32,device=dev); lse=torch.empty(bs,HQ,S,device=dev)
         def f():
             if S==1: ops.decode_attention_fwd_paged(q,kb,vb,o,r2td,rpi,lens_d,None,None,None,1,D**-0.5,page_size=PS,kv_layout=lay,request_order=order)
-            else: ops.decode_attention_fwd_paged(q,kb,vb,o,r2td,rpi,lens_d,al,lse,ns,S,D**-0.5,page_size=PS,kv_layout=lay,merge_counters=cnt,request_order=order)
+            else: ops.decode_attention_fwd_paged(q,kb,vb,o,r2td,rpi,lens_d,al,lse,ns,S,D**-0.5,page_size=PS,kv_layout=lay,merge_counters=cnt,request_order=order,split_items=si)
         for _ in range(3): f()
         torch.cuda.synchronize()
         e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
@@ -40,7 +41,7 @@ def case(lens):
         print(f"  K3 formula, max {S:2d}     ", t(ref,S), ref.tolist()[:3], int(ref.max()))
         tot=sum(lens)*HKV; tstar=max(512, tot/512.0)
         bal=torch.tensor([min(S,max(1,int(np.ceil(n/tstar)))) for n in lens],dtype=torch.int32,device=dev)
-        print(f"  balanced, max {S:2d}       ", t(bal,S,order), bal.tolist()[:3], int(bal.max()))
+        print(f"  balanced, max {S:2d}       ", t(bal,S,order), "| live pairs only:", t(bal,S,order,True), bal.tolist()[:3], int(bal.max()))
 case([32768]+[1024]*63)
 case([8192]*4+[512]*124)
 case(list(np.random.default_rng(1).integers(100,6000,size=96)))
