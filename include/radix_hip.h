@@ -219,6 +219,11 @@ typedef struct rx_decode_params {
   const void* extra_o;
   const float* extra_lse;
   int32_t num_extra_partials;
+  /* Several shared prefixes in one batch (one per radix-tree node, round 3): the extra partials hold rows for the
+   * MEMBERS of the groups only, in group order.  extra_index (int32[bs] or NULL = the identity over bs rows): row of
+   * request b inside one partial, < 0 = b belongs to no group (no extras merged); extra_rows: rows per partial. */
+  const int32_t* extra_index;
+  int32_t extra_rows;
   /* 0 = stage 1 then stage 2 (default); 1 = stage 1 only (partials to attn_logits / attn_lse);
    * 2 = stage 2 only.  Lets a caller produce the extra partials on another stream while stage 1 runs
    * and join before the merge.  1 / 2 need max_kv_splits > 1. */

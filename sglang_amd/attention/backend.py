@@ -216,6 +216,10 @@ class HipRadixAttnBackend:
         self.cascade_min_bs, self.cascade_min_shared = int(cascade_min_bs), int(cascade_min_shared)
         self._cascade = None
         self._cascade_on = False
+        self._cascade_groups = None       # ops.CascadeGroups: several prefixes (forward_batch.radix_last_nodes / cascade_groups)
+        self._cascade_call = None
+        self.cascade_min_members = 4      # a group of fewer requests re-reads its prefix instead
+        self.cascade_groups_max_shared = 1 << 20  # slots of all shared prefixes of one batch together
         self._verify_split = None      # ops.VerifySplitKV, built on the first TARGET_VERIFY forward
         self._verify_split_on = False
         self._extend_split_on = False
@@ -332,11 +336,48 @@ class HipRadixAttnBackend:
             return buf[:bs]
         return order
 
+    def _plan_cascade_groups(self, fb: ForwardBatch, bs: int):
+        """Shared-prefix groups of this decode batch, when the scheduler handed the radix nodes (or the groups) over:
+        None unless they describe something the batch-wide device plan (ops.CascadeDecode) cannot -- more than one group,
+        or a group that is only part of the batch."""
+        groups = getattr(fb, "cascade_groups", None)
+        nodes = getattr(fb, "radix_last_nodes", None)
+        if groups is None and nodes is not None and self._kv_head_dim_ok_for_groups():
+            from ..mem_cache.radix_cache import plan_shared_prefix_groups
+            lens = None if fb.seq_lens_cpu is None else fb.seq_lens_cpu.tolist()
+            groups = plan_shared_prefix_groups(nodes, lens, min_shared=self.cascade_min_shared,
+                                               min_members=self.cascade_min_members)
+        if not groups or not self._kv_head_dim_ok_for_groups():
+            return None
+        groups = groups[: 32]
+        if len(groups) == 1 and len(groups[0][0]) == bs:
+            return None
+        return groups
+
+    def _kv_head_dim_ok_for_groups(self) -> bool:
+        kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
+        return (kb.shape[-1] in (64, 96, 128, 256) and kb.shape[-1] == self.v_head_dim
+                and kb.dtype in (torch.bfloat16, torch.float16))
+
     def _decode_metadata(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool) -> ForwardMetadata:
         # (latent MLA rows are shared by all heads already: the cascade pays from ~128 requests on -- 64 x (3584 shared +
         # 512 own): 54 -> 78 us per layer, 256: 194 -> 122, 256 x (8192 + 256): 348 -> 158; tools/cascade_bench.py MLA=1)
         self._cascade_on = self.cascade_decode and bs >= (max(self.cascade_min_bs, 128) if self._is_mla_pool
                                                           else self.cascade_min_bs)
+        self._cascade_call = None
+        groups = (self._plan_cascade_groups(fb, bs)
+                  if (self.cascade_decode and not self._is_mla_pool and not use_graph_bufs) else None)  # (geometry varies: eager steps only)
+        if groups:
+            # several shared prefixes (one per radix-tree node), or one that only part of the batch shares
+            if self._cascade_groups is None:
+                kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
+                self._cascade_groups = ops.CascadeGroups(
+                    self.req_to_token_pool.size, self.num_head, self.num_kv_head, kb.shape[-1], self._q_dtype(kb),
+                    self.device, max_shared_total=max(self.req_to_token.shape[1], self.cascade_groups_max_shared),
+                    cu_count=self.device_core_count, max_kv_splits=self.native_split_cap)
+            self._cascade_groups.plan(self.req_to_token, fb.req_pool_indices, fb.seq_lens, groups)
+            self._cascade_on, self._cascade_call = True, self._cascade_groups
+            return ForwardMetadata(None, None, None, None, None, None, None, 1)
         if self._cascade_on:
             if self._cascade is None:
                 kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
@@ -354,6 +395,7 @@ class HipRadixAttnBackend:
                         v_head_dim=self.v_head_dim)
             if self._cascade_on:
                 self._cascade.plan(self.req_to_token, fb.req_pool_indices, fb.seq_lens)
+                self._cascade_call = self._cascade
                 return ForwardMetadata(None, None, None, None, None, None, None, 1)
         if self.split_policy == "native" and self.sliding_window_size is None:
             return self._decode_metadata_native(fb, bs, use_graph_bufs)
@@ -861,7 +903,7 @@ class HipRadixAttnBackend:
             hnd = getattr(self.token_to_kv_pool, "use_hnd", False)
             kn = k.view(-1, layer.tp_k_head_num, layer.qk_head_dim) if fuse else None
             vn = v.view(-1, layer.tp_v_head_num, layer.v_head_dim) if fuse else None
-            self._cascade(q3, k_buf, v_buf, o3, layer.scaling, k_descale, v_descale, layer.logit_cap,
+            self._cascade_call(q3, k_buf, v_buf, o3, layer.scaling, k_descale, v_descale, layer.logit_cap,
                           sinks if sinks is None or sinks.dtype == torch.float32 else sinks.float(),
                           page_size=self.page_size, kv_layout=ops.kv_layout_hnd(k_buf, v_buf) if hnd else None,
                           k_new=kn, v_new=vn)

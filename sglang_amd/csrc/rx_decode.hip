@@ -54,6 +54,8 @@ struct DecodeArgs {
   const uint16_t* extra_o;   // [num_extra, bs, hq, dv] partial outputs merged by stage 2 (or NULL)
   const float* extra_lse;    // [num_extra, bs, hq]
   int32_t num_extra;
+  const int32_t* extra_index;  // row of request b inside one extra partial (NULL: b; < 0: the request has none)
+  int32_t extra_rows;          // rows of one extra partial (bs unless extra_index compacts them)
   int32_t stages;  // 0 both, 1 stage 1 only, 2 stage 2 only
   int32_t* merge_counters;  // in-kernel stage 2 (rx_common.h split_arrive_is_last), or NULL: stage-2 launch
   // fused store of the new token (16-bit pools, one q block per kv head): its K / V rows [bs, Hkv, D], or NULL
@@ -84,12 +86,14 @@ template <typename T>
 __device__ __forceinline__ void fold_extras(const DecodeArgs& a, int b, int h, int d, int dv, float& mx, float& lsum,
                                             float& acc) {
   constexpr int kBatch = 4;  // loads of a batch are issued together: one memory latency per batch, not per partial
+  const int xb = a.extra_index ? a.extra_index[b] : b;
+  if (xb < 0) return;  // not a member of any shared-prefix group
   for (int x0 = 0; x0 < a.num_extra; x0 += kBatch) {
     float xl[kBatch], xv[kBatch];
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) {
       const int x = min(x0 + j, a.num_extra - 1);
-      const int64_t xrow = (static_cast<int64_t>(x) * a.bs + b) * a.hq + h;
+      const int64_t xrow = (static_cast<int64_t>(x) * a.extra_rows + xb) * a.hq + h;
       xl[j] = a.extra_lse[xrow];
       xv[j] = T::to_f32(a.extra_o[xrow * dv + d]);
     }
@@ -684,8 +688,11 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const DecodeArgs a, i
   const float* lse = a.attn_lse + row0;
   float e_max = -INFINITY;
   for (int s = 0; s < live; ++s) e_max = fmaxf(e_max, lse[s]);
-  const int64_t xstride = static_cast<int64_t>(a.bs) * a.hq;  // one extra partial = [bs, hq] rows
-  for (int x = 0; x < a.num_extra; ++x) e_max = fmaxf(e_max, a.extra_lse[x * xstride + bh]);
+  const int64_t xstride = static_cast<int64_t>(a.extra_rows) * a.hq;  // one extra partial = [extra_rows, hq] rows
+  const int xb = a.extra_index ? a.extra_index[b] : b;
+  const int64_t xbh = static_cast<int64_t>(xb) * a.hq + h;
+  const int nx = xb < 0 ? 0 : a.num_extra;  // not in any shared-prefix group: no extras
+  for (int x = 0; x < nx; ++x) e_max = fmaxf(e_max, a.extra_lse[x * xstride + xbh]);
   float e_sum = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const float* lp = a.attn_logits + row0 * dv + d;
@@ -696,11 +703,11 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const DecodeArgs a, i
     acc += w * tv;
     e_sum += w;
   }
-  for (int x = 0; x < a.num_extra; ++x) {  // 16-bit partials of another pass (shared-prefix phase)
-    const float xl = a.extra_lse[x * xstride + bh];
+  for (int x = 0; x < nx; ++x) {  // 16-bit partials of another pass (shared-prefix phase)
+    const float xl = a.extra_lse[x * xstride + xbh];
     if (!(xl > -INFINITY)) continue;  // empty partial: its row is undefined
     const float w = __expf(xl - e_max);
-    const u32x2 raw = *reinterpret_cast<const u32x2*>(a.extra_o + (x * xstride + bh) * dv + d);
+    const u32x2 raw = *reinterpret_cast<const u32x2*>(a.extra_o + (x * xstride + xbh) * dv + d);
     acc += w * f32x4{T::to_f32(static_cast<uint16_t>(raw[0] & 0xffff)), T::to_f32(static_cast<uint16_t>(raw[0] >> 16)),
                      T::to_f32(static_cast<uint16_t>(raw[1] & 0xffff)), T::to_f32(static_cast<uint16_t>(raw[1] >> 16))};
     e_sum += w;
@@ -739,8 +746,9 @@ __global__ __launch_bounds__(128) void decode_merge_scalar_kernel(const DecodeAr
         e_max = n_max;
       }
     }
-    for (int x = 0; x < a.num_extra; ++x) {
-      const int64_t xrow = (static_cast<int64_t>(x) * a.bs + b) * a.hq + h;
+    const int xb = a.extra_index ? a.extra_index[b] : b;
+    for (int x = 0; x < (xb < 0 ? 0 : a.num_extra); ++x) {
+      const int64_t xrow = (static_cast<int64_t>(x) * a.extra_rows + xb) * a.hq + h;
       const float tl = a.extra_lse[xrow];
       if (!(tl > -INFINITY)) continue;
       const float tv = T::to_f32(a.extra_o[xrow * dv + d]);
@@ -922,6 +930,8 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.num_extra = p->num_extra_partials > 0 ? p->num_extra_partials : 0;
   a.extra_o = a.num_extra ? (const uint16_t*)p->extra_o : nullptr;
   a.extra_lse = a.num_extra ? p->extra_lse : nullptr;
+  a.extra_index = a.num_extra ? p->extra_index : nullptr;
+  a.extra_rows = (a.num_extra && p->extra_index && p->extra_rows > 0) ? p->extra_rows : p->bs;
   if (a.num_extra)
     RX_REQUIRE(p->extra_o && p->extra_lse && (max_splits > 1 || mfma_ok),
                "rx_decode_attn: extra partials need extra_o, extra_lse and either max_kv_splits > 1 (stage 2 merges "

@@ -69,6 +69,11 @@ class ForwardBatch:
     extend_prefix_lens_cpu: Optional[List[int]] = None
     encoder_lens: Optional[torch.Tensor] = None
     spec_info: object = None
+    # decode-only, optional: the radix-tree node each request's cached prefix ends in (req.last_node, kept by the
+    # scheduler from RadixCache.match_prefix, radix_cache.py:352-430) -- or the shared-prefix groups themselves,
+    # [(member batch rows, shared token count)] -- for the backend's cascade over several prefixes (ops.CascadeGroups)
+    radix_last_nodes: Optional[list] = None
+    cascade_groups: Optional[list] = None
 
     @classmethod
     def for_decode(cls, req_pool_indices, seq_lens, out_cache_loc, seq_lens_cpu=None):

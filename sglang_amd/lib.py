@@ -52,6 +52,7 @@ class RxDecodeParams(C.Structure):
         ("sinks", c_void_p), ("dtype", c_int32),
         ("xai_temperature_len", c_int32),
         ("kv_start", c_void_p), ("extra_o", c_void_p), ("extra_lse", c_void_p), ("num_extra_partials", c_int32),
+        ("extra_index", c_void_p), ("extra_rows", c_int32),
         ("stages", c_int32), ("merge_counters", c_void_p),
         ("k_new", c_void_p), ("v_new", c_void_p),
         ("k_new_stride_t", c_int64), ("k_new_stride_h", c_int64), ("v_new_stride_t", c_int64), ("v_new_stride_h", c_int64),

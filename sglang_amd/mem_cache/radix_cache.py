@@ -336,3 +336,80 @@ class RadixCache:
         req.cache_protected_len = m
         req.last_node = TreeNode(self, out[6])
         req.prefix_indices = cached if m == row.numel() else torch.cat([cached, row[m:]])
+
+
+def plan_shared_prefix_groups(last_nodes, seq_lens=None, min_shared: int = 1024, min_members: int = 2):
+    """Shared-prefix groups of a decode batch from the radix tree (the planner of ops.CascadeGroups).
+
+    ``last_nodes[i]``: the node request i's cached prefix ends in -- ``MatchResult.last_device_node`` of
+    RadixCache.match_prefix (srt/mem_cache/radix_cache.py:352-430), kept as ``req.last_node`` by the scheduler.  Every
+    ancestor n of it is a prefix of ``depth(n)`` tokens (the key lengths root -> n summed) that request i shares, slot
+    for slot, with every other request below n.  Reading the prefix of n once for its ``count(n)`` requests saves
+    ``(count(n) - 1) * depth(n)`` K/V row reads; a request joins ONE group (single-level cascade), so the groups are an
+    antichain of the tree, and the best one is a bottom-up choice per node: the node itself, or the best of its children.
+
+    Returns [(member batch rows (ascending), shared token count)], largest saving first.  ``seq_lens`` (host ints,
+    optional) caps the shared count at the shortest member (a prefix node cannot be longer, this only guards a caller
+    that truncated a request).  Works on this package's TreeNode handles and on the reference's TreeNode objects
+    (``.parent``, ``.key``)."""
+    def ident(n):
+        return getattr(n, "id", None) if getattr(n, "id", None) is not None else id(n)
+
+    def klen(n):
+        f = getattr(n, "key_len", None)
+        if callable(f):
+            return int(f())
+        k = getattr(n, "key", None)
+        return 0 if k is None else len(k)
+
+    info = {}      # node id -> [parent id or None, key length, requests below, depth]
+    for i, node in enumerate(last_nodes):
+        n, path = node, []
+        while n is not None:
+            k = ident(n)
+            ent = info.get(k)
+            if ent is None:
+                par = n.parent
+                ent = info[k] = [None if par is None else ident(par), klen(n) if par is not None else 0, [], None]
+                path.append(k)
+                n = par
+            else:
+                path.append(k)
+                n = None
+        # every node on the whole path (also the part found already) counts request i
+        k = ident(node)
+        while k is not None:
+            info[k][2].append(i)
+            k = info[k][0]
+    def depth(k):
+        ent = info[k]
+        if ent[3] is None:
+            ent[3] = ent[1] + (depth(ent[0]) if ent[0] is not None else 0)
+        return ent[3]
+
+    children = {}
+    for k, ent in info.items():
+        children.setdefault(ent[0], []).append(k)
+    order = sorted(info, key=depth, reverse=True)  # children before parents
+    best = {}      # node -> (saving, [group nodes])
+    for k in order:
+        cnt, d = len(info[k][2]), depth(k)
+        own = (cnt - 1) * d if (cnt >= min_members and d >= min_shared) else 0
+        sub_gain, sub_nodes = 0, []
+        for c in children.get(k, []):
+            g, nodes = best[c]
+            sub_gain += g
+            sub_nodes += nodes
+        best[k] = (own, [k]) if own > sub_gain else (sub_gain, sub_nodes)
+    roots = children.get(None, [])
+    groups = []
+    for r in roots:
+        for k in best[r][1] if best[r][0] > 0 else []:
+            members = sorted(info[k][2])
+            L = depth(k)
+            if seq_lens is not None:
+                L = min(L, min(int(seq_lens[i]) for i in members))
+            if L >= min_shared and len(members) >= min_members:
+                groups.append((members, int(L)))
+    groups.sort(key=lambda g: -(len(g[0]) - 1) * g[1])
+    return groups

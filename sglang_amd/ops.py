@@ -330,7 +330,7 @@ def _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indice
                                attn_logits, attn_lse, num_kv_splits, max_kv_splits, sm_scale,
                                k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
                                page_size: int = 1, kv_layout=None, xai_temperature_len=-1,
-                               kv_start=None, extra_o=None, extra_lse=None, stages: int = 0):
+                               kv_start=None, extra_o=None, extra_lse=None, stages: int = 0, extra_index=None):
     """MI355X-native entry: the kernel walks req_to_token itself (as the reference's CPU kernel
     decode_attention_cpu does, aot/csrc/cpu/decode.cpp:1586), so no kv_indices are materialised.
     ``kv_start`` int32[bs]: attend tokens [kv_start[b], seq_len_b) only; ``extra_o`` [P,bs,Hq,Dv] +
@@ -355,7 +355,7 @@ def _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indice
             raise TypeError("kv_start must be int32")
         p.kv_start = kv_start.data_ptr()
     if extra_o is not None:
-        _set_extra_partials(p, extra_o, extra_lse, q)
+        _set_extra_partials(p, extra_o, extra_lse, q, extra_index)
     p.stages = int(stages)
     return p
 
@@ -414,14 +414,22 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
-def _set_extra_partials(p, extra_o, extra_lse, q):
+def _set_extra_partials(p, extra_o, extra_lse, q, extra_index=None):
     bs, hq = q.shape[0], q.shape[1]
     if extra_o.dtype != q.dtype or extra_lse.dtype != torch.float32:
         raise TypeError("extra_o must have q's dtype, extra_lse float32")
-    if (extra_o.dim() != 4 or tuple(extra_o.shape[1:3]) != (bs, hq) or not extra_o.is_contiguous()
+    rows = bs if extra_index is None else extra_o.shape[1]
+    if (extra_o.dim() != 4 or tuple(extra_o.shape[1:3]) != (rows, hq) or not extra_o.is_contiguous()
             or tuple(extra_lse.shape) != tuple(extra_o.shape[:3]) or not extra_lse.is_contiguous()):
-        raise ValueError("extra_o must be contiguous [P, bs, Hq, Dv], extra_lse contiguous [P, bs, Hq]")
+        raise ValueError("extra_o must be contiguous [P, bs, Hq, Dv], extra_lse contiguous [P, bs, Hq] "
+                         "(with extra_index: [P, rows, Hq, Dv] / [P, rows, Hq])")
     p.extra_o, p.extra_lse, p.num_extra_partials = extra_o.data_ptr(), extra_lse.data_ptr(), extra_o.shape[0]
+    if extra_index is not None:
+        if extra_index.dtype != torch.int32 or extra_index.numel() < bs or not extra_index.is_cuda:
+            raise TypeError("extra_index must be a device int32[bs]")
+        p.extra_index, p.extra_rows = extra_index.data_ptr(), rows
+    else:
+        p.extra_index, p.extra_rows = None, 0
 
 
 def _fill_decode_common(p, q, k_buffer, v_buffer, o, attn_logits, attn_lse, num_kv_splits,
@@ -762,6 +770,157 @@ class CascadeDecode:
         phase2(1)
         cur.wait_stream(self._side)
         phase2(2)
+
+
+class CascadeGroups:
+    """Shared-prefix decode with SEVERAL prefixes in one batch: one per radix-tree node the scheduler found requests
+    under (RadixCache.match_prefix groups, srt/mem_cache/radix_cache.py:352-430; plan them with
+    mem_cache.radix_cache.plan_shared_prefix_groups).  CascadeDecode is the one-group case with a device-side plan.
+
+    * ``plan(req_to_token, req_pool_indices, seq_lens, groups)`` once per forward: ``groups`` = [(member batch rows,
+      shared token count)], disjoint.  Host work is O(groups * chunks); the slot lists are gathered on the device.
+    * ``__call__`` per layer: (1) ONE launch of the extend MFMA kernel over pseudo-requests (chunk c, group g): the
+      queries of the group's members (gathered, M rows in group order) against chunk c of the group's prefix;
+      (2) the decode kernel over every request's own suffix [L_g(b), seq_len_b) (the whole row for requests in no
+      group); its stage 2 / single-pass epilogue merges the chunk partials of the request's row
+      (rx_decode_params.extra_index).
+
+    Same result as plain decode attention up to the partials' 16-bit rounding (merge_state.py:8-96 is the reference's
+    building block)."""
+
+    def __init__(self, max_bs: int, num_q_heads: int, num_kv_heads: int, head_dim: int, dtype, device,
+                 max_shared_total: int, cu_count: int = 256, max_groups: int = 32, max_chunks: int = 16,
+                 max_kv_splits: int = 16):
+        if head_dim not in (64, 96, 128, 256):
+            raise ValueError("CascadeGroups: head_dim 64 / 96 / 128 / 256 (the MFMA extend and decode kernels)")
+        self.max_bs, self.hq, self.hkv, self.d = int(max_bs), num_q_heads, num_kv_heads, head_dim
+        self.cu_count, self.max_groups, self.max_chunks = int(cu_count), int(max_groups), int(max_chunks)
+        self.split_cap = max(2, int(max_kv_splits))
+        self.device = device
+        i32 = dict(dtype=torch.int32, device=device)
+        P = self.max_groups * self.max_chunks
+        self.max_shared_total = int(max_shared_total)
+        self.shared_indices = torch.zeros(max(1, self.max_shared_total), **i32)
+        # one packed int32 table per plan: [kv_indptr P+1 | qo_indptr P+1 | src_row P | src_col P | kv_start bs |
+        # extra_index bs | gather C*bs]
+        self._tab_len = 2 * (P + 1) + 2 * P + 2 * self.max_bs + self.max_chunks * self.max_bs
+        self._tab_host = torch.zeros(self._tab_len, dtype=torch.int32).pin_memory() if torch.cuda.is_available() \
+            else torch.zeros(self._tab_len, dtype=torch.int32)
+        self._tab = torch.zeros(self._tab_len, **i32)
+        self.suffix_lens = torch.zeros(self.max_bs, **i32)
+        self.num_kv_splits = torch.ones(self.max_bs, **i32)
+        rows = self.max_chunks * self.max_bs
+        self.q_rep = torch.zeros(rows * num_q_heads * head_dim, dtype=dtype, device=device)
+        self.o_parts = torch.zeros(rows * num_q_heads * head_dim, dtype=dtype, device=device)
+        self.lse_parts = torch.zeros(rows * num_q_heads, dtype=torch.float32, device=device)
+        group = max(1, num_q_heads // num_kv_heads)
+        prow = (max(2 * self.max_bs, cu_count // (num_kv_heads * ((group + 15) // 16)) + self.max_bs) + 1) * num_q_heads
+        self.attn_logits = torch.empty(prow * head_dim, dtype=torch.float32, device=device)
+        self.attn_lse = torch.empty(prow, dtype=torch.float32, device=device)
+        self._lib = _L.load()
+        self.bs = self.members = self.num_chunks = self.num_groups = 0
+
+    @staticmethod
+    def layout(groups, bs: int, hq: int, cu_count: int, max_chunks: int, chunk_align: int = 64):
+        """Host half of the plan (pure numpy, no device): returns a dict of int32 arrays -- the pseudo-request tables
+        of phase 1 and the per-request tables of phase 2.  Pseudo-request p = c * G + g; the shared slot list is laid
+        out in the same order, so both indptr arrays are monotone."""
+        G = len(groups)
+        sizes = np.asarray([len(m) for m, _ in groups], dtype=np.int64)
+        lens = np.asarray([int(L) for _, L in groups], dtype=np.int64)
+        members = np.concatenate([np.asarray(m, dtype=np.int64) for m, _ in groups]) if G else np.zeros(0, np.int64)
+        if len(np.unique(members)) != len(members) or (members < 0).any() or (members >= bs).any():
+            raise ValueError("CascadeGroups: groups must be disjoint sets of batch rows")
+        M = int(sizes.sum())
+        wgs = int((-(-sizes // 128)).sum()) * hq  # phase-1 workgroups per chunk
+        C = int(max(1, min(max_chunks, -(-cu_count // max(1, wgs)))))
+        per = -(-(-(-lens // C)) // chunk_align) * chunk_align          # chunk length of each group, aligned
+        starts = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+        kv_indptr = np.zeros(C * G + 1, np.int64)
+        qo_indptr = np.zeros(C * G + 1, np.int64)
+        src_col = np.zeros(C * G, np.int64)
+        for c in range(C):
+            lo = np.minimum(c * per, lens)
+            hi = np.minimum((c + 1) * per, lens)
+            kv_indptr[c * G + 1: (c + 1) * G + 1] = hi - lo
+            src_col[c * G: (c + 1) * G] = lo
+            qo_indptr[c * G: (c + 1) * G] = c * M + starts
+        qo_indptr[C * G] = C * M
+        kv_indptr = np.cumsum(kv_indptr)
+        kv_start = np.zeros(bs, np.int64)
+        extra_index = np.full(bs, -1, np.int64)
+        if G:
+            kv_start[members] = np.repeat(lens, sizes)
+            extra_index[members] = np.arange(M)
+        gather = (np.tile(members, C) if M else np.zeros(0, np.int64))
+        first = np.asarray([int(m[0]) for m, _ in groups], dtype=np.int64) if G else np.zeros(0, np.int64)
+        return dict(C=C, G=G, M=M, kv_indptr=kv_indptr, qo_indptr=qo_indptr, src_col=src_col,
+                    src_member=np.tile(first, C), kv_start=kv_start, extra_index=extra_index, gather=gather,
+                    max_group=int(sizes.max()) if G else 0, total_shared=int(kv_indptr[-1]))
+
+    def plan(self, req_to_token, req_pool_indices, seq_lens, groups) -> None:
+        bs = self.bs = req_pool_indices.shape[0]
+        if bs > self.max_bs or len(groups) > self.max_groups:
+            raise ValueError(f"CascadeGroups: bs {bs} / {len(groups)} groups beyond max_bs {self.max_bs} / max_groups {self.max_groups}")
+        lay = self.layout(groups, bs, self.hq, self.cu_count, self.max_chunks)
+        C, G, M = lay["C"], lay["G"], lay["M"]
+        if lay["total_shared"] > self.max_shared_total:
+            raise ValueError(f"CascadeGroups: {lay['total_shared']} shared tokens > max_shared_total {self.max_shared_total}")
+        self.num_chunks, self.num_groups, self.members, self.max_group = C, G, M, lay["max_group"]
+        self._tabs = (req_to_token, req_pool_indices, seq_lens)
+        P = C * G
+        parts = [lay["kv_indptr"], lay["qo_indptr"], lay["src_member"], lay["src_col"], lay["kv_start"],
+                 lay["extra_index"], lay["gather"]]
+        offs = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
+        host = self._tab_host
+        host[: offs[-1]] = torch.from_numpy(np.concatenate(parts).astype(np.int32))
+        self._tab[: offs[-1]].copy_(host[: offs[-1]], non_blocking=True)
+        view = lambda i: self._tab[int(offs[i]): int(offs[i + 1])]
+        self.kv_indptr, self.qo_indptr, src_member, src_col = view(0), view(1), view(2), view(3)
+        self.kv_start, self.extra_index, self.gather = view(4), view(5), view(6).long()
+        # the shared slot lists, gathered from the first member's req_to_token row (every member holds the same slots)
+        T = lay["total_shared"]
+        if T:
+            pos = torch.arange(T, dtype=torch.int32, device=self.device)
+            pr = torch.searchsorted(self.kv_indptr[1:].contiguous(), pos, right=True)
+            col = src_col[pr].long() + (pos - self.kv_indptr[pr]).long()
+            row = req_pool_indices.long()[src_member[pr].long()]
+            self.shared_indices[:T] = req_to_token[row, col]
+        torch.sub(seq_lens.to(torch.int32), self.kv_start, out=self.suffix_lens[:bs])
+        self.max_kv_splits = native_max_kv_splits(bs, self.hq, self.hkv, self.cu_count, self.split_cap)
+        if self.max_kv_splits > 1:
+            get_num_kv_splits_native(self.num_kv_splits[:bs], self.suffix_lens[:bs], self.hq, self.hkv,
+                                     self.max_kv_splits, self.cu_count)
+
+    def __call__(self, q, k_buffer, v_buffer, o, sm_scale, k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
+                 page_size: int = 1, kv_layout=None, k_new=None, v_new=None) -> None:
+        bs, nc, M = self.bs, self.num_chunks, self.members
+        if q.shape != (bs, self.hq, self.d):
+            raise ValueError(f"CascadeGroups: q {tuple(q.shape)} != {(bs, self.hq, self.d)}")
+        req_to_token, req_pool_indices, seq_lens = self._tabs
+        S = self.max_kv_splits
+        attn_logits = self.attn_logits[: bs * self.hq * S * self.d].view(bs, self.hq, S, self.d)
+        attn_lse = self.attn_lse[: bs * self.hq * S].view(bs, self.hq, S)
+        extra_o = extra_lse = None
+        if M:
+            rows = nc * M
+            q_rep = self.q_rep[: rows * self.hq * self.d].view(rows, self.hq, self.d)
+            o_parts = self.o_parts[: rows * self.hq * self.d].view(rows, self.hq, self.d)
+            lse_parts = self.lse_parts[: rows * self.hq].view(rows, self.hq)
+            torch.index_select(q, 0, self.gather, out=q_rep)
+            pe = _extend_params(q_rep, q_rep, q_rep, o_parts, k_buffer, v_buffer, self.qo_indptr, self.kv_indptr,
+                                self.shared_indices, None, False, None, self.max_group, k_scale, 1.0, sm_scale=sm_scale,
+                                logit_cap=logit_cap, lse_extend=lse_parts, skip_extend=True, page_size=page_size,
+                                kv_layout=kv_layout, _num_kv_heads=self.hkv, avg_kv_len_hint=0)
+            _L.check(self._lib.rx_extend_attn(C.byref(pe), _stream(q)), "rx_extend_attn")
+            extra_o = o_parts.view(nc, M, self.hq, self.d)
+            extra_lse = lse_parts.view(nc, M, self.hq)
+        pd = _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse,
+                                  self.num_kv_splits[:bs] if S > 1 else None, S, sm_scale, k_scale, v_scale, logit_cap,
+                                  sinks, page_size, kv_layout, kv_start=self.kv_start, extra_o=extra_o,
+                                  extra_lse=extra_lse, extra_index=self.extra_index if M else None)
+        _set_new_kv(pd, k_new, v_new, bs)
+        _L.check(self._lib.rx_decode_attn(C.byref(pd), _stream(q)), "rx_decode_attn")
 
 
 class StoreLayoutLauncher:

@@ -1,0 +1,208 @@
+"""Cascade over SEVERAL shared prefixes (one per radix-tree node).
+
+CPU: the planner (mem_cache.radix_cache.plan_shared_prefix_groups, from RadixCache.match_prefix nodes --
+srt/mem_cache/radix_cache.py:352-430) and the host half of ops.CascadeGroups.plan.  GPU: a batch with three shared
+prefixes of different depth plus requests that share nothing, through ops.CascadeGroups and through the backend, against
+the fp64 oracle of plain decode attention (decode_attention_fwd, kernels/ops/attention/decode_attention.py:820-912)."""
+import numpy as np
+import pytest
+import torch
+
+import parity_util as parity
+from oracle import radix_oracle as orc
+
+DEV = "cuda"
+
+
+def _bits(t):
+    if t.dtype == torch.bfloat16:
+        return t.detach().cpu().contiguous().view(torch.uint16).numpy()
+    return t.detach().cpu().numpy()
+
+
+def _tree_batch(rng, spec):
+    """spec: list of request token lists.  Inserts them into a RadixCache (slot = running counter) and returns the
+    cache, each request's last node and each request's slot row as the tree hands it out (shared prefixes share slots)."""
+    from sglang_amd.mem_cache.radix_cache import InsertParams, MatchPrefixParams, RadixCache, RadixKey
+
+    rc = RadixCache.create_simulated()
+    nodes, rows, slot = [], [], 1
+    for toks in spec:
+        m = rc.match_prefix(MatchPrefixParams(RadixKey(toks)))
+        have = m.device_indices.cpu().numpy().astype(np.int64)
+        own = np.arange(slot, slot + len(toks) - len(have), dtype=np.int64)
+        slot += len(own)
+        row = np.concatenate([have, own])
+        rc.insert(InsertParams(RadixKey(toks), torch.from_numpy(row)))
+        rows.append(row)
+    for toks in spec:  # nodes after all inserts: splits have happened by now
+        nodes.append(rc.match_prefix(MatchPrefixParams(RadixKey(toks))).last_device_node)
+    return rc, nodes, rows, slot
+
+
+def _spec(rng, sys_a=700, sys_b=400, doc=300):
+    A = rng.integers(0, 5000, sys_a).tolist()
+    B = rng.integers(0, 5000, sys_b).tolist()
+    D1, D2 = rng.integers(0, 5000, doc).tolist(), rng.integers(0, 5000, doc).tolist()
+    tail = lambda n: rng.integers(5000, 9000, n).tolist()  # noqa: E731
+    reqs = [A + D1 + tail(20 + i) for i in range(5)]        # 0-4: system prompt A + document 1
+    reqs += [A + D2 + tail(33 + i) for i in range(4)]       # 5-8: A + document 2
+    reqs += [B + tail(50 + 7 * i) for i in range(6)]        # 9-14: system prompt B
+    reqs += [tail(90), tail(260)]                           # 15, 16: nothing shared
+    return reqs
+
+
+def test_planner_picks_the_antichain_with_the_largest_saving():
+    from sglang_amd.mem_cache.radix_cache import plan_shared_prefix_groups
+
+    rng = np.random.default_rng(3)
+    reqs = _spec(rng)
+    _, nodes, rows, _ = _tree_batch(rng, reqs)
+    lens = [len(r) for r in reqs]
+    groups = plan_shared_prefix_groups(nodes, lens, min_shared=256, min_members=2)
+    # A's children win: 4 * 1000 + 3 * 1000 = 7000 rows saved against 8 * 700 = 5600 for A itself
+    assert groups == [(list(range(0, 5)), 1000), (list(range(5, 9)), 1000), (list(range(9, 15)), 400)]
+    for members, L in groups:  # the shared slots really are the same
+        for m in members:
+            assert np.array_equal(rows[m][:L], rows[members[0]][:L])
+    # a deeper threshold on members: document 2 (4 requests) no longer forms a group, A (9 requests) is better then
+    g5 = plan_shared_prefix_groups(nodes, lens, min_shared=256, min_members=5)
+    assert g5 == [(list(range(0, 9)), 700), (list(range(9, 15)), 400)]
+    # min_shared above B: only the documents remain
+    assert plan_shared_prefix_groups(nodes, lens, min_shared=512) == [(list(range(0, 5)), 1000), (list(range(5, 9)), 1000)]
+    assert plan_shared_prefix_groups(nodes[15:], lens[15:], min_shared=1) == []
+    assert plan_shared_prefix_groups([], None) == []
+
+
+def test_layout_tables_cover_every_group_prefix_once():
+    from sglang_amd.ops import CascadeGroups
+
+    groups = [([3, 4, 9], 1000), ([0, 7], 130), ([1, 2, 5, 6, 8, 10], 64)]
+    bs, hq = 12, 8
+    for cu, max_chunks in ((256, 16), (8, 16), (256, 3)):
+        lay = CascadeGroups.layout(groups, bs, hq, cu, max_chunks)
+        C, G, M = lay["C"], lay["G"], lay["M"]
+        assert G == 3 and M == 11 and 1 <= C <= max_chunks
+        kv, qo = lay["kv_indptr"], lay["qo_indptr"]
+        assert kv[0] == 0 and np.all(np.diff(kv) >= 0) and np.all(np.diff(qo) >= 0) and qo[-1] == C * M
+        starts = [0, 3, 5]
+        for g, (members, L) in enumerate(groups):
+            covered = []
+            for c in range(C):
+                p = c * G + g
+                n = kv[p + 1] - kv[p]
+                covered += list(range(lay["src_col"][p], lay["src_col"][p] + n))
+                assert qo[p] == c * M + starts[g] and qo[p + 1] - qo[p] == len(members)
+                assert lay["src_member"][p] == members[0]
+            assert covered == list(range(L))  # every shared token in exactly one chunk, in order
+        assert lay["kv_start"].tolist() == [130, 64, 64, 1000, 1000, 64, 64, 130, 64, 1000, 64, 0]
+        assert lay["extra_index"].tolist() == [3, 5, 6, 0, 1, 7, 8, 4, 9, 2, 10, -1]
+        assert lay["gather"].tolist() == [3, 4, 9, 0, 7, 1, 2, 5, 6, 8, 10] * C
+    with pytest.raises(ValueError):
+        CascadeGroups.layout([([0, 1], 10), ([1, 2], 10)], 4, 8, 256, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("geom", [(8, 2, 128), (16, 1, 128), (4, 4, 64)], ids=["d128_gqa4", "d128_mqa16", "d64_mha"])
+def test_three_prefix_batch_matches_plain_decode_oracle(dtype, geom):
+    from sglang_amd import ops
+    from sglang_amd.mem_cache.radix_cache import plan_shared_prefix_groups
+
+    hq, hkv, d = geom
+    rng = np.random.default_rng(11)
+    reqs = _spec(rng)
+    _, nodes, rows, nslots = _tree_batch(rng, reqs)
+    bs = len(reqs)
+    lens = np.asarray([len(r) for r in reqs], dtype=np.int64)
+    ctx = int(lens.max()) + 8
+    # slots -> pool rows: a random injective map (pages of `page` tokens keep their inner order, as a paged pool would)
+    perm = rng.permutation(nslots + 3)
+    r2t = np.zeros((bs + 2, ctx), dtype=np.int32)
+    order = rng.permutation(bs)  # batch order != tree order: groups are scattered over the batch
+    rpi = np.zeros(bs, dtype=np.int64)
+    for pos, i in enumerate(order):
+        r2t[pos + 1, : lens[i]] = perm[rows[i]]
+        rpi[pos] = pos + 1
+    lens_b = lens[order]
+    nodes_b = [nodes[i] for i in order]
+    groups = plan_shared_prefix_groups(nodes_b, lens_b.tolist(), min_shared=256, min_members=2)
+    assert len(groups) == 3 and sum(len(m) for m, _ in groups) == 15
+    pool = int(perm.max()) + 1
+    g = torch.Generator().manual_seed(5)
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    q = torch.randn(bs, hq, d, generator=g).to(dtype)
+    sm = d ** -0.5
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens_b)
+    want = orc.decode_attention(_bits(q), _bits(kb), _bits(vb), kv_indptr, kv_indices, sm)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
+    cg = ops.CascadeGroups(bs + 3, hq, hkv, d, dtype, DEV, max_shared_total=4096)
+    r2t_d, rpi_d, lens_d = T(r2t), T(rpi), T(lens_b)
+    outs = []
+    for gsel in (groups, groups[:1], []):  # three prefixes; one prefix that only part of the batch shares; none
+        cg.plan(r2t_d, rpi_d, lens_d, gsel)
+        o = torch.full((bs, hq, d), float("nan"), dtype=dtype, device=DEV)
+        cg(q.to(DEV), kb.to(DEV), vb.to(DEV), o, sm, page_size=1)
+        torch.cuda.synchronize()
+        got = o.float().cpu().numpy().astype(np.float64)
+        assert not np.isnan(got).any()
+        tol = 3e-3 if dtype == torch.float16 else 1.5e-2
+        parity.check(np.abs(got - want).max(), tol, (len(gsel), geom))
+        outs.append(got)
+    # requests in no group never see a partial: their rows are those of the plain decode kernel, bit for bit
+    loners = [pos for pos, i in enumerate(order) if i >= 15]
+    assert np.array_equal(outs[0][loners], outs[2][loners])
+    # the plan's tables
+    total = sum(L for _, L in groups)
+    cg.plan(r2t_d, rpi_d, lens_d, groups)
+    assert int(cg.kv_indptr[-1]) == total
+    ks = cg.kv_start.cpu().numpy()
+    for members, L in groups:
+        assert (ks[members] == L).all()
+    assert (ks[loners] == 0).all()
+
+
+@pytest.mark.gpu
+def test_backend_cascades_per_radix_node_when_the_scheduler_hands_the_nodes_over():
+    """HipRadixAttnBackend(cascade_decode=True) with forward_batch.radix_last_nodes: the same three-prefix batch, one
+    decode step with the KV store through the layer, against the oracle's torch-native semantics."""
+    from sglang_amd.attention.backend import HipRadixAttnBackend
+    from sglang_amd.forward_batch import ForwardBatch
+    from tests.test_gpu_backend import _Harness
+    from tests.test_gpu_cascade import _runner_of
+
+    hq, hkv, d = 8, 2, 128
+    rng = np.random.default_rng(21)
+    reqs = _spec(rng, sys_a=300, sys_b=200, doc=150)
+    _, nodes, rows_tree, _ = _tree_batch(rng, reqs)
+    bs = len(reqs)
+    hs = _Harness(1, hq, hkv, d, torch.bfloat16, "contiguous", "paged", max_ctx=1200, max_reqs=bs + 2)
+    hs.backend = HipRadixAttnBackend(_runner_of(hs), cascade_decode=True, cascade_min_bs=2, cascade_min_shared=128)
+    hs.backend.cascade_min_members = 2
+    rows = hs.r2t.alloc(bs)
+    # one pool slot per tree slot: requests that share tree slots share pool rows
+    n_tree = int(max(r.max() for r in rows_tree)) + 1
+    slots = hs.alloc.alloc(n_tree)
+    hs.pool.set_kv_buffer(hs.layer, slots, hs.rand(n_tree, hkv, d), hs.rand(n_tree, hkv, d))
+    prefix_lens = [len(r) for r in rows_tree]
+    for r, tr in zip(rows, rows_tree):
+        hs.r2t.req_to_token[r, : len(tr)] = slots[torch.from_numpy(tr).to(DEV)].to(torch.int32)
+    seq_lens = [p + 1 for p in prefix_lens]
+    seq_t = torch.tensor(seq_lens, dtype=torch.int64)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    loc = hs.alloc.alloc(bs)
+    hs.r2t.req_to_token[rpi, torch.tensor(prefix_lens, device=DEV)] = loc.to(torch.int32)
+    q, k, v = hs.rand(bs, hq * d), hs.rand(bs, hkv * d), hs.rand(bs, hkv * d)
+    fb = ForwardBatch.for_decode(rpi, seq_t.to(DEV), loc, seq_t)
+    fb.radix_last_nodes = nodes
+    hs.backend.init_forward_metadata(fb)
+    o = hs.layer(q, k, v, fb, hs.backend)
+    cg = hs.backend._cascade_groups
+    assert cg is not None and cg.num_groups == 3 and cg.members == 15
+    kb, vb = hs.pool.get_kv_buffer(0)
+    want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, d)), _bits(kb), _bits(vb), _bits(hs.r2t.req_to_token),
+                                        np.array(rows), np.array(seq_lens), d ** -0.5)
+    got = o.view(bs, hq, d).float().cpu().numpy().astype(np.float64)
+    assert hs.pool.check_errors() == 0
+    parity.check(np.abs(got - want).max(), 1.5e-2, None)
