@@ -79,7 +79,11 @@ __device__ __forceinline__ void mla_merge_if_last(const MlaArgs& a, int b, int q
 }
 
 constexpr int kMlaRowBytes = kMlaDk * 2;          // 1152
-constexpr int kMlaLdsRow = kMlaRowBytes + 16;     // 1168: padded LDS row stride
+// padded LDS row stride: TWO pad chunks.  ds_read_b128 is served in four non-contiguous 16-lane groups (MI355X_MICROARCH.md,
+// LDS) that mix rows 0-3 / 12-15 of k-group g with rows 4-11 of g + 1: with one pad chunk (1168 B, rounds 1-2) two of
+// them share a bank, and so do two rows of a transposed V read -- both took twice their cycles (SQ_LDS_BANK_CONFLICT
+// 0.29 of the LDS cycles); 1184 B is conflict-free for both.
+constexpr int kMlaLdsRow = kMlaRowBytes + 32;
 constexpr int kMlaChunks = kMlaRowBytes / 16;     // 72 16-byte chunks per row
 
 template <bool LINEAR>
@@ -491,6 +495,13 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
 // hipcc neither counts nor orders the asm DMA: every wait on it is written out below.
 constexpr int kM8Row = 592;                    // LDS row stride of the fp8 image
 constexpr int kM8Cpr = kM8Row / 16;            // 37 chunks per row (36 data + 1 pad)
+// Rows 16-31 of a tile image start kM8HalfShift bytes late.  A score fragment read (ds_read_b64, served per 32-lane
+// half) takes rows {0-3, 8-11, 16-19, 24-27} (+4 for the odd waves) at one column: 16 rows apart is 37 bank rows apart,
+// the same bank, and no row stride separates them (8 rows x an odd chunk count is 8 slots, x an even one 0) -- every
+// such read took twice its cycles (SQ_LDS_BANK_CONFLICT = 0.53 of SQ_LDS_IDX_ACTIVE).  Four chunks of offset move the
+// upper rows onto the eight 16-byte slots the lower ones leave free; the transposed V reads take 16 consecutive rows
+// of ONE half and do not notice.
+constexpr int kM8HalfShift = 64;
 constexpr int kM8Pieces = 20;                  // 1-KiB DMA pieces per tile buffer: 5 per wave (18.5 carry data)
 constexpr int kM8Buf = kM8Pieces * 1024;       // 20 KB
 #ifndef RX_M8_DBG
@@ -625,7 +636,10 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
   int prow[NP], pcol[NP];
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const int c = min((w + 4 * i) * 64 + lane, kMlaTile * kM8Cpr - 1);  // chunk of the padded image; the tail repeats the last
+    // chunk position of the padded image; rows 16-31 sit kM8HalfShift bytes further (see kM8HalfShift), the four
+    // positions in between re-read row 16's first chunk, the tail repeats the last chunk
+    const int pos = min((w + 4 * i) * 64 + lane, kMlaTile * kM8Cpr + kM8HalfShift / 16 - 1);
+    const int c = pos < 16 * kM8Cpr ? pos : max(pos - kM8HalfShift / 16, 16 * kM8Cpr);
     prow[i] = c / kM8Cpr;
     pcol[i] = 16 * min(c % kM8Cpr, kM8Cpr - 2);  // pad chunk: re-reads the row's last data chunk
   }
@@ -704,7 +718,7 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
     // ---- partial S^T of this wave: token block bb_w, k-steps [ks0, ks0 + 9)
     f32x4 sacc[2];
     {
-      const char* kb0 = kt + (8 * (r >> 2) + 4 * bb_w + (r & 3)) * kM8Row + 8 * g + 32 * ks0;
+      const char* kb0 = kt + (8 * (r >> 2) + 4 * bb_w + (r & 3)) * kM8Row + (r >= 8 ? kM8HalfShift : 0) + 8 * g + 32 * ks0;
       constexpr int PD = 4;
       u32x2 kf[KSW];
 #pragma unroll
@@ -772,7 +786,7 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
     MLA_STAMP(4);  // softmax
     // ---- O^T[128 w + ...] += V^T P^T: one transposed byte read per fragment (rows 8 g .. 8 g + 7), upcast, MFMA
     {
-      const char* vp = kt + (8 * g + (i16 >> 1)) * kM8Row + 128 * w + 8 * (i16 & 1);
+      const char* vp = kt + (8 * g + (i16 >> 1)) * kM8Row + (g >= 2 ? kM8HalfShift : 0) + 128 * w + 8 * (i16 & 1);
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) {
         auto lp = (__attribute__((address_space(3))) v2i_t*)(uintptr_t)(uint32_t)(uintptr_t)(vp + 16 * nb);

@@ -38,9 +38,11 @@
 namespace rx {
 
 constexpr int kXDk = 576, kXDv = 512, kXTT = 32;
-constexpr int kXCpr = kXDk * 2 / 16 + 1;        // 73 chunks per LDS row (72 data + 1 pad)
-constexpr int kXRow = kXCpr * 16;               // 1168 B: 9 (odd) chunks past a multiple of 256
-constexpr int kXPieces = 37;                    // 1-KiB DMA pieces per image (36.5 carry rows)
+// 74 chunks per LDS row (72 data + 2 pad): with ONE pad chunk (rounds 1-2) the non-contiguous 16-lane groups of
+// ds_read_b128 (MI355X_MICROARCH.md, LDS) and the 32-lane halves of the transposed V reads both put two rows on one bank
+constexpr int kXCpr = kXDk * 2 / 16 + 2;
+constexpr int kXRow = kXCpr * 16;               // 1184 B
+constexpr int kXPieces = (kXTT * kXCpr + 63) / 64;  // 37 1-KiB DMA pieces per image
 constexpr int kXImg = kXPieces * 1024;
 constexpr int kXRows = 128;                     // query rows per workgroup
 constexpr float kXSlack = 8.0f;                 // log2 units a row's max may run ahead of its reference
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
     for (int i = 0; i < NP; ++i) {
       const bool past = row >= kXTT;
       const int rw = past ? kXTT - 1 : row;
-      col16[i] = 16 * ((past || col == kXCpr - 1) ? kXCpr - 2 : col);
+      col16[i] = 16 * ((past || col >= kXCpr - 2) ? kXCpr - 3 : col);  // pad chunks re-read the row's last data chunk
       slot[i] = pre ? x_lds_read4(sl + 4 * rw) : max(min((t - nt1) * kXTT + rw, n_end_wg - 1), 0);
       row += 512 / kXCpr;
       col += 512 % kXCpr;
