@@ -851,7 +851,7 @@ def hetero_decode_bench(dev):
         al = torch.empty(bs, HQ, max(S, 1), D, dtype=torch.float32, device=dev)
         lse = torch.empty(bs, HQ, max(S, 1), dtype=torch.float32, device=dev)
         # items: the grid = the live (request, split) pairs, longest request first (rx_decode_params.split_items)
-        si = ops.SplitItems(int(ns.clamp_min(1).sum()), dev).build(ns, order) if items else None
+        si = ops.SplitItems(int(ns.clamp_min(1).sum()), dev).build(ns, order, wgs_per_cu=3 if items == 3 else 0) if items else None
 
         def run():
             if S == 1:
@@ -894,11 +894,17 @@ def hetero_decode_bench(dev):
     res = {"workload": "64 requests: one of 32768 tokens, 63 of 1024 (Hq 32 / Hkv 8 / D 128 bf16, page 16 shuffled, one layer)",
            "kv_bytes": byt}
     for name, ns, S, items in (("one_pass_per_request", None, 1, False), ("reference_formula_max8", k3, 8, False),
-                               ("length_aware_split_slots", old, r8(S_old), False), ("length_aware_native", bal, r8(S_bal), True)):
+                               ("length_aware_split_slots", old, r8(S_old), False),
+                               # graph replay / a step whose store rides in the decode launch: the pairs grid at the
+                               # kernel's usual two workgroups per CU, first-pass schedule
+                               ("length_aware_pairs_two_per_cu", old, r8(S_old), 2),
+                               # an eager step with its own store launch: mixed-batch schedule + the three-per-CU instance
+                               ("length_aware_native", bal, r8(S_bal), 3)):
         us = timed(ns, S, items)
         res[name] = {"us_per_layer": us, "TBps": byt / us / 1e6, "frac_of_hbm_peak": byt / us / 1e6 / 8.0,
                      "splits_of_the_long_request": 1 if ns is None else int(ns[0]),
-                     "grid": "live (request, split) pairs, longest first" if items else "bs x split slots"}
+                     "grid": (f"live (request, split) pairs, longest first, {items} workgroups per CU" if items
+                              else "bs x split slots")}
     return res
 
 

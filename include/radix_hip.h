@@ -266,6 +266,11 @@ typedef struct rx_decode_params {
   const int32_t* split_items;       /* int32[2 * split_items_cap], device */
   const int32_t* split_items_count; /* int32[1], device: live pairs */
   int32_t split_items_cap;
+  /* 0 / 2: the kernel's usual register budget (two workgroups per CU).  3: the three-per-CU instance (plain D = 128
+   * 16-bit kernel without k_new only; ignored elsewhere) -- for a MIXED batch whose schedule was made for 3 x CUs
+   * near-equal pieces (rx_num_kv_splits_balanced, wg_target_mixed), all resident at once.  A uniform batch is ~0.5 %
+   * faster at two, and a caller that cannot know (a captured graph replayed with new lengths) leaves it 0. */
+  int32_t split_items_wgs_per_cu;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);

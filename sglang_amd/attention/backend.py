@@ -466,7 +466,12 @@ class HipRadixAttnBackend:
         # a MIXED batch (some requests cut, some whole) runs on the live-pairs grid, whose kernel form holds three
         # workgroups per CU: its schedule aims at that many near-equal pieces (rx_num_kv_splits_balanced, wg_target_mixed)
         use_items = not self._is_mla_pool and not self._no_split_items
-        wg_mixed = self.device_core_count * 3 if use_items else 0
+        # ... when the launch can take that form: an eager step (a captured graph is replayed with other lengths and a
+        # uniform batch is faster at two per CU) whose store does not ride in the decode launch (the fused-store kernel has
+        # no three-per-CU instance: it spills there) -- foreign pools, fp8 / scaled stores
+        three = (use_items and not use_graph_bufs and fb.seq_lens_cpu is not None
+                 and (self._no_fused_store or not self._pool_allows_fused_store))
+        wg_mixed = self.device_core_count * 3 if three else 0
         host_pairs = None
         if not use_graph_bufs and fb.seq_lens_cpu is not None:
             host_counts = ops.balanced_kv_splits_host(fb.seq_lens_cpu.numpy()[:bs], self.num_head, self.num_kv_head, cap,
@@ -508,8 +513,9 @@ class HipRadixAttnBackend:
             if use_graph_bufs:
                 items = self._graph["split_items"].build(num_kv_splits, order, cap=self._split_pairs_bound(bs, S_cap))
             else:
+                mixed = three and bool((host_counts > 1).any() and (host_counts == 1).any())
                 items = ops.SplitItems(host_pairs if host_pairs is not None else bs * S_cap, self.device).build(
-                    num_kv_splits, order)
+                    num_kv_splits, order, wgs_per_cu=3 if mixed else 0)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S,
                                request_order=order, partial_pairs_hint=pairs, split_items=items)
 

@@ -69,6 +69,7 @@ struct DecodeArgs {
   // compacted (request, split) pairs of the split schedule (rx_split_items), or NULL: bs x max_kv_splits slots
   const int32_t* items;
   const int32_t* items_count;
+  int32_t items_occ3;  // the three-workgroups-per-CU instance asked for (split_items_wgs_per_cu == 3)
   int32_t items_cap;
 };
 
@@ -206,10 +207,11 @@ __device__ __forceinline__ u32x4 kv_frag16(V raw) {
 // KV store of the step (K1) without its own launch (a small-batch or TP-shard layer is 35-100 us, the store launch
 // ~5).  Only with ONE q block per kv head: then exactly one workgroup ever touches that row.
 //
-// OCC3: the register budget of THREE workgroups per CU (168 VGPRs: no spills in the plain D = 128 form, 7-14 dwords in
-// the fused-store one).  The split-items grid takes it: its schedule cuts the batch into ~3 x CUs near-equal
-// workgroups that are all resident at once, so nothing waits for a second round (one 32 k request among 63 of 1 k:
-// 87 us per layer at two per CU -> 76 at three); a uniform batch of one-pass requests is ~0.5 % faster at two.
+// OCC3: the register budget of THREE workgroups per CU (168 VGPRs: no spills in the plain D = 128 form; the fused-store
+// form spills 7-14 dwords there and runs 10 % slower, so it has no such instance).  A split-items grid asks for it
+// (rx_decode_params.split_items_wgs_per_cu) when its schedule cut a MIXED batch into ~3 x CUs near-equal workgroups that
+// are all resident at once, so nothing waits for a second round (one 32 k request among 63 of 1 k: 83 us per layer at
+// two per CU -> 78 at three); a uniform batch of one-pass requests is ~0.5 % faster at two.
 template <typename T, int D, typename IdxT, bool LINEAR, bool KV8, bool FUSE = false, bool OCC3 = false>
 __global__ __launch_bounds__(256, OCC3 ? 3 : RX_DEC_MINW) void decode_mfma_kernel(const DecodeArgs a) {
   static_assert(!(FUSE && KV8), "the fused store writes 16-bit rows");
@@ -789,9 +791,8 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
     if (grid == 0) return RX_OK;
 #define RX_DEC(DD, K8, FU) \
   hipLaunchKernelGGL((decode_mfma_kernel<T, DD, IdxT, LINEAR, K8, FU>), dim3(grid), dim3(256), 0, s, a)
-    if (a.items && dk == 128 && !a.kv_fp8) {  // the split-items schedule: three workgroups per CU (OCC3)
-      if (a.k_new) hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR, false, true, true>), dim3(grid), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR, false, false, true>), dim3(grid), dim3(256), 0, s, a);
+    if (a.items && a.items_occ3 && dk == 128 && !a.kv_fp8 && !a.k_new) {  // a mixed batch's schedule: three workgroups per CU
+      hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR, false, false, true>), dim3(grid), dim3(256), 0, s, a);
     } else if (a.kv_fp8) {
       if (dk == 64) RX_DEC(64, true, false);
       else RX_DEC(128, true, false);
@@ -974,6 +975,7 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   a.items = p->split_items;
   a.items_count = p->split_items_count;
   a.items_cap = p->split_items_cap;
+  a.items_occ3 = p->split_items_wgs_per_cu == 3 ? 1 : 0;
   if (a.items) {
     RX_REQUIRE(a.items_count && a.items_cap >= 0, "rx_decode_attn: split_items without its count / cap");
     RX_REQUIRE(p->num_kv_splits && p->max_kv_splits > 1, "rx_decode_attn: split_items go with a split schedule (num_kv_splits, max_kv_splits > 1)");

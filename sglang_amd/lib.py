@@ -58,6 +58,7 @@ class RxDecodeParams(C.Structure):
         ("k_new_stride_t", c_int64), ("k_new_stride_h", c_int64), ("v_new_stride_t", c_int64), ("v_new_stride_h", c_int64),
         ("request_order", c_void_p), ("partial_pairs_hint", c_int32),
         ("split_items", c_void_p), ("split_items_count", c_void_p), ("split_items_cap", c_int32),
+        ("split_items_wgs_per_cu", c_int32),
     ]
 
 

@@ -372,9 +372,13 @@ class SplitItems:
         self.items = torch.zeros(max(1, int(max_items)) * 2, dtype=torch.int32, device=device)
         self.count = torch.zeros(1, dtype=torch.int32, device=device)
         self.cap = 0
+        self.wgs_per_cu = 0
 
-    def build(self, num_kv_splits, request_order=None, cap: Optional[int] = None):
-        """num_kv_splits int32[bs] (device), request_order int32[bs] or None; cap defaults to the table's size."""
+    def build(self, num_kv_splits, request_order=None, cap: Optional[int] = None, wgs_per_cu: int = 0):
+        """num_kv_splits int32[bs] (device), request_order int32[bs] or None; cap defaults to the table's size.
+        wgs_per_cu = 3: the schedule was made for 3 x CUs pieces of a MIXED batch (get_num_kv_splits_balanced,
+        wg_target_mixed) -- the launch takes the kernel's three-per-CU instance (rx_decode_params.split_items_wgs_per_cu)."""
+        self.wgs_per_cu = int(wgs_per_cu)
         _require_cuda(num_kv_splits, request_order)
         bs = num_kv_splits.shape[0]
         if num_kv_splits.dtype != torch.int32 or (request_order is not None and request_order.dtype != torch.int32):
@@ -392,10 +396,10 @@ class SplitItems:
 
 def _set_split_items(p, split_items):
     if split_items is None:
-        p.split_items, p.split_items_count, p.split_items_cap = None, None, 0
+        p.split_items, p.split_items_count, p.split_items_cap, p.split_items_wgs_per_cu = None, None, 0, 0
     else:
         p.split_items, p.split_items_count = split_items.items.data_ptr(), split_items.count.data_ptr()
-        p.split_items_cap = int(split_items.cap)
+        p.split_items_cap, p.split_items_wgs_per_cu = int(split_items.cap), int(split_items.wgs_per_cu)
 
 
 def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,

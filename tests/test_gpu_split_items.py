@@ -64,7 +64,7 @@ def test_decode_with_split_items_is_bit_identical_to_split_slots(dtype, lookup):
     kbd, vbd, qd = kb.to(DEV), vb.to(DEV), q.to(DEV)
     ip, ii = orc.build_kv_indices(r2t, rpi, lens)
     outs = []
-    for items in (None, "exact", "upper"):
+    for items in (None, "exact", "upper", "three_per_cu"):
         o = torch.full((bs, hq, d), float("nan"), dtype=dtype, device=DEV)
         al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
         ls = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
@@ -72,7 +72,9 @@ def test_decode_with_split_items_is_bit_identical_to_split_slots(dtype, lookup):
         si = None
         if items:
             n_live = int(splits.clamp_min(1).sum())
-            si = ops.SplitItems(n_live if items == "exact" else bs * S, DEV).build(splits, order)
+            # "three_per_cu": the kernel's OCC3 instance (rx_decode_params.split_items_wgs_per_cu): same arithmetic
+            si = ops.SplitItems(n_live if items != "upper" else bs * S, DEV).build(
+                splits, order, wgs_per_cu=3 if items == "three_per_cu" else 0)
         if lookup == "paged":
             ops.decode_attention_fwd_paged(qd, kbd, vbd, o, torch.from_numpy(r2t).to(DEV), torch.from_numpy(rpi).to(DEV),
                                            lens_d, al, ls, splits, S, d ** -0.5, page_size=ps, merge_counters=cnt,
@@ -84,8 +86,8 @@ def test_decode_with_split_items_is_bit_identical_to_split_slots(dtype, lookup):
         torch.cuda.synchronize()
         assert int(cnt.abs().sum()) == 0            # the in-kernel merge left its counters at zero
         outs.append(o)
-    a, b, c = (x.view(torch.int16).cpu().numpy() for x in outs)
-    assert (a == b).all() and (a == c).all()
+    a, b, c, e = (x.view(torch.int16).cpu().numpy() for x in outs)
+    assert (a == b).all() and (a == c).all() and (a == e).all()
     live = lens > 0
     want = orc.decode_attention(q.view(torch.uint16).numpy() if dtype == torch.bfloat16 else q.numpy(),
                                 kb.view(torch.uint16).numpy() if dtype == torch.bfloat16 else kb.numpy(),

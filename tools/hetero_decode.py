@@ -20,7 +20,7 @@ def case(lens):
     byt=sum(lens)*HKV*D*2*2
     def t(ns, S, order=None, items=False):
         cnt=torch.zeros(bs*HQ,dtype=torch.int32,device=dev)
-        si=ops.SplitItems(int(ns.clamp_min(1).sum()),dev).build(ns,order) if items else None
+        si=ops.SplitItems(int(ns.clamp_min(1).sum()),dev).build(ns,order,wgs_per_cu=3 if items==3 else 0) if items else None
         al=torch.empty(bs,HQ,S,D,dtype=torch.float32,device=dev); lse=torch.empty(bs,HQ,S,device=dev)
         def f():
             if S==1: ops.decode_attention_fwd_paged(q,kb,vb,o,r2td,rpi,lens_d,None,None,None,1,D**-0.5,page_size=PS,kv_layout=lay,request_order=order)

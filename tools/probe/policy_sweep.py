@@ -25,7 +25,7 @@ def case(lens, name):
         S8=(S+7)//8*8
         ns=torch.from_numpy(hc).to(dev)
         cnt=torch.zeros(bs*HQ,dtype=torch.int32,device=dev)
-        si=ops.SplitItems(int(hc.sum()),dev).build(ns,order) if items else None
+        si=ops.SplitItems(int(hc.sum()),dev).build(ns,order,wgs_per_cu=3 if mixed else 0) if items else None
         al=torch.empty(bs,HQ,S8,D,dtype=torch.float32,device=dev); lse=torch.empty(bs,HQ,S8,device=dev)
         def f():
             ops.decode_attention_fwd_paged(q,kb,vb,o,r2td,rpi,lens_d,al,lse,ns,S8,D**-0.5,page_size=PS,kv_layout=lay,merge_counters=cnt,request_order=order,split_items=si)

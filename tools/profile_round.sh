@@ -26,6 +26,8 @@ cp $(find $OUT/mlaext -name "*_kernel_stats.csv" | head -1) $R/profiles/${TAG}_m
 # shared-prefix (cascade) decode: per-kernel times of the radix-hit batch (plain vs cascade, 4 layer buffers)
 rocprofv3 --kernel-trace --stats -d $OUT/casc -o casc --output-format csv -- python3 $R/tools/cascade_bench.py > $OUT/${TAG}_cascade_bench.txt 2> $OUT/casc.err
 cp $OUT/casc/casc_kernel_stats.csv $R/profiles/${TAG}_cascade_kernel_stats.csv 2>/dev/null
+# cascade over several shared prefixes (one per radix-tree node): plain vs ops.CascadeGroups
+(python3 $R/tools/cascade_groups_bench.py; GROUPS=8 PER=32 python3 $R/tools/cascade_groups_bench.py; GROUPS=3 PER=64 LONERS=64 python3 $R/tools/cascade_groups_bench.py) > $OUT/${TAG}_cascade_groups_bench.txt 2> $OUT/cascg.err
 cp $OUT/${TAG}_bench_default.json $OUT/${TAG}_bench_under_kernel_trace.json $R/gpurun_out/ 2>/dev/null
-mkdir -p $R/gpurun_out/profiles_new && cp $R/profiles/${TAG}_kernel_stats.csv $R/profiles/${TAG}_pmc_summary.json $R/profiles/${TAG}_cascade_kernel_stats.csv $R/profiles/${TAG}_mla_bf16_kernel_stats.csv $R/profiles/${TAG}_mla_fp8_kernel_stats.csv $R/profiles/${TAG}_mla_pmc_summary.json $OUT/${TAG}_cascade_bench.txt $OUT/mla16.txt $OUT/mla8.txt $R/profiles/${TAG}_mla_extend_kernel_stats.csv $OUT/${TAG}_mla_extend.txt $R/gpurun_out/profiles_new/ 2>/dev/null
+mkdir -p $R/gpurun_out/profiles_new && cp $R/profiles/${TAG}_kernel_stats.csv $R/profiles/${TAG}_pmc_summary.json $R/profiles/${TAG}_cascade_kernel_stats.csv $R/profiles/${TAG}_mla_bf16_kernel_stats.csv $R/profiles/${TAG}_mla_fp8_kernel_stats.csv $R/profiles/${TAG}_mla_pmc_summary.json $OUT/${TAG}_cascade_bench.txt $OUT/mla16.txt $OUT/mla8.txt $R/profiles/${TAG}_mla_extend_kernel_stats.csv $OUT/${TAG}_mla_extend.txt $OUT/${TAG}_cascade_groups_bench.txt $R/gpurun_out/profiles_new/ 2>/dev/null
 tail -c 1500 $OUT/${TAG}_bench_default.json
