@@ -21,6 +21,9 @@
 
 namespace rx {
 
+#ifndef RX_D256_FASTMASK
+#define RX_D256_FASTMASK 1  // dev A/B: 0 = mask every half tile
+#endif
 constexpr int kYTT = 64;
 constexpr int kYSlotBlock = 256;
 constexpr int kYRows = 256;                  // query rows per workgroup
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
     for (int hh = 0; hh < 2; ++hh) {
       const int n0 = tile_n0 + 32 * hh;
       if (n0 >= lim || n0 + 32 <= win_lo_w) continue;  // nothing visible to this wave in this half (wave-uniform)
+      const bool half_full = !windowed && n0 + 32 <= (prefix ? p_len : min(n_end_w, a.causal ? tok_lo_w + 1 : E));
       // ---- S^T = K Q^T: tokens 16 bb + 4 g + i of the half on the lane, query row r of block c
       f32x4 sacc[2][2];
 #pragma unroll
@@ -319,7 +323,9 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
 #pragma unroll
           for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * cs / a.logit_cap);
         }
-        {
+        // (a half that every row of the wave sees in full -- the whole prefix but its ragged end, the new tokens below
+        // the wave's first row -- takes no mask: 2 of its ~10 VALU per score; wave-uniform branch)
+        if (!RX_D256_FASTMASK || !half_full) {
           int lnm = lane;
           asm volatile("" : "+v"(lnm));
           const int32_t tk1 = row_tok(rbase + 16 * c + (lnm & 15)) + 1;
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
           psum += sv[j];
         }
         l_run[c] = l_run[c] * alpha + psum;
-        if (prefix && a.v_scale != 1.0f) {
+        if (EXTRAS && prefix && a.v_scale != 1.0f) {  // (a scaled V pool takes the EXTRAS instance)
 #pragma unroll
           for (int j = 0; j < 8; ++j) sv[j] *= a.v_scale;
         }
@@ -496,7 +502,7 @@ int launch_extend_d256(const rx_extend_params* p, hipStream_t s) {
   } while (0)
   const bool bf = p->dtype == RX_BF16;
   const int dk = p->head_dim, dv = p->v_head_dim;
-  const bool extras = a.window > 0 || a.logit_cap > 0.f;
+  const bool extras = a.window > 0 || a.logit_cap > 0.f || a.v_scale != 1.0f;
   if (bf) {
     if (extras) RX_D256_DIMS(BF16, true);
     else RX_D256_DIMS(BF16, false);
