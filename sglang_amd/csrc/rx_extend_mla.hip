@@ -156,6 +156,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   const int32_t row0 = mb * kXRows;
   if (row0 >= R) return;
   const int32_t rbase = row0 + 16 * w;
+  const int32_t tok_lo_w = rbase / a.hq;  // the wave's first query token (rows are (token, head) pairs)
   const bool active = rbase < R;
 
   vec8 qf[KS];
@@ -348,7 +349,8 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
         for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[bb][i];
-      {
+      // (a tile every row of the wave sees in full takes no mask -- wave-uniform branch; rx_extend_d256.hip)
+      if (n0 + kXTT > (prefix ? p_len : min(n_end_w, a.causal ? tok_lo_w + 1 : E))) {
         int lnm = lane;
         asm volatile("" : "+v"(lnm));
         const int32_t tk1 = row_tok(rbase + (lnm & 15)) + 1;
