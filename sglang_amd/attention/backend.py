@@ -201,6 +201,7 @@ class HipRadixAttnBackend:
         if os.environ.get("RX_NO_INKERNEL_MERGE"):  # dev A/B: stage 2 as its own launch
             self._merge_counters = None
         self._no_fused_store = bool(os.environ.get("RX_NO_FUSED_STORE"))  # dev A/B: the store as its own launch
+        self._graph_occ3 = os.environ.get("RX_GRAPH_OCC3", "0") == "1"  # graph-replayed steps on the three-per-CU kernel form
         self._no_split_items = bool(os.environ.get("RX_NO_SPLIT_ITEMS"))  # dev A/B: split slots instead of compacted pairs
         # RX_DEBUG_CHECKS=1: host-synchronising assertions of the backend's preconditions (see forward_decode)
         self._debug_checks = os.environ.get("RX_DEBUG_CHECKS", "0") not in ("", "0")
@@ -466,11 +467,10 @@ class HipRadixAttnBackend:
         # a MIXED batch (some requests cut, some whole) runs on the live-pairs grid, whose kernel form holds three
         # workgroups per CU: its schedule aims at that many near-equal pieces (rx_num_kv_splits_balanced, wg_target_mixed)
         use_items = not self._is_mla_pool and not self._no_split_items
-        # ... when the launch can take that form: an eager step (a captured graph is replayed with other lengths and a
-        # uniform batch is faster at two per CU) whose store does not ride in the decode launch (the fused-store kernel has
-        # no three-per-CU instance: it spills there) -- foreign pools, fp8 / scaled stores
-        three = (use_items and not use_graph_bufs and fb.seq_lens_cpu is not None
-                 and (self._no_fused_store or not self._pool_allows_fused_store))
+        # ... an eager step knows from the host copy of the lengths whether the batch is mixed; a captured graph is
+        # replayed with other lengths and cannot (RX_GRAPH_OCC3=1: it takes the three-per-CU form regardless -- a uniform
+        # batch is ~0.5 % faster at two)
+        three = use_items and ((not use_graph_bufs and fb.seq_lens_cpu is not None) or (use_graph_bufs and self._graph_occ3))
         wg_mixed = self.device_core_count * 3 if three else 0
         host_pairs = None
         if not use_graph_bufs and fb.seq_lens_cpu is not None:
@@ -511,7 +511,8 @@ class HipRadixAttnBackend:
         items = None
         if use_items:
             if use_graph_bufs:
-                items = self._graph["split_items"].build(num_kv_splits, order, cap=self._split_pairs_bound(bs, S_cap))
+                items = self._graph["split_items"].build(num_kv_splits, order, cap=self._split_pairs_bound(bs, S_cap),
+                                                         wgs_per_cu=3 if three else 0)
             else:
                 mixed = three and bool((host_counts > 1).any() and (host_counts == 1).any())
                 items = ops.SplitItems(host_pairs if host_pairs is not None else bs * S_cap, self.device).build(

@@ -364,12 +364,12 @@ __global__ __launch_bounds__(256, OCC3 ? 3 : RX_DEC_MINW) void decode_mfma_kerne
         if (lo + t * kTile + r >= hi - 1) {
           kp0 = reinterpret_cast<const KvE*>(knew);
           vp0 = reinterpret_cast<const KvE*>(vnew);
-          new_slot = s0;  // (clamped rows carry the same slot)
+          if constexpr (!OCC3) new_slot = s0;  // (clamped rows carry the same slot)
         }
         if (lo + t * kTile + 16 + r >= hi - 1) {
           kp1 = reinterpret_cast<const KvE*>(knew);
           vp1 = reinterpret_cast<const KvE*>(vnew);
-          new_slot = s1;
+          if constexpr (!OCC3) new_slot = s1;
         }
       }
     }
@@ -441,6 +441,9 @@ __global__ __launch_bounds__(256, OCC3 ? 3 : RX_DEC_MINW) void decode_mfma_kerne
         const int32_t tn = hi - 1 - (lo + t * kTile);  // row of the newest token in this tile
         if (r == (tn & 15)) {
           const int bb = tn >> 4;
+          // (three workgroups per CU: no register pair to carry the slot in -- read it again, one dependent load in ONE
+          // wave's last tile)
+          if constexpr (OCC3) new_slot = static_cast<int64_t>(idx[hi - 1]);
           KvE* kd = const_cast<KvE*>(kbase) + slot_offset<LINEAR>(new_slot, a.page_size, a.k_page_stride, a.k_tok_stride);
           KvE* vd = const_cast<KvE*>(vbase) + slot_offset<LINEAR>(new_slot, a.page_size, a.v_page_stride, a.v_tok_stride);
 #pragma unroll
@@ -791,8 +794,9 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
     if (grid == 0) return RX_OK;
 #define RX_DEC(DD, K8, FU) \
   hipLaunchKernelGGL((decode_mfma_kernel<T, DD, IdxT, LINEAR, K8, FU>), dim3(grid), dim3(256), 0, s, a)
-    if (a.items && a.items_occ3 && dk == 128 && !a.kv_fp8 && !a.k_new) {  // a mixed batch's schedule: three workgroups per CU
-      hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR, false, false, true>), dim3(grid), dim3(256), 0, s, a);
+    if (a.items && a.items_occ3 && dk == 128 && !a.kv_fp8) {  // a mixed batch's schedule: three workgroups per CU
+      if (a.k_new) hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR, false, true, true>), dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR, false, false, true>), dim3(grid), dim3(256), 0, s, a);
     } else if (a.kv_fp8) {
       if (dk == 64) RX_DEC(64, true, false);
       else RX_DEC(128, true, false);
