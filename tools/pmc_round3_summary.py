@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/pmc3 (tools/pmc_round3.sh) into profiles/r03_*_sq_counters.json: mean per launch of every counter
+of the named kernel + the derived fractions DESIGN.md quotes.  python tools/pmc_round3_summary.py [src] [dst]"""
+import collections, csv, glob, json, os, sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc3"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+
+
+def counters(prefix, sub):
+    acc = collections.defaultdict(list)
+    names = set()
+    for f in glob.glob(os.path.join(src, prefix + "_p*", "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if sub in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                names.add(r["Kernel_Name"])
+    return {k: sum(v) / len(v) for k, v in sorted(acc.items())}, sorted(names), {k: len(v) for k, v in acc.items()}
+
+
+def derived(c):
+    d = {}
+    if "GRBM_GUI_ACTIVE" in c:
+        cyc = c["GRBM_GUI_ACTIVE"] / 8
+        d["kernel_cycles_per_launch(GRBM_GUI_ACTIVE/8)"] = cyc
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+            d["mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (kernel_cycles * 1024 SIMDs)"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024)
+    if c.get("SQ_INSTS_MFMA"):
+        d["valu_per_mfma"] = c.get("SQ_INSTS_VALU", 0) / c["SQ_INSTS_MFMA"]
+        d["salu_per_mfma"] = c.get("SQ_INSTS_SALU", 0) / c["SQ_INSTS_MFMA"]
+        d["lds_insts_per_mfma"] = c.get("SQ_INSTS_LDS", 0) / c["SQ_INSTS_MFMA"]
+    if c.get("SQ_WAVE_CYCLES"):
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"):
+            if k in c:
+                d[k.lower() + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_frac_of_lds_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]
+    return d
+
+
+JOBS = [
+    ("r03_extend32_sq_counters.json", "ext32", "extend_mfma32_kernel", "python3 bench.py --extend-only (config-3 chunk, D = 128, the dispatched eight-wave kernel)"),
+    ("r03_extend_pw_sq_counters.json", "pw", "extend_pw_kernel", "RX_EXT_PW=2 python3 bench.py --extend-only (the one-wave-per-SIMD kernel, forced)"),
+    ("r03_extend_d256_sq_counters.json", "dims", "extend_d256_kernel<rx::BF16, 256", "DIMS=256x256,64x64,192x128 python3 tools/extend_dims.py (config-3 chunk at D = 256)"),
+    ("r03_extend_d64_sq_counters.json", "dims", "extend_mfma_kernel<rx::BF16, 64", "the same run, D = 64 (config 0's head dim)"),
+    ("r03_mla_decode_fp8_sq_counters.json", "mla8", "decode_mla8", "PS=64 FP8=1 python3 tools/mla_bench.py (config-5 shard shape, fp8 rows)"),
+    ("r03_mla_decode_bf16_sq_counters.json", "mla16", "decode_mla_kernel", "PS=64 python3 tools/mla_bench.py (16-bit rows)"),
+]
+for out, prefix, sub, what in JOBS:
+    c, names, n = counters(prefix, sub)
+    if not c:
+        print("no data for", out)
+        continue
+    json.dump({"source": "bash tools/pmc_round3.sh: two rocprofv3 --pmc passes of `" + what + "`, means per launch", "kernels": names,
+               "launches_per_counter": n, "counters": c, "derived": derived(c)}, open(os.path.join(dst, out), "w"), indent=1)
+    print(out, json.dumps(derived(c)))
