@@ -47,6 +47,12 @@
 #define RX_EXT32_STAMP 0  // 1: diagnostic build with s_memtime phase stamps (tools/ext_stamps.py); outputs are clobbered
 #endif
 
+#ifndef RX_EXT32_PADV
+#define RX_EXT32_PADV 0
+#endif
+#ifndef RX_EXT32_PADS
+#define RX_EXT32_PADS 0
+#endif
 namespace rx {
 
 struct Ext32Args {
@@ -843,6 +849,20 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       RX_STAMP(5);
       if (!late) __syncthreads();
       RX_STAMP(0);
+#if RX_EXT32_PADV  // dev probe: N independent VALU / SALU instructions per fast tile -- the cost of one more instruction
+      {
+        int pad_v = lane;
+#pragma unroll
+        for (int z = 0; z < RX_EXT32_PADV; ++z) asm volatile("v_mov_b32 %0, %0" : "+v"(pad_v));
+      }
+#endif
+#if RX_EXT32_PADS
+      {
+        int pad_s = w;
+#pragma unroll
+        for (int z = 0; z < RX_EXT32_PADS; ++z) asm volatile("s_mov_b32 %0, %0" : "+s"(pad_s));
+      }
+#endif
       const char* tile = smem + (t % RING) * kBufBytes;
       // ===== fast body: a hand-ordered wave-level software pipeline.  Measured before it: the tile's
       // phases (QK^T MFMAs, softmax VALU, PV MFMAs, staging) cost their SUM -- hipcc issues all MFMAs

@@ -21,6 +21,24 @@
 
 namespace rx {
 
+#ifndef RX_D256_PD
+#define RX_D256_PD 4    // K fragments read ahead of their MFMA
+#endif
+#ifndef RX_D256_NPRE
+#define RX_D256_NPRE 4  // V^T fragment pairs read ahead
+#endif
+#ifndef RX_D256_PADV
+#define RX_D256_PADV 0
+#endif
+#ifndef RX_D256_PADS
+#define RX_D256_PADS 0
+#endif
+#ifndef RX_D256_TBL
+#define RX_D256_TBL 1   // DMA issue from a per-tile row-pointer table in LDS (0: slot lookup + address math per piece)
+#endif
+#ifndef RX_D256_SV
+#define RX_D256_SV 1    // S^T accumulators pinned in VGPRs by asm MFMAs (0: the builtin, which lands them in AGPRs)
+#endif
 #ifndef RX_D256_FASTMASK
 #define RX_D256_FASTMASK 1  // dev A/B: 0 = mask every half tile
 #endif
@@ -46,7 +64,8 @@ struct YGeom {
   static constexpr int STAGE = KIMG + VIMG;
   static constexpr int SLOTS_AT = 2 * STAGE;
   static constexpr int BOUNCE_AT = SLOTS_AT + 2 * kYSlotBlock * 4;
-  static constexpr int LDS = BOUNCE_AT + 8 * 1024;  // 256 / 256: 151552 B
+  static constexpr int TBL_AT = BOUNCE_AT + 8 * 1024;  // row-pointer tables: 2 tiles x 64 rows x {K ptr, V ptr}
+  static constexpr int LDS = TBL_AT + 2 * kYTT * 16;   // 256 / 256: 151552 B
   static_assert(LDS <= 160 * 1024, "image geometry");
 };
 
@@ -87,6 +106,28 @@ template <typename T>
 __device__ __forceinline__ void y_pv_mfma(u32x4 a, u32x4 b, f32x4& c) {
   if constexpr (std::is_same_v<T, BF16>) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// S^T accumulators pinned in VGPRs (RX_D256_SV): left to itself hipcc puts the builtin's result in the AGPR half -- which
+// the 128 O^T accumulators fill -- and moves 16 of THEM out and back around every half tile's scores (104 v_accvgpr_read +
+// 72 v_accvgpr_write per tile and wave in the loop's ISA).  hipcc pads nothing around asm MFMAs: the four chains
+// (2 token blocks x 2 row blocks) are issued round robin, so a dependent MFMA follows its predecessor by four 8-pass
+// instructions, and the scores are read by VALU only behind y_scores_ready().
+template <typename T>
+__device__ __forceinline__ void y_qk_mfma0(u32x4 a, u32x4 b, f32x4& c) {
+  if constexpr (std::is_same_v<T, BF16>) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+}
+template <typename T>
+__device__ __forceinline__ void y_qk_mfma(u32x4 a, u32x4 b, f32x4& c) {
+  if constexpr (std::is_same_v<T, BF16>) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void y_scores_ready(f32x4 (&sacc)[2][2]) {
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");  // XDL write -> VALU read of an 8-pass result: 11 wait states
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(sacc[c][b]));
 }
 template <int N>
 __device__ __forceinline__ void y_settle(f32x4 (&o)[N]) {
@@ -231,6 +272,71 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+#if RX_D256_TBL
+  // ---- table-driven issue.  The ISA of the per-piece form above was a third of the loop's instruction stream (per
+  // piece: slot read + wait, page / token split, two 64-bit multiplies, ~12 VALU + 10 SALU + two branches), and this
+  // kernel pays ~5 cycles for EVERY instruction a wave issues (rx_extend_d256.hip header, round 3).  One wave per tile
+  // writes the 64 rows' K and V pointers to LDS two tiles ahead (lane = row); a piece is then: its (row, column) by
+  // three adds, one ds_read_b64, one 64-bit add, the DMA.
+  constexpr int kYTblAt = Y::TBL_AT;
+  auto build_table = [&](int u) {  // wave u & 7, lane = row of tile u
+    if (w != (u & 7)) return;
+    const uint32_t dst = smem_u + kYTblAt + ((u & 1) * kYTT + lane) * 16;
+    const char* kp;
+    const char* vp;
+    if (u < nt1) {
+      const uint32_t sl = smem_u + kYSlotsAt + 4 * (((u * kYTT / kYSlotBlock) & 1) * kYSlotBlock + (u * kYTT) % kYSlotBlock + lane);
+      const uint32_t slot = static_cast<uint32_t>(y_lds_read4(sl));
+      const uint32_t lo = sh_p == 31 ? slot : (slot & ((1u << sh_p) - 1u));
+      uint64_t ko = static_cast<uint64_t>(lo) * (2u * static_cast<uint32_t>(a.k_tok_stride));
+      uint64_t vo = static_cast<uint64_t>(lo) * (2u * static_cast<uint32_t>(a.v_tok_stride));
+      if (sh_p != 31) {
+        ko += static_cast<uint64_t>(slot >> sh_p) * (2u * static_cast<uint32_t>(a.k_page_stride));
+        vo += static_cast<uint64_t>(slot >> sh_p) * (2u * static_cast<uint32_t>(a.v_page_stride));
+      }
+      kp = kbuf_b + ko;
+      vp = vbuf_b + vo;
+    } else {
+      const uint32_t n = static_cast<uint32_t>(max(min((u - nt1) * kYTT + lane, n_end_wg - 1), 0));
+      kp = kext_b + static_cast<uint64_t>(n) * (2u * static_cast<uint32_t>(a.k_stride_t));
+      vp = vext_b + static_cast<uint64_t>(n) * (2u * static_cast<uint32_t>(a.v_stride_t));
+    }
+    const uint64_t k64 = reinterpret_cast<uint64_t>(kp), v64 = reinterpret_cast<uint64_t>(vp);
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(dst) =
+        u32x4{static_cast<uint32_t>(k64), static_cast<uint32_t>(k64 >> 32), static_cast<uint32_t>(v64), static_cast<uint32_t>(v64 >> 32)};
+  };
+  auto dma_image_tbl = [&](int t, auto cpr_c, auto np_c, auto data_c, bool vside) {
+    constexpr int CPR = decltype(cpr_c)::value, NPIECES = decltype(np_c)::value, DATA = decltype(data_c)::value;
+    constexpr int NP = (NPIECES + 7) / 8;
+    const uint32_t tb = smem_u + kYTblAt + (t & 1) * (kYTT * 16) + (vside ? 8 : 0);
+    const uint32_t img = smem_u + (t & 1) * kYStage + (vside ? kYKimg : 0);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int c0 = 64 * w + ln;  // chunk of the padded image held by this lane in piece w; piece w + 8 i is 512 i further
+    int row = c0 / CPR, col = c0 - row * CPR;
+    typedef __attribute__((address_space(3))) const u32x2* lds_u32x2;
+    u32x2 ptr[NP];
+    uint32_t c16[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      ptr[i] = *reinterpret_cast<lds_u32x2>(tb + 16 * min(row, kYTT - 1));  // (the last piece's tail repeats row 63)
+      c16[i] = 16u * static_cast<uint32_t>(min(col, DATA - 1));             // pad chunks re-read the row's last data chunk
+      row += 512 / CPR;
+      col += 512 % CPR;
+      if (col >= CPR) {
+        col -= CPR;
+        row += 1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (w + 8 * i < NPIECES) {  // wave-uniform
+        const uint64_t src = (static_cast<uint64_t>(ptr[i][1]) << 32 | ptr[i][0]) + c16[i];
+        y_dma16(reinterpret_cast<const void*>(src), __builtin_amdgcn_readfirstlane(img + (w + 8 * i) * 1024));
+      }
+    }
+  };
+#endif
   using KC = std::integral_constant<int, kYKc>;
   using VC = std::integral_constant<int, kYVc>;
   using KP = std::integral_constant<int, kYKpieces>;
@@ -238,9 +344,19 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   using KD = std::integral_constant<int, Y::KCPR>;
   using VD = std::integral_constant<int, Y::VCPR>;
   auto dma_tile = [&](int t) {
+#if RX_D256_TBL
+    dma_image_tbl(t, KC{}, KP{}, KD{}, false);
+    dma_image_tbl(t, VC{}, VP{}, VD{}, true);
+#else
     dma_image(t, KC{}, KP{}, KD{}, false);
     dma_image(t, VC{}, VP{}, VD{}, true);
+#endif
   };
+#if RX_D256_TBL
+  if (t_begin < nt) build_table(t_begin);
+  if (t_begin + 1 < nt) build_table(t_begin + 1);
+  __syncthreads();  // the first two tables are readable
+#endif
   if (t_begin < nt) dma_tile(t_begin);
 
   f32x4 oacc[2][NB];
@@ -257,12 +373,17 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   const uint32_t k_lane = r * kYKrow + g * 16;
   const uint32_t v_lane = (4 * g + qd) * kYVrow + 8 * (pp & 1) + (pp >> 1) * 16;
   const uint32_t bounce = smem_u + kYBounceAt + (w * 64 + lane) * 16;  // this lane's 16 bytes of the rescale bounce
+  int pad_v = lane, pad_s = w;
+  (void)pad_v; (void)pad_s;
   const bool late = w >= 4;  // the SIMD partner of an early wave: issues its pieces behind its first QK^T
 
   for (int t = t_begin; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
     __syncthreads();                                   // everybody's have; everybody is done with tile t - 1
     if (t % TPB == 0 && (t / TPB + 1) * kYSlotBlock < nt1 * kYTT) stage_slots(t / TPB + 1);
+#if RX_D256_TBL
+    if (t + 2 < nt) build_table(t + 2);  // read by tile t + 2's issue, which runs behind the next barrier
+#endif
     const bool more = t + 1 < nt;
     if (more && !late) dma_tile(t + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -276,6 +397,14 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
       if (late_pending) dma_tile(t + 1);
       continue;
     }
+#if RX_D256_PADV  // dev probe: N independent VALU / SALU instructions per tile -- what does one more instruction cost?
+#pragma unroll
+    for (int z = 0; z < RX_D256_PADV; ++z) asm volatile("v_mov_b32 %0, %0" : "+v"(pad_v));
+#endif
+#if RX_D256_PADS
+#pragma unroll
+    for (int z = 0; z < RX_D256_PADS; ++z) asm volatile("s_mov_b32 %0, %0" : "+s"(pad_s));
+#endif
     const uint32_t kt = smem_u + (t & 1) * kYStage;
     const uint32_t vt = kt + kYKimg;
     const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
@@ -287,10 +416,33 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
       const bool half_full = !windowed && n0 + 32 <= (prefix ? p_len : min(n_end_w, a.causal ? tok_lo_w + 1 : E));
       // ---- S^T = K Q^T: tokens 16 bb + 4 g + i of the half on the lane, query row r of block c
       f32x4 sacc[2][2];
+#if RX_D256_SV
+      {
+        // i = 2 s + blk: token blocks alternate, so the four accumulator chains are issued round robin
+        constexpr int PD = RX_D256_PD;
+        const uint32_t krow = kt + k_lane + 32 * hh * kYKrow;
+        auto kfrag = [&](int i) { return y_lds_read16(krow + (i & 1) * 16 * kYKrow + (i >> 1) * 64); };
+        u32x4 kf[PD];
+#pragma unroll
+        for (int i = 0; i < PD; ++i) kf[i] = kfrag(i);
+#pragma unroll
+        for (int i = 0; i < 2 * KS; ++i) {
+          const u32x4 ka = kf[i % PD];
+          if (i + PD < 2 * KS) kf[i % PD] = kfrag(i + PD);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            if (i < 2) y_qk_mfma0<T>(ka, __builtin_bit_cast(u32x4, qf[c][0]), sacc[c][i & 1]);
+            else y_qk_mfma<T>(ka, __builtin_bit_cast(u32x4, qf[c][i >> 1]), sacc[c][i & 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // source order is the pipeline
+        }
+        y_scores_ready(sacc);
+      }
+#else
 #pragma unroll
       for (int c = 0; c < 2; ++c) sacc[c][0] = sacc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       {
-        constexpr int PD = 4;
+        constexpr int PD = RX_D256_PD;
         const uint32_t krow = kt + k_lane + 32 * hh * kYKrow;
         auto kfrag = [&](int i) { return y_lds_read16(krow + (i / KS) * 16 * kYKrow + (i % KS) * 64); };
         u32x4 kf[PD];
@@ -305,6 +457,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
           __builtin_amdgcn_sched_barrier(0);  // source order is the pipeline
         }
       }
+#endif
       if (hh == 0 && late_pending) {
         dma_tile(t + 1);
         late_pending = false;
@@ -389,7 +542,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
       // ---- O^T += V^T P^T
       const uint32_t rp0 = vt + v_lane + 32 * hh * kYVrow;
       const uint32_t rp1 = rp0 + 16 * kYVrow;
-      constexpr int NPRE = 4;
+      constexpr int NPRE = RX_D256_NPRE;
       u32x2 vlo[NPRE], vhi[NPRE];
 #pragma unroll
       for (int nb = 0; nb < NPRE; ++nb) {
