@@ -65,7 +65,9 @@ struct YGeom {
   static constexpr int SLOTS_AT = 2 * STAGE;
   static constexpr int BOUNCE_AT = SLOTS_AT + 2 * kYSlotBlock * 4;
   static constexpr int TBL_AT = BOUNCE_AT + 8 * 1024;  // row-pointer tables: 2 tiles x 64 rows x {K ptr, V ptr}
-  static constexpr int LDS = TBL_AT + 2 * kYTT * 16;   // 256 / 256: 151552 B
+  static constexpr int GEO_AT = TBL_AT + 2 * kYTT * 16;  // per-thread piece geometry (loop invariant), one dword per piece
+  static constexpr int GEO_N = (KPIECES + 7) / 8 + ((KC == VC && KCPR == VCPR) ? 0 : (VPIECES + 7) / 8);
+  static constexpr int LDS = GEO_AT + GEO_N * 512 * 4;  // 256 / 256: 161792 B
   static_assert(LDS <= 160 * 1024, "image geometry");
 };
 
@@ -305,22 +307,18 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
     *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(dst) =
         u32x4{static_cast<uint32_t>(k64), static_cast<uint32_t>(k64 >> 32), static_cast<uint32_t>(v64), static_cast<uint32_t>(v64 >> 32)};
   };
-  auto dma_image_tbl = [&](int t, auto cpr_c, auto np_c, auto data_c, bool vside) {
-    constexpr int CPR = decltype(cpr_c)::value, NPIECES = decltype(np_c)::value, DATA = decltype(data_c)::value;
-    constexpr int NP = (NPIECES + 7) / 8;
-    const uint32_t tb = smem_u + kYTblAt + (t & 1) * (kYTT * 16) + (vside ? 8 : 0);
-    const uint32_t img = smem_u + (t & 1) * kYStage + (vside ? kYKimg : 0);
+  // a lane's chunk positions are loop invariant: piece w + 8 i holds chunk 64 w + lane + 512 i of the padded image; its
+  // (row * 16 | column * 16 << 16) is computed once per image geometry and kept in registers (RX_D256_GEO)
+  auto piece_geo = [&](auto cpr_c, auto np_c, auto data_c, uint32_t (&geo)[(decltype(np_c)::value + 7) / 8]) {
+    constexpr int CPR = decltype(cpr_c)::value, NP = (decltype(np_c)::value + 7) / 8, DATA = decltype(data_c)::value;
     int ln = lane;
     asm volatile("" : "+v"(ln));
-    const int c0 = 64 * w + ln;  // chunk of the padded image held by this lane in piece w; piece w + 8 i is 512 i further
+    const int c0 = 64 * w + ln;
     int row = c0 / CPR, col = c0 - row * CPR;
-    typedef __attribute__((address_space(3))) const u32x2* lds_u32x2;
-    u32x2 ptr[NP];
-    uint32_t c16[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      ptr[i] = *reinterpret_cast<lds_u32x2>(tb + 16 * min(row, kYTT - 1));  // (the last piece's tail repeats row 63)
-      c16[i] = 16u * static_cast<uint32_t>(min(col, DATA - 1));             // pad chunks re-read the row's last data chunk
+      // (the last piece's tail repeats row 63; pad chunks re-read the row's last data chunk)
+      geo[i] = 16u * static_cast<uint32_t>(min(row, kYTT - 1)) | (16u * static_cast<uint32_t>(min(col, DATA - 1))) << 16;
       row += 512 / CPR;
       col += 512 % CPR;
       if (col >= CPR) {
@@ -328,12 +326,58 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
         row += 1;
       }
     }
+  };
+  // ... and kept in LDS (kNPK [+ kNPV] dwords per thread): in registers they cost the 256 / 256 instance four Q fragments
+  // (32 spilled dwords, eight scratch reloads per tile)
+  constexpr int kNPK = (kYKpieces + 7) / 8, kNPV = (kYVpieces + 7) / 8;
+  constexpr bool kSameGeo = (kYKc == kYVc) && (Y::KCPR == Y::VCPR);
+  constexpr int kYGeoAt = Y::GEO_AT;
+  {
+    uint32_t geo_k[kNPK];
+    piece_geo(std::integral_constant<int, kYKc>{}, std::integral_constant<int, kYKpieces>{},
+              std::integral_constant<int, Y::KCPR>{}, geo_k);
+#pragma unroll
+    for (int i = 0; i < kNPK; ++i)
+      *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(smem_u + kYGeoAt + (i * 512 + tid) * 4) = geo_k[i];
+    if constexpr (!kSameGeo) {
+      uint32_t geo_v[kNPV];
+      piece_geo(std::integral_constant<int, kYVc>{}, std::integral_constant<int, kYVpieces>{},
+                std::integral_constant<int, Y::VCPR>{}, geo_v);
+#pragma unroll
+      for (int i = 0; i < kNPV; ++i)
+        *reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(smem_u + kYGeoAt + ((kNPK + i) * 512 + tid) * 4) = geo_v[i];
+    }
+  }  // (read back by the same thread only: no barrier needed, the LDS queue is in order per wave)
+  typedef __attribute__((address_space(3))) const u32x2* lds_u32x2;
+  typedef __attribute__((address_space(3))) const uint32_t* lds_u32;
+  auto issue_pieces = [&](int t, auto np_c, const uint32_t (&geo)[(decltype(np_c)::value + 7) / 8], bool vside) {
+    constexpr int NPIECES = decltype(np_c)::value;
+    constexpr int NP = (NPIECES + 7) / 8;
+    const uint32_t tb = smem_u + kYTblAt + (t & 1) * (kYTT * 16) + (vside ? 8 : 0);  // 1 KiB aligned (+8): OR-able
+    const uint32_t img = smem_u + (t & 1) * kYStage + (vside ? kYKimg : 0);
+    u32x2 ptr[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) ptr[i] = *reinterpret_cast<lds_u32x2>(tb | (geo[i] & 0xffffu));
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       if (w + 8 * i < NPIECES) {  // wave-uniform
-        const uint64_t src = (static_cast<uint64_t>(ptr[i][1]) << 32 | ptr[i][0]) + c16[i];
+        const uint64_t src = (static_cast<uint64_t>(ptr[i][1]) << 32 | ptr[i][0]) + (geo[i] >> 16);
         y_dma16(reinterpret_cast<const void*>(src), __builtin_amdgcn_readfirstlane(img + (w + 8 * i) * 1024));
       }
+    }
+  };
+  auto dma_tile_tbl = [&](int t) {
+    uint32_t gk[kNPK];
+#pragma unroll
+    for (int i = 0; i < kNPK; ++i) gk[i] = *reinterpret_cast<lds_u32>(smem_u + kYGeoAt + (i * 512 + tid) * 4);
+    issue_pieces(t, std::integral_constant<int, kYKpieces>{}, gk, false);
+    if constexpr (kSameGeo) {
+      issue_pieces(t, std::integral_constant<int, kYVpieces>{}, gk, true);
+    } else {
+      uint32_t gv[kNPV];
+#pragma unroll
+      for (int i = 0; i < kNPV; ++i) gv[i] = *reinterpret_cast<lds_u32>(smem_u + kYGeoAt + ((kNPK + i) * 512 + tid) * 4);
+      issue_pieces(t, std::integral_constant<int, kYVpieces>{}, gv, true);
     }
   };
 #endif
@@ -345,8 +389,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   using VD = std::integral_constant<int, Y::VCPR>;
   auto dma_tile = [&](int t) {
 #if RX_D256_TBL
-    dma_image_tbl(t, KC{}, KP{}, KD{}, false);
-    dma_image_tbl(t, VC{}, VP{}, VD{}, true);
+    dma_tile_tbl(t);
 #else
     dma_image(t, KC{}, KP{}, KD{}, false);
     dma_image(t, VC{}, VP{}, VD{}, true);
