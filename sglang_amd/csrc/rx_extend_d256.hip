@@ -469,14 +469,23 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
 #pragma unroll
         for (int i = 0; i < PD; ++i) kf[i] = kfrag(i);
 #pragma unroll
-        for (int i = 0; i < 2 * KS; ++i) {
-          const u32x4 ka = kf[i % PD];
-          if (i + PD < 2 * KS) kf[i % PD] = kfrag(i + PD);
+        for (int i2 = 0; i2 < 2 * KS; i2 += 2) {
+          // fragments in pairs, the LATER one first: LDS returns in order, so its s_waitcnt covers both -- one wait
+          // instruction per two fragments (every instruction is ~5 cycles here; the two token blocks are different
+          // accumulators, so the sums are unchanged)
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            if (i < 2) y_qk_mfma0<T>(ka, __builtin_bit_cast(u32x4, qf[c][0]), sacc[c][i & 1]);
-            else y_qk_mfma<T>(ka, __builtin_bit_cast(u32x4, qf[c][i >> 1]), sacc[c][i & 1]);
+          for (int j = 1; j >= 0; --j) {
+            const int i = i2 + j;
+            const u32x4 ka = kf[i % PD];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              if (i < 2) y_qk_mfma0<T>(ka, __builtin_bit_cast(u32x4, qf[c][0]), sacc[c][i & 1]);
+              else y_qk_mfma<T>(ka, __builtin_bit_cast(u32x4, qf[c][i >> 1]), sacc[c][i & 1]);
+            }
           }
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (i2 + j + PD < 2 * KS) kf[(i2 + j) % PD] = kfrag(i2 + j + PD);
           __builtin_amdgcn_sched_barrier(0);  // source order is the pipeline
         }
         y_scores_ready(sacc);
@@ -593,15 +602,23 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
         vhi[nb] = T::ds_read_tr((const void*)(uintptr_t)(rp1 + nb * 32));
       }
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const u32x2 lo = vlo[nb % NPRE], hi = vhi[nb % NPRE];
-        if (nb + NPRE < NB) {
-          vlo[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp0 + (nb + NPRE) * 32));
-          vhi[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp1 + (nb + NPRE) * 32));
-        }
-        const u32x4 av = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      for (int nb2 = 0; nb2 < NB; nb2 += 2) {  // (d blocks in pairs, the later pair of reads first: see the K fragments)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) y_pv_mfma<T>(av, pf[c], oacc[c][nb]);
+        for (int j = 1; j >= 0; --j) {
+          const int nb = nb2 + j;
+          const u32x2 lo = vlo[nb % NPRE], hi = vhi[nb % NPRE];
+          const u32x4 av = u32x4{lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+          for (int c = 0; c < 2; ++c) y_pv_mfma<T>(av, pf[c], oacc[c][nb]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int nb = nb2 + j;
+          if (nb + NPRE < NB) {
+            vlo[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp0 + (nb + NPRE) * 32));
+            vhi[nb % NPRE] = T::ds_read_tr((const void*)(uintptr_t)(rp1 + (nb + NPRE) * 32));
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
