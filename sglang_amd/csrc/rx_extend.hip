@@ -50,7 +50,7 @@ struct ExtendArgs {
 #ifndef RX_EXT_CB
 #define RX_EXT_CB 2
 #endif
-constexpr int kQPerWave = 16 * RX_EXT_CB;
+constexpr int kQPerWaveDefault = 16 * RX_EXT_CB;
 
 template <int D>
 __device__ __forceinline__ int v_swz(int row) {
@@ -88,12 +88,15 @@ constexpr int kTT = RX_EXT_TT;  // tokens per LDS tile
 #ifndef RX_EXT_MINW
 #define RX_EXT_MINW 2
 #endif
-constexpr int kCB = RX_EXT_CB;
 
 // PLAIN: no sliding window and no logit cap in this instance (their scalars and branches cost a plain call several per
 // cent even when both are off); picked by the launcher
-template <typename T, int D, typename IdxT, bool LINEAR, bool VSCALE, bool PLAIN = false>
+// CB: 16-query blocks per wave.  4 (64 queries per wave, 256 per workgroup) for long D = 64 extends: a staged tile and every
+// K / V^T fragment read then feed twice the MFMAs, and at 256 FLOP per score this kernel's time is its instruction count
+// (DESIGN 4.2, round 3); the 64 accumulator registers of D = 64 leave room for it.
+template <typename T, int D, typename IdxT, bool LINEAR, bool VSCALE, bool PLAIN = false, int CB = RX_EXT_CB>
 __global__ __launch_bounds__(256, RX_EXT_MINW) void extend_mfma_kernel(const ExtendArgs a0) {
+  constexpr int kCB = CB, kQPerWave = 16 * CB;
   ExtendArgs a = a0;
   if constexpr (PLAIN) {
     a.window = 0;
@@ -531,7 +534,13 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
     const bool vs = a.v_scale != 1.0f;
     const bool plain = a.window <= 0 && a.logit_cap <= 0.f;
     if (dk == 64) {
-      if (plain) {
+      if (plain && !vs && a.mblocks >= 4 && RX_EXT_CB == 2) {  // (>= 4 blocks of 128 rows: extends past 384 tokens)
+        // long extends: 64 queries per wave (a.mblocks counts 128-row blocks: two of them per workgroup)
+        ExtendArgs b = a;
+        b.mblocks = (a.mblocks + 1) / 2;
+        const unsigned grid4 = static_cast<unsigned>(b.bs) * b.hq * b.mblocks;
+        hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, false, true, 4>), dim3(grid4), dim3(256), 0, s, b);
+      } else if (plain) {
         if (vs) hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, true, true>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, false, true>), dim3(grid), dim3(256), 0, s, a);
       } else {
@@ -689,7 +698,7 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   a.hq = p->num_q_heads;
   a.hkv = p->num_kv_heads;
   a.group = p->num_q_heads / p->num_kv_heads;
-  a.mblocks = (p->max_extend_len + 4 * kQPerWave - 1) / (4 * kQPerWave);
+  a.mblocks = (p->max_extend_len + 4 * kQPerWaveDefault - 1) / (4 * kQPerWaveDefault);
   a.sm_scale = p->sm_scale;
   a.k_scale = p->k_scale;
   a.v_scale = p->v_scale;
