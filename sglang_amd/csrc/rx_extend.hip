@@ -78,6 +78,10 @@ __device__ __forceinline__ int64_t slot_off(int64_t slot, int32_t page_size, int
 #define RX_EXT_TT 64
 #endif
 constexpr int kTT = RX_EXT_TT;  // tokens per LDS tile
+#ifndef RX_EXT_MAX_SLACK
+#define RX_EXT_MAX_SLACK 8.0f  // log2 units (0: the plain running max)
+#endif
+constexpr float kExtMaxSlack = RX_EXT_MAX_SLACK;
 
 #ifndef RX_EXT_CB
 #define RX_EXT_CB 2  // 16-query N blocks per wave (2 -> 32 queries / wave, 128 / workgroup)
@@ -330,7 +334,10 @@ __global__ __launch_bounds__(256, RX_EXT_MINW) void extend_mfma_kernel(const Ext
           mt *= c2;  // c2 > 0: max commutes with the scale
           // fully masked row so far: keep the max finite (extend_attention.py:474-475)
           const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
-          const float m_new = fmaxf(m_run[c], mt_fixed);
+          // thresholded running max (rx_extend32.hip): the reference max moves only when the tile's exceeds it by more
+          // than 2^8 -- exact algebra (l uses the same m; exp2 reaches 2^8 at most, inside fp32 sums and 16-bit P) -- so
+          // the O^T rescale below runs on the first tile and almost never again instead of on ~70 % of the tiles
+          const float m_new = (mt_fixed > m_run[c] + kExtMaxSlack) ? mt_fixed : m_run[c];
           const float alpha = fast_exp2(m_run[c] - m_new);
           m_run[c] = m_new;
           float psum = 0.f;
