@@ -889,17 +889,21 @@ def hetero_decode_bench(dev):
     S_bal = int(ops.balanced_kv_splits_host(lens, HQ, HKV, 64, 512, 1024, 768).max())
     bal = torch.zeros(bs, dtype=torch.int32, device=dev)
     ops.get_num_kv_splits_balanced(bal, lens_d, HQ, HKV, S_bal, 512, 1024, 768)
+    S_rr = int(ops.balanced_kv_splits_host(lens, HQ, HKV, 64, 512, 1024, -1).max())
+    rr = torch.zeros(bs, dtype=torch.int32, device=dev)
+    ops.get_num_kv_splits_balanced(rr, lens_d, HQ, HKV, S_rr, 512, 1024, -1)
     r8 = lambda x: (x + 7) // 8 * 8
     byt = sum(lens) * HKV * D * 2 * 2
     res = {"workload": "64 requests: one of 32768 tokens, 63 of 1024 (Hq 32 / Hkv 8 / D 128 bf16, page 16 shuffled, one layer)",
            "kv_bytes": byt}
     for name, ns, S, items in (("one_pass_per_request", None, 1, False), ("reference_formula_max8", k3, 8, False),
                                ("length_aware_split_slots", old, r8(S_old), False),
-                               # graph replay / a step whose store rides in the decode launch: the pairs grid at the
-                               # kernel's usual two workgroups per CU, first-pass schedule
-                               ("length_aware_pairs_two_per_cu", old, r8(S_old), 2),
-                               # an eager step with its own store launch: mixed-batch schedule + the three-per-CU instance
-                               ("length_aware_native", bal, r8(S_bal), 3)):
+                               # the pairs grid with the first-pass schedule (two workgroups per CU)
+                               ("length_aware_pairs_first_pass", old, r8(S_old), 2),
+                               # RX_SPLIT_OCC3=1: mixed-batch schedule for 3 x CUs pieces + the three-per-CU kernel instance
+                               ("length_aware_three_per_cu", bal, r8(S_bal), 3),
+                               # what the backend runs, eager or graph-replayed: the pairs grid + the rounds rule, two per CU
+                               ("length_aware_native", rr, r8(S_rr), 2)):
         us = timed(ns, S, items)
         res[name] = {"us_per_layer": us, "TBps": byt / us / 1e6, "frac_of_hbm_peak": byt / us / 1e6 / 8.0,
                      "splits_of_the_long_request": 1 if ns is None else int(ns[0]),

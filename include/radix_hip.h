@@ -101,7 +101,12 @@ int rx_num_kv_splits_native(const void* seq_lens, int seq_lens_is_i64, int bs, i
  * cut, some whole, i.e. workgroups of different sizes -- the counts are re-derived with wg_target_mixed in place of
  * wg_target (the budget of the live-pairs grid: three workgroups per CU, all resident at once), and if rounding up
  * overshoots it (pairs * wg_per_request > wg_target_mixed) t* is scaled up by that ratio once.  A uniform batch keeps
- * the first pass: fewer, larger workgroups are faster there (4 x 16 k: 54 us at 512 workgroups, 56 at 768). */
+ * the first pass: fewer, larger workgroups are faster there (4 x 16 k: 54 us at 512 workgroups, 56 at 768).
+ * wg_target_mixed = -1: the ROUNDS rule instead, for the kernel's usual two workgroups per CU (what a graph-replayed
+ * step runs): if the first pass of a mixed batch needs R1 = ceil(pairs * wg_per_request / wg_target) >= 2 rounds of
+ * workgroups, the split requests are cut into pieces of p = R * a tokens, a = the mean length of the unsplit requests
+ * (rounded up; never below the first pass's t*), R = the smallest of 1..4 with ceil(workgroups(p) / wg_target) <= R: a long request's pieces then end
+ * with the last round of the short ones.  R1 = 1 keeps the first pass (all resident: the even share fills the slots). */
 int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int wg_target,
                               int max_kv_splits, int min_tokens_per_split, int wg_target_mixed, int32_t* out,
                               void* stream);

@@ -201,7 +201,7 @@ class HipRadixAttnBackend:
         if os.environ.get("RX_NO_INKERNEL_MERGE"):  # dev A/B: stage 2 as its own launch
             self._merge_counters = None
         self._no_fused_store = bool(os.environ.get("RX_NO_FUSED_STORE"))  # dev A/B: the store as its own launch
-        self._graph_occ3 = os.environ.get("RX_GRAPH_OCC3", "0") == "1"  # graph-replayed steps on the three-per-CU kernel form
+        self._split_occ3 = os.environ.get("RX_SPLIT_OCC3", "0") == "1"  # eager mixed batches on the three-per-CU kernel form
         self._no_split_items = bool(os.environ.get("RX_NO_SPLIT_ITEMS"))  # dev A/B: split slots instead of compacted pairs
         # RX_DEBUG_CHECKS=1: host-synchronising assertions of the backend's preconditions (see forward_decode)
         self._debug_checks = os.environ.get("RX_DEBUG_CHECKS", "0") not in ("", "0")
@@ -464,14 +464,15 @@ class HipRadixAttnBackend:
         # ~1 k tokens is all prologue (32 x 1 k: 31 us at 1 split, 33 at 2): t* has a 1 k floor there, 128 for tiny batches.
         min_tokens = 1024 if (2 * blocks >= self.device_core_count and not self._is_mla_pool) else 128
         cap = self.native_split_cap
-        # a MIXED batch (some requests cut, some whole) runs on the live-pairs grid, whose kernel form holds three
-        # workgroups per CU: its schedule aims at that many near-equal pieces (rx_num_kv_splits_balanced, wg_target_mixed)
+        # a MIXED batch (some requests cut, some whole) takes the ROUNDS rule of rx_num_kv_splits_balanced
+        # (wg_target_mixed = -1): long requests are cut into pieces that last as many rounds of workgroups as the unsplit
+        # ones need -- made for the kernel's usual two workgroups per CU, so eager and graph-replayed steps share it
+        # (one 32 k request among 63 of 1 k: 94 -> 80 us per layer at two per CU).  RX_SPLIT_OCC3=1 (eager steps only):
+        # the three-per-CU kernel instance with its own schedule (3 x CUs near-equal pieces) instead -- the same times
+        # within 2 % on the batches of tools/probe/rounds_rule.py.
         use_items = not self._is_mla_pool and not self._no_split_items
-        # ... an eager step knows from the host copy of the lengths whether the batch is mixed; a captured graph is
-        # replayed with other lengths and cannot (RX_GRAPH_OCC3=1: it takes the three-per-CU form regardless -- a uniform
-        # batch is ~0.5 % faster at two)
-        three = use_items and ((not use_graph_bufs and fb.seq_lens_cpu is not None) or (use_graph_bufs and self._graph_occ3))
-        wg_mixed = self.device_core_count * 3 if three else 0
+        three = use_items and self._split_occ3 and not use_graph_bufs and fb.seq_lens_cpu is not None
+        wg_mixed = self.device_core_count * 3 if three else (-1 if use_items else 0)
         host_pairs = None
         if not use_graph_bufs and fb.seq_lens_cpu is not None:
             host_counts = ops.balanced_kv_splits_host(fb.seq_lens_cpu.numpy()[:bs], self.num_head, self.num_kv_head, cap,
@@ -511,8 +512,7 @@ class HipRadixAttnBackend:
         items = None
         if use_items:
             if use_graph_bufs:
-                items = self._graph["split_items"].build(num_kv_splits, order, cap=self._split_pairs_bound(bs, S_cap),
-                                                         wgs_per_cu=3 if three else 0)
+                items = self._graph["split_items"].build(num_kv_splits, order, cap=self._split_pairs_bound(bs, S_cap))
             else:
                 mixed = three and bool((host_counts > 1).any() and (host_counts == 1).any())
                 items = ops.SplitItems(host_pairs if host_pairs is not None else bs * S_cap, self.device).build(

@@ -809,11 +809,51 @@ __global__ __launch_bounds__(1024) void num_kv_splits_balanced_kernel(const void
     any_split |= n > 1;
     any_whole |= n == 1;
   }
-  if (wg_mixed <= wg_target) return;
+  if (wg_mixed >= 0 && wg_mixed <= wg_target) return;
   if (any_split) flags_s[0] = 1;
   if (any_whole) flags_s[1] = 1;
   __syncthreads();
   if (!(flags_s[0] && flags_s[1])) return;
+  if (wg_mixed < 0) {
+    // The ROUNDS rule (for the kernel's usual two workgroups per CU, i.e. also for a graph-replayed step): wg_target
+    // slots take the workgroups in launch order, longest pieces first, and a workgroup's rate hardly depends on how many
+    // others run -- so when the batch needs R >= 2 rounds of workgroups, the unsplit requests (mean length a) go through
+    // in R rounds and a long request's pieces should last exactly as long: p = R a.  (Measured, one 32 k request among
+    // 63 of 1 k: 22 pieces of 1.5 k from the even share 94 us, 16 pieces of 2 k = 2 a 80 us.)  With R = 1 everything is
+    // resident at once and the even share above is what fills the slots.
+    unsigned long long p1 = 0, su = 0, cu = 0;
+    for (int i = tid; i < bs; i += 1024) {
+      const int64_t len = max<int64_t>(load_idx(seq_lens, i, is64), 0);
+      const int64_t n = balanced_count(len, tstar, cap);
+      p1 += static_cast<unsigned long long>(n);
+      if (n == 1) {
+        su += static_cast<unsigned long long>(len);
+        cu += 1;
+      }
+    }
+    const unsigned long long tot1 = block_sum(p1) * static_cast<unsigned long long>(wg_per_request);
+    su = block_sum(su);
+    cu = block_sum(cu);
+    if ((tot1 + wg_target - 1) / wg_target < 2) return;
+    const int64_t a = max<int64_t>(1, static_cast<int64_t>((su + cu - 1) / cu));
+    int64_t p = a;
+    for (int R = 1; R <= 4; ++R) {
+      p = max<int64_t>(R * a, tstar);  // never finer than the even share (a batch whose unsplit requests are tiny)
+      unsigned long long pc = 0;
+      for (int i = tid; i < bs; i += 1024) {
+        const int64_t len = max<int64_t>(load_idx(seq_lens, i, is64), 0);
+        if (balanced_count(len, tstar, cap) > 1) pc += static_cast<unsigned long long>(min<int64_t>(cap, (len + p - 1) / p));
+      }
+      const unsigned long long tot = (cu + block_sum(pc)) * static_cast<unsigned long long>(wg_per_request);
+      if ((tot + wg_target - 1) / wg_target <= static_cast<unsigned long long>(R)) break;
+    }
+    for (int i = tid; i < bs; i += 1024) {
+      const int64_t len = max<int64_t>(load_idx(seq_lens, i, is64), 0);
+      if (balanced_count(len, tstar, cap) > 1)
+        out[i] = static_cast<int32_t>(max<int64_t>(1, min<int64_t>(cap, (len + p - 1) / p)));
+    }
+    return;
+  }
   // a MIXED batch (some requests cut, some not) is where workgroups differ in size: re-derive the schedule for the
   // budget of the live-pairs grid (three workgroups per CU, all resident: rx_decode_params.split_items), and scale t*
   // up once if rounding up overshoots that budget (a second round of workgroups costs more than coarser pieces)
@@ -887,7 +927,7 @@ int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs,
   RX_REQUIRE(bs >= 0, "rx_num_kv_splits_balanced: bs < 0");
   if (bs == 0) return RX_OK;
   RX_REQUIRE(seq_lens && out, "rx_num_kv_splits_balanced: null pointer");
-  RX_REQUIRE(wg_per_request > 0 && wg_target > 0 && max_kv_splits > 0 && min_tokens_per_split > 0 && wg_target_mixed >= 0,
+  RX_REQUIRE(wg_per_request > 0 && wg_target > 0 && max_kv_splits > 0 && min_tokens_per_split > 0 && wg_target_mixed >= -1,
              "rx_num_kv_splits_balanced: bad sizes");
   hipLaunchKernelGGL(rx::num_kv_splits_balanced_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), seq_lens,
                      seq_lens_is_i64, bs, wg_per_request, wg_target, max_kv_splits, min_tokens_per_split, wg_target_mixed, out);

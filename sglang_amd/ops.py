@@ -225,6 +225,21 @@ def balanced_kv_splits_host(lens, num_head: int, num_kv_head: int, max_kv_splits
         return np.maximum(n, 1).astype(np.int32)
 
     n = counts(max(int(min_tokens_per_split), -(-work // wg_target)))
+    if wg_target_mixed < 0 and (n > 1).any() and (n == 1).any():  # the rounds rule (two workgroups per CU)
+        split = n > 1
+        if -(-int(n.sum()) * wgpr // wg_target) < 2:
+            return n
+        cu = int((~split).sum())
+        a = max(1, -(-int(lens[~split].sum()) // cu))
+        t1 = max(int(min_tokens_per_split), -(-work // wg_target))
+        for R in (1, 2, 3, 4):
+            p = max(R * a, t1)
+            pieces = np.minimum(max_kv_splits, -(-lens[split] // p))
+            if -(-(cu + int(pieces.sum())) * wgpr // wg_target) <= R:
+                break
+        n = n.copy()
+        n[split] = np.maximum(1, pieces).astype(np.int32)
+        return n
     if wg_target_mixed > wg_target and (n > 1).any() and (n == 1).any():  # a mixed batch: the live-pairs grid's budget
         tstar = max(int(min_tokens_per_split), -(-work // wg_target_mixed))
         wgs = int(counts(tstar).sum()) * wgpr

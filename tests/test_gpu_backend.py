@@ -629,7 +629,7 @@ def test_balanced_split_schedule_kernel_matches_its_host_mirror_and_heterogeneou
                           [[0, 5, 70000], 8, 8]):
         lt = torch.tensor(lens, dtype=torch.int64, device=DEV)
         for mt in (128, 1024):
-            for mixed in (0, 768, 2048):  # the mixed-batch budget (wg_target_mixed) and its overshoot step
+            for mixed in (0, 768, 2048, -1):  # the mixed-batch budget (wg_target_mixed), its overshoot step; -1: the rounds rule
                 out = torch.zeros(len(lens), dtype=torch.int32, device=DEV)
                 ops.get_num_kv_splits_balanced(out, lt, hq, hkv, 32, 512, mt, mixed)
                 want = ops.balanced_kv_splits_host(lens, hq, hkv, 32, 512, mt, mixed)
@@ -637,6 +637,11 @@ def test_balanced_split_schedule_kernel_matches_its_host_mirror_and_heterogeneou
     mixed = ops.balanced_kv_splits_host([32768] + [1024] * 63, 32, 8, 64, 512, 1024, 768)
     assert mixed[0] == 32 and mixed[1:].max() == 1 and int(mixed.sum()) * 8 <= 768               # equal 1 k pieces, all resident
     assert (ops.balanced_kv_splits_host([4096] * 16, 32, 8, 64, 512, 1024, 768) == 4).all()      # uniform: first pass kept
+    rr = ops.balanced_kv_splits_host([32768] + [1024] * 63, 32, 8, 64, 512, 1024, -1)
+    assert rr[0] == 16 and rr[1:].max() == 1                                                     # rounds rule: 2 rounds -> pieces of 2 x 1 k
+    assert ops.balanced_kv_splits_host([16384] * 2 + [2048] * 30, 32, 8, 64, 512, 1024, -1).max() == 12  # one round: first pass kept
+    tiny = ops.balanced_kv_splits_host([30000] * 20 + [16], 32, 8, 64, 512, 128, -1)
+    assert tiny[:20].max() <= ops.balanced_kv_splits_host([30000] * 20 + [16], 32, 8, 64, 512, 128).max()  # never finer than the even share
     assert ops.balanced_kv_splits_host([4096] * 256, 32, 8, 32, 512, 1024).max() == 1          # the headline batch: one pass
     out = ops.balanced_kv_splits_host([32768] + [1024] * 63, 32, 8, 32, 512, 1024)
     assert out[0] >= 16 and out[1:].max() == 1                                                  # only the outlier is cut
