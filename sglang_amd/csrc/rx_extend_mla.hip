@@ -103,6 +103,9 @@ __device__ __forceinline__ void x_settle(f32x4 (&o)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) asm volatile("" : "+a"(o[i]));
 }
+#ifndef RX_XMLA_TBL
+#define RX_XMLA_TBL 1  // DMA issue from a per-tile row-pointer table in LDS (rx_extend_d256.hip, round 3); 0: per-piece address math
+#endif
 #ifndef RX_XMLA_STAMP
 #define RX_XMLA_STAMP 0  // 1: diagnostic build, s_memtime phase stamps of waves 0 and 4 go to lse[16 * block ...] (tools/mla_extend_bench.py STAMPS=1)
 #endif
@@ -119,7 +122,8 @@ struct XGeom8 {  // (the eight-wave form's geometry; the four-wave first form is
   static constexpr int SLOTS_AT = NSTAGE * STAGE;
   static constexpr int SLOTBLK = 256;
   static constexpr int BOUNCE_AT = SLOTS_AT + 2 * SLOTBLK * 4;
-  static constexpr int LDS = BOUNCE_AT + NW * 1024;  // 161792 B
+  static constexpr int TBL_AT = BOUNCE_AT + NW * 1024;  // row-pointer tables: 2 tiles x 32 rows x {K ptr, V ptr}
+  static constexpr int LDS = TBL_AT + 2 * kXTT * 16;    // 162816 B
 };
 static_assert(XGeom8::LDS <= 160 * 1024, "LDS budget");
 
@@ -254,6 +258,80 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+#if RX_XMLA_TBL
+  static_assert(G::AHEAD == 1 || !RX_XMLA_TBL, "the table is built two tiles ahead of its use: one tile in flight");
+  // One wave per tile writes the 32 rows' K and V pointers two tiles ahead (lane = row: slot lookup, page / token split
+  // and the 64-bit multiplies once per ROW); a piece is then its row and column, one ds_read_b64, one 64-bit add, the DMA.
+  // The per-piece form above was ~30 instructions x 5 pieces per tile and wave next to 68 MFMAs, in a kernel that pays
+  // ~5 cycles for every instruction it issues (rx_extend_d256.hip).
+  auto build_table = [&](int u) {
+    if (w != (u & 7) || u >= nt) return;
+    const int rw = lane & 31;
+    const char* kp;
+    const char* vp;
+    if (u < nt1) {
+      const uint32_t sl = smem_u + G::SLOTS_AT + 4 * (((u * kXTT / kXSlotBlock) & 1) * kXSlotBlock + (u * kXTT) % kXSlotBlock + rw);
+      const uint32_t slot = static_cast<uint32_t>(x_lds_read4(sl));
+      const uint32_t lo = sh_p == 31 ? slot : (slot & ((1u << sh_p) - 1u));
+      uint64_t ko = static_cast<uint64_t>(lo) * (2u * static_cast<uint32_t>(a.k_tok_stride));
+      uint64_t vo = static_cast<uint64_t>(lo) * (2u * static_cast<uint32_t>(a.v_tok_stride));
+      if (sh_p != 31) {
+        ko += static_cast<uint64_t>(slot >> sh_p) * (2u * static_cast<uint32_t>(a.k_page_stride));
+        vo += static_cast<uint64_t>(slot >> sh_p) * (2u * static_cast<uint32_t>(a.v_page_stride));
+      }
+      kp = kbuf_b + ko;
+      vp = vbuf_b + vo;
+    } else {
+      const uint32_t n = static_cast<uint32_t>(max(min((u - nt1) * kXTT + rw, n_end_wg - 1), 0));
+      kp = kext_b + static_cast<uint64_t>(n) * (2u * static_cast<uint32_t>(a.k_stride_t));
+      vp = vext_b + static_cast<uint64_t>(n) * (2u * static_cast<uint32_t>(a.v_stride_t));
+    }
+    const uint64_t k64 = reinterpret_cast<uint64_t>(kp), v64 = reinterpret_cast<uint64_t>(vp);
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(smem_u + G::TBL_AT + ((u & 1) * kXTT + rw) * 16) =
+        u32x4{static_cast<uint32_t>(k64), static_cast<uint32_t>(k64 >> 32), static_cast<uint32_t>(v64), static_cast<uint32_t>(v64 >> 32)};
+  };
+  auto dma_tile_tbl = [&](int t, int ring) {
+    const uint32_t tb = smem_u + G::TBL_AT + (t & 1) * (kXTT * 16);
+    const uint32_t img = smem_u + (ring & (G::NSTAGE - 1)) * G::STAGE;
+    const bool ownv = own_v(t);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int c0 = 64 * w + ln;
+    int row = c0 / kXCpr, col = c0 - row * kXCpr;
+    typedef __attribute__((address_space(3))) const u32x2* lds_u32x2;
+    u32x2 kp[NP], vp[NP];
+    uint32_t c16[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const bool past = row >= kXTT;
+      const uint32_t ra = tb + 16u * static_cast<uint32_t>(past ? kXTT - 1 : row);
+      kp[i] = *reinterpret_cast<lds_u32x2>(ra);
+      if (ownv) vp[i] = *reinterpret_cast<lds_u32x2>(ra + 8);
+      c16[i] = 16u * static_cast<uint32_t>((past || col >= kXCpr - 2) ? kXCpr - 3 : col);  // pad chunks re-read the row's last data chunk
+      row += 512 / kXCpr;
+      col += 512 % kXCpr;
+      if (col >= kXCpr) {
+        col -= kXCpr;
+        row += 1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (w + G::NW * i < kPieces) {
+        const uint64_t ks = (static_cast<uint64_t>(kp[i][1]) << 32 | kp[i][0]) + c16[i];
+        x_dma16(reinterpret_cast<const void*>(ks), __builtin_amdgcn_readfirstlane(img + (w + G::NW * i) * 1024));
+        if (ownv) {  // the same piece of the V image (columns past the 64 v chunks re-read the last one)
+          const uint64_t vs = (static_cast<uint64_t>(vp[i][1]) << 32 | vp[i][0]) + min(c16[i], static_cast<uint32_t>(kXDv * 2 - 16));
+          x_dma16(reinterpret_cast<const void*>(vs), __builtin_amdgcn_readfirstlane(img + kXImg + (w + G::NW * i) * 1024));
+        }
+      }
+    }
+  };
+  build_table(0);
+  build_table(1);
+  __syncthreads();  // the first two tables are readable
+#define dma_tile dma_tile_tbl
+#endif
   if (nt > 0) {  // tiles past the end are "loaded" as well (the last one again): the counted waits stay uniform
 #pragma unroll
     for (int i = 0; i < G::AHEAD; ++i) dma_tile(min(i, nt - 1), i);
@@ -294,6 +372,9 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
     X_STAMP(0);
     constexpr int TPB = kXSlotBlock / kXTT;
     if (t % TPB == 0 && (t / TPB + 1) * kXSlotBlock < nt1 * kXTT) stage_slots(t / TPB + 1);
+#if RX_XMLA_TBL
+    build_table(t + 2);  // read by tile t + 2's issue, behind the next barrier
+#endif
     const bool more = true;
     const int t_next = min(t + G::AHEAD, nt - 1), r_next = t + G::AHEAD;
     if (!late) dma_tile(t_next, r_next);
@@ -449,6 +530,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   }
   if (a.lse && g == 0 && !RX_XMLA_STAMP) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run * kLn2 + __logf(l);
 }
+#undef dma_tile
 
 bool extend_mla_supports(const rx_extend_params* p) {
   if (p->head_dim != kXDk || p->v_head_dim != kXDv || p->num_kv_heads != 1 || p->kv.kv_fp8) return false;
