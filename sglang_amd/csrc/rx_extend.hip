@@ -637,6 +637,10 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   }
   // D = 128, the plain call, enough tiles per workgroup to amortise a 256-row workgroup's prologue: four waves x 64 rows
   // (rx_extend_pw.hip).  RX_EXT_PW: 0 never, 2 whenever the kernel supports the call (tests), default = by the estimate.
+  if (dk == 128 && dv == 128 && getenv("RX_EXT_D256_AT128") && extend_d256_supports(p)) {  // dev: the 16x16x32 AGPR / LDS-DMA form at D = 128
+    const int rc = launch_extend_d256(p, static_cast<hipStream_t>(stream));
+    return rc != RX_OK ? rc : check_launch("rx_extend_attn");
+  }
   if (mfma_ok && dk == 128 && o16 && extend_pw_supports(p)) {
     const char* pw_env = getenv("RX_EXT_PW");  // read per call: tests flip it inside one process
     const int pw_mode = pw_env ? atoi(pw_env) : RX_EXT_PW_DEFAULT;

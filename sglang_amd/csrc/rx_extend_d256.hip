@@ -653,7 +653,11 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
 // tensors, and extends long enough to fill 256-row workgroups (short ones: rx_extend_nd.hip's smaller blocks)
 bool extend_d256_supports(const rx_extend_params* p) {
   const int dk = p->head_dim, dv = p->v_head_dim;
-  if (!((dk == 256 && dv == 256) || (dk == 192 && (dv == 128 || dv == 192))) || p->kv.kv_fp8) return false;
+  // (128 / 128 as well, on request: RX_EXT_D256_AT128=1 -- a dev switch to measure this kernel form against the
+  // 32x32x16 kernel of rx_extend32.hip on the headline shape)
+  static const bool at128 = getenv("RX_EXT_D256_AT128") != nullptr;
+  if (!((dk == 256 && dv == 256) || (dk == 192 && (dv == 128 || dv == 192)) || (at128 && dk == 128 && dv == 128)) || p->kv.kv_fp8)
+    return false;
   if (p->sinks || p->custom_mask || p->xai_temperature_len > 0 || p->unified_prefix_lens || p->q_pack > 1 ||
       p->window_kv_offsets)
     return false;
@@ -709,7 +713,8 @@ int launch_extend_d256(const rx_extend_params* p, hipStream_t s) {
   } while (0)
 #define RX_D256_DIMS(TT, EX_)                                 \
   do {                                                        \
-    if (dk == 256) RX_D256(TT, 256, 256, EX_);                \
+    if (dk == 128) RX_D256(TT, 128, 128, EX_);                \
+    else if (dk == 256) RX_D256(TT, 256, 256, EX_);           \
     else if (dv == 128) RX_D256(TT, 192, 128, EX_);           \
     else RX_D256(TT, 192, 192, EX_);                          \
   } while (0)
