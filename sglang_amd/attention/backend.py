@@ -517,6 +517,10 @@ class HipRadixAttnBackend:
                 mixed = three and bool((host_counts > 1).any() and (host_counts == 1).any())
                 items = ops.SplitItems(host_pairs if host_pairs is not None else bs * S_cap, self.device).build(
                     num_kv_splits, order, wgs_per_cu=3 if mixed else 0)
+        if items is not None and self._debug_checks:  # RX_DEBUG_CHECKS=1 (a host sync): the table holds every live pair
+            live = int(items.count.item())
+            if live > items.cap:
+                raise AssertionError(f"split items: {live} live (request, split) pairs > the table's {items.cap}")
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S,
                                request_order=order, partial_pairs_hint=pairs, split_items=items)
 

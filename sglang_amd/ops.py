@@ -893,7 +893,9 @@ class CascadeGroups:
         offs = np.concatenate([[0], np.cumsum([len(x) for x in parts])])
         host = self._tab_host
         host[: offs[-1]] = torch.from_numpy(np.concatenate(parts).astype(np.int32))
-        self._tab[: offs[-1]].copy_(host[: offs[-1]], non_blocking=True)
+        # (a blocking copy: the pinned staging buffer is rewritten by the next plan(), which may run before the GPU has
+        # reached this one)
+        self._tab[: offs[-1]].copy_(host[: offs[-1]], non_blocking=False)
         view = lambda i: self._tab[int(offs[i]): int(offs[i + 1])]
         self.kv_indptr, self.qo_indptr, src_member, src_col = view(0), view(1), view(2), view(3)
         self.kv_start, self.extra_index, self.gather = view(4), view(5), view(6).long()

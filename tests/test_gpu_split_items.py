@@ -93,3 +93,61 @@ def test_decode_with_split_items_is_bit_identical_to_split_slots(dtype, lookup):
                                 kb.view(torch.uint16).numpy() if dtype == torch.bfloat16 else kb.numpy(),
                                 vb.view(torch.uint16).numpy() if dtype == torch.bfloat16 else vb.numpy(), ip, ii, d ** -0.5)
     parity.check_out(outs[1].float().cpu().numpy()[live], want[live], dtype, ("split items", lookup), ulps=1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_store_with_split_items_at_two_and_three_workgroups_per_cu(dtype):
+    """The step's KV store inside the decode launch (rx_decode_params.k_new) on the live-pairs grid: the usual kernel and
+    its three-per-CU instance (which re-reads the newest token's slot instead of carrying it through the loop) must write
+    the same pool rows and outputs as store-then-decode on the split-slot grid, bit for bit."""
+    from sglang_amd import ops
+
+    hq, hkv, d, ps = 32, 8, 128, 16
+    lens = np.array([6000, 1, 300, 2049, 33, 4100, 17, 5000], dtype=np.int64)  # lengths INCLUDING the new token
+    bs = len(lens)
+    rng = np.random.default_rng(9)
+    pages = [-(-int(n) // ps) for n in lens]
+    perm = rng.permutation(np.arange(1, sum(pages) + 1))
+    r2t = np.zeros((bs + 1, int(lens.max()) + ps), dtype=np.int32)
+    pi = 0
+    for i, n in enumerate(lens):
+        r2t[i + 1, :n] = (perm[pi: pi + pages[i], None] * ps + np.arange(ps)[None]).reshape(-1)[:n]
+        pi += pages[i]
+    pool = (sum(pages) + 1) * ps
+    g = torch.Generator().manual_seed(4)
+    kb0 = torch.randn(pool, hkv, d, generator=g).to(dtype).to(DEV)
+    vb0 = torch.randn(pool, hkv, d, generator=g).to(dtype).to(DEV)
+    q = torch.randn(bs, hq, d, generator=g).to(dtype).to(DEV)
+    kn = torch.randn(bs, hkv, d, generator=g).to(dtype).to(DEV)
+    vn = torch.randn(bs, hkv, d, generator=g).to(dtype).to(DEV)
+    r2t_d = torch.from_numpy(r2t).to(DEV)
+    rpi = torch.arange(1, bs + 1, device=DEV)
+    lens_d = torch.from_numpy(lens).to(DEV)
+    S = 16
+    splits = torch.zeros(bs, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits_balanced(splits, lens_d, hq, hkv, S, 512, 128)
+    order = torch.argsort(lens_d, descending=True).to(torch.int32)
+    new_slots = r2t_d[rpi, (lens_d - 1)].long()
+
+    def run(mode):
+        kb, vb = kb0.clone(), vb0.clone()
+        o = torch.full((bs, hq, d), float("nan"), dtype=dtype, device=DEV)
+        al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
+        ls = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+        cnt = torch.zeros(bs * hq, dtype=torch.int32, device=DEV)
+        if mode == "store_then_decode":
+            kb[new_slots], vb[new_slots] = kn, vn
+            ops.decode_attention_fwd_paged(q, kb, vb, o, r2t_d, rpi, lens_d, al, ls, splits, S, d ** -0.5, page_size=ps,
+                                           merge_counters=cnt, request_order=order)
+        else:
+            si = ops.SplitItems(int(splits.clamp_min(1).sum()), DEV).build(splits, order, wgs_per_cu=3 if mode == "three" else 0)
+            ops.decode_attention_fwd_paged(q, kb, vb, o, r2t_d, rpi, lens_d, al, ls, splits, S, d ** -0.5, page_size=ps,
+                                           merge_counters=cnt, request_order=order, split_items=si, k_new=kn, v_new=vn)
+        torch.cuda.synchronize()
+        return o.view(torch.int16).cpu().numpy(), kb.view(torch.int16).cpu().numpy(), vb.view(torch.int16).cpu().numpy()
+
+    ref = run("store_then_decode")
+    for mode in ("two", "three"):
+        got = run(mode)
+        for a, b, what in zip(ref, got, ("o", "k pool", "v pool")):
+            assert (a == b).all(), (mode, what)
