@@ -24,6 +24,8 @@
 extern "C" {
 #endif
 
+/* 8 (round 3): rx_split_items; rx_decode_params.split_items / split_items_count / split_items_cap /
+ * split_items_wgs_per_cu and extra_index / extra_rows; rx_num_kv_splits_balanced gained wg_target_mixed. */
 #define RX_ABI_VERSION 8
 
 typedef enum rx_status {
