@@ -641,9 +641,12 @@ def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=8):
     kv_indptr = (torch.arange(chunk + 1, device=dev) * P).to(torch.int32)
     qo_indptr = (torch.arange(chunk + 1, device=dev) * E).to(torch.int64)
 
+    qp = int(os.environ.get("RX_EXTEND_QPACK", "1"))  # dev: GQA-packed query rows (rx_extend_params.q_pack) on this shape
+
     def run():
         ops.extend_attention_fwd(q, k_ext, v_ext, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True,
-                                 None, E, 1.0, 1.0, sm_scale=D ** -0.5, page_size=ps, kv_layout=lay)
+                                 None, E, 1.0, 1.0, sm_scale=D ** -0.5, page_size=ps, kv_layout=lay,
+                                 **({"q_pack": qp} if qp > 1 else {}))
 
     for _ in range(2):
         run()

@@ -184,11 +184,16 @@ __device__ __forceinline__ float half_swap_max(float x) {
 // fields are then compile-time constants: the fast loop of the general instance keeps ~30 more scalars alive and
 // hipcc spills SGPRs into VGPR lanes, reading 26 of them back with v_readlane EVERY tile (VALU issue slots in a
 // VALU-issue-bound loop).
-template <typename T, typename IdxT, bool LINEAR, bool VSCALE, int NW, int QB, bool KV8, bool PLAIN>
+// PKC (PLAIN instances only): the GQA packing factor as a compile-time constant (0 = none).  A long causal extend under
+// GQA walks fewer tiles packed -- a 256-row block is 64 tokens x 4 heads instead of 256 tokens of one head, so its
+// diagonal is one boundary tile instead of four -- but the general instance that used to serve q_pack lost that to its
+// scalars; with the factor a constant (row -> token is a shift) the packed call keeps the PLAIN loop.
+template <typename T, typename IdxT, bool LINEAR, bool VSCALE, int NW, int QB, bool KV8, bool PLAIN, int PKC = 0>
 __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel(const Ext32Args a_in) {
+  static_assert(PKC == 0 || PLAIN, "a constant packing factor goes with the PLAIN instance");
   Ext32Args a = a_in;
   if constexpr (PLAIN) {
-    a.q_pack = 1;
+    a.q_pack = PKC > 0 ? PKC : 1;
     a.unified_prefix = nullptr;
     a.custom_mask = nullptr;
     a.mask_indptr = nullptr;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const int req = bid / a.group;
 
   const int64_t qo0 = load_idx(a.qo_indptr, req, a.qo64);
-  const int32_t pack = a.q_pack;
+  const int32_t pack = PLAIN ? (PKC > 0 ? PKC : 1) : a.q_pack;
   // queries of this request as ROWS: one per new token, or (q_pack = G) one per (new token, q head of the group)
   const int32_t E = static_cast<int32_t>(load_idx(a.qo_indptr, req + 1, a.qo64) - qo0) * pack;
   const int32_t kv0 = a.kv_indptr[req];
@@ -1241,13 +1246,13 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
 }
 
 // launcher used by rx_extend.hip for head_dim == v_head_dim == 128
-template <int NW, int QB, bool KV8, bool PLAIN>
+template <int NW, int QB, bool KV8, bool PLAIN, int PKC = 0>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
   constexpr unsigned kLds = ((QB > 1 || (NW == 8 && (RX_EXT32_DEEP >= 1 || RX_EXT32_FINE))) ? 3 : 2) * kBufBytes;  // 74 / 111 KiB: above the 64 KiB static limit, hence dynamic
 #define RX_E32(TT, IT, LIN, VS)                                                                        \
   do {                                                                                                 \
-    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB, KV8, PLAIN>;                             \
+    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB, KV8, PLAIN, PKC>;                             \
     static const hipError_t attr = hipFuncSetAttribute(                                                \
         reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);       \
     (void)attr;                                                                                        \
@@ -1308,6 +1313,15 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.skip_prefix_mask = p->skip_prefix_custom_mask; a.xai_len = p->xai_temperature_len;
   a.unified_prefix = p->unified_prefix_lens;
   a.q_pack = p->q_pack > 1 ? p->q_pack : 1;
+  // Long causal extends of a GQA-4 model pack by themselves (bit-identical results, +2.6 % at the config-3 chunk: a
+  // 256-row block's diagonal is one boundary tile instead of four); RX_EXT32_AUTOPACK=0 turns it off
+  const char* ap_env = getenv("RX_EXT32_AUTOPACK");  // (read per call: tests flip it inside one process)
+  const bool autopack = !(ap_env && atoi(ap_env) == 0);
+  if (autopack && a.q_pack == 1 && RX_EXT32_QB == 1 && p->num_q_heads == 4 * p->num_kv_heads && p->is_causal &&
+      !p->skip_extend && p->max_extend_len >= 256 && !p->kv.kv_fp8 && p->v_scale == 1.0f && !p->unified_prefix_lens &&
+      !p->custom_mask && p->sliding_window_size <= 0 && p->xai_temperature_len <= 0 && !(p->logit_cap > 0.f) &&
+      (p->avg_kv_len_hint + p->max_extend_len / 2) / kTok >= RX_EXT32_SMALL_WG_TILES)
+    a.q_pack = 4;
   if (a.q_pack > 1) {  // the grid's heads are KV heads; their rows carry the q heads of the group
     a.hq = p->num_kv_heads;
     a.group = 1;
@@ -1327,8 +1341,13 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.mblocks = (p->max_extend_len * a.q_pack + nw * QB * 32 - 1) / (nw * QB * 32);
   a.kv_fp8 = p->kv.kv_fp8;
   const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0, vsc = p->v_scale != 1.0f;
-  const bool plain = !a.kv_fp8 && !vsc && a.q_pack == 1 && !a.unified_prefix && !a.custom_mask && a.window <= 0 &&
-                     a.xai_len <= 0 && !(a.logit_cap > 0.f) && !getenv("RX_EXT32_NO_PLAIN");
+  const bool plain_any = !a.kv_fp8 && !vsc && !a.unified_prefix && !a.custom_mask && a.window <= 0 &&
+                         a.xai_len <= 0 && !(a.logit_cap > 0.f) && !getenv("RX_EXT32_NO_PLAIN");
+  const bool plain = plain_any && a.q_pack == 1;
+  if (plain_any && a.q_pack == 4 && !small_wg && QB == 1) {  // packed rows on the PLAIN loop (Llama-3-class GQA 4)
+    launch32_nw<8, 1, false, true, 4>(a, bf, i64, linear, false, s);
+    return RX_OK;
+  }
   if (small_wg) {
     if (plain) launch32_nw<4, 1, false, true>(a, bf, i64, linear, false, s);
     else if (a.kv_fp8) launch32_nw<4, 1, true, false>(a, bf, i64, linear, vsc, s);
