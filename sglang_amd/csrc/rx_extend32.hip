@@ -1313,15 +1313,16 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.skip_prefix_mask = p->skip_prefix_custom_mask; a.xai_len = p->xai_temperature_len;
   a.unified_prefix = p->unified_prefix_lens;
   a.q_pack = p->q_pack > 1 ? p->q_pack : 1;
-  // Long causal extends of a GQA-4 model pack by themselves (bit-identical results, +2.6 % at the config-3 chunk: a
+  // Long causal extends of a GQA-4 / GQA-8 model pack by themselves (bit-identical results, +2.6 % at the config-3 chunk: a
   // 256-row block's diagonal is one boundary tile instead of four); RX_EXT32_AUTOPACK=0 turns it off
   const char* ap_env = getenv("RX_EXT32_AUTOPACK");  // (read per call: tests flip it inside one process)
   const bool autopack = !(ap_env && atoi(ap_env) == 0);
-  if (autopack && a.q_pack == 1 && RX_EXT32_QB == 1 && p->num_q_heads == 4 * p->num_kv_heads && p->is_causal &&
+  const int grp = p->num_kv_heads > 0 ? p->num_q_heads / p->num_kv_heads : 1;
+  if (autopack && a.q_pack == 1 && RX_EXT32_QB == 1 && (grp == 4 || grp == 8) && p->num_q_heads == grp * p->num_kv_heads && p->is_causal &&
       !p->skip_extend && p->max_extend_len >= 256 && !p->kv.kv_fp8 && p->v_scale == 1.0f && !p->unified_prefix_lens &&
       !p->custom_mask && p->sliding_window_size <= 0 && p->xai_temperature_len <= 0 && !(p->logit_cap > 0.f) &&
       (p->avg_kv_len_hint + p->max_extend_len / 2) / kTok >= RX_EXT32_SMALL_WG_TILES)
-    a.q_pack = 4;
+    a.q_pack = grp;
   if (a.q_pack > 1) {  // the grid's heads are KV heads; their rows carry the q heads of the group
     a.hq = p->num_kv_heads;
     a.group = 1;
@@ -1344,8 +1345,9 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const bool plain_any = !a.kv_fp8 && !vsc && !a.unified_prefix && !a.custom_mask && a.window <= 0 &&
                          a.xai_len <= 0 && !(a.logit_cap > 0.f) && !getenv("RX_EXT32_NO_PLAIN");
   const bool plain = plain_any && a.q_pack == 1;
-  if (plain_any && a.q_pack == 4 && !small_wg && QB == 1) {  // packed rows on the PLAIN loop (Llama-3-class GQA 4)
-    launch32_nw<8, 1, false, true, 4>(a, bf, i64, linear, false, s);
+  if (plain_any && (a.q_pack == 4 || a.q_pack == 8) && !small_wg && QB == 1) {  // packed rows on the PLAIN loop (GQA 4 / 8)
+    if (a.q_pack == 4) launch32_nw<8, 1, false, true, 4>(a, bf, i64, linear, false, s);
+    else launch32_nw<8, 1, false, true, 8>(a, bf, i64, linear, false, s);
     return RX_OK;
   }
   if (small_wg) {

@@ -25,11 +25,12 @@ def _bits(t):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [([1800, 2300], [300, 513]), ([0], [1100]), ([4000, 5, 1999], [256, 700, 257])],
                          ids=["two_requests", "no_prefix", "ragged"])
-def test_autopacked_extend_is_bit_identical_and_matches_oracle(dtype, shape):
+@pytest.mark.parametrize("heads", [(8, 2), (8, 1)], ids=["gqa4", "gqa8"])
+def test_autopacked_extend_is_bit_identical_and_matches_oracle(dtype, shape, heads):
     from sglang_amd import ops
 
     prefix, extend = shape
-    hq, hkv, d, ps = 8, 2, 128, 16
+    (hq, hkv), d, ps = heads, 128, 16
     g = torch.Generator().manual_seed(len(prefix) * 7 + sum(extend))
     npg = sum(-(-p // ps) for p in prefix) + 3
     perm = torch.randperm(npg - 1, generator=g) + 1
