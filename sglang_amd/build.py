@@ -23,6 +23,7 @@ SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_decode_mla.hip", "rx_extend.hip",
 # config-3 extend 758 -> 782 TFLOP/s.
 EXTRA_FLAGS = {"rx_extend32.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "rx_extend_pw.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+               "rx_extend.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
                "rx_extend_nd.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
                "rx_extend_mla.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "rx_extend_d256.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}

@@ -195,8 +195,8 @@ __global__ __launch_bounds__(256, RX_EXT_MINW) void extend_mfma_kernel(const Ext
     } else {
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
-        stg_k[i] = *reinterpret_cast<const u32x4*>(kext_h + slot[i] * a.k_stride_t);
-        stg_v[i] = *reinterpret_cast<const u32x4*>(vext_h + slot[i] * a.v_stride_t);
+        stg_k[i] = *reinterpret_cast<const u32x4*>(kext_h + mul_u32(slot[i], a.k_stride_t));
+        stg_v[i] = *reinterpret_cast<const u32x4*>(vext_h + mul_u32(slot[i], a.v_stride_t));
       }
     }
   };
