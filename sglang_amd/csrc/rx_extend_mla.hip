@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   constexpr int kPieces = 37;
   constexpr int NP = (kPieces + G::NW - 1) / G::NW;  // 5
   // all pieces of tile t (this wave's: w, w + 8, ...) -> stage t & 1
-  auto dma_tile = [&](int t, int ring) {  // tile t -> stage ring % NSTAGE
+  auto dma_tile_pp = [&](int t, int ring) {  // tile t -> stage ring % NSTAGE, addresses per piece (RX_XMLA_TBL=0)
     const bool pre = t < nt1;
     const uint32_t sl = smem_u + G::SLOTS_AT + 4 * (((t * kXTT / kXSlotBlock) & 1) * kXSlotBlock + (t * kXTT) % kXSlotBlock);
     const uint32_t img = smem_u + (ring & (G::NSTAGE - 1)) * G::STAGE;
@@ -330,7 +330,10 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   build_table(0);
   build_table(1);
   __syncthreads();  // the first two tables are readable
-#define dma_tile dma_tile_tbl
+  auto dma_tile = [&](int t, int ring) { dma_tile_tbl(t, ring); };
+  (void)dma_tile_pp;
+#else
+  auto dma_tile = [&](int t, int ring) { dma_tile_pp(t, ring); };
 #endif
   if (nt > 0) {  // tiles past the end are "loaded" as well (the last one again): the counted waits stay uniform
 #pragma unroll
@@ -530,7 +533,6 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   }
   if (a.lse && g == 0 && !RX_XMLA_STAMP) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run * kLn2 + __logf(l);
 }
-#undef dma_tile
 
 bool extend_mla_supports(const rx_extend_params* p) {
   if (p->head_dim != kXDk || p->v_head_dim != kXDv || p->num_kv_heads != 1 || p->kv.kv_fp8) return false;
