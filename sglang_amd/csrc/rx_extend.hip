@@ -637,7 +637,8 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
   }
   // D = 128, the plain call, enough tiles per workgroup to amortise a 256-row workgroup's prologue: four waves x 64 rows
   // (rx_extend_pw.hip).  RX_EXT_PW: 0 never, 2 whenever the kernel supports the call (tests), default = by the estimate.
-  if (dk == 128 && dv == 128 && getenv("RX_EXT_D256_AT128") && extend_d256_supports(p)) {  // dev: the 16x16x32 AGPR / LDS-DMA form at D = 128
+  if (((dk == 128 && dv == 128 && getenv("RX_EXT_D256_AT128")) || (dk == 64 && dv == 64)) &&
+      extend_d256_supports(p)) {  // the 16x16x32 AGPR / LDS-DMA form at D = 64 (default) / 128 (dev switch)
     const int rc = launch_extend_d256(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }

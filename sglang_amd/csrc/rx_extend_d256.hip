@@ -173,8 +173,11 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   const int32_t rbase = row0 + 32 * w;
   const bool active = rbase < R;
 
-  const uint32_t g_magic = static_cast<uint32_t>(0x100000000ull / static_cast<uint32_t>(G)) + 1u;
-  auto row_tok = [&](int m) { return static_cast<int32_t>(__umulhi(static_cast<uint32_t>(m), g_magic)); };
+  // row -> token by multiply-high.  G = 1 (MHA: Gemma-7B-class heads) has no 32-bit magic -- 2^32 / 1 wraps to 0 and every
+  // row would map to token 0 (found in round 3 with the D = 64 instance; the round-2 kernel had this bug for MHA models
+  // at 256 / 192 with extends past 128 tokens) -- so it is the identity there.
+  const uint32_t g_magic = G == 1 ? 0u : static_cast<uint32_t>(0x100000000ull / static_cast<uint32_t>(G)) + 1u;
+  auto row_tok = [&](int m) { return G == 1 ? m : static_cast<int32_t>(__umulhi(static_cast<uint32_t>(m), g_magic)); };
 
   // ---- Q^T fragments: block c, lane (r, g) holds Q[row rbase + 16 c + r][32 s + 8 g .. +8]
   vec8 qf[2][KS];
@@ -655,8 +658,13 @@ bool extend_d256_supports(const rx_extend_params* p) {
   const int dk = p->head_dim, dv = p->v_head_dim;
   // (128 / 128 as well, on request: RX_EXT_D256_AT128=1 -- a dev switch to measure this kernel form against the
   // 32x32x16 kernel of rx_extend32.hip on the headline shape)
-  static const bool at128 = getenv("RX_EXT_D256_AT128") != nullptr;
-  if (!((dk == 256 && dv == 256) || (dk == 192 && (dv == 128 || dv == 192)) || (at128 && dk == 128 && dv == 128)) || p->kv.kv_fp8)
+  const bool at128 = getenv("RX_EXT_D256_AT128") != nullptr;  // (dev switch, read per call)
+  // D = 64 takes this kernel form by default since round 3 (588-609 TFLOP/s at the config-3 chunk against 533 for the
+  // 16x16 kernel of rx_extend.hip with 64 queries per wave); RX_EXT_D256_AT64=0 turns it off
+  const char* e64 = getenv("RX_EXT_D256_AT64");
+  const bool at64 = !(e64 && atoi(e64) == 0);
+  if (!((dk == 256 && dv == 256) || (dk == 192 && (dv == 128 || dv == 192)) || (at128 && dk == 128 && dv == 128) ||
+        (at64 && dk == 64 && dv == 64)) || p->kv.kv_fp8)
     return false;
   if (p->sinks || p->custom_mask || p->xai_temperature_len > 0 || p->unified_prefix_lens || p->q_pack > 1 ||
       p->window_kv_offsets)
@@ -713,7 +721,8 @@ int launch_extend_d256(const rx_extend_params* p, hipStream_t s) {
   } while (0)
 #define RX_D256_DIMS(TT, EX_)                                 \
   do {                                                        \
-    if (dk == 128) RX_D256(TT, 128, 128, EX_);                \
+    if (dk == 64) RX_D256(TT, 64, 64, EX_);                   \
+    else if (dk == 128) RX_D256(TT, 128, 128, EX_);           \
     else if (dk == 256) RX_D256(TT, 256, 256, EX_);           \
     else if (dv == 128) RX_D256(TT, 192, 128, EX_);           \
     else RX_D256(TT, 192, 192, EX_);                          \

@@ -164,8 +164,9 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   const bool active = rbase < R;
 
   vec8 qf[KS];
-  const uint32_t hq_magic = static_cast<uint32_t>(0x100000000ull / static_cast<uint32_t>(a.hq)) + 1u;
-  auto row_tok = [&](int m) { return static_cast<int32_t>(__umulhi(static_cast<uint32_t>(m), hq_magic)); };
+  // (one q head: 2^32 / 1 has no 32-bit magic -- the identity; see rx_extend_d256.hip)
+  const uint32_t hq_magic = a.hq == 1 ? 0u : static_cast<uint32_t>(0x100000000ull / static_cast<uint32_t>(a.hq)) + 1u;
+  auto row_tok = [&](int m) { return a.hq == 1 ? m : static_cast<int32_t>(__umulhi(static_cast<uint32_t>(m), hq_magic)); };
   {
     const int m = rbase + r;
     const bool ok = m < R;

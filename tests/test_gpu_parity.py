@@ -481,17 +481,21 @@ def test_extend_generic_head_dims(ops, d):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("dk,dv", [(256, 256), (192, 128), (192, 192), (96, 96)])
 @pytest.mark.parametrize("variant", ["plain", "window", "window_100_noncausal", "cap", "cap_sinks_noncausal", "hnd_pool",
-                                     "short_extends", "max_jumps"])
+                                     "short_extends", "max_jumps", "mha"])
 def test_extend_mfma_other_head_dims(ops, dtype, dk, dv, variant):
     """rx::extend_nd_kernel (MFMA 16x16x32 for head dims 256 / 192+128 / 192 / 96 -- the shapes the reference retunes
     for gfx950, extend_attention.py:66-77, and the MLA prefill shape) vs the fp64 oracle: ragged batch with zero /
     tile-crossing prefixes and extends, GQA, LSE; sliding window; logit cap + sinks + non-causal; a paged HND pool."""
     rng = np.random.default_rng(dk + dv)
-    hq, hkv = 8, 2
+    # ("mha": one q head per kv head -- Gemma-7B-class -- takes the row -> token map of the 256-row kernels through its
+    # G = 1 case, which has no 32-bit multiply-high magic; found broken in round 3)
+    hq, hkv = (4, 4) if variant == "mha" else (8, 2)
     pre = np.array([0, 16, 33, 200, 5, 64], dtype=np.int32)
     # the longest extend picks the kernel form: > 64 (Dv > 128) / > 128 rows -> eight waves and 64-token tiles for
     # Dk > 128, else the four-wave form ("short_extends" runs every head dim through that one)
     ext = np.array([1, 32, 50, 140, 129, 64] if variant != "short_extends" else [1, 32, 50, 40, 29, 64], dtype=np.int32)
+    if variant == "mha":
+        ext = np.array([1, 32, 50, 300, 129, 257], dtype=np.int32)  # (> 128 rows per kv head: the 256-row kernel)
     bs, T = len(pre), int(ext.sum())
     total = int((pre + ext).sum())
     ps = 16
