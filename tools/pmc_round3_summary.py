@@ -42,7 +42,7 @@ JOBS = [
     ("r03_extend32_sq_counters.json", "ext32", "extend_mfma32_kernel", "python3 bench.py --extend-only (config-3 chunk, D = 128, the dispatched eight-wave kernel)"),
     ("r03_extend_pw_sq_counters.json", "pw", "extend_pw_kernel", "RX_EXT_PW=2 python3 bench.py --extend-only (the one-wave-per-SIMD kernel, forced)"),
     ("r03_extend_d256_sq_counters.json", "dims", "extend_d256_kernel<rx::BF16, 256", "DIMS=256x256,64x64,192x128 python3 tools/extend_dims.py (config-3 chunk at D = 256)"),
-    ("r03_extend_d64_sq_counters.json", "dims", "extend_mfma_kernel<rx::BF16, 64", "the same run, D = 64 (config 0's head dim)"),
+    ("r03_extend_d64_sq_counters.json", "dims", "extend_d256_kernel<rx::BF16, 64", "the same run, D = 64 (config 0's head dim; since late round 3 on the D = 256 kernel's template)"),
     ("r03_mla_decode_fp8_sq_counters.json", "mla8", "decode_mla8", "PS=64 FP8=1 python3 tools/mla_bench.py (config-5 shard shape, fp8 rows)"),
     ("r03_mla_decode_bf16_sq_counters.json", "mla16", "decode_mla_kernel", "PS=64 python3 tools/mla_bench.py (16-bit rows)"),
 ]
