@@ -663,8 +663,10 @@ bool extend_d256_supports(const rx_extend_params* p) {
   // 16x16 kernel of rx_extend.hip with 64 queries per wave); RX_EXT_D256_AT64=0 turns it off
   const char* e64 = getenv("RX_EXT_D256_AT64");
   const bool at64 = !(e64 && atoi(e64) == 0);
+  const char* e96 = getenv("RX_EXT_D256_AT96");
+  const bool at96 = !(e96 && atoi(e96) == 0);
   if (!((dk == 256 && dv == 256) || (dk == 192 && (dv == 128 || dv == 192)) || (at128 && dk == 128 && dv == 128) ||
-        (at64 && dk == 64 && dv == 64)) || p->kv.kv_fp8)
+        (at64 && dk == 64 && dv == 64) || (at96 && dk == 96 && dv == 96)) || p->kv.kv_fp8)
     return false;
   if (p->sinks || p->custom_mask || p->xai_temperature_len > 0 || p->unified_prefix_lens || p->q_pack > 1 ||
       p->window_kv_offsets)
@@ -722,6 +724,7 @@ int launch_extend_d256(const rx_extend_params* p, hipStream_t s) {
 #define RX_D256_DIMS(TT, EX_)                                 \
   do {                                                        \
     if (dk == 64) RX_D256(TT, 64, 64, EX_);                   \
+    else if (dk == 96) RX_D256(TT, 96, 96, EX_);              \
     else if (dk == 128) RX_D256(TT, 128, 128, EX_);           \
     else if (dk == 256) RX_D256(TT, 256, 256, EX_);           \
     else if (dv == 128) RX_D256(TT, 192, 128, EX_);           \
