@@ -685,9 +685,9 @@ def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=8):
 
 def extend_head_dims(args, dev):
     """The same config-3 chunk at the other head dims the reference tunes for gfx950 (extend_attention.py:66-77):
-    64, 256, and the MLA prefill shape 192 / 128."""
+    64, 256, and the MLA prefill shape 192 / 128; plus 96 (Phi-3-class heads)."""
     res = {}
-    for name, d, dv in (("d64", 64, 64), ("d256", 256, 256), ("d192_v128", 192, 128)):
+    for name, d, dv in (("d64", 64, 64), ("d96", 96, 96), ("d256", 256, 256), ("d192_v128", 192, 128)):
         try:
             r = extend_bench(args, dev, 1, d, dv, nchunks=3)
             res[name] = {"tflops": r["tflops"], "ms_per_chunk": r["ms_per_chunk"], "frac": r["roofline"]["frac"]}
