@@ -91,6 +91,7 @@ struct ExtD256Args {
   int32_t bs, hkv, group, mblocks;
   float sm_scale, k_scale, v_scale, logit_cap;
   int32_t causal, skip_prefix, skip_extend, window;  // window <= 0: off
+  const float* sinks;  // fp32 [Hq] or null
 };
 
 typedef __attribute__((address_space(3))) const u32x4* y_lds_u32x4;
@@ -637,8 +638,10 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
     l += __shfl_xor(l, 32);
     const int m = rbase + 16 * c + r;
     if (m >= R) continue;
-    const float inv = 1.0f / l;
     const int32_t tk = m / G, hd = kvh * G + (m - tk * G);
+    float den = l;
+    if (a.sinks) den += fast_exp2(a.sinks[hd] * kLog2e - m_run[c]);  // attention sinks join the softmax sum (extend_attention.py:633-635)
+    const float inv = 1.0f / den;
     uint16_t* op = a.o + (qo0 + tk) * a.o_stride_t + hd * a.o_stride_h + 4 * g;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   }
 }
 
-// what the kernel serves: head dims 256 / 256 on a 16-bit pool, no window / cap / sinks / mask / unified form, aligned
+// what the kernel serves: head dims 256 / 256 (192, 96, 64) on a 16-bit pool, no tree mask / unified form / Grok temperature, aligned
 // tensors, and extends long enough to fill 256-row workgroups (short ones: rx_extend_nd.hip's smaller blocks)
 bool extend_d256_supports(const rx_extend_params* p) {
   const int dk = p->head_dim, dv = p->v_head_dim;
@@ -668,8 +671,7 @@ bool extend_d256_supports(const rx_extend_params* p) {
   if (!((dk == 256 && dv == 256) || (dk == 192 && (dv == 128 || dv == 192)) || (at128 && dk == 128 && dv == 128) ||
         (at64 && dk == 64 && dv == 64) || (at96 && dk == 96 && dv == 96)) || p->kv.kv_fp8)
     return false;
-  if (p->sinks || p->custom_mask || p->xai_temperature_len > 0 || p->unified_prefix_lens || p->q_pack > 1 ||
-      p->window_kv_offsets)
+  if (p->custom_mask || p->xai_temperature_len > 0 || p->unified_prefix_lens || p->q_pack > 1 || p->window_kv_offsets)
     return false;
   const int64_t all = p->q_stride_t | p->q_stride_h | p->k_stride_t | p->k_stride_h | p->v_stride_t | p->v_stride_h |
                       p->kv.k_page_stride | p->kv.k_tok_stride | p->kv.k_head_stride | p->kv.v_page_stride |
@@ -712,6 +714,7 @@ int launch_extend_d256(const rx_extend_params* p, hipStream_t s) {
   a.sm_scale = p->sm_scale; a.k_scale = p->k_scale; a.v_scale = p->v_scale; a.logit_cap = p->logit_cap;
   a.causal = p->is_causal; a.skip_prefix = p->skip_prefix; a.skip_extend = p->skip_extend;
   a.window = p->sliding_window_size;
+  a.sinks = p->sinks;
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hkv * a.mblocks;
 #define RX_D256(TT, DK_, DV_, EX_)                                                                                     \
   do {                                                                                                               \
