@@ -1,4 +1,5 @@
-"""Dev probe that found the G = 1 row -> token bug of the 256-row extend kernels: q picks score 0 for every key, V[t] = t, so\nrow t of a causal extend must be mean(0..t); RX_EXT_D256_AT64 selects the kernel.  python tools/probe/causal_probe_d64.py"""
+"""Dev probe that found the G = 1 row -> token bug of the 256-row extend kernels: q picks score 0 for every key, V[t] = t, so
+row t of a causal extend must be mean(0..t); RX_EXT_D256_AT64 selects the kernel.  python tools/probe/causal_probe_d64.py"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sglang_amd import ops
