@@ -33,6 +33,9 @@ namespace rx {
 #ifndef RX_D256_PADS
 #define RX_D256_PADS 0
 #endif
+#ifndef RX_D256_ABL
+#define RX_D256_ABL 0
+#endif
 #ifndef RX_D256_TBL
 #define RX_D256_TBL 1   // DMA issue from a per-tile row-pointer table in LDS (0: slot lookup + address math per piece)
 #endif
@@ -425,8 +428,12 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   const bool late = w >= 4;  // the SIMD partner of an early wave: issues its pieces behind its first QK^T
 
   for (int t = t_begin; t < nt; ++t) {
+#if !(RX_D256_ABL & 1)  // dev ablations (results are wrong): 1 = no landing wait, 2 = no barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
+#endif
+#if !(RX_D256_ABL & 2)
     __syncthreads();                                   // everybody's have; everybody is done with tile t - 1
+#endif
     if (t % TPB == 0 && (t / TPB + 1) * kYSlotBlock < nt1 * kYTT) stage_slots(t / TPB + 1);
 #if RX_D256_TBL
     if (t + 2 < nt) build_table(t + 2);  // read by tile t + 2's issue, which runs behind the next barrier
