@@ -206,3 +206,25 @@ def test_backend_cascades_per_radix_node_when_the_scheduler_hands_the_nodes_over
     got = o.view(bs, hq, d).float().cpu().numpy().astype(np.float64)
     assert hs.pool.check_errors() == 0
     parity.check(np.abs(got - want).max(), 1.5e-2, None)
+
+
+def test_rounds_rule_of_the_balanced_schedule_host_mirror():
+    """ops.balanced_kv_splits_host with wg_target_mixed = -1 (the mirror of rx_num_kv_splits_balanced's rounds rule; the
+    device kernel is held to it in tests/test_gpu_backend.py): pieces of R x the mean unsplit length when the first pass
+    needs R >= 2 rounds of workgroups, the first pass itself otherwise, never finer than the first pass."""
+    from sglang_amd import ops
+
+    first = lambda lens, mt=1024: ops.balanced_kv_splits_host(lens, 32, 8, 64, 512, mt)  # noqa: E731
+    rr = lambda lens, mt=1024: ops.balanced_kv_splits_host(lens, 32, 8, 64, 512, mt, -1)  # noqa: E731
+    skew = [32768] + [1024] * 63
+    assert first(skew)[0] == 22 and rr(skew)[0] == 16 and (rr(skew)[1:] == 1).all()      # 680 workgroups = 2 rounds: 2 x 1 k pieces
+    one_round = [16384] * 2 + [2048] * 30
+    assert (rr(one_round) == first(one_round)).all()                                    # 432 workgroups fit at once: unchanged
+    uniform = [4096] * 16
+    assert (rr(uniform) == first(uniform)).all() and (rr(uniform) == 4).all()           # not mixed: unchanged
+    tiny = [30000] * 20 + [16]
+    assert (rr(tiny, 128) <= first(tiny, 128)).all()                                    # a tiny unsplit request does not shred the rest
+    ragged = [32768] + np.random.default_rng(2).integers(300, 2000, size=63).tolist()
+    a, b = first(ragged), rr(ragged)
+    assert b[0] <= a[0] and (b[1:] == a[1:]).all() and int(b.sum()) <= int(a.sum())
+    assert (rr([]) == first([])).all() and rr([0, 0]).tolist() == [1, 1]
