@@ -517,7 +517,7 @@ class HipRadixAttnBackend:
                 mixed = three and bool((host_counts > 1).any() and (host_counts == 1).any())
                 items = ops.SplitItems(host_pairs if host_pairs is not None else bs * S_cap, self.device).build(
                     num_kv_splits, order, wgs_per_cu=3 if mixed else 0)
-        if items is not None and self._debug_checks:  # RX_DEBUG_CHECKS=1 (a host sync): the table holds every live pair
+        if items is not None and self._debug_checks and not torch.cuda.is_current_stream_capturing():  # RX_DEBUG_CHECKS=1 (a host sync): the table holds every live pair
             live = int(items.count.item())
             if live > items.cap:
                 raise AssertionError(f"split items: {live} live (request, split) pairs > the table's {items.cap}")
@@ -891,7 +891,8 @@ class HipRadixAttnBackend:
             o = torch.empty_like(q)
         # the KV store of the step rides in the decode launch when the kernel can take it (see _fused_store_ok)
         fuse = save_kv_cache and k is not None and self._fused_store_ok(layer, k, v)
-        if fuse and self._debug_checks and forward_batch.out_cache_loc is not None:
+        if (fuse and self._debug_checks and forward_batch.out_cache_loc is not None
+                and not torch.cuda.is_current_stream_capturing()):  # (a host sync: not inside a graph capture)
             slot = self.req_to_token[forward_batch.req_pool_indices.long(), forward_batch.seq_lens.long() - 1]
             if not torch.equal(slot.long(), forward_batch.out_cache_loc.long().view(-1)):
                 raise AssertionError("fused decode store: req_to_token[req, seq_len - 1] != out_cache_loc "
