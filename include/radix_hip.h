@@ -24,9 +24,10 @@
 extern "C" {
 #endif
 
-/* 8 (round 3): rx_split_items; rx_decode_params.split_items / split_items_count / split_items_cap /
+/* 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
+ * 8 (round 3): rx_split_items; rx_decode_params.split_items / split_items_count / split_items_cap /
  * split_items_wgs_per_cu and extra_index / extra_rows; rx_num_kv_splits_balanced gained wg_target_mixed. */
-#define RX_ABI_VERSION 8
+#define RX_ABI_VERSION 9
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -48,6 +49,21 @@ int rx_version(void);
  * stale library next to newer host code (or the reverse) fails loudly instead of reading a shifted layout. */
 int64_t rx_abi_sizeof(int which);
 const char* rx_last_error(void);
+
+/* ---- dispatch switches and introspection (round 4; no reference counterpart: the reference picks its Triton
+ * configs inside extend_attention_fwd / decode_attention_fwd, extend_attention.py:664-812, decode_attention.py:968-1044).
+ * rx_extend_attn / rx_decode_attn choose a kernel instance from the call's shapes.  rx_last_dispatch() names the
+ * instance the calling thread's last such call launched, spelled as the instance's own symbol demangles --
+ * "extend_mfma32_kernel<rx::BF16, long, false, false, 8, false, true, 4>", optionally followed by "|" and run-time
+ * facts ("|paged,g4"); "" before the first call.  tests/test_dispatch_coverage.py lists the attention-kernel instances
+ * in the library's symbol table and fails if one of them has no parity case that provably ran it.
+ * The few process-wide switches that override the default choice (A/B of kernel forms) are named ints: set through
+ * rx_set_option, read once from RX_OPT_<NAME> at load -- the launch path itself never reads the environment.
+ * Names: ext32_autopack, ext32_small_wg, ext32_plain, extend_16x16_d128, extend_d256, extend_d256_at128,
+ * extend_d256_at64, extend_d256_at96, extend_nd, extend_nd_big, extend_mla, extend_mla_shared_v, decode_mla8_dma. */
+const char* rx_last_dispatch(void);
+int rx_set_option(const char* name, int value);
+int rx_get_option(const char* name, int* value);
 
 /* ---- K1: KV store -------------------------------------------------------------------
  * store_cache (kernels/ops/kvcache/kvcache.py:57-110) -> store_kvcache

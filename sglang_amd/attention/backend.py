@@ -165,6 +165,8 @@ class HipRadixAttnBackend:
             raise ValueError(f"split_policy must be 'native' or 'reference', got {split_policy}")
         self.split_policy = split_policy
         self.native_split_cap = 32
+        # graph replay: upper bound of the fp32 kv-split partials [bs, Hq, slots, Dv] kept address-stable (bytes)
+        self.graph_partials_budget = int(getattr(sa, "rx_graph_partials_budget", 256 << 20) or (256 << 20))
         # workgroups the native schedule aims for: one per CU for the dense kernel (four independent waves
         # each); two per CU for the MLA kernel, whose four waves share one staged tile (config-5 shape:
         # 256 workgroups 157 us, 512 workgroups 134 us)
@@ -217,6 +219,7 @@ class HipRadixAttnBackend:
         self.cascade_min_bs, self.cascade_min_shared = int(cascade_min_bs), int(cascade_min_shared)
         self._cascade = None
         self._cascade_on = False
+        self._groups_plan_cache = None    # (node ids, groups) of the last tree plan
         self._cascade_groups = None       # ops.CascadeGroups: several prefixes (forward_batch.radix_last_nodes / cascade_groups)
         self._cascade_call = None
         self.cascade_min_members = 4      # a group of fewer requests re-reads its prefix instead
@@ -343,11 +346,31 @@ class HipRadixAttnBackend:
         or a group that is only part of the batch."""
         groups = getattr(fb, "cascade_groups", None)
         nodes = getattr(fb, "radix_last_nodes", None)
+        lens = None if fb.seq_lens_cpu is None else fb.seq_lens_cpu.tolist()
         if groups is None and nodes is not None and self._kv_head_dim_ok_for_groups():
             from ..mem_cache.radix_cache import plan_shared_prefix_groups
-            lens = None if fb.seq_lens_cpu is None else fb.seq_lens_cpu.tolist()
-            groups = plan_shared_prefix_groups(nodes, lens, min_shared=self.cascade_min_shared,
-                                               min_members=self.cascade_min_members)
+            # the tree plan is O(bs * depth) host Python: re-used while the batch's nodes (and the lengths' floor,
+            # which only grows during decode) are the ones it was made for
+            key = tuple(getattr(n, "id", None) if getattr(n, "id", None) is not None else id(n) for n in nodes)
+            cached = self._groups_plan_cache
+            if cached is not None and cached[0] == key and (lens is None or all(
+                    L < min(lens[i] for i in m) for m, L in cached[1])):
+                groups = cached[1]
+            else:
+                groups = plan_shared_prefix_groups(nodes, lens, min_shared=self.cascade_min_shared,
+                                                   min_members=self.cascade_min_members)
+                self._groups_plan_cache = (key, groups)
+        elif groups is not None and lens is not None:
+            # caller-supplied groups: a shared length must leave every member a non-empty suffix (the step's own row)
+            checked = []
+            for m, L in groups:
+                m = [int(i) for i in m]
+                if any(i < 0 or i >= bs for i in m):
+                    raise ValueError(f"cascade_groups: member rows {m} outside the batch of {bs}")
+                L = min(int(L), min(lens[i] for i in m) - 1)
+                if L >= 1 and len(m) >= 1:
+                    checked.append((m, L))
+            groups = checked
         if not groups or not self._kv_head_dim_ok_for_groups():
             return None
         groups = groups[: 32]
@@ -372,13 +395,19 @@ class HipRadixAttnBackend:
             # several shared prefixes (one per radix-tree node), or one that only part of the batch shares
             if self._cascade_groups is None:
                 kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
-                self._cascade_groups = ops.CascadeGroups(
-                    self.req_to_token_pool.size, self.num_head, self.num_kv_head, kb.shape[-1], self._q_dtype(kb),
-                    self.device, max_shared_total=max(self.req_to_token.shape[1], self.cascade_groups_max_shared),
-                    cu_count=self.device_core_count, max_kv_splits=self.native_split_cap)
-            self._cascade_groups.plan(self.req_to_token, fb.req_pool_indices, fb.seq_lens, groups)
-            self._cascade_on, self._cascade_call = True, self._cascade_groups
-            return ForwardMetadata(None, None, None, None, None, None, None, 1)
+                try:
+                    self._cascade_groups = ops.CascadeGroups(
+                        self.req_to_token_pool.size, self.num_head, self.num_kv_head, kb.shape[-1], self._q_dtype(kb),
+                        self.device, max_shared_total=max(self.req_to_token.shape[1], self.cascade_groups_max_shared),
+                        cu_count=self.device_core_count, max_kv_splits=self.native_split_cap)
+                except torch.OutOfMemoryError:
+                    # created on the first grouped step, after the KV pool took its share of the memory: without room
+                    # for the gathered queries / partials the batch takes the plain path (same results)
+                    self._cascade_groups = False
+            if self._cascade_groups:
+                self._cascade_groups.plan(self.req_to_token, fb.req_pool_indices, fb.seq_lens, groups)
+                self._cascade_on, self._cascade_call = True, self._cascade_groups
+                return ForwardMetadata(None, None, None, None, None, None, None, 1)
         if self._cascade_on:
             if self._cascade is None:
                 kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
@@ -504,7 +533,12 @@ class HipRadixAttnBackend:
         else:
             num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
             attn_logits, attn_lse = self._scratch(bs, S)
-        ops.get_num_kv_splits_balanced(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S_cap, wg_target,
+        # The device schedule takes the cap the HOST mirror ran with: under the rounds rule the cap feeds
+        # the round tests, so a device pass with the smaller cap S_cap = max(host counts) can stop at a smaller R and hand
+        # out MORE pairs than the host counted -- the table and grid sized from host_pairs would then leave the shortest
+        # requests without a workgroup.  With one cap the two are the same integer arithmetic (max = S_cap <= S slots).
+        ops.get_num_kv_splits_balanced(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head,
+                                       cap if host_pairs is not None else S_cap, wg_target,
                                        min_tokens_per_split=min_tokens, wg_target_mixed=wg_mixed)
         order = self._request_order(fb, bs, use_graph_bufs, force=True)
         # the grid holds the LIVE (request, split) pairs only, longest requests first (rx_decode_params.split_items): with
@@ -532,6 +566,17 @@ class HipRadixAttnBackend:
         wgpr = self.num_kv_head * ((group + 15) // 16)
         return min(bs * slots, bs + -(-3 * self.device_core_count // wgpr) + 1)
 
+    def _decode_honours_split_items(self) -> bool:
+        """rx_decode_attn reads the (request, split) table only in its MFMA kernel (head dims 64 / 96 / 128 / 256 with
+        equal k and v dims); every other layer shape replays the bs x slots grid, where an unused slot IS a dead
+        workgroup."""
+        try:
+            kb = self.token_to_kv_pool.get_key_buffer(getattr(self.token_to_kv_pool, "start_layer", 0))
+            dk = int(kb.shape[-1])
+        except Exception:
+            return False
+        return dk == self.v_head_dim and dk in (64, 96, 128, 256)
+
     def _graph_split_slots(self, bs: int) -> int:
         """Split slots of a graph-replayed dense decode step: enough for a small batch to fill the chip, and at least 8
         so that a long request in a large batch can still be cut (the counts themselves are refilled on the device
@@ -539,10 +584,15 @@ class HipRadixAttnBackend:
         group = max(1, self.num_head // self.num_kv_head)
         blocks = max(1, bs * self.num_kv_head * ((group + 15) // 16))
         S = max(8, min(self.native_split_cap, -(-2 * self.device_core_count // blocks)))
-        if not self._is_mla_pool and not self._no_split_items:
-            # the live-pairs grid: a slot nobody uses costs nothing (no dead workgroup), so every batch size keeps the
-            # full cap -- the long request of a mixed batch is cut as finely under graph replay as in an eager step
-            S = max(S, self.native_split_cap)
+        if not self._is_mla_pool and not self._no_split_items and self._decode_honours_split_items():
+            # the live-pairs grid: a slot nobody uses costs nothing (no dead workgroup), so a batch keeps the full cap --
+            # the long request of a mixed batch is cut as finely under graph replay as in an eager step -- while the
+            # fp32 partials [bs, Hq, slots, Dv] stay inside graph_partials_budget (512 requests x 64 heads x
+            # 32 slots x 128 x 4 B = 537 MB): halve the slots (never below 8) until they fit
+            S_full = max(S, self.native_split_cap)
+            while S_full > max(S, 8) and bs * self.num_head * S_full * self.v_head_dim * 4 > self.graph_partials_budget:
+                S_full //= 2
+            S = max(S, S_full)
         if self._merge_counters is not None and S % 8 and bs * self.num_head * ((S + 7) // 8 * 8) * self.v_head_dim * 4 <= (4 << 20):
             S = (S + 7) // 8 * 8
         return S

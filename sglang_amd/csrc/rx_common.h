@@ -15,6 +15,30 @@ namespace rx {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 
+// ---- dispatch switches and the dispatch record ---------------------------------------------------------------
+// Everything that picks a kernel instance beyond the call's own arguments lives in ONE struct, filled once when the
+// library is loaded (defaults; RX_OPT_<NAME> in the environment at load time overrides one) and changed only through
+// rx_set_option() -- the launch path reads plain ints, never the environment.  Tests flip switches through
+// rx_set_option and learn which instance a call took from rx_last_dispatch().
+struct Options {
+  int ext32_autopack = 1;     // long causal GQA-4 / GQA-8 extends at D = 128 pack their rows by themselves
+  int ext32_small_wg = -1;    // D = 128 workgroup form: -1 by the tile estimate, 0 always eight waves, 1 always four
+  int ext32_plain = 1;        // PLAIN instances (features compile-time off) when the call uses none of them
+  int extend_16x16_d128 = 0;  // the 16x16x32 kernel of rx_extend.hip for plain D = 128 calls (A/B of the two shapes)
+  int extend_d256 = 1;        // the AGPR / LDS-DMA template (256, 192, 96, 64) where it supports the call
+  int extend_d256_at128 = 0;  // ... instantiated at 128 / 128 (A/B against rx_extend32)
+  int extend_d256_at64 = 1;   // ... at 64 / 64 (0: extend_mfma_kernel)
+  int extend_d256_at96 = 1;   // ... at 96 / 96 (0: extend_nd_kernel)
+  int extend_nd = 1;          // extend_nd_kernel for the other head dims
+  int extend_nd_big = 1;      // its eight-wave form for Dk > 128
+  int extend_mla = 1;         // the latent (576 / 512) extend kernel
+  int extend_mla_shared_v = 1;  // V^T read from the K image when v aliases k[..., :512]
+  int decode_mla8_dma = 1;    // fp8 latent rows through the LDS-DMA kernel (0: upcast-while-staging form)
+};
+Options& options();
+// name of the kernel instance the calling thread's last rx_extend_attn / rx_decode_attn launched (rx_last_dispatch)
+void note_dispatch(const char* fmt, ...);
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(RX_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
@@ -82,6 +106,16 @@ struct F16 {
     return __builtin_bit_cast(uint16_t, static_cast<_Float16>(f));
   }
 };
+
+// template arguments as c++filt prints them: the dispatch record names an instance the way its symbol does
+template <typename T>
+inline const char* tname() {
+  if constexpr (std::is_same_v<T, BF16>) return "rx::BF16";
+  else if constexpr (std::is_same_v<T, F16>) return "rx::F16";
+  else if constexpr (std::is_same_v<T, int64_t>) return "long";
+  else return "int";
+}
+inline const char* tbool(bool b) { return b ? "true" : "false"; }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;

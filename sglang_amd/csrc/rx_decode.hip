@@ -792,6 +792,12 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
     const unsigned grid = a.items ? static_cast<unsigned>(a.items_cap) * a.hkv * a.qblocks
                                   : static_cast<unsigned>(a.bs) * a.hkv * a.qblocks * a.max_kv_splits;
     if (grid == 0) return RX_OK;
+    {
+      const bool occ3 = a.items && a.items_occ3 && dk == 128 && !a.kv_fp8;
+      note_dispatch("decode_mfma_kernel<%s, %d, %s, %s, %s, %s, %s>|%s,%s", tname<T>(), dk, tname<IdxT>(), tbool(LINEAR),
+                    tbool(a.kv_fp8 != 0), tbool(a.k_new != nullptr && !a.kv_fp8), tbool(occ3), a.items ? "pairs" : "slots",
+                    a.kv_indices ? "indices" : "req_to_token");
+    }
 #define RX_DEC(DD, K8, FU) \
   hipLaunchKernelGGL((decode_mfma_kernel<T, DD, IdxT, LINEAR, K8, FU>), dim3(grid), dim3(256), 0, s, a)
     if (a.items && a.items_occ3 && dk == 128 && !a.kv_fp8) {  // a mixed batch's schedule: three workgroups per CU
@@ -816,6 +822,7 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
                   dk, dv);
     if (dv > 512) return fail(RX_ERR_UNSUPPORTED, "rx_decode_attn: v_head_dim %d > 512", dv);
     const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.max_kv_splits;
+    note_dispatch("decode_generic_kernel<%s, %s, %s>|dk%d,dv%d", tname<T>(), tname<IdxT>(), tbool(LINEAR), dk, dv);
     hipLaunchKernelGGL((decode_generic_kernel<T, IdxT, LINEAR>), dim3(grid), dim3(64),
                        dk * sizeof(float), s, a, dk, dv);
   }

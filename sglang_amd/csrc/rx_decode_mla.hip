@@ -52,12 +52,6 @@ struct MlaArgs {
   int32_t direct_single;    // a request with one kv split writes its final output from stage 1 (see rx_decode.hip)
 };
 
-#ifndef RX_MLA_STAMP
-#define RX_MLA_STAMP 0  // 1: diagnostic build, s_memtime phase stamps overwrite the split's first partial row
-#endif
-#ifndef RX_MLA_SPLIT_S
-#define RX_MLA_SPLIT_S 1  // 1: the four waves split the score block and exchange partial sums; 0: each wave computes all of it
-#endif
 #ifndef RX_MLA_PD
 #define RX_MLA_PD 4  // K-fragment prefetch distance (LDS reads in flight ahead of the MFMA)
 #endif
@@ -99,9 +93,6 @@ __device__ __forceinline__ int64_t mla_slot_off(int64_t slot, int32_t page_size,
 
 // KV8: the latent rows are fp8 e4m3fn (576 B); they are upcast (exact) while being staged, so the LDS
 // image and everything after it is the 16-bit kernel's.
-#ifndef RX_MLA_FP8_SINGLE_BUF
-#define RX_MLA_FP8_SINGLE_BUF 1
-#endif
 // fp8 rows carry half the bytes per tile through the same per-tile compute path, so that path -- a chain of
 // latency-bound steps (LDS round trips, the score exchange, the softmax dependency chain) at two waves per SIMD --
 // sets the rate, not HBM (round 1: 4.0-4.3 TB/s against 5.1 for 16-bit rows).  The fp8 instance therefore keeps ONE
@@ -109,7 +100,7 @@ __device__ __forceinline__ int64_t mla_slot_off(int64_t slot, int32_t page_size,
 // flight and a third wave per SIMD to fill the bubbles, for one more barrier per tile.
 template <bool KV8>
 struct MlaBuf {
-  static constexpr int NBUF = (KV8 && RX_MLA_FP8_SINGLE_BUF) ? 1 : 2;
+  static constexpr int NBUF = KV8 ? 1 : 2;
   static constexpr int WGS = NBUF == 1 ? 3 : 2;  // workgroups per CU (= waves per SIMD) to allocate registers for
 };
 
@@ -122,7 +113,7 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
   constexpr int KS = kMlaDk / 32;       // 18 k-steps
   constexpr int NBW = kMlaDv / 16 / 4;  // 8 d-blocks of 16 per wave
   // two staged tiles + (split-S form) the 4 x 1 KiB exchange of partial score blocks
-  __shared__ __attribute__((aligned(16))) char smem[NBUF * kMlaTile * kMlaLdsRow + (RX_MLA_SPLIT_S ? 4 * 64 * 16 : 0)];
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * kMlaTile * kMlaLdsRow + 4 * 64 * 16];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -196,8 +187,8 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
   // token block (w & 1) over k-steps [9 (w >> 1), +9) -- and the partial sums are exchanged through LDS, so
   // a wave issues 9 MFMAs (and keeps 9 Q fragments) instead of the 36 / 18 of the redundant form.  The sum
   // is taken in one fixed order, so every wave still holds bitwise-identical scores.
-  constexpr int KSW = RX_MLA_SPLIT_S ? KS / 2 : KS;  // k-steps whose Q fragments this wave keeps
-  const int ks0 = RX_MLA_SPLIT_S ? KSW * (w >> 1) : 0;
+  constexpr int KSW = KS / 2;  // k-steps whose Q fragments this wave keeps
+  const int ks0 = KSW * (w >> 1);
   vec8 qf[KSW];
   {
     const uint16_t* qp = a.q + b * a.q_stride_t + (q_valid ? h : 0) * a.q_stride_h + 8 * g + 32 * ks0;
@@ -289,19 +280,6 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
   }
   __syncthreads();
 
-#if RX_MLA_STAMP
-  uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
-  uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
-#define MLA_STAMP(i)                                               \
-  do {                                                             \
-    const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();  \
-    st_acc[i] += now_ - st_prev;                                   \
-    st_prev = now_;                                                \
-  } while (0)
-#else
-#define MLA_STAMP(i)
-#endif
-  MLA_STAMP(5);
   const int qd = r >> 2, pp = r & 3;
   for (int t0 = 0; t0 < ntiles; t0 += DEPTH) {
 #pragma unroll
@@ -314,7 +292,6 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
     // a 16x16x32 MFMA 16; hipcc left alone reads two ahead and the in-order wave then waits on LDS
     // before nearly every one of the 36 MFMAs (measured: ~10k cycles per tile, every pipe < 25 % busy).
     f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#if RX_MLA_SPLIT_S
     {
       constexpr int PD = KSW < RX_MLA_PD ? KSW : RX_MLA_PD;
       u32x4 kf[KSW];
@@ -333,30 +310,6 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
       sacc[0] = xch[0 * 64 + lane] + xch[2 * 64 + lane];
       sacc[1] = xch[1 * 64 + lane] + xch[3 * 64 + lane];
     }
-#else
-    {
-      constexpr int NF = 2 * KS, PD = KV8 ? 2 * RX_MLA_PD : RX_MLA_PD;  // fp8 rows leave 18 registers for it (+5 %)
-      u32x4 kf[NF];
-      const char* kb0 = kt + r * kMlaLdsRow + g * 16;
-      auto kload = [&](int i) {  // i = 2 s + bb
-        return *reinterpret_cast<const u32x4*>(kb0 + (i & 1) * 16 * kMlaLdsRow + (i >> 1) * 64);
-      };
-#pragma unroll
-      for (int i = 0; i < PD; ++i) kf[i] = kload(i);
-#pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        if (i + PD < NF) kf[i + PD] = kload(i + PD);
-        sacc[i & 1] = T::mfma(__builtin_bit_cast(vec8, kf[i]), qf[i >> 1], sacc[i & 1]);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
-#pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        if (i + PD < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      }
-    }
-#endif
-    MLA_STAMP(0);
     // ---- online softmax (identical in all four waves) -----------------------------------------------
     float sv[8];
     const int tok_base = lo + t * kMlaTile + 4 * g;
@@ -401,7 +354,6 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) oacc[nb] *= alpha;
     }
-    MLA_STAMP(1);
     // ---- O^T[128w + ...] += V^T P^T, V = columns [0,512) of the staged rows -------------------------
     {
       const char* rp0 = kt + (4 * g + qd) * kMlaLdsRow + (128 * w) * 2 + 8 * pp;
@@ -414,22 +366,16 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
         oacc[nb] = T::mfma(av, pf, oacc[nb]);
       }
     }
-    MLA_STAMP(2);
     // ---- stage the next tile into the other buffer -------------------------------------------------
     if constexpr (NBUF == 1) __syncthreads();  // every wave has read tile t: its buffer may be overwritten
     if (t + 1 < ntiles) {
       write_lds((t + 1) % NBUF, stg[(u + 1) % DEPTH]);
-#if RX_MLA_STAMP == 2
-      MLA_STAMP(5);  // finer diagnostic: slot 5 = the LDS write (incl. its vmcnt waits), 3 = the re-issue
-#endif
       if (t + 1 + DEPTH < ntiles) {
         issue_loads(stg[(u + 1) % DEPTH]);
         if (t + 2 + DEPTH < ntiles) load_slots(t + 2 + DEPTH);
       }
     }
-    MLA_STAMP(3);
     __syncthreads();
-    MLA_STAMP(4);
    }
   }
 
@@ -463,12 +409,6 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
         if (a.merge_counters) store_dev(a.attn_lse + row, m_run * kLn2 + __logf(l_run));
         else a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
       }
-#if RX_MLA_STAMP
-      if (w == 0 && lane == 0) {
-        uint32_t* dbg = reinterpret_cast<uint32_t*>(a.attn_logits + row * kMlaDv);
-        for (int i = 0; i < 6; ++i) dbg[i] = st_acc[i];
-      }
-#endif
     }
     if (a.merge_counters) mla_merge_if_last<T>(a, b, qb, seq_len, splits);
   }
@@ -504,12 +444,6 @@ constexpr int kM8Cpr = kM8Row / 16;            // 37 chunks per row (36 data + 1
 constexpr int kM8HalfShift = 64;
 constexpr int kM8Pieces = 20;                  // 1-KiB DMA pieces per tile buffer: 5 per wave (18.5 carry data)
 constexpr int kM8Buf = kM8Pieces * 1024;       // 20 KB
-#ifndef RX_M8_DBG
-#define RX_M8_DBG 0  // dev: 1 = DMA and waits only, 2 = compute only (no DMA in the loop); results are wrong
-#endif
-#ifndef RX_M8_SPREAD
-#define RX_M8_SPREAD 1  // the five DMA pieces of a tile are issued in three places of the iteration (0: in one) -- the issue stalls on the full memory queue, and three short stalls overlap the partner workgroup better than one long one
-#endif
 #ifndef RX_M8_RING
 #define RX_M8_RING 3  // tile buffers; RING - 1 tiles are in flight or resident ahead of the one being read
 #endif
@@ -519,19 +453,8 @@ constexpr int kM8SlotBlock = 1024;             // tokens whose slot ids are stag
 constexpr int kM8Lds = kM8Ring * kM8Buf + 4 * 64 * 16 + 2 * kM8SlotBlock * 4;
 
 // one 1-KiB LDS-DMA piece: lane l's 16 bytes land at lds_dst + 16 l (recipe: cdna_hip_programming.md 5.7)
-#ifndef RX_M8_M0_RESTORE
-#define RX_M8_M0_RESTORE 0  // 1: save / restore M0 around every piece (the guide's recipe).  The restore waits until the DMA has consumed M0: tools/probe/dma_issue.hip, +60-100 cycles per piece.  hipcc uses M0 for nothing else in this kernel (checked in the ISA).
-#endif
 __device__ __forceinline__ void m8_dma16(const void* gsrc, uint32_t lds_dst) {
-#if RX_M8_M0_RESTORE
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-#else
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
-#endif
 }
 
 template <typename T, typename IdxT, bool LINEAR>
@@ -683,10 +606,6 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
   const float c2 = (capped ? kLog2e : a.sm_scale * kLog2e) * xai;
   const int bb_w = w & 1;
   const int i16 = lane & 15;
-#if RX_MLA_STAMP
-  uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
-  uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
-#endif
 
   for (int t = 0; t < ntiles; ++t) {
     // tile t has landed (ours: all but the 5 youngest pieces = tile t+1's; everybody's: the barrier)
@@ -694,26 +613,15 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
     else if constexpr (kM8Ahead == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     __syncthreads();
-    MLA_STAMP(0);  // landing wait + barrier
     const char* kt = smem + (t % kM8Ring) * kM8Buf;
     // next slot block, one block ahead of the DMA that will read it (rare: every 32 tiles)
     if ((t & 31) == 0 && (t / 32 + 1) * kM8SlotBlock < hi - lo + (kM8Ahead + 2) * kMlaTile) {
       stage_slots(t / 32 + 1);  // published by the exchange barrier below; first read at iteration 32 k + 31 - kM8Ahead - 1
     }
     // tile t+2 -> the buffer tile t-1 was read from (every wave is past this iteration's barrier, i.e. done with t-1)
-#if RX_M8_DBG != 2
-#if RX_M8_SPREAD
     dma_addr();
     dma_pieces(t + kM8Ahead, 0, 2);
-#else
-    dma_tile(t + kM8Ahead);
-#endif
     read_slots(t + kM8Ahead + 1);  // for the next iteration's issue
-#endif
-#if RX_M8_DBG == 1
-    continue;
-#endif
-    MLA_STAMP(1);  // DMA issue
 
     // ---- partial S^T of this wave: token block bb_w, k-steps [ks0, ks0 + 9)
     f32x4 sacc[2];
@@ -734,15 +642,11 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
       const f32x4 part = part3[0] + part3[1] + part3[2];
       f32x4* xch = reinterpret_cast<f32x4*>(xch_base);
       xch[w * 64 + lane] = part;
-      MLA_STAMP(2);  // K fragments, upcast, score MFMAs
       __syncthreads();
       sacc[0] = xch[0 * 64 + lane] + xch[2 * 64 + lane];
       sacc[1] = xch[1 * 64 + lane] + xch[3 * 64 + lane];
-      MLA_STAMP(3);  // exchange barrier
     }
-#if RX_M8_SPREAD && RX_M8_DBG != 2
     dma_pieces(t + kM8Ahead, 2, 4);
-#endif
     // ---- online softmax (identical in all four waves); score (bb, i) of this lane is token 8 g + 4 bb + i
     float sv[8];
 #pragma unroll
@@ -780,10 +684,7 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) oacc[nb] *= alpha;
     }
-#if RX_M8_SPREAD && RX_M8_DBG != 2
     dma_pieces(t + kM8Ahead, 4, NP);
-#endif
-    MLA_STAMP(4);  // softmax
     // ---- O^T[128 w + ...] += V^T P^T: one transposed byte read per fragment (rows 8 g .. 8 g + 7), upcast, MFMA
     {
       const char* vp = kt + (8 * g + (i16 >> 1)) * kM8Row + (g >= 2 ? kM8HalfShift : 0) + 128 * w + 8 * (i16 & 1);
@@ -795,7 +696,6 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
         oacc[nb] = T::mfma(av, pf, oacc[nb]);
       }
     }
-    MLA_STAMP(5);  // PV
   }
   // nothing of this workgroup may still be landing in LDS when the block retires
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -830,12 +730,6 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
         if (a.merge_counters) store_dev(a.attn_lse + row, m_run * kLn2 + __logf(l_run));
         else a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
       }
-#if RX_MLA_STAMP
-      if (w == 0 && lane == 0) {
-        uint32_t* dbg = reinterpret_cast<uint32_t*>(a.attn_logits + row * kMlaDv);
-        for (int i = 0; i < 6; ++i) dbg[i] = st_acc[i];
-      }
-#endif
     }
     if (a.merge_counters) mla_merge_if_last<T>(a, b, qb, seq_len, splits);
   }
@@ -888,7 +782,13 @@ int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, int di
   const unsigned pairs = static_cast<unsigned>(a.bs) * a.max_kv_splits;
   const unsigned grid = (pairs + 7) / 8 * 8 * a.qblocks;  // whole groups of 8 pairs (one per XCD)
   const bool kv8 = p->kv.kv_fp8 != 0;
-  static const bool old8 = getenv("RX_MLA8_OLD") != nullptr;  // dev: the upcast-while-staging form for fp8 rows
+  const bool old8 = !options().decode_mla8_dma;  // (A/B switch: the upcast-while-staging form for fp8 rows)
+  if (kv8 && !old8)
+    note_dispatch("decode_mla8_dma_kernel<%s, %s, %s>", p->dtype == RX_BF16 ? "rx::BF16" : "rx::F16", idx64 ? "long" : "int",
+                  tbool(linear));
+  else
+    note_dispatch("decode_mla_kernel<%s, %s, %s, %s>", p->dtype == RX_BF16 ? "rx::BF16" : "rx::F16", idx64 ? "long" : "int",
+                  tbool(linear), tbool(kv8));
 #define RX_MLA_L(TT, IT, LIN)                                                                          \
   do {                                                                                                 \
     if (kv8 && !old8) {                                                                                \

@@ -541,6 +541,11 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
     const bool vs = a.v_scale != 1.0f;
     const bool plain = a.window <= 0 && a.logit_cap <= 0.f;
     if (dk == 64) {
+      {
+        const bool cb4 = plain && !vs && a.mblocks >= 4 && RX_EXT_CB == 2;
+        note_dispatch("extend_mfma_kernel<%s, 64, %s, %s, %s, %s, %d>", tname<T>(), tname<IdxT>(), tbool(LINEAR),
+                      tbool(vs), tbool(plain), cb4 ? 4 : 2);
+      }
       if (plain && !vs && a.mblocks >= 4 && RX_EXT_CB == 2) {  // (>= 4 blocks of 128 rows: extends past 384 tokens)
         // long extends: 64 queries per wave (a.mblocks counts 128-row blocks: two of them per workgroup)
         ExtendArgs b = a;
@@ -555,12 +560,14 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
         else hipLaunchKernelGGL((extend_mfma_kernel<T, 64, IdxT, LINEAR, false>), dim3(grid), dim3(256), 0, s, a);
       }
     } else {
+      note_dispatch("extend_mfma_kernel<%s, 128, %s, %s, %s, false, 2>", tname<T>(), tname<IdxT>(), tbool(LINEAR), tbool(vs));
       if (vs) hipLaunchKernelGGL((extend_mfma_kernel<T, 128, IdxT, LINEAR, true>), dim3(grid), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((extend_mfma_kernel<T, 128, IdxT, LINEAR, false>), dim3(grid), dim3(256), 0, s, a);
     }
   } else {
     if (dv > 512) return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: v_head_dim %d > 512", dv);
     const unsigned grid = static_cast<unsigned>(total_q * a.hq);
+    note_dispatch("extend_generic_kernel<%s, %s, %s>|dk%d,dv%d", tname<T>(), tname<IdxT>(), tbool(LINEAR), dk, dv);
     hipLaunchKernelGGL((extend_generic_kernel<T, IdxT, LINEAR>), dim3(grid), dim3(64),
                        dk * sizeof(float), s, a, dk, dv, (const int32_t*)nullptr);
   }
@@ -568,8 +575,6 @@ static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, h
 }
 
 int launch_extend32(const rx_extend_params* p, hipStream_t s);  // rx_extend32.hip (D = 128)
-bool extend_pw_supports(const rx_extend_params* p);               // rx_extend_pw.hip (D = 128 plain call, 4 waves x 64 rows)
-int launch_extend_pw(const rx_extend_params* p, hipStream_t s);
 bool extend_nd_supports(int dk, int dv);                          // rx_extend_nd.hip (256/256, 192/128, ...)
 int launch_extend_nd(const rx_extend_params* p, hipStream_t s);
 bool extend_d256_supports(const rx_extend_params* p);              // rx_extend_d256.hip (256 / 256, AGPR accumulators, LDS-DMA tiles)
@@ -580,10 +585,6 @@ int launch_extend_mla(const rx_extend_params* p, hipStream_t s);
 }  // namespace rx
 
 using namespace rx;
-
-#ifndef RX_EXT_PW_DEFAULT
-#define RX_EXT_PW_DEFAULT 0  // until the four-wave kernel is parity-green and faster on the GPU: opt-in
-#endif
 
 // total_q for the generic path is bs * max_extend_len (an upper bound); blocks past the real
 // token count exit early.
@@ -635,31 +636,24 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
     RX_REQUIRE(p->num_q_heads == p->num_kv_heads * p->q_pack, "rx_extend_attn: q_pack = %d must be Hq / Hkv = %d / %d",
                p->q_pack, p->num_q_heads, p->num_kv_heads);
   }
-  // D = 128, the plain call, enough tiles per workgroup to amortise a 256-row workgroup's prologue: four waves x 64 rows
-  // (rx_extend_pw.hip).  RX_EXT_PW: 0 never, 2 whenever the kernel supports the call (tests), default = by the estimate.
-  if (((dk == 128 && dv == 128 && getenv("RX_EXT_D256_AT128")) || (dk == 64 && dv == 64)) &&
-      extend_d256_supports(p)) {  // the 16x16x32 AGPR / LDS-DMA form at D = 64 (default) / 128 (dev switch)
+  // Dispatch (switches: rx_set_option, read here as plain ints).  D = 64 and, as an A/B switch, D = 128 on the
+  // 16x16x32 AGPR / LDS-DMA template; D = 128 on the 32x32x16 kernel; the other MFMA head dims; the latent MLA shape;
+  // everything else on the generic kernel below.
+  const Options& opt = options();
+  if (((dk == 128 && dv == 128 && opt.extend_d256_at128) || (dk == 64 && dv == 64)) && opt.extend_d256 &&
+      extend_d256_supports(p)) {
     const int rc = launch_extend_d256(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }
-  if (mfma_ok && dk == 128 && o16 && extend_pw_supports(p)) {
-    const char* pw_env = getenv("RX_EXT_PW");  // read per call: tests flip it inside one process
-    const int pw_mode = pw_env ? atoi(pw_env) : RX_EXT_PW_DEFAULT;
-    const int est_tiles = (p->avg_kv_len_hint + p->max_extend_len / 2) / 64;
-    if (pw_mode == 2 || (pw_mode == 1 && est_tiles >= 28 && p->max_extend_len > 128)) {
-      const int rc = launch_extend_pw(p, static_cast<hipStream_t>(stream));
-      return rc != RX_OK ? rc : check_launch("rx_extend_attn");
-    }
-  }
-  if (mfma_ok && dk == 128 && o16 && (p->q_pack > 1 || p->kv.kv_fp8 || extras || !getenv("RX_EXTEND_16X16"))) {  // 32x32x16 fast path
+  if (mfma_ok && dk == 128 && o16 && (p->q_pack > 1 || p->kv.kv_fp8 || extras || !opt.extend_16x16_d128)) {  // 32x32x16 fast path
     const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }
-  if (extend_d256_supports(p) && !getenv("RX_EXTEND_NO_D256")) {
+  if (opt.extend_d256 && extend_d256_supports(p)) {
     const int rc = launch_extend_d256(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }
-  if (!extras && !p->kv.kv_fp8 && p->q_pack <= 1 && extend_nd_supports(dk, dv) && !getenv("RX_EXTEND_NO_ND")) {
+  if (!extras && !p->kv.kv_fp8 && p->q_pack <= 1 && extend_nd_supports(dk, dv) && opt.extend_nd) {
     // MFMA 16x16x32 kernel for the other head dims, when the tensors allow 16-byte row chunks
     const int64_t all = p->q_stride_t | p->q_stride_h | p->k_stride_t | p->k_stride_h | p->v_stride_t | p->v_stride_h |
                         p->kv.k_page_stride | p->kv.k_tok_stride | p->kv.k_head_stride | p->kv.v_page_stride |
@@ -672,7 +666,7 @@ extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
       return rc != RX_OK ? rc : check_launch("rx_extend_attn");
     }
   }
-  if (extend_mla_supports(p) && !getenv("RX_EXTEND_NO_MLA")) {
+  if (opt.extend_mla && extend_mla_supports(p)) {
     const int rc = launch_extend_mla(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }

@@ -21,37 +21,9 @@
 // one block under the softmax VALU of the other); boundary tiles take a plain masked path.
 #include "rx_common.h"
 
+
 #ifndef RX_EXT32_SMALL_WG_TILES
 #define RX_EXT32_SMALL_WG_TILES 28  // below this many estimated tiles per workgroup: 128-query workgroups
-#endif
-#ifndef RX_EXT32_FINE
-#define RX_EXT32_FINE 0  // 1: eight-wave form on the fine-grained (one softmax unit per MFMA) two-tile-deep pipeline
-#endif
-#ifndef RX_EXT32_KA
-#define RX_EXT32_KA 2  // K fragments (ds_read_b128) in flight ahead of their QK^T MFMA in the eight-wave fast loop
-#endif
-#ifndef RX_EXT32_PRIO
-#define RX_EXT32_PRIO 0
-#endif
-#ifndef RX_EXT32_DEEP
-// Deeper-pipeline experiments of round 2, all measured SLOWER than the default at config 3 and therefore off (same box,
-// TFLOP/s): 0 default 784-815 | 2 ring of three tiles written two ahead 793-802 | 1 the same + the next tile's first
-// K fragments read before its barrier 781-792 | 3 the ring + waves 4-7 taking their barrier after the QK^T group
-// (half-tile stagger of the SIMD partners) 763-770: QK^T group 1779 -> 1130 cycles, but the PV groups grow by more.
-#define RX_EXT32_DEEP 0
-#endif
-#ifndef RX_EXT32_JUMPT
-#define RX_EXT32_JUMPT 1  // 1: jump test instead of the per-block max exchange in the plain eight-wave fast loop (see sm_slice)
-#endif
-#ifndef RX_EXT32_STAMP
-#define RX_EXT32_STAMP 0  // 1: diagnostic build with s_memtime phase stamps (tools/ext_stamps.py); outputs are clobbered
-#endif
-
-#ifndef RX_EXT32_PADV
-#define RX_EXT32_PADV 0
-#endif
-#ifndef RX_EXT32_PADS
-#define RX_EXT32_PADS 0
 #endif
 namespace rx {
 
@@ -123,45 +95,16 @@ __device__ __forceinline__ f32x16 mfma32<F16>(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// O^T accumulators held in AGPRs (the 64-queries-per-wave form, QB == 2): at one wave per SIMD a wave owns 512
-// registers, but VALU instructions only address v0..v255.  hipcc given 128 accumulator registers on top of
-// the Q fragments and score tiles keeps shuffling them through v_accvgpr moves (755 in the loop); here the PV
-// MFMAs are written as inline asm with the accumulator pinned to the "a" class, so it never leaves the AGPR
-// half and only the (rare) rescale and the epilogue read it.  hipcc's hazard recogniser does not see through
-// inline asm: acc_settle() supplies the wait states of "XDL write -> VALU read" (and back) by hand.
-template <typename T, bool AG>
+
+template <typename T>
 __device__ __forceinline__ void pv_mfma(u32x4 a, u32x4 b, f32x16& c) {
-  if constexpr (AG) {
-    if constexpr (std::is_same_v<T, BF16>)
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    else
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-  } else {
-    c = mfma32<T>(__builtin_bit_cast(typename T::vec8, a), __builtin_bit_cast(typename T::vec8, b), c);
-  }
+  c = mfma32<T>(__builtin_bit_cast(typename T::vec8, a), __builtin_bit_cast(typename T::vec8, b), c);
 }
-// QK^T step: S^T (+)= K fragment x Q fragment.  AG: the Q fragments live in AGPRs as well (MFMA reads its B
-// operand from either half; they are loaded once and never touched by VALU), the score tile stays in VGPRs.
-template <typename T, bool AG, bool FIRST>
+// QK^T step: S^T (+)= K fragment x Q fragment
+template <typename T, bool FIRST>
 __device__ __forceinline__ void qk_mfma(u32x4 k, const typename T::vec8& q, f32x16& sc) {
-  if constexpr (AG) {
-    const u32x4 qr = __builtin_bit_cast(u32x4, q);
-    if constexpr (std::is_same_v<T, BF16>) {
-      if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sc) : "v"(k), "a"(qr));
-      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sc) : "v"(k), "a"(qr));
-    } else {
-      if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(sc) : "v"(k), "a"(qr));
-      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(sc) : "v"(k), "a"(qr));
-    }
-  } else {
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    sc = mfma32<T>(__builtin_bit_cast(typename T::vec8, k), q, FIRST ? zero16 : sc);
-  }
-}
-template <bool AG, int N>
-__device__ __forceinline__ void acc_settle(f32x16 (&o)[N]) {
-  static_assert(N == 4, "one 128-wide O^T block row");
-  if constexpr (AG) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0]), "+a"(o[1]), "+a"(o[2]), "+a"(o[3]));
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  sc = mfma32<T>(__builtin_bit_cast(typename T::vec8, k), q, FIRST ? zero16 : sc);
 }
 
 // This file is compiled with -fno-honor-nans (sglang_amd/build.py): with NaNs honoured hipcc
@@ -188,8 +131,8 @@ __device__ __forceinline__ float half_swap_max(float x) {
 // GQA walks fewer tiles packed -- a 256-row block is 64 tokens x 4 heads instead of 256 tokens of one head, so its
 // diagonal is one boundary tile instead of four -- but the general instance that used to serve q_pack lost that to its
 // scalars; with the factor a constant (row -> token is a shift) the packed call keeps the PLAIN loop.
-template <typename T, typename IdxT, bool LINEAR, bool VSCALE, int NW, int QB, bool KV8, bool PLAIN, int PKC = 0>
-__global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel(const Ext32Args a_in) {
+template <typename T, typename IdxT, bool LINEAR, bool VSCALE, int NW, bool KV8, bool PLAIN, int PKC = 0>
+__global__ __launch_bounds__(64 * NW, 2) void extend_mfma32_kernel(const Ext32Args a_in) {
   static_assert(PKC == 0 || PLAIN, "a constant packing factor goes with the PLAIN instance");
   Ext32Args a = a_in;
   if constexpr (PLAIN) {
@@ -207,30 +150,10 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;  // prefix pool element
   constexpr int KS = kD / 16;                  // 8 k-steps of the QK^T product
   constexpr int DB = kD / 32;                  // 4 output d blocks of 32
-  constexpr bool AG = QB > 1;                  // O^T accumulators pinned to AGPRs (pv_mfma)
-  // FINE: the two-tile-deep pipeline with ONE softmax unit behind EVERY MFMA (written for the AGPR form) also for the
-  // eight-wave form: its 7 slices of ~13 VALU behind the MFMAs of two of the four groups overflow a 32-cycle MFMA gap
-  // (the other two groups' gaps stay empty), 16 units of 1-2 exp spread the same work over all 32 gaps
-  constexpr bool FINE = AG || (RX_EXT32_FINE && NW == 8);
   constexpr int THREADS = 64 * NW;
   constexpr int RPP = THREADS / 16;            // rows staged per pass
   constexpr int NPASS = kTok / RPP;            // 2 (NW=8) or 4 (NW=4)
-  constexpr int QPW = 32 * QB;                 // queries per wave: QB blocks of 32
-  // DEEP (eight-wave form): tiles are written TWO ahead into a ring of three, so tile t+1 is complete one barrier
-  // early and a wave reads its first K fragments of tile t+1 BEFORE barrier t+1 -- the QK^T group then starts on
-  // registers instead of waiting out an LDS round trip with both waves of the SIMD stalled the same way.
-  constexpr bool RING3 = !FINE && NW == 8 && RX_EXT32_DEEP >= 1;
-  constexpr bool DEEP = RING3 && RX_EXT32_DEEP == 1;   // cross-barrier K prefetch on top of the deeper ring
-  // STAGGER: with tiles complete one barrier early, the second-dispatched half of the workgroup (waves 4-7, the
-  // SIMD partners of waves 0-3) takes its one barrier per tile AFTER the QK^T group instead of before it.  Same
-  // code, same barrier count -- but after every release one wave of a SIMD is in its matrix-heavy group while its
-  // partner is in a softmax-heavy one, instead of both queueing on the matrix pipe and then both on VALU issue
-  // (MI355X_MICROARCH.md, Two waves per SIMD, item 9).  Legal because tile t is complete at barrier t-1 (written
-  // during tile t-2) and tile t-1's last reads (the late half's PV groups) precede barrier t, after which tile
-  // t+2 overwrites its buffer.
-  constexpr bool STAGGER = RING3 && RX_EXT32_DEEP == 3;
-  constexpr int AHEAD = RING3 ? 2 : 1;         // tile t + AHEAD is written during tile t
-  constexpr int RING = (FINE || RING3) ? 3 : 2;   // LDS tile ring (the AG pipeline reads tile t-1's V after barrier t)
+  constexpr int QPW = 32;                      // queries per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
 
   const int tid = threadIdx.x;
@@ -267,13 +190,8 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const int32_t qbase = qb0 + w * QPW;
   const bool active = qbase < E;
   const IdxT* idx = reinterpret_cast<const IdxT*>(a.kv_indices) + kv0;
-  // this lane's queries (index inside the extend part): one per 32-query block
-  int m[QB];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) m[qb] = qbase + 32 * qb + ql;
-  int mp[QB];  // token index (position inside the extend part) of the lane's query row
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) mp[qb] = pack == 1 ? m[qb] : m[qb] / pack;
+  const int m = qbase + ql;                      // this lane's query row (index inside the extend part)
+  const int mp = pack == 1 ? m : m / pack;       // its token (position inside the extend part)
 
   // K8 unified form: the kv list holds prefix + new tokens; q_off = the query's distance from list start
   const bool unified = a.unified_prefix != nullptr;
@@ -286,46 +204,31 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const bool mask_prefix = masked && (unified || !a.skip_prefix_mask);
   const bool causal_in_list = unified && a.causal && !masked;  // the causal rule applies inside the kv list
   // Grok temperature: per-query multiplier of the scaled scores (1 when off)
-  float xai[QB];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    xai[qb] = 1.0f;
-    const int32_t qidx = q_off + mp[qb];
+  float xai = 1.0f;
+  {
+    const int32_t qidx = q_off + mp;
     if (a.xai_len > 0) {
       if (unified) {  // extend_attention.py:940-946
-        if (qidx >= a.xai_len) xai[qb] = static_cast<float>(a.xai_len) / (static_cast<float>(qidx) + 1.0f);
+        if (qidx >= a.xai_len) xai = static_cast<float>(a.xai_len) / (static_cast<float>(qidx) + 1.0f);
       } else if (qidx > a.xai_len) {  // :336-343
-        xai[qb] = __log2f(static_cast<float>(qidx)) / __log2f(static_cast<float>(a.xai_len));
+        xai = __log2f(static_cast<float>(qidx)) / __log2f(static_cast<float>(a.xai_len));
       }
     }
   }
 
   // ---- Q^T fragments: lane (q, h) holds Q[q][16 ks + 8 h .. +8] ------------------------------------
-  vec8 qf[QB][KS];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const bool ok = m[qb] < E;
-    const int32_t tk = ok ? mp[qb] : 0, gq = ok ? m[qb] - mp[qb] * pack : 0;
+  vec8 qf[KS];
+  {
+    const bool ok = m < E;
+    const int32_t tk = ok ? mp : 0, gq = ok ? m - mp * pack : 0;
     const uint16_t* qp = a.q + (qo0 + tk) * a.q_stride_t + (head * pack + gq) * a.q_stride_h + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       u32x4 raw = ok ? *reinterpret_cast<const u32x4*>(qp + 16 * ks) : u32x4{0, 0, 0, 0};
-      qf[qb][ks] = __builtin_bit_cast(vec8, raw);
+      qf[ks] = __builtin_bit_cast(vec8, raw);
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // Q landed before the loop (see rx_extend.hip)
-  if constexpr (AG) {
-    // re-define every Q fragment as an AGPR-class value: with the loads' VGPR-class definitions hipcc copies a
-    // fragment into a fresh AGPR tuple in front of EVERY asm use (4 v_accvgpr_write per QK^T MFMA, in the loop)
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        u32x4 t = __builtin_bit_cast(u32x4, qf[qb][ks]);
-        asm volatile("" : "+a"(t));
-        qf[qb][ks] = __builtin_bit_cast(vec8, t);
-      }
-  }
 
   const bool no_ext = a.skip_extend || a.unified_prefix != nullptr;  // unified: every key comes from the pool
   const int32_t p_len = a.skip_prefix ? 0 : P;
@@ -386,16 +289,6 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       }
     }
   };
-  // one staged chunk (piece i < NPASS: K row chunk i; else V row chunk i - NPASS) -> LDS
-  auto write_lds_piece = [&](int buf, bool from_pool, int piece) {
-    const bool is_v = piece >= NPASS;
-    const int i = is_v ? piece - NPASS : piece;
-    char* dst = smem + buf * kBufBytes + (is_v ? kKTile + st_row * kVStride : st_row * kKStride) + st_chunk * 16 +
-                i * RPP * (is_v ? kVStride : kKStride);
-    const u32x4 raw = is_v ? stg_v[i] : stg_k[i];
-    if (KV8 && from_pool) *reinterpret_cast<u32x4*>(dst) = fp8x8_to_16<T>(u32x2{raw[0], raw[1]});
-    else *reinterpret_cast<u32x4*>(dst) = raw;
-  };
   auto write_lds = [&](int buf, bool from_pool) {  // from_pool: the staged tile is a prefix tile
     char* kt = smem + buf * kBufBytes + st_row * kKStride + st_chunk * 16;
     char* vt = smem + buf * kBufBytes + kKTile + st_row * kVStride + st_chunk * 16;
@@ -414,17 +307,12 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     }
   };
 
-  f32x16 oacc[QB][DB];
-  float m_run[QB], l_run[QB];
+  f32x16 oacc[DB];
+  float m_run = -INFINITY, l_run = 0.f;
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    m_run[qb] = -INFINITY;
-    l_run[qb] = 0.f;
+  for (int db = 0; db < DB; ++db)
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) oacc[qb][db][i] = 0.f;
-  }
+    for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
 
   // sliding window (plain lists only: no tree mask, unified list or window offsets): tiles wholly below the
   // workgroup's first row's bound are never staged (rx_extend.hip)
@@ -438,20 +326,10 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
     load_idx_tile(t0);
     issue_loads(t0);
     if (nt > t0 + 1) load_idx_tile(t0 + 1);
-    write_lds(t0 % RING, t0 < nt1);
+    write_lds(t0 % 2, t0 < nt1);
     if (nt > t0 + 1) {
       issue_loads(t0 + 1);
       if (nt > t0 + 2) load_idx_tile(t0 + 2);
-    }
-    if constexpr (RING3) {  // one more tile in the ring, one more in flight
-      if (nt > t0 + 1) {
-        write_lds((t0 + 1) % RING, t0 + 1 < nt1);
-        if (nt > t0 + 2) {
-          issue_loads(t0 + 2);
-          if (nt > t0 + 3) load_idx_tile(t0 + 3);
-        }
-      }
-      __syncthreads();  // tiles 0 and 1 are complete: from here on tile t is readable after barrier t - 1
     }
   }
 
@@ -463,16 +341,11 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   const bool capped = a.logit_cap > 0.f;
 
   // K fragment (block b, k-step ks): lane (ql, h) <- K[32 b + ql][16 ks + 8 h .. +8]
-#ifndef RX_EXT32_ABL
-#define RX_EXT32_ABL 0  // dev ablations of the fast loop (results are garbage): 1 no softmax slices, 2 no LDS fragment reads, 4 no staging
-#endif
   auto load_k = [&](const char* tile, int b, int ks) {
-    if constexpr ((RX_EXT32_ABL & 2) != 0) return u32x4{(uint32_t)b, (uint32_t)ks, 0x3c003c00u, 0x3c003c00u};
     return *reinterpret_cast<const u32x4*>(tile + kaddr + b * 32 * kKStride + ks * 32);
   };
   // V^T fragments of k-step `step` (16 tokens): rows 16 step + 4 h + qd (+8), d block db
   auto load_v1 = [&](const char* tile, int step, int db) {
-    if constexpr ((RX_EXT32_ABL & 2) != 0) return u32x4{(uint32_t)step, (uint32_t)db, 0x3c003c00u, 0x3c003c00u};
     const u32x2 lo2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64);
     const u32x2 hi2 = T::ds_read_tr(tile + vaddr + step * 16 * kVStride + db * 64 + 8 * kVStride);
     return u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
@@ -532,302 +405,25 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   // and tile t+2's global loads are re-issued at once, so they have this whole tile to land
   auto tile_sync_and_stage = [&](int t) {
     __syncthreads();
-    if (t + AHEAD < nt) {
-      write_lds((t + AHEAD) % RING, t + AHEAD < nt1);
-      if (t + AHEAD + 1 < nt) {
-        issue_loads(t + AHEAD + 1);
-        if (t + AHEAD + 2 < nt) load_idx_tile(t + AHEAD + 2);
+    if (t + 1 < nt) {
+      write_lds((t + 1) % 2, t + 1 < nt1);
+      if (t + 2 < nt) {
+        issue_loads(t + 2);
+        if (t + 3 < nt) load_idx_tile(t + 3);
       }
     }
   };
 
-#if RX_EXT32_STAMP
-  uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
-#define RX_STAMP(i)                                                   \
-  do {                                                                \
-    const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();     \
-    st_acc[i] += now_ - st_prev;                                      \
-    st_prev = now_;                                                   \
-  } while (0)
-  uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
-#else
-#define RX_STAMP(i)
-#endif
-
   // The two tile bodies live in two separate inner loops (runs of fast tiles, runs of boundary
   // tiles): with both bodies inside one loop hipcc's allocator spills 147 registers, each alone fits.
   // Waves of one workgroup may be in different loops at the same t; every tile is one barrier either way.
-#if RX_EXT32_PRIO
-  // static priority for the second-dispatched half (MI355X_MICROARCH.md, Two waves per SIMD, item 4)
-  if (w >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
   int t = t0;
   while (t < nt) {
-
-    if constexpr (FINE) {
-      // ===== one wave per SIMD (QB = 2): a two-tile-deep pipeline with ONE small filler behind EVERY MFMA.
-      // A single in-order wave hides VALU work only inside the 32-cycle shadow of the MFMA it follows (about
-      // 24 cycles of issue; MI355X_MICROARCH.md 'vector-instruction ISSUE cost'): two MFMAs back to back just
-      // wait out the first, and a VALU lump behind the second overflows its gap.  So the softmax of one
-      // (query block, 32-key block) is cut into 16 units -- two of row max, two for the reference max, twelve
-      // with one or two exp each -- and dealt over the 16 MFMAs of that query block in the two following groups:
-      //   G1  QK^T block 0 of tile t    | units 8-15 of block 1, tile t-1
-      //   G2  QK^T block 1 of tile t    | units 0-7  of block 0, tile t   (+ V^T reads of tile t-1)
-      //   G3  PV   block 1 of tile t-1  | units 8-15 of block 0, tile t   (+ tile t+1 registers -> LDS)
-      //   G4  PV   block 0 of tile t    | units 0-7  of block 1, tile t   (+ tile t+2 global loads)
-      // Tile t-1's V rows are read after barrier t, hence the ring of three tiles.  A run of fast tiles starts
-      // from a DUMMY predecessor (scores -inf: P = 0, max and sum unchanged; its PV multiplies this tile's V
-      // rows by zero) instead of a peeled iteration and ends with a drain (units 8-15 + PV of the last block 1).
-      f32x16 s0[QB], s1[QB];
-      u32x4 pk0[QB][2], pk1[QB][2];
-      u32x4 vfa[DB], vfb[DB];
-      float ma0[QB], mb0[QB], ma1[QB], mb1[QB], m0[QB], m1[QB], alpha0[QB], alpha1[QB];
-      float ps0[QB][2], ps1[QB][2];
-      // elements (of the 16 per lane) finished by unit u >= 4:  2 1 1 2 1 1 2 1 1 2 1 1
-      auto sm_unit = [&](int u, int qb, f32x16& sc, float& ma, float& mb, float m_prev, float& m_new, float& alpha,
-                         float (&ps)[2], u32x4 (&pk)[2], float c2u, float vs) {
-        const float c2 = c2u * xai[qb];
-        if (u == 0) {
-          ma = max3f(sc[0], sc[1], sc[2]);
-          mb = max3f(sc[3], sc[4], sc[5]);
-          ma = max3f(ma, sc[6], sc[7]);
-          mb = max3f(mb, sc[8], sc[9]);
-          asm volatile("" ::"v"(ma), "v"(mb));
-        } else if (u == 1) {
-          ma = max3f(ma, sc[10], sc[11]);
-          mb = max3f(mb, sc[12], sc[13]);
-          ma = max3f(ma, sc[14], sc[15]);
-          ma = max2f(ma, mb);
-          asm volatile("" ::"v"(ma));
-        } else if (u == 2) {
-          float mt = half_swap_max(ma) * c2;
-          ma = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
-          asm volatile("" ::"v"(ma));
-        } else if (u == 3) {
-          const float m_cand = max2f(m_prev, ma);
-          m_new = (m_cand - m_prev > kMaxSlack) ? m_cand : m_prev;  // thresholded running max, see the QB = 1 body
-          alpha = fast_exp2(m_prev - m_new);
-          ps[0] = ps[1] = 0.f;
-          asm volatile("" ::"v"(m_new), "v"(alpha));
-        } else {
-          const int k3 = (u - 4) / 3, r3 = (u - 4) % 3;
-          const int e0 = 4 * k3 + (r3 == 0 ? 0 : r3 + 1), ne = r3 == 0 ? 2 : 1;
-          asm volatile("" : "+v"(m_new));  // input-side anchor: keeps the unit where it is written
-          float v[2];
-#pragma unroll
-          for (int i = 0; i < ne; ++i) {
-            v[i] = fast_exp2(__builtin_fmaf(sc[e0 + i], c2, -m_new));
-            ps[(e0 + i) & 1] += v[i];
-            if constexpr (VSCALE) v[i] *= vs;
-          }
-          // scores become P in place (the score registers are dead after this unit); pairs (2p, 2p+1) are packed
-          // by the unit that finishes the odd element
-#pragma unroll
-          for (int i = 0; i < ne; ++i) sc[e0 + i] = v[i];
-          const int elast = e0 + ne - 1;
-          if (elast & 1) {
-            const int pi = elast >> 1;
-            pk[pi >> 2][pi & 3] = pack2<T>(sc[elast - 1], sc[elast]);
-            asm volatile("" ::"v"(pk[pi >> 2][pi & 3]), "v"(ps[0]), "v"(ps[1]));
-          } else {
-            asm volatile("" ::"v"(sc[elast]), "v"(ps[0]), "v"(ps[1]));
-          }
-        }
-      };
-      auto rescale = [&](int qb, float alpha) {
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-          acc_settle<AG>(oacc[qb]);
-#pragma unroll
-          for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha;
-          acc_settle<AG>(oacc[qb]);
-        }
-      };
-      // first tile >= t that is not fast, inside t's segment (prefix or new tokens); tile t itself is fast.
-      // Closed form of tile_info().fast: the tile-independent conditions hold (tile t passed them), the rest is
-      // "both blocks inside the visible range".
-      auto fast_run_end = [&](int t0) {
-        int lim, base;
-        if (t0 < nt1) {
-          lim = causal_in_list ? min(p_len, q_off + qbase + 1) : p_len;
-          base = 0;
-        } else {
-          lim = a.causal ? min(Ek, qbase / pack + 1) : Ek;
-          base = nt1;
-        }
-        const int end = base + lim / kTok;
-        return min(min(end, t0 < nt1 ? nt1 : nt), nt - 3);
-      };
-      while (t + 3 < nt) {
-        const TileInfo ti0 = tile_info(t);
-        if (!ti0.fast) break;
-        const int run_end = max(fast_run_end(t), t + 1);  // tile t itself is fast by tile_info
-        const float c2r = ti0.c2, vsr = ti0.vs;
-        // dummy predecessor: block 1 of "tile t-1" with every score -inf, units 0-7 done
-        const char* tile_p = smem + (t % RING) * kBufBytes;
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) s1[qb][i] = -INFINITY;
-          m0[qb] = m_run[qb];
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            sm_unit(u, qb, s1[qb], ma1[qb], mb1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], c2r, vsr);
-        }
-        for (; t < run_end; ++t) {
-          RX_STAMP(5);
-          __syncthreads();
-          RX_STAMP(0);
-          const char* tile = smem + (t % RING) * kBufBytes;
-          // ---- G1: QK^T(b0, t) | units 8-15 of (b1, t-1)
-          {
-            u32x4 kf[KS];
-            kf[0] = load_k(tile, 0, 0);
-            kf[1] = load_k(tile, 0, 1);
-#pragma unroll
-            for (int i = 0; i < KS; ++i) {
-              if (i + 2 < KS) kf[i + 2] = load_k(tile, 0, i + 2);
-#pragma unroll
-              for (int qb = 0; qb < QB; ++qb) {
-                if (i == 0) qk_mfma<T, AG, true>(kf[i], qf[qb][0], s0[qb]);
-                else qk_mfma<T, AG, false>(kf[i], qf[qb][i], s0[qb]);
-                sm_unit(8 + i, qb, s1[qb], ma1[qb], mb1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], c2r, vsr);
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
-          }
-          RX_STAMP(1);
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) l_run[qb] = l_run[qb] * alpha1[qb] + (ps1[qb][0] + ps1[qb][1]);
-          // ---- G2: QK^T(b1, t) | units 0-7 of (b0, t), V^T fragments of tile t-1's rows 32..47
-          {
-            u32x4 kf[KS];
-            kf[0] = load_k(tile, 1, 0);
-            kf[1] = load_k(tile, 1, 1);
-#pragma unroll
-            for (int i = 0; i < KS; ++i) {
-              if (i + 2 < KS) kf[i + 2] = load_k(tile, 1, i + 2);
-              else {
-                vfa[2 * (i + 2 - KS)] = load_v1(tile_p, 2, 2 * (i + 2 - KS));
-                vfa[2 * (i + 2 - KS) + 1] = load_v1(tile_p, 2, 2 * (i + 2 - KS) + 1);
-              }
-#pragma unroll
-              for (int qb = 0; qb < QB; ++qb) {
-                if (i == 0) qk_mfma<T, AG, true>(kf[i], qf[qb][0], s1[qb]);
-                else qk_mfma<T, AG, false>(kf[i], qf[qb][i], s1[qb]);
-                // (s0's last MFMA is >= 12 issued instructions back: XDL write -> VALU read needs no pad here)
-                sm_unit(i, qb, s0[qb], ma0[qb], mb0[qb], m1[qb], m0[qb], alpha0[qb], ps0[qb], pk0[qb], c2r, vsr);
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
-          }
-          RX_STAMP(2);
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) rescale(qb, alpha1[qb]);
-          // ---- G3: PV(b1, t-1) | units 8-15 of (b0, t), tile t+1 registers -> LDS
-#pragma unroll
-          for (int g = 0; g < 2 * DB; ++g) {
-            if (g < 2) {
-              vfb[2 * g] = load_v1(tile_p, 3, 2 * g);
-              vfb[2 * g + 1] = load_v1(tile_p, 3, 2 * g + 1);
-            }
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-              if (g < DB) pv_mfma<T, AG>(vfa[g], pk1[qb][0], oacc[qb][g]);
-              else pv_mfma<T, AG>(vfb[g - DB], pk1[qb][1], oacc[qb][g - DB]);
-              sm_unit(8 + g, qb, s0[qb], ma0[qb], mb0[qb], m1[qb], m0[qb], alpha0[qb], ps0[qb], pk0[qb], c2r, vsr);
-              if (qb == QB - 1 && g < 2 * NPASS && !(RX_EXT32_ABL & (4 | 32))) write_lds_piece((t + 1) % RING, t + 1 < nt1, g);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            if (g >= DB && g < DB + 2) {  // tile t's rows 0..15 for G4
-              vfa[2 * (g - DB)] = load_v1(tile, 0, 2 * (g - DB));
-              vfa[2 * (g - DB) + 1] = load_v1(tile, 0, 2 * (g - DB) + 1);
-            }
-          }
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) {
-            l_run[qb] = l_run[qb] * alpha0[qb] + (ps0[qb][0] + ps0[qb][1]);
-            rescale(qb, alpha0[qb]);
-          }
-          // ---- G4: PV(b0, t) | units 0-7 of (b1, t), tile t+2 global loads
-          {
-            const int t2 = t + 2;
-            const bool pre = t2 < nt1;
-            const int esz = (KV8 && pre) ? 1 : 2;
-            const char* kb = pre ? reinterpret_cast<const char*>(kbuf_h) : reinterpret_cast<const char*>(kext_h);
-            const char* vb = pre ? reinterpret_cast<const char*>(vbuf_h) : reinterpret_cast<const char*>(vext_h);
-            const int64_t kts = (pre ? a.k_tok_stride : k_ext_stride) * esz, vts = (pre ? a.v_tok_stride : v_ext_stride) * esz;
-            const int64_t kps = a.k_page_stride * esz, vps = a.v_page_stride * esz;
-            const int sh = (LINEAR || !pre) ? 31 : -a.page_size - 1;
-            const uint32_t lo_mask = (1u << sh) - 1u;
-            auto reissue = [&](int i, int which) {  // which: 0 the K row, 1 the V row (one per MFMA gap)
-              const uint32_t sl = static_cast<uint32_t>(slot[i]);
-              if (which == 0) {
-                const char* kp = kb + mul_u32(sl >> sh, kps) + mul_u32(sl & lo_mask, kts);
-                if (KV8 && pre) {
-                  const u32x2 kr = *reinterpret_cast<const u32x2*>(kp);
-                  stg_k[i] = u32x4{kr[0], kr[1], 0u, 0u};
-                } else {
-                  stg_k[i] = *reinterpret_cast<const u32x4*>(kp);
-                }
-              } else {
-                const char* vp = vb + mul_u32(sl >> sh, vps) + mul_u32(sl & lo_mask, vts);
-                if (KV8 && pre) {
-                  const u32x2 vr = *reinterpret_cast<const u32x2*>(vp);
-                  stg_v[i] = u32x4{vr[0], vr[1], 0u, 0u};
-                } else {
-                  stg_v[i] = *reinterpret_cast<const u32x4*>(vp);
-                }
-              }
-            };
-#pragma unroll
-            for (int g = 0; g < 2 * DB; ++g) {
-              if (g < 2) {
-                vfb[2 * g] = load_v1(tile, 1, 2 * g);
-                vfb[2 * g + 1] = load_v1(tile, 1, 2 * g + 1);
-              }
-#pragma unroll
-              for (int qb = 0; qb < QB; ++qb) {
-                if (g < DB) pv_mfma<T, AG>(vfa[g], pk0[qb][0], oacc[qb][g]);
-                else pv_mfma<T, AG>(vfb[g - DB], pk0[qb][1], oacc[qb][g - DB]);
-                sm_unit(g, qb, s1[qb], ma1[qb], mb1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], c2r, vsr);
-                if (g * QB + qb < 2 * NPASS && !(RX_EXT32_ABL & (4 | 64))) reissue((g * QB + qb) >> 1, (g * QB + qb) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-              }
-            }
-            static_assert(2 * NPASS <= 2 * DB * QB, "staging pieces fit the PV groups");
-          }
-          load_idx_tile(t + 3);
-          tile_p = tile;
-          RX_STAMP(3);
-        }
-        // drain: units 8-15 and the PV of the last fast tile's block 1
-#pragma unroll
-        for (int u = 8; u < 16; ++u)
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb)
-            sm_unit(u, qb, s1[qb], ma1[qb], mb1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], c2r, vsr);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-          l_run[qb] = l_run[qb] * alpha1[qb] + (ps1[qb][0] + ps1[qb][1]);
-          m_run[qb] = m1[qb];
-          rescale(qb, alpha1[qb]);
-        }
-#pragma unroll
-        for (int step = 2; step < 4; ++step)
-#pragma unroll
-          for (int db = 0; db < DB; ++db) {
-            const u32x4 vf = load_v1(tile_p, step, db);
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) pv_mfma<T, AG>(vf, pk1[qb][step - 2], oacc[qb][db]);
-          }
-        break;  // the boundary loop below takes over (it re-enters this pipeline at the next run)
-      }
-    }
     // A run of fast tiles [t, fe): found ONCE per run in closed form (tile_info per tile cost ~310 cycles of scalar
     // work between the end of a tile and its barrier), and it may reach the very last tile: staging past the end is
     // harmless (see has_ext above).
     int fe = t;
-    if constexpr (!FINE) {
+    {
       const TileInfo ti0 = tile_info(t);
       if (ti0.fast) {  // the tile-independent conditions hold; the rest is "both blocks inside the visible range"
         if (t < nt1) fe = min(nt1, (causal_in_list ? min(p_len, q_off + qbase + 1) : p_len) / kTok);
@@ -836,119 +432,73 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       }
     }
     const float c2u = tile_info(t).c2, vs = tile_info(t).vs;  // constant inside a run (prefix or new tokens)
-    // JUMPT: the jump test of sm_slice (plain eight-wave instance only: one scale per run, no per-query temperature)
-    constexpr bool JUMPT = PLAIN && !FINE && RX_EXT32_JUMPT;
-    float thr[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) thr[qb] = (m_run[qb] + kMaxSlack) / (c2u * xai[qb]);
-    u32x4 kpre[3];  // DEEP: the next tile's first K fragments, read before its barrier
-    if constexpr (DEEP) {
-      if (t < fe) {
-        const char* tile0 = smem + (t % RING) * kBufBytes;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) kpre[i] = load_k(tile0, 0, i);
-      }
-    }
-    const bool late = STAGGER && w >= NW / 2;  // wave-uniform
-    for (; !FINE && t < fe; ++t) {
-      RX_STAMP(5);
-      if (!late) __syncthreads();
-      RX_STAMP(0);
-#if RX_EXT32_PADV  // dev probe: N independent VALU / SALU instructions per fast tile -- the cost of one more instruction
-      {
-        int pad_v = lane;
-#pragma unroll
-        for (int z = 0; z < RX_EXT32_PADV; ++z) asm volatile("v_mov_b32 %0, %0" : "+v"(pad_v));
-      }
-#endif
-#if RX_EXT32_PADS
-      {
-        int pad_s = w;
-#pragma unroll
-        for (int z = 0; z < RX_EXT32_PADS; ++z) asm volatile("s_mov_b32 %0, %0" : "+s"(pad_s));
-      }
-#endif
-      const char* tile = smem + (t % RING) * kBufBytes;
+    // JUMPT: the jump test of sm_slice (plain instances only: one scale per run, no per-query temperature)
+    constexpr bool JUMPT = PLAIN;
+    float thr = (m_run + kMaxSlack) / (c2u * xai);
+    for (; t < fe; ++t) {
+      __syncthreads();
+      const char* tile = smem + (t % 2) * kBufBytes;
       // ===== fast body: a hand-ordered wave-level software pipeline.  Measured before it: the tile's
       // phases (QK^T MFMAs, softmax VALU, PV MFMAs, staging) cost their SUM -- hipcc issues all MFMAs
       // of a phase back to back and the in-order wave then does its VALU with the matrix pipe idle.
-      // Here every group of QB MFMAs (one K or V^T fragment against each 32-query block) is followed
+      // Here every MFMA (one K or V^T fragment against the wave's 32-query block) is followed
       // by one slice of independent work, fenced so the order survives:
       //   QK^T(b0)            | K fragment reads two k-steps ahead
       //   QK^T(b1)            | softmax of block 0 (its own online-softmax step: no wait for b1's max)
       //   PV(b0), k-steps 0,1 | softmax of block 1, V^T fragment reads
       //   PV(b1), k-steps 2,3 | staging: tile t+1 registers -> LDS, tile t+2 global loads
       // (tile t+1 may be written any time after barrier t: its buffer's last readers were tile t-1's)
-      f32x16 s0[QB], s1[QB];
-      u32x4 pk0[QB][2], pk1[QB][2];
+      f32x16 s0, s1;
+      u32x4 pk0[2], pk1[2];
       u32x4 vfa[DB], vfb[DB];
-      float ma[QB], mb_[QB], m0[QB], m1[QB], alpha0[QB], alpha1[QB];
-      float ps0[QB][2], ps1[QB][2];
+      float ma, mb_, m0, m1, alpha0, alpha1;
+      float ps0[2] = {0.f, 0.f}, ps1[2] = {0.f, 0.f};
       bool jumped0 = false, jumped1 = false;  // wave-uniform: slice j == 2 of block 0 / 1 moved a reference max (JUMPT)
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) ps0[qb][0] = ps0[qb][1] = ps1[qb][0] = ps1[qb][1] = 0.f;
-      if constexpr ((RX_EXT32_ABL & 25) != 0) {
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-          alpha0[qb] = alpha1[qb] = 1.f;
-          m0[qb] = m1[qb] = m_run[qb];
-          pk0[qb][0] = pk0[qb][1] = pk1[qb][0] = pk1[qb][1] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-        }
-      }
-      // one slice of a block's softmax for query block qb; j = 0..6
-      auto sm_slice = [&](int j, int qb, f32x16& sc, float m_prev, float& m_new, float& alpha, float (&ps)[2],
+      // one slice of a block's softmax; j = 0..6
+      auto sm_slice = [&](int j, f32x16& sc, float m_prev, float& m_new, float& alpha, float (&ps)[2],
                           u32x4 (&pk)[2], bool& jumped) {
-        const float c2 = c2u * xai[qb];
+        const float c2 = c2u * xai;
         if (j == 0) {
-          ma[qb] = max3f(sc[0], sc[1], sc[2]);
-          mb_[qb] = max3f(sc[3], sc[4], sc[5]);
-          ma[qb] = max3f(ma[qb], sc[6], sc[7]);
-          mb_[qb] = max3f(mb_[qb], sc[8], sc[9]);
-          asm volatile("" ::"v"(ma[qb]), "v"(mb_[qb]));  // anchors: hipcc otherwise sinks a slice to its first use
+          ma = max3f(sc[0], sc[1], sc[2]);
+          mb_ = max3f(sc[3], sc[4], sc[5]);
+          ma = max3f(ma, sc[6], sc[7]);
+          mb_ = max3f(mb_, sc[8], sc[9]);
+          asm volatile("" ::"v"(ma), "v"(mb_));  // anchors: hipcc otherwise sinks a slice to its first use
         } else if (j == 1) {
-          ma[qb] = max3f(ma[qb], sc[10], sc[11]);
-          mb_[qb] = max3f(mb_[qb], sc[12], sc[13]);
-          ma[qb] = max3f(ma[qb], sc[14], sc[15]);
-          ma[qb] = max2f(ma[qb], mb_[qb]);
-          asm volatile("" ::"v"(ma[qb]));
+          ma = max3f(ma, sc[10], sc[11]);
+          mb_ = max3f(mb_, sc[12], sc[13]);
+          ma = max3f(ma, sc[14], sc[15]);
+          ma = max2f(ma, mb_);
+          asm volatile("" ::"v"(ma));
         } else if (j == 2) {
           // thresholded running max: a row moves its reference max only when the tile's max exceeds it by more
           // than kMaxSlack (log2 units).  exp2(s - m) then reaches 2^kMaxSlack at most -- exact algebra (l uses
-          // the same m), fp32 sums and 16-bit P have the range -- and the O^T rescale, which costs 64 (VGPR) or
-          // 192 + wait states (AGPR) instructions per block, runs on the first tile and almost never again;
-          // with the plain rule some row of a 32-row block sets a new max in ~70 % of 56 random tiles.
-          // Round 3 (JUMPT): in a VALU-issue-bound loop even the TEST was 12 instructions per block (half swap, scale,
+          // the same m), fp32 sums and 16-bit P have the range -- and the O^T rescale, which costs 64
+          // instructions per block, runs on the first tile and almost never again; with the plain rule some row
+          // of a 32-row block sets a new max in ~70 % of 56 random tiles.
+          // JUMPT (round 3): in a VALU-issue-bound loop even the TEST was 12 instructions per block (half swap, scale,
           // compare, select, exp2 of the difference).  Now one compare of the lane's raw maximum against a per-lane
           // threshold thr = (m + slack) / c2 and a wave-uniform branch: no lane above it means m_new = m_prev and
           // alpha = 1 for every row (a half row below the threshold cannot lift the row's maximum above it); only a
           // wave with a jumping row takes the old code, which also moves the threshold.
-          if constexpr (JUMPT) {
-            if (__builtin_amdgcn_ballot_w64(ma[qb] > thr[qb]) != 0) {
-              float mt = half_swap_max(ma[qb]) * c2;
-              mt = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
-              const float m_cand = max2f(m_prev, mt);
-              m_new = (m_cand - m_prev > kMaxSlack) ? m_cand : m_prev;
-              alpha = fast_exp2(m_prev - m_new);
-              thr[qb] = (m_new + kMaxSlack) / c2;
+          if (!JUMPT || __builtin_amdgcn_ballot_w64(ma > thr) != 0) {
+            float mt = half_swap_max(ma) * c2;
+            mt = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
+            const float m_cand = max2f(m_prev, mt);
+            m_new = (m_cand - m_prev > kMaxSlack) ? m_cand : m_prev;
+            alpha = fast_exp2(m_prev - m_new);
+            if constexpr (JUMPT) {
+              thr = (m_new + kMaxSlack) / c2;
               jumped = true;
-            } else {
-              m_new = m_prev;
-              alpha = 1.0f;
             }
           } else {
-          float mt = half_swap_max(ma[qb]) * c2;
-          mt = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
-          const float m_cand = max2f(m_prev, mt);
-          m_new = (m_cand - m_prev > kMaxSlack) ? m_cand : m_prev;
-          alpha = fast_exp2(m_prev - m_new);
+            m_new = m_prev;
+            alpha = 1.0f;
           }
           asm volatile("" ::"v"(m_new), "v"(alpha));
         } else {
           const int e = 4 * (j - 3);
           float v[4];
-          // AG build: without an input-side anchor hipcc hoists all four exp slices up to where m_new is
-          // first known (one 100-instruction VALU lump behind a single MFMA pair)
-          if constexpr (AG) asm volatile("" : "+v"(m_new));
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = fast_exp2(__builtin_fmaf(sc[e + i], c2, -m_new));
           ps[0] += v[0] + v[2];
@@ -965,14 +515,9 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
       };
       {
         u32x4 kf[2 * KS + 8];
-        constexpr int KA = DEEP ? 3 : RX_EXT32_KA;  // K fragments in flight ahead of the MFMA that consumes them
-        if constexpr (DEEP) {
+        constexpr int KA = 2;  // K fragments in flight ahead of the MFMA that consumes them
 #pragma unroll
-          for (int i = 0; i < 3; ++i) kf[i] = kpre[i];
-        } else {
-#pragma unroll
-          for (int i = 0; i < KA; ++i) kf[i] = load_k(tile, i >> 3, i & 7);
-        }
+        for (int i = 0; i < KA; ++i) kf[i] = load_k(tile, i >> 3, i & 7);
 #pragma unroll
         for (int i = 0; i < 2 * KS; ++i) {
           if (i + KA < 2 * KS) kf[i + KA] = load_k(tile, (i + KA) >> 3, (i + KA) & 7);
@@ -980,31 +525,17 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
             vfa[2 * (i + 2 - 2 * KS)] = load_v1(tile, 0, 2 * (i + 2 - 2 * KS));
             vfa[2 * (i + 2 - 2 * KS) + 1] = load_v1(tile, 0, 2 * (i + 2 - 2 * KS) + 1);
           }
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) {
-            if (i == 0) qk_mfma<T, AG, true>(kf[i], qf[qb][0], s0[qb]);
-            else if (i < KS) qk_mfma<T, AG, false>(kf[i], qf[qb][i], s0[qb]);
-            else if (i == KS) qk_mfma<T, AG, true>(kf[i], qf[qb][0], s1[qb]);
-            else qk_mfma<T, AG, false>(kf[i], qf[qb][i - KS], s1[qb]);
-          }
-          if (i > KS && !(RX_EXT32_ABL & 9)) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-              sm_slice(i - KS - 1, qb, s0[qb], m_run[qb], m0[qb], alpha0[qb], ps0[qb], pk0[qb], jumped0);
-          }
+          if (i == 0) qk_mfma<T, true>(kf[i], qf[0], s0);
+          else if (i < KS) qk_mfma<T, false>(kf[i], qf[i], s0);
+          else if (i == KS) qk_mfma<T, true>(kf[i], qf[0], s1);
+          else qk_mfma<T, false>(kf[i], qf[i - KS], s1);
+          if (i > KS) sm_slice(i - KS - 1, s0, m_run, m0, alpha0, ps0, pk0, jumped0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      RX_STAMP(1);
-      if (late) __syncthreads();
+      if (JUMPT ? jumped0 : (__builtin_amdgcn_ballot_w64(alpha0 != 1.0f) != 0)) {
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        if (JUMPT ? jumped0 : (__builtin_amdgcn_ballot_w64(alpha0[qb] != 1.0f) != 0)) {
-          acc_settle<AG>(oacc[qb]);
-#pragma unroll
-          for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha0[qb];
-          acc_settle<AG>(oacc[qb]);
-        }
+        for (int db = 0; db < DB; ++db) oacc[db] *= alpha0;
       }
       // PV(b0): k-steps 0 (vfa), 1 (vfb) | softmax of block 1
 #pragma unroll
@@ -1013,44 +544,24 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
           vfb[2 * g] = load_v1(tile, 1, 2 * g);
           vfb[2 * g + 1] = load_v1(tile, 1, 2 * g + 1);
         }
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-          if (g < DB)
-            pv_mfma<T, AG>(vfa[g], pk0[qb][0], oacc[qb][g]);
-          else
-            pv_mfma<T, AG>(vfb[g - DB], pk0[qb][1], oacc[qb][g - DB]);
-        }
+        if (g < DB) pv_mfma<T>(vfa[g], pk0[0], oacc[g]);
+        else pv_mfma<T>(vfb[g - DB], pk0[1], oacc[g - DB]);
         if (g >= DB && g < DB + 2) {
           vfa[2 * (g - DB)] = load_v1(tile, 2, 2 * (g - DB));
           vfa[2 * (g - DB) + 1] = load_v1(tile, 2, 2 * (g - DB) + 1);
         }
-        // AG: the score MFMAs are inline asm, so hipcc does not pad "XDL write -> VALU read" itself; block 1's
-        // softmax starts one group later, behind four more MFMAs (>= 96 cycles of matrix pipe)
-        constexpr int SH = AG ? 1 : 0;
-        if (g >= SH && g < 7 + SH && !(RX_EXT32_ABL & 17)) {
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) sm_slice(g - SH, qb, s1[qb], m0[qb], m1[qb], alpha1[qb], ps1[qb], pk1[qb], jumped1);
-        }
+        if (g < 7) sm_slice(g, s1, m0, m1, alpha1, ps1, pk1, jumped1);
         __builtin_amdgcn_sched_barrier(0);
       }
+      l_run = (l_run * alpha0 + (ps0[0] + ps0[1])) * alpha1 + (ps1[0] + ps1[1]);
+      m_run = m1;
+      if (JUMPT ? jumped1 : (__builtin_amdgcn_ballot_w64(alpha1 != 1.0f) != 0)) {
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        l_run[qb] = (l_run[qb] * alpha0[qb] + (ps0[qb][0] + ps0[qb][1])) * alpha1[qb] + (ps1[qb][0] + ps1[qb][1]);
-        m_run[qb] = m1[qb];
-      }
-      RX_STAMP(2);
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        if (JUMPT ? jumped1 : (__builtin_amdgcn_ballot_w64(alpha1[qb] != 1.0f) != 0)) {
-          acc_settle<AG>(oacc[qb]);
-#pragma unroll
-          for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha1[qb];
-          acc_settle<AG>(oacc[qb]);
-        }
+        for (int db = 0; db < DB; ++db) oacc[db] *= alpha1;
       }
       // PV(b1): k-steps 2 (vfa), 3 (vfb) | staging
       {
-        const int t2 = t + AHEAD + 1;
+        const int t2 = t + 2;
         const bool pre = t2 < nt1;
         // one address form for pool rows and new rows: (slot >> sh) * page_stride + (slot & mask) * tok_stride
         // in BYTES (an fp8 pool's elements are bytes, everything else is 16-bit)
@@ -1080,111 +591,93 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
             vfb[2 * g] = load_v1(tile, 3, 2 * g);
             vfb[2 * g + 1] = load_v1(tile, 3, 2 * g + 1);
           }
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) {
-            if (g < DB)
-              pv_mfma<T, AG>(vfa[g], pk1[qb][0], oacc[qb][g]);
-            else
-              pv_mfma<T, AG>(vfb[g - DB], pk1[qb][1], oacc[qb][g - DB]);
-          }
-          if (g == 2 && !(RX_EXT32_ABL & 4)) write_lds((t + AHEAD) % RING, t + AHEAD < nt1);
-          if (g >= 3 && g - 3 < NPASS && !(RX_EXT32_ABL & 4)) reissue(g - 3);
-          if constexpr (DEEP) {  // tile t+1 has been complete since barrier t: its first K fragments, now
-            if (g >= 2 * DB - 3) kpre[g - (2 * DB - 3)] = load_k(smem + ((t + 1) % RING) * kBufBytes, 0, g - (2 * DB - 3));
-          }
+          if (g < DB) pv_mfma<T>(vfa[g], pk1[0], oacc[g]);
+          else pv_mfma<T>(vfb[g - DB], pk1[1], oacc[g - DB]);
+          if (g == 2) write_lds((t + 1) % 2, t + 1 < nt1);
+          if (g >= 3 && g - 3 < NPASS) reissue(g - 3);
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int i = 2 * DB - 3; i < NPASS; ++i)
-          if (!(RX_EXT32_ABL & 4)) reissue(i);
-        load_idx_tile(t + AHEAD + 2);
+        for (int i = 2 * DB - 3; i < NPASS; ++i) reissue(i);
+        load_idx_tile(t + 3);
       }
-      RX_STAMP(3);
     }
-    RX_STAMP(5);
     for (; t < nt; ++t) {
       const TileInfo ti = tile_info(t);
-      if (ti.fast && (!FINE || t + 3 < nt)) break;
+      if (ti.fast) break;
       tile_sync_and_stage(t);
       if (!ti.work) continue;
-      const char* tile = smem + (t % RING) * kBufBytes;
+      const char* tile = smem + (t % 2) * kBufBytes;
       const bool prefix = ti.prefix, full = ti.full;
       const int tile_n0 = ti.tile_n0, nblk = ti.nblk;
-      const float cs = ti.cs, c2u = ti.c2, vs = ti.vs;
-      // ===== boundary tiles: causal diagonal, ragged ends, window, logit cap; one query block at a time
+      const float cs = ti.cs, c2b = ti.c2, vsb = ti.vs;
+      // ===== boundary tiles: causal diagonal, ragged ends, window, logit cap
+      f32x16 sacc[2];
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        f32x16 sacc[2];
+      for (int b = 0; b < 2; ++b) {
+        if (b < nblk) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if (b < nblk) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-              if (ks == 0) qk_mfma<T, AG, true>(load_k(tile, b, ks), qf[qb][ks], sacc[b]);
-              else qk_mfma<T, AG, false>(load_k(tile, b, ks), qf[qb][ks], sacc[b]);
-          }
+          for (int ks = 0; ks < KS; ++ks)
+            if (ks == 0) qk_mfma<T, true>(load_k(tile, b, ks), qf[ks], sacc[b]);
+            else qk_mfma<T, false>(load_k(tile, b, ks), qf[ks], sacc[b]);
         }
-        if constexpr (AG) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(sacc[0]), "+v"(sacc[1]));  // XDL write -> VALU read
-        float mt = -INFINITY;
+      }
+      float mt = -INFINITY;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if (b < nblk) {
-            if (capped) {
+      for (int b = 0; b < 2; ++b) {
+        if (b < nblk) {
+          if (capped) {
 #pragma unroll
-              for (int i = 0; i < 16; ++i) sacc[b][i] = a.logit_cap * tanhf(sacc[b][i] * cs / a.logit_cap);
-            }
-            if (!full) {
+            for (int i = 0; i < 16; ++i) sacc[b][i] = a.logit_cap * tanhf(sacc[b][i] * cs / a.logit_cap);
+          }
+          if (!full) {
 #pragma unroll
-              for (int i = 0; i < 16; ++i) {
-                const int n = tile_n0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
-                bool keep;
-                if (prefix) {
-                  keep = n < p_len && (!causal_in_list || n <= q_off + mp[qb]);
-                  if (a.window > 0) keep = keep && (q_off + mp[qb] <= n + a.window);
-                  if (mask_prefix && keep && m[qb] < E) keep = mask_base[mp[qb] * mask_row + n] != 0;
-                } else {
-                  keep = n < n_end_w && (masked || !a.causal || n <= mp[qb]);
-                  if (a.window > 0) keep = keep && (mp[qb] <= n + a.window);
-                  if (masked && keep && m[qb] < E) keep = mask_base[mp[qb] * mask_row + P + n] != 0;
-                }
-                sacc[b][i] = keep ? sacc[b][i] : -INFINITY;
+            for (int i = 0; i < 16; ++i) {
+              const int n = tile_n0 + 32 * b + (i & 3) + 8 * (i >> 2) + 4 * h;
+              bool keep;
+              if (prefix) {
+                keep = n < p_len && (!causal_in_list || n <= q_off + mp);
+                if (a.window > 0) keep = keep && (q_off + mp <= n + a.window);
+                if (mask_prefix && keep && m < E) keep = mask_base[mp * mask_row + n] != 0;
+              } else {
+                keep = n < n_end_w && (masked || !a.causal || n <= mp);
+                if (a.window > 0) keep = keep && (mp <= n + a.window);
+                if (masked && keep && m < E) keep = mask_base[mp * mask_row + P + n] != 0;
               }
+              sacc[b][i] = keep ? sacc[b][i] : -INFINITY;
             }
-            mt = fmaxf(mt, row_max16(sacc[b]));
           }
+          mt = fmaxf(mt, row_max16(sacc[b]));
         }
-        const float c2 = c2u * xai[qb];
-        mt = half_swap_max(mt);
-        mt *= c2;
-        const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
-        const float m_cand = fmaxf(m_run[qb], mt_fixed);
-        const float m_new = (m_cand - m_run[qb] > kMaxSlack) ? m_cand : m_run[qb];
-        const float alpha = fast_exp2(m_run[qb] - m_new);
-        m_run[qb] = m_new;
-        float psum = 0.f;
-        u32x4 pk[2][2];  // [block][k-step within block]: 8 bf16 = registers 8s..8s+7
+      }
+      const float c2 = c2b * xai;
+      mt = half_swap_max(mt);
+      mt *= c2;
+      const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
+      const float m_cand = fmaxf(m_run, mt_fixed);
+      const float m_new = (m_cand - m_run > kMaxSlack) ? m_cand : m_run;
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+      u32x4 pk[2][2];  // [block][k-step within block]: 8 bf16 = registers 8s..8s+7
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-          if (b < nblk) psum += exp_pack(sacc[b], c2, m_new, vs, pk[b]);
-        l_run[qb] = l_run[qb] * alpha + psum;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-          acc_settle<AG>(oacc[qb]);
+      for (int b = 0; b < 2; ++b)
+        if (b < nblk) psum += exp_pack(sacc[b], c2, m_new, vsb, pk[b]);
+      l_run = l_run * alpha + psum;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-          for (int db = 0; db < DB; ++db) oacc[qb][db] *= alpha;
-          acc_settle<AG>(oacc[qb]);
-        }
+        for (int db = 0; db < DB; ++db) oacc[db] *= alpha;
+      }
 #pragma unroll
-        for (int step = 0; step < 4; ++step) {
-          if (step < 2 * nblk) {
+      for (int step = 0; step < 4; ++step) {
+        if (step < 2 * nblk) {
 #pragma unroll
-            for (int db = 0; db < DB; ++db) pv_mfma<T, AG>(load_v1(tile, step, db), pk[step >> 1][step & 1], oacc[qb][db]);
-          }
+          for (int db = 0; db < DB; ++db) pv_mfma<T>(load_v1(tile, step, db), pk[step >> 1][step & 1], oacc[db]);
         }
       }
     }
   }
 
-  RX_STAMP(4);
   // ---- epilogue -------------------------------------------------------------------------------------
   // The accumulator has one query ROW per lane: stored as it stands, every store instruction touches 32
   // different rows (8 bytes each, sixteen of them per lane) and the tail is store-issue bound (~4 us per
@@ -1194,65 +687,51 @@ __global__ __launch_bounds__(64 * NW, QB == 1 ? 2 : 1) void extend_mfma32_kernel
   if (!active) return;
   constexpr int kORow = 272;  // 256 + 16: keeps ds_read_b128 aligned, spreads the row-per-lane writes
   char* obuf = smem + w * (32 * kORow);
+  float l = l_run;
+  {
+    float a2 = l, b2 = l;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(a2), "+v"(b2));
+    l = a2;
+  }
+  float den = l;
+  if (a.sinks) den += fast_exp2(a.sinks[head * pack + (m < E ? m - mp * pack : 0)] * kLog2e - m_run);
+  const float inv = 1.0f / den;
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    float l = l_run[qb];
-    {
-      float a2 = l, b2 = l;
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_add_f32 %0, %0, %1" : "+v"(a2), "+v"(b2));
-      l = a2;
-    }
-    float den = l;
-    if (a.sinks) den += fast_exp2(a.sinks[head * pack + (m[qb] < E ? m[qb] - mp[qb] * pack : 0)] * kLog2e - m_run[qb]);
-    const float inv = 1.0f / den;
-    acc_settle<AG>(oacc[qb]);
+  for (int db = 0; db < DB; ++db) {
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {  // registers 4 gq .. 4 gq + 3 = d 32 db + 8 gq + 4 h + 0..3
-        u32x2 pk2;
-        pk2[0] = pack2<T>(oacc[qb][db][4 * gq] * inv, oacc[qb][db][4 * gq + 1] * inv);
-        pk2[1] = pack2<T>(oacc[qb][db][4 * gq + 2] * inv, oacc[qb][db][4 * gq + 3] * inv);
-        *reinterpret_cast<u32x2*>(obuf + ql * kORow + (32 * db + 8 * gq + 4 * h) * 2) = pk2;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int32_t row0 = qbase + 32 * qb;  // first query of this block
-#pragma unroll
-    for (int pss = 0; pss < 8; ++pss) {
-      const int row = 4 * pss + (lane >> 4), chunk = lane & 15;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(obuf + row * kORow + chunk * 16);
-      if (row0 + row < E) {
-        const int32_t r = row0 + row, tk = pack == 1 ? r : r / pack, gq = r - tk * pack;
-        *reinterpret_cast<u32x4*>(a.o + (qo0 + tk) * a.o_stride_t + (head * pack + gq) * a.o_stride_h + 8 * chunk) = v;
-      }
-    }
-    if (a.lse && h == 0 && m[qb] < E)
-      a.lse[(qo0 + mp[qb]) * a.lse_stride_t + (head * pack + (m[qb] - mp[qb] * pack)) * a.lse_stride_h] =
-          m_run[qb] * kLn2 + __logf(l);
-    if (qb + 1 < QB) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+    for (int gq = 0; gq < 4; ++gq) {  // registers 4 gq .. 4 gq + 3 = d 32 db + 8 gq + 4 h + 0..3
+      u32x2 pk2;
+      pk2[0] = pack2<T>(oacc[db][4 * gq] * inv, oacc[db][4 * gq + 1] * inv);
+      pk2[1] = pack2<T>(oacc[db][4 * gq + 2] * inv, oacc[db][4 * gq + 3] * inv);
+      *reinterpret_cast<u32x2*>(obuf + ql * kORow + (32 * db + 8 * gq + 4 * h) * 2) = pk2;
     }
   }
-#if RX_EXT32_STAMP
-  if (lane == 0) {  // diagnostic build: the stamps REPLACE the first 24 bytes of the wave's first output row
-    uint32_t* dbg = reinterpret_cast<uint32_t*>(a.o + (qo0 + qbase) * a.o_stride_t + head * a.o_stride_h);
-    for (int i = 0; i < 6; ++i) dbg[i] = st_acc[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int pss = 0; pss < 8; ++pss) {
+    const int row = 4 * pss + (lane >> 4), chunk = lane & 15;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(obuf + row * kORow + chunk * 16);
+    if (qbase + row < E) {
+      const int32_t r = qbase + row, tk = pack == 1 ? r : r / pack, gq = r - tk * pack;
+      *reinterpret_cast<u32x4*>(a.o + (qo0 + tk) * a.o_stride_t + (head * pack + gq) * a.o_stride_h + 8 * chunk) = v;
+    }
   }
-#endif
+  if (a.lse && h == 0 && m < E)
+    a.lse[(qo0 + mp) * a.lse_stride_t + (head * pack + (m - mp * pack)) * a.lse_stride_h] = m_run * kLn2 + __logf(l);
 }
 
 // launcher used by rx_extend.hip for head_dim == v_head_dim == 128
-template <int NW, int QB, bool KV8, bool PLAIN, int PKC = 0>
+template <int NW, bool KV8, bool PLAIN, int PKC = 0>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
-  constexpr unsigned kLds = ((QB > 1 || (NW == 8 && (RX_EXT32_DEEP >= 1 || RX_EXT32_FINE))) ? 3 : 2) * kBufBytes;  // 74 / 111 KiB: above the 64 KiB static limit, hence dynamic
+  constexpr unsigned kLds = 2 * kBufBytes;  // 74 KiB: above the 64 KiB static limit, hence dynamic
+  note_dispatch("extend_mfma32_kernel<%s, %s, %s, %s, %d, %s, %s, %d>", bf16 ? "rx::BF16" : "rx::F16", idx64 ? "long" : "int",
+                tbool(linear), tbool(!PLAIN && vs), NW, tbool(KV8), tbool(PLAIN), PKC);
 #define RX_E32(TT, IT, LIN, VS)                                                                        \
   do {                                                                                                 \
-    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, QB, KV8, PLAIN, PKC>;                             \
+    auto kern = extend_mfma32_kernel<TT, IT, LIN, VS, NW, KV8, PLAIN, PKC>;                            \
     static const hipError_t attr = hipFuncSetAttribute(                                                \
         reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);       \
     (void)attr;                                                                                        \
@@ -1276,16 +755,8 @@ static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, 
 #undef RX_E32
 }
 
-#ifndef RX_EXT32_QB
-// 32-query blocks per wave.  1 = eight waves x 32 queries, two waves per SIMD (default: 753 TFLOP/s at
-// config 3).  2 = four waves x 64 queries, one wave per SIMD with the 512-register file: halves the LDS
-// fragment traffic per FLOP, but as compiled by hipcc (accumulators shuffled between VGPRs and AGPRs,
-// no second wave to cover the in-order stalls) it measured 373 TFLOP/s -- kept for a hand-allocated
-// follow-up, not dispatched.
-#define RX_EXT32_QB 1
-#endif
-
 int launch_extend32(const rx_extend_params* p, hipStream_t s) {
+  const Options& opt = options();
   Ext32Args a;
   a.q = (const uint16_t*)p->q;
   a.k_ext = (const uint16_t*)p->k_extend;
@@ -1314,11 +785,9 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.unified_prefix = p->unified_prefix_lens;
   a.q_pack = p->q_pack > 1 ? p->q_pack : 1;
   // Long causal extends of a GQA-4 / GQA-8 model pack by themselves (bit-identical results, +2.6 % at the config-3 chunk: a
-  // 256-row block's diagonal is one boundary tile instead of four); RX_EXT32_AUTOPACK=0 turns it off
-  const char* ap_env = getenv("RX_EXT32_AUTOPACK");  // (read per call: tests flip it inside one process)
-  const bool autopack = !(ap_env && atoi(ap_env) == 0);
+  // 256-row block's diagonal is one boundary tile instead of four); option ext32_autopack = 0 turns it off
   const int grp = p->num_kv_heads > 0 ? p->num_q_heads / p->num_kv_heads : 1;
-  if (autopack && a.q_pack == 1 && RX_EXT32_QB == 1 && (grp == 4 || grp == 8) && p->num_q_heads == grp * p->num_kv_heads && p->is_causal &&
+  if (opt.ext32_autopack && a.q_pack == 1 && (grp == 4 || grp == 8) && p->num_q_heads == grp * p->num_kv_heads && p->is_causal &&
       !p->skip_extend && p->max_extend_len >= 256 && !p->kv.kv_fp8 && p->v_scale == 1.0f && !p->unified_prefix_lens &&
       !p->custom_mask && p->sliding_window_size <= 0 && p->xai_temperature_len <= 0 && !(p->logit_cap > 0.f) &&
       (p->avg_kv_len_hint + p->max_extend_len / 2) / kTok >= RX_EXT32_SMALL_WG_TILES)
@@ -1330,34 +799,33 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
-  constexpr int QB = RX_EXT32_QB;
   // Workgroup size.  One 256-query workgroup per CU (8 waves) is best when a (request, head, query block)
   // walks many tiles (config 3: 60 tiles, 739 vs 706 TFLOP/s); with few tiles the per-workgroup
   // prologue / epilogue and the launch itself dominate and two 128-query workgroups per CU overlap them
   // (no prefix, 2 Ki new tokens: 452 -> 512; 512 + 128: 356 -> 493).  Estimated tiles per workgroup from
-  // the host-side hints: (mean prefix + half the longest extend) / 64.
+  // the host-side hints: (mean prefix + half the longest extend) / 64.  Option ext32_small_wg: 0 / 1 force a form.
   const int est_tiles = (p->avg_kv_len_hint + p->max_extend_len / 2) / kTok;
-  const bool small_wg = QB == 1 && est_tiles < RX_EXT32_SMALL_WG_TILES && !getenv("RX_EXT32_FORCE_NW8");
-  const int nw = small_wg ? 4 : 8 / QB;
-  a.mblocks = (p->max_extend_len * a.q_pack + nw * QB * 32 - 1) / (nw * QB * 32);
+  const bool small_wg = opt.ext32_small_wg < 0 ? est_tiles < RX_EXT32_SMALL_WG_TILES : opt.ext32_small_wg != 0;
+  const int nw = small_wg ? 4 : 8;
+  a.mblocks = (p->max_extend_len * a.q_pack + nw * 32 - 1) / (nw * 32);
   a.kv_fp8 = p->kv.kv_fp8;
   const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0, vsc = p->v_scale != 1.0f;
   const bool plain_any = !a.kv_fp8 && !vsc && !a.unified_prefix && !a.custom_mask && a.window <= 0 &&
-                         a.xai_len <= 0 && !(a.logit_cap > 0.f) && !getenv("RX_EXT32_NO_PLAIN");
+                         a.xai_len <= 0 && !(a.logit_cap > 0.f) && opt.ext32_plain;
   const bool plain = plain_any && a.q_pack == 1;
-  if (plain_any && (a.q_pack == 4 || a.q_pack == 8) && !small_wg && QB == 1) {  // packed rows on the PLAIN loop (GQA 4 / 8)
-    if (a.q_pack == 4) launch32_nw<8, 1, false, true, 4>(a, bf, i64, linear, false, s);
-    else launch32_nw<8, 1, false, true, 8>(a, bf, i64, linear, false, s);
+  if (plain_any && (a.q_pack == 4 || a.q_pack == 8) && !small_wg) {  // packed rows on the PLAIN loop (GQA 4 / 8)
+    if (a.q_pack == 4) launch32_nw<8, false, true, 4>(a, bf, i64, linear, false, s);
+    else launch32_nw<8, false, true, 8>(a, bf, i64, linear, false, s);
     return RX_OK;
   }
   if (small_wg) {
-    if (plain) launch32_nw<4, 1, false, true>(a, bf, i64, linear, false, s);
-    else if (a.kv_fp8) launch32_nw<4, 1, true, false>(a, bf, i64, linear, vsc, s);
-    else launch32_nw<4, 1, false, false>(a, bf, i64, linear, vsc, s);
+    if (plain) launch32_nw<4, false, true>(a, bf, i64, linear, false, s);
+    else if (a.kv_fp8) launch32_nw<4, true, false>(a, bf, i64, linear, vsc, s);
+    else launch32_nw<4, false, false>(a, bf, i64, linear, vsc, s);
   } else {
-    if (plain) launch32_nw<8 / QB, QB, false, true>(a, bf, i64, linear, false, s);
-    else if (a.kv_fp8) launch32_nw<8 / QB, QB, true, false>(a, bf, i64, linear, vsc, s);
-    else launch32_nw<8 / QB, QB, false, false>(a, bf, i64, linear, vsc, s);
+    if (plain) launch32_nw<8, false, true>(a, bf, i64, linear, false, s);
+    else if (a.kv_fp8) launch32_nw<8, true, false>(a, bf, i64, linear, vsc, s);
+    else launch32_nw<8, false, false>(a, bf, i64, linear, vsc, s);
   }
   return RX_OK;
 }

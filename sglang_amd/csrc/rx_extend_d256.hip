@@ -27,24 +27,6 @@ namespace rx {
 #ifndef RX_D256_NPRE
 #define RX_D256_NPRE 4  // V^T fragment pairs read ahead
 #endif
-#ifndef RX_D256_PADV
-#define RX_D256_PADV 0
-#endif
-#ifndef RX_D256_PADS
-#define RX_D256_PADS 0
-#endif
-#ifndef RX_D256_ABL
-#define RX_D256_ABL 0
-#endif
-#ifndef RX_D256_TBL
-#define RX_D256_TBL 1   // DMA issue from a per-tile row-pointer table in LDS (0: slot lookup + address math per piece)
-#endif
-#ifndef RX_D256_SV
-#define RX_D256_SV 1    // S^T accumulators pinned in VGPRs by asm MFMAs (0: the builtin, which lands them in AGPRs)
-#endif
-#ifndef RX_D256_FASTMASK
-#define RX_D256_FASTMASK 1  // dev A/B: 0 = mask every half tile
-#endif
 constexpr int kYTT = 64;
 constexpr int kYSlotBlock = 256;
 constexpr int kYRows = 256;                  // query rows per workgroup
@@ -113,7 +95,7 @@ __device__ __forceinline__ void y_pv_mfma(u32x4 a, u32x4 b, f32x4& c) {
   if constexpr (std::is_same_v<T, BF16>) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
-// S^T accumulators pinned in VGPRs (RX_D256_SV): left to itself hipcc puts the builtin's result in the AGPR half -- which
+// S^T accumulators pinned in VGPRs: left to itself hipcc puts the builtin's result in the AGPR half -- which
 // the 128 O^T accumulators fill -- and moves 16 of THEM out and back around every half tile's scores (104 v_accvgpr_read +
 // 72 v_accvgpr_write per tile and wave in the loop's ISA).  hipcc pads nothing around asm MFMAs: the four chains
 // (2 token blocks x 2 row blocks) are issued round robin, so a dependent MFMA follows its predecessor by four 8-pass
@@ -240,48 +222,6 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   const char* const kext_b = reinterpret_cast<const char*>(a.k_ext + qo0 * a.k_stride_t + kvh * a.k_stride_h);
   const char* const vext_b = reinterpret_cast<const char*>(a.v_ext + qo0 * a.v_stride_t + kvh * a.v_stride_h);
   const int32_t sh_p = a.page_shift < 0 ? 31 : a.page_shift;
-  // this wave's pieces of an image: w, w + 8, ... (CPR chunks per padded row, NPIECES 1-KiB pieces)
-  auto dma_image = [&](int t, auto cpr_c, auto np_c, auto data_c, bool vside) {
-    constexpr int CPR = decltype(cpr_c)::value, NPIECES = decltype(np_c)::value, DATA = decltype(data_c)::value;
-    constexpr int NP = (NPIECES + 7) / 8;  // 5
-    const bool pre = t < nt1;
-    const uint32_t sl = smem_u + kYSlotsAt + 4 * (((t * kYTT / kYSlotBlock) & 1) * kYSlotBlock + (t * kYTT) % kYSlotBlock);
-    const uint32_t img = smem_u + (t & 1) * kYStage + (vside ? kYKimg : 0);
-    const char* const base = pre ? (vside ? vbuf_b : kbuf_b) : (vside ? vext_b : kext_b);
-    const int32_t sh = pre ? sh_p : 31;
-    const uint32_t mask = sh == 31 ? 0x7fffffffu : (1u << sh) - 1u;
-    const uint32_t ts2 = 2u * static_cast<uint32_t>(pre ? (vside ? a.v_tok_stride : a.k_tok_stride) : (vside ? a.v_stride_t : a.k_stride_t));
-    const uint32_t ps2 = pre ? 2u * static_cast<uint32_t>(vside ? a.v_page_stride : a.k_page_stride) : 0u;
-    const bool paged = pre && sh != 31;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));  // opaque: the per-piece chunk arithmetic stays inside the loop
-    const int c0 = 64 * w + ln;   // < 512
-    int row = c0 / CPR, col = c0 - row * CPR;
-    int32_t slot[NP], col16[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const bool past = row >= kYTT;  // the last piece's tail: repeats a valid chunk
-      const int rw = past ? kYTT - 1 : row;
-      col16[i] = 16 * ((past || col >= DATA) ? DATA - 1 : col);  // pad chunks re-read the row's last data chunk
-      slot[i] = pre ? y_lds_read4(sl + 4 * rw) : max(min((t - nt1) * kYTT + rw, n_end_wg - 1), 0);
-      row += 512 / CPR;
-      col += 512 % CPR;
-      if (col >= CPR) {
-        col -= CPR;
-        row += 1;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      if (w + 8 * i < NPIECES) {  // wave-uniform
-        uint64_t off = static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) & mask) * ts2 + static_cast<uint32_t>(col16[i]);
-        if (paged) off += static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) >> sh) * ps2;
-        y_dma16(base + off, __builtin_amdgcn_readfirstlane(img + (w + 8 * i) * 1024));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-#if RX_D256_TBL
   // ---- table-driven issue.  The ISA of the per-piece form above was a third of the loop's instruction stream (per
   // piece: slot read + wait, page / token split, two 64-bit multiplies, ~12 VALU + 10 SALU + two branches), and this
   // kernel pays ~5 cycles for EVERY instruction a wave issues (rx_extend_d256.hip header, round 3).  One wave per tile
@@ -387,26 +327,12 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
       issue_pieces(t, std::integral_constant<int, kYVpieces>{}, gv, true);
     }
   };
-#endif
-  using KC = std::integral_constant<int, kYKc>;
-  using VC = std::integral_constant<int, kYVc>;
-  using KP = std::integral_constant<int, kYKpieces>;
-  using VP = std::integral_constant<int, kYVpieces>;
-  using KD = std::integral_constant<int, Y::KCPR>;
-  using VD = std::integral_constant<int, Y::VCPR>;
   auto dma_tile = [&](int t) {
-#if RX_D256_TBL
     dma_tile_tbl(t);
-#else
-    dma_image(t, KC{}, KP{}, KD{}, false);
-    dma_image(t, VC{}, VP{}, VD{}, true);
-#endif
   };
-#if RX_D256_TBL
   if (t_begin < nt) build_table(t_begin);
   if (t_begin + 1 < nt) build_table(t_begin + 1);
   __syncthreads();  // the first two tables are readable
-#endif
   if (t_begin < nt) dma_tile(t_begin);
 
   f32x4 oacc[2][NB];
@@ -423,21 +349,13 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
   const uint32_t k_lane = r * kYKrow + g * 16;
   const uint32_t v_lane = (4 * g + qd) * kYVrow + 8 * (pp & 1) + (pp >> 1) * 16;
   const uint32_t bounce = smem_u + kYBounceAt + (w * 64 + lane) * 16;  // this lane's 16 bytes of the rescale bounce
-  int pad_v = lane, pad_s = w;
-  (void)pad_v; (void)pad_s;
   const bool late = w >= 4;  // the SIMD partner of an early wave: issues its pieces behind its first QK^T
 
   for (int t = t_begin; t < nt; ++t) {
-#if !(RX_D256_ABL & 1)  // dev ablations (results are wrong): 1 = no landing wait, 2 = no barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
-#endif
-#if !(RX_D256_ABL & 2)
     __syncthreads();                                   // everybody's have; everybody is done with tile t - 1
-#endif
     if (t % TPB == 0 && (t / TPB + 1) * kYSlotBlock < nt1 * kYTT) stage_slots(t / TPB + 1);
-#if RX_D256_TBL
     if (t + 2 < nt) build_table(t + 2);  // read by tile t + 2's issue, which runs behind the next barrier
-#endif
     const bool more = t + 1 < nt;
     if (more && !late) dma_tile(t + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -451,14 +369,6 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
       if (late_pending) dma_tile(t + 1);
       continue;
     }
-#if RX_D256_PADV  // dev probe: N independent VALU / SALU instructions per tile -- what does one more instruction cost?
-#pragma unroll
-    for (int z = 0; z < RX_D256_PADV; ++z) asm volatile("v_mov_b32 %0, %0" : "+v"(pad_v));
-#endif
-#if RX_D256_PADS
-#pragma unroll
-    for (int z = 0; z < RX_D256_PADS; ++z) asm volatile("s_mov_b32 %0, %0" : "+s"(pad_s));
-#endif
     const uint32_t kt = smem_u + (t & 1) * kYStage;
     const uint32_t vt = kt + kYKimg;
     const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
@@ -470,7 +380,6 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
       const bool half_full = !windowed && n0 + 32 <= (prefix ? p_len : min(n_end_w, a.causal ? tok_lo_w + 1 : E));
       // ---- S^T = K Q^T: tokens 16 bb + 4 g + i of the half on the lane, query row r of block c
       f32x4 sacc[2][2];
-#if RX_D256_SV
       {
         // i = 2 s + blk: token blocks alternate, so the four accumulator chains are issued round robin
         constexpr int PD = RX_D256_PD;
@@ -501,26 +410,6 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
         }
         y_scores_ready(sacc);
       }
-#else
-#pragma unroll
-      for (int c = 0; c < 2; ++c) sacc[c][0] = sacc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      {
-        constexpr int PD = RX_D256_PD;
-        const uint32_t krow = kt + k_lane + 32 * hh * kYKrow;
-        auto kfrag = [&](int i) { return y_lds_read16(krow + (i / KS) * 16 * kYKrow + (i % KS) * 64); };
-        u32x4 kf[PD];
-#pragma unroll
-        for (int i = 0; i < PD; ++i) kf[i] = kfrag(i);
-#pragma unroll
-        for (int i = 0; i < 2 * KS; ++i) {
-          const vec8 ka = __builtin_bit_cast(vec8, kf[i % PD]);
-          if (i + PD < 2 * KS) kf[i % PD] = kfrag(i + PD);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) sacc[c][i / KS] = T::mfma(ka, qf[c][i % KS], sacc[c][i / KS]);
-          __builtin_amdgcn_sched_barrier(0);  // source order is the pipeline
-        }
-      }
-#endif
       if (hh == 0 && late_pending) {
         dma_tile(t + 1);
         late_pending = false;
@@ -541,7 +430,7 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
         }
         // (a half that every row of the wave sees in full -- the whole prefix but its ragged end, the new tokens below
         // the wave's first row -- takes no mask: 2 of its ~10 VALU per score; wave-uniform branch)
-        if (!RX_D256_FASTMASK || !half_full) {
+        if (!half_full) {
           int lnm = lane;
           asm volatile("" : "+v"(lnm));
           const int32_t tk1 = row_tok(rbase + 16 * c + (lnm & 15)) + 1;
@@ -666,15 +555,12 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
 // tensors, and extends long enough to fill 256-row workgroups (short ones: rx_extend_nd.hip's smaller blocks)
 bool extend_d256_supports(const rx_extend_params* p) {
   const int dk = p->head_dim, dv = p->v_head_dim;
-  // (128 / 128 as well, on request: RX_EXT_D256_AT128=1 -- a dev switch to measure this kernel form against the
-  // 32x32x16 kernel of rx_extend32.hip on the headline shape)
-  const bool at128 = getenv("RX_EXT_D256_AT128") != nullptr;  // (dev switch, read per call)
-  // D = 64 takes this kernel form by default since round 3 (588-609 TFLOP/s at the config-3 chunk against 533 for the
-  // 16x16 kernel of rx_extend.hip with 64 queries per wave); RX_EXT_D256_AT64=0 turns it off
-  const char* e64 = getenv("RX_EXT_D256_AT64");
-  const bool at64 = !(e64 && atoi(e64) == 0);
-  const char* e96 = getenv("RX_EXT_D256_AT96");
-  const bool at96 = !(e96 && atoi(e96) == 0);
+  // (128 / 128 as well, on request -- option extend_d256_at128: this kernel form against the 32x32x16 kernel of
+  // rx_extend32.hip on the headline shape.)  D = 64 takes this form by default since round 3 (588-609 TFLOP/s at the
+  // config-3 chunk against 533 for the 16x16 kernel of rx_extend.hip with 64 queries per wave) and so does D = 96;
+  // options extend_d256_at64 / extend_d256_at96 = 0 turn that off.
+  const Options& opt = options();
+  const bool at128 = opt.extend_d256_at128 != 0, at64 = opt.extend_d256_at64 != 0, at96 = opt.extend_d256_at96 != 0;
   if (!((dk == 256 && dv == 256) || (dk == 192 && (dv == 128 || dv == 192)) || (at128 && dk == 128 && dv == 128) ||
         (at64 && dk == 64 && dv == 64) || (at96 && dk == 96 && dv == 96)) || p->kv.kv_fp8)
     return false;
@@ -743,6 +629,8 @@ int launch_extend_d256(const rx_extend_params* p, hipStream_t s) {
   const bool bf = p->dtype == RX_BF16;
   const int dk = p->head_dim, dv = p->v_head_dim;
   const bool extras = a.window > 0 || a.logit_cap > 0.f || a.v_scale != 1.0f;
+  note_dispatch("extend_d256_kernel<%s, %d, %d, %s>|%s,g%d", bf ? "rx::BF16" : "rx::F16", dk, dv, tbool(extras),
+                linear ? "linear" : "paged", a.group);
   if (bf) {
     if (extras) RX_D256_DIMS(BF16, true);
     else RX_D256_DIMS(BF16, false);

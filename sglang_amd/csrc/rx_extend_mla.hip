@@ -103,12 +103,6 @@ __device__ __forceinline__ void x_settle(f32x4 (&o)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i) asm volatile("" : "+a"(o[i]));
 }
-#ifndef RX_XMLA_TBL
-#define RX_XMLA_TBL 1  // DMA issue from a per-tile row-pointer table in LDS (rx_extend_d256.hip, round 3); 0: per-piece address math
-#endif
-#ifndef RX_XMLA_STAMP
-#define RX_XMLA_STAMP 0  // 1: diagnostic build, s_memtime phase stamps of waves 0 and 4 go to lse[16 * block ...] (tools/mla_extend_bench.py STAMPS=1)
-#endif
 
 // LDS: the stages | two blocks of slot ids | 1 KiB per wave for the rescale's way through LDS
 struct XGeom8 {  // (the eight-wave form's geometry; the four-wave first form is in the history and DESIGN 4.2b)
@@ -210,57 +204,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   const int32_t sh_p = a.page_shift < 0 ? 31 : a.page_shift;
   constexpr int kPieces = 37;
   constexpr int NP = (kPieces + G::NW - 1) / G::NW;  // 5
-  // all pieces of tile t (this wave's: w, w + 8, ...) -> stage t & 1
-  auto dma_tile_pp = [&](int t, int ring) {  // tile t -> stage ring % NSTAGE, addresses per piece (RX_XMLA_TBL=0)
-    const bool pre = t < nt1;
-    const uint32_t sl = smem_u + G::SLOTS_AT + 4 * (((t * kXTT / kXSlotBlock) & 1) * kXSlotBlock + (t * kXTT) % kXSlotBlock);
-    const uint32_t img = smem_u + (ring & (G::NSTAGE - 1)) * G::STAGE;
-    const char* const base = pre ? kbuf_b : kext_b;
-    const int32_t sh = pre ? sh_p : 31;
-    const uint32_t mask = sh == 31 ? 0x7fffffffu : (1u << sh) - 1u;
-    const uint32_t ts2 = 2u * static_cast<uint32_t>(pre ? a.k_tok_stride : a.k_stride_t);
-    const uint32_t ps2 = pre ? 2u * static_cast<uint32_t>(a.k_page_stride) : 0u;
-    const bool paged = pre && sh != 31;
-    const bool ownv = own_v(t);
-    const char* const vbase = pre ? vbuf_b : vext_b;
-    const uint32_t vts2 = 2u * static_cast<uint32_t>(pre ? a.v_tok_stride : a.v_stride_t);
-    const uint32_t vps2 = pre ? 2u * static_cast<uint32_t>(a.v_page_stride) : 0u;
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int c0 = 64 * w + ln;  // < 512
-    int row = c0 / (kXCpr), col = c0 - row * kXCpr;
-    int32_t slot[NP], col16[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const bool past = row >= kXTT;
-      const int rw = past ? kXTT - 1 : row;
-      col16[i] = 16 * ((past || col >= kXCpr - 2) ? kXCpr - 3 : col);  // pad chunks re-read the row's last data chunk
-      slot[i] = pre ? x_lds_read4(sl + 4 * rw) : max(min((t - nt1) * kXTT + rw, n_end_wg - 1), 0);
-      row += 512 / kXCpr;
-      col += 512 % kXCpr;
-      if (col >= kXCpr) {
-        col -= kXCpr;
-        row += 1;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      if (w + G::NW * i < kPieces) {
-        uint64_t ko = static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) & mask) * ts2 + static_cast<uint32_t>(col16[i]);
-        if (paged) ko += static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) >> sh) * ps2;
-        x_dma16(base + ko, __builtin_amdgcn_readfirstlane(img + (w + G::NW * i) * 1024));
-        if (ownv) {  // the same piece of the V image (columns past the 64 v chunks re-read the last one)
-          uint64_t vo = static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) & mask) * vts2 +
-                        static_cast<uint32_t>(min(col16[i], kXDv * 2 - 16));
-          if (paged) vo += static_cast<uint64_t>(static_cast<uint32_t>(slot[i]) >> sh) * vps2;
-          x_dma16(vbase + vo, __builtin_amdgcn_readfirstlane(img + kXImg + (w + G::NW * i) * 1024));
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-#if RX_XMLA_TBL
-  static_assert(G::AHEAD == 1 || !RX_XMLA_TBL, "the table is built two tiles ahead of its use: one tile in flight");
+  static_assert(G::AHEAD == 1, "the table is built two tiles ahead of its use: one tile in flight");
   // One wave per tile writes the 32 rows' K and V pointers two tiles ahead (lane = row: slot lookup, page / token split
   // and the 64-bit multiplies once per ROW); a piece is then its row and column, one ds_read_b64, one 64-bit add, the DMA.
   // The per-piece form above was ~30 instructions x 5 pieces per tile and wave next to 68 MFMAs, in a kernel that pays
@@ -332,10 +276,6 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   build_table(1);
   __syncthreads();  // the first two tables are readable
   auto dma_tile = [&](int t, int ring) { dma_tile_tbl(t, ring); };
-  (void)dma_tile_pp;
-#else
-  auto dma_tile = [&](int t, int ring) { dma_tile_pp(t, ring); };
-#endif
   if (nt > 0) {  // tiles past the end are "loaded" as well (the last one again): the counted waits stay uniform
 #pragma unroll
     for (int i = 0; i < G::AHEAD; ++i) dma_tile(min(i, nt - 1), i);
@@ -352,19 +292,6 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
   const uint32_t v_lane = vrow0 * kXRow + 8 * (pp & 1) + (pp >> 1) * 16;
   const uint32_t bounce = smem_u + G::BOUNCE_AT + (w * 64 + lane) * 16;
   const bool late = w >= 4;  // the SIMD partner of an early wave: issues its pieces behind its QK^T
-#undef X_STAMP
-#if RX_XMLA_STAMP
-  uint32_t st_acc[6] = {0, 0, 0, 0, 0, 0};
-  uint32_t st_prev = (uint32_t)__builtin_amdgcn_s_memtime();
-#define X_STAMP(i)                                                 \
-  do {                                                             \
-    const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();  \
-    st_acc[i] += now_ - st_prev;                                   \
-    st_prev = now_;                                                \
-  } while (0)
-#else
-#define X_STAMP(i)
-#endif
 
   for (int t = 0; t < nt; ++t) {
     // this wave's pieces of tile t have landed: everything but the AHEAD - 1 youngest tiles' 4 (waves 0-4: 5, so they
@@ -373,17 +300,13 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
     else if constexpr (G::AHEAD == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else static_assert(G::AHEAD == 1 || G::AHEAD == 3, "two or four stages");
     __syncthreads();
-    X_STAMP(0);
     constexpr int TPB = kXSlotBlock / kXTT;
     if (t % TPB == 0 && (t / TPB + 1) * kXSlotBlock < nt1 * kXTT) stage_slots(t / TPB + 1);
-#if RX_XMLA_TBL
     build_table(t + 2);  // read by tile t + 2's issue, behind the next barrier
-#endif
     const bool more = true;
     const int t_next = min(t + G::AHEAD, nt - 1), r_next = t + G::AHEAD;
     if (!late) dma_tile(t_next, r_next);
     __builtin_amdgcn_sched_barrier(0);
-    X_STAMP(1);
     const bool prefix = t < nt1;
     const int n0 = (prefix ? t : t - nt1) * kXTT;
     const int32_t lim = prefix ? p_len : n_end_w;
@@ -416,13 +339,8 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
         __builtin_amdgcn_sched_barrier(0);  // source order IS the pipeline (hipcc left alone hoists the reads and serialises them)
       }
     }
-    X_STAMP(2);
-#ifndef RX_XMLA_LATE_AT
-#define RX_XMLA_LATE_AT 1  // where waves 4-7 issue their pieces: 1 behind QK^T, 2 behind the softmax
-#endif
-    if (RX_XMLA_LATE_AT == 1 && more && late) dma_tile(t_next, r_next);
+    if (more && late) dma_tile(t_next, r_next);  // waves 4-7 issue their pieces behind QK^T
     __builtin_amdgcn_sched_barrier(0);
-    X_STAMP(1);
     const uint32_t rp0 = kt + (own_v(t) ? kXImg : 0) + v_lane;
     const uint32_t rp1 = rp0 + 16 * kXRow;
     const float cs = prefix ? a.sm_scale * a.k_scale : a.sm_scale;
@@ -483,10 +401,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    X_STAMP(3);
-    if (RX_XMLA_LATE_AT == 2 && more && late) dma_tile(t_next, r_next);
     __builtin_amdgcn_sched_barrier(0);
-    X_STAMP(1);
     constexpr int NPRE = 4;
     u32x2 vlo[NPRE], vhi[NPRE];
 #pragma unroll
@@ -504,15 +419,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
       const u32x4 av = u32x4{lo[0], lo[1], hi[0], hi[1]};
       x_pv_mfma<T>(av, pf, oacc[nb]);
     }
-    X_STAMP(4);
   }
-#if RX_XMLA_STAMP
-  if ((w == 0 || w == 4) && lane == 0 && a.lse) {
-    uint32_t* dbg = reinterpret_cast<uint32_t*>(a.lse) + 16 * blockIdx.x + 2 * w;  // wave 0 at +0, wave 4 at +8
-    for (int i = 0; i < 5; ++i) dbg[i] = st_acc[i];
-    dbg[5] = nt;
-  }
-#endif
 
   if (!active) return;
   x_settle(oacc);
@@ -532,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
     *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (a.lse && g == 0 && !RX_XMLA_STAMP) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run * kLn2 + __logf(l);
+  if (a.lse && g == 0) a.lse[(qo0 + tk) * a.lse_stride_t + hd * a.lse_stride_h] = m_run * kLn2 + __logf(l);
 }
 
 bool extend_mla_supports(const rx_extend_params* p) {
@@ -581,8 +488,7 @@ int launch_extend_mla(const rx_extend_params* p, hipStream_t s) {
   const unsigned groups = a.xcd_bind ? static_cast<unsigned>((a.bs + 7) / 8) * 8 : static_cast<unsigned>(a.bs);
   const unsigned grid = groups * a.mblocks;
   const bool bf = p->dtype == RX_BF16;
-  static const bool no_shared = getenv("RX_XMLA_NO_SHARED") != nullptr;  // dev: the own-v-image path for aliased tensors too
-  if (no_shared) a.share_p = a.share_e = 0;
+  if (!options().extend_mla_shared_v) a.share_p = a.share_e = 0;  // (A/B switch: the own-v-image path for aliased tensors too)
 #define RX_XMLA(TT, OV)                                                                                       \
   do {                                                                                                        \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(extend_mla_kernel<TT, OV>), \
@@ -591,6 +497,7 @@ int launch_extend_mla(const rx_extend_params* p, hipStream_t s) {
     hipLaunchKernelGGL((extend_mla_kernel<TT, OV>), dim3(grid), dim3(512), XGeom8::LDS, s, a);                \
   } while (0)
   const bool ownv = !(a.share_p && a.share_e);
+  note_dispatch("extend_mla_kernel<%s, %s>|%s", bf ? "rx::BF16" : "rx::F16", tbool(ownv), linear ? "linear" : "paged");
   if (bf) {
     if (ownv) RX_XMLA(BF16, true);
     else RX_XMLA(BF16, false);

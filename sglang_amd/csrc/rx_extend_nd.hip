@@ -433,11 +433,13 @@ int launch_extend_nd(const rx_extend_params* p, hipStream_t s) {
   a.window = p->sliding_window_size; a.sinks = p->sinks;
   const int dk = p->head_dim, dv = p->v_head_dim, mel = p->max_extend_len;
   const bool bf = p->dtype == RX_BF16;
-  static const bool no_big = getenv("RX_ND_NO_BIG") != nullptr;  // dev: four-wave form only
+  const bool no_big = !options().extend_nd_big;  // (A/B switch: the four-wave form only)
   // the eight-wave form when the longest extend fills more than a four-wave workgroup's query rows
 #define RX_ND(DK_, DV_)                                                           \
   if (dk == DK_ && dv == DV_) {                                                   \
     const bool big = DK_ > 128 && mel > NdGeom<DK_, DV_, false>::QPWG && !no_big; \
+    note_dispatch("extend_nd_kernel<%s, %d, %d, %s, %s>", bf ? "rx::BF16" : "rx::F16", DK_, DV_, tbool(big), \
+                  tbool(!(a.window > 0 || a.logit_cap > 0.f)));                     \
     if (bf) {                                                                     \
       if (big) launch_nd_one<BF16, DK_, DV_, (DK_ > 128)>(a, mel, s);             \
       else launch_nd_one<BF16, DK_, DV_, false>(a, mel, s);                       \

@@ -3,6 +3,10 @@
 // All HBM-bound byte movers: 16-byte per-lane accesses, one wave (or a fraction) per row.
 #include "rx_common.h"
 
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+
 namespace rx {
 
 static thread_local char g_err[512];
@@ -13,6 +17,43 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+static thread_local char g_dispatch[256];
+void note_dispatch(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_dispatch, sizeof(g_dispatch), fmt, ap);
+  va_end(ap);
+}
+
+struct OptionEntry {
+  const char* name;
+  int Options::*field;
+};
+static const OptionEntry kOptionTable[] = {
+    {"ext32_autopack", &Options::ext32_autopack},         {"ext32_small_wg", &Options::ext32_small_wg},
+    {"ext32_plain", &Options::ext32_plain},               {"extend_16x16_d128", &Options::extend_16x16_d128},
+    {"extend_d256", &Options::extend_d256},               {"extend_d256_at128", &Options::extend_d256_at128},
+    {"extend_d256_at64", &Options::extend_d256_at64},     {"extend_d256_at96", &Options::extend_d256_at96},
+    {"extend_nd", &Options::extend_nd},                   {"extend_nd_big", &Options::extend_nd_big},
+    {"extend_mla", &Options::extend_mla},                 {"extend_mla_shared_v", &Options::extend_mla_shared_v},
+    {"decode_mla8_dma", &Options::decode_mla8_dma},
+};
+static Options load_options() {  // once, at first use: RX_OPT_<NAME> (upper case) overrides a default
+  Options o;
+  for (const OptionEntry& e : kOptionTable) {
+    char env[64] = "RX_OPT_";
+    size_t n = strlen(env);
+    for (const char* c = e.name; *c && n + 1 < sizeof(env); ++c) env[n++] = static_cast<char>(toupper(*c));
+    env[n] = 0;
+    if (const char* v = getenv(env)) o.*(e.field) = atoi(v);
+  }
+  return o;
+}
+Options& options() {
+  static Options o = load_options();
+  return o;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -533,6 +574,25 @@ int64_t rx_abi_sizeof(int which) {
   }
 }
 const char* rx_last_error(void) { return rx::err_buf(); }
+const char* rx_last_dispatch(void) { return rx::g_dispatch; }
+int rx_set_option(const char* name, int value) {
+  RX_REQUIRE(name, "rx_set_option: null name");
+  for (const rx::OptionEntry& e : rx::kOptionTable)
+    if (!strcmp(e.name, name)) {
+      rx::options().*(e.field) = value;
+      return RX_OK;
+    }
+  return rx::fail(RX_ERR_INVALID_ARG, "rx_set_option: unknown option '%s'", name);
+}
+int rx_get_option(const char* name, int* value) {
+  RX_REQUIRE(name && value, "rx_get_option: null argument");
+  for (const rx::OptionEntry& e : rx::kOptionTable)
+    if (!strcmp(e.name, name)) {
+      *value = rx::options().*(e.field);
+      return RX_OK;
+    }
+  return rx::fail(RX_ERR_INVALID_ARG, "rx_get_option: unknown option '%s'", name);
+}
 
 int rx_store_kv(const void* k, const void* v, void* k_cache, void* v_cache, const void* loc,
                 int64_t n, int64_t k_row_bytes, int64_t v_row_bytes, int64_t k_stride_bytes,

@@ -16,7 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
-RX_ABI_VERSION = 8  # include/radix_hip.h
+RX_ABI_VERSION = 9  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -88,6 +88,9 @@ PROTOTYPES = {
     "rx_version": (c_int, []),
     "rx_abi_sizeof": (c_int64, [c_int]),
     "rx_last_error": (C.c_char_p, []),
+    "rx_last_dispatch": (C.c_char_p, []),
+    "rx_set_option": (c_int, [C.c_char_p, c_int]),
+    "rx_get_option": (c_int, [C.c_char_p, C.POINTER(c_int)]),
     "rx_store_kv": (c_int, [c_void_p] * 5 + [c_int64] * 7 + [c_int, c_int64, c_int64, c_void_p, c_void_p]),
     "rx_store_kv_layout": (c_int, [c_void_p, c_void_p, C.POINTER(RxKvLayout), c_void_p, c_int64, c_int, c_int,
                                    c_int, c_int64, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p]),
@@ -228,3 +231,38 @@ def check(status: int, what: str = "") -> None:
         msg = load().rx_last_error()
         raise RadixHipError(f"{what or 'libradix_hip'} failed with status {status}: "
                             f"{msg.decode() if msg else ''}")
+
+
+def last_dispatch() -> str:
+    """Name of the kernel instance this thread's last rx_extend_attn / rx_decode_attn launched (rx_last_dispatch)."""
+    msg = load().rx_last_dispatch()
+    return msg.decode() if msg else ""
+
+
+def set_option(name: str, value: int) -> int:
+    """rx_set_option: a process-wide dispatch switch (include/radix_hip.h lists the names).  Returns the old value."""
+    old = c_int(0)
+    check(load().rx_get_option(name.encode(), C.byref(old)), "rx_get_option")
+    check(load().rx_set_option(name.encode(), int(value)), "rx_set_option")
+    return int(old.value)
+
+
+def get_option(name: str) -> int:
+    v = c_int(0)
+    check(load().rx_get_option(name.encode(), C.byref(v)), "rx_get_option")
+    return int(v.value)
+
+
+class option:
+    """``with lib.option("ext32_autopack", 0): ...`` -- a dispatch switch for the duration of a block (tests)."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name, int(value)
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False

@@ -381,11 +381,16 @@ def plan_shared_prefix_groups(last_nodes, seq_lens=None, min_shared: int = 1024,
         while k is not None:
             info[k][2].append(i)
             k = info[k][0]
-    def depth(k):
-        ent = info[k]
-        if ent[3] is None:
-            ent[3] = ent[1] + (depth(ent[0]) if ent[0] is not None else 0)
-        return ent[3]
+    def depth(k):  # iterative: a long radix chain must not hit the recursion limit
+        chain = []
+        while k is not None and info[k][3] is None:
+            chain.append(k)
+            k = info[k][0]
+        d = info[k][3] if k is not None else 0
+        for c in reversed(chain):
+            d += info[c][1]
+            info[c][3] = d
+        return d if chain else (info[k][3] if k is not None else 0)
 
     children = {}
     for k, ent in info.items():
@@ -408,7 +413,9 @@ def plan_shared_prefix_groups(last_nodes, seq_lens=None, min_shared: int = 1024,
             members = sorted(info[k][2])
             L = depth(k)
             if seq_lens is not None:
-                L = min(L, min(int(seq_lens[i]) for i in members))
+                # at most seq_len - 1: with L == seq_len a member's suffix is empty -- the decode launch then never
+                # walks (or, fused, stores) the step's newest row
+                L = min(L, min(int(seq_lens[i]) for i in members) - 1)
             if L >= min_shared and len(members) >= min_members:
                 groups.append((members, int(L)))
     groups.sort(key=lambda g: -(len(g[0]) - 1) * g[1])

@@ -214,7 +214,9 @@ def get_num_kv_splits_native(num_kv_splits: torch.Tensor, seq_lens: torch.Tensor
 def balanced_kv_splits_host(lens, num_head: int, num_kv_head: int, max_kv_splits: int, wg_target: int,
                             min_tokens_per_split: int = 128, wg_target_mixed: int = 0) -> np.ndarray:
     """Host mirror of rx_num_kv_splits_balanced (include/radix_hip.h) on the CPU copy of the lengths: what the eager
-    metadata path uses to size the split slots (the device kernel clamps to them, so a mismatch is harmless)."""
+    metadata path uses to size the split slots, the (request, split) table and the grid.  The device pass MUST run
+    with the same ``max_kv_splits`` cap: under the rounds rule the cap feeds the round tests, so a smaller cap on the
+    device can hand out more pairs than counted here."""
     lens = np.maximum(np.asarray(lens, dtype=np.int64), 0)
     group = max(1, num_head // num_kv_head)
     wgpr = num_kv_head * ((group + 15) // 16)
@@ -822,13 +824,16 @@ class CascadeGroups:
         self.shared_indices = torch.zeros(max(1, self.max_shared_total), **i32)
         # one packed int32 table per plan: [kv_indptr P+1 | qo_indptr P+1 | src_row P | src_col P | kv_start bs |
         # extra_index bs | gather C*bs]
-        self._tab_len = 2 * (P + 1) + 2 * P + 2 * self.max_bs + self.max_chunks * self.max_bs
+        self._tab_len = 2 * (P + 1) + 2 * P + 2 * self.max_bs + self.max_chunks * self.max_bs  # (int32 words only)
         self._tab_host = torch.zeros(self._tab_len, dtype=torch.int32).pin_memory() if torch.cuda.is_available() \
             else torch.zeros(self._tab_len, dtype=torch.int32)
         self._tab = torch.zeros(self._tab_len, **i32)
         self.suffix_lens = torch.zeros(self.max_bs, **i32)
         self.num_kv_splits = torch.ones(self.max_bs, **i32)
-        rows = self.max_chunks * self.max_bs
+        # rows of the gathered queries / chunk partials: C * M with C = layout()'s chunk count, which shrinks as the member
+        # count M grows (C <= ceil(CUs / (ceil(M / 128) * Hq))) -- the maximum over reachable layouts, not
+        # max_chunks * max_bs (16x oversized, ~1 GB at a 4096-request pool)
+        rows = self.rows_max = self.rows_bound(self.max_bs, num_q_heads, self.cu_count, self.max_chunks)
         self.q_rep = torch.zeros(rows * num_q_heads * head_dim, dtype=dtype, device=device)
         self.o_parts = torch.zeros(rows * num_q_heads * head_dim, dtype=dtype, device=device)
         self.lse_parts = torch.zeros(rows * num_q_heads, dtype=torch.float32, device=device)
@@ -838,6 +843,12 @@ class CascadeGroups:
         self.attn_lse = torch.empty(prow, dtype=torch.float32, device=device)
         self._lib = _L.load()
         self.bs = self.members = self.num_chunks = self.num_groups = 0
+
+    @staticmethod
+    def rows_bound(max_bs: int, hq: int, cu_count: int, max_chunks: int) -> int:
+        """max over member counts M <= max_bs of layout()'s C * M: C <= min(max_chunks, ceil(CUs / (ceil(M/128) * Hq)))
+        (layout's workgroup count sum(ceil(size_g / 128)) * Hq is at least ceil(M / 128) * Hq)."""
+        return max(min(max_chunks, max(1, -(-cu_count // (-(-m // 128) * hq)))) * m for m in range(1, max_bs + 1))
 
     @staticmethod
     def layout(groups, bs: int, hq: int, cu_count: int, max_chunks: int, chunk_align: int = 64):
@@ -885,6 +896,8 @@ class CascadeGroups:
         C, G, M = lay["C"], lay["G"], lay["M"]
         if lay["total_shared"] > self.max_shared_total:
             raise ValueError(f"CascadeGroups: {lay['total_shared']} shared tokens > max_shared_total {self.max_shared_total}")
+        if C * M > self.rows_max:
+            raise ValueError(f"CascadeGroups: {C} chunks x {M} member rows beyond the {self.rows_max} rows allocated")
         self.num_chunks, self.num_groups, self.members, self.max_group = C, G, M, lay["max_group"]
         self._tabs = (req_to_token, req_pool_indices, seq_lens)
         P = C * G

@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(l, s), f"{s} declared in include/radix_hip.h but not exported"
         assert s in lib.PROTOTYPES, f"{s} has no ctypes prototype"
-    assert l.rx_version() == lib.RX_ABI_VERSION == 8
+    assert l.rx_version() == lib.RX_ABI_VERSION == 9
     assert [l.rx_abi_sizeof(i) for i in range(4)][3] == -1 and l.rx_abi_sizeof(1) > 0
 
 
@@ -217,3 +217,36 @@ def test_split_kv_planner_accepts_the_head_dims_its_kernels_serve():
     with pytest.raises(ValueError):        # the latent shape is one kv head
         ops.VerifySplitKV(16, 2, torch.bfloat16, "cpu", head_dim=576, v_head_dim=512)
 
+
+
+def test_dispatch_options_are_named_ints_set_through_the_abi():
+    """rx_set_option / rx_get_option (round 4): the dispatch switches live in one struct; unknown names are errors; the
+    dispatch record is empty before the first attention launch of a thread."""
+    from sglang_amd import lib
+
+    l = lib.load()
+    assert lib.get_option("ext32_autopack") == 1 and lib.get_option("extend_d256_at128") == 0
+    with lib.option("ext32_autopack", 0):
+        assert lib.get_option("ext32_autopack") == 0
+    assert lib.get_option("ext32_autopack") == 1
+    assert l.rx_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in l.rx_last_error()
+    assert l.rx_get_option(b"ext32_plain", None) == -1
+    assert isinstance(lib.last_dispatch(), str)
+
+
+def test_the_launch_path_reads_no_environment_and_carries_no_wrong_result_builds():
+    """zero getenv on the rx_extend_attn / rx_decode_attn call path (the one getenv left fills the
+    option struct once, at load), no 'results are wrong' ablation or output-clobbering stamp build in the product's
+    translation units."""
+    import glob
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hits = []
+    for path in sorted(glob.glob(os.path.join(root, "sglang_amd", "csrc", "*"))):
+        text = open(path).read()
+        for i, line in enumerate(text.split("\n"), 1):
+            if "getenv" in line and not (path.endswith("rx_misc.hip") and "load_options" in text[: text.index(line)][-600:]):
+                hits.append((os.path.basename(path), i, "getenv"))
+            if re.search(r"results are (wrong|garbage)|outputs are clobbered|_STAMP\b|_ABL\b", line):
+                hits.append((os.path.basename(path), i, line.strip()[:60]))
+    assert not hits, hits

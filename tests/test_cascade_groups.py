@@ -228,3 +228,57 @@ def test_rounds_rule_of_the_balanced_schedule_host_mirror():
     a, b = first(ragged), rr(ragged)
     assert b[0] <= a[0] and (b[1:] == a[1:]).all() and int(b.sum()) <= int(a.sum())
     assert (rr([]) == first([])).all() and rr([0, 0]).tolist() == [1, 1]
+
+
+def test_planner_caps_the_shared_length_below_every_member_and_survives_deep_chains():
+    """L == seq_len would leave a member an empty suffix (its newest row never walked or stored), and the
+    depth of a long radix chain must not recurse."""
+    from sglang_amd.mem_cache.radix_cache import plan_shared_prefix_groups
+
+    class N:  # the reference's TreeNode shape: .parent, .key
+        def __init__(self, parent, n):
+            self.parent, self.key = parent, [0] * n
+
+    root = N(None, 0)
+    shared = N(root, 300)
+    a, b = N(shared, 5), N(shared, 9)
+    # request 1 IS the shared prefix (seq_len 300): the group shares 299 tokens, not 300
+    assert plan_shared_prefix_groups([a, shared, b], [305, 300, 309], min_shared=64) == [([0, 1, 2], 299)]
+    assert plan_shared_prefix_groups([a, shared, b], None, min_shared=64) == [([0, 1, 2], 300)]
+    n = root
+    for _ in range(5000):  # deeper than Python's recursion limit
+        n = N(n, 1)
+    leaves = [N(n, 3), N(n, 4)]
+    assert plan_shared_prefix_groups(leaves, [5003, 5004], min_shared=64) == [([0, 1], 5000)]
+
+
+def test_cascade_groups_buffers_cover_every_reachable_layout():
+    """ADVICE r3 (medium): the gathered-query / partial buffers hold rows_bound(max_bs) rows, not max_chunks * max_bs;
+    every layout() of every member count stays inside, and the bound is ~16x smaller at serving sizes."""
+    from sglang_amd.ops import CascadeGroups
+
+    rng = np.random.default_rng(0)
+    for max_bs, hq, cu in ((512, 32, 256), (4096, 32, 256), (300, 8, 256), (64, 64, 304)):
+        bound = CascadeGroups.rows_bound(max_bs, hq, cu, 16)
+        for _ in range(200):
+            bs = int(rng.integers(1, max_bs + 1))
+            rows = rng.permutation(bs)
+            cuts = np.sort(rng.choice(np.arange(1, bs), size=min(bs - 1, int(rng.integers(0, 6))), replace=False)) if bs > 1 else []
+            groups = [(m.tolist(), int(rng.integers(64, 4000))) for m in np.split(rows, cuts) if len(m)]
+            if rng.random() < 0.5 and len(groups) > 1:
+                groups = groups[:-1]  # some requests in no group
+            lay = CascadeGroups.layout(groups, bs, hq, cu, 16)
+            assert lay["C"] * lay["M"] <= bound, (max_bs, hq, cu, lay["C"], lay["M"], bound)
+    assert CascadeGroups.rows_bound(4096, 32, 256, 16) <= 4096 + 128 * 8 + 128   # (was 16 * 4096)
+
+
+def test_host_mirror_depends_on_the_cap_under_the_rounds_rule():
+    """Why the eager metadata hands the device schedule the cap the host mirror ran with: a smaller cap
+    ends the rounds-rule search earlier and yields MORE (request, split) pairs."""
+    from sglang_amd import ops
+
+    lens = [17702, 2856, 201, 518, 2486, 2851, 822, 1004, 2620, 1327, 892, 2500, 845, 1286, 1967, 1693, 348, 179, 2610,
+            2285, 2529, 1660, 2470, 1056, 1412, 2386]
+    h32 = ops.balanced_kv_splits_host(lens, 32, 8, 32, 512, 1024, -1)
+    hS = ops.balanced_kv_splits_host(lens, 32, 8, int(h32.max()), 512, 1024, -1)
+    assert int(h32.sum()) == 49 and int(hS.sum()) == 59

@@ -45,14 +45,13 @@ def _bits(t):
 
 class _Harness:
     def __init__(self, page_size, hq, hkv, d, dtype, layout, index_mode, max_ctx=4200, max_reqs=8,
-                 split_policy="native"):
+                 split_policy="native", size=8192):
         from sglang_amd.attention.backend import HipRadixAttnBackend
         from sglang_amd.attention.radix_attention import RadixAttention
         from sglang_amd.mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
         from sglang_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
 
         self.ps, self.hq, self.hkv, self.d, self.dtype = page_size, hq, hkv, d, dtype
-        size = 8192
         self.pool = MHATokenToKVPool(size, page_size, dtype, hkv, d, 1, DEV)
         self.r2t = ReqToTokenPool(max_reqs, max_ctx, DEV)
         if page_size == 1:
@@ -671,6 +670,46 @@ def test_balanced_split_schedule_kernel_matches_its_host_mirror_and_heterogeneou
     want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, d)), _bits(kb), _bits(vb), *args)
     absw = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, d)), _bits(kb), parity.abs_values(_bits(vb)), *args)
     parity.check_out(o.view(bs, hq, d).float().cpu().numpy(), want, torch.bfloat16, "heterogeneous batch", absw=absw)
+
+
+def test_eager_split_items_table_holds_every_pair_the_device_schedule_emits():
+    """the eager metadata sized the (request, split) table and the grid from the host mirror run with
+    cap = native_split_cap while the device pass ran with cap = max(host counts); under the rounds rule the smaller cap
+    ends the round search earlier and hands out MORE pairs (this batch: host 49, device 59), so the shortest requests got
+    no workgroup and their rows stayed uninitialised.  Both passes now take the same cap: the table's count equals the
+    host's, every request's output meets the oracle."""
+    from sglang_amd import ops
+    from sglang_amd.forward_batch import ForwardBatch
+
+    lens = [17702, 2856, 201, 518, 2486, 2851, 822, 1004, 2620, 1327, 892, 2500, 845, 1286, 1967, 1693, 348, 179, 2610,
+            2285, 2529, 1660, 2470, 1056, 1412, 2386]
+    hq, hkv, d, ps = 32, 8, 128, 16
+    host32 = ops.balanced_kv_splits_host(lens, hq, hkv, 32, 512, 1024, -1)
+    hostS = ops.balanced_kv_splits_host(lens, hq, hkv, int(host32.max()), 512, 1024, -1)
+    assert int(hostS.sum()) > int(host32.sum())  # the batch does separate the two caps (else it tests nothing)
+    bs = len(lens)
+    hs = _Harness(ps, hq, hkv, d, torch.bfloat16, "shuffled_pages", "paged", max_ctx=18000, max_reqs=32, size=1 << 16)
+    assert hs.backend.device_core_count == 256, "the example is tuned to 256 CUs"
+    rows = hs.r2t.alloc(bs)
+    hs.fill_prefix(rows, [n - 1 for n in lens])
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    seq = torch.tensor(lens, dtype=torch.int64)
+    last = torch.tensor([int(hs.r2t.req_to_token[r, n - 2]) for r, n in zip(rows, lens)], dtype=torch.int64, device=DEV)
+    loc = hs.alloc.alloc_decode(seq.to(DEV), seq, last)
+    hs.r2t.req_to_token[rpi, torch.tensor([n - 1 for n in lens], device=DEV)] = loc.to(torch.int32)
+    q, k, v = hs.rand(bs, hq * d), hs.rand(bs, hkv * d), hs.rand(bs, hkv * d)
+    fb = ForwardBatch.for_decode(rpi, seq.to(DEV), loc, seq)
+    hs.backend.init_forward_metadata(fb)
+    md = hs.backend.forward_metadata
+    assert md.split_items is not None
+    live = int(md.split_items.count.item())
+    assert live <= md.split_items.cap, (live, md.split_items.cap)
+    assert live == int(host32.sum()) and md.num_kv_splits.tolist() == host32.tolist()
+    o = hs.layer(q, k, v, fb, hs.backend)
+    kb, vb = hs.pool.get_kv_buffer(0)
+    args = (_bits(hs.r2t.req_to_token), np.array(rows), np.array(lens), d ** -0.5)
+    want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, d)), _bits(kb), _bits(vb), *args)
+    parity.check_out(o.view(bs, hq, d).float().cpu().numpy(), want, torch.bfloat16, "skewed batch, rounds rule")
 
 
 def test_short_extend_over_long_prefix_takes_split_kv_path():

@@ -1,7 +1,7 @@
 """Long causal extends of a GQA-4 model run GQA-packed by themselves (rx_extend32.hip: PLAIN instance with the packing
 factor as a compile-time constant).  Packing only regroups the query rows into workgroups -- (token, q head of the group)
 pairs instead of the tokens of one q head -- so outputs and LSEs must be bit-identical to the unpacked launch
-(RX_EXT32_AUTOPACK=0) and inside the usual bound of the fp64 oracle (extend_attention_fwd,
+(option ext32_autopack = 0) and inside the usual bound of the fp64 oracle (extend_attention_fwd,
 kernels/ops/attention/extend_attention.py:664-812)."""
 import os
 
@@ -51,10 +51,10 @@ def test_autopacked_extend_is_bit_identical_and_matches_oracle(dtype, shape, hea
     qo = np.concatenate([[0], np.cumsum(extend)]).astype(np.int64)
     sm = d ** -0.5
     outs = {}
-    old = os.environ.get("RX_EXT32_AUTOPACK")
-    try:
-        for mode in ("1", "0"):
-            os.environ["RX_EXT32_AUTOPACK"] = mode
+    from sglang_amd import lib as rxlib
+
+    for mode in ("1", "0"):
+        with rxlib.option("ext32_autopack", int(mode)):
             o = torch.full((T, hq, d), float("nan"), dtype=dtype, device=DEV)
             lse = torch.zeros(T, hq, dtype=torch.float32, device=DEV)
             ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV),
@@ -62,12 +62,9 @@ def test_autopacked_extend_is_bit_identical_and_matches_oracle(dtype, shape, hea
                                      kvi.to(DEV), None, True, None, max(extend), 1.0, 1.0, sm_scale=sm, lse_extend=lse,
                                      page_size=1, avg_kv_len_hint=int(np.mean(prefix)) + 2048)  # (the hint: the eight-wave launch)
             torch.cuda.synchronize()
+            # the dispatch record says which instance ran: the packed PLAIN one (PKC = group) or the unpacked one
+            assert ("pkc%d" % (hq // hkv if mode == "1" else 0)) in rxlib.last_dispatch(), rxlib.last_dispatch()
             outs[mode] = (o, lse)
-    finally:
-        if old is None:
-            os.environ.pop("RX_EXT32_AUTOPACK", None)
-        else:
-            os.environ["RX_EXT32_AUTOPACK"] = old
     assert torch.equal(outs["1"][0].view(torch.int16), outs["0"][0].view(torch.int16))
     assert torch.equal(outs["1"][1], outs["0"][1])
     want = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, np.asarray(kvp, dtype=np.int32),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sliding-window / capped extend at head dim 256 (Gemma-class layers): ms per call of the config-3 chunk shape
-(32 requests x (3584 cached + 512 new), 16 q / 8 kv heads; env BS P E HQ HKV D W).  RX_EXTEND_NO_D256=1 times
+(32 requests x (3584 cached + 512 new), 16 q / 8 kv heads; env BS P E HQ HKV D W).  RX_OPT_EXTEND_D256=0 times
 rx_extend_nd.hip instead; D=64 HQ=64 HKV=8 P=0 E=8192 W=128 BS=4 is a gpt-oss-like sliding-window layer."""
 import os
 import sys

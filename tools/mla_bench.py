@@ -57,10 +57,3 @@ ms = e0.elapsed_time(e1) / 20
 byt = bs * ctx * dk * (1 if FP8 else 2)
 print(f"MLA decode bs={bs} ctx={ctx} Hq={hq}: {ms*1e3:.1f} us  {byt/ms/1e6:.0f} GB/s ({byt/ms/1e6/8000:.1%} of 8 TB/s)")
 
-if os.environ.get("STAMPS"):
-    run(); torch.cuda.synchronize()
-    st = al[:, 0].contiguous().view(torch.int32)[..., :6].double()   # [bs, S, 6] (head 0 = lane 0 of wave 0)
-    names = (["landing", "dma issue", "S=KQ^T", "xch barrier", "softmax", "PV"] if FP8 and not os.environ.get("RX_MLA8_OLD")
-             else ["S=KQ^T", "softmax", "PV", "stage", "barrier", "prologue"])
-    print("mean cycles per WG:", {n: round(v) for n, v in zip(names, st.mean((0, 1)).tolist())})
-    print("per tile:", {n: round(v / (ctx / S / 32)) for n, v in zip(names, st.mean((0, 1)).tolist())})

@@ -4,8 +4,7 @@
     python tools/mla_extend_bench.py                 # bs 32 x (3584 cached + 512 new), 16 q heads (DeepSeek TP8 shard)
     SHAPES=32x3584+512,8x8192+2048 HQ=16,128 python tools/mla_extend_bench.py
     OWNV=1  ... the new tokens' v is its own tensor (the kernel's two-image form)
-    STAMPS=1 ... with a library built with RX_CFLAGS=-DRX_XMLA_STAMP=1: phase times per tile
-    GENERIC=1 ... also time the scalar generic kernel (RX_EXTEND_NO_MLA=1 in a child process) on the first shape
+    GENERIC=1 ... also time the scalar generic kernel (RX_OPT_EXTEND_MLA=0 in a child process) on the first shape
 
 FLOPs = 2 * (576 + 512) * Hq * sum_i (E_i * P_i + E_i (E_i + 1) / 2)   (causal)."""
 import json
@@ -39,7 +38,7 @@ def run(bs, P, E, hq, own_v, iters):
     ke = latent[ext_slots].contiguous()
     ve = ke[..., :DV].contiguous() if own_v else ke[..., :DV]
     o = torch.empty(bs * E, hq, DV, device=DEV, dtype=torch.bfloat16)
-    lse = torch.zeros(bs * E, hq, device=DEV, dtype=torch.float32) if os.environ.get("STAMPS") else None
+    lse = None
     sm = 1.0 / (192 ** 0.5)
 
     def call():
@@ -64,19 +63,6 @@ def run(bs, P, E, hq, own_v, iters):
     torch.cuda.synchronize()
     ms = ev[0].elapsed_time(ev[1]) / iters
     flops = 2.0 * (DK + DV) * hq * bs * (E * P + E * (E + 1) / 2)
-    if lse is not None:  # a build with -DRX_XMLA_STAMP=1: per-workgroup phase cycles of wave 0 (s_memtime, 100 MHz ticks)
-        nwg = ((bs + 7) // 8 * 8 if bs >= 8 else bs) * ((E * hq + 127) // 128)
-        if True:  # the eight-wave form writes two records per workgroup: wave 0 (early DMA) and wave 4 (late)
-            rec = lse.view(torch.int32).flatten()[: 16 * nwg].view(nwg, 2, 8).double()
-            for nm, st in (("wave 0", rec[:, 0]), ("wave 4", rec[:, 1])):
-                st = st[st[:, 5] > 0]
-                per = (st[:, :5] / st[:, 5:6]).mean(0).tolist()
-                print(nm, "cycles per tile:", {n: round(v, 1) for n, v in zip(["wait+barrier", "dma issue", "QK", "softmax", "PV"], per)})
-        st = lse.view(torch.int32).flatten()[: 8 * nwg].view(nwg, 8).double()
-        st = st[st[:, 5] > 0]
-        names = ["wait+barrier", "dma issue", "QK", "softmax", "PV"]
-        per = (st[:, :5] / st[:, 5:6]).mean(0).tolist()
-        print("ticks per tile (wave 0):", {n: round(v, 1) for n, v in zip(names, per)}, "tiles/wg", st[:, 5].mean().item())
     return ms, flops / ms / 1e9, o
 
 
@@ -91,10 +77,10 @@ def main():
         for hq in hqs:
             ms, tf, _ = run(int(bs), int(P), int(E), hq, own_v, iters)
             print(json.dumps({"bs": int(bs), "prefix": int(P), "extend": int(E), "hq": hq, "own_v": own_v,
-                              "kernel": "generic" if os.environ.get("RX_EXTEND_NO_MLA") else "extend_mla",
+                              "kernel": "generic" if (os.environ.get("RX_OPT_EXTEND_MLA") == "0") else "extend_mla",
                               "ms": round(ms, 3), "tflops": round(tf, 1), "frac_of_2.5PF": round(tf / 2500, 3)}), flush=True)
-    if os.environ.get("GENERIC") and not os.environ.get("RX_EXTEND_NO_MLA"):
-        env = dict(os.environ, RX_EXTEND_NO_MLA="1", SHAPES=shapes[0], HQ=str(hqs[0]), ITERS="1")
+    if os.environ.get("GENERIC") and not (os.environ.get("RX_OPT_EXTEND_MLA") == "0"):
+        env = dict(os.environ, RX_OPT_EXTEND_MLA="0", SHAPES=shapes[0], HQ=str(hqs[0]), ITERS="1")
         env.pop("GENERIC")
         subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, check=False)
 
