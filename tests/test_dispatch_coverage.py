@@ -181,21 +181,18 @@ def _bits(t):
 
 def _device_pool(ops, kb, vb, lin, ps, hnd):
     """canonical pools [slots, H, D] -> device tensors, page_size, layout, and a function giving the device K rows back
-    as [slots, H, D].  linear = plain slot-major rows; otherwise page-granular with a page stride that is NOT
-    page_size x token stride (HND, or NHD pages with two pad tokens)."""
+    as [slots, H, D].  linear = plain slot-major rows; otherwise HND pages [pages, H, page, D], with two pad
+    tokens per (page, head) when one kv head would make plain HND slot-major."""
     if lin:
         kd, vd = kb.to(DEV), vb.to(DEV)
         return kd, vd, 1, None, lambda: kd
     pages = kb.shape[0] // ps
-    if hnd:
-        kd = kb.view(pages, ps, *kb.shape[1:]).permute(0, 2, 1, 3).contiguous().to(DEV)
-        vd = vb.view(pages, ps, *vb.shape[1:]).permute(0, 2, 1, 3).contiguous().to(DEV)
-        return kd, vd, ps, ops.kv_layout_hnd(kd, vd), lambda: kd.permute(0, 2, 1, 3).reshape(pages * ps, *kb.shape[1:])
-    kd = torch.zeros(pages, ps + 2, *kb.shape[1:], dtype=kb.dtype)
-    vd = torch.zeros(pages, ps + 2, *vb.shape[1:], dtype=vb.dtype)
-    kd[:, :ps], vd[:, :ps] = kb.view(pages, ps, *kb.shape[1:]), vb.view(pages, ps, *vb.shape[1:])
-    kd, vd = kd.to(DEV)[:, :ps], vd.to(DEV)[:, :ps]
-    return kd, vd, ps, ops._kv_layout(kd, vd, ps), lambda: kd.reshape(pages * ps, *kb.shape[1:])
+    pad = 0 if (hnd and kb.shape[1] > 1) else 2   # (with one kv head plain HND IS slot-major: two pad tokens per page then)
+    kd = torch.zeros(pages, kb.shape[1], ps + pad, kb.shape[2], dtype=kb.dtype)
+    vd = torch.zeros(pages, vb.shape[1], ps + pad, vb.shape[2], dtype=vb.dtype)
+    kd[:, :, :ps], vd[:, :, :ps] = kb.view(pages, ps, *kb.shape[1:]).permute(0, 2, 1, 3), vb.view(pages, ps, *vb.shape[1:]).permute(0, 2, 1, 3)
+    kd, vd = kd.to(DEV)[:, :, :ps], vd.to(DEV)[:, :, :ps]
+    return kd, vd, ps, ops.kv_layout_hnd(kd, vd), lambda: kd.permute(0, 2, 1, 3).reshape(pages * ps, *kb.shape[1:])
 
 
 def _run_extend(c, ops, rxlib):
@@ -247,11 +244,11 @@ def _run_extend(c, ops, rxlib):
             kd = kb.to(DEV)
             vd, page, lay = kd[..., :dv], 1, None
         else:
-            kd = torch.zeros(n_pages, ps + 2, 1, dk, dtype=pdt)
-            kd[:, :ps] = kb.view(n_pages, ps, 1, dk)
-            kd = kd.to(DEV)[:, :ps]
+            kd = torch.zeros(n_pages, 1, ps + 2, dk, dtype=pdt)
+            kd[:, :, :ps] = kb.view(n_pages, ps, 1, dk).permute(0, 2, 1, 3)
+            kd = kd.to(DEV)[:, :, :ps]
             vd, page = kd[..., :dv], ps
-            lay = ops._kv_layout(kd, vd, ps)
+            lay = ops.kv_layout_hnd(kd, vd)
         ked = ke.to(DEV)
         ved = ked[..., :dv].contiguous() if c["own_v"] else ked[..., :dv]
     else:
@@ -327,11 +324,11 @@ def _run_decode(c, ops, rxlib):
             kd = kb_dev.to(DEV)
             vd, page, lay = kd[..., :dv], 1, None
         else:
-            kd = torch.zeros(n_pages, ps + 2, 1, dk, dtype=pdt)
-            kd[:, :ps] = kb_dev.view(n_pages, ps, 1, dk)
-            kd = kd.to(DEV)[:, :ps]
+            kd = torch.zeros(n_pages, 1, ps + 2, dk, dtype=pdt)
+            kd[:, :, :ps] = kb_dev.view(n_pages, ps, 1, dk).permute(0, 2, 1, 3)
+            kd = kd.to(DEV)[:, :, :ps]
             vd, page = kd[..., :dv], ps
-            lay = ops._kv_layout(kd, vd, ps)
+            lay = ops.kv_layout_hnd(kd, vd)
     else:
         kd, vd, page, lay, k_rows = _device_pool(ops, kb_dev, vb_dev, c["lin"], ps, hnd=(len(c["expect"]) % 2 == 0))
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731

@@ -63,7 +63,7 @@ def test_autopacked_extend_is_bit_identical_and_matches_oracle(dtype, shape, hea
                                      page_size=1, avg_kv_len_hint=int(np.mean(prefix)) + 2048)  # (the hint: the eight-wave launch)
             torch.cuda.synchronize()
             # the dispatch record says which instance ran: the packed PLAIN one (PKC = group) or the unpacked one
-            assert ("pkc%d" % (hq // hkv if mode == "1" else 0)) in rxlib.last_dispatch(), rxlib.last_dispatch()
+            assert rxlib.last_dispatch().endswith("true, %d>" % (hq // hkv if mode == "1" else 0)), rxlib.last_dispatch()
             outs[mode] = (o, lse)
     assert torch.equal(outs["1"][0].view(torch.int16), outs["0"][0].view(torch.int16))
     assert torch.equal(outs["1"][1], outs["0"][1])
