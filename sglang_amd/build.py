@@ -26,7 +26,7 @@ EXTRA_FLAGS = {"rx_extend32.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-ml
                "rx_extend_nd.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
                "rx_extend_mla.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "rx_extend_d256.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
-HEADERS = ["rx_common.h", os.path.join(ROOT, "include", "radix_hip.h")]
+HEADERS = ["rx_common.h", os.path.join(ROOT, "include", "radix_hip.h"), "rx_extend32_kernel.inc"]
 
 
 def _hipcc() -> str:
