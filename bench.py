@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extend", action="store_true")
     ap.add_argument("--no-radix-hit", action="store_true", help="skip the shared-prefix (radix-hit) decode leg")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the `extra` legs (TP shards of the step, BASELINE configs[1], the ragged batch), each a child run")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--cpu-chunk", type=int, default=8,
                     help="requests of the config-3 chunk the extend CPU baseline runs (the GPU leg runs 32)")
@@ -240,6 +242,8 @@ def decode_layers(st, fb, world, lo, hi, ev_pairs=None, attn_only_first=False, s
             o = be.forward_decode(st.q, None, None, layer, fb, save_kv_cache=False)
             e1.record()
             ev_pairs.append((e0, e1))
+            from sglang_amd import lib as _rxlib
+            st.probe_kernel = _rxlib.last_dispatch()
         else:
             o = layer(st.q, st.k, st.v, fb, be)
         if pending is not None:
@@ -273,11 +277,16 @@ class GraphStep:
         be.init_cuda_graph_state(fb.batch_size, fb.batch_size)
         be.init_forward_metadata_out_graph(fb, in_capture=True)
         layer_p = st.layers[p]
+        # the probe layer runs what every other layer runs: where the backend fuses the step's KV store into the decode
+        # launch (16-bit pools, D 64 / 128: the FUSE instance), the timed launch carries the store as theirs do;
+        # otherwise the store goes into graph A and the plain instance is timed
+        self.fuse = bool(be._fused_store_ok(layer_p, st.k.view(-1, st.hkv, st.D), st.v.view(-1, st.hkv, st.D)))
         st.probe_o = be.forward_decode(st.q, None, None, layer_p, fb, save_kv_cache=False)  # address-stable output
 
         def seg_a():
             decode_layers(st, fb, world, 0, p)
-            be.token_to_kv_pool.set_kv_buffer(layer_p, fb.out_cache_loc, st.k, st.v)
+            if not self.fuse:
+                be.token_to_kv_pool.set_kv_buffer(layer_p, fb.out_cache_loc, st.k, st.v)
 
         def seg_b():
             decode_layers(st, fb, world, p, L, skip_attn_first=True)
@@ -302,10 +311,15 @@ class GraphStep:
         if ev_pairs is not None:
             e0, e1 = st.ev_pool.pop(), st.ev_pool.pop()
             e0.record()
-        o = st.backend.forward_decode(st.q, None, None, st.layers[self.p], self.fb, save_kv_cache=False)
+        if self.fuse:
+            o = st.backend.forward_decode(st.q, st.k, st.v, st.layers[self.p], self.fb, save_kv_cache=True)
+        else:
+            o = st.backend.forward_decode(st.q, None, None, st.layers[self.p], self.fb, save_kv_cache=False)
         if ev_pairs is not None:
             e1.record()
             ev_pairs.append((e0, e1))
+            from sglang_amd import lib as _rxlib
+            st.probe_kernel = _rxlib.last_dispatch()
         st.probe_o.copy_(o)  # 2 MiB device copy into the buffer graph B reads (outside the event pair)
 
     def __call__(self, ev_pairs=None):
@@ -617,59 +631,116 @@ def gpu_warm(fn, ms=80.0, batch=8):
             return
 
 
-def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=20):
+def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=20, shape=None, layers=None):
     """Config 3: bs=256 sharing one 3584-token prefix (radix hit) + 512 new tokens each, chunked to 32 requests
-    (16 Ki tokens) per forward; one layer.  The cached prefix sits where the decode leg's KV sits: page_size-16
-    pages in SHUFFLED order (page 0 reserved) of a pool in the bench's --kv-layout (HND by default), and every
-    request's kv_indices row lists the same slots -- the radix hit."""
+    (16 Ki tokens) per forward.  The cached prefix sits where the decode leg's KV sits: page_size-16 pages in SHUFFLED
+    order (page 0 reserved) of a pool in the bench's --kv-layout (HND by default), and every request's req_to_token row
+    starts with the same slots -- the radix hit.
+
+    Timed like the decode leg, through the backend: one FORWARD = HipRadixAttnBackend.init_forward_metadata (qo / kv
+    indptr, the kv_indices gather from req_to_token) + per layer RadixAttention.forward in EXTEND mode = set_kv_buffer
+    of the chunk's 16 Ki new tokens + extend attention (VERDICT r03 "weak" 6: the leg used to time the bare operator on
+    prebuilt indices).  `tflops` = layers x attention FLOPs / forward time; `kernel_only` = the bare
+    ops.extend_attention_fwd launch on the same tensors (what `roofline` prices: the dominant kernel alone)."""
     from sglang_amd import ops
+    from sglang_amd.attention.backend import HipRadixAttnBackend
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+    from sglang_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
 
     D = head_dim
     Dv = v_head_dim or D
     HQ, HKV = 32 // tp, max(1, 8 // tp)
-    P, E, chunk = 3584, 512, 32
+    P, E, chunk = shape or (3584, 512, 32)
     if os.environ.get("RX_EXTEND_SHAPE"):  # dev: "P,E,chunk", e.g. config 2's 2k prompts without a prefix: 0,2048,8
         P, E, chunk = (int(x) for x in os.environ["RX_EXTEND_SHAPE"].split(","))
+    L = layers or args.layers
     ps = args.page_size
     g = torch.Generator(device=dev).manual_seed(1)
-    n_pages = (P + ps - 1) // ps + chunk * ((E + ps - 1) // ps) + 1   # prefix pages + the new tokens' + page 0
+    pre_pages, new_pages = (P + ps - 1) // ps, (E + ps - 1) // ps
+    n_pages = pre_pages + chunk * new_pages
     hnd = args.kv_layout == "hnd"
-    kshape = (n_pages, HKV, ps, D) if hnd else (n_pages * ps, HKV, D)
-    vshape = (n_pages, HKV, ps, Dv) if hnd else (n_pages * ps, HKV, Dv)
-    kb = torch.randn(kshape, device=dev, generator=g).to(torch.bfloat16)
-    vb = torch.randn(vshape, device=dev, generator=g).to(torch.bfloat16)
-    lay = ops.kv_layout_hnd(kb, vb) if hnd else None
+    pool = MHATokenToKVPool(n_pages * ps, ps, torch.bfloat16, HKV, D, L, dev, v_head_dim=Dv, use_hnd=hnd)
+    zero = bool(os.environ.get("RX_EXTEND_ZERO"))  # dev: all-zero operands -- same instruction stream, minimal switching
+    for l in range(L):                              # power: separates "cycles" from "clock held under load" (DVFS)
+        if not zero:
+            pool.k_buffer[l].normal_(generator=g)
+            pool.v_buffer[l].normal_(generator=g)
+    r2t = ReqToTokenPool(chunk, P + E + ps, dev)
+    perm = torch.randperm(n_pages, device=dev, generator=g) + 1  # shuffled pages, page 0 reserved
+    tok = torch.arange(ps, device=dev)[None, :]
+    prefix_slots = (perm[:pre_pages, None] * ps + tok).reshape(-1)[:P]
+    rows = r2t.alloc(chunk)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=dev)
+    new_slots = (perm[pre_pages:].view(chunk, new_pages)[:, :, None] * ps + tok[None]).reshape(chunk, -1)[:, :E]
+    r2t.req_to_token[rpi, :P] = prefix_slots.to(torch.int32)[None, :]
+    r2t.req_to_token[rpi, P: P + E] = new_slots.to(torch.int32)
+
+    class MC:
+        num_attention_heads, num_key_value_heads, context_len = HQ * tp, HKV * tp, P + E + ps
+
+    class MR:
+        device = dev
+        req_to_token_pool = r2t
+        token_to_kv_pool = pool
+        model_config = MC
+        page_size = ps
+        tp_size = tp
+
+        class server_args:
+            triton_attention_num_kv_splits = args.max_kv_splits
+
+    backend = HipRadixAttnBackend(MR)
+    lay_objs = [RadixAttention(HQ, D, D ** -0.5, HKV, l, v_head_dim=Dv) for l in range(L)]
     T = chunk * E
-    q = torch.randn(T, HQ, D, device=dev, generator=g).to(torch.bfloat16)
-    k_ext = torch.randn(T, HKV, D, device=dev, generator=g).to(torch.bfloat16)
-    v_ext = torch.randn(T, HKV, Dv, device=dev, generator=g).to(torch.bfloat16)
-    o = torch.empty(T, HQ, Dv, device=dev, dtype=torch.bfloat16)
-    if os.environ.get("RX_EXTEND_ZERO"):  # dev: all-zero operands -- same instruction stream, minimal switching power:
-        for t_ in (kb, vb, q, k_ext, v_ext):  # separates "cycles" from "clock held under load" (DVFS)
-            t_.zero_()
-    pages = torch.randperm(n_pages - 1, device=dev, generator=g)[: (P + ps - 1) // ps] + 1
-    prefix_slots = (pages[:, None] * ps + torch.arange(ps, device=dev)[None, :]).reshape(-1)[:P].to(torch.int64)
-    kv_indices = prefix_slots.repeat(chunk)  # identical rows: every request hits the same pages
+    mk = (lambda *sh: torch.zeros(*sh, device=dev, dtype=torch.bfloat16)) if zero else (
+        lambda *sh: torch.randn(*sh, device=dev, generator=g).to(torch.bfloat16))
+    q, k_ext, v_ext = mk(T, HQ * D), mk(T, HKV * D), mk(T, HKV * Dv)
+    seq = torch.full((chunk,), P + E, dtype=torch.int64, device=dev)
+    fb = ForwardBatch.for_extend(rpi, seq, new_slots.reshape(-1).to(torch.int64), [P] * chunk, [E] * chunk)
+
+    def forward():
+        backend.init_forward_metadata(fb)
+        for lo in lay_objs:
+            lo(q, k_ext, v_ext, fb, backend)
+
+    forward()
+    torch.cuda.synchronize()
+    from sglang_amd import lib as rxlib
+    kernel_name = rxlib.last_dispatch()
+    gpu_warm(forward, batch=1)
+    nfwd = max(2, nchunks // L) if L > 1 else nchunks
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(nfwd):
+        forward()
+    e1.record()
+    torch.cuda.synchronize()
+    ms_fwd = e0.elapsed_time(e1) / nfwd
+    flops = 2.0 * HQ * (D + Dv) * chunk * (E * P + E * (E + 1) / 2)   # one layer's attention
+    tflops = L * flops / (ms_fwd * 1e-3) / 1e12
+
+    # the dominant kernel alone: the bare operator on the same pool and page table (layer 0)
+    kb, vb = pool.get_kv_buffer(0)
+    lay = ops.kv_layout_hnd(kb, vb) if hnd else None
+    kv_indices = r2t.req_to_token[rpi, :P].reshape(-1).to(torch.int64)
     kv_indptr = (torch.arange(chunk + 1, device=dev) * P).to(torch.int32)
     qo_indptr = (torch.arange(chunk + 1, device=dev) * E).to(torch.int64)
-
-    qp = int(os.environ.get("RX_EXTEND_QPACK", "1"))  # dev: GQA-packed query rows (rx_extend_params.q_pack) on this shape
+    o = torch.empty(T, HQ, Dv, device=dev, dtype=torch.bfloat16)
+    q3, k3, v3 = q.view(T, HQ, D), k_ext.view(T, HKV, D), v_ext.view(T, HKV, Dv)
 
     def run():
-        ops.extend_attention_fwd(q, k_ext, v_ext, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True,
-                                 None, E, 1.0, 1.0, sm_scale=D ** -0.5, page_size=ps, kv_layout=lay,
-                                 **({"q_pack": qp} if qp > 1 else {}))
+        ops.extend_attention_fwd(q3, k3, v3, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True,
+                                 None, E, 1.0, 1.0, sm_scale=D ** -0.5, page_size=ps, kv_layout=lay)
 
     gpu_warm(run)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(nchunks):
         run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / nchunks
-    flops = 2.0 * HQ * (D + Dv) * chunk * (E * P + E * (E + 1) / 2)
-    tflops = flops / (ms * 1e-3) / 1e12
+    k_tflops = flops / (ms * 1e-3) / 1e12
     # MFMA-pipe busy fraction: an SQ-counter figure (SQ_VALU_MFMA_BUSY_CYCLES) that needs its own rocprofv3 --pmc passes;
     # the committed summary of those passes is quoted with its provenance, for the shape it was measured on only
     mfma_busy = None
@@ -681,16 +752,70 @@ def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=20):
             key = next(k for k in doc["derived"] if k.startswith("mfma_pipe_busy_frac"))
             mfma_busy = {"frac_of_simd_cycles": doc["derived"][key], "valu_per_mfma": doc["derived"].get("valu_per_mfma"),
                          "file": "profiles/" + os.path.basename(cand[-1]),
-                         "note": "three rocprofv3 --pmc passes of `bench.py --extend-only` on another box, not this run"}
+                         "note": "rocprofv3 --pmc passes of `bench.py --extend-only` on another box, not this run"}
     except Exception:  # noqa: BLE001
         pass
+    del pool, backend
     return {"metric": f"extend attention TFLOP/s (config 3: {P}-token shared prefix + {E} new, bf16, head_dim {D}"
                       + (f"/{Dv}" if Dv != D else "") + ")",
+            "path": f"HipRadixAttnBackend: init_forward_metadata + {L} x (set_kv_buffer of {T} new tokens + extend attention)",
             "mfma_busy": mfma_busy,
-            "tflops": tflops, "ms_per_chunk": ms, "chunk_requests": chunk, "flops_per_chunk": flops,
+            "tflops": tflops, "ms_per_forward": ms_fwd, "layers": L, "ms_per_chunk": ms_fwd / L, "chunk_requests": chunk,
+            "flops_per_chunk": flops, "kernel": "rx::" + kernel_name,
+            "kernel_only": {"tflops": k_tflops, "ms_per_launch": ms, "launches_timed": nchunks},
             "prefix_layout": f"page_size {ps}, shuffled pages, {args.kv_layout.upper()} pool",
-            "roofline": {"bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": None}}
+            "warmup": "each timed region follows ~80 ms of the same launches (gpu_warm: clock ramp after idle)",
+            # the dominant kernel's roofline: algorithmic FLOPs per launch / its launch-to-launch time
+            "roofline": {"bound": "mfma", "achieved": k_tflops, "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": k_tflops / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "rx::" + kernel_name}}
+
+
+def child_decode_leg(args, argv, timeout=900):
+    """One more decode-step measurement as a CHILD `python bench.py ...` (its own process: the step's state is built
+    from scratch, this process holds no pool meanwhile) -- returns the fields of its JSON line that matter."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extend", "--no-radix-hit", "--no-cpu-baseline",
+           "--no-extra", "--steps", "10", "--warmup", "3", "--layers", str(args.layers), "--kv-layout", args.kv_layout] + argv
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+    if r.returncode != 0 or line is None:
+        return {"error": f"rc={r.returncode} {r.stderr.strip()[-300:]}"}
+    d = json.loads(line)
+    rf = d["roofline"]
+    return {"cmd": "python bench.py " + " ".join(cmd[2:]), "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+            "kernel": rf.get("kernel"), "kernel_ms": rf["avg_launch_ms"], "kernel_frac_of_hbm_peak": rf["frac"],
+            "bytes_per_launch": rf["bytes_per_launch"], "workload": d["config"]["workload"],
+            "seq_lens": d["config"]["seq_lens"], "step_launch": d["config"]["step_launch"]}
+
+
+def extra_legs(args, dev):
+    """Legs next to the headline, each the same step measured on another input:
+    * tp_sim: ONE rank's shard of the TP = 2 / 4 / 8 step on this one GPU (Hq / tp, Hkv / tp heads; no collective) -- what
+      each GPU of the 1 -> 8 curve runs between its all-reduces; at TP = 8 (one kv head per rank) also with page_size 64,
+      where a (page, head) run of the HND pool is 16 KiB contiguous instead of 4;
+    * ragged_decode: SURVEY 8d's second input (lengths uniform in [ctx / 2, ctx]);
+    * config1: BASELINE configs[1] -- bs 64, 2 k prompt / 128 generated: the decode step at its final length (bs 64,
+      ctx 2176) and the prefill as extend attention without a prefix (8 requests x 2048 new tokens per forward)."""
+    ex = {"tp_sim": {"note": "one rank's shard on ONE GPU, no collective: not an N-GPU measurement"}}
+    for tp in (2, 4, 8):
+        ex["tp_sim"][f"tp{tp}"] = child_decode_leg(args, ["--tp-sim", str(tp), "--bs", str(args.bs), "--ctx", str(args.ctx),
+                                                          "--page-size", str(args.page_size)])
+    ex["tp_sim"]["tp8_page64"] = child_decode_leg(args, ["--tp-sim", "8", "--bs", str(args.bs), "--ctx", str(args.ctx),
+                                                         "--page-size", "64"])
+    ex["ragged_decode"] = child_decode_leg(args, ["--ragged", "--bs", str(args.bs), "--ctx", str(args.ctx),
+                                                  "--page-size", str(args.page_size)])
+    c1 = {"workload": "BASELINE configs[1]: Llama-3-8B bf16 TP=1, bs=64, 2k prompt / 128 gen"}
+    c1["decode"] = child_decode_leg(args, ["--bs", "64", "--ctx", "2176", "--page-size", str(args.page_size)])
+    try:
+        r = extend_bench(args, dev, 1, shape=(0, 2048, 8), layers=8, nchunks=10)
+        c1["prefill_extend"] = {k: r[k] for k in ("metric", "path", "tflops", "ms_per_forward", "layers", "kernel", "kernel_only")}
+        c1["prefill_extend"]["frac_of_mfma_peak"] = r["roofline"]["frac"]
+    except Exception as e:  # noqa: BLE001
+        c1["prefill_extend"] = {"error": f"{type(e).__name__}: {e}"}
+    ex["config1"] = c1
+    return ex
 
 
 def extend_head_dims(args, dev):
@@ -699,8 +824,9 @@ def extend_head_dims(args, dev):
     res = {}
     for name, d, dv in (("d64", 64, 64), ("d96", 96, 96), ("d256", 256, 256), ("d192_v128", 192, 128)):
         try:
-            r = extend_bench(args, dev, 1, d, dv, nchunks=10)
-            res[name] = {"tflops": r["tflops"], "ms_per_chunk": r["ms_per_chunk"], "frac": r["roofline"]["frac"]}
+            r = extend_bench(args, dev, 1, d, dv, nchunks=10, layers=4)
+            res[name] = {"tflops": r["kernel_only"]["tflops"], "ms_per_chunk": r["kernel_only"]["ms_per_launch"],
+                         "frac": r["roofline"]["frac"], "kernel": r["kernel"], "path_tflops": r["tflops"]}
         except Exception as e:  # noqa: BLE001
             res[name] = {"error": f"{type(e).__name__}: {e}"}
     return res
@@ -1235,7 +1361,9 @@ def main():
         pass
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "rx::decode_mfma_kernel",
+                # the instance the timed launches ran, as rx_last_dispatch() names it (graph mode: the probe layer takes
+                # the same instance as the replayed layers -- with the step's KV store inside where the backend fuses it)
+                "kernel": "rx::" + (getattr(st, "probe_kernel", None) or "decode_mfma_kernel"),
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": dur_ms, "launches": len(ev_pairs),
                 # spread of the same launches (the mean above is what `achieved` uses): a box in its slow state
                 # shows up here as min ~= median ~= mean, one-off stalls as a max far above the median
@@ -1345,6 +1473,16 @@ def main():
             out["heterogeneous_decode"] = hetero_decode_bench(dev)
         except Exception as e:
             out["heterogeneous_decode"] = {"error": str(e)}
+    if rank == 0 and world == 1 and not args.no_extra and not args.tp_sim:
+        st = fb = step = None  # (the radix-hit branch above may have dropped them already)
+        ev_pairs.clear()
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            out["extra"] = extra_legs(args, dev)
+        except Exception as e:  # noqa: BLE001
+            out["extra"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
         if isinstance(out.get("extend"), dict) and "error" not in out["extend"]:
