@@ -91,3 +91,13 @@ def check_out(got, want, dtype, tag=None, ulps=1.0, absw=None):
         pass
     assert ratio <= 1.0, (tag, name, "max-abs err", err, "worst err/bound", ratio)
     return err
+
+
+def want_and_absw(fn, args, v_idx, **kwargs):
+    """The oracle's output and its |V| twin for check_out's `absw`: fn(*args, **kwargs), and the same call with the
+    value tensors (positions `v_idx` of args) replaced by their absolute values."""
+    want = fn(*args, **kwargs)
+    a2 = list(args)
+    for i in v_idx:
+        a2[i] = abs_values(a2[i])
+    return want, fn(*a2, **kwargs)

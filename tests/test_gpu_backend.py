@@ -270,11 +270,11 @@ def test_mla_latent_pool_and_decode():
     o = layer(q, k_new, k_new[..., :rank], fb, be)
     assert o.shape == (bs, hq * rank)
     kb = pool.get_key_buffer(0)
-    want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, rank + rope)), _bits(kb),
-                                        _bits(kb[..., :rank].contiguous()), _bits(r2t.req_to_token),
-                                        np.array(rows), np.array(lens), layer.scaling)
+    want, absw = parity.want_and_absw(orc.sdpa_decode_req_to_token, (_bits(q.view(bs, hq, rank + rope)), _bits(kb),
+                                                                     _bits(kb[..., :rank].contiguous()), _bits(r2t.req_to_token),
+                                                                     np.array(rows), np.array(lens), layer.scaling), (2,))
     got = o.view(bs, hq, rank).float().cpu().numpy()
-    parity.check(np.abs(got - want).max(), 1e-2, None)
+    parity.check_out(got, want, o.dtype, "mla latent pool decode", ulps=1, absw=absw)
 
 
 @pytest.mark.parametrize("own_v", [False, True, "flag"], ids=["v_view_of_k", "v_own_tensor", "v_own_tensor_flagged_as_latent_prefix"])
@@ -476,7 +476,7 @@ def test_hnd_pool_extend_with_prefix():
     assert torch.equal(outs[0], outs[1])
 
 
-def _swa_expected(q3, kb, vb, r2t, rows, seq_lens, prefix_lens, extend_lens, d, window, mask=None):
+def _swa_expected(q3, kb, vb, r2t, rows, seq_lens, prefix_lens, extend_lens, d, window, mask=None, abs_v=False):
     """Semantics of a sliding-window layer: the reference's window metadata (last min(prefix, W) prefix
     tokens, triton_backend.py:2043-2110) + the in-kernel window mask (extend_attention.py:391-397,550-556)."""
     bs = len(rows)
@@ -491,6 +491,8 @@ def _swa_expected(q3, kb, vb, r2t, rows, seq_lens, prefix_lens, extend_lens, d, 
         sl = r2t[rows[i], prefix_lens[i]: seq_lens[i]]
         ke[qo[i]: qo[i + 1]], ve[qo[i]: qo[i + 1]] = kb[sl], vb[sl]
     kw = dict(custom_mask=mask[0], mask_indptr=mask[1], window_kv_offsets=pre - wlen) if mask else {}
+    if abs_v:  # the |V| twin of parity_util.check_out's absw term
+        ve, vb = parity.abs_values(ve), parity.abs_values(vb)
     return orc.extend_attention(q3, ke, ve, kb, vb, qo, kv_indptr, kv_indices, is_causal=True, sm_scale=d ** -0.5,
                                 sliding_window_size=window, **kw)
 
@@ -523,13 +525,14 @@ def test_sliding_window_layers_decode_and_extend(index_mode):
     o_full = hs.layer(q, k, v, fb, hs.backend, save_kv_cache=False)
     kb, vb = hs.pool.get_kv_buffer(0)
     r2t = _bits(hs.r2t.req_to_token)
-    want = _swa_expected(_bits(q.view(T, hq, d)), _bits(kb), _bits(vb), r2t, rows, seq_lens, prefix_lens,
-                         extend_lens, d, W)
-    parity.check(np.abs(_bits(o_swa.view(T, hq, d)).astype(np.float64) - want).max(), 3e-3, None)
-    want_full = orc.sdpa_extend_req_to_token(_bits(q.view(T, hq, d)), _bits(kb), _bits(vb), r2t, np.array(rows),
-                                             np.array(seq_lens), np.array(prefix_lens), np.array(extend_lens),
-                                             d ** -0.5)
-    parity.check(np.abs(_bits(o_full.view(T, hq, d)).astype(np.float64) - want_full).max(), 3e-3, None)
+    swa_args = (_bits(q.view(T, hq, d)), _bits(kb), _bits(vb), r2t, rows, seq_lens, prefix_lens, extend_lens, d, W)
+    want, absw = _swa_expected(*swa_args), _swa_expected(*swa_args, abs_v=True)
+    parity.check_out(o_swa.view(T, hq, d).float().cpu().numpy(), want, o_swa.dtype, "swa extend", ulps=1, absw=absw)
+    want_full, absw_full = parity.want_and_absw(orc.sdpa_extend_req_to_token, (
+        _bits(q.view(T, hq, d)), _bits(kb), _bits(vb), r2t, np.array(rows), np.array(seq_lens), np.array(prefix_lens),
+        np.array(extend_lens), d ** -0.5), (2,))
+    parity.check_out(o_full.view(T, hq, d).float().cpu().numpy(), want_full, o_full.dtype, "full-attention layer of the swa model", ulps=1,
+                     absw=absw_full)
     # ---- decode: the window layer sees the last min(seq, W) tokens
     seq_t = torch.tensor([s + 1 for s in seq_lens], dtype=torch.int64)
     last = torch.tensor([int(hs.r2t.req_to_token[r, s - 1]) for r, s in zip(rows, seq_lens)], dtype=torch.int64,
@@ -544,8 +547,9 @@ def test_sliding_window_layers_decode_and_extend(index_mode):
     sl = seq_t.numpy()
     wl = np.minimum(sl, W)
     kv_indptr, kv_indices = orc.build_kv_indices(_bits(hs.r2t.req_to_token), np.array(rows), wl, kv_start=sl - wl)
-    want1 = orc.decode_attention(_bits(q1.view(bs, hq, d)), _bits(kb), _bits(vb), kv_indptr, kv_indices, d ** -0.5)
-    parity.check(np.abs(_bits(o1.view(bs, hq, d)).astype(np.float64) - want1).max(), 3e-3, None)
+    want1, absw1 = parity.want_and_absw(orc.decode_attention, (_bits(q1.view(bs, hq, d)), _bits(kb), _bits(vb), kv_indptr,
+                                                               kv_indices, d ** -0.5), (2,))
+    parity.check_out(o1.view(bs, hq, d).float().cpu().numpy(), want1, o1.dtype, "swa decode", ulps=1, absw=absw1)
     assert hs.pool.check_errors() == 0
 
 
@@ -597,9 +601,10 @@ def test_target_verify_mode_with_tree_mask():
     ke = np.concatenate([kbn[r2t[rows[i], seq_lens[i]: total[i]]] for i in range(bs)])
     ve = np.concatenate([vbn[r2t[rows[i], seq_lens[i]: total[i]]] for i in range(bs)])
     mi = np.concatenate([[0], np.cumsum([m.size for m in masks])]).astype(np.int64)
-    want = orc.extend_attention(_bits(q.view(T, hq, d)), ke, ve, kbn, vbn, qo, kv_indptr, kv_indices, is_causal=True,
-                                sm_scale=d ** -0.5, custom_mask=cm, mask_indptr=mi)
-    parity.check(np.abs(_bits(o.view(T, hq, d)).astype(np.float64) - want).max(), 3e-3, None)
+    want, absw = parity.want_and_absw(orc.extend_attention, (_bits(q.view(T, hq, d)), ke, ve, kbn, vbn, qo, kv_indptr, kv_indices),
+                                      (2, 4), is_causal=True, sm_scale=d ** -0.5, custom_mask=cm, mask_indptr=mi)
+    # (a small batch takes the split-KV verify path: 16-bit chunk partials merged by LSE -- two roundings, 2 ulp)
+    parity.check_out(o.view(T, hq, d).float().cpu().numpy(), want, o.dtype, "target verify", ulps=2, absw=absw)
 
 
 def test_native_split_schedule_values():
@@ -733,12 +738,12 @@ def test_short_extend_over_long_prefix_takes_split_kv_path():
     assert hs.backend._extend_split_on and hs.backend._verify_split.num_chunks(bs, 40) >= 2
     o = hs.layer(q, k, v, fb, hs.backend)
     kb, vb = hs.pool.get_kv_buffer(0)
-    want = orc.sdpa_extend_req_to_token(_bits(q.view(T, hq, d)), _bits(kb), _bits(vb), _bits(hs.r2t.req_to_token),
-                                        np.array(rows), np.array(seq_lens), np.array(prefix_lens),
-                                        np.array(extend_lens), d ** -0.5)
+    want, absw = parity.want_and_absw(orc.sdpa_extend_req_to_token, (
+        _bits(q.view(T, hq, d)), _bits(kb), _bits(vb), _bits(hs.r2t.req_to_token), np.array(rows), np.array(seq_lens),
+        np.array(prefix_lens), np.array(extend_lens), d ** -0.5), (2,))
     got = o.view(T, hq, d).float().cpu().numpy().astype(np.float64)
     assert hs.pool.check_errors() == 0
-    parity.check(np.abs(got - want).max(), 1.5e-2, None)
+    parity.check_out(got, want, o.dtype, "short extend, split-KV path", ulps=2, absw=absw)  # (16-bit chunk partials: 2 ulp)
 
 
 def test_mla_fp8_latent_pool_radix_hit_extend():
@@ -847,11 +852,11 @@ def test_short_mla_extend_over_long_prefix_takes_split_kv_path():
     kv_indptr = np.concatenate([[0], np.cumsum(pre)]).astype(np.int32)
     qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
     kv_indices = np.concatenate([_bits(r2t.req_to_token[r, :p_]).astype(np.int64) for r, p_ in zip(rows, pre)])
-    want = orc.extend_attention(q.view(T, hq, rank + rope).float().cpu().numpy(), k_new.float().cpu().numpy(),
-                                k_new[..., :rank].float().cpu().numpy(), kbn, kbn[..., :rank], qo, kv_indptr, kv_indices,
-                                sm_scale=layer.scaling)
+    want, absw = parity.want_and_absw(orc.extend_attention, (
+        q.view(T, hq, rank + rope).float().cpu().numpy(), k_new.float().cpu().numpy(), k_new[..., :rank].float().cpu().numpy(),
+        kbn, kbn[..., :rank], qo, kv_indptr, kv_indices), (2, 4), sm_scale=layer.scaling)
     got = o.view(T, hq, rank).float().cpu().numpy().astype(np.float64)
-    parity.check(np.abs(got - want).max(), 1.5e-2, None)
+    parity.check_out(got, want, o.dtype, "short mla extend, split-KV path", ulps=2, absw=absw)  # (16-bit chunk partials: 2 ulp)
 
 
 def _capture(fn):
@@ -910,10 +915,11 @@ def test_graph_replay_refreshes_static_metadata(index_mode, policy):
         be.init_forward_metadata(fb_e)
         eager = hs.layer(q, k, v, fb_e, be)
         kb, vb = hs.pool.get_kv_buffer(0)
-        want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, 32, 128)), _bits(kb), _bits(vb),
-                                            _bits(hs.r2t.req_to_token), np.array(rows), seq.numpy(), 128 ** -0.5)
-        err = np.abs(replayed.view(bs, 32, 128).float().cpu().numpy().astype(np.float64) - want).max()
-        parity.check(err, 1e-2, (index_mode, policy, prefix, err))
+        want, absw = parity.want_and_absw(orc.sdpa_decode_req_to_token, (
+            _bits(q.view(bs, 32, 128)), _bits(kb), _bits(vb), _bits(hs.r2t.req_to_token), np.array(rows), seq.numpy(),
+            128 ** -0.5), (2,))
+        parity.check_out(replayed.view(bs, 32, 128).float().cpu().numpy(), want, replayed.dtype,
+                         ("graph replay", index_mode, policy, prefix), ulps=1, absw=absw)
         assert torch.equal(replayed, eager), (index_mode, policy, prefix)
         # free the batch's pages so that the next one starts from empty rows
         for r, p in zip(rows, prefix):
@@ -978,10 +984,10 @@ def test_target_verify_graph_replay_refreshes_indices_and_mask():
         ke = np.concatenate([kbn[r2t[rows[i], seq_lens[i]: total[i]]] for i in range(bs)])
         ve = np.concatenate([vbn[r2t[rows[i], seq_lens[i]: total[i]]] for i in range(bs)])
         mi = np.concatenate([[0], np.cumsum([m.size for m in masks])]).astype(np.int64)
-        want = orc.extend_attention(_bits(q.view(T, hq, d)), ke, ve, kbn, vbn, qo, kv_indptr, kv_indices,
-                                    is_causal=True, sm_scale=d ** -0.5, custom_mask=cm, mask_indptr=mi)
-        err = np.abs(_bits(out.view(T, hq, d)).astype(np.float64) - want).max()
-        parity.check(err, 3e-3, (seq_lens, err))
+        want, absw = parity.want_and_absw(orc.extend_attention, (_bits(q.view(T, hq, d)), ke, ve, kbn, vbn, qo, kv_indptr,
+                                                                 kv_indices), (2, 4), is_causal=True, sm_scale=d ** -0.5,
+                                          custom_mask=cm, mask_indptr=mi)
+        parity.check_out(out.view(T, hq, d).float().cpu().numpy(), want, out.dtype, ("verify graph replay", seq_lens), ulps=2, absw=absw)  # (split-KV partials: 2 ulp)
         for r, t in zip(rows, total):
             hs.alloc.free(hs.r2t.req_to_token[r, :t].to(torch.int64))
     assert hs.pool.check_errors() == 0

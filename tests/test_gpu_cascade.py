@@ -91,8 +91,8 @@ def test_cascade_decode_matches_oracle(ops, case, dtype):
     ks, vs = (0.9, 1.1) if case % 3 == 0 else (1.0, 1.0)
     sm = d ** -0.5
     kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
-    want = orc.decode_attention(_bits(q), _bits(kb), _bits(vb), kv_indptr, kv_indices, sm, k_scale=ks, v_scale=vs,
-                                logit_cap=cap, sinks=None if sinks is None else sinks.numpy())
+    want, absw = parity.want_and_absw(orc.decode_attention, (_bits(q), _bits(kb), _bits(vb), kv_indptr, kv_indices, sm), (2,),
+                                      k_scale=ks, v_scale=vs, logit_cap=cap, sinks=None if sinks is None else sinks.numpy())
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
     cd = ops.CascadeDecode(bs, hq, hkv, d, dtype, DEV, max_shared=ctx, min_shared=min_shared,
                            num_chunks=[None, 1, 3][case % 3], overlap=bool(case % 2 == 0))
@@ -110,9 +110,8 @@ def test_cascade_decode_matches_oracle(ops, case, dtype):
     o = torch.zeros(bs, hq, d, dtype=dtype, device=DEV)
     cd(q.to(DEV), kb.to(DEV), vb.to(DEV), o, sm, ks, vs, cap, None if sinks is None else sinks.to(DEV),
        page_size=page)
-    tol = 3e-3 if dtype == torch.float16 else 1.5e-2
-    err = np.abs(o.float().cpu().numpy().astype(np.float64) - want).max()
-    parity.check(err, tol, err)
+    # (two 16-bit roundings: the chunk partials cross 16-bit buffers before the merge -- 2 ulp)
+    parity.check_out(o.float().cpu().numpy(), want, dtype, ("cascade", case), ulps=2, absw=absw)
 
 
 MLA_CASES = [
@@ -147,8 +146,9 @@ def test_cascade_decode_latent_mla(ops, case, dtype):
     ks, vs = (0.9, 1.1) if case == 0 else (1.0, 1.0)
     sm = 192 ** -0.5
     kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
-    want = orc.decode_attention(_bits(q), _bits(kb), _bits(kb[..., :dv].contiguous()), kv_indptr, kv_indices, sm,
-                                k_scale=ks, v_scale=vs, sinks=None if sinks is None else sinks.numpy())
+    want, absw = parity.want_and_absw(orc.decode_attention, (_bits(q), _bits(kb), _bits(kb[..., :dv].contiguous()), kv_indptr,
+                                                             kv_indices, sm), (2,), k_scale=ks, v_scale=vs,
+                                      sinks=None if sinks is None else sinks.numpy())
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
     cd = ops.CascadeDecode(bs, hq, 1, dk, dtype, DEV, max_shared=ctx, min_shared=min_shared, v_head_dim=dv,
                            num_chunks=[None, 1, 3, None, None][case])
@@ -158,9 +158,7 @@ def test_cascade_decode_latent_mla(ops, case, dtype):
     o = torch.zeros(bs, hq, dv, dtype=dtype, device=DEV)
     kbd = kb.to(DEV)
     cd(q.to(DEV), kbd, kbd[..., :dv], o, sm, ks, vs, 0.0, None if sinks is None else sinks.to(DEV), page_size=page)
-    tol = 3e-3 if dtype == torch.float16 else 1.5e-2
-    err = np.abs(o.float().cpu().numpy().astype(np.float64) - want).max()
-    parity.check(err, tol, err)
+    parity.check_out(o.float().cpu().numpy(), want, dtype, ("cascade mla", case), ulps=2, absw=absw)  # (two 16-bit roundings: the chunk partials cross 16-bit buffers before the merge -- 2 ulp)
 
 
 def test_cascade_decode_fp8_pool(ops):
@@ -226,11 +224,12 @@ def test_backend_cascade_decode_on_radix_hit_batch(page_size):
     o = hs.layer(q, k, v, fb, hs.backend)
     assert hs.backend._cascade is not None and hs.backend._cascade.shared_len() == shared
     kb, vb = hs.pool.get_kv_buffer(0)
-    want = orc.sdpa_decode_req_to_token(_bits(q.view(bs, hq, d)), _bits(kb), _bits(vb), _bits(hs.r2t.req_to_token),
-                                        np.array(rows), np.array(seq_lens), d ** -0.5)
+    want, absw = parity.want_and_absw(orc.sdpa_decode_req_to_token, (_bits(q.view(bs, hq, d)), _bits(kb), _bits(vb),
+                                                                     _bits(hs.r2t.req_to_token), np.array(rows),
+                                                                     np.array(seq_lens), d ** -0.5), (2,))
     got = o.view(bs, hq, d).float().cpu().numpy().astype(np.float64)
     assert hs.pool.check_errors() == 0
-    parity.check(np.abs(got - want).max(), 1.5e-2, None)
+    parity.check_out(got, want, o.dtype, "backend cascade", ulps=2, absw=absw)  # (two 16-bit roundings: the chunk partials cross 16-bit buffers before the merge -- 2 ulp)
 
 
 def _runner_of(hs):
@@ -314,14 +313,14 @@ def test_cascade_decode_hnd_pool(ops):
     lay = ops.kv_layout_hnd(kh, vh)
     sm = d ** -0.5
     kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
-    want = orc.decode_attention(_bits(q), _bits(kb), _bits(vb), kv_indptr, kv_indices, sm)
+    want, absw = parity.want_and_absw(orc.decode_attention, (_bits(q), _bits(kb), _bits(vb), kv_indptr, kv_indices, sm), (2,))
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)  # noqa: E731
     cd = ops.CascadeDecode(bs, hq, hkv, d, torch.bfloat16, DEV, max_shared=ctx, min_shared=64)
     cd.plan(T(r2t), T(rpi), T(lens))
     assert cd.shared_len() >= shared
     o = torch.zeros(bs, hq, d, dtype=torch.bfloat16, device=DEV)
     cd(q.to(DEV), kh, vh, o, sm, page_size=page, kv_layout=lay)
-    parity.check(np.abs(o.float().cpu().numpy().astype(np.float64) - want).max(), 1.5e-2, None)
+    parity.check_out(o.float().cpu().numpy(), want, torch.bfloat16, "cascade hnd", ulps=2, absw=absw)  # (two 16-bit roundings: the chunk partials cross 16-bit buffers before the merge -- 2 ulp)
 
 
 def test_cascade_chunk_count_follows_the_batch(ops):

@@ -137,14 +137,16 @@ def test_decode_fp8_pool_vs_oracle(ops, dtype, hq, hkv, d, page_size):
     kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
     want = orc.decode_attention(_bits(q), _dq(kb.view(torch.uint8)), _dq(vb.view(torch.uint8)), kv_indptr,
                                 kv_indices, sm, k_scale=ks, v_scale=vs)
-    tol = 2e-3 if dtype == torch.float16 else 1e-2
+    # (the fp8 rows are upcast EXACTLY: the result carries the one output rounding of a 16-bit pool's -- 1 ulp, with the
+    # P-rounding term of parity_util.check_out)
+    absw = orc.decode_attention(_bits(q), _dq(kb.view(torch.uint8)), np.abs(_dq(vb.view(torch.uint8))), kv_indptr,
+                                kv_indices, sm, k_scale=ks, v_scale=vs)
     qd, kbd, vbd = q.to(DEV), kb.to(DEV), vb.to(DEV)
     o = torch.zeros(bs, hq, d, dtype=dtype, device=DEV)
     T = lambda a: torch.from_numpy(a).to(DEV)  # noqa: E731
     ops.decode_attention_fwd_paged(qd, kbd, vbd, o, T(r2t), T(rpi), T(lens), None, None, None, 1, sm, ks, vs,
                                    page_size=page_size)
-    err = np.abs(_f32(o).astype(np.float64) - want).max()
-    parity.check(err, tol, ("single", err))
+    parity.check_out(_f32(o), want, dtype, "fp8 pool / single", ulps=1, absw=absw)
     S = 8
     nsplit = torch.zeros(bs, dtype=torch.int32, device=DEV)
     ops.get_num_kv_splits(nsplit, T(lens).int(), hq, hkv, S, 256)
@@ -153,8 +155,7 @@ def test_decode_fp8_pool_vs_oracle(ops, dtype, hq, hkv, d, page_size):
     o2 = torch.zeros_like(o)
     ops.decode_attention_fwd(qd, kbd.view(torch.uint8), vbd.view(torch.uint8), o2, T(kv_indptr), T(kv_indices),
                              al, lse, nsplit, S, sm, ks, vs, page_size=page_size)
-    err2 = np.abs(_f32(o2).astype(np.float64) - want).max()
-    parity.check(err2, tol, ("split", err2))
+    parity.check_out(_f32(o2), want, dtype, "fp8 pool / split", ulps=1, absw=absw)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
@@ -218,15 +219,16 @@ def test_extend_fp8_prefix_pool_vs_oracle(ops, dtype, page_size):
     ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), T(qo), T(kv_indptr),
                              T(kv_indices), None, True, None, int(ext.max()), ks, vs, sm_scale=sm,
                              page_size=page_size)
-    tol = 3e-3 if dtype == torch.float16 else 1e-2
-    err = np.abs(_f32(o).astype(np.float64) - want).max()
-    parity.check(err, tol, err)
+    absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve)), _dq(kb.view(torch.uint8)),
+                                np.abs(_dq(vb.view(torch.uint8))), qo, kv_indptr, kv_indices, is_causal=True,
+                                sm_scale=sm, k_scale=ks, v_scale=vs)
+    parity.check_out(_f32(o), want, dtype, "fp8 prefix pool", ulps=1, absw=absw)
     # GQA-packed query rows over the same fp8 prefix pool: the same result
     o2 = torch.zeros_like(o)
     ops.extend_attention_fwd_gqa_packed(q.to(DEV), ke.to(DEV), ve.to(DEV), o2, kb.to(DEV), vb.to(DEV), T(qo),
                                         T(kv_indptr), T(kv_indices), None, True, None, int(ext.max()), ks, vs,
                                         sm_scale=sm, page_size=page_size)
-    parity.check(np.abs(_f32(o2).astype(np.float64) - want).max(), tol, None)
+    parity.check_out(_f32(o2), want, dtype, "fp8 prefix pool / packed rows", ulps=1, absw=absw)
 
 
 def test_fp8_pools_roundtrip_through_the_pool_classes(ops):

@@ -299,7 +299,8 @@ def test_decode_hnd_layout_and_sinks(ops):
     q, kb, vb, r2t, rpi = _make_paged_case(rng, bs, hq, hkv, d, lens, ps, torch.float16)
     sinks = torch.randn(hq)
     kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
-    want = orc.decode_attention(_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, 0.1, sinks=sinks.numpy())
+    want, absw = parity.want_and_absw(orc.decode_attention, (_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, 0.1), (2,),
+                                      sinks=sinks.numpy())
     pages = kb.shape[0] // ps
     k_hnd = kb.view(pages, ps, hkv, d).permute(0, 2, 1, 3).contiguous().to(DEV)
     v_hnd = vb.view(pages, ps, hkv, d).permute(0, 2, 1, 3).contiguous().to(DEV)
@@ -307,7 +308,7 @@ def test_decode_hnd_layout_and_sinks(ops):
     o = torch.zeros(bs, hq, d, dtype=torch.float16, device=DEV)
     ops.decode_attention_fwd_paged(q.to(DEV), k_hnd, v_hnd, o, _t(r2t), _t(rpi), _t(lens), None, None,
                                    None, 1, 0.1, sinks=sinks.to(DEV), kv_layout=lay)
-    parity.check(np.abs(_np(o.float()) - want).max(), 2e-3, None)
+    parity.check_out(_np(o.float()), want, torch.float16, "hnd + sinks", ulps=1, absw=absw)
 
 
 @pytest.mark.parametrize("hq,hkv,dk,dv", [(4, 4, 80, 80), (4, 4, 13, 13), (16, 1, 96, 96), (16, 1, 576, 512)])
@@ -321,14 +322,14 @@ def test_decode_generic_head_dims(ops, hq, hkv, dk, dv):
     kv_indptr = np.array([0, S, 2 * S], dtype=np.int32)
     kv_indices = np.arange(B * S)
     sm = 1.0 / dk ** 0.5
-    want = orc.decode_attention(_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, sm)
+    want, absw = parity.want_and_absw(orc.decode_attention, (_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, sm), (2,))
     o = torch.zeros(B, hq, dv, dtype=torch.bfloat16, device=DEV)
     nsplit = torch.full((B,), 4, dtype=torch.int32, device=DEV)
     al = torch.zeros(B, hq, 8, dv, dtype=torch.float32, device=DEV)
     lse = torch.zeros(B, hq, 8, dtype=torch.float32, device=DEV)
     ops.decode_attention_fwd(q.to(DEV), kb.to(DEV), vb.to(DEV), o, _t(kv_indptr), _t(kv_indices), al, lse,
                              nsplit, 8, sm, 1.0, 1.0)
-    np.testing.assert_allclose(_np(o.float()), want, atol=1e-2, rtol=1e-2)
+    parity.check_out(_np(o.float()), want, torch.bfloat16, ("generic decode", dk, dv), ulps=1, absw=absw)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
@@ -728,7 +729,7 @@ def test_decode_edge_cases(ops):
     bs = len(lens)
     q, kb, vb, r2t, rpi = _make_paged_case(rng, bs, hq, hkv, d, lens, ps, torch.bfloat16)
     kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
-    want = orc.decode_attention(_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, d ** -0.5)
+    want, absw = parity.want_and_absw(orc.decode_attention, (_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, d ** -0.5), (2,))
     kbd, vbd = kb.to(DEV), vb.to(DEV)
     qkv = torch.zeros(bs, (hq + 2 * hkv) * d, dtype=torch.bfloat16, device=DEV)
     qkv[:, : hq * d] = q.view(bs, -1).to(DEV)
@@ -746,13 +747,14 @@ def test_decode_edge_cases(ops):
                                    S, d ** -0.5, page_size=ps)
     got = _np(o.float()).astype(np.float64)
     live = lens > 0
-    parity.check(np.abs(got[live] - want[live]).max(), 1e-2, None)
+    parity.check_out(got[live], want[live], torch.bfloat16, "decode edge cases / split", ulps=1, absw=absw[live])
     # single pass: the empty request gets a defined (zero) output
     o1 = torch.full((bs, hq, d), 7.0, dtype=torch.bfloat16, device=DEV)
     ops.decode_attention_fwd_paged(q_view, kbd, vbd, o1, _t(r2t), _t(rpi), _t(lens), None, None, None, 1,
                                    d ** -0.5, page_size=ps)
     got1 = _np(o1.float()).astype(np.float64)
-    assert np.abs(got1[live] - want[live]).max() <= 1e-2 and np.all(got1[~live] == 0)
+    parity.check_out(got1[live], want[live], torch.bfloat16, "decode edge cases / single pass", ulps=1, absw=absw[live])
+    assert np.all(got1[~live] == 0)
 
 
 def test_extend_edge_cases(ops):
@@ -779,13 +781,13 @@ def test_extend_edge_cases(ops):
         kv_indices[kv_indptr[i]: kv_indptr[i + 1]] = s[: pre[i]]
         ext_slots[qo[i]: qo[i + 1]] = s[pre[i]:]
     ke, ve = kb[ext_slots], vb[ext_slots]
-    want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
-                                sm_scale=d ** -0.5)
+    want, absw = parity.want_and_absw(orc.extend_attention, (_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices),
+                                      (2, 4), sm_scale=d ** -0.5)
     o = torch.zeros(T, hq, d, dtype=torch.float16, device=DEV)
     ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo).to(torch.int32),
                              _t(kv_indptr), _t(kv_indices).to(torch.int32), None, True, None, int(ext.max()),
                              1.0, 1.0)
-    parity.check(np.abs(_np(o.float()).astype(np.float64) - want).max(), 3e-3, None)
+    parity.check_out(_np(o.float()), want, torch.float16, "extend edge cases", ulps=1, absw=absw)
 
 
 def test_k_and_v_scales(ops):
@@ -796,11 +798,12 @@ def test_k_and_v_scales(ops):
     lens = np.array([50, 9], dtype=np.int64)
     q, kb, vb, r2t, rpi = _make_paged_case(rng, 2, hq, hkv, d, lens, 1, torch.float16)
     kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
-    want = orc.decode_attention(_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, 0.2, k_scale=0.5, v_scale=2.0)
+    want, absw = parity.want_and_absw(orc.decode_attention, (_np(q), _np(kb), _np(vb), kv_indptr, kv_indices, 0.2), (2,),
+                                      k_scale=0.5, v_scale=2.0)
     o = torch.zeros(2, hq, d, dtype=torch.float16, device=DEV)
     ops.decode_attention_fwd(q.to(DEV), kb.to(DEV), vb.to(DEV), o, _t(kv_indptr), _t(kv_indices), None, None, None,
                              1, 0.2, 0.5, 2.0)
-    parity.check(np.abs(_np(o.float()) - want).max(), 4e-3, None)
+    parity.check_out(_np(o.float()), want, torch.float16, "k / v scales, decode", ulps=1, absw=absw)
     # extend: scales apply to the cached prefix only
     pre, ext = np.array([20], dtype=np.int32), np.array([40], dtype=np.int32)
     g = torch.Generator().manual_seed(4)
@@ -808,12 +811,13 @@ def test_k_and_v_scales(ops):
     qe = torch.randn(40, hq, d, generator=g).half()
     ke = torch.randn(40, hkv, d, generator=g).half(); ve = torch.randn(40, hkv, d, generator=g).half()
     kvi = np.arange(1, 21, dtype=np.int64)
-    want_e = orc.extend_attention(_np(qe), _np(ke), _np(ve), _np(kbe), _np(vbe), np.array([0, 40]), np.array([0, 20], dtype=np.int32),
-                                  kvi, sm_scale=0.2, k_scale=0.5, v_scale=2.0)
+    want_e, absw_e = parity.want_and_absw(orc.extend_attention, (_np(qe), _np(ke), _np(ve), _np(kbe), _np(vbe), np.array([0, 40]),
+                                                                 np.array([0, 20], dtype=np.int32), kvi), (2, 4),
+                                          sm_scale=0.2, k_scale=0.5, v_scale=2.0)
     oe = torch.zeros(40, hq, d, dtype=torch.float16, device=DEV)
     ops.extend_attention_fwd(qe.to(DEV), ke.to(DEV), ve.to(DEV), oe, kbe.to(DEV), vbe.to(DEV), _t(np.array([0, 40])),
                              _t(np.array([0, 20], dtype=np.int32)), _t(kvi), None, True, None, 40, 0.5, 2.0, sm_scale=0.2)
-    parity.check(np.abs(_np(oe.float()) - want_e).max(), 6e-3, None)
+    parity.check_out(_np(oe.float()), want_e, torch.float16, "k / v scales, extend", ulps=1, absw=absw_e)
 
 
 def test_torch_custom_ops_match_direct_calls_and_capture(ops, golden_dir):
@@ -877,14 +881,14 @@ def test_extend_tree_mask_window_xai_golden(ops, golden_dir):
         got = _np(o).astype(np.float64)
         want = c["o"].astype(np.float64)
         ok = np.isfinite(want).all(axis=-1)  # rows that see nothing: 0/0 in the reference
-        parity.check(np.abs(got[ok] - want[ok]).max(), 1e-2, (name, "vs triton golden"))
-        ref = orc.extend_attention(
-            c["q"], c["k_ext"], c["v_ext"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"],
+        ref, absw = parity.want_and_absw(orc.extend_attention, (
+            c["q"], c["k_ext"], c["v_ext"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"]), (2, 4),
             is_causal=True, sm_scale=float(c["sm_scale"]), sliding_window_size=int(c["window"]),
             custom_mask=c.get("custom_mask"), mask_indptr=c.get("mask_indptr"),
             skip_prefix_custom_mask=(skipm != 0), window_kv_offsets=c.get("window_kv_offsets"),
             xai_temperature_len=int(c["xai"]))
-        parity.check(np.abs(got[ok] - ref[ok]).max(), 3e-3, (name, np.abs(got[ok] - ref[ok]).max()))
+        parity.check_out(got[ok], want[ok], torch.float16, (name, "vs triton golden"), ulps=2, absw=2 * absw[ok])  # (vs the reference kernel's own fp16 output: both sides round the result AND their P operand to 16 bits -- 2 ulp, twice the P term)
+        parity.check_out(got[ok], ref[ok], torch.float16, (name, "vs oracle"), ulps=1, absw=absw[ok])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
@@ -916,14 +920,12 @@ def test_extend_tree_mask_long_prefix_vs_oracle(ops, dtype):
     cm = np.concatenate(rows).astype(np.uint8)
     mi = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
     sm = d ** -0.5
-    want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
-                                is_causal=True, sm_scale=sm, custom_mask=cm, mask_indptr=mi)
+    want, absw = parity.want_and_absw(orc.extend_attention, (_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices),
+                                      (2, 4), is_causal=True, sm_scale=sm, custom_mask=cm, mask_indptr=mi)
     o = torch.zeros_like(q, device=DEV)
     ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo), _t(kv_indptr),
                              _t(kv_indices), _t(cm).bool(), True, _t(mi), nd, 1.0, 1.0, sm_scale=sm)
-    tol = 3e-3 if dtype == torch.float16 else 1e-2
-    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    parity.check(err, tol, err)
+    parity.check_out(_np(o.float()), want, dtype, "tree mask, long prefix", ulps=1, absw=absw)
 
 
 def test_decode_xai_temperature_golden(ops, golden_dir):
@@ -937,10 +939,10 @@ def test_decode_xai_temperature_golden(ops, golden_dir):
         o = torch.zeros_like(q)
         ops.decode_attention_fwd(q, kb, vb, o, _t(c["kv_indptr"]), _t(c["kv_indices"]), al, lse, _t(c["nsplit"]), S,
                                  float(c["sm_scale"]), 1.0, 1.0, xai_temperature_len=int(c["xai"]))
-        parity.check(np.abs(_np(o).astype(np.float64) - c["o"].astype(np.float64)).max(), 1e-2, name)
-        want = orc.decode_attention(c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"], float(c["sm_scale"]),
-                                    xai_temperature_len=int(c["xai"]))
-        parity.check(np.abs(_np(o).astype(np.float64) - want).max(), 2e-3, name)
+        want, absw = parity.want_and_absw(orc.decode_attention, (c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"],
+                                                                 float(c["sm_scale"])), (2,), xai_temperature_len=int(c["xai"]))
+        parity.check_out(_np(o), c["o"], torch.float16, (name, "vs triton golden"), ulps=2, absw=2 * absw)  # (vs the reference kernel's own fp16 output: both sides round the result AND their P operand to 16 bits -- 2 ulp, twice the P term)
+        parity.check_out(_np(o), want, torch.float16, (name, "vs oracle"), ulps=1, absw=absw)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
@@ -956,8 +958,8 @@ def test_merge_state_and_prefix_cascade(ops, dtype):
     la[0, 0], lb[1, 1] = float("inf"), float("-inf")
     out, lse = ops.merge_state(a, la, b, lb)
     want, want_lse = orc.merge_state(_np(a), la.cpu().numpy(), _np(b), lb.cpu().numpy())
-    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
-    parity.check(np.abs(orc.to_f64(_np(out)) - want).max(), tol, None)
+    fin = np.isfinite(want)  # (the +inf / -inf LSE rows: one side takes all)
+    parity.check_out(orc.to_f64(_np(out))[fin], want[fin], dtype, "merge_state", ulps=1)  # one rounding of an exact blend
     np.testing.assert_allclose(lse.cpu().numpy(), want_lse, atol=1e-5, rtol=1e-5)
 
     # cascade
@@ -1055,12 +1057,12 @@ def test_extend_unified_golden(ops, golden_dir):
         got = _np(o).astype(np.float64)
         want = c["o"].astype(np.float64)
         ok = np.isfinite(want).all(axis=-1)
-        parity.check(np.abs(got[ok] - want[ok]).max(), 1e-2, (name, "vs triton golden"))
-        ref = orc.extend_attention_unified(
-            c["q"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"], c["prefix_lens"],
+        ref, absw = parity.want_and_absw(orc.extend_attention_unified, (
+            c["q"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"], c["prefix_lens"]), (2,),
             sm_scale=float(c["sm_scale"]), sliding_window_size=int(c["window"]), custom_mask=c.get("custom_mask"),
             mask_indptr=c.get("mask_indptr"), xai_temperature_len=int(c["xai"]))
-        parity.check(np.abs(got[ok] - ref[ok]).max(), 3e-3, (name, np.abs(got[ok] - ref[ok]).max()))
+        parity.check_out(got[ok], want[ok], torch.float16, (name, "vs triton golden"), ulps=2, absw=2 * absw[ok])  # (vs the reference kernel's own fp16 output: both sides round the result AND their P operand to 16 bits -- 2 ulp, twice the P term)
+        parity.check_out(got[ok], ref[ok], torch.float16, (name, "vs oracle"), ulps=1, absw=absw[ok])
 
 
 def test_extend_unified_equals_two_stage_on_long_batch(ops):
@@ -1136,13 +1138,13 @@ def test_extend_thresholded_max_adversarial_scores(ops, dtype, pattern):
     ke, ve = kfull[P:].contiguous(), vfull[P:].contiguous()
     want, want_lse = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
                                           sm_scale=1.0 / d ** 0.5, return_lse=True)
+    absw = orc.extend_attention(_np(q), _np(ke), parity.abs_values(_np(ve)), _np(kb), parity.abs_values(_np(vb)), qo,
+                                kv_indptr, kv_indices, sm_scale=1.0 / d ** 0.5)
     o = torch.zeros(E, hq, d, dtype=dtype, device=DEV)
     lse = torch.zeros(E, hq, dtype=torch.float32, device=DEV)
     ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo), _t(kv_indptr),
                              _t(kv_indices), None, True, None, E, 1.0, 1.0, lse_extend=lse)
-    tol = 4e-3 if dtype == torch.float16 else 2e-2
-    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    parity.check(err, tol, (pattern, err))
+    parity.check_out(_np(o.float()), want, dtype, ("thresholded max", pattern), ulps=1, absw=absw)
     np.testing.assert_allclose(_np(lse), want_lse, atol=5e-3, rtol=2e-3)
 
 
@@ -1187,9 +1189,9 @@ def test_extend_gqa_packed_rows_match_oracle(ops, dtype, hq, hkv, mode):
         mask = np.concatenate(rows)
         mask_indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
     window = 40 if mode == "window" else -1
-    want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
-                                sm_scale=1.0 / d ** 0.5, custom_mask=mask, mask_indptr=mask_indptr,
-                                sliding_window_size=window)
+    want, absw = parity.want_and_absw(orc.extend_attention, (_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices),
+                                      (2, 4), sm_scale=1.0 / d ** 0.5, custom_mask=mask, mask_indptr=mask_indptr,
+                                      sliding_window_size=window)
     o = torch.zeros(T, hq, d, dtype=dtype, device=DEV)
     ops.extend_attention_fwd_gqa_packed(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo),
                                         _t(kv_indptr), _t(kv_indices), None if mask is None else _t(mask), True,
@@ -1197,8 +1199,7 @@ def test_extend_gqa_packed_rows_match_oracle(ops, dtype, hq, hkv, mode):
                                         sliding_window_size=window)
     got = _np(o.float()).astype(np.float64)
     ok = np.isfinite(want).all(axis=(1, 2))  # a window / mask can hide everything from a row (0/0 in the reference)
-    tol = 3e-3 if dtype == torch.float16 else 1.5e-2
-    parity.check(np.abs(got[ok] - want[ok]).max(), tol, None)
+    parity.check_out(got[ok], want[ok], dtype, ("gqa packed rows", mode), ulps=1, absw=absw[ok])
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
@@ -1231,14 +1232,12 @@ def test_verify_attention_splitkv_vs_oracle(ops, dtype, chunks):
     cm = np.concatenate(rows).astype(np.uint8)
     mi = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
     sm = d ** -0.5
-    want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices,
-                                is_causal=True, sm_scale=sm, custom_mask=cm, mask_indptr=mi)
+    want, absw = parity.want_and_absw(orc.extend_attention, (_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices),
+                                      (2, 4), is_causal=True, sm_scale=sm, custom_mask=cm, mask_indptr=mi)
     o = torch.zeros_like(q, device=DEV)
     ops.verify_attention_splitkv(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo), _t(kv_indptr),
                                  _t(kv_indices), _t(cm), _t(mi), nd, chunks, 1.0, 1.0, sm_scale=sm)
-    tol = 4e-3 if dtype == torch.float16 else 1.5e-2
-    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    parity.check(err, tol, err)
+    parity.check_out(_np(o.float()), want, dtype, ("verify split-KV", chunks), ulps=2, absw=absw)  # (16-bit chunk partials merged by LSE: two roundings, 2 ulp)
 
 
 @pytest.mark.parametrize("masked", [False, True], ids=["causal", "tree_mask"])
@@ -1275,15 +1274,15 @@ def test_verify_attention_splitkv_latent_mla(ops, masked, chunks):
         mi = np.concatenate([[0], np.cumsum([r.size for r in rows])]).astype(np.int64)
     sm = 192 ** -0.5
     okw = dict(custom_mask=cm, mask_indptr=mi) if masked else {}
-    want = orc.extend_attention(_np(q), _np(ke), _np(ke[..., :dv]), _np(kb), _np(kb[..., :dv]), qo, kv_indptr, kv_indices,
-                                is_causal=True, sm_scale=sm, **okw)
+    want, absw = parity.want_and_absw(orc.extend_attention, (_np(q), _np(ke), _np(ke[..., :dv].contiguous()), _np(kb),
+                                                             _np(kb[..., :dv].contiguous()), qo, kv_indptr, kv_indices), (2, 4),
+                                      is_causal=True, sm_scale=sm, **okw)
     o = torch.zeros(T_, hq, dv, dtype=dtype, device=DEV)
     kbd, ked = kb.to(DEV), ke.to(DEV)
     ops.verify_attention_splitkv(q.to(DEV), ked, ked[..., :dv], o, kbd, kbd[..., :dv], _t(qo), _t(kv_indptr),
                                  _t(kv_indices), _t(cm) if masked else None, _t(mi) if masked else None, nd, chunks,
                                  1.0, 1.0, sm_scale=sm)
-    err = np.abs(_np(o.float()).astype(np.float64) - want).max()
-    parity.check(err, 1.5e-2, err)
+    parity.check_out(_np(o.float()), want, dtype, ("latent split-KV", masked, chunks), ulps=2, absw=absw)  # (16-bit chunk partials merged by LSE: two roundings, 2 ulp)
 
 
 def test_verify_splitkv_replays_under_hip_graph(ops):
@@ -1340,10 +1339,10 @@ def test_verify_splitkv_replays_under_hip_graph(ops):
         graph.replay()
         torch.cuda.synchronize()
         ip = np.concatenate([[0], np.cumsum(prefix)]).astype(np.int32)
-        want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo.cpu().numpy(), ip,
-                                    kv_indices.cpu().numpy()[: int(prefix.sum())], is_causal=True, sm_scale=d ** -0.5,
-                                    custom_mask=cm, mask_indptr=mi.cpu().numpy())
-        parity.check(np.abs(_np(o.float()).astype(np.float64) - want).max(), 1.5e-2, None)
+        want, absw = parity.want_and_absw(orc.extend_attention, (_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo.cpu().numpy(), ip,
+                                                                 kv_indices.cpu().numpy()[: int(prefix.sum())]), (2, 4),
+                                          is_causal=True, sm_scale=d ** -0.5, custom_mask=cm, mask_indptr=mi.cpu().numpy())
+        parity.check_out(_np(o.float()), want, o.dtype, ("split-KV graph replay", seed), ulps=2, absw=absw)  # (16-bit chunk partials merged by LSE: two roundings, 2 ulp)
 
 
 def test_decode_in_kernel_merge_edges_and_graph_replay(ops):
