@@ -24,10 +24,11 @@
 extern "C" {
 #endif
 
-/* 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
+/* 10 (round 4): rx_decode_params.rope_* (fused RoPE of the latent decode).
+ * 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
  * 8 (round 3): rx_split_items; rx_decode_params.split_items / split_items_count / split_items_cap /
  * split_items_wgs_per_cu and extra_index / extra_rows; rx_num_kv_splits_balanced gained wg_target_mixed. */
-#define RX_ABI_VERSION 9
+#define RX_ABI_VERSION 10
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -294,6 +295,28 @@ typedef struct rx_decode_params {
    * near-equal pieces (rx_num_kv_splits_balanced, wg_target_mixed), all resident at once.  A uniform batch is ~0.5 %
    * faster at two, and a caller that cannot know (a captured graph replayed with new lengths) leaves it 0. */
   int32_t split_items_wgs_per_cu;
+  /* ---- fused RoPE of the latent (MLA) decode, round 4: decode_attention_fwd_grouped_rope
+   * (kernels/ops/attention/rocm_mla_decode_rope.py:45-439, called from forward_mla_fused_rope_rocm.py:177-215).
+   * head_dim 576 = 512 latent + 64 rope, v_head_dim 512, one kv head, a 16-bit pool.  With rope_cos_sin set, q's rope
+   * columns 512..575 arrive UNrotated and are rotated inside the kernel at rope_positions[b] (neox: partner c <-> c + 32,
+   * GPT-J style: pairs (2 i, 2 i + 1); fp32 arithmetic, one rounding to the 16-bit operand), and so is the k_pe of each
+   * request's NEWEST token (position seq_len - 1), every older row of the pool being rotated already.  Two forms:
+   *   - the reference's: the newest row sits in the pool with its k_pe not rotated; the kernel uses the rotated values,
+   *     returns them in rope_k_pe_out [bs, 64] and leaves the pool alone (the caller stores the row again);
+   *   - k_new = [bs, 576] (k_new_stride_t elements apart; v_new unused): the step's rows have NOT been stored; the kernel
+   *     reads them from k_new, rotates the rope part, attends, and writes the finished row to its slot -- RoPE, KV store
+   *     and attention in one launch.
+   * rope_cos_sin: [max_pos, >= 64] rows of cos (32) | sin (32), fp32 or the call's 16-bit dtype (_is_f32);
+   * rope_positions int64 / int32 [bs]; rope_dim must be 64; rope_k_pe_out may be NULL. */
+  const void* rope_cos_sin;
+  int32_t rope_cos_sin_is_f32;
+  int64_t rope_cos_sin_stride;
+  const void* rope_positions;
+  int32_t rope_positions_is_i64;
+  int32_t rope_dim;
+  int32_t rope_is_neox;
+  void* rope_k_pe_out;
+  int64_t rope_k_pe_out_stride;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);

@@ -731,6 +731,43 @@ def rope(x, positions, cos_sin_cache, is_neox, rotary_dim=None):
     return x
 
 
+def decode_attention_grouped_rope(q, k_buffer, kv_indptr, kv_indices, cos_sin_cache, positions, sm_scale,
+                                  kv_lora_rank=512, is_neox=True, logit_cap=0.0, new_rows=None):
+    """Semantics of decode_attention_fwd_grouped_rope (kernels/ops/attention/rocm_mla_decode_rope.py:45-439) with
+    use_rope: q [bs, Hq, c + r] holds [q_nope | q_pe NOT rotated]; k_buffer rows [c + r] hold the latent and the k_pe --
+    rotated for every cached token EXCEPT each request's newest one (the last index of its kv_indices list), which the
+    kernel rotates itself (:180-199, used at :228-236) at positions[b], like q_pe (:119-178).  Scores
+    (q_nope . kv + q_pe' . k_pe') sm_scale (:238-252), values = the first c columns of the same rows.
+    new_rows [bs, c + r] (this library's k_new form): the newest rows come from there instead of the pool.
+    Returns (o float64 [bs, Hq, c], k_pe_out float64 [bs, r]: the newest tokens' rotated k_pe, :285-292)."""
+    qf, kb = to_f64(q), to_f64(k_buffer)
+    kb = kb.reshape(kb.shape[0], -1).copy()
+    bs, hq, dk = qf.shape
+    c = int(kv_lora_rank)
+    r = dk - c
+    pos = np.asarray(positions)
+    q_rot = qf.copy()
+    q_rot[..., c:] = rope(qf[..., c:], pos, cos_sin_cache, is_neox, r)
+    o = np.zeros((bs, hq, c))
+    kpe_out = np.zeros((bs, r))
+    for b in range(bs):
+        idx = np.asarray(kv_indices[int(kv_indptr[b]): int(kv_indptr[b + 1])]).astype(np.int64)
+        if idx.size == 0:
+            continue
+        rows = kb[idx].copy()
+        newest = rows[-1] if new_rows is None else to_f64(new_rows)[b].reshape(-1).copy()
+        newest[c:] = rope(newest[None, None, c:], pos[b: b + 1], cos_sin_cache, is_neox, r)[0, 0]
+        rows[-1] = newest
+        kpe_out[b] = newest[c:]
+        s_ = (q_rot[b] @ rows.T) * sm_scale
+        if logit_cap > 0:
+            s_ = logit_cap * np.tanh(s_ / logit_cap)
+        s_ -= s_.max(axis=-1, keepdims=True)
+        p_ = np.exp(s_)
+        o[b] = (p_ / p_.sum(axis=-1, keepdims=True)) @ rows[:, :c]
+    return o, kpe_out
+
+
 def merge_state(a, lse_a, b, lse_b):
     """merge_state_triton (kernels/ops/attention/merge_state.py:8-64): LSE-weighted blend of two partial
     attention outputs; a +inf LSE is read as -inf.  Returns (out float64, out_lse float64)."""

@@ -993,7 +993,9 @@ extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
   }
   a.direct_single = ((mfma_ok || mla) && a.num_extra == 0 && max_splits > 1 && p->stages == 0) ? 1 : 0;
   a.k_new = a.v_new = nullptr;
-  if (p->k_new || p->v_new) {
+  if (mla) {
+    // the latent kernel takes k_new (the whole new row, v is its prefix) only with fused RoPE: checked in launch_decode_mla
+  } else if (p->k_new || p->v_new) {
     RX_REQUIRE(p->k_new && p->v_new, "rx_decode_attn: k_new and v_new come together");
     RX_REQUIRE(mfma_ok && dk <= 128 && dk != 96 && !mla && !p->kv.kv_fp8 && a.qblocks == 1 && p->stages != 2,
                "rx_decode_attn: the fused store needs the D = 64 / 128 kernel on a 16-bit pool with at most 16 q heads "

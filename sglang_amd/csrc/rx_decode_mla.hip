@@ -50,6 +50,17 @@ struct MlaArgs {
   int32_t xai_len;
   int32_t* merge_counters;  // in-kernel stage 2 (rx_common.h split_arrive_is_last), or NULL
   int32_t direct_single;    // a request with one kv split writes its final output from stage 1 (see rx_decode.hip)
+  // fused RoPE (rx_decode_params.rope_*; decode_mla_kernel on 16-bit rows): q_pe rotated in registers, the newest
+  // token's k_pe rotated on its way into the staged tile
+  const void* rope_cache;   // [max_pos, 64]: cos (32) | sin (32) per position; NULL = off
+  int32_t rope_f32;         // the table is fp32 (else the call's 16-bit dtype)
+  int64_t rope_stride;      // elements per position row
+  const void* rope_pos;     // [bs]
+  int32_t rope_pos64, rope_neox;
+  uint16_t* kpe_out;        // [bs, 64] rotated k_pe of every request's newest token, or NULL
+  int64_t kpe_out_stride;
+  const uint16_t* k_new;    // [bs, 576] the step's new latent rows (k_pe NOT rotated), or NULL: the pool holds them
+  int64_t k_new_stride;
 };
 
 #ifndef RX_MLA_PD
@@ -198,6 +209,64 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
       qf[s] = __builtin_bit_cast(vec8, raw);
     }
   }
+  // ---- fused RoPE (rocm_mla_decode_rope.py:119-178): q_pe = q_pe cos + rot(q_pe) sin at positions[b] --------------
+  // The rope columns 512..575 are k-steps 16 / 17: fragments 7 and 8 of the waves that keep k-steps 9..17.  Lane
+  // (head r, group g) holds elements c = 8 g + j of the lower half in fragment 7 and c + 32 in fragment 8: the neox
+  // partner (c <-> c + 32) is the same element of the other fragment, the interleaved (GPT-J) partner the
+  // neighbouring element of the same fragment -- no cross-lane traffic either way.  fp32 arithmetic, one rounding to
+  // the 16-bit operand (as rx_rope_store_kv / apply_rotary_emb write the rotated q back).
+  float rc[8], rs[8];   // cos / sin for this lane's eight rope elements (this lane's k rotation uses others: see below)
+  const bool rope = a.rope_cache != nullptr;
+  auto rope_row = [&](int idx, float& c, float& s_) {  // table entries idx (cos) and 32 + idx (sin) of request b's position
+    const int64_t pos = load_idx(a.rope_pos, b, a.rope_pos64);
+    if (a.rope_f32) {
+      const float* t = reinterpret_cast<const float*>(a.rope_cache) + pos * a.rope_stride;
+      c = t[idx];
+      s_ = t[32 + idx];
+    } else {
+      const uint16_t* t = reinterpret_cast<const uint16_t*>(a.rope_cache) + pos * a.rope_stride;
+      c = T::to_f32(t[idx]);
+      s_ = T::to_f32(t[32 + idx]);
+    }
+  };
+  if (rope && ks0 + KSW == KS) {  // waves 2, 3
+    u32x4 lo4 = __builtin_bit_cast(u32x4, qf[KSW - 2]), hi4 = __builtin_bit_cast(u32x4, qf[KSW - 1]);
+    float xl[8], xh[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xl[2 * j] = T::to_f32(static_cast<uint16_t>(lo4[j] & 0xffffu));
+      xl[2 * j + 1] = T::to_f32(static_cast<uint16_t>(lo4[j] >> 16));
+      xh[2 * j] = T::to_f32(static_cast<uint16_t>(hi4[j] & 0xffffu));
+      xh[2 * j + 1] = T::to_f32(static_cast<uint16_t>(hi4[j] >> 16));
+    }
+    float yl[8], yh[8];
+    if (a.rope_neox) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        rope_row(8 * g + j, rc[j], rs[j]);
+        yl[j] = xl[j] * rc[j] - xh[j] * rs[j];
+        yh[j] = xh[j] * rc[j] + xl[j] * rs[j];
+      }
+    } else {  // pairs (2 i, 2 i + 1), table index i = c / 2: elements c = 8 g + j (low fragment) and 32 + 8 g + j (high)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        float c0, s0, c1, s1;
+        rope_row(4 * g + jj, c0, s0);
+        rope_row(16 + 4 * g + jj, c1, s1);
+        yl[2 * jj] = xl[2 * jj] * c0 - xl[2 * jj + 1] * s0;
+        yl[2 * jj + 1] = xl[2 * jj + 1] * c0 + xl[2 * jj] * s0;
+        yh[2 * jj] = xh[2 * jj] * c1 - xh[2 * jj + 1] * s1;
+        yh[2 * jj + 1] = xh[2 * jj + 1] * c1 + xh[2 * jj] * s1;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lo4[j] = pack2<T>(yl[2 * j], yl[2 * j + 1]);
+      hi4[j] = pack2<T>(yh[2 * j], yh[2 * j + 1]);
+    }
+    qf[KSW - 2] = __builtin_bit_cast(vec8, lo4);
+    qf[KSW - 1] = __builtin_bit_cast(vec8, hi4);
+  }
 
   // The Q fragments must have LANDED before the tile loop: hipcc's waitcnt pass merges the loop-entry
   // state (Q loads possibly pending) into the loop header and would otherwise emit vmcnt(0) in front
@@ -252,6 +321,59 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
     }
   };
 
+  // ---- the newest token's row under fused RoPE (rocm_mla_decode_rope.py:180-199, 228-236) ------------------------
+  // Its k_pe is NOT rotated yet -- in the pool (the reference's contract: the caller stored the row, gets the rotated
+  // k_pe back in k_pe_out and stores again) or in k_new (this library's form: the row has not been stored at all).  The
+  // workgroups of the LAST kv split hold it in their last tile: after that tile's LDS image is complete, threads
+  // 0..71 rewrite the row's chunks from the source -- rope chunks rotated -- and, with k_new, q block 0 writes the
+  // finished row to its pool slot (nobody reads the slot's old bytes: every workgroup that stages the row rewrites it).
+  const bool patch_wg = rope && hi == seq_len && !KV8;
+  const int patch_tile = patch_wg ? ntiles - 1 : -1;
+  auto patch_newest_row = [&](int buf) {
+    const int first = a.k_new ? 0 : 64;  // chunks rewritten: the whole row, or its 8 rope chunks
+    const int c = first + tid;
+    if (c < kMlaChunks) {
+      const int row = (hi - 1 - lo) % kMlaTile;
+      const int64_t slot = static_cast<int64_t>(idx[hi - 1]);
+      uint16_t* prow = const_cast<uint16_t*>(a.kv_buf) + mla_slot_off<LINEAR>(slot, a.page_size, a.page_stride, a.tok_stride);
+      const uint16_t* src = a.k_new ? a.k_new + b * a.k_new_stride : prow;
+      u32x4 v = *reinterpret_cast<const u32x4*>(src + 8 * c);
+      if (c >= 64) {
+        const int e0 = 8 * (c - 64);  // first rope element of this chunk
+        float x[8], y[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[2 * j] = T::to_f32(static_cast<uint16_t>(v[j] & 0xffffu));
+          x[2 * j + 1] = T::to_f32(static_cast<uint16_t>(v[j] >> 16));
+        }
+        if (a.rope_neox) {
+          const bool low = e0 < 32;
+          const u32x4 pv = *reinterpret_cast<const u32x4*>(src + 512 + (low ? e0 + 32 : e0 - 32));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float part = T::to_f32(static_cast<uint16_t>(j & 1 ? pv[j >> 1] >> 16 : pv[j >> 1] & 0xffffu));
+            float cc, ss;
+            rope_row((e0 & 31) + j, cc, ss);
+            y[j] = low ? x[j] * cc - part * ss : x[j] * cc + part * ss;
+          }
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            float cc, ss;
+            rope_row(e0 / 2 + jj, cc, ss);
+            y[2 * jj] = x[2 * jj] * cc - x[2 * jj + 1] * ss;
+            y[2 * jj + 1] = x[2 * jj + 1] * cc + x[2 * jj] * ss;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = pack2<T>(y[2 * j], y[2 * j + 1]);
+        if (a.kpe_out && qb == 0) *reinterpret_cast<u32x4*>(a.kpe_out + b * a.kpe_out_stride + e0) = v;
+      }
+      *reinterpret_cast<u32x4*>(smem + buf * kMlaTile * kMlaLdsRow + row * kMlaLdsRow + c * 16) = v;
+      if (a.k_new && qb == 0) *reinterpret_cast<u32x4*>(prow + 8 * c) = v;
+    }
+  };
+
   f32x4 oacc[NBW];
 #pragma unroll
   for (int nb = 0; nb < NBW; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -279,6 +401,10 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
     if (DEPTH + 1 < ntiles) load_slots(DEPTH + 1);
   }
   __syncthreads();
+  if (patch_tile == 0) {  // (workgroup-uniform)
+    patch_newest_row(0);
+    __syncthreads();
+  }
 
   const int qd = r >> 2, pp = r & 3;
   for (int t0 = 0; t0 < ntiles; t0 += DEPTH) {
@@ -376,6 +502,10 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
       }
     }
     __syncthreads();
+    if (t + 1 == patch_tile) {  // (workgroup-uniform, once per kernel: the image of the last tile is complete)
+      patch_newest_row((t + 1) % NBUF);
+      __syncthreads();
+    }
    }
   }
 
@@ -777,6 +907,29 @@ int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, int di
   a.logit_cap = p->logit_cap;
   a.sinks = p->sinks;
   a.xai_len = p->xai_temperature_len;
+  a.rope_cache = p->rope_cos_sin;
+  a.rope_f32 = p->rope_cos_sin_is_f32;
+  a.rope_stride = p->rope_cos_sin_stride;
+  a.rope_pos = p->rope_positions;
+  a.rope_pos64 = p->rope_positions_is_i64;
+  a.rope_neox = p->rope_is_neox;
+  a.kpe_out = (uint16_t*)p->rope_k_pe_out;
+  a.kpe_out_stride = p->rope_k_pe_out_stride;
+  a.k_new = (const uint16_t*)p->k_new;
+  a.k_new_stride = p->k_new_stride_t;
+  if (a.rope_cache) {
+    RX_REQUIRE(!p->kv.kv_fp8, "rx_decode_attn: fused RoPE reads and rewrites 16-bit latent rows (an fp8 pool: rotate with "
+                              "rx_rope_store_kv first)");
+    RX_REQUIRE(p->rope_dim == 64 && a.rope_pos && a.rope_stride >= 64,
+               "rx_decode_attn: fused RoPE needs rotary_dim 64 (= qk_rope_head_dim), positions and a [max_pos, 64] table");
+    RX_REQUIRE(p->stages != 2, "rx_decode_attn: fused RoPE belongs to a call that runs stage 1");
+    RX_REQUIRE(!a.kpe_out || (((uintptr_t)a.kpe_out & 15) == 0 && a.kpe_out_stride % 8 == 0),
+               "rx_decode_attn: rope_k_pe_out needs 16-byte aligned rows");
+    RX_REQUIRE(!a.k_new || (((uintptr_t)a.k_new & 15) == 0 && a.k_new_stride % 8 == 0),
+               "rx_decode_attn: k_new needs 16-byte aligned rows");
+  } else {
+    RX_REQUIRE(!a.k_new, "rx_decode_attn: k_new on the latent kernel is the fused-RoPE form (rope_cos_sin)");
+  }
   const bool linear = p->kv.page_size == 1 || p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride;
   const bool idx64 = p->kv_indices != nullptr && p->kv_indices_is_i64;
   const unsigned pairs = static_cast<unsigned>(a.bs) * a.max_kv_splits;

@@ -16,7 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
-RX_ABI_VERSION = 9  # include/radix_hip.h
+RX_ABI_VERSION = 10  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -59,6 +59,9 @@ class RxDecodeParams(C.Structure):
         ("request_order", c_void_p), ("partial_pairs_hint", c_int32),
         ("split_items", c_void_p), ("split_items_count", c_void_p), ("split_items_cap", c_int32),
         ("split_items_wgs_per_cu", c_int32),
+        ("rope_cos_sin", c_void_p), ("rope_cos_sin_is_f32", c_int32), ("rope_cos_sin_stride", c_int64),
+        ("rope_positions", c_void_p), ("rope_positions_is_i64", c_int32), ("rope_dim", c_int32),
+        ("rope_is_neox", c_int32), ("rope_k_pe_out", c_void_p), ("rope_k_pe_out_stride", c_int64),
     ]
 
 

@@ -343,6 +343,75 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
+def _set_rope(p, cos_sin_cache, positions, rotary_dim, is_neox_style, k_pe_tokens, k_new):
+    """rx_decode_params.rope_*: fused RoPE of the latent decode (see decode_attention_fwd_grouped_rope)."""
+    _require_cuda(cos_sin_cache, positions, k_pe_tokens, k_new)
+    if cos_sin_cache.dim() != 2 or cos_sin_cache.stride(-1) != 1:
+        raise ValueError("cos_sin_cache must be [max_pos, rotary_dim], contiguous in its rows")
+    if cos_sin_cache.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise TypeError("cos_sin_cache: float32 or the 16-bit dtype of q")
+    if positions.dtype not in (torch.int64, torch.int32) or not positions.is_contiguous():
+        raise TypeError("positions must be a contiguous int64 / int32 vector")
+    p.rope_cos_sin = cos_sin_cache.data_ptr()
+    p.rope_cos_sin_is_f32 = int(cos_sin_cache.dtype == torch.float32)
+    p.rope_cos_sin_stride = cos_sin_cache.stride(0)
+    p.rope_positions = positions.data_ptr()
+    p.rope_positions_is_i64 = int(positions.dtype == torch.int64)
+    p.rope_dim = int(rotary_dim)
+    p.rope_is_neox = int(bool(is_neox_style))
+    if k_pe_tokens is not None:
+        kp = k_pe_tokens.view(k_pe_tokens.shape[0], -1)
+        if kp.shape[1] != 64 or kp.stride(1) != 1:
+            raise ValueError("k_pe_tokens must hold [bs, 64] rows")
+        p.rope_k_pe_out = kp.data_ptr()
+        p.rope_k_pe_out_stride = kp.stride(0)
+    if k_new is not None:
+        kn = k_new.view(k_new.shape[0], -1)
+        if kn.shape[1] != 576 or kn.stride(1) != 1:
+            raise ValueError("k_new must hold [bs, 576] latent rows (512 latent + 64 rope, not rotated)")
+        p.k_new = kn.data_ptr()
+        p.k_new_stride_t, p.k_new_stride_h = kn.stride(0), 576
+    p._keep_rope = (cos_sin_cache, positions, k_pe_tokens, k_new)
+
+
+def decode_attention_fwd_grouped_rope(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, k_pe_tokens, kv_lora_rank,
+                                      rotary_dim, cos_sin_cache, positions, attn_logits, num_kv_splits, sm_scale,
+                                      logit_cap=0.0, use_rope=False, is_neox_style=False, page_size: int = 1,
+                                      kv_layout=None, k_new=None, attn_lse=None, split_counts=None):
+    """kernels/ops/attention/rocm_mla_decode_rope.py:402-439 -- the ROCm MLA decode that rotates q_pe and the newest
+    token's k_pe inside the attention kernel (DeepSeek absorbed MLA: q [bs, Hq, 512 + 64], one latent kv head, v = the
+    first ``kv_lora_rank`` columns of the same rows).  Same arguments: ``k_buffer`` holds every cached row, the step's
+    own row included with its k_pe NOT yet rotated; the rotated k_pe comes back in ``k_pe_tokens`` [bs, 1, 64] and the
+    pool is left alone (forward_mla_fused_rope_rocm.py:205-210 stores the row again).  ``attn_logits`` is the reference's
+    [bs, Hq, num_kv_splits, kv_lora_rank + 1] scratch: accepted for signature parity -- this library keeps the LSEs in
+    ``attn_lse`` (made here if not given) and lays its partials out itself.
+    Beyond the reference: ``k_new`` [bs, 576] -- the step's rows NOT stored yet: the launch reads them from k_new,
+    rotates, attends and stores the finished rows (RoPE + KV store + attention in one launch); ``page_size`` /
+    ``kv_layout`` for paged pools (the reference kernel is page_size 1 only).  16-bit pools, rotary_dim 64."""
+    _require_cuda(q, k_buffer, v_buffer, o, kv_indptr, kv_indices)
+    if kv_lora_rank != 512 or q.shape[-1] != 576 or o.shape[-1] != 512:
+        raise NotImplementedError("decode_attention_fwd_grouped_rope: the latent shape 512 + 64 only")
+    bs, hq = q.shape[0], q.shape[1]
+    S = max(1, int(num_kv_splits))
+    logits = torch.empty((bs, hq, S, 512), dtype=torch.float32, device=q.device) if S > 1 else None
+    lse = (attn_lse if attn_lse is not None else torch.empty((bs, hq, S), dtype=torch.float32, device=q.device)) if S > 1 else None
+    if S > 1 and split_counts is None:
+        split_counts = torch.full((bs,), S, dtype=torch.int32, device=q.device)  # the reference cuts every request S ways
+    p = _L.RxDecodeParams()
+    _fill_decode_common(p, q, k_buffer, v_buffer, o, logits, lse, split_counts, S, sm_scale, 1.0, 1.0, logit_cap, None,
+                        page_size, kv_layout)
+    if kv_indptr.dtype != torch.int32:
+        raise TypeError("kv_indptr must be int32")
+    p.kv_indptr, p.kv_indices = kv_indptr.data_ptr(), kv_indices.data_ptr()
+    p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
+    if use_rope:
+        if k_pe_tokens is None and k_new is None:
+            raise ValueError("fused RoPE returns the rotated k_pe of the step's tokens: pass k_pe_tokens (or k_new)")
+        _set_rope(p, cos_sin_cache, positions, rotary_dim, is_neox_style, k_pe_tokens, k_new)
+    p._keep_scratch = (logits, lse, split_counts)
+    _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
+
+
 def _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens,
                                attn_logits, attn_lse, num_kv_splits, max_kv_splits, sm_scale,
                                k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,

@@ -23,6 +23,7 @@ Fixture families:
   F12 unified one-stage extend (deterministic inference) -> extend_unified.npz
   F11 rotary embedding (torch-native apply_rotary_emb) -> rope.npz
   F9 extend with custom (tree) masks, sliding window (+ window_kv_offsets), xai temperature -> extend_mask.npz
+  F16 ROCm MLA decode with fused RoPE (stage-1 kernel of rocm_mla_decode_rope.py, LSE-merged) -> mla_rope.npz
 """
 import json
 import os
@@ -1021,8 +1022,70 @@ def f15():
     save("dcp.npz", **out)
 
 
+def f16():
+    """F16 the ROCm MLA decode with fused RoPE -> mla_rope.npz.  The reference's stage-1 kernel
+    _fwd_grouped_kernel_stage1_rope (kernels/ops/attention/rocm_mla_decode_rope.py:45-315) under TRITON_INTERPRET=1
+    (fp16), both rotation styles; its public wrapper decode_attention_fwd_grouped_rope calls the stage-2 reduce with a
+    stale signature in this tree (:439 vs decode_attention.py's _decode_softmax_reducev_fwd) and cannot run, so the
+    stage-1 partials [bs, Hq, splits, c + 1] (normalised acc | lse, :294-315) are merged here by their LSEs -- what
+    stage 2 computes (decode_attention.py:731-805).  The module asks Triton's active driver for its backend at import
+    time; a CPU box has none, so a stub driver answers (the interpreter never uses it)."""
+    import triton
+
+    class _Target:
+        backend = "cuda"
+
+    class _Drv:
+        def get_current_target(self):
+            return _Target()
+
+        def get_current_device(self):
+            return 0
+
+    triton.runtime.driver.set_active(_Drv())
+    from sglang.kernels.ops.attention.rocm_mla_decode_rope import _decode_grouped_att_m_fwd_rope
+
+    torch.manual_seed(16)
+    rng = np.random.default_rng(16)
+    dtype = torch.float16
+    C, R, maxpos = 512, 64, 256
+    inv = 1.0 / (10000 ** (torch.arange(0, R, 2).float() / R))
+    fr = torch.outer(torch.arange(maxpos).float(), inv)
+    cache = torch.cat((fr.cos(), fr.sin()), dim=-1)  # fp32 [maxpos, 64]
+    flat = {}
+    for name, H, lens, S, neox in [("neox", 16, [5, 70, 33, 1], 2, True), ("gptj", 16, [40, 129, 2], 4, False),
+                                   ("neox_h20", 20, [64, 9], 1, True)]:
+        lens = np.array(lens, dtype=np.int32)
+        B = len(lens)
+        pool = int(lens.sum()) + 3
+        kb = (torch.randn(pool, 1, C + R) * 0.5).to(dtype)
+        q = (torch.randn(B, H, C + R) * 0.5).to(dtype)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.from_numpy(np.cumsum(lens))
+        kv_indices = torch.from_numpy(rng.permutation(pool - 1)[: int(lens.sum())] + 1).to(torch.int64)
+        positions = torch.from_numpy(lens.astype(np.int64) - 1 + rng.integers(0, 50, size=B))
+        att = torch.zeros(B, H, S, C + 1, dtype=torch.float32)
+        kpe = torch.zeros(B, 1, R, dtype=dtype)
+        sm = 1.0 / (192 ** 0.5)
+        _decode_grouped_att_m_fwd_rope(q, kb, kb[..., :C], att, kpe, C, cache, positions, R, kv_indptr, kv_indices, S,
+                                       sm, 0.0, True, neox)
+        # stage 2: LSE merge of the splits that hold tokens (split s covers [s * ceil(len / S), ...): :112-114)
+        o = torch.zeros(B, H, C, dtype=torch.float64)
+        for b in range(B):
+            per = -(-int(lens[b]) // S)
+            live = [s_ for s_ in range(S) if per * s_ < int(lens[b])]
+            l = att[b, :, live, C].double()                     # [H, live]
+            w = torch.exp(l - l.max(dim=1, keepdim=True).values)
+            o[b] = ((att[b, :, live, :C].double() * w[..., None]).sum(1) / w.sum(1, keepdim=True))
+        c = dict(q=q, kb=kb, kv_indptr=kv_indptr, kv_indices=kv_indices, positions=positions, cos_sin=cache,
+                 sm_scale=sm, neox=int(neox), splits=S, o=o.to(dtype), k_pe_out=kpe)
+        for k, v in c.items():
+            flat[f"{name}.{k}"] = bits(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+    save("mla_rope.npz", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14",
-                             "f15"]
+                             "f15", "f16"]
     for w in which:
         globals()[w]()

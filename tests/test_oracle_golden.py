@@ -438,3 +438,16 @@ def test_dcp_host_lens_match_the_reference(golden_dir):
         start = torch.from_numpy(c["start"]) if int(c["use_start"]) else None
         got = get_dcp_lens(torch.from_numpy(c["lens"]), int(c["dcp"]), int(c["rank"]), start)
         assert np.array_equal(got.numpy(), c["dcp_lens"]), i
+
+
+# ------------------------------------------------------------------ F16
+def test_mla_decode_fused_rope_oracle_matches_reference_kernel(golden_dir):
+    """oracle.decode_attention_grouped_rope against the reference's own stage-1 kernel run under the Triton interpreter
+    (rocm_mla_decode_rope.py:45-315; partials merged by LSE in make_golden.f16): the attention output within the
+    reference's own decode tolerance, the rotated k_pe of the newest tokens to one fp16 rounding."""
+    for name, c in _cases(_load_npz(golden_dir, "mla_rope.npz")).items():
+        o, kpe = orc.decode_attention_grouped_rope(c["q"], c["kb"], c["kv_indptr"], c["kv_indices"], c["cos_sin"],
+                                                   c["positions"], float(c["sm_scale"]), is_neox=bool(c["neox"]))
+        np.testing.assert_allclose(o, c["o"].astype(np.float64), atol=2e-3, rtol=2e-3, err_msg=name)
+        want_k = c["k_pe_out"].astype(np.float64).reshape(kpe.shape)
+        assert np.abs(kpe - want_k).max() <= 2.0 ** -10 * max(1.0, np.abs(want_k).max()), name
