@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/pmc3 (tools/pmc_round3.sh) into profiles/r03_*_sq_counters.json: mean per launch of every counter
-of the named kernel + the derived fractions DESIGN.md quotes.  python tools/pmc_round3_summary.py [src] [dst]"""
+"""Condense gpurun_out/pmc (tools/pmc_round.sh) into profiles/<tag>_*_sq_counters.json: mean per launch of every counter
+of the named kernel + the derived fractions DESIGN.md quotes.  python tools/pmc_round_summary.py [src] [dst] [tag]"""
 import collections, csv, glob, json, os, sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc3"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+tag = sys.argv[3] if len(sys.argv) > 3 else "r04"
 
 
 def counters(prefix, sub):
@@ -39,18 +40,17 @@ def derived(c):
 
 
 JOBS = [
-    ("r03_extend32_sq_counters.json", "ext32", "extend_mfma32_kernel", "python3 bench.py --extend-only (config-3 chunk, D = 128, the dispatched eight-wave kernel)"),
-    ("r03_extend_pw_sq_counters.json", "pw", "extend_pw_kernel", "RX_EXT_PW=2 python3 bench.py --extend-only (the one-wave-per-SIMD kernel, forced)"),
-    ("r03_extend_d256_sq_counters.json", "dims", "extend_d256_kernel<rx::BF16, 256", "DIMS=256x256,64x64,192x128 python3 tools/extend_dims.py (config-3 chunk at D = 256)"),
-    ("r03_extend_d64_sq_counters.json", "dims", "extend_d256_kernel<rx::BF16, 64", "the same run, D = 64 (config 0's head dim; since late round 3 on the D = 256 kernel's template)"),
-    ("r03_mla_decode_fp8_sq_counters.json", "mla8", "decode_mla8", "PS=64 FP8=1 python3 tools/mla_bench.py (config-5 shard shape, fp8 rows)"),
-    ("r03_mla_decode_bf16_sq_counters.json", "mla16", "decode_mla_kernel", "PS=64 python3 tools/mla_bench.py (16-bit rows)"),
+    (tag + "_extend32_sq_counters.json", "ext32", "extend_mfma32_kernel", "python3 bench.py --extend-only (config-3 chunk, D = 128, the dispatched eight-wave kernel)"),
+    (tag + "_extend_d256_sq_counters.json", "dims", "extend_d256_kernel<rx::BF16, 256", "DIMS=256x256,64x64,192x128 python3 tools/extend_dims.py (config-3 chunk at D = 256)"),
+    (tag + "_extend_d64_sq_counters.json", "dims", "extend_d256_kernel<rx::BF16, 64", "the same run, D = 64 (config 0's head dim; on the D = 256 kernel's template)"),
+    (tag + "_mla_decode_fp8_sq_counters.json", "mla8", "decode_mla8", "PS=64 FP8=1 python3 tools/mla_bench.py (config-5 shard shape, fp8 rows)"),
+    (tag + "_mla_decode_bf16_sq_counters.json", "mla16", "decode_mla_kernel", "PS=64 python3 tools/mla_bench.py (16-bit rows)"),
 ]
 for out, prefix, sub, what in JOBS:
     c, names, n = counters(prefix, sub)
     if not c:
         print("no data for", out)
         continue
-    json.dump({"source": "bash tools/pmc_round3.sh: two rocprofv3 --pmc passes of `" + what + "`, means per launch", "kernels": names,
+    json.dump({"source": "bash tools/pmc_round.sh: two rocprofv3 --pmc passes of `" + what + "`, means per launch", "kernels": names,
                "launches_per_counter": n, "counters": c, "derived": derived(c)}, open(os.path.join(dst, out), "w"), indent=1)
     print(out, json.dumps(derived(c)))

@@ -1,5 +1,7 @@
+# end-of-round GPU pass (through gpurun):  bash tools/probe/final.sh <tag>
+TAG=${1:-r04}
 rm -f gpurun_out/parity_errors.jsonl
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -4
-bash tools/profile_round.sh r03 > gpurun_out/profile_round.log 2>&1
-bash tools/pmc_round3.sh > gpurun_out/pmc_round3.log 2>&1
+timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -4
+bash tools/profile_round.sh $TAG > gpurun_out/profile_round.log 2>&1
+bash tools/pmc_round.sh > gpurun_out/pmc_round.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2

@@ -1,16 +1,16 @@
 #!/bin/bash
 # Reproduces the committed profiles/ set on an MI355X box:  bash tools/profile_round.sh <tag>
 # (run through gpurun; then `python profiles/summarize.py gpurun_out/prof <tag>` condenses the CSVs)
-TAG=${1:-r02}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-radix-hit --steps 2 --warmup 1 > $OUT/${TAG}_bench_under_kernel_trace.json 2> $OUT/kt.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $R/bench.py --no-extra --no-cpu-baseline --no-radix-hit --steps 2 --warmup 1 > $OUT/${TAG}_bench_under_kernel_trace.json 2> $OUT/kt.err
 # counter passes: eager launches (--no-graph), one counter family per pass, nothing but --pmc on the command line
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pf --output-format csv -- python3 $R/bench.py --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pf.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pw --output-format csv -- python3 $R/bench.py --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pw.err
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pf --output-format csv -- python3 $R/bench.py --no-extra --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pf.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pw --output-format csv -- python3 $R/bench.py --no-extra --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pw.err
 # MLA decode kernels: HBM read bytes per launch (one --pmc pass each, nothing else on the command line)
 rocprofv3 --pmc FETCH_SIZE -d $OUT/mla16_pmc -o p --output-format csv -- python3 $R/tools/mla_bench.py > /dev/null 2> $OUT/mla16_pmc.err
 FP8=1 rocprofv3 --pmc FETCH_SIZE -d $OUT/mla8_pmc -o p --output-format csv -- python3 $R/tools/mla_bench.py > /dev/null 2> $OUT/mla8_pmc.err
