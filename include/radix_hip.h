@@ -125,7 +125,14 @@ int rx_num_kv_splits_native(const void* seq_lens, int seq_lens_is_i64, int bs, i
  * step runs): if the first pass of a mixed batch needs R1 = ceil(pairs * wg_per_request / wg_target) >= 2 rounds of
  * workgroups, the split requests are cut into pieces of p = R * a tokens, a = the mean length of the unsplit requests
  * (rounded up; never below the first pass's t*), R = the smallest of 1..4 with ceil(workgroups(p) / wg_target) <= R: a long request's pieces then end
- * with the last round of the short ones.  R1 = 1 keeps the first pass (all resident: the even share fills the slots). */
+ * with the last round of the short ones.  R1 = 1 keeps the first pass (all resident: the even share fills the slots).
+ * The FILL rule (round 4; only with wg_target_mixed != 0, i.e. the live-pairs schedules; CUs = wg_target / 2) comes
+ * before all of the above: a NEAR-UNIFORM batch (2 max(len) <= 3 mean(len) over the live requests) whose whole-request
+ * workgroups number blocks = live * wg_per_request with 0.7 CUs <= blocks < 3 CUs takes ONE count S for everybody --
+ * S = 1 when blocks <= CUs (the launch is bound by HBM as a whole: a split only adds its merge), otherwise the smallest
+ * S <= min(max_kv_splits, 6) with blocks * S >= 0.85 * ceil(blocks * S / CUs) * CUs (the pieces fill whole rounds of
+ * CUs: the launch lasts as long as the CU with the most bytes), or the best-filling S if none reaches 0.85 -- and
+ * out[b] = max(1, min(S, len_b / 256)). */
 int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int wg_target,
                               int max_kv_splits, int min_tokens_per_split, int wg_target_mixed, int32_t* out,
                               void* stream);

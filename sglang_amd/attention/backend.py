@@ -483,9 +483,11 @@ class HipRadixAttnBackend:
         group = max(1, self.num_head // self.num_kv_head)
         blocks = bs * self.num_kv_head * ((group + 15) // 16)
         wg_target = self.device_core_count * 2
-        # Dense kernel: the LENGTH-AWARE schedule (rx_num_kv_splits_balanced).  Two workgroups per CU in total is where
-        # the kernel is fastest (one per CU is one wave per SIMD: TP=8 shard 256 x 4 k 113 -> 106 us per layer at 2
-        # splits; 16 x 4 k 57 -> 55; 8 x 8 k 56 -> 51; beyond that every split only costs), and a request takes
+        # Dense kernel: the LENGTH-AWARE schedule (rx_num_kv_splits_balanced).  A batch with fewer whole-request
+        # workgroups than ~0.7 per CU is cut to two workgroups per CU in total (16 x 4 k 72 -> 53 us per layer; 8 x 8 k
+        # 127 -> 54; beyond that every split only costs); a near-uniform batch of 0.7 - 3 per CU goes by the FILL rule
+        # (round 4, radix_hip.h: whole up to one per CU -- TP=8 shard 256 x 4 k 105 -> 100 us, 192 x 4 k 93 -> 76 -- and
+        # above it the count whose pieces fill whole rounds of CUs: 320 x 4 k 153 -> 125).  Otherwise a request takes
         # ceil(len / t*) splits, t* = the batch's even share per workgroup -- but ONLY if it is well above that share:
         # in a uniform batch nobody is split (bs 256 x 4 k: one pass each), while one 32 k-token request among 63 of 1 k
         # is cut ~20 ways instead of being the kernel's tail (516 -> 139 us per layer).  Requests with one split write

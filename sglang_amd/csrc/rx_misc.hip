@@ -856,11 +856,71 @@ __global__ __launch_bounds__(1024) void num_kv_splits_balanced_kernel(const void
     __syncthreads();
     return total_s;
   };
+  auto block_max = [&](unsigned long long acc) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const unsigned long long o = __shfl_xor(acc, d);
+      acc = o > acc ? o : acc;
+    }
+    __syncthreads();
+    if (lane == 0) part[wid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long t = 0;
+      for (int w = 0; w < 16; ++w) t = part[w] > t ? part[w] : t;
+      total_s = t;
+    }
+    __syncthreads();
+    return total_s;
+  };
   if (tid < 2) flags_s[tid] = 0;
-  unsigned long long acc = 0;
-  for (int i = tid; i < bs; i += 1024) acc += static_cast<unsigned long long>(max<int64_t>(load_idx(seq_lens, i, is64), 0));
+  unsigned long long acc = 0, amax = 0, alive = 0;
+  for (int i = tid; i < bs; i += 1024) {
+    const unsigned long long len = static_cast<unsigned long long>(max<int64_t>(load_idx(seq_lens, i, is64), 0));
+    acc += len;
+    amax = len > amax ? len : amax;
+    alive += len > 0;
+  }
+  const unsigned long long total = block_sum(acc);
   // tokens one workgroup should carry so that wg_target workgroups share the batch evenly
-  const unsigned long long work = block_sum(acc) * static_cast<unsigned long long>(wg_per_request);
+  const unsigned long long work = total * static_cast<unsigned long long>(wg_per_request);
+  if (wg_mixed != 0) {
+    // The FILL rule (round 4; a near-uniform batch of about one to three whole-request workgroups per CU).  The decode
+    // kernel moves ~27 GB/s per CU however many workgroups the CU holds, so the launch lasts as long as the CU with the
+    // most bytes: 1.25 requests per CU unsplit is two requests' time on a quarter of the chip with the rest idle
+    // (TP = 8 shard, 320 x 4 k: 153 us; every request cut in 3 -> 3.75 pieces per CU -> 125 us), while a batch of
+    // 0.7 - 1 requests per CU is bound by HBM as a whole and every split only adds its merge (256 x 4 k: 100 us
+    // whole, 105 cut in two; 192 x 4 k: 76 vs 93 cut in three).  So: nobody is cut at 0.7 - 1 blocks per CU, and
+    // between 1 and 3 every request takes the smallest count S <= 6 whose pieces fill >= 85 % of a whole number of
+    // rounds of CUs.  tools/decode_sweep.py has the sweep.
+    const unsigned long long mx = block_max(amax), live = block_sum(alive);
+    const long long cus = max(1, wg_target / 2), blocks = static_cast<long long>(live) * wg_per_request;
+    if (live > 0 && 2 * mx * live <= 3 * total && 10 * blocks >= 7 * cus && blocks < 3 * cus) {
+      long long S = 1;
+      if (blocks > cus) {
+        long long best = 1, bn = 0, bd = 1;  // best fill so far as the fraction bn / bd
+        S = 0;
+        for (long long sp = 1; sp <= min(cap, 6); ++sp) {
+          const long long rounds = (blocks * sp + cus - 1) / cus;
+          if (100 * blocks * sp >= 85 * rounds * cus) {
+            S = sp;
+            break;
+          }
+          if (blocks * sp * bd > bn * rounds * cus) {
+            best = sp;
+            bn = blocks * sp;
+            bd = rounds * cus;
+          }
+        }
+        if (S == 0) S = best;
+      }
+      for (int i = tid; i < bs; i += 1024) {
+        const int64_t len = max<int64_t>(load_idx(seq_lens, i, is64), 0);
+        out[i] = static_cast<int32_t>(max<int64_t>(1, min<int64_t>(S, len / 256)));  // pieces of at least 256 tokens
+      }
+      return;
+    }
+  }
   int64_t tstar = max<int64_t>(min_tokens, static_cast<int64_t>((work + wg_target - 1) / wg_target));
   bool any_split = false, any_whole = false;
   for (int i = tid; i < bs; i += 1024) {

@@ -226,6 +226,22 @@ def balanced_kv_splits_host(lens, num_head: int, num_kv_head: int, max_kv_splits
         n = np.where(2 * lens > 3 * tstar, np.minimum(max_kv_splits, -(-lens // tstar)), 1)
         return np.maximum(n, 1).astype(np.int32)
 
+    if wg_target_mixed != 0:  # the fill rule (rx_misc.hip: near-uniform batches of ~1-3 whole-request workgroups per CU)
+        live, total, mx = int((lens > 0).sum()), int(lens.sum()), int(lens.max()) if lens.size else 0
+        cus, blocks = max(1, wg_target // 2), live * wgpr
+        if live > 0 and 2 * mx * live <= 3 * total and 10 * blocks >= 7 * cus and blocks < 3 * cus:
+            S = 1
+            if blocks > cus:
+                S, best, bn, bd = 0, 1, 0, 1
+                for sp in range(1, min(int(max_kv_splits), 6) + 1):
+                    rounds = -(-blocks * sp // cus)
+                    if 100 * blocks * sp >= 85 * rounds * cus:
+                        S = sp
+                        break
+                    if blocks * sp * bd > bn * rounds * cus:
+                        best, bn, bd = sp, blocks * sp, rounds * cus
+                S = S or best
+            return np.maximum(1, np.minimum(S, lens // 256)).astype(np.int32)
     n = counts(max(int(min_tokens_per_split), -(-work // wg_target)))
     if wg_target_mixed < 0 and (n > 1).any() and (n == 1).any():  # the rounds rule (two workgroups per CU)
         split = n > 1

@@ -230,6 +230,31 @@ def test_rounds_rule_of_the_balanced_schedule_host_mirror():
     assert (rr([]) == first([])).all() and rr([0, 0]).tolist() == [1, 1]
 
 
+def test_fill_rule_of_the_balanced_schedule_host_mirror():
+    """Round 4: near-uniform batches of 0.7 - 3 whole-request workgroups per CU (wg_target = 2 x 256 CUs) take one count
+    for everybody -- nobody is cut up to one per CU, above it the smallest count whose pieces fill >= 85 % of whole rounds
+    of CUs (the optima of tools/decode_sweep.py on the TP = 8 shard: 288 -> 4, 320 -> 3, 384 -> 2, 448 -> 1, 640 -> 2)."""
+    from sglang_amd import ops
+
+    tp8 = lambda lens, mixed=-1, cap=32: ops.balanced_kv_splits_host(lens, 4, 1, cap, 512, 1024, mixed)  # noqa: E731
+    for bs, want in ((192, 1), (224, 1), (256, 1), (288, 4), (320, 3), (384, 2), (448, 1), (512, 1), (640, 2), (768, 1)):
+        got = tp8([4096] * bs)
+        assert (got == want).all(), (bs, got[:4])
+    assert (tp8([4096] * 256, 0) == 2).all() and (tp8([4096] * 256, 768) == 1).all()    # off without a live-pairs schedule
+    assert (tp8([4096] * 160) == tp8([4096] * 160, 0)).all()                             # below 0.7 per CU: the even share
+    assert (tp8([4096] * 1024) == 1).all()                                               # 4 per CU: nobody is cut
+    assert tp8([4096] * 288, cap=2).max() == 2                                           # the cap holds (best fill under it)
+    short = tp8([300] * 320)
+    assert (short == 1).all()                                                            # pieces of at least 256 tokens
+    assert tp8([600] * 320).max() == 2
+    skew = [32768] + [1024] * 319
+    assert tp8(skew)[0] > 6 and (tp8(skew)[1:] == 1).all()                               # not near-uniform: the rounds rule's business
+    assert (tp8([0] * 64 + [4096] * 256) == 1).all()                                     # empty requests do not count as blocks
+    ragged = np.random.default_rng(3).integers(3000, 4097, size=320)
+    assert (tp8(ragged) == 3).all()                                                      # 2 max <= 3 mean: still one count
+    assert (ops.balanced_kv_splits_host([4096] * 40, 32, 8, 32, 512, 1024, -1) == 3).all()  # 320 blocks at Hkv = 8 as well
+
+
 def test_planner_caps_the_shared_length_below_every_member_and_survives_deep_chains():
     """L == seq_len would leave a member an empty suffix (its newest row never walked or stored), and the
     depth of a long radix chain must not recurse."""

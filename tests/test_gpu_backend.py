@@ -630,7 +630,11 @@ def test_balanced_split_schedule_kernel_matches_its_host_mirror_and_heterogeneou
     rng = np.random.default_rng(5)
     for lens, hq, hkv in ([[4096] * 256, 32, 8], [[32768] + [1024] * 63, 32, 8], [[8192] * 4 + [512] * 124, 32, 8],
                           [rng.integers(0, 6000, size=96).tolist(), 32, 8], [[4096] * 256, 4, 1], [[32768], 32, 8],
-                          [[0, 5, 70000], 8, 8]):
+                          [[0, 5, 70000], 8, 8],
+                          # the fill rule's range (0.7 - 3 whole-request workgroups per CU, near-uniform lengths)
+                          [[4096] * 192, 4, 1], [[4096] * 288, 4, 1], [[4096] * 320, 4, 1], [[4096] * 384, 4, 1],
+                          [[4096] * 640, 4, 1], [[4096] * 40, 32, 8], [[2048] * 80, 32, 8], [[300] * 300 + [0] * 20, 4, 1],
+                          [rng.integers(2048, 4097, size=320).tolist(), 4, 1], [rng.integers(1000, 4097, size=320).tolist(), 4, 1]):
         lt = torch.tensor(lens, dtype=torch.int64, device=DEV)
         for mt in (128, 1024):
             for mixed in (0, 768, 2048, -1):  # the mixed-batch budget (wg_target_mixed), its overshoot step; -1: the rounds rule
@@ -649,7 +653,8 @@ def test_balanced_split_schedule_kernel_matches_its_host_mirror_and_heterogeneou
     assert ops.balanced_kv_splits_host([4096] * 256, 32, 8, 32, 512, 1024).max() == 1          # the headline batch: one pass
     out = ops.balanced_kv_splits_host([32768] + [1024] * 63, 32, 8, 32, 512, 1024)
     assert out[0] >= 16 and out[1:].max() == 1                                                  # only the outlier is cut
-    assert ops.balanced_kv_splits_host([4096] * 256, 4, 1, 32, 512, 1024).max() == 2            # TP=8 shard: two per CU
+    assert ops.balanced_kv_splits_host([4096] * 256, 4, 1, 32, 512, 1024).max() == 2            # TP=8 shard, fill rule off: two per CU
+    assert ops.balanced_kv_splits_host([4096] * 256, 4, 1, 32, 512, 1024, -1).max() == 1        # ... on (what the backend runs): whole
 
     ps, hq, hkv, d = 16, 8, 2, 128
     hs = _Harness(ps, hq, hkv, d, torch.bfloat16, "shuffled_pages", "paged", max_ctx=4200, max_reqs=40)
