@@ -77,7 +77,8 @@ def mla(src, tag):
                          "algorithmic_kv_bytes": alg, "read_over_algorithmic": 2 * kib * 1024 / alg}
     if res:
         with open(os.path.join(out_dir, f"{tag}_mla_pmc_summary.json"), "w") as f:
-            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE -- python3 tools/mla_bench.py (FP8=1 for fp8 rows); same "
+            json.dump({"source": "PS=64 rocprofv3 --pmc FETCH_SIZE -- python3 tools/mla_bench.py (FP8=1 for fp8 rows; PS = the page_size, 64 as in "
+                                 "the bench leg since r04 -- r02 / r03 ran page_size 1); same "
                                  "gfx950 correction as the decode summary", "kernels": res}, f, indent=1)
 
 

@@ -11,9 +11,9 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3
 # counter passes: eager launches (--no-graph), one counter family per pass, nothing but --pmc on the command line
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pf --output-format csv -- python3 $R/bench.py --no-extra --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pf.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pw --output-format csv -- python3 $R/bench.py --no-extra --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pw.err
-# MLA decode kernels: HBM read bytes per launch (one --pmc pass each, nothing else on the command line)
-rocprofv3 --pmc FETCH_SIZE -d $OUT/mla16_pmc -o p --output-format csv -- python3 $R/tools/mla_bench.py > /dev/null 2> $OUT/mla16_pmc.err
-FP8=1 rocprofv3 --pmc FETCH_SIZE -d $OUT/mla8_pmc -o p --output-format csv -- python3 $R/tools/mla_bench.py > /dev/null 2> $OUT/mla8_pmc.err
+# MLA decode kernels: HBM read bytes per launch at the bench's page_size 64 (one --pmc pass each, nothing else on the command line)
+PS=64 rocprofv3 --pmc FETCH_SIZE -d $OUT/mla16_pmc -o p --output-format csv -- python3 $R/tools/mla_bench.py > /dev/null 2> $OUT/mla16_pmc.err
+PS=64 FP8=1 rocprofv3 --pmc FETCH_SIZE -d $OUT/mla8_pmc -o p --output-format csv -- python3 $R/tools/mla_bench.py > /dev/null 2> $OUT/mla8_pmc.err
 python3 $R/profiles/summarize.py $OUT $TAG
 # MLA decode (config 5 shape): kernel traces for 16-bit and fp8 latent rows
 rocprofv3 --kernel-trace --stats -d $OUT/mla16 -o m --output-format csv -- python3 $R/tools/mla_bench.py > $OUT/mla16.txt 2> $OUT/mla16.err
