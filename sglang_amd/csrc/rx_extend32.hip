@@ -40,13 +40,26 @@ static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, 
 int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const Options& opt = options();
   Ext32Args a = make_ext32_args(p);
-  // Long causal extends of a GQA-4 / GQA-8 model pack by themselves (bit-identical results, +2.6 % at the config-3 chunk: a
-  // 256-row block's diagonal is one boundary tile instead of four); option ext32_autopack = 0 turns it off
+  a.kv_fp8 = p->kv.kv_fp8;
+  const bool vsc = p->v_scale != 1.0f;
+  // (PLAIN instances compute ONE row offset for the K and the V load: both sides must have the same strides)
+  const bool same_kv = p->kv.k_page_stride == p->kv.v_page_stride && p->kv.k_tok_stride == p->kv.v_tok_stride &&
+                       p->k_stride_t == p->v_stride_t;
+  const bool plain_any = !a.kv_fp8 && !vsc && !a.unified_prefix && !a.custom_mask && a.window <= 0 &&
+                         a.xai_len <= 0 && !(a.logit_cap > 0.f) && same_kv && opt.ext32_plain;
+  // tiles a workgroup walks, estimated from the host-side hints: (mean prefix + half the longest extend) / 64
+  const int est_tiles = (p->avg_kv_len_hint + p->max_extend_len / 2) / kTok;
+  // Causal extends of a GQA-4 / GQA-8 model pack by themselves (bit-identical results): a 256-row block is then 64 or 32
+  // tokens of the whole group -- its diagonal one boundary tile instead of four, a kv head's tiles staged once for the
+  // group -- on the eight-wave PLAIN loop.  Round 3 did this for long extends over long prefixes only; round 4
+  // (tools/extend_forms.py, bare operator, TFLOP/s unpacked four-wave / unpacked eight-wave / packed): the packed form
+  // wins wherever a workgroup walks a few tiles -- no prefix + 2 k new tokens 812 / 710 / 895, + 512: 415 / 354 / 467;
+  // 512 + 512: 731 / 683 / 789; 2 k + 128: 917 / 783 / 964; 2 k + 64: 634 / 454 / 981; 4 k + 32: 407 / 252 / 872;
+  // config 3's 3584 + 512: 995 / 1033 / 1065 -- and loses only where there is next to nothing to do (no prefix + 256:
+  // 280 / 224 / 260).  Options: ext32_autopack = 0 turns it off, ext32_pack_min_len / ext32_pack_min_tiles move the gates.
   const int grp = p->num_kv_heads > 0 ? p->num_q_heads / p->num_kv_heads : 1;
-  if (opt.ext32_autopack && a.q_pack == 1 && (grp == 4 || grp == 8) && p->num_q_heads == grp * p->num_kv_heads && p->is_causal &&
-      !p->skip_extend && p->max_extend_len >= 256 && !p->kv.kv_fp8 && p->v_scale == 1.0f && !p->unified_prefix_lens &&
-      !p->custom_mask && p->sliding_window_size <= 0 && p->xai_temperature_len <= 0 && !(p->logit_cap > 0.f) &&
-      (p->avg_kv_len_hint + p->max_extend_len / 2) / kTok >= RX_EXT32_SMALL_WG_TILES)
+  if (opt.ext32_autopack && a.q_pack == 1 && plain_any && (grp == 4 || grp == 8) && p->num_q_heads == grp * p->num_kv_heads &&
+      p->is_causal && !p->skip_extend && p->max_extend_len >= opt.ext32_pack_min_len && est_tiles >= opt.ext32_pack_min_tiles)
     a.q_pack = grp;
   if (a.q_pack > 1) {  // the grid's heads are KV heads; their rows carry the q heads of the group
     a.hq = p->num_kv_heads;
@@ -55,24 +68,19 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);
-  // Workgroup size.  One 256-query workgroup per CU (8 waves) is best when a (request, head, query block)
-  // walks many tiles (config 3: 60 tiles, 739 vs 706 TFLOP/s); with few tiles the per-workgroup
-  // prologue / epilogue and the launch itself dominate and two 128-query workgroups per CU overlap them
-  // (no prefix, 2 Ki new tokens: 452 -> 512; 512 + 128: 356 -> 493).  Estimated tiles per workgroup from
-  // the host-side hints: (mean prefix + half the longest extend) / 64.  Option ext32_small_wg: 0 / 1 force a form.
-  const int est_tiles = (p->avg_kv_len_hint + p->max_extend_len / 2) / kTok;
-  const bool small_wg = opt.ext32_small_wg < 0 ? est_tiles < RX_EXT32_SMALL_WG_TILES : opt.ext32_small_wg != 0;
+  // Workgroup size.  Unpacked rows: one 256-query workgroup per CU (8 waves) is best when a (request, head, query block)
+  // walks many tiles (config 3: 60 tiles, 1033 vs 995 TFLOP/s); with few tiles the per-workgroup prologue / epilogue
+  // dominate and two 128-query workgroups per CU overlap them (no prefix, 2 Ki new tokens: 710 vs 812; 512 + 128: 513 vs
+  // 679).  Packed rows on the PLAIN loop (the caller's q_pack or the self-packing above) take eight waves from
+  // ext32_pack_min_tiles up.  Option ext32_small_wg: 0 / 1 force a form.
+  const bool packed_plain = plain_any && (a.q_pack == 4 || a.q_pack == 8);
+  const bool small_wg = opt.ext32_small_wg < 0 ? est_tiles < (packed_plain ? opt.ext32_pack_min_tiles : opt.ext32_small_wg_tiles)
+                                               : opt.ext32_small_wg != 0;
   const int nw = small_wg ? 4 : 8;
   a.mblocks = (p->max_extend_len * a.q_pack + nw * 32 - 1) / (nw * 32);
-  a.kv_fp8 = p->kv.kv_fp8;
-  const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0, vsc = p->v_scale != 1.0f;
-  // (PLAIN instances compute ONE row offset for the K and the V load: both sides must have the same strides)
-  const bool same_kv = p->kv.k_page_stride == p->kv.v_page_stride && p->kv.k_tok_stride == p->kv.v_tok_stride &&
-                       p->k_stride_t == p->v_stride_t;
-  const bool plain_any = !a.kv_fp8 && !vsc && !a.unified_prefix && !a.custom_mask && a.window <= 0 &&
-                         a.xai_len <= 0 && !(a.logit_cap > 0.f) && same_kv && opt.ext32_plain;
+  const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0;
   const bool plain = plain_any && a.q_pack == 1;
-  if (plain_any && (a.q_pack == 4 || a.q_pack == 8) && !small_wg) {  // packed rows on the PLAIN loop (GQA 4 / 8)
+  if (packed_plain && !small_wg) {  // packed rows on the PLAIN loop (GQA 4 / 8)
     if (a.q_pack == 4) launch32_nw<8, false, true, 4>(a, bf, i64, linear, false, s);
     else launch32_nw<8, false, true, 8>(a, bf, i64, linear, false, s);
     return RX_OK;

@@ -24,7 +24,8 @@ static int launch_var(const rx_extend_params* p, hipStream_t s) {
   a.kv_fp8 = 0;
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
   constexpr unsigned kLds = 2 * kBufBytes;
-  auto kern = extend_mfma32_kernel<BF16, int64_t, false, false, 8, false, true, 4, VAR>;
+  static_assert(VAR == 0, "add a trailing `int VAR = 0` template parameter to the kernel to study variants");
+  auto kern = extend_mfma32_kernel<BF16, int64_t, false, false, 8, false, true, 4>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
   (void)attr;
