@@ -26,6 +26,7 @@ struct Options {
   int ext32_small_wg_tiles = 28;  // ... the estimate below which the four-wave form runs (unpacked calls)
   int ext32_pack_min_len = 1;     // self-packing from this many new tokens (longest request) up ...
   int ext32_pack_min_tiles = 4;   // ... and this tile estimate; packed PLAIN rows take eight waves from here
+  int ext32_pack_min_wgs = -1;    // ... while the packed grid holds this many workgroups (-1: the device's CU count)
   int ext32_plain = 1;        // PLAIN instances (features compile-time off) when the call uses none of them
   int extend_16x16_d128 = 0;  // the 16x16x32 kernel of rx_extend.hip for plain D = 128 calls (A/B of the two shapes)
   int extend_d256 = 1;        // the AGPR / LDS-DMA template (256, 192, 96, 64) where it supports the call

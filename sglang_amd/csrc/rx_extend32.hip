@@ -56,10 +56,20 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   // wins wherever a workgroup walks a few tiles -- no prefix + 2 k new tokens 812 / 710 / 895, + 512: 415 / 354 / 467;
   // 512 + 512: 731 / 683 / 789; 2 k + 128: 917 / 783 / 964; 2 k + 64: 634 / 454 / 981; 4 k + 32: 407 / 252 / 872;
   // config 3's 3584 + 512: 995 / 1033 / 1065 -- and loses only where there is next to nothing to do (no prefix + 256:
-  // 280 / 224 / 260).  Options: ext32_autopack = 0 turns it off, ext32_pack_min_len / ext32_pack_min_tiles move the gates.
+  // 280 / 224 / 260).  Options: ext32_autopack = 0 turns it off, ext32_pack_min_len / ext32_pack_min_tiles /
+  // ext32_pack_min_wgs move the gates.
+  // Packing trades workgroups for work: it is taken only while the packed grid still covers the chip (1 request x 32 k +
+  // 64 tokens: 32 per-head workgroups 636 us, 8 packed ones 993 -- a batch that small needs the parallelism more).
   const int grp = p->num_kv_heads > 0 ? p->num_q_heads / p->num_kv_heads : 1;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n > 0 ? n : 256;
+  }();
   if (opt.ext32_autopack && a.q_pack == 1 && plain_any && (grp == 4 || grp == 8) && p->num_q_heads == grp * p->num_kv_heads &&
-      p->is_causal && !p->skip_extend && p->max_extend_len >= opt.ext32_pack_min_len && est_tiles >= opt.ext32_pack_min_tiles)
+      p->is_causal && !p->skip_extend && p->max_extend_len >= opt.ext32_pack_min_len && est_tiles >= opt.ext32_pack_min_tiles &&
+      static_cast<int64_t>(a.bs) * p->num_kv_heads * ((static_cast<int64_t>(p->max_extend_len) * grp + 255) / 256) >=
+          (opt.ext32_pack_min_wgs < 0 ? cus : opt.ext32_pack_min_wgs))
     a.q_pack = grp;
   if (a.q_pack > 1) {  // the grid's heads are KV heads; their rows carry the q heads of the group
     a.hq = p->num_kv_heads;
@@ -74,8 +84,14 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   // 679).  Packed rows on the PLAIN loop (the caller's q_pack or the self-packing above) take eight waves from
   // ext32_pack_min_tiles up.  Option ext32_small_wg: 0 / 1 force a form.
   const bool packed_plain = plain_any && (a.q_pack == 4 || a.q_pack == 8);
-  const bool small_wg = opt.ext32_small_wg < 0 ? est_tiles < (packed_plain ? opt.ext32_pack_min_tiles : opt.ext32_small_wg_tiles)
-                                               : opt.ext32_small_wg != 0;
+  // Either way eight waves only while their grid covers the chip: 2 requests x 8 k + 512 tokens are 128 eight-wave
+  // workgroups (661 TFLOP/s) or 256 four-wave ones (862).
+  const int64_t rows = static_cast<int64_t>(p->max_extend_len) * a.q_pack;
+  const bool thin_grid = rows > 128 && static_cast<int64_t>(a.bs) * a.hq * ((rows + 255) / 256) <
+                                           (opt.ext32_pack_min_wgs < 0 ? cus : opt.ext32_pack_min_wgs);
+  const bool small_wg = opt.ext32_small_wg < 0
+                            ? (thin_grid || est_tiles < (packed_plain ? opt.ext32_pack_min_tiles : opt.ext32_small_wg_tiles))
+                            : opt.ext32_small_wg != 0;
   const int nw = small_wg ? 4 : 8;
   a.mblocks = (p->max_extend_len * a.q_pack + nw * 32 - 1) / (nw * 32);
   const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0;

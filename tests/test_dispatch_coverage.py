@@ -52,6 +52,7 @@ def _cases():
                 pkc = arg
                 if pkc:  # the packed PLAIN instances: GQA 4 / 8, causal, long extends (autopack)
                     c["hq"], c["hkv"] = (8, 2) if pkc == 4 else (8, 1)
+                    c["opts"]["ext32_pack_min_wgs"] = 0  # (four requests: the packed grid is below the chip-coverage gate)
                 else:    # never auto-packed: group 1, 2 or 16
                     c["hq"], c["hkv"] = [(4, 4), (4, 2), (16, 1)][next(n) % 3]
                 vs, kv8, plain = False, False, True

@@ -54,7 +54,8 @@ def test_autopacked_extend_is_bit_identical_and_matches_oracle(dtype, shape, hea
     from sglang_amd import lib as rxlib
 
     for mode in ("1", "0"):
-        with rxlib.option("ext32_autopack", int(mode)):
+        # (ext32_pack_min_wgs = 0: these batches are far below the chip-coverage gate of the self-packing)
+        with rxlib.option("ext32_autopack", int(mode)), rxlib.option("ext32_pack_min_wgs", 0):
             o = torch.full((T, hq, d), float("nan"), dtype=dtype, device=DEV)
             lse = torch.zeros(T, hq, dtype=torch.float32, device=DEV)
             ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV),
@@ -76,3 +77,52 @@ def test_autopacked_extend_is_bit_identical_and_matches_oracle(dtype, shape, hea
     got = outs["1"][0].float().cpu().numpy()
     assert not np.isnan(got).any()
     parity.check_out(got, want, dtype, ("autopack", shape), ulps=1, absw=absw)
+
+
+def test_self_packing_gates_tile_estimate_and_chip_coverage():
+    """The launcher's gates (rx_extend32.hip, round 4): GQA-4 rows pack by themselves from four estimated tiles up
+    (prefix hint + half the longest extend, in 64-token tiles) and only while the packed grid -- requests x kv heads x
+    256-row blocks -- still covers the chip's CUs; below either gate the unpacked form runs.  Same bits both ways, for
+    short extends over a prefix too (the case that gained most: 2 k + 64 tokens)."""
+    from sglang_amd import lib as rxlib
+    from sglang_amd import ops
+
+    hq, hkv, d = 8, 2, 128
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def run(bs, P, E, **opts):
+        g = torch.Generator().manual_seed(bs * 1000 + P + E)
+        pool = bs * P + 1
+        kb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+        vb = torch.randn(pool, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+        q = torch.randn(bs * E, hq, d, generator=g).to(torch.bfloat16).to(DEV)
+        ke = torch.randn(bs * E, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+        ve = torch.randn(bs * E, hkv, d, generator=g).to(torch.bfloat16).to(DEV)
+        qo = torch.arange(bs + 1, dtype=torch.int64, device=DEV) * E
+        kvp = torch.arange(bs + 1, dtype=torch.int32, device=DEV) * P
+        kvi = torch.randperm(bs * P, generator=g).to(torch.int64).to(DEV) + 1
+        o = torch.full((bs * E, hq, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ctx = [rxlib.option(k, v) for k, v in opts.items()]
+        for c in ctx:
+            c.__enter__()
+        try:
+            ops.extend_attention_fwd(q, ke, ve, o, kb, vb, qo, kvp, kvi, None, True, None, E, 1.0, 1.0, sm_scale=d ** -0.5,
+                                     page_size=1, avg_kv_len_hint=P)
+            torch.cuda.synchronize()
+            return o, rxlib.last_dispatch()
+        finally:
+            for c in reversed(ctx):
+                c.__exit__()
+
+    big = -(-cus // hkv)                      # requests whose packed grid (one block each) just covers the chip
+    o_p, name = run(big, 512, 64)
+    assert name.endswith("8, false, true, 4>"), name          # 9 estimated tiles, grid >= CUs: packed, eight waves
+    o_u, name = run(big, 512, 64, ext32_autopack=0)
+    assert name.endswith("4, false, true, 0>"), name          # switched off: the four-wave unpacked form of that estimate
+    assert torch.equal(o_p.view(torch.int16), o_u.view(torch.int16)) and not torch.isnan(o_p.float()).any()
+    _, name = run(big - 8, 512, 64)
+    assert name.endswith("true, 0>"), name                    # the packed grid would leave CUs idle: unpacked
+    _, name = run(big, 64, 64)
+    assert name.endswith("4, false, true, 0>"), name          # one estimated tile: next to nothing to do, unpacked
+    _, name = run(big - 8, 512, 64, ext32_pack_min_wgs=0)
+    assert name.endswith("8, false, true, 4>"), name          # the gate is an option

@@ -15,4 +15,11 @@ for P in "$P1" "$P2"; do i=$((i+1))
   PS=64 FP8=1 rocprofv3 --pmc $P -d $O/mla8_p$i -o p --output-format csv -- python3 $R/tools/mla_bench.py > $O/mla8_$i.log 2>&1
   PS=64 rocprofv3 --pmc $P -d $O/mla16_p$i -o p --output-format csv -- python3 $R/tools/mla_bench.py > $O/mla16_$i.log 2>&1
 done
+# the D = 128 extend kernel's issue / wait classes: two more passes, this kernel only
+P3="SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_LEVEL_LDS"
+P4="SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_CVT"
+i=2
+for P in "$P3" "$P4"; do i=$((i+1))
+  rocprofv3 --pmc $P -d $O/ext32_p$i -o p --output-format csv -- python3 $R/bench.py --extend-only > $O/ext32_$i.log 2>&1
+done
 ls $O

@@ -34,6 +34,16 @@ def derived(c):
         for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"):
             if k in c:
                 d[k.lower() + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
+    if c.get("SQ_WAVE_CYCLES"):  # issue classes: cycles a wave had an instruction of the class in flight / wave cycles
+        for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC",
+                  "SQ_ACTIVE_INST_ANY"):
+            if k in c:
+                d[k.lower() + "_frac_of_wave_cycles"] = c[k] / c["SQ_WAVE_CYCLES"]
+    if c.get("SQ_INSTS_MFMA") and "SQ_INSTS_VALU_TRANS_F32" in c:
+        d["trans_per_mfma"] = c["SQ_INSTS_VALU_TRANS_F32"] / c["SQ_INSTS_MFMA"]
+        d["vmem_rd_per_mfma"] = c.get("SQ_INSTS_VMEM_RD", 0) / c["SQ_INSTS_MFMA"]
+    if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and "SQ_VALU_MFMA_COEXEC_CYCLES" in c:
+        d["valu_coexec_frac_of_mfma_busy"] = c["SQ_VALU_MFMA_COEXEC_CYCLES"] / c["SQ_VALU_MFMA_BUSY_CYCLES"]
     if c.get("SQ_LDS_IDX_ACTIVE"):
         d["lds_bank_conflict_frac_of_lds_cycles"] = c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"]
     return d
