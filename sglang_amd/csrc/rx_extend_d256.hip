@@ -31,6 +31,7 @@ constexpr int kYTT = 64;
 constexpr int kYSlotBlock = 256;
 constexpr int kYRows = 256;                  // query rows per workgroup
 constexpr float kYSlack = 8.0f;
+constexpr float kYSumLimit = 4096.0f;  // a lane's partial row sum above this sends the wave to the max-based step
 
 // (Dk, Dv): 256 / 256, and the MLA prefill shape 192 / 128 (qk_nope 128 + rope 64 against v 128) and 192 / 192
 template <int DK, int DV>
@@ -420,44 +421,72 @@ __global__ __launch_bounds__(512, 1) void extend_d256_kernel(const ExtD256Args a
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         float sv[8];
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
-        if (capped) {  // logit cap (wave-uniform branch): cap * tanh(s * scale / cap)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * cs / a.logit_cap);
-        }
-        // (a half that every row of the wave sees in full -- the whole prefix but its ragged end, the new tokens below
-        // the wave's first row -- takes no mask: 2 of its ~10 VALU per score; wave-uniform branch)
-        if (!half_full) {
-          int lnm = lane;
-          asm volatile("" : "+v"(lnm));
-          const int32_t tk1 = row_tok(rbase + 16 * c + (lnm & 15)) + 1;
-          const int32_t vis = (prefix ? p_len : min(n_end_w, a.causal ? tk1 : E)) - n0 - 4 * (lnm >> 4);  // visible: index < vis
+        // the block's 8 scores per lane as the softmax takes them: capped, masked
+        auto load_sv = [&]() {
 #pragma unroll
           for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i < vis) ? sv[bb * 4 + i] : -INFINITY;
-          if (windowed) {  // ... and index >= the row's window bound (wave-uniform branch)
-            const int32_t wlo = (prefix ? P : 0) + tk1 - 1 - a.window - n0 - 4 * (lnm >> 4);
+            for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
+          if (capped) {  // logit cap (wave-uniform branch): cap * tanh(s * scale / cap)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * cs / a.logit_cap);
+          }
+          // (a half that every row of the wave sees in full -- the whole prefix but its ragged end, the new tokens below
+          // the wave's first row -- takes no mask: 2 of its ~10 VALU per score; wave-uniform branch)
+          if (!half_full) {
+            int lnm = lane;
+            asm volatile("" : "+v"(lnm));
+            const int32_t tk1 = row_tok(rbase + 16 * c + (lnm & 15)) + 1;
+            const int32_t vis = (prefix ? p_len : min(n_end_w, a.causal ? tk1 : E)) - n0 - 4 * (lnm >> 4);  // visible: index < vis
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-              for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i >= wlo) ? sv[bb * 4 + i] : -INFINITY;
-          }
-        }
-        float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-        mt = quad_row_max(mt) * c2;
-        const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
-        const float m_new = (mt_fixed > m_run[c] + kYSlack) ? mt_fixed : m_run[c];
-        const float alpha = fast_exp2(m_run[c] - m_new);
-        m_run[c] = m_new;
-        float psum = 0.f;
+              for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i < vis) ? sv[bb * 4 + i] : -INFINITY;
+            if (windowed) {  // ... and index >= the row's window bound (wave-uniform branch)
+              const int32_t wlo = (prefix ? P : 0) + tk1 - 1 - a.window - n0 - 4 * (lnm >> 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
-          psum += sv[j];
+              for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i >= wlo) ? sv[bb * 4 + i] : -INFINITY;
+            }
+          }
+        };
+        load_sv();
+        // Softmax WITHOUT a row maximum on the common path (round 4, as rx_extend32_kernel.inc): the scores are
+        // exponentiated against the STANDING running max, and the lane's partial row sum is the check -- every p is <= it,
+        // so while it stays <= kYSumLimit nothing overflowed or lost precision against the running scale.  Only when a
+        // lane's sum runs away (or is NaN: the first tile's m = -inf) the wave takes the max-based step and redoes the
+        // block.  Saves the 7-max chain, the cross-lane quad max, the select and the alpha exponential per 8 scores.
+        float alpha = 1.0f, psum = 0.f;
+        {
+          const float m_old = m_run[c];
+          float e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            e[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_old));
+            psum += e[j];
+          }
+          // (compared as BITS: the sum is never negative, so the unsigned order is the float order with +inf and every
+          // NaN on top -- the file is built with -fno-honor-nans, under which !(x <= limit) need not catch a NaN, and a
+          // masked score against m = -inf is exactly that)
+          if (__builtin_amdgcn_ballot_w64(__builtin_bit_cast(uint32_t, psum) > __builtin_bit_cast(uint32_t, kYSumLimit)) != 0) {
+            load_sv();
+            float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+            mt = quad_row_max(mt) * c2;
+            const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
+            const float m_new = (mt_fixed > m_old + kYSlack) ? mt_fixed : m_old;
+            alpha = fast_exp2(m_old - m_new);
+            m_run[c] = m_new;
+            psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+              psum += sv[j];
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sv[j] = e[j];
+          }
         }
         l_run[c] = l_run[c] * alpha + psum;
         if (EXTRAS && prefix && a.v_scale != 1.0f) {  // (a scaled V pool takes the EXTRAS instance)
