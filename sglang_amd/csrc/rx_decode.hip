@@ -769,12 +769,64 @@ __global__ __launch_bounds__(128) void decode_merge_scalar_kernel(const DecodeAr
   }
 }
 
+// Eight split slots, no extra partials (the MLA config-5 launch: 17 MB of partials, 6 us): everything the thread needs --
+// the request's length and split count, its 8 LSEs (two 16-byte loads) and its 8 partial rows -- is loaded AT ONCE, dead
+// slots included (selected away, never multiplied: their memory is allocated but undefined), so the kernel is one round
+// trip plus the store instead of four dependent ones (length -> LSEs -> rows in batches of four -> store).
+template <typename T>
+__global__ __launch_bounds__(256) void decode_merge8_kernel(const DecodeArgs a, int dv) {
+  const int dv4 = dv >> 2;
+  const int64_t gid = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t bh = gid / dv4;
+  if (bh >= static_cast<int64_t>(a.bs) * a.hq) return;
+  const int d = static_cast<int>(gid % dv4) * 4;
+  const int h = static_cast<int>(bh % a.hq);
+  const int b = static_cast<int>(bh / a.hq);
+  const int64_t row0 = bh * 8;
+  const f32x4 l0 = *reinterpret_cast<const f32x4*>(a.attn_lse + row0), l1 = *reinterpret_cast<const f32x4*>(a.attn_lse + row0 + 4);
+  const float* lp = a.attn_logits + row0 * dv + d;
+  f32x4 tv[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) tv[s] = *reinterpret_cast<const f32x4*>(lp + static_cast<int64_t>(s) * dv);
+  int32_t kv_begin;
+  const int32_t seq_len = attended_len(a, b, kv_begin);
+  const int32_t splits = a.num_kv_splits ? a.num_kv_splits[b] : 1;
+  if (a.direct_single && splits == 1) return;  // stage 1 wrote this request's final output
+  const int32_t per = ((seq_len + splits - 1) / splits + kMinBlockKV - 1) / kMinBlockKV * kMinBlockKV;
+  int32_t live = per > 0 ? (seq_len + per - 1) / per : 0;
+  live = min(live, min(splits, 8));
+  const float lse[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+  float e_max = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) e_max = s < live ? fmaxf(e_max, lse[s]) : e_max;
+  float e_sum = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float w = s < live ? __expf(lse[s] - e_max) : 0.f;
+    const f32x4 row = s < live ? tv[s] : f32x4{0.f, 0.f, 0.f, 0.f};
+    acc += w * row;
+    e_sum += w;
+  }
+  if (a.sinks) e_sum += __expf(a.sinks[h] - e_max);
+  const float inv = a.v_scale / e_sum;
+  u32x2 pk;
+  pk[0] = pack2<T>(acc[0] * inv, acc[1] * inv);
+  pk[1] = pack2<T>(acc[2] * inv, acc[3] * inv);
+  *reinterpret_cast<u32x2*>(a.o + b * a.o_stride_t + h * a.o_stride_h + d) = pk;
+}
+
 template <typename T>
 static void launch_merge(const DecodeArgs& a, int dv, hipStream_t s) {
   const bool vec = dv % 4 == 0 && ((a.o_stride_t | a.o_stride_h) & 3) == 0 &&
                    (reinterpret_cast<uintptr_t>(a.o) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.extra_o) & 7) == 0;
   if (vec) {
     const unsigned grid = static_cast<unsigned>((static_cast<int64_t>(a.bs) * a.hq * (dv >> 2) + 255) / 256);
+    if (a.max_kv_splits == 8 && a.num_extra == 0 && (reinterpret_cast<uintptr_t>(a.attn_lse) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(a.attn_logits) & 15) == 0) {
+      hipLaunchKernelGGL((decode_merge8_kernel<T>), dim3(grid), dim3(256), 0, s, a, dv);
+      return;
+    }
     hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(grid), dim3(256), 0, s, a, dv);
   } else {
     hipLaunchKernelGGL((decode_merge_scalar_kernel<T>), dim3(a.bs * a.hq), dim3(128), 0, s, a, dv);

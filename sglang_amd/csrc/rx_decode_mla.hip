@@ -69,6 +69,7 @@ struct MlaArgs {
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 constexpr int kMlaDk = 576, kMlaDv = 512;
 constexpr int kMlaTile = 32;
+constexpr float kMlaSumLimit = 4096.0f;  // a lane's partial row sum above this sends the wave to the max-based softmax step
 
 // stage 2 inside the kernel: called by every thread of a workgroup that wrote a partial of (request b, q block qb)
 template <typename T>
@@ -439,7 +440,6 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
     // ---- online softmax (identical in all four waves) -----------------------------------------------
     float sv[8];
     const int tok_base = lo + t * kMlaTile + 4 * g;
-    float mt = -INFINITY;
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
@@ -453,21 +453,37 @@ __global__ __launch_bounds__(256, MlaBuf<KV8>::WGS) void decode_mla_kernel(const
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float x = (tok_base + 16 * bb + i < hi) ? sv[bb * 4 + i] : -INFINITY;
-        sv[bb * 4 + i] = x;
-        mt = fmaxf(mt, x);
-      }
-    mt = quad_row_max(mt);
-    mt *= c2;
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = fast_exp2(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+      for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (tok_base + 16 * bb + i < hi) ? sv[bb * 4 + i] : -INFINITY;
+    // No row maximum on the common path (round 4; rx_extend32_kernel.inc): the scores are exponentiated against the
+    // STANDING running max and the lane's partial row sum is the check (every p <= it); the max tree, the cross-lane
+    // quad max and the alpha exponential -- all on the tile's dependency chain between the score exchange and the PV
+    // MFMAs -- run only when a lane's sum exceeds kMlaSumLimit (or is inf / NaN: the split's first tile, m = -inf).
+    // Compared as bits: sums are never negative, so the unsigned order is the float order with inf and NaN on top.
+    float alpha = 1.0f, psum = 0.f;
+    {
+      const float m_old = m_run;
+      float e[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
-      psum += sv[j];
+      for (int j = 0; j < 8; ++j) {
+        e[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_old));
+        psum += e[j];
+      }
+      if (__builtin_amdgcn_ballot_w64(__builtin_bit_cast(uint32_t, psum) > __builtin_bit_cast(uint32_t, kMlaSumLimit)) != 0) {
+        float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+        mt = quad_row_max(mt) * c2;
+        const float m_new = fmaxf(m_old, mt);
+        alpha = fast_exp2(m_old - m_new);
+        m_run = m_new;
+        psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+          psum += sv[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[j] = e[j];
+      }
     }
     l_run = l_run * alpha + psum;
     u32x4 praw;
@@ -792,16 +808,32 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
 #pragma unroll
       for (int j = 0; j < 8; ++j) sv[j] = (tok_base + j < hi) ? sv[j] : -INFINITY;
     }
-    float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-    mt = quad_row_max(mt) * c2;
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = fast_exp2(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+    // (no row maximum on the common path: the sum check of the first form above)
+    float alpha = 1.0f, psum = 0.f;
+    {
+      const float m_old = m_run;
+      float e[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
-      psum += sv[j];
+      for (int j = 0; j < 8; ++j) {
+        e[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_old));
+        psum += e[j];
+      }
+      if (__builtin_amdgcn_ballot_w64(__builtin_bit_cast(uint32_t, psum) > __builtin_bit_cast(uint32_t, kMlaSumLimit)) != 0) {
+        float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+        mt = quad_row_max(mt) * c2;
+        const float m_new = fmaxf(m_old, mt);
+        alpha = fast_exp2(m_old - m_new);
+        m_run = m_new;
+        psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+          psum += sv[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sv[j] = e[j];
+      }
     }
     l_run = l_run * alpha + psum;
     u32x4 praw;

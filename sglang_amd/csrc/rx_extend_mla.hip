@@ -46,6 +46,7 @@ constexpr int kXPieces = (kXTT * kXCpr + 63) / 64;  // 37 1-KiB DMA pieces per i
 constexpr int kXImg = kXPieces * 1024;
 constexpr int kXRows = 128;                     // query rows per workgroup
 constexpr float kXSlack = 8.0f;                 // log2 units a row's max may run ahead of its reference
+constexpr float kXSumLimit = 4096.0f;           // a lane's partial row sum above this sends the wave to the max-based step
 
 struct ExtMlaArgs {
   const uint16_t* q;
@@ -348,32 +349,54 @@ __global__ __launch_bounds__(512, 1) void extend_mla_kernel(const ExtMlaArgs a) 
     u32x4 pf;
     {
       float sv[8];
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[bb][i];
-      // (a tile every row of the wave sees in full takes no mask -- wave-uniform branch; rx_extend_d256.hip)
-      if (n0 + kXTT > (prefix ? p_len : min(n_end_w, a.causal ? tok_lo_w + 1 : E))) {
-        int lnm = lane;
-        asm volatile("" : "+v"(lnm));
-        const int32_t tk1 = row_tok(rbase + (lnm & 15)) + 1;
-        const int32_t vis = (prefix ? p_len : min(n_end_w, a.causal ? tk1 : E)) - n0 - 4 * (lnm >> 4);
+      auto load_sv = [&]() {  // the tile's 8 scores per lane as the softmax takes them (masked)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i < vis) ? sv[bb * 4 + i] : -INFINITY;
-      }
-      float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-      mt = quad_row_max(mt) * c2;
-      const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
-      const float m_new = (mt_fixed > m_run + kXSlack) ? mt_fixed : m_run;
-      const float alpha = fast_exp2(m_run - m_new);
-      m_run = m_new;
-      float psum = 0.f;
+          for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[bb][i];
+        // (a tile every row of the wave sees in full takes no mask -- wave-uniform branch; rx_extend_d256.hip)
+        if (n0 + kXTT > (prefix ? p_len : min(n_end_w, a.causal ? tok_lo_w + 1 : E))) {
+          int lnm = lane;
+          asm volatile("" : "+v"(lnm));
+          const int32_t tk1 = row_tok(rbase + (lnm & 15)) + 1;
+          const int32_t vis = (prefix ? p_len : min(n_end_w, a.causal ? tk1 : E)) - n0 - 4 * (lnm >> 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
-        psum += sv[j];
+          for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = (16 * bb + i < vis) ? sv[bb * 4 + i] : -INFINITY;
+        }
+      };
+      load_sv();
+      // no row maximum on the common path (round 4, rx_extend_d256.hip / rx_extend32_kernel.inc): exponentials against
+      // the standing running max, the lane's partial row sum as the check (compared as bits: NaN-proof under
+      // -fno-honor-nans); the max-based step only when a lane's sum runs away
+      float alpha = 1.0f, psum = 0.f;
+      {
+        const float m_old = m_run;
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          e[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_old));
+          psum += e[j];
+        }
+        if (__builtin_amdgcn_ballot_w64(__builtin_bit_cast(uint32_t, psum) > __builtin_bit_cast(uint32_t, kXSumLimit)) != 0) {
+          load_sv();
+          float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+          mt = quad_row_max(mt) * c2;
+          const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
+          const float m_new = (mt_fixed > m_old + kXSlack) ? mt_fixed : m_old;
+          alpha = fast_exp2(m_old - m_new);
+          m_run = m_new;
+          psum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+            psum += sv[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sv[j] = e[j];
+        }
       }
       l_run = l_run * alpha + psum;
       if (prefix && a.v_scale != 1.0f) {
