@@ -82,6 +82,7 @@ constexpr int kTT = RX_EXT_TT;  // tokens per LDS tile
 #define RX_EXT_MAX_SLACK 8.0f  // log2 units (0: the plain running max)
 #endif
 constexpr float kExtMaxSlack = RX_EXT_MAX_SLACK;
+constexpr float kExtSumLimit = 4096.0f;  // a lane's partial row sum above this sends the wave to the max-based step
 
 #ifndef RX_EXT_CB
 #define RX_EXT_CB 2  // 16-query N blocks per wave (2 -> 32 queries / wave, 128 / workgroup)
@@ -303,48 +304,70 @@ __global__ __launch_bounds__(256, RX_EXT_MINW) void extend_mfma_kernel(const Ext
         for (int c = 0; c < kCB; ++c) {
           const int m = qbase + 16 * c + r;
           float sv[8];
-#pragma unroll
-          for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
-          if (capped) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * cs / a.logit_cap);
-          }
-          if (!full) {
+          auto load_sv = [&]() {  // the block's 8 scores per lane as the softmax takes them: capped, masked
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const int n = n0 + 16 * bb + 4 * g + i;
-                bool keep;
-                if (prefix) {
-                  keep = n < p_len;
-                  if (a.window > 0) keep = keep && (P + m <= n + a.window);
-                } else {
-                  keep = n < n_end_w && (!a.causal || n <= m);
-                  if (a.window > 0) keep = keep && (m <= n + a.window);
-                }
-                sv[bb * 4 + i] = keep ? sv[bb * 4 + i] : -INFINITY;
-              }
-          }
-          float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])),
-                           fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-          mt = quad_row_max(mt);
-          mt *= c2;  // c2 > 0: max commutes with the scale
-          // fully masked row so far: keep the max finite (extend_attention.py:474-475)
-          const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
-          // thresholded running max (rx_extend32.hip): the reference max moves only when the tile's exceeds it by more
-          // than 2^8 -- exact algebra (l uses the same m; exp2 reaches 2^8 at most, inside fp32 sums and 16-bit P) -- so
-          // the O^T rescale below runs on the first tile and almost never again instead of on ~70 % of the tiles
-          const float m_new = (mt_fixed > m_run[c] + kExtMaxSlack) ? mt_fixed : m_run[c];
-          const float alpha = fast_exp2(m_run[c] - m_new);
-          m_run[c] = m_new;
-          float psum = 0.f;
+              for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
+            if (capped) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
-            psum += sv[j];
+              for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * cs / a.logit_cap);
+            }
+            if (!full) {
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const int n = n0 + 16 * bb + 4 * g + i;
+                  bool keep;
+                  if (prefix) {
+                    keep = n < p_len;
+                    if (a.window > 0) keep = keep && (P + m <= n + a.window);
+                  } else {
+                    keep = n < n_end_w && (!a.causal || n <= m);
+                    if (a.window > 0) keep = keep && (m <= n + a.window);
+                  }
+                  sv[bb * 4 + i] = keep ? sv[bb * 4 + i] : -INFINITY;
+                }
+            }
+          };
+          load_sv();
+          // Round 4 (rx_extend32_kernel.inc / rx_extend_d256.hip): no row maximum on the common path.  The scores are
+          // exponentiated against the STANDING running max and the lane's partial row sum is the check (every p <= it;
+          // compared as bits -- sums are never negative, so the unsigned order is the float order with inf and NaN on
+          // top, and -fno-honor-nans cannot fold it away); only when a lane's sum runs away the wave takes the
+          // thresholded max step (exact algebra: l uses the same m) and redoes the block.  The step's rule as before: the
+          // reference max moves only when the tile's exceeds it by more than 2^8 (extend_attention.py:474-475 keeps a
+          // fully masked row's max finite).
+          float alpha = 1.0f, psum = 0.f;
+          {
+            const float m_old = m_run[c];
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              e[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_old));
+              psum += e[j];
+            }
+            if (__builtin_amdgcn_ballot_w64(__builtin_bit_cast(uint32_t, psum) > __builtin_bit_cast(uint32_t, kExtSumLimit)) != 0) {
+              load_sv();
+              float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])),
+                               fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+              mt = quad_row_max(mt);
+              mt *= c2;  // c2 > 0: max commutes with the scale
+              const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;
+              const float m_new = (mt_fixed > m_old + kExtMaxSlack) ? mt_fixed : m_old;
+              alpha = fast_exp2(m_old - m_new);
+              m_run[c] = m_new;
+              psum = 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+                psum += sv[j];
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) sv[j] = e[j];
+            }
           }
           l_run[c] = l_run[c] * alpha + psum;
           if constexpr (VSCALE) {  // fp8-style per-tensor V scale: prefix (cached) part only

@@ -277,42 +277,64 @@ __global__ __launch_bounds__((NdGeom<DK, DV, BIG>::NT), (NdGeom<DK, DV, BIG>::MI
         for (int c = 0; c < CB; ++c) {
           const int m = qbase + 16 * c + r;
           float sv[8];
-#pragma unroll
-          for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
-          if (capped) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * cs / a.logit_cap);
-          }
-          if (!full) {
+          auto load_sv = [&]() {  // the block's 8 scores per lane as the softmax takes them: capped, masked
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const int n = n0 + 16 * bb + 4 * g + i;
-                bool keep;
-                if (prefix) {
-                  keep = n < p_len;
-                  if (a.window > 0) keep = keep && (P + m <= n + a.window);
-                } else {
-                  keep = n < n_end_w && (!a.causal || n <= m);
-                  if (a.window > 0) keep = keep && (m <= n + a.window);
-                }
-                sv[bb * 4 + i] = keep ? sv[bb * 4 + i] : -INFINITY;
-              }
-          }
-          float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-          mt = quad_row_max(mt) * c2;  // c2 > 0: max commutes with the scale
-          const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
-          const float m_new = fmaxf(m_run[c], mt_fixed);
-          const float alpha = fast_exp2(m_run[c] - m_new);
-          m_run[c] = m_new;
-          float psum = 0.f;
+              for (int i = 0; i < 4; ++i) sv[bb * 4 + i] = sacc[c][bb][i];
+            if (capped) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
-            psum += sv[j];
+              for (int j = 0; j < 8; ++j) sv[j] = a.logit_cap * tanhf(sv[j] * cs / a.logit_cap);
+            }
+            if (!full) {
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const int n = n0 + 16 * bb + 4 * g + i;
+                  bool keep;
+                  if (prefix) {
+                    keep = n < p_len;
+                    if (a.window > 0) keep = keep && (P + m <= n + a.window);
+                  } else {
+                    keep = n < n_end_w && (!a.causal || n <= m);
+                    if (a.window > 0) keep = keep && (m <= n + a.window);
+                  }
+                  sv[bb * 4 + i] = keep ? sv[bb * 4 + i] : -INFINITY;
+                }
+            }
+          };
+          load_sv();
+          // no row maximum on the common path (round 4; rx_extend.hip has the full comment): exponentials against the
+          // standing running max, the lane's partial row sum as the check (compared as bits: NaN-proof under
+          // -fno-honor-nans); the max step only when a lane's sum runs away
+          float alpha = 1.0f, psum = 0.f;
+          {
+            const float m_old = m_run[c];
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              e[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_old));
+              psum += e[j];
+            }
+            if (__builtin_amdgcn_ballot_w64(__builtin_bit_cast(uint32_t, psum) > __builtin_bit_cast(uint32_t, 4096.0f)) != 0) {
+              load_sv();
+              float mt = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+              mt = quad_row_max(mt) * c2;  // c2 > 0: max commutes with the scale
+              const float mt_fixed = (mt == -INFINITY) ? -1e20f : mt;  // extend_attention.py:474-475
+              const float m_new = fmaxf(m_old, mt_fixed);
+              alpha = fast_exp2(m_old - m_new);
+              m_run[c] = m_new;
+              psum = 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                sv[j] = fast_exp2(__builtin_fmaf(sv[j], c2, -m_new));
+                psum += sv[j];
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) sv[j] = e[j];
+            }
           }
           l_run[c] = l_run[c] * alpha + psum;
           if (prefix && a.v_scale != 1.0f) {  // per-tensor V scale of the cached part (wave-uniform branch)
