@@ -30,6 +30,7 @@ struct Options {
   int ext32_plain = 1;        // PLAIN instances (features compile-time off) when the call uses none of them
   int extend_16x16_d128 = 0;  // the 16x16x32 kernel of rx_extend.hip for plain D = 128 calls (A/B of the two shapes)
   int extend_d256 = 1;        // the AGPR / LDS-DMA template (256, 192, 96, 64) where it supports the call
+  int extend_d256_min_rows = 1;    // ... for short extends (<= 128 rows of the longest request) from this many rows up, given >= 4 estimated tiles
   int extend_d256_at128 = 0;  // ... instantiated at 128 / 128 (A/B against rx_extend32)
   int extend_d256_at64 = 1;   // ... at 64 / 64 (0: extend_mfma_kernel)
   int extend_d256_at96 = 1;   // ... at 96 / 96 (0: extend_nd_kernel)

@@ -607,7 +607,15 @@ bool extend_d256_supports(const rx_extend_params* p) {
   if (!linear && (p->kv.page_size & (p->kv.page_size - 1)) != 0) return false;
   const int64_t group = p->num_q_heads / p->num_kv_heads;
   if (static_cast<int64_t>(p->max_extend_len + 1) * group * group >= (1ll << 31)) return false;  // row -> token by multiply-high
-  return static_cast<int64_t>(p->max_extend_len) * group > 128;  // more than half a workgroup's rows
+  // Rows of the longest request.  Until round 4 only calls with more than half a workgroup's rows (128) came here and
+  // short extends ran one workgroup per (request, q head) on rx_extend_nd.hip / rx_extend.hip; with the rows of a kv
+  // head's group packed into one block the template wins from a few rows up wherever there is a prefix to walk
+  // (tools/probe/short_ext.py, 64 requests, TFLOP/s before / after: D 256, 1 k + 32 tokens 227 / 652; 2 k + 16: 126 / 410;
+  // 4 k + 8: 64 / 230; D 64, 2 k + 32: 214 / 541; 192 / 128, 2 k + 16: 86 / 317; D 96, 2 k + 8: 36 / 220) and loses only
+  // where a workgroup walks next to nothing (no prefix + 32 tokens: 42 / 35) -- hence the tile estimate below.
+  const int64_t rows = static_cast<int64_t>(p->max_extend_len) * group;
+  if (rows > 128) return true;
+  return rows >= opt.extend_d256_min_rows && (p->avg_kv_len_hint + p->max_extend_len / 2) / 64 >= 4;
 }
 
 int launch_extend_d256(const rx_extend_params* p, hipStream_t s) {

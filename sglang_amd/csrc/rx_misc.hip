@@ -36,7 +36,8 @@ static const OptionEntry kOptionTable[] = {
     {"ext32_small_wg_tiles", &Options::ext32_small_wg_tiles}, {"ext32_pack_min_len", &Options::ext32_pack_min_len},
     {"ext32_pack_min_tiles", &Options::ext32_pack_min_tiles}, {"ext32_pack_min_wgs", &Options::ext32_pack_min_wgs},
     {"ext32_plain", &Options::ext32_plain},               {"extend_16x16_d128", &Options::extend_16x16_d128},
-    {"extend_d256", &Options::extend_d256},               {"extend_d256_at128", &Options::extend_d256_at128},
+    {"extend_d256", &Options::extend_d256},               {"extend_d256_min_rows", &Options::extend_d256_min_rows},
+                   {"extend_d256_at128", &Options::extend_d256_at128},
     {"extend_d256_at64", &Options::extend_d256_at64},     {"extend_d256_at96", &Options::extend_d256_at96},
     {"extend_nd", &Options::extend_nd},                   {"extend_nd_big", &Options::extend_nd_big},
     {"extend_mla", &Options::extend_mla},                 {"extend_mla_shared_v", &Options::extend_mla_shared_v},

@@ -126,3 +126,58 @@ def test_self_packing_gates_tile_estimate_and_chip_coverage():
     assert name.endswith("4, false, true, 0>"), name          # one estimated tile: next to nothing to do, unpacked
     _, name = run(big - 8, 512, 64, ext32_pack_min_wgs=0)
     assert name.endswith("8, false, true, 4>"), name          # the gate is an option
+
+
+@pytest.mark.parametrize("dims", [(256, 256), (64, 64), (192, 128), (96, 96)], ids=["d256", "d64", "d192_128", "d96"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_short_extends_over_a_prefix_take_the_packed_template(dims, dtype):
+    """Round 4: a short extend (a few new tokens per request -- draft / verify-sized, chunk tails, follow-up turns) at the
+    AGPR template's head dims runs that template with the kv head's group packed into one row block, from four estimated
+    tiles up (rx_extend_d256.hip: extend_d256_supports; 2.5-6x the per-head launch, tools/probe/short_ext.py); with
+    next to no prefix, or with option extend_d256_min_rows above its rows, the call takes the short-extend kernel as
+    before.  Both against the oracle at the bar."""
+    from sglang_amd import lib as rxlib
+    from sglang_amd import ops
+
+    dk, dv = dims
+    hq, hkv = 8, 2
+    prefix, extend = [700, 333, 1025], [8, 1, 17]
+    g = torch.Generator().manual_seed(dk + dv)
+    pool = sum(prefix) + 1
+    kb = torch.randn(pool, hkv, dk, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, dv, generator=g).to(dtype)
+    T = sum(extend)
+    q = torch.randn(T, hq, dk, generator=g).to(dtype)
+    ke = torch.randn(T, hkv, dk, generator=g).to(dtype)
+    ve = torch.randn(T, hkv, dv, generator=g).to(dtype)
+    qo = np.concatenate([[0], np.cumsum(extend)]).astype(np.int64)
+    kvp = np.concatenate([[0], np.cumsum(prefix)]).astype(np.int32)
+    kvi = (torch.randperm(pool - 1, generator=g) + 1).numpy().astype(np.int64)
+    sm = dk ** -0.5
+    want = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kvp, kvi, sm_scale=sm)
+    absw = None
+    if dtype == torch.bfloat16:
+        absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve)), _bits(kb), parity.abs_values(_bits(vb)),
+                                    qo, kvp, kvi, sm_scale=sm)
+
+    def run(**opts):
+        ctx = [rxlib.option(k, v) for k, v in opts.items()]
+        for c in ctx:
+            c.__enter__()
+        try:
+            o = torch.full((T, hq, dv), float("nan"), dtype=dtype, device=DEV)
+            ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), torch.from_numpy(qo).to(DEV),
+                                     torch.from_numpy(kvp).to(DEV), torch.from_numpy(kvi).to(DEV), None, True, None,
+                                     max(extend), 1.0, 1.0, sm_scale=sm, page_size=1)
+            torch.cuda.synchronize()
+            return o.float().cpu().numpy(), rxlib.last_dispatch()
+        finally:
+            for c in reversed(ctx):
+                c.__exit__()
+
+    got, name = run()
+    assert name.startswith("extend_d256_kernel<") and name.endswith("g4"), name      # 17 tokens x 4 heads = 68 rows: packed
+    parity.check_out(got, want, dtype, ("short extend, packed template", dims), ulps=1, absw=absw)
+    got, name = run(extend_d256_min_rows=129)
+    assert not name.startswith("extend_d256_kernel<"), name                           # the per-head short-extend kernel
+    parity.check_out(got, want, dtype, ("short extend, per-head kernel", dims), ulps=1, absw=absw)
