@@ -503,7 +503,11 @@ class HipRadixAttnBackend:
         # within 2 % on the batches of tools/probe/rounds_rule.py.
         use_items = not self._is_mla_pool and not self._no_split_items
         three = use_items and self._split_occ3 and not use_graph_bufs and fb.seq_lens_cpu is not None
-        wg_mixed = self.device_core_count * 3 if three else (-1 if use_items else 0)
+        # (an MLA pool: no live-pairs grid and no mixed-batch rule -- wg_target_mixed = wg_target switches those off and
+        # selects the fill rule's whole-requests form: from 0.8 requests per CU up nobody is cut.  256 requests x 4 k latent
+        # rows one pass each 122 us, cut in two 135 (fp8 rows; 16-bit 216 vs 235); 224 x 4 k 113 vs 127 cut in three;
+        # tools/probe/mla_split_sweep.py)
+        wg_mixed = self.device_core_count * 3 if three else (-1 if use_items else wg_target)
         host_pairs = None
         if not use_graph_bufs and fb.seq_lens_cpu is not None:
             host_counts = ops.balanced_kv_splits_host(fb.seq_lens_cpu.numpy()[:bs], self.num_head, self.num_kv_head, cap,

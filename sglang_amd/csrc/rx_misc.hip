@@ -898,7 +898,16 @@ __global__ __launch_bounds__(1024) void num_kv_splits_balanced_kernel(const void
     // rounds of CUs.  tools/decode_sweep.py has the sweep.
     const unsigned long long mx = block_max(amax), live = block_sum(alive);
     const long long cus = max(1, wg_target / 2), blocks = static_cast<long long>(live) * wg_per_request;
-    if (live > 0 && 2 * mx * live <= 3 * total && 10 * blocks >= 7 * cus && blocks < 3 * cus) {
+    // (0 < wg_mixed <= wg_target: a kernel without the live-pairs grid whose workgroups are latency-bound one by one --
+    // the MLA kernels: several of them on a CU do not slow each other, so from 0.8 blocks per CU up the launch is bound
+    // by HBM as a whole and nobody is cut, whatever the count: 384 x 4 k fp8 rows 184 us whole, 197 cut in two)
+    const bool whole_only = wg_mixed > 0 && wg_mixed <= wg_target;
+    if (whole_only) {
+      if (live > 0 && 2 * mx * live <= 3 * total && 10 * blocks >= 8 * cus) {
+        for (int i = tid; i < bs; i += 1024) out[i] = 1;
+        return;
+      }
+    } else if (live > 0 && 2 * mx * live <= 3 * total && 10 * blocks >= 7 * cus && blocks < 3 * cus) {
       long long S = 1;
       if (blocks > cus) {
         long long best = 1, bn = 0, bd = 1;  // best fill so far as the fraction bn / bd

@@ -229,7 +229,10 @@ def balanced_kv_splits_host(lens, num_head: int, num_kv_head: int, max_kv_splits
     if wg_target_mixed != 0:  # the fill rule (rx_misc.hip: near-uniform batches of ~1-3 whole-request workgroups per CU)
         live, total, mx = int((lens > 0).sum()), int(lens.sum()), int(lens.max()) if lens.size else 0
         cus, blocks = max(1, wg_target // 2), live * wgpr
-        if live > 0 and 2 * mx * live <= 3 * total and 10 * blocks >= 7 * cus and blocks < 3 * cus:
+        if 0 < wg_target_mixed <= wg_target:  # no live-pairs grid (MLA kernels): whole requests from 0.8 blocks per CU up
+            if live > 0 and 2 * mx * live <= 3 * total and 10 * blocks >= 8 * cus:
+                return np.ones(lens.shape, dtype=np.int32)
+        elif live > 0 and 2 * mx * live <= 3 * total and 10 * blocks >= 7 * cus and blocks < 3 * cus:
             S = 1
             if blocks > cus:
                 S, best, bn, bd = 0, 1, 0, 1

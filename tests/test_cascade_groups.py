@@ -253,6 +253,13 @@ def test_fill_rule_of_the_balanced_schedule_host_mirror():
     ragged = np.random.default_rng(3).integers(3000, 4097, size=320)
     assert (tp8(ragged) == 3).all()                                                      # 2 max <= 3 mean: still one count
     assert (ops.balanced_kv_splits_host([4096] * 40, 32, 8, 32, 512, 1024, -1) == 3).all()  # 320 blocks at Hkv = 8 as well
+    # the whole-requests form (0 < wg_target_mixed <= wg_target: kernels without the live-pairs grid, the MLA pools): from
+    # 0.8 requests per CU up nobody is cut, whatever the count (tools/probe/mla_split_sweep.py: 224 / 256 / 320 / 384
+    # requests all fastest whole); below it the even share as before
+    mla = lambda lens: ops.balanced_kv_splits_host(lens, 16, 1, 32, 512, 128, 512)  # noqa: E731
+    for bs, want in ((64, 8), (128, 4), (192, 3), (224, 1), (256, 1), (320, 1), (384, 1), (1024, 1)):
+        assert (mla([8192 if bs <= 192 else 4096] * bs) == want).all(), bs
+    assert mla([32768] + [1024] * 255)[0] > 1                                           # not near-uniform: the long one is cut
 
 
 def test_planner_caps_the_shared_length_below_every_member_and_survives_deep_chains():

@@ -637,7 +637,7 @@ def test_balanced_split_schedule_kernel_matches_its_host_mirror_and_heterogeneou
                           [rng.integers(2048, 4097, size=320).tolist(), 4, 1], [rng.integers(1000, 4097, size=320).tolist(), 4, 1]):
         lt = torch.tensor(lens, dtype=torch.int64, device=DEV)
         for mt in (128, 1024):
-            for mixed in (0, 768, 2048, -1):  # the mixed-batch budget (wg_target_mixed), its overshoot step; -1: the rounds rule
+            for mixed in (0, 512, 768, 2048, -1):  # the mixed-batch budget (wg_target_mixed), its overshoot step; -1: the rounds rule; 512 = wg_target: the whole-requests fill form (MLA)
                 out = torch.zeros(len(lens), dtype=torch.int32, device=DEV)
                 ops.get_num_kv_splits_balanced(out, lt, hq, hkv, 32, 512, mt, mixed)
                 want = ops.balanced_kv_splits_host(lens, hq, hkv, 32, 512, mt, mixed)
