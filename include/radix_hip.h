@@ -132,7 +132,10 @@ int rx_num_kv_splits_native(const void* seq_lens, int seq_lens_is_i64, int bs, i
  * S = 1 when blocks <= CUs (the launch is bound by HBM as a whole: a split only adds its merge), otherwise the smallest
  * S <= min(max_kv_splits, 6) with blocks * S >= 0.85 * ceil(blocks * S / CUs) * CUs (the pieces fill whole rounds of
  * CUs: the launch lasts as long as the CU with the most bytes), or the best-filling S if none reaches 0.85 -- and
- * out[b] = max(1, min(S, len_b / 256)).  With 0 < wg_target_mixed <= wg_target (kernels without the live-pairs grid whose
+ * out[b] = max(1, min(S, len_b / 256)).  Below 0.7 CUs blocks of a near-uniform batch, where everybody is cut: if the even
+ * share's count n = ceil(mean(len) / t*) gives workgroups that fill < 85 % of whole rounds of CUs (or fewer than 1.5 per
+ * CU), the nearest count (n - 1, n + 1, n - 2, ...; >= 2, pieces >= min_tokens_per_split) that fills replaces it for
+ * everybody; otherwise the even share stands.  With 0 < wg_target_mixed <= wg_target (kernels without the live-pairs grid whose
  * workgroups are latency-bound one by one: the MLA kernels) the fill rule is instead: near-uniform and blocks >= 0.8 CUs
  * -> every count is 1. */
 int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int wg_target,

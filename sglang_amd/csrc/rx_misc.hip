@@ -907,7 +907,35 @@ __global__ __launch_bounds__(1024) void num_kv_splits_balanced_kernel(const void
         for (int i = tid; i < bs; i += 1024) out[i] = 1;
         return;
       }
-    } else if (live > 0 && 2 * mx * live <= 3 * total && 10 * blocks >= 7 * cus && blocks < 3 * cus) {
+    } else if (live > 0 && 2 * mx * live <= 3 * total && 10 * blocks < 7 * cus) {
+      // Fewer than 0.7 blocks per CU: everybody is cut, and the count decides how evenly the pieces cover the chip.  The
+      // even share's n = ceil(mean / t*) lands anywhere: 176 requests -> 3 pieces = 528 workgroups, 2.06 per CU: 92 us
+      // (4 -> 704 = 2.75 per CU: 77 us); 104 blocks of 8 k tokens 5 -> 108 us (7 -> 92).  When n's workgroups fill < 85 %
+      // of whole rounds of CUs, the nearest count (smaller first) that does, with >= 1.5 workgroups per CU in total and
+      // pieces of at least min_tokens, replaces it; if there is none, or n fills well, the even share below stands.
+      const long long mean = static_cast<long long>(total / live);
+      const long long ts = max<long long>(min_tokens, static_cast<long long>((work + wg_target - 1) / wg_target));
+      const long long n0 = max<long long>(1, min<long long>(cap, (mean + ts - 1) / ts));
+      const long long smax = min<long long>(cap, max<long long>(1, mean / min_tokens));
+      auto fills = [&](long long sp) {
+        const long long w = blocks * sp, rounds = (w + cus - 1) / cus;
+        return 2 * w >= 3 * cus && 100 * w >= 85 * rounds * cus;
+      };
+      long long S = 0;
+      if (!fills(n0)) {
+        for (long long dlt = 1; dlt <= 8 && S == 0; ++dlt) {
+          if (n0 - dlt >= 2 && fills(n0 - dlt)) S = n0 - dlt;
+          else if (n0 + dlt <= smax && fills(n0 + dlt)) S = n0 + dlt;
+        }
+      }
+      if (S > 0) {
+        for (int i = tid; i < bs; i += 1024) {
+          const int64_t len = max<int64_t>(load_idx(seq_lens, i, is64), 0);
+          out[i] = static_cast<int32_t>(max<int64_t>(1, min<int64_t>(S, len / min_tokens)));
+        }
+        return;
+      }
+    } else if (live > 0 && 2 * mx * live <= 3 * total && blocks < 3 * cus) {
       long long S = 1;
       if (blocks > cus) {
         long long best = 1, bn = 0, bd = 1;  // best fill so far as the fraction bn / bd

@@ -232,7 +232,29 @@ def balanced_kv_splits_host(lens, num_head: int, num_kv_head: int, max_kv_splits
         if 0 < wg_target_mixed <= wg_target:  # no live-pairs grid (MLA kernels): whole requests from 0.8 blocks per CU up
             if live > 0 and 2 * mx * live <= 3 * total and 10 * blocks >= 8 * cus:
                 return np.ones(lens.shape, dtype=np.int32)
-        elif live > 0 and 2 * mx * live <= 3 * total and 10 * blocks >= 7 * cus and blocks < 3 * cus:
+        elif live > 0 and 2 * mx * live <= 3 * total and 10 * blocks < 7 * cus:  # everybody is cut: a count that covers the chip evenly
+            mt = int(min_tokens_per_split)
+            mean = total // live
+            ts = max(mt, -(-work // wg_target))
+            n0 = max(1, min(int(max_kv_splits), -(-mean // ts)))
+            smax = min(int(max_kv_splits), max(1, mean // mt))
+
+            def fills(sp):
+                w = blocks * sp
+                return 2 * w >= 3 * cus and 100 * w >= 85 * -(-w // cus) * cus
+
+            S = 0
+            if not fills(n0):
+                for dlt in range(1, 9):
+                    if n0 - dlt >= 2 and fills(n0 - dlt):
+                        S = n0 - dlt
+                    elif n0 + dlt <= smax and fills(n0 + dlt):
+                        S = n0 + dlt
+                    if S:
+                        break
+            if S:
+                return np.maximum(1, np.minimum(S, lens // mt)).astype(np.int32)
+        elif live > 0 and 2 * mx * live <= 3 * total and blocks < 3 * cus:
             S = 1
             if blocks > cus:
                 S, best, bn, bd = 0, 1, 0, 1

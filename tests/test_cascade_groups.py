@@ -241,7 +241,7 @@ def test_fill_rule_of_the_balanced_schedule_host_mirror():
         got = tp8([4096] * bs)
         assert (got == want).all(), (bs, got[:4])
     assert (tp8([4096] * 256, 0) == 2).all() and (tp8([4096] * 256, 768) == 1).all()    # off without a live-pairs schedule
-    assert (tp8([4096] * 160) == tp8([4096] * 160, 0)).all()                             # below 0.7 per CU: the even share
+    assert (tp8([4096] * 128) == tp8([4096] * 128, 0)).all()                             # below 0.7 per CU: the even share where it fills (see below)
     assert (tp8([4096] * 1024) == 1).all()                                               # 4 per CU: nobody is cut
     assert tp8([4096] * 288, cap=2).max() == 2                                           # the cap holds (best fill under it)
     short = tp8([300] * 320)
@@ -253,6 +253,15 @@ def test_fill_rule_of_the_balanced_schedule_host_mirror():
     ragged = np.random.default_rng(3).integers(3000, 4097, size=320)
     assert (tp8(ragged) == 3).all()                                                      # 2 max <= 3 mean: still one count
     assert (ops.balanced_kv_splits_host([4096] * 40, 32, 8, 32, 512, 1024, -1) == 3).all()  # 320 blocks at Hkv = 8 as well
+    # below 0.7 per CU everybody is cut; the even share's count stands when its workgroups fill whole rounds of CUs
+    # (64 -> 8 = 512, 128 -> 4 = 512) and is replaced by the nearest count that does when they do not (tools/decode_sweep.py:
+    # 176 -> 3 = 528 workgroups 92 us, 4 = 704: 77; 104 x 8 k -> 5: 108 us, 7: 92; 160 -> 4: 71, 3: 67; 100 -> 6: 49, 5: 45)
+    low = lambda bs, ctx=4096, mixed=-1: ops.balanced_kv_splits_host([ctx] * bs, 4, 1, 32, 512, 128, mixed)  # noqa: E731
+    for bs, ctx, want, old in ((64, 4096, 8, 8), (128, 4096, 4, 4), (176, 4096, 4, 3), (104, 8192, 7, 5), (160, 4096, 3, 4),
+                               (100, 4096, 5, 6), (144, 4096, 5, 4), (72, 8192, 7, 8)):
+        assert (low(bs, ctx) == want).all() and (low(bs, ctx, 0) == old).all(), (bs, ctx)
+    assert (ops.balanced_kv_splits_host([4096] * 20, 32, 8, 32, 512, 1024, -1) == 3).all()   # 160 blocks at Hkv = 8, 1 k pieces
+    assert (ops.balanced_kv_splits_host([4096] * 18, 32, 8, 32, 512, 1024, -1) == 4).all()   # 144: no better count of >= 1 k pieces
     # the whole-requests form (0 < wg_target_mixed <= wg_target: kernels without the live-pairs grid, the MLA pools): from
     # 0.8 requests per CU up nobody is cut, whatever the count (tools/probe/mla_split_sweep.py: 224 / 256 / 320 / 384
     # requests all fastest whole); below it the even share as before

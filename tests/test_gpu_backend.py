@@ -634,7 +634,10 @@ def test_balanced_split_schedule_kernel_matches_its_host_mirror_and_heterogeneou
                           # the fill rule's range (0.7 - 3 whole-request workgroups per CU, near-uniform lengths)
                           [[4096] * 192, 4, 1], [[4096] * 288, 4, 1], [[4096] * 320, 4, 1], [[4096] * 384, 4, 1],
                           [[4096] * 640, 4, 1], [[4096] * 40, 32, 8], [[2048] * 80, 32, 8], [[300] * 300 + [0] * 20, 4, 1],
-                          [rng.integers(2048, 4097, size=320).tolist(), 4, 1], [rng.integers(1000, 4097, size=320).tolist(), 4, 1]):
+                          [rng.integers(2048, 4097, size=320).tolist(), 4, 1], [rng.integers(1000, 4097, size=320).tolist(), 4, 1],
+                          # ... and below 0.7 per CU, where the even share's count is replaced when it fills the chip badly
+                          [[4096] * 176, 4, 1], [[8192] * 104, 4, 1], [[4096] * 144, 4, 1], [[4096] * 20, 32, 8],
+                          [[8192] * 72, 4, 1], [rng.integers(3000, 4097, size=100).tolist(), 4, 1], [[300] * 100, 4, 1]):
         lt = torch.tensor(lens, dtype=torch.int64, device=DEV)
         for mt in (128, 1024):
             for mixed in (0, 512, 768, 2048, -1):  # the mixed-batch budget (wg_target_mixed), its overshoot step; -1: the rounds rule; 512 = wg_target: the whole-requests fill form (MLA)
