@@ -24,11 +24,12 @@
 extern "C" {
 #endif
 
-/* 10 (round 4): rx_decode_params.rope_* (fused RoPE of the latent decode).
+/* 11 (round 4): rx_qknorm_rope_store_kv (fused QK-norm + RoPE + store).
+ * 10 (round 4): rx_decode_params.rope_* (fused RoPE of the latent decode).
  * 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
  * 8 (round 3): rx_split_items; rx_decode_params.split_items / split_items_count / split_items_cap /
  * split_items_wgs_per_cu and extra_index / extra_rows; rx_num_kv_splits_balanced gained wg_target_mixed. */
-#define RX_ABI_VERSION 10
+#define RX_ABI_VERSION 11
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -431,6 +432,30 @@ int rx_rope_store_kv(void* q, void* k, const void* v, int64_t q_stride_t, int64_
                      int64_t cos_sin_stride, int is_neox, const rx_kv_layout* lay /* HOST, or NULL */,
                      const void* loc, int loc_is_i64, int64_t size_limit, int64_t skip_index, float k_scale,
                      float v_scale, int dtype, int32_t* err_flag, void* stream);
+
+/* ---- fused per-head RMSNorm of q and k + rotary embedding (+ KV store) (ABI v11) ---------------------
+ * fused_qk_norm_rope (kernels/ops/attention/fused_qknorm_rope.py:37-100, :127-186; kernel
+ * kernels/jit/csrc/elementwise/fused_qknorm_rope.cuh:78-246, frequencies :42-63; the reference's own check of it against
+ * RMSNorm + RotaryEmbedding: kernels/aot/tests/test_fused_qk_norm_rope.py:31-128): what a QK-norm model runs on its
+ * qkv projection in front of attention.  Per (token, head), IN PLACE on q [n, Hq, D] and k [n, Hkv, D] (views of one
+ * qkv tensor are fine: strides in elements; v is never written):
+ *   x <- x * rsqrt(mean(x^2) + eps) * w         w = q_weight / k_weight [D], the call's 16-bit dtype, fp32 math
+ *   RoPE on the first rotary_dim columns (neox: pairs (p, p + rot/2); else (2p, 2p + 1)), times attention_factor,
+ *   angle = position * freq_p with freq_p = base^(-2 p / rotary_dim) computed on the fly -- under YaRN (factor != 1)
+ *   blended with freq_p / factor by the ramp clamp((p - low) / (high - low), 0, 1) as the reference kernel does -- or,
+ *   when cos_sin_cache != NULL, read from the fp32 cache [max_pos, rotary_dim] = [cos | sin] (base / factor / low /
+ *   high then unused);  ONE rounding to the 16-bit dtype at the end.
+ * positions int32 (the reference's) or int64.  With lay != NULL the finished k rows and the v rows also go to the pool
+ * at loc in the same launch, exactly as rx_rope_store_kv does (16-bit pool or fp8 quant-on-write). */
+int rx_qknorm_rope_store_kv(void* q, void* k, const void* v, int64_t q_stride_t, int64_t q_stride_h,
+                            int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
+                            int64_t n, int num_q_heads, int num_kv_heads, int head_dim, int v_head_dim,
+                            int rotary_dim, const void* q_weight, const void* k_weight, float eps,
+                            const void* positions, int positions_is_i64, float base, float factor, float low,
+                            float high, float attention_factor, const float* cos_sin_cache /* or NULL */,
+                            int64_t cos_sin_stride, int is_neox, const rx_kv_layout* lay /* HOST, or NULL */,
+                            const void* loc, int loc_is_i64, int64_t size_limit, int64_t skip_index, float k_scale,
+                            float v_scale, int dtype, int32_t* err_flag, void* stream);
 
 /* ---- merge of two partial attention states ----------------------------------------------------
  * merge_state_triton (kernels/ops/attention/merge_state.py:8-96; CUDA twin

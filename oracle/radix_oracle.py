@@ -731,6 +731,54 @@ def rope(x, positions, cos_sin_cache, is_neox, rotary_dim=None):
     return x
 
 
+def qknorm_rope_freqs(rotary_dim, base, factor=1.0, low=0.0, high=0.0):
+    """compute_freq of the reference kernel (kernels/jit/csrc/elementwise/fused_qknorm_rope.cuh:42-63): freq_p =
+    base^(-2 p / rotary_dim) for p < rotary_dim / 2; with YaRN (factor != 1) blended with freq_p / factor by the ramp
+    clamp((p - low) / (high' - low), 0, 1), high' = high + 0.001 when |low - high| <= 1e-6.  float64 [rotary_dim / 2]."""
+    p = np.arange(int(rotary_dim) // 2, dtype=np.float64)
+    freq = np.power(float(base), -2.0 * p / float(rotary_dim))
+    if float(factor) != 1.0:
+        high_adj = float(high) + 0.001 if abs(float(low) - float(high)) <= 1e-6 else float(high)
+        ramp = np.clip((p - float(low)) / (high_adj - float(low)), 0.0, 1.0)
+        extr = 1.0 - ramp
+        freq = (freq / float(factor)) * (1.0 - extr) + freq * extr
+    return freq
+
+
+def fused_qk_norm_rope(q, k, q_weight, k_weight, positions, eps, base, is_neox, factor=1.0, low=0.0, high=0.0,
+                       attention_factor=1.0, rotary_dim=None, cos_sin_cache=None):
+    """fused_qk_norm_rope (kernels/ops/attention/fused_qknorm_rope.py:37-100; kernel fused_qknorm_rope.cuh:78-246), in
+    float64 and WITHOUT the final rounding: per (token, head) x * rsqrt(mean(x^2) + eps) * w (:131-155), then RoPE on
+    the first rotary_dim columns -- neox pairs (p, p + rot/2) (:206-230), else (2p, 2p + 1) (:168-203) -- with
+    angle = position * freq_p (qknorm_rope_freqs) and the rotated pair times attention_factor; columns >= rotary_dim
+    stay normalised only (:236-245).  cos_sin_cache (float [max_pos, rot] = [cos | sin]): the angles' cos / sin come from
+    there instead (this library's second form).  q [n, Hq, D], k [n, Hkv, D] (uint16 = bf16 bits, or float) ->
+    (q', k') float64."""
+    pos = np.asarray(positions).astype(np.int64)
+    outs = []
+    for x, w in ((q, q_weight), (k, k_weight)):
+        xf, wf = to_f64(x), to_f64(w).reshape(-1)
+        d = xf.shape[-1]
+        rot = int(rotary_dim or d)
+        half = rot // 2
+        y = xf / np.sqrt((xf * xf).mean(axis=-1, keepdims=True) + float(eps)) * wf
+        if cos_sin_cache is not None:
+            cs = np.asarray(cos_sin_cache, dtype=np.float64)[pos]
+            cos, sin = cs[:, None, :half], cs[:, None, half:rot]
+        else:
+            ang = pos[:, None].astype(np.float64) * qknorm_rope_freqs(rot, base, factor, low, high)[None, :]
+            cos, sin = np.cos(ang)[:, None, :], np.sin(ang)[:, None, :]
+        o = y.copy()
+        if is_neox:
+            y0, y1 = y[..., :half], y[..., half:rot]
+            o[..., :half], o[..., half:rot] = (y0 * cos - y1 * sin) * attention_factor, (y1 * cos + y0 * sin) * attention_factor
+        else:
+            y0, y1 = y[..., 0:rot:2], y[..., 1:rot:2]
+            o[..., 0:rot:2], o[..., 1:rot:2] = (y0 * cos - y1 * sin) * attention_factor, (y1 * cos + y0 * sin) * attention_factor
+        outs.append(o)
+    return outs[0], outs[1]
+
+
 def decode_attention_grouped_rope(q, k_buffer, kv_indptr, kv_indices, cos_sin_cache, positions, sm_scale,
                                   kv_lora_rank=512, is_neox=True, logit_cap=0.0, new_rows=None):
     """Semantics of decode_attention_fwd_grouped_rope (kernels/ops/attention/rocm_mla_decode_rope.py:45-439) with

@@ -163,7 +163,16 @@ def shared_prefix_plan(req_to_token: Tensor, req_pool_indices: Tensor, seq_lens:
                            kv_start, suffix_lens, min_shared=min_shared, chunk_align=chunk_align)
 
 
-ALL_OPS = (merge_state, shared_prefix_plan, store_cache, build_kv_indices, get_num_kv_splits, decode_attention, decode_attention_paged,
+# fused_qk_norm_rope_out (kernels/ops/attention/fused_qknorm_rope.py:33-100: op_name, argument order, mutates qkv)
+@_op("fused_qk_norm_rope_out", ("qkv",))
+def fused_qk_norm_rope_out(qkv: Tensor, q_weight: Tensor, k_weight: Tensor, position_ids: Tensor, num_heads_q: int,
+                           num_heads_k: int, num_heads_v: int, head_dim: int, eps: float, base: float, is_neox: bool,
+                           factor: float, low: float, high: float, attention_factor: float, rotary_dim: int) -> None:
+    ops.fused_qk_norm_rope(qkv, num_heads_q, num_heads_k, num_heads_v, head_dim, eps, q_weight, k_weight, base, is_neox,
+                           position_ids, factor, low, high, attention_factor, rotary_dim)
+
+
+ALL_OPS = (fused_qk_norm_rope_out, merge_state, shared_prefix_plan, store_cache, build_kv_indices, get_num_kv_splits, decode_attention, decode_attention_paged,
            extend_attention, extend_attention_lse, alloc_extend, alloc_decode, write_req_to_token, move_kv)
 
 for _o in ALL_OPS:  # in-place ops: the fake implementation has nothing to compute

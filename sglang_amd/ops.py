@@ -1394,6 +1394,58 @@ def extend_attention_fwd_unified(q, o, k_buffer, v_buffer, k_scale, v_scale, qo_
 
 
 # --------------------------------------------------------------------------------------
+# fused QK-norm + RoPE (+ KV store)     fused_qk_norm_rope, kernels/ops/attention/fused_qknorm_rope.py:127-186
+# --------------------------------------------------------------------------------------
+def fused_qk_norm_rope(qkv: torch.Tensor, num_heads_q: int, num_heads_k: int, num_heads_v: int, head_dim: int, eps: float,
+                       q_weight: torch.Tensor, k_weight: torch.Tensor, base: float, is_neox: bool,
+                       position_ids: torch.Tensor, factor: float = 1.0, low: float = 0.0, high: float = 0.0,
+                       attention_factor: float = 1.0, rotary_dim: Optional[int] = None, *, cos_sin_cache=None,
+                       layout: Optional["_L.RxKvLayout"] = None, loc=None, size_limit: int = 0, k_scale: float = 1.0,
+                       v_scale: float = 1.0, reserved_skip_index: int = 0, err_flag=None) -> None:
+    """Per-head RMSNorm of q and k + RoPE, IN PLACE on qkv [num_tokens, (nq + nk + nv) * head_dim] -- the reference's name,
+    argument order and meaning (fused_qknorm_rope.py:127-186; kernel jit/csrc/elementwise/fused_qknorm_rope.cuh): frequencies
+    on the fly from ``base`` (YaRN blend when factor != 1), the rotated part times attention_factor, v untouched.
+    Beyond the reference: fp16 as well as bf16, int32 or int64 positions, any even head_dim <= 512, frequencies from a
+    ``cos_sin_cache`` (fp32 [max_pos, rotary_dim]) instead, and -- with ``layout`` + ``loc`` -- the finished k rows and the
+    v rows written to the paged pool in the same launch (as rope_store_kv)."""
+    _require_cuda(qkv, q_weight, k_weight, position_ids, cos_sin_cache, loc)
+    nq, nk, nv, d = int(num_heads_q), int(num_heads_k), int(num_heads_v), int(head_dim)
+    if qkv.dim() != 2 or qkv.shape[1] != (nq + nk + nv) * d or qkv.stride(1) != 1:
+        raise ValueError(f"fused_qk_norm_rope: qkv must be [num_tokens, {(nq + nk + nv) * d}] with unit inner stride, "
+                         f"got {tuple(qkv.shape)} / strides {qkv.stride()}")
+    if qkv.dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError("fused_qk_norm_rope: qkv must be bfloat16 or float16")
+    for nm, w in (("q_weight", q_weight), ("k_weight", k_weight)):
+        if w.dtype != qkv.dtype or w.numel() != d or not w.is_contiguous():
+            raise ValueError(f"fused_qk_norm_rope: {nm} must be a contiguous [{d}] tensor of qkv's dtype")
+    if position_ids.dtype not in (torch.int32, torch.int64) or position_ids.numel() != qkv.shape[0]:
+        raise ValueError("fused_qk_norm_rope: position_ids must be int32 / int64 [num_tokens]")
+    rot = d if rotary_dim is None else int(rotary_dim)
+    n = qkv.shape[0]
+    st = qkv.stride(0)
+    qp = qkv.data_ptr()
+    es = qkv.element_size()
+    kp, vp = qp + nq * d * es, qp + (nq + nk) * d * es
+    cs_ptr, cs_stride = 0, 0
+    if cos_sin_cache is not None:
+        if cos_sin_cache.dtype != torch.float32 or cos_sin_cache.stride(-1) != 1 or cos_sin_cache.shape[-1] != rot:
+            raise TypeError("fused_qk_norm_rope: cos_sin_cache must be float32 [max_pos, rotary_dim]")
+        cs_ptr, cs_stride = cos_sin_cache.data_ptr(), cos_sin_cache.stride(0)
+    lay_ref, locp, l64 = None, None, 0
+    if layout is not None:
+        if loc is None or nv != nk:
+            raise ValueError("fused_qk_norm_rope: the pool store needs loc and as many v heads as k heads")
+        lay_ref, locp, l64 = C.byref(layout), _ptr(loc.contiguous()), _is64(loc, "loc")
+    pos = position_ids.contiguous()
+    stt = _L.load().rx_qknorm_rope_store_kv(
+        qp, kp, vp, st, d, st, d, st, d, n, nq, nk, d, d if layout is not None else 0, rot, _ptr(q_weight), _ptr(k_weight),
+        float(eps), _ptr(pos), int(pos.dtype == torch.int64), float(base), float(factor), float(low), float(high),
+        float(attention_factor), cs_ptr, cs_stride, int(bool(is_neox)), lay_ref, locp, l64, int(size_limit),
+        int(reserved_skip_index), float(k_scale), float(v_scale), _rx_dtype(qkv), _ptr(err_flag), _stream(qkv))
+    _L.check(stt, "rx_qknorm_rope_store_kv")
+
+
+# --------------------------------------------------------------------------------------
 # fused RoPE + KV store      RotaryEmbedding.forward + set_kv_buffer; kernels/ops/kvcache/rope_cache.py
 # --------------------------------------------------------------------------------------
 def rope_store_kv(q, k, v, positions, cos_sin_cache, is_neox: bool, *, rotary_dim: Optional[int] = None,

@@ -24,6 +24,7 @@ Fixture families:
   F11 rotary embedding (torch-native apply_rotary_emb) -> rope.npz
   F9 extend with custom (tree) masks, sliding window (+ window_kv_offsets), xai temperature -> extend_mask.npz
   F16 ROCm MLA decode with fused RoPE (stage-1 kernel of rocm_mla_decode_rope.py, LSE-merged) -> mla_rope.npz
+  F17 QK-norm + RoPE (RMSNorm.forward_native + apply_rotary_emb, the pair the reference tests its fused kernel against) -> qknorm_rope.npz
 """
 import json
 import os
@@ -1084,8 +1085,65 @@ def f16():
     save("mla_rope.npz", **flat)
 
 
+def f17():
+    """F17 fused QK-norm + RoPE -> qknorm_rope.npz.  The reference's fused kernel (kernels/jit/csrc/elementwise/
+    fused_qknorm_rope.cuh) is CUDA-only; its own test (kernels/aot/tests/test_fused_qk_norm_rope.py:31-128) checks it
+    against RMSNorm + RotaryEmbedding, and that pair is what runs here, in fp32 (the fused kernel rounds once, at the
+    end): RMSNorm.forward_native (srt/layers/layernorm.py:644-692) -- the module itself does not import in this container
+    (transformers' image-processing chain), so the METHOD is taken from the file with `ast` at run time and executed on a
+    stand-in object carrying the attributes it reads; nothing of its text is stored -- then apply_rotary_emb
+    (srt/layers/rotary_embedding/utils.py:36-62) with the cos / sin of RotaryEmbedding._compute_cos_sin_cache
+    (base.py:171-181) at the positions.  Cases: neox / interleaved, partial rotary, head dims 64 / 128 / 256, bf16 inputs
+    (+ one fp16), the reference test's weights (randn * 5) and positions (+100)."""
+    import ast
+    import types
+
+    from sglang.srt.layers.rotary_embedding.utils import apply_rotary_emb
+
+    path = "/root/reference/python/sglang/srt/layers/layernorm.py"
+    tree = ast.parse(open(path).read())
+    fn = next(b for node in tree.body if isinstance(node, ast.ClassDef) and node.name == "RMSNorm"
+              for b in node.body if isinstance(b, ast.FunctionDef) and b.name == "forward_native")
+    fn.decorator_list = []
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"torch": torch, "Optional": __import__("typing").Optional, "Union": __import__("typing").Union,
+          "Tuple": __import__("typing").Tuple}
+    exec(compile(mod, path, "exec"), ns)
+    forward_native = ns["forward_native"]
+
+    def rmsnorm_fp32(x, w, eps):
+        self = types.SimpleNamespace(override_orig_dtype=torch.float32, fp32_residual=False, hidden_size=x.shape[-1],
+                                     variance_size_override=None, variance_epsilon=eps, cast_x_before_out_mul=False,
+                                     weight=w.float())
+        return forward_native(self, x)
+
+    torch.manual_seed(17)
+    flat = {}
+    cases = [("neox128", 128, 128, True, torch.bfloat16, 10000.0, 1e-5), ("gptj128", 128, 128, False, torch.bfloat16, 10000.0, 1e-5),
+             ("partial64of128", 128, 64, True, torch.bfloat16, 500000.0, 1e-6), ("gptj64", 64, 64, False, torch.bfloat16, 10000.0, 1e-5),
+             ("neox256", 256, 256, True, torch.bfloat16, 1000000.0, 1e-6), ("partial_gptj32of64", 64, 32, False, torch.float16, 10000.0, 1e-5)]
+    for name, D, rot, neox, dt, base, eps in cases:
+        n, HQ, HKV = 7, 4, 2
+        pos = torch.tensor([100, 101, 102, 0, 1, 4095, 777])
+        qkv = torch.randn(n, (HQ + 2 * HKV) * D).to(dt)
+        qw, kw = (torch.randn(D) * 5.0).to(dt), (torch.randn(D) * 5.0).to(dt)
+        inv_freq = 1.0 / (base ** (torch.arange(0, rot, 2, dtype=torch.float) / rot))
+        freqs = torch.einsum("i,j -> ij", pos.float(), inv_freq)
+        cos, sin = freqs.cos(), freqs.sin()
+        outs = []
+        for x, w, H in ((qkv[:, : HQ * D], qw, HQ), (qkv[:, HQ * D: (HQ + HKV) * D], kw, HKV)):
+            y = rmsnorm_fp32(x.reshape(-1, D), w, eps).view(n, H, D)
+            yr = apply_rotary_emb(y[..., :rot].float(), cos, sin, neox)
+            outs.append(torch.cat((yr, y[..., rot:].float()), dim=-1))
+        c = dict(qkv=qkv, q_weight=qw, k_weight=kw, positions=pos, eps=np.float64(eps), base=np.float64(base), rotary_dim=rot,
+                 is_neox=int(neox), hq=HQ, hkv=HKV, head_dim=D, q_out=outs[0], k_out=outs[1], cos_sin=torch.cat((cos, sin), dim=-1))
+        for kk, v in c.items():
+            flat[f"{name}.{kk}"] = bits(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+    save("qknorm_rope.npz", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14",
-                             "f15", "f16"]
+                             "f15", "f16", "f17"]
     for w in which:
         globals()[w]()

@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(l, s), f"{s} declared in include/radix_hip.h but not exported"
         assert s in lib.PROTOTYPES, f"{s} has no ctypes prototype"
-    assert l.rx_version() == lib.RX_ABI_VERSION == 10
+    assert l.rx_version() == lib.RX_ABI_VERSION == 11
     assert [l.rx_abi_sizeof(i) for i in range(4)][3] == -1 and l.rx_abi_sizeof(1) > 0
 
 
@@ -68,7 +68,8 @@ def test_torch_custom_ops_registered_with_fake_impls():
     names = {o._qualname.split("::")[1] for o in custom_ops.ALL_OPS}
     assert names == {"store_cache", "build_kv_indices", "get_num_kv_splits", "decode_attention",
                      "decode_attention_paged", "extend_attention", "extend_attention_lse", "alloc_extend", "alloc_decode",
-                     "write_req_to_token", "move_kv", "merge_state", "shared_prefix_plan"}
+                     "write_req_to_token", "move_kv", "merge_state", "shared_prefix_plan", "fused_qk_norm_rope_out"}
+    assert "Tensor(a0!) qkv" in str(torch.ops.radix_hip.fused_qk_norm_rope_out.default._schema)   # the reference's op name, mutates qkv
     sch = str(torch.ops.radix_hip.decode_attention.default._schema)
     assert "Tensor(a3!) o" in sch and "attn_logits" in sch and sch.endswith("-> ()")
     assert "!" in str(torch.ops.radix_hip.store_cache.default._schema)

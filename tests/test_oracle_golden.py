@@ -451,3 +451,34 @@ def test_mla_decode_fused_rope_oracle_matches_reference_kernel(golden_dir):
         np.testing.assert_allclose(o, c["o"].astype(np.float64), atol=2e-3, rtol=2e-3, err_msg=name)
         want_k = c["k_pe_out"].astype(np.float64).reshape(kpe.shape)
         assert np.abs(kpe - want_k).max() <= 2.0 ** -10 * max(1.0, np.abs(want_k).max()), name
+
+
+# ------------------------------------------------------------------ F17
+def test_fused_qk_norm_rope_oracle_matches_reference_norm_and_rope(golden_dir):
+    """oracle.fused_qk_norm_rope against RMSNorm.forward_native + apply_rotary_emb run in fp32 (make_golden.f17: the pair the
+    reference's own test holds its fused kernel to, kernels/aot/tests/test_fused_qk_norm_rope.py:31-128): with the
+    frequencies computed from `base` (the fused kernel's way, fused_qknorm_rope.cuh:42-63) and with the golden's cos / sin
+    rows as a cache, both to fp32 rounding of values up to |w| * sqrt(D) ~ 100; YaRN off (factor 1) reduces to the same."""
+    cases = _npz_cases(os.path.join(golden_dir, "qknorm_rope.npz"))
+    assert set(cases) == {"neox128", "gptj128", "partial64of128", "gptj64", "neox256", "partial_gptj32of64"}
+    for name, c in cases.items():
+        hq, hkv, d = int(c["hq"]), int(c["hkv"]), int(c["head_dim"])
+        n = c["qkv"].shape[0]
+        q = c["qkv"][:, : hq * d].reshape(n, hq, d)
+        k = c["qkv"][:, hq * d: (hq + hkv) * d].reshape(n, hkv, d)
+        want_q, want_k = c["q_out"].astype(np.float64), c["k_out"].astype(np.float64)
+        scale = max(np.abs(want_q).max(), np.abs(want_k).max())
+        for kw in (dict(), dict(cos_sin_cache=c["cos_sin"], positions=np.arange(n))):
+            args = dict(positions=c["positions"], eps=float(c["eps"]), base=float(c["base"]), is_neox=bool(c["is_neox"]),
+                        rotary_dim=int(c["rotary_dim"]))
+            args.update(kw)
+            gq, gk = orc.fused_qk_norm_rope(q, k, c["q_weight"], c["k_weight"], **args)
+            # fp32 pipeline vs float64: the angle pos * freq carries fp32 rounding of both factors (pos <= 4095)
+            tol = scale * (3e-4 if not kw else 4e-6)
+            assert np.abs(gq - want_q).max() <= tol and np.abs(gk - want_k).max() <= tol, (name, bool(kw), np.abs(gq - want_q).max(), tol)
+    # YaRN: the ramp's two ends (fused_qknorm_rope.cuh:46-60): below `low` pure extrapolation, above `high` freq / factor
+    f = orc.qknorm_rope_freqs(64, 10000.0, factor=4.0, low=8.0, high=24.0)
+    f0 = orc.qknorm_rope_freqs(64, 10000.0)
+    assert np.allclose(f[:9], f0[:9]) and np.allclose(f[24:], f0[24:] / 4.0) and (f[9:24] < f0[9:24]).all() and (f[9:24] > f0[9:24] / 4).all()
+    g = orc.qknorm_rope_freqs(64, 10000.0, factor=2.0, low=5.0, high=5.0)      # low == high: high + 0.001
+    assert np.allclose(g[:6], f0[:6]) and np.allclose(g[6:], f0[6:] / 2.0)
