@@ -124,6 +124,7 @@ struct QkNormRopeArgs {
   float eps, base, factor, low, high, attention_factor;
   const void* positions;  // int32 or int64
   int32_t pos64, on_the_fly;
+  int32_t cache_vec;  // the cache rows can be read 16 bytes at a time (aligned base and row stride, rotary_dim % 8 == 0)
 };
 
 template <typename T>
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(const QkNormRope
 // the transcendental unit, the angle taken to revolutions and reduced by fract() in front of v_sin / v_cos -- fp32
 // throughout, as accurate as the fp32 angle itself (the reference kernel uses __sincosf on the same product).
 // For head dims 64 / 128 / 256 / 512 with contiguous, 16-byte aligned head rows; neox needs rotary_dim % 16 == 0.
-template <typename T, int LPH>
+template <typename T, int LPH, bool NORM = true>
 __global__ __launch_bounds__(256) void qknorm_rope_fast_kernel(const QkNormRopeArgs qa) {
   const RopeArgs& a = qa.r;
   constexpr int HPW = 64 / LPH;   // heads per wave and pass
@@ -252,7 +253,11 @@ __global__ __launch_bounds__(256) void qknorm_rope_fast_kernel(const QkNormRopeA
     raw[u] = *reinterpret_cast<const u32x4*>(xp[u]);
     pos_i[u] = load_idx(qa.positions, tt[u], qa.pos64);
   }
-  const u32x4 wq = *reinterpret_cast<const u32x4*>(qa.q_weight + base_i), wk = *reinterpret_cast<const u32x4*>(qa.k_weight + base_i);
+  u32x4 wq = {0, 0, 0, 0}, wk = {0, 0, 0, 0};
+  if constexpr (NORM) {
+    wq = *reinterpret_cast<const u32x4*>(qa.q_weight + base_i);
+    wk = *reinterpret_cast<const u32x4*>(qa.k_weight + base_i);
+  }
 #pragma unroll
   for (int u = 0; u < UNR; ++u) {
     const int64_t t = tt[u];
@@ -267,14 +272,16 @@ __global__ __launch_bounds__(256) void qknorm_rope_fast_kernel(const QkNormRopeA
       w[2 * i] = T::to_f32(static_cast<uint16_t>(wraw[i] & 0xffffu));
       w[2 * i + 1] = T::to_f32(static_cast<uint16_t>(wraw[i] >> 16));
     }
-    float ss = 0.f;
+    if constexpr (NORM) {
+      float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ss += e[i] * e[i];
+      for (int i = 0; i < 8; ++i) ss += e[i] * e[i];
 #pragma unroll
-    for (int m = LPH / 2; m > 0; m >>= 1) ss += __shfl_xor(ss, m);
-    const float rcp = __frsqrt_rn(ss / static_cast<float>(D) + qa.eps);
+      for (int m = LPH / 2; m > 0; m >>= 1) ss += __shfl_xor(ss, m);
+      const float rcp = __frsqrt_rn(ss / static_cast<float>(D) + qa.eps);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] *= rcp * w[i];
+      for (int i = 0; i < 8; ++i) e[i] *= rcp * w[i];
+    }
     // ---- RoPE
     const float pos = static_cast<float>(pos_i[u]);
     const float* cs = qa.on_the_fly ? nullptr : a.cos_sin + pos_i[u] * a.cos_sin_stride;
@@ -303,23 +310,48 @@ __global__ __launch_bounds__(256) void qknorm_rope_fast_kernel(const QkNormRopeA
       const bool in_rot = base_i < a.rot;             // (rot % 16 == 0: a lane is wholly inside or outside)
       const bool low = sub < hl;
       const int partner = lane + (in_rot ? (low ? hl : -hl) : 0);
+      const int p0 = base_i - (low ? 0 : half);       // first pair index of this lane: a multiple of 8
+      float cv[8], sv[8];
+      if (in_rot) {
+        if (qa.on_the_fly || !qa.cache_vec) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cos_sin_of(p0 + i, cv[i], sv[i]);
+        } else {  // the cache row's 8 cosines and 8 sines of this lane as four 16-byte loads (16 scalar loads cost 2x the kernel)
+          const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + p0), c1 = *reinterpret_cast<const f32x4*>(cs + p0 + 4);
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + half + p0), s1 = *reinterpret_cast<const f32x4*>(cs + half + p0 + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            cv[i] = c0[i];
+            cv[4 + i] = c1[i];
+            sv[i] = s0[i];
+            sv[4 + i] = s1[i];
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const float other = __shfl(e[i], partner);
-        if (in_rot) {
-          float c, sn;
-          cos_sin_of((base_i + i) - (low ? 0 : half), c, sn);
-          o[i] = (low ? e[i] * c - other * sn : e[i] * c + other * sn) * qa.attention_factor;
-        } else {
-          o[i] = e[i];
-        }
+        o[i] = in_rot ? (low ? e[i] * cv[i] - other * sv[i] : e[i] * cv[i] + other * sv[i]) * qa.attention_factor : e[i];
       }
     } else {
+      float cv[4], sv[4];
+      const int p0 = base_i >> 1;                     // a multiple of 4
+      if (!qa.on_the_fly && qa.cache_vec && base_i + 8 <= a.rot) {
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + p0), s0 = *reinterpret_cast<const f32x4*>(cs + half + p0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          cv[i] = c0[i];
+          sv[i] = s0[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (base_i + 2 * i + 1 < a.rot) cos_sin_of(p0 + i, cv[i], sv[i]);
+      }
 #pragma unroll
       for (int i = 0; i < 8; i += 2) {
         if (base_i + i + 1 < a.rot) {
-          float c, sn;
-          cos_sin_of((base_i + i) >> 1, c, sn);
+          const float c = cv[i >> 1], sn = sv[i >> 1];
           o[i] = (e[i] * c - e[i + 1] * sn) * qa.attention_factor;
           o[i + 1] = (e[i + 1] * c + e[i] * sn) * qa.attention_factor;
         } else {
@@ -401,8 +433,42 @@ extern "C" int rx_rope_store_kv(void* q, void* k, const void* v, int64_t q_strid
     a.k_scale = k_scale; a.v_scale = v_scale; a.err_flag = err_flag;
   }
   const int64_t units = n * (num_q_heads + num_kv_heads);
-  const dim3 grid(static_cast<unsigned>((units + 3) / 4)), block(256);
   auto s = static_cast<hipStream_t>(stream);
+  // round 4: the 16-byte / lane-shuffle form of the QK-norm kernel below, without the norm (Llama-3-8B heads, 16 Ki tokens
+  // with the store: 148.6 us = 2.9 TB/s on the one-element-per-lane kernel above), for power-of-two head dims with
+  // contiguous, 16-byte aligned rows; everything else stays on the kernel above
+  const bool pow2 = head_dim == 64 || head_dim == 128 || head_dim == 256 || head_dim == 512;
+  bool fast = pow2 && (is_neox ? rotary_dim % 16 == 0 : true) &&
+              ((q_stride_t | q_stride_h | k_stride_t | k_stride_h) % 8 == 0) && (((uintptr_t)q | (uintptr_t)k) & 15) == 0;
+  if (fast && lay) {
+    fast = v_head_dim == head_dim && ((v_stride_t | v_stride_h) % 8 == 0) && ((uintptr_t)v & 15) == 0 &&
+           (lay->kv_fp8 || (((lay->k_page_stride | lay->k_tok_stride | lay->k_head_stride | lay->v_page_stride |
+                              lay->v_tok_stride | lay->v_head_stride) % 8 == 0) &&
+                            (((uintptr_t)lay->k_buf | (uintptr_t)lay->v_buf) & 15) == 0));
+  }
+  if (fast) {
+    QkNormRopeArgs qa{};
+    qa.r = a;
+    qa.attention_factor = 1.0f;
+    qa.positions = positions;
+    qa.pos64 = 1;
+    qa.on_the_fly = 0;
+    qa.cache_vec = ((uintptr_t)cos_sin_cache & 15) == 0 && cos_sin_stride % 4 == 0 && rotary_dim % 8 == 0;
+    const int lph = head_dim / 8, hpw = 64 / lph;
+    const dim3 grid(static_cast<unsigned>((units + 4 * hpw - 1) / (4 * hpw))), block(256);
+#define RX_ROPE_FAST(TT)                                                                               \
+  do {                                                                                                 \
+    if (lph == 8) hipLaunchKernelGGL((qknorm_rope_fast_kernel<TT, 8, false>), grid, block, 0, s, qa);        \
+    else if (lph == 16) hipLaunchKernelGGL((qknorm_rope_fast_kernel<TT, 16, false>), grid, block, 0, s, qa); \
+    else if (lph == 32) hipLaunchKernelGGL((qknorm_rope_fast_kernel<TT, 32, false>), grid, block, 0, s, qa); \
+    else hipLaunchKernelGGL((qknorm_rope_fast_kernel<TT, 64, false>), grid, block, 0, s, qa);                \
+  } while (0)
+    if (dtype == RX_BF16) RX_ROPE_FAST(BF16);
+    else RX_ROPE_FAST(F16);
+#undef RX_ROPE_FAST
+    return check_launch("rx_rope_store_kv");
+  }
+  const dim3 grid(static_cast<unsigned>((units + 3) / 4)), block(256);
   if (dtype == RX_BF16) hipLaunchKernelGGL(rope_store_kernel<BF16>, grid, block, 0, s, a);
   else hipLaunchKernelGGL(rope_store_kernel<F16>, grid, block, 0, s, a);
   return check_launch("rx_rope_store_kv");
@@ -441,6 +507,7 @@ extern "C" int rx_qknorm_rope_store_kv(void* q, void* k, const void* v, int64_t 
   qa.k_weight = static_cast<const uint16_t*>(k_weight);
   qa.eps = eps; qa.base = base; qa.factor = factor; qa.low = low; qa.high = high; qa.attention_factor = attention_factor;
   qa.positions = positions; qa.pos64 = positions_is_i64; qa.on_the_fly = cos_sin_cache == nullptr;
+  qa.cache_vec = cos_sin_cache && ((uintptr_t)cos_sin_cache & 15) == 0 && cos_sin_stride % 4 == 0 && rotary_dim % 8 == 0;
   if (lay) {
     RX_REQUIRE(v && loc && lay->k_buf && lay->v_buf && v_head_dim > 0, "rx_qknorm_rope_store_kv: pool store needs v, loc and the layout's buffers");
     RX_REQUIRE(lay->page_size >= 1 && size_limit > 0, "rx_qknorm_rope_store_kv: bad page_size / size_limit");
