@@ -815,7 +815,66 @@ def extra_legs(args, dev):
     except Exception as e:  # noqa: BLE001
         c1["prefill_extend"] = {"error": f"{type(e).__name__}: {e}"}
     ex["config1"] = c1
+    try:
+        ex["pre_attention_ops"] = pre_attention_ops_bench(dev)
+    except Exception as e:  # noqa: BLE001
+        ex["pre_attention_ops"] = {"error": f"{type(e).__name__}: {e}"}
     return ex
+
+
+def pre_attention_ops_bench(dev):
+    """SURVEY 8f rank 3, the fused ops in front of attention, on a prefill-sized input (16 Ki tokens, bf16, D 128), each
+    WITH the step's KV store in the same launch: rx_rope_store_kv (Llama-3-8B heads 32 / 8, cos_sin_cache) and
+    rx_qknorm_rope_store_kv (Qwen3-8B heads 32 / 8 / 8, frequencies on the fly).  HBM-bound byte work: algorithmic bytes
+    = q and k rows read and written + v rows read + k / v pool rows written; 20 launches per graph replay."""
+    from sglang_amd import ops
+
+    n, hq, hkv, d = 16384, 32, 8, 128
+    g = torch.Generator(device=dev).manual_seed(5)
+    byt = n * (hq + hkv) * d * 2 * 2 + n * hkv * d * 2 * 3
+    kb = torch.zeros(n + 16, hkv, d, dtype=torch.bfloat16, device=dev)
+    vb = torch.zeros_like(kb)
+    lay = ops._kv_layout(kb, vb, 1)
+    loc = torch.randperm(n, device=dev, generator=g) + 1
+    pos = torch.arange(n, device=dev) % 8192
+
+    def timed(run):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(20):
+                run()
+        gpu_warm(gr.replay, ms=20)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 100 * 1e3
+        return {"us": us, "bytes": byt, "GBps": byt / us / 1e3, "frac_of_hbm_peak": byt / us / 1e3 / HBM_PEAK_GBS}
+
+    res = {"workload": "16384 tokens, bf16, head_dim 128, KV store to an NHD pool in the same launch"}
+    q = torch.randn(n, hq, d, device=dev, generator=g).to(torch.bfloat16)
+    k = torch.randn(n, hkv, d, device=dev, generator=g).to(torch.bfloat16)
+    v = torch.randn(n, hkv, d, device=dev, generator=g).to(torch.bfloat16)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, dtype=torch.float, device=dev) / d))
+    fr = torch.einsum("i,j->ij", torch.arange(8192, dtype=torch.float, device=dev), inv)
+    cache = torch.cat((fr.cos(), fr.sin()), dim=-1).contiguous()
+    res["rope_store_kv"] = timed(lambda: ops.rope_store_kv(q, k, v, pos.to(torch.int64), cache, True, layout=lay, loc=loc,
+                                                           size_limit=n + 16))
+    qkv = torch.randn(n, (hq + 2 * hkv) * d, device=dev, generator=g).to(torch.bfloat16)
+    qw = torch.randn(d, device=dev, generator=g).to(torch.bfloat16)
+    kw = torch.randn(d, device=dev, generator=g).to(torch.bfloat16)
+    res["qknorm_rope_store_kv"] = timed(lambda: ops.fused_qk_norm_rope(qkv, hq, hkv, hkv, d, 1e-6, qw, kw, 10000.0, True,
+                                                                       pos.to(torch.int32), layout=lay, loc=loc, size_limit=n + 16))
+    return res
 
 
 def extend_head_dims(args, dev):
