@@ -65,7 +65,8 @@ def main():
     dl = C.CDLL(LIB)
     dl.rx_dev_extend32.restype = C.c_int
     dl.rx_dev_extend32.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    params = {v: ops._extend_params(q, ke, ve, outs[v], kb, vb, qo, kvp, kvi, None, True, None, E, 1.0, 1.0,
+    causal = not os.environ.get("NONCAUSAL")  # NONCAUSAL=1: every new-token tile is a full tile (what the diagonal costs: compare the times)
+    params = {v: ops._extend_params(q, ke, ve, outs[v], kb, vb, qo, kvp, kvi, None, causal, None, E, 1.0, 1.0,
                                     sm_scale=D ** -0.5, page_size=ps, kv_layout=lay) for v in VARS}
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -75,7 +76,7 @@ def main():
 
     # production kernel as the reference output
     o_ref = torch.zeros_like(outs[VARS[0]])
-    ops.extend_attention_fwd(q, ke, ve, o_ref, kb, vb, qo, kvp, kvi, None, True, None, E, 1.0, 1.0, sm_scale=D ** -0.5,
+    ops.extend_attention_fwd(q, ke, ve, o_ref, kb, vb, qo, kvp, kvi, None, causal, None, E, 1.0, 1.0, sm_scale=D ** -0.5,
                              page_size=ps, kv_layout=lay)
     print("production instance:", rxlib.last_dispatch())
     for v in VARS:
@@ -99,7 +100,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / reps)
-    flops = 4.0 * HQ * D * chunk * (E * P + E * (E + 1) / 2)
+    flops = 4.0 * HQ * D * chunk * (E * P + (E * (E + 1) / 2 if causal else E * E))
     for v in VARS:
         t = sorted(times[v])
         med, mn = t[len(t) // 2], t[0]
