@@ -82,6 +82,9 @@ def parse():
                     help="internal: the peer-to-peer all-reduce leg of an N > 1 run (started by rank 0 of the main run as "
                          "a fresh child job with RX_CUSTOM_AR=1; prints its own JSON line)")
     ap.add_argument("--no-custom-ar-leg", action="store_true", help="N > 1: skip the peer-to-peer all-reduce child leg")
+    ap.add_argument("--full-json", action="store_true",
+                    help="print the FULL record as the final JSON line (default: the full record goes to an earlier "
+                         "'[bench-full] ' line and gpurun_out/bench_full.json, the final line is the compact one)")
     return ap.parse_args()
 
 
@@ -777,7 +780,8 @@ def child_decode_leg(args, argv, timeout=900):
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extend", "--no-radix-hit", "--no-cpu-baseline",
-           "--no-extra", "--steps", "10", "--warmup", "3", "--layers", str(args.layers), "--kv-layout", args.kv_layout] + argv
+           "--no-extra", "--full-json", "--steps", "10", "--warmup", "3", "--layers", str(args.layers), "--kv-layout",
+           args.kv_layout] + argv
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
     if r.returncode != 0 or line is None:
@@ -1296,6 +1300,127 @@ def ar_leg_main(args, st, fb, world, rank, dev, contact):
         raise SystemExit(3)
 
 
+def _get(d, *path, default=None):
+    """d[path[0]][path[1]]... or `default` when any hop is missing / an error record."""
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def _r(x, n=4):
+    return round(x, n) if isinstance(x, float) else x
+
+
+def compact_record(out):
+    """The FINAL line of a default run: the contract's keys plus, inside `roofline` (the dict the driver keeps), the
+    extend half of the metric and one number per other measured leg.  Everything else stays in the full record
+    ('[bench-full] ' line / gpurun_out/bench_full.json).  Kept under 2 KB (the 15-KB line pushed
+    `extend` out of the driver's 8-KB tail)."""
+    rf = out["roofline"]
+    c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                             "scaling", "vs_baseline", "dtype", "data")}
+    c["metric"] = "decode tokens/sec + extend TFLOPS, Llama-3-8B bs=256 ctx=4k (value = decode tokens/s; extend under roofline.extend)"
+    c["value"], c["ms_per_step"] = _r(out["value"], 1), _r(out["ms_per_step"], 4)
+    cfg = out["config"]
+    c["config"] = {"workload": "configs[2] decode: Llama-3-8B bf16 attention path (KV store + paged decode attn + o_proj"
+                               + (" + all-reduce" if out["n_gpus"] > 1 else "") + " per layer), bs=%d ctx=%d, %d layer pools, "
+                               "page %s shuffled %s, %s" % (cfg["global_batch"], cfg["seq_len"], cfg["distinct_layer_buffers"],
+                                                            cfg["workload"].split("page_size=")[1].split(" ")[0],
+                                                            cfg["kv_layout"].upper(), cfg["step_launch"].split(" (")[0]),
+                   "global_batch": cfg["global_batch"], "seq_len": cfg["seq_len"], "parallelism": cfg["parallelism"]}
+    if cfg.get("all_reduce", "none") != "none":
+        c["config"]["all_reduce"] = cfg["all_reduce"]
+    if "tp_sim" in cfg:
+        c["config"]["tp_sim"] = cfg["tp_sim"]
+    r = {k: _r(rf[k], 4) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    r["kernel"] = rf["kernel"].split("|")[0]
+    r["bytes_per_launch"], r["avg_launch_ms"], r["launches"] = rf["bytes_per_launch"], _r(rf["avg_launch_ms"], 5), rf["launches"]
+    if rf.get("traffic_source"):
+        r["traffic_from"] = rf["traffic_source"]["file"] + " (separate --pmc passes, not this run)"
+    if "per_rank_frac" in rf:
+        r["per_rank_frac"] = [_r(x, 4) for x in rf["per_rank_frac"]]
+    ext = out.get("extend")
+    if isinstance(ext, dict):
+        if "error" in ext:
+            r["extend"] = {"error": str(ext["error"])[:200]}
+        else:
+            e = {"tflops": _r(ext["tflops"], 1), "kernel_tflops": _r(_get(ext, "kernel_only", "tflops"), 1),
+                 "frac": _r(_get(ext, "roofline", "frac"), 4), "peak": _get(ext, "roofline", "peak"), "bound": "mfma",
+                 "kernel": ext["kernel"], "ms_per_launch": _r(_get(ext, "kernel_only", "ms_per_launch"), 5),
+                 "flops_per_launch": ext["flops_per_chunk"],
+                 "workload": "configs[2] extend: %d req x (3584 shared-prefix + 512 new) per launch, bf16 D=128; tflops = via "
+                             "backend (metadata + KV store + attn, %d layers), kernel_tflops = attn launch alone"
+                             % (ext["chunk_requests"], ext["layers"])}
+            if "sharding" in ext:
+                e["sharding"] = ext["sharding"]
+            for name in ("d64", "d96", "d256", "d192_v128"):
+                v = _get(ext, "other_head_dims", name, "frac")
+                if v is not None:
+                    e[name + "_frac"] = _r(v, 4)
+            v = _get(ext, "mla_latent", "v_view_of_k", "frac_of_mfma_peak")
+            if v is not None:
+                e["mla_latent_frac"] = _r(v, 4)
+            pk = ext.get("peaked_input")
+            if isinstance(pk, dict):
+                e["peaked_input"] = {k: _r(v, 4) for k, v in pk.items() if k in ("frac", "tflops", "redo_rate", "scores")}
+            cb = ext.get("cpu_baseline")
+            if isinstance(cb, dict) and "value" in cb:
+                e["cpu_tflops"] = _r(cb["value"], 3)
+            r["extend"] = e
+    for key, path in (("prefill2k_kernel_frac", ("extra", "config1", "prefill_extend", "frac_of_mfma_peak")),
+                      ("mla_decode_fp8_op_frac", ("mla_decode", "fp8_rows", "op_frac_of_hbm_peak")),
+                      ("mla_decode_fp8_kernel_frac", ("mla_decode", "fp8_rows", "roofline", "frac")),
+                      ("mla_decode_bf16_op_frac", ("mla_decode", "bf16_rows", "op_frac_of_hbm_peak")),
+                      ("tp2_kernel_frac", ("extra", "tp_sim", "tp2", "kernel_frac_of_hbm_peak")),
+                      ("tp4_kernel_frac", ("extra", "tp_sim", "tp4", "kernel_frac_of_hbm_peak")),
+                      ("tp8_kernel_frac", ("extra", "tp_sim", "tp8", "kernel_frac_of_hbm_peak")),
+                      ("tp8_ms_per_step", ("extra", "tp_sim", "tp8", "ms_per_step")),
+                      ("ragged_kernel_frac", ("extra", "ragged_decode", "kernel_frac_of_hbm_peak")),
+                      ("config1_decode_kernel_frac", ("extra", "config1", "decode", "kernel_frac_of_hbm_peak")),
+                      ("radix_hit_cascade_tok_s", ("radix_hit_decode", "cascade_decode", "tokens_per_s")),
+                      ("rope_store_frac", ("extra", "pre_attention_ops", "rope_store_kv", "frac_of_hbm_peak")),
+                      ("qknorm_rope_store_frac", ("extra", "pre_attention_ops", "qknorm_rope_store_kv", "frac_of_hbm_peak"))):
+        v = _get(out, *path)
+        if v is not None:
+            r[key] = _r(v, 4)
+    c["roofline"] = r
+    ar = out.get("all_reduce")
+    if isinstance(ar, dict):
+        c["all_reduce"] = {k: _r(ar[k], 4) for k in ("implementation", "alone_us", "step_ms_overlap", "step_ms_no_overlap", "error")
+                           if k in ar}
+        leg = ar.get("p2p_two_shot_leg")
+        if isinstance(leg, dict):
+            c["all_reduce"]["p2p_two_shot"] = {k: _r(leg[k], 4) for k in ("alone_us", "step_ms_overlap", "step_ms_no_overlap",
+                                                                        "device_side_timeouts", "error") if k in leg}
+    fc = out.get("first_contact")
+    if isinstance(fc, dict):
+        c["first_contact_ok"] = bool(_get(fc, "all_reduce_check", "ok_on_every_rank"))
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c["cpu_baseline"] = {k: (_r(cb[k], 3) if k != "sample" else str(cb[k])[:96]) for k in ("value", "unit", "cores", "kind", "sample")
+                             if k in cb}
+    c["full_record"] = "gpurun_out/bench_full.json"
+    return c
+
+
+def emit(out, args):
+    """rank 0: the full record on an earlier line (and in gpurun_out/), then ONE compact JSON line last."""
+    full = json.dumps(out)
+    if args.full_json:
+        print(full, flush=True)
+        return
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError:
+        pass
+    print("[bench-full] " + full, flush=True)
+    print(json.dumps(compact_record(out)), flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_worker:
@@ -1548,7 +1673,7 @@ def main():
             # the extend half of the metric beside its own CPU figure (SURVEY 8d names both CPU kernels)
             out["extend"]["cpu_baseline"] = cpu_baseline(args, leg="extend")
     if rank == 0:
-        print(json.dumps(out))
+        emit(out, args)
     if world > 1:
         import torch.distributed as dist
 

@@ -66,7 +66,7 @@ def test_bench_gpus_2_runs_two_ranks_on_one_gpu(extra):
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--settle", "1", "--bs", "16", "--ctx", "512", "--layers", "4", "--no-cpu-baseline"] + extra,
+                        "--settle", "1", "--bs", "16", "--ctx", "512", "--layers", "4", "--no-cpu-baseline", "--full-json"] + extra,
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -96,8 +96,41 @@ def test_bench_tp_sim_shard_replays_from_hip_graphs():
     and the roofline kernel is still timed live."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tp-sim", "8", "--steps", "3", "--warmup", "1",
                         "--settle", "1", "--bs", "64", "--ctx", "1024", "--layers", "8", "--no-cpu-baseline",
-                        "--no-extend", "--no-radix-hit"], capture_output=True, text=True, timeout=900)
+                        "--no-extend", "--no-radix-hit", "--no-extra"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert out["n_gpus"] == 1 and out["config"]["step_launch"].startswith("hip-graph")
-    assert out["roofline"]["launches"] == 3 and out["roofline"]["avg_launch_ms"] > 0
+    # default output: the full record on a '[bench-full] ' line, then ONE compact JSON line, last
+    lines = r.stdout.splitlines()
+    full = json.loads(next(ln for ln in lines if ln.startswith("[bench-full] "))[len("[bench-full] "):])
+    assert full["n_gpus"] == 1 and full["config"]["step_launch"].startswith("hip-graph")
+    assert full["roofline"]["launches"] == 3 and full["roofline"]["avg_launch_ms"] > 0
+    assert lines[-1].startswith("{") and len(lines[-1]) < 2560
+    out = json.loads(lines[-1])
+    assert out["value"] == pytest.approx(full["value"], rel=1e-3) and out["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], abs=1e-4)
+    assert out["config"]["parallelism"] == "tp8" and "tp_sim" in out["config"]
+
+
+def test_compact_line_carries_both_halves_of_the_metric():
+    """The final line of a default run: under 2.5 KB, the contract's keys, and -- inside the
+    `roofline` dict -- the extend half of the metric plus one number per other leg.  Fed with a committed full record."""
+    bench = _load_bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    c = bench.compact_record(full)
+    line = json.dumps(c)
+    assert len(line) < 2560, len(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    assert set(c["config"]) >= {"workload", "global_batch", "seq_len", "parallelism"}
+    rf = c["roofline"]
+    assert rf["bound"] == "hbm" and rf["frac"] == pytest.approx(full["roofline"]["frac"], abs=1e-4)
+    e = rf["extend"]
+    assert e["frac"] == pytest.approx(full["extend"]["roofline"]["frac"], abs=1e-4)
+    assert e["kernel_tflops"] == pytest.approx(full["extend"]["kernel_only"]["tflops"], rel=1e-3)
+    assert e["frac"] == pytest.approx(e["flops_per_launch"] / (e["ms_per_launch"] * 1e-3) / 1e12 / 2500.0, rel=1e-3)
+    assert {"kernel", "ms_per_launch", "workload", "tflops"} <= set(e)
+    assert rf["mla_decode_fp8_op_frac"] == pytest.approx(full["mla_decode"]["fp8_rows"]["op_frac_of_hbm_peak"], abs=1e-4)
+    assert rf["tp8_kernel_frac"] == pytest.approx(full["extra"]["tp_sim"]["tp8"]["kernel_frac_of_hbm_peak"], abs=1e-4)
+    assert c["cpu_baseline"]["kind"] in ("reference", "port") and c["cpu_baseline"]["cores"] >= 1
+    # an errored leg must not take the line down
+    full["extend"] = {"error": "boom"}
+    assert bench.compact_record(full)["roofline"]["extend"] == {"error": "boom"}
