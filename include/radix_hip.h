@@ -24,12 +24,13 @@
 extern "C" {
 #endif
 
-/* 11 (round 4): rx_qknorm_rope_store_kv (fused QK-norm + RoPE + store).
+/* 12 (round 5): rx_split_items_guarded.
+ * 11 (round 4): rx_qknorm_rope_store_kv (fused QK-norm + RoPE + store).
  * 10 (round 4): rx_decode_params.rope_* (fused RoPE of the latent decode).
  * 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
  * 8 (round 3): rx_split_items; rx_decode_params.split_items / split_items_count / split_items_cap /
  * split_items_wgs_per_cu and extra_index / extra_rows; rx_num_kv_splits_balanced gained wg_target_mixed. */
-#define RX_ABI_VERSION 11
+#define RX_ABI_VERSION 12
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -150,6 +151,14 @@ int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs,
  * copy of the lengths).  One launch of one block, no host sync. */
 int rx_split_items(const int32_t* num_kv_splits, const int32_t* order, int bs, int32_t* items, int32_t* count, int cap,
                    void* stream);
+
+/* The same table for a caller that sized cap from a BOUND (graph replay: the counts are refilled on the device, the
+ * grid is fixed at capture): if the schedule holds more live pairs than cap (>= bs, checked), the schedule itself is
+ * replaced -- every num_kv_splits[b] becomes 1, the table becomes the bs whole-request pairs in `order`, count[0] = bs
+ * and overflow[0] (optional, sticky: only ever set) = 1.  The decode launch that follows reads a consistent schedule:
+ * slower than the one asked for, never a request without its workgroups. */
+int rx_split_items_guarded(int32_t* num_kv_splits, const int32_t* order, int bs, int32_t* items, int32_t* count, int cap,
+                           int32_t* overflow, void* stream);
 
 /* ---- KV buffer addressing shared by decode / extend ------------------------------------
  * element offset of (slot, kv_head) = (slot / page_size) * page_stride

@@ -36,6 +36,22 @@ from ..forward_batch import ForwardBatch
 from ..mem_cache import memory_pool as _own_pools
 
 
+def split_pairs_bound(bs: int, slots: int, wgpr: int, cus: int) -> int:
+    """max over all length vectors of sum(rx_num_kv_splits_balanced(...)) for ``bs`` requests, cap ``slots``, ``wgpr``
+    workgroups per (request, split) pair and wg_target = 2 x ``cus`` (any wg_target_mixed the backend passes), rule by rule:
+    * even share / rounds rule / 3-per-CU mixed budget: a request takes <= ceil(len / t*) <= len / t* + 1 pieces with
+      t* >= work / budget, so sum <= bs + budget / wgpr + 1, budget <= 3 x cus;
+    * fill rule, near-uniform batch below 3 workgroups per CU (live x wgpr < 3 cus): ONE count <= min(slots, 6) for every
+      live request (ADVICE r4: 257 requests x 6 = 1542 pairs against the old bound's 1026);
+    * fill rule, everybody cut (live x wgpr < 0.7 cus): one count <= ceil(2 cus / (live x wgpr)) + 8."""
+    even = bs + -(-3 * cus // wgpr) + 1
+    live3 = min(bs, max(0, -(-3 * cus // wgpr) - 1))         # most live requests the < 3-per-CU rule admits
+    fill = (min(slots, 6) - 1) * live3 + bs
+    live07 = min(bs, max(0, -(-7 * cus // (10 * wgpr))))     # ... the everybody-is-cut rule admits
+    cut = -(-2 * cus // wgpr) + 9 * live07 + bs
+    return min(bs * slots, max(even, fill, cut))
+
+
 @dataclass
 class ForwardMetadata:
     """Subset of triton_backend.py:91-113 that the dense path uses."""
@@ -525,7 +541,10 @@ class HipRadixAttnBackend:
         wgpr = self.num_kv_head * ((group + 15) // 16)
         # split requests share ~wg_target workgroups: (request, split) pairs with a partial <= that / blocks per request,
         # with slack for rounding up -- what the in-kernel stage 2's size bound looks at, not bs * slots
-        pairs = 2 * max(wg_target, wg_mixed) // wgpr + 8
+        # (the fill rule hands a near-uniform batch ONE count for everybody: the exact host count when the lengths are
+        # known, else the same bound the graph path sizes its table by -- ADVICE r4)
+        pairs = (int(host_counts[host_counts > 1].sum()) if host_pairs is not None  # (a request with one split writes none)
+                 else self._split_pairs_bound(bs, S_cap))
         if self._merge_counters is not None and S % 8:
             S8 = (S + 7) // 8 * 8
             if min(bs * S8, pairs) * self.num_head * self.v_head_dim * 4 <= (4 << 20):
@@ -552,7 +571,10 @@ class HipRadixAttnBackend:
         items = None
         if use_items:
             if use_graph_bufs:
-                items = self._graph["split_items"].build(num_kv_splits, order, cap=self._split_pairs_bound(bs, S_cap))
+                # the cap is a BOUND here (the counts are refilled on the device before every replay): the guarded build
+                # replaces a schedule that outgrows it by whole-request passes instead of dropping pairs
+                items = self._graph["split_items"].build(num_kv_splits, order, cap=self._split_pairs_bound(bs, S_cap),
+                                                         guarded=True)
             else:
                 mixed = three and bool((host_counts > 1).any() and (host_counts == 1).any())
                 items = ops.SplitItems(host_pairs if host_pairs is not None else bs * S_cap, self.device).build(
@@ -565,12 +587,11 @@ class HipRadixAttnBackend:
                                request_order=order, partial_pairs_hint=pairs, split_items=items)
 
     def _split_pairs_bound(self, bs: int, slots: int) -> int:
-        """An upper bound of the (request, split) pairs rx_num_kv_splits_balanced can hand out: every request takes at
-        most ceil(len / t*) <= len / t* + 1 pieces and sum(len) / t* <= workgroup budget / workgroups per pair (t* >= the
-        even share of the LARGER budget; the overshoot step only raises it)."""
+        """An upper bound of the (request, split) pairs rx_num_kv_splits_balanced can hand out to ``bs`` requests with
+        ``slots`` as its cap, whatever the lengths (split_pairs_bound below; tests/test_cabi_and_host.py sweeps the host
+        mirror against it)."""
         group = max(1, self.num_head // self.num_kv_head)
-        wgpr = self.num_kv_head * ((group + 15) // 16)
-        return min(bs * slots, bs + -(-3 * self.device_core_count // wgpr) + 1)
+        return split_pairs_bound(bs, slots, self.num_kv_head * ((group + 15) // 16), self.device_core_count)
 
     def _decode_honours_split_items(self) -> bool:
         """rx_decode_attn reads the (request, split) table only in its MFMA kernel (head dims 64 / 96 / 128 / 256 with

@@ -1031,8 +1031,11 @@ __global__ __launch_bounds__(1024) void num_kv_splits_balanced_kernel(const void
 
 namespace rx {
 // one block: exclusive scan of the split counts in launch order, then the pairs (rx_decode_params.split_items)
-__global__ __launch_bounds__(1024) void split_items_kernel(const int32_t* __restrict__ splits, const int32_t* __restrict__ order,
-                                                           int bs, int32_t* __restrict__ items, int32_t* __restrict__ count, int cap) {
+// fix != NULL (rx_split_items_guarded; == splits, writable): a schedule with more live pairs than cap is REPLACED by one
+// whole pass per request (every count 1, bs pairs; cap >= bs) and overflow[0] is set -- never a table with pairs missing
+__global__ __launch_bounds__(1024) void split_items_kernel(const int32_t* splits, const int32_t* __restrict__ order,
+                                                           int bs, int32_t* __restrict__ items, int32_t* __restrict__ count, int cap,
+                                                           int32_t* fix, int32_t* __restrict__ overflow) {
   __shared__ int32_t wsum[16];
   __shared__ int32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1063,7 +1066,21 @@ __global__ __launch_bounds__(1024) void split_items_kernel(const int32_t* __rest
     if (tid == 1023) carry_s = off + x;
     __syncthreads();
   }
-  if (tid == 0) count[0] = carry_s;
+  const int32_t total = carry_s;
+  if (fix && total > cap) {  // wave-uniform: carry_s is one LDS word behind the loop's last barrier
+    for (int i = tid; i < bs; i += 1024) {
+      const int b = order ? order[i] : i;
+      fix[b] = 1;
+      items[2 * i] = b;
+      items[2 * i + 1] = 0;
+    }
+    if (tid == 0) {
+      count[0] = bs;
+      if (overflow) overflow[0] = 1;
+    }
+    return;
+  }
+  if (tid == 0) count[0] = total;
 }
 }  // namespace rx
 
@@ -1077,8 +1094,22 @@ int rx_split_items(const int32_t* num_kv_splits, const int32_t* order, int bs, i
   }
   RX_REQUIRE(num_kv_splits && (items || cap == 0), "rx_split_items: null pointer");
   hipLaunchKernelGGL(rx::split_items_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), num_kv_splits, order, bs,
-                     items, count, cap);
+                     items, count, cap, static_cast<int32_t*>(nullptr), static_cast<int32_t*>(nullptr));
   return check_launch("rx_split_items");
+}
+
+int rx_split_items_guarded(int32_t* num_kv_splits, const int32_t* order, int bs, int32_t* items, int32_t* count, int cap,
+                           int32_t* overflow, void* stream) {
+  RX_REQUIRE(bs >= 0 && cap >= bs, "rx_split_items_guarded: cap must hold one pair per request (cap >= bs)");
+  RX_REQUIRE(count, "rx_split_items_guarded: null count");
+  if (bs == 0) {
+    hipMemsetAsync(count, 0, sizeof(int32_t), static_cast<hipStream_t>(stream));
+    return check_launch("rx_split_items_guarded");
+  }
+  RX_REQUIRE(num_kv_splits && items, "rx_split_items_guarded: null pointer");
+  hipLaunchKernelGGL(rx::split_items_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), num_kv_splits, order, bs,
+                     items, count, cap, num_kv_splits, overflow);
+  return check_launch("rx_split_items_guarded");
 }
 
 int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int wg_target,

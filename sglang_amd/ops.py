@@ -498,13 +498,18 @@ class SplitItems:
     def __init__(self, max_items: int, device):
         self.items = torch.zeros(max(1, int(max_items)) * 2, dtype=torch.int32, device=device)
         self.count = torch.zeros(1, dtype=torch.int32, device=device)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)  # sticky: a guarded build replaced a schedule
         self.cap = 0
         self.wgs_per_cu = 0
 
-    def build(self, num_kv_splits, request_order=None, cap: Optional[int] = None, wgs_per_cu: int = 0):
+    def build(self, num_kv_splits, request_order=None, cap: Optional[int] = None, wgs_per_cu: int = 0,
+              guarded: bool = False):
         """num_kv_splits int32[bs] (device), request_order int32[bs] or None; cap defaults to the table's size.
         wgs_per_cu = 3: the schedule was made for 3 x CUs pieces of a MIXED batch (get_num_kv_splits_balanced,
-        wg_target_mixed) -- the launch takes the kernel's three-per-CU instance (rx_decode_params.split_items_wgs_per_cu)."""
+        wg_target_mixed) -- the launch takes the kernel's three-per-CU instance (rx_decode_params.split_items_wgs_per_cu).
+        guarded (cap is a BOUND, not a count: graph replay): rx_split_items_guarded -- a schedule with more live pairs
+        than cap is replaced on the device by one whole pass per request (num_kv_splits is rewritten) and
+        ``self.overflow`` is set, instead of a table with pairs missing."""
         self.wgs_per_cu = int(wgs_per_cu)
         _require_cuda(num_kv_splits, request_order)
         bs = num_kv_splits.shape[0]
@@ -515,6 +520,11 @@ class SplitItems:
         self.cap = self.items.numel() // 2 if cap is None else int(cap)
         if self.cap > self.items.numel() // 2:
             raise ValueError(f"SplitItems.build: cap {self.cap} exceeds the table ({self.items.numel() // 2} pairs)")
+        if guarded:
+            st = _L.load().rx_split_items_guarded(_ptr(num_kv_splits), _ptr(request_order), bs, _ptr(self.items),
+                                                  _ptr(self.count), self.cap, _ptr(self.overflow), _stream(num_kv_splits))
+            _L.check(st, "rx_split_items_guarded")
+            return self
         st = _L.load().rx_split_items(_ptr(num_kv_splits), _ptr(request_order), bs, _ptr(self.items), _ptr(self.count),
                                       self.cap, _stream(num_kv_splits))
         _L.check(st, "rx_split_items")

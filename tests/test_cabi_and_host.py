@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(l, s), f"{s} declared in include/radix_hip.h but not exported"
         assert s in lib.PROTOTYPES, f"{s} has no ctypes prototype"
-    assert l.rx_version() == lib.RX_ABI_VERSION == 11
+    assert l.rx_version() == lib.RX_ABI_VERSION == 12
     assert [l.rx_abi_sizeof(i) for i in range(4)][3] == -1 and l.rx_abi_sizeof(1) > 0
 
 
@@ -251,3 +251,37 @@ def test_the_launch_path_reads_no_environment_and_carries_no_wrong_result_builds
             if re.search(r"results are (wrong|garbage)|outputs are clobbered|_STAMP\b|_ABL\b", line):
                 hits.append((os.path.basename(path), i, line.strip()[:60]))
     assert not hits, hits
+
+
+def test_split_pairs_bound_covers_every_rule_of_the_balanced_schedule():
+    """the graph-replay path sizes the (request, split) table and the decode grid from
+    split_pairs_bound; the fill rule hands a near-uniform batch one count <= 6 for EVERY request, which the old
+    even-share bound (bs + 3 CUs / wgpr + 1) did not cover (bs 257, Hq 8 / Hkv 1: 1542 pairs vs 1026).  Sweep the host
+    mirror of rx_num_kv_splits_balanced over uniform and ragged batches, every rule (wg_target_mixed -1 / = / 3 per CU)."""
+    import numpy as np
+
+    from sglang_amd import ops
+    from sglang_amd.attention.backend import split_pairs_bound
+
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for cus in (256, 304):
+        for hq, hkv in ((8, 1), (16, 2), (32, 4), (4, 4), (32, 8), (64, 8), (8, 8)):
+            group = max(1, hq // hkv)
+            wgpr = hkv * ((group + 15) // 16)
+            for slots in (8, 32):
+                for mt in (128, 1024):
+                    bss = list(range(1, 40)) + list(range(40, 1025, 7)) + [129, 257, 320, 1024]
+                    for bs in bss:
+                        batches = [np.full(bs, n) for n in (1024, 4096, 16384)]
+                        batches.append(rng.integers(1, 8192, size=bs))
+                        mixed = np.full(bs, 1024)
+                        mixed[0] = 32768
+                        batches.append(mixed)
+                        for lens in batches:
+                            for wgm in (-1, 2 * cus, 3 * cus):
+                                n = ops.balanced_kv_splits_host(lens, hq, hkv, slots, 2 * cus, mt, wgm)
+                                bound = split_pairs_bound(bs, slots, wgpr, cus)
+                                assert int(n.sum()) <= bound, (cus, hq, hkv, slots, mt, bs, wgm, int(n.sum()), bound)
+                                worst = max(worst, int(n.sum()) / bound)
+    assert worst > 0.9  # and the bound is not vacuous: some batch comes within 10 % of it

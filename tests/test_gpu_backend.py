@@ -935,6 +935,70 @@ def test_graph_replay_refreshes_static_metadata(index_mode, policy):
     assert hs.pool.check_errors() == 0
 
 
+@pytest.mark.parametrize("bs,ntok,cap_to_bs", [(257, 1536, False), (129, 2048, False), (257, 1536, True)])
+def test_graph_replay_of_a_fill_rule_batch_runs_every_pair(bs, ntok, cap_to_bs):
+    """a TP=8 shard (Hq 8 / Hkv 1) replaying a near-uniform batch from a HIP graph.  The fill rule
+    gives every request the same count (up to 6), far more (request, split) pairs than the even-share bound the graph
+    path used to size its table and grid with -- the shortest requests then merged partial rows nobody wrote.
+    Replay must equal the eager step bit for bit and meet the oracle.  cap_to_bs: the bound is forced down to bs, so
+    the guarded build must replace the schedule (whole requests) rather than drop pairs -- still correct."""
+    from sglang_amd.attention import backend as bk
+    from sglang_amd.forward_batch import ForwardBatch
+
+    hq, hkv, d = 8, 1, 128
+    hs = _Harness(16, hq, hkv, d, torch.bfloat16, "shuffled_pages", "paged", max_ctx=ntok + 64, max_reqs=bs + 1,
+                  size=(bs + 2) * (ntok + 32))
+    be = hs.backend
+    if cap_to_bs:
+        be._split_pairs_bound = lambda b, slots: b
+    be.init_cuda_graph_state(bs, bs)
+    fill = be.get_cuda_graph_seq_len_fill_value()
+    s_rpi = torch.zeros(bs, dtype=torch.int64, device=DEV)
+    s_seq = torch.full((bs,), fill, dtype=torch.int64, device=DEV)
+    s_loc = torch.zeros(bs, dtype=torch.int64, device=DEV)
+    q, k, v = hs.rand(bs, hq * d), hs.rand(bs, hkv * d), hs.rand(bs, hkv * d)
+    fb_g = ForwardBatch.for_decode(s_rpi, s_seq, s_loc, torch.full((bs,), fill, dtype=torch.int64))
+    be.init_forward_metadata_out_graph(fb_g, in_capture=True)
+    graph, out = _capture(lambda: hs.layer(q, k, v, fb_g, be))
+    rows = hs.r2t.alloc(bs)
+    prefix = [ntok - 1] * bs
+    hs.fill_prefix(rows, prefix)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    seq = torch.tensor([p + 1 for p in prefix], dtype=torch.int64)
+    last = hs.r2t.req_to_token[rpi, ntok - 2].to(torch.int64)
+    loc = hs.alloc.alloc_decode(seq.to(DEV), seq, last)
+    hs.r2t.req_to_token[rpi, ntok - 1] = loc.to(torch.int32)
+    s_rpi.copy_(rpi); s_seq.copy_(seq.to(DEV)); s_loc.copy_(loc)
+    fb_r = ForwardBatch.for_decode(s_rpi, s_seq, s_loc, seq)
+    be.init_forward_metadata_out_graph(fb_r)
+    graph.replay()
+    torch.cuda.synchronize()
+    replayed = out.clone()
+    md = be.forward_metadata
+    counts = md.num_kv_splits.cpu().numpy()
+    live = int(md.split_items.count.item())
+    assert live == int(counts.sum()) <= md.split_items.cap        # the table holds every live pair
+    if cap_to_bs:
+        assert int(md.split_items.overflow.item()) == 1 and (counts == 1).all()
+    else:
+        assert int(md.split_items.overflow.item()) == 0 and counts.max() > 1
+        if bs == 257 and be.device_core_count == 256:
+            assert live == 6 * bs > bs + 3 * be.device_core_count + 1   # beyond the OLD bound: the case of the finding
+        assert live <= bk.split_pairs_bound(bs, int(md.max_kv_splits), 1, be.device_core_count)
+    kb, vb = hs.pool.get_kv_buffer(0)
+    want, absw = parity.want_and_absw(orc.sdpa_decode_req_to_token, (
+        _bits(q.view(bs, hq, d)), _bits(kb), _bits(vb), _bits(hs.r2t.req_to_token), np.array(rows), seq.numpy(),
+        d ** -0.5), (2,))
+    parity.check_out(replayed.view(bs, hq, d).float().cpu().numpy(), want, replayed.dtype,
+                     ("graph replay, fill rule", bs, ntok, cap_to_bs), ulps=1, absw=absw)
+    if not cap_to_bs:
+        fb_e = ForwardBatch.for_decode(rpi, seq.to(DEV), loc, seq)
+        be.init_forward_metadata(fb_e)
+        eager = hs.layer(q, k, v, fb_e, be)
+        assert torch.equal(replayed, eager)
+    assert hs.pool.check_errors() == 0
+
+
 def test_target_verify_graph_replay_refreshes_indices_and_mask():
     """TARGET_VERIFY under a HIP graph: qo_indptr / kv_indices / mask_indptr / the mask bytes are address-stable
     and refilled by init_forward_metadata_out_graph before each replay (triton_backend.py:1016-1063)."""

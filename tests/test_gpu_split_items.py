@@ -34,6 +34,37 @@ def test_split_items_table_matches_its_definition():
                 assert (got[n:] == -7).all()                           # nothing written past cap
 
 
+def test_guarded_build_replaces_a_schedule_that_outgrows_its_cap():
+    """rx_split_items_guarded: within cap = the plain table, counts untouched; beyond cap the SCHEDULE is
+    replaced (every count 1, bs whole-request pairs in launch order, count = bs, overflow set) -- never dropped pairs."""
+    from sglang_amd import ops
+
+    rng = np.random.default_rng(1)
+    for bs in (1, 9, 257, 2500):
+        splits = rng.integers(1, 7, size=bs).astype(np.int32)
+        order = rng.permutation(bs).astype(np.int32)
+        total = int(splits.sum())
+        for use_order in (False, True):
+            od = torch.from_numpy(order).to(DEV) if use_order else None
+            want = [[int(b), s] for b in (order if use_order else range(bs)) for s in range(int(splits[b]))]
+            for cap in (total, total + 3, max(bs, total - 1), bs):
+                si = ops.SplitItems(cap, DEV)
+                si.items.fill_(-7)
+                sp = torch.from_numpy(splits).to(DEV)
+                si.build(sp, od, cap=cap, guarded=True)
+                torch.cuda.synchronize()
+                got = si.items.cpu().numpy().reshape(-1, 2)
+                if total <= cap:
+                    assert int(si.count.item()) == total and int(si.overflow.item()) == 0
+                    assert got[:total].tolist() == want and sp.cpu().numpy().tolist() == splits.tolist()
+                else:
+                    assert int(si.count.item()) == bs and int(si.overflow.item()) == 1
+                    assert sp.cpu().numpy().tolist() == [1] * bs
+                    assert got[:bs].tolist() == [[int(b), 0] for b in (order if use_order else range(bs))]
+    with pytest.raises(Exception):  # cap < bs cannot hold even the whole-request schedule
+        ops.SplitItems(4, DEV).build(torch.ones(8, dtype=torch.int32, device=DEV), None, cap=4, guarded=True)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("lookup", ["paged", "indices"])
 def test_decode_with_split_items_is_bit_identical_to_split_slots(dtype, lookup):
