@@ -62,7 +62,7 @@ const char* rx_last_error(void);
  * in the library's symbol table and fails if one of them has no parity case that provably ran it.
  * The few process-wide switches that override the default choice (A/B of kernel forms) are named ints: set through
  * rx_set_option, read once from RX_OPT_<NAME> at load -- the launch path itself never reads the environment.
- * Names: ext32_autopack, ext32_small_wg, ext32_plain, extend_16x16_d128, extend_d256, extend_d256_at128,
+ * Names: ext32_autopack, ext32_small_wg, ext32_plain, ext64, extend_16x16_d128, extend_d256, extend_d256_at128,
  * extend_d256_at64, extend_d256_at96, extend_nd, extend_nd_big, extend_mla, extend_mla_shared_v, decode_mla8_dma. */
 const char* rx_last_dispatch(void);
 int rx_set_option(const char* name, int value);

@@ -37,6 +37,8 @@ static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, 
 #undef RX_E32
 }
 
+void launch_extend64(const Ext32Args& a, bool bf16, bool idx64, bool linear, hipStream_t s);  // rx_extend64.hip
+
 int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const Options& opt = options();
   Ext32Args a = make_ext32_args(p);
@@ -102,6 +104,12 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.mblocks = (p->max_extend_len * a.q_pack + nw * 32 - 1) / (nw * 32);
   const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0;
   const bool plain = plain_any && a.q_pack == 1;
+  // Option ext64 (default off: measured 0.83x of the eight-wave kernel on the config-3 chunk): PLAIN eight-wave
+  // calls (packed or not) as the same 256-row blocks on FOUR waves of 64 rows, one per SIMD (rx_extend64.hip)
+  if (opt.ext64 && !small_wg && (packed_plain || plain) && !(a.page_size >= 0 && !linear)) {
+    launch_extend64(a, bf, i64, linear, s);
+    return RX_OK;
+  }
   if (packed_plain && !small_wg) {  // packed rows on the PLAIN loop (GQA 4 / 8)
     if (a.q_pack == 4) launch32_nw<8, false, true, 4>(a, bf, i64, linear, false, s);
     else launch32_nw<8, false, true, 8>(a, bf, i64, linear, false, s);

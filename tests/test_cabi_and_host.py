@@ -285,3 +285,29 @@ def test_split_pairs_bound_covers_every_rule_of_the_balanced_schedule():
                                 assert int(n.sum()) <= bound, (cus, hq, hkv, slots, mt, bs, wgm, int(n.sum()), bound)
                                 worst = max(worst, int(n.sum()) / bound)
     assert worst > 0.9  # and the bound is not vacuous: some batch comes within 10 % of it
+
+
+def test_extend64_owns_its_accumulator_registers():
+    """rx::extend_mfma64_kernel keeps O and Q^T in accumulator registers it owns BY NAME (a[0:191], every MFMA an asm
+    statement).  That is only sound while hipcc itself never touches an AGPR in that kernel -- a spill into a[..] or a
+    v_accvgpr_* of its own would corrupt the accumulators silently (cdna_hip_programming.md 5.7 item 4).  Compile the
+    library's source to ISA and audit every instance: no accumulator reference outside the kernel's asm statements, no
+    spill, no scratch."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+
+    from sglang_amd import build as b
+
+    hipcc = b._hipcc()
+    if not (hipcc and shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rx_extend64.s")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *b.EXTRA_FLAGS["rx_extend64.hip"], "-I", os.path.join(ROOT, "include"),
+               "-I", b.CSRC, "-S", "--cuda-device-only", os.path.join(b.CSRC, "rx_extend64.hip"), "-o", out]
+        subprocess.run(cmd, check=True, capture_output=True)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_acc_ownership.py"), out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-3000:]
+        assert r.stdout.count("all inside the kernel's asm statements") == 24, r.stdout  # 2 dtypes x 2 index types x 2 x 3 packings

@@ -11,14 +11,16 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LIB = os.path.join(ROOT, "tools", "probe", "libext32_dev.so")
-SRC = os.path.join(ROOT, "tools", "probe", "ext32_dev.hip")
+DEV = os.environ.get("DEV", "32")  # DEV=64: rx::extend_mfma64_kernel's dev variants (tools/probe/ext64_dev.hip: VARIANTS = its bit masks)
+LIB = os.path.join(ROOT, "tools", "probe", f"libext{DEV}_dev.so")
+SRC = os.path.join(ROOT, "tools", "probe", f"ext{DEV}_dev.hip")
 VARS = [int(x) for x in os.environ.get("VARIANTS", "0").split(",")]
 
 
 def build():
     from sglang_amd import build as b
-    deps = [SRC, os.path.join(b.CSRC, "rx_extend32_kernel.inc"), os.path.join(b.CSRC, "rx_common.h")]
+    deps = [SRC, os.path.join(b.CSRC, "rx_extend32_kernel.inc"), os.path.join(b.CSRC, "rx_extend64_kernel.inc"),
+            os.path.join(b.CSRC, "rx_common.h")]
     tag = LIB + ".vars"
     want = ",".join(str(v) for v in sorted(set(VARS)))
     if (os.path.exists(LIB) and os.path.exists(tag) and open(tag).read() == want
@@ -26,7 +28,7 @@ def build():
         return
     cases = " ".join(f"RX_V({v})" for v in sorted(set(VARS)) if v != 0)
     cmd = [b._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-           *b.EXTRA_FLAGS["rx_extend32.hip"], "-I", os.path.join(ROOT, "include"), "-I", b.CSRC,
+           *b.EXTRA_FLAGS[f"rx_extend{DEV}.hip"], "-I", os.path.join(ROOT, "include"), "-I", b.CSRC,
            f"-DRX_DEV_VARIANT_CASES={cases}", SRC, "-o", LIB]
     print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
@@ -63,15 +65,16 @@ def main():
     qo = (torch.arange(chunk + 1, device=dev) * E).to(torch.int64)
     outs = {v: torch.zeros(T, HQ, D, device=dev, dtype=torch.bfloat16) for v in VARS}
     dl = C.CDLL(LIB)
-    dl.rx_dev_extend32.restype = C.c_int
-    dl.rx_dev_extend32.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    entry = getattr(dl, f"rx_dev_extend{DEV}")
+    entry.restype = C.c_int
+    entry.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     causal = not os.environ.get("NONCAUSAL")  # NONCAUSAL=1: every new-token tile is a full tile (what the diagonal costs: compare the times)
     params = {v: ops._extend_params(q, ke, ve, outs[v], kb, vb, qo, kvp, kvi, None, causal, None, E, 1.0, 1.0,
                                     sm_scale=D ** -0.5, page_size=ps, kv_layout=lay) for v in VARS}
     stream = torch.cuda.current_stream().cuda_stream
 
     def run(v):
-        rc = dl.rx_dev_extend32(C.byref(params[v]), v, stream)
+        rc = entry(C.byref(params[v]), v, stream)
         assert rc == 0, (v, rc)
 
     # production kernel as the reference output

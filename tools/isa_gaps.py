@@ -60,10 +60,15 @@ def main():
         if ln and not ln.startswith((".", "#")) or re.match(r"\.LBB\d+_\d+:", ln):
             lines.append(ln)
     pos = {ln[:-1]: i for i, ln in enumerate(lines) if ln.endswith(":")}
-    # innermost loop with the most MFMAs
+    # innermost loop with the most MFMAs (or `loop:<label>`: the loop that starts at that label, up to its last backward branch)
     best = None
+    forced = next((a[5:] for a in sys.argv[3:] if a.startswith("loop:")), None)
     for i, ln in enumerate(lines):
-        m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", ln)
+        m = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
+        if forced:
+            if m and m.group(1) == forced and pos[forced] < i:
+                best = (pos[forced], i, sum(1 for x in lines[pos[forced]:i] if x.startswith("v_mfma")))
+            continue
         if m and m.group(1) in pos and pos[m.group(1)] < i:
             lo = pos[m.group(1)]
             n = sum(1 for x in lines[lo:i] if x.startswith("v_mfma"))
