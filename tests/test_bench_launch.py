@@ -91,6 +91,36 @@ def test_bench_gpus_2_runs_two_ranks_on_one_gpu(extra):
 
 
 @pytest.mark.gpu
+def test_bench_gpus_8_first_contact_on_one_gpu():
+    """The target world size before the driver's SCALE run meets it: `python bench.py --gpus 8`
+    self-launches eight ranks (all on device 0, gloo reducing through the host), every rank passes first_contact() --
+    peer-access matrix, the all-reduce checked against the fp32 sum -- the TP = 8 shard (Hq 4 / Hkv 1 per rank) steps
+    from HIP graphs or eagerly, and the peer-to-peer two-shot kernel's own eight-rank child leg reports no device-side
+    timeout."""
+    env = dict(os.environ, RX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--settle", "1", "--bs", "16", "--ctx", "512", "--layers", "2", "--no-cpu-baseline", "--full-json"],
+                       capture_output=True, text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "tp8" and "Hq=4,Hkv=1" in out["config"]["workload"]
+    assert len(out["roofline"]["per_rank_frac"]) == 8
+    fc = out["first_contact"]
+    assert fc["ranks_seen"] == list(range(8)) and fc["all_reduce_check"]["ok_on_every_rank"] and len(fc["can_access_peer"]) == 8
+    leg = out["all_reduce"]["p2p_two_shot_leg"]
+    assert "error" not in leg, leg
+    assert leg["device_side_timeouts"] == 0 and leg["first_contact"]["ok_on_every_rank"]
+    assert out["extend"]["sharding"].startswith("tp8") and out["extend"]["tflops"] > 0
+    # the compact line of an N > 1 run keeps the collective's figures
+    c = _load_bench().compact_record(out)
+    assert c["n_gpus"] == 8 and c["first_contact_ok"] and "p2p_two_shot" in c["all_reduce"] and len(json.dumps(c)) < 3000
+
+
+@pytest.mark.gpu
 def test_bench_tp_sim_shard_replays_from_hip_graphs():
     """One rank's shard of a TP=8 job (no collective) under graph replay: the step is launched as HIP-graph replays
     and the roofline kernel is still timed live."""

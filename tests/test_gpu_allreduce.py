@@ -29,7 +29,7 @@ def parts_for(seed, n, dt):
     return [torch.randn(n, generator=g).to(dt) for _ in range(world)]   # same on every rank
 
 for it, (n, dt) in enumerate([(8, torch.bfloat16), (256 * 4096, torch.bfloat16), (1000 * 8, torch.float16),
-                              (2 << 20, torch.bfloat16), (4096, torch.float16)] * 3):
+                              (2 << 20, torch.bfloat16), (4096, torch.float16)] * int(os.environ.get("AR_REPS", "3"))):
     parts = parts_for(100 * it, n, dt)
     x = parts[rank].to(dev)
     want = sum(p.float() for p in parts).to(dt)                          # fp32 sum in rank order, one rounding
@@ -60,7 +60,7 @@ graph = torch.cuda.CUDAGraph()
 with torch.cuda.graph(graph):
     for b_ in bufs:
         ar.all_reduce(b_)
-for rep in range(3):
+for rep in range(int(os.environ.get("AR_REPS", "3"))):
     wants = []
     for j, b_ in enumerate(bufs):
         parts = parts_for(1000 + 10 * rep + j, n, torch.bfloat16)
@@ -141,7 +141,8 @@ for n, dt in [(7, torch.bfloat16), (1024, torch.float32), ((4 << 20) // 2 + 8, t
     tp.all_reduce(x)
     torch.cuda.synchronize()
     want = sum(p.float() for p in parts)
-    if not torch.allclose(x.cpu().float(), want, rtol=2e-2, atol=2e-2):
+    # (the backend sums in the tensor's own 16-bit type: one rounding per rank, each up to half an ulp of a partial sum)
+    if not torch.allclose(x.cpu().float(), want, rtol=2e-2, atol=2e-2 * world):
         ok = False
         print(f"rank {rank} fallback n {n} {dt}: max diff", (x.cpu().float() - want).abs().max().item(), flush=True)
 parts = parts_for(99, 2 * 4096, torch.bfloat16)
@@ -169,18 +170,21 @@ sys.exit(0 if ok else 1)
 '''
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 6, 8])
 def test_custom_allreduce_across_processes(world, tmp_path):
+    """World sizes of the reference's custom all-reduce (custom_all_reduce.py:41 _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]);
+    8 = kArMaxWorld = the target node.  6 is the one size where the element count does not divide by the ranks."""
     script = tmp_path / "ar_worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, RX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + world),
-               WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+               WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               AR_REPS="3" if world <= 4 else "1")  # (6 / 8 processes time-slice ONE GPU here: every call waits for all of them)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=240)
+            out, _ = p.communicate(timeout=240 + 30 * world)
         except subprocess.TimeoutExpired:
             p.kill()
             out, _ = p.communicate()
