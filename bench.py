@@ -774,6 +774,93 @@ def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=20, shape
                          "kernel": "rx::" + kernel_name}}
 
 
+def extend_peaked_bench(args, dev, nchunks=20):
+    """The config-3 chunk again, on scores that are NOT the bench's N(0, 1): sigma = 4 nats (q scaled by 4) plus a
+    recency ramp of +4 nats over the 4096 positions (a constant query coordinate against a key coordinate that grows with
+    the position).  The D = 128 kernel's softmax takes exp2 against a STANDING reference max and redoes a 32-token block
+    the classic way only when a lane's partial row sum exceeds 4096 (rx_extend32_kernel.inc, sm_slice): on gaussian
+    scores that happens on a row's first tile only, on peaked ones it can happen anywhere -- a second softmax of the
+    block each time.  Reported: the kernel's TFLOP/s on this input, the same launch on the N(0, 1) input of the headline
+    leg (same pool, same process, interleaved), and the redo RATE (blocks redone / blocks, rx_debug_counters: one launch
+    of the counting twin of the kernel on each input)."""
+    from sglang_amd import lib as rxlib
+    from sglang_amd import ops
+    from sglang_amd.mem_cache.memory_pool import MHATokenToKVPool
+
+    D, HQ, HKV = 128, 32, 8
+    P, E, chunk = 3584, 512, 32
+    ps = args.page_size
+    g = torch.Generator(device=dev).manual_seed(2)
+    pre_pages = (P + ps - 1) // ps
+    pools, qs, kes, ves = {}, {}, {}, {}
+    perm = torch.randperm(pre_pages, device=dev, generator=g) + 1
+    tok = torch.arange(ps, device=dev)[None, :]
+    prefix_slots = (perm[:, None] * ps + tok).reshape(-1)[:P]
+    T = chunk * E
+    for name in ("gaussian", "peaked"):
+        pool = MHATokenToKVPool((pre_pages + 1) * ps, ps, torch.bfloat16, HKV, D, 1, dev, use_hnd=args.kv_layout == "hnd")
+        kb, vb = pool.get_kv_buffer(0)
+        kb.normal_(generator=g)
+        vb.normal_(generator=g)
+        q = torch.randn(T, HQ, D, device=dev, generator=g)
+        ke = torch.randn(T, HKV, D, device=dev, generator=g)
+        ve = torch.randn(T, HKV, D, device=dev, generator=g).to(torch.bfloat16)
+        if name == "peaked":
+            q *= 4.0                                                   # sigma of q.k / sqrt(D): 1 -> 4 nats
+            q[:, :, 0] = D ** 0.5                                      # score += k[n][0]
+            ramp = lambda pos: 4.0 * pos.float() / (P + E)             # noqa: E731  (+4 nats from the oldest to the newest key)
+            kflat = kb.view(-1, D) if kb.dim() == 3 else None
+            if args.kv_layout == "hnd":                                # [pages, Hkv, page, D]
+                pg, tk = prefix_slots // ps, prefix_slots % ps
+                kb.view(-1, HKV, ps, D)[pg, :, tk, 0] = ramp(torch.arange(P, device=dev))[:, None].to(kb.dtype)
+            else:
+                kb.view(-1, HKV, D)[prefix_slots, :, 0] = ramp(torch.arange(P, device=dev))[:, None].to(kb.dtype)
+            ke.view(chunk, E, HKV, D)[:, :, :, 0] = ramp(P + torch.arange(E, device=dev))[None, :, None]
+            del kflat
+        pools[name], qs[name], kes[name], ves[name] = pool, q.to(torch.bfloat16), ke.to(torch.bfloat16), ve
+    hnd = args.kv_layout == "hnd"
+    kv_indices = prefix_slots.repeat(chunk).to(torch.int64)
+    kv_indptr = (torch.arange(chunk + 1, device=dev) * P).to(torch.int32)
+    qo_indptr = (torch.arange(chunk + 1, device=dev) * E).to(torch.int64)
+    o = torch.empty(T, HQ, D, device=dev, dtype=torch.bfloat16)
+
+    def run(name):
+        kb, vb = pools[name].get_kv_buffer(0)
+        ops.extend_attention_fwd(qs[name], kes[name], ves[name], o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True, None, E,
+                                 1.0, 1.0, sm_scale=D ** -0.5, page_size=ps, kv_layout=ops.kv_layout_hnd(kb, vb) if hnd else None)
+
+    flops = 2.0 * HQ * 2 * D * chunk * (E * P + E * (E + 1) / 2)
+    res = {"workload": "the config-3 chunk (32 x (3584 cached + 512 new), D = 128 bf16) with scores of sigma = 4 nats + a recency ramp "
+                       "of +4 nats over the context, beside the same launch on N(0, 1) scores"}
+    times = {"gaussian": [], "peaked": []}
+    gpu_warm(lambda: (run("gaussian"), run("peaked")), batch=4)
+    for r in range(6):                                                  # interleaved: both inputs see the same clock state
+        for name in (("gaussian", "peaked") if r % 2 == 0 else ("peaked", "gaussian")):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(max(2, nchunks // 4)):
+                run(name)
+            e1.record()
+            torch.cuda.synchronize()
+            times[name].append(e0.elapsed_time(e1) / max(2, nchunks // 4))
+    res["kernel"] = "rx::" + rxlib.last_dispatch()
+    for name in times:
+        ms = sorted(times[name])[len(times[name]) // 2]
+        res[name] = {"ms_per_launch": ms, "tflops": flops / (ms * 1e-3) / 1e12, "frac": flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS}
+    try:                                                                # the redo rate, from the counting twin of the kernel
+        with rxlib.option("ext32_count_redo", 1):
+            for name in times:
+                rxlib.debug_counters(reset=True)
+                run(name)
+                blocks, redone = rxlib.debug_counters(reset=True)
+                res[name]["softmax_blocks"], res[name]["blocks_redone"] = blocks, redone
+                res[name]["redo_rate"] = redone / blocks if blocks else None
+            res["counted_by"] = "rx::" + rxlib.last_dispatch()
+    except Exception as e:  # noqa: BLE001
+        res["redo_rate_error"] = f"{type(e).__name__}: {e}"
+    return res
+
+
 def child_decode_leg(args, argv, timeout=900):
     """One more decode-step measurement as a CHILD `python bench.py ...` (its own process: the step's state is built
     from scratch, this process holds no pool meanwhile) -- returns the fields of its JSON line that matter."""
@@ -1363,8 +1450,9 @@ def compact_record(out):
             if v is not None:
                 e["mla_latent_frac"] = _r(v, 4)
             pk = ext.get("peaked_input")
-            if isinstance(pk, dict):
-                e["peaked_input"] = {k: _r(v, 4) for k, v in pk.items() if k in ("frac", "tflops", "redo_rate", "scores")}
+            if isinstance(pk, dict) and isinstance(pk.get("peaked"), dict):  # sigma = 4 nats + recency ramp: frac and redo rate
+                e["peaked_input"] = {"frac": _r(pk["peaked"].get("frac"), 4), "redo_rate": _r(pk["peaked"].get("redo_rate"), 5),
+                                     "gaussian_redo_rate": _r(_get(pk, "gaussian", "redo_rate"), 5)}
             cb = ext.get("cpu_baseline")
             if isinstance(cb, dict) and "value" in cb:
                 e["cpu_tflops"] = _r(cb["value"], 3)
@@ -1437,7 +1525,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     dev = torch.device("cuda", local_rank)
     if args.extend_only:
-        print(json.dumps(extend_bench(args, dev, world)))
+        res = extend_bench(args, dev, world)
+        if os.environ.get("RX_BENCH_PEAKED"):  # dev: + the peaked-input leg
+            res["peaked_input"] = extend_peaked_bench(args, dev)
+        print(json.dumps(res))
         return
     from sglang_amd.forward_batch import ForwardBatch
 
@@ -1614,6 +1705,7 @@ def main():
             out["extend"] = extend_bench(args, dev, world)
             out["extend"]["other_head_dims"] = extend_head_dims(args, dev)
             out["extend"]["mla_latent"] = mla_extend_bench(dev)
+            out["extend"]["peaked_input"] = extend_peaked_bench(args, dev)
         except Exception as e:
             out["extend"] = {"error": str(e)}
     if world > 1 and not args.no_extend:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-/* 12 (round 5): rx_split_items_guarded.
+/* 12 (round 5): rx_split_items_guarded, rx_debug_counters.
  * 11 (round 4): rx_qknorm_rope_store_kv (fused QK-norm + RoPE + store).
  * 10 (round 4): rx_decode_params.rope_* (fused RoPE of the latent decode).
  * 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
@@ -62,9 +62,14 @@ const char* rx_last_error(void);
  * in the library's symbol table and fails if one of them has no parity case that provably ran it.
  * The few process-wide switches that override the default choice (A/B of kernel forms) are named ints: set through
  * rx_set_option, read once from RX_OPT_<NAME> at load -- the launch path itself never reads the environment.
- * Names: ext32_autopack, ext32_small_wg, ext32_plain, ext64, extend_16x16_d128, extend_d256, extend_d256_at128,
+ * Names: ext32_autopack, ext32_small_wg, ext32_plain, ext64, ext32_count_redo, extend_16x16_d128, extend_d256, extend_d256_at128,
  * extend_d256_at64, extend_d256_at96, extend_nd, extend_nd_big, extend_mla, extend_mla_shared_v, decode_mla8_dma. */
 const char* rx_last_dispatch(void);
+/* Debug counters (round 5; no reference counterpart).  With option ext32_count_redo = 1 the GQA-4 packed eight-wave D = 128
+ * extend call (bf16, int64 indices, paged pool: the bench's instance) runs a counting twin of its kernel: out2[0] = 32-token
+ * softmax blocks its pipelined tiles processed, out2[1] = how many of them took the sum check's redo (a block whose lane sum
+ * exceeded 4096 against the standing reference max), summed over all such launches since the last reset.  Synchronises. */
+int rx_debug_counters(uint64_t* out2, int reset);
 int rx_set_option(const char* name, int value);
 int rx_get_option(const char* name, int* value);
 

@@ -28,6 +28,7 @@ struct Options {
   int ext32_pack_min_tiles = 4;   // ... and this tile estimate; packed PLAIN rows take eight waves from here
   int ext32_pack_min_wgs = -1;    // ... while the packed grid holds this many workgroups (-1: the device's CU count)
   int ext32_plain = 1;        // PLAIN instances (features compile-time off) when the call uses none of them
+  int ext32_count_redo = 0;   // debug: the bench-shaped packed call runs the COUNTING instance (rx_debug_counters)
   int ext64 = 0;              // 1: PLAIN eight-wave calls take rx_extend64.hip's kernel (four waves of 64 rows, one per SIMD; experimental: slower)
   int extend_16x16_d128 = 0;  // the 16x16x32 kernel of rx_extend.hip for plain D = 128 calls (A/B of the two shapes)
   int extend_d256 = 1;        // the AGPR / LDS-DMA template (256, 192, 96, 64) where it supports the call

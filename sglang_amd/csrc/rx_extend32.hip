@@ -4,6 +4,9 @@
 
 namespace rx {
 
+// debug counters of the one counting instance (option ext32_count_redo): [0] softmax blocks of pipelined tiles, [1] redone
+__device__ unsigned long long g_ext32_counters[2];
+
 // launcher used by rx_extend.hip for head_dim == v_head_dim == 128
 template <int NW, bool KV8, bool PLAIN, int PKC = 0>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
@@ -110,6 +113,18 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
     launch_extend64(a, bf, i64, linear, s);
     return RX_OK;
   }
+  if (opt.ext32_count_redo && packed_plain && !small_wg && a.q_pack == 4 && bf && i64 && !linear) {  // the counting instance
+    unsigned long long* ctr = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&ctr), HIP_SYMBOL(g_ext32_counters)) != hipSuccess)
+      return fail(RX_ERR_LAUNCH, "rx_extend_attn: no address for the debug counters");
+    auto kern = extend_mfma32_count_kernel<BF16, int64_t, false, false, 8, false, true, 4>;
+    constexpr unsigned kLds = 2 * kBufBytes;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    (void)attr;
+    note_dispatch("extend_mfma32_count_kernel<rx::BF16, long, false, false, 8, false, true, 4>");
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(a.bs) * a.hq * a.mblocks), dim3(512), kLds, s, a, ctr);
+    return RX_OK;
+  }
   if (packed_plain && !small_wg) {  // packed rows on the PLAIN loop (GQA 4 / 8)
     if (a.q_pack == 4) launch32_nw<8, false, true, 4>(a, bf, i64, linear, false, s);
     else launch32_nw<8, false, true, 8>(a, bf, i64, linear, false, s);
@@ -128,3 +143,18 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
 }
 
 }  // namespace rx
+
+int rx_debug_counters(uint64_t* out2, int reset) {
+  RX_REQUIRE(out2, "rx_debug_counters: null output");
+  unsigned long long v[2] = {0, 0};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(rx::g_ext32_counters), sizeof(v)) != hipSuccess)  // (synchronises with the device)
+    return rx::fail(RX_ERR_LAUNCH, "rx_debug_counters: %s", hipGetErrorString(hipGetLastError()));
+  out2[0] = v[0];
+  out2[1] = v[1];
+  if (reset) {
+    const unsigned long long z[2] = {0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(rx::g_ext32_counters), z, sizeof(z)) != hipSuccess)
+      return rx::fail(RX_ERR_LAUNCH, "rx_debug_counters: reset failed");
+  }
+  return RX_OK;
+}

@@ -35,7 +35,7 @@ static const OptionEntry kOptionTable[] = {
     {"ext32_autopack", &Options::ext32_autopack},         {"ext32_small_wg", &Options::ext32_small_wg},
     {"ext32_small_wg_tiles", &Options::ext32_small_wg_tiles}, {"ext32_pack_min_len", &Options::ext32_pack_min_len},
     {"ext32_pack_min_tiles", &Options::ext32_pack_min_tiles}, {"ext32_pack_min_wgs", &Options::ext32_pack_min_wgs},
-    {"ext64", &Options::ext64},
+    {"ext64", &Options::ext64},                           {"ext32_count_redo", &Options::ext32_count_redo},
     {"ext32_plain", &Options::ext32_plain},               {"extend_16x16_d128", &Options::extend_16x16_d128},
     {"extend_d256", &Options::extend_d256},               {"extend_d256_min_rows", &Options::extend_d256_min_rows},
                    {"extend_d256_at128", &Options::extend_d256_at128},

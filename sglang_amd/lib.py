@@ -122,6 +122,7 @@ PROTOTYPES = {
                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rx_num_kv_splits_native": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rx_split_items": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "rx_debug_counters": (c_int, [c_void_p, c_int]),
     "rx_split_items_guarded": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rx_num_kv_splits_balanced": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rx_merge_state": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_void_p]),
@@ -245,6 +246,15 @@ def last_dispatch() -> str:
     """Name of the kernel instance this thread's last rx_extend_attn / rx_decode_attn launched (rx_last_dispatch)."""
     msg = load().rx_last_dispatch()
     return msg.decode() if msg else ""
+
+
+def debug_counters(reset: bool = False):
+    """rx_debug_counters: (softmax blocks, redone blocks) of the counting extend instance (option ext32_count_redo)."""
+    import ctypes as _C
+
+    out = (_C.c_uint64 * 2)()
+    check(load().rx_debug_counters(out, int(bool(reset))), "rx_debug_counters")
+    return int(out[0]), int(out[1])
 
 
 def set_option(name: str, value: int) -> int:

@@ -236,3 +236,50 @@ def test_ext64_one_wave_per_simd_kernel_is_bit_identical_to_the_eight_wave_kerne
                 absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve)), _bits(kb), parity.abs_values(_bits(vb)),
                                             qo, np.asarray(kvp, dtype=np.int32), kvi.numpy(), sm_scale=d ** -0.5)
             parity.check_out(outs[1][0].float().cpu().numpy(), want, dtype, ("ext64", prefix, extend), ulps=1, absw=absw)
+
+
+def test_redo_counters_of_the_counting_instance():
+    """rx_debug_counters + option ext32_count_redo: the counting twin of the bench's kernel instance returns the same bits
+    and counts.  N(0, 1) scores: a redo on every wave's FIRST block only (reference max still -inf);
+    scores that jump by +12 nats in the middle of the prefix: more."""
+    from sglang_amd import lib as rxlib
+    from sglang_amd import ops
+
+    hq, hkv, d, ps, P, E, bs = 8, 2, 128, 16, 1024, 256, 2
+    g = torch.Generator().manual_seed(4)
+    npg = bs * (P // ps) + 2
+    kb = torch.randn(npg, hkv, ps, d, generator=g).to(torch.bfloat16)      # an HND pool (the bench's layout: not linear)
+    vb = torch.randn(npg, hkv, ps, d, generator=g).to(torch.bfloat16)
+    perm = torch.randperm(npg - 1, generator=g) + 1
+    kvi = torch.cat([(perm[i * (P // ps): (i + 1) * (P // ps)][:, None] * ps + torch.arange(ps)[None]).reshape(-1) for i in range(bs)])
+    kvp = torch.arange(bs + 1, dtype=torch.int32) * P
+    T = bs * E
+    q = torch.randn(T, hq, d, generator=g).to(torch.bfloat16)
+    ke = torch.randn(T, hkv, d, generator=g).to(torch.bfloat16)
+    ve = torch.randn(T, hkv, d, generator=g).to(torch.bfloat16)
+    qo = torch.arange(bs + 1, dtype=torch.int64) * E
+
+    def run(kbuf, count):
+        o = torch.zeros(T, hq, d, dtype=torch.bfloat16, device=DEV)
+        with rxlib.option("ext32_count_redo", int(count)), rxlib.option("ext32_small_wg", 0), rxlib.option("ext32_pack_min_wgs", 0):
+            kd, vd = kbuf.to(DEV), vb.to(DEV)
+            ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kd, vd, qo.to(DEV), kvp.to(DEV), kvi.to(DEV), None, True,
+                                     None, E, 1.0, 1.0, sm_scale=d ** -0.5, page_size=ps, kv_layout=ops.kv_layout_hnd(kd, vd))
+            torch.cuda.synchronize()
+            return o, rxlib.last_dispatch()
+
+    rxlib.debug_counters(reset=True)
+    o0, n0 = run(kb, False)
+    assert n0.startswith("extend_mfma32_kernel") and rxlib.debug_counters() == (0, 0)
+    o1, n1 = run(kb, True)
+    assert n1.startswith("extend_mfma32_count_kernel") and torch.equal(o0, o1)
+    blocks, redone = rxlib.debug_counters(reset=True)
+    wgs = bs * hkv * (E * 4 // 256)                       # (request, kv head, 256-row block); 8 waves each
+    assert redone == wgs * 8, (blocks, redone)            # the FIRST block of each wave (m = -inf), nothing else
+    assert blocks >= wgs * 8 * 2 * (P // 64) and rxlib.debug_counters() == (0, 0)
+    kb2 = kb.clone()
+    half = kvi[P // 2:P]
+    kb2[half // ps, :, half % ps, :] *= 4.0               # the second half of request 0's prefix: scores four times as large
+    _, _ = run(kb2, True)
+    _, redone2 = rxlib.debug_counters(reset=True)
+    assert redone2 > redone

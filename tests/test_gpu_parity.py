@@ -1102,10 +1102,12 @@ def test_extend_unified_equals_two_stage_on_long_batch(ops):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("pattern", ["ramp", "spikes", "plateau"])
 def test_extend_thresholded_max_adversarial_scores(ops, dtype, pattern):
-    """The D = 128 MFMA kernel moves a row's reference max only when a tile's max exceeds it by > 2^8
-    (kMaxSlack, rx_extend32.hip).  Score sequences built to stress that rule -- a slow ramp that stays inside
-    the slack tile after tile, rare huge spikes, a long flat plateau after one early peak -- must still match
-    the fp64 oracle (output and LSE)."""
+    """The D = 128 MFMA kernel takes exp2 against the STANDING reference max of a row and redoes a 32-token block the
+    classic way only when a lane's partial row sum exceeds 4096; the redo moves the reference max only when the block's
+    max exceeds it by > 2^8 (kMaxSlack; rx_extend32_kernel.inc, sm_slice).  Score sequences built to stress that rule --
+    a slow ramp that stays inside the slack tile after tile, rare huge spikes, a long flat plateau after one early
+    peak -- must still match the fp64 oracle (output and LSE).  This is the unpacked four-wave instance; every other
+    kernel that carries the sum check, and two more patterns, are in tests/test_gpu_adversarial_scores.py."""
     hq, hkv, d, P, E = 2, 1, 128, 1024 + 37, 192
     rng = np.random.default_rng({"ramp": 1, "spikes": 2, "plateau": 3}[pattern])
     g = torch.Generator().manual_seed(3)
