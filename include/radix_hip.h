@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-/* 12 (round 5): rx_split_items_guarded, rx_debug_counters.
+/* 12 (round 5): rx_split_items_guarded, rx_debug_counters, rx_draft_decode_kv_indices.
  * 11 (round 4): rx_qknorm_rope_store_kv (fused QK-norm + RoPE + store).
  * 10 (round 4): rx_decode_params.rope_* (fused RoPE of the latent decode).
  * 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
@@ -97,6 +97,21 @@ int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,
                         const void* req_pool_indices, int pool_idx_is_i64, const void* lens,
                         int lens_is_i64, const int32_t* kv_start, int32_t* kv_indptr_out,
                         void* kv_indices_out, int out_is_i64, int bs, void* stream);
+
+/* ---- EAGLE multi-step draft decode: the per-step page tables of the top-k branches (round 5) ----------------------
+ * generate_draft_decode_kv_indices (kernels/ops/speculative/cache_locs.py:56-141), launched by
+ * TritonMultiStepDraftBackend.common_template (srt/layers/attention/triton_backend.py:1929-1945).  For step i (iters = i + 1),
+ * request b, branch k < topk, with n = seq_lens[b] and row = req_to_token[req_pool_indices[b]]:
+ *   off = sum(seq_lens[:b]) * topk + b * iters * topk + k * (n + iters)
+ *   kv_indices[i][off + j] = row[j], j < n;   kv_indices[i][off + n + j] = row[start + j], j < iters, where
+ *   start = n + k * num_steps (page_size == 1 or topk == 1), else n / page * page + k * ceil((n % page + num_steps) / page) * page + n % page
+ *   kv_indptr[i][z] = sum(positions[:z]) + z * iters for z = b * topk + k, with z = 0 standing for num_seqs * topk
+ * (kv_indptr[i][0] is not written: the caller's buffer holds 0 there).  kv_indices rows are kv_indices_stride apart (int64 or
+ * int32 words), kv_indptr rows kv_indptr_stride (>= num_seqs * topk + 1).  One launch, no host sync. */
+int rx_draft_decode_kv_indices(const int32_t* req_to_token, int64_t row_stride, const void* req_pool_indices, int pool_idx_is_i64,
+                               const void* seq_lens, int seq_lens_is_i64, const void* positions, int positions_is_i64,
+                               int num_seqs, int topk, int num_steps, int page_size, void* kv_indices, int kv_indices_is_i64,
+                               int64_t kv_indices_stride, int32_t* kv_indptr, int64_t kv_indptr_stride, void* stream);
 
 /* ---- K3: kv-split scheduler -----------------------------------------------------------
  * get_num_kv_splits_triton (kernels/ops/attention/metadata.py:11-60).

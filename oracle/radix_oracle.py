@@ -389,6 +389,49 @@ def build_kv_indices(req_to_token, req_pool_indices, lens, kv_start=None,
     return kv_indptr, kv_indices
 
 
+def draft_decode_kv_indices(req_to_token, req_pool_indices, seq_lens, positions, topk, num_steps, page_size,
+                            kv_indices_width, kv_indptr_width, fill=-1):
+    """generate_draft_decode_kv_indices (kernels/ops/speculative/cache_locs.py:56-141), the per-step page tables of EAGLE's
+    multi-step draft decode (TritonMultiStepDraftBackend.common_template, triton_backend.py:1929-1945).  For step i
+    (iters = i + 1), request b and branch k (of topk) the branch's keys are the request's seq_len cached tokens plus the
+    iters draft tokens this branch has written so far:
+        offset(i, b, k) = sum(seq_lens[:b]) * topk + b * iters * topk + k * (seq_len_b + iters)      (:89)
+        kv_indices[i, offset : offset + seq_len_b]       = req_to_token[row_b, : seq_len_b]             (:94-100)
+        kv_indices[i, offset + seq_len_b + j], j < iters = req_to_token[row_b, start + j]               (:102-123)
+    with start = seq_len_b + k * num_steps when page_size == 1 or topk == 1, else -- every branch on pages of its own --
+    seq_len_b // page * page + k * ceil((seq_len_b % page + num_steps) / page) * page + seq_len_b % page.
+        kv_indptr[i, z] = sum(positions[:z]) + z * iters for z = b * topk + k, z = 0 standing for num_seqs * topk (:125-134;
+    kv_indptr[i, 0] is never written).  Returns (kv_indices int64 [num_steps, kv_indices_width] pre-filled with `fill`,
+    kv_indptr int32 [num_steps, kv_indptr_width] pre-filled with 0)."""
+    req_to_token = np.asarray(req_to_token)
+    seq_lens = np.asarray(seq_lens, dtype=np.int64)
+    positions = np.asarray(positions, dtype=np.int64)
+    num_seqs = len(seq_lens)
+    kv_indices = np.full((num_steps, kv_indices_width), fill, dtype=np.int64)
+    kv_indptr = np.zeros((num_steps, kv_indptr_width), dtype=np.int32)
+    cum = np.concatenate([[0], np.cumsum(seq_lens)])
+    for i in range(num_steps):
+        iters = i + 1
+        for b in range(num_seqs):
+            row = req_to_token[int(req_pool_indices[b])]
+            n = int(seq_lens[b])
+            for k in range(topk):
+                off = int(cum[b]) * topk + b * iters * topk + k * (n + iters)
+                kv_indices[i, off: off + n] = row[:n]
+                if page_size == 1 or topk == 1:
+                    start = n + k * num_steps
+                else:
+                    last = n % page_size
+                    new_pages = (last + num_steps + page_size - 1) // page_size
+                    start = n // page_size * page_size + k * new_pages * page_size + last
+                kv_indices[i, off + n: off + n + iters] = row[start: start + iters]
+                z = b * topk + k
+                if z == 0:
+                    z = num_seqs * topk
+                kv_indptr[i, z] = int(positions[:z].sum()) + z * iters
+    return kv_indices, kv_indptr
+
+
 # --------------------------------------------------------------------------
 # a11 kv-split scheduler   kernels/ops/attention/metadata.py:11-60
 # --------------------------------------------------------------------------

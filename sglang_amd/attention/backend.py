@@ -36,6 +36,17 @@ from ..forward_batch import ForwardBatch
 from ..mem_cache import memory_pool as _own_pools
 
 
+def draft_kv_indices_buffer_width(num_seqs: int, topk: int, max_context_len: int) -> int:
+    """Row width of the multi-step draft kv_indices buffer (srt/speculative/spec_utils.py:181-192)."""
+    assert num_seqs * topk * max_context_len < 2 ** 31, "kv_indices flat offset would overflow int32; reduce batch/topk/context"
+    return num_seqs * topk * max_context_len
+
+
+def draft_kv_indices_used_len(seq_lens_sum: int, topk: int, bs: int, num_steps: int) -> int:
+    """kv_indices words in use after num_steps draft steps (spec_utils.py:195-203)."""
+    return seq_lens_sum * topk + bs * num_steps
+
+
 def split_pairs_bound(bs: int, slots: int, wgpr: int, cus: int) -> int:
     """max over all length vectors of sum(rx_num_kv_splits_balanced(...)) for ``bs`` requests, cap ``slots``, ``wgpr``
     workgroups per (request, split) pair and wg_target = 2 x ``cus`` (any wg_target_mixed the backend passes), rule by rule:
@@ -78,6 +89,7 @@ class ForwardMetadata:
     partial_pairs_hint: int = 0
     # decode, length-aware schedule: the live (request, split) pairs, compacted (ops.SplitItems)
     split_items: Optional[object] = None
+    draft: bool = False  # kv_indptr / kv_indices came from spec_info (multi-step draft decode: one row per top-k branch)
 
 
 def host_num_kv_splits(seq_lens: np.ndarray, num_head: int, num_kv_head: int, max_kv_splits: int,
@@ -139,8 +151,11 @@ class HipRadixAttnBackend:
     def __init__(self, model_runner, decode_index_mode: str = "paged",
                  max_kv_splits: Optional[int] = None, split_policy: str = "native",
                  cascade_decode: bool = False, cascade_min_bs: int = 16, cascade_min_shared: int = 1024,
-                 dcp=None, mla_v_is_latent_prefix: bool = False):
+                 dcp=None, mla_v_is_latent_prefix: bool = False, skip_prefill: bool = False,
+                 kv_indptr_buf: Optional[torch.Tensor] = None):
         self.device = model_runner.device
+        self.skip_prefill = bool(skip_prefill)      # (signature parity with TritonAttnBackend: a draft-decode-only backend)
+        self._kv_indptr_buf = kv_indptr_buf
         # MLA pools keep ONE latent row per token and serve v as its first kv_lora_rank columns (the reference's
         # MLATokenToKVPool.set_kv_buffer drops cache_v); the model hands forward_extend v = k_nope, a tensor of its own
         # with the same values.  With this flag the extend reads the new tokens' v from their k rows as well -- the
@@ -199,7 +214,8 @@ class HipRadixAttnBackend:
             raise ValueError(f"decode_index_mode must be 'paged' or 'indices', got {decode_index_mode}")
         self.decode_index_mode = decode_index_mode
         max_bs = self.req_to_token_pool.size
-        self.kv_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
+        self.kv_indptr = (self._kv_indptr_buf if self._kv_indptr_buf is not None
+                          else torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device))
         self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int64, device=self.device)
         self.mask_indptr = torch.zeros((max_bs + 1,), dtype=torch.int64, device=self.device)
         # hybrid sliding-window models (triton_backend.py:259-276): a second set of window indices
@@ -214,8 +230,8 @@ class HipRadixAttnBackend:
         self._scratch_lse = None
         # stage 2 inside the stage-1 kernel (rx_decode_params.merge_counters): one zeroed word per (request, head);
         # the kernels leave it zero, so one buffer serves every layer and every replay of a captured step
-        self._merge_counters = torch.zeros(max(1, self.req_to_token_pool.size) * self.num_head, dtype=torch.int32,
-                                           device=self.device)
+        self._merge_counters = torch.zeros(max(1, self.req_to_token_pool.size) * self.num_head * (8 if self.skip_prefill else 1),
+                                           dtype=torch.int32, device=self.device)  # (draft backends: up to 8 branches per request)
         if os.environ.get("RX_NO_INKERNEL_MERGE"):  # dev A/B: stage 2 as its own launch
             self._merge_counters = None
         self._no_fused_store = bool(os.environ.get("RX_NO_FUSED_STORE"))  # dev A/B: the store as its own launch
@@ -301,7 +317,8 @@ class HipRadixAttnBackend:
         if mode.is_idle():
             self.forward_metadata = ForwardMetadata(None, None, None, None, None, None, None)
             return
-        if graph and bs > self._graph["max_bs"]:
+        draft = mode.is_decode() and forward_batch.spec_info is not None and getattr(forward_batch.spec_info, "kv_indptr", None) is not None
+        if graph and not draft and bs > self._graph["max_bs"]:
             raise ValueError(f"batch size {bs} exceeds init_cuda_graph_state's max_bs {self._graph['max_bs']}")
         if self.dcp is not None:
             if mode.is_decode():
@@ -399,7 +416,33 @@ class HipRadixAttnBackend:
         return (kb.shape[-1] in (64, 96, 128, 256) and kb.shape[-1] == self.v_head_dim
                 and kb.dtype in (torch.bfloat16, torch.float16))
 
+    def _decode_metadata_draft(self, fb: ForwardBatch, use_graph_bufs: bool) -> ForwardMetadata:
+        """Multi-step draft decode (triton_backend.py:772-774, :587-602): the page tables come from spec_info -- one row per
+        (request, top-k branch), built by HipRadixMultiStepDraftBackend -- so the batch the kernel sees has
+        kv_indptr.shape[0] - 1 rows; the split schedule is the reference's K3 formula with num_group = topk."""
+        spec = fb.spec_info
+        kv_indptr, kv_indices = spec.kv_indptr, spec.kv_indices
+        rows = kv_indptr.shape[0] - 1
+        S = self.max_kv_splits
+        dg = getattr(self, "_draft_graph", None)
+        if use_graph_bufs and dg is not None:
+            if rows > dg["max_rows"]:
+                raise ValueError(f"draft decode: {rows} rows exceed init_cuda_graph_state's max_num_tokens {dg['max_rows']}")
+            num_kv_splits = dg["num_kv_splits"][:rows]
+            attn_logits, attn_lse = dg["attn_logits"][:rows], dg["attn_lse"][:rows]
+        else:
+            num_kv_splits = torch.empty((rows,), dtype=torch.int32, device=self.device)
+            attn_logits, attn_lse = self._scratch(rows, S)
+        num_seqs = fb.seq_lens.shape[0]
+        if rows % max(num_seqs, 1) == 0 and num_seqs > 0:
+            ops.get_num_kv_splits(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S, self.device_core_count)
+        else:  # (rows that are not whole top-k groups: every row keeps the full cap; unused slots cost a dead workgroup)
+            num_kv_splits.fill_(S)
+        return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S, draft=True)
+
     def _decode_metadata(self, fb: ForwardBatch, bs: int, use_graph_bufs: bool) -> ForwardMetadata:
+        if fb.spec_info is not None and getattr(fb.spec_info, "kv_indptr", None) is not None:
+            return self._decode_metadata_draft(fb, use_graph_bufs)
         # (latent MLA rows are shared by all heads already: the cascade pays from ~128 requests on -- 64 x (3584 shared +
         # 512 own): 54 -> 78 us per layer, 256: 194 -> 122, 256 x (8192 + 256): 348 -> 158; tools/cascade_bench.py MLA=1)
         self._cascade_on = self.cascade_decode and bs >= (max(self.cascade_min_bs, 128) if self._is_mla_pool
@@ -856,10 +899,21 @@ class HipRadixAttnBackend:
                                qo_indptr, custom_mask=custom_mask, mask_indptr=mask_indptr)
 
     # ------------------------------------------------------------------ graph support
-    def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int):
+    def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int, kv_indices_buf: Optional[torch.Tensor] = None,
+                              cuda_graph_num_kv_splits_buf: Optional[torch.Tensor] = None):
         """Address-stable buffers (triton_backend.py:962-1063).  Everything a captured kernel reads that
-        init_forward_metadata_out_graph rewrites before a replay lives here."""
+        init_forward_metadata_out_graph rewrites before a replay lives here.  kv_indices_buf / cuda_graph_num_kv_splits_buf
+        (:970-1001): the multi-step draft backend's shared buffers -- this backend then only serves draft decode steps
+        under graphs and keeps the fp32 partials for max_num_tokens branch rows."""
         dev = self.device
+        if kv_indices_buf is not None:
+            rows = int(max_num_tokens)
+            self._draft_graph = {
+                "max_rows": rows, "kv_indices": kv_indices_buf,
+                "num_kv_splits": (cuda_graph_num_kv_splits_buf if cuda_graph_num_kv_splits_buf is not None
+                                  else torch.full((rows,), self.max_kv_splits, dtype=torch.int32, device=dev)),
+                "attn_logits": torch.zeros((rows, self.num_head, self.max_kv_splits, self.v_head_dim), dtype=torch.float32, device=dev),
+                "attn_lse": torch.zeros((rows, self.num_head, self.max_kv_splits), dtype=torch.float32, device=dev)}
         self._graph = {
             "max_bs": int(max_bs),
             "num_kv_splits": torch.full((max_bs,), 1, dtype=torch.int32, device=dev),
@@ -967,7 +1021,8 @@ class HipRadixAttnBackend:
         else:
             o = torch.empty_like(q)
         # the KV store of the step rides in the decode launch when the kernel can take it (see _fused_store_ok)
-        fuse = save_kv_cache and k is not None and self._fused_store_ok(layer, k, v)
+        fuse = (save_kv_cache and k is not None and not getattr(self.forward_metadata, "draft", False)
+                and self._fused_store_ok(layer, k, v))  # (draft rows are top-k branches: their slot is not req_to_token[req, len - 1])
         if (fuse and self._debug_checks and forward_batch.out_cache_loc is not None
                 and not torch.cuda.is_current_stream_capturing()):  # (a host sync: not inside a graph capture)
             slot = self.req_to_token[forward_batch.req_pool_indices.long(), forward_batch.seq_lens.long() - 1]
@@ -1017,11 +1072,14 @@ class HipRadixAttnBackend:
                                 max_kv_splits=md.max_kv_splits if md.attn_logits is not None else 1,
                                 attn_logits=md.attn_logits, attn_lse=md.attn_lse,
                                 merge_counters=self._merge_counters)
-            elif self.decode_index_mode == "indices":
+            elif self.decode_index_mode == "indices" or md.draft:
+                mc = self._merge_counters  # (a draft step has one row per top-k BRANCH: more rows than the request pool)
+                if mc is not None and mc.numel() < q3.shape[0] * layer.tp_q_head_num:
+                    mc = self._merge_counters = torch.zeros(q3.shape[0] * layer.tp_q_head_num, dtype=torch.int32, device=self.device)
                 ln.set_metadata(self._md_version, q3.shape[0], kv_indptr=md.kv_indptr,
                                 kv_indices=md.kv_indices, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
-                                attn_lse=md.attn_lse, merge_counters=self._merge_counters,
+                                attn_lse=md.attn_lse, merge_counters=mc,
                                 request_order=md.request_order, partial_pairs_hint=md.partial_pairs_hint,
                                 split_items=md.split_items)
             else:
@@ -1124,3 +1182,82 @@ class HipRadixAttnBackend:
 
     def support_triton(self):
         return False
+
+
+class HipRadixMultiStepDraftBackend:
+    """TritonMultiStepDraftBackend (srt/layers/attention/triton_backend.py:1867-2040): the attention backends of EAGLE's
+    ``speculative_num_steps - 1`` consecutive draft decode steps as one object.  Step i attends, for every request and
+    each of its ``topk`` branches, to the request's cached tokens plus the i + 1 draft tokens the branch has written;
+    the page tables of ALL steps come from one launch of rx_draft_decode_kv_indices (the reference's
+    generate_draft_decode_kv_indices, cache_locs.py:56-141) into ``kv_indptr [steps, max_bs * topk + 1]`` and a
+    ``kv_indices [steps, num_seqs * topk * max_context_len]`` buffer; step i's backend reads row i through
+    ``forward_batch.spec_info.kv_indptr / kv_indices``."""
+
+    needs_cpu_seq_lens: bool = False
+
+    def __init__(self, model_runner, topk: int, speculative_num_steps: int, **backend_kwargs):
+        self.topk = int(topk)
+        self.speculative_num_steps = int(speculative_num_steps)
+        max_bs = model_runner.req_to_token_pool.size * self.topk
+        self.device = model_runner.device
+        self.kv_indptr = torch.zeros((self.speculative_num_steps, max_bs + 1), dtype=torch.int32, device=self.device)
+        self.attn_backends = [HipRadixAttnBackend(model_runner, skip_prefill=True, kv_indptr_buf=self.kv_indptr[i], **backend_kwargs)
+                              for i in range(self.speculative_num_steps - 1)]
+        self.max_context_len = (self.attn_backends[0].max_context_len if self.attn_backends
+                                else model_runner.model_config.context_len)
+        self.req_to_token_pool = model_runner.req_to_token_pool
+        self.pool_len = self.req_to_token_pool.req_to_token.shape[1]
+        self.page_size = getattr(model_runner, "page_size", 1) or 1
+        self.cuda_graph_kv_indices = None
+
+    def common_template(self, forward_batch: ForwardBatch, kv_indices_buffer: Optional[torch.Tensor], call_fn):
+        if kv_indices_buffer is None:
+            kv_indices_buffer = self.cuda_graph_kv_indices
+        num_seqs = forward_batch.batch_size
+        bs = self.topk * num_seqs
+        seq_lens_sum = forward_batch.seq_lens_sum
+        if seq_lens_sum is None:  # only slice-clamps the preallocated buffer: an over-estimate is safe
+            seq_lens_sum = num_seqs * self.max_context_len
+        ops.generate_draft_decode_kv_indices(forward_batch.req_pool_indices, self.req_to_token_pool.req_to_token,
+                                             forward_batch.seq_lens, kv_indices_buffer, self.kv_indptr, forward_batch.positions,
+                                             self.topk, self.speculative_num_steps, self.page_size)
+        if call_fn is None:
+            return
+        for i in range(self.speculative_num_steps - 1):
+            forward_batch.spec_info.kv_indptr = self.kv_indptr[i, : bs + 1]
+            forward_batch.spec_info.kv_indices = kv_indices_buffer[i][: draft_kv_indices_used_len(seq_lens_sum, self.topk, bs, i + 1)]
+            call_fn(i, forward_batch)
+
+    def init_forward_metadata(self, forward_batch: ForwardBatch):
+        width = draft_kv_indices_buffer_width(forward_batch.batch_size, self.topk, self.max_context_len)
+        kv_indices = torch.empty((self.speculative_num_steps, width), dtype=torch.int64, device=self.device)
+
+        def call_fn(i, fb):
+            # every step's backend keeps ITS OWN copies: the loop rewrites spec_info for the next step (:1967-1974)
+            fb.spec_info.kv_indptr = fb.spec_info.kv_indptr.clone()
+            fb.spec_info.kv_indices = fb.spec_info.kv_indices.clone()
+            self.attn_backends[i].init_forward_metadata(fb)
+
+        self.common_template(forward_batch, kv_indices, call_fn)
+
+    def init_cuda_graph_state(self, max_bs: int, max_num_tokens: int):
+        width = draft_kv_indices_buffer_width(max_bs, self.topk, self.max_context_len)
+        self.cuda_graph_kv_indices = torch.zeros((self.speculative_num_steps, width), dtype=torch.int64, device=self.device)
+        cap = self.attn_backends[0].max_kv_splits if self.attn_backends else 1
+        self.cuda_graph_num_kv_splits = torch.full((max_num_tokens,), cap, dtype=torch.int32, device=self.device)
+        for i in range(self.speculative_num_steps - 1):
+            self.attn_backends[i].init_cuda_graph_state(max_bs, max_num_tokens, kv_indices_buf=self.cuda_graph_kv_indices[i],
+                                                        cuda_graph_num_kv_splits_buf=self.cuda_graph_num_kv_splits)
+
+    def init_forward_metadata_out_graph(self, forward_batch: ForwardBatch, in_capture: bool = False):
+        """Before capture AND before every replay (:2002-2036): the page tables of all steps are rebuilt into the
+        address-stable buffers; the per-step backends point their metadata at row i (whole rows: the kernels stop at
+        kv_indptr) and refill the shared split counts."""
+        def call_fn(i, fb):
+            self.attn_backends[i].init_forward_metadata_out_graph(fb, in_capture=in_capture)
+
+        self.common_template(forward_batch, None, call_fn)
+
+    def init_forward_metadata_in_graph(self, forward_batch: ForwardBatch) -> None:
+        for b in self.attn_backends:
+            b.init_forward_metadata_in_graph(forward_batch)

@@ -566,6 +566,58 @@ __global__ __launch_bounds__(256) void move_kv_layout_kernel(const uint64_t* __r
 
 using namespace rx;
 
+// ---- per-step page tables of EAGLE's multi-step draft decode (generate_draft_decode_kv_indices, cache_locs.py:56-141) ----
+// One launch for every (step, request, branch): block (z = b * topk + k, chunk, step).  A branch's keys at step i are the
+// request's cached tokens plus the i + 1 draft tokens the branch has written.  The prefix sums the reference recomputes per
+// program (tl.sum over the lengths / positions before this one) are block reductions here; rows are copied 1024 tokens per
+// block, int32 page-table words read coalesced, index words written coalesced.
+namespace rx {
+__device__ __forceinline__ int64_t block_sum_before(const void* v, int is64, int n, int64_t* sh) {
+  int64_t acc = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += load_idx(v, i, is64);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  int64_t tot = 0;
+  for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) tot += sh[w];
+  __syncthreads();
+  return tot;
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void draft_decode_kv_indices_kernel(
+    const int32_t* __restrict__ req_to_token, int64_t row_stride, const void* __restrict__ req_pool_indices, int rpi64,
+    const void* __restrict__ seq_lens, int sl64, const void* __restrict__ positions, int pos64, int num_seqs, int topk,
+    int num_steps, int page_size, OutT* __restrict__ kv_indices, int64_t kv_indices_stride, int32_t* __restrict__ kv_indptr,
+    int64_t kv_indptr_stride) {
+  __shared__ int64_t sh[4];
+  const int z = blockIdx.x, b = z / topk, k = z - b * topk;
+  const int chunk = blockIdx.y, iters = blockIdx.z + 1;
+  const int64_t n = load_idx(seq_lens, b, sl64);
+  const int64_t lo = static_cast<int64_t>(chunk) * 1024;
+  if (chunk > 0 && lo >= n) return;                     // (block-uniform)
+  const int64_t cum = block_sum_before(seq_lens, sl64, b, sh);
+  const int32_t* row = req_to_token + load_idx(req_pool_indices, b, rpi64) * row_stride;
+  OutT* dst = kv_indices + kv_indices_stride * blockIdx.z + cum * topk + static_cast<int64_t>(b) * iters * topk +
+              static_cast<int64_t>(k) * (n + iters);
+  for (int64_t j = lo + threadIdx.x; j < min(lo + 1024, n); j += 256) dst[j] = static_cast<OutT>(row[j]);
+  if (chunk != 0) return;
+  int64_t start;
+  if (page_size == 1 || topk == 1) {
+    start = n + static_cast<int64_t>(k) * num_steps;
+  } else {  // every branch on pages of its own behind the request's last (partial) page
+    const int64_t last = n % page_size, new_pages = (last + num_steps + page_size - 1) / page_size;
+    start = n / page_size * page_size + static_cast<int64_t>(k) * new_pages * page_size + last;
+  }
+  if (static_cast<int>(threadIdx.x) < iters) dst[n + threadIdx.x] = static_cast<OutT>(row[start + threadIdx.x]);
+  const int zz = z == 0 ? num_seqs * topk : z;          // (entry 0 stays as the caller left it: 0)
+  const int64_t base = block_sum_before(positions, pos64, zz, sh);
+  if (threadIdx.x == 0) kv_indptr[kv_indptr_stride * blockIdx.z + zz] = static_cast<int32_t>(base + static_cast<int64_t>(zz) * iters);
+}
+}  // namespace rx
+
+
 extern "C" {
 
 int rx_version(void) { return RX_ABI_VERSION; }
@@ -788,6 +840,30 @@ int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,
                          (int32_t*)kv_indices_out);
   }
   return check_launch("rx_build_kv_indices");
+}
+
+int rx_draft_decode_kv_indices(const int32_t* req_to_token, int64_t row_stride, const void* req_pool_indices, int pool_idx_is_i64,
+                               const void* seq_lens, int seq_lens_is_i64, const void* positions, int positions_is_i64,
+                               int num_seqs, int topk, int num_steps, int page_size, void* kv_indices, int kv_indices_is_i64,
+                               int64_t kv_indices_stride, int32_t* kv_indptr, int64_t kv_indptr_stride, void* stream) {
+  RX_REQUIRE(num_seqs >= 0 && topk >= 1 && num_steps >= 1 && num_steps <= 256 && page_size >= 1,
+             "rx_draft_decode_kv_indices: bad sizes (topk >= 1, 1 <= num_steps <= 256, page_size >= 1)");
+  if (num_seqs == 0) return RX_OK;
+  RX_REQUIRE(req_to_token && req_pool_indices && seq_lens && positions && kv_indices && kv_indptr,
+             "rx_draft_decode_kv_indices: null pointer");
+  RX_REQUIRE(kv_indptr_stride >= static_cast<int64_t>(num_seqs) * topk + 1, "rx_draft_decode_kv_indices: kv_indptr rows too short");
+  const unsigned chunks = static_cast<unsigned>((row_stride + 1023) / 1024);
+  const dim3 grid(static_cast<unsigned>(num_seqs) * topk, chunks ? chunks : 1, num_steps);
+  auto s = static_cast<hipStream_t>(stream);
+  if (kv_indices_is_i64)
+    hipLaunchKernelGGL(rx::draft_decode_kv_indices_kernel<int64_t>, grid, dim3(256), 0, s, req_to_token, row_stride, req_pool_indices,
+                       pool_idx_is_i64, seq_lens, seq_lens_is_i64, positions, positions_is_i64, num_seqs, topk, num_steps,
+                       page_size, static_cast<int64_t*>(kv_indices), kv_indices_stride, kv_indptr, kv_indptr_stride);
+  else
+    hipLaunchKernelGGL(rx::draft_decode_kv_indices_kernel<int32_t>, grid, dim3(256), 0, s, req_to_token, row_stride, req_pool_indices,
+                       pool_idx_is_i64, seq_lens, seq_lens_is_i64, positions, positions_is_i64, num_seqs, topk, num_steps,
+                       page_size, static_cast<int32_t*>(kv_indices), kv_indices_stride, kv_indptr, kv_indptr_stride);
+  return check_launch("rx_draft_decode_kv_indices");
 }
 
 int rx_num_kv_splits(const void* seq_lens, int seq_lens_is_i64, int num_seq, int num_group,

@@ -192,6 +192,27 @@ def get_num_kv_splits(num_kv_splits: torch.Tensor, seq_lens: torch.Tensor, num_h
     _L.check(st, "rx_num_kv_splits")
 
 
+def generate_draft_decode_kv_indices(req_pool_indices, req_to_token, paged_kernel_lens, kv_indices, kv_indptr, positions,
+                                     topk: int, num_steps: int, page_size: int) -> None:
+    """generate_draft_decode_kv_indices (kernels/ops/speculative/cache_locs.py:56-141) with the reference launch's grid
+    (speculative_num_steps, num_seqs, topk) folded into the arguments: fills kv_indices [num_steps, width] (int64 or
+    int32) and kv_indptr [num_steps, >= num_seqs * topk + 1] (int32, entry 0 untouched) for every step, request and
+    top-k branch.  include/radix_hip.h: rx_draft_decode_kv_indices."""
+    _require_cuda(req_pool_indices, req_to_token, paged_kernel_lens, kv_indices, kv_indptr, positions)
+    if req_to_token.dtype != torch.int32 or kv_indptr.dtype != torch.int32:
+        raise TypeError("req_to_token / kv_indptr must be int32")
+    if kv_indices.dim() != 2 or kv_indptr.dim() != 2 or kv_indices.shape[0] < num_steps or kv_indptr.shape[0] < num_steps:
+        raise ValueError("kv_indices / kv_indptr must be [num_steps, ...]")
+    if kv_indices.stride(1) != 1 or kv_indptr.stride(1) != 1:
+        raise ValueError("kv_indices / kv_indptr rows must be contiguous")
+    st = _L.load().rx_draft_decode_kv_indices(
+        _ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _is64(req_pool_indices, "req_pool_indices"),
+        _ptr(paged_kernel_lens), _is64(paged_kernel_lens, "paged_kernel_lens"), _ptr(positions), _is64(positions, "positions"),
+        paged_kernel_lens.shape[0], int(topk), int(num_steps), int(page_size), _ptr(kv_indices),
+        _is64(kv_indices, "kv_indices"), kv_indices.stride(0), _ptr(kv_indptr), kv_indptr.stride(0), _stream(kv_indices))
+    _L.check(st, "rx_draft_decode_kv_indices")
+
+
 def native_max_kv_splits(bs: int, num_head: int, num_kv_head: int, cu_count: int, cap: int) -> int:
     """Uniform split count of the MI355X-native schedule (include/radix_hip.h, rx_num_kv_splits_native)."""
     group = max(1, num_head // num_kv_head)

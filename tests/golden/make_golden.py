@@ -25,6 +25,7 @@ Fixture families:
   F9 extend with custom (tree) masks, sliding window (+ window_kv_offsets), xai temperature -> extend_mask.npz
   F16 ROCm MLA decode with fused RoPE (stage-1 kernel of rocm_mla_decode_rope.py, LSE-merged) -> mla_rope.npz
   F17 QK-norm + RoPE (RMSNorm.forward_native + apply_rotary_emb, the pair the reference tests its fused kernel against) -> qknorm_rope.npz
+  F18 EAGLE multi-step draft decode: per-step kv_indices / kv_indptr of the top-k branches (generate_draft_decode_kv_indices) -> draft_kv_indices.npz
 """
 import json
 import os
@@ -1142,8 +1143,44 @@ def f17():
     save("qknorm_rope.npz", **flat)
 
 
+def f18():
+    """F18 multi-step draft decode indices -> draft_kv_indices.npz.  The reference's Triton kernel
+    generate_draft_decode_kv_indices (kernels/ops/speculative/cache_locs.py:56-141) under TRITON_INTERPRET=1, launched as
+    TritonMultiStepDraftBackend.common_template does (triton_backend.py:1929-1945): grid (speculative_num_steps, num_seqs,
+    topk), kv_indices [steps, num_seqs * topk * max_context_len] int64, kv_indptr [steps, max_bs * topk + 1] int32,
+    positions = every branch's sequence length (what the draft worker passes in its first step).  Cases: top-k 1 / 4 / 8,
+    page size 1 / 16 / 64 (the paged branch layout of top-k > 1), 1-5 steps, ragged lengths incl. page-aligned ones."""
+    from sglang.kernels.ops.speculative.cache_locs import generate_draft_decode_kv_indices
+    from sglang.srt.utils import next_power_of_2
+
+    rng = np.random.default_rng(18)
+    flat = {}
+    cases = [("topk1_ps1", 1, 1, 3, [5, 17, 1]), ("topk4_ps1", 4, 1, 4, [33, 2, 100, 64, 7]), ("topk4_ps16", 4, 16, 3, [33, 16, 100, 64, 7]),
+             ("topk8_ps64", 8, 64, 5, [130, 64, 1, 200]), ("topk1_ps16", 1, 16, 5, [40, 16]), ("topk2_ps16_step1", 2, 16, 1, [31, 32, 33])]
+    for name, topk, ps, steps, lens in cases:
+        num_seqs = len(lens)
+        max_ctx = max(lens) + (steps + ps) * topk + 8
+        pool_rows = num_seqs + 3
+        r2t = torch.from_numpy(rng.integers(1, 10 ** 6, size=(pool_rows, max_ctx)).astype(np.int32))
+        rpi = torch.from_numpy(rng.permutation(pool_rows)[:num_seqs].astype(np.int64))
+        seq = torch.tensor(lens, dtype=torch.int64)
+        bs = num_seqs * topk
+        positions = seq.repeat_interleave(topk)
+        width = num_seqs * topk * max_ctx
+        kv_indices = torch.full((steps, width), -1, dtype=torch.int64)
+        kv_indptr = torch.zeros((steps, pool_rows * topk + 1), dtype=torch.int32)
+        generate_draft_decode_kv_indices[(steps, num_seqs, topk)](
+            rpi, r2t, seq, kv_indices, kv_indptr, positions, r2t.shape[1], kv_indices.shape[1], kv_indptr.shape[1],
+            next_power_of_2(num_seqs), next_power_of_2(steps), next_power_of_2(bs), ps)
+        c = dict(req_to_token=r2t, req_pool_indices=rpi, seq_lens=seq, positions=positions, topk=topk, page_size=ps,
+                 num_steps=steps, kv_indices=kv_indices, kv_indptr=kv_indptr)
+        for kk, v in c.items():
+            flat[f"{name}.{kk}"] = bits(v) if isinstance(v, torch.Tensor) else np.asarray(v)
+    save("draft_kv_indices.npz", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14",
-                             "f15", "f16", "f17"]
+                             "f15", "f16", "f17", "f18"]
     for w in which:
         globals()[w]()

@@ -482,3 +482,18 @@ def test_fused_qk_norm_rope_oracle_matches_reference_norm_and_rope(golden_dir):
     assert np.allclose(f[:9], f0[:9]) and np.allclose(f[24:], f0[24:] / 4.0) and (f[9:24] < f0[9:24]).all() and (f[9:24] > f0[9:24] / 4).all()
     g = orc.qknorm_rope_freqs(64, 10000.0, factor=2.0, low=5.0, high=5.0)      # low == high: high + 0.001
     assert np.allclose(g[:6], f0[:6]) and np.allclose(g[6:], f0[6:] / 2.0)
+
+
+def test_draft_decode_kv_indices_golden(golden_dir):
+    """F18: the oracle's restatement of generate_draft_decode_kv_indices against the reference's Triton kernel (run under
+    the interpreter by tests/golden/make_golden.py f18), every element of both outputs, bit-exact."""
+    z = np.load(os.path.join(golden_dir, "draft_kv_indices.npz"))
+    names = sorted({k.split(".")[0] for k in z.files})
+    assert len(names) == 6
+    for n in names:
+        g = {k.split(".", 1)[1]: z[k] for k in z.files if k.startswith(n + ".")}
+        kvi, kvp = orc.draft_decode_kv_indices(g["req_to_token"], g["req_pool_indices"], g["seq_lens"], g["positions"],
+                                               int(g["topk"]), int(g["num_steps"]), int(g["page_size"]),
+                                               g["kv_indices"].shape[1], g["kv_indptr"].shape[1])
+        assert np.array_equal(kvi, g["kv_indices"]), n
+        assert np.array_equal(kvp, g["kv_indptr"]), n
