@@ -239,6 +239,7 @@ class HipRadixAttnBackend:
         self._no_split_items = bool(os.environ.get("RX_NO_SPLIT_ITEMS"))  # dev A/B: split slots instead of compacted pairs
         # RX_DEBUG_CHECKS=1: host-synchronising assertions of the backend's preconditions (see forward_decode)
         self._debug_checks = os.environ.get("RX_DEBUG_CHECKS", "0") not in ("", "0")
+        self._roctx = False
         self._graph = None  # static buffers of init_cuda_graph_state
         self._md_version = 0  # bumped by every init_forward_metadata_out_graph
         self._decode_launchers = {}  # layer_id -> ops.DecodeLauncher
@@ -311,6 +312,8 @@ class HipRadixAttnBackend:
             self._graph["captured"] = True
 
     def _build_metadata(self, forward_batch: ForwardBatch, graph: bool):
+        from .. import lib as _lib
+        self._roctx = bool(_lib.get_option("roctx"))
         bs = forward_batch.batch_size
         mode = forward_batch.forward_mode
         self._md_version += 1
@@ -979,6 +982,15 @@ class HipRadixAttnBackend:
         mode = forward_batch.forward_mode
         if mode.is_idle():
             return q.new_empty(q.shape[0], layer.tp_q_head_num * layer.v_head_dim)
+        if self._roctx:  # option `roctx` (read when the metadata is built): one named range per layer around its launches
+            from .. import lib as _lib
+            _lib.range_push(f"layer{layer.layer_id}.{'decode' if mode.is_decode() else 'extend'}")
+            try:
+                if mode.is_decode():
+                    return self.forward_decode(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache, **kwargs)
+                return self.forward_extend(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache, **kwargs)
+            finally:
+                _lib.range_pop()
         if mode.is_decode():
             return self.forward_decode(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache, **kwargs)
         return self.forward_extend(q, k, v, layer, forward_batch, save_kv_cache=save_kv_cache, **kwargs)

@@ -435,6 +435,7 @@ static ArArgs ar_args(const ArCtx* c) {
 }
 
 int rx_allreduce(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int dtype, void* stream) {
+  RX_RANGE("rx_allreduce");
   RX_REQUIRE(ctx && in && out, "rx_allreduce: null pointer");
   auto* c = reinterpret_cast<ArCtx*>(ctx);
   RX_REQUIRE(dtype == RX_BF16 || dtype == RX_F16, "rx_allreduce: dtype %d", dtype);
@@ -457,6 +458,7 @@ int rx_allreduce(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int d
 
 int rx_allreduce_rmsnorm(rx_ar_ctx* ctx, const void* in, const void* residual_in, const void* weight, void* out,
                          void* residual_out, int64_t rows, int64_t hidden, float eps, int dtype, void* stream) {
+  RX_RANGE("rx_allreduce_rmsnorm");
   RX_REQUIRE(ctx && in && residual_in && weight && out && residual_out, "rx_allreduce_rmsnorm: null pointer");
   auto* c = reinterpret_cast<ArCtx*>(ctx);
   RX_REQUIRE(dtype == RX_BF16 || dtype == RX_F16, "rx_allreduce_rmsnorm: dtype %d", dtype);

@@ -28,6 +28,7 @@ struct Options {
   int ext32_pack_min_tiles = 4;   // ... and this tile estimate; packed PLAIN rows take eight waves from here
   int ext32_pack_min_wgs = -1;    // ... while the packed grid holds this many workgroups (-1: the device's CU count)
   int ext32_plain = 1;        // PLAIN instances (features compile-time off) when the call uses none of them
+  int roctx = 0;              // roctx ranges around the entry points' launches (RX_RANGE)
   int ext32_count_redo = 0;   // debug: the bench-shaped packed call runs the COUNTING instance (rx_debug_counters)
   int ext64 = 0;              // 1: PLAIN eight-wave calls take rx_extend64.hip's kernel (four waves of 64 rows, one per SIMD; experimental: slower)
   int extend_16x16_d128 = 0;  // the 16x16x32 kernel of rx_extend.hip for plain D = 128 calls (A/B of the two shapes)
@@ -43,6 +44,24 @@ struct Options {
   int decode_mla8_dma = 1;    // fp8 latent rows through the LDS-DMA kernel (0: upcast-while-staging form)
 };
 Options& options();
+
+// ---- optional tooling hooks (round 5; SURVEY 5: named ranges around the library's launches, an argument dump at the C-ABI
+// boundary as sglang/kernel_api_logging.py:52-60 has for the reference's kernel API) ----------------------------------
+// RX_RANGE("rx_decode_attn"): a roctx range around the entry point's launches when option `roctx` is on (RX_OPT_ROCTX=1 at
+// load, or rx_set_option): rocprofv3 --marker-trace then names store / metadata / decode / extend in the timeline.
+// libroctx64.so is dlopen'ed on first use; absent, the option does nothing.
+struct RangeGuard {
+  bool on;
+  explicit RangeGuard(const char* name);
+  ~RangeGuard();
+};
+#define RX_RANGE(name) ::rx::RangeGuard rx_range_guard_(name)
+// RX_DUMP_DIR (read once at load): an entry point that returns a non-zero status leaves <dir>/rx_<entry>_<pid>_<n>.txt (status,
+// rx_last_error) and .bin (the raw parameter struct: tools/decode_dump.py prints its fields through the ctypes binding).
+int dump_on_error(const char* entry, int status, const void* params, size_t bytes);
+// CU count of the CURRENT device (cached per device id: a process may drive GPUs of different sizes, and the first call
+// may come before its hipSetDevice -- ADVICE r4).  256 when the query fails.
+int device_cu_count();
 // name of the kernel instance the calling thread's last rx_extend_attn / rx_decode_attn launched (rx_last_dispatch)
 void note_dispatch(const char* fmt, ...);
 

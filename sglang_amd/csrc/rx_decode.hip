@@ -911,7 +911,12 @@ static int run_mla(const rx_decode_params* p, const DecodeArgs& a, hipStream_t s
 
 using namespace rx;
 
+static int decode_attn_impl(const rx_decode_params* p, void* stream);
 extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {
+  RX_RANGE("rx_decode_attn");
+  return rx::dump_on_error("decode_attn", decode_attn_impl(p, stream), p, p ? sizeof(*p) : 0);
+}
+static int decode_attn_impl(const rx_decode_params* p, void* stream) {
   RX_REQUIRE(p, "rx_decode_attn: params is null");
   RX_REQUIRE(p->bs >= 0, "rx_decode_attn: bs < 0");
   if (p->bs == 0) return RX_OK;

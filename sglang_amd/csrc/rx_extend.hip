@@ -611,7 +611,12 @@ using namespace rx;
 
 // total_q for the generic path is bs * max_extend_len (an upper bound); blocks past the real
 // token count exit early.
+static int extend_attn_impl(const rx_extend_params* p, void* stream);
 extern "C" int rx_extend_attn(const rx_extend_params* p, void* stream) {
+  RX_RANGE("rx_extend_attn");
+  return rx::dump_on_error("extend_attn", extend_attn_impl(p, stream), p, p ? sizeof(*p) : 0);
+}
+static int extend_attn_impl(const rx_extend_params* p, void* stream) {
   RX_REQUIRE(p, "rx_extend_attn: params is null");
   RX_REQUIRE(p->bs >= 0 && p->max_extend_len >= 0, "rx_extend_attn: negative sizes");
   if (p->bs == 0 || p->max_extend_len == 0) return RX_OK;

@@ -66,11 +66,7 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   // Packing trades workgroups for work: it is taken only while the packed grid still covers the chip (1 request x 32 k +
   // 64 tokens: 32 per-head workgroups 636 us, 8 packed ones 993 -- a batch that small needs the parallelism more).
   const int grp = p->num_kv_heads > 0 ? p->num_q_heads / p->num_kv_heads : 1;
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n > 0 ? n : 256;
-  }();
+  const int cus = device_cu_count();  // (of the current device; rx_set_option / options() are process-wide and not thread-safe)
   if (opt.ext32_autopack && a.q_pack == 1 && plain_any && (grp == 4 || grp == 8) && p->num_q_heads == grp * p->num_kv_heads &&
       p->is_causal && !p->skip_extend && p->max_extend_len >= opt.ext32_pack_min_len && est_tiles >= opt.ext32_pack_min_tiles &&
       static_cast<int64_t>(a.bs) * p->num_kv_heads * ((static_cast<int64_t>(p->max_extend_len) * grp + 255) / 256) >=

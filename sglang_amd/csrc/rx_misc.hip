@@ -1,6 +1,13 @@
 // Integer / byte kernels of the RadixAttention path: KV store (K1), kv-index build (K2),
 // kv-split scheduler (K3), paged slot allocation (K9), KV move (K10), req_to_token write (K11).
 // All HBM-bound byte movers: 16-byte per-lane accesses, one wave (or a fraction) per row.
+#include <dlfcn.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
 #include "rx_common.h"
 
 #include <cctype>
@@ -27,6 +34,80 @@ void note_dispatch(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- tooling hooks -------------------------------------------------------------------------------------------------
+namespace {
+using roctx_push_t = int (*)(const char*);
+using roctx_pop_t = int (*)();
+struct Roctx {
+  roctx_push_t push = nullptr;
+  roctx_pop_t pop = nullptr;
+  Roctx() {
+    for (const char* name : {"libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        push = reinterpret_cast<roctx_push_t>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<roctx_pop_t>(dlsym(h, "roctxRangePop"));
+        if (push && pop) return;
+        push = nullptr;
+        pop = nullptr;
+      }
+    }
+  }
+};
+Roctx& roctx() {
+  static Roctx r;
+  return r;
+}
+const char* g_dump_dir = nullptr;  // RX_DUMP_DIR, read with the options (load_options below): once, off every launch path
+const char* dump_dir() {
+  (void)options();
+  return g_dump_dir;
+}
+}  // namespace
+
+int device_cu_count() {
+  static std::atomic<int> cache[64];  // 0 = not asked yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
+RangeGuard::RangeGuard(const char* name) : on(false) {
+  if (options().roctx && roctx().push) {
+    roctx().push(name);
+    on = true;
+  }
+}
+RangeGuard::~RangeGuard() {
+  if (on) roctx().pop();
+}
+
+int dump_on_error(const char* entry, int status, const void* params, size_t bytes) {
+  const char* dir = dump_dir();
+  if (status == RX_OK || !dir) return status;
+  static std::atomic<int> seq{0};
+  char path[768];
+  const int n = seq.fetch_add(1);
+  snprintf(path, sizeof(path), "%s/rx_%s_%d_%d.txt", dir, entry, static_cast<int>(getpid()), n);
+  if (FILE* f = fopen(path, "w")) {
+    fprintf(f, "entry: %s\nstatus: %d\nabi: %d\nerror: %s\nparams_bytes: %zu\nlast_dispatch: %s\n", entry, status, RX_ABI_VERSION,
+            err_buf(), bytes, g_dispatch);
+    fclose(f);
+  }
+  if (params && bytes) {
+    snprintf(path, sizeof(path), "%s/rx_%s_%d_%d.bin", dir, entry, static_cast<int>(getpid()), n);
+    if (FILE* f = fopen(path, "wb")) {
+      fwrite(params, 1, bytes, f);
+      fclose(f);
+    }
+  }
+  return status;
+}
+
 struct OptionEntry {
   const char* name;
   int Options::*field;
@@ -35,6 +116,7 @@ static const OptionEntry kOptionTable[] = {
     {"ext32_autopack", &Options::ext32_autopack},         {"ext32_small_wg", &Options::ext32_small_wg},
     {"ext32_small_wg_tiles", &Options::ext32_small_wg_tiles}, {"ext32_pack_min_len", &Options::ext32_pack_min_len},
     {"ext32_pack_min_tiles", &Options::ext32_pack_min_tiles}, {"ext32_pack_min_wgs", &Options::ext32_pack_min_wgs},
+    {"roctx", &Options::roctx},
     {"ext64", &Options::ext64},                           {"ext32_count_redo", &Options::ext32_count_redo},
     {"ext32_plain", &Options::ext32_plain},               {"extend_16x16_d128", &Options::extend_16x16_d128},
     {"extend_d256", &Options::extend_d256},               {"extend_d256_min_rows", &Options::extend_d256_min_rows},
@@ -53,6 +135,8 @@ static Options load_options() {  // once, at first use: RX_OPT_<NAME> (upper cas
     env[n] = 0;
     if (const char* v = getenv(env)) o.*(e.field) = atoi(v);
   }
+  if (const char* d = getenv("RX_DUMP_DIR"))  // (load_options: the argument-dump directory, see dump_on_error)
+    if (*d) g_dump_dir = strdup(d);
   return o;
 }
 Options& options() {
@@ -655,6 +739,7 @@ int rx_store_kv(const void* k, const void* v, void* k_cache, void* v_cache, cons
                 int64_t v_stride_bytes, int64_t kc_stride_bytes, int64_t vc_stride_bytes,
                 int loc_is_i64, int64_t size_limit, int64_t skip_index, int32_t* err_flag,
                 void* stream) {
+  RX_RANGE("rx_store_kv");
   RX_REQUIRE(n >= 0, "rx_store_kv: n=%lld < 0", (long long)n);
   if (n == 0) return RX_OK;
   RX_REQUIRE(k && v && k_cache && v_cache && loc, "rx_store_kv: null pointer");
@@ -689,6 +774,7 @@ int rx_store_kv_layout(const void* k, const void* v, const rx_kv_layout* lay, co
                        int64_t n, int num_kv_heads, int head_dim, int v_head_dim,
                        int64_t k_stride_t, int64_t v_stride_t, int loc_is_i64, int64_t size_limit,
                        int64_t skip_index, int32_t* err_flag, void* stream) {
+  RX_RANGE("rx_store_kv_layout");
   RX_REQUIRE(n >= 0, "rx_store_kv_layout: n < 0");
   if (n == 0) return RX_OK;
   RX_REQUIRE(k && v && lay && lay->k_buf && lay->v_buf && loc, "rx_store_kv_layout: null pointer");
@@ -713,6 +799,7 @@ int rx_store_kv_fp8(const void* k, const void* v, const rx_kv_layout* lay, const
                     int num_kv_heads, int head_dim, int v_head_dim, int64_t k_stride_t,
                     int64_t v_stride_t, int src_dtype, float k_scale, float v_scale, int loc_is_i64,
                     int64_t size_limit, int64_t skip_index, int32_t* err_flag, void* stream) {
+  RX_RANGE("rx_store_kv_fp8");
   RX_REQUIRE(n >= 0, "rx_store_kv_fp8: n < 0");
   if (n == 0) return RX_OK;
   RX_REQUIRE(k && v && lay && lay->k_buf && lay->v_buf && loc, "rx_store_kv_fp8: null pointer");
@@ -771,6 +858,7 @@ int rx_get_mla_kv(const void* kv_buf, int64_t row_stride, int kv_fp8, const void
 
 int rx_merge_state(const void* a, const float* lse_a, const void* b, const float* lse_b, void* out,
                    float* out_lse, int64_t num_tokens, int num_heads, int head_size, int dtype, void* stream) {
+  RX_RANGE("rx_merge_state");
   RX_REQUIRE(num_tokens >= 0 && num_heads > 0, "rx_merge_state: bad sizes");
   if (num_tokens == 0) return RX_OK;
   RX_REQUIRE(a && b && lse_a && lse_b && out, "rx_merge_state: null pointer");
@@ -816,6 +904,7 @@ int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,
                         const void* req_pool_indices, int pool_idx_is_i64, const void* lens,
                         int lens_is_i64, const int32_t* kv_start, int32_t* kv_indptr_out,
                         void* kv_indices_out, int out_is_i64, int bs, void* stream) {
+  RX_RANGE("rx_build_kv_indices");
   RX_REQUIRE(bs >= 0, "rx_build_kv_indices: bs < 0");
   RX_REQUIRE(kv_indptr_out, "rx_build_kv_indices: kv_indptr_out is null");
   auto s = static_cast<hipStream_t>(stream);
@@ -846,6 +935,7 @@ int rx_draft_decode_kv_indices(const int32_t* req_to_token, int64_t row_stride, 
                                const void* seq_lens, int seq_lens_is_i64, const void* positions, int positions_is_i64,
                                int num_seqs, int topk, int num_steps, int page_size, void* kv_indices, int kv_indices_is_i64,
                                int64_t kv_indices_stride, int32_t* kv_indptr, int64_t kv_indptr_stride, void* stream) {
+  RX_RANGE("rx_draft_decode_kv_indices");
   RX_REQUIRE(num_seqs >= 0 && topk >= 1 && num_steps >= 1 && num_steps <= 256 && page_size >= 1,
              "rx_draft_decode_kv_indices: bad sizes (topk >= 1, 1 <= num_steps <= 256, page_size >= 1)");
   if (num_seqs == 0) return RX_OK;
@@ -869,6 +959,7 @@ int rx_draft_decode_kv_indices(const int32_t* req_to_token, int64_t row_stride, 
 int rx_num_kv_splits(const void* seq_lens, int seq_lens_is_i64, int num_seq, int num_group,
                      int num_head, int num_kv_head, int max_kv_splits, int device_core_count,
                      int32_t* out, void* stream) {
+  RX_RANGE("rx_num_kv_splits");
   RX_REQUIRE(seq_lens && out, "rx_num_kv_splits: null pointer");
   RX_REQUIRE(num_seq > 0 && num_group > 0 && num_head > 0 && num_kv_head > 0 &&
                  max_kv_splits > 0 && num_head % num_kv_head == 0,
@@ -892,6 +983,7 @@ __global__ __launch_bounds__(256) void num_kv_splits_native_kernel(const void* _
 
 int rx_num_kv_splits_native(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int cu_count,
                             int max_kv_splits, int min_tokens_per_split, int32_t* out, void* stream) {
+  RX_RANGE("rx_num_kv_splits_native");
   RX_REQUIRE(bs >= 0, "rx_num_kv_splits_native: bs < 0");
   if (bs == 0) return RX_OK;
   RX_REQUIRE(seq_lens && out, "rx_num_kv_splits_native: null pointer");
@@ -1163,6 +1255,7 @@ __global__ __launch_bounds__(1024) void split_items_kernel(const int32_t* splits
 
 int rx_split_items(const int32_t* num_kv_splits, const int32_t* order, int bs, int32_t* items, int32_t* count, int cap,
                    void* stream) {
+  RX_RANGE("rx_split_items");
   RX_REQUIRE(bs >= 0 && cap >= 0, "rx_split_items: negative sizes");
   RX_REQUIRE(count, "rx_split_items: null count");
   if (bs == 0) {
@@ -1177,6 +1270,7 @@ int rx_split_items(const int32_t* num_kv_splits, const int32_t* order, int bs, i
 
 int rx_split_items_guarded(int32_t* num_kv_splits, const int32_t* order, int bs, int32_t* items, int32_t* count, int cap,
                            int32_t* overflow, void* stream) {
+  RX_RANGE("rx_split_items_guarded");
   RX_REQUIRE(bs >= 0 && cap >= bs, "rx_split_items_guarded: cap must hold one pair per request (cap >= bs)");
   RX_REQUIRE(count, "rx_split_items_guarded: null count");
   if (bs == 0) {
@@ -1192,6 +1286,7 @@ int rx_split_items_guarded(int32_t* num_kv_splits, const int32_t* order, int bs,
 int rx_num_kv_splits_balanced(const void* seq_lens, int seq_lens_is_i64, int bs, int wg_per_request, int wg_target,
                               int max_kv_splits, int min_tokens_per_split, int wg_target_mixed, int32_t* out,
                               void* stream) {
+  RX_RANGE("rx_num_kv_splits_balanced");
   RX_REQUIRE(bs >= 0, "rx_num_kv_splits_balanced: bs < 0");
   if (bs == 0) return RX_OK;
   RX_REQUIRE(seq_lens && out, "rx_num_kv_splits_balanced: null pointer");
@@ -1245,6 +1340,7 @@ int rx_write_req_to_token(int32_t* req_to_token, int64_t row_stride,
 
 int rx_move_kv(const uint64_t* data_ptrs, const int64_t* row_bytes, int num_bufs,
                const int64_t* tgt_loc, const int64_t* src_loc, int64_t n, void* stream) {
+  RX_RANGE("rx_move_kv");
   RX_REQUIRE(num_bufs >= 0 && n >= 0, "rx_move_kv: bad sizes");
   if (num_bufs == 0 || n == 0) return RX_OK;
   RX_REQUIRE(data_ptrs && row_bytes && tgt_loc && src_loc, "rx_move_kv: null pointer");

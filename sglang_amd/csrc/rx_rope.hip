@@ -12,6 +12,8 @@
 //   gptj : pairs (2i, 2i+1)    :  o[2i] = x[2i] cos_i - x[2i+1] sin_i ;   o[2i+1]   = x[2i+1] cos_i + x[2i] sin_i
 // computed in fp32 from the fp32 cache, rounded once to the 16-bit dtype; columns >= rot_dim pass through.
 // One wave per (token, head): q heads first, then the kv heads (which also carry the v row to the pool).
+#include <cmath>
+
 #include "rx_common.h"
 
 namespace rx {
@@ -122,6 +124,7 @@ struct QkNormRopeArgs {
   const uint16_t* q_weight;
   const uint16_t* k_weight;
   float eps, base, factor, low, high, attention_factor;
+  float kf;  // -2 / rotary_dim * log2(base), computed on the HOST in double (the fast kernel's exp2 exponent per pair index)
   const void* positions;  // int32 or int64
   int32_t pos64, on_the_fly;
   int32_t cache_vec;  // the cache rows can be read 16 bytes at a time (aligned base and row stride, rotary_dim % 8 == 0)
@@ -233,7 +236,9 @@ __global__ __launch_bounds__(256) void qknorm_rope_fast_kernel(const QkNormRopeA
   const int64_t total = a.n * heads;
   const int base_i = 8 * sub;
   const int half = a.rot >> 1;
-  const float kf = -2.0f / static_cast<float>(a.rot) * __log2f(qa.base);
+  // (from the host: the approximate __log2f's relative error is multiplied by the position in the angle -- at 128 k it put
+  // the fast and the generic kernel noticeably apart)
+  const float kf = qa.kf;
   int64_t tt[UNR];
   int hd[UNR];
   bool isk[UNR], live[UNR];
@@ -405,6 +410,7 @@ extern "C" int rx_rope_store_kv(void* q, void* k, const void* v, int64_t q_strid
                                 int64_t cos_sin_stride, int is_neox, const rx_kv_layout* lay, const void* loc,
                                 int loc_is_i64, int64_t size_limit, int64_t skip_index, float k_scale,
                                 float v_scale, int dtype, int32_t* err_flag, void* stream) {
+  RX_RANGE("rx_rope_store_kv");
   RX_REQUIRE(n >= 0, "rx_rope_store_kv: n < 0");
   if (n == 0) return RX_OK;
   RX_REQUIRE(q && k && positions && cos_sin_cache, "rx_rope_store_kv: null pointer");
@@ -483,6 +489,7 @@ extern "C" int rx_qknorm_rope_store_kv(void* q, void* k, const void* v, int64_t 
                                        int64_t cos_sin_stride, int is_neox, const rx_kv_layout* lay, const void* loc,
                                        int loc_is_i64, int64_t size_limit, int64_t skip_index, float k_scale,
                                        float v_scale, int dtype, int32_t* err_flag, void* stream) {
+  RX_RANGE("rx_qknorm_rope_store_kv");
   RX_REQUIRE(n >= 0, "rx_qknorm_rope_store_kv: n < 0");
   if (n == 0) return RX_OK;
   RX_REQUIRE(q && k && positions && q_weight && k_weight, "rx_qknorm_rope_store_kv: null pointer");
@@ -505,6 +512,7 @@ extern "C" int rx_qknorm_rope_store_kv(void* q, void* k, const void* v, int64_t 
   a.cos_sin = cos_sin_cache; a.cos_sin_stride = cos_sin_stride; a.is_neox = is_neox;
   qa.q_weight = static_cast<const uint16_t*>(q_weight);
   qa.k_weight = static_cast<const uint16_t*>(k_weight);
+  qa.kf = static_cast<float>(-2.0 / static_cast<double>(rotary_dim) * std::log2(static_cast<double>(base)));
   qa.eps = eps; qa.base = base; qa.factor = factor; qa.low = low; qa.high = high; qa.attention_factor = attention_factor;
   qa.positions = positions; qa.pos64 = positions_is_i64; qa.on_the_fly = cos_sin_cache == nullptr;
   qa.cache_vec = cos_sin_cache && ((uintptr_t)cos_sin_cache & 15) == 0 && cos_sin_stride % 4 == 0 && rotary_dim % 8 == 0;

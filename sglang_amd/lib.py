@@ -259,6 +259,29 @@ def debug_counters(reset: bool = False):
     return int(out[0]), int(out[1])
 
 
+_roctx = None
+
+
+def range_push(name: str) -> None:
+    """A roctx range from the host side (e.g. one per layer around RadixAttention.forward) when option `roctx` is on;
+    the library's own entry points add theirs inside it (RX_RANGE, csrc/rx_common.h)."""
+    global _roctx
+    if not get_option("roctx"):
+        return
+    if _roctx is None:
+        try:
+            _roctx = C.CDLL("libroctx64.so")
+        except OSError:
+            _roctx = False
+    if _roctx:
+        _roctx.roctxRangePushA(name.encode())
+
+
+def range_pop() -> None:
+    if _roctx and get_option("roctx"):
+        _roctx.roctxRangePop()
+
+
 def set_option(name: str, value: int) -> int:
     """rx_set_option: a process-wide dispatch switch (include/radix_hip.h lists the names).  Returns the old value."""
     old = c_int(0)

@@ -1466,7 +1466,8 @@ def fused_qk_norm_rope(qkv: torch.Tensor, num_heads_q: int, num_heads_k: int, nu
     if layout is not None:
         if loc is None or nv != nk:
             raise ValueError("fused_qk_norm_rope: the pool store needs loc and as many v heads as k heads")
-        lay_ref, locp, l64 = C.byref(layout), _ptr(loc.contiguous()), _is64(loc, "loc")
+        loc_c = loc.contiguous()  # (kept alive in a local until the launch is queued: the kernel reads it asynchronously)
+        lay_ref, locp, l64 = C.byref(layout), _ptr(loc_c), _is64(loc, "loc")
     pos = position_ids.contiguous()
     stt = _L.load().rx_qknorm_rope_store_kv(
         qp, kp, vp, st, d, st, d, st, d, n, nq, nk, d, d if layout is not None else 0, rot, _ptr(q_weight), _ptr(k_weight),
@@ -1499,7 +1500,8 @@ def rope_store_kv(q, k, v, positions, cos_sin_cache, is_neox: bool, *, rotary_di
             raise ValueError("rope_store_kv: the pool store needs v and loc")
         if v.dim() != 3 or v.stride(-1) != 1:
             raise ValueError("rope_store_kv: v must be [n, Hkv, Dv], contiguous in Dv")
-        lay_ref, locp, l64 = C.byref(layout), _ptr(loc.contiguous()), _is64(loc, "loc")
+        loc_c = loc.contiguous()  # (kept alive in a local until the launch is queued)
+        lay_ref, locp, l64 = C.byref(layout), _ptr(loc_c), _is64(loc, "loc")
         dv, vs_t, vs_h = v.shape[-1], v.stride(0), v.stride(1)
     st = _L.load().rx_rope_store_kv(
         _ptr(q), _ptr(k), _ptr(v), q.stride(0), q.stride(1), k.stride(0), k.stride(1), vs_t, vs_h, q.shape[0],

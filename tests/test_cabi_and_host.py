@@ -311,3 +311,35 @@ def test_extend64_owns_its_accumulator_registers():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_acc_ownership.py"), out], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout[-3000:]
         assert r.stdout.count("all inside the kernel's asm statements") == 24, r.stdout  # 2 dtypes x 2 index types x 2 x 3 packings
+
+
+def test_dump_dir_records_a_failing_call(tmp_path):
+    """RX_DUMP_DIR (read once at load, so a fresh process): an entry point that returns a non-zero status leaves a text
+    record (status, rx_last_error) and the raw parameter struct, which tools/decode_dump.py prints field by field.  The
+    call fails in argument validation, before any GPU work."""
+    import subprocess
+    import sys
+
+    code = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from sglang_amd import lib
+l = lib.load()
+p = lib.RxExtendParams()
+p.bs = 3
+p.head_dim = 128
+p.max_extend_len = 5      # (q / o stay null: the call fails in argument validation)
+rc = l.rx_extend_attn(C.byref(p), None)
+assert rc != 0
+print("RC", rc, l.rx_last_error().decode())
+''' % ROOT
+    env = dict(os.environ, RX_DUMP_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    txt = sorted(f for f in os.listdir(tmp_path) if f.endswith(".txt"))
+    assert len(txt) == 1 and txt[0].startswith("rx_extend_attn_"), os.listdir(tmp_path)
+    rec = open(os.path.join(tmp_path, txt[0])).read()
+    assert "status:" in rec and "error:" in rec and "abi: 12" in rec
+    d = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "decode_dump.py"), os.path.join(tmp_path, txt[0])],
+                       capture_output=True, text=True)
+    assert d.returncode == 0 and "bs = 3" in d.stdout and "head_dim = 128" in d.stdout, d.stdout[-1500:] + d.stderr[-500:]

@@ -1063,3 +1063,29 @@ def test_target_verify_graph_replay_refreshes_indices_and_mask():
         for r, t in zip(rows, total):
             hs.alloc.free(hs.r2t.req_to_token[r, :t].to(torch.int64))
     assert hs.pool.check_errors() == 0
+
+
+def test_roctx_ranges_do_not_change_a_decode_step():
+    """Option `roctx` (named ranges around the library's launches and per layer from the backend): the same decode
+    step with the option on and off -- libroctx64.so present or not -- gives the same bits."""
+    from sglang_amd import lib as rxlib
+    from sglang_amd.forward_batch import ForwardBatch
+
+    hs = _Harness(16, 32, 8, 128, torch.bfloat16, "shuffled_pages", "paged")
+    rows = hs.r2t.alloc(3)
+    prefix = (200, 33, 1024)
+    hs.fill_prefix(rows, prefix)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    seq = torch.tensor([p + 1 for p in prefix], dtype=torch.int64)
+    last = torch.tensor([int(hs.r2t.req_to_token[r, p - 1]) for r, p in zip(rows, prefix)], dtype=torch.int64, device=DEV)
+    loc = hs.alloc.alloc_decode(seq.to(DEV), seq, last)
+    hs.r2t.req_to_token[rpi, torch.tensor(prefix, device=DEV)] = loc.to(torch.int32)
+    q, k, v = hs.rand(3, 32 * 128), hs.rand(3, 8 * 128), hs.rand(3, 8 * 128)
+    outs = []
+    for on in (0, 1):
+        with rxlib.option("roctx", on):
+            fb = ForwardBatch.for_decode(rpi, seq.to(DEV), loc, seq)
+            hs.backend.init_forward_metadata(fb)
+            outs.append(hs.layer(q, k, v, fb, hs.backend).clone())
+            torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])

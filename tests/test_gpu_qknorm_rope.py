@@ -211,3 +211,37 @@ def test_fused_qk_norm_rope_out_custom_op_matches_the_direct_call():
     ops.fused_qk_norm_rope(b, 8, 2, 2, 128, 1e-6, qw, kw_, 10000.0, False, pos, 1.0, 0.0, 0.0, 1.0, 64)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and not torch.equal(a, qkv0)
+
+
+def test_fast_and_generic_kernels_agree_at_long_context_positions():
+    """the fast kernel builds its frequencies as exp2(p * kf) with kf = -2 / rot * log2(base); with the approximate
+    __log2f in the kernel the relative error of kf was multiplied by the position inside the angle and the two kernels
+    (which one runs depends only on alignment) drifted apart at long contexts.  kf now comes from the host in double.
+    Positions up to 200 k: the aligned call (fast kernel) and the same rows at a misaligned head row stride (generic
+    kernel) agree, and both meet the fp64 oracle at the angle error the fp32 product pos * freq itself carries."""
+    from sglang_amd import ops
+
+    hq, hkv, d, rot, n = 4, 2, 128, 128, 64
+    g = torch.Generator().manual_seed(3)
+    qkv0 = torch.randn(n, (hq + 2 * hkv) * d, generator=g).to(torch.bfloat16)
+    qw, kw_ = (1 + 0.1 * torch.randn(d, generator=g)).to(torch.bfloat16), (1 + 0.1 * torch.randn(d, generator=g)).to(torch.bfloat16)
+    pos = torch.cat([torch.randint(120_000, 200_000, (n - 2,), generator=g), torch.tensor([131071, 199999])]).to(torch.int32)
+    outs = []
+    for misalign in (False, True):
+        if misalign:   # rows that start 2 bytes off a 16-byte boundary: the generic kernel
+            buf = torch.zeros(n * (hq + 2 * hkv) * d + 1, dtype=torch.bfloat16, device=DEV)
+            qkv = buf[1:].view(n, -1)
+            qkv.copy_(qkv0)
+        else:
+            qkv = qkv0.clone().to(DEV)
+        ops.fused_qk_norm_rope(qkv, hq, hkv, hkv, d, 1e-6, qw.to(DEV), kw_.to(DEV), 500000.0, True, pos.to(DEV), 1.0, 0.0, 0.0, 1.0, rot)
+        torch.cuda.synchronize()
+        outs.append(qkv.float().cpu().numpy())
+    q = qkv0[:, : hq * d].reshape(n, hq, d)
+    k = qkv0[:, hq * d: (hq + hkv) * d].reshape(n, hkv, d)
+    want_q, want_k = orc.fused_qk_norm_rope(_bits(q), _bits(k), _bits(qw), _bits(kw_), pos.numpy(), 1e-6, 500000.0, True, 1.0, 0.0, 0.0, 1.0, rot)
+    # the angle pos * freq in fp32: relative 2^-23 of up to 2e5 rad -> ~0.025 rad at the lowest pair index; values are O(3)
+    for got in outs:
+        assert np.abs(got[:, : hq * d].reshape(n, hq, d) - want_q).max() < 0.12
+        assert np.abs(got[:, hq * d: (hq + hkv) * d].reshape(n, hkv, d) - want_k).max() < 0.12
+    assert np.abs(outs[0] - outs[1]).max() < 0.1
