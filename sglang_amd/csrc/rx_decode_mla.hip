@@ -684,6 +684,62 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
       qf[s] = __builtin_bit_cast(vec8, raw);
     }
   }
+  // Q8 (bf16 queries, round 5): QK^T on the fp8 MFMA with the latent rows AS STORED -- no upcast of the K fragments (36 of
+  // the wave's 68 converts per tile).  q is the sum of TWO e4m3 terms under one power-of-two scale per (head, this wave's
+  // half of the 576 columns): x = q s, hi = e4m3(x), lo = e4m3((x - hi) 16); S = (K hi + K lo / 16) / s.  A bf16 value
+  // has 8 significant bits, hi keeps 4 and the remainder fits lo's 4 (tools/mla_fp8_qk_study.py: logit error 1e-7 rms,
+  // worst err / bound 0.52 = the 16-bit path's; ONE term: 63).  fp16 queries would need three terms: they keep the upcast.
+  // MEASURED AND NOT ENABLED (RX_MLA_Q8 = 0): parity green (60 GPU cases incl. the adversarial patterns), VALU 151 -> 119 per
+  // wave and tile, MFMAs 17 -> 26 -- and the config-5 shard ran 62.4 -> 66 us.  The tile's critical path is its latency chain
+  // (DMA landing -> QK^T chain -> exchange barrier -> softmax -> PV), not the wave's VALU issue: nine more dependent
+  // 16x16x32 links in the first phase lengthen exactly that.  What would pay is the block-scaled 16x16x128 form (K = 128 per
+  // MFMA: FEWER links, both contractions on fp8 operands) on 128-token tiles -- a different kernel, DESIGN 4.1b.
+#ifndef RX_MLA_Q8
+#define RX_MLA_Q8 0
+#endif
+  constexpr bool Q8 = RX_MLA_Q8 && std::is_same_v<T, BF16>;
+  long qh[Q8 ? KSW : 1], ql[Q8 ? KSW : 1];
+  float q_inv_scale = 1.0f;
+  if constexpr (Q8) {
+    float amax = 0.f;
+#pragma unroll
+    for (int s = 0; s < KSW; ++s) {
+      const u32x4 raw = __builtin_bit_cast(u32x4, qf[s]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        amax = fmaxf(amax, fabsf(__builtin_bit_cast(float, raw[j] << 16)));
+        amax = fmaxf(amax, fabsf(__builtin_bit_cast(float, raw[j] & 0xffff0000u)));
+      }
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 16));  // the head's four lane groups hold its other columns
+    amax = fmaxf(amax, __shfl_xor(amax, 32));
+    // s = 2^(7 - e) for amax = m 2^e, m in [1, 2): the largest |x| lands in [128, 256) (e4m3 tops out at 448)
+    const int e = static_cast<int>((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xffu) - 127;
+    const int es = amax > 0.f ? min(max(7 - e, -100), 100) : 0;
+    const float sc = __builtin_bit_cast(float, static_cast<uint32_t>(127 + es) << 23);
+    q_inv_scale = __builtin_bit_cast(float, static_cast<uint32_t>(127 - es) << 23);
+#pragma unroll
+    for (int s = 0; s < KSW; ++s) {
+      const u32x4 raw = __builtin_bit_cast(u32x4, qf[s]);
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[2 * j] = __builtin_bit_cast(float, raw[j] << 16) * sc;
+        x[2 * j + 1] = __builtin_bit_cast(float, raw[j] & 0xffff0000u) * sc;
+      }
+      int hw[2] = {0, 0}, lw[2] = {0, 0};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {  // (the word selector of the converts is an immediate: low half, then high half)
+        hw[j] = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * j], x[4 * j + 1], hw[j], false);
+        hw[j] = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * j + 2], x[4 * j + 3], hw[j], true);
+        const f32x2 b0 = __builtin_amdgcn_cvt_pk_f32_fp8(hw[j], false), b1 = __builtin_amdgcn_cvt_pk_f32_fp8(hw[j], true);
+        lw[j] = __builtin_amdgcn_cvt_pk_fp8_f32((x[4 * j] - b0[0]) * 16.0f, (x[4 * j + 1] - b0[1]) * 16.0f, lw[j], false);
+        lw[j] = __builtin_amdgcn_cvt_pk_fp8_f32((x[4 * j + 2] - b1[0]) * 16.0f, (x[4 * j + 3] - b1[1]) * 16.0f, lw[j], true);
+      }
+      qh[s] = static_cast<long>((static_cast<uint64_t>(static_cast<uint32_t>(hw[1])) << 32) | static_cast<uint32_t>(hw[0]));
+      ql[s] = static_cast<long>((static_cast<uint64_t>(static_cast<uint32_t>(lw[1])) << 32) | static_cast<uint32_t>(lw[0]));
+    }
+  }
   // ---- slot ids of the first block of tokens -> LDS
   auto stage_slots = [&](int blk) {  // tokens [blk * 1024, +1024) of this split -> slot block blk & 1
     int32_t* dst = slots_lds + (blk & 1) * kM8SlotBlock;
@@ -777,15 +833,30 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
       u32x2 kf[KSW];
 #pragma unroll
       for (int i = 0; i < PD; ++i) kf[i] = *reinterpret_cast<const u32x2*>(kb0 + i * 32);
-      f32x4 part3[3];  // three independent chains: a dependent 16x16x32 waits out its predecessor
+      f32x4 part;
+      if constexpr (Q8) {  // four independent chains (hi / lo x even / odd k-step): a dependent 16x16x32 waits out its predecessor
+        f32x4 ph[2], pl[2];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) part3[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 2; ++c) ph[c] = pl[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < KSW; ++i) {
-        if (i + PD < KSW) kf[i + PD] = *reinterpret_cast<const u32x2*>(kb0 + (i + PD) * 32);
-        part3[i % 3] = T::mfma(__builtin_bit_cast(vec8, fp8x8_to_16<T>(kf[i])), qf[i], part3[i % 3]);
+        for (int i = 0; i < KSW; ++i) {
+          if (i + PD < KSW) kf[i + PD] = *reinterpret_cast<const u32x2*>(kb0 + (i + PD) * 32);
+          const long kraw = static_cast<long>((static_cast<uint64_t>(kf[i][1]) << 32) | kf[i][0]);
+          ph[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kraw, qh[i], ph[i & 1], 0, 0, 0);
+          pl[i & 1] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(kraw, ql[i], pl[i & 1], 0, 0, 0);
+        }
+        part = ((ph[0] + ph[1]) + (pl[0] + pl[1]) * 0.0625f) * q_inv_scale;
+      } else {
+        f32x4 part3[3];  // three independent chains: a dependent 16x16x32 waits out its predecessor
+#pragma unroll
+        for (int c = 0; c < 3; ++c) part3[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KSW; ++i) {
+          if (i + PD < KSW) kf[i + PD] = *reinterpret_cast<const u32x2*>(kb0 + (i + PD) * 32);
+          part3[i % 3] = T::mfma(__builtin_bit_cast(vec8, fp8x8_to_16<T>(kf[i])), qf[i], part3[i % 3]);
+        }
+        part = part3[0] + part3[1] + part3[2];
       }
-      const f32x4 part = part3[0] + part3[1] + part3[2];
       f32x4* xch = reinterpret_cast<f32x4*>(xch_base);
       xch[w * 64 + lane] = part;
       __syncthreads();
