@@ -1,13 +1,28 @@
 #!/bin/bash
 # Reproduces the committed profiles/ set on an MI355X box:  bash tools/profile_round.sh <tag>
 # (run through gpurun; then `python profiles/summarize.py gpurun_out/prof <tag>` condenses the CSVs)
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
-python3 $R/bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $R/bench.py --no-extra --no-cpu-baseline --no-radix-hit --steps 2 --warmup 1 > $OUT/${TAG}_bench_under_kernel_trace.json 2> $OUT/kt.err
+# bench.py prints the full record on a '[bench-full] ' line and the compact line (what the driver keeps) last: both are kept
+split_lines() {  # <stdout file> <stem>: <stem>.json = the compact line, <stem>_full.json = the full record
+  python3 - "$1" "$2" <<'PY'
+import sys
+lines = open(sys.argv[1]).read().splitlines()
+full = [ln[len("[bench-full] "):] for ln in lines if ln.startswith("[bench-full] ")]
+js = [ln for ln in lines if ln.startswith("{")]
+if js:
+    open(sys.argv[2] + ".json", "w").write(js[-1] + "\n")
+if full:
+    open(sys.argv[2] + "_full.json", "w").write(full[-1] + "\n")
+PY
+}
+python3 $R/bench.py > $OUT/bench_default.out 2> $OUT/bench_default.err
+split_lines $OUT/bench_default.out $OUT/${TAG}_bench_default
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $R/bench.py --no-extra --no-cpu-baseline --no-radix-hit --steps 2 --warmup 1 > $OUT/bench_kt.out 2> $OUT/kt.err
+split_lines $OUT/bench_kt.out $OUT/${TAG}_bench_under_kernel_trace
 # counter passes: eager launches (--no-graph), one counter family per pass, nothing but --pmc on the command line
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pf --output-format csv -- python3 $R/bench.py --no-extra --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pf.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pw --output-format csv -- python3 $R/bench.py --no-extra --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pw.err
@@ -28,6 +43,6 @@ rocprofv3 --kernel-trace --stats -d $OUT/casc -o casc --output-format csv -- pyt
 cp $OUT/casc/casc_kernel_stats.csv $R/profiles/${TAG}_cascade_kernel_stats.csv 2>/dev/null
 # cascade over several shared prefixes (one per radix-tree node): plain vs ops.CascadeGroups
 (python3 $R/tools/cascade_groups_bench.py; GROUPS=8 PER=32 python3 $R/tools/cascade_groups_bench.py; GROUPS=3 PER=64 LONERS=64 python3 $R/tools/cascade_groups_bench.py) > $OUT/${TAG}_cascade_groups_bench.txt 2> $OUT/cascg.err
-cp $OUT/${TAG}_bench_default.json $OUT/${TAG}_bench_under_kernel_trace.json $R/gpurun_out/ 2>/dev/null
+cp $OUT/${TAG}_bench_default.json $OUT/${TAG}_bench_default_full.json $OUT/${TAG}_bench_under_kernel_trace.json $OUT/${TAG}_bench_under_kernel_trace_full.json $R/gpurun_out/ 2>/dev/null
 mkdir -p $R/gpurun_out/profiles_new && cp $R/profiles/${TAG}_kernel_stats.csv $R/profiles/${TAG}_pmc_summary.json $R/profiles/${TAG}_cascade_kernel_stats.csv $R/profiles/${TAG}_mla_bf16_kernel_stats.csv $R/profiles/${TAG}_mla_fp8_kernel_stats.csv $R/profiles/${TAG}_mla_pmc_summary.json $OUT/${TAG}_cascade_bench.txt $OUT/mla16.txt $OUT/mla8.txt $R/profiles/${TAG}_mla_extend_kernel_stats.csv $OUT/${TAG}_mla_extend.txt $OUT/${TAG}_cascade_groups_bench.txt $R/gpurun_out/profiles_new/ 2>/dev/null
 tail -c 1500 $OUT/${TAG}_bench_default.json
