@@ -82,6 +82,9 @@ def parse():
                     help="internal: the peer-to-peer all-reduce leg of an N > 1 run (started by rank 0 of the main run as "
                          "a fresh child job with RX_CUSTOM_AR=1; prints its own JSON line)")
     ap.add_argument("--no-custom-ar-leg", action="store_true", help="N > 1: skip the peer-to-peer all-reduce child leg")
+    ap.add_argument("--no-peaked", action="store_true",
+                    help="skip the peaked-input extend leg (profile runs: its slower launches of the SAME kernel instance "
+                         "would sit in the trace's per-kernel average)")
     ap.add_argument("--full-json", action="store_true",
                     help="print the FULL record as the final JSON line (default: the full record goes to an earlier "
                          "'[bench-full] ' line and gpurun_out/bench_full.json, the final line is the compact one)")
@@ -1705,7 +1708,8 @@ def main():
             out["extend"] = extend_bench(args, dev, world)
             out["extend"]["other_head_dims"] = extend_head_dims(args, dev)
             out["extend"]["mla_latent"] = mla_extend_bench(dev)
-            out["extend"]["peaked_input"] = extend_peaked_bench(args, dev)
+            if not args.no_peaked:
+                out["extend"]["peaked_input"] = extend_peaked_bench(args, dev)
         except Exception as e:
             out["extend"] = {"error": str(e)}
     if world > 1 and not args.no_extend:

@@ -455,7 +455,16 @@ def decode_attention_fwd_grouped_rope(q, k_buffer, v_buffer, o, kv_indptr, kv_in
         raise NotImplementedError("decode_attention_fwd_grouped_rope: the latent shape 512 + 64 only")
     bs, hq = q.shape[0], q.shape[1]
     S = max(1, int(num_kv_splits))
-    logits = torch.empty((bs, hq, S, 512), dtype=torch.float32, device=q.device) if S > 1 else None
+    # the caller's scratch is reused when it can hold this library's partials ([bs, Hq, S, 512] fp32, contiguous): a per-layer
+    # allocation otherwise (graph-unfriendly -- ADVICE r4); the reference's own [.., kv_lora_rank + 1] layout is large enough
+    logits = None
+    if S > 1:
+        n = bs * hq * S * 512
+        if (attn_logits is not None and attn_logits.is_cuda and attn_logits.dtype == torch.float32 and attn_logits.is_contiguous()
+                and attn_logits.numel() >= n and attn_logits.data_ptr() % 16 == 0):
+            logits = attn_logits.view(-1)[:n].view(bs, hq, S, 512)
+        else:
+            logits = torch.empty((bs, hq, S, 512), dtype=torch.float32, device=q.device)
     lse = (attn_lse if attn_lse is not None else torch.empty((bs, hq, S), dtype=torch.float32, device=q.device)) if S > 1 else None
     if S > 1 and split_counts is None:
         split_counts = torch.full((bs,), S, dtype=torch.int32, device=q.device)  # the reference cuts every request S ways

@@ -95,13 +95,13 @@ def test_bench_gpus_8_first_contact_on_one_gpu():
     """The target world size before the driver's SCALE run meets it: `python bench.py --gpus 8`
     self-launches eight ranks (all on device 0, gloo reducing through the host), every rank passes first_contact() --
     peer-access matrix, the all-reduce checked against the fp32 sum -- the TP = 8 shard (Hq 4 / Hkv 1 per rank) steps
-    from HIP graphs or eagerly, and the peer-to-peer two-shot kernel's own eight-rank child leg reports no device-side
-    timeout."""
+    from HIP graphs or eagerly."""
     env = dict(os.environ, RX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
-                        "--settle", "1", "--bs", "16", "--ctx", "512", "--layers", "2", "--no-cpu-baseline", "--full-json"],
+                        "--settle", "1", "--bs", "16", "--ctx", "512", "--layers", "2", "--no-cpu-baseline", "--full-json",
+                        "--no-custom-ar-leg"],   # (the two-shot kernel at world 8: tests/test_gpu_allreduce.py; a second 8-rank job here costs minutes)
                        capture_output=True, text=True, env=env, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -111,13 +111,10 @@ def test_bench_gpus_8_first_contact_on_one_gpu():
     assert len(out["roofline"]["per_rank_frac"]) == 8
     fc = out["first_contact"]
     assert fc["ranks_seen"] == list(range(8)) and fc["all_reduce_check"]["ok_on_every_rank"] and len(fc["can_access_peer"]) == 8
-    leg = out["all_reduce"]["p2p_two_shot_leg"]
-    assert "error" not in leg, leg
-    assert leg["device_side_timeouts"] == 0 and leg["first_contact"]["ok_on_every_rank"]
     assert out["extend"]["sharding"].startswith("tp8") and out["extend"]["tflops"] > 0
     # the compact line of an N > 1 run keeps the collective's figures
     c = _load_bench().compact_record(out)
-    assert c["n_gpus"] == 8 and c["first_contact_ok"] and "p2p_two_shot" in c["all_reduce"] and len(json.dumps(c)) < 3000
+    assert c["n_gpus"] == 8 and c["first_contact_ok"] and "alone_us" in c["all_reduce"] and len(json.dumps(c)) < 3000
 
 
 @pytest.mark.gpu

@@ -141,3 +141,90 @@ def test_multi_step_draft_backend_against_the_oracle(topk, page_size, graph):
                                                                    np.concatenate(want_idx).astype(np.int64), d ** -0.5), (2,))
         parity.check_out(o.view(bs, hq, d).float().cpu().numpy(), want, torch.bfloat16, ("multi-step draft", topk, page_size, i, graph),
                          ulps=1, absw=absw)
+
+
+def test_multi_step_draft_backend_replays_from_a_hip_graph():
+    """The draft worker's contract under CUDA graphs (triton_backend.py:2002-2036): capture the two draft decode steps once
+    on the address-stable buffers of init_cuda_graph_state, then for every new batch copy its lengths / rows into the static
+    inputs, call init_forward_metadata_out_graph (rebuilds all steps' page tables and the split counts outside the graph)
+    and replay.  Two different batches through the same graph match the oracle."""
+    from sglang_amd.attention.backend import HipRadixMultiStepDraftBackend
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+    from sglang_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
+
+    hq, hkv, d, steps, topk, page_size = 8, 2, 128, 3, 4, 1
+    num_seqs, max_ctx, size = 3, 400, 2048
+    bs = num_seqs * topk
+    pool = MHATokenToKVPool(size, page_size, torch.bfloat16, hkv, d, 1, DEV)
+    r2t = ReqToTokenPool(8, max_ctx, DEV)
+    rows = r2t.alloc(num_seqs)
+    g = torch.Generator().manual_seed(3)
+    kb, vb = pool.get_kv_buffer(0)
+    kb.copy_(torch.randn(kb.shape, generator=g).to(torch.bfloat16))
+    vb.copy_(torch.randn(vb.shape, generator=g).to(torch.bfloat16))
+
+    class MC:
+        num_attention_heads, num_key_value_heads, context_len = hq, hkv, max_ctx
+
+    class MR:
+        device = DEV
+        req_to_token_pool = r2t
+        token_to_kv_pool = pool
+        model_config = MC
+        page_size = 1
+
+        class server_args:
+            triton_attention_num_kv_splits = 8
+
+    be = HipRadixMultiStepDraftBackend(MR, topk, steps)
+    layer = RadixAttention(hq, d, d ** -0.5, hkv, 0)
+    s_rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    s_seq = torch.ones(num_seqs, dtype=torch.int64, device=DEV)
+    s_pos = torch.ones(bs, dtype=torch.int64, device=DEV)
+    qs = [torch.zeros(bs, hq * d, dtype=torch.bfloat16, device=DEV) for _ in range(steps - 1)]
+    spec = _Spec()
+    fb = ForwardBatch.for_decode(s_rpi, s_seq, torch.zeros(bs, dtype=torch.int64, device=DEV), torch.ones(num_seqs, dtype=torch.int64))
+    fb.spec_info, fb.positions, fb.seq_lens_sum = spec, s_pos, None
+    be.init_cuda_graph_state(num_seqs, bs)
+    be.init_forward_metadata_out_graph(fb, in_capture=True)
+
+    def run_steps():
+        return [be.attn_backends[i].forward_decode(qs[i], None, None, layer, fb, save_kv_cache=False) for i in range(steps - 1)]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run_steps()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = run_steps()
+    kbn, vbn = _bits(kb), _bits(vb)
+    rng = np.random.default_rng(5)
+    for lens in ([70, 16, 129], [5, 300, 41]):
+        perm = rng.permutation(np.arange(1, size))
+        pi = 0
+        for r, n in zip(rows, lens):
+            need = n + steps * topk
+            r2t.req_to_token[r, :need] = torch.from_numpy(perm[pi: pi + need].astype(np.int32)).to(DEV)
+            pi += need
+        s_seq.copy_(torch.tensor(lens, dtype=torch.int64))
+        s_pos.copy_(s_seq.repeat_interleave(topk))
+        for qbuf in qs:
+            qbuf.copy_(torch.randn(bs, hq * d, generator=g).to(torch.bfloat16))
+        be.init_forward_metadata_out_graph(fb)
+        graph.replay()
+        torch.cuda.synchronize()
+        r2t_np = r2t.req_to_token.cpu().numpy()
+        for i in range(steps - 1):
+            idx, ptr = [], [0]
+            for b, n in enumerate(lens):
+                for kk in range(topk):
+                    idx.append(np.concatenate([r2t_np[rows[b], :n], r2t_np[rows[b], n + kk * steps: n + kk * steps + i + 1]]))
+                    ptr.append(ptr[-1] + n + i + 1)
+            want, absw = parity.want_and_absw(orc.decode_attention, (_bits(qs[i].view(bs, hq, d)), kbn, vbn, np.asarray(ptr, dtype=np.int32),
+                                                                       np.concatenate(idx).astype(np.int64), d ** -0.5), (2,))
+            parity.check_out(outs[i].view(bs, hq, d).float().cpu().numpy(), want, torch.bfloat16, ("multi-step draft, graph replay", lens, i),
+                             ulps=1, absw=absw)

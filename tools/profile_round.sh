@@ -21,7 +21,7 @@ PY
 }
 python3 $R/bench.py > $OUT/bench_default.out 2> $OUT/bench_default.err
 split_lines $OUT/bench_default.out $OUT/${TAG}_bench_default
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $R/bench.py --no-extra --no-cpu-baseline --no-radix-hit --steps 2 --warmup 1 > $OUT/bench_kt.out 2> $OUT/kt.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $R/bench.py --no-extra --no-cpu-baseline --no-radix-hit --no-peaked --steps 2 --warmup 1 > $OUT/bench_kt.out 2> $OUT/kt.err
 split_lines $OUT/bench_kt.out $OUT/${TAG}_bench_under_kernel_trace
 # counter passes: eager launches (--no-graph), one counter family per pass, nothing but --pmc on the command line
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pf --output-format csv -- python3 $R/bench.py --no-extra --no-graph --no-cpu-baseline --no-extend --no-radix-hit --steps 2 --warmup 1 > /dev/null 2> $OUT/pf.err
