@@ -41,6 +41,9 @@ struct Options {
   int extend_nd_big = 1;      // its eight-wave form for Dk > 128
   int extend_mla = 1;         // the latent (576 / 512) extend kernel
   int extend_mla_shared_v = 1;  // V^T read from the K image when v aliases k[..., :512]
+  int decode_mla8_t64 = 0;    // ... in its 64-token-tile form (every wave owns 16 tokens of the tile; 0: the 32-token K-split form; A/B: DESIGN 4.1b)
+  int merge_in_kernel_max_mb = 4;      // stage 2 inside the stage-1 kernel while the partials are at most this many MB ...
+  int merge_in_kernel_max_mb_mla = 4;  // ... and for latent (576 / 512) rows
   int decode_mla8_dma = 1;    // fp8 latent rows through the LDS-DMA kernel (0: upcast-while-staging form)
 };
 Options& options();
@@ -244,25 +247,73 @@ __device__ __forceinline__ bool split_arrive_is_last(int32_t* counter, int live)
 // one request, by the 256 threads of the calling workgroup; same arithmetic as decode_merge_kernel (rx_decode.hip).
 // logits / lse point at the block's first head: partial (q, s) is logits[(q * max_splits + s) * dv ...], lse[q *
 // max_splits + s]; o at the block's first head of the request.
-template <typename T>
+// R: output chunks (4 columns of one head) a thread has in flight per device-scope round trip.  The merging workgroup is
+// alone on the critical path of its request (and the launch's tail, when it is the last one): with one chunk per
+// round trip the 16 x 512 MLA block took 8 dependent ~2 us trips (round 2's 67.6 -> 69.5 us); R = 4 makes it two.
+// The loads are buffer loads with the sc0 sc1 policy bits (aux 17 = device scope, as load_dev_chunk8's) issued through
+// the builtin, so hipcc counts them itself and ANY number can be in flight (an asm statement stops at 30 operands).
+template <typename T, int R = 1>
 __device__ __forceinline__ void merge_splits_in_kernel(const float* logits, const float* lse, int nheads, int dv, int live,
                                                        int max_splits, const float* sinks /* block's first head, or NULL */,
                                                        float v_scale, uint16_t* o, int64_t o_stride_h) {
   // requires max_splits % 8 == 0 and 16-byte aligned buffers (the host enables the in-kernel form only then)
   const int dv4 = dv >> 2;
-  for (int i = threadIdx.x; i < nheads * dv4; i += 256) {
+  const int items = nheads * dv4;
+  if (live <= 8) {
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(logits), 0, nheads * max_splits * dv * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lse), 0, nheads * max_splits * 4, 0x00020000);
+    for (int i0 = threadIdx.x; i0 < items; i0 += 256 * R) {
+      f32x4 la[R], lb[R], x[R][8];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int i = min(i0 + 256 * r, items - 1);
+        const int q = i / dv4, d = (i % dv4) * 4;
+        la[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(re, q * max_splits * 4, 0, 17));
+        lb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(re, q * max_splits * 4 + 16, 0, 17));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          x[r][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rl, ((q * max_splits + min(j, live - 1)) * dv + d) * 4, 0, 17));
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int i = i0 + 256 * r;
+        if (i >= items) break;
+        const int q = i / dv4, d = (i % dv4) * 4;
+        float e_max = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < live) e_max = fmaxf(e_max, j < 4 ? la[r][j] : lb[r][j - 4]);
+        float e_sum = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j < live) {  // in stage 2's order
+            const float w = __expf((j < 4 ? la[r][j] : lb[r][j - 4]) - e_max);
+            acc += w * x[r][j];
+            e_sum += w;
+          }
+        }
+        if (sinks) e_sum += __expf(sinks[q] - e_max);
+        const float inv = v_scale / e_sum;
+        u32x2 pk;
+        pk[0] = pack2<T>(acc[0] * inv, acc[1] * inv);
+        pk[1] = pack2<T>(acc[2] * inv, acc[3] * inv);
+        *reinterpret_cast<u32x2*>(o + q * o_stride_h + d) = pk;
+      }
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < items; i += 256) {  // more than 8 live splits: two passes, as stage 2 (the maximum over ALL splits first)
     const int q = i / dv4, d = (i % dv4) * 4;
     const float* l = lse + q * max_splits;
     const float* lp = logits + static_cast<int64_t>(q) * max_splits * dv + d;
     float e_max = -INFINITY;
-    if (live > 8) {  // two passes, as stage 2: the maximum over ALL live splits first
-      for (int s0 = 0; s0 < live; s0 += 8) {
-        f32x4 la, lb;
-        load_dev_lse8(l + s0, la, lb);
+    for (int s0 = 0; s0 < live; s0 += 8) {
+      f32x4 la, lb;
+      load_dev_lse8(l + s0, la, lb);
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (s0 + j < live) e_max = fmaxf(e_max, j < 4 ? la[j] : lb[j - 4]);
-      }
+      for (int j = 0; j < 8; ++j)
+        if (s0 + j < live) e_max = fmaxf(e_max, j < 4 ? la[j] : lb[j - 4]);
     }
     float e_sum = 0.f;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -272,11 +323,6 @@ __device__ __forceinline__ void merge_splits_in_kernel(const float* logits, cons
       for (int j = 0; j < 8; ++j) row[j] = lp + static_cast<int64_t>(min(s0 + j, live - 1)) * dv;
       f32x4 la, lb, x[8];
       load_dev_chunk8(l + s0, row, la, lb, x);
-      if (live <= 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j < live) e_max = fmaxf(e_max, j < 4 ? la[j] : lb[j - 4]);
-      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (s0 + j < live) {  // in stage 2's order

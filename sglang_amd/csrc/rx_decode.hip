@@ -1035,7 +1035,8 @@ static int decode_attn_impl(const rx_decode_params* p, void* stream) {
                                                                                                            : p->split_items_cap),
                                                               static_cast<int64_t>(p->bs) * max_splits)
                                                         : static_cast<int64_t>(p->bs) * max_splits) *
-                                       p->num_q_heads * dv * 4 <= (4ll << 20);
+                                       p->num_q_heads * dv * 4 <=
+                                   (static_cast<int64_t>(mla ? options().merge_in_kernel_max_mb_mla : options().merge_in_kernel_max_mb) << 20);
   a.merge_counters = merge_in_kernel ? p->merge_counters : nullptr;
   // fused store of the new token: one q block per kv head (one workgroup touches the row), a 16-bit pool, the whole
   // request attended in one pass of the MFMA kernel, 16-byte chunks

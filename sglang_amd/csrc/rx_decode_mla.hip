@@ -71,6 +71,9 @@ constexpr int kMlaDk = 576, kMlaDv = 512;
 constexpr int kMlaTile = 32;
 constexpr float kMlaSumLimit = 4096.0f;  // a lane's partial row sum above this sends the wave to the max-based softmax step
 
+#ifndef RX_MLA_MERGE_R
+#define RX_MLA_MERGE_R 4  // output chunks per thread and device-scope round trip of the in-kernel stage 2 (rx_common.h)
+#endif
 // stage 2 inside the kernel: called by every thread of a workgroup that wrote a partial of (request b, q block qb)
 template <typename T>
 __device__ __forceinline__ void mla_merge_if_last(const MlaArgs& a, int b, int qb, int32_t seq_len, int32_t splits) {
@@ -79,7 +82,7 @@ __device__ __forceinline__ void mla_merge_if_last(const MlaArgs& a, int b, int q
   if (!split_arrive_is_last(a.merge_counters + b * a.qblocks + qb, live)) return;
   const int h0 = qb * 16;
   const int64_t row0 = (static_cast<int64_t>(b) * a.hq + h0) * a.max_kv_splits;
-  merge_splits_in_kernel<T>(a.attn_logits + row0 * kMlaDv, a.attn_lse + row0, min(16, a.hq - h0), kMlaDv, live,
+  merge_splits_in_kernel<T, RX_MLA_MERGE_R>(a.attn_logits + row0 * kMlaDv, a.attn_lse + row0, min(16, a.hq - h0), kMlaDv, live,
                             a.max_kv_splits, a.sinks ? a.sinks + h0 : nullptr, a.v_scale,
                             a.o + b * a.o_stride_t + h0 * a.o_stride_h, a.o_stride_h);
 }
@@ -599,8 +602,18 @@ constexpr int kM8SlotBlock = 1024;             // tokens whose slot ids are stag
 constexpr int kM8Lds = kM8Ring * kM8Buf + 4 * 64 * 16 + 2 * kM8SlotBlock * 4;
 
 // one 1-KiB LDS-DMA piece: lane l's 16 bytes land at lds_dst + 16 l (recipe: cdna_hip_programming.md 5.7)
+#ifndef RX_M8_PROBE
+#define RX_M8_PROBE 0  // dev: 1 = the DMA stream, waits and barriers only (no products): the access pattern's ceiling
+#endif
+#ifndef RX_M8_NT
+#define RX_M8_NT 0  // 1: non-temporal DMA loads (the rows are read once per step)
+#endif
 __device__ __forceinline__ void m8_dma16(const void* gsrc, uint32_t lds_dst) {
+#if RX_M8_NT
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gsrc), "s"(lds_dst) : "memory");
+#else
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory");
+#endif
 }
 
 template <typename T, typename IdxT, bool LINEAR>
@@ -813,7 +826,10 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
     // tile t has landed (ours: all but the 5 youngest pieces = tile t+1's; everybody's: the barrier)
     if constexpr (kM8Ahead == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (kM8Ahead == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (kM8Ahead == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (kM8Ahead == 4) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else if constexpr (kM8Ahead == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
     __syncthreads();
     const char* kt = smem + (t % kM8Ring) * kM8Buf;
     // next slot block, one block ahead of the DMA that will read it (rare: every 32 tiles)
@@ -825,6 +841,7 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
     dma_pieces(t + kM8Ahead, 0, 2);
     read_slots(t + kM8Ahead + 1);  // for the next iteration's issue
 
+#if !RX_M8_PROBE
     // ---- partial S^T of this wave: token block bb_w, k-steps [ks0, ks0 + 9)
     f32x4 sacc[2];
     {
@@ -863,7 +880,9 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
       sacc[0] = xch[0 * 64 + lane] + xch[2 * 64 + lane];
       sacc[1] = xch[1 * 64 + lane] + xch[3 * 64 + lane];
     }
+#endif
     dma_pieces(t + kM8Ahead, 2, 4);
+#if !RX_M8_PROBE
     // ---- online softmax (identical in all four waves); score (bb, i) of this lane is token 8 g + 4 bb + i
     float sv[8];
 #pragma unroll
@@ -917,7 +936,9 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) oacc[nb] *= alpha;
     }
+#endif
     dma_pieces(t + kM8Ahead, 4, NP);
+#if !RX_M8_PROBE
     // ---- O^T[128 w + ...] += V^T P^T: one transposed byte read per fragment (rows 8 g .. 8 g + 7), upcast, MFMA
     {
       const char* vp = kt + (8 * g + (i16 >> 1)) * kM8Row + (g >= 2 ? kM8HalfShift : 0) + 128 * w + 8 * (i16 & 1);
@@ -929,6 +950,9 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
         oacc[nb] = T::mfma(av, pf, oacc[nb]);
       }
     }
+#else
+    __syncthreads();
+#endif
   }
   // nothing of this workgroup may still be landing in LDS when the block retires
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -957,6 +981,299 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) {
         if (a.merge_counters) store_dev(lp + 16 * nb, oacc[nb] * inv);  // may be merged from another XCD
+        else *reinterpret_cast<f32x4*>(lp + 16 * nb) = oacc[nb] * inv;
+      }
+      if (w == 0 && g == 0) {
+        if (a.merge_counters) store_dev(a.attn_lse + row, m_run * kLn2 + __logf(l_run));
+        else a.attn_lse[row] = m_run * kLn2 + __logf(l_run);
+      }
+    }
+    if (a.merge_counters) mla_merge_if_last<T>(a, b, qb, seq_len, splits);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp8 latent rows, third form (round 5): 64-token tiles, every wave owns 16 TOKENS of the tile.
+//
+// The second form above splits QK^T four ways inside a 32-token tile (2 token blocks x 2 halves of the 576 columns):
+// every tile pays an exchange of partial sums through LDS behind a barrier, and all four waves then run the SAME softmax
+// of the tile's 512 scores.  Measured: that kernel is bound by the tile's latency chain -- landing ->
+// QK^T chain -> exchange barrier -> softmax -> PV -- not by VALU issue or HBM.  Here
+//   * a tile is 64 rows x 592 B = exactly 37 one-KiB DMA pieces, two tile buffers per workgroup (two workgroups per CU);
+//   * wave w computes the scores of tokens 16 w .. 16 w + 15 against ALL 576 columns (18 k-steps, no partial sums), does the
+//     softmax of those 256 scores only (4 per lane instead of 8 redundant ones per 32 tokens), and publishes its P block
+//     (16 tokens x 16 heads, 16-bit) in LDS; behind ONE barrier every wave reads the tile's whole P as its PV B operands
+//     and accumulates its own 128 output columns.  Two barriers per 64 tokens instead of four, no score exchange;
+//   * 16 CONSECUTIVE rows at one column land on 16 different 16-byte bank groups (592 B = 148 banks, 148 mod 64 = 20),
+//     so neither the score fragment reads nor the transposed V reads need the second form's half shift;
+//   * the standing reference max of a head must be the same in all four waves (their P blocks meet in one PV product):
+//     a wave whose sum check fires raises a flag next to its P block, and behind the barrier ALL waves take the redo --
+//     per-head maxima through LDS, a common new max, P recomputed and republished (three more barriers; rare).
+constexpr int kT64 = 64;                                   // tokens per tile
+constexpr int kT64Buf = kT64 * kM8Row;                     // 37,888 B = 37 pieces
+constexpr int kT64Pieces = kT64Buf / 1024;                 // 37
+constexpr int kT64PRow = 144;                              // bytes per head row of the P image (64 tokens x 2 B + 16: bank spread)
+constexpr int kT64SlotBlock = 256;                         // tokens whose slot ids are staged at a time (4 tiles)
+constexpr int kT64Lds = 2 * kT64Buf + 16 * kT64PRow + 64 /* flags */ + 4 * 16 * 4 /* maxima */ + 4 * 16 * 4 /* sums */ +
+                        2 * kT64SlotBlock * 4;             // 80,192 B: two workgroups per CU
+static_assert(kT64Buf % 1024 == 0 && 2 * kT64Lds <= 160 * 1024, "tile image / LDS budget");
+
+template <typename T, typename IdxT, bool LINEAR>
+__global__ __launch_bounds__(256, 2) void decode_mla8_t64_kernel(const MlaArgs a) {
+  using vec8 = typename T::vec8;
+  constexpr int KS = kMlaDk / 32;       // 18 k-steps
+  constexpr int NBW = kMlaDv / 16 / 4;  // 8 d-blocks of 16 per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 tiles][P image][flags][maxima][sums][2 slot blocks]
+  char* const p_img = smem + 2 * kT64Buf;
+  int32_t* const flags = reinterpret_cast<int32_t*>(p_img + 16 * kT64PRow);
+  float* const maxbuf = reinterpret_cast<float*>(flags + 16);
+  float* const sumbuf = maxbuf + 4 * 16;
+  int32_t* const slots_lds = reinterpret_cast<int32_t*>(sumbuf + 4 * 16);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  int qb, b, split;
+  {
+    const int G = a.qblocks;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    qb = j % G;
+    const int pr = (j / G) * 8 + xcd;  // (request, split) pair, bound to one XCD (see the first form)
+    if (pr >= a.bs * a.max_kv_splits) return;
+    b = pr % a.bs;
+    split = pr / a.bs;
+  }
+  int32_t seq_len;
+  const IdxT* idx;
+  if (a.kv_indices) {
+    const int32_t beg = a.kv_indptr[b];
+    seq_len = a.kv_indptr[b + 1] - beg;
+    idx = reinterpret_cast<const IdxT*>(a.kv_indices) + beg;
+  } else {
+    const int64_t req = load_idx(a.req_pool_indices, b, a.rpi64);
+    seq_len = static_cast<int32_t>(load_idx(a.seq_lens, b, a.sl64));
+    idx = reinterpret_cast<const IdxT*>(a.req_to_token + req * a.req_row_stride);
+  }
+  const int32_t full_len = seq_len;
+  if (a.kv_start && !a.kv_indices) {
+    const int32_t st = min(max(a.kv_start[b], 0), seq_len);
+    idx += st;
+    seq_len -= st;
+  }
+  const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
+  const bool single = (a.max_kv_splits == 1) || (a.direct_single && splits == 1);
+  const int h = qb * 16 + r;
+  const bool q_valid = h < a.hq;
+  if (!single && a.merge_counters && seq_len == 0) {  // nobody will arrive: stage 2's zero-split result, by split 0
+    if (split == 0)
+      for (int i = tid; i < 16 * kMlaDv; i += 256) {
+        const int q = i / kMlaDv, d = i % kMlaDv;
+        if (qb * 16 + q < a.hq)
+          a.o[b * a.o_stride_t + (qb * 16 + q) * a.o_stride_h + d] = T::from_f32(0.f * (a.v_scale / (a.sinks ? INFINITY : 0.f)));
+      }
+    return;
+  }
+  if (split >= splits) return;
+  const int32_t per = ((seq_len + splits - 1) / splits + 31) / 32 * 32;  // (the split boundaries of the stage-2 contract)
+  const int32_t lo = per * split;
+  const int32_t hi = min(lo + per, seq_len);
+  if (hi <= lo) {
+    if (single && seq_len == 0)
+      for (int i = tid; i < 16 * kMlaDv; i += 256) {
+        const int q = i / kMlaDv, d = i % kMlaDv;
+        if (qb * 16 + q < a.hq) a.o[b * a.o_stride_t + (qb * 16 + q) * a.o_stride_h + d] = 0;
+      }
+    return;
+  }
+  const int ntiles = (hi - lo + kT64 - 1) / kT64;
+
+  // ---- Q^T fragments of all 18 k-steps: lane (head r, k group g) holds q[h][32 s + 8 g .. + 8]
+  vec8 qf[KS];
+  {
+    const uint16_t* qp = a.q + b * a.q_stride_t + (q_valid ? h : 0) * a.q_stride_h + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      u32x4 raw = q_valid ? *reinterpret_cast<const u32x4*>(qp + 32 * s) : u32x4{0, 0, 0, 0};
+      qf[s] = __builtin_bit_cast(vec8, raw);
+    }
+  }
+  // slot ids of 256 tokens (4 tiles) at a time, one per thread: LOADED at the end of an iteration and written to LDS at the
+  // top of the next one, behind that iteration's own vmcnt(0) -- hipcc does not count the asm DMA pieces, so a wait it places
+  // for this load right after they were issued would wait for all of them
+  int32_t slot_pending = 0;
+  auto load_slot = [&](int blk) { slot_pending = static_cast<int32_t>(idx[min(lo + blk * kT64SlotBlock + tid, hi - 1)]); };
+  auto store_slot = [&](int blk) { slots_lds[(blk & 1) * kT64SlotBlock + tid] = slot_pending; };
+  load_slot(0);
+  store_slot(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q and the slot ids have landed
+  __syncthreads();
+
+  // ---- DMA of one tile: wave w issues pieces w, w + 4, ...: 10 / 9 / 9 / 9 of the 37
+  const uint8_t* kvb = reinterpret_cast<const uint8_t*>(a.kv_buf);
+  constexpr int NP = (kT64Pieces + 3) / 4;  // 10
+  int prow[NP], pcol[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pos = min((w + 4 * i) * 64 + lane, kT64 * kM8Cpr - 1);  // 16-byte chunk of the image
+    prow[i] = pos / kM8Cpr;
+    pcol[i] = 16 * min(pos % kM8Cpr, kM8Cpr - 2);  // the pad chunk re-reads the row's last data chunk
+  }
+  int32_t pslot[NP];
+  auto read_slots = [&](int t) {
+    const int32_t* sl = slots_lds + ((t * kT64 / kT64SlotBlock) & 1) * kT64SlotBlock + (t * kT64) % kT64SlotBlock;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) pslot[i] = sl[prow[i]];
+  };
+  auto dma_pieces = [&](int t, int i0, int i1) {  // pieces [i0, i1) of tile t from pslot
+    const uint32_t buf = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(smem)) + (t & 1) * kT64Buf;
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+      if (w + 4 * i < kT64Pieces) {  // (wave-uniform: only wave 0 has a tenth piece)
+        const uint8_t* src = kvb + mla_slot_off<LINEAR>(static_cast<int64_t>(pslot[i]), a.page_size, a.page_stride, a.tok_stride) + pcol[i];
+        m8_dma16(src, __builtin_amdgcn_readfirstlane(buf + (w + 4 * i) * 1024));
+      }
+    }
+  };
+  read_slots(0);
+  dma_pieces(0, 0, NP);
+  if (ntiles > 1) read_slots(1);
+
+  f32x4 oacc[NBW];
+#pragma unroll
+  for (int nb = 0; nb < NBW; ++nb) oacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;   // m_run: the head's reference max (identical in all four waves); l_run: THIS wave's tokens
+  float xai = 1.0f;
+  if (a.xai_len > 0 && full_len - 1 > a.xai_len)
+    xai = __log2f(static_cast<float>(full_len - 1)) / __log2f(static_cast<float>(a.xai_len));
+  const bool capped = a.logit_cap > 0.f;
+  const float c2 = (capped ? kLog2e : a.sm_scale * kLog2e) * xai;
+  const int i16 = lane & 15;
+
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile t have landed ...
+    __syncthreads();                                   // ... and everybody's; everybody is done with tile t - 1 and its P image
+    const char* kt = smem + (t & 1) * kT64Buf;
+    // slot block t / 4 + 1 (loaded at the end of iteration t - 1): visible behind this iteration's second barrier, first
+    // read at iteration t + 1 (tile t + 3)
+    if ((t & 3) == 1) store_slot(t / 4 + 1);
+    // tile t + 1 -> the buffer tile t - 1 was read from
+    if (t + 1 < ntiles) dma_pieces(t + 1, 0, 3);
+
+    // ---- S^T of this wave's 16 tokens: 18 k-steps, three independent chains
+    f32x4 sacc;
+    {
+      const char* kb0 = kt + (16 * w + r) * kM8Row + 8 * g;   // A operand: row = token 16 w + r, k group g
+      constexpr int PD = 4;
+      u32x2 kf[KS];
+#pragma unroll
+      for (int i = 0; i < PD; ++i) kf[i] = *reinterpret_cast<const u32x2*>(kb0 + i * 32);
+      f32x4 part3[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) part3[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        if (i + PD < KS) kf[i + PD] = *reinterpret_cast<const u32x2*>(kb0 + (i + PD) * 32);
+        part3[i % 3] = T::mfma(__builtin_bit_cast(vec8, fp8x8_to_16<T>(kf[i])), qf[i], part3[i % 3]);
+        if (i == 5 && t + 1 < ntiles) dma_pieces(t + 1, 3, 6);
+        if (i == 11 && t + 1 < ntiles) dma_pieces(t + 1, 6, NP);
+      }
+      sacc = part3[0] + part3[1] + part3[2];
+    }
+    if (t + 2 < ntiles) read_slots(t + 2);  // for the next iteration's issue (its slot block was stored >= 1 barrier ago)
+    if ((t & 3) == 0) load_slot(t / 4 + 1);
+    // ---- softmax of the wave's own scores: lane (head r, group g) holds tokens 16 w + 4 g + i, i < 4
+    float sv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sv[i] = sacc[i];
+    if (capped) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv[i] = a.logit_cap * tanhf(sv[i] * a.sm_scale / a.logit_cap);
+    }
+    if (t == ntiles - 1) {  // only the split's last tile can reach past its end
+      const int tok_base = lo + t * kT64 + 16 * w + 4 * g;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sv[i] = (tok_base + i < hi) ? sv[i] : -INFINITY;
+    }
+    float e[4], psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      e[i] = fast_exp2(__builtin_fmaf(sv[i], c2, -m_run));
+      psum += e[i];
+    }
+    const bool mine = __builtin_amdgcn_ballot_w64(__builtin_bit_cast(uint32_t, psum) > __builtin_bit_cast(uint32_t, kMlaSumLimit)) != 0;
+    char* const prow_w = p_img + r * kT64PRow + (16 * w + 4 * g) * 2;   // P image: [head][token], 16-bit
+    *reinterpret_cast<u32x2*>(prow_w) = u32x2{pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3])};
+    if (lane == 0) flags[w] = mine ? 1 : 0;
+    __syncthreads();
+    float alpha = 1.0f;
+    if ((flags[0] | flags[1] | flags[2] | flags[3]) != 0) {  // (workgroup-uniform) some lane's sum ran away: the classic step, together
+      float mt = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+      mt = quad_row_max(mt);                     // over the head's four lane groups: this wave's 16 tokens
+      if (g == 0) maxbuf[w * 16 + r] = mt;
+      __syncthreads();
+      mt = fmaxf(fmaxf(maxbuf[r], maxbuf[16 + r]), fmaxf(maxbuf[32 + r], maxbuf[48 + r])) * c2;
+      const float m_new = fmaxf(m_run, mt);
+      alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i] = fast_exp2(__builtin_fmaf(sv[i], c2, -m_new));
+        psum += e[i];
+      }
+      *reinterpret_cast<u32x2*>(prow_w) = u32x2{pack2<T>(e[0], e[1]), pack2<T>(e[2], e[3])};
+      __syncthreads();  // (the flags and maxima are rewritten only behind the next iteration's first barrier)
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) oacc[nb] *= alpha;
+    }
+    l_run = l_run * alpha + psum;
+    // ---- O^T[128 w + ...] += V^T P^T over the tile's 64 tokens: two k-steps of 32
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const vec8 pf = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(p_img + r * kT64PRow + (32 * ks + 8 * g) * 2));
+      const char* vp = kt + (32 * ks + 8 * g + (i16 >> 1)) * kM8Row + 128 * w + 8 * (i16 & 1);
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        auto lp = (__attribute__((address_space(3))) v2i_t*)(uintptr_t)(uint32_t)(uintptr_t)(vp + 16 * nb);
+        const v2i_t raw = __builtin_amdgcn_ds_read_tr8_b64_v2i32(lp);
+        const vec8 av = __builtin_bit_cast(vec8, fp8x8_to_16<T>(u32x2{static_cast<uint32_t>(raw[0]), static_cast<uint32_t>(raw[1])}));
+        oacc[nb] = T::mfma(av, pf, oacc[nb]);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this workgroup may still be landing in LDS when it retires
+
+  // ---- the head's row sum: this wave's four lane groups, then the four waves
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  __syncthreads();
+  if (g == 0) sumbuf[w * 16 + r] = l_run;
+  __syncthreads();
+  l_run = (sumbuf[r] + sumbuf[16 + r]) + (sumbuf[32 + r] + sumbuf[48 + r]);
+  if (single) {
+    if (!q_valid) return;
+    float den = l_run;
+    if (a.sinks) den += fast_exp2(a.sinks[h] * kLog2e - m_run);
+    const float inv = a.v_scale / den;
+    uint16_t* op = a.o + b * a.o_stride_t + h * a.o_stride_h + 128 * w + 4 * g;
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+      u32x2 pk;
+      pk[0] = pack2<T>(oacc[nb][0] * inv, oacc[nb][1] * inv);
+      pk[1] = pack2<T>(oacc[nb][2] * inv, oacc[nb][3] * inv);
+      *reinterpret_cast<u32x2*>(op + 16 * nb) = pk;
+    }
+  } else {
+    if (q_valid) {
+      const int64_t row = (static_cast<int64_t>(b) * a.hq + h) * a.max_kv_splits + split;
+      const float inv = 1.0f / l_run;
+      float* lp = a.attn_logits + row * kMlaDv + 128 * w + 4 * g;
+#pragma unroll
+      for (int nb = 0; nb < NBW; ++nb) {
+        if (a.merge_counters) store_dev(lp + 16 * nb, oacc[nb] * inv);
         else *reinterpret_cast<f32x4*>(lp + 16 * nb) = oacc[nb] * inv;
       }
       if (w == 0 && g == 0) {
@@ -1039,7 +1356,11 @@ int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, int di
   const unsigned grid = (pairs + 7) / 8 * 8 * a.qblocks;  // whole groups of 8 pairs (one per XCD)
   const bool kv8 = p->kv.kv_fp8 != 0;
   const bool old8 = !options().decode_mla8_dma;  // (A/B switch: the upcast-while-staging form for fp8 rows)
-  if (kv8 && !old8)
+  const bool t64 = kv8 && !old8 && options().decode_mla8_t64;  // the 64-token-tile form (round 5)
+  if (t64)
+    note_dispatch("decode_mla8_t64_kernel<%s, %s, %s>", p->dtype == RX_BF16 ? "rx::BF16" : "rx::F16", idx64 ? "long" : "int",
+                  tbool(linear));
+  else if (kv8 && !old8)
     note_dispatch("decode_mla8_dma_kernel<%s, %s, %s>", p->dtype == RX_BF16 ? "rx::BF16" : "rx::F16", idx64 ? "long" : "int",
                   tbool(linear));
   else
@@ -1047,7 +1368,13 @@ int launch_decode_mla(const rx_decode_params* p, int32_t* merge_counters, int di
                   tbool(linear), tbool(kv8));
 #define RX_MLA_L(TT, IT, LIN)                                                                          \
   do {                                                                                                 \
-    if (kv8 && !old8) {                                                                                \
+    if (t64) {                                                                                         \
+      auto kern = decode_mla8_t64_kernel<TT, IT, LIN>;                                                 \
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),          \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kT64Lds); \
+      (void)attr;                                                                                      \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kT64Lds, s, a);                                  \
+    } else if (kv8 && !old8) {                                                                         \
       auto kern = decode_mla8_dma_kernel<TT, IT, LIN>;                                                 \
       static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),          \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, kM8Lds); \

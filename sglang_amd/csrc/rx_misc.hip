@@ -124,7 +124,8 @@ static const OptionEntry kOptionTable[] = {
     {"extend_d256_at64", &Options::extend_d256_at64},     {"extend_d256_at96", &Options::extend_d256_at96},
     {"extend_nd", &Options::extend_nd},                   {"extend_nd_big", &Options::extend_nd_big},
     {"extend_mla", &Options::extend_mla},                 {"extend_mla_shared_v", &Options::extend_mla_shared_v},
-    {"decode_mla8_dma", &Options::decode_mla8_dma},
+    {"decode_mla8_dma", &Options::decode_mla8_dma},       {"decode_mla8_t64", &Options::decode_mla8_t64},
+    {"merge_in_kernel_max_mb", &Options::merge_in_kernel_max_mb}, {"merge_in_kernel_max_mb_mla", &Options::merge_in_kernel_max_mb_mla},
 };
 static Options load_options() {  // once, at first use: RX_OPT_<NAME> (upper case) overrides a default
   Options o;

@@ -23,7 +23,7 @@ from oracle import radix_oracle as orc
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILIES = ("extend_mfma32_kernel", "extend_mfma64_kernel", "extend_mfma_kernel", "extend_generic_kernel", "extend_d256_kernel", "extend_nd_kernel",
-            "extend_mla_kernel", "decode_mfma_kernel", "decode_generic_kernel", "decode_mla_kernel", "decode_mla8_dma_kernel")
+            "extend_mla_kernel", "decode_mfma_kernel", "decode_generic_kernel", "decode_mla_kernel", "decode_mla8_dma_kernel", "decode_mla8_t64_kernel")
 TN = {"bf16": "rx::BF16", "f16": "rx::F16"}
 TB = {True: "true", False: "false"}
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}
@@ -138,12 +138,14 @@ def _cases():
         hq, hkv = heads()
         out.append(dict(fam="decode", dt=dt, idx=idx, lin=lin, dk=80, dv=80, hq=hq, hkv=hkv, mode="indices",
                         expect=f"decode_generic_kernel<{TN[dt]}, {idx}, {TB[lin]}>"))
-        for kind in ("rows16", "fp8_staged", "fp8_dma"):
+        for kind in ("rows16", "fp8_staged", "fp8_dma", "fp8_t64"):
             exp = (f"decode_mla8_dma_kernel<{TN[dt]}, {idx}, {TB[lin]}>" if kind == "fp8_dma"
+                   else f"decode_mla8_t64_kernel<{TN[dt]}, {idx}, {TB[lin]}>" if kind == "fp8_t64"
                    else f"decode_mla_kernel<{TN[dt]}, {idx}, {TB[lin]}, {TB[kind != 'rows16']}>")
             out.append(dict(fam="decode", dt=dt, idx=idx, lin=lin, dk=576, dv=512, hq=(16, 128, 5)[next(n) % 3], hkv=1, mla=True,
                             fp8=kind != "rows16", mode="indices" if idx == "long" else "r2t",
-                            opts={"decode_mla8_dma": 0} if kind == "fp8_staged" else {}, expect=exp))
+                            opts={"decode_mla8_dma": 0} if kind == "fp8_staged" else ({"decode_mla8_t64": int(kind == "fp8_t64")} if kind in ("fp8_dma", "fp8_t64") else {}),
+                            expect=exp))
     # int32 kv_indices only exist in "indices" mode; a req_to_token walk has no IdxT (the launcher takes int)
     for c in out:
         if c["fam"] == "decode" and c["idx"] == "int" and c.get("mode") == "indices":

@@ -156,7 +156,7 @@ def test_extend_kernels_under_adversarial_scores(case, pattern, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("pattern", PATTERNS)
-@pytest.mark.parametrize("rows", ["16bit", "fp8"])
+@pytest.mark.parametrize("rows", ["16bit", "fp8", "fp8_k_split"])
 def test_mla_decode_kernels_under_adversarial_scores(rows, pattern, dtype):
     """rx::decode_mla_kernel (16-bit latent rows) and rx::decode_mla8_dma_kernel (fp8 rows), single pass and split-KV: the
     same patterns along the context of two requests (one ending inside a tile)."""
@@ -188,11 +188,13 @@ def test_mla_decode_kernels_under_adversarial_scores(rows, pattern, dtype):
     q = q.to(dtype)
     rpi = np.arange(1, bs + 1, dtype=np.int64)
     kv_indptr, kv_indices = orc.build_kv_indices(r2t, rpi, lens)
+    k_split = rows == "fp8_k_split"   # the 32-token form that splits QK^T over the waves (option decode_mla8_t64 = 0)
+    rows = "fp8" if k_split else rows
     if rows == "fp8":
         kvq = kv.to(torch.float8_e4m3fn)
         kvn = kvq.float().numpy().astype(np.float64)           # the dequantised rows: what the kernel computes with
         kvd = kvq.to(DEV)
-        expect = "decode_mla8_dma_kernel"
+        expect = "decode_mla8_dma_kernel" if k_split else "decode_mla8_t64_kernel"
     else:
         kvq = kv.to(dtype)
         kvn = _np(kvq)
@@ -214,8 +216,9 @@ def test_mla_decode_kernels_under_adversarial_scores(rows, pattern, dtype):
         assert rxlib.last_dispatch().startswith(expect), rxlib.last_dispatch()
         parity.check_out(o.float().cpu().numpy(), want, dtype, ("adversarial", rows, pattern, "single"), absw=absw)
     o2 = torch.full_like(o, float("nan"))
-    ops.decode_attention_fwd(qd, kvd, kvd[..., :512], o2, _t(kv_indptr), _t(kv_indices), al, lse, nsplit, S, sm, 1.0, 1.0, page_size=ps)
-    torch.cuda.synchronize()
+    with rxlib.option("decode_mla8_t64", 0 if k_split else 1):
+        ops.decode_attention_fwd(qd, kvd, kvd[..., :512], o2, _t(kv_indptr), _t(kv_indices), al, lse, nsplit, S, sm, 1.0, 1.0, page_size=ps)
+        torch.cuda.synchronize()
     assert rxlib.last_dispatch().startswith(expect), rxlib.last_dispatch()
     parity.check_out(o2.float().cpu().numpy(), want, dtype, ("adversarial", rows, pattern, "split"), absw=absw)
 

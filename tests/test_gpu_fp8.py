@@ -160,7 +160,16 @@ def test_decode_fp8_pool_vs_oracle(ops, dtype, hq, hkv, d, page_size):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("hq,page_size", [(16, 1), (128, 16)])
-def test_decode_mla_fp8_rows_vs_oracle(ops, dtype, hq, page_size):
+@pytest.mark.parametrize("form", ["k_split", "t64"])   # option decode_mla8_t64: the 32-token K-split kernel / the 64-token-tile kernel
+def test_decode_mla_fp8_rows_vs_oracle(ops, dtype, hq, page_size, form):
+    from sglang_amd import lib as rxlib
+    with rxlib.option("decode_mla8_t64", int(form == "t64")):
+        _decode_mla_fp8_rows_vs_oracle(ops, dtype, hq, page_size)
+        want_kernel = "decode_mla8_t64_kernel" if form == "t64" else "decode_mla8_dma_kernel"
+        assert want_kernel in rxlib.last_dispatch(), rxlib.last_dispatch()
+
+
+def _decode_mla_fp8_rows_vs_oracle(ops, dtype, hq, page_size):
     rng = np.random.default_rng(hq)
     lens = np.array([1, 31, 32, 33, 700, 64, 2049], dtype=np.int64)
     bs = len(lens)
