@@ -95,6 +95,17 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+// p[i] and p[i + 1] of an int32 or int64 array, branch-free: two 8-byte loads issued back to back (a load behind an
+// `is64 ?` branch is waited for at the join, so two load_idx calls cost two dependent round trips).  int32: the first
+// load holds both entries and the second re-reads the same address (no byte past p[i + 1] is touched).
+__device__ __forceinline__ void load_idx_pair(const void* p, int64_t i, bool is64, int64_t& v0, int64_t& v1) {
+  const char* b = reinterpret_cast<const char*>(p);
+  const u32x2 x = *reinterpret_cast<const u32x2*>(b + (is64 ? i * 8 : i * 4));
+  const u32x2 y = *reinterpret_cast<const u32x2*>(b + (is64 ? (i + 1) * 8 : i * 4));
+  v0 = is64 ? static_cast<int64_t>((static_cast<uint64_t>(x[1]) << 32) | x[0]) : static_cast<int64_t>(static_cast<int32_t>(x[0]));
+  v1 = is64 ? static_cast<int64_t>((static_cast<uint64_t>(y[1]) << 32) | y[0]) : static_cast<int64_t>(static_cast<int32_t>(x[1]));
+}
+
 
 struct BF16 {
   using vec8 = bf16x8;

@@ -602,9 +602,6 @@ constexpr int kM8SlotBlock = 1024;             // tokens whose slot ids are stag
 constexpr int kM8Lds = kM8Ring * kM8Buf + 4 * 64 * 16 + 2 * kM8SlotBlock * 4;
 
 // one 1-KiB LDS-DMA piece: lane l's 16 bytes land at lds_dst + 16 l (recipe: cdna_hip_programming.md 5.7)
-#ifndef RX_M8_PROBE
-#define RX_M8_PROBE 0  // dev: 1 = the DMA stream, waits and barriers only (no products): the access pattern's ceiling
-#endif
 #ifndef RX_M8_NT
 #define RX_M8_NT 0  // 1: non-temporal DMA loads (the rows are read once per step)
 #endif
@@ -841,7 +838,6 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
     dma_pieces(t + kM8Ahead, 0, 2);
     read_slots(t + kM8Ahead + 1);  // for the next iteration's issue
 
-#if !RX_M8_PROBE
     // ---- partial S^T of this wave: token block bb_w, k-steps [ks0, ks0 + 9)
     f32x4 sacc[2];
     {
@@ -880,9 +876,7 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
       sacc[0] = xch[0 * 64 + lane] + xch[2 * 64 + lane];
       sacc[1] = xch[1 * 64 + lane] + xch[3 * 64 + lane];
     }
-#endif
     dma_pieces(t + kM8Ahead, 2, 4);
-#if !RX_M8_PROBE
     // ---- online softmax (identical in all four waves); score (bb, i) of this lane is token 8 g + 4 bb + i
     float sv[8];
 #pragma unroll
@@ -936,9 +930,7 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
 #pragma unroll
       for (int nb = 0; nb < NBW; ++nb) oacc[nb] *= alpha;
     }
-#endif
     dma_pieces(t + kM8Ahead, 4, NP);
-#if !RX_M8_PROBE
     // ---- O^T[128 w + ...] += V^T P^T: one transposed byte read per fragment (rows 8 g .. 8 g + 7), upcast, MFMA
     {
       const char* vp = kt + (8 * g + (i16 >> 1)) * kM8Row + (g >= 2 ? kM8HalfShift : 0) + 128 * w + 8 * (i16 & 1);
@@ -950,9 +942,6 @@ __global__ __launch_bounds__(256, (kM8Ring == 2 ? 3 : 2)) void decode_mla8_dma_k
         oacc[nb] = T::mfma(av, pf, oacc[nb]);
       }
     }
-#else
-    __syncthreads();
-#endif
   }
   // nothing of this workgroup may still be landing in LDS when the block retires
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -11,7 +11,7 @@ __device__ unsigned long long g_ext32_counters[2];
 template <int NW, bool KV8, bool PLAIN, int PKC = 0>
 static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, bool vs, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
-  constexpr unsigned kLds = 2 * kBufBytes;  // 74 KiB: above the 64 KiB static limit, hence dynamic
+  constexpr unsigned kLds = ext32_lds_bytes<NW>();  // 74 KiB (+ 68 KiB of epilogue rows with eight waves): dynamic
   note_dispatch("extend_mfma32_kernel<%s, %s, %s, %s, %d, %s, %s, %d>", bf16 ? "rx::BF16" : "rx::F16", idx64 ? "long" : "int",
                 tbool(linear), tbool(!PLAIN && vs), NW, tbool(KV8), tbool(PLAIN), PKC);
 #define RX_E32(TT, IT, LIN, VS)                                                                        \
@@ -114,7 +114,7 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
     if (hipGetSymbolAddress(reinterpret_cast<void**>(&ctr), HIP_SYMBOL(g_ext32_counters)) != hipSuccess)
       return fail(RX_ERR_LAUNCH, "rx_extend_attn: no address for the debug counters");
     auto kern = extend_mfma32_count_kernel<BF16, int64_t, false, false, 8, false, true, 4>;
-    constexpr unsigned kLds = 2 * kBufBytes;
+    constexpr unsigned kLds = ext32_lds_bytes<8>();
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     (void)attr;
     note_dispatch("extend_mfma32_count_kernel<rx::BF16, long, false, false, 8, false, true, 4>");

@@ -13,6 +13,8 @@ namespace rx {
 char* err_buf() { static thread_local char b[8]; return b; }
 int fail(int code, const char*, ...) { return code; }
 
+__device__ unsigned g_dev_work[16];
+
 template <int VAR>
 static int launch_var(const rx_extend_params* p, hipStream_t s) {
   Ext32Args a = make_ext32_args(p);
@@ -23,8 +25,22 @@ static int launch_var(const rx_extend_params* p, hipStream_t s) {
   a.mblocks = (p->max_extend_len * a.q_pack + 8 * 32 - 1) / (8 * 32);
   a.kv_fp8 = 0;
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
-  constexpr unsigned kLds = 2 * kBufBytes;
-  static_assert(VAR == 0, "add a trailing `int VAR = 0` template parameter to the kernel to study variants");
+  constexpr unsigned kLds = ext32_lds_bytes<8>();
+  static_assert(VAR == 0 || VAR == 1, "add a trailing `int VAR = 0` template parameter to the kernel to study variants");
+  if constexpr (VAR == 1) {  // the resident-workgroup form (rx::extend_mfma32_persist_kernel)
+    auto kern = extend_mfma32_persist_kernel<BF16, int64_t, false, 4>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    (void)attr;
+    unsigned* work = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&work), HIP_SYMBOL(g_dev_work)) != hipSuccess) return -4;
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    const unsigned g = std::min<unsigned>(grid, static_cast<unsigned>(cus)) & ~7u;
+    if (g < 8) return -5;
+    hipLaunchKernelGGL(kern, dim3(g), dim3(512), kLds, s, a, work);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
   auto kern = extend_mfma32_kernel<BF16, int64_t, false, false, 8, false, true, 4>;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
@@ -34,6 +50,11 @@ static int launch_var(const rx_extend_params* p, hipStream_t s) {
 }
 }  // namespace rx
 
+#ifdef RX_EXT32_TIMELINE
+extern "C" int rx_dev_stamps(void* out, int nblocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(rx::rx_ext32_timeline), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int rx_dev_extend32(const rx_extend_params* p, int variant, void* stream) {
   auto s = static_cast<hipStream_t>(stream);
   if (p->num_q_heads != 4 * p->num_kv_heads || p->dtype != RX_BF16 || !p->kv_indices_is_i64) return -2;
