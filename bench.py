@@ -747,6 +747,29 @@ def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=20, shape
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / nchunks
     k_tflops = flops / (ms * 1e-3) / 1e12
+    # the shader clock these launches sustain: one sleeping wave on a side stream reads s_memtime against s_memrealtime for
+    # six launch times while the same launches keep running (rx_clock_probe).  On random operands the chip is power-capped
+    # well below its 2.4 GHz peak clock (the same cycles per tile on all-zero operands run at 2.38 GHz).
+    sclk = None
+    try:
+        probe_out = torch.zeros(2, dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        for _ in range(4):
+            run()
+        side.wait_stream(torch.cuda.current_stream())  # (the probe starts among the launches, not before them)
+        rxlib.clock_probe(probe_out, max(1000, int(ms * 1000 * 6)), side.cuda_stream)
+        for _ in range(12):
+            run()
+        torch.cuda.synchronize()
+        cyc, ticks = (int(x) for x in probe_out.tolist())
+        if ticks > 0:
+            mhz = cyc / ticks * 100.0
+            peak_at = MFMA_BF16_PEAK_TFLOPS * mhz / 2400.0
+            sclk = {"mhz": mhz, "peak_at_this_clock_tflops": peak_at, "frac_at_this_clock": k_tflops / peak_at,
+                    "how": "rx_clock_probe: s_memtime cycles / s_memrealtime ticks of one sleeping wave on a side stream "
+                           "over 6 launch times, the same launches running; the 2.5 PF peak is at 2.4 GHz"}
+    except Exception as e:  # noqa: BLE001
+        sclk = {"error": f"{type(e).__name__}: {e}"}
     # MFMA-pipe busy fraction: an SQ-counter figure (SQ_VALU_MFMA_BUSY_CYCLES) that needs its own rocprofv3 --pmc passes;
     # the committed summary of those passes is quoted with its provenance, for the shape it was measured on only
     mfma_busy = None
@@ -769,6 +792,7 @@ def extend_bench(args, dev, tp, head_dim=128, v_head_dim=None, nchunks=20, shape
             "tflops": tflops, "ms_per_forward": ms_fwd, "layers": L, "ms_per_chunk": ms_fwd / L, "chunk_requests": chunk,
             "flops_per_chunk": flops, "kernel": "rx::" + kernel_name,
             "kernel_only": {"tflops": k_tflops, "ms_per_launch": ms, "launches_timed": nchunks},
+            "sustained_clock": sclk,
             "prefix_layout": f"page_size {ps}, shuffled pages, {args.kv_layout.upper()} pool",
             "warmup": "each timed region follows ~80 ms of the same launches (gpu_warm: clock ramp after idle)",
             # the dominant kernel's roofline: algorithmic FLOPs per launch / its launch-to-launch time
@@ -1445,6 +1469,10 @@ def compact_record(out):
                              % (ext["chunk_requests"], ext["layers"])}
             if "sharding" in ext:
                 e["sharding"] = ext["sharding"]
+            sc = ext.get("sustained_clock")
+            if isinstance(sc, dict) and "mhz" in sc:  # the clock the launch runs at (power-capped on random operands) and the frac against the peak AT that clock
+                e["sclk_mhz"] = _r(sc["mhz"], 0)
+                e["frac_at_sclk"] = _r(sc["frac_at_this_clock"], 4)
             for name in ("d64", "d96", "d256", "d192_v128"):
                 v = _get(ext, "other_head_dims", name, "frac")
                 if v is not None:

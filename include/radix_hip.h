@@ -24,13 +24,14 @@
 extern "C" {
 #endif
 
-/* 12 (round 5): rx_split_items_guarded, rx_debug_counters, rx_draft_decode_kv_indices.
+/* 13 (round 5): rx_clock_probe.
+ * 12 (round 5): rx_split_items_guarded, rx_debug_counters, rx_draft_decode_kv_indices.
  * 11 (round 4): rx_qknorm_rope_store_kv (fused QK-norm + RoPE + store).
  * 10 (round 4): rx_decode_params.rope_* (fused RoPE of the latent decode).
  * 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
  * 8 (round 3): rx_split_items; rx_decode_params.split_items / split_items_count / split_items_cap /
  * split_items_wgs_per_cu and extra_index / extra_rows; rx_num_kv_splits_balanced gained wg_target_mixed. */
-#define RX_ABI_VERSION 12
+#define RX_ABI_VERSION 13
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -70,6 +71,12 @@ const char* rx_last_dispatch(void);
  * softmax blocks its pipelined tiles processed, out2[1] = how many of them took the sum check's redo (a block whose lane sum
  * exceeded 4096 against the standing reference max), summed over all such launches since the last reset.  Synchronises. */
 int rx_debug_counters(uint64_t* out2, int reset);
+/* Clock probe (round 5; no reference counterpart).  Launches ONE wave on `stream` that sleeps for spin_us microseconds of the
+ * constant-rate clock and then writes out2_dev[0] = shader cycles (s_memtime), out2_dev[1] = 100-MHz ticks (s_memrealtime)
+ * it saw pass (device memory, 16 bytes): launched on a side stream next to a kernel under test, cycles / ticks * 100 is
+ * the shader clock in MHz that kernel sustains -- bench.py quotes the D = 128 extend launch against the MFMA peak at THAT clock
+ * beside the nominal one (the launch is power-capped on random operands: DESIGN 4.2). */
+int rx_clock_probe(uint64_t* out2_dev, int32_t spin_us, void* stream);
 int rx_set_option(const char* name, int value);
 int rx_get_option(const char* name, int* value);
 

@@ -703,7 +703,32 @@ __global__ __launch_bounds__(256) void draft_decode_kv_indices_kernel(
 }  // namespace rx
 
 
+namespace rx {
+// one wave: both clocks before and after spin_ticks of the constant-rate one, asleep in between (no issue slots, no power)
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned long long spin_ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64(), c0 = clock64();
+  unsigned long long t1 = t0;
+  while (t1 - t0 < spin_ticks) {
+    __builtin_amdgcn_s_sleep(64);
+    t1 = wall_clock64();
+  }
+  const unsigned long long c1 = clock64();
+  out[0] = c1 - c0;
+  out[1] = t1 - t0;
+}
+}  // namespace rx
+
 extern "C" {
+
+int rx_clock_probe(uint64_t* out2_dev, int32_t spin_us, void* stream) {
+  RX_REQUIRE(out2_dev, "rx_clock_probe: null output");
+  RX_REQUIRE(spin_us > 0 && spin_us <= 1000000, "rx_clock_probe: spin_us must be in (0, 1e6]");
+  hipLaunchKernelGGL(rx::clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<unsigned long long*>(out2_dev), static_cast<unsigned long long>(spin_us) * 100ull);
+  if (hipGetLastError() != hipSuccess) return rx::fail(RX_ERR_LAUNCH, "rx_clock_probe: launch failed");
+  return RX_OK;
+}
 
 int rx_version(void) { return RX_ABI_VERSION; }
 int64_t rx_abi_sizeof(int which) {

@@ -16,7 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
-RX_ABI_VERSION = 12  # include/radix_hip.h
+RX_ABI_VERSION = 13  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -123,6 +123,7 @@ PROTOTYPES = {
     "rx_num_kv_splits_native": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rx_split_items": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "rx_debug_counters": (c_int, [c_void_p, c_int]),
+    "rx_clock_probe": (c_int, [c_void_p, c_int32, c_void_p]),
     "rx_draft_decode_kv_indices": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                            c_int, c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "rx_split_items_guarded": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
@@ -257,6 +258,12 @@ def debug_counters(reset: bool = False):
     out = (_C.c_uint64 * 2)()
     check(load().rx_debug_counters(out, int(bool(reset))), "rx_debug_counters")
     return int(out[0]), int(out[1])
+
+
+def clock_probe(out2_dev, spin_us: int, stream) -> None:
+    """rx_clock_probe: one wave on `stream` that watches both clocks for spin_us; out2_dev = 2 x uint64 device tensor
+    (shader cycles, 100-MHz ticks)."""
+    check(load().rx_clock_probe(out2_dev.data_ptr(), int(spin_us), stream), "rx_clock_probe")
 
 
 _roctx = None

@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(l, s), f"{s} declared in include/radix_hip.h but not exported"
         assert s in lib.PROTOTYPES, f"{s} has no ctypes prototype"
-    assert l.rx_version() == lib.RX_ABI_VERSION == 12
+    assert l.rx_version() == lib.RX_ABI_VERSION == 13
     assert [l.rx_abi_sizeof(i) for i in range(4)][3] == -1 and l.rx_abi_sizeof(1) > 0
 
 

@@ -1089,3 +1089,19 @@ def test_roctx_ranges_do_not_change_a_decode_step():
             outs.append(hs.layer(q, k, v, fb, hs.backend).clone())
             torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_clock_probe_reads_a_plausible_shader_clock():
+    """rx_clock_probe (bench.py's sustained-clock figure): one sleeping wave, s_memtime cycles against 100-MHz s_memrealtime
+    ticks over the requested time."""
+    from sglang_amd import lib as rxlib
+
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    rxlib.clock_probe(out, 2000, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    cyc, ticks = (int(x) for x in out.tolist())
+    assert 2000 * 100 <= ticks < 2000 * 100 * 2, ticks           # 2 ms of the constant-rate clock (it overshoots by one sleep at most)
+    assert 50.0 < cyc / ticks * 100.0 < 3000.0, (cyc, ticks)     # MHz: anything from the idle state to the 2.4 GHz peak
+    with pytest.raises(rxlib.RadixHipError):
+        rxlib.clock_probe(out, 0, torch.cuda.current_stream().cuda_stream)
