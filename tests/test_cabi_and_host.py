@@ -339,7 +339,7 @@ print("RC", rc, l.rx_last_error().decode())
     txt = sorted(f for f in os.listdir(tmp_path) if f.endswith(".txt"))
     assert len(txt) == 1 and txt[0].startswith("rx_extend_attn_"), os.listdir(tmp_path)
     rec = open(os.path.join(tmp_path, txt[0])).read()
-    assert "status:" in rec and "error:" in rec and "abi: 12" in rec
+    assert "status:" in rec and "error:" in rec and "abi: 13" in rec
     d = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "decode_dump.py"), os.path.join(tmp_path, txt[0])],
                        capture_output=True, text=True)
     assert d.returncode == 0 and "bs = 3" in d.stdout and "head_dim = 128" in d.stdout, d.stdout[-1500:] + d.stderr[-500:]
