@@ -27,6 +27,7 @@ struct Options {
   int ext32_pack_min_len = 1;     // self-packing from this many new tokens (longest request) up ...
   int ext32_pack_min_tiles = 4;   // ... and this tile estimate; packed PLAIN rows take eight waves from here
   int ext32_pack_min_wgs = -1;    // ... while the packed grid holds this many workgroups (-1: the device's CU count)
+  int ext32_pack4_tiles = 24;    // ... and FOUR waves (two workgroups per CU) below this tile estimate
   int ext32_plain = 1;        // PLAIN instances (features compile-time off) when the call uses none of them
   int roctx = 0;              // roctx ranges around the entry points' launches (RX_RANGE)
   int ext32_count_redo = 0;   // debug: the bench-shaped packed call runs the COUNTING instance (rx_debug_counters)

@@ -99,17 +99,23 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const bool small_wg = opt.ext32_small_wg < 0
                             ? (!few_small && (thin_grid || est_tiles < (packed_plain ? opt.ext32_pack_min_tiles : opt.ext32_small_wg_tiles)))
                             : opt.ext32_small_wg != 0;
-  const int nw = small_wg ? 4 : 8;
+  // Packed rows on FEW tiles (round 5): four waves of the same PLAIN loop, 128-row blocks -- two workgroups share a CU and one
+  // runs tiles while the other is in its prologue, diagonal tile or epilogue (per 256-row block: 3.8 + 1.0 us, + ~3 us until
+  // the CU's next workgroup starts, against 1.74 us a tile).  tools/ext32_ab.py, eight vs four waves, TFLOP/s: no prefix +
+  // 512 new tokens 412 / 468, + 1 k 603 / 650, + 2 k 814 / 831; 512 + 512 725 / 755; 2 k + 128 (33 tiles) 937 / 944 median,
+  // 995 / 971 best.  Option ext32_pack4_tiles moves the gate (0: never).
+  const bool pack4 = packed_plain && (small_wg || (opt.ext32_small_wg < 0 && !few_small && est_tiles < opt.ext32_pack4_tiles));
+  const int nw = (small_wg || pack4) ? 4 : 8;
   a.mblocks = (p->max_extend_len * a.q_pack + nw * 32 - 1) / (nw * 32);
   const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0;
   const bool plain = plain_any && a.q_pack == 1;
   // Option ext64 (default off: measured 0.83x of the eight-wave kernel on the config-3 chunk): PLAIN eight-wave
   // calls (packed or not) as the same 256-row blocks on FOUR waves of 64 rows, one per SIMD (rx_extend64.hip)
-  if (opt.ext64 && !small_wg && (packed_plain || plain) && !(a.page_size >= 0 && !linear)) {
+  if (opt.ext64 && nw == 8 && (packed_plain || plain) && !(a.page_size >= 0 && !linear)) {
     launch_extend64(a, bf, i64, linear, s);
     return RX_OK;
   }
-  if (opt.ext32_count_redo && packed_plain && !small_wg && a.q_pack == 4 && bf && i64 && !linear) {  // the counting instance
+  if (opt.ext32_count_redo && packed_plain && nw == 8 && a.q_pack == 4 && bf && i64 && !linear) {  // the counting instance
     unsigned long long* ctr = nullptr;
     if (hipGetSymbolAddress(reinterpret_cast<void**>(&ctr), HIP_SYMBOL(g_ext32_counters)) != hipSuccess)
       return fail(RX_ERR_LAUNCH, "rx_extend_attn: no address for the debug counters");
@@ -121,9 +127,14 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(a.bs) * a.hq * a.mblocks), dim3(512), kLds, s, a, ctr);
     return RX_OK;
   }
-  if (packed_plain && !small_wg) {  // packed rows on the PLAIN loop (GQA 4 / 8)
-    if (a.q_pack == 4) launch32_nw<8, false, true, 4>(a, bf, i64, linear, false, s);
-    else launch32_nw<8, false, true, 8>(a, bf, i64, linear, false, s);
+  if (packed_plain) {  // packed rows on the PLAIN loop (GQA 4 / 8)
+    if (nw == 8) {
+      if (a.q_pack == 4) launch32_nw<8, false, true, 4>(a, bf, i64, linear, false, s);
+      else launch32_nw<8, false, true, 8>(a, bf, i64, linear, false, s);
+    } else {
+      if (a.q_pack == 4) launch32_nw<4, false, true, 4>(a, bf, i64, linear, false, s);
+      else launch32_nw<4, false, true, 8>(a, bf, i64, linear, false, s);
+    }
     return RX_OK;
   }
   if (small_wg) {

@@ -43,8 +43,7 @@ def _cases():
     # ---- extend, D = 128, 32x32x16: <T, IdxT, LINEAR, VSCALE, NW, KV8, PLAIN, PKC>
     for dt, idx, lin, nw in itertools.product(TN, ("int", "long"), (False, True), (4, 8)):
         variants = [("plain", 0), ("extras", False), ("extras", True), ("fp8", False), ("fp8", True)]
-        if nw == 8:
-            variants += [("plain", 4), ("plain", 8)]
+        variants += [("plain", 4), ("plain", 8)]  # (packed PLAIN rows: eight waves, or -- few tiles, round 5 -- four)
         for kind, arg in variants:
             c = dict(fam="extend", dt=dt, idx=idx, lin=lin, dk=128, dv=128, opts={"ext32_small_wg": int(nw == 4)},
                      ext=[300, 40, 257, 129], pre=[0, 70, 200, 33], kw={})
@@ -53,6 +52,8 @@ def _cases():
                 if pkc:  # the packed PLAIN instances: GQA 4 / 8, causal, long extends (autopack)
                     c["hq"], c["hkv"] = (8, 2) if pkc == 4 else (8, 1)
                     c["opts"]["ext32_pack_min_wgs"] = 0  # (four requests: the packed grid is below the chip-coverage gate)
+                    if nw == 4:
+                        c["opts"]["ext32_pack_min_tiles"] = 0  # (no length hint: the tile estimate is below the packing gate)
                 else:    # never auto-packed: group 1, 2 or 16
                     c["hq"], c["hkv"] = [(4, 4), (4, 2), (16, 1)][next(n) % 3]
                 vs, kv8, plain = False, False, True

@@ -116,7 +116,12 @@ def test_self_packing_gates_tile_estimate_and_chip_coverage():
 
     big = -(-cus // hkv)                      # requests whose packed grid (one block each) just covers the chip
     o_p, name = run(big, 512, 64)
-    assert name.endswith("8, false, true, 4>"), name          # 9 estimated tiles, grid >= CUs: packed, eight waves
+    assert name.endswith("4, false, true, 4>"), name          # 8 estimated tiles, grid >= CUs: packed, on four waves (round 5: < 24 tiles)
+    o_8, name = run(big, 512, 64, ext32_pack4_tiles=0)
+    assert name.endswith("8, false, true, 4>"), name          # ... that gate is an option: eight waves, same bits
+    assert torch.equal(o_p.view(torch.int16), o_8.view(torch.int16))
+    _, name = run(big, 1600, 64)
+    assert name.endswith("8, false, true, 4>"), name          # 25 estimated tiles: packed, eight waves
     o_u, name = run(big, 512, 64, ext32_autopack=0)
     assert name.endswith("4, false, true, 0>"), name          # switched off: the four-wave unpacked form of that estimate
     assert torch.equal(o_p.view(torch.int16), o_u.view(torch.int16)) and not torch.isnan(o_p.float()).any()
@@ -125,7 +130,7 @@ def test_self_packing_gates_tile_estimate_and_chip_coverage():
     _, name = run(big, 64, 64)
     assert name.endswith("4, false, true, 0>"), name          # one estimated tile: next to nothing to do, unpacked
     _, name = run(big - 8, 512, 64, ext32_pack_min_wgs=0)
-    assert name.endswith("8, false, true, 4>"), name          # the gate is an option
+    assert name.endswith("4, false, true, 4>"), name          # the gate is an option
 
 
 @pytest.mark.parametrize("dims", [(256, 256), (64, 64), (192, 128), (96, 96)], ids=["d256", "d64", "d192_128", "d96"])

@@ -26,7 +26,17 @@ static int launch_var(const rx_extend_params* p, hipStream_t s) {
   a.kv_fp8 = 0;
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
   constexpr unsigned kLds = ext32_lds_bytes<8>();
-  static_assert(VAR == 0 || VAR == 1, "add a trailing `int VAR = 0` template parameter to the kernel to study variants");
+  static_assert(VAR == 0 || VAR == 1 || VAR == 2, "add a trailing `int VAR = 0` template parameter to the kernel to study variants");
+  if constexpr (VAR == 2) {  // packed rows on FOUR waves: 128-row blocks, two workgroups per CU
+    a.mblocks = (p->max_extend_len * a.q_pack + 4 * 32 - 1) / (4 * 32);
+    constexpr unsigned kLds4 = ext32_lds_bytes<4>();
+    auto kern = extend_mfma32_kernel<BF16, int64_t, false, false, 4, false, true, 4>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLds4);
+    (void)attr;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(a.bs) * a.hq * a.mblocks), dim3(256), kLds4, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
   if constexpr (VAR == 1) {  // the resident-workgroup form (rx::extend_mfma32_persist_kernel)
     auto kern = extend_mfma32_persist_kernel<BF16, int64_t, false, 4>;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -57,7 +67,8 @@ extern "C" int rx_dev_stamps(void* out, int nblocks) {
 #endif
 extern "C" int rx_dev_extend32(const rx_extend_params* p, int variant, void* stream) {
   auto s = static_cast<hipStream_t>(stream);
-  if (p->num_q_heads != 4 * p->num_kv_heads || p->dtype != RX_BF16 || !p->kv_indices_is_i64) return -2;
+  // (a call without a prefix has an empty index list: the int64 instance never reads it)
+  if (p->num_q_heads != 4 * p->num_kv_heads || p->dtype != RX_BF16 || (!p->kv_indices_is_i64 && p->kv_indices != nullptr)) return -2;
   switch (variant) {
     case 0: return rx::launch_var<0>(p, s);
 #define RX_V(n) case n: return rx::launch_var<n>(p, s);
