@@ -31,7 +31,7 @@ extern "C" {
  * 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
  * 8 (round 3): rx_split_items; rx_decode_params.split_items / split_items_count / split_items_cap /
  * split_items_wgs_per_cu and extra_index / extra_rows; rx_num_kv_splits_balanced gained wg_target_mixed. */
-#define RX_ABI_VERSION 13
+#define RX_ABI_VERSION 14
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -366,6 +366,17 @@ typedef struct rx_decode_params {
   int32_t rope_is_neox;
   void* rope_k_pe_out;
   int64_t rope_k_pe_out_stride;
+  /* ---- relative-position score bias, round 5 (ABI 14): the reference's score_mod = relative_bias_score_mod with
+   * aux_tensors = [rel_logits] (kernels/ops/attention/score_mod.py:44-56; call sites decode_attention.py:215-227,
+   * 539-551; used by srt/models/inkling_common/attn.py:934-946).  score_bias [bs, Hq, score_bias_len] (fp32, or the
+   * call's 16-bit dtype; last dim contiguous, element strides for request and head): the score of request b, head h
+   * against list position n gets + score_bias[b, h, r], r = (len_b - 1) - n, when 0 <= r < score_bias_len -- after
+   * scale, logit cap and the Grok temperature, before the softmax; len_b = the request's kv length.  D = 64 / 96 /
+   * 128 / 256 kernel and the generic kernel; not the MLA kernels.  NULL: off. */
+  const void* score_bias;
+  int32_t score_bias_is_f32;
+  int32_t score_bias_len;
+  int64_t score_bias_stride_t, score_bias_stride_h;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);
@@ -449,6 +460,18 @@ typedef struct rx_extend_params {
    * (speculative verify, short chunks) fills the 32-row query blocks and stages its K/V tiles once per kv head
    * instead of once per q head.  Bit-identical results. */
   int32_t q_pack;
+  /* ---- relative-position score bias, round 5 (ABI 14): score_mod = relative_bias_score_mod, aux_tensors = [rel_logits]
+   * (score_mod.py:44-56; call sites extend_attention.py:463-476 prefix stage, :594-607 extend stage, :1093-1104
+   * unified).  score_bias [T, Hq, score_bias_len] (fp32 or the call's 16-bit dtype, last dim contiguous): the score of
+   * query token t = qo_indptr[i] + m, head h against a key gets + score_bias[t, h, r], r = q_pos - kv_pos, when
+   * 0 <= r < score_bias_len (after scale, cap and temperature; masked scores stay -inf).  q_pos = P_i + m; kv_pos = the
+   * list position n for prefix keys and P_i + n for new tokens (unified form: q_pos = prefix_i + m, kv_pos = n).
+   * D = 128 kernel (tiles out of the bias's reach keep the pipelined body) and the generic kernel (other head dims);
+   * not with q_pack.  NULL: off. */
+  const void* score_bias;
+  int32_t score_bias_is_f32;
+  int32_t score_bias_len;
+  int64_t score_bias_stride_t, score_bias_stride_h;
 } rx_extend_params;
 
 int rx_extend_attn(const rx_extend_params* p /* HOST */, void* stream);

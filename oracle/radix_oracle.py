@@ -518,6 +518,14 @@ def _tanh_cap(x, cap):
     return cap * np.tanh(x / cap) if cap > 0 else x
 
 
+def _rel_bias(bias_row, q_pos, kv_pos):
+    """relative_bias_score_mod (kernels/ops/attention/score_mod.py:44-56): bias_row[q_pos - kv_pos] where
+    0 <= q_pos - kv_pos < len(bias_row), else 0.  bias_row float64 [extent]; kv_pos an integer array."""
+    rel = q_pos - np.asarray(kv_pos, dtype=np.int64)
+    ok = (rel >= 0) & (rel < bias_row.shape[0])
+    return np.where(ok, bias_row[np.clip(rel, 0, bias_row.shape[0] - 1)], 0.0)
+
+
 def _gather_kv(buf, slots, kv_head):
     """buf [slots, Hkv, D] (NHD, memory_pool.py:2030-2041) -> [n, D] float64."""
     return to_f64(buf[slots, kv_head])
@@ -525,8 +533,11 @@ def _gather_kv(buf, slots, kv_head):
 
 def decode_attention(q, k_buffer, v_buffer, kv_indptr, kv_indices, sm_scale,
                      k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
-                     return_lse=False, xai_temperature_len=-1):
-    """Semantics of decode_attention_fwd (decode_attention.py:968-1044):
+                     return_lse=False, xai_temperature_len=-1, score_bias=None):
+    """score_bias [bs, Hq, extent] (already decoded to float): the reference's score_mod = relative_bias_score_mod with
+    aux_tensors = [score_bias] (decode_attention.py:215-227,539-551: q_pos = seq_len - 1, kv_pos = list position,
+    q_idx = request), added after scale, cap and temperature.
+    Semantics of decode_attention_fwd (decode_attention.py:968-1044):
     o[b,h] = softmax(q[b,h]·K[idx]^T * sm_scale*k_scale [tanh cap]) · V[idx] * v_scale,
     idx = kv_indices[kv_indptr[b]:kv_indptr[b+1]], kv head = h // (Hq/Hkv).
     Optional per-head sink logit joins the denominator (stage2 :796-798).
@@ -550,6 +561,8 @@ def decode_attention(q, k_buffer, v_buffer, kv_indptr, kv_indices, sm_scale,
             vv = _gather_kv(v_buffer, idx, kvh)
             for h in range(kvh * group, (kvh + 1) * group):
                 s = _tanh_cap(kk @ qf[b, h] * (sm_scale * k_scale), logit_cap) * xai
+                if score_bias is not None:
+                    s = s + _rel_bias(np.asarray(score_bias[b, h], dtype=np.float64), idx.size - 1, np.arange(idx.size))
                 m = s.max()
                 p = np.exp(s - m)
                 den = p.sum()
@@ -620,8 +633,11 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
                      k_scale=1.0, v_scale=1.0, logit_cap=0.0,
                      sliding_window_size=-1, sinks=None, skip_prefix=False,
                      skip_extend=False, return_lse=False, custom_mask=None, mask_indptr=None,
-                     skip_prefix_custom_mask=True, window_kv_offsets=None, xai_temperature_len=-1):
-    """Semantics of extend_attention_fwd (extend_attention.py:664-812).  Request i
+                     skip_prefix_custom_mask=True, window_kv_offsets=None, xai_temperature_len=-1, score_bias=None):
+    """score_bias [T, Hq, extent] (float): score_mod = relative_bias_score_mod, aux_tensors = [score_bias]
+    (extend_attention.py:463-476 prefix stage: q_pos = P + m, kv_pos = list position; :594-607 extend stage:
+    kv_pos = P + n; q_idx = global query token), added after scale, cap and temperature, before the masks.
+    Semantics of extend_attention_fwd (extend_attention.py:664-812).  Request i
     has prefix tokens kv_indices[kv_indptr[i]:kv_indptr[i+1]] read from the cache
     (stage 1, :372-510; scaled by k_scale / v_scale) and E_i = qo_indptr[i+1]-
     qo_indptr[i] new tokens whose K/V are the contiguous k_extend/v_extend rows
@@ -672,6 +688,8 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
                         xai = math.log2(p_len + m) / math.log2(float(xai_temperature_len))
                     if kp.shape[0]:
                         s1 = _tanh_cap(kp @ qf[q0 + m, h] * (sm_scale * k_scale), logit_cap) * xai
+                        if score_bias is not None:
+                            s1 = s1 + _rel_bias(np.asarray(score_bias[q0 + m, h], dtype=np.float64), p_len + m, np.arange(p_len))
                         if cm is not None and not skip_prefix_custom_mask:
                             s1 = np.where(cm[m, :p_len], s1, -np.inf)
                         if sliding_window_size > 0:
@@ -681,6 +699,8 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
                     if not skip_extend:
                         n_end = (m + 1) if (is_causal and cm is None) else e
                         s2 = _tanh_cap(ke[:n_end] @ qf[q0 + m, h] * sm_scale, logit_cap) * xai
+                        if score_bias is not None:
+                            s2 = s2 + _rel_bias(np.asarray(score_bias[q0 + m, h], dtype=np.float64), p_len + m, p_len + np.arange(n_end))
                         if cm is not None:
                             s2 = np.where(cm[m, p_len : p_len + n_end], s2, -np.inf)
                         if sliding_window_size > 0:
@@ -705,8 +725,9 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
 
 def extend_attention_unified(q, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, prefix_lens, sm_scale=None,
                              k_scale=1.0, v_scale=1.0, logit_cap=0.0, is_causal=True, sliding_window_size=-1,
-                             sinks=None, custom_mask=None, mask_indptr=None, xai_temperature_len=-1):
-    """Semantics of extend_attention_fwd_unified / _fwd_kernel_unified (extend_attention.py:852-1158): one pass
+                             sinks=None, custom_mask=None, mask_indptr=None, xai_temperature_len=-1, score_bias=None):
+    """score_bias [T, Hq, extent]: relative_bias_score_mod through :1093-1104 (q_pos = prefix_i + m, kv_pos = list position).
+    Semantics of extend_attention_fwd_unified / _fwd_kernel_unified (extend_attention.py:852-1158): one pass
     over a kv list holding prefix + new tokens.  Query m of request i sees list position n iff n < prefix_i or
     n - prefix_i <= m (causal, :993-1008), window prefix_i + m <= n + W (:1010-1027); a custom mask row is
     kv_len wide and replaces the causal rule (:980-990); xai factor L / (prefix_i + m + 1) once
@@ -737,6 +758,8 @@ def extend_attention_unified(q, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_ind
                     if xai_temperature_len > 0 and pre + m >= xai_temperature_len:
                         xai = xai_temperature_len / (pre + m + 1.0)
                     s = _tanh_cap(kk @ qf[q0 + m, h] * (sm_scale * k_scale), logit_cap) * xai
+                    if score_bias is not None:
+                        s = s + _rel_bias(np.asarray(score_bias[q0 + m, h], dtype=np.float64), pre + m, pos)
                     keep = np.ones(n_kv, dtype=bool)
                     if cm is not None:
                         keep &= cm[m]

@@ -1021,8 +1021,11 @@ class HipRadixAttnBackend:
         return (k.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0 and k.stride(-1) == 1 and v.stride(-1) == 1
                 and (layer.tp_k_head_num * d) % 8 == 0)
 
-    def forward_decode(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, sinks=None):
-        """triton_backend.py:1714-1864.  PRECONDITION of the fused store (`_fused_store_ok`): the step's slot is
+    def forward_decode(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, sinks=None,
+                       score_mod=None, aux_tensors=None):
+        """triton_backend.py:1714-1864.  ``score_mod`` / ``aux_tensors`` (:1723-1724, :1861-1862): the reference's
+        relative_bias_score_mod runs as the kernels' built-in bias (ops.relative_bias_score_mod); such a call stores the
+        step's rows on their own and takes the plain per-request launch.  PRECONDITION of the fused store (`_fused_store_ok`): the step's slot is
         already in the page table, ``req_to_token[req_pool_indices, seq_lens - 1] == out_cache_loc`` -- what
         alloc_for_decode leaves behind (allocation.py:578-580) -- because the kernel writes the new row to the slot it
         READS for position seq_len - 1; the separate store (every foreign pool, fp8 / scaled / windowed layers) goes
@@ -1034,7 +1037,7 @@ class HipRadixAttnBackend:
             o = torch.empty_like(q)
         # the KV store of the step rides in the decode launch when the kernel can take it (see _fused_store_ok)
         fuse = (save_kv_cache and k is not None and not getattr(self.forward_metadata, "draft", False)
-                and self._fused_store_ok(layer, k, v))  # (draft rows are top-k branches: their slot is not req_to_token[req, len - 1])
+                and score_mod is None and self._fused_store_ok(layer, k, v))  # (draft rows are top-k branches: their slot is not req_to_token[req, len - 1])
         if (fuse and self._debug_checks and forward_batch.out_cache_loc is not None
                 and not torch.cuda.is_current_stream_capturing()):  # (a host sync: not inside a graph capture)
             slot = self.req_to_token[forward_batch.req_pool_indices.long(), forward_batch.seq_lens.long() - 1]
@@ -1051,7 +1054,27 @@ class HipRadixAttnBackend:
         q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
         if self.dcp is not None:
+            if score_mod is not None:
+                raise NotImplementedError("DCP decode does not support score_mod (as the reference, triton_backend.py:1798-1801)")
             self._forward_decode_dcp(q3, o3, layer, forward_batch, sinks)
+            return o
+        if score_mod is not None:
+            k_descale, v_descale = self._scales(layer)
+            k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+            lay = ops.kv_layout_hnd(k_buf, v_buf) if getattr(self.token_to_kv_pool, "use_hnd", False) else None
+            if sinks is not None and sinks.dtype != torch.float32:
+                sinks = sinks.float()
+            splits = md.max_kv_splits if md.attn_logits is not None else 1
+            common = dict(logit_cap=layer.logit_cap, sinks=sinks, page_size=self.page_size, kv_layout=lay,
+                          xai_temperature_len=max(0, int(getattr(layer, "xai_temperature_len", -1) or 0)),
+                          score_mod=score_mod, aux_tensors=aux_tensors)
+            if md.kv_indices is not None:
+                ops.decode_attention_fwd(q3, k_buf, v_buf, o3, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse,
+                                         md.num_kv_splits, splits, layer.scaling, k_descale, v_descale, **common)
+            else:
+                ops.decode_attention_fwd_paged(q3, k_buf, v_buf, o3, self.req_to_token, forward_batch.req_pool_indices,
+                                               forward_batch.seq_lens, md.attn_logits, md.attn_lse, md.num_kv_splits,
+                                               splits, layer.scaling, k_descale, v_descale, **common)
             return o
         if self._cascade_on and not (getattr(layer, "xai_temperature_len", -1) or 0) > 0:
             k_descale, v_descale = self._scales(layer)
@@ -1111,7 +1134,9 @@ class HipRadixAttnBackend:
             ln(q3, o3, torch.cuda.current_stream(q.device).cuda_stream, sinks)
         return o
 
-    def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, sinks=None):
+    def forward_extend(self, q, k, v, layer, forward_batch: ForwardBatch, save_kv_cache=True, sinks=None,
+                       score_mod=None, aux_tensors=None):
+        """triton_backend.py:1250-1437 (score_mod / aux_tensors: :1259-1260, :1348-1349, :1434-1435)."""
         if layer.qk_head_dim != layer.v_head_dim:
             o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim))
         else:
@@ -1120,6 +1145,8 @@ class HipRadixAttnBackend:
             raise ValueError("forward_extend needs the new tokens' k and v")
         causal = not (layer.is_cross_attention or layer.attn_type.value == "encoder_only")
         if self.dcp is not None:
+            if score_mod is not None:
+                raise NotImplementedError("DCP extend does not support score_mod (as the reference, triton_backend.py:1330-1333)")
             # attention first: the new tokens' K/V are read from k / v, the cache holds the prefix only
             self._forward_extend_dcp(q.view(-1, layer.tp_q_head_num, layer.qk_head_dim),
                                      k.view(-1, layer.tp_k_head_num, layer.qk_head_dim),
@@ -1161,7 +1188,7 @@ class HipRadixAttnBackend:
         split = ((self._verify_split_on and forward_batch.forward_mode.is_target_verify())
                  or (self._extend_split_on and forward_batch.forward_mode.is_extend() and causal
                      and not forward_batch.forward_mode.is_target_verify() and md.custom_mask is None))
-        if (split and sinks is None
+        if (split and sinks is None and score_mod is None
                 and (layer.qk_head_dim, layer.v_head_dim) == (self._verify_split.d, self._verify_split.dv)
                 and not (getattr(layer, "xai_temperature_len", -1) or 0) > 0
                 and not (layer.sliding_window_size is not None and layer.sliding_window_size > -1)
@@ -1178,7 +1205,7 @@ class HipRadixAttnBackend:
         # (only when the per-head launch would over-subscribe the chip: packing trades workgroups for work, and a tiny
         # batch needs the parallelism more -- 1 request x 32k + 64 tokens: per head 636 us, packed 993 us)
         n_req = md.qo_indptr.shape[0] - 1
-        packed = (md.max_extend_len is not None and md.max_extend_len <= 64 and sinks is None
+        packed = (md.max_extend_len is not None and md.max_extend_len <= 64 and sinks is None and score_mod is None
                   and layer.tp_q_head_num > layer.tp_k_head_num and layer.qk_head_dim == 128 == layer.v_head_dim
                   and n_req * layer.tp_q_head_num >= 2 * self.device_core_count)
         (ops.extend_attention_fwd_gqa_packed if packed else ops.extend_attention_fwd)(
@@ -1189,7 +1216,8 @@ class HipRadixAttnBackend:
             kv_indptr, kv_indices, md.custom_mask, causal, md.mask_indptr, md.max_extend_len, k_descale,
             v_descale, sm_scale=layer.scaling, logit_cap=layer.logit_cap, sliding_window_size=window,
             sinks=sinks, window_kv_offsets=window_kv_offsets if md.custom_mask is not None else None,
-            xai_temperature_len=layer.xai_temperature_len, page_size=page_size, kv_layout=lay)
+            xai_temperature_len=layer.xai_temperature_len, page_size=page_size, kv_layout=lay,
+            score_mod=score_mod, aux_tensors=aux_tensors)
         return o
 
     def support_triton(self):

@@ -370,4 +370,11 @@ __device__ __forceinline__ float quad_row_max(float x) {
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
+// relative-position score bias (relative_bias_score_mod, kernels/ops/attention/score_mod.py:44-56): element r of a
+// (query token, head) row, fp32 or the call's 16-bit dtype
+template <typename T>
+__device__ __forceinline__ float load_bias(const void* row, int32_t is_f32, int32_t r) {
+  return is_f32 ? static_cast<const float*>(row)[r] : T::to_f32(static_cast<const uint16_t*>(row)[r]);
+}
+
 }  // namespace rx

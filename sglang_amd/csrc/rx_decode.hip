@@ -71,6 +71,10 @@ struct DecodeArgs {
   const int32_t* items_count;
   int32_t items_occ3;  // the three-workgroups-per-CU instance asked for (split_items_wgs_per_cu == 3)
   int32_t items_cap;
+  // relative-position score bias [bs, Hq, bias_len] (radix_hip.h: score_bias; decode_mfma_bias_kernel and the generic kernel), or NULL
+  const void* bias;
+  int32_t bias_f32, bias_len;
+  int64_t bias_stride_t, bias_stride_h;
 };
 
 // Grok temperature factor of a request (decode_attention.py:156-160): the single query sits at seq_len-1
@@ -212,9 +216,14 @@ __device__ __forceinline__ u32x4 kv_frag16(V raw) {
 // (rx_decode_params.split_items_wgs_per_cu) when its schedule cut a MIXED batch into ~3 x CUs near-equal workgroups that
 // are all resident at once, so nothing waits for a second round (one 32 k request among 63 of 1 k: 83 us per layer at
 // two per CU -> 78 at three); a uniform batch of one-pass requests is ~0.5 % faster at two.
-template <typename T, int D, typename IdxT, bool LINEAR, bool KV8, bool FUSE = false, bool OCC3 = false>
-__global__ __launch_bounds__(256, OCC3 ? 3 : RX_DEC_MINW) void decode_mfma_kernel(const DecodeArgs a) {
+//
+// BIAS (decode_mfma_bias_kernel, round 5): the reference's relative_bias_score_mod (score_mod.py:44-56 through
+// decode_attention.py:539-551) -- the score against list position n gets + bias[b, h, (len - 1) - n] inside [0, bias_len).
+// Its own instances: the plain kernels carry none of it.
+template <typename T, int D, typename IdxT, bool LINEAR, bool KV8, bool FUSE, bool OCC3, bool BIAS>
+__device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
   static_assert(!(FUSE && KV8), "the fused store writes 16-bit rows");
+  static_assert(!BIAS || (!FUSE && !KV8 && !OCC3), "the biased instances are the plain 16-bit ones");
   using vec8 = typename T::vec8;
   using KvE = std::conditional_t<KV8, uint8_t, uint16_t>;  // pool element
   using KvV = u32x4;  // 16 B per lane and load: 8 elements of a 16-bit pool, 16 of an fp8 pool
@@ -462,6 +471,24 @@ __global__ __launch_bounds__(256, OCC3 ? 3 : RX_DEC_MINW) void decode_mfma_kerne
     float sv[8];
     const int tok_base = lo + t * kTile + 4 * g;
     float mt = -INFINITY;
+    float bv[8];
+    if constexpr (BIAS) {
+      // the lane's 8 tokens sit rel0, rel0 - 1, ... behind the query (position len - 1); only a request's last
+      // bias_len tokens carry a bias (a wave-uniform skip for every tile before them)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+      const int32_t rel0 = si.seq_len - 1 - tok_base;
+      if (si.seq_len - 1 - (lo + t * kTile + kTile - 1) < a.bias_len && q_valid) {
+        const char* brow = static_cast<const char*>(a.bias) + (b * a.bias_stride_t + h * a.bias_stride_h) * (a.bias_f32 ? 4 : 2);
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int32_t rel = rel0 - 16 * bb - i;
+            if (rel >= 0 && rel < a.bias_len) bv[bb * 4 + i] = load_bias<T>(brow, a.bias_f32, rel) * kLog2e;
+          }
+      }
+    }
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
@@ -472,6 +499,7 @@ __global__ __launch_bounds__(256, OCC3 ? 3 : RX_DEC_MINW) void decode_mfma_kerne
         } else {
           x *= scale_log2;
         }
+        if constexpr (BIAS) x += bv[bb * 4 + i];
         x = (tok_base + 16 * bb + i < hi) ? x : -INFINITY;
         sv[bb * 4 + i] = x;
         mt = fmaxf(mt, x);
@@ -578,6 +606,15 @@ __global__ __launch_bounds__(256, OCC3 ? 3 : RX_DEC_MINW) void decode_mfma_kerne
   }
 }
 
+template <typename T, int D, typename IdxT, bool LINEAR, bool KV8, bool FUSE = false, bool OCC3 = false>
+__global__ __launch_bounds__(256, OCC3 ? 3 : RX_DEC_MINW) void decode_mfma_kernel(const DecodeArgs a) {
+  decode_mfma_body<T, D, IdxT, LINEAR, KV8, FUSE, OCC3, false>(a);
+}
+template <typename T, int D, typename IdxT, bool LINEAR>
+__global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_bias_kernel(const DecodeArgs a) {
+  decode_mfma_body<T, D, IdxT, LINEAR, false, false, false, true>(a);
+}
+
 // ---- generic fallback: any head dims (Dk != Dv, 13, 80, 96, 576/512 ...) --------------------
 // One wave per (request, q head, split); lane = token for QK^T, lane = d for PV.  Correctness
 // path for shapes outside the MFMA kernel; same outputs / scratch layout.
@@ -622,7 +659,13 @@ __global__ __launch_bounds__(64) void decode_generic_kernel(const DecodeArgs a, 
     for (int d = 0; d < dk; ++d) s += qs[d] * T::to_f32(kp[d]);
     s *= a.sm_scale;
     if (a.logit_cap > 0.f) s = a.logit_cap * tanhf(s / a.logit_cap);
-    s = valid ? s * (kLog2e * xai_factor(a.xai_len, si.full_len)) : -INFINITY;
+    s *= xai_factor(a.xai_len, si.full_len);
+    if (a.bias) {  // score_mod.py:44-56 through decode_attention.py:215-227
+      const int32_t rel = si.seq_len - 1 - tok;
+      if (valid && rel < a.bias_len)
+        s += load_bias<T>(static_cast<const char*>(a.bias) + (b * a.bias_stride_t + h * a.bias_stride_h) * (a.bias_f32 ? 4 : 2), a.bias_f32, rel);
+    }
+    s = valid ? s * kLog2e : -INFINITY;
     float mt = s;
 #pragma unroll
     for (int dd = 32; dd > 0; dd >>= 1) mt = fmaxf(mt, __shfl_xor(mt, dd));
@@ -835,7 +878,7 @@ static void launch_merge(const DecodeArgs& a, int dv, hipStream_t s) {
 
 template <typename T, typename IdxT, bool LINEAR>
 static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
-  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128 || ((dk == 256 || dk == 96) && !a.kv_fp8));
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128 || ((dk == 256 || dk == 96) && !a.kv_fp8 && !a.bias));
   if (a.stages == 2) {
     launch_merge<T>(a, dv, s);
     return check_launch("rx_decode_attn");
@@ -852,7 +895,12 @@ static int launch_decode(const DecodeArgs& a, int dk, int dv, hipStream_t s) {
     }
 #define RX_DEC(DD, K8, FU) \
   hipLaunchKernelGGL((decode_mfma_kernel<T, DD, IdxT, LINEAR, K8, FU>), dim3(grid), dim3(256), 0, s, a)
-    if (a.items && a.items_occ3 && dk == 128 && !a.kv_fp8) {  // a mixed batch's schedule: three workgroups per CU
+    if (a.bias) {  // (mfma_ok: D = 64 / 128 on a 16-bit pool without the fused store)
+      note_dispatch("decode_mfma_bias_kernel<%s, %d, %s, %s>|%s,%s", tname<T>(), dk, tname<IdxT>(), tbool(LINEAR),
+                    a.items ? "pairs" : "slots", a.kv_indices ? "indices" : "req_to_token");
+      if (dk == 64) hipLaunchKernelGGL((decode_mfma_bias_kernel<T, 64, IdxT, LINEAR>), dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((decode_mfma_bias_kernel<T, 128, IdxT, LINEAR>), dim3(grid), dim3(256), 0, s, a);
+    } else if (a.items && a.items_occ3 && dk == 128 && !a.kv_fp8) {  // a mixed batch's schedule: three workgroups per CU
       if (a.k_new) hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR, false, true, true>), dim3(grid), dim3(256), 0, s, a);
       else hipLaunchKernelGGL((decode_mfma_kernel<T, 128, IdxT, LINEAR, false, false, true>), dim3(grid), dim3(256), 0, s, a);
     } else if (a.kv_fp8) {
@@ -941,7 +989,13 @@ static int decode_attn_impl(const rx_decode_params* p, void* stream) {
                "rx_decode_attn: max_kv_splits=%d needs attn_logits, attn_lse and num_kv_splits",
                max_splits);
   const int dk = p->head_dim, dv = p->v_head_dim;
-  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128 || ((dk == 256 || dk == 96) && !p->kv.kv_fp8));
+  if (p->score_bias) {
+    RX_REQUIRE(p->score_bias_len > 0, "rx_decode_attn: score_bias_len = %d", p->score_bias_len);
+    RX_REQUIRE(((uintptr_t)p->score_bias & (p->score_bias_is_f32 ? 3 : 1)) == 0, "rx_decode_attn: misaligned score_bias");
+    if (p->kv.kv_fp8 || p->k_new || p->v_new || p->rope_cos_sin || (p->head_dim == 576 && p->v_head_dim == 512))
+      return fail(RX_ERR_UNSUPPORTED, "rx_decode_attn: score_bias needs a 16-bit non-latent pool and no fused store / RoPE");
+  }
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128 || ((dk == 256 || dk == 96) && !p->kv.kv_fp8 && !p->score_bias));
   if (mfma_ok) {
     // 16-byte vector loads: every stride a multiple of 8 elements, bases 16-byte aligned
     const int64_t all = p->q_stride_t | p->q_stride_h | p->kv.k_page_stride | p->kv.k_tok_stride |
@@ -992,6 +1046,11 @@ static int decode_attn_impl(const rx_decode_params* p, void* stream) {
   a.sinks = p->sinks;
   a.kv_fp8 = p->kv.kv_fp8;
   a.xai_len = p->xai_temperature_len;
+  a.bias = p->score_bias;
+  a.bias_f32 = p->score_bias_is_f32;
+  a.bias_len = p->score_bias_len;
+  a.bias_stride_t = p->score_bias_stride_t;
+  a.bias_stride_h = p->score_bias_stride_h;
   RX_REQUIRE(p->stages >= 0 && p->stages <= 2 && (p->stages == 0 || max_splits > 1),
              "rx_decode_attn: stages = %d (1 / 2 need max_kv_splits > 1)", p->stages);
   a.stages = p->stages;

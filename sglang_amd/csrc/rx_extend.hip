@@ -45,6 +45,9 @@ struct ExtendArgs {
   int32_t skip_prefix_mask, xai_len;
   const int32_t* unified_prefix;  // K8 unified form (see radix_hip.h), or null
   const float* sinks;
+  const void* bias;  // relative-position score bias [T, Hq, bias_len] (generic kernel; the D = 128 kernel has its own copy), or null
+  int32_t bias_f32, bias_len;
+  int64_t bias_stride_t, bias_stride_h;
 };
 
 #ifndef RX_EXT_CB
@@ -508,6 +511,11 @@ __global__ __launch_bounds__(64) void extend_generic_kernel(const ExtendArgs a, 
     if (a.logit_cap > 0.f) s = a.logit_cap * tanhf(s / a.logit_cap);
     s *= xai;
     bool keep = inb;
+    if (a.bias) {  // score_mod.py:44-56: + bias[q token, head, q_pos - kv_pos] inside [0, bias_len)
+      const int32_t rel = prefix ? q_off + m - nn : m - (nn - p_len);
+      if (inb && rel >= 0 && rel < a.bias_len)
+        s += load_bias<T>(static_cast<const char*>(a.bias) + (tq * a.bias_stride_t + h * a.bias_stride_h) * (a.bias_f32 ? 4 : 2), a.bias_f32, rel);
+    }
     if (prefix && causal_in_list) keep = keep && (nn <= q_off + m);
     if (a.window > 0) {
       if (prefix) keep = keep && (q_off + m <= nn + a.window);
@@ -558,7 +566,7 @@ template <typename T, typename IdxT, bool LINEAR>
 static int launch_extend(const ExtendArgs& a, int dk, int dv, int64_t total_q, hipStream_t s) {
   // tree masks and the xai temperature live in the D = 128 kernel (rx_extend32.hip) and in the generic
   // kernel; the 16x16x32 kernel below does not carry them
-  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128) && !a.custom_mask && a.xai_len <= 0 && !a.unified_prefix;
+  const bool mfma_ok = (dk == dv) && (dk == 64 || dk == 128) && !a.custom_mask && a.xai_len <= 0 && !a.unified_prefix && !a.bias;
   if (mfma_ok) {
     const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
     const bool vs = a.v_scale != 1.0f;
@@ -653,7 +661,12 @@ static int extend_attn_impl(const rx_extend_params* p, void* stream) {
   if (p->kv.kv_fp8 && !p->skip_prefix && !(mfma_ok && dk == 128))
     return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: an fp8 prefix pool needs head_dim 128, got %d/%d", dk, dv);
   if (p->custom_mask) RX_REQUIRE(p->mask_indptr, "rx_extend_attn: custom_mask given without mask_indptr");
-  const bool extras = p->custom_mask || p->xai_temperature_len > 0 || p->unified_prefix_lens;
+  const bool extras = p->custom_mask || p->xai_temperature_len > 0 || p->unified_prefix_lens || p->score_bias;
+  if (p->score_bias) {
+    RX_REQUIRE(p->score_bias_len > 0, "rx_extend_attn: score_bias_len = %d", p->score_bias_len);
+    RX_REQUIRE(((uintptr_t)p->score_bias & (p->score_bias_is_f32 ? 3 : 1)) == 0, "rx_extend_attn: misaligned score_bias");
+    if (p->q_pack > 1) return fail(RX_ERR_UNSUPPORTED, "rx_extend_attn: score_bias does not combine with q_pack");
+  }
   // the D = 128 kernel stores whole 16-byte row chunks of o
   const bool o16 = ((p->o_stride_t | p->o_stride_h) % 8 == 0) && ((uintptr_t)p->o & 15) == 0;
   if (mfma_ok && dk == 128 && !o16 && (p->kv.kv_fp8 || extras))
@@ -668,7 +681,7 @@ static int extend_attn_impl(const rx_extend_params* p, void* stream) {
   // 16x16x32 AGPR / LDS-DMA template; D = 128 on the 32x32x16 kernel; the other MFMA head dims; the latent MLA shape;
   // everything else on the generic kernel below.
   const Options& opt = options();
-  if (((dk == 128 && dv == 128 && opt.extend_d256_at128) || (dk == 64 && dv == 64)) && opt.extend_d256 &&
+  if (((dk == 128 && dv == 128 && opt.extend_d256_at128) || (dk == 64 && dv == 64)) && opt.extend_d256 && !p->score_bias &&
       extend_d256_supports(p)) {
     const int rc = launch_extend_d256(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
@@ -677,7 +690,7 @@ static int extend_attn_impl(const rx_extend_params* p, void* stream) {
     const int rc = launch_extend32(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }
-  if (opt.extend_d256 && extend_d256_supports(p)) {
+  if (opt.extend_d256 && !p->score_bias && extend_d256_supports(p)) {
     const int rc = launch_extend_d256(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }
@@ -694,7 +707,7 @@ static int extend_attn_impl(const rx_extend_params* p, void* stream) {
       return rc != RX_OK ? rc : check_launch("rx_extend_attn");
     }
   }
-  if (opt.extend_mla && extend_mla_supports(p)) {
+  if (opt.extend_mla && !p->score_bias && extend_mla_supports(p)) {
     const int rc = launch_extend_mla(p, static_cast<hipStream_t>(stream));
     return rc != RX_OK ? rc : check_launch("rx_extend_attn");
   }
@@ -748,6 +761,11 @@ static int extend_attn_impl(const rx_extend_params* p, void* stream) {
   a.xai_len = p->xai_temperature_len;
   a.unified_prefix = p->unified_prefix_lens;
   a.sinks = p->sinks;
+  a.bias = p->score_bias;
+  a.bias_f32 = p->score_bias_is_f32;
+  a.bias_len = p->score_bias_len;
+  a.bias_stride_t = p->score_bias_stride_t;
+  a.bias_stride_h = p->score_bias_stride_h;
   const bool linear = p->kv.page_size == 1 ||
                       (p->kv.k_page_stride == p->kv.page_size * p->kv.k_tok_stride &&
                        p->kv.v_page_stride == p->kv.page_size * p->kv.v_tok_stride);

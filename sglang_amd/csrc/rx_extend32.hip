@@ -51,7 +51,7 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const bool same_kv = p->kv.k_page_stride == p->kv.v_page_stride && p->kv.k_tok_stride == p->kv.v_tok_stride &&
                        p->k_stride_t == p->v_stride_t;
   const bool plain_any = !a.kv_fp8 && !vsc && !a.unified_prefix && !a.custom_mask && a.window <= 0 &&
-                         a.xai_len <= 0 && !(a.logit_cap > 0.f) && same_kv && opt.ext32_plain;
+                         a.xai_len <= 0 && !(a.logit_cap > 0.f) && !a.bias && same_kv && opt.ext32_plain;
   // tiles a workgroup walks, estimated from the host-side hints: (mean prefix + half the longest extend) / 64
   const int est_tiles = (p->avg_kv_len_hint + p->max_extend_len / 2) / kTok;
   // Causal extends of a GQA-4 / GQA-8 model pack by themselves (bit-identical results): a 256-row block is then 64 or 32

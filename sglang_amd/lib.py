@@ -16,7 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
-RX_ABI_VERSION = 13  # include/radix_hip.h
+RX_ABI_VERSION = 14  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -62,6 +62,8 @@ class RxDecodeParams(C.Structure):
         ("rope_cos_sin", c_void_p), ("rope_cos_sin_is_f32", c_int32), ("rope_cos_sin_stride", c_int64),
         ("rope_positions", c_void_p), ("rope_positions_is_i64", c_int32), ("rope_dim", c_int32),
         ("rope_is_neox", c_int32), ("rope_k_pe_out", c_void_p), ("rope_k_pe_out_stride", c_int64),
+        ("score_bias", c_void_p), ("score_bias_is_f32", c_int32), ("score_bias_len", c_int32),
+        ("score_bias_stride_t", c_int64), ("score_bias_stride_h", c_int64),
     ]
 
 
@@ -83,6 +85,8 @@ class RxExtendParams(C.Structure):
         ("custom_mask", c_void_p), ("mask_indptr", c_void_p), ("skip_prefix_custom_mask", c_int32),
         ("window_kv_offsets", c_void_p), ("xai_temperature_len", c_int32),
         ("unified_prefix_lens", c_void_p), ("avg_kv_len_hint", c_int32), ("q_pack", c_int32),
+        ("score_bias", c_void_p), ("score_bias_is_f32", c_int32), ("score_bias_len", c_int32),
+        ("score_bias_stride_t", c_int64), ("score_bias_stride_h", c_int64),
     ]
 
 

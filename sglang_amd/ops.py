@@ -367,6 +367,48 @@ def kv_layout_hnd(k_buffer: torch.Tensor, v_buffer: torch.Tensor) -> _L.RxKvLayo
 
 
 # --------------------------------------------------------------------------------------
+# score_mod / aux_tensors       kernels/ops/attention/score_mod.py:30-56
+# --------------------------------------------------------------------------------------
+def relative_bias_score_mod(*_args, **_kwargs):
+    """Marker with the name of the reference's one Triton score_mod (score_mod.py:44-56: qk + Aux0[q_idx, head,
+    q_pos - kv_pos] inside [0, aux0_len)).  Pass it -- or the reference's own ``relative_bias_score_mod`` object -- as
+    ``score_mod`` with ``aux_tensors = [rel_logits]``; the kernels implement it natively (rx_*_params.score_bias).  Any
+    other callable cannot cross a C ABI and raises NotImplementedError."""
+    raise RuntimeError("relative_bias_score_mod is a marker for the HIP kernels' built-in bias; it is never called")
+
+
+def _is_relative_bias(score_mod) -> bool:
+    if score_mod is relative_bias_score_mod:
+        return True
+    for obj in (score_mod, getattr(score_mod, "fn", None)):  # (a triton JITFunction keeps the python function in .fn)
+        if getattr(obj, "__name__", None) == "relative_bias_score_mod":
+            return True
+    return False
+
+
+def _set_score_bias(p, score_mod, aux_tensors, q: torch.Tensor) -> None:
+    """unpack_aux_tensors (score_mod.py:30-41), into rx_{decode,extend}_params.score_bias*."""
+    if score_mod is None:
+        return  # (the reference ignores aux_tensors without a score_mod)
+    if not _is_relative_bias(score_mod):
+        raise NotImplementedError("score_mod: the HIP path implements relative_bias_score_mod only (a Triton callable "
+                                  "cannot be inlined behind a C ABI)")
+    assert aux_tensors is not None and len(aux_tensors) == 1, "Triton score_mod currently requires exactly one aux tensor"
+    aux0 = aux_tensors[0]
+    assert aux0.dim() == 3 and aux0.stride(2) == 1, (
+        f"aux_tensors[0] must be 3D with a contiguous last dim, got shape={tuple(aux0.shape)} stride={aux0.stride()}")
+    _require_cuda(aux0)
+    if aux0.dtype not in (torch.float32, q.dtype):
+        raise TypeError(f"aux_tensors[0] must be float32 or {q.dtype}, got {aux0.dtype}")
+    if aux0.shape[0] < q.shape[0] or aux0.shape[1] != q.shape[1]:
+        raise ValueError(f"aux_tensors[0] {tuple(aux0.shape)} does not cover q {tuple(q.shape)}")
+    p.score_bias = aux0.data_ptr()
+    p.score_bias_is_f32 = int(aux0.dtype == torch.float32)
+    p.score_bias_len = int(aux0.shape[2])
+    p.score_bias_stride_t, p.score_bias_stride_h = aux0.stride(0), aux0.stride(1)
+
+
+# --------------------------------------------------------------------------------------
 # K4-K6  decode_attention_fwd   kernels/ops/attention/decode_attention.py:968-1044
 # --------------------------------------------------------------------------------------
 def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse,
@@ -377,9 +419,8 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     """Same contract as the reference.  q [bs,Hq,Dk], o [bs,Hq,Dv], kv_indptr int32[bs+1],
     kv_indices int32/int64, attn_logits fp32[bs,Hq,max_kv_splits,Dv], attn_lse fp32[bs,Hq,S].
     ``max_kv_splits == 1`` (or num_kv_splits None) runs the single-pass kernel.  ``stages`` as in
-    rx_decode_params (1 = the kv-split partials only)."""
-    if score_mod is not None or aux_tensors is not None:
-        raise NotImplementedError("score_mod / aux_tensors: outside the HIP path")
+    rx_decode_params (1 = the kv-split partials only).  ``score_mod`` = relative_bias_score_mod with
+    ``aux_tensors = [rel_logits [bs, Hq, extent]]`` (decode_attention.py:215-227,539-551)."""
     # has_mla only selects a Triton block shape in the reference; here the MLA kernel is chosen from the
     # tensor shapes (Dk 576 / Dv 512, one kv head, V aliasing K)
     _require_cuda(q, k_buffer, v_buffer, o, kv_indptr, kv_indices)
@@ -397,6 +438,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     p.kv_indices = kv_indices.data_ptr()
     p.kv_indices_is_i64 = _is64(kv_indices, "kv_indices")
     p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
+    _set_score_bias(p, score_mod, aux_tensors, q)
     p.stages = int(stages)
     p.merge_counters = _merge_counters_ptr(merge_counters, q.shape[0], q.shape[1])
     _set_new_kv(p, k_new, v_new, q.shape[0])
@@ -574,7 +616,8 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
                                k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
                                page_size: int = 1, kv_layout=None, xai_temperature_len=-1,
                                kv_start=None, extra_o=None, extra_lse=None, stages: int = 0, merge_counters=None,
-                               k_new=None, v_new=None, request_order=None, split_items=None):
+                               k_new=None, v_new=None, request_order=None, split_items=None,
+                               score_mod=None, aux_tensors=None):
     p = _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse,
                              num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap, sinks, page_size,
                              kv_layout, xai_temperature_len, kv_start, extra_o, extra_lse, stages)
@@ -582,6 +625,7 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
     _set_new_kv(p, k_new, v_new, q.shape[0])
     p.request_order = _request_order_ptr(request_order, q.shape[0])
     _set_split_items(p, split_items if p.max_kv_splits > 1 else None)
+    _set_score_bias(p, score_mod, aux_tensors, q)
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -1166,8 +1210,6 @@ def _extend_params(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, q
                          skip_prefix=False, skip_extend=False, page_size: int = 1,
                          score_mod=None, aux_tensors=None, kv_layout=None, unified_prefix_lens=None,
                          _num_kv_heads=None, avg_kv_len_hint=None, q_pack: int = 1):
-    if score_mod is not None or aux_tensors is not None:
-        raise NotImplementedError("score_mod / aux_tensors: outside the HIP path")
     _require_cuda(q_extend, k_extend, v_extend, o_extend, qo_indptr, kv_indptr, custom_mask, mask_indptr,
                   window_kv_offsets, unified_prefix_lens)
     unified = unified_prefix_lens is not None
@@ -1250,6 +1292,7 @@ def _extend_params(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, q
     p.xai_temperature_len = int(xai_temperature_len) if xai_temperature_len and xai_temperature_len > 0 else 0
     p._keep_mask = keep
     p.q_pack = int(q_pack)
+    _set_score_bias(p, score_mod, aux_tensors, q_extend)  # extend_attention.py:463-476,594-607,1093-1104
     return p
 
 

@@ -25,6 +25,8 @@ Fixture families:
   F9 extend with custom (tree) masks, sliding window (+ window_kv_offsets), xai temperature -> extend_mask.npz
   F16 ROCm MLA decode with fused RoPE (stage-1 kernel of rocm_mla_decode_rope.py, LSE-merged) -> mla_rope.npz
   F17 QK-norm + RoPE (RMSNorm.forward_native + apply_rotary_emb, the pair the reference tests its fused kernel against) -> qknorm_rope.npz
+  F19 relative-position score bias (score_mod = relative_bias_score_mod, aux_tensors = [rel_logits]) through the extend,
+      unified-extend and decode kernels -> score_bias.npz
   F18 EAGLE multi-step draft decode: per-step kv_indices / kv_indptr of the top-k branches (generate_draft_decode_kv_indices) -> draft_kv_indices.npz
 """
 import json
@@ -1179,8 +1181,102 @@ def f18():
     save("draft_kv_indices.npz", **flat)
 
 
+def f19():
+    """F19 score_mod = relative_bias_score_mod with aux_tensors = [rel_logits] (kernels/ops/attention/score_mod.py:44-56)
+    through the reference's Triton kernels under TRITON_INTERPRET=1 (fp16): extend_attention_fwd (both stages, with a
+    prefix longer and shorter than the bias extent, a sliding window, a logit cap), extend_attention_fwd_unified, and
+    decode_attention_fwd (grouped and MHA stage-1 kernels, split KV) -> score_bias.npz.  The aux tensor is fp32 in half
+    of the cases and fp16 in the others (the kernels add it to the fp32 logits either way)."""
+    from sglang.kernels.ops.attention.extend_attention import extend_attention_fwd_unified
+    from sglang.kernels.ops.attention.score_mod import relative_bias_score_mod
+
+    torch.manual_seed(19)
+    dtype = torch.float16
+    rng = np.random.default_rng(190)
+    flat = {}
+
+    def put(name, c):
+        for k, v in c.items():
+            flat[f"{name}.{k}"] = bits(v) if isinstance(v, torch.Tensor) and v.dtype == torch.float16 else (
+                v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+
+    # ---- two-stage extend: name, Hq, Hkv, D, prefix, extend, extent, aux dtype, window, logit cap
+    for name, HQ, HKV, D, pre, ext, extent, adt, window, cap in [
+            ("ext_gqa", 8, 2, 128, [40, 0, 7], [6, 20, 9], 16, torch.float32, -1, 0.0),
+            ("ext_long", 4, 1, 128, [150, 3], [70, 33], 48, torch.float16, -1, 0.0),
+            ("ext_mha64", 4, 4, 64, [33, 5], [5, 9], 64, torch.float32, -1, 0.0),
+            ("ext_swa_cap", 8, 2, 128, [70, 10], [12, 40], 20, torch.float16, 24, 30.0)]:
+        pre = np.array(pre, dtype=np.int32); ext = np.array(ext, dtype=np.int32)
+        B, T = len(pre), int(ext.sum())
+        pool = int(pre.sum()) + 9
+        kb = torch.randn(pool, HKV, D).to(dtype)
+        vb = torch.randn(pool, HKV, D).to(dtype)
+        q = torch.randn(T, HQ, D).to(dtype)
+        k_ext = torch.randn(T, HKV, D).to(dtype)
+        v_ext = torch.randn(T, HKV, D).to(dtype)
+        aux = (2.0 * torch.randn(T, HQ, extent)).to(adt)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.from_numpy(np.cumsum(pre))
+        qo_indptr = torch.zeros(B + 1, dtype=torch.int64)
+        qo_indptr[1:] = torch.from_numpy(np.cumsum(ext))
+        kv_indices = torch.from_numpy(rng.permutation(pool - 1)[: int(pre.sum())] + 1).to(torch.int64)
+        o = torch.zeros(T, HQ, D, dtype=dtype)
+        extend_attention_fwd(q, k_ext, v_ext, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True, None,
+                             int(ext.max()), 1.0, 1.0, sm_scale=1.0 / D**0.5, logit_cap=cap, sliding_window_size=window,
+                             score_mod=relative_bias_score_mod, aux_tensors=[aux])
+        put(name, dict(q=q, k_ext=k_ext, v_ext=v_ext, kb=kb, vb=vb, qo_indptr=qo_indptr, kv_indptr=kv_indptr,
+                       kv_indices=kv_indices, sm_scale=1.0 / D**0.5, window=window, cap=cap, aux=aux,
+                       aux_f32=int(adt == torch.float32), o=o))
+    # ---- unified one-stage extend
+    for name, HQ, HKV, D, pre, ext, extent, adt in [("uni_gqa", 8, 2, 128, [40, 0, 7], [6, 20, 9], 24, torch.float16),
+                                                    ("uni_mha64", 4, 4, 64, [33, 5], [5, 9], 8, torch.float32)]:
+        pre = np.array(pre, dtype=np.int32); ext = np.array(ext, dtype=np.int32)
+        B, T = len(pre), int(ext.sum())
+        tot = pre + ext
+        pool = int(tot.sum()) + 9
+        kb = torch.randn(pool, HKV, D).to(dtype)
+        vb = torch.randn(pool, HKV, D).to(dtype)
+        q = torch.randn(T, HQ, D).to(dtype)
+        aux = (2.0 * torch.randn(T, HQ, extent)).to(adt)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.from_numpy(np.cumsum(tot))
+        qo_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        qo_indptr[1:] = torch.from_numpy(np.cumsum(ext))
+        kv_indices = torch.from_numpy(rng.permutation(pool - 1)[: int(tot.sum())] + 1).to(torch.int64)
+        o = torch.zeros(T, HQ, D, dtype=dtype)
+        extend_attention_fwd_unified(q, o, kb, vb, 1.0, 1.0, qo_indptr, kv_indptr, kv_indices, torch.from_numpy(pre),
+                                     int(ext.max()), sm_scale=1.0 / D**0.5, is_causal=True,
+                                     score_mod=relative_bias_score_mod, aux_tensors=[aux])
+        put(name, dict(q=q, kb=kb, vb=vb, qo_indptr=qo_indptr, kv_indptr=kv_indptr, kv_indices=kv_indices,
+                       prefix_lens=torch.from_numpy(pre), sm_scale=1.0 / D**0.5, aux=aux, aux_f32=int(adt == torch.float32), o=o))
+    # ---- decode (grouped and MHA stage 1), two kv splits
+    for name, HQ, HKV, D, lens, extent, adt in [("dec_gqa", 8, 2, 128, [5, 40, 200, 17], 32, torch.float32),
+                                                ("dec_mha64", 4, 4, 64, [100, 3], 8, torch.float16),
+                                                ("dec_wide", 8, 1, 128, [70, 9], 128, torch.float16)]:
+        lens = np.array(lens, dtype=np.int32)
+        B = len(lens)
+        pool = int(lens.sum()) + 5
+        kb = torch.randn(pool, HKV, D).to(dtype)
+        vb = torch.randn(pool, HKV, D).to(dtype)
+        q = torch.randn(B, HQ, D).to(dtype)
+        aux = (2.0 * torch.randn(B, HQ, extent)).to(adt)
+        kv_indptr = torch.zeros(B + 1, dtype=torch.int32)
+        kv_indptr[1:] = torch.from_numpy(np.cumsum(lens))
+        kv_indices = torch.from_numpy(rng.permutation(pool - 1)[: int(lens.sum())] + 1).to(torch.int64)
+        S = 4
+        nsplit = torch.full((B,), 2, dtype=torch.int32)
+        o = torch.zeros(B, HQ, D, dtype=dtype)
+        al = torch.zeros(B, HQ, S, D, dtype=torch.float32)
+        lse = torch.zeros(B, HQ, S, dtype=torch.float32)
+        decode_attention_fwd(q, kb, vb, o, kv_indptr, kv_indices, al, lse, nsplit, S, 1.0 / D**0.5, 1.0, 1.0,
+                             score_mod=relative_bias_score_mod, aux_tensors=[aux])
+        put(name, dict(q=q, kb=kb, vb=vb, kv_indptr=kv_indptr, kv_indices=kv_indices, nsplit=nsplit, max_splits=S,
+                       sm_scale=1.0 / D**0.5, aux=aux, aux_f32=int(adt == torch.float32), o=o))
+    save("score_bias.npz", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14",
-                             "f15", "f16", "f17", "f18"]
+                             "f15", "f16", "f17", "f18", "f19"]
     for w in which:
         globals()[w]()

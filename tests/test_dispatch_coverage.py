@@ -23,7 +23,7 @@ from oracle import radix_oracle as orc
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILIES = ("extend_mfma32_kernel", "extend_mfma64_kernel", "extend_mfma_kernel", "extend_generic_kernel", "extend_d256_kernel", "extend_nd_kernel",
-            "extend_mla_kernel", "decode_mfma_kernel", "decode_generic_kernel", "decode_mla_kernel", "decode_mla8_dma_kernel", "decode_mla8_t64_kernel")
+            "extend_mla_kernel", "decode_mfma_kernel", "decode_mfma_bias_kernel", "decode_generic_kernel", "decode_mla_kernel", "decode_mla8_dma_kernel", "decode_mla8_t64_kernel")
 TN = {"bf16": "rx::BF16", "f16": "rx::F16"}
 TB = {True: "true", False: "false"}
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}
@@ -136,6 +136,11 @@ def _cases():
             out.append(dict(fam="decode", dt=dt, idx=idx, lin=lin, dk=d, dv=d, hq=hq, hkv=hkv, fp8=kv8, fuse=fuse, occ3=occ3,
                             mode=("indices" if idx == "long" else ("r2t", "indices")[next(n) % 2]),
                             expect=f"decode_mfma_kernel<{TN[dt]}, {d}, {idx}, {TB[lin]}, {TB[kv8]}, {TB[fuse]}, {TB[occ3]}>"))
+        for d in (64, 128):  # the relative-position score bias (round 5): <T, D, IdxT, LINEAR>
+            hq, hkv = heads()
+            out.append(dict(fam="decode", dt=dt, idx=idx, lin=lin, dk=d, dv=d, hq=hq, hkv=hkv, bias=True,
+                            mode=("indices" if idx == "long" else ("r2t", "indices")[next(n) % 2]),
+                            expect=f"decode_mfma_bias_kernel<{TN[dt]}, {d}, {idx}, {TB[lin]}>"))
         hq, hkv = heads()
         out.append(dict(fam="decode", dt=dt, idx=idx, lin=lin, dk=80, dv=80, hq=hq, hkv=hkv, mode="indices",
                         expect=f"decode_generic_kernel<{TN[dt]}, {idx}, {TB[lin]}>"))
@@ -332,8 +337,10 @@ def _run_decode(c, ops, rxlib):
     else:
         kbo, vbo = _bits(kb), _bits(vb.contiguous())
     ks, vs = (0.8, 1.25) if (fp8 and not c.get("mla")) else (1.0, 1.0)
-    want = orc.decode_attention(_bits(q), kbo, vbo, ip, ii, sm, k_scale=ks, v_scale=vs)
-    absw = orc.decode_attention(_bits(q), kbo, np.abs(vbo) if fp8 else parity.abs_values(vbo), ip, ii, sm, k_scale=ks, v_scale=vs)
+    aux = (1.5 * torch.randn(bs, hq, 70, generator=g)).to(dtype if len(c["expect"]) % 2 else torch.float32) if c.get("bias") else None
+    okw = dict(k_scale=ks, v_scale=vs, score_bias=None if aux is None else aux.double().numpy())
+    want = orc.decode_attention(_bits(q), kbo, vbo, ip, ii, sm, **okw)
+    absw = orc.decode_attention(_bits(q), kbo, np.abs(vbo) if fp8 else parity.abs_values(vbo), ip, ii, sm, **okw)
     if c.get("mla"):
         if c["lin"]:
             kd = kb_dev.to(DEV)
@@ -355,7 +362,7 @@ def _run_decode(c, ops, rxlib):
     al = torch.zeros(bs, hq, S, dv, dtype=torch.float32, device=DEV)
     ls = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
     o = torch.full((bs, hq, dv), float("nan"), dtype=dtype, device=DEV)
-    mfma = c["expect"].startswith("decode_mfma_kernel")
+    mfma = c["expect"].startswith("decode_mfma_kernel") or c["expect"].startswith("decode_mfma_bias_kernel")
     order = torch.argsort(lens_d, descending=True).to(torch.int32) if mfma else None
     items = None
     if mfma and (c.get("occ3") or len(c["expect"]) % 3 == 0):
@@ -363,6 +370,8 @@ def _run_decode(c, ops, rxlib):
     extra = dict(request_order=order, split_items=items)
     if c.get("fuse"):
         extra.update(k_new=kn.to(DEV), v_new=vn.to(DEV))
+    if aux is not None:
+        extra.update(score_mod=ops.relative_bias_score_mod, aux_tensors=[aux.to(DEV)])
     opts = [rxlib.option(k, v) for k, v in c.get("opts", {}).items()]
     for cm in opts:
         cm.__enter__()

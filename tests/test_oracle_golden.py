@@ -327,6 +327,35 @@ def test_extend_unified_golden(golden_dir):
         assert np.abs(got[ok] - want[ok]).max() <= 2e-3, (name, np.abs(got[ok] - want[ok]).max())
 
 
+def test_score_bias_golden(golden_dir):
+    """F19: score_mod = relative_bias_score_mod with aux_tensors = [rel_logits] (score_mod.py:44-56) through the reference's
+    extend (both stages; sliding window + logit cap), unified-extend and decode Triton kernels (fp16, interpreter)."""
+    cases = _npz_cases(os.path.join(golden_dir, "score_bias.npz"))
+    assert set(cases) == {"ext_gqa", "ext_long", "ext_mha64", "ext_swa_cap", "uni_gqa", "uni_mha64", "dec_gqa", "dec_mha64", "dec_wide"}
+    for name, c in cases.items():
+        aux = c["aux"].astype(np.float64)
+        assert (c["aux"].dtype == np.float32) == bool(c["aux_f32"])
+        if name.startswith("ext_"):
+            args = (c["q"], c["k_ext"], c["v_ext"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"])
+            kw = dict(is_causal=True, sm_scale=float(c["sm_scale"]), sliding_window_size=int(c["window"]), logit_cap=float(c["cap"]))
+            fn = orc.extend_attention
+        elif name.startswith("uni_"):
+            args = (c["q"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"], c["prefix_lens"])
+            kw = dict(sm_scale=float(c["sm_scale"]))
+            fn = orc.extend_attention_unified
+        else:
+            args = (c["q"], c["kb"], c["vb"], c["kv_indptr"], c["kv_indices"], float(c["sm_scale"]))
+            kw = {}
+            fn = orc.decode_attention
+        got = fn(*args, score_bias=aux, **kw)
+        want = c["o"].astype(np.float64)
+        ok = np.isfinite(want).all(axis=-1)
+        assert ok.mean() > 0.8, name
+        assert np.abs(got[ok] - want[ok]).max() <= 2e-3, (name, np.abs(got[ok] - want[ok]).max())
+        off = fn(*args, **kw)
+        assert np.abs(off[ok] - want[ok]).max() > 1e-2, (name, "the case must exercise the bias")
+
+
 def test_cpu_baseline_container_fixture(golden_dir):
     """SURVEY 8(d) CPU-baseline item (1): the reference's compiled CPU kernel and the C restatement timed in
     the build container on identical inputs (oracle/time_cpu_container.py) -- fixture present and consistent."""
