@@ -105,6 +105,21 @@ int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,
                         int lens_is_i64, const int32_t* kv_start, int32_t* kv_indptr_out,
                         void* kv_indices_out, int out_is_i64, int bs, void* stream);
 
+/* ---- K8 metadata: the unified kv list of the one-stage extend (round 5, deterministic inference) ----
+ * build_unified_kv_indices (kernels/ops/attention/extend_attention.py:193-238, copy kernel :135-190), called from
+ * TritonAttnBackend._forward_extend_unified (srt/layers/attention/triton_backend.py:1572-1712).
+ *   prefix_lens[i]          = prefix_kv_indptr[i+1] - prefix_kv_indptr[i]                       (int32, may be NULL)
+ *   unified_kv_indptr[0]    = 0;  [i+1] = [i] + prefix_lens[i] + extend_seq_lens[i]            (int32[bs+1])
+ *   unified_kv_indices[unified_kv_indptr[i] + j] = j < prefix_lens[i]
+ *        ? prefix_kv_indices[prefix_kv_indptr[i] + j] : extend_kv_indices[extend_start_loc[i] + j - prefix_lens[i]]   (int64)
+ * prefix_kv_indices may be NULL when every prefix is empty.  max_tokens_per_request (> 0: an upper estimate of
+ * prefix + extend of one request, 0 = unknown) only sizes the grid. */
+int rx_build_unified_kv_indices(const int32_t* prefix_kv_indptr, const void* prefix_kv_indices, int prefix_is_i64,
+                                const void* extend_start_loc, int start_is_i64, const void* extend_seq_lens,
+                                int lens_is_i64, const void* extend_kv_indices, int extend_is_i64, int bs,
+                                int64_t max_tokens_per_request, int32_t* unified_kv_indptr, int64_t* unified_kv_indices,
+                                int32_t* prefix_lens, void* stream);
+
 /* ---- EAGLE multi-step draft decode: the per-step page tables of the top-k branches (round 5) ----------------------
  * generate_draft_decode_kv_indices (kernels/ops/speculative/cache_locs.py:56-141), launched by
  * TritonMultiStepDraftBackend.common_template (srt/layers/attention/triton_backend.py:1929-1945).  For step i (iters = i + 1),

@@ -389,6 +389,23 @@ def build_kv_indices(req_to_token, req_pool_indices, lens, kv_start=None,
     return kv_indptr, kv_indices
 
 
+def build_unified_kv_indices(prefix_kv_indptr, prefix_kv_indices, extend_start_loc, extend_seq_lens, extend_kv_indices, bs):
+    """build_unified_kv_indices (kernels/ops/attention/extend_attention.py:193-238; _copy_unified_indices_kernel
+    :135-190): per request the prefix slots, then the new tokens' slots.  Returns (unified_kv_indptr int32[bs + 1],
+    unified_kv_indices int64[indptr[bs]], prefix_lens int32[bs]) -- the reference's buffer is len(prefix) + len(extend)
+    long and undefined past indptr[bs]."""
+    pre = np.asarray(prefix_kv_indptr, dtype=np.int64)
+    prefix_lens = (pre[1: bs + 1] - pre[:bs]).astype(np.int32)
+    ext = np.asarray(extend_seq_lens, dtype=np.int64)[:bs]
+    indptr = np.concatenate([[0], np.cumsum(prefix_lens.astype(np.int64) + ext)]).astype(np.int32)
+    out = np.zeros(int(indptr[-1]), dtype=np.int64)
+    for i in range(bs):
+        u0, pl, e0 = int(indptr[i]), int(prefix_lens[i]), int(extend_start_loc[i])
+        out[u0: u0 + pl] = np.asarray(prefix_kv_indices[int(pre[i]): int(pre[i]) + pl], dtype=np.int64)
+        out[u0 + pl: u0 + pl + int(ext[i])] = np.asarray(extend_kv_indices[e0: e0 + int(ext[i])], dtype=np.int64)
+    return indptr, out, prefix_lens
+
+
 def draft_decode_kv_indices(req_to_token, req_pool_indices, seq_lens, positions, topk, num_steps, page_size,
                             kv_indices_width, kv_indptr_width, fill=-1):
     """generate_draft_decode_kv_indices (kernels/ops/speculative/cache_locs.py:56-141), the per-step page tables of EAGLE's

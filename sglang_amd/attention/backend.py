@@ -194,6 +194,20 @@ class HipRadixAttnBackend:
         # --triton-attention-num-kv-splits as the cap
         if split_policy not in ("native", "reference"):
             raise ValueError(f"split_policy must be 'native' or 'reference', got {split_policy}")
+        # --enable-deterministic-inference (triton_backend.py:247-264, :325-333, :1339-1350): results that depend on the
+        # REQUEST only, not on the batch it rides in nor on where the radix cache cut its prompt.  Decode: a request is
+        # cut into ceil(len / tile) splits of a fixed tile (SGLANG_TRITON_DECODE_SPLIT_TILE_SIZE, 256) whatever else the
+        # batch holds -- no chip-filling schedule, no shared-prefix cascade.  Extend: the ONE-stage kernel over the unified
+        # kv list (prefix slots + the new tokens' slots, rx_build_unified_kv_indices), whose tiles are cut from the list's
+        # start and all run one tile body (rx_extend32_kernel.inc), so a query row's arithmetic does not move with the
+        # prefix / extend split.
+        self.enable_deterministic = bool(getattr(sa, "enable_deterministic_inference", False))
+        self.split_tile_size = getattr(sa, "triton_attention_split_tile_size", None)
+        if self.enable_deterministic:
+            self.split_tile_size = int(os.environ.get("SGLANG_TRITON_DECODE_SPLIT_TILE_SIZE", "256"))
+            split_policy, cascade_decode = "reference", False
+        if self.split_tile_size is not None:
+            self.max_kv_splits = (self.max_context_len + self.split_tile_size - 1) // self.split_tile_size
         self.split_policy = split_policy
         self.native_split_cap = 32
         # graph replay: upper bound of the fp32 kv-split partials [bs, Hq, slots, Dv] kept address-stable (bytes)
@@ -419,6 +433,17 @@ class HipRadixAttnBackend:
         return (kb.shape[-1] in (64, 96, 128, 256) and kb.shape[-1] == self.v_head_dim
                 and kb.dtype in (torch.bfloat16, torch.float16))
 
+    def _fill_num_kv_splits(self, out: torch.Tensor, lens: torch.Tensor, max_kv_splits: Optional[int] = None):
+        """get_num_kv_splits (triton_backend.py:303-349): the reference's K3 formula, or -- deterministic inference --
+        ceil(len / split_tile_size) per request (rows of a top-k group share their request's count)."""
+        if self.enable_deterministic:
+            n = ((lens + (self.split_tile_size - 1)) // self.split_tile_size).to(torch.int32)
+            group = out.shape[0] // max(1, lens.shape[0])
+            out.copy_(n.repeat_interleave(group) if group > 1 else n)
+            return
+        ops.get_num_kv_splits(out, lens, self.num_head, self.num_kv_head,
+                              self.max_kv_splits if max_kv_splits is None else max_kv_splits, self.device_core_count)
+
     def _decode_metadata_draft(self, fb: ForwardBatch, use_graph_bufs: bool) -> ForwardMetadata:
         """Multi-step draft decode (triton_backend.py:772-774, :587-602): the page tables come from spec_info -- one row per
         (request, top-k branch), built by HipRadixMultiStepDraftBackend -- so the batch the kernel sees has
@@ -438,7 +463,7 @@ class HipRadixAttnBackend:
             attn_logits, attn_lse = self._scratch(rows, S)
         num_seqs = fb.seq_lens.shape[0]
         if rows % max(num_seqs, 1) == 0 and num_seqs > 0:
-            ops.get_num_kv_splits(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head, S, self.device_core_count)
+            self._fill_num_kv_splits(num_kv_splits, fb.seq_lens, S)
         else:  # (rows that are not whole top-k groups: every row keeps the full cap; unused slots cost a dead workgroup)
             num_kv_splits.fill_(S)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S, draft=True)
@@ -492,7 +517,9 @@ class HipRadixAttnBackend:
         if self.split_policy == "native" and self.sliding_window_size is None:
             return self._decode_metadata_native(fb, bs, use_graph_bufs)
         splits_needed = True
-        if not use_graph_bufs and fb.seq_lens_cpu is not None and self.max_kv_splits > 1:
+        if self.enable_deterministic:
+            splits_needed = self.max_kv_splits > 1  # (one launch shape for every batch)
+        elif not use_graph_bufs and fb.seq_lens_cpu is not None and self.max_kv_splits > 1:
             host = host_num_kv_splits(np.asarray(fb.seq_lens_cpu), self.num_head, self.num_kv_head,
                                       self.max_kv_splits, self.device_core_count)
             splits_needed = bool(host.max() > 1)
@@ -512,8 +539,7 @@ class HipRadixAttnBackend:
             wp, wi, wl, _ = self._window(fb.seq_lens, fb.req_pool_indices, bs, use_graph_bufs)
             wsplits = (self._graph["window_num_kv_splits"][:bs] if use_graph_bufs
                        else torch.empty((bs,), dtype=torch.int32, device=self.device))
-            ops.get_num_kv_splits(wsplits, wl, self.num_head, self.num_kv_head, self.max_kv_splits,
-                                  self.device_core_count)
+            self._fill_num_kv_splits(wsplits, wl)
             win = dict(window_kv_indptr=wp, window_kv_indices=wi, window_num_kv_splits=wsplits)
             splits_needed = splits_needed or self.max_kv_splits > 1  # window launch uses the scratch too
         if not splits_needed:
@@ -525,8 +551,7 @@ class HipRadixAttnBackend:
         else:
             num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
             attn_logits, attn_lse = self._scratch(bs)
-        ops.get_num_kv_splits(num_kv_splits, fb.seq_lens, self.num_head, self.num_kv_head,
-                              self.max_kv_splits, self.device_core_count)
+        self._fill_num_kv_splits(num_kv_splits, fb.seq_lens)
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices,
                                None, self.max_kv_splits, **win)
 
@@ -1158,6 +1183,8 @@ class HipRadixAttnBackend:
         if save_kv_cache:
             self.token_to_kv_pool.set_kv_buffer(layer, self._loc_info(forward_batch.out_cache_loc), k, v,
                                                 layer.k_scale, layer.v_scale)
+        if self.enable_deterministic:  # triton_backend.py:1339-1350
+            return self._forward_extend_unified(q, o, layer, forward_batch, causal, sinks, score_mod, aux_tensors)
         md = self.forward_metadata
         k_descale, v_descale = self._scales(layer)
         k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
@@ -1218,6 +1245,43 @@ class HipRadixAttnBackend:
             sinks=sinks, window_kv_offsets=window_kv_offsets if md.custom_mask is not None else None,
             xai_temperature_len=layer.xai_temperature_len, page_size=page_size, kv_layout=lay,
             score_mod=score_mod, aux_tensors=aux_tensors)
+        return o
+
+    def _forward_extend_unified(self, q, o, layer, forward_batch: ForwardBatch, causal: bool, sinks, score_mod=None,
+                                aux_tensors=None):
+        """_forward_extend_unified (triton_backend.py:1572-1712): the one-stage extend of deterministic inference.  The new
+        tokens' K / V are in the pool already; prefix and new tokens are read through ONE kv list (built once per forward
+        and kind of layer: rx_build_unified_kv_indices) whose tiles do not depend on where the prefix ends."""
+        md = self.forward_metadata
+        bs = forward_batch.batch_size
+        swa = (layer.sliding_window_size is not None and layer.sliding_window_size > -1 and md.window_kv_indptr is not None)
+        window = layer.sliding_window_size if (layer.sliding_window_size is not None and layer.sliding_window_size > -1) else -1
+        cache = md.__dict__.setdefault("_unified", {})
+        if swa not in cache:
+            pre_indptr, pre_indices = (md.window_kv_indptr, md.window_kv_indices) if swa else (md.kv_indptr, md.kv_indices)
+            ext_lens = forward_batch.extend_seq_lens
+            if ext_lens is None:  # TARGET_VERIFY: every request extends by the draft tokens (:1632-1647)
+                n_draft = getattr(forward_batch.spec_info, "draft_token_num", None)
+                if n_draft is None:
+                    raise RuntimeError("extend_seq_lens is None but cannot infer from spec_info")
+                ext_lens = torch.full((bs,), int(n_draft), dtype=torch.int32, device=self.device)
+            start = forward_batch.extend_start_loc
+            if start is None:
+                start = torch.zeros_like(ext_lens)
+                start[1:] = torch.cumsum(ext_lens[:-1], dim=0)
+            cache[swa] = ops.build_unified_kv_indices(pre_indptr[: bs + 1], pre_indices, start.contiguous(), ext_lens.contiguous(),
+                                                      forward_batch.out_cache_loc.contiguous(), bs,
+                                                      max_tokens_per_request=self.max_context_len)
+        u_indptr, u_indices, prefix_lens = cache[swa]
+        k_descale, v_descale = self._scales(layer)
+        k_buf, v_buf = self.token_to_kv_pool.get_kv_buffer(layer.layer_id)
+        lay = ops.kv_layout_hnd(k_buf, v_buf) if getattr(self.token_to_kv_pool, "use_hnd", False) else None
+        ops.extend_attention_fwd_unified(
+            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+            k_buf, v_buf, k_descale, v_descale, md.qo_indptr, u_indptr, u_indices, prefix_lens, md.max_extend_len,
+            custom_mask=md.custom_mask, mask_indptr=md.mask_indptr, sm_scale=layer.scaling, logit_cap=layer.logit_cap,
+            is_causal=causal, sliding_window_size=window, sinks=sinks, xai_temperature_len=layer.xai_temperature_len,
+            page_size=self.page_size, score_mod=score_mod, aux_tensors=aux_tensors, kv_layout=lay)
         return o
 
     def support_triton(self):

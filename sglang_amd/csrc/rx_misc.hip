@@ -422,6 +422,60 @@ __global__ __launch_bounds__(1024) void indptr_scan_kernel(const void* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// K8 metadata: build_unified_kv_indices (kernels/ops/attention/extend_attention.py:193-238; copy kernel :135-190)
+// One scan block (unified lens = prefix len + extend len -> indptr, prefix_lens), then a (chunk, request) grid that
+// copies the request's prefix slots and then its new tokens' slots, coalesced.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void unified_indptr_kernel(const int32_t* __restrict__ prefix_indptr, const void* __restrict__ ext_lens,
+                                                              int lens64, int bs, int32_t* __restrict__ out,
+                                                              int32_t* __restrict__ prefix_lens) {
+  __shared__ int32_t wave_sums[16];
+  __shared__ int32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) {
+    carry_s = 0;
+    out[0] = 0;
+  }
+  __syncthreads();
+  for (int base = 0; base < bs; base += 1024) {
+    const int i = base + tid;
+    int32_t x = 0;
+    if (i < bs) {
+      const int32_t pl = prefix_indptr[i + 1] - prefix_indptr[i];
+      if (prefix_lens) prefix_lens[i] = pl;
+      x = pl + static_cast<int32_t>(load_idx(ext_lens, i, lens64));
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int32_t y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wave_sums[wid] = x;
+    __syncthreads();
+    int32_t prefix = carry_s;
+    for (int w = 0; w < wid; ++w) prefix += wave_sums[w];
+    if (i < bs) out[i + 1] = prefix + x;
+    __syncthreads();
+    if (tid == 1023) carry_s = prefix + x;
+    __syncthreads();
+  }
+}
+
+template <typename PreT, typename ExtT>
+__global__ __launch_bounds__(256) void unified_indices_copy_kernel(const int32_t* __restrict__ prefix_indptr, const PreT* __restrict__ prefix_idx,
+                                                                   const void* __restrict__ ext_start, int start64,
+                                                                   const ExtT* __restrict__ ext_idx,
+                                                                   const int32_t* __restrict__ unified_indptr,
+                                                                   int64_t* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int32_t p0 = prefix_indptr[b], pl = prefix_indptr[b + 1] - p0;
+  const int32_t u0 = unified_indptr[b], total = unified_indptr[b + 1] - u0;
+  const int64_t e0 = load_idx(ext_start, b, start64);
+  for (int32_t j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256)
+    out[u0 + j] = j < pl ? static_cast<int64_t>(prefix_idx[p0 + j]) : static_cast<int64_t>(ext_idx[e0 + (j - pl)]);
+}
+
 template <typename OutT>
 __global__ __launch_bounds__(256) void kv_indices_gather_kernel(
     const int32_t* __restrict__ req_to_token, int64_t row_stride,
@@ -924,6 +978,40 @@ int rx_merge_chunks(const void* o_chunks, const float* lse_chunks, int num_chunk
                        num_chunks, (const uint16_t*)o_last, lse_last, (uint16_t*)out, out_lse, groups, rows_per_group,
                        num_heads, head_size);
   return check_launch("rx_merge_chunks");
+}
+
+int rx_build_unified_kv_indices(const int32_t* prefix_kv_indptr, const void* prefix_kv_indices, int prefix_is_i64,
+                                const void* extend_start_loc, int start_is_i64, const void* extend_seq_lens,
+                                int lens_is_i64, const void* extend_kv_indices, int extend_is_i64, int bs,
+                                int64_t max_tokens_per_request, int32_t* unified_kv_indptr, int64_t* unified_kv_indices,
+                                int32_t* prefix_lens, void* stream) {
+  RX_RANGE("rx_build_unified_kv_indices");
+  RX_REQUIRE(bs >= 0, "rx_build_unified_kv_indices: bs < 0");
+  RX_REQUIRE(unified_kv_indptr, "rx_build_unified_kv_indices: unified_kv_indptr is null");
+  auto s = static_cast<hipStream_t>(stream);
+  if (bs == 0) {
+    (void)hipMemsetAsync(unified_kv_indptr, 0, sizeof(int32_t), s);
+    return check_launch("rx_build_unified_kv_indices(memset)");
+  }
+  RX_REQUIRE(prefix_kv_indptr && extend_start_loc && extend_seq_lens && unified_kv_indices,
+             "rx_build_unified_kv_indices: null pointer");
+  hipLaunchKernelGGL(unified_indptr_kernel, dim3(1), dim3(1024), 0, s, prefix_kv_indptr, extend_seq_lens, lens_is_i64, bs,
+                     unified_kv_indptr, prefix_lens);
+  // grid.x: 256-slot chunks of the longest request the caller allows for (grid-stride beyond it)
+  const int64_t per = max_tokens_per_request > 0 ? max_tokens_per_request : 4096;
+  const dim3 grid(static_cast<unsigned>(std::min<int64_t>((per + 255) / 256, 1024)), bs);
+#define RX_UC(PT, ET)                                                                                                 \
+  hipLaunchKernelGGL((unified_indices_copy_kernel<PT, ET>), grid, dim3(256), 0, s, prefix_kv_indptr, (const PT*)prefix_kv_indices, \
+                     extend_start_loc, start_is_i64, (const ET*)extend_kv_indices, unified_kv_indptr, unified_kv_indices)
+  if (prefix_is_i64) {
+    if (extend_is_i64) RX_UC(int64_t, int64_t);
+    else RX_UC(int64_t, int32_t);
+  } else {
+    if (extend_is_i64) RX_UC(int32_t, int64_t);
+    else RX_UC(int32_t, int32_t);
+  }
+#undef RX_UC
+  return check_launch("rx_build_unified_kv_indices");
 }
 
 int rx_build_kv_indices(const int32_t* req_to_token, int64_t row_stride,

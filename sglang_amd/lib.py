@@ -140,6 +140,8 @@ PROTOTYPES = {
                                 c_void_p, c_void_p]),
     "rx_build_kv_indices": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                     c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rx_build_unified_kv_indices": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                            c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rx_num_kv_splits": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p, c_void_p]),
     "rx_decode_attn": (c_int, [C.POINTER(RxDecodeParams), c_void_p]),

@@ -174,6 +174,38 @@ def build_kv_indices(req_to_token: torch.Tensor, req_pool_indices: torch.Tensor,
     return kv_indptr[: bs + 1]
 
 
+def build_unified_kv_indices(prefix_kv_indptr: torch.Tensor, prefix_kv_indices: Optional[torch.Tensor],
+                             extend_start_loc: torch.Tensor, extend_seq_lens: torch.Tensor,
+                             extend_kv_indices: torch.Tensor, bs: int, out_indptr: Optional[torch.Tensor] = None,
+                             out_indices: Optional[torch.Tensor] = None, max_tokens_per_request: int = 0):
+    """build_unified_kv_indices (kernels/ops/attention/extend_attention.py:193-238): the kv list of the one-stage extend
+    -- every request's prefix slots followed by its new tokens' slots.  Same arguments and returns as the reference:
+    ``(unified_kv_indptr int32[bs + 1], unified_kv_indices int64[len(prefix) + len(extend)], prefix_lens int32[bs])``;
+    out_indptr / out_indices let a caller keep address-stable buffers."""
+    _require_cuda(prefix_kv_indptr, prefix_kv_indices, extend_start_loc, extend_seq_lens, extend_kv_indices)
+    if prefix_kv_indptr.dtype != torch.int32:
+        raise TypeError("prefix_kv_indptr must be int32")
+    dev = prefix_kv_indptr.device
+    n_pre = 0 if prefix_kv_indices is None else prefix_kv_indices.numel()
+    total = n_pre + extend_kv_indices.numel()
+    indptr = out_indptr if out_indptr is not None else torch.empty(bs + 1, dtype=torch.int32, device=dev)
+    indices = out_indices if out_indices is not None else torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+    if indptr.dtype != torch.int32 or indptr.numel() < bs + 1 or indices.dtype != torch.int64 or indices.numel() < total:
+        raise ValueError("build_unified_kv_indices: out_indptr int32[bs + 1] / out_indices int64[len(prefix) + len(extend)]")
+    prefix_lens = torch.empty(bs, dtype=torch.int32, device=dev)
+    for name, t in (("extend_start_loc", extend_start_loc), ("extend_seq_lens", extend_seq_lens)):
+        if t.numel() < bs or not t.is_contiguous():
+            raise ValueError(f"build_unified_kv_indices: {name} must be a contiguous vector of at least bs entries")
+    st = _L.load().rx_build_unified_kv_indices(
+        _ptr(prefix_kv_indptr), _ptr(prefix_kv_indices) if n_pre else None,
+        _is64(prefix_kv_indices, "prefix_kv_indices") if n_pre else 0,
+        _ptr(extend_start_loc), _is64(extend_start_loc, "extend_start_loc"), _ptr(extend_seq_lens),
+        _is64(extend_seq_lens, "extend_seq_lens"), _ptr(extend_kv_indices), _is64(extend_kv_indices, "extend_kv_indices"),
+        int(bs), int(max_tokens_per_request), _ptr(indptr), _ptr(indices), _ptr(prefix_lens), _stream(prefix_kv_indptr))
+    _L.check(st, "rx_build_unified_kv_indices")
+    return indptr[: bs + 1], indices[:total] if out_indices is None else indices, prefix_lens
+
+
 # --------------------------------------------------------------------------------------
 # K3  get_num_kv_splits      kernels/ops/attention/metadata.py:11-60
 # --------------------------------------------------------------------------------------

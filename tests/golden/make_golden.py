@@ -27,6 +27,7 @@ Fixture families:
   F17 QK-norm + RoPE (RMSNorm.forward_native + apply_rotary_emb, the pair the reference tests its fused kernel against) -> qknorm_rope.npz
   F19 relative-position score bias (score_mod = relative_bias_score_mod, aux_tensors = [rel_logits]) through the extend,
       unified-extend and decode kernels -> score_bias.npz
+  F20 the unified kv list of the one-stage extend (build_unified_kv_indices) -> unified_kv_indices.npz
   F18 EAGLE multi-step draft decode: per-step kv_indices / kv_indptr of the top-k branches (generate_draft_decode_kv_indices) -> draft_kv_indices.npz
 """
 import json
@@ -1275,8 +1276,41 @@ def f19():
     save("score_bias.npz", **flat)
 
 
+def f20():
+    """F20 build_unified_kv_indices (kernels/ops/attention/extend_attention.py:193-238, Triton copy kernel under
+    TRITON_INTERPRET=1) -> unified_kv_indices.npz: ragged prefixes incl. empty ones, extends of 1 .. 300 tokens, int64
+    prefix indices + int64 out_cache_loc (what TritonAttnBackend._forward_extend_unified passes), and a case with
+    int32 extend_seq_lens / extend_start_loc as ForwardBatch carries them."""
+    from sglang.kernels.ops.attention.extend_attention import build_unified_kv_indices
+
+    rng = np.random.default_rng(20)
+    flat = {}
+    for name, pre, ext, ldt in [("ragged", [40, 0, 7, 300], [6, 20, 9, 1], torch.int32),
+                                ("no_prefix", [0, 0], [129, 300], torch.int64),
+                                ("one", [513], [64], torch.int32),
+                                ("many", list(rng.integers(0, 90, size=37)), list(rng.integers(1, 50, size=37)), torch.int32)]:
+        pre = np.array(pre, dtype=np.int64); ext = np.array(ext, dtype=np.int64)
+        bs = len(pre)
+        pool = int(pre.sum() + ext.sum()) + 11
+        perm = rng.permutation(pool - 1) + 1
+        prefix_idx = torch.from_numpy(perm[: int(pre.sum())].astype(np.int64))
+        ext_idx = torch.from_numpy(perm[int(pre.sum()): int(pre.sum() + ext.sum())].astype(np.int64))
+        indptr = torch.zeros(bs + 1, dtype=torch.int32)
+        indptr[1:] = torch.from_numpy(np.cumsum(pre))
+        start = torch.from_numpy(np.concatenate([[0], np.cumsum(ext)[:-1]])).to(ldt)
+        lens = torch.from_numpy(ext).to(ldt)
+        u_indptr, u_idx, p_lens = build_unified_kv_indices(indptr, prefix_idx, start, lens, ext_idx, bs)
+        total = int(u_indptr[-1])
+        c = dict(prefix_kv_indptr=indptr, prefix_kv_indices=prefix_idx, extend_start_loc=start, extend_seq_lens=lens,
+                 extend_kv_indices=ext_idx, unified_kv_indptr=u_indptr.to(torch.int32), unified_kv_indices=u_idx[:total],
+                 prefix_lens=p_lens.to(torch.int32))
+        for k, v in c.items():
+            flat[f"{name}.{k}"] = v.numpy()
+    save("unified_kv_indices.npz", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14",
-                             "f15", "f16", "f17", "f18", "f19"]
+                             "f15", "f16", "f17", "f18", "f19", "f20"]
     for w in which:
         globals()[w]()

@@ -45,7 +45,7 @@ def _bits(t):
 
 class _Harness:
     def __init__(self, page_size, hq, hkv, d, dtype, layout, index_mode, max_ctx=4200, max_reqs=8,
-                 split_policy="native", size=8192):
+                 split_policy="native", size=8192, server_args_extra=None):
         from sglang_amd.attention.backend import HipRadixAttnBackend
         from sglang_amd.attention.radix_attention import RadixAttention
         from sglang_amd.mem_cache.allocator import PagedTokenToKVPoolAllocator, TokenToKVPoolAllocator
@@ -80,6 +80,8 @@ class _Harness:
             class server_args:
                 triton_attention_num_kv_splits = 8
 
+        for key, val in (server_args_extra or {}).items():
+            setattr(MR.server_args, key, val)
         self.backend = HipRadixAttnBackend(MR, decode_index_mode=index_mode, split_policy=split_policy)
         self.layer = RadixAttention(hq, d, d ** -0.5, hkv, 0)
         self.gen = torch.Generator().manual_seed(11)

@@ -356,6 +356,19 @@ def test_score_bias_golden(golden_dir):
         assert np.abs(off[ok] - want[ok]).max() > 1e-2, (name, "the case must exercise the bias")
 
 
+def test_unified_kv_indices_golden(golden_dir):
+    """F20: build_unified_kv_indices (the reference's Triton copy kernel + torch cumsum), bit-exact."""
+    cases = _npz_cases(os.path.join(golden_dir, "unified_kv_indices.npz"))
+    assert set(cases) == {"ragged", "no_prefix", "one", "many"}
+    for name, c in cases.items():
+        bs = len(c["prefix_lens"])
+        indptr, idx, pl = orc.build_unified_kv_indices(c["prefix_kv_indptr"], c["prefix_kv_indices"], c["extend_start_loc"],
+                                                       c["extend_seq_lens"], c["extend_kv_indices"], bs)
+        assert np.array_equal(indptr, c["unified_kv_indptr"]) and indptr.dtype == np.int32, name
+        assert np.array_equal(idx, c["unified_kv_indices"]) and idx.dtype == np.int64, name
+        assert np.array_equal(pl, c["prefix_lens"]), name
+
+
 def test_cpu_baseline_container_fixture(golden_dir):
     """SURVEY 8(d) CPU-baseline item (1): the reference's compiled CPU kernel and the C restatement timed in
     the build container on identical inputs (oracle/time_cpu_container.py) -- fixture present and consistent."""

@@ -1,5 +1,5 @@
 """Dev fuzz: the D = 128 extend launcher's forms against each other on random ragged batches -- what the gates pick by
-themselves, four waves unpacked, eight waves unpacked, eight waves self-packed (forced) -- for GQA 4 / 8, causal, plain
+themselves, four waves unpacked, eight waves unpacked, eight waves self-packed (forced), four waves self-packed (forced) -- for GQA 4 / 8, causal, plain
 calls.  Every form walks the same tiles per row, so outputs and LSEs must agree to the last bit on ordinary data (the
 fast and the boundary tile bodies differ only when a running max moves); reported: max |diff| per form, and the instance
 each form dispatched.  env: N (60) SEED (0)"""
@@ -21,6 +21,7 @@ FORMS = {
     "4w": {"ext32_autopack": 0, "ext32_small_wg": 1},
     "8w": {"ext32_autopack": 0, "ext32_small_wg": 0},
     "8w-packed": {"ext32_small_wg": 0, "ext32_pack_min_wgs": 0, "ext32_pack_min_tiles": 0},
+    "4w-packed": {"ext32_small_wg": 1, "ext32_pack_min_wgs": 0, "ext32_pack_min_tiles": 0},  # (round 5: packed rows on four waves)
 }
 worst, picked, bad = {k: 0.0 for k in FORMS}, {}, 0
 for it in range(N):
