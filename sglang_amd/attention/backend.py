@@ -201,6 +201,9 @@ class HipRadixAttnBackend:
         # kv list (prefix slots + the new tokens' slots, rx_build_unified_kv_indices), whose tiles are cut from the list's
         # start and all run one tile body (rx_extend32_kernel.inc), so a query row's arithmetic does not move with the
         # prefix / extend split.
+        self.static_kv_splits = os.environ.get("SGLANG_TRITON_DECODE_ATTN_STATIC_KV_SPLITS", "false").lower() in ("1", "true")
+        if self.static_kv_splits:
+            split_policy = "reference"  # (every request gets the cap: the reference's K3 path, not the chip-filling one)
         self.enable_deterministic = bool(getattr(sa, "enable_deterministic_inference", False))
         self.split_tile_size = getattr(sa, "triton_attention_split_tile_size", None)
         if self.enable_deterministic:
@@ -441,8 +444,11 @@ class HipRadixAttnBackend:
             group = out.shape[0] // max(1, lens.shape[0])
             out.copy_(n.repeat_interleave(group) if group > 1 else n)
             return
-        ops.get_num_kv_splits(out, lens, self.num_head, self.num_kv_head,
-                              self.max_kv_splits if max_kv_splits is None else max_kv_splits, self.device_core_count)
+        cap = self.max_kv_splits if max_kv_splits is None else max_kv_splits
+        if self.static_kv_splits or self.device_core_count <= 0:  # SGLANG_TRITON_DECODE_ATTN_STATIC_KV_SPLITS (:215-217, :321-325)
+            out.fill_(cap)
+            return
+        ops.get_num_kv_splits(out, lens, self.num_head, self.num_kv_head, cap, self.device_core_count)
 
     def _decode_metadata_draft(self, fb: ForwardBatch, use_graph_bufs: bool) -> ForwardMetadata:
         """Multi-step draft decode (triton_backend.py:772-774, :587-602): the page tables come from spec_info -- one row per
@@ -517,7 +523,7 @@ class HipRadixAttnBackend:
         if self.split_policy == "native" and self.sliding_window_size is None:
             return self._decode_metadata_native(fb, bs, use_graph_bufs)
         splits_needed = True
-        if self.enable_deterministic:
+        if self.enable_deterministic or self.static_kv_splits:
             splits_needed = self.max_kv_splits > 1  # (one launch shape for every batch)
         elif not use_graph_bufs and fb.seq_lens_cpu is not None and self.max_kv_splits > 1:
             host = host_num_kv_splits(np.asarray(fb.seq_lens_cpu), self.num_head, self.num_kv_head,

@@ -152,3 +152,32 @@ def test_decode_rows_do_not_depend_on_the_batch(index_mode):
     qa = torch.cat([qs[n] for n in lens_all]).view(len(lens_all), hq, d)
     want, absw = parity.want_and_absw(orc.decode_attention, (bits(qa), bits(kb), bits(vb), kvp, kvi, d ** -0.5), (2,))
     parity.check_out(o_all.view(len(lens_all), hq, d).float().cpu().numpy(), want, dtype, ("deterministic decode", index_mode), absw=absw)
+
+
+def test_static_kv_splits_env(monkeypatch):
+    """SGLANG_TRITON_DECODE_ATTN_STATIC_KV_SPLITS (triton_backend.py:215-217, :321-325): every request gets the cap."""
+    from test_gpu_backend import _Harness
+
+    from sglang_amd.forward_batch import ForwardBatch
+
+    monkeypatch.setenv("SGLANG_TRITON_DECODE_ATTN_STATIC_KV_SPLITS", "true")
+    hs = _Harness(16, 8, 2, 128, torch.float16, "contiguous", "indices")
+    assert hs.backend.static_kv_splits and hs.backend.split_policy == "reference"
+    lens = [40, 700, 3]
+    rows = hs.r2t.alloc(3)
+    hs.fill_prefix(rows, lens)
+    seq_t = torch.tensor(lens, dtype=torch.int64)
+    fb = ForwardBatch.for_decode(torch.tensor(rows, dtype=torch.int64, device=DEV), seq_t.to(DEV),
+                                 torch.zeros(3, dtype=torch.int64, device=DEV), seq_t)
+    hs.backend.init_forward_metadata(fb)
+    md = hs.backend.forward_metadata
+    assert md.num_kv_splits.tolist() == [8, 8, 8] and md.max_kv_splits == 8
+    q = hs.rand(3, 8 * 128)
+    o = hs.layer(q, None, None, fb, hs.backend, save_kv_cache=False)
+    kb, vb = hs.pool.get_kv_buffer(0)
+    r2t = hs.r2t.req_to_token.cpu().numpy()
+    kvi = np.concatenate([r2t[r, :n] for r, n in zip(rows, lens)]).astype(np.int64)
+    kvp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    want, absw = parity.want_and_absw(orc.decode_attention, (q.view(3, 8, 128).cpu().numpy(), kb.cpu().numpy(), vb.cpu().numpy(),
+                                                             kvp, kvi, 128 ** -0.5), (2,))
+    parity.check_out(o.view(3, 8, 128).float().cpu().numpy(), want, torch.float16, "static kv splits", absw=absw)
