@@ -201,6 +201,10 @@ class HipRadixAttnBackend:
         # kv list (prefix slots + the new tokens' slots, rx_build_unified_kv_indices), whose tiles are cut from the list's
         # start and all run one tile body (rx_extend32_kernel.inc), so a query row's arithmetic does not move with the
         # prefix / extend split.
+        # (:235-245) safe only when a prefill is never split or padded: no chunked prefill, and no graph mode that could
+        # (the runner says so through server_args.disable_cuda_graph; eager prefill is what this backend runs)
+        self.allow_bidirectional_attention_in_extend = (getattr(sa, "chunked_prefill_size", None) == -1
+                                                        and bool(getattr(sa, "disable_cuda_graph", True)))
         self.static_kv_splits = os.environ.get("SGLANG_TRITON_DECODE_ATTN_STATIC_KV_SPLITS", "false").lower() in ("1", "true")
         if self.static_kv_splits:
             split_policy = "reference"  # (every request gets the cap: the reference's K3 path, not the chip-filling one)
@@ -1174,7 +1178,12 @@ class HipRadixAttnBackend:
             o = torch.empty_like(q)
         if k is None or v is None:
             raise ValueError("forward_extend needs the new tokens' k and v")
-        causal = not (layer.is_cross_attention or layer.attn_type.value == "encoder_only")
+        if getattr(layer, "logit_capping_method", "tanh") != "tanh":  # logit_capping_mod (triton_backend.py:83-88)
+            raise ValueError(f"logit_capping_method {layer.logit_capping_method!r}: only 'tanh'")
+        # (:1318-1327) cross attention, encoder-only layers and -- where the runner guarantees whole, unpadded prefills --
+        # bidirectional decoder layers (image tokens) attend without the causal triangle
+        causal = not (layer.is_cross_attention or layer.attn_type.value == "encoder_only"
+                      or (layer.attn_type.value == "decoder_bidirectional" and self.allow_bidirectional_attention_in_extend))
         if self.dcp is not None:
             if score_mod is not None:
                 raise NotImplementedError("DCP extend does not support score_mod (as the reference, triton_backend.py:1330-1333)")

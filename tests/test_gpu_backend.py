@@ -1107,3 +1107,43 @@ def test_clock_probe_reads_a_plausible_shader_clock():
     assert 50.0 < cyc / ticks * 100.0 < 3000.0, (cyc, ticks)     # MHz: anything from the idle state to the 2.4 GHz peak
     with pytest.raises(rxlib.RadixHipError):
         rxlib.clock_probe(out, 0, torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.gpu
+def test_bidirectional_decoder_layer_extends_without_the_causal_triangle():
+    """triton_backend.py:235-245,1318-1327: a DECODER_BIDIRECTIONAL layer (image tokens) attends non-causally in an extend
+    when prefills are whole (chunked_prefill_size == -1, no graph mode) and causally otherwise."""
+    from sglang_amd.attention.radix_attention import AttentionType, RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+
+    hq, hkv, d = 4, 2, 128
+    outs = {}
+    for whole in (True, False):
+        hs = _Harness(16, hq, hkv, d, torch.float16, "contiguous", "paged",
+                      server_args_extra={"chunked_prefill_size": -1 if whole else 8192, "disable_cuda_graph": True})
+        assert hs.backend.allow_bidirectional_attention_in_extend == whole
+        layer = RadixAttention(hq, d, d ** -0.5, hkv, 0, attn_type=AttentionType.DECODER_BIDIRECTIONAL)
+        prefix_lens, extend_lens = [40, 0], [70, 33]
+        rows = hs.r2t.alloc(2)
+        hs.fill_prefix(rows, prefix_lens)
+        seq_lens = [p + e for p, e in zip(prefix_lens, extend_lens)]
+        loc = hs.alloc_extend(rows, prefix_lens, seq_lens)
+        T = sum(extend_lens)
+        q, k, v = hs.rand(T, hq * d), hs.rand(T, hkv * d), hs.rand(T, hkv * d)
+        fb = ForwardBatch.for_extend(torch.tensor(rows, dtype=torch.int64, device=DEV), torch.tensor(seq_lens, device=DEV), loc,
+                                     prefix_lens, extend_lens)
+        hs.backend.init_forward_metadata(fb)
+        o = layer(q, k, v, fb, hs.backend)
+        kb, vb = hs.pool.get_kv_buffer(0)
+        r2t = hs.r2t.req_to_token.cpu().numpy()
+        kvi = np.concatenate([r2t[r, :p] for r, p in zip(rows, prefix_lens)]).astype(np.int64)
+        kvp = np.concatenate([[0], np.cumsum(prefix_lens)]).astype(np.int32)
+        qo = np.concatenate([[0], np.cumsum(extend_lens)]).astype(np.int64)
+        want, absw = parity.want_and_absw(orc.extend_attention, (_bits(q.view(T, hq, d)), _bits(k.view(T, hkv, d)), _bits(v.view(T, hkv, d)),
+                                                                 _bits(kb), _bits(vb), qo, kvp, kvi), (2, 4), is_causal=not whole, sm_scale=d ** -0.5)
+        parity.check_out(_bits(o.view(T, hq, d)).astype(np.float64), want, torch.float16, ("bidirectional", whole), absw=absw)
+        outs[whole] = o
+    assert not torch.equal(outs[True], outs[False])
+    with pytest.raises(ValueError):
+        layer.logit_capping_method = "sigmoid"
+        layer(q, k, v, fb, hs.backend)
