@@ -372,6 +372,21 @@ constexpr float kLn2 = 0.6931471805599453f;
 
 // relative-position score bias (relative_bias_score_mod, kernels/ops/attention/score_mod.py:44-56): element r of a
 // (query token, head) row, fp32 or the call's 16-bit dtype
+// ... and four consecutive elements r0 .. r0 + 3 in ONE load.  The address is only element-aligned (r0 is a distance of
+// positions): gfx950 takes under-aligned global loads, and hipcc emits global_load_dwordx2 / dwordx4 for these types.
+typedef u32x2 __attribute__((aligned(2))) u32x2_a2;
+typedef f32x4 __attribute__((aligned(4))) f32x4_a4;
+template <typename T>
+__device__ __forceinline__ void load_bias4(const void* row, int32_t is_f32, int32_t r0, float (&out)[4]) {
+  if (is_f32) {
+    const f32x4_a4 v = *reinterpret_cast<const f32x4_a4*>(static_cast<const float*>(row) + r0);
+    out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+  } else {
+    const u32x2_a2 v = *reinterpret_cast<const u32x2_a2*>(static_cast<const uint16_t*>(row) + r0);
+    out[0] = T::to_f32(static_cast<uint16_t>(v[0] & 0xFFFFu)); out[1] = T::to_f32(static_cast<uint16_t>(v[0] >> 16));
+    out[2] = T::to_f32(static_cast<uint16_t>(v[1] & 0xFFFFu)); out[3] = T::to_f32(static_cast<uint16_t>(v[1] >> 16));
+  }
+}
 template <typename T>
 __device__ __forceinline__ float load_bias(const void* row, int32_t is_f32, int32_t r) {
   return is_f32 ? static_cast<const float*>(row)[r] : T::to_f32(static_cast<const uint16_t*>(row)[r]);
