@@ -550,8 +550,10 @@ def _gather_kv(buf, slots, kv_head):
 
 def decode_attention(q, k_buffer, v_buffer, kv_indptr, kv_indices, sm_scale,
                      k_scale=1.0, v_scale=1.0, logit_cap=0.0, sinks=None,
-                     return_lse=False, xai_temperature_len=-1, score_bias=None):
-    """score_bias [bs, Hq, extent] (already decoded to float): the reference's score_mod = relative_bias_score_mod with
+                     return_lse=False, xai_temperature_len=-1, score_bias=None, return_absw=False):
+    """return_absw: also return A = sum_j p_j |v_j| (same softmax, |V| in place of V: parity_util.check_out's `absw`)
+    as the LAST element of the result -- one pass instead of a second call on abs_values(v).
+    score_bias [bs, Hq, extent] (already decoded to float): the reference's score_mod = relative_bias_score_mod with
     aux_tensors = [score_bias] (decode_attention.py:215-227,539-551: q_pos = seq_len - 1, kv_pos = list position,
     q_idx = request), added after scale, cap and temperature.
     Semantics of decode_attention_fwd (decode_attention.py:968-1044):
@@ -565,6 +567,7 @@ def decode_attention(q, k_buffer, v_buffer, kv_indptr, kv_indices, sm_scale,
     group = hq // hkv
     qf = to_f64(q)
     o = np.zeros((bs, hq, dv), dtype=np.float64)
+    oa = np.zeros((bs, hq, dv), dtype=np.float64) if return_absw else None
     lse = np.full((bs, hq), -np.inf, dtype=np.float64)
     for b in range(bs):
         idx = np.asarray(kv_indices[kv_indptr[b] : kv_indptr[b + 1]]).astype(np.int64)
@@ -586,8 +589,13 @@ def decode_attention(q, k_buffer, v_buffer, kv_indptr, kv_indices, sm_scale,
                 if sinks is not None:
                     den = den + math.exp(float(sinks[h]) - m)
                 o[b, h] = (p @ vv) / den * v_scale
+                if return_absw:
+                    oa[b, h] = (p @ np.abs(vv)) / den * v_scale
                 lse[b, h] = m + math.log(p.sum())
-    return (o, lse) if return_lse else o
+    res = (o, lse) if return_lse else o
+    if return_absw:
+        return (res + (oa,)) if return_lse else (o, oa)
+    return res
 
 
 _MIN_BLOCK_KV = 32  # decode_attention.py:36
@@ -650,8 +658,10 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
                      k_scale=1.0, v_scale=1.0, logit_cap=0.0,
                      sliding_window_size=-1, sinks=None, skip_prefix=False,
                      skip_extend=False, return_lse=False, custom_mask=None, mask_indptr=None,
-                     skip_prefix_custom_mask=True, window_kv_offsets=None, xai_temperature_len=-1, score_bias=None):
-    """score_bias [T, Hq, extent] (float): score_mod = relative_bias_score_mod, aux_tensors = [score_bias]
+                     skip_prefix_custom_mask=True, window_kv_offsets=None, xai_temperature_len=-1, score_bias=None,
+                     return_absw=False):
+    """return_absw: also return sum_j p_j |v_j| (see decode_attention) as the last element of the result.
+    score_bias [T, Hq, extent] (float): score_mod = relative_bias_score_mod, aux_tensors = [score_bias]
     (extend_attention.py:463-476 prefix stage: q_pos = P + m, kv_pos = list position; :594-607 extend stage:
     kv_pos = P + n; q_idx = global query token), added after scale, cap and temperature, before the masks.
     Semantics of extend_attention_fwd (extend_attention.py:664-812).  Request i
@@ -676,6 +686,7 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
         sm_scale = 1.0 / math.sqrt(dq)
     qf, kf, vf = to_f64(q_extend), to_f64(k_extend), to_f64(v_extend)
     o = np.zeros((t, hq, dv), dtype=np.float64)
+    oa = np.zeros((t, hq, dv), dtype=np.float64) if return_absw else None
     lse = np.full((t, hq), -np.inf, dtype=np.float64)
     bs = len(qo_indptr) - 1
     for i in range(bs):
@@ -737,13 +748,20 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
                     if sinks is not None:
                         den = den + math.exp(float(sinks[h]) - mx)
                     o[q0 + m, h] = (p @ vv) / den
-    return (o, lse) if return_lse else o
+                    if return_absw:
+                        oa[q0 + m, h] = (p @ np.abs(vv)) / den
+    res = (o, lse) if return_lse else o
+    if return_absw:
+        return (res + (oa,)) if return_lse else (o, oa)
+    return res
 
 
 def extend_attention_unified(q, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, prefix_lens, sm_scale=None,
                              k_scale=1.0, v_scale=1.0, logit_cap=0.0, is_causal=True, sliding_window_size=-1,
-                             sinks=None, custom_mask=None, mask_indptr=None, xai_temperature_len=-1, score_bias=None):
-    """score_bias [T, Hq, extent]: relative_bias_score_mod through :1093-1104 (q_pos = prefix_i + m, kv_pos = list position).
+                             sinks=None, custom_mask=None, mask_indptr=None, xai_temperature_len=-1, score_bias=None,
+                             return_absw=False):
+    """return_absw: also return sum_j p_j |v_j| (see decode_attention).
+    score_bias [T, Hq, extent]: relative_bias_score_mod through :1093-1104 (q_pos = prefix_i + m, kv_pos = list position).
     Semantics of extend_attention_fwd_unified / _fwd_kernel_unified (extend_attention.py:852-1158): one pass
     over a kv list holding prefix + new tokens.  Query m of request i sees list position n iff n < prefix_i or
     n - prefix_i <= m (causal, :993-1008), window prefix_i + m <= n + W (:1010-1027); a custom mask row is
@@ -757,6 +775,7 @@ def extend_attention_unified(q, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_ind
         sm_scale = 1.0 / math.sqrt(dq)
     qf = to_f64(q)
     o = np.zeros((t, hq, dv), dtype=np.float64)
+    oa = np.zeros((t, hq, dv), dtype=np.float64) if return_absw else None
     for i in range(len(qo_indptr) - 1):
         q0, q1 = int(qo_indptr[i]), int(qo_indptr[i + 1])
         e = q1 - q0
@@ -793,7 +812,9 @@ def extend_attention_unified(q, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_ind
                     if sinks is not None:
                         den = den + math.exp(float(sinks[h]) - mx)
                     o[q0 + m, h] = (p @ vv) / den * v_scale
-    return o
+                    if return_absw:
+                        oa[q0 + m, h] = (p @ np.abs(vv)) / den * v_scale
+    return (o, oa) if return_absw else o
 
 
 def rope(x, positions, cos_sin_cache, is_neox, rotary_dim=None):

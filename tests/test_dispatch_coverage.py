@@ -254,11 +254,9 @@ def _run_extend(c, ops, rxlib):
     else:
         kbo, vbo = _bits(kb), _bits(vb.contiguous())
     okw = dict(kw, k_scale=ks, v_scale=vs)
-    want = orc.extend_attention(_bits(q), _bits(ke), _bits(ve.contiguous()), kbo, vbo, qo, np.asarray(kvp, np.int32), kvi,
-                                is_causal=True, sm_scale=sm, **okw)
-    absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve.contiguous())), kbo,
-                                np.abs(vbo) if fp8 else parity.abs_values(vbo), qo, np.asarray(kvp, np.int32), kvi,
-                                is_causal=True, sm_scale=sm, **okw)
+    # (the |V| twin of check_out's absw comes out of the same pass: return_absw)
+    want, absw = orc.extend_attention(_bits(q), _bits(ke), _bits(ve.contiguous()), kbo, vbo, qo, np.asarray(kvp, np.int32), kvi,
+                                      is_causal=True, sm_scale=sm, return_absw=True, **okw)
     if c.get("mla"):  # one latent tensor; v is its view (the pool always aliases) -- padded pages for the non-linear form
         if c["lin"]:
             kd = kb.to(DEV)
@@ -339,8 +337,7 @@ def _run_decode(c, ops, rxlib):
     ks, vs = (0.8, 1.25) if (fp8 and not c.get("mla")) else (1.0, 1.0)
     aux = (1.5 * torch.randn(bs, hq, 70, generator=g)).to(dtype if len(c["expect"]) % 2 else torch.float32) if c.get("bias") else None
     okw = dict(k_scale=ks, v_scale=vs, score_bias=None if aux is None else aux.double().numpy())
-    want = orc.decode_attention(_bits(q), kbo, vbo, ip, ii, sm, **okw)
-    absw = orc.decode_attention(_bits(q), kbo, np.abs(vbo) if fp8 else parity.abs_values(vbo), ip, ii, sm, **okw)
+    want, absw = orc.decode_attention(_bits(q), kbo, vbo, ip, ii, sm, return_absw=True, **okw)
     if c.get("mla"):
         if c["lin"]:
             kd = kb_dev.to(DEV)

@@ -124,10 +124,8 @@ def test_extend_kernels_under_adversarial_scores(case, pattern, dtype):
     kv_indices = slots[:P].astype(np.int64)
     qo = np.array([0, E], dtype=np.int64)
     ke, ve = kfull[P:].contiguous(), vfull[P:].contiguous()
-    want, want_lse = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices, sm_scale=sm,
-                                          return_lse=True)
-    absw = orc.extend_attention(_np(q), _np(ke), parity.abs_values(_np(ve)), _np(kb), parity.abs_values(_np(vb)), qo, kv_indptr,
-                                kv_indices, sm_scale=sm)
+    want, want_lse, absw = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, kv_indices, sm_scale=sm,
+                                                return_lse=True, return_absw=True)  # (the |V| twin from the same pass)
     o = torch.full((E, hq, dv), float("nan"), dtype=dtype, device=DEV)
     lse = torch.zeros(E, hq, dtype=torch.float32, device=DEV)
     ctx = [rxlib.option(k, v) for k, v in opts.items()]
@@ -200,9 +198,7 @@ def test_mla_decode_kernels_under_adversarial_scores(rows, pattern, dtype):
         kvn = _np(kvq)
         kvd = kvq.to(DEV)
         expect = "decode_mla_kernel"
-    want = orc.decode_attention(_np(q), kvn, kvn[..., :512], kv_indptr, kv_indices, sm)
-    absw = orc.decode_attention(_np(q), kvn, np.abs(kvn[..., :512]) if rows == "fp8" else parity.abs_values(kvn[..., :512]),
-                                kv_indptr, kv_indices, sm)
+    want, absw = orc.decode_attention(_np(q), kvn, kvn[..., :512], kv_indptr, kv_indices, sm, return_absw=True)
     qd = q.to(DEV)
     o = torch.full((bs, hq, 512), float("nan"), dtype=dtype, device=DEV)
     S = 8
@@ -254,10 +250,8 @@ def test_rows_with_a_fully_masked_prefix(dk, hq, hkv, dtype):
     qo = np.array([0, E], dtype=np.int64)
     mi = np.array([0, mask.size], dtype=np.int64)
     sm = dk ** -0.5
-    want = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, slots, custom_mask=mask.reshape(-1),
-                                mask_indptr=mi, sm_scale=sm, skip_prefix_custom_mask=False)
-    absw = orc.extend_attention(_np(q), _np(ke), parity.abs_values(_np(ve)), _np(kb), parity.abs_values(_np(vb)), qo, kv_indptr,
-                                slots, custom_mask=mask.reshape(-1), mask_indptr=mi, sm_scale=sm, skip_prefix_custom_mask=False)
+    want, absw = orc.extend_attention(_np(q), _np(ke), _np(ve), _np(kb), _np(vb), qo, kv_indptr, slots, custom_mask=mask.reshape(-1),
+                                      mask_indptr=mi, sm_scale=sm, skip_prefix_custom_mask=False, return_absw=True)
     o = torch.full((E, hq, dk), float("nan"), dtype=dtype, device=DEV)
     ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _t(qo), _t(kv_indptr), _t(slots),
                              _t(mask.reshape(-1)), True, _t(mi), E, 1.0, 1.0, sm_scale=sm, skip_prefix_custom_mask=False)

@@ -137,7 +137,7 @@ assert not ar.supports(torch.zeros(7, device=dev, dtype=torch.bfloat16))
 # per-tensor routing (GroupCoordinator.all_reduce's should_custom_ar, parallel_state.py:672-700): what the kernel cannot
 # take -- odd counts, fp32, messages above max_bytes -- is reduced by the group's backend; a strided view the shape
 # rule accepts goes through a contiguous copy.  The rule reads dtype and element count only (same on every rank).
-for n, dt in ([(7, torch.bfloat16), (1024, torch.float32)] if LIGHT else
+for n, dt in ([(7, torch.bfloat16)] if LIGHT else
               [(7, torch.bfloat16), (1024, torch.float32), ((4 << 20) // 2 + 8, torch.bfloat16)]):
     parts = parts_for(n, n, dt)
     x = parts[rank].to(dev)
@@ -182,7 +182,7 @@ def test_custom_allreduce_across_processes(world, tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, RX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + world),
                WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0",
-               AR_REPS="3" if world <= 4 else "1")  # (6 / 8 processes time-slice ONE GPU here: every call waits for all of them)
+               AR_REPS="3" if world <= 2 else "1")  # (4 / 6 / 8 processes time-slice ONE GPU here: every call waits for all of them; the full set runs at world 2)
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []

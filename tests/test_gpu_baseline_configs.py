@@ -85,14 +85,12 @@ def _extend_then_decode(ops, dtype, hq, hkv, d, page, prefix, ext, tol_o):
     o = torch.zeros(T_, hq, d, dtype=dtype, device=DEV)
     ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb, vb, _T(qo), _T(kv_indptr), _T(kv_indices),
                              None, True, None, int(max(ext)), 1.0, 1.0, sm_scale=sm, page_size=page)
-    want = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr, kv_indices,
-                                sm_scale=sm)
+    want, absw = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr, kv_indices,
+                                      sm_scale=sm, return_absw=True)
     # bf16 P carries 8 bits: on the first causal rows (few visible keys, cancelling values) its rounding exceeds an ulp
     # of |o| -- the u * sum p|v| term (parity_util.check_out) covers exactly that; fp16 is held to the bar as written
-    absw = None
-    if dtype == torch.bfloat16:
-        absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve)), _bits(kb),
-                                    parity.abs_values(_bits(vb)), qo, kv_indptr, kv_indices, sm_scale=sm)
+    if dtype != torch.bfloat16:
+        absw = None
     parity.check_out(o.float().cpu().numpy(), want, dtype, "extend", ulps=1, absw=absw)
     # one decode step on top
     lens = np.asarray(seq, dtype=np.int64)
@@ -147,12 +145,10 @@ def test_config2_shared_prefix_extend(ops, dtype):
     lse = torch.zeros(bs * E, hq, dtype=torch.float32, device=DEV)
     ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), _T(qo), _T(kv_indptr),
                              _T(kv_indices), None, True, None, E, 1.0, 1.0, sm_scale=sm, lse_extend=lse, page_size=page)
-    want, want_lse = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr,
-                                          kv_indices, sm_scale=sm, return_lse=True)
-    absw = None
-    if dtype == torch.bfloat16:  # bf16 P carries 8 bits: its rounding exceeds an ulp of |o| on the first causal rows
-        absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve)), _bits(kb),
-                                    parity.abs_values(_bits(vb)), qo, kv_indptr, kv_indices, sm_scale=sm)
+    want, want_lse, absw = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr,
+                                                kv_indices, sm_scale=sm, return_lse=True, return_absw=True)
+    if dtype != torch.bfloat16:  # bf16 P carries 8 bits: its rounding exceeds an ulp of |o| on the first causal rows
+        absw = None
     parity.check_out(o.float().cpu().numpy(), want, dtype, "config 2/3 chunk", ulps=1, absw=absw)   # fp16: the bar as written
     np.testing.assert_allclose(lse.cpu().numpy(), want_lse, atol=5e-3, rtol=2e-3)
 
@@ -193,12 +189,10 @@ def test_config2_shared_prefix_extend_at_the_tp1_geometry(ops, dtype):
     torch.cuda.synchronize()
     tn = "rx::BF16" if dtype == torch.bfloat16 else "rx::F16"
     assert rxlib.last_dispatch() == f"extend_mfma32_kernel<{tn}, long, false, false, 8, false, true, 4>", rxlib.last_dispatch()
-    want, want_lse = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr,
-                                          kv_indices, sm_scale=sm, return_lse=True)
-    absw = None
-    if dtype == torch.bfloat16:  # bf16 P carries 8 bits: its rounding exceeds an ulp of |o| on the first causal rows
-        absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve)), _bits(kb),
-                                    parity.abs_values(_bits(vb)), qo, kv_indptr, kv_indices, sm_scale=sm)
+    want, want_lse, absw = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, kv_indptr,
+                                                kv_indices, sm_scale=sm, return_lse=True, return_absw=True)
+    if dtype != torch.bfloat16:  # bf16 P carries 8 bits: its rounding exceeds an ulp of |o| on the first causal rows
+        absw = None
     parity.check_out(o.float().cpu().numpy(), want, dtype, "config 2/3 chunk, TP = 1 geometry", ulps=1, absw=absw)  # fp16: the bar as written
     np.testing.assert_allclose(lse.cpu().numpy(), want_lse, atol=5e-3, rtol=2e-3)
 

@@ -181,3 +181,53 @@ def test_static_kv_splits_env(monkeypatch):
     want, absw = parity.want_and_absw(orc.decode_attention, (q.view(3, 8, 128).cpu().numpy(), kb.cpu().numpy(), vb.cpu().numpy(),
                                                              kvp, kvi, 128 ** -0.5), (2,))
     parity.check_out(o.view(3, 8, 128).float().cpu().numpy(), want, torch.float16, "static kv splits", absw=absw)
+
+
+def test_target_verify_under_deterministic_mode():
+    """TARGET_VERIFY through _forward_extend_unified (triton_backend.py:1632-1647: extend lens from spec_info.draft_token_num,
+    start locs by cumsum; the tree mask rows are kv_len wide in the unified form): the draft rows against the oracle's
+    two-stage semantics with the same mask."""
+    from sglang_amd.forward_batch import ForwardBatch, ForwardMode
+
+    hq, hkv, d, nd = 8, 2, 128, 5
+    hs = _harness(torch.float16, d, hq, hkv)
+    seq_lens = [300, 17, 129]
+    bs = len(seq_lens)
+    rows = hs.r2t.alloc(bs)
+    hs.fill_prefix(rows, seq_lens)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    total = [s + nd for s in seq_lens]
+    loc = hs.alloc_extend(rows, list(seq_lens), total)
+    rng = np.random.default_rng(4)
+    masks = []
+    for s in seq_lens:
+        m = np.ones((nd, s + nd), dtype=bool)
+        tri = np.tril(rng.random((nd, nd)) < 0.5)
+        np.fill_diagonal(tri, True)
+        m[:, s:] = tri
+        masks.append(m.reshape(-1))
+    cm = np.concatenate(masks)
+
+    class Spec:
+        draft_token_num = nd
+        custom_mask = torch.from_numpy(cm).to(DEV)
+
+    T = bs * nd
+    q, k, v = hs.rand(T, hq * d), hs.rand(T, hkv * d), hs.rand(T, hkv * d)
+    seq_t = torch.tensor(seq_lens, dtype=torch.int64)
+    fb = ForwardBatch(forward_mode=ForwardMode.TARGET_VERIFY, batch_size=bs, req_pool_indices=rpi,
+                      seq_lens=seq_t.to(DEV), out_cache_loc=loc, seq_lens_sum=int(seq_t.sum()), seq_lens_cpu=seq_t,
+                      spec_info=Spec)
+    hs.backend.init_forward_metadata(fb)
+    o = hs.layer(q, k, v, fb, hs.backend)
+    kb, vb = hs.pool.get_kv_buffer(0)
+    r2t = hs.r2t.req_to_token.cpu().numpy()
+    kv_indptr, kv_indices = orc.build_kv_indices(r2t, np.array(rows), np.array(seq_lens))
+    qo = (np.arange(bs + 1) * nd).astype(np.int64)
+    kbn, vbn = kb.cpu().numpy(), vb.cpu().numpy()
+    ke = np.concatenate([kbn[r2t[rows[i], seq_lens[i]: total[i]]] for i in range(bs)])
+    ve = np.concatenate([vbn[r2t[rows[i], seq_lens[i]: total[i]]] for i in range(bs)])
+    mi = np.concatenate([[0], np.cumsum([m.size for m in masks])]).astype(np.int64)
+    want, absw = parity.want_and_absw(orc.extend_attention, (q.view(T, hq, d).cpu().numpy(), ke, ve, kbn, vbn, qo, kv_indptr, kv_indices),
+                                      (2, 4), is_causal=True, sm_scale=d ** -0.5, custom_mask=cm, mask_indptr=mi, skip_prefix_custom_mask=False)
+    parity.check_out(o.view(T, hq, d).float().cpu().numpy(), want, torch.float16, "deterministic target verify", absw=absw)
