@@ -709,6 +709,128 @@ def extend_attention(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr
             ke = kf[q0:q1, kvh]
             ve = vf[q0:q1, kvh]
             for h in range(kvh * group, (kvh + 1) * group):
+                # All query rows of the (request, head) at once -- the same arithmetic as one row at a time
+                # (_extend_attention_rows below keeps that form; tests/test_oracle_golden.py holds the two together).
+                if e == 0:
+                    continue
+                M = np.arange(e)
+                Q = qf[q0:q1, h]
+                xai = np.ones(e)
+                if xai_temperature_len > 0:
+                    a = (p_len + M).astype(np.float64)
+                    xai = np.where(a > xai_temperature_len, np.log2(np.maximum(a, 1.0)) / math.log2(float(xai_temperature_len)), 1.0)
+                bias = None if score_bias is None else np.asarray(score_bias[q0:q1, h], dtype=np.float64)
+
+                def _bias(rel):  # [e, n] distances -> the rows' bias values, 0 outside [0, extent)
+                    ok = (rel >= 0) & (rel < bias.shape[1])
+                    return np.where(ok, np.take_along_axis(bias, np.clip(rel, 0, bias.shape[1] - 1), axis=1), 0.0)
+
+                parts_s, parts_v = [], []
+                if kp.shape[0]:
+                    N = np.arange(p_len)
+                    s1 = _tanh_cap((Q @ kp.T) * (sm_scale * k_scale), logit_cap) * xai[:, None]
+                    if bias is not None:
+                        s1 = s1 + _bias((p_len + M)[:, None] - N[None, :])
+                    if cm is not None and not skip_prefix_custom_mask:
+                        s1 = np.where(cm[:, :p_len], s1, -np.inf)
+                    if sliding_window_size > 0:
+                        s1 = np.where((p_len + M)[:, None] <= N[None, :] + sliding_window_size, s1, -np.inf)
+                    parts_s.append(s1); parts_v.append(vp * v_scale)
+                if not skip_extend:
+                    N = np.arange(e)
+                    s2 = _tanh_cap((Q @ ke.T) * sm_scale, logit_cap) * xai[:, None]
+                    if bias is not None:
+                        s2 = s2 + _bias(M[:, None] - N[None, :])
+                    if cm is not None:
+                        s2 = np.where(cm[:, p_len: p_len + e], s2, -np.inf)
+                    elif is_causal:  # (row m's list ends at key m)
+                        s2 = np.where(N[None, :] <= M[:, None], s2, -np.inf)
+                    if sliding_window_size > 0:
+                        s2 = np.where(M[:, None] <= N[None, :] + sliding_window_size, s2, -np.inf)
+                    parts_s.append(s2); parts_v.append(ve)
+                if not parts_s:
+                    continue
+                sc = np.concatenate(parts_s, axis=1)
+                vv = np.concatenate(parts_v, axis=0)
+                if sc.shape[1] == 0:
+                    continue
+                mx = sc.max(axis=1)
+                live = np.isfinite(mx)
+                pm = np.exp(sc - np.where(live, mx, 0.0)[:, None])
+                den = pm.sum(axis=1)
+                rows = q0 + M[live]
+                with np.errstate(divide="ignore"):
+                    lse[rows, h] = (mx + np.log(den))[live]
+                if sinks is not None:
+                    den = den + np.exp(float(sinks[h]) - np.where(live, mx, 0.0))
+                den = np.where(live, den, 1.0)
+                o[rows, h] = ((pm @ vv) / den[:, None])[live]
+                if return_absw:
+                    oa[rows, h] = ((pm @ np.abs(vv)) / den[:, None])[live]
+    res = (o, lse) if return_lse else o
+    if return_absw:
+        return (res + (oa,)) if return_lse else (o, oa)
+    return res
+
+
+def _extend_attention_rows(q_extend, k_extend, v_extend, k_buffer, v_buffer, qo_indptr,
+                     kv_indptr, kv_indices, is_causal=True, sm_scale=None,
+                     k_scale=1.0, v_scale=1.0, logit_cap=0.0,
+                     sliding_window_size=-1, sinks=None, skip_prefix=False,
+                     skip_extend=False, return_lse=False, custom_mask=None, mask_indptr=None,
+                     skip_prefix_custom_mask=True, window_kv_offsets=None, xai_temperature_len=-1, score_bias=None,
+                     return_absw=False):
+    """extend_attention one query row at a time: the form the restatement was pinned in (rounds 1-5); kept as the cross-check of
+    the row-vectorised function above (same arguments, same results up to fp64 summation order).
+    return_absw: also return sum_j p_j |v_j| (see decode_attention) as the last element of the result.
+    score_bias [T, Hq, extent] (float): score_mod = relative_bias_score_mod, aux_tensors = [score_bias]
+    (extend_attention.py:463-476 prefix stage: q_pos = P + m, kv_pos = list position; :594-607 extend stage:
+    kv_pos = P + n; q_idx = global query token), added after scale, cap and temperature, before the masks.
+    Semantics of extend_attention_fwd (extend_attention.py:664-812).  Request i
+    has prefix tokens kv_indices[kv_indptr[i]:kv_indptr[i+1]] read from the cache
+    (stage 1, :372-510; scaled by k_scale / v_scale) and E_i = qo_indptr[i+1]-
+    qo_indptr[i] new tokens whose K/V are the contiguous k_extend/v_extend rows
+    (stage 2, :512-631).  Query m (0-based inside the extend part) sees every
+    prefix token and extend tokens n <= m when causal, all E_i otherwise.
+    sliding window W>0: q_abs <= kv_abs + W (:385-390, :556-561).
+    custom_mask (speculative tree attention, :320-326, :378-390, :525-539): request i owns the flat
+    bytes mask[mask_indptr[i]:], a row-major [E_i, woff_i + P_i + E_i] matrix (woff = window_kv_offsets,
+    0 without SWA); in the extend part it REPLACES the causal mask, in the prefix part it applies
+    unless skip_prefix_custom_mask.  xai_temperature_len L>0 (:336-343, :460, :591): scores of the
+    query at absolute position a = P_i + m are multiplied by log2(a)/log2(L) when a > L, after scale
+    and cap.  Rows with nothing visible come out NaN in the reference (0/0); here they stay 0.
+    Returns o float64 [T,Hq,Dv] (+ lse [T,Hq])."""
+    t, hq, dq = q_extend.shape
+    hkv = k_extend.shape[1]
+    dv = v_extend.shape[-1]
+    group = hq // hkv
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(dq)
+    qf, kf, vf = to_f64(q_extend), to_f64(k_extend), to_f64(v_extend)
+    o = np.zeros((t, hq, dv), dtype=np.float64)
+    oa = np.zeros((t, hq, dv), dtype=np.float64) if return_absw else None
+    lse = np.full((t, hq), -np.inf, dtype=np.float64)
+    bs = len(qo_indptr) - 1
+    for i in range(bs):
+        q0, q1 = int(qo_indptr[i]), int(qo_indptr[i + 1])
+        e = q1 - q0
+        idx = np.asarray(kv_indices[kv_indptr[i] : kv_indptr[i + 1]]).astype(np.int64)
+        p_len = idx.size
+        cm = None
+        if custom_mask is not None:
+            woff = int(window_kv_offsets[i]) if window_kv_offsets is not None else 0
+            row = woff + p_len + e
+            m0 = int(mask_indptr[i])
+            cm = np.asarray(custom_mask[m0 : m0 + e * row]).astype(bool).reshape(e, row)[:, woff:]
+        for kvh in range(hkv):
+            if p_len and not skip_prefix:
+                kp = _gather_kv(k_buffer, idx, kvh)
+                vp = _gather_kv(v_buffer, idx, kvh)
+            else:
+                kp = np.zeros((0, dq)); vp = np.zeros((0, dv))
+            ke = kf[q0:q1, kvh]
+            ve = vf[q0:q1, kvh]
+            for h in range(kvh * group, (kvh + 1) * group):
                 for m in range(e):
                     parts_s, parts_v = [], []
                     xai = 1.0
@@ -761,6 +883,75 @@ def extend_attention_unified(q, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_ind
                              sinks=None, custom_mask=None, mask_indptr=None, xai_temperature_len=-1, score_bias=None,
                              return_absw=False):
     """return_absw: also return sum_j p_j |v_j| (see decode_attention).
+    score_bias [T, Hq, extent]: relative_bias_score_mod through :1093-1104 (q_pos = prefix_i + m, kv_pos = list position).
+    Semantics of extend_attention_fwd_unified / _fwd_kernel_unified (extend_attention.py:852-1158): one pass
+    over a kv list holding prefix + new tokens.  Query m of request i sees list position n iff n < prefix_i or
+    n - prefix_i <= m (causal, :993-1008), window prefix_i + m <= n + W (:1010-1027); a custom mask row is
+    kv_len wide and replaces the causal rule (:980-990); xai factor L / (prefix_i + m + 1) once
+    prefix_i + m >= L (:940-946)."""
+    t, hq, dq = q.shape
+    hkv = k_buffer.shape[-2]
+    dv = v_buffer.shape[-1]
+    group = hq // hkv
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(dq)
+    qf = to_f64(q)
+    o = np.zeros((t, hq, dv), dtype=np.float64)
+    oa = np.zeros((t, hq, dv), dtype=np.float64) if return_absw else None
+    for i in range(len(qo_indptr) - 1):
+        q0, q1 = int(qo_indptr[i]), int(qo_indptr[i + 1])
+        e = q1 - q0
+        idx = np.asarray(kv_indices[kv_indptr[i]: kv_indptr[i + 1]]).astype(np.int64)
+        n_kv, pre = idx.size, int(prefix_lens[i])
+        cm = None
+        if custom_mask is not None:
+            m0 = int(mask_indptr[i])
+            cm = np.asarray(custom_mask[m0: m0 + e * n_kv]).astype(bool).reshape(e, n_kv)
+        pos = np.arange(n_kv)
+        for kvh in range(hkv):
+            kk, vv = _gather_kv(k_buffer, idx, kvh), _gather_kv(v_buffer, idx, kvh)
+            for h in range(kvh * group, (kvh + 1) * group):
+                if e == 0 or n_kv == 0:
+                    continue
+                M = np.arange(e)
+                Q = qf[q0:q1, h]
+                xai = np.ones(e)
+                if xai_temperature_len > 0:
+                    xai = np.where(pre + M >= xai_temperature_len, xai_temperature_len / (pre + M + 1.0), 1.0)
+                sc = _tanh_cap((Q @ kk.T) * (sm_scale * k_scale), logit_cap) * xai[:, None]
+                if score_bias is not None:
+                    bias = np.asarray(score_bias[q0:q1, h], dtype=np.float64)
+                    rel = (pre + M)[:, None] - pos[None, :]
+                    ok = (rel >= 0) & (rel < bias.shape[1])
+                    sc = sc + np.where(ok, np.take_along_axis(bias, np.clip(rel, 0, bias.shape[1] - 1), axis=1), 0.0)
+                keep = np.ones((e, n_kv), dtype=bool)
+                if cm is not None:
+                    keep &= cm
+                elif is_causal:
+                    keep &= (pos[None, :] < pre) | (pos[None, :] - pre <= M[:, None])
+                if sliding_window_size > 0:
+                    keep &= (pre + M)[:, None] <= (pos[None, :] + sliding_window_size)
+                sc = np.where(keep, sc, -np.inf)
+                mx = sc.max(axis=1)
+                live = np.isfinite(mx)
+                pm = np.exp(sc - np.where(live, mx, 0.0)[:, None])
+                den = pm.sum(axis=1)
+                if sinks is not None:
+                    den = den + np.exp(float(sinks[h]) - np.where(live, mx, 0.0))
+                den = np.where(live, den, 1.0)
+                rows = q0 + M[live]
+                o[rows, h] = ((pm @ vv) / den[:, None] * v_scale)[live]
+                if return_absw:
+                    oa[rows, h] = ((pm @ np.abs(vv)) / den[:, None] * v_scale)[live]
+    return (o, oa) if return_absw else o
+
+
+def _extend_attention_unified_rows(q, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, prefix_lens, sm_scale=None,
+                             k_scale=1.0, v_scale=1.0, logit_cap=0.0, is_causal=True, sliding_window_size=-1,
+                             sinks=None, custom_mask=None, mask_indptr=None, xai_temperature_len=-1, score_bias=None,
+                             return_absw=False):
+    """extend_attention_unified one query row at a time (the form it was pinned in; the cross-check of the row-vectorised
+    function above).  return_absw: also return sum_j p_j |v_j| (see decode_attention).
     score_bias [T, Hq, extent]: relative_bias_score_mod through :1093-1104 (q_pos = prefix_i + m, kv_pos = list position).
     Semantics of extend_attention_fwd_unified / _fwd_kernel_unified (extend_attention.py:852-1158): one pass
     over a kv list holding prefix + new tokens.  Query m of request i sees list position n iff n < prefix_i or

@@ -369,6 +369,54 @@ def test_unified_kv_indices_golden(golden_dir):
         assert np.array_equal(pl, c["prefix_lens"]), name
 
 
+def test_row_vectorised_extend_oracle_equals_its_row_at_a_time_form():
+    """The extend oracles work on all query rows of a (request, head) at once (round 5: the GPU suite's wall time was
+    mostly their per-row Python loops); the row-at-a-time forms they were pinned in stay in the module and must agree to
+    fp64 summation order on every feature: causal / not, window, cap + temperature, tree masks (prefix masked or not),
+    relative bias + sinks, skip_prefix / skip_extend, scales -- and on which rows see nothing."""
+    rng = np.random.default_rng(1)
+    hq, hkv, d = 8, 2, 32
+    pre, ext = [40, 0, 7], [6, 20, 9]
+    T, pool = sum(ext), sum(pre) + sum(ext) + 9
+    f16 = lambda *sh: rng.standard_normal(sh).astype(np.float16)  # noqa: E731
+    q, ke, ve, kb, vb = f16(T, hq, d), f16(T, hkv, d), f16(T, hkv, d), f16(pool, hkv, d), f16(pool, hkv, d)
+    kvp = np.concatenate([[0], np.cumsum(pre)]).astype(np.int32)
+    perm = rng.permutation(pool - 1) + 1
+    kvi = perm[: sum(pre)]
+    qo = np.concatenate([[0], np.cumsum(ext)])
+    masks, mi = [], [0]
+    for p_, e_ in zip(pre, ext):
+        m = rng.random((e_, p_ + e_)) < 0.6
+        for r in range(e_):
+            m[r, p_ + r] = True
+            m[r, p_ + r + 1:] = False
+        m[0, :p_] = False  # (with the prefix part masked, row 0 sees only itself)
+        masks.append(m.reshape(-1)); mi.append(mi[-1] + m.size)
+    cm, mi = np.concatenate(masks), np.array(mi)
+    aux = rng.standard_normal((T, hq, 11))
+    variants = [dict(), dict(is_causal=False), dict(sliding_window_size=5), dict(logit_cap=20.0, xai_temperature_len=8),
+                dict(custom_mask=cm, mask_indptr=mi, skip_prefix_custom_mask=False), dict(custom_mask=cm, mask_indptr=mi),
+                dict(score_bias=aux, sinks=rng.standard_normal(hq)), dict(skip_prefix=True), dict(skip_extend=True, is_causal=False),
+                dict(k_scale=0.7, v_scale=1.3, score_bias=aux, sliding_window_size=9)]
+    for kw in variants:
+        a = orc.extend_attention(q, ke, ve, kb, vb, qo, kvp, kvi, return_lse=True, return_absw=True, **kw)
+        b = orc._extend_attention_rows(q, ke, ve, kb, vb, qo, kvp, kvi, return_lse=True, return_absw=True, **kw)
+        for x, y in zip(a, b):
+            fin = np.isfinite(y)
+            assert np.array_equal(np.isfinite(x), fin), kw
+            assert np.abs(x[fin] - y[fin]).max() <= 1e-12, kw
+    # unified form: the kv list holds prefix + new tokens
+    tot = np.array(pre) + np.array(ext)
+    ukvp = np.concatenate([[0], np.cumsum(tot)]).astype(np.int32)
+    ukvi = perm[: int(tot.sum())]
+    for kw in [dict(), dict(sliding_window_size=5), dict(logit_cap=20.0, xai_temperature_len=8), dict(custom_mask=cm, mask_indptr=mi),
+               dict(score_bias=aux, sinks=rng.standard_normal(hq), k_scale=0.7, v_scale=1.3), dict(is_causal=False)]:
+        a = orc.extend_attention_unified(q, kb, vb, qo, ukvp, ukvi, np.array(pre), return_absw=True, **kw)
+        b = orc._extend_attention_unified_rows(q, kb, vb, qo, ukvp, ukvi, np.array(pre), return_absw=True, **kw)
+        for x, y in zip(a, b):
+            assert np.abs(x - y).max() <= 1e-12, kw
+
+
 def test_cpu_baseline_container_fixture(golden_dir):
     """SURVEY 8(d) CPU-baseline item (1): the reference's compiled CPU kernel and the C restatement timed in
     the build container on identical inputs (oracle/time_cpu_container.py) -- fixture present and consistent."""
