@@ -995,6 +995,66 @@ def pre_attention_ops_bench(dev):
     return res
 
 
+def extend_forms_bench(dev, nlaunch=20):
+    """The config-3 chunk (32 req x (3584 prefix + 512 new), Hq 32 / Hkv 8, D 128, bf16, page 16 HND shuffled) through the
+    other FORMS of the extend operator (round 5): the one-stage kernel over the unified kv list that deterministic
+    inference runs (rx_build_unified_kv_indices + ops.extend_attention_fwd_unified: every tile takes the one masked body),
+    and score_mod = relative_bias_score_mod with a [T, Hq, 1024] bf16 aux tensor (Inkling's extent) on both forms.
+    TFLOP/s of the attention launch alone against the same FLOP count as the plain leg."""
+    from sglang_amd import lib as rxlib
+    from sglang_amd import ops
+
+    HQ, HKV, D, ps = 32, 8, 128, 16
+    P, E, chunk = 3584, 512, 32
+    g = torch.Generator(device=dev).manual_seed(1)
+    n_pages = (P + chunk * E) // ps + 2
+    kb = torch.randn((n_pages, HKV, ps, D), device=dev, generator=g).to(torch.bfloat16)
+    vb = torch.randn((n_pages, HKV, ps, D), device=dev, generator=g).to(torch.bfloat16)
+    lay = ops.kv_layout_hnd(kb, vb)
+    T = chunk * E
+    q = torch.randn(T, HQ, D, device=dev, generator=g).to(torch.bfloat16)
+    perm = torch.randperm(n_pages - 1, device=dev, generator=g) + 1
+    slots = (perm[:, None] * ps + torch.arange(ps, device=dev)[None, :]).reshape(-1)
+    pre, new = slots[:P].to(torch.int64), slots[P: P + T].to(torch.int64)
+    # the new tokens' K / V as the pool holds them: both forms see the same values
+    kf, vf = kb.permute(0, 2, 1, 3).reshape(-1, HKV, D), vb.permute(0, 2, 1, 3).reshape(-1, HKV, D)
+    ke, ve = kf[new].contiguous(), vf[new].contiguous()
+    kvi = pre.repeat(chunk)
+    kvp = (torch.arange(chunk + 1, device=dev) * P).to(torch.int32)
+    qo = (torch.arange(chunk + 1, device=dev) * E).to(torch.int64)
+    start = (torch.arange(chunk, device=dev) * E).to(torch.int32)
+    elens = torch.full((chunk,), E, dtype=torch.int32, device=dev)
+    u_indptr, u_idx, plens = ops.build_unified_kv_indices(kvp, kvi, start, elens, new, chunk, max_tokens_per_request=P + E)
+    aux = torch.randn(T, HQ, 1024, device=dev, generator=g).to(torch.bfloat16)
+    o1, o2 = torch.empty_like(q), torch.empty_like(q)
+    flops = 4.0 * HQ * D * chunk * (E * P + E * (E + 1) / 2)
+
+    def two_stage(**kw):
+        ops.extend_attention_fwd(q, ke, ve, o1, kb, vb, qo, kvp, kvi, None, True, None, E, 1.0, 1.0, sm_scale=D ** -0.5,
+                                 page_size=ps, kv_layout=lay, **kw)
+
+    def unified(**kw):
+        ops.extend_attention_fwd_unified(q, o2, kb, vb, 1.0, 1.0, qo, u_indptr, u_idx, plens, E, sm_scale=D ** -0.5,
+                                         page_size=ps, kv_layout=lay, **kw)
+
+    bias = dict(score_mod=ops.relative_bias_score_mod, aux_tensors=[aux])
+    res = {"workload": "config-3 chunk, attention launch alone", "flops_per_launch": flops}
+    for name, fn in (("two_stage", two_stage), ("unified_deterministic", unified),
+                     ("two_stage_rel_bias_1024", lambda: two_stage(**bias)), ("unified_rel_bias_1024", lambda: unified(**bias))):
+        gpu_warm(fn, batch=4)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(nlaunch):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / nlaunch
+        res[name] = {"ms_per_launch": ms, "tflops": flops / ms / 1e9, "frac": flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS,
+                     "kernel": "rx::" + rxlib.last_dispatch()}
+    res["max_abs_diff_two_stage_vs_unified"] = (o1.float() - o2.float()).abs().max().item()
+    return res
+
+
 def extend_head_dims(args, dev):
     """The same config-3 chunk at the other head dims the reference tunes for gfx950 (extend_attention.py:66-77):
     64, 256, and the MLA prefill shape 192 / 128; plus 96 (Phi-3-class heads)."""
@@ -1480,6 +1540,10 @@ def compact_record(out):
             v = _get(ext, "mla_latent", "v_view_of_k", "frac_of_mfma_peak")
             if v is not None:
                 e["mla_latent_frac"] = _r(v, 4)
+            for key, name in (("unified_deterministic", "deterministic_unified_frac"), ("two_stage_rel_bias_1024", "rel_bias_1024_frac")):
+                v = _get(ext, "forms", key, "frac")
+                if v is not None:
+                    e[name] = _r(v, 4)
             pk = ext.get("peaked_input")
             if isinstance(pk, dict) and isinstance(pk.get("peaked"), dict):  # sigma = 4 nats + recency ramp: frac and redo rate
                 e["peaked_input"] = {"frac": _r(pk["peaked"].get("frac"), 4), "redo_rate": _r(pk["peaked"].get("redo_rate"), 5),
@@ -1736,6 +1800,10 @@ def main():
             out["extend"] = extend_bench(args, dev, world)
             out["extend"]["other_head_dims"] = extend_head_dims(args, dev)
             out["extend"]["mla_latent"] = mla_extend_bench(dev)
+            try:
+                out["extend"]["forms"] = extend_forms_bench(dev)
+            except Exception as e:  # noqa: BLE001
+                out["extend"]["forms"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_peaked:
                 out["extend"]["peaked_input"] = extend_peaked_bench(args, dev)
         except Exception as e:
