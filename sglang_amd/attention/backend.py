@@ -90,6 +90,9 @@ class ForwardMetadata:
     # decode, length-aware schedule: the live (request, split) pairs, compacted (ops.SplitItems)
     split_items: Optional[object] = None
     draft: bool = False  # kv_indptr / kv_indices came from spec_info (multi-step draft decode: one row per top-k branch)
+    # deterministic inference: the unified kv list of this forward, built by the first layer that needs it --
+    # {is sliding-window layer: (unified_kv_indptr, unified_kv_indices, prefix_lens)}
+    unified: Optional[dict] = None
 
 
 def host_num_kv_splits(seq_lens: np.ndarray, num_head: int, num_kv_head: int, max_kv_splits: int,
@@ -1271,7 +1274,9 @@ class HipRadixAttnBackend:
         bs = forward_batch.batch_size
         swa = (layer.sliding_window_size is not None and layer.sliding_window_size > -1 and md.window_kv_indptr is not None)
         window = layer.sliding_window_size if (layer.sliding_window_size is not None and layer.sliding_window_size > -1) else -1
-        cache = md.__dict__.setdefault("_unified", {})
+        if md.unified is None:
+            md.unified = {}
+        cache = md.unified
         if swa not in cache:
             pre_indptr, pre_indices = (md.window_kv_indptr, md.window_kv_indices) if swa else (md.kv_indptr, md.kv_indices)
             ext_lens = forward_batch.extend_seq_lens
