@@ -2,7 +2,7 @@
 """Dev sweep: dense decode kernel time vs (batch, ctx, forced split count) at Llama-3-8B head geometry.
 env: HQ / HKV (head counts, default 32 / 8), SHAPES (e.g. 256x4096,1x32768), SPLITS (e.g. 1,2,8), NS (live splits of the
 S allocated), GRAPH=1 (20 calls captured once: GPU time without the host), MC=1 (in-kernel stage 2: merge_counters),
-CONTIG=1 (pages in order instead of shuffled), VPAD=<bytes> (K and V in one allocation, V displaced)."""
+CONTIG=1 (pages in order instead of shuffled), INTERLEAVE=1 (K and V pages side by side in one allocation), VPAD=<bytes> (K and V in one allocation, V displaced)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,11 +19,16 @@ def run(bs, ctx, splits_list):
     rpi = torch.arange(1, bs + 1, device=dev); lens = torch.full((bs,), ctx, dtype=torch.int64, device=dev)
     pool = (bs * pages + 1) * PS
     kb = torch.randn(pool // PS, HKV, PS, D, device=dev).to(torch.bfloat16)
+    if os.environ.get("INTERLEAVE"):  # K and V pages of one allocation side by side: [pages, 2, Hkv, page, D] (strides are arguments)
+        big = torch.randn(pool // PS, 2, HKV, PS, D, device=dev).to(torch.bfloat16)
+        kb = big[:, 0]
     if os.environ.get("VPAD"):  # K and V in ONE allocation, V displaced by VPAD bytes past K's end (DRAM channel / bank aliasing probe)
         pad = int(os.environ["VPAD"]) // 2
         big = torch.empty(2 * kb.numel() + pad + 64, dtype=torch.bfloat16, device=dev)
         big[: kb.numel()].copy_(kb.view(-1)); kb = big[: kb.numel()].view(kb.shape)
         vb = big[kb.numel() + pad: 2 * kb.numel() + pad].view(kb.shape); vb.normal_()
+    elif os.environ.get("INTERLEAVE"):
+        vb = big[:, 1]
     else:
         vb = torch.randn_like(kb)
     lay = ops.kv_layout_hnd(kb, vb)
