@@ -42,6 +42,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s flo
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
 
+# (q heads, kv heads, head dim, hidden size) of the models BASELINE.json's configs name
+MODELS = {"llama3-8b": (32, 8, 128, 4096), "llama3-70b": (64, 8, 128, 8192)}
+MODEL_NAMES = {"llama3-8b": "Llama-3-8B", "llama3-70b": "Llama-3-70B"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +56,8 @@ def parse():
     ap.add_argument("--bs", type=int, default=256)
     ap.add_argument("--ctx", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--model", default="llama3-8b", choices=sorted(MODELS),
+                    help="head geometry of the decode step (the headline is llama3-8b; llama3-70b serves BASELINE configs[3]'s leg)")
     ap.add_argument("--page-size", type=int, default=16)
     ap.add_argument("--index-mode", default="paged", choices=["paged", "indices"])
     ap.add_argument("--kv-layout", default="hnd", choices=["nhd", "hnd"],
@@ -146,7 +153,7 @@ def make_decode_state(args, tp, dev, shared_prefix=0, cascade=False):
     from sglang_amd.attention.radix_attention import RadixAttention
     from sglang_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool
 
-    HQ, HKV, D, HID = 32, 8, 128, 4096
+    HQ, HKV, D, HID = MODELS[args.model]
     hq, hkv = HQ // tp, max(1, HKV // tp)
     bs, ctx, ps, L = args.bs, args.ctx, args.page_size, args.layers
     pages_per_req = (ctx + ps - 1) // ps
@@ -908,6 +915,16 @@ def child_decode_leg(args, argv, timeout=900):
             "seq_lens": d["config"]["seq_lens"], "step_launch": d["config"]["step_launch"]}
 
 
+def dict_args(args, **over):
+    """A copy of the parsed arguments with some fields replaced (child legs that differ in more than their argv tail)."""
+    import copy
+
+    a = copy.copy(args)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
 def extra_legs(args, dev):
     """Legs next to the headline, each the same step measured on another input:
     * tp_sim: ONE rank's shard of the TP = 2 / 4 / 8 step on this one GPU (Hq / tp, Hkv / tp heads; no collective) -- what
@@ -933,6 +950,11 @@ def extra_legs(args, dev):
     except Exception as e:  # noqa: BLE001
         c1["prefill_extend"] = {"error": f"{type(e).__name__}: {e}"}
     ex["config1"] = c1
+    # BASELINE configs[3]: Llama-3-70B bf16 TP=8, bs=128, 4k ctx -- ONE rank's shard of its decode step (8 q heads over one
+    # kv head, hidden 8192, 80 layers) on this one GPU; the all-reduce it overlaps is the N > 1 path's business
+    ex["config3"] = {"workload": "BASELINE configs[3]: Llama-3-70B bf16 TP=8, bs=128, 4k ctx: one rank's shard, no collective",
+                     "decode": child_decode_leg(dict_args(args, layers=80), ["--model", "llama3-70b", "--tp-sim", "8", "--bs", "128",
+                                                                          "--ctx", "4096", "--page-size", str(args.page_size)])}
     try:
         ex["pre_attention_ops"] = pre_attention_ops_bench(dev)
     except Exception as e:  # noqa: BLE001
@@ -1498,7 +1520,8 @@ def compact_record(out):
     c["metric"] = "decode tokens/sec + extend TFLOPS, Llama-3-8B bs=256 ctx=4k (value = decode tokens/s; extend under roofline.extend)"
     c["value"], c["ms_per_step"] = _r(out["value"], 1), _r(out["ms_per_step"], 4)
     cfg = out["config"]
-    c["config"] = {"workload": "configs[2] decode: Llama-3-8B bf16 attention path (KV store + paged decode attn + o_proj"
+    model = next((n for n in MODEL_NAMES.values() if n in cfg["workload"]), "Llama-3-8B")  # (a dev run of another model's leg says so)
+    c["config"] = {"workload": "configs[2] decode: " + model + " bf16 attention path (KV store + paged decode attn + o_proj"
                                + (" + all-reduce" if out["n_gpus"] > 1 else "") + " per layer), bs=%d ctx=%d, %d layer pools, "
                                "page %s shuffled %s, %s" % (cfg["global_batch"], cfg["seq_len"], cfg["distinct_layer_buffers"],
                                                             cfg["workload"].split("page_size=")[1].split(" ")[0],
@@ -1562,6 +1585,7 @@ def compact_record(out):
                       ("tp8_ms_per_step", ("extra", "tp_sim", "tp8", "ms_per_step")),
                       ("ragged_kernel_frac", ("extra", "ragged_decode", "kernel_frac_of_hbm_peak")),
                       ("config1_decode_kernel_frac", ("extra", "config1", "decode", "kernel_frac_of_hbm_peak")),
+                      ("config3_70b_tp8_shard_kernel_frac", ("extra", "config3", "decode", "kernel_frac_of_hbm_peak")),
                       ("radix_hit_cascade_tok_s", ("radix_hit_decode", "cascade_decode", "tokens_per_s")),
                       ("rope_store_frac", ("extra", "pre_attention_ops", "rope_store_kv", "frac_of_hbm_peak")),
                       ("qknorm_rope_store_frac", ("extra", "pre_attention_ops", "qknorm_rope_store_kv", "frac_of_hbm_peak"))):
@@ -1770,10 +1794,10 @@ def main():
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "configs[2]-shaped decode: Llama-3-8B bf16 attention path, bs=%d, ctx=%d, "
+        "config": {"workload": "configs[2]-shaped decode: %s bf16 attention path, bs=%d, ctx=%d, "
                                "%d layers, page_size=%d shuffled pages, %s KV layout, TP=%d (Hq=%d,Hkv=%d per GPU), "
                                "per layer: KV store + paged decode attention + o_proj GEMM%s"
-                               % (bs, ctx, L, args.page_size, args.kv_layout.upper(), tp, st.hq, st.hkv,
+                               % (MODEL_NAMES[args.model], bs, ctx, L, args.page_size, args.kv_layout.upper(), tp, st.hq, st.hkv,
                                   " + all-reduce (side stream, one in flight)" if world > 1 else ""),
                    "global_batch": bs, "seq_len": ctx, "parallelism": f"tp{tp}",
                    "seq_lens": ("uniform int in [%d, %d], seed 0 (mean %.0f)" % (ctx // 2, ctx, float(st.seq_lens_cpu.float().mean()))
