@@ -231,3 +231,29 @@ def test_target_verify_under_deterministic_mode():
     want, absw = parity.want_and_absw(orc.extend_attention, (q.view(T, hq, d).cpu().numpy(), ke, ve, kbn, vbn, qo, kv_indptr, kv_indices),
                                       (2, 4), is_causal=True, sm_scale=d ** -0.5, custom_mask=cm, mask_indptr=mi, skip_prefix_custom_mask=False)
     parity.check_out(o.view(T, hq, d).float().cpu().numpy(), want, torch.float16, "deterministic target verify", absw=absw)
+
+
+def test_window_start_pos_shifts_both_sides_of_the_window_test_and_cancels(golden_dir):
+    """extend_attention_fwd_unified's window_start_pos (extend_attention.py:1010-1027): the reference adds it to the query's
+    AND the key's absolute position before the window test, so any value gives the same mask; here the argument is accepted
+    and has no effect -- checked against the reference's own sliding-window output (F12 `swa`, produced with zeros) while
+    passing non-zero starts."""
+    from sglang_amd import ops
+
+    z = np.load(os.path.join(golden_dir, "extend_unified.npz"))
+    c = {k.split(".", 1)[1]: z[k] for k in z.files if k.startswith("swa.")}
+    q, kb, vb = _t(c["q"]), _t(c["kb"]), _t(c["vb"])
+    outs = []
+    for wsp in (None, torch.tensor([7, 123], dtype=torch.int32, device=DEV)):
+        o = torch.zeros_like(q)
+        ops.extend_attention_fwd_unified(q, o, kb, vb, 1.0, 1.0, _t(c["qo_indptr"]), _t(c["kv_indptr"]), _t(c["kv_indices"]),
+                                         _t(c["prefix_lens"]), int(np.diff(c["qo_indptr"]).max()), sm_scale=float(c["sm_scale"]),
+                                         sliding_window_size=int(c["window"]), window_start_pos=wsp)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    want = c["o"].astype(np.float64)
+    ok = np.isfinite(want).all(axis=-1)
+    ref, absw = parity.want_and_absw(orc.extend_attention_unified, (c["q"], c["kb"], c["vb"], c["qo_indptr"], c["kv_indptr"], c["kv_indices"],
+                                                                  c["prefix_lens"]), (2,), sm_scale=float(c["sm_scale"]),
+                                     sliding_window_size=int(c["window"]))
+    parity.check_out(outs[1].float().cpu().numpy()[ok], want[ok], torch.float16, "window_start_pos vs triton golden", ulps=2, absw=2 * absw[ok])
