@@ -50,7 +50,7 @@ def derived(c):
 
 
 JOBS = [
-    (tag + "_extend32_sq_counters.json", "ext32", "extend_mfma32_kernel", "python3 bench.py --extend-only (config-3 chunk, D = 128, the dispatched eight-wave kernel)"),
+    (tag + "_extend32_sq_counters.json", "ext32", "extend_mfma32_kernel<rx::BF16, long, false, false, 8, false, true, 4>", "python3 bench.py --extend-only (config-3 chunk, D = 128, the dispatched eight-wave packed PLAIN instance only: the forms leg runs other instances)"),
     (tag + "_extend_d256_sq_counters.json", "dims", "extend_d256_kernel<rx::BF16, 256", "DIMS=256x256,64x64,192x128 python3 tools/extend_dims.py (config-3 chunk at D = 256)"),
     (tag + "_extend_d64_sq_counters.json", "dims", "extend_d256_kernel<rx::BF16, 64", "the same run, D = 64 (config 0's head dim; on the D = 256 kernel's template)"),
     (tag + "_mla_decode_fp8_sq_counters.json", "mla8", "decode_mla8", "PS=64 FP8=1 python3 tools/mla_bench.py (config-5 shard shape, fp8 rows)"),
