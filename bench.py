@@ -630,6 +630,56 @@ def cpu_baseline(args, leg="decode"):
     return {"value": None, "unit": unit, "cores": 0, "kind": "port", "sample": "; ".join(errors)}
 
 
+
+def parity_vs_reference_cpu(dev, bs=256, ctx=4096, hq=32, hkv=8):
+    """The headline decode launch (fused-store instance, page-16 shuffled HND pool) against the reference's own compiled
+    `decode_attention_cpu` on IDENTICAL tensors: the CPU-only child tests/ref_cpu_child.py builds the
+    seeded case, runs the reference kernel (oracle/_ref) and leaves inputs + output as .npy; this process runs the HIP launch
+    on them.  Reported: max-abs error, the reference test's own tolerance (test/registered/cpu/test_decode.py:266) and
+    whether it holds.  The same comparison is asserted in tests/test_gpu_vs_reference_cpu.py."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    from sglang_amd import lib as rxlib
+    from sglang_amd import ops
+
+    D, ps = 128, 16
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    out = tempfile.mkdtemp(prefix="rx_refcpu_", dir=base)
+    try:
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(os.cpu_count()), OMP_WAIT_POLICY="passive")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_cpu_child.py"), "--kind", "decode", "--out", out,
+                            "--bs", str(bs), "--ctx", str(ctx), "--hq", str(hq), "--hkv", str(hkv), "--d", str(D), "--ps", str(ps)],
+                           capture_output=True, text=True, env=env, timeout=600)
+        if r.returncode != 0:
+            return {"error": f"reference child rc={r.returncode}: {r.stderr.strip()[-200:]}"}
+
+        def load(name, bf16=False):
+            t = torch.from_numpy(np.ascontiguousarray(np.load(os.path.join(out, name + ".npy"), mmap_mode="r"))).to(dev)
+            return t.view(torch.bfloat16) if bf16 else t
+
+        kb, vb = load("k_buffer", True), load("v_buffer", True)
+        kh = kb.view(-1, ps, hkv, D).permute(0, 2, 1, 3).contiguous()
+        vh = vb.view(-1, ps, hkv, D).permute(0, 2, 1, 3).contiguous()
+        del kb, vb
+        q, k_new, v_new = load("q", True), load("k_new", True), load("v_new", True)
+        r2t, lens, want = load("req_to_token"), load("seq_lens"), load("out", True)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    rpi = torch.arange(1, bs + 1, dtype=torch.int64, device=dev)
+    o = torch.empty_like(q)
+    ops.decode_attention_fwd_paged(q, kh, vh, o, r2t, rpi, lens, None, None, None, 1, D ** -0.5, page_size=ps,
+                                   kv_layout=ops.kv_layout_hnd(kh, vh), k_new=k_new, v_new=v_new)
+    torch.cuda.synchronize()
+    diff = (o.float() - want.float()).abs()
+    err = float(diff.max().item())
+    ok = bool((diff <= 3e-2 + 1e-6 * want.float().abs()).all().item())
+    return {"max_abs_err": err, "atol": 3e-2, "rtol": 1e-6, "within_reference_tolerance": ok,
+            "kernel": "rx::" + rxlib.last_dispatch(),
+            "what": f"rx_decode_attn vs decode_attention_cpu (oracle/_ref) on identical tensors: bs={bs} ctx={ctx} Hq={hq} Hkv={hkv} "
+                    f"D={D} bf16, page {ps} shuffled, KV store of the step included; bound = test/registered/cpu/test_decode.py:266"}
+
 def gpu_warm(fn, ms=80.0, batch=8):
     """Run ``fn`` back to back for about ``ms`` of wall time right before a timed region.  After idle the chip takes tens
     of milliseconds of sustained load to reach the clock it then holds (tools/probe/cold_start.py: the first ~30 launches
@@ -1517,82 +1567,96 @@ def compact_record(out):
     rf = out["roofline"]
     c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                              "scaling", "vs_baseline", "dtype", "data")}
-    c["metric"] = "decode tokens/sec + extend TFLOPS, Llama-3-8B bs=256 ctx=4k (value = decode tokens/s; extend under roofline.extend)"
-    c["value"], c["ms_per_step"] = _r(out["value"], 1), _r(out["ms_per_step"], 4)
     cfg = out["config"]
     model = next((n for n in MODEL_NAMES.values() if n in cfg["workload"]), "Llama-3-8B")  # (a dev run of another model's leg says so)
+    ctx_txt = "%dk" % (cfg["seq_len"] // 1024) if cfg["seq_len"] % 1024 == 0 else str(cfg["seq_len"])
+    c["metric"] = ("decode tokens/sec + extend TFLOPS, %s bs=%d ctx=%s (value = decode tokens/s; extend half = roofline.extend_*)"
+                   % (model, cfg["global_batch"], ctx_txt))
+    c["value"], c["ms_per_step"] = _r(out["value"], 1), _r(out["ms_per_step"], 4)
     c["config"] = {"workload": "configs[2] decode: " + model + " bf16 attention path (KV store + paged decode attn + o_proj"
                                + (" + all-reduce" if out["n_gpus"] > 1 else "") + " per layer), bs=%d ctx=%d, %d layer pools, "
                                "page %s shuffled %s, %s" % (cfg["global_batch"], cfg["seq_len"], cfg["distinct_layer_buffers"],
-                                                            cfg["workload"].split("page_size=")[1].split(" ")[0],
+                                                            (cfg["workload"].split("page_size=") + ["?"])[1].split(" ")[0],
                                                             cfg["kv_layout"].upper(), cfg["step_launch"].split(" (")[0]),
                    "global_batch": cfg["global_batch"], "seq_len": cfg["seq_len"], "parallelism": cfg["parallelism"]}
     if cfg.get("all_reduce", "none") != "none":
         c["config"]["all_reduce"] = cfg["all_reduce"]
     if "tp_sim" in cfg:
         c["config"]["tp_sim"] = cfg["tp_sim"]
-    r = {k: _r(rf[k], 4) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-    r["kernel"] = rf["kernel"].split("|")[0]
-    r["bytes_per_launch"], r["avg_launch_ms"], r["launches"] = rf["bytes_per_launch"], _r(rf["avg_launch_ms"], 5), rf["launches"]
-    if rf.get("traffic_source"):
-        r["traffic_from"] = rf["traffic_source"]["file"] + " (separate --pmc passes, not this run)"
-    if "per_rank_frac" in rf:
-        r["per_rank_frac"] = [_r(x, 4) for x in rf["per_rank_frac"]]
+    # The driver's parser keeps SCALAR keys of `roofline` only, about two dozen of them (round 5: the nested `extend`
+    # dict and the last two scalars were dropped from BENCH_r05.parsed).  So: the contract's six keys, then the extend half
+    # of the metric as flat scalars, then the decode launch's provenance, then the legs VERDICT r05 sets targets on -- 24
+    # keys; everything else goes to the top-level `more` dict (and the full record).
+    r = {k: _r(rf.get(k), 4) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    more = {}
     ext = out.get("extend")
     if isinstance(ext, dict):
         if "error" in ext:
-            r["extend"] = {"error": str(ext["error"])[:200]}
+            r["extend_error"] = str(ext["error"])[:120]
         else:
-            e = {"tflops": _r(ext["tflops"], 1), "kernel_tflops": _r(_get(ext, "kernel_only", "tflops"), 1),
-                 "frac": _r(_get(ext, "roofline", "frac"), 4), "peak": _get(ext, "roofline", "peak"), "bound": "mfma",
-                 "kernel": ext["kernel"], "ms_per_launch": _r(_get(ext, "kernel_only", "ms_per_launch"), 5),
-                 "flops_per_launch": ext["flops_per_chunk"],
-                 "workload": "configs[2] extend: %d req x (3584 shared-prefix + 512 new) per launch, bf16 D=128; tflops = via "
-                             "backend (metadata + KV store + attn, %d layers), kernel_tflops = attn launch alone"
-                             % (ext["chunk_requests"], ext["layers"])}
-            if "sharding" in ext:
-                e["sharding"] = ext["sharding"]
+            r["extend_frac"] = _r(_get(ext, "roofline", "frac"), 4)
+            r["extend_kernel_tflops"] = _r(_get(ext, "kernel_only", "tflops"), 1)
+            r["extend_tflops"] = _r(ext.get("tflops"), 1)
+            r["extend_ms_per_launch"] = _r(_get(ext, "kernel_only", "ms_per_launch"), 5)
+            r["extend_kernel"] = ext.get("kernel")
+            r["extend_flops_per_launch"] = ext.get("flops_per_chunk")
             sc = ext.get("sustained_clock")
             if isinstance(sc, dict) and "mhz" in sc:  # the clock the launch runs at (power-capped on random operands) and the frac against the peak AT that clock
-                e["sclk_mhz"] = _r(sc["mhz"], 0)
-                e["frac_at_sclk"] = _r(sc["frac_at_this_clock"], 4)
+                r["extend_frac_at_sclk"] = _r(sc.get("frac_at_this_clock"), 4)
+                more["extend_sclk_mhz"] = _r(sc["mhz"], 0)
+            more["extend_workload"] = ("configs[2] extend: %s req x (3584 shared-prefix + 512 new) per launch, bf16 D=128; extend_tflops = via "
+                                       "backend (metadata + KV store + attn, %s layers), extend_kernel_tflops = attn launch alone, "
+                                       "extend_frac = extend_kernel_tflops / 2500" % (ext.get("chunk_requests"), ext.get("layers")))
+            if "sharding" in ext:
+                more["extend_sharding"] = ext["sharding"]
             for name in ("d64", "d96", "d256", "d192_v128"):
                 v = _get(ext, "other_head_dims", name, "frac")
                 if v is not None:
-                    e[name + "_frac"] = _r(v, 4)
+                    more[name + "_frac"] = _r(v, 4)
             v = _get(ext, "mla_latent", "v_view_of_k", "frac_of_mfma_peak")
             if v is not None:
-                e["mla_latent_frac"] = _r(v, 4)
-            for key, name in (("unified_deterministic", "deterministic_unified_frac"), ("two_stage_rel_bias_1024", "rel_bias_1024_frac")):
-                v = _get(ext, "forms", key, "frac")
-                if v is not None:
-                    e[name] = _r(v, 4)
+                more["mla_latent_frac"] = _r(v, 4)
             pk = ext.get("peaked_input")
             if isinstance(pk, dict) and isinstance(pk.get("peaked"), dict):  # sigma = 4 nats + recency ramp: frac and redo rate
-                e["peaked_input"] = {"frac": _r(pk["peaked"].get("frac"), 4), "redo_rate": _r(pk["peaked"].get("redo_rate"), 5),
-                                     "gaussian_redo_rate": _r(_get(pk, "gaussian", "redo_rate"), 5)}
+                more["peaked_input_frac"] = _r(pk["peaked"].get("frac"), 4)
+                more["peaked_input_redo_rate"] = _r(pk["peaked"].get("redo_rate"), 5)
+                more["gaussian_redo_rate"] = _r(_get(pk, "gaussian", "redo_rate"), 5)
             cb = ext.get("cpu_baseline")
             if isinstance(cb, dict) and "value" in cb:
-                e["cpu_tflops"] = _r(cb["value"], 3)
-            r["extend"] = e
-    for key, path in (("prefill2k_kernel_frac", ("extra", "config1", "prefill_extend", "frac_of_mfma_peak")),
-                      ("mla_decode_fp8_op_frac", ("mla_decode", "fp8_rows", "op_frac_of_hbm_peak")),
-                      ("mla_decode_fp8_kernel_frac", ("mla_decode", "fp8_rows", "roofline", "frac")),
-                      ("mla_decode_bf16_op_frac", ("mla_decode", "bf16_rows", "op_frac_of_hbm_peak")),
-                      ("tp2_kernel_frac", ("extra", "tp_sim", "tp2", "kernel_frac_of_hbm_peak")),
-                      ("tp4_kernel_frac", ("extra", "tp_sim", "tp4", "kernel_frac_of_hbm_peak")),
-                      ("tp8_kernel_frac", ("extra", "tp_sim", "tp8", "kernel_frac_of_hbm_peak")),
-                      ("tp8_ms_per_step", ("extra", "tp_sim", "tp8", "ms_per_step")),
-                      ("ragged_kernel_frac", ("extra", "ragged_decode", "kernel_frac_of_hbm_peak")),
-                      ("config1_decode_kernel_frac", ("extra", "config1", "decode", "kernel_frac_of_hbm_peak")),
-                      ("config3_70b_tp8_shard_kernel_frac", ("extra", "config3", "decode", "kernel_frac_of_hbm_peak")),
-                      ("radix_hit_cascade_tok_s", ("radix_hit_decode", "cascade_decode", "tokens_per_s")),
-                      ("rope_store_frac", ("extra", "pre_attention_ops", "rope_store_kv", "frac_of_hbm_peak")),
-                      ("qknorm_rope_store_frac", ("extra", "pre_attention_ops", "qknorm_rope_store_kv", "frac_of_hbm_peak"))):
-        v = _get(out, *path)
-        if v is not None:
-            r[key] = _r(v, 4)
+                more["extend_cpu_tflops"] = _r(cb["value"], 3)
+                if "parity_vs_reference_cpu" in cb:
+                    more["extend_parity_vs_reference_cpu"] = cb["parity_vs_reference_cpu"]
+    r["kernel"] = str(rf.get("kernel", "")).split("|")[0]
+    r["bytes_per_launch"], r["avg_launch_ms"], r["launches"] = rf.get("bytes_per_launch"), _r(rf.get("avg_launch_ms"), 5), rf.get("launches")
+    if "per_rank_frac" in rf:
+        r["per_rank_frac_min"] = _r(min(rf["per_rank_frac"]), 4)
+        more["per_rank_frac"] = [_r(x, 4) for x in rf["per_rank_frac"]]
+    first = (("config3_70b_tp8_shard_kernel_frac", ("extra", "config3", "decode", "kernel_frac_of_hbm_peak")),
+             ("tp8_kernel_frac", ("extra", "tp_sim", "tp8", "kernel_frac_of_hbm_peak")),
+             ("config1_decode_kernel_frac", ("extra", "config1", "decode", "kernel_frac_of_hbm_peak")),
+             ("mla_decode_fp8_op_frac", ("mla_decode", "fp8_rows", "op_frac_of_hbm_peak")),
+             ("deterministic_unified_frac", ("extend", "forms", "unified_deterministic", "frac")),
+             ("rel_bias_1024_frac", ("extend", "forms", "two_stage_rel_bias_1024", "frac")),
+             ("prefill2k_kernel_frac", ("extra", "config1", "prefill_extend", "frac_of_mfma_peak")))
+    rest = (("mla_decode_fp8_kernel_frac", ("mla_decode", "fp8_rows", "roofline", "frac")),
+            ("mla_decode_bf16_op_frac", ("mla_decode", "bf16_rows", "op_frac_of_hbm_peak")),
+            ("tp2_kernel_frac", ("extra", "tp_sim", "tp2", "kernel_frac_of_hbm_peak")),
+            ("tp4_kernel_frac", ("extra", "tp_sim", "tp4", "kernel_frac_of_hbm_peak")),
+            ("tp8_ms_per_step", ("extra", "tp_sim", "tp8", "ms_per_step")),
+            ("ragged_kernel_frac", ("extra", "ragged_decode", "kernel_frac_of_hbm_peak")),
+            ("radix_hit_cascade_tok_s", ("radix_hit_decode", "cascade_decode", "tokens_per_s")),
+            ("rope_store_frac", ("extra", "pre_attention_ops", "rope_store_kv", "frac_of_hbm_peak")),
+            ("qknorm_rope_store_frac", ("extra", "pre_attention_ops", "qknorm_rope_store_kv", "frac_of_hbm_peak")))
+    for dst, table in ((r, first), (more, rest)):
+        for key, path in table:
+            v = _get(out, *path)
+            if v is not None:
+                dst[key] = _r(v, 4)
+    if rf.get("traffic_source"):
+        more["traffic_from"] = rf["traffic_source"]["file"] + " (separate --pmc passes, not this run)"
     c["roofline"] = r
+    if more:
+        c["more"] = more
     ar = out.get("all_reduce")
     if isinstance(ar, dict):
         c["all_reduce"] = {k: _r(ar[k], 4) for k in ("implementation", "alone_us", "step_ms_overlap", "step_ms_no_overlap", "error")
@@ -1608,6 +1672,11 @@ def compact_record(out):
     if isinstance(cb, dict):
         c["cpu_baseline"] = {k: (_r(cb[k], 3) if k != "sample" else str(cb[k])[:96]) for k in ("value", "unit", "cores", "kind", "sample")
                              if k in cb}
+        pv = cb.get("parity_vs_reference_cpu")
+        if isinstance(pv, dict):  # the headline launch vs the reference's compiled kernel on identical tensors
+            c["cpu_baseline"]["parity_vs_reference_cpu_max_abs_err"] = _r(pv.get("max_abs_err"), 6) if "error" not in pv else str(pv["error"])[:96]
+            if "within_reference_tolerance" in pv:
+                c["cpu_baseline"]["parity_within_reference_atol_3e-2"] = pv["within_reference_tolerance"]
     c["full_record"] = "gpurun_out/bench_full.json"
     return c
 
@@ -1625,7 +1694,19 @@ def emit(out, args):
     except OSError:
         pass
     print("[bench-full] " + full, flush=True)
-    print(json.dumps(compact_record(out)), flush=True)
+    try:
+        line = json.dumps(compact_record(out))
+    except Exception as e:  # noqa: BLE001 -- a missing key on a non-default path must not cost the run its final line
+        keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data")
+        mini = {k: out.get(k) for k in keep}
+        rf = out.get("roofline") if isinstance(out.get("roofline"), dict) else {}
+        mini["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        mini["config"] = {"workload": str(_get(out, "config", "workload"))[:200]}
+        mini["cpu_baseline"] = out.get("cpu_baseline")
+        mini["compact_record_error"] = f"{type(e).__name__}: {e}"
+        line = json.dumps(mini)
+    print(line, flush=True)
 
 
 def main():
@@ -1822,16 +1903,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_extend:
         try:
             out["extend"] = extend_bench(args, dev, world)
-            out["extend"]["other_head_dims"] = extend_head_dims(args, dev)
-            out["extend"]["mla_latent"] = mla_extend_bench(dev)
-            try:
-                out["extend"]["forms"] = extend_forms_bench(dev)
-            except Exception as e:  # noqa: BLE001
-                out["extend"]["forms"] = {"error": f"{type(e).__name__}: {e}"}
-            if not args.no_peaked:
-                out["extend"]["peaked_input"] = extend_peaked_bench(args, dev)
         except Exception as e:
             out["extend"] = {"error": str(e)}
+        # the secondary extend legs are fenced one by one: none of them may take the headline extend result down
+        if "error" not in out["extend"]:
+            for key, leg in (("other_head_dims", lambda: extend_head_dims(args, dev)), ("mla_latent", lambda: mla_extend_bench(dev)),
+                             ("forms", lambda: extend_forms_bench(dev)),
+                             ("peaked_input", (lambda: extend_peaked_bench(args, dev)) if not args.no_peaked else None)):
+                if leg is None:
+                    continue
+                try:
+                    out["extend"][key] = leg()
+                except Exception as e:  # noqa: BLE001
+                    out["extend"][key] = {"error": f"{type(e).__name__}: {e}"}
+                    torch.cuda.empty_cache()
     if world > 1 and not args.no_extend:
         # the extend half of the metric at N GPUs: every rank runs ITS head shard of the same config-3 chunk (heads are
         # independent: no exchange inside attention); whole-job TFLOP/s = all ranks' FLOPs / the slowest rank's time
@@ -1885,6 +1970,12 @@ def main():
             out["extra"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
+        if out["cpu_baseline"].get("kind") == "reference" and not args.tp_sim and (args.bs, args.ctx) == (256, 4096):
+            try:
+                torch.cuda.empty_cache()
+                out["cpu_baseline"]["parity_vs_reference_cpu"] = parity_vs_reference_cpu(dev)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"]["parity_vs_reference_cpu"] = {"error": f"{type(e).__name__}: {e}"}
         if isinstance(out.get("extend"), dict) and "error" not in out["extend"]:
             # the extend half of the metric beside its own CPU figure (SURVEY 8d names both CPU kernels)
             out["extend"]["cpu_baseline"] = cpu_baseline(args, leg="extend")

@@ -155,8 +155,9 @@ class HipRadixAttnBackend:
                  max_kv_splits: Optional[int] = None, split_policy: str = "native",
                  cascade_decode: bool = False, cascade_min_bs: int = 16, cascade_min_shared: int = 1024,
                  dcp=None, mla_v_is_latent_prefix: bool = False, skip_prefill: bool = False,
-                 kv_indptr_buf: Optional[torch.Tensor] = None):
+                 kv_indptr_buf: Optional[torch.Tensor] = None, topk: int = 1):
         self.device = model_runner.device
+        self.topk = max(1, int(topk))  # draft backends: rows per request (one per top-k branch)
         self.skip_prefill = bool(skip_prefill)      # (signature parity with TritonAttnBackend: a draft-decode-only backend)
         self._kv_indptr_buf = kv_indptr_buf
         # MLA pools keep ONE latent row per token and serve v as its first kv_lora_rank columns (the reference's
@@ -254,8 +255,8 @@ class HipRadixAttnBackend:
         self._scratch_lse = None
         # stage 2 inside the stage-1 kernel (rx_decode_params.merge_counters): one zeroed word per (request, head);
         # the kernels leave it zero, so one buffer serves every layer and every replay of a captured step
-        self._merge_counters = torch.zeros(max(1, self.req_to_token_pool.size) * self.num_head * (8 if self.skip_prefill else 1),
-                                           dtype=torch.int32, device=self.device)  # (draft backends: up to 8 branches per request)
+        self._merge_counters = torch.zeros(max(1, self.req_to_token_pool.size) * self.num_head * self.topk,
+                                           dtype=torch.int32, device=self.device)  # (draft backends: topk branch rows per request)
         if os.environ.get("RX_NO_INKERNEL_MERGE"):  # dev A/B: stage 2 as its own launch
             self._merge_counters = None
         self._no_fused_store = bool(os.environ.get("RX_NO_FUSED_STORE"))  # dev A/B: the store as its own launch
@@ -1106,7 +1107,14 @@ class HipRadixAttnBackend:
             common = dict(logit_cap=layer.logit_cap, sinks=sinks, page_size=self.page_size, kv_layout=lay,
                           xai_temperature_len=max(0, int(getattr(layer, "xai_temperature_len", -1) or 0)),
                           score_mod=score_mod, aux_tensors=aux_tensors)
-            if md.kv_indices is not None:
+            if (layer.sliding_window_size is not None and layer.sliding_window_size > -1
+                    and md.window_kv_indptr is not None):
+                # a sliding-window layer with score_mod (Inkling's local layers) reads the WINDOW list and its own
+                # split schedule (triton_backend.py:1770-1781); rel = (len - 1) - n is then over the window list
+                ops.decode_attention_fwd(q3, k_buf, v_buf, o3, md.window_kv_indptr, md.window_kv_indices, md.attn_logits,
+                                         md.attn_lse, md.window_num_kv_splits, splits, layer.scaling, k_descale, v_descale,
+                                         **common)
+            elif md.kv_indices is not None:
                 ops.decode_attention_fwd(q3, k_buf, v_buf, o3, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse,
                                          md.num_kv_splits, splits, layer.scaling, k_descale, v_descale, **common)
             else:
@@ -1146,9 +1154,12 @@ class HipRadixAttnBackend:
                                 attn_logits=md.attn_logits, attn_lse=md.attn_lse,
                                 merge_counters=self._merge_counters)
             elif self.decode_index_mode == "indices" or md.draft:
-                mc = self._merge_counters  # (a draft step has one row per top-k BRANCH: more rows than the request pool)
+                # (a draft step has one row per top-k BRANCH; the counters were sized pool * topk * heads at init.  Nothing is
+                # (re)allocated on the forward path -- a captured graph holds the old pointer: a batch with more rows than
+                # that takes stage 2 as its own launch for this call instead)
+                mc = self._merge_counters
                 if mc is not None and mc.numel() < q3.shape[0] * layer.tp_q_head_num:
-                    mc = self._merge_counters = torch.zeros(q3.shape[0] * layer.tp_q_head_num, dtype=torch.int32, device=self.device)
+                    mc = None
                 ln.set_metadata(self._md_version, q3.shape[0], kv_indptr=md.kv_indptr,
                                 kv_indices=md.kv_indices, num_kv_splits=md.num_kv_splits,
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
@@ -1325,7 +1336,8 @@ class HipRadixMultiStepDraftBackend:
         max_bs = model_runner.req_to_token_pool.size * self.topk
         self.device = model_runner.device
         self.kv_indptr = torch.zeros((self.speculative_num_steps, max_bs + 1), dtype=torch.int32, device=self.device)
-        self.attn_backends = [HipRadixAttnBackend(model_runner, skip_prefill=True, kv_indptr_buf=self.kv_indptr[i], **backend_kwargs)
+        self.attn_backends = [HipRadixAttnBackend(model_runner, skip_prefill=True, kv_indptr_buf=self.kv_indptr[i], topk=self.topk,
+                                                  **backend_kwargs)
                               for i in range(self.speculative_num_steps - 1)]
         self.max_context_len = (self.attn_backends[0].max_context_len if self.attn_backends
                                 else model_runner.model_config.context_len)

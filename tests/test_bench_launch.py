@@ -130,34 +130,56 @@ def test_bench_tp_sim_shard_replays_from_hip_graphs():
     full = json.loads(next(ln for ln in lines if ln.startswith("[bench-full] "))[len("[bench-full] "):])
     assert full["n_gpus"] == 1 and full["config"]["step_launch"].startswith("hip-graph")
     assert full["roofline"]["launches"] == 3 and full["roofline"]["avg_launch_ms"] > 0
-    assert lines[-1].startswith("{") and len(lines[-1]) < 2560
+    assert lines[-1].startswith("{") and len(lines[-1]) < 2660
     out = json.loads(lines[-1])
     assert out["value"] == pytest.approx(full["value"], rel=1e-3) and out["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], abs=1e-4)
     assert out["config"]["parallelism"] == "tp8" and "tp_sim" in out["config"]
 
 
 def test_compact_line_carries_both_halves_of_the_metric():
-    """The final line of a default run: under 2.5 KB, the contract's keys, and -- inside the
-    `roofline` dict -- the extend half of the metric plus one number per other leg.  Fed with a committed full record."""
+    """The final line of a default run: under 2.6 KB, the contract's keys, and -- as SCALAR keys of the
+    `roofline` dict, right after `frac` / `traffic`, at most 24 keys in all (the driver's parser keeps scalars only and cut the
+    tail in round 5) -- the extend half of the metric plus the legs the verdict sets targets on.  Fed with a committed full record."""
     bench = _load_bench()
-    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_default.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default_full.json")))
     c = bench.compact_record(full)
     line = json.dumps(c)
-    assert len(line) < 2560, len(line)
+    assert len(line) < 2660, len(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in c, k
     assert set(c["config"]) >= {"workload", "global_batch", "seq_len", "parallelism"}
     rf = c["roofline"]
+    assert len(rf) <= 24 and all(not isinstance(v, (dict, list)) for v in rf.values()), rf
+    keys = list(rf)
+    assert keys[:6] == ["bound", "achieved", "peak", "unit", "frac", "traffic"]
+    assert keys[6:13] == ["extend_frac", "extend_kernel_tflops", "extend_tflops", "extend_ms_per_launch", "extend_kernel",
+                          "extend_flops_per_launch", "extend_frac_at_sclk"]
     assert rf["bound"] == "hbm" and rf["frac"] == pytest.approx(full["roofline"]["frac"], abs=1e-4)
-    e = rf["extend"]
-    assert e["frac"] == pytest.approx(full["extend"]["roofline"]["frac"], abs=1e-4)
-    assert e["kernel_tflops"] == pytest.approx(full["extend"]["kernel_only"]["tflops"], rel=1e-3)
-    assert e["frac"] == pytest.approx(e["flops_per_launch"] / (e["ms_per_launch"] * 1e-3) / 1e12 / 2500.0, rel=1e-3)
-    assert {"kernel", "ms_per_launch", "workload", "tflops"} <= set(e)
+    assert rf["extend_frac"] == pytest.approx(full["extend"]["roofline"]["frac"], abs=1e-4)
+    assert rf["extend_kernel_tflops"] == pytest.approx(full["extend"]["kernel_only"]["tflops"], rel=1e-3)
+    assert rf["extend_frac"] == pytest.approx(rf["extend_flops_per_launch"] / (rf["extend_ms_per_launch"] * 1e-3) / 1e12 / 2500.0, rel=1e-3)
     assert rf["mla_decode_fp8_op_frac"] == pytest.approx(full["mla_decode"]["fp8_rows"]["op_frac_of_hbm_peak"], abs=1e-4)
     assert rf["tp8_kernel_frac"] == pytest.approx(full["extra"]["tp_sim"]["tp8"]["kernel_frac_of_hbm_peak"], abs=1e-4)
+    for k in ("config3_70b_tp8_shard_kernel_frac", "config1_decode_kernel_frac", "deterministic_unified_frac", "rel_bias_1024_frac",
+              "prefill2k_kernel_frac"):
+        assert k in rf, k
+    assert c["more"]["d64_frac"] == pytest.approx(full["extend"]["other_head_dims"]["d64"]["frac"], abs=1e-4)
     assert c["cpu_baseline"]["kind"] in ("reference", "port") and c["cpu_baseline"]["cores"] >= 1
     # an errored leg must not take the line down
     full["extend"] = {"error": "boom"}
-    assert bench.compact_record(full)["roofline"]["extend"] == {"error": "boom"}
+    assert bench.compact_record(full)["roofline"]["extend_error"] == "boom"
+    # nor a record that misses keys the compact form indexes: emit() falls back to a minimal line
+    import contextlib
+    import io
+
+    broken = {k: v for k, v in full.items() if k != "config"}
+    buf = io.StringIO()
+
+    class A:
+        full_json = False
+
+    with contextlib.redirect_stdout(buf):
+        bench.emit(broken, A)
+    last = json.loads(buf.getvalue().splitlines()[-1])
+    assert last["value"] == full["value"] and "compact_record_error" in last and last["roofline"]["frac"] == full["roofline"]["frac"]

@@ -313,3 +313,53 @@ def test_backend_forward_with_score_mod(ops, index_mode):
                                         (2,), score_bias=aux2.double().cpu().numpy())
     parity.check_out(o2.view(bs, hq, d).float().cpu().numpy().astype(np.float64), want2, torch.bfloat16, ("backend decode", index_mode), absw=absw2)
     assert hs.pool.check_errors() == 0
+
+
+@pytest.mark.parametrize("index_mode", ["paged", "indices"])
+def test_backend_decode_score_mod_on_a_sliding_window_layer(ops, index_mode):
+    """a sliding-window layer that passes score_mod (Inkling's local layers,
+    sliding_window_size = local_extent - 1) must attend the WINDOW list with the window's split schedule
+    (triton_backend.py:1770-1781, also when score_mod is set), with rel = (len - 1) - n taken over that list."""
+    from test_gpu_backend import _Harness, _bits
+
+    from sglang_amd.attention.radix_attention import RadixAttention
+    from sglang_amd.forward_batch import ForwardBatch
+
+    hq, hkv, d, ps, W, extent = 8, 2, 128, 16, 48, 64
+    hs = _Harness(ps, hq, hkv, d, torch.bfloat16, "shuffled_pages", index_mode)
+    hs.backend.sliding_window_size = W
+    hs.backend.window_kv_indptr = torch.zeros_like(hs.backend.kv_indptr)
+    swa_layer = RadixAttention(hq, d, d ** -0.5, hkv, 0, sliding_window_size=W)
+    seq_lens = [10, 170, 48, 333]
+    bs = len(seq_lens)
+    rows = hs.r2t.alloc(bs)
+    hs.fill_prefix(rows, seq_lens)
+    rpi = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    seq_t = torch.tensor([s + 1 for s in seq_lens], dtype=torch.int64)
+    last = torch.tensor([int(hs.r2t.req_to_token[r, s - 1]) for r, s in zip(rows, seq_lens)], dtype=torch.int64, device=DEV)
+    dloc = hs.alloc.alloc_decode(seq_t.to(DEV), seq_t, last)
+    hs.r2t.req_to_token[rpi, torch.tensor(seq_lens, device=DEV)] = dloc.to(torch.int32)
+    q1, k1, v1 = hs.rand(bs, hq * d), hs.rand(bs, hkv * d), hs.rand(bs, hkv * d)
+    aux = (1.5 * torch.randn(bs, hq, extent, generator=hs.gen)).to(DEV)
+    fbd = ForwardBatch.for_decode(rpi, seq_t.to(DEV), dloc, seq_t)
+    hs.backend.init_forward_metadata(fbd)
+    assert hs.backend.forward_metadata.window_kv_indptr is not None
+    o_swa = swa_layer(q1, k1, v1, fbd, hs.backend, score_mod=ops.relative_bias_score_mod, aux_tensors=[aux])
+    o_full = hs.layer(q1, k1, v1, fbd, hs.backend, save_kv_cache=False, score_mod=ops.relative_bias_score_mod, aux_tensors=[aux])
+    kb, vb = hs.pool.get_kv_buffer(0)
+    sl = seq_t.numpy()
+    wl = np.minimum(sl, W)
+    r2t = _bits(hs.r2t.req_to_token)
+    kvp, kvi = orc.build_kv_indices(r2t, np.array(rows), wl, kv_start=sl - wl)
+    want, absw = parity.want_and_absw(orc.decode_attention, (_bits(q1.view(bs, hq, d)), _bits(kb), _bits(vb), kvp, kvi, d ** -0.5),
+                                      (2,), score_bias=aux.double().cpu().numpy())
+    parity.check_out(o_swa.view(bs, hq, d).float().cpu().numpy().astype(np.float64), want, torch.bfloat16,
+                     ("backend swa decode + score_mod", index_mode), absw=absw)
+    kvp_f, kvi_f = orc.build_kv_indices(r2t, np.array(rows), sl)
+    want_f, absw_f = parity.want_and_absw(orc.decode_attention, (_bits(q1.view(bs, hq, d)), _bits(kb), _bits(vb), kvp_f, kvi_f, d ** -0.5),
+                                          (2,), score_bias=aux.double().cpu().numpy())
+    parity.check_out(o_full.view(bs, hq, d).float().cpu().numpy().astype(np.float64), want_f, torch.bfloat16,
+                     ("backend full decode + score_mod in the swa model", index_mode), absw=absw_f)
+    # the long requests' window rows differ from their full-context rows
+    assert (o_swa.float() - o_full.float()).abs().max().item() > 1e-2
+    assert hs.pool.check_errors() == 0
