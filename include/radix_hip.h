@@ -24,14 +24,17 @@
 extern "C" {
 #endif
 
-/* 13 (round 5): rx_clock_probe.
+/* 15 (round 6): rx_fused_fp8_qkv_kv_cache, rx_pool_alloc_extend_rows, rx_allreduce_det (deterministic fixed-order reduce);
+ * the experimental rx_extend64 kernel left the product library (dev builds: RX_WITH_EXT64=1).
+ * 14 (round 5): score_bias* appended to rx_decode_params / rx_extend_params (score_mod = relative_bias_score_mod).
+ * 13 (round 5): rx_clock_probe.
  * 12 (round 5): rx_split_items_guarded, rx_debug_counters, rx_draft_decode_kv_indices.
  * 11 (round 4): rx_qknorm_rope_store_kv (fused QK-norm + RoPE + store).
  * 10 (round 4): rx_decode_params.rope_* (fused RoPE of the latent decode).
  * 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
  * 8 (round 3): rx_split_items; rx_decode_params.split_items / split_items_count / split_items_cap /
  * split_items_wgs_per_cu and extra_index / extra_rows; rx_num_kv_splits_balanced gained wg_target_mixed. */
-#define RX_ABI_VERSION 14
+#define RX_ABI_VERSION 15
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -63,8 +66,12 @@ const char* rx_last_error(void);
  * in the library's symbol table and fails if one of them has no parity case that provably ran it.
  * The few process-wide switches that override the default choice (A/B of kernel forms) are named ints: set through
  * rx_set_option, read once from RX_OPT_<NAME> at load -- the launch path itself never reads the environment.
- * Names: ext32_autopack, ext32_small_wg, ext32_plain, ext64, ext32_count_redo, extend_16x16_d128, extend_d256, extend_d256_at128,
- * extend_d256_at64, extend_d256_at96, extend_nd, extend_nd_big, extend_mla, extend_mla_shared_v, decode_mla8_dma. */
+ * Names: ext32_autopack, ext32_small_wg, ext32_plain, ext32_count_redo, extend_16x16_d128, extend_d256, extend_d256_at128,
+ * extend_d256_at64, extend_d256_at96, extend_nd, extend_nd_big, extend_mla, extend_mla_shared_v, decode_mla8_dma, decode_mla8_t64,
+ * decode_resident (round 6), merge_in_kernel_max_mb[_mla], roctx; ext64 only acts in a dev build (RX_WITH_EXT64=1).
+ * NOT THREAD-SAFE: the switches are plain process-wide ints that the launch path reads without synchronisation.  Set them
+ * before other threads launch (tests and A/B tools flip them from the one thread that also launches); a set that races with
+ * a launch on another thread gives that launch the old or the new value, nothing is torn, but no ordering is promised. */
 const char* rx_last_dispatch(void);
 /* Debug counters (round 5; no reference counterpart).  With option ext32_count_redo = 1 the GQA-4 packed eight-wave D = 128
  * extend call (bf16, int64 indices, paged pool: the bench's instance) runs a counting twin of its kernel: out2[0] = 32-token
@@ -244,6 +251,20 @@ int rx_store_kv_fp8(const void* k, const void* v, const rx_kv_layout* lay /* HOS
                     int64_t k_stride_t, int64_t v_stride_t, int src_dtype /* rx_dtype */,
                     float k_scale, float v_scale, int loc_is_i64, int64_t size_limit,
                     int64_t skip_index, int32_t* err_flag, void* stream);
+
+/* fused_fp8_qkv_kv_cache (kernels/ops/kvcache/fused_fp8_qkv_kv_cache.py:35-80; kernel
+ * kernels/jit/csrc/attention/fused_fp8_qkv_kv_cache.cuh:56-91; caller trtllm_mha_backend.py:764-790): fp8 e4m3fn
+ * quantisation of the step's K / V rows into the paged pool AND, when q != NULL, of the q rows into a dense
+ * q_out [n, q_dim] -- one launch.  Per element y = float(x) * (1.0f / *scale), saturated to +-448, round-to-nearest-even
+ * (the reference kernel's static_cast<fp8_e4m3_t>; q uses scale 1).  NOTE the arithmetic differs from rx_store_kv_fp8's
+ * (set_kv_buffer divides and rounds to the source dtype first): the two reference operators differ the same way.
+ * k_scale / v_scale: DEVICE fp32 scalars (NULL = 1.0), as the reference passes them.  No slot is skipped (the reference
+ * writes slot 0 too); a slot outside [0, size_limit) is dropped and flagged in err_flag. */
+int rx_fused_fp8_qkv_kv_cache(const void* q /* or NULL */, const void* k, const void* v, void* q_out /* NULL iff q is */,
+                              const rx_kv_layout* lay /* HOST; kv_fp8 = 1 */, const void* cache_loc, int loc_is_i64,
+                              const float* k_scale, const float* v_scale, int64_t n, int q_dim, int num_kv_heads,
+                              int head_dim, int v_head_dim, int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t,
+                              int src_dtype /* rx_dtype */, int64_t size_limit, int32_t* err_flag, void* stream);
 
 /* K12 read side: get_mla_kv_buffer_triton (kernels/ops/kvcache/mla_buffer.py; caller
  * MLATokenToKVPool.get_mla_kv_buffer, memory_pool.py:4117-4138).  Gathers latent rows
@@ -673,6 +694,14 @@ int rx_pool_alloc_decode(const rx_pool_desc* d, const int64_t* seq_lens, const i
 int rx_pool_alloc_decode_rows(const rx_pool_desc* d, int32_t* req_to_token, int64_t row_stride,
                               const int64_t* req_pool_indices, const int64_t* seq_lens, int64_t* out_indices, int bs,
                               int page_size, int64_t num_new_pages, void* stream);
+/* alloc_for_extend as ONE launch (srt/mem_cache/allocation.py:303-403: last_loc from the cached prefixes, alloc_extend
+ * (kernels/ops/memory/allocator.py:16-95; page_size 1: alloc_token_slots, one fresh id per token) and
+ * write_cache_indices :55-101).  table: DEVICE int64 [4, bs], rows = req_pool_idx | prefix_len | seq_len | device address of
+ * the request's cached prefix slots (int64[prefix_len]; 0 when prefix_len == 0) -- one packed host table, one H2D copy.
+ * out_indices int64[sum(seq - prefix)] (the batch's out_cache_loc); req_to_token row i gets the prefix slots at
+ * [0, prefix_len) and the new slots at [prefix_len, seq_len).  num_new_pages as rx_pool_alloc_extend's. */
+int rx_pool_alloc_extend_rows(const rx_pool_desc* d, int32_t* req_to_token, int64_t row_stride, const int64_t* table,
+                              int64_t* out_indices, int bs, int page_size, int64_t num_new_pages, void* stream);
 /* list := list + ids (token.py:66-76) */
 int rx_pool_append(const rx_pool_desc* d, int which, const int64_t* ids, int64_t n, void* stream);
 /* list := reps + list, reps = ([idx[0]] if has_first) + idx[start::stride], each / page_size  (free_segment's
@@ -770,6 +799,13 @@ int rx_ipc_close_handle(void* dev_ptr);
 int rx_ar_init(rx_ar_ctx** ctx_out, int rank, int world, void* const* peer_regions, int64_t max_bytes,
                int32_t* dev_err);
 int rx_allreduce(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int dtype, void* stream);
+/* The deterministic form (round 6): the reference's AMD path under --enable-deterministic-inference forces its ONE-stage
+ * kernel (device_communicators/custom_all_reduce.py:294-301; kernels/aot/csrc/allreduce/deterministic_all_reduce.hip:1-14:
+ * every GPU reads all peers' data and reduces it locally in a fixed order).  Same arguments, context and stream rules as
+ * rx_allreduce (the two may be mixed on one context); one flag exchange; every rank sums ALL elements itself in fp32 in rank
+ * order 0 .. world-1 and rounds once, so an element's bits depend on the world's inputs for THAT element only -- not on the
+ * message size, the batch it is embedded in, the rank or the run. */
+int rx_allreduce_det(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int dtype, void* stream);
 
 /* Fused all-reduce + residual add + RMSNorm (GroupCoordinator.fused_allreduce_rmsnorm, srt/distributed/
  * parallel_state.py:748-878; the split path it replaces: benchmark/kernels/all_reduce/benchmark_fused_ar_rms_amd.py

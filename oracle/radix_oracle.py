@@ -87,6 +87,18 @@ def quantize_kv_fp8(x: np.ndarray, scale: float, src_is_bf16: bool) -> np.ndarra
     return fp8_e4m3fn_encode(x)
 
 
+
+def quantize_fused_fp8(x: np.ndarray, scale: float = 1.0) -> np.ndarray:
+    """fused_fp8_qkv_kv_cache's per-element arithmetic (kernels/jit/csrc/attention/fused_fp8_qkv_kv_cache.cuh:33-55,64-66):
+    ``static_cast<fp8_e4m3_t>(float(x) * inv_scale)`` with ``inv_scale = 1.0f / scale`` in fp32 -- CUDA's satfinite,
+    round-to-nearest-even cast; the reference test states it as ``(x.float() * inv).clamp(-448, 448).to(float8_e4m3fn)``
+    (test/registered/kernels/ops/kvcache/test_fused_fp8_qkv_kv_cache.py:13-16).  x: float32 values of the 16-bit source."""
+    x = np.asarray(x, dtype=np.float32)
+    inv = np.float32(1.0) / np.float32(scale)
+    y = np.clip(x * inv, np.float32(-448.0), np.float32(448.0))  # (np.clip keeps NaN)
+    return fp8_e4m3fn_encode(y)
+
+
 def to_f64(x: np.ndarray) -> np.ndarray:
     """Accept bf16-bits (uint16), float16, float32 -> float64."""
     if x.dtype == np.uint16:

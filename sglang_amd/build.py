@@ -12,8 +12,13 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 # RX_LIB_NAME / RX_CFLAGS: developer knobs for A/B-ing kernel variants built side by side
 LIB_PATH = os.path.join(HERE, os.environ.get("RX_LIB_NAME", "libradix_hip.so"))
-SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_decode_mla.hip", "rx_extend.hip", "rx_extend32.hip", "rx_extend64.hip", "rx_extend_nd.hip", "rx_extend_mla.hip", "rx_extend_d256.hip",
+SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_decode_mla.hip", "rx_extend.hip", "rx_extend32.hip", "rx_extend_nd.hip", "rx_extend_mla.hip", "rx_extend_d256.hip",
            "rx_allreduce.hip", "rx_rope.hip", "rx_pool.hip", "rx_dcp.hip", "rx_radix.cpp"]
+# RX_WITH_EXT64=1 (dev): the experimental one-wave-per-SIMD D = 128 extend kernel (tools/probe/rx_extend64.hip, 0.83x of the
+# shipped kernel: DESIGN 4.2) is compiled in and option `ext64` routes PLAIN eight-wave calls to it.  The product library
+# does not carry it; tools/ext64_check.py and tools/probe/pmc_ext64.sh need such a build.
+WITH_EXT64 = bool(os.environ.get("RX_WITH_EXT64"))
+PROBE = os.path.join(ROOT, "tools", "probe")
 # rx_extend32: without -fno-honor-nans every fmaxf on an MFMA result is preceded by a canonicalising
 # v_max_f32 x, x, x (one extra VALU per score in a VALU-issue-bound loop).  The kernel creates no NaN.
 # -amdgpu-mfma-vgpr-form: at one wave per SIMD hipcc otherwise puts every MFMA result in AGPRs and
@@ -27,7 +32,10 @@ EXTRA_FLAGS = {"rx_extend32.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-ml
                "rx_extend_nd.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
                "rx_extend_mla.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                "rx_extend_d256.hip": ["-fno-honor-nans", "-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
-HEADERS = ["rx_common.h", os.path.join(ROOT, "include", "radix_hip.h"), "rx_extend32_kernel.inc", "rx_extend64_kernel.inc"]
+HEADERS = ["rx_common.h", os.path.join(ROOT, "include", "radix_hip.h"), "rx_extend32_kernel.inc"]
+if WITH_EXT64:
+    SOURCES.append(os.path.join(PROBE, "rx_extend64.hip"))
+    HEADERS.append(os.path.join(PROBE, "rx_extend64_kernel.inc"))
 
 
 def _hipcc() -> str:
@@ -41,7 +49,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]  # (join keeps an absolute source)
     deps += [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -62,10 +70,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if not os.path.exists(sp):
             continue
         variant = not only or src in only
-        obj = os.path.join(HERE, "build", os.path.splitext(src)[0] + (os.environ.get("RX_LIB_NAME", "") if variant else "") + ".o")
+        obj = os.path.join(HERE, "build", os.path.splitext(os.path.basename(src))[0] + (os.environ.get("RX_LIB_NAME", "") if variant else "")
+                           + ("_ext64" if WITH_EXT64 else "") + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
-               "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-c", sp, "-o", obj]
-        cmd[1:1] = EXTRA_FLAGS.get(src, []) + (os.environ.get("RX_CFLAGS", "").split() if variant else [])
+               "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", sp, "-o", obj]
+        cmd[1:1] = (EXTRA_FLAGS.get(os.path.basename(src), []) + (["-DRX_WITH_EXT64"] if WITH_EXT64 else [])
+                    + (os.environ.get("RX_CFLAGS", "").split() if variant else []))
         objs.append(obj)
         # per-object incremental build: recompile only what is older than its source, the headers or its flags
         stamp = obj + ".cmd"

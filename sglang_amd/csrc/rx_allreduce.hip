@@ -107,7 +107,12 @@ __device__ __forceinline__ uint32_t ar_next_call(const ArArgs& a, int b, uint32_
 }
 
 // 8 elements (16 B) per thread step; chunk c = elements [c * per, min((c+1) * per, n)), per % 8 == 0
-template <typename T>
+// ONE_SHOT (rx_allreduce_det; the reference's deterministic all-reduce on AMD forces its one-stage kernel,
+// device_communicators/custom_all_reduce.py:294-301, kernels/aot/csrc/allreduce/deterministic_all_reduce.hip:1-14): after
+// the staging exchange EVERY rank reduces ALL chunks itself -- fp32, rank order 0 .. W-1, one rounding -- straight into
+// `out`; no second flag exchange, no gather.  (The two-shot form sums in the same fixed order; what the one-shot form adds
+// is the reference's structure: no rank's result depends on another rank's reduction.)
+template <typename T, bool ONE_SHOT = false>
 __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const ArArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x, W = a.world, r = a.rank;
   __shared__ uint32_t call_s;
@@ -141,8 +146,8 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
 
   // ---- phase 1: reduce my chunk over all ranks' staging buffers (fp32 accumulate, rank order fixed
   // so that every rank computes bit-identical sums)
-  {
-    const int64_t lo = r * per, hi = min(lo + per, nv);
+  for (int c = ONE_SHOT ? 0 : r; c < (ONE_SHOT ? W : r + 1); ++c) {  // (one-shot: every chunk, by the block that staged its slices)
+    const int64_t lo = c * per, hi = min(lo + per, nv);
     u32x4* my_res = reinterpret_cast<u32x4*>(a.peers[r] + result_off);
     u32x4* out_v = reinterpret_cast<u32x4*>(a.out);
     for (int64_t i = lo + b * kArThreads + tid; i < hi; i += kArBlocks * kArThreads) {
@@ -158,10 +163,11 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
       u32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = pack2<T>(acc[2 * j], acc[2 * j + 1]);
-      my_res[i] = o;
+      if constexpr (!ONE_SHOT) my_res[i] = o;
       out_v[i] = o;
     }
   }
+  if constexpr (ONE_SHOT) return;  // (the staging buffer of this parity is reused at call + 2, behind the peers' ready(call + 1))
   __threadfence_system();
   __syncthreads();
   if (tid < W && tid != r)
@@ -454,6 +460,28 @@ int rx_allreduce(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int d
   else
     hipLaunchKernelGGL(allreduce_two_shot_kernel<F16>, dim3(kArBlocks), dim3(kArThreads), 0, s, a);
   return check_launch("rx_allreduce");
+}
+
+int rx_allreduce_det(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int dtype, void* stream) {
+  RX_RANGE("rx_allreduce_det");
+  RX_REQUIRE(ctx && in && out, "rx_allreduce_det: null pointer");
+  auto* c = reinterpret_cast<ArCtx*>(ctx);
+  RX_REQUIRE(dtype == RX_BF16 || dtype == RX_F16, "rx_allreduce_det: dtype %d", dtype);
+  RX_REQUIRE(count >= 0 && count % 8 == 0, "rx_allreduce_det: count %lld must be a multiple of 8", (long long)count);
+  RX_REQUIRE(count * 2 <= c->max_bytes, "rx_allreduce_det: %lld bytes exceed the context's %lld", (long long)count * 2,
+             (long long)c->max_bytes);
+  RX_REQUIRE((((uintptr_t)in | (uintptr_t)out) & 15) == 0, "rx_allreduce_det: in/out must be 16-byte aligned");
+  if (count == 0) return RX_OK;
+  ArArgs a = ar_args(c);
+  a.in = static_cast<const uint16_t*>(in);
+  a.out = static_cast<uint16_t*>(out);
+  a.n = count;
+  auto s = static_cast<hipStream_t>(stream);
+  if (dtype == RX_BF16)
+    hipLaunchKernelGGL((allreduce_two_shot_kernel<BF16, true>), dim3(kArBlocks), dim3(kArThreads), 0, s, a);
+  else
+    hipLaunchKernelGGL((allreduce_two_shot_kernel<F16, true>), dim3(kArBlocks), dim3(kArThreads), 0, s, a);
+  return check_launch("rx_allreduce_det");
 }
 
 int rx_allreduce_rmsnorm(rx_ar_ctx* ctx, const void* in, const void* residual_in, const void* weight, void* out,

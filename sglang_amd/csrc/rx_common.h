@@ -31,7 +31,7 @@ struct Options {
   int ext32_plain = 1;        // PLAIN instances (features compile-time off) when the call uses none of them
   int roctx = 0;              // roctx ranges around the entry points' launches (RX_RANGE)
   int ext32_count_redo = 0;   // debug: the bench-shaped packed call runs the COUNTING instance (rx_debug_counters)
-  int ext64 = 0;              // 1: PLAIN eight-wave calls take rx_extend64.hip's kernel (four waves of 64 rows, one per SIMD; experimental: slower)
+  int ext64 = 0;              // dev builds (RX_WITH_EXT64=1) only: PLAIN eight-wave calls take tools/probe/rx_extend64.hip's kernel; no effect in the product library
   int extend_16x16_d128 = 0;  // the 16x16x32 kernel of rx_extend.hip for plain D = 128 calls (A/B of the two shapes)
   int extend_d256 = 1;        // the AGPR / LDS-DMA template (256, 192, 96, 64) where it supports the call
   int extend_d256_min_rows = 1;    // ... for short extends (<= 128 rows of the longest request) from this many rows up, given >= 4 estimated tiles
@@ -96,13 +96,14 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef u32x2 __attribute__((aligned(4))) u32x2_a4;  // an 8-byte load from an address that is only 4-byte aligned (int32 pairs at odd i)
 // p[i] and p[i + 1] of an int32 or int64 array, branch-free: two 8-byte loads issued back to back (a load behind an
 // `is64 ?` branch is waited for at the join, so two load_idx calls cost two dependent round trips).  int32: the first
 // load holds both entries and the second re-reads the same address (no byte past p[i + 1] is touched).
 __device__ __forceinline__ void load_idx_pair(const void* p, int64_t i, bool is64, int64_t& v0, int64_t& v1) {
   const char* b = reinterpret_cast<const char*>(p);
-  const u32x2 x = *reinterpret_cast<const u32x2*>(b + (is64 ? i * 8 : i * 4));
-  const u32x2 y = *reinterpret_cast<const u32x2*>(b + (is64 ? (i + 1) * 8 : i * 4));
+  const u32x2 x = *reinterpret_cast<const u32x2_a4*>(b + (is64 ? i * 8 : i * 4));
+  const u32x2 y = *reinterpret_cast<const u32x2_a4*>(b + (is64 ? (i + 1) * 8 : i * 4));
   v0 = is64 ? static_cast<int64_t>((static_cast<uint64_t>(x[1]) << 32) | x[0]) : static_cast<int64_t>(static_cast<int32_t>(x[0]));
   v1 = is64 ? static_cast<int64_t>((static_cast<uint64_t>(y[1]) << 32) | y[0]) : static_cast<int64_t>(static_cast<int32_t>(x[1]));
 }

@@ -40,7 +40,9 @@ static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, 
 #undef RX_E32
 }
 
-void launch_extend64(const Ext32Args& a, bool bf16, bool idx64, bool linear, hipStream_t s);  // rx_extend64.hip
+#ifdef RX_WITH_EXT64
+void launch_extend64(const Ext32Args& a, bool bf16, bool idx64, bool linear, hipStream_t s);  // tools/probe/rx_extend64.hip (dev builds only)
+#endif
 
 int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   const Options& opt = options();
@@ -109,12 +111,14 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
   a.mblocks = (p->max_extend_len * a.q_pack + nw * 32 - 1) / (nw * 32);
   const bool bf = p->dtype == RX_BF16, i64 = p->kv_indices_is_i64 != 0;
   const bool plain = plain_any && a.q_pack == 1;
-  // Option ext64 (default off: measured 0.83x of the eight-wave kernel on the config-3 chunk): PLAIN eight-wave
-  // calls (packed or not) as the same 256-row blocks on FOUR waves of 64 rows, one per SIMD (rx_extend64.hip)
+#ifdef RX_WITH_EXT64
+  // Option ext64 (dev builds, RX_WITH_EXT64=1; measured 0.83x of the eight-wave kernel on the config-3 chunk): PLAIN
+  // eight-wave calls (packed or not) as the same 256-row blocks on FOUR waves of 64 rows, one per SIMD (tools/probe/rx_extend64.hip)
   if (opt.ext64 && nw == 8 && (packed_plain || plain) && !(a.page_size >= 0 && !linear)) {
     launch_extend64(a, bf, i64, linear, s);
     return RX_OK;
   }
+#endif
   if (opt.ext32_count_redo && packed_plain && nw == 8 && a.q_pack == 4 && bf && i64 && !linear) {  // the counting instance
     unsigned long long* ctr = nullptr;
     if (hipGetSymbolAddress(reinterpret_cast<void**>(&ctr), HIP_SYMBOL(g_ext32_counters)) != hipSuccess)

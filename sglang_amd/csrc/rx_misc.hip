@@ -257,6 +257,59 @@ __global__ __launch_bounds__(256) void store_kv_fp8_kernel(
   }
 }
 
+// fused_fp8_qkv_kv_cache (kernels/jit/csrc/attention/fused_fp8_qkv_kv_cache.cuh:56-91): y = float(x) * (1.0f / *scale)
+// saturated to +-448 and rounded to e4m3fn (CUDA's static_cast<fp8_e4m3>: satfinite, RNE); q with scale 1.  One wave per
+// token, 8 source elements (16 B) -> 8 fp8 bytes per lane.  The scales are DEVICE scalars, as the reference's.
+template <typename T, bool QUANT_Q>
+__global__ __launch_bounds__(256) void fused_fp8_qkv_store_kernel(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+    uint8_t* __restrict__ q_out, uint8_t* __restrict__ kc, uint8_t* __restrict__ vc, const void* __restrict__ loc,
+    const float* __restrict__ k_scale, const float* __restrict__ v_scale, int64_t n, int q_dim, int hkv, int dk, int dv,
+    int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t, int page_size, int64_t kps, int64_t kts, int64_t khs,
+    int64_t vps, int64_t vts, int64_t vhs, int loc64, int64_t size_limit, int32_t* err_flag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  auto quant8 = [](u32x4 raw, float inv) {
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = T::to_f32(static_cast<uint16_t>(raw[i] & 0xffffu)) * inv;
+      f[2 * i + 1] = T::to_f32(static_cast<uint16_t>(raw[i] >> 16)) * inv;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (f[i] != f[i]) ? f[i] : fminf(fmaxf(f[i], -448.f), 448.f);  // satfinite; NaN stays NaN
+    u32x2 out;
+    out[0] = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0u, false);
+    out[0] = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], out[0], true);
+    out[1] = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0u, false);
+    out[1] = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], out[1], true);
+    return out;
+  };
+  if constexpr (QUANT_Q) {
+    for (int e = lane * 8; e < q_dim; e += 64 * 8)
+      *reinterpret_cast<u32x2*>(q_out + row * q_dim + e) = quant8(*reinterpret_cast<const u32x4*>(q + row * q_stride_t + e), 1.0f);
+  }
+  const int64_t idx = load_idx(loc, row, loc64);
+  if (idx < 0 || idx >= size_limit) {
+    if (lane == 0 && err_flag) atomicOr(err_flag, RX_DEVERR_SLOT_OOB);
+    return;
+  }
+  const float inv_k = 1.0f / (k_scale ? *k_scale : 1.0f);
+  const float inv_v = 1.0f / (v_scale ? *v_scale : 1.0f);
+  const int64_t pg = idx / page_size, off = idx % page_size;
+  for (int e = lane * 8; e < hkv * dk; e += 64 * 8) {
+    const int h = e / dk, d = e % dk;
+    *reinterpret_cast<u32x2*>(kc + pg * kps + off * kts + h * khs + d) =
+        quant8(*reinterpret_cast<const u32x4*>(k + row * k_stride_t + e), inv_k);
+  }
+  for (int e = lane * 8; e < hkv * dv; e += 64 * 8) {
+    const int h = e / dv, d = e % dv;
+    *reinterpret_cast<u32x2*>(vc + pg * vps + off * vts + h * vhs + d) =
+        quant8(*reinterpret_cast<const u32x4*>(v + row * v_stride_t + e), inv_v);
+  }
+}
+
 // K12 read side: one wave per gathered row, 8 elements per lane per step.
 template <typename T, bool KV8>
 __global__ __launch_bounds__(256) void get_mla_kv_kernel(const void* __restrict__ buf, int64_t row_stride,
@@ -906,6 +959,41 @@ int rx_store_kv_fp8(const void* k, const void* v, const rx_kv_layout* lay, const
   else RX_SQ(F16);
 #undef RX_SQ
   return check_launch("rx_store_kv_fp8");
+}
+
+int rx_fused_fp8_qkv_kv_cache(const void* q, const void* k, const void* v, void* q_out, const rx_kv_layout* lay,
+                              const void* cache_loc, int loc_is_i64, const float* k_scale, const float* v_scale, int64_t n,
+                              int q_dim, int num_kv_heads, int head_dim, int v_head_dim, int64_t q_stride_t,
+                              int64_t k_stride_t, int64_t v_stride_t, int src_dtype, int64_t size_limit, int32_t* err_flag,
+                              void* stream) {
+  RX_RANGE("rx_fused_fp8_qkv_kv_cache");
+  RX_REQUIRE(n >= 0, "rx_fused_fp8_qkv_kv_cache: n < 0");
+  if (n == 0) return RX_OK;
+  RX_REQUIRE(k && v && lay && lay->k_buf && lay->v_buf && cache_loc, "rx_fused_fp8_qkv_kv_cache: null pointer");
+  RX_REQUIRE((q == nullptr) == (q_out == nullptr), "rx_fused_fp8_qkv_kv_cache: q and q_out must both be given or both omitted");
+  RX_REQUIRE(lay->kv_fp8 == 1, "rx_fused_fp8_qkv_kv_cache: the layout is not an fp8 pool (kv_fp8 = %d)", lay->kv_fp8);
+  RX_REQUIRE(src_dtype == RX_BF16 || src_dtype == RX_F16, "rx_fused_fp8_qkv_kv_cache: src_dtype %d", src_dtype);
+  RX_REQUIRE(num_kv_heads > 0 && head_dim > 0 && v_head_dim > 0 && head_dim % 8 == 0 && v_head_dim % 8 == 0,
+             "rx_fused_fp8_qkv_kv_cache: head dims must be positive multiples of 8");
+  const int64_t all = k_stride_t | v_stride_t | lay->k_page_stride | lay->k_tok_stride | lay->k_head_stride |
+                      lay->v_page_stride | lay->v_tok_stride | lay->v_head_stride;
+  RX_REQUIRE(all % 8 == 0 && lay->page_size >= 1 && size_limit > 0 &&
+                 (((uintptr_t)lay->k_buf | (uintptr_t)lay->v_buf) % 8 == 0) && (((uintptr_t)k | (uintptr_t)v) % 16 == 0),
+             "rx_fused_fp8_qkv_kv_cache: strides must be multiples of 8 elements, sources 16-byte and pool 8-byte aligned");
+  if (q)
+    RX_REQUIRE(q_dim > 0 && q_dim % 8 == 0 && q_stride_t % 8 == 0 && (uintptr_t)q % 16 == 0 && (uintptr_t)q_out % 8 == 0,
+               "rx_fused_fp8_qkv_kv_cache: q rows must be multiples of 8 elements, q 16-byte and q_out 8-byte aligned");
+#define RX_FQ(TT, QQ)                                                                                               \
+  hipLaunchKernelGGL((fused_fp8_qkv_store_kernel<TT, QQ>), dim3(static_cast<unsigned>((n + 3) / 4)), dim3(256), 0,  \
+                     static_cast<hipStream_t>(stream), (const uint16_t*)q, (const uint16_t*)k, (const uint16_t*)v,  \
+                     (uint8_t*)q_out, (uint8_t*)lay->k_buf, (uint8_t*)lay->v_buf, cache_loc, k_scale, v_scale, n,   \
+                     q_dim, num_kv_heads, head_dim, v_head_dim, q_stride_t, k_stride_t, v_stride_t, lay->page_size, \
+                     lay->k_page_stride, lay->k_tok_stride, lay->k_head_stride, lay->v_page_stride,                 \
+                     lay->v_tok_stride, lay->v_head_stride, loc_is_i64, size_limit, err_flag)
+  if (src_dtype == RX_BF16) { if (q) RX_FQ(BF16, true); else RX_FQ(BF16, false); }
+  else { if (q) RX_FQ(F16, true); else RX_FQ(F16, false); }
+#undef RX_FQ
+  return check_launch("rx_fused_fp8_qkv_kv_cache");
 }
 
 int rx_get_mla_kv(const void* kv_buf, int64_t row_stride, int kv_fp8, const void* loc, int loc_is_i64,

@@ -186,6 +186,59 @@ __global__ __launch_bounds__(256) void pool_alloc_decode_rows_kernel(PoolArgs p,
   row[s] = static_cast<int32_t>(loc);
 }
 
+// alloc_for_extend in one launch (srt/mem_cache/allocation.py:303-403: build last_loc from the cached prefixes,
+// alloc_extend / alloc_token_slots, write_cache_indices): per request read the last cached slot through the request's
+// prefix pointer, assign the new tokens' slots (alloc_extend_kernel's three parts; page_size 1: one fresh id per token),
+// write them to out AND -- with the cached prefix slots in front -- to the request's req_to_token row.
+// table: DEVICE int64 [4, bs] = req_pool_idx | prefix_len | seq_len | device address of the request's prefix slots
+// (int64[prefix_len], 0 when prefix_len is 0): ONE host-to-device copy of a packed host table feeds the call.
+__global__ __launch_bounds__(256) void pool_alloc_extend_rows_kernel(PoolArgs p, int32_t* __restrict__ req_to_token,
+                                                                     int64_t row_stride, const int64_t* __restrict__ table,
+                                                                     int bs, int64_t* __restrict__ out, int page_size,
+                                                                     int64_t need) {
+  __shared__ int64_t sh[4];
+  if (p.state[kFreeCount] < need) return;
+  const int64_t head = p.state[kFreeHead];
+  const int pid = blockIdx.x, tid = threadIdx.x;
+  const int64_t ps = page_size;
+  const int64_t* pre_lens = table + bs;
+  const int64_t* seq_lens = table + 2 * bs;
+  int64_t ext_before = 0, pages_before = 0;
+  for (int i = tid; i < pid; i += 256) {
+    const int64_t s = seq_lens[i], q = pre_lens[i];
+    ext_before += s - q;
+    pages_before += (s + ps - 1) / ps - (q + ps - 1) / ps;
+  }
+  const int64_t out_start = pool_block_sum(ext_before, sh);
+  const int64_t page_start = pool_block_sum(pages_before, sh);
+  const int64_t seq = seq_lens[pid], pre = pre_lens[pid];
+  const int64_t* prefix = reinterpret_cast<const int64_t*>(static_cast<uintptr_t>(table[3 * bs + pid]));
+  int32_t* row = req_to_token + table[pid] * row_stride;
+  for (int64_t j = tid; j < pre; j += 256) row[j] = static_cast<int32_t>(prefix[j]);  // write_cache_indices, prefix part
+  const int64_t new_pages = (seq + ps - 1) / ps - (pre + ps - 1) / ps;
+  const int64_t pre_up = (pre + ps - 1) / ps * ps;
+  const int64_t n1 = min(seq, pre_up) - pre;        // the rest of the last cached page
+  const int64_t ll = (pre > 0) ? prefix[pre - 1] : -1;
+  for (int64_t j = tid; j < n1; j += 256) {
+    out[out_start + j] = ll + 1 + j;
+    row[pre + j] = static_cast<int32_t>(ll + 1 + j);
+  }
+  if (pre + n1 == seq) return;
+  const int64_t n2 = seq / ps * ps - pre_up;        // whole new pages
+  for (int64_t j = tid; j < n2; j += 256) {
+    const int64_t loc = p.ring[0][wrap(head + page_start + j / ps, p.cap)] * ps + j % ps;
+    out[out_start + n1 + j] = loc;
+    row[pre + n1 + j] = static_cast<int32_t>(loc);
+  }
+  if (pre + n1 + n2 == seq) return;
+  const int64_t n3 = seq - seq / ps * ps;           // the new partial page
+  const int64_t start = p.ring[0][wrap(head + page_start + new_pages - 1, p.cap)];
+  for (int64_t j = tid; j < n3; j += 256) {
+    out[out_start + n1 + n2 + j] = start * ps + j;
+    row[pre + n1 + n2 + j] = static_cast<int32_t>(start * ps + j);
+  }
+}
+
 // list `which` := list + ids   (token.py:66-76: free_pages = cat((free_pages, free_index)))
 __global__ __launch_bounds__(256) void pool_append_kernel(PoolArgs p, int which, const int64_t* __restrict__ ids,
                                                           int64_t n) {
@@ -431,6 +484,19 @@ int rx_pool_alloc_decode_rows(const rx_pool_desc* d, int32_t* req_to_token, int6
                      req_pool_indices, seq_lens, out_indices, page_size, num_new_pages);
   if (num_new_pages > 0) hipLaunchKernelGGL(pool_advance_kernel, dim3(1), dim3(1), 0, s, pool_args(d), num_new_pages);
   return check_launch("rx_pool_alloc_decode_rows");
+}
+
+int rx_pool_alloc_extend_rows(const rx_pool_desc* d, int32_t* req_to_token, int64_t row_stride, const int64_t* table,
+                              int64_t* out_indices, int bs, int page_size, int64_t num_new_pages, void* stream) {
+  RX_POOL_CHECK(d);
+  RX_REQUIRE(bs >= 0 && page_size >= 1 && num_new_pages >= 0 && row_stride > 0, "rx_pool_alloc_extend_rows: bad sizes");
+  if (bs == 0) return RX_OK;
+  RX_REQUIRE(req_to_token && table && out_indices, "rx_pool_alloc_extend_rows: null pointer");
+  auto s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(pool_alloc_extend_rows_kernel, dim3(bs), dim3(256), 0, s, pool_args(d), req_to_token, row_stride,
+                     table, bs, out_indices, page_size, num_new_pages);
+  if (num_new_pages > 0) hipLaunchKernelGGL(pool_advance_kernel, dim3(1), dim3(1), 0, s, pool_args(d), num_new_pages);
+  return check_launch("rx_pool_alloc_extend_rows");
 }
 
 int rx_pool_append(const rx_pool_desc* d, int which, const int64_t* ids, int64_t n, void* stream) {

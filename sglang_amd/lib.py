@@ -16,7 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
-RX_ABI_VERSION = 14  # include/radix_hip.h
+RX_ABI_VERSION = 15  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -109,6 +109,7 @@ PROTOTYPES = {
     "rx_ipc_close_handle": (c_int, [c_void_p]),
     "rx_ar_init": (c_int, [C.POINTER(c_void_p), c_int, c_int, C.POINTER(c_void_p), c_int64, c_void_p]),
     "rx_allreduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rx_allreduce_det": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rx_allreduce_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                      c_float, c_int, c_void_p]),
     "rx_ar_destroy": (c_int, [c_void_p]),
@@ -138,6 +139,9 @@ PROTOTYPES = {
     "rx_store_kv_fp8": (c_int, [c_void_p, c_void_p, C.POINTER(RxKvLayout), c_void_p, c_int64, c_int, c_int, c_int,
                                 c_int64, c_int64, c_int, C.c_float, C.c_float, c_int, c_int64, c_int64,
                                 c_void_p, c_void_p]),
+    "rx_fused_fp8_qkv_kv_cache": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(RxKvLayout), c_void_p, c_int,
+                                          c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int64, c_int64,
+                                          c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "rx_build_kv_indices": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                     c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rx_build_unified_kv_indices": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
@@ -163,6 +167,8 @@ PROTOTYPES = {
                                      c_void_p]),
     "rx_pool_alloc_decode_rows": (c_int, [C.POINTER(RxPoolDesc), c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int,
                                           c_int, c_int64, c_void_p]),
+    "rx_pool_alloc_extend_rows": (c_int, [C.POINTER(RxPoolDesc), c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                          c_void_p]),
     "rx_pool_append": (c_int, [C.POINTER(RxPoolDesc), c_int, c_void_p, c_int64, c_void_p]),
     "rx_pool_prepend_strided": (c_int, [C.POINTER(RxPoolDesc), c_int, c_void_p, c_int64, c_int, c_int64, c_int64,
                                         c_int, c_void_p]),

@@ -35,7 +35,11 @@ def alloc_for_extend(reqs: Sequence[Req], prefix_lens: Sequence[int], seq_lens: 
                      req_to_token_pool, allocator, tree_cache=None):
     """Returns (out_cache_loc int64[sum extend], req_pool_indices int64[bs] on device).
     ``reqs[i].prefix_indices`` holds the cached slots of the first prefix_lens[i] tokens
-    (from RadixCache.match_prefix); a request without a row gets one."""
+    (from RadixCache.match_prefix); a request without a row gets one.
+
+    The device side is ONE host-to-device copy of a packed [4, bs] table (row, prefix_len, seq_len, prefix pointer) and
+    ONE native call (rx_pool_alloc_extend_rows: last_loc gather + alloc_extend / alloc_token_slots + write_cache_indices,
+    srt/mem_cache/allocation.py:303-403) -- as alloc_for_decode is one call."""
     dev = req_to_token_pool.device
     bs = len(reqs)
     need_rows = [r for r in reqs if r.req_pool_idx is None]
@@ -44,33 +48,29 @@ def alloc_for_extend(reqs: Sequence[Req], prefix_lens: Sequence[int], seq_lens: 
         raise RuntimeError("alloc_req_slots: req_to_token_pool exhausted")
     for r, row in zip(need_rows, rows):
         r.req_pool_idx = row
-    prefix_cpu = torch.tensor(list(prefix_lens), dtype=torch.int64)
-    seq_cpu = torch.tensor(list(seq_lens), dtype=torch.int64)
-    ext_cpu = seq_cpu - prefix_cpu
-    prefix_d, seq_d, ext_d = prefix_cpu.to(dev), seq_cpu.to(dev), ext_cpu.to(dev)
-    rpi = torch.tensor([r.req_pool_idx for r in reqs], dtype=torch.int64, device=dev)
-    n_ext = int(ext_cpu.sum())
+    keep = []  # int64 prefix tensors, read through raw pointers by a kernel on the current stream: the caching allocator
+    ptrs = []  # only re-uses that memory for later work on the same stream, so dropping them after the call is safe
+    for r, p in zip(reqs, prefix_lens):
+        t = r.prefix_indices
+        if t is None or p == 0:
+            ptrs.append(0)
+            continue
+        if t.dtype != torch.int64 or not t.is_contiguous():
+            t = t.to(torch.int64).contiguous()
+        if t.numel() < p:
+            raise ValueError("alloc_for_extend: prefix_indices shorter than prefix_len")
+        keep.append(t)
+        ptrs.append(t.data_ptr())
+    table = torch.tensor([[r.req_pool_idx for r in reqs], list(prefix_lens), list(seq_lens), ptrs], dtype=torch.int64)
+    n_ext = int((table[2] - table[1]).sum())
     ps = allocator.page_size
-    prefix_tensors = [
-        (r.prefix_indices.to(torch.int64) if r.prefix_indices is not None and p > 0
-         else torch.empty(0, dtype=torch.int64, device=dev))
-        for r, p in zip(reqs, prefix_lens)]
-    if ps == 1:
-        out_cache_loc = alloc_token_slots(tree_cache, allocator, n_ext)
-    else:
-        last_loc = torch.cat([t[-1:] if len(t) > 0 else torch.full((1,), -1, dtype=torch.int64, device=dev)
-                              for t in prefix_tensors])
-        evict_from_tree_cache(tree_cache, allocator, n_ext + bs * ps)
-        out_cache_loc = allocator.alloc_extend(prefix_d, prefix_cpu, seq_d, seq_cpu, last_loc, n_ext)
-        if out_cache_loc is None:
-            raise RuntimeError(f"Prefill out of memory: need {n_ext} tokens, "
-                               f"available {allocator.available_size()}")
-    keep = [t.contiguous() for t in prefix_tensors]
-    ptrs = torch.tensor([t.data_ptr() if t.numel() else 0 for t in keep], dtype=torch.int64).to(dev)
-    ops.write_req_to_token(req_to_token_pool.req_to_token, rpi, ptrs, prefix_d, seq_d, ext_d,
-                           out_cache_loc)
-    # `keep` is read through raw pointers by a kernel on the current stream; the caching allocator
-    # only re-uses that memory for later work on the same stream, so dropping it here is safe.
+    evict_from_tree_cache(tree_cache, allocator, n_ext if ps == 1 else n_ext + bs * ps)
+    out_cache_loc = allocator.alloc_extend_rows(req_to_token_pool.req_to_token, table, n_ext)
+    if out_cache_loc is None:
+        raise RuntimeError(f"{'Out of memory' if ps == 1 else 'Prefill out of memory'}: need {n_ext} tokens, "
+                           f"available {allocator.available_size()}")
+    rpi = table[0].to(dev, non_blocking=True)
+    del keep
     return out_cache_loc, rpi
 
 

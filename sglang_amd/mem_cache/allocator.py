@@ -226,6 +226,33 @@ class BaseTokenToKVPoolAllocator:
         self._n_free -= need
         return out
 
+    def alloc_extend_rows(self, req_to_token: torch.Tensor, table_cpu: torch.Tensor, extend_num_tokens: int):
+        """alloc_for_extend's device side (srt/mem_cache/allocation.py:303-403: last_loc gather, alloc_extend or -- page
+        size 1 -- alloc_token_slots, write_cache_indices) as ONE copy + ONE launch.  table_cpu: int64 [4, bs] on the HOST
+        (ideally pinned) = req_pool_idx | prefix_len | seq_len | device address of the request's cached prefix slots
+        (int64; 0 = none).  Returns out_cache_loc int64[extend_num_tokens], or None when the pages run out."""
+        ps, bs = self.page_size, table_cpu.shape[1]
+        if req_to_token.dtype != torch.int32 or req_to_token.stride(-1) != 1:
+            raise TypeError("req_to_token must be int32 with contiguous rows")
+        if table_cpu.dtype != torch.int64 or table_cpu.dim() != 2 or table_cpu.shape[0] != 4 or not table_cpu.is_contiguous():
+            raise TypeError("table_cpu must be a contiguous host int64 [4, bs]")
+        pre, seq = table_cpu[1], table_cpu[2]
+        need = int(((seq + ps - 1) // ps - (pre + ps - 1) // ps).sum())
+        # the reference's sort-merge triggers, so that the list order -- hence the indices -- evolves identically
+        # (paged.py:188-193 on the estimate tokens / page + bs + 1; token.py:55-58 on the need itself)
+        if ps > 1 and self.need_sort and extend_num_tokens // ps + bs + 1 > self._free_count():
+            self.merge_and_sort_free()
+        if not self._ensure(need):
+            return None
+        out = torch.empty((extend_num_tokens,), dtype=torch.int64, device=self.device)
+        table = table_cpu.to(self.device, non_blocking=True)
+        self._list._call("rx_pool_alloc_extend_rows", C.c_void_p(req_to_token.data_ptr()), req_to_token.stride(0),
+                         C.c_void_p(table.data_ptr()), C.c_void_p(out.data_ptr()), bs, ps, need)
+        self._n_free -= need
+        if getattr(self, "debug_mode", False):
+            assert out.unique().numel() == out.numel(), "alloc_extend_rows handed out a slot twice"
+        return out
+
     def free_group_begin(self):
         self._grouping = True
         self._group_pending = []

@@ -126,6 +126,62 @@ def store_cache_fp8(k, v, layout: "_L.RxKvLayout", indices, num_kv_heads, head_d
     _L.check(st, "rx_store_kv_fp8")
 
 
+def fused_fp8_qkv_kv_cache(q: Optional[torch.Tensor], k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor,
+                           v_cache: torch.Tensor, cache_loc: torch.Tensor, k_scale: Optional[torch.Tensor] = None,
+                           v_scale: Optional[torch.Tensor] = None, *, kv_layout=None, page_size: int = 1,
+                           err_flag: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """fused_fp8_qkv_kv_cache (kernels/ops/kvcache/fused_fp8_qkv_kv_cache.py:35-80), same name, argument order and
+    return: fp8 e4m3fn quantisation of K / V into the paged cache at ``cache_loc`` and -- when ``q`` is given -- of q into
+    a fresh dense fp8 tensor that is returned (``None`` otherwise).  k / v: 16-bit [n, Hkv, D] or [n, Hkv*D], rows may be
+    strided (slices of a fused qkv tensor); k_cache / v_cache: fp8 (or uint8) pools ``[slots, Hkv, D]`` -- or an HND pool
+    with ``kv_layout=ops.kv_layout_hnd(...)``; k_scale / v_scale: fp32 DEVICE scalars or None (= 1).  y = x * (1 / scale),
+    saturated to +-448 (the reference kernel's arithmetic; rx_fused_fp8_qkv_kv_cache)."""
+    if k.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError(f"Unsupported dtype {k.dtype}. Supported: bfloat16, float16")
+    _require_cuda(q, k, v, k_cache, v_cache, cache_loc, k_scale, v_scale)
+    n = k.shape[0]
+    k2, v2 = k.reshape(n, -1), v.reshape(n, -1)
+    if v2.dtype != k2.dtype or k2.stride(-1) != 1 or v2.stride(-1) != 1 or cache_loc.numel() != n:
+        raise ValueError("fused_fp8_qkv_kv_cache: k / v must share a dtype and be contiguous in the last dim; one cache_loc per token")
+    if not (_is_fp8_pool(k_cache) and _is_fp8_pool(v_cache)):
+        raise TypeError("fused_fp8_qkv_kv_cache: k_cache / v_cache must be fp8 e4m3fn (or uint8) pools")
+    if kv_layout is not None:
+        lay, hkv, dk, dv = kv_layout, k_cache.shape[1], k_cache.shape[-1], v_cache.shape[-1]
+        slots = k_cache.shape[0] * k_cache.shape[2]
+    else:
+        kc = k_cache if k_cache.dim() == 3 else k_cache.view(k_cache.shape[0], 1, -1)
+        vc = v_cache if v_cache.dim() == 3 else v_cache.view(v_cache.shape[0], 1, -1)
+        lay, hkv, dk, dv = _kv_layout(kc, vc, page_size), kc.shape[1], kc.shape[2], vc.shape[2]
+        slots = kc.shape[0]
+    if k2.shape[1] != hkv * dk or v2.shape[1] != hkv * dv:
+        raise ValueError("fused_fp8_qkv_kv_cache: k / v row width does not match the cache's [Hkv, D]")
+
+    def scale_ptr(sc):
+        if sc is None:
+            return None, None
+        if sc.dtype != torch.float32 or sc.numel() != 1:
+            sc = sc.to(torch.float32).reshape(1)  # (the reference's _scale_to_f32)
+        return sc, sc.data_ptr()
+
+    ks, ksp = scale_ptr(k_scale)
+    vs, vsp = scale_ptr(v_scale)
+    q2 = q_out = None
+    if q is not None:
+        q2 = q.reshape(n, -1)
+        if q2.dtype != k2.dtype or q2.stride(-1) != 1:
+            raise ValueError("fused_fp8_qkv_kv_cache: q must have k's dtype and be contiguous in the last dim")
+        q_out = torch.empty(q2.shape, dtype=torch.float8_e4m3fn, device=q.device)
+    if n == 0:
+        return q_out
+    idx = cache_loc if cache_loc.is_contiguous() else cache_loc.contiguous()
+    st = _L.load().rx_fused_fp8_qkv_kv_cache(_ptr(q2), _ptr(k2), _ptr(v2), _ptr(q_out), C.byref(lay), _ptr(idx), _is64(idx, "cache_loc"),
+                                             ksp, vsp, n, 0 if q2 is None else q2.shape[1], hkv, dk, dv,
+                                             0 if q2 is None else q2.stride(0), k2.stride(0), v2.stride(0), _rx_dtype(k2), slots,
+                                             _ptr(err_flag), _stream(k2))
+    _L.check(st, "rx_fused_fp8_qkv_kv_cache")
+    return q_out
+
+
 def get_mla_kv(kv_buffer: torch.Tensor, loc: torch.Tensor, nope_cols: int, rope_cols: int,
                dst_dtype: torch.dtype, *, size_limit: int, err_flag=None):
     """get_mla_kv_buffer_triton (kernels/ops/kvcache/mla_buffer.py): gather latent rows into dense

@@ -124,6 +124,33 @@ class CustomAllReduce:
         self._L.check(st, "rx_allreduce")
         return out
 
+    def all_reduce_det(self, x: torch.Tensor, lane: int = 0) -> torch.Tensor:
+        """Deterministic in-place sum (rx_allreduce_det: the one-shot form, every rank sums every element in fp32 in rank
+        order and rounds once -- the reference's AMD path under --enable-deterministic-inference,
+        custom_all_reduce.py:294-301).  ANY size: a message above the context's max_bytes goes through the staging
+        region in max_bytes pieces (custom_all_reduce.py:277-278: the deterministic implementation takes every size);
+        the arithmetic is per element, so the cut points do not show in the result.  16-bit, contiguous, 16-byte
+        aligned, a multiple of 8 elements -- ``det_ok(x)``."""
+        if not self.det_ok(x):
+            raise ValueError("all_reduce_det: needs a contiguous, 16-byte aligned bf16 / fp16 tensor of a multiple of 8 elements")
+        flat = x.view(-1)
+        step = self.max_bytes // 2
+        cp = self._C.c_void_p
+        stream = cp(torch.cuda.current_stream(x.device).cuda_stream)
+        for lo in range(0, flat.numel(), step):
+            piece = flat[lo: lo + step]
+            st = self._lib.rx_allreduce_det(self._ctxs[lane], cp(piece.data_ptr()), cp(piece.data_ptr()), piece.numel(),
+                                            self._dt(x), stream)
+            self._L.check(st, "rx_allreduce_det")
+        return x
+
+    def det_shape_ok(self, x: torch.Tensor) -> bool:
+        """Rank-independent: dtype and element count only."""
+        return x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.numel() > 0 and x.numel() % 8 == 0
+
+    def det_ok(self, x: torch.Tensor) -> bool:
+        return self.det_shape_ok(x) and x.is_contiguous() and x.data_ptr() % 16 == 0
+
     def supports_fused_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor) -> bool:
         return (x.dim() == 2 and self.supports(x) and residual.shape == x.shape and residual.dtype == x.dtype
                 and residual.is_contiguous() and weight.dtype == x.dtype and weight.is_contiguous()
@@ -168,7 +195,8 @@ class TPGroup:
     """Thin coordinator over one torch.distributed process group (GroupCoordinator's all_reduce
     entry, parallel_state.py:622-732)."""
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None, custom_ar: Optional[CustomAllReduce] = None):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, custom_ar: Optional[CustomAllReduce] = None,
+                 deterministic: bool = False):
         if not dist.is_initialized():
             self.rank, self.world_size, self.group = 0, 1, None
         else:
@@ -180,6 +208,44 @@ class TPGroup:
         import os
 
         self._strict = os.environ.get("RX_CUSTOM_AR_STRICT", "0") not in ("", "0")
+        # Deterministic inference with TP > 1: the o_proj / fused-RMSNorm reduce leaves RCCL (whose
+        # summation order is not pinned) for the fixed rank-order kernels -- rx_allreduce_det for every size, and the fused
+        # all-reduce + RMSNorm, which sums in the same fixed order.  The reference does the same on AMD
+        # (custom_all_reduce.py:277-278,294-301,415-421: SGLANG_USE_1STAGE_ALLREDUCE, else
+        # SGLANG_ENABLE_DETERMINISTIC_INFERENCE).  Needs the peer-to-peer context: a deterministic group without one raises
+        # on its first GPU reduce rather than silently keeping RCCL.
+        self.deterministic = bool(deterministic) and self.world_size > 1
+        self._warned_det = False
+
+    @staticmethod
+    def deterministic_collectives_enabled(server_args=None) -> bool:
+        """GroupCoordinator._deterministic_collectives_enabled (parallel_state.py:1204-1208) + the server flag:
+        SGLANG_USE_1STAGE_ALLREDUCE when set, else SGLANG_ENABLE_DETERMINISTIC_INFERENCE / --enable-deterministic-inference."""
+        import os
+
+        def env_bool(name):
+            v = os.environ.get(name)
+            return None if v is None else v.strip().lower() in ("1", "true", "yes", "on")
+
+        one_stage = env_bool("SGLANG_USE_1STAGE_ALLREDUCE")
+        if one_stage is not None:
+            return one_stage
+        return bool(getattr(server_args, "enable_deterministic_inference", False)) or bool(env_bool("SGLANG_ENABLE_DETERMINISTIC_INFERENCE"))
+
+    @classmethod
+    def from_server_args(cls, group: Optional[dist.ProcessGroup], server_args, device: torch.device,
+                         max_bytes: int = 8 << 20) -> "TPGroup":
+        """The group a model runner builds: under deterministic inference (see deterministic_collectives_enabled) with more
+        than one rank the peer-to-peer context is created and every GPU reduce takes the fixed-order kernels; otherwise the
+        defaults (RCCL, the two-shot kernel as opt-in through RX_CUSTOM_AR=1)."""
+        import os
+
+        det = cls.deterministic_collectives_enabled(server_args)
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        ar = None
+        if world > 1 and torch.device(device).type == "cuda" and (det or os.environ.get("RX_CUSTOM_AR", "0") not in ("", "0")):
+            ar = CustomAllReduce(group, torch.device(device), max_bytes=max_bytes)
+        return cls(group, custom_ar=ar, deterministic=det)
 
     def _reduce(self, x: torch.Tensor, lane: int = 0) -> None:
         # Per tensor, like GroupCoordinator.all_reduce's should_custom_ar test (parallel_state.py:672-700): the
@@ -191,6 +257,28 @@ class TPGroup:
         # through a contiguous copy.  RX_CUSTOM_AR_STRICT=1 raises instead of falling back (debugging: "which of my
         # tensors are missing the fast path").
         ar = self.custom_ar
+        if self.deterministic and x.is_cuda:
+            if ar is None:
+                raise RuntimeError("deterministic inference with TP > 1 needs the peer-to-peer all-reduce context "
+                                   "(TPGroup.from_server_args builds it); refusing to fall back to RCCL")
+            if ar.det_shape_ok(x):   # dtype and element count only: the same answer on every rank
+                if ar.det_ok(x):
+                    ar.all_reduce_det(x, lane=lane)
+                else:
+                    tmp = x.contiguous().clone() if x.is_contiguous() else x.contiguous()
+                    ar.all_reduce_det(tmp, lane=lane)
+                    x.copy_(tmp)
+                return
+            if self._strict:
+                raise ValueError(f"deterministic all-reduce: {x.dtype} x {x.numel()} is not a 16-bit tensor of a multiple of 8 elements")
+            if not self._warned_det:
+                import warnings
+
+                warnings.warn(f"deterministic all-reduce covers 16-bit tensors of a multiple of 8 elements; {x.dtype} x "
+                              f"{x.numel()} is reduced by the group's backend (order not pinned)", RuntimeWarning)
+                self._warned_det = True
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+            return
         if ar is not None and ar.shape_ok(x):
             if ar.supports(x):
                 ar.all_reduce(x, lane=lane)

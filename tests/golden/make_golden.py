@@ -28,6 +28,7 @@ Fixture families:
   F19 relative-position score bias (score_mod = relative_bias_score_mod, aux_tensors = [rel_logits]) through the extend,
       unified-extend and decode kernels -> score_bias.npz
   F20 the unified kv list of the one-stage extend (build_unified_kv_indices) -> unified_kv_indices.npz
+  F21 fused_fp8_qkv_kv_cache: the reference test's expectation formula (torch CPU casts) -> fused_fp8_qkv.npz
   F18 EAGLE multi-step draft decode: per-step kv_indices / kv_indptr of the top-k branches (generate_draft_decode_kv_indices) -> draft_kv_indices.npz
 """
 import json
@@ -1309,8 +1310,56 @@ def f20():
     save("unified_kv_indices.npz", **flat)
 
 
+
+def f21():
+    """F21 fused_fp8_qkv_kv_cache (kernels/ops/kvcache/fused_fp8_qkv_kv_cache.py:35-80) -> fused_fp8_qkv.npz.  The operator
+    is a CUDA JIT kernel (kernels/jit/csrc/attention/fused_fp8_qkv_kv_cache.cuh) that cannot run in this container; the
+    expected bytes are the reference TEST's own expectation (test/registered/kernels/ops/kvcache/
+    test_fused_fp8_qkv_kv_cache.py:13-16,76-90): ``(x.float() * inv_scale).clamp(-448, 448).to(float8_e4m3fn)`` with
+    ``inv_scale = 1 / float(scale)`` for K / V and ``q.to(float8_e4m3fn)`` for q, computed with torch on the CPU.  Cases: the
+    test's (hq, hkv, head_dim) table x {bf16, fp16} x scale {None, 0.5, 2.0} at 1 / 5 / 33 tokens, rows sliced from a fused
+    qkv tensor, plus one case of edge values (+-448, values that saturate, ties, subnormals, -0.0)."""
+    FP8 = torch.float8_e4m3fn
+    g = torch.Generator().manual_seed(21)
+    flat = {}
+    n_case = 0
+    for dtype, dn in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        for hq, hkv, hd in ((8, 1, 128), (8, 8, 128), (4, 2, 64), (64, 2, 128)):
+            for n in ((1, 5) if hq == 64 else (1, 5, 33)):
+                for scale in (None, 0.5, 2.0):
+                    q_dim, kv_dim = hq * hd, hkv * hd
+                    qkv = torch.randn(n, q_dim + 2 * kv_dim, generator=g).to(dtype)
+                    q, k, v = qkv[:, :q_dim], qkv[:, q_dim: q_dim + kv_dim], qkv[:, q_dim + kv_dim:]
+                    slots = n + 4
+                    loc = torch.randperm(slots, generator=g)[:n].to(torch.int64)
+                    inv_k = 1.0 if scale is None else 1.0 / float(torch.tensor(scale, dtype=torch.float32))
+                    inv_v = 1.0 if scale is None else 1.0 / float(torch.tensor(scale * 1.5, dtype=torch.float32))
+                    name = f"c{n_case}"
+                    n_case += 1
+                    flat[name + ".meta"] = np.array([hq, hkv, hd, n, slots, 0 if scale is None else 1, dtype == torch.bfloat16], dtype=np.int64)
+                    flat[name + ".scale"] = np.array([1.0 if scale is None else scale, 1.0 if scale is None else scale * 1.5], dtype=np.float32)
+                    flat[name + ".qkv"] = bits(qkv) if dtype == torch.bfloat16 else qkv.numpy().copy()
+                    flat[name + ".loc"] = loc.numpy()
+                    flat[name + ".q_fp8"] = q.to(FP8).view(torch.uint8).numpy().copy()
+                    flat[name + ".k_fp8"] = (k.float() * inv_k).clamp(-448.0, 448.0).to(FP8).view(torch.uint8).numpy().copy()
+                    flat[name + ".v_fp8"] = (v.float() * inv_v).clamp(-448.0, 448.0).to(FP8).view(torch.uint8).numpy().copy()
+    # edge values through the K / V formula (clamped) -- q is kept inside the finite range (torch's q.to(FP8) makes NaN
+    # beyond 448 where the kernel's satfinite cast gives 448; the reference test never leaves the range)
+    edge = torch.tensor([0.0, -0.0, 448.0, -448.0, 449.0, 464.0, 465.0, 1000.0, -1e5, 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10,
+                         0.0009765625 * 1.5, 17.0, 18.0, 19.0, 20.0, 21.0, 22.0, 23.0, 24.0, 25.0, 26.0, 27.0, 28.0, 0.4375, 0.46875,
+                         0.40625, 240.0, 232.0, 248.0, 1.0625], dtype=torch.float32)
+    for dtype, dn in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        x = edge.to(dtype)
+        for sc in (1.0, 0.5, 3.0, 0.3):
+            inv = 1.0 / float(torch.tensor(sc, dtype=torch.float32))
+            flat[f"edge_{dn}_{sc}.x"] = bits(x) if dtype == torch.bfloat16 else x.numpy().copy()
+            flat[f"edge_{dn}_{sc}.fp8"] = (x.float() * inv).clamp(-448.0, 448.0).to(FP8).view(torch.uint8).numpy().copy()
+    flat["n_cases"] = np.array([n_case])
+    save("fused_fp8_qkv.npz", **flat)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f9", "f10", "f11", "f12", "f13", "f14",
-                             "f15", "f16", "f17", "f18", "f19", "f20"]
+                             "f15", "f16", "f17", "f18", "f19", "f20", "f21"]
     for w in which:
         globals()[w]()

@@ -70,17 +70,6 @@ def _cases():
                     c["kw"]["v_scale"] = 1.25
             c["expect"] = (f"extend_mfma32_kernel<{TN[dt]}, {idx}, {TB[lin]}, {TB[vs]}, {nw}, {TB[kv8]}, {TB[plain]}, {pkc}>")
             out.append(c)
-    # ---- extend, D = 128, the one-wave-per-SIMD form (option ext64, round 5): <T, IdxT, LINEAR, PKC, QB, VAR>
-    for dt, idx, lin, pkc in itertools.product(TN, ("int", "long"), (False, True), (0, 4, 8)):
-        c = dict(fam="extend", dt=dt, idx=idx, lin=lin, dk=128, dv=128, opts={"ext32_small_wg": 0, "ext64": 1},
-                 ext=[300, 40, 257, 129], pre=[0, 70, 200, 33], kw={})
-        if pkc:
-            c["hq"], c["hkv"] = (8, 2) if pkc == 4 else (8, 1)
-            c["opts"]["ext32_pack_min_wgs"] = 0
-        else:
-            c["hq"], c["hkv"] = [(4, 4), (4, 2), (16, 1)][next(n) % 3]
-        c["expect"] = f"extend_mfma64_kernel<{TN[dt]}, {idx}, {TB[lin]}, {pkc}, 2, 0>"
-        out.append(c)
     # ---- extend, 16x16x32 kernel of rx_extend.hip: <T, D, IdxT, LINEAR, VSCALE, PLAIN, CB>
     for dt, idx, lin in itertools.product(TN, ("int", "long"), (False, True)):
         for vs, plain, cb in [(False, True, 4), (False, True, 2), (True, True, 2), (False, False, 2), (True, False, 2)]:

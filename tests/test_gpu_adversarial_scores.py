@@ -74,8 +74,6 @@ EXTEND_CASES = [
     ("mfma32_pk4_8w", 128, 128, 8, 2, {"ext32_small_wg": 0, "ext32_pack_min_wgs": 0}, "extend_mfma32_kernel<{T}, long, true, false, 8, false, true, 4>"),
     ("mfma32_pk8_8w", 128, 128, 8, 1, {"ext32_small_wg": 0, "ext32_pack_min_wgs": 0}, "extend_mfma32_kernel<{T}, long, true, false, 8, false, true, 8>"),
     ("mfma32_plain_4w", 128, 128, 2, 1, {"ext32_small_wg": 1}, "extend_mfma32_kernel<{T}, long, true, false, 4, false, true, 0>"),
-    ("mfma64_pk4", 128, 128, 8, 2, {"ext32_small_wg": 0, "ext32_pack_min_wgs": 0, "ext64": 1}, "extend_mfma64_kernel<{T}, long, true, 4, 2, 0>"),
-    ("mfma64_plain", 128, 128, 2, 2, {"ext32_small_wg": 0, "ext64": 1}, "extend_mfma64_kernel<{T}, long, true, 0, 2, 0>"),
     ("d256_g1", 256, 256, 2, 2, {}, "extend_d256_kernel<{T}, 256, 256, false>"),
     ("d256_g4", 256, 256, 8, 2, {}, "extend_d256_kernel<{T}, 256, 256, false>"),
     ("d192_g1", 192, 128, 2, 2, {}, "extend_d256_kernel<{T}, 192, 128, false>"),

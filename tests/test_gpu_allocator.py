@@ -202,3 +202,55 @@ def test_alloc_decode_rows_equals_gather_alloc_scatter(ps):
     for x, y in zip(*outs):
         assert torch.equal(x, y)
     assert outs[0][0].unique().numel() == bs
+
+
+def test_alloc_extend_rows_replays_the_reference_logs_and_writes_the_rows():
+    """rx_pool_alloc_extend_rows (alloc_for_extend as ONE copy + ONE launch): the reference op logs
+    replayed with every `alloc_extend` -- and, at page size 1, every `alloc` -- routed through the one-call path (prefix
+    tensors whose last slot is the log's last_loc): the returned slots, both free lists after every call and the calls the
+    reference answers with None stay bit-exact, AND the req_to_token rows hold prefix slots + new slots
+    (write_cache_indices, srt/mem_cache/allocation.py:55-101)."""
+    cases = json.load(open(os.path.join(GOLD, "alloc_sequences.json")))
+    n_ext = 0
+    for case in cases:
+        a = _make(case)
+        ps = case["page_size"]
+        for step, ent in enumerate(case["log"]):
+            tag = (ps, case["need_sort"], step, ent["op"])
+            if ent["op"] == "alloc_extend" or (ent["op"] == "alloc" and ps == 1 and ent["need"] > 0):
+                if ent["op"] == "alloc":
+                    pre_l, seq_l, last = [0, 0], [ent["need"] // 2, ent["need"] - ent["need"] // 2], [-1, -1]
+                else:
+                    pre_l, seq_l, last = ent["prefix_lens"], ent["seq_lens"], ent["last_loc"]
+                bs = len(pre_l)
+                r2t = torch.full((bs + 1, max(seq_l) + 3), -7, dtype=torch.int32, device=DEV)
+                prefixes = []
+                for p, ll in zip(pre_l, last):
+                    t = torch.arange(900000, 900000 + p, dtype=torch.int64, device=DEV)
+                    if p:
+                        t[-1] = ll
+                    prefixes.append(t)
+                table = torch.tensor([list(range(1, bs + 1)), pre_l, seq_l, [t.data_ptr() if t.numel() else 0 for t in prefixes]],
+                                     dtype=torch.int64)
+                got = a.alloc_extend_rows(r2t, table, int(sum(seq_l) - sum(pre_l)))
+                assert (got is None) == (ent["out"] is None), tag
+                if got is not None:
+                    assert got.dtype == torch.int64 and got.tolist() == ent["out"], tag
+                    off = 0
+                    for i, (p, s) in enumerate(zip(pre_l, seq_l)):
+                        row = r2t[i + 1].tolist()
+                        assert row[:p] == [int(x) for x in prefixes[i].tolist()], tag
+                        assert row[p:s] == ent["out"][off: off + s - p], tag
+                        assert all(x == -7 for x in row[s:]), tag
+                        off += s - p
+                    assert r2t[0].eq(-7).all()
+                    n_ext += 1
+            else:
+                got = _replay(a, ent)
+                if got != "void":
+                    assert (got is None) == (ent["out"] is None), tag
+                    if got is not None:
+                        assert got.tolist() == ent["out"], tag
+            assert a.free_pages.tolist() == ent["free"][0], tag
+            assert a.release_pages.tolist() == ent["free"][1], tag
+    assert n_ext > 40, n_ext

@@ -29,8 +29,8 @@ def parts_for(seed, n, dt):
     return [torch.randn(n, generator=g).to(dt) for _ in range(world)]   # same on every rank
 
 LIGHT = os.environ.get("AR_REPS", "3") == "1"   # world 4 / 6 / 8: the processes time-slice ONE GPU and every call waits for all of them
-TINY = LIGHT and world > 4                      # (a collective among 6 / 8 time-sliced processes costs seconds: the protocol once per call kind)
-for it, (n, dt) in enumerate(([(8, torch.bfloat16), (256 * 4096, torch.bfloat16)] if TINY else
+TINY = LIGHT and world > 4                      # (a collective among 6 / 8 time-sliced processes costs seconds: the protocol ONCE per call kind)
+for it, (n, dt) in enumerate(([(256 * 4096, torch.bfloat16)] if TINY else
                               [(8, torch.bfloat16), (256 * 4096, torch.bfloat16), (1000 * 8, torch.float16)] if LIGHT else
                               [(8, torch.bfloat16), (256 * 4096, torch.bfloat16), (1000 * 8, torch.float16),
                                (2 << 20, torch.bfloat16), (4096, torch.float16)]) * int(os.environ.get("AR_REPS", "3"))):
@@ -51,7 +51,7 @@ for it, (n, dt) in enumerate(([(8, torch.bfloat16), (256 * 4096, torch.bfloat16)
 # numbers live on the device, so every replay is calls g+1, g+2, g+3 -- with a host-side counter the replays
 # would resend the capture-time numbers and read stale (or not yet written) peer buffers.
 n = 64 * 4096
-bufs = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+bufs = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for _ in range(2 if TINY else 3)]
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
@@ -109,6 +109,71 @@ for (T, H, dt, tol) in ([(7, 8192, torch.float16, 2e-3)] if TINY else [(256, 409
     if not err <= tol:
         ok = False
         print(f"rank {rank} fused norm {T}x{H}: max err {err}", flush=True)
+# ---- the deterministic one-shot form (rx_allreduce_det; VERDICT r05 item 5) ------------------------------------------
+# (a) == the fp32 rank-order sum, one rounding; (b) bit-identical across three runs; (c) across ranks (every rank compares
+# with the same host value); (d) the same rows embedded in a LARGER batch give the same bits; (e) a message above the
+# context's max_bytes (cut into pieces) and (f) TPGroup(deterministic=True) routes every GPU reduce through it.
+tpd = TPGroup(None, custom_ar=ar, deterministic=True)
+assert tpd.deterministic
+for (T, H, dt) in ([(16, 4096, torch.bfloat16)] if TINY else [(16, 4096, torch.bfloat16), (3, 8192, torch.float16)]):
+    big = [p.view(4 * T, H) for p in parts_for(4242 + T, 4 * T * H, dt)]      # the larger batch
+    want_big = sum(p.float() for p in big).to(dt)
+    runs = []
+    for rep in range(1 if TINY else 3):
+        x = big[rank][T: 2 * T].to(dev).contiguous()                           # the message on its own ...
+        ar.all_reduce_det(x)
+        torch.cuda.synchronize()
+        runs.append(x.cpu())
+    xb = big[rank].to(dev)                                                       # ... and embedded in the batch
+    tpd.all_reduce(xb)
+    torch.cuda.synchronize()
+    if not all(torch.equal(r_, want_big[T: 2 * T]) for r_ in runs):
+        ok = False
+        print(f"rank {rank} det {T}x{H}: differs from the fp32 rank-order sum / between runs", flush=True)
+    if not torch.equal(xb.cpu(), want_big) or not torch.equal(xb.cpu()[T: 2 * T], runs[0]):
+        ok = False
+        print(f"rank {rank} det {T}x{H}: embedded rows differ", flush=True)
+if not TINY:
+    n_big = (4 << 20) // 2 * 2 + 4096                                            # 2 x max_bytes + a tail: three pieces
+    parts = parts_for(77, n_big, torch.bfloat16)
+    x = parts[rank].to(dev)
+    h = tpd.all_reduce_async(x)                                                  # side stream, lane 1
+    got = h.wait()
+    torch.cuda.synchronize()
+    if not torch.equal(got.cpu(), sum(p.float() for p in parts).to(torch.bfloat16)):
+        ok = False
+        print(f"rank {rank} det over max_bytes: mismatch", flush=True)
+    # under graph replay, mixed with a two-shot call on the same context
+    gb = torch.zeros(32 * 4096, dtype=torch.bfloat16, device=dev)
+    with torch.cuda.stream(side):
+        ar.all_reduce_det(gb); ar.all_reduce(gb)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    dist.barrier()
+    gd = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gd):
+        ar.all_reduce_det(gb)
+    for rep in range(2):
+        parts = parts_for(900 + rep, gb.numel(), torch.bfloat16)
+        gb.copy_(parts[rank])
+        gd.replay()
+        torch.cuda.synchronize()
+        if not torch.equal(gb.cpu(), sum(p.float() for p in parts).to(torch.bfloat16)):
+            ok = False
+            print(f"rank {rank} det graph replay {rep}: mismatch", flush=True)
+    # a deterministic group WITHOUT the context refuses to fall back to the backend
+    try:
+        TPGroup(None, custom_ar=None, deterministic=True).all_reduce(torch.zeros(8, device=dev, dtype=torch.bfloat16))
+        ok = False
+    except RuntimeError:
+        pass
+assert ar.check_errors() == 0
+if TINY:
+    ar.close()
+    dist.destroy_process_group()
+    print("RANK_OK" if ok else "RANK_FAIL", flush=True)
+    sys.exit(0 if ok else 1)
+
 # fused under graph replay as well (same device-side counters)
 T, H = 64, 4096
 xg = torch.zeros(T, H, dtype=torch.bfloat16, device=dev)
@@ -179,7 +244,9 @@ sys.exit(0 if ok else 1)
 @pytest.mark.parametrize("world", [2, 4, 6, 8])
 def test_custom_allreduce_across_processes(world, tmp_path):
     """World sizes of the reference's custom all-reduce (custom_all_reduce.py:41 _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]);
-    8 = kArMaxWorld = the target node.  6 is the one size where the element count does not divide by the ranks."""
+    8 = kArMaxWorld = the target node.  6 is the one size where the element count does not divide by the ranks.
+    World 6 / 8 run the protocol ONCE per call kind (eager two-shot, graph capture + one replay, fused RMSNorm, deterministic
+    one-shot): eight processes time-slicing one GPU pay seconds per collective (127 s at world 8)."""
     script = tmp_path / "ar_worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, RX_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + world),

@@ -188,61 +188,6 @@ def test_short_extends_over_a_prefix_take_the_packed_template(dims, dtype):
     parity.check_out(got, want, dtype, ("short extend, per-head kernel", dims), ulps=1, absw=absw)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 1), (4, 4)], ids=["gqa4", "gqa8", "mha"])
-def test_ext64_one_wave_per_simd_kernel_is_bit_identical_to_the_eight_wave_kernel(hq, hkv, dtype):
-    """Option ext64 (round 5): the PLAIN eight-wave calls on rx::extend_mfma64_kernel -- four waves of 64 rows, one per
-    SIMD, O / Q^T in accumulator registers owned by name, every MFMA an asm statement, one software pipeline across
-    tiles.  Per row it performs the eight-wave kernel's arithmetic in the same order, so o and lse must match BIT FOR
-    BIT, on shapes that take every path: a pipelined run across the prefix / new-token seam (prefix a multiple of 64),
-    run -> ragged prefix tile -> second run -> diagonal (the case that exposed a missing MFMA -> VALU wait state),
-    no prefix, extends shorter than a block, and the oracle on top."""
-    from sglang_amd import lib as rxlib
-    from sglang_amd import ops
-
-    d, ps = 128, 16
-    for prefix, extend in (([1000, 192, 0], [512, 700, 300]), ([1024, 64], [704, 100]), ([0, 0], [2048, 5]), ([3584], [512])):
-        bs = len(prefix)
-        g = torch.Generator().manual_seed(hq * 100 + sum(prefix) + sum(extend))
-        npg = sum(-(-p // ps) for p in prefix) + 2
-        perm = torch.randperm(npg - 1, generator=g) + 1
-        kvi, kvp, pi = [], [0], 0
-        for p in prefix:
-            n = -(-p // ps)
-            kvi.append((perm[pi: pi + n][:, None] * ps + torch.arange(ps)[None]).reshape(-1)[:p])
-            pi += n
-            kvp.append(kvp[-1] + p)
-        kvi = torch.cat(kvi).to(torch.int64) if sum(prefix) else torch.zeros(0, dtype=torch.int64)
-        kb = torch.randn(npg * ps, hkv, d, generator=g).to(dtype)
-        vb = torch.randn(npg * ps, hkv, d, generator=g).to(dtype)
-        T = sum(extend)
-        q = torch.randn(T, hq, d, generator=g).to(dtype)
-        ke = torch.randn(T, hkv, d, generator=g).to(dtype)
-        ve = torch.randn(T, hkv, d, generator=g).to(dtype)
-        qo = np.concatenate([[0], np.cumsum(extend)]).astype(np.int64)
-        outs = {}
-        for mode in (1, 0):
-            with rxlib.option("ext64", mode), rxlib.option("ext32_small_wg", 0), rxlib.option("ext32_pack_min_wgs", 0):
-                o = torch.full((T, hq, d), float("nan"), dtype=dtype, device=DEV)
-                lse = torch.zeros(T, hq, dtype=torch.float32, device=DEV)
-                ops.extend_attention_fwd(q.to(DEV), ke.to(DEV), ve.to(DEV), o, kb.to(DEV), vb.to(DEV), torch.from_numpy(qo).to(DEV),
-                                         torch.tensor(kvp, dtype=torch.int32, device=DEV), kvi.to(DEV), None, True, None, max(extend),
-                                         1.0, 1.0, sm_scale=d ** -0.5, lse_extend=lse, page_size=ps)
-                torch.cuda.synchronize()
-                assert rxlib.last_dispatch().startswith("extend_mfma64_kernel" if mode else "extend_mfma32_kernel"), rxlib.last_dispatch()
-                outs[mode] = (o, lse)
-        assert torch.equal(outs[1][0].view(torch.int16), outs[0][0].view(torch.int16)), (prefix, extend)
-        assert torch.equal(outs[1][1], outs[0][1]), (prefix, extend)
-        if sum(prefix) + sum(extend) < 3000:
-            want = orc.extend_attention(_bits(q), _bits(ke), _bits(ve), _bits(kb), _bits(vb), qo, np.asarray(kvp, dtype=np.int32),
-                                        kvi.numpy(), sm_scale=d ** -0.5)
-            absw = None
-            if dtype == torch.bfloat16:
-                absw = orc.extend_attention(_bits(q), _bits(ke), parity.abs_values(_bits(ve)), _bits(kb), parity.abs_values(_bits(vb)),
-                                            qo, np.asarray(kvp, dtype=np.int32), kvi.numpy(), sm_scale=d ** -0.5)
-            parity.check_out(outs[1][0].float().cpu().numpy(), want, dtype, ("ext64", prefix, extend), ulps=1, absw=absw)
-
-
 def test_redo_counters_of_the_counting_instance():
     """rx_debug_counters + option ext32_count_redo: the counting twin of the bench's kernel instance returns the same bits
     and counts.  N(0, 1) scores: a redo on every wave's FIRST block only (reference max still -inf);

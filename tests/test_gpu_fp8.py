@@ -277,3 +277,84 @@ def test_fp8_pools_roundtrip_through_the_pool_classes(ops):
     mla16.set_mla_kv_buffer(layer, loc, nope, rope)
     n3, r3 = mla16.get_mla_kv_buffer(layer, loc)
     assert torch.equal(n3, nope) and torch.equal(r3, rope)
+
+
+def test_fused_fp8_qkv_kv_cache_matches_the_reference_tests_bytes(ops, golden_dir):
+    """ops.fused_fp8_qkv_kv_cache (the reference operator's name and signature, kernels/ops/kvcache/
+    fused_fp8_qkv_kv_cache.py:35-80) on golden F21: q / k / v sliced out of one fused qkv tensor (strided rows), NHD fp8
+    pools, device scalar scales; q_out, the K rows and the V rows bit-exact; untouched slots stay zero."""
+    import os
+
+    z = np.load(os.path.join(golden_dir, "fused_fp8_qkv.npz"))
+    for c in range(int(z["n_cases"][0])):
+        hq, hkv, hd, n, slots, has_scale, is_bf16 = (int(x) for x in z[f"c{c}.meta"])
+        raw = torch.from_numpy(z[f"c{c}.qkv"])
+        qkv = (raw.view(torch.bfloat16) if is_bf16 else raw).to(DEV)
+        q_dim, kv_dim = hq * hd, hkv * hd
+        q, k, v = qkv[:, :q_dim], qkv[:, q_dim: q_dim + kv_dim].view(n, hkv, hd), qkv[:, q_dim + kv_dim:].view(n, hkv, hd)
+        loc = torch.from_numpy(z[f"c{c}.loc"]).to(DEV)
+        ks = vs = None
+        if has_scale:
+            ks = torch.tensor(float(z[f"c{c}.scale"][0]), dtype=torch.float32, device=DEV)
+            vs = torch.tensor(float(z[f"c{c}.scale"][1]), dtype=torch.float32, device=DEV)
+        for with_q in (True, False):
+            k_cache = torch.zeros(slots, hkv, hd, dtype=FP8, device=DEV)
+            v_cache = torch.zeros(slots, hkv, hd, dtype=FP8, device=DEV)
+            q_out = ops.fused_fp8_qkv_kv_cache(q if with_q else None, k, v, k_cache, v_cache, loc, ks, vs)
+            if with_q:
+                assert q_out.dtype == FP8 and tuple(q_out.shape) == (n, q_dim)
+                assert np.array_equal(q_out.view(torch.uint8).cpu().numpy(), z[f"c{c}.q_fp8"]), c
+            else:
+                assert q_out is None
+            kb = k_cache.view(torch.uint8).view(slots, kv_dim).cpu().numpy()
+            vb = v_cache.view(torch.uint8).view(slots, kv_dim).cpu().numpy()
+            assert np.array_equal(kb[z[f"c{c}.loc"]], z[f"c{c}.k_fp8"]) and np.array_equal(vb[z[f"c{c}.loc"]], z[f"c{c}.v_fp8"]), c
+            rest = np.setdiff1d(np.arange(slots), z[f"c{c}.loc"])
+            assert not kb[rest].any() and not vb[rest].any()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_fused_fp8_qkv_kv_cache_edge_values_hnd_pool_and_errors(ops, dtype, golden_dir):
+    """Edge values (saturation to +-448, ties, subnormals, -0.0) against the golden bytes AND the oracle; an HND page pool
+    through kv_layout; int32 cache_loc; the reference's error for a non-16-bit k; an out-of-range slot is dropped + flagged."""
+    import os
+
+    z = np.load(os.path.join(golden_dir, "fused_fp8_qkv.npz"))
+    dn = "bf16" if dtype == torch.bfloat16 else "fp16"
+    for sc in (1.0, 0.5, 3.0, 0.3):
+        raw = torch.from_numpy(z[f"edge_{dn}_{sc}.x"])
+        x = (raw.view(torch.bfloat16) if dtype == torch.bfloat16 else raw).to(DEV)
+        row = x.repeat(4)[:128].contiguous().view(1, 1, 128)          # one token, one head of 128
+        want = np.tile(z[f"edge_{dn}_{sc}.fp8"], 4)[:128]
+        k_cache = torch.zeros(3, 1, 128, dtype=FP8, device=DEV)
+        v_cache = torch.zeros(3, 1, 128, dtype=FP8, device=DEV)
+        s = torch.tensor(sc, dtype=torch.float32, device=DEV)
+        ops.fused_fp8_qkv_kv_cache(None, row, row, k_cache, v_cache, torch.tensor([2], dtype=torch.int32, device=DEV), s, s)
+        got = k_cache.view(torch.uint8)[2, 0].cpu().numpy()
+        assert np.array_equal(got, want), (sc, got[:32], want[:32])
+        assert np.array_equal(got, orc.quantize_fused_fp8(row.float().cpu().numpy().reshape(-1), sc))
+        assert np.array_equal(v_cache.view(torch.uint8)[2, 0].cpu().numpy(), want)
+    # HND pool [pages, Hkv, page, D] through kv_layout, random rows, vs the oracle
+    g = torch.Generator().manual_seed(3)
+    n, hkv, d, page, pages = 37, 4, 128, 16, 5
+    k = (torch.randn(n, hkv, d, generator=g) * 2).to(dtype).to(DEV)
+    v = (torch.randn(n, hkv, d, generator=g) * 2).to(dtype).to(DEV)
+    q = torch.randn(n, 8 * d, generator=g).to(dtype).to(DEV)
+    kh = torch.zeros(pages, hkv, page, d, dtype=FP8, device=DEV)
+    vh = torch.zeros(pages, hkv, page, d, dtype=FP8, device=DEV)
+    loc = (torch.randperm(pages * page - 1, generator=g)[:n] + 1).to(DEV)
+    ks, vs = torch.tensor(0.37, device=DEV), torch.tensor(2.5, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    q8 = ops.fused_fp8_qkv_kv_cache(q, k, v, kh, vh, loc, ks, vs, kv_layout=ops.kv_layout_hnd(kh, vh), err_flag=err)
+    got_k = kh.view(torch.uint8)[loc // page, :, loc % page].cpu().numpy()
+    got_v = vh.view(torch.uint8)[loc // page, :, loc % page].cpu().numpy()
+    assert np.array_equal(got_k, orc.quantize_fused_fp8(k.float().cpu().numpy(), np.float32(0.37)))
+    assert np.array_equal(got_v, orc.quantize_fused_fp8(v.float().cpu().numpy(), np.float32(2.5)))
+    assert np.array_equal(q8.view(torch.uint8).cpu().numpy(), orc.quantize_fused_fp8(q.float().cpu().numpy()))
+    assert int(err.item()) == 0
+    bad = loc.clone()
+    bad[3] = pages * page + 5
+    ops.fused_fp8_qkv_kv_cache(None, k, v, kh, vh, bad, ks, vs, kv_layout=ops.kv_layout_hnd(kh, vh), err_flag=err)
+    assert int(err.item()) & 1
+    with pytest.raises(RuntimeError, match="Unsupported dtype"):
+        ops.fused_fp8_qkv_kv_cache(None, k.float(), v.float(), kh, vh, loc)

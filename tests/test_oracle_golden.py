@@ -587,3 +587,26 @@ def test_draft_decode_kv_indices_golden(golden_dir):
                                                g["kv_indices"].shape[1], g["kv_indptr"].shape[1])
         assert np.array_equal(kvi, g["kv_indices"]), n
         assert np.array_equal(kvp, g["kv_indptr"]), n
+
+
+def test_fused_fp8_qkv_quantisation_golden(golden_dir):
+    """F21: the oracle's restatement of fused_fp8_qkv_kv_cache's arithmetic (x * (1.0f / scale), satfinite RNE to e4m3fn)
+    against the reference test's expected bytes -- every case of the fixture, K / V with their scales, q with scale 1, and
+    the edge values (+-448, saturating values, ties, subnormals, -0.0); bit-exact."""
+    z = np.load(os.path.join(golden_dir, "fused_fp8_qkv.npz"))
+    n_cases = int(z["n_cases"][0])
+    assert n_cases >= 60
+    for c in range(n_cases):
+        hq, hkv, hd, n, slots, has_scale, is_bf16 = (int(x) for x in z[f"c{c}.meta"])
+        qkv = z[f"c{c}.qkv"]
+        x = orc.bf16_to_f32(qkv) if is_bf16 else qkv.astype(np.float32)
+        q_dim, kv_dim = hq * hd, hkv * hd
+        ks, vs = (float(s) for s in z[f"c{c}.scale"])
+        assert np.array_equal(orc.quantize_fused_fp8(x[:, :q_dim]), z[f"c{c}.q_fp8"]), c
+        assert np.array_equal(orc.quantize_fused_fp8(x[:, q_dim: q_dim + kv_dim], ks), z[f"c{c}.k_fp8"]), c
+        assert np.array_equal(orc.quantize_fused_fp8(x[:, q_dim + kv_dim:], vs), z[f"c{c}.v_fp8"]), c
+    for dn in ("bf16", "fp16"):
+        for sc in (1.0, 0.5, 3.0, 0.3):
+            xe = z[f"edge_{dn}_{sc}.x"]
+            xf = orc.bf16_to_f32(xe) if dn == "bf16" else xe.astype(np.float32)
+            assert np.array_equal(orc.quantize_fused_fp8(xf, sc), z[f"edge_{dn}_{sc}.fp8"]), (dn, sc)

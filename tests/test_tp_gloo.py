@@ -76,6 +76,15 @@ def _worker(rank, world, port, out_dir):
         proj = RowParallelOProj(torch.from_numpy(w_o).double(), sh, D, group)
         y = proj.forward(torch.from_numpy(part.reshape(bs, -1)), overlap=(rank == 0)).wait()
         np.testing.assert_allclose(y.numpy(), want, atol=1e-9)
+        # deterministic inference: the group built from server_args carries the flag; on CPU
+        # tensors (this test) the reduce stays on the group's backend, a GPU reduce would demand the peer-to-peer context
+        class SA:
+            enable_deterministic_inference = True
+
+        gdet = TPGroup.from_server_args(None, SA, torch.device("cpu"))
+        assert gdet.deterministic and gdet.custom_ar is None
+        yd = RowParallelOProj(torch.from_numpy(w_o).double(), sh, D, gdet).forward(torch.from_numpy(part.reshape(bs, -1))).wait()
+        np.testing.assert_allclose(yd.numpy(), want, atol=1e-9)
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -151,3 +160,28 @@ def test_dcp2_exchanges_reproduce_whole_sequence_attention(tmp_path):
     port = _free_port()
     mp.spawn(_dcp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"dcp_ok{r}") for r in range(world))
+
+
+def test_deterministic_collectives_switch_follows_the_reference_precedence(monkeypatch):
+    """GroupCoordinator._deterministic_collectives_enabled (parallel_state.py:1204-1208) / _use_amd_deterministic_impl
+    (custom_all_reduce.py:415-421): SGLANG_USE_1STAGE_ALLREDUCE wins when set, else SGLANG_ENABLE_DETERMINISTIC_INFERENCE
+    or --enable-deterministic-inference; a world-1 group never turns the mode on."""
+    from sglang_amd.parallel import TPGroup
+
+    class On:
+        enable_deterministic_inference = True
+
+    class Off:
+        enable_deterministic_inference = False
+
+    monkeypatch.delenv("SGLANG_USE_1STAGE_ALLREDUCE", raising=False)
+    monkeypatch.delenv("SGLANG_ENABLE_DETERMINISTIC_INFERENCE", raising=False)
+    f = TPGroup.deterministic_collectives_enabled
+    assert f(On) and not f(Off) and not f(None)
+    monkeypatch.setenv("SGLANG_ENABLE_DETERMINISTIC_INFERENCE", "1")
+    assert f(Off)
+    monkeypatch.setenv("SGLANG_USE_1STAGE_ALLREDUCE", "0")
+    assert not f(On)
+    monkeypatch.setenv("SGLANG_USE_1STAGE_ALLREDUCE", "true")
+    assert f(Off)
+    assert not TPGroup(None, deterministic=True).deterministic   # world size 1: nothing to reduce

@@ -20,7 +20,7 @@ VARS = [int(x) for x in os.environ.get("VARIANTS", "0").split(",")]
 
 def build():
     from sglang_amd import build as b
-    deps = [SRC, os.path.join(b.CSRC, "rx_extend32_kernel.inc"), os.path.join(b.CSRC, "rx_extend64_kernel.inc"),
+    deps = [SRC, os.path.join(b.CSRC, "rx_extend32_kernel.inc"), os.path.join(ROOT, "tools", "probe", "rx_extend64_kernel.inc"),
             os.path.join(b.CSRC, "rx_common.h")]
     tag = LIB + ".vars"
     want = ",".join(str(v) for v in sorted(set(VARS)))

@@ -1,6 +1,7 @@
-"""A/B of rx::extend_mfma64_kernel (one wave per SIMD, 64 rows per wave) against rx::extend_mfma32_kernel's eight-wave
-PLAIN instances on the same inputs: max |o| / |lse| difference per shape (they round differently: not bit-equal) and
-the two timings.  env SHAPES="bs x P + E , ..." (default a few), HQ / HKV (32 / 8), PS (page size, 16)."""
+"""A/B of rx::extend_mfma64_kernel (one wave per SIMD, 64 rows per wave; tools/probe/rx_extend64.hip) against
+rx::extend_mfma32_kernel's eight-wave PLAIN instances on the same inputs: max |o| / |lse| difference per shape and the two timings.
+NEEDS A DEV BUILD of the library: RX_WITH_EXT64=1 RX_LIB_NAME=libradix_hip_ext64.so python -m sglang_amd.build (the product
+library does not carry the kernel; option ext64 is a no-op there).  env SHAPES="bs x P + E , ..." (default a few), HQ / HKV (32 / 8), PS (page size, 16)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
