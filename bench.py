@@ -656,7 +656,7 @@ def parity_vs_reference_cpu(dev, bs=256, ctx=4096, hq=32, hkv=8):
             return {"error": f"reference child rc={r.returncode}: {r.stderr.strip()[-200:]}"}
 
         def load(name, bf16=False):
-            t = torch.from_numpy(np.ascontiguousarray(np.load(os.path.join(out, name + ".npy"), mmap_mode="r"))).to(dev)
+            t = torch.from_numpy(np.array(np.load(os.path.join(out, name + ".npy"), mmap_mode="r"))).to(dev)
             return t.view(torch.bfloat16) if bf16 else t
 
         kb, vb = load("k_buffer", True), load("v_buffer", True)

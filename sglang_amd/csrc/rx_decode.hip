@@ -115,6 +115,21 @@ __device__ __forceinline__ void fold_extras(const DecodeArgs& a, int b, int h, i
   }
 }
 
+// RX_DEC_TIMELINE (dev builds only: RX_CFLAGS=-DRX_DEC_TIMELINE RX_LIB_NAME=... RX_VARIANT_SOURCES=rx_decode.hip; tools/decode_timeline.py):
+// wave 0 of every workgroup stamps the constant-rate clock (s_memrealtime, 100 MHz) at kernel entry, when its first K/V tile
+// has landed, when its tile loop ends and at exit, plus the XCC it ran on, into a buffer of its own -- where a short launch's
+// fixed cost goes.  No output value depends on a stamp; the product build compiles none of this.
+#ifdef RX_DEC_TIMELINE
+constexpr int kTlMax = 8192;
+__device__ unsigned long long g_dec_timeline[kTlMax * 6];
+#define RX_TL(slot)                                                                                         \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < kTlMax) g_dec_timeline[blockIdx.x * 6 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define RX_TL(slot) do {} while (0)
+#endif
+
 constexpr int kMinBlockKV = 32;  // decode_attention.py:36 (_MIN_BLOCK_KV)
 constexpr int kTile = 32;        // tokens per wave tile (K of the PV MFMA)
 constexpr int kWavesPerWG = 4;
@@ -244,6 +259,15 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, g = lane >> 4;
+  RX_TL(0);
+#ifdef RX_DEC_TIMELINE
+  if (tid == 0 && blockIdx.x < kTlMax) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_dec_timeline[blockIdx.x * 6 + 4] = xcc & 0xf;
+    g_dec_timeline[blockIdx.x * 6 + 5] = 0;
+  }
+#endif
 
   // split is the SLOWEST grid dimension: workgroups are dealt round-robin over the 8 XCDs, and
   // with split fastest only `splits` of every `max_kv_splits` consecutive blocks do any work, i.e.
@@ -419,6 +443,12 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
    for (int u = 0; u < DEPTH; ++u) {  // unrolled: the register set is a compile-time index
     const int t = t0 + kWavesPerWG * u;
     if (t >= ntiles) break;
+#ifdef RX_DEC_TIMELINE
+    if (t0 == w && u == 0) {  // the first tile's operands have landed
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      RX_TL(1);
+    }
+#endif
     // ---- S^T[token][q] = K Q^T ---------------------------------------------------------
     f32x4 sacc[2];
 #pragma unroll
@@ -547,6 +577,7 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
   }
 
   // ---- merge the four waves through LDS ----------------------------------------------------
+  RX_TL(2);
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
   float* sm_m = reinterpret_cast<float*>(smem + kWavesPerWG * TILE_BYTES);
@@ -594,6 +625,7 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
       }
     }
   }
+  RX_TL(3);
   if (!single && a.merge_counters) {  // stage 2 here: the last of this head block's live splits merges them
     const int32_t per = ((si.seq_len + splits - 1) / splits + kMinBlockKV - 1) / kMinBlockKV * kMinBlockKV;
     const int32_t live = min((si.seq_len + per - 1) / per, min(splits, a.max_kv_splits));
@@ -603,6 +635,10 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
     merge_splits_in_kernel<T>(a.attn_logits + row0 * D, a.attn_lse + row0, min(16, a.group - qb * 16), D, live,
                               a.max_kv_splits, a.sinks ? a.sinks + h0 : nullptr, a.v_scale,
                               a.o + b * a.o_stride_t + h0 * a.o_stride_h, a.o_stride_h);
+#ifdef RX_DEC_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && blockIdx.x < kTlMax) g_dec_timeline[blockIdx.x * 6 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
   }
 }
 
@@ -958,6 +994,16 @@ static int run_mla(const rx_decode_params* p, const DecodeArgs& a, hipStream_t s
 }  // namespace rx
 
 using namespace rx;
+
+#ifdef RX_DEC_TIMELINE
+// dev builds only (not in include/radix_hip.h): copies the first n workgroups' stamps to host memory, [n][6] =
+// entry, first tile landed, loop end, epilogue end, xcc id, merge end (0 when the workgroup did not merge)
+extern "C" int rx_dev_decode_timeline(unsigned long long* out_host, int n) {
+  if (n > kTlMax) n = kTlMax;
+  hipError_t e = hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_dec_timeline), sizeof(unsigned long long) * 6 * n);
+  return e == hipSuccess ? 0 : -3;
+}
+#endif
 
 static int decode_attn_impl(const rx_decode_params* p, void* stream);
 extern "C" int rx_decode_attn(const rx_decode_params* p, void* stream) {

@@ -40,6 +40,31 @@ static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, 
 #undef RX_E32
 }
 
+// the unified (deterministic) instance: extend_mfma32_uni_kernel<T, IdxT, LINEAR, NW>
+template <int NW>
+static void launch32_uni(const Ext32Args& a, bool bf16, bool idx64, bool linear, hipStream_t s) {
+  const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
+  constexpr unsigned kLds = ext32_lds_bytes<NW>();
+  note_dispatch("extend_mfma32_uni_kernel<%s, %s, %s, %d>", bf16 ? "rx::BF16" : "rx::F16", idx64 ? "long" : "int", tbool(linear), NW);
+#define RX_U32(TT, IT, LIN)                                                                            \
+  do {                                                                                                 \
+    auto kern = extend_mfma32_uni_kernel<TT, IT, LIN, NW>;                                             \
+    static const hipError_t attr = hipFuncSetAttribute(                                                \
+        reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);       \
+    (void)attr;                                                                                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), kLds, s, a);                                   \
+  } while (0)
+#define RX_U32_LIN(TT, IT) \
+  do { if (linear) RX_U32(TT, IT, true); else RX_U32(TT, IT, false); } while (0)
+#define RX_U32_IDX(TT) \
+  do { if (idx64) RX_U32_LIN(TT, int64_t); else RX_U32_LIN(TT, int32_t); } while (0)
+  if (bf16) RX_U32_IDX(BF16);
+  else RX_U32_IDX(F16);
+#undef RX_U32_IDX
+#undef RX_U32_LIN
+#undef RX_U32
+}
+
 #ifdef RX_WITH_EXT64
 void launch_extend64(const Ext32Args& a, bool bf16, bool idx64, bool linear, hipStream_t s);  // tools/probe/rx_extend64.hip (dev builds only)
 #endif
@@ -139,6 +164,17 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
       if (a.q_pack == 4) launch32_nw<4, false, true, 4>(a, bf, i64, linear, false, s);
       else launch32_nw<4, false, true, 8>(a, bf, i64, linear, false, s);
     }
+    return RX_OK;
+  }
+  // The one-stage (unified) extend of deterministic inference with no other extra: its own instance, every tile on the
+  // pipelined body in its row-deterministic form (rx_extend32_kernel.inc, UNI).  Option ext32_uni = 0: the general instance
+  // (every tile on the three-phase masked body, as round 5).
+  if (opt.ext32_uni && a.unified_prefix && !a.kv_fp8 && !vsc && !a.custom_mask && a.window <= 0 && a.xai_len <= 0 &&
+      !(a.logit_cap > 0.f) && !a.bias && a.q_pack == 1 && same_kv && !p->skip_prefix && (linear || a.page_size < 0)) {
+    a.sm_scale *= a.k_scale;  // (every key is a pool row: one scale)
+    a.k_scale = 1.0f;
+    if (small_wg) launch32_uni<4>(a, bf, i64, linear, s);
+    else launch32_uni<8>(a, bf, i64, linear, s);
     return RX_OK;
   }
   if (small_wg) {

@@ -22,7 +22,7 @@ from oracle import radix_oracle as orc
 
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAMILIES = ("extend_mfma32_kernel", "extend_mfma64_kernel", "extend_mfma_kernel", "extend_generic_kernel", "extend_d256_kernel", "extend_nd_kernel",
+FAMILIES = ("extend_mfma32_kernel", "extend_mfma32_uni_kernel", "extend_mfma64_kernel", "extend_mfma_kernel", "extend_generic_kernel", "extend_d256_kernel", "extend_nd_kernel",
             "extend_mla_kernel", "decode_mfma_kernel", "decode_mfma_bias_kernel", "decode_generic_kernel", "decode_mla_kernel", "decode_mla8_dma_kernel", "decode_mla8_t64_kernel")
 TN = {"bf16": "rx::BF16", "f16": "rx::F16"}
 TB = {True: "true", False: "false"}
@@ -70,6 +70,12 @@ def _cases():
                     c["kw"]["v_scale"] = 1.25
             c["expect"] = (f"extend_mfma32_kernel<{TN[dt]}, {idx}, {TB[lin]}, {TB[vs]}, {nw}, {TB[kv8]}, {TB[plain]}, {pkc}>")
             out.append(c)
+    # ---- extend, D = 128, the unified (deterministic) instance, round 6: <T, IdxT, LINEAR, NW>
+    for dt, idx, lin, nw in itertools.product(TN, ("int", "long"), (False, True), (4, 8)):
+        hq, hkv = heads()
+        out.append(dict(fam="extend_unified", dt=dt, idx=idx, lin=lin, dk=128, dv=128, hq=hq, hkv=hkv, opts={"ext32_small_wg": int(nw == 4)},
+                        ext=[300, 40, 257, 129], pre=[0, 70, 200, 33], kw={},
+                        expect=f"extend_mfma32_uni_kernel<{TN[dt]}, {idx}, {TB[lin]}, {nw}>"))
     # ---- extend, 16x16x32 kernel of rx_extend.hip: <T, D, IdxT, LINEAR, VSCALE, PLAIN, CB>
     for dt, idx, lin in itertools.product(TN, ("int", "long"), (False, True)):
         for vs, plain, cb in [(False, True, 4), (False, True, 2), (True, True, 2), (False, False, 2), (True, False, 2)]:
@@ -284,6 +290,50 @@ def _run_extend(c, ops, rxlib):
     parity.check_out(o.float().cpu().numpy(), want, dtype, ("dispatch", c["expect"]), ulps=1, absw=absw)
 
 
+def _run_extend_unified(c, ops, rxlib):
+    """The one-stage extend over the unified kv list (prefix slots + the new tokens' slots, all rows in the pool)."""
+    dtype = DT[c["dt"]]
+    hq, hkv, d, ps = c["hq"], c["hkv"], c["dk"], 16
+    pre, ext = np.asarray(c["pre"], np.int64), np.asarray(c["ext"], np.int64)
+    bs, T = len(pre), int(ext.sum())
+    rng = np.random.default_rng(zlib.crc32(c["expect"].encode()))
+    g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+    n_pages = int(sum(-(-int(p + e) // ps) for p, e in zip(pre, ext))) + 3
+    page_ids = rng.permutation(np.arange(1, n_pages))
+    kvi, kvp, pi = [], [0], 0
+    for p_, e_ in zip(pre, ext):
+        n = int(p_ + e_)
+        npg = -(-n // ps)
+        kvi.append((page_ids[pi: pi + npg, None] * ps + np.arange(ps)[None]).reshape(-1)[:n])
+        pi += npg
+        kvp.append(kvp[-1] + n)
+    kvi = np.concatenate(kvi).astype(np.int64)
+    kb = torch.randn(n_pages * ps, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(n_pages * ps, hkv, d, generator=g).to(dtype)
+    q = torch.randn(T, hq, d, generator=g).to(dtype)
+    qo = np.concatenate([[0], np.cumsum(ext)]).astype(np.int64)
+    sm = d ** -0.5
+    want, absw = orc.extend_attention_unified(_bits(q), _bits(kb), _bits(vb), qo, np.asarray(kvp, np.int32), kvi, pre, sm_scale=sm,
+                                              return_absw=True)
+    kd, vd, page, lay, _ = _device_pool(ops, kb, vb, c["lin"], ps, hnd=(len(c["expect"]) % 2 == 0))
+    o = torch.full((T, hq, d), float("nan"), dtype=dtype, device=DEV)
+    idt = torch.int32 if c["idx"] == "int" else torch.int64
+    opts = [rxlib.option(k, v) for k, v in c["opts"].items()]
+    for cm in opts:
+        cm.__enter__()
+    try:
+        ops.extend_attention_fwd_unified(q.to(DEV), o, kd, vd, 1.0, 1.0, torch.from_numpy(qo).to(DEV), torch.tensor(kvp, dtype=torch.int32, device=DEV),
+                                         torch.from_numpy(kvi).to(DEV).to(idt), torch.from_numpy(pre.astype(np.int32)).to(DEV), int(ext.max()),
+                                         sm_scale=sm, is_causal=True, page_size=page, kv_layout=lay)
+        torch.cuda.synchronize()
+        got_name = rxlib.last_dispatch()
+    finally:
+        for cm in reversed(opts):
+            cm.__exit__(None, None, None)
+    assert got_name.split("|")[0] == c["expect"], (got_name, c["expect"])
+    parity.check_out(o.float().cpu().numpy(), want, dtype, ("dispatch", c["expect"]), ulps=1, absw=absw)
+
+
 def _run_decode(c, ops, rxlib):
     dtype = DT[c["dt"]]
     hq, hkv, dk, dv, ps = c["hq"], c["hkv"], c["dk"], c["dv"], 16
@@ -388,4 +438,4 @@ def test_instance_is_dispatched_and_matches_the_oracle(case):
     from sglang_amd import lib as rxlib
     from sglang_amd import ops
 
-    (_run_extend if case["fam"] == "extend" else _run_decode)(case, ops, rxlib)
+    {"extend": _run_extend, "extend_unified": _run_extend_unified}.get(case["fam"], _run_decode)(case, ops, rxlib)

@@ -17,19 +17,26 @@ import os, sys
 import torch, torch.distributed as dist
 sys.path.insert(0, os.environ["RX_ROOT"])
 from sglang_amd.parallel import CustomAllReduce, TPGroup
+import time
+T0 = time.perf_counter()
+def mark(what):   # rank 0: where the wall time of a many-process run goes (GPUTEST budget, VERDICT r05 weak 10)
+    if rank == 0:
+        print(f"[t+{time.perf_counter() - T0:6.1f}s] {what}", flush=True)
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 dev = torch.device("cuda:0")
-ar = CustomAllReduce(None, dev, max_bytes=4 << 20)
+LIGHT = os.environ.get("AR_REPS", "3") == "1"   # world 4 / 6 / 8: the processes time-slice ONE GPU and every call waits for all of them
+TINY = LIGHT and world > 4                      # (a collective among 6 / 8 time-sliced processes costs seconds: the protocol ONCE per call kind)
+mark("process group up")
+ar = CustomAllReduce(None, dev, max_bytes=4 << 20, lanes=1 if TINY else 2)
 tp = TPGroup(None, custom_ar=ar)
 ok = True
+mark("IPC regions mapped")
 
 def parts_for(seed, n, dt):
     g = torch.Generator().manual_seed(seed)
     return [torch.randn(n, generator=g).to(dt) for _ in range(world)]   # same on every rank
 
-LIGHT = os.environ.get("AR_REPS", "3") == "1"   # world 4 / 6 / 8: the processes time-slice ONE GPU and every call waits for all of them
-TINY = LIGHT and world > 4                      # (a collective among 6 / 8 time-sliced processes costs seconds: the protocol ONCE per call kind)
 for it, (n, dt) in enumerate(([(256 * 4096, torch.bfloat16)] if TINY else
                               [(8, torch.bfloat16), (256 * 4096, torch.bfloat16), (1000 * 8, torch.float16)] if LIGHT else
                               [(8, torch.bfloat16), (256 * 4096, torch.bfloat16), (1000 * 8, torch.float16),
@@ -47,11 +54,12 @@ for it, (n, dt) in enumerate(([(256 * 4096, torch.bfloat16)] if TINY else
         ok = False
         print(f"rank {rank} it {it} n {n}: max diff", (got.cpu().float() - want.float()).abs().max().item(), flush=True)
 
+mark("eager calls")
 # ---- HIP-graph capture: THREE consecutive calls in one graph, replayed three times with fresh inputs.  The call
 # numbers live on the device, so every replay is calls g+1, g+2, g+3 -- with a host-side counter the replays
 # would resend the capture-time numbers and read stale (or not yet written) peer buffers.
 n = 64 * 4096
-bufs = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for _ in range(2 if TINY else 3)]
+bufs = [torch.zeros(n, dtype=torch.bfloat16, device=dev) for _ in range(1 if TINY else 3)]
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
@@ -83,6 +91,7 @@ ar.all_reduce(x)
 torch.cuda.synchronize()
 ok = ok and torch.equal(x.cpu(), sum(p.float() for p in parts).to(torch.bfloat16))
 
+mark("graph capture + replays")
 # ---- fused all-reduce + residual add + RMSNorm vs the split path in fp32 torch (parallel_state.py:748-878)
 for (T, H, dt, tol) in ([(7, 8192, torch.float16, 2e-3)] if TINY else [(256, 4096, torch.bfloat16, 2e-2), (7, 8192, torch.float16, 2e-3)] if LIGHT else
                         [(256, 4096, torch.bfloat16, 2e-2), (7, 8192, torch.float16, 2e-3), (33, 1024, torch.bfloat16, 2e-2),
@@ -109,6 +118,7 @@ for (T, H, dt, tol) in ([(7, 8192, torch.float16, 2e-3)] if TINY else [(256, 409
     if not err <= tol:
         ok = False
         print(f"rank {rank} fused norm {T}x{H}: max err {err}", flush=True)
+mark("fused rmsnorm")
 # ---- the deterministic one-shot form (rx_allreduce_det; VERDICT r05 item 5) ------------------------------------------
 # (a) == the fp32 rank-order sum, one rounding; (b) bit-identical across three runs; (c) across ranks (every rank compares
 # with the same host value); (d) the same rows embedded in a LARGER batch give the same bits; (e) a message above the
@@ -168,6 +178,7 @@ if not TINY:
     except RuntimeError:
         pass
 assert ar.check_errors() == 0
+mark("deterministic form")
 if TINY:
     ar.close()
     dist.destroy_process_group()
@@ -263,5 +274,6 @@ def test_custom_allreduce_across_processes(world, tmp_path):
             out, _ = p.communicate()
             out += "\nTIMEOUT"
         outs.append(out)
+    print(f"[world {world}] rank 0 timeline:\n" + "\n".join(ln for ln in outs[0].splitlines() if ln.startswith("[t+")))  # (pytest -s / -rA)
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "RANK_OK" in out, f"rank {r}:\n{out[-2000:]}"

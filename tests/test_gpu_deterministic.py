@@ -87,7 +87,7 @@ def test_extend_rows_do_not_depend_on_the_prefix_split_or_the_batch(dtype, d):
     assert hs.backend.enable_deterministic and hs.backend.split_tile_size == 256
     rows = hs.r2t.alloc(1)
     o_whole = _extend(hs, rows, [0], [L], q, k, v)
-    assert rxlib.last_dispatch().startswith("extend_mfma32_kernel" if d == 128 else "extend_generic_kernel"), rxlib.last_dispatch()
+    assert rxlib.last_dispatch().startswith("extend_mfma32_uni_kernel" if d == 128 else "extend_generic_kernel"), rxlib.last_dispatch()
     kb, vb = hs.pool.get_kv_buffer(0)
     r2t = hs.r2t.req_to_token.cpu().numpy()
     idx = r2t[rows[0], :L].astype(np.int64)

@@ -57,7 +57,7 @@ def _run_child(kind, **kw):
 
 def _load(out, name, bf16=False):
     a = np.load(os.path.join(out, name + ".npy"), mmap_mode="r")
-    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    t = torch.from_numpy(np.array(a)).to(DEV)
     return t.view(torch.bfloat16) if bf16 else t
 
 
@@ -72,16 +72,19 @@ def _hnd_pool(out, ps):
 
 
 def _close(got, want, atol, rtol, tag):
-    """torch.testing.assert_close's rule |got - want| <= atol + rtol * |want|, with the observed error recorded."""
+    """torch.testing.assert_close's rule |got - want| <= atol + rtol * |want| (the reference tests' own), with the observed
+    error recorded: the element with the worst error / bound ratio goes to parity_util.check (err, its bound)."""
     g, w = got.float(), want.float()
     diff = (g - w).abs()
-    excess = float((diff - (atol + rtol * w.abs())).max().item())
-    err = float(diff.max().item())
+    bound = atol + rtol * w.abs()
+    ratio = diff / bound
+    i = int(ratio.argmax().item())
+    err_max = float(diff.max().item())
     cos = float(torch.nn.functional.cosine_similarity(g.flatten(), w.flatten(), dim=0).item())
-    parity.check(err, atol, tag=f"{tag} vs reference CPU kernel (cos {cos:.6f})")
-    assert excess <= 0.0, (tag, "max-abs err", err, "excess over atol + rtol*|want|", excess)
+    parity.check(float(diff.flatten()[i].item()), float(bound.flatten()[i].item()),
+                 tag=f"{tag} vs reference CPU kernel (max-abs err {err_max:.3e}, cos {cos:.6f}, bound atol {atol} + rtol {rtol} |want|)")
     assert cos > 0.99, (tag, cos)
-    return err
+    return err_max
 
 
 DECODE_CASES = [
