@@ -202,6 +202,9 @@ __device__ __forceinline__ void split_range(int32_t seq_len, int32_t splits, int
 #ifndef RX_DEC_FP8_DEPTH
 #define RX_DEC_FP8_DEPTH 2  // K/V register sets (tiles in flight per wave) of the fp8-pool kernel
 #endif
+#ifndef RX_DEC_16_DEPTH
+#define RX_DEC_16_DEPTH 1  // K/V register sets of the 16-bit kernels (dev A/B: 2 = two tiles in flight per wave)
+#endif
 #ifndef RX_DEC_NT
 #define RX_DEC_NT 0  // 1: non-temporal K/V loads
 #endif
@@ -334,23 +337,6 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
   }
   const int ntiles = (hi - lo + kTile - 1) / kTile;
 
-  // ---- Q^T fragments (B operand): lane (r,g) holds Q[h][32s + 8g .. +8] ----------------
-  vec8 qf[KS];
-  {
-    const uint16_t* qp = a.q + b * a.q_stride_t + (q_valid ? h : 0) * a.q_stride_h + 8 * g;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      // element offset of k-step s for this lane (qp already carries + 8 g)
-      const int qoff = KV8 ? 64 * (s >> 1) + 8 * g + 8 * (s & 1) : 32 * s;  // fp8: 64 j + 16 g + 8 e
-      u32x4 raw = q_valid ? *reinterpret_cast<const u32x4*>(qp + qoff) : u32x4{0, 0, 0, 0};
-      qf[s] = __builtin_bit_cast(vec8, raw);
-    }
-  }
-
-  // The Q fragments must have LANDED before the tile loop: hipcc's waitcnt pass merges the loop-entry
-  // state (Q loads possibly pending) into the loop header and would otherwise emit vmcnt(0) in front
-  // of the first MFMA of EVERY iteration, i.e. wait for the next tile's prefetch before computing.
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
   const KvE* kbase = reinterpret_cast<const KvE*>(a.k_buf) + kvh * a.k_head_stride + (KV8 ? 16 : 8) * g;
   const KvE* vbase = reinterpret_cast<const KvE*>(a.v_buf) + kvh * a.v_head_stride + (KV8 ? 16 : 8) * g;
   char* vt = smem + w * TILE_BYTES;  // this wave's V tile
@@ -375,7 +361,7 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
   // Register sets of K/V tiles in flight per wave.  One 32-token tile is 16 KiB of a 16-bit pool but
   // 8 KiB of an fp8 pool: with a single set the fp8 kernel has half the bytes in flight and ran at
   // 4.55 TB/s; two sets restore the 128 KiB per CU of the 16-bit kernel in the same registers.
-  constexpr int DEPTH = KV8 ? RX_DEC_FP8_DEPTH : 1;
+  constexpr int DEPTH = KV8 ? RX_DEC_FP8_DEPTH : ((D <= 128 && !OCC3 && !BIAS) ? RX_DEC_16_DEPTH : 1);
   KvV kf[DEPTH][2][NL], vf[DEPTH][2][NL];  // fp8 pools: upcast (exact) where consumed
   constexpr int LSTEP = KV8 ? 64 : 32;  // elements between a lane's consecutive loads
   int64_t new_slot = 0;  // FUSE: pool slot of the newest token, kept from the slot list (no dependent load at the tail)
@@ -426,14 +412,38 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
   // set u holds tile w + 4 (u + DEPTH k); n0/n1[u] = the slots of the tile that will refill it
   constexpr int STEP = kWavesPerWG * DEPTH;
   int64_t n0[DEPTH], n1[DEPTH];
+  // The first tiles' slot ids are requested BEFORE the q rows and land with them (one wait): the prologue is a chain of
+  // dependent round trips -- kernel arguments -> request row / length -> slot ids -> K / V rows -> first product -- and q used
+  // to be a link of its own in it (tools/decode_timeline.py, round 6: entry -> first tile landed 5.0 us on an idle chip).
+  int64_t f0[DEPTH], f1[DEPTH];
 #pragma unroll
   for (int u = 0; u < DEPTH; ++u) {
-    n0[u] = n1[u] = 0;
+    n0[u] = n1[u] = f0[u] = f1[u] = 0;
+    const int tt = w + kWavesPerWG * u;
+    if (tt < ntiles) load_slots(tt, f0[u], f1[u]);
+  }
+  // ---- Q^T fragments (B operand): lane (r,g) holds Q[h][32s + 8g .. +8] ----------------
+  vec8 qf[KS];
+  {
+    const uint16_t* qp = a.q + b * a.q_stride_t + (q_valid ? h : 0) * a.q_stride_h + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      // element offset of k-step s for this lane (qp already carries + 8 g)
+      const int qoff = KV8 ? 64 * (s >> 1) + 8 * g + 8 * (s & 1) : 32 * s;  // fp8: 64 j + 16 g + 8 e
+      u32x4 raw = q_valid ? *reinterpret_cast<const u32x4*>(qp + qoff) : u32x4{0, 0, 0, 0};
+      qf[s] = __builtin_bit_cast(vec8, raw);
+    }
+  }
+
+  // The Q fragments must have LANDED before the tile loop: hipcc's waitcnt pass merges the loop-entry
+  // state (Q loads possibly pending) into the loop header and would otherwise emit vmcnt(0) in front
+  // of the first MFMA of EVERY iteration, i.e. wait for the next tile's prefetch before computing.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), lgkmcnt/expcnt untouched
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) {
     const int tt = w + kWavesPerWG * u;
     if (tt < ntiles) {
-      int64_t s0, s1;
-      load_slots(tt, s0, s1);
-      load_kv(tt, s0, s1, kf[u], vf[u]);
+      load_kv(tt, f0[u], f1[u], kf[u], vf[u]);
       if (tt + STEP < ntiles) load_slots(tt + STEP, n0[u], n1[u]);
     }
   }
