@@ -29,7 +29,6 @@ struct Options {
   int ext32_pack_min_wgs = -1;    // ... while the packed grid holds this many workgroups (-1: the device's CU count)
   int ext32_pack4_tiles = 24;    // ... and FOUR waves (two workgroups per CU) below this tile estimate
   int ext32_plain = 1;        // PLAIN instances (features compile-time off) when the call uses none of them
-  int ext32_bias = 1;         // biased (relative_bias_score_mod) D = 128 calls on their own instance with the pipelined biased tile body (0: the general instance)
   int ext32_uni = 1;          // the unified (deterministic) extend on its own instance: pipelined, row-deterministic (0: the general instance's masked body)
   int roctx = 0;              // roctx ranges around the entry points' launches (RX_RANGE)
   int ext32_count_redo = 0;   // debug: the bench-shaped packed call runs the COUNTING instance (rx_debug_counters)

@@ -40,17 +40,15 @@ static void launch32_nw(const Ext32Args& a, bool bf16, bool idx64, bool linear, 
 #undef RX_E32
 }
 
-// the unified (deterministic) instance extend_mfma32_uni_kernel<T, IdxT, LINEAR, NW> (BIASK = false) or the biased instance
-// extend_mfma32_bias_kernel<T, IdxT, LINEAR, NW> (BIASK = true)
-template <int NW, bool BIASK = false>
+// the unified (deterministic) instance: extend_mfma32_uni_kernel<T, IdxT, LINEAR, NW>
+template <int NW>
 static void launch32_uni(const Ext32Args& a, bool bf16, bool idx64, bool linear, hipStream_t s) {
   const unsigned grid = static_cast<unsigned>(a.bs) * a.hq * a.mblocks;
   constexpr unsigned kLds = ext32_lds_bytes<NW>();
-  note_dispatch(BIASK ? "extend_mfma32_bias_kernel<%s, %s, %s, %d>" : "extend_mfma32_uni_kernel<%s, %s, %s, %d>", bf16 ? "rx::BF16" : "rx::F16",
-                idx64 ? "long" : "int", tbool(linear), NW);
+  note_dispatch("extend_mfma32_uni_kernel<%s, %s, %s, %d>", bf16 ? "rx::BF16" : "rx::F16", idx64 ? "long" : "int", tbool(linear), NW);
 #define RX_U32(TT, IT, LIN)                                                                            \
   do {                                                                                                 \
-    auto kern = BIASK ? extend_mfma32_bias_kernel<TT, IT, LIN, NW> : extend_mfma32_uni_kernel<TT, IT, LIN, NW>; \
+    auto kern = extend_mfma32_uni_kernel<TT, IT, LIN, NW>;                                             \
     static const hipError_t attr = hipFuncSetAttribute(                                                \
         reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);       \
     (void)attr;                                                                                        \
@@ -181,13 +179,6 @@ int launch_extend32(const rx_extend_params* p, hipStream_t s) {
     a.k_scale = 1.0f;
     if (small_wg) launch32_uni<4>(a, bf, i64, linear, s);
     else launch32_uni<8>(a, bf, i64, linear, s);
-    return RX_OK;
-  }
-  // A biased call (score_mod = relative_bias_score_mod) on a 16-bit pool without a v scale: its own instance, with the
-  // pipelined biased tile body for the tiles inside the extent.  Option ext32_bias = 0: the general instance.
-  if (opt.ext32_bias && a.bias && !a.unified_prefix && !a.kv_fp8 && !vsc && (linear || a.page_size < 0)) {
-    if (small_wg) launch32_uni<4, true>(a, bf, i64, linear, s);
-    else launch32_uni<8, true>(a, bf, i64, linear, s);
     return RX_OK;
   }
   if (small_wg) {

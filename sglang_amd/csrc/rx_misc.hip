@@ -118,7 +118,7 @@ static const OptionEntry kOptionTable[] = {
     {"ext32_pack_min_tiles", &Options::ext32_pack_min_tiles}, {"ext32_pack4_tiles", &Options::ext32_pack4_tiles}, {"ext32_pack_min_wgs", &Options::ext32_pack_min_wgs},
     {"roctx", &Options::roctx},
     {"ext64", &Options::ext64},                           {"ext32_count_redo", &Options::ext32_count_redo},
-    {"ext32_plain", &Options::ext32_plain},               {"ext32_uni", &Options::ext32_uni},               {"ext32_bias", &Options::ext32_bias},
+    {"ext32_plain", &Options::ext32_plain},               {"ext32_uni", &Options::ext32_uni},               
                  {"extend_16x16_d128", &Options::extend_16x16_d128},
     {"extend_d256", &Options::extend_d256},               {"extend_d256_min_rows", &Options::extend_d256_min_rows},
                    {"extend_d256_at128", &Options::extend_d256_at128},

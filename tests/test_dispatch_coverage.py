@@ -22,7 +22,7 @@ from oracle import radix_oracle as orc
 
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAMILIES = ("extend_mfma32_kernel", "extend_mfma32_uni_kernel", "extend_mfma32_bias_kernel", "extend_mfma64_kernel", "extend_mfma_kernel", "extend_generic_kernel", "extend_d256_kernel", "extend_nd_kernel",
+FAMILIES = ("extend_mfma32_kernel", "extend_mfma32_uni_kernel", "extend_mfma64_kernel", "extend_mfma_kernel", "extend_generic_kernel", "extend_d256_kernel", "extend_nd_kernel",
             "extend_mla_kernel", "decode_mfma_kernel", "decode_mfma_bias_kernel", "decode_generic_kernel", "decode_mla_kernel", "decode_mla8_dma_kernel", "decode_mla8_t64_kernel")
 TN = {"bf16": "rx::BF16", "f16": "rx::F16"}
 TB = {True: "true", False: "false"}
@@ -76,12 +76,6 @@ def _cases():
         out.append(dict(fam="extend_unified", dt=dt, idx=idx, lin=lin, dk=128, dv=128, hq=hq, hkv=hkv, opts={"ext32_small_wg": int(nw == 4)},
                         ext=[300, 40, 257, 129], pre=[0, 70, 200, 33], kw={},
                         expect=f"extend_mfma32_uni_kernel<{TN[dt]}, {idx}, {TB[lin]}, {nw}>"))
-    # ---- extend, D = 128, the biased instance (score_mod = relative_bias_score_mod), round 6: <T, IdxT, LINEAR, NW>
-    for dt, idx, lin, nw in itertools.product(TN, ("int", "long"), (False, True), (4, 8)):
-        hq, hkv = heads()
-        out.append(dict(fam="extend", dt=dt, idx=idx, lin=lin, dk=128, dv=128, hq=hq, hkv=hkv, opts={"ext32_small_wg": int(nw == 4)},
-                        ext=[300, 40, 257, 129], pre=[0, 70, 200, 33], kw={}, bias=True,
-                        expect=f"extend_mfma32_bias_kernel<{TN[dt]}, {idx}, {TB[lin]}, {nw}>"))
     # ---- extend, 16x16x32 kernel of rx_extend.hip: <T, D, IdxT, LINEAR, VSCALE, PLAIN, CB>
     for dt, idx, lin in itertools.product(TN, ("int", "long"), (False, True)):
         for vs, plain, cb in [(False, True, 4), (False, True, 2), (True, True, 2), (False, False, 2), (True, False, 2)]:
