@@ -239,7 +239,7 @@ __device__ __forceinline__ u32x4 kv_frag16(V raw) {
 // decode_attention.py:539-551) -- the score against list position n gets + bias[b, h, (len - 1) - n] inside [0, bias_len).
 // Its own instances: the plain kernels carry none of it.
 template <typename T, int D, typename IdxT, bool LINEAR, bool KV8, bool FUSE, bool OCC3, bool BIAS>
-__device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
+__device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a, const int block_id) {
   static_assert(!(FUSE && KV8), "the fused store writes 16-bit rows");
   static_assert(!BIAS || (!FUSE && !KV8 && !OCC3), "the biased instances are the plain 16-bit ones");
   using vec8 = typename T::vec8;
@@ -275,7 +275,7 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
   // split is the SLOWEST grid dimension: workgroups are dealt round-robin over the 8 XCDs, and
   // with split fastest only `splits` of every `max_kv_splits` consecutive blocks do any work, i.e.
   // the live blocks would pile onto splits/8 of the chip (measured: 2 live splits of 8 -> 2.0 TB/s).
-  int bid = blockIdx.x;
+  int bid = block_id;
   const int qb = bid % a.qblocks;
   bid /= a.qblocks;
   const int kvh = bid % a.hkv;
@@ -654,11 +654,16 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a) {
 
 template <typename T, int D, typename IdxT, bool LINEAR, bool KV8, bool FUSE = false, bool OCC3 = false>
 __global__ __launch_bounds__(256, OCC3 ? 3 : RX_DEC_MINW) void decode_mfma_kernel(const DecodeArgs a) {
-  decode_mfma_body<T, D, IdxT, LINEAR, KV8, FUSE, OCC3, false>(a);
+  decode_mfma_body<T, D, IdxT, LINEAR, KV8, FUSE, OCC3, false>(a, blockIdx.x);
 }
+// (A RESIDENT form of this kernel -- at most two workgroups per CU, each walking (request, split) units handed out by a
+// device-side queue -- was built and measured in round 6 and removed: without the next unit's first tiles requested under the
+// current unit's tail, every unit pays its whole prologue and epilogue, and finer pieces cost more than the balance buys.
+// TP = 8 shard, 256 x 4 k, us per launch, queue-fed / hardware-dispatched grid: 1 split 106.7 / 104.0, 4 splits 112.9 / 111.0,
+// 8 splits 116.5 / 113.2; configs[1] 8 splits 131.4 / 131.8.  DESIGN 4.1 has the per-workgroup timeline behind it.)
 template <typename T, int D, typename IdxT, bool LINEAR>
 __global__ __launch_bounds__(256, RX_DEC_MINW) void decode_mfma_bias_kernel(const DecodeArgs a) {
-  decode_mfma_body<T, D, IdxT, LINEAR, false, false, false, true>(a);
+  decode_mfma_body<T, D, IdxT, LINEAR, false, false, false, true>(a, blockIdx.x);
 }
 
 // ---- generic fallback: any head dims (Dk != Dv, 13, 80, 96, 576/512 ...) --------------------

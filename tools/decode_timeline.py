@@ -77,6 +77,13 @@ def run(bs, ctx, S, mc):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
+    if os.environ.get("NOSTAMPS"):  # (a product library: the launch time only; checks the result against the unsplit pass)
+        o_s = o.clone()
+        ops.decode_attention_fwd_paged(q, kb, vb, o, r2t, rpi, lens, None, None, None, 1, D ** -0.5, page_size=PS, kv_layout=lay)
+        torch.cuda.synchronize()
+        print(f"bs={bs} ctx={ctx} Hq={HQ} Hkv={HKV} S={S}: graph {us:.1f} us/launch ({bs * ctx * HKV * D * 4 / us / 1e6:.2f} TB/s) "
+              f"{rxlib.last_dispatch() if False else ''} max|o - o_unsplit| {(o_s.float() - o.float()).abs().max().item():.4f}")
+        return
     for _ in range(5):
         f()
     torch.cuda.synchronize()
