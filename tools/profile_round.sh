@@ -1,7 +1,7 @@
 #!/bin/bash
 # Reproduces the committed profiles/ set on an MI355X box:  bash tools/profile_round.sh <tag>
 # (run through gpurun; then `python profiles/summarize.py gpurun_out/prof <tag>` condenses the CSVs)
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof
@@ -30,6 +30,15 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pw --output-format csv -- python
 PS=64 rocprofv3 --pmc FETCH_SIZE -d $OUT/mla16_pmc -o p --output-format csv -- python3 $R/tools/mla_bench.py > /dev/null 2> $OUT/mla16_pmc.err
 PS=64 FP8=1 rocprofv3 --pmc FETCH_SIZE -d $OUT/mla8_pmc -o p --output-format csv -- python3 $R/tools/mla_bench.py > /dev/null 2> $OUT/mla8_pmc.err
 python3 $R/profiles/summarize.py $OUT $TAG
+# SHORT decode launches (round 6): the shard legs' kernel under the kernel trace -- rocprofv3's duration of the decode kernel
+# is what bench.py's back-to-back figure (GraphStep.probe_back_to_back) must agree with, not the single launch between events
+rocprofv3 --kernel-trace --stats -d $OUT/c3 -o c3 --output-format csv -- python3 $R/bench.py --model llama3-70b --tp-sim 8 --bs 128 --ctx 4096 --layers 80 --no-extend --no-radix-hit --no-cpu-baseline --no-extra --steps 3 --warmup 1 > $OUT/c3.out 2> $OUT/c3.err
+split_lines $OUT/c3.out $OUT/${TAG}_config3_shard_under_kernel_trace
+cp $(find $OUT/c3 -name "*_kernel_stats.csv" | head -1) $R/profiles/${TAG}_config3_shard_kernel_stats.csv 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $OUT/tp8 -o tp8 --output-format csv -- python3 $R/bench.py --tp-sim 8 --no-extend --no-radix-hit --no-cpu-baseline --no-extra --steps 3 --warmup 1 > $OUT/tp8.out 2> $OUT/tp8.err
+split_lines $OUT/tp8.out $OUT/${TAG}_tp8_shard_under_kernel_trace
+cp $(find $OUT/tp8 -name "*_kernel_stats.csv" | head -1) $R/profiles/${TAG}_tp8_shard_kernel_stats.csv 2>/dev/null
+cp $OUT/${TAG}_config3_shard_under_kernel_trace_full.json $OUT/${TAG}_tp8_shard_under_kernel_trace_full.json $R/profiles/ 2>/dev/null
 # MLA decode (config 5 shape): kernel traces for 16-bit and fp8 latent rows
 rocprofv3 --kernel-trace --stats -d $OUT/mla16 -o m --output-format csv -- python3 $R/tools/mla_bench.py > $OUT/mla16.txt 2> $OUT/mla16.err
 FP8=1 rocprofv3 --kernel-trace --stats -d $OUT/mla8 -o m --output-format csv -- python3 $R/tools/mla_bench.py > $OUT/mla8.txt 2> $OUT/mla8.err
