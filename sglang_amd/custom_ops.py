@@ -172,7 +172,22 @@ def fused_qk_norm_rope_out(qkv: Tensor, q_weight: Tensor, k_weight: Tensor, posi
                            position_ids, factor, low, high, attention_factor, rotary_dim)
 
 
-ALL_OPS = (fused_qk_norm_rope_out, merge_state, shared_prefix_plan, store_cache, build_kv_indices, get_num_kv_splits, decode_attention, decode_attention_paged,
+# fused_fp8_qkv_kv_cache (kernels/ops/kvcache/fused_fp8_qkv_kv_cache.py:35-80) as out-variant ops: the reference's function
+# allocates and returns q's fp8 copy; behind torch.library the caller owns it (an optional mutated argument cannot be omitted,
+# so the form without q is its own op)
+@_op("fused_fp8_qkv_kv_cache_out", ("q_out", "k_cache", "v_cache"))
+def fused_fp8_qkv_kv_cache_out(q: Tensor, k: Tensor, v: Tensor, q_out: Tensor, k_cache: Tensor, v_cache: Tensor,
+                               cache_loc: Tensor, k_scale: Optional[Tensor] = None, v_scale: Optional[Tensor] = None) -> None:
+    ops.fused_fp8_qkv_kv_cache(q, k, v, k_cache, v_cache, cache_loc, k_scale, v_scale, q_out=q_out)
+
+
+@_op("fused_fp8_kv_cache", ("k_cache", "v_cache"))
+def fused_fp8_kv_cache(k: Tensor, v: Tensor, k_cache: Tensor, v_cache: Tensor, cache_loc: Tensor,
+                       k_scale: Optional[Tensor] = None, v_scale: Optional[Tensor] = None) -> None:
+    ops.fused_fp8_qkv_kv_cache(None, k, v, k_cache, v_cache, cache_loc, k_scale, v_scale)
+
+
+ALL_OPS = (fused_fp8_qkv_kv_cache_out, fused_fp8_kv_cache, fused_qk_norm_rope_out, merge_state, shared_prefix_plan, store_cache, build_kv_indices, get_num_kv_splits, decode_attention, decode_attention_paged,
            extend_attention, extend_attention_lse, alloc_extend, alloc_decode, write_req_to_token, move_kv)
 
 for _o in ALL_OPS:  # in-place ops: the fake implementation has nothing to compute

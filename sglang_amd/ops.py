@@ -129,13 +129,14 @@ def store_cache_fp8(k, v, layout: "_L.RxKvLayout", indices, num_kv_heads, head_d
 def fused_fp8_qkv_kv_cache(q: Optional[torch.Tensor], k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor,
                            v_cache: torch.Tensor, cache_loc: torch.Tensor, k_scale: Optional[torch.Tensor] = None,
                            v_scale: Optional[torch.Tensor] = None, *, kv_layout=None, page_size: int = 1,
-                           err_flag: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                           err_flag: Optional[torch.Tensor] = None, q_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """fused_fp8_qkv_kv_cache (kernels/ops/kvcache/fused_fp8_qkv_kv_cache.py:35-80), same name, argument order and
     return: fp8 e4m3fn quantisation of K / V into the paged cache at ``cache_loc`` and -- when ``q`` is given -- of q into
     a fresh dense fp8 tensor that is returned (``None`` otherwise).  k / v: 16-bit [n, Hkv, D] or [n, Hkv*D], rows may be
     strided (slices of a fused qkv tensor); k_cache / v_cache: fp8 (or uint8) pools ``[slots, Hkv, D]`` -- or an HND pool
     with ``kv_layout=ops.kv_layout_hnd(...)``; k_scale / v_scale: fp32 DEVICE scalars or None (= 1).  y = x * (1 / scale),
-    saturated to +-448 (the reference kernel's arithmetic; rx_fused_fp8_qkv_kv_cache)."""
+    saturated to +-448 (the reference kernel's arithmetic; rx_fused_fp8_qkv_kv_cache).  ``q_out``: a caller-owned fp8 output for q
+    (the custom-op out-variant, torch.ops.radix_hip.fused_fp8_qkv_kv_cache_out); by default a fresh tensor as the reference."""
     if k.dtype not in (torch.bfloat16, torch.float16):
         raise RuntimeError(f"Unsupported dtype {k.dtype}. Supported: bfloat16, float16")
     _require_cuda(q, k, v, k_cache, v_cache, cache_loc, k_scale, v_scale)
@@ -170,7 +171,10 @@ def fused_fp8_qkv_kv_cache(q: Optional[torch.Tensor], k: torch.Tensor, v: torch.
         q2 = q.reshape(n, -1)
         if q2.dtype != k2.dtype or q2.stride(-1) != 1:
             raise ValueError("fused_fp8_qkv_kv_cache: q must have k's dtype and be contiguous in the last dim")
-        q_out = torch.empty(q2.shape, dtype=torch.float8_e4m3fn, device=q.device)
+        if q_out is None:
+            q_out = torch.empty(q2.shape, dtype=torch.float8_e4m3fn, device=q.device)
+        elif (not _is_fp8_pool(q_out) or q_out.numel() != q2.numel() or not q_out.is_contiguous() or not q_out.is_cuda):
+            raise ValueError("fused_fp8_qkv_kv_cache: q_out must be a contiguous fp8 GPU tensor of q's element count")
     if n == 0:
         return q_out
     idx = cache_loc if cache_loc.is_contiguous() else cache_loc.contiguous()

@@ -68,7 +68,10 @@ def test_torch_custom_ops_registered_with_fake_impls():
     names = {o._qualname.split("::")[1] for o in custom_ops.ALL_OPS}
     assert names == {"store_cache", "build_kv_indices", "get_num_kv_splits", "decode_attention",
                      "decode_attention_paged", "extend_attention", "extend_attention_lse", "alloc_extend", "alloc_decode",
-                     "write_req_to_token", "move_kv", "merge_state", "shared_prefix_plan", "fused_qk_norm_rope_out"}
+                     "write_req_to_token", "move_kv", "merge_state", "shared_prefix_plan", "fused_qk_norm_rope_out",
+                     "fused_fp8_qkv_kv_cache_out", "fused_fp8_kv_cache"}
+    sch8 = str(torch.ops.radix_hip.fused_fp8_qkv_kv_cache_out.default._schema)   # q's fp8 copy and both pools are mutated
+    assert "q_out" in sch8 and sch8.count("!") == 3 and sch8.endswith("-> ()")
     assert "Tensor(a0!) qkv" in str(torch.ops.radix_hip.fused_qk_norm_rope_out.default._schema)   # the reference's op name, mutates qkv
     sch = str(torch.ops.radix_hip.decode_attention.default._schema)
     assert "Tensor(a3!) o" in sch and "attn_logits" in sch and sch.endswith("-> ()")

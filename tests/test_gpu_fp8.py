@@ -352,6 +352,16 @@ def test_fused_fp8_qkv_kv_cache_edge_values_hnd_pool_and_errors(ops, dtype, gold
     assert np.array_equal(got_v, orc.quantize_fused_fp8(v.float().cpu().numpy(), np.float32(2.5)))
     assert np.array_equal(q8.view(torch.uint8).cpu().numpy(), orc.quantize_fused_fp8(q.float().cpu().numpy()))
     assert int(err.item()) == 0
+    # the custom-op out-variants (torch.ops.radix_hip.*: the caller owns q's fp8 copy) write the same bytes
+    import sglang_amd.custom_ops  # noqa: F401
+    kc2, vc2 = torch.zeros(pages * page, hkv, d, dtype=FP8, device=DEV), torch.zeros(pages * page, hkv, d, dtype=FP8, device=DEV)
+    q8b = torch.zeros_like(q8)
+    torch.ops.radix_hip.fused_fp8_qkv_kv_cache_out(q, k, v, q8b, kc2, vc2, loc, ks, vs)
+    assert torch.equal(q8b.view(torch.uint8), q8.view(torch.uint8))
+    assert np.array_equal(kc2.view(torch.uint8)[loc].cpu().numpy(), got_k) and np.array_equal(vc2.view(torch.uint8)[loc].cpu().numpy(), got_v)
+    kc3, vc3 = torch.zeros_like(kc2), torch.zeros_like(vc2)
+    torch.ops.radix_hip.fused_fp8_kv_cache(k, v, kc3, vc3, loc, ks, vs)
+    assert torch.equal(kc3.view(torch.uint8), kc2.view(torch.uint8)) and torch.equal(vc3.view(torch.uint8), vc2.view(torch.uint8))
     bad = loc.clone()
     bad[3] = pages * page + 5
     ops.fused_fp8_qkv_kv_cache(None, k, v, kh, vh, bad, ks, vs, kv_layout=ops.kv_layout_hnd(kh, vh), err_flag=err)

@@ -1,5 +1,5 @@
 # end-of-round GPU pass (through gpurun):  bash tools/probe/final.sh <tag>
-TAG=${1:-r04}
+TAG=${1:-r06}
 rm -f gpurun_out/parity_errors.jsonl
 timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -4
 bash tools/profile_round.sh $TAG > gpurun_out/profile_round.log 2>&1
