@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-/* 15 (round 6): rx_fused_fp8_qkv_kv_cache, rx_pool_alloc_extend_rows, rx_allreduce_det (deterministic fixed-order reduce);
+/* 15 (round 6): rx_fused_fp8_qkv_kv_cache, rx_pool_alloc_extend_rows, rx_allreduce_det (deterministic fixed-order reduce),
+ * rx_decode_units + rx_decode_params.unit_desc / unit_first_slots (appended);
  * the experimental rx_extend64 kernel left the product library (dev builds: RX_WITH_EXT64=1).
  * 14 (round 5): score_bias* appended to rx_decode_params / rx_extend_params (score_mod = relative_bias_score_mod).
  * 13 (round 5): rx_clock_probe.
@@ -413,9 +414,28 @@ typedef struct rx_decode_params {
   int32_t score_bias_is_f32;
   int32_t score_bias_len;
   int64_t score_bias_stride_t, score_bias_stride_h;
+  /* ---- per-unit descriptors, round 6 (ABI 15; no reference counterpart): tables built ONCE per forward by rx_decode_units
+   * (all layers share them) that shorten every decode launch's prologue.  A workgroup otherwise walks a chain of dependent
+   * round trips before its first K / V byte is requested -- kernel arguments -> (request, split) pair -> request row /
+   * length / split count -> slot ids of its first tiles -> K / V rows; ~1.1 us each at kernel start, tools/decode_timeline.py
+   * -- with the tables the chain is kernel arguments -> {descriptor, first-tile slot ids} -> K / V rows.
+   * unit_desc int32 [units][8] = b, split, seq_len, num_kv_splits[b], row offset (low, high 32 bits, elements of
+   * req_to_token), lo, hi (the split's token range); unit_first_slots int32 [units][128] = the slot of token
+   * min(lo + j, hi - 1).  Unit u = the u-th (request, split) pair of split_items, or (max_kv_splits == 1) the u-th request in
+   * launch order.  req_to_token mode of the D = 64 / 96 / 128 / 256 kernel only (ignored elsewhere); both or neither;
+   * the tables must have been built from the SAME req_to_token / seq_lens / schedule the call passes. */
+  const int32_t* unit_desc;
+  const int32_t* unit_first_slots;
 } rx_decode_params;
 
 int rx_decode_attn(const rx_decode_params* p /* HOST */, void* stream);
+/* Builds rx_decode_params.unit_desc / unit_first_slots (see there) on the device: one launch, stream ordered, allocation free.
+ * split_items / split_items_count (with their cap = the number of table rows to fill) or, for an unsplit step, NULL and
+ * cap = bs; request_order as in rx_decode_params (or NULL).  unit_desc holds cap x 8, unit_first_slots cap x 128 int32. */
+int rx_decode_units(const int32_t* req_to_token, int64_t req_row_stride, const void* req_pool_indices,
+                    int req_pool_indices_is_i64, const void* seq_lens, int seq_lens_is_i64, const int32_t* num_kv_splits,
+                    int max_kv_splits, const int32_t* split_items, const int32_t* split_items_count, int cap,
+                    const int32_t* request_order, int bs, int32_t* unit_desc, int32_t* unit_first_slots, void* stream);
 
 /* ---- shared-prefix (cascade) decode plan ----------------------------------------------------------
  * SURVEY 8f-2.  The reference has only the building block (merge_state); with RadixAttention every request

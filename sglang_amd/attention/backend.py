@@ -89,6 +89,7 @@ class ForwardMetadata:
     partial_pairs_hint: int = 0
     # decode, length-aware schedule: the live (request, split) pairs, compacted (ops.SplitItems)
     split_items: Optional[object] = None
+    decode_units: Optional[object] = None   # ops.DecodeUnits of this forward (req_to_token mode; rx_decode_params.unit_desc)
     draft: bool = False  # kv_indptr / kv_indices came from spec_info (multi-step draft decode: one row per top-k branch)
     # deterministic inference: the unified kv list of this forward, built by the first layer that needs it --
     # {is sliding-window layer: (unified_kv_indptr, unified_kv_indices, prefix_lens)}
@@ -261,6 +262,7 @@ class HipRadixAttnBackend:
             self._merge_counters = None
         self._no_fused_store = bool(os.environ.get("RX_NO_FUSED_STORE"))  # dev A/B: the store as its own launch
         self._split_occ3 = os.environ.get("RX_SPLIT_OCC3", "0") == "1"  # eager mixed batches on the three-per-CU kernel form
+        self._no_decode_units = bool(os.environ.get("RX_NO_DECODE_UNITS"))  # dev A/B: the prologue's own chain of loads
         self._no_split_items = bool(os.environ.get("RX_NO_SPLIT_ITEMS"))  # dev A/B: split slots instead of compacted pairs
         # RX_DEBUG_CHECKS=1: host-synchronising assertions of the backend's preconditions (see forward_decode)
         self._debug_checks = os.environ.get("RX_DEBUG_CHECKS", "0") not in ("", "0")
@@ -618,8 +620,9 @@ class HipRadixAttnBackend:
         else:  # lengths unknown here (graph replay refills the counts on the device): slots by batch size alone
             S = self._graph_split_slots(bs)
         if S <= 1:
-            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1,
-                                   request_order=self._request_order(fb, bs, use_graph_bufs))
+            order1 = self._request_order(fb, bs, use_graph_bufs)
+            return ForwardMetadata(None, None, None, None, kv_indptr, kv_indices, None, 1, request_order=order1,
+                                   decode_units=self._build_decode_units(fb, bs, use_graph_bufs, None, 1, None, order1, kv_indices))
         S_cap = S
         # the in-kernel stage 2 (merge_counters) wants the partial rows of a head in chunks of 8: round the slots up while
         # the partials fit its bound -- the surplus workgroups exit at once, and the second launch goes
@@ -669,7 +672,21 @@ class HipRadixAttnBackend:
             if live > items.cap:
                 raise AssertionError(f"split items: {live} live (request, split) pairs > the table's {items.cap}")
         return ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices, None, S,
-                               request_order=order, partial_pairs_hint=pairs, split_items=items)
+                               request_order=order, partial_pairs_hint=pairs, split_items=items,
+                               decode_units=self._build_decode_units(fb, bs, use_graph_bufs, num_kv_splits, S, items, order, kv_indices))
+
+    def _build_decode_units(self, fb, bs, use_graph_bufs, num_kv_splits, S, items, order, kv_indices):
+        """The per-unit tables of this forward's decode launches (ops.DecodeUnits, rx_decode_units): req_to_token mode of
+        the dense MFMA kernel only -- whole requests, or the live-pairs grid of a split schedule.  Under graph replay the
+        tables are address-stable buffers refilled here before every replay, like every other piece of metadata."""
+        if (self._no_decode_units or kv_indices is not None or self.decode_index_mode != "paged" or self._is_mla_pool
+                or self.dcp is not None or not self._decode_honours_split_items() or (S > 1 and items is None)):
+            return None
+        if use_graph_bufs:
+            units = self._graph["decode_units"]
+        else:
+            units = ops.DecodeUnits(bs if items is None else items.cap, self.device)
+        return units.build(self.req_to_token, fb.req_pool_indices, fb.seq_lens, num_kv_splits, S, items, order)
 
     def _split_pairs_bound(self, bs: int, slots: int) -> int:
         """An upper bound of the (request, split) pairs rx_num_kv_splits_balanced can hand out to ``bs`` requests with
@@ -980,6 +997,8 @@ class HipRadixAttnBackend:
         # ... the (request, split) pairs of the length-aware schedule
         self._graph["split_items"] = ops.SplitItems(
             max(self._split_pairs_bound(b, self._graph_split_slots(b)) for b in range(1, max_bs + 1)), dev)
+        # ... the per-unit descriptor tables of the decode launches (a unit = a pair of that table, or a whole request)
+        self._graph["decode_units"] = ops.DecodeUnits(max(max_bs, self._graph["split_items"].items.numel() // 2), dev)
         # ... and the draft tree's mask bytes of TARGET_VERIFY, sized from speculative_num_draft_tokens
         nd = int(self.num_draft_tokens or 0)
         if nd > 0:
@@ -1173,7 +1192,7 @@ class HipRadixAttnBackend:
                                 max_kv_splits=md.max_kv_splits, attn_logits=md.attn_logits,
                                 attn_lse=md.attn_lse, merge_counters=self._merge_counters,
                                 request_order=md.request_order, partial_pairs_hint=md.partial_pairs_hint,
-                                split_items=md.split_items)
+                                split_items=md.split_items, units=md.decode_units)
         if sinks is not None and sinks.dtype != torch.float32:
             sinks = sinks.float()
         if fuse:

@@ -75,6 +75,9 @@ struct DecodeArgs {
   const void* bias;
   int32_t bias_f32, bias_len;
   int64_t bias_stride_t, bias_stride_h;
+  // per-unit descriptors (radix_hip.h: unit_desc / unit_first_slots), req_to_token mode only, or NULL
+  const int32_t* desc;
+  const int32_t* first;
 };
 
 // Grok temperature factor of a request (decode_attention.py:156-160): the single query sits at seq_len-1
@@ -283,18 +286,42 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a, const int 
   // a ragged batch is dealt longest request first (a.order): the chip's last round of workgroups is then the
   // short requests, not a 4 k-token one that starts when the others are finishing
   int b, split;
+  // With the per-unit tables (round 6) everything the prologue needs sits at an address known from the block index alone:
+  // the unit's descriptor and the slot ids of its first tiles are requested together, before anything else has returned.
+  const bool use_desc = a.desc != nullptr;  // (the host sets it in req_to_token mode only: IdxT == int32_t)
+  u32x4 d0 = {0u, 0u, 0u, 0u}, d1 = {0u, 0u, 0u, 0u};
+  int32_t fs0 = 0, fs1 = 0;
+  if (use_desc) {
+    const int32_t* dp = a.desc + 8 * static_cast<int64_t>(bid);
+    d0 = *reinterpret_cast<const u32x4*>(dp);
+    d1 = *reinterpret_cast<const u32x4*>(dp + 4);
+    const int32_t* fp = a.first + 128 * static_cast<int64_t>(bid) + 32 * w + r;
+    fs0 = fp[0];
+    fs1 = fp[16];
+  }
+  SeqInfo si;
+  int32_t splits;
   if (a.items) {  // live (request, split) pairs only, longest requests first (rx_decode_params.split_items)
     if (bid >= a.items_count[0]) return;
-    b = a.items[2 * bid];
-    split = a.items[2 * bid + 1];
-  } else {
+    if (!use_desc) {
+      b = a.items[2 * bid];
+      split = a.items[2 * bid + 1];
+    }
+  } else if (!use_desc) {
     b = a.order ? a.order[bid % a.bs] : bid % a.bs;
     split = bid / a.bs;
   }
-
-  const SeqInfo si = seq_info<IdxT>(a, b);
+  if (use_desc) {
+    b = static_cast<int>(d0[0]);
+    split = static_cast<int>(d0[1]);
+    si.seq_len = si.full_len = static_cast<int32_t>(d0[2]);
+    splits = static_cast<int32_t>(d0[3]);
+    si.idx = a.req_to_token + static_cast<int64_t>((static_cast<uint64_t>(d1[1]) << 32) | d1[0]);
+  } else {
+    si = seq_info<IdxT>(a, b);
+    splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
+  }
   const IdxT* idx = reinterpret_cast<const IdxT*>(si.idx);
-  const int32_t splits = (a.num_kv_splits && a.max_kv_splits > 1) ? a.num_kv_splits[b] : 1;
   const bool single = (a.max_kv_splits == 1) || (a.direct_single && splits == 1);
   const int gq = qb * 16 + r;            // q head inside the GQA group handled by this lane
   const bool q_valid = gq < a.group;
@@ -315,7 +342,12 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a, const int 
   }
   if (split >= splits) return;
   int32_t lo, hi;
-  split_range(si.seq_len, splits, split, lo, hi);
+  if (use_desc) {  // (the table's builder ran the same split_range)
+    lo = static_cast<int32_t>(d1[2]);
+    hi = static_cast<int32_t>(d1[3]);
+  } else {
+    split_range(si.seq_len, splits, split, lo, hi);
+  }
   if (hi <= lo) {
     if (single && si.seq_len == 0) {  // empty request: define the output (reference: 0/0)
       for (int i = tid; i < 16 * D; i += 256) {
@@ -420,7 +452,14 @@ __device__ __forceinline__ void decode_mfma_body(const DecodeArgs& a, const int 
   for (int u = 0; u < DEPTH; ++u) {
     n0[u] = n1[u] = f0[u] = f1[u] = 0;
     const int tt = w + kWavesPerWG * u;
-    if (tt < ntiles) load_slots(tt, f0[u], f1[u]);
+    if (tt < ntiles) {
+      if (use_desc && u == 0) {  // tile w's slot ids came with the descriptor
+        f0[0] = static_cast<int64_t>(fs0);
+        f1[0] = static_cast<int64_t>(fs1);
+      } else {
+        load_slots(tt, f0[u], f1[u]);
+      }
+    }
   }
   // ---- Q^T fragments (B operand): lane (r,g) holds Q[h][32s + 8g .. +8] ----------------
   vec8 qf[KS];
@@ -1008,7 +1047,64 @@ static int run_mla(const rx_decode_params* p, const DecodeArgs& a, hipStream_t s
 
 }  // namespace rx
 
+namespace rx {
+// rx_decode_units: one workgroup of 128 threads per unit; thread j resolves the slot of token min(lo + j, hi - 1), thread 0
+// writes the descriptor
+__global__ __launch_bounds__(128) void decode_units_kernel(const int32_t* __restrict__ r2t, int64_t row_stride, const void* rpi, int rpi64,
+                                                          const void* seq_lens, int sl64, const int32_t* __restrict__ nsplits,
+                                                          int max_kv_splits, const int32_t* __restrict__ items,
+                                                          const int32_t* __restrict__ count, const int32_t* __restrict__ order, int bs,
+                                                          int32_t* __restrict__ desc, int32_t* __restrict__ first) {
+  const int u = blockIdx.x, j = threadIdx.x;
+  int b, split;
+  if (items) {
+    if (u >= count[0]) return;
+    b = items[2 * u];
+    split = items[2 * u + 1];
+  } else {
+    if (u >= bs) return;
+    b = order ? order[u] : u;
+    split = 0;
+  }
+  const int64_t req = load_idx(rpi, b, rpi64);
+  const int32_t seq = static_cast<int32_t>(load_idx(seq_lens, b, sl64));
+  const int32_t sp = (nsplits && max_kv_splits > 1) ? nsplits[b] : 1;
+  int32_t lo = 0, hi = 0;
+  if (sp > 0 && split < sp) split_range(seq, sp, split, lo, hi);
+  const int64_t row = req * row_stride;
+  first[128 * static_cast<int64_t>(u) + j] = hi > lo ? r2t[row + min(lo + j, hi - 1)] : 0;
+  if (j == 0) {
+    int32_t* d = desc + 8 * static_cast<int64_t>(u);
+    d[0] = b;
+    d[1] = split;
+    d[2] = seq;
+    d[3] = sp;
+    d[4] = static_cast<int32_t>(static_cast<uint64_t>(row) & 0xffffffffu);
+    d[5] = static_cast<int32_t>(static_cast<uint64_t>(row) >> 32);
+    d[6] = lo;
+    d[7] = hi;
+  }
+}
+}  // namespace rx
+
 using namespace rx;
+
+extern "C" int rx_decode_units(const int32_t* req_to_token, int64_t req_row_stride, const void* req_pool_indices,
+                               int req_pool_indices_is_i64, const void* seq_lens, int seq_lens_is_i64, const int32_t* num_kv_splits,
+                               int max_kv_splits, const int32_t* split_items, const int32_t* split_items_count, int cap,
+                               const int32_t* request_order, int bs, int32_t* unit_desc, int32_t* unit_first_slots, void* stream) {
+  RX_RANGE("rx_decode_units");
+  RX_REQUIRE(bs >= 0 && cap >= 0, "rx_decode_units: negative sizes");
+  if (bs == 0 || cap == 0) return RX_OK;
+  RX_REQUIRE(req_to_token && req_pool_indices && seq_lens && unit_desc && unit_first_slots, "rx_decode_units: null pointer");
+  RX_REQUIRE((split_items == nullptr) == (split_items_count == nullptr), "rx_decode_units: split_items and its count come together");
+  RX_REQUIRE(split_items || cap <= bs, "rx_decode_units: an unsplit step has bs units (cap %d > bs %d)", cap, bs);
+  RX_REQUIRE((((uintptr_t)unit_desc | (uintptr_t)unit_first_slots) & 15) == 0, "rx_decode_units: tables must be 16-byte aligned");
+  hipLaunchKernelGGL(rx::decode_units_kernel, dim3(static_cast<unsigned>(cap)), dim3(128), 0, static_cast<hipStream_t>(stream),
+                     req_to_token, req_row_stride, req_pool_indices, req_pool_indices_is_i64, seq_lens, seq_lens_is_i64, num_kv_splits,
+                     max_kv_splits, split_items, split_items_count, request_order, bs, unit_desc, unit_first_slots);
+  return check_launch("rx_decode_units");
+}
 
 #ifdef RX_DEC_TIMELINE
 // dev builds only (not in include/radix_hip.h): copies the first n workgroups' stamps to host memory, [n][6] =
@@ -1112,6 +1208,7 @@ static int decode_attn_impl(const rx_decode_params* p, void* stream) {
   a.bias_len = p->score_bias_len;
   a.bias_stride_t = p->score_bias_stride_t;
   a.bias_stride_h = p->score_bias_stride_h;
+  a.desc = a.first = nullptr;
   RX_REQUIRE(p->stages >= 0 && p->stages <= 2 && (p->stages == 0 || max_splits > 1),
              "rx_decode_attn: stages = %d (1 / 2 need max_kv_splits > 1)", p->stages);
   a.stages = p->stages;
@@ -1185,6 +1282,15 @@ static int decode_attn_impl(const rx_decode_params* p, void* stream) {
     a.v_new = (const uint16_t*)p->v_new;
     a.kn_stride_t = p->k_new_stride_t; a.kn_stride_h = p->k_new_stride_h;
     a.vn_stride_t = p->v_new_stride_t; a.vn_stride_h = p->v_new_stride_h;
+  }
+  // per-unit tables: req_to_token mode of the MFMA kernel, whole requests or the live-pairs grid, no kv_start
+  if (p->unit_desc || p->unit_first_slots) {
+    RX_REQUIRE(p->unit_desc && p->unit_first_slots, "rx_decode_attn: unit_desc and unit_first_slots come together");
+    RX_REQUIRE((((uintptr_t)p->unit_desc | (uintptr_t)p->unit_first_slots) & 15) == 0, "rx_decode_attn: unit tables must be 16-byte aligned");
+    if (!mode_a && mfma_ok && !mla && !p->kv_start && p->stages != 2 && (a.items || max_splits == 1)) {
+      a.desc = p->unit_desc;
+      a.first = p->unit_first_slots;
+    }
   }
   if (mla) return p->dtype == RX_BF16 ? run_mla<BF16>(p, a, s) : run_mla<F16>(p, a, s);
   return p->dtype == RX_BF16 ? dispatch_decode<BF16>(a, dk, dv, idx64, linear, s)

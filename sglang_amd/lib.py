@@ -64,6 +64,7 @@ class RxDecodeParams(C.Structure):
         ("rope_is_neox", c_int32), ("rope_k_pe_out", c_void_p), ("rope_k_pe_out_stride", c_int64),
         ("score_bias", c_void_p), ("score_bias_is_f32", c_int32), ("score_bias_len", c_int32),
         ("score_bias_stride_t", c_int64), ("score_bias_stride_h", c_int64),
+        ("unit_desc", c_void_p), ("unit_first_slots", c_void_p),
     ]
 
 
@@ -149,6 +150,8 @@ PROTOTYPES = {
     "rx_num_kv_splits": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  c_void_p, c_void_p]),
     "rx_decode_attn": (c_int, [C.POINTER(RxDecodeParams), c_void_p]),
+    "rx_decode_units": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rx_extend_attn": (c_int, [C.POINTER(RxExtendParams), c_void_p]),
     "rx_alloc_extend": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "rx_alloc_decode": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),

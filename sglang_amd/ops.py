@@ -166,7 +166,9 @@ def fused_fp8_qkv_kv_cache(q: Optional[torch.Tensor], k: torch.Tensor, v: torch.
 
     ks, ksp = scale_ptr(k_scale)
     vs, vsp = scale_ptr(v_scale)
-    q2 = q_out = None
+    q2 = None
+    if q is None:
+        q_out = None
     if q is not None:
         q2 = q.reshape(n, -1)
         if q2.dtype != k2.dtype or q2.stride(-1) != 1:
@@ -695,6 +697,44 @@ class SplitItems:
         return self
 
 
+class DecodeUnits:
+    """rx_decode_params.unit_desc / unit_first_slots: per-unit descriptors of ONE forward's decode launches, built on the
+    device by rx_decode_units and shared by every layer (a unit = a (request, split) pair of a SplitItems table, or a whole
+    request of an unsplit step).  They shorten each launch's prologue from five dependent round trips to three: the
+    descriptor and the first tiles' slot ids sit at addresses a workgroup knows from its block index."""
+
+    def __init__(self, max_units: int, device):
+        self.max_units = max(1, int(max_units))
+        self.desc = torch.zeros(self.max_units * 8, dtype=torch.int32, device=device)
+        self.first = torch.zeros(self.max_units * 128, dtype=torch.int32, device=device)
+
+    def build(self, req_to_token, req_pool_indices, seq_lens, num_kv_splits=None, max_kv_splits: int = 1, split_items=None,
+              request_order=None):
+        """From the SAME tensors the decode calls of this forward will pass.  split_items: the SplitItems of a split
+        schedule (its cap rows are filled; rows past the live count are never read), or None for an unsplit step."""
+        _require_cuda(req_to_token, req_pool_indices, seq_lens, num_kv_splits, request_order)
+        if req_to_token.dtype != torch.int32:
+            raise TypeError("req_to_token must be int32")
+        bs = seq_lens.shape[0]
+        cap = bs if split_items is None else int(split_items.cap)
+        if cap > self.max_units:
+            raise ValueError(f"DecodeUnits.build: {cap} units exceed the tables ({self.max_units})")
+        st = _L.load().rx_decode_units(
+            req_to_token.data_ptr(), req_to_token.stride(0), req_pool_indices.data_ptr(), _is64(req_pool_indices, "req_pool_indices"),
+            seq_lens.data_ptr(), _is64(seq_lens, "seq_lens"), _ptr(num_kv_splits) if max_kv_splits > 1 else None, int(max_kv_splits),
+            None if split_items is None else split_items.items.data_ptr(), None if split_items is None else split_items.count.data_ptr(),
+            cap, _request_order_ptr(request_order, bs), bs, self.desc.data_ptr(), self.first.data_ptr(), _stream(req_to_token))
+        _L.check(st, "rx_decode_units")
+        return self
+
+
+def _set_units(p, units):
+    if units is None:
+        p.unit_desc = p.unit_first_slots = None
+    else:
+        p.unit_desc, p.unit_first_slots = units.desc.data_ptr(), units.first.data_ptr()
+
+
 def _set_split_items(p, split_items):
     if split_items is None:
         p.split_items, p.split_items_count, p.split_items_cap, p.split_items_wgs_per_cu = None, None, 0, 0
@@ -709,7 +749,7 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
                                page_size: int = 1, kv_layout=None, xai_temperature_len=-1,
                                kv_start=None, extra_o=None, extra_lse=None, stages: int = 0, merge_counters=None,
                                k_new=None, v_new=None, request_order=None, split_items=None,
-                               score_mod=None, aux_tensors=None):
+                               score_mod=None, aux_tensors=None, units=None):
     p = _decode_paged_params(q, k_buffer, v_buffer, o, req_to_token, req_pool_indices, seq_lens, attn_logits, attn_lse,
                              num_kv_splits, max_kv_splits, sm_scale, k_scale, v_scale, logit_cap, sinks, page_size,
                              kv_layout, xai_temperature_len, kv_start, extra_o, extra_lse, stages)
@@ -718,6 +758,8 @@ def decode_attention_fwd_paged(q, k_buffer, v_buffer, o, req_to_token, req_pool_
     p.request_order = _request_order_ptr(request_order, q.shape[0])
     _set_split_items(p, split_items if p.max_kv_splits > 1 else None)
     _set_score_bias(p, score_mod, aux_tensors, q)
+    _set_units(p, units)
+    p._keep_units = units
     _L.check(_L.load().rx_decode_attn(C.byref(p), _stream(q)), "rx_decode_attn")
 
 
@@ -840,7 +882,7 @@ class DecodeLauncher:
     def set_metadata(self, version, bs, *, kv_indptr=None, kv_indices=None, req_to_token=None,
                      req_pool_indices=None, seq_lens=None, num_kv_splits=None, max_kv_splits=1,
                      attn_logits=None, attn_lse=None, merge_counters=None, request_order=None,
-                     partial_pairs_hint: int = 0, split_items=None):
+                     partial_pairs_hint: int = 0, split_items=None, units=None):
         p = self.p
         p.bs = bs
         p.partial_pairs_hint = int(partial_pairs_hint)
@@ -861,8 +903,9 @@ class DecodeLauncher:
         else:
             p.num_kv_splits, p.max_kv_splits = None, 1
         _set_split_items(p, split_items if p.max_kv_splits > 1 else None)
+        _set_units(p, units if kv_indices is None else None)
         self._keep = (kv_indptr, kv_indices, req_to_token, req_pool_indices, seq_lens, num_kv_splits,
-                      attn_logits, attn_lse, merge_counters, request_order, split_items)
+                      attn_logits, attn_lse, merge_counters, request_order, split_items, units)
         self.version = version
 
     def can_fuse_store(self) -> bool:

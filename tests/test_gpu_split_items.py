@@ -182,3 +182,105 @@ def test_fused_store_with_split_items_at_two_and_three_workgroups_per_cu(dtype):
         got = run(mode)
         for a, b, what in zip(ref, got, ("o", "k pool", "v pool")):
             assert (a == b).all(), (mode, what)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("fuse", [False, True], ids=["plain", "fused_store"])
+def test_decode_units_tables_match_their_definition_and_change_no_bit(dtype, fuse):
+    """rx_decode_units + rx_decode_params.unit_desc / unit_first_slots (round 6): the per-unit descriptor (request, split,
+    length, split count, row offset, token range) and the first tiles' slot ids against their definition, and the decode
+    outputs with the tables BIT-identical to the same launches without them -- unsplit (whole requests in launch order), a
+    split schedule on the live-pairs grid (exact and upper-bound caps), with and without the fused store of the new token;
+    ragged lengths incl. an empty request, one token, lengths below one tile per wave."""
+    from sglang_amd import ops
+
+    hq, hkv, d, ps = 32, 8, 128, 16
+    lens = np.array([6000, 1, 0 if not fuse else 2, 300, 2049, 33, 4100, 17, 5000, 129], dtype=np.int64)
+    bs = len(lens)
+    rng = np.random.default_rng(11)
+    pages = [-(-int(n) // ps) for n in lens]
+    perm = rng.permutation(np.arange(1, sum(pages) + 1))
+    r2t = np.zeros((bs + 3, int(lens.max()) + ps), dtype=np.int32)
+    rows = rng.permutation(np.arange(1, bs + 3))[:bs]              # request rows in any order
+    pi = 0
+    for i, n in enumerate(lens):
+        r2t[rows[i], :n] = (perm[pi: pi + pages[i], None] * ps + np.arange(ps)[None]).reshape(-1)[:n]
+        pi += pages[i]
+    pool = (sum(pages) + 1) * ps
+    g = torch.Generator().manual_seed(2)
+    kb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    vb = torch.randn(pool, hkv, d, generator=g).to(dtype)
+    q = torch.randn(bs, hq, d, generator=g).to(dtype).to(DEV)
+    kn = torch.randn(bs, hkv, d, generator=g).to(dtype).to(DEV) if fuse else None
+    vn = torch.randn(bs, hkv, d, generator=g).to(dtype).to(DEV) if fuse else None
+    r2t_d, rpi = torch.from_numpy(r2t).to(DEV), torch.from_numpy(rows.astype(np.int64)).to(DEV)
+    lens_d = torch.from_numpy(lens).to(DEV)
+    S = 16
+    splits = torch.zeros(bs, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits_balanced(splits, lens_d, hq, hkv, S, 512, 128)
+    order = torch.argsort(lens_d, descending=True).to(torch.int32)
+    sp = splits.cpu().numpy()
+
+    def split_range(n, s, i):  # decode_attention.py:466-472
+        per = (-(-n // s) + 31) // 32 * 32
+        return per * i, min(per * i + per, n)
+
+    # ---- the tables against their definition
+    for mode in ("unsplit", "items_exact", "items_upper"):
+        si = None
+        if mode != "unsplit":
+            n_live = int(splits.clamp_min(1).sum())
+            si = ops.SplitItems(n_live if mode == "items_exact" else bs * S, DEV).build(splits, order)
+        units = ops.DecodeUnits(bs if si is None else si.cap, DEV).build(r2t_d, rpi, lens_d, splits if si is not None else None,
+                                                                        S if si is not None else 1, si, order)
+        torch.cuda.synchronize()
+        desc = units.desc.cpu().numpy().reshape(-1, 8)
+        first = units.first.cpu().numpy().reshape(-1, 128)
+        od = order.cpu().numpy()
+        pairs = ([(int(b), 0, 1) for b in od] if si is None else
+                 [(int(b), s, int(sp[b])) for b in od for s in range(max(int(sp[b]), 1))])
+        for u, (b, s, nsp) in enumerate(pairs):
+            n = int(lens[b])
+            lo, hi = split_range(n, nsp, s) if nsp > 0 and s < nsp else (0, 0)
+            row = int(rows[b]) * r2t.shape[1]
+            assert desc[u].tolist() == [b, s, n, nsp, row & 0xffffffff, row >> 32, lo, hi], (mode, u)
+            want = [int(r2t[rows[b], min(lo + j, hi - 1)]) if hi > lo else 0 for j in range(128)]
+            assert first[u].tolist() == want, (mode, u)
+
+    # ---- decode with and without the tables: the same bits (and the same stored rows)
+    outs, pools = {}, {}
+    for mode in ("unsplit", "split"):
+        for with_units in (False, True):
+            kbd, vbd = kb.to(DEV), vb.to(DEV)
+            o = torch.full((bs, hq, d), float("nan"), dtype=dtype, device=DEV)
+            kw = dict(page_size=ps, request_order=order, k_new=kn, v_new=vn)
+            if mode == "unsplit":
+                units = ops.DecodeUnits(bs, DEV).build(r2t_d, rpi, lens_d, None, 1, None, order) if with_units else None
+                ops.decode_attention_fwd_paged(q, kbd, vbd, o, r2t_d, rpi, lens_d, None, None, None, 1, d ** -0.5, units=units, **kw)
+            else:
+                al = torch.zeros(bs, hq, S, d, dtype=torch.float32, device=DEV)
+                ls = torch.zeros(bs, hq, S, dtype=torch.float32, device=DEV)
+                cnt = torch.zeros(bs * hq, dtype=torch.int32, device=DEV)
+                si = ops.SplitItems(bs * S, DEV).build(splits, order)
+                units = ops.DecodeUnits(si.cap, DEV).build(r2t_d, rpi, lens_d, splits, S, si, order) if with_units else None
+                ops.decode_attention_fwd_paged(q, kbd, vbd, o, r2t_d, rpi, lens_d, al, ls, splits, S, d ** -0.5, merge_counters=cnt,
+                                               split_items=si, units=units, **kw)
+                torch.cuda.synchronize()
+                assert int(cnt.abs().sum()) == 0
+            torch.cuda.synchronize()
+            outs[(mode, with_units)] = o.view(torch.int16).cpu().numpy()
+            pools[(mode, with_units)] = (kbd.view(torch.int16).cpu().numpy(), vbd.view(torch.int16).cpu().numpy())
+    for mode in ("unsplit", "split"):
+        assert (outs[(mode, False)] == outs[(mode, True)]).all(), mode
+        assert (pools[(mode, False)][0] == pools[(mode, True)][0]).all() and (pools[(mode, False)][1] == pools[(mode, True)][1]).all(), mode
+    # ... and they are the oracle's result (the fused store's rows included)
+    kb2, vb2 = kb.clone(), vb.clone()
+    if fuse:
+        last = torch.from_numpy(np.array([r2t[rows[i], lens[i] - 1] for i in range(bs)], dtype=np.int64))
+        kb2[last], vb2[last] = kn.cpu(), vn.cpu()
+    ip, ii = orc.build_kv_indices(r2t, rows.astype(np.int64), lens)
+    bits = (lambda t: t.view(torch.uint16).numpy()) if dtype == torch.bfloat16 else (lambda t: t.numpy())
+    want, absw = orc.decode_attention(bits(q.cpu()), bits(kb2), bits(vb2), ip, ii, d ** -0.5, return_absw=True)
+    live = lens > 0
+    got = torch.from_numpy(outs[("split", True)]).view(dtype).float().numpy()
+    parity.check_out(got[live], want[live], dtype, ("decode units", fuse), ulps=1, absw=absw[live])
