@@ -179,6 +179,21 @@ if not LIGHT:
         if not torch.equal(gb.cpu(), sum(p.float() for p in parts).to(torch.bfloat16)):
             ok = False
             print(f"rank {rank} det graph replay {rep}: mismatch", flush=True)
+    # the group a model runner builds from its server_args: deterministic inference => its own peer-to-peer context, every
+    # GPU reduce through the fixed-order kernel
+    class SA:
+        enable_deterministic_inference = True
+    tps = TPGroup.from_server_args(None, SA, dev, max_bytes=1 << 20)
+    assert tps.deterministic and tps.custom_ar is not None and tps.custom_ar is not ar
+    parts = parts_for(4321, 3 * 4096, torch.float16)
+    xs = parts[rank].to(dev)
+    tps.all_reduce(xs)
+    torch.cuda.synchronize()
+    if not torch.equal(xs.cpu(), sum(p.float() for p in parts).to(torch.float16)):
+        ok = False
+        print(f"rank {rank} from_server_args group: mismatch", flush=True)
+    assert tps.custom_ar.check_errors() == 0
+    tps.custom_ar.close()
     # a deterministic group WITHOUT the context refuses to fall back to the backend
     try:
         TPGroup(None, custom_ar=None, deterministic=True).all_reduce(torch.zeros(8, device=dev, dtype=torch.bfloat16))
