@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-/* 15 (round 6): rx_fused_fp8_qkv_kv_cache, rx_pool_alloc_extend_rows, rx_allreduce_det (deterministic fixed-order reduce),
+/* 16 (round 6): the quick all-reduce (rx_qr_region_bytes, rx_qr_init, rx_quick_allreduce, rx_qr_destroy) + rx_rcp_f16_table.
+ * 15 (round 6): rx_fused_fp8_qkv_kv_cache, rx_pool_alloc_extend_rows, rx_allreduce_det (deterministic fixed-order reduce),
  * rx_decode_units + rx_decode_params.unit_desc / unit_first_slots (appended);
  * the experimental rx_extend64 kernel left the product library (dev builds: RX_WITH_EXT64=1).
  * 14 (round 5): score_bias* appended to rx_decode_params / rx_extend_params (score_mod = relative_bias_score_mod).
@@ -35,7 +36,7 @@ extern "C" {
  * 9 (round 4): rx_last_dispatch, rx_set_option / rx_get_option.
  * 8 (round 3): rx_split_items; rx_decode_params.split_items / split_items_count / split_items_cap /
  * split_items_wgs_per_cu and extra_index / extra_rows; rx_num_kv_splits_balanced gained wg_target_mixed. */
-#define RX_ABI_VERSION 15
+#define RX_ABI_VERSION 16
 
 typedef enum rx_status {
   RX_OK = 0,
@@ -838,6 +839,34 @@ int rx_allreduce_det(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, i
 int rx_allreduce_rmsnorm(rx_ar_ctx* ctx, const void* in, const void* residual_in, const void* weight, void* out,
                          void* residual_out, int64_t rows, int64_t hidden, float eps, int dtype, void* stream);
 int rx_ar_destroy(rx_ar_ctx* ctx);
+
+/* ---- C3: the "quick" all-reduce -- large 16-bit messages over a block-scaled integer wire format (round 6) --------------
+ * QuickAllReduce (srt/distributed/device_communicators/quick_all_reduce.py:41-267), which GroupCoordinator.all_reduce takes
+ * behind the custom all-reduce and ahead of NCCL (parallel_state.py:886-948); kernel kernels/aot/csrc/allreduce/
+ * quick_all_reduce.cuh:52-632 (ops init_custom_qr / qr_get_handle / qr_open_handles / qr_all_reduce / qr_destroy,
+ * quick_all_reduce.cu:10-89).  Two-shot, pushed: every rank encodes its input in groups of 64 elements (two 32-element scale
+ * blocks: even / odd elements) and writes segment r to rank r, which decodes the `world` versions, adds them in rank order in
+ * the 16-bit type, encodes the sum and writes it to everybody.  quant_level: RX_QR_FP moves the 16-bit values (the result is
+ * the rank-order sum in the tensor's type), RX_QR_INT8 / INT6 / INT4 move 8 / 6 / 4-bit codes + one 16-bit scale per block.
+ * cast_bf16_to_fp16 != 0 (the reference's default, ROCM_QUICK_REDUCE_CAST_BF16_TO_FP16): bf16 tensors are converted to fp16 on
+ * the way in, reduced by the fp16 arithmetic and converted back.  The arithmetic is the reference's operation for operation
+ * (csrc/rx_quick_allreduce.hip header; CPU restatement: quick_allreduce under oracle/); the slot / flag protocol is this
+ * library's own: a FIXED region of rx_qr_region_bytes() whatever the message size, no per-call host state, HIP-graph safe.
+ *
+ * Setup as for rx_allreduce: a region of rx_qr_region_bytes() from rx_ar_alloc_region on every rank, handles exchanged and
+ * mapped with rx_ipc_*, rx_qr_init with the `world` (2, 4 or 8) region pointers.  rx_quick_allreduce is stream ordered and
+ * allocation free; same order, count, dtype and level on every rank; in == out allowed; count a multiple of 8 elements, any
+ * size (the tail of the last 64-element group is taken as zeros, as the reference's bounded buffer loads do). */
+typedef struct rx_qr_ctx rx_qr_ctx;
+enum rx_qr_level { RX_QR_FP = 0, RX_QR_INT8 = 1, RX_QR_INT6 = 2, RX_QR_INT4 = 3 }; /* QuickReduceRegime, quick_all_reduce.py:41-46 */
+int64_t rx_qr_region_bytes(void);
+int rx_qr_init(rx_qr_ctx** ctx_out, int rank, int world, void* const* peer_regions, int32_t* dev_err);
+int rx_quick_allreduce(rx_qr_ctx* ctx, const void* in, void* out, int64_t count, int dtype, int quant_level,
+                       int cast_bf16_to_fp16, void* stream);
+int rx_qr_destroy(rx_qr_ctx* ctx);
+/* Test support: v_rcp_f16 of all 65536 fp16 bit patterns into dev_out_65536 (the fp16 codecs' encode scale is that
+ * instruction's output, specified to 1 ulp; the oracle takes the table rather than assuming a rounding). */
+int rx_rcp_f16_table(uint16_t* dev_out_65536, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1197,6 +1197,167 @@ def dcp_merge(outs, lses):
 
 
 # --------------------------------------------------------------------------
+# C3 quick all-reduce   kernels/aot/csrc/allreduce/quick_all_reduce.cuh:52-632 (codecs, two-shot schedule),
+#                       quick_all_reduce_base.h:98-300 (packed 16-bit arithmetic, group_abs_max)
+# Parity status of THIS section: the reference's kernel is HIP-only, so nothing here could be pinned against an execution of
+# it in the build container.  It is pinned to (a) the reference's own test properties (test/manual/test_quick_allreduce.py:
+# level FP is exact on small integers, INT4 of all-ones is exactly `world`, zeros stay zeros, integers in [1, 23) land within
+# atol 1.25 W / rtol 0.5 W at every level) and (b) the hardware: the one instruction whose result the ISA leaves open,
+# v_rcp_f16, enters as a TABLE (tests/golden/rcp_f16_gfx950.npy, read back from an MI355X through rx_rcp_f16_table; the GPU
+# test re-reads it live), every other step is an IEEE operation with one rounding.
+# --------------------------------------------------------------------------
+QR_FP, QR_INT8, QR_INT6, QR_INT4 = 0, 1, 2, 3   # QuickReduceRegime, quick_all_reduce.py:41-46
+_QR_BITS = {QR_FP: 16, QR_INT8: 8, QR_INT6: 6, QR_INT4: 4}
+
+
+def rcp_f16_correctly_rounded() -> np.ndarray:
+    """1 / x for all 65536 fp16 bit patterns, correctly rounded (the stand-in where no hardware table is at hand)."""
+    with np.errstate(all="ignore"):
+        x = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float64)
+        return (1.0 / x).astype(np.float16).view(np.uint16)
+
+
+class _QrF16:
+    """Packed-fp16 instruction semantics on uint16 bit patterns: exact in float64, ONE rounding to fp16."""
+    eps = np.uint16(0x0001)   # kScaleEpsilon: fp16's smallest subnormal
+
+    def __init__(self, rcp_table=None):
+        self.table = rcp_f16_correctly_rounded() if rcp_table is None else np.asarray(rcp_table, dtype=np.uint16)
+
+    @staticmethod
+    def val(b):
+        return np.asarray(b, dtype=np.uint16).view(np.float16).astype(np.float64)
+
+    @staticmethod
+    def rnd(x):
+        return np.asarray(x, dtype=np.float64).astype(np.float16).view(np.uint16)
+
+    def const(self, v):
+        return self.rnd(np.float64(v))
+
+    def mul(self, a, b):
+        return self.rnd(self.val(a) * self.val(b))
+
+    def add(self, a, b):
+        return self.rnd(self.val(a) + self.val(b))
+
+    @staticmethod
+    def _key(b):   # total order of the non-NaN patterns: -0 below +0 (v_pk_max_f16 / v_pk_min_f16 order the zeros)
+        b = np.asarray(b, dtype=np.uint16).astype(np.int32)
+        return np.where(b & 0x8000, 0xFFFF - b, b | 0x8000)
+
+    def vmax(self, a, b):
+        a, b = np.broadcast_arrays(np.asarray(a, np.uint16), np.asarray(b, np.uint16))
+        na, nb = np.isnan(self.val(a)), np.isnan(self.val(b))
+        return np.where(na, b, np.where(nb, a, np.where(self._key(a) >= self._key(b), a, b))).astype(np.uint16)
+
+    def vmin(self, a, b):
+        a, b = np.broadcast_arrays(np.asarray(a, np.uint16), np.asarray(b, np.uint16))
+        na, nb = np.isnan(self.val(a)), np.isnan(self.val(b))
+        return np.where(na, b, np.where(nb, a, np.where(self._key(a) <= self._key(b), a, b))).astype(np.uint16)
+
+    def rcp(self, a):
+        return self.table[np.asarray(a, dtype=np.uint16)]
+
+    def pick_abs(self, a, b):   # __hgt(|a|, |b|) ? a : b
+        return np.where(np.abs(self.val(a)) > np.abs(self.val(b)), a, b).astype(np.uint16)
+
+
+class _QrBF16:
+    """The HIP bf16 operators: fp32 arithmetic, round to nearest even after every operation."""
+    eps = np.uint16(0x33D7)
+
+    @staticmethod
+    def val(b):
+        return bf16_to_f32(np.asarray(b, dtype=np.uint16))
+
+    @staticmethod
+    def rnd(x):
+        return f32_to_bf16(np.asarray(x, dtype=np.float32))
+
+    def const(self, v):
+        return self.rnd(np.float32(v))
+
+    def mul(self, a, b):
+        return self.rnd(self.val(a) * self.val(b))
+
+    def add(self, a, b):
+        return self.rnd(self.val(a) + self.val(b))
+
+    def vmax(self, a, b):   # __hmax: a NaN loses; a > b ? a : b -- the SECOND operand on equality (+0 / -0)
+        a, b = np.broadcast_arrays(np.asarray(a, np.uint16), np.asarray(b, np.uint16))
+        va, vb = self.val(a), self.val(b)
+        return np.where(np.isnan(va), b, np.where(np.isnan(vb), a, np.where(va > vb, a, b))).astype(np.uint16)
+
+    def vmin(self, a, b):
+        a, b = np.broadcast_arrays(np.asarray(a, np.uint16), np.asarray(b, np.uint16))
+        va, vb = self.val(a), self.val(b)
+        return np.where(np.isnan(va), b, np.where(np.isnan(vb), a, np.where(va < vb, a, b))).astype(np.uint16)
+
+    def rcp(self, a):   # hrcp: __float2bfloat16(1.0f / x)
+        return self.rnd(np.float32(1.0) / self.val(a))
+
+    def pick_abs(self, a, b):
+        return np.where(np.abs(self.val(a)) > np.abs(self.val(b)), a, b).astype(np.uint16)
+
+
+def _qr_block_scale(num, x, bits):
+    """x: uint16 [G, 64] (groups of 64 consecutive elements) -> decode scale per (group, parity) [G, 2].  A lane holds 8
+    consecutive elements as 4 packed pairs; the comparisons run pair 0-1, pair 2-3, then both, then a binary tree over the 8
+    lanes towards lane 0, own value first (group_abs_max, quick_all_reduce_base.h:268-300)."""
+    v = x.reshape(-1, 8, 4, 2)   # [group, lane, pair, parity]
+
+    def reduce(op):
+        m = op(op(v[:, :, 0], v[:, :, 1]), op(v[:, :, 2], v[:, :, 3]))   # [G, lane, parity]
+        m = op(m[:, 0:7], m[:, 1:8])        # lane l <- (l, l + 1); lanes 0, 2, 4, 6 are used
+        m = op(m[:, 0:5], m[:, 2:7])        # lane l <- (l, l + 2); lanes 0, 4
+        return op(m[:, 0], m[:, 4])         # [G, parity]
+
+    mx, mn = reduce(num.vmax), reduce(num.vmin)
+    return num.mul(num.pick_abs(mx, mn), num.const(-1.0 / (1 << (bits - 1))))
+
+
+def qr_codec_roundtrip(num, x, bits):
+    """decode(encode(x)) for one rank's padded message x (uint16 bits, a multiple of 64 elements), and the codes."""
+    r = 1 << (bits - 1)
+    g = x.reshape(-1, 64)
+    d = _qr_block_scale(num, g, bits)                               # [G, 2]
+    e = num.rcp(num.add(d, num.eps))
+    v = g.reshape(-1, 32, 2)
+    w = num.vmin(num.vmax(num.mul(v, e[:, None, :]), num.const(-r)), num.const(r - 1))
+    code = np.rint(num.val(w).astype(np.float64)).astype(np.int64) + r      # rintf: ties to even
+    out = num.mul(num.rnd((code - r).astype(np.float64 if isinstance(num, _QrF16) else np.float32)), d[:, None, :])
+    return out.reshape(-1), code.reshape(-1)
+
+
+def quick_allreduce(parts: Sequence[np.ndarray], is_bf16: bool, level: int, cast_bf16_to_fp16: bool = False,
+                    rcp_f16_table: Optional[np.ndarray] = None) -> np.ndarray:
+    """AllReduceTwoshot<T, Codec, cast_bf2half>::run (quick_all_reduce.cuh:448-632) for all ranks at once.
+    parts: the `world` inputs as uint16 bit patterns of the tensor's dtype (fp16, or bf16 with is_bf16), equal lengths (a
+    multiple of 8).  Returns the bits every rank ends with.  See the section comment for the arithmetic and its pinning."""
+    bits = _QR_BITS[level]
+    n = len(parts[0])
+    assert n % 8 == 0 and all(len(p) == n for p in parts)
+    with np.errstate(all="ignore"):
+        as_f16 = (not is_bf16) or cast_bf16_to_fp16
+        num = _QrF16(rcp_f16_table) if as_f16 else _QrBF16()
+        xs = []
+        for p in parts:
+            p = np.ascontiguousarray(p, dtype=np.uint16).reshape(-1)
+            if is_bf16 and cast_bf16_to_fp16:   # __float22half2_rn(__bfloat1622float2(x))
+                p = bf16_to_f32(p).astype(np.float16).view(np.uint16)
+            xs.append(np.concatenate([p, np.zeros((-n) % 64, dtype=np.uint16)]))
+        acc = np.zeros_like(xs[0])              # +0
+        for x in xs:                            # rank order, every partial sum rounded to the type
+            acc = num.add(acc, x if bits == 16 else qr_codec_roundtrip(num, x, bits)[0])
+        out = acc if bits == 16 else qr_codec_roundtrip(num, acc, bits)[0]
+        out = out[:n]
+        if is_bf16 and cast_bf16_to_fp16:       # __float22bfloat162_rn(__half22float2(x))
+            out = f32_to_bf16(out.view(np.float16).astype(np.float32))
+        return out
+
+
+# --------------------------------------------------------------------------
 # a14 torch-native semantics   srt/layers/attention/torch_native_backend.py:61-277
 # --------------------------------------------------------------------------
 

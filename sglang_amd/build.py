@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 # RX_LIB_NAME / RX_CFLAGS: developer knobs for A/B-ing kernel variants built side by side
 LIB_PATH = os.path.join(HERE, os.environ.get("RX_LIB_NAME", "libradix_hip.so"))
 SOURCES = ["rx_misc.hip", "rx_decode.hip", "rx_decode_mla.hip", "rx_extend.hip", "rx_extend32.hip", "rx_extend_nd.hip", "rx_extend_mla.hip", "rx_extend_d256.hip",
-           "rx_allreduce.hip", "rx_rope.hip", "rx_pool.hip", "rx_dcp.hip", "rx_radix.cpp"]
+           "rx_allreduce.hip", "rx_quick_allreduce.hip", "rx_rope.hip", "rx_pool.hip", "rx_dcp.hip", "rx_radix.cpp"]
 # RX_WITH_EXT64=1 (dev): the experimental one-wave-per-SIMD D = 128 extend kernel (tools/probe/rx_extend64.hip, 0.83x of the
 # shipped kernel: DESIGN 4.2) is compiled in and option `ext64` routes PLAIN eight-wave calls to it.  The product library
 # does not carry it; tools/ext64_check.py and tools/probe/pmc_ext64.sh need such a build.

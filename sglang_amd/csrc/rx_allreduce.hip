@@ -376,6 +376,12 @@ int rx_ar_alloc_region(int64_t bytes, void** dev_ptr_out) {
                                    hipGetErrorString(e));
   e = hipMemset(*dev_ptr_out, 0, static_cast<size_t>(bytes));
   if (e != hipSuccess) return fail(RX_ERR_LAUNCH, "hipMemset: %s", hipGetErrorString(e));
+  // The zeroing must have HAPPENED before the handle leaves this process: hipMemset of device memory is asynchronous, and a
+  // peer that maps the region may raise a flag in it before this GPU queue has run the fill -- which then wipes the flag
+  // and the owner waits for it until the timeout (seen with four processes time-slicing one GPU: the owner's queue got its
+  // turn after a peer's first kernel; round 6).
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) return fail(RX_ERR_LAUNCH, "hipDeviceSynchronize: %s", hipGetErrorString(e));
   return RX_OK;
 }
 

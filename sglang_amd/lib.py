@@ -16,7 +16,7 @@ _lib = None
 
 c_void_p, c_int, c_int32, c_int64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 
-RX_ABI_VERSION = 15  # include/radix_hip.h
+RX_ABI_VERSION = 16  # include/radix_hip.h
 RX_BF16, RX_F16 = 0, 1
 RX_DEVERR_SLOT_OOB = 1
 
@@ -114,6 +114,11 @@ PROTOTYPES = {
     "rx_allreduce_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                      c_float, c_int, c_void_p]),
     "rx_ar_destroy": (c_int, [c_void_p]),
+    "rx_qr_region_bytes": (c_int64, []),
+    "rx_qr_init": (c_int, [C.POINTER(c_void_p), c_int, c_int, C.POINTER(c_void_p), c_void_p]),
+    "rx_quick_allreduce": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "rx_qr_destroy": (c_int, [c_void_p]),
+    "rx_rcp_f16_table": (c_int, [c_void_p, c_void_p]),
     "rx_rope_store_kv": (c_int, [c_void_p] * 3 + [c_int64] * 7 + [c_int] * 5 + [c_void_p, c_void_p, c_int64, c_int,
                                  C.POINTER(RxKvLayout), c_void_p, c_int, c_int64, c_int64, c_float, c_float, c_int,
                                  c_void_p, c_void_p]),

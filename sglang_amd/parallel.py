@@ -14,6 +14,8 @@ bandwidth does not matter.
 """
 from __future__ import annotations
 
+import enum
+import warnings
 from dataclasses import dataclass
 from typing import Optional
 
@@ -186,9 +188,167 @@ class CustomAllReduce:
                 self._lib.rx_ar_destroy(ctx)
             for p in self._opened:
                 self._lib.rx_ipc_close_handle(p)
+            dist.barrier(group=self.group)  # ... and nobody frees a region a peer still has mapped (see QuickAllReduce.close)
             for own in self._own:
                 self._lib.rx_ar_free_region(own)
             self._ctxs, self._ctx = [], None
+
+
+class QuickReduceRegime(enum.Enum):
+    """quick_all_reduce.py:41-46; the first four are rx_qr_level (include/radix_hip.h)."""
+    FP = 0
+    INT8 = 1
+    INT6 = 2
+    INT4 = 3
+    NONE = 4
+
+
+MB = 1024 * 1024
+
+
+class QuickAllReduce:
+    """The quick all-reduce for LARGE 16-bit messages (csrc/rx_quick_allreduce.hip): two-shot, pushed, with a block-scaled
+    INT8 / INT6 / INT4 (or plain 16-bit) wire format.  Mirrors the reference's QuickAllReduce (srt/distributed/
+    device_communicators/quick_all_reduce.py:49-267): same environment switches --
+      ROCM_QUICK_REDUCE_QUANTIZATION = FP | INT8 | INT6 | INT4 | NONE (default NONE: the communicator stays disabled),
+      ROCM_QUICK_REDUCE_CAST_BF16_TO_FP16 (default 1: bf16 tensors travel and are summed as fp16),
+      ROCM_QUICK_REDUCE_MAX_SIZE_BYTES_MB (default: 2 GiB) --
+    same world sizes (2, 4, 8), dtypes and size gate (``should_quick_allreduce``), out-of-place ``quick_all_reduce``, and
+    the same arithmetic (the result of a level is a function of the inputs, not of the schedule; the tests hold it to the
+    CPU restatement under oracle/, bit for bit).  The minimum sizes are the reference's table: it was measured for ITS kernel on
+    MI300 and is kept as the contract of the environment switch, not as a tuned MI355X threshold -- this pool has one GPU
+    per box, so neither this kernel nor the table has been timed across xGMI.
+
+    One context = one fixed 64-MiB region per rank whatever the message size; calls of one context must be stream ordered
+    (HIP-graph capture is fine: the tile counters live in device memory)."""
+
+    _SUPPORTED_WORLD_SIZES = [2, 4, 8]
+    _SUPPORTED_DTYPES = [torch.float16, torch.bfloat16]
+    # [FP, INT8, INT6, INT4] (quick_all_reduce.py:55-66)
+    _QR_MIN_SIZE = {
+        (torch.float16, 2): [1 * MB, 2 * MB, 2 * MB, 1 * MB],
+        (torch.float16, 4): [1 * MB, 16 * MB, 4 * MB, 2 * MB],
+        (torch.float16, 8): [16 * MB, 4 * MB, 4 * MB, 2 * MB],
+        (torch.bfloat16, 2): [2 * MB, 8 * MB, 8 * MB, 8 * MB],
+        (torch.bfloat16, 4): [8 * MB, 64 * MB, 64 * MB, 16 * MB],
+        (torch.bfloat16, 8): [16 * MB, 2048 * MB, 2048 * MB, 2048 * MB],
+    }
+
+    def __init__(self, group: Optional[dist.ProcessGroup], device, regime: Optional[str] = None,
+                 cast_bf16_to_fp16: Optional[bool] = None, max_size_mb: Optional[int] = None):
+        import os
+
+        self.disabled = True
+        self.group = group
+        self.device = torch.device(f"cuda:{device}") if isinstance(device, int) else torch.device(device)
+        self._ctx = None
+        if not dist.is_initialized():
+            return
+        self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
+        if self.world_size == 1:
+            return
+        if self.world_size not in self._SUPPORTED_WORLD_SIZES:
+            warnings.warn(f"quick all-reduce is disabled: world size {self.world_size} not in {self._SUPPORTED_WORLD_SIZES}")
+            return
+        regime = os.environ.get("ROCM_QUICK_REDUCE_QUANTIZATION", "NONE") if regime is None else regime
+        if regime not in QuickReduceRegime.__members__:
+            warnings.warn(f"quick all-reduce: invalid quantization level {regime!r}; supported: {list(QuickReduceRegime.__members__)}")
+            return
+        if regime == "NONE":
+            return
+        self.qr_quant_level = QuickReduceRegime[regime]
+        self.use_fp16_kernels = (int(os.environ.get("ROCM_QUICK_REDUCE_CAST_BF16_TO_FP16", 1)) if cast_bf16_to_fp16 is None
+                                 else int(bool(cast_bf16_to_fp16)))
+        mb = int(os.environ.get("ROCM_QUICK_REDUCE_MAX_SIZE_BYTES_MB", 0)) if max_size_mb is None else int(max_size_mb)
+        self.qr_max_size = mb * MB if mb > 0 else 1 << 31   # (qr_max_size(), quick_all_reduce.cu:86-89)
+        if self.device.type != "cuda":
+            return   # (CPU groups of the gloo tests: the gate above is all that runs there)
+        import ctypes as C
+
+        from . import lib as _L
+
+        self._L, self._C = _L, C
+        lib = self._lib = _L.load()
+        self._opened = []
+        with torch.cuda.device(self.device):
+            self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+            own = C.c_void_p()
+            _L.check(lib.rx_ar_alloc_region(lib.rx_qr_region_bytes(), C.byref(own)), "rx_ar_alloc_region")
+            self._own = own
+            handle = C.create_string_buffer(64)
+            _L.check(lib.rx_ipc_get_handle(own, handle), "rx_ipc_get_handle")
+            handles = [None] * self.world_size
+            dist.all_gather_object(handles, bytes(handle.raw), group=group)
+            ptrs = (C.c_void_p * self.world_size)()
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    ptrs[r] = own.value
+                else:
+                    q = C.c_void_p()
+                    _L.check(lib.rx_ipc_open_handle(C.create_string_buffer(h, 64), C.byref(q)), "rx_ipc_open_handle")
+                    ptrs[r] = q.value
+                    self._opened.append(q)
+            ctx = C.c_void_p()
+            _L.check(lib.rx_qr_init(C.byref(ctx), self.rank, self.world_size, ptrs, C.c_void_p(self.err_flag.data_ptr())),
+                     "rx_qr_init")
+            self._ctx = ctx
+        dist.barrier(group=group)   # every region is mapped everywhere before the first call
+        self.disabled = False
+
+    def size_ok(self, dtype: torch.dtype, nbytes: int) -> bool:
+        """The rank-independent gate (quick_all_reduce.py:222-244): dtype, a multiple of 16 bytes, and the level's size
+        window for (dtype as it travels, world size)."""
+        if self.disabled or dtype not in self._SUPPORTED_DTYPES or nbytes % 16 != 0 or nbytes == 0:
+            return False
+        travel = torch.float16 if self.use_fp16_kernels else dtype
+        return self._QR_MIN_SIZE[(travel, self.world_size)][self.qr_quant_level.value] <= nbytes <= self.qr_max_size
+
+    def should_quick_allreduce(self, inp: torch.Tensor) -> bool:
+        if self.disabled or not inp.is_cuda:
+            return False
+        dense = inp.is_contiguous() or (inp.untyped_storage().nbytes() - inp.storage_offset() * inp.element_size()
+                                        == inp.numel() * inp.element_size())
+        return dense and self.size_ok(inp.dtype, inp.numel() * inp.element_size())
+
+    def quick_all_reduce(self, inp: torch.Tensor, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Out of place (``out`` may be ``inp``)."""
+        if self.disabled:
+            raise RuntimeError("quick all-reduce is disabled (ROCM_QUICK_REDUCE_QUANTIZATION, world size, device)")
+        if inp.dtype not in self._SUPPORTED_DTYPES or inp.numel() % 8 != 0 or inp.data_ptr() % 16 != 0:
+            raise ValueError("quick_all_reduce: needs a 16-byte aligned fp16 / bf16 tensor of a multiple of 8 elements")
+        if out is None:
+            out = torch.empty_like(inp)
+        cp = self._C.c_void_p
+        st = self._lib.rx_quick_allreduce(self._ctx, cp(inp.data_ptr()), cp(out.data_ptr()), inp.numel(),
+                                          self._L.RX_BF16 if inp.dtype == torch.bfloat16 else self._L.RX_F16,
+                                          self.qr_quant_level.value, int(self.use_fp16_kernels),
+                                          cp(torch.cuda.current_stream(inp.device).cuda_stream))
+        self._L.check(st, "rx_quick_allreduce")
+        return out
+
+    def check_errors(self) -> int:
+        v = int(self.err_flag.item())
+        if v:
+            self.err_flag.zero_()
+        return v
+
+    def close(self):
+        """Collective.  A context is meant to live as long as its process group (GroupCoordinator builds qr_comm once): with
+        eight processes on this driver stack (dmabuf IPC), contexts created AFTER an earlier one had been closed and freed
+        either failed in hipIpcGetMemHandle or never saw their peers' flags -- the freed region's mapping appears to be
+        reused on the importing side.  Create once, close at exit."""
+        if getattr(self, "_ctx", None):
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)
+            self._lib.rx_qr_destroy(self._ctx)
+            for q in self._opened:
+                self._lib.rx_ipc_close_handle(q)
+            # every mapping is gone before any owner frees: with eight processes a region freed while a peer still had it
+            # open made the NEXT hipIpcGetMemHandle of that owner fail ("invalid argument", dmabuf IPC; round 6)
+            dist.barrier(group=self.group)
+            self._lib.rx_ar_free_region(self._own)
+            self._ctx = None
+            self.disabled = True
 
 
 class TPGroup:
@@ -196,7 +356,7 @@ class TPGroup:
     entry, parallel_state.py:622-732)."""
 
     def __init__(self, group: Optional[dist.ProcessGroup] = None, custom_ar: Optional[CustomAllReduce] = None,
-                 deterministic: bool = False):
+                 deterministic: bool = False, quick_ar: Optional[QuickAllReduce] = None):
         if not dist.is_initialized():
             self.rank, self.world_size, self.group = 0, 1, None
         else:
@@ -205,6 +365,9 @@ class TPGroup:
             self.world_size = dist.get_world_size(group)
         self._comm_stream = None
         self.custom_ar = custom_ar if self.world_size > 1 else None
+        # C3 (GroupCoordinator.qr_comm, parallel_state.py:443-472): taken behind the peer-to-peer kernel's size window and
+        # ahead of the backend, for the messages its gate admits (parallel_state.py:886-900)
+        self.quick_ar = quick_ar if (self.world_size > 1 and quick_ar is not None and not quick_ar.disabled) else None
         import os
 
         self._strict = os.environ.get("RX_CUSTOM_AR_STRICT", "0") not in ("", "0")
@@ -242,10 +405,15 @@ class TPGroup:
 
         det = cls.deterministic_collectives_enabled(server_args)
         world = dist.get_world_size(group) if dist.is_initialized() else 1
-        ar = None
+        ar = qr = None
         if world > 1 and torch.device(device).type == "cuda" and (det or os.environ.get("RX_CUSTOM_AR", "0") not in ("", "0")):
             ar = CustomAllReduce(group, torch.device(device), max_bytes=max_bytes)
-        return cls(group, custom_ar=ar, deterministic=det)
+        # the quick all-reduce is opt-in through the reference's own switch (ROCM_QUICK_REDUCE_QUANTIZATION != NONE); a lossy
+        # wire format has no place under deterministic inference, whose reduce is the fixed-order 16-bit kernel
+        if world in QuickAllReduce._SUPPORTED_WORLD_SIZES and torch.device(device).type == "cuda" and not det \
+                and os.environ.get("ROCM_QUICK_REDUCE_QUANTIZATION", "NONE") != "NONE":
+            qr = QuickAllReduce(group, torch.device(device))
+        return cls(group, custom_ar=ar, deterministic=det, quick_ar=qr)
 
     def _reduce(self, x: torch.Tensor, lane: int = 0) -> None:
         # Per tensor, like GroupCoordinator.all_reduce's should_custom_ar test (parallel_state.py:672-700): the
@@ -285,6 +453,16 @@ class TPGroup:
             else:
                 tmp = x.contiguous().clone() if x.is_contiguous() else x.contiguous()
                 ar.all_reduce(tmp, lane=lane)
+                x.copy_(tmp)
+            return
+        qr = self.quick_ar
+        # (rank-independent like the rule above: dtype and byte count only; a strided or misaligned view goes through a copy)
+        if qr is not None and x.is_cuda and qr.size_ok(x.dtype, x.numel() * x.element_size()):
+            if x.is_contiguous() and x.data_ptr() % 16 == 0:
+                qr.quick_all_reduce(x, out=x)
+            else:
+                tmp = x.contiguous().clone() if x.is_contiguous() else x.contiguous()
+                qr.quick_all_reduce(tmp, out=tmp)
                 x.copy_(tmp)
             return
         if ar is not None and self._strict:

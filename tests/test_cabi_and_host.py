@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(l, s), f"{s} declared in include/radix_hip.h but not exported"
         assert s in lib.PROTOTYPES, f"{s} has no ctypes prototype"
-    assert l.rx_version() == lib.RX_ABI_VERSION == 15
+    assert l.rx_version() == lib.RX_ABI_VERSION == 16
     assert [l.rx_abi_sizeof(i) for i in range(4)][3] == -1 and l.rx_abi_sizeof(1) > 0
 
 
@@ -316,7 +316,7 @@ print("RC", rc, l.rx_last_error().decode())
     txt = sorted(f for f in os.listdir(tmp_path) if f.endswith(".txt"))
     assert len(txt) == 1 and txt[0].startswith("rx_extend_attn_"), os.listdir(tmp_path)
     rec = open(os.path.join(tmp_path, txt[0])).read()
-    assert "status:" in rec and "error:" in rec and "abi: 15" in rec
+    assert "status:" in rec and "error:" in rec and "abi: 16" in rec
     d = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "decode_dump.py"), os.path.join(tmp_path, txt[0])],
                        capture_output=True, text=True)
     assert d.returncode == 0 and "bs = 3" in d.stdout and "head_dim = 128" in d.stdout, d.stdout[-1500:] + d.stderr[-500:]
