@@ -75,6 +75,7 @@ struct QrArgs {
   int64_t n;       // elements (multiple of 8)
   int64_t ntiles;
   int32_t* dev_err;
+  int32_t fenced;  // option qr_fenced: release / acquire fences around the flags (see qr_signal)
 };
 
 // ---- 16-bit arithmetic on packed pairs (one 32-bit register = elements 2 i, 2 i + 1) ---------------------------------------
@@ -288,13 +289,34 @@ __device__ __forceinline__ u32x4 qr_load_row(qr_rsrc src, int row, int tid) {
   }
 }
 
-__device__ __forceinline__ void qr_signal(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Publication of a slot (what makes the payload visible before the flag), default form:
+//   every wave waits until ITS region stores have been ACKNOWLEDGED (vmcnt counts stores on gfx950; the region is uncached
+//   memory -- rx_ar_alloc_region -- so an acknowledged store has left this GPU's caches for the memory it targets) ->
+//   workgroup barrier -> the signalling lanes store the flag (a relaxed system-scope atomic: nothing is left to order).
+// Consumption: the polling lanes spin on relaxed system-scope loads, the workgroup barrier, then the slot is read with
+// non-temporal loads of uncached memory (never served from a cache of this GPU).
+// Option qr_fenced = 1 is the memory-model form of the same handshake -- release store of the flag (buffer_wbl2 + wait), an
+// acquire fence in every wave behind the wait (buffer_inv) -- for a platform where the acknowledgement argument should not
+// hold; it is what the first version of this kernel did, and it is expensive because the write-back and the invalidate
+// are whole-L2 operations issued twice per tile and workgroup.  Round 6, two processes on ONE GPU, 64 MiB fp16, ms per call
+// (FP / INT4): __threadfence_system() in every wave + acquire loads in the spin 1.38 / 1.17; release store + one acquire
+// fence per wave 0.53 / 0.46 (= qr_fenced); release store only 0.38 / 0.27; acquire fence only 0.30 / 0.29; neither (default)
+// 0.127 / 0.120 -- at FP that is 6 bytes of HBM traffic per message byte and rank, 6.2 TB/s for the two ranks: the device's
+// copy rate, i.e. the handshake is hidden.  (One GPU: no link was involved; see the file header.)
+__device__ __forceinline__ void qr_stores_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
+__device__ __forceinline__ void qr_signal(uint32_t* p, uint32_t v, bool fenced) {
+  if (fenced) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ bool qr_wait(const uint32_t* p, uint32_t v) {
   for (uint32_t i = 0; i < kQrSpinLimit; ++i) {
-    if (static_cast<int32_t>(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - v) >= 0) return true;
+    if (static_cast<int32_t>(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) >= 0) return true;
     __builtin_amdgcn_s_sleep(1);
   }
   return false;
+}
+__device__ __forceinline__ void qr_acquire(bool fenced) {
+  if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope
 }
 
 __device__ __forceinline__ uint32_t qr_bf16x2_to_f16x2(uint32_t v) {
@@ -351,14 +373,15 @@ __global__ __launch_bounds__(kQrThreads, 4) void quick_allreduce_kernel(const Qr
 #pragma unroll
       for (int k = 0; k < RA; ++k) qr_store_row<BITS>(dst, p1_slot + me * kSub + k * kRow, qr_encode<NT, BITS>(atom[r * RA + k]), tid);
     }
-    __threadfence_system();
+    qr_stores_done();
     __syncthreads();
     if (tid < W) {
-      qr_signal(&reinterpret_cast<QrFlags*>(a.peers[tid])->p1[b][me], colour);
+      qr_signal(&reinterpret_cast<QrFlags*>(a.peers[tid])->p1[b][me], colour, a.fenced != 0);
       if (!qr_wait(&my_flags->p1[b][tid], colour)) timeout_s = 1;
     }
     __syncthreads();
     if (timeout_s) break;
+    qr_acquire(a.fenced != 0);
     // ---- my segment: the W versions, decoded and added in rank order in the 16-bit type
     u32x4 acc[RA];
 #pragma unroll
@@ -379,14 +402,15 @@ __global__ __launch_bounds__(kQrThreads, 4) void quick_allreduce_kernel(const Qr
 #pragma unroll
       for (int r = 0; r < W; ++r) qr_store_row<BITS>(qr_region(a.peers[r]), p2_slot + me * kSub + k * kRow, p, tid);
     }
-    __threadfence_system();
+    qr_stores_done();
     __syncthreads();
     if (tid < W) {
-      qr_signal(&reinterpret_cast<QrFlags*>(a.peers[tid])->p2[b][me], colour);
+      qr_signal(&reinterpret_cast<QrFlags*>(a.peers[tid])->p2[b][me], colour, a.fenced != 0);
       if (!qr_wait(&my_flags->p2[b][tid], colour)) timeout_s = 1;
     }
     __syncthreads();
     if (timeout_s) break;
+    qr_acquire(a.fenced != 0);
 #pragma unroll
     for (int r = 0; r < W; ++r) {
 #pragma unroll
@@ -479,6 +503,7 @@ int rx_quick_allreduce(rx_qr_ctx* ctx, const void* in, void* out, int64_t count,
   a.n = count;
   a.ntiles = (count + kQrTileElems - 1) / kQrTileElems;
   a.dev_err = c->dev_err;
+  a.fenced = options().qr_fenced;
   const int cap = options().qr_max_blocks;  // (tests: a small grid walks many tiles per workgroup on a small message)
   const unsigned grid = static_cast<unsigned>(std::min<int64_t>(a.ntiles, cap > 0 && cap < kQrMaxBlocks ? cap : kQrMaxBlocks));
   auto s = static_cast<hipStream_t>(stream);

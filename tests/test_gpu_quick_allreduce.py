@@ -151,6 +151,11 @@ for level, dt, cast in COMBOS:
                 print(f"rank {rank} {level} {dt} replay {v}: got {out.float().unique().tolist()[:4]}", flush=True)
         del graph
     mark("graph replays done")
+    if dt == torch.float16 and level in ("FP", "INT6"):   # option qr_fenced: the release / acquire form of the flag handshake, same bits
+        L.set_option("qr_fenced", 1)
+        seed += 1
+        check(qr, parts_for(seed, SIZES[-1], dt, "acts"), dt, f"{level} {dt} fenced")
+        L.set_option("qr_fenced", 0)
     if qr.check_errors() != 0:
         ok = False
         print(f"rank {rank}: device error word set", flush=True)

@@ -85,6 +85,22 @@ def _worker(rank, world, port, out_dir):
         assert gdet.deterministic and gdet.custom_ar is None
         yd = RowParallelOProj(torch.from_numpy(w_o).double(), sh, D, gdet).forward(torch.from_numpy(part.reshape(bs, -1))).wait()
         np.testing.assert_allclose(yd.numpy(), want, atol=1e-9)
+        # the quick all-reduce (C3) under its environment switch: on a CPU group the communicator stays disabled (no region,
+        # no kernel) and every reduce goes to the group's backend; its level parses as the reference's does
+        os.environ["ROCM_QUICK_REDUCE_QUANTIZATION"] = "INT6"
+        try:
+            from sglang_amd.parallel import QuickAllReduce, QuickReduceRegime
+            qr = QuickAllReduce(None, "cpu")
+            assert qr.disabled and qr.qr_quant_level is QuickReduceRegime.INT6 and qr.use_fp16_kernels == 1
+            gq = TPGroup(None, quick_ar=qr)
+            assert gq.quick_ar is None
+            big = torch.full((1 << 20,), float(rank + 1), dtype=torch.bfloat16)   # 2 MiB: inside the level's window on a GPU
+            gq.all_reduce(big)
+            assert float(big[0]) == sum(range(1, world + 1))
+            gcpu = TPGroup.from_server_args(None, None, torch.device("cpu"))
+            assert gcpu.quick_ar is None and not gcpu.deterministic
+        finally:
+            del os.environ["ROCM_QUICK_REDUCE_QUANTIZATION"]
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
