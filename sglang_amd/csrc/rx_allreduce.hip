@@ -80,18 +80,34 @@ struct ArArgs {
   uint16_t* out_res;
   int32_t rows, hidden;
   float eps;
+  int32_t fenced;  // option ar_fenced
 };
 
-__device__ __forceinline__ void ar_signal(uint32_t* p, uint32_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+// The flag handshake (round 6; measured on rx_quick_allreduce.hip, which documents the numbers): a block's stores into the
+// shared regions are ACKNOWLEDGED before its flag goes out -- every wave waits vmcnt(0) (stores count on gfx950; the regions
+// are uncached memory, an acknowledged store is out of this GPU's caches), workgroup barrier, relaxed system-scope flag
+// store -- and consumed by relaxed polling, barrier, non-temporal loads of uncached memory.  Option ar_fenced = 1: the
+// memory-model form (system fence in every wave, release store, acquire fence behind the wait), what this file did until
+// round 6: the whole-L2 write-back / invalidate behind those fences were most of a small message's latency (two processes
+// on one GPU, 2 MiB: 42 us -> see DESIGN 7).
+__device__ __forceinline__ void ar_publish_begin(bool fenced) {
+  if (fenced) __threadfence_system();
+  else __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+}
+__device__ __forceinline__ void ar_signal(uint32_t* p, uint32_t v, bool fenced) {
+  if (fenced) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ bool ar_wait(const uint32_t* p, uint32_t v) {
   for (uint32_t i = 0; i < kArSpinLimit; ++i) {
     // calls are numbered 1, 2, 3, ...: "at least v" (a fast peer may already be a call ahead)
-    if (static_cast<int32_t>(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - v) >= 0) return true;
+    if (static_cast<int32_t>(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) >= 0) return true;
     __builtin_amdgcn_s_sleep(1);
   }
   return false;
+}
+__device__ __forceinline__ void ar_acquire(bool fenced) {
+  if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 // call number of this launch for block b: previous + 1, kept in the rank's own region
@@ -112,9 +128,13 @@ __device__ __forceinline__ uint32_t ar_next_call(const ArArgs& a, int b, uint32_
 // the staging exchange EVERY rank reduces ALL chunks itself -- fp32, rank order 0 .. W-1, one rounding -- straight into
 // `out`; no second flag exchange, no gather.  (The two-shot form sums in the same fixed order; what the one-shot form adds
 // is the reference's structure: no rank's result depends on another rank's reduction.)
-template <typename T, bool ONE_SHOT = false>
+// WT: the world size as a compile-time constant (2, 4, 6, 8): the W loads of one reduction step are then issued together
+// instead of one per trip of a run-time loop (uncached reads are ~2 us round trips; round 6, two processes on one GPU, 2 MiB:
+// one-shot 44 -> see DESIGN 7).
+template <typename T, bool ONE_SHOT, int WT>
 __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const ArArgs a) {
-  const int b = blockIdx.x, tid = threadIdx.x, W = a.world, r = a.rank;
+  constexpr int W = WT;
+  const int b = blockIdx.x, tid = threadIdx.x, r = a.rank;
   __shared__ uint32_t call_s;
   __shared__ int timeout_s;
   if (tid == 0) timeout_s = 0;
@@ -129,12 +149,14 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
   const u32x4* in_v = reinterpret_cast<const u32x4*>(a.in);
   for (int c = 0; c < W; ++c) {
     const int64_t lo = c * per, hi = min(lo + per, nv);
+#pragma unroll 4
     for (int64_t i = lo + b * kArThreads + tid; i < hi; i += kArBlocks * kArThreads) my_stage[i] = in_v[i];
   }
-  __threadfence_system();
+  const bool fenced = a.fenced != 0;
+  ar_publish_begin(fenced);
   __syncthreads();
   if (tid < W && tid != r)
-    ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->ready[b][r], call);
+    ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->ready[b][r], call, fenced);
   if (tid < W && tid != r) {
     if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->ready[b][tid], call)) timeout_s = 1;
   }
@@ -143,6 +165,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
     if (tid == 0) atomicOr(a.dev_err, RX_DEVERR_AR_TIMEOUT);
     return;
   }
+  ar_acquire(fenced);
 
   // ---- phase 1: reduce my chunk over all ranks' staging buffers (fp32 accumulate, rank order fixed
   // so that every rank computes bit-identical sums)
@@ -150,10 +173,15 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
     const int64_t lo = c * per, hi = min(lo + per, nv);
     u32x4* my_res = reinterpret_cast<u32x4*>(a.peers[r] + result_off);
     u32x4* out_v = reinterpret_cast<u32x4*>(a.out);
+#pragma unroll 2
     for (int64_t i = lo + b * kArThreads + tid; i < hi; i += kArBlocks * kArThreads) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int p = 0; p < W; ++p) {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.peers[p] + stage_off) + i);
+      u32x4 vs[W];
+#pragma unroll
+      for (int p = 0; p < W; ++p) vs[p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.peers[p] + stage_off) + i);
+#pragma unroll
+      for (int p = 0; p < W; ++p) {   // (rank order 0 .. W-1: the sum's order is part of the contract)
+        const u32x4 v = vs[p];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           acc[2 * j] += T::to_f32(static_cast<uint16_t>(v[j] & 0xffffu));
@@ -167,11 +195,13 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
       out_v[i] = o;
     }
   }
+#ifndef RX_AR_DET_SECOND_EXCHANGE
   if constexpr (ONE_SHOT) return;  // (the staging buffer of this parity is reused at call + 2, behind the peers' ready(call + 1))
-  __threadfence_system();
+#endif
+  ar_publish_begin(fenced);
   __syncthreads();
   if (tid < W && tid != r)
-    ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->done[b][r], call);
+    ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->done[b][r], call, fenced);
   if (tid < W && tid != r) {
     if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->done[b][tid], call)) timeout_s = 1;
   }
@@ -180,14 +210,16 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
     if (tid == 0) atomicOr(a.dev_err, RX_DEVERR_AR_TIMEOUT);
     return;
   }
+  ar_acquire(fenced);
 
   // ---- phase 2: gather the other ranks' reduced chunks
-  {
+  if constexpr (!ONE_SHOT) {
     u32x4* out_v = reinterpret_cast<u32x4*>(a.out);
     for (int c = 0; c < W; ++c) {
       if (c == r) continue;
       const int64_t lo = c * per, hi = min(lo + per, nv);
       const u32x4* res = reinterpret_cast<const u32x4*>(a.peers[c] + result_off);
+#pragma unroll 4
       for (int64_t i = lo + b * kArThreads + tid; i < hi; i += kArBlocks * kArThreads)
         out_v[i] = __builtin_nontemporal_load(res + i);
     }
@@ -272,9 +304,10 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
         for (int v = tid; v < nvec; v += kArThreads) my_stage[row * nvec + v] = in_v[row * nvec + v];
     }
   }
-  __threadfence_system();
+  const bool fenced = a.fenced != 0;
+  ar_publish_begin(fenced);
   __syncthreads();
-  if (tid < W && tid != r) ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->ready[b][r], call);
+  if (tid < W && tid != r) ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->ready[b][r], call, fenced);
   if (tid < W && tid != r) {
     if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->ready[b][tid], call)) timeout_s = 1;
   }
@@ -283,6 +316,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
     if (tid == 0) atomicOr(a.dev_err, RX_DEVERR_AR_TIMEOUT);
     return;
   }
+  ar_acquire(fenced);
 
   // ---- phase 1: my rows = sum over ranks (fp32, fixed order) -> 16-bit, + residual -> 16-bit, normalise
   {
@@ -324,9 +358,9 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
       ar_norm_row<T>(a, ro, nvec, row, red_s);
     }
   }
-  __threadfence_system();
+  ar_publish_begin(fenced);
   __syncthreads();
-  if (tid < W && tid != r) ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->done[b][r], call);
+  if (tid < W && tid != r) ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->done[b][r], call, fenced);
   if (tid < W && tid != r) {
     if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->done[b][tid], call)) timeout_s = 1;
   }
@@ -335,6 +369,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
     if (tid == 0) atomicOr(a.dev_err, RX_DEVERR_AR_TIMEOUT);
     return;
   }
+  ar_acquire(fenced);
 
   // ---- phase 2: the other ranks' residual_out rows: copy and normalise on the way through
   {
@@ -357,6 +392,27 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
       }
     }
   }
+}
+
+template <bool ONE_SHOT>
+static void launch_two_shot(const ArArgs& a, int dtype, hipStream_t s) {
+#define RX_AR_W(TT, WW) hipLaunchKernelGGL((allreduce_two_shot_kernel<TT, ONE_SHOT, WW>), dim3(kArBlocks), dim3(kArThreads), 0, s, a)
+#define RX_AR_T(TT)                                                  \
+  do {                                                               \
+    switch (a.world) {                                               \
+      case 2: RX_AR_W(TT, 2); break;                                 \
+      case 3: RX_AR_W(TT, 3); break;                                 \
+      case 4: RX_AR_W(TT, 4); break;                                 \
+      case 5: RX_AR_W(TT, 5); break;                                 \
+      case 6: RX_AR_W(TT, 6); break;                                 \
+      case 7: RX_AR_W(TT, 7); break;                                 \
+      default: RX_AR_W(TT, 8); break;                                \
+    }                                                                \
+  } while (0)
+  if (dtype == RX_BF16) RX_AR_T(BF16);
+  else RX_AR_T(F16);
+#undef RX_AR_T
+#undef RX_AR_W
 }
 
 }  // namespace rx
@@ -443,6 +499,7 @@ static ArArgs ar_args(const ArCtx* c) {
   a.world = c->world;
   a.max_bytes = c->max_bytes;
   a.dev_err = c->dev_err;
+  a.fenced = options().ar_fenced;
   return a;
 }
 
@@ -461,10 +518,7 @@ int rx_allreduce(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int d
   a.out = static_cast<uint16_t*>(out);
   a.n = count;
   auto s = static_cast<hipStream_t>(stream);
-  if (dtype == RX_BF16)
-    hipLaunchKernelGGL(allreduce_two_shot_kernel<BF16>, dim3(kArBlocks), dim3(kArThreads), 0, s, a);
-  else
-    hipLaunchKernelGGL(allreduce_two_shot_kernel<F16>, dim3(kArBlocks), dim3(kArThreads), 0, s, a);
+  launch_two_shot<false>(a, dtype, s);
   return check_launch("rx_allreduce");
 }
 
@@ -483,10 +537,7 @@ int rx_allreduce_det(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, i
   a.out = static_cast<uint16_t*>(out);
   a.n = count;
   auto s = static_cast<hipStream_t>(stream);
-  if (dtype == RX_BF16)
-    hipLaunchKernelGGL((allreduce_two_shot_kernel<BF16, true>), dim3(kArBlocks), dim3(kArThreads), 0, s, a);
-  else
-    hipLaunchKernelGGL((allreduce_two_shot_kernel<F16, true>), dim3(kArBlocks), dim3(kArThreads), 0, s, a);
+  launch_two_shot<true>(a, dtype, s);
   return check_launch("rx_allreduce_det");
 }
 

@@ -17,6 +17,7 @@ import os, sys
 import torch, torch.distributed as dist
 sys.path.insert(0, os.environ["RX_ROOT"])
 from sglang_amd.parallel import CustomAllReduce, TPGroup
+from sglang_amd import lib as L
 import time
 T0 = time.perf_counter()
 def mark(what):   # rank 0: where the wall time of a many-process run goes (GPUTEST budget, VERDICT r05 weak 10)
@@ -49,6 +50,7 @@ for it, (n, dt) in enumerate(([(256 * 4096, torch.bfloat16)] if TINY else
     parts = parts_for(100 * it, n, dt)
     x = parts[rank].to(dev)
     want = sum(p.float() for p in parts).to(dt)                          # fp32 sum in rank order, one rounding
+    L.set_option("ar_fenced", int(it == 1))   # (option ar_fenced: the release / acquire form of the flag handshake, same result)
     if it % 2 == 0:
         tp.all_reduce(x)                      # in place, current stream (lane 0)
         got = x
@@ -59,6 +61,7 @@ for it, (n, dt) in enumerate(([(256 * 4096, torch.bfloat16)] if TINY else
         ok = False
         print(f"rank {rank} it {it} n {n}: max diff", (got.cpu().float() - want.float()).abs().max().item(), flush=True)
 
+L.set_option("ar_fenced", 0)
 mark("eager calls")
 if SKIP_GRAPH:
     side = torch.cuda.Stream()
