@@ -1500,27 +1500,47 @@ def custom_ar_child_leg(args, world):
            "--bs", str(args.bs), "--ctx", str(args.ctx), "--layers", str(args.layers), "--page-size", str(args.page_size),
            "--kv-layout", args.kv_layout, "--index-mode", args.index_mode, "--split-policy", args.split_policy,
            "--max-kv-splits", str(args.max_kv_splits)]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RX_CUSTOM_AR="1")
+    base_env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RX_CUSTOM_AR="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE",
               "GROUP_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
               "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
-        env.pop(k, None)
-    env.setdefault("OMP_NUM_THREADS", "8")
-    limit = float(os.environ.get("RX_BENCH_AR_LEG_TIMEOUT_S", "300"))
-    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-    try:
-        out, err = pr.communicate(timeout=limit)
-    except subprocess.TimeoutExpired:
+        base_env.pop(k, None)
+    base_env.setdefault("OMP_NUM_THREADS", "8")
+    # a flag wait that will never be satisfied gives up after 2^22 polls (seconds) instead of the library's 2^27 (minutes):
+    # the kernel then raises its error word, first_contact sees a wrong sum and the child exits non-zero
+    base_env.setdefault("RX_OPT_AR_SPIN_LOG2", "22")
+    limit = float(os.environ.get("RX_BENCH_AR_LEG_TIMEOUT_S", "240"))
+
+    def run_child(extra):
+        pr = subprocess.Popen(cmd, env=dict(base_env, **extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              start_new_session=True)
         try:
-            os.killpg(pr.pid, signal.SIGKILL)  # exactly the process group started above
-        except OSError:
-            pass
-        out, err = pr.communicate()
-        return {"error": f"child job exceeded {limit:.0f} s and was stopped", "stderr_tail": err[-400:]}
-    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
-    if pr.returncode != 0 or not lines:
-        return {"error": f"child job rc={pr.returncode}", "stderr_tail": err[-600:]}
-    return json.loads(lines[-1])
+            out, err = pr.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(pr.pid, signal.SIGKILL)  # exactly the process group started above
+            except OSError:
+                pass
+            out, err = pr.communicate()
+            return {"error": f"child job exceeded {limit:.0f} s and was stopped", "stderr_tail": err[-400:]}
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if pr.returncode != 0 or not lines:
+            return {"error": f"child job rc={pr.returncode}", "stderr_tail": err[-600:]}
+        return json.loads(lines[-1])
+
+    # The kernels' default flag handshake orders payload and flag by ACKNOWLEDGED uncached stores (rx_allreduce.hip, round 6):
+    # measured with N processes on one GPU only.  If it fails its first contact across xGMI, the memory-model form (system
+    # fences, release / acquire: option ar_fenced) gets one try, and the record says which one ran.
+    res = run_child({})
+    if "error" not in res:
+        res["flag_handshake"] = "acknowledged uncached stores (default)"
+        return res
+    second = run_child({"RX_OPT_AR_FENCED": "1"})
+    if "error" not in second:
+        second["flag_handshake"] = "fenced (RX_OPT_AR_FENCED=1)"
+        second["default_handshake_error"] = res
+        return second
+    return {"error": res["error"], "stderr_tail": res.get("stderr_tail", ""), "fenced_handshake_error": second}
 
 
 def allreduce_figures(st, fb, world, args, step_fn_factory):

@@ -81,6 +81,7 @@ struct ArArgs {
   int32_t rows, hidden;
   float eps;
   int32_t fenced;  // option ar_fenced
+  uint32_t spin_limit;  // polls before a wait gives up (option ar_spin_log2; default 2^27)
 };
 
 // The flag handshake (round 6; measured on rx_quick_allreduce.hip, which documents the numbers): a block's stores into the
@@ -98,8 +99,8 @@ __device__ __forceinline__ void ar_signal(uint32_t* p, uint32_t v, bool fenced) 
   if (fenced) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ bool ar_wait(const uint32_t* p, uint32_t v) {
-  for (uint32_t i = 0; i < kArSpinLimit; ++i) {
+__device__ __forceinline__ bool ar_wait(const uint32_t* p, uint32_t v, uint32_t limit) {
+  for (uint32_t i = 0; i < limit; ++i) {
     // calls are numbered 1, 2, 3, ...: "at least v" (a fast peer may already be a call ahead)
     if (static_cast<int32_t>(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) >= 0) return true;
     __builtin_amdgcn_s_sleep(1);
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
   if (tid < W && tid != r)
     ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->ready[b][r], call, fenced);
   if (tid < W && tid != r) {
-    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->ready[b][tid], call)) timeout_s = 1;
+    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->ready[b][tid], call, a.spin_limit)) timeout_s = 1;
   }
   __syncthreads();
   if (timeout_s) {
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
   if (tid < W && tid != r)
     ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->done[b][r], call, fenced);
   if (tid < W && tid != r) {
-    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->done[b][tid], call)) timeout_s = 1;
+    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->done[b][tid], call, a.spin_limit)) timeout_s = 1;
   }
   __syncthreads();
   if (timeout_s) {
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
   __syncthreads();
   if (tid < W && tid != r) ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->ready[b][r], call, fenced);
   if (tid < W && tid != r) {
-    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->ready[b][tid], call)) timeout_s = 1;
+    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->ready[b][tid], call, a.spin_limit)) timeout_s = 1;
   }
   __syncthreads();
   if (timeout_s) {
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
   __syncthreads();
   if (tid < W && tid != r) ar_signal(&reinterpret_cast<ArFlags*>(a.peers[tid])->done[b][r], call, fenced);
   if (tid < W && tid != r) {
-    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->done[b][tid], call)) timeout_s = 1;
+    if (!ar_wait(&reinterpret_cast<ArFlags*>(a.peers[r])->done[b][tid], call, a.spin_limit)) timeout_s = 1;
   }
   __syncthreads();
   if (timeout_s) {
@@ -392,6 +393,11 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
       }
     }
   }
+}
+
+uint32_t ar_spin_limit() {  // (rx_quick_allreduce.hip uses it too)
+  const int lg = options().ar_spin_log2;
+  return lg >= 10 && lg <= 31 ? 1u << lg : kArSpinLimit;
 }
 
 template <bool ONE_SHOT>
@@ -500,6 +506,7 @@ static ArArgs ar_args(const ArCtx* c) {
   a.max_bytes = c->max_bytes;
   a.dev_err = c->dev_err;
   a.fenced = options().ar_fenced;
+  a.spin_limit = ar_spin_limit();
   return a;
 }
 

@@ -47,7 +47,7 @@ constexpr int kQrTileElems = kQrThreads * kQrAtoms * 8;       // 16384 elements 
 constexpr int kQrSlotBytes = kQrTileElems * 2;                // one (workgroup, phase) slot: the FP level's payload
 constexpr int kQrMaxBlocks = 1024;
 constexpr int kQrMaxWorld = 8;
-constexpr uint32_t kQrSpinLimit = 1u << 27;
+uint32_t ar_spin_limit();  // rx_allreduce.hip: 2^ar_spin_log2 polls (default 2^27) before a wait raises RX_DEVERR_AR_TIMEOUT
 
 struct QrFlags {
   uint32_t p1[kQrMaxBlocks][kQrMaxWorld];  // p1[b][src]: src's workgroup b has written its phase-1 payload of tile-count `value`
@@ -76,6 +76,7 @@ struct QrArgs {
   int64_t ntiles;
   int32_t* dev_err;
   int32_t fenced;  // option qr_fenced: release / acquire fences around the flags (see qr_signal)
+  uint32_t spin_limit;  // polls before a wait gives up (option ar_spin_log2)
 };
 
 // ---- 16-bit arithmetic on packed pairs (one 32-bit register = elements 2 i, 2 i + 1) ---------------------------------------
@@ -308,8 +309,8 @@ __device__ __forceinline__ void qr_signal(uint32_t* p, uint32_t v, bool fenced) 
   if (fenced) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ bool qr_wait(const uint32_t* p, uint32_t v) {
-  for (uint32_t i = 0; i < kQrSpinLimit; ++i) {
+__device__ __forceinline__ bool qr_wait(const uint32_t* p, uint32_t v, uint32_t limit) {
+  for (uint32_t i = 0; i < limit; ++i) {
     if (static_cast<int32_t>(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) >= 0) return true;
     __builtin_amdgcn_s_sleep(1);
   }
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(kQrThreads, 4) void quick_allreduce_kernel(const Qr
     __syncthreads();
     if (tid < W) {
       qr_signal(&reinterpret_cast<QrFlags*>(a.peers[tid])->p1[b][me], colour, a.fenced != 0);
-      if (!qr_wait(&my_flags->p1[b][tid], colour)) timeout_s = 1;
+      if (!qr_wait(&my_flags->p1[b][tid], colour, a.spin_limit)) timeout_s = 1;
     }
     __syncthreads();
     if (timeout_s) break;
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(kQrThreads, 4) void quick_allreduce_kernel(const Qr
     __syncthreads();
     if (tid < W) {
       qr_signal(&reinterpret_cast<QrFlags*>(a.peers[tid])->p2[b][me], colour, a.fenced != 0);
-      if (!qr_wait(&my_flags->p2[b][tid], colour)) timeout_s = 1;
+      if (!qr_wait(&my_flags->p2[b][tid], colour, a.spin_limit)) timeout_s = 1;
     }
     __syncthreads();
     if (timeout_s) break;
@@ -504,6 +505,7 @@ int rx_quick_allreduce(rx_qr_ctx* ctx, const void* in, void* out, int64_t count,
   a.ntiles = (count + kQrTileElems - 1) / kQrTileElems;
   a.dev_err = c->dev_err;
   a.fenced = options().qr_fenced;
+  a.spin_limit = ar_spin_limit();
   const int cap = options().qr_max_blocks;  // (tests: a small grid walks many tiles per workgroup on a small message)
   const unsigned grid = static_cast<unsigned>(std::min<int64_t>(a.ntiles, cap > 0 && cap < kQrMaxBlocks ? cap : kQrMaxBlocks));
   auto s = static_cast<hipStream_t>(stream);
