@@ -32,11 +32,14 @@ def run(kind):
         ar.all_reduce_det(x)
     else:
         ar.fused_allreduce_rmsnorm(x, res, w, 1e-6)
+CAPTURE = torch.cuda.Stream()   # ONE capture stream for the whole run: every new stream is a new hardware queue, and once the
+# processes' queues outnumber the hardware's the scheduler time-slices them -- a spinning kernel then burns its whole quantum:
+# 8 processes, a fresh stream per measurement: 76 us per call for the first measurement, 21 ms (two exchanges x ~10.6 ms) after
 def measure(kind):
     for _ in range(3):
         run(kind)
     torch.cuda.synchronize(); dist.barrier()
-    s = torch.cuda.Stream()
+    s = CAPTURE
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=s):
         for _ in range(16):
@@ -54,8 +57,7 @@ def measure(kind):
     dist.barrier()
     del g
     return t.item()
-# every kind is measured three times with a fresh graph and the best is quoted: whatever is measured SECOND in a process reads
-# ~20 us per call too long, kind or size regardless (tools/probe/det_probe.py: the same kernel 7.5 us first and third, 28 us second)
+# every kind is measured three times with a fresh graph and the best is quoted
 for kind in ("two_shot", "two_shot", "one_shot_det", "fused_rmsnorm"):
     us = min(measure(kind) for _ in range(3))
     if rank == 0:
