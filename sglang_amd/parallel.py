@@ -220,7 +220,8 @@ class QuickAllReduce:
     per box, so neither this kernel nor the table has been timed across xGMI.
 
     One context = one fixed 64-MiB region per rank whatever the message size; calls of one context must be stream ordered
-    (HIP-graph capture is fine: the tile counters live in device memory)."""
+    (HIP-graph capture is fine: the tile counters live in device memory), so the object owns ``lanes`` contexts: lane 0 for
+    the caller's stream, lane 1 for TPGroup.all_reduce_async's communication stream."""
 
     _SUPPORTED_WORLD_SIZES = [2, 4, 8]
     _SUPPORTED_DTYPES = [torch.float16, torch.bfloat16]
@@ -235,7 +236,7 @@ class QuickAllReduce:
     }
 
     def __init__(self, group: Optional[dist.ProcessGroup], device, regime: Optional[str] = None,
-                 cast_bf16_to_fp16: Optional[bool] = None, max_size_mb: Optional[int] = None):
+                 cast_bf16_to_fp16: Optional[bool] = None, max_size_mb: Optional[int] = None, lanes: int = 2):
         import os
 
         self.disabled = True
@@ -269,29 +270,33 @@ class QuickAllReduce:
 
         self._L, self._C = _L, C
         lib = self._lib = _L.load()
-        self._opened = []
+        self._opened, self._own, self._ctxs = [], [], []
         with torch.cuda.device(self.device):
             self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-            own = C.c_void_p()
-            _L.check(lib.rx_ar_alloc_region(lib.rx_qr_region_bytes(), C.byref(own)), "rx_ar_alloc_region")
-            self._own = own
-            handle = C.create_string_buffer(64)
-            _L.check(lib.rx_ipc_get_handle(own, handle), "rx_ipc_get_handle")
-            handles = [None] * self.world_size
-            dist.all_gather_object(handles, bytes(handle.raw), group=group)
-            ptrs = (C.c_void_p * self.world_size)()
-            for r, h in enumerate(handles):
-                if r == self.rank:
-                    ptrs[r] = own.value
-                else:
-                    q = C.c_void_p()
-                    _L.check(lib.rx_ipc_open_handle(C.create_string_buffer(h, 64), C.byref(q)), "rx_ipc_open_handle")
-                    ptrs[r] = q.value
-                    self._opened.append(q)
-            ctx = C.c_void_p()
-            _L.check(lib.rx_qr_init(C.byref(ctx), self.rank, self.world_size, ptrs, C.c_void_p(self.err_flag.data_ptr())),
-                     "rx_qr_init")
-            self._ctx = ctx
+            # one context (= one 64-MiB region) per LANE: a context's launches must be ordered, and TPGroup reduces on two
+            # streams -- lane 0 the caller's, lane 1 the communication stream of all_reduce_async (as CustomAllReduce)
+            for _ in range(max(1, int(lanes))):
+                own = C.c_void_p()
+                _L.check(lib.rx_ar_alloc_region(lib.rx_qr_region_bytes(), C.byref(own)), "rx_ar_alloc_region")
+                self._own.append(own)
+                handle = C.create_string_buffer(64)
+                _L.check(lib.rx_ipc_get_handle(own, handle), "rx_ipc_get_handle")
+                handles = [None] * self.world_size
+                dist.all_gather_object(handles, bytes(handle.raw), group=group)
+                ptrs = (C.c_void_p * self.world_size)()
+                for r, h in enumerate(handles):
+                    if r == self.rank:
+                        ptrs[r] = own.value
+                    else:
+                        q = C.c_void_p()
+                        _L.check(lib.rx_ipc_open_handle(C.create_string_buffer(h, 64), C.byref(q)), "rx_ipc_open_handle")
+                        ptrs[r] = q.value
+                        self._opened.append(q)
+                ctx = C.c_void_p()
+                _L.check(lib.rx_qr_init(C.byref(ctx), self.rank, self.world_size, ptrs, C.c_void_p(self.err_flag.data_ptr())),
+                         "rx_qr_init")
+                self._ctxs.append(ctx)
+            self._ctx = self._ctxs[0]
         dist.barrier(group=group)   # every region is mapped everywhere before the first call
         self.disabled = False
 
@@ -310,8 +315,8 @@ class QuickAllReduce:
                                         == inp.numel() * inp.element_size())
         return dense and self.size_ok(inp.dtype, inp.numel() * inp.element_size())
 
-    def quick_all_reduce(self, inp: torch.Tensor, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Out of place (``out`` may be ``inp``)."""
+    def quick_all_reduce(self, inp: torch.Tensor, *, out: Optional[torch.Tensor] = None, lane: int = 0) -> torch.Tensor:
+        """Out of place (``out`` may be ``inp``).  ``lane``: which of the object's contexts (one per stream of launches)."""
         if self.disabled:
             raise RuntimeError("quick all-reduce is disabled (ROCM_QUICK_REDUCE_QUANTIZATION, world size, device)")
         if inp.dtype not in self._SUPPORTED_DTYPES or inp.numel() % 8 != 0 or inp.data_ptr() % 16 != 0:
@@ -319,7 +324,7 @@ class QuickAllReduce:
         if out is None:
             out = torch.empty_like(inp)
         cp = self._C.c_void_p
-        st = self._lib.rx_quick_allreduce(self._ctx, cp(inp.data_ptr()), cp(out.data_ptr()), inp.numel(),
+        st = self._lib.rx_quick_allreduce(self._ctxs[min(lane, len(self._ctxs) - 1)], cp(inp.data_ptr()), cp(out.data_ptr()), inp.numel(),
                                           self._L.RX_BF16 if inp.dtype == torch.bfloat16 else self._L.RX_F16,
                                           self.qr_quant_level.value, int(self.use_fp16_kernels),
                                           cp(torch.cuda.current_stream(inp.device).cuda_stream))
@@ -340,14 +345,16 @@ class QuickAllReduce:
         if getattr(self, "_ctx", None):
             torch.cuda.synchronize(self.device)
             dist.barrier(group=self.group)
-            self._lib.rx_qr_destroy(self._ctx)
+            for ctx in self._ctxs:
+                self._lib.rx_qr_destroy(ctx)
             for q in self._opened:
                 self._lib.rx_ipc_close_handle(q)
             # every mapping is gone before any owner frees: with eight processes a region freed while a peer still had it
             # open made the NEXT hipIpcGetMemHandle of that owner fail ("invalid argument", dmabuf IPC; round 6)
             dist.barrier(group=self.group)
-            self._lib.rx_ar_free_region(self._own)
-            self._ctx = None
+            for own in self._own:
+                self._lib.rx_ar_free_region(own)
+            self._ctx, self._ctxs = None, []
             self.disabled = True
 
 
@@ -459,10 +466,10 @@ class TPGroup:
         # (rank-independent like the rule above: dtype and byte count only; a strided or misaligned view goes through a copy)
         if qr is not None and x.is_cuda and qr.size_ok(x.dtype, x.numel() * x.element_size()):
             if x.is_contiguous() and x.data_ptr() % 16 == 0:
-                qr.quick_all_reduce(x, out=x)
+                qr.quick_all_reduce(x, out=x, lane=lane)
             else:
                 tmp = x.contiguous().clone() if x.is_contiguous() else x.contiguous()
-                qr.quick_all_reduce(tmp, out=tmp)
+                qr.quick_all_reduce(tmp, out=tmp, lane=lane)
                 x.copy_(tmp)
             return
         if ar is not None and self._strict:

@@ -172,6 +172,18 @@ for level, dt, cast in COMBOS:
         if not np.array_equal(bits(xb), want) or "quick_allreduce_kernel" not in L.last_dispatch():
             ok = False
             print(f"rank {rank}: TPGroup.all_reduce did not take the quick kernel for a 1 MiB message", flush=True)
+        # ... and on the communication stream (all_reduce_async: the object's second context), interleaved with a reduce on the
+        # caller's stream: two ordered streams of launches, one context each
+        big2 = parts_for(998, 1 << 19, dt, "acts")
+        xa, xm = big2[rank].to(dev), big[rank].to(dev)
+        h = tp.all_reduce_async(xa)
+        tp.all_reduce(xm)
+        h.wait()
+        torch.cuda.synchronize()
+        want2 = O.quick_allreduce([bits(p) for p in big2], False, 3, False, rcp_f16_table=table)
+        if not np.array_equal(bits(xa), want2) or not np.array_equal(bits(xm), want):
+            ok = False
+            print(f"rank {rank}: side-stream / main-stream quick all-reduces disagree with the oracle", flush=True)
         if qr.size_ok(dt, (1 << 20) - 16) or qr.size_ok(torch.float32, 1 << 22):
             ok = False
             print(f"rank {rank}: size gate", flush=True)
