@@ -282,9 +282,10 @@ __device__ __forceinline__ void ar_norm_row(const ArArgs& a, const u32x4 (&ro)[k
   }
 }
 
-template <typename T>
+template <typename T, int WT>
 __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArArgs a) {
-  const int b = blockIdx.x, tid = threadIdx.x, W = a.world, r = a.rank;
+  constexpr int W = WT;
+  const int b = blockIdx.x, tid = threadIdx.x, r = a.rank;
   __shared__ uint32_t call_s;
   __shared__ int timeout_s;
   __shared__ float red_s[4];
@@ -332,9 +333,13 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
         const int v = tid + k * kArThreads;
         if (v < nvec) {
           float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          for (int p = 0; p < W; ++p) {
-            const u32x4 x = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.peers[p] + stage_off) +
-                                                       row * nvec + v);
+          u32x4 xs[W];
+#pragma unroll
+          for (int p = 0; p < W; ++p)
+            xs[p] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.peers[p] + stage_off) + row * nvec + v);
+#pragma unroll
+          for (int p = 0; p < W; ++p) {   // (rank order: the sum's order is part of the contract)
+            const u32x4 x = xs[p];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               acc[2 * j] += T::to_f32(static_cast<uint16_t>(x[j] & 0xffffu));
@@ -574,10 +579,23 @@ int rx_allreduce_rmsnorm(rx_ar_ctx* ctx, const void* in, const void* residual_in
   a.eps = eps;
   a.n = rows * hidden;
   auto s = static_cast<hipStream_t>(stream);
-  if (dtype == RX_BF16)
-    hipLaunchKernelGGL(allreduce_rmsnorm_kernel<BF16>, dim3(kArBlocks), dim3(kArThreads), 0, s, a);
-  else
-    hipLaunchKernelGGL(allreduce_rmsnorm_kernel<F16>, dim3(kArBlocks), dim3(kArThreads), 0, s, a);
+#define RX_ARN_W(TT, WW) hipLaunchKernelGGL((allreduce_rmsnorm_kernel<TT, WW>), dim3(kArBlocks), dim3(kArThreads), 0, s, a)
+#define RX_ARN_T(TT)                                                  \
+  do {                                                                \
+    switch (a.world) {                                                \
+      case 2: RX_ARN_W(TT, 2); break;                                 \
+      case 3: RX_ARN_W(TT, 3); break;                                 \
+      case 4: RX_ARN_W(TT, 4); break;                                 \
+      case 5: RX_ARN_W(TT, 5); break;                                 \
+      case 6: RX_ARN_W(TT, 6); break;                                 \
+      case 7: RX_ARN_W(TT, 7); break;                                 \
+      default: RX_ARN_W(TT, 8); break;                                \
+    }                                                                 \
+  } while (0)
+  if (dtype == RX_BF16) RX_ARN_T(BF16);
+  else RX_ARN_T(F16);
+#undef RX_ARN_T
+#undef RX_ARN_W
   return check_launch("rx_allreduce_rmsnorm");
 }
 
