@@ -188,6 +188,21 @@ for level, dt, cast in COMBOS:
             ok = False
             print(f"rank {rank}: size gate", flush=True)
         L.set_option("qr_max_blocks", 4)
+if world == 2:
+    # a peer that never arrives: the wait is BOUNDED (option ar_spin_log2 polls), the kernel raises RX_DEVERR_AR_TIMEOUT in the
+    # context's error word and returns -- no hang.  Own context: its tile counters are out of step afterwards.
+    qt = QuickAllReduce(None, dev, regime="FP", lanes=1)
+    dist.barrier()
+    if rank == 0:
+        L.set_option("ar_spin_log2", 12)
+        y = qt.quick_all_reduce(torch.ones(16384, dtype=torch.float16, device=dev))
+        torch.cuda.synchronize()
+        L.set_option("ar_spin_log2", 27)
+        if qt.check_errors() != 2:   # RX_DEVERR_AR_TIMEOUT
+            ok = False
+            print("rank 0: a reduce without its peer did not raise the timeout word", flush=True)
+    dist.barrier()
+    qt.close()
 qr.close()
 dist.barrier()
 print("RANK_OK" if ok else "RANK_FAIL", flush=True)
