@@ -242,7 +242,7 @@ class QuickAllReduce:
         self.disabled = True
         self.group = group
         self.device = torch.device(f"cuda:{device}") if isinstance(device, int) else torch.device(device)
-        self._ctx = None
+        self._ptr, self._ptrs = None, []
         if not dist.is_initialized():
             return
         self.rank, self.world_size = dist.get_rank(group), dist.get_world_size(group)
@@ -264,39 +264,21 @@ class QuickAllReduce:
         self.qr_max_size = mb * MB if mb > 0 else 1 << 31   # (qr_max_size(), quick_all_reduce.cu:86-89)
         if self.device.type != "cuda":
             return   # (CPU groups of the gloo tests: the gate above is all that runs there)
-        import ctypes as C
+        from . import quick_ar_ops as ops   # the reference's op names (custom_all_reduce_ops.py:131-163) over the C ABI
 
-        from . import lib as _L
-
-        self._L, self._C = _L, C
-        lib = self._lib = _L.load()
-        self._opened, self._own, self._ctxs = [], [], []
+        self._ops = ops
+        self._ptrs = []
         with torch.cuda.device(self.device):
-            self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-            # one context (= one 64-MiB region) per LANE: a context's launches must be ordered, and TPGroup reduces on two
-            # streams -- lane 0 the caller's, lane 1 the communication stream of all_reduce_async (as CustomAllReduce)
+            # one communicator (= one 64-MiB region) per LANE: a communicator's launches must be ordered, and TPGroup reduces
+            # on two streams -- lane 0 the caller's, lane 1 the communication stream of all_reduce_async (as CustomAllReduce).
+            # init_quick_all_reduce + create_shared_buffer, quick_all_reduce.py:176-220:
             for _ in range(max(1, int(lanes))):
-                own = C.c_void_p()
-                _L.check(lib.rx_ar_alloc_region(lib.rx_qr_region_bytes(), C.byref(own)), "rx_ar_alloc_region")
-                self._own.append(own)
-                handle = C.create_string_buffer(64)
-                _L.check(lib.rx_ipc_get_handle(own, handle), "rx_ipc_get_handle")
+                ptr = ops.init_custom_qr(self.rank, self.world_size, self.qr_max_size)
                 handles = [None] * self.world_size
-                dist.all_gather_object(handles, bytes(handle.raw), group=group)
-                ptrs = (C.c_void_p * self.world_size)()
-                for r, h in enumerate(handles):
-                    if r == self.rank:
-                        ptrs[r] = own.value
-                    else:
-                        q = C.c_void_p()
-                        _L.check(lib.rx_ipc_open_handle(C.create_string_buffer(h, 64), C.byref(q)), "rx_ipc_open_handle")
-                        ptrs[r] = q.value
-                        self._opened.append(q)
-                ctx = C.c_void_p()
-                _L.check(lib.rx_qr_init(C.byref(ctx), self.rank, self.world_size, ptrs, C.c_void_p(self.err_flag.data_ptr())),
-                         "rx_qr_init")
-                self._ctxs.append(ctx)
-            self._ctx = self._ctxs[0]
+                dist.all_gather_object(handles, ops.qr_get_handle(ptr), group=group)
+                ops.qr_open_handles(ptr, handles)
+                self._ptrs.append(ptr)
+            self._ptr = self._ptrs[0]
         dist.barrier(group=group)   # every region is mapped everywhere before the first call
         self.disabled = False
 
@@ -323,18 +305,14 @@ class QuickAllReduce:
             raise ValueError("quick_all_reduce: needs a 16-byte aligned fp16 / bf16 tensor of a multiple of 8 elements")
         if out is None:
             out = torch.empty_like(inp)
-        cp = self._C.c_void_p
-        st = self._lib.rx_quick_allreduce(self._ctxs[min(lane, len(self._ctxs) - 1)], cp(inp.data_ptr()), cp(out.data_ptr()), inp.numel(),
-                                          self._L.RX_BF16 if inp.dtype == torch.bfloat16 else self._L.RX_F16,
-                                          self.qr_quant_level.value, int(self.use_fp16_kernels),
-                                          cp(torch.cuda.current_stream(inp.device).cuda_stream))
-        self._L.check(st, "rx_quick_allreduce")
+        self._ops.qr_all_reduce(self._ptrs[min(lane, len(self._ptrs) - 1)], inp, out, self.qr_quant_level.value,
+                                bool(self.use_fp16_kernels))
         return out
 
     def check_errors(self) -> int:
-        v = int(self.err_flag.item())
-        if v:
-            self.err_flag.zero_()
+        v = 0
+        for ptr in getattr(self, "_ptrs", []):
+            v |= self._ops.qr_check_errors(ptr)
         return v
 
     def close(self):
@@ -342,19 +320,17 @@ class QuickAllReduce:
         eight processes on this driver stack (dmabuf IPC), contexts created AFTER an earlier one had been closed and freed
         either failed in hipIpcGetMemHandle or never saw their peers' flags -- the freed region's mapping appears to be
         reused on the importing side.  Create once, close at exit."""
-        if getattr(self, "_ctx", None):
+        if getattr(self, "_ptrs", None):
             torch.cuda.synchronize(self.device)
             dist.barrier(group=self.group)
-            for ctx in self._ctxs:
-                self._lib.rx_qr_destroy(ctx)
-            for q in self._opened:
-                self._lib.rx_ipc_close_handle(q)
+            for ptr in self._ptrs:
+                self._ops.qr_close_peers(ptr)
             # every mapping is gone before any owner frees: with eight processes a region freed while a peer still had it
             # open made the NEXT hipIpcGetMemHandle of that owner fail ("invalid argument", dmabuf IPC; round 6)
             dist.barrier(group=self.group)
-            for own in self._own:
-                self._lib.rx_ar_free_region(own)
-            self._ctx, self._ctxs = None, []
+            for ptr in self._ptrs:
+                self._ops.qr_destroy(ptr)
+            self._ptrs, self._ptr = [], None
             self.disabled = True
 
 

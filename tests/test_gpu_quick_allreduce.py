@@ -203,6 +203,37 @@ if world == 2:
             print("rank 0: a reduce without its peer did not raise the timeout word", flush=True)
     dist.barrier()
     qt.close()
+if world == 2:
+    # the op-level surface in the reference's own call order (qr_variable_input, test_quick_allreduce.py:189-240:
+    # init_custom_qr -> qr_get_handle -> all_gather_object -> qr_open_handles -> qr_all_reduce(ptr, inp, out, 3, cast_bf2half=True))
+    import sglang_amd.quick_ar_ops as ops
+    assert ops.IS_QUICK_AR_AVAILABLE and ops.qr_max_size() == 1 << 31
+    _ptr = ops.init_custom_qr(rank, world, None)
+    handle = ops.qr_get_handle(_ptr)
+    assert handle.dtype == torch.uint8 and handle.numel() == 64 and not handle.is_cuda
+    handles = [None] * world
+    dist.all_gather_object(handles, handle)
+    ops.qr_open_handles(_ptr, handles)
+    dist.barrier()
+    for num in range(1, 9):
+        s2 = 1024 if num % 2 == 0 else 2048
+        inp1 = (torch.zeros if num % 2 == 0 else torch.ones)((64, s2), dtype=torch.float16, device=dev)
+        result = torch.empty_like(inp1)
+        ops.qr_all_reduce(_ptr, inp1, result, 3, cast_bf2half=True)
+        torch.cuda.synchronize()
+        if not bool(torch.all(result == (0 if num % 2 == 0 else world))):
+            ok = False
+            print(f"rank {rank}: op-level variable-input round {num} wrong", flush=True)
+    try:
+        ops.qr_all_reduce(_ptr, torch.zeros(8, device=dev), torch.zeros(8, device=dev), 0)
+        ok = False
+    except RuntimeError as e:   # quick_all_reduce.cu:82-84
+        assert "float16 and bfloat16" in str(e)
+    dist.barrier()
+    ops.qr_close_peers(_ptr)
+    dist.barrier()
+    ops.qr_destroy(_ptr)
+    ops.qr_destroy(0)   # (null handle: a no-op, as the reference's check)
 qr.close()
 dist.barrier()
 print("RANK_OK" if ok else "RANK_FAIL", flush=True)

@@ -139,3 +139,29 @@ def test_environment_switches(monkeypatch):
     assert q.disabled and not q.size_ok(torch.float16, 1 << 22)
     tp = TPGroup(None, quick_ar=q)
     assert tp.quick_ar is None
+
+
+def test_op_surface_matches_the_reference_ops_module():
+    """sglang_amd.quick_ar_ops carries the names and parameter lists of the reference's quick all-reduce ops
+    (custom_all_reduce_ops.py:131-163), so the reference's QuickAllReduce runs on it with `ops` swapped.  Compared against the
+    reference's source where it is present (the build container); the names alone otherwise."""
+    import ast
+    import inspect
+
+    import sglang_amd.quick_ar_ops as ops
+
+    names = ["init_custom_qr", "qr_get_handle", "qr_open_handles", "qr_all_reduce", "qr_destroy", "qr_max_size"]
+    for n in names:
+        assert callable(getattr(ops, n))
+    assert ops.IS_QUICK_AR_AVAILABLE is True
+    ref = "/root/reference/python/sglang/srt/distributed/device_communicators/custom_all_reduce_ops.py"
+    if not os.path.exists(ref):
+        pytest.skip("reference sources not present")
+    found = {}
+    for node in ast.walk(ast.parse(open(ref).read())):
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            found[node.name] = [a.arg for a in node.args.args]
+    assert set(found) == set(names)
+    for n in names:
+        mine = list(inspect.signature(getattr(ops, n)).parameters)
+        assert mine == found[n], (n, mine, found[n])
