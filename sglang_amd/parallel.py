@@ -174,6 +174,32 @@ class CustomAllReduce:
         self._L.check(st, "rx_allreduce_rmsnorm")
         return out, residual
 
+    # ---- the reference class's own method names (CustomAllreduce, custom_all_reduce.py:40-340), for a caller written against it
+    disabled = False
+    _SUPPORTED_WORLD_SIZES = [2, 3, 4, 5, 6, 7, 8]   # (the reference: 2, 4, 6, 8; the kernels here take any 2 .. 8)
+
+    def should_custom_ar(self, inp: torch.Tensor) -> bool:
+        """custom_all_reduce.py:260-283: a multiple of 16 bytes, dense, at most max_bytes (16-bit dtypes only here)."""
+        dense = inp.is_contiguous() or (inp.untyped_storage().nbytes() - inp.storage_offset() * inp.element_size()
+                                        == inp.numel() * inp.element_size())
+        return bool(dense and self.shape_ok(inp) and inp.data_ptr() % 16 == 0)
+
+    def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:   # noqa: A002  (the reference's parameter name)
+        """custom_all_reduce.py:309-329: the OUT-OF-PLACE sum, or None when this communicator does not take the tensor (the
+        caller then falls through to the next one).  Graph capture needs no special casing here: nothing is registered, the
+        kernels count their calls on the device."""
+        if not self.should_custom_ar(input):
+            return None
+        out = torch.empty_like(input)
+        return self.all_reduce(input, out=out)   # (element-wise: a dense permuted layout sums as it lies; empty_like keeps the strides)
+
+    def capture(self):
+        """custom_all_reduce.py:182-194 registers the graph's buffers at the end of the capture; the staging regions of this
+        implementation are fixed, so the context manager has nothing to do."""
+        import contextlib
+
+        return contextlib.nullcontext()
+
     def check_errors(self) -> int:
         v = int(self.err_flag.item())
         if v:
@@ -192,6 +218,9 @@ class CustomAllReduce:
             for own in self._own:
                 self._lib.rx_ar_free_region(own)
             self._ctxs, self._ctx = [], None
+
+
+CustomAllreduce = CustomAllReduce   # the reference's spelling (custom_all_reduce.py:40)
 
 
 class QuickReduceRegime(enum.Enum):

@@ -62,6 +62,21 @@ for it, (n, dt) in enumerate(([(256 * 4096, torch.bfloat16)] if TINY else
         print(f"rank {rank} it {it} n {n}: max diff", (got.cpu().float() - want.float()).abs().max().item(), flush=True)
 
 L.set_option("ar_fenced", 0)
+if not TINY:
+    # the reference class's own surface (CustomAllreduce.should_custom_ar / custom_all_reduce / capture, custom_all_reduce.py:
+    # 182-194, 260-329): out of place, None for a tensor the communicator does not take
+    parts = parts_for(4242, 512 * 64, torch.bfloat16)
+    x = parts[rank].to(dev).view(512, 64)
+    with ar.capture():
+        y = ar.custom_all_reduce(x)
+    torch.cuda.synchronize()
+    if y is None or y.shape != x.shape or not torch.equal(y.cpu().view(-1), sum(p.float() for p in parts).to(torch.bfloat16)) \
+            or not torch.equal(x.cpu().view(-1), parts[rank]):
+        ok = False
+        print(f"rank {rank}: custom_all_reduce (out of place) wrong", flush=True)
+    if ar.custom_all_reduce(torch.zeros(8, device=dev)) is not None or ar.should_custom_ar(torch.zeros(16 << 20, dtype=torch.bfloat16, device=dev)):
+        ok = False
+        print(f"rank {rank}: should_custom_ar gate", flush=True)
 mark("eager calls")
 if SKIP_GRAPH:
     side = torch.cuda.Stream()
