@@ -1570,6 +1570,58 @@ def allreduce_figures(st, fb, world, args, step_fn_factory):
     return res
 
 
+def quick_allreduce_figures(world, rank, dev):
+    """--ar-leg, world 2 / 4 / 8: the quick all-reduce (C3, csrc/rx_quick_allreduce.hip) on a prefill-sized message -- its
+    first contact with real links.  Per level: a check against the fp32 sum of seeded per-rank inputs at the reference
+    test's own tolerance (test_quick_allreduce.py:150-160: atol 1.25 W, rtol 0.5 W on integers in [1, 23); FP exact), then
+    the time of a 64-MiB bf16 message (travelling as fp16, the reference's default).  Every rank must agree."""
+    import torch.distributed as dist
+
+    from sglang_amd.parallel import QuickAllReduce, QuickReduceRegime
+
+    if world not in (2, 4, 8):
+        return {"skipped": f"world size {world} (2, 4 or 8)"}
+    qr = QuickAllReduce(None, dev, regime="FP", cast_bf16_to_fp16=True, lanes=1)
+    out = {"message_MiB": 64, "dtype": "bf16 (as fp16 on the wire)", "levels": {}}
+    n_chk, n = 1 << 20, 32 << 20
+    parts = [torch.randint(1, 23, (n_chk,), generator=torch.Generator().manual_seed(77 + r)).to(torch.bfloat16) for r in range(world)]
+    exact = torch.stack([p.float() for p in parts]).sum(0)
+    x = torch.randn(n, device=dev).to(torch.bfloat16)
+    y = torch.empty_like(x)
+    try:
+        for level in ("FP", "INT8", "INT6", "INT4"):
+            qr.qr_quant_level = QuickReduceRegime[level]
+            got = qr.quick_all_reduce(parts[rank].to(dev))
+            torch.cuda.synchronize()
+            err = (got.float().cpu() - exact).abs()
+            okv = bool((err <= 1.25 * world + 0.5 * world * exact.abs()).all()) and (level != "FP" or float(err.max()) == 0.0)
+            ok = torch.tensor([1 if okv else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            rec = {"max_abs_err_on_integers": float(err.max()), "ok_on_every_rank": bool(ok.item())}
+            if bool(ok.item()):
+                for _ in range(3):
+                    qr.quick_all_reduce(x, out=y)
+                torch.cuda.synchronize()
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    qr.quick_all_reduce(x, out=y)
+                e1.record()
+                torch.cuda.synchronize()
+                t = torch.tensor([e0.elapsed_time(e1) / 10], device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                rec["ms_per_call"] = float(t.item())
+                rec["message_GB_per_s"] = 64 / 1024 * 1.073741824 / (float(t.item()) / 1e3)
+            out["levels"][level] = rec
+        flag = torch.tensor([qr.check_errors()], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        out["device_side_timeouts"] = int(flag.item())
+    finally:
+        qr.close()
+    return out
+
+
 def ar_leg_main(args, st, fb, world, rank, dev, contact):
     """--ar-leg (child job of custom_ar_child_leg): the decode step with the peer-to-peer all-reduce -- first
     contact already passed -- timed alone and inside the step with / without the side-stream overlap."""
@@ -1600,6 +1652,10 @@ def ar_leg_main(args, st, fb, world, rank, dev, contact):
     res.update({"implementation": contact["implementation"], "n_gpus": world, "ms_per_step": dt / args.steps * 1e3,
                 "tokens_per_s": args.bs / (dt / args.steps), "first_contact": contact["all_reduce_check"],
                 "device_side_timeouts": int(flag.item())})
+    try:  # (a failure here costs this figure, not the leg)
+        res["quick_allreduce"] = quick_allreduce_figures(world, rank, dev)
+    except Exception as e:  # noqa: BLE001
+        res["quick_allreduce"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if st.custom_ar is not None:
