@@ -1614,6 +1614,8 @@ def quick_allreduce_figures(world, rank, dev):
                 rec["ms_per_call"] = float(t.item())
                 rec["message_GB_per_s"] = 64 / 1024 * 1.073741824 / (float(t.item()) / 1e3)
             out["levels"][level] = rec
+            if not bool(ok.item()):
+                break   # (a level that fails its check is not timed, and the others are not tried: a stuck flag wait costs seconds)
         flag = torch.tensor([qr.check_errors()], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         out["device_side_timeouts"] = int(flag.item())
