@@ -9,7 +9,8 @@ collective as one rank sees it, on one GPU (no link involved).  W = 2 is what th
 process's streams onto a few hardware queues (4 by default), and two "ranks" whose streams share a queue deadlock -- the
 first kernel spins on a flag that the kernel queued BEHIND it would raise (W = 4 hung until its spin limit; one process per
 GPU, the real deployment, has no such coupling).  The tool lowers the spin limit so that such a hang ends in seconds.
-Results are checked: two-shot / one-shot / fused against the
+(`--pmc` passes are NOT possible: counter collection serialises kernels, the two ranks' kernels can no longer run side by
+side and every flag wait ends in its timeout -- tried, round 6.)  Results are checked: two-shot / one-shot / fused against the
 fp32 rank-order sum, every quick level against the oracle."""
 import ctypes as C
 import json
