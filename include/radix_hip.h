@@ -72,7 +72,7 @@ const char* rx_last_error(void);
  * extend_d256_at64, extend_d256_at96, extend_nd, extend_nd_big, extend_mla, extend_mla_shared_v, decode_mla8_dma, decode_mla8_t64,
  * merge_in_kernel_max_mb[_mla], ext32_uni (round 6), roctx; ar_fenced / qr_fenced (the all-reduce kernels' flag handshake
  * in its fenced form), ar_spin_log2 (polls before a
- * flag wait gives up), qr_max_blocks (the quick all-reduce's grid cap); ext64 only acts in a dev build (RX_WITH_EXT64=1).
+ * flag wait gives up), ar_blocks (blocks of the decode-sized all-reduce kernels; 0 = by message size), qr_max_blocks (the quick all-reduce's grid cap); ext64 only acts in a dev build (RX_WITH_EXT64=1).
  * NOT THREAD-SAFE: the switches are plain process-wide ints that the launch path reads without synchronisation.  Set them
  * before other threads launch (tests and A/B tools flip them from the one thread that also launches); a set that races with
  * a launch on another thread gives that launch the old or the new value, nothing is torn, but no ordering is promised. */

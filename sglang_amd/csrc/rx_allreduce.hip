@@ -42,7 +42,7 @@
 namespace rx {
 
 constexpr int kArMaxWorld = 8;
-constexpr int kArBlocks = 64;      // blocks per rank (= independent flag lanes)
+constexpr int kArBlocks = 256;     // most blocks per rank (= independent flag lanes); a launch uses ar_grid() of them
 constexpr int kArThreads = 256;
 constexpr uint32_t kArSpinLimit = 1u << 27;
 
@@ -82,6 +82,7 @@ struct ArArgs {
   float eps;
   int32_t fenced;  // option ar_fenced
   uint32_t spin_limit;  // polls before a wait gives up (option ar_spin_log2; default 2^27)
+  int32_t active;       // blocks that take part in this call (ar_grid); the others only count it
 };
 
 // The flag handshake (round 6; measured on rx_quick_allreduce.hip, which documents the numbers): a block's stores into the
@@ -140,18 +141,23 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
   __shared__ int timeout_s;
   if (tid == 0) timeout_s = 0;
   const uint32_t call = ar_next_call(a, b, &call_s);
+  // Every launch has kArBlocks blocks so that ALL per-block call counters advance together (the staging / result buffers
+  // alternate by the call's parity, which must be one value per launch); only the first `active` of them -- the same number
+  // on every rank, a function of the message size -- move data and exchange flags.
+  const int nb = a.active;
+  if (b >= nb) return;
   const int64_t stage_off = ar_align(sizeof(ArFlags)) + (call & 1) * ar_align(a.max_bytes);
   const int64_t result_off = ar_align(sizeof(ArFlags)) + (2 + (call & 1)) * ar_align(a.max_bytes);
   const int64_t nv = a.n / 8;                     // 16-byte vectors
   const int64_t per = (nv + W - 1) / W;           // vectors per chunk
 
-  // ---- phase 0: stage my input (block b takes every kArBlocks-th group of 256 vectors of each chunk)
+  // ---- phase 0: stage my input (block b takes every nb-th group of 256 vectors of each chunk)
   u32x4* my_stage = reinterpret_cast<u32x4*>(a.peers[r] + stage_off);
   const u32x4* in_v = reinterpret_cast<const u32x4*>(a.in);
   for (int c = 0; c < W; ++c) {
     const int64_t lo = c * per, hi = min(lo + per, nv);
 #pragma unroll 4
-    for (int64_t i = lo + b * kArThreads + tid; i < hi; i += kArBlocks * kArThreads) my_stage[i] = in_v[i];
+    for (int64_t i = lo + b * kArThreads + tid; i < hi; i += nb * kArThreads) my_stage[i] = in_v[i];
   }
   const bool fenced = a.fenced != 0;
   ar_publish_begin(fenced);
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
     u32x4* my_res = reinterpret_cast<u32x4*>(a.peers[r] + result_off);
     u32x4* out_v = reinterpret_cast<u32x4*>(a.out);
 #pragma unroll 2
-    for (int64_t i = lo + b * kArThreads + tid; i < hi; i += kArBlocks * kArThreads) {
+    for (int64_t i = lo + b * kArThreads + tid; i < hi; i += nb * kArThreads) {
       float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       u32x4 vs[W];
 #pragma unroll
@@ -221,14 +227,14 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
       const int64_t lo = c * per, hi = min(lo + per, nv);
       const u32x4* res = reinterpret_cast<const u32x4*>(a.peers[c] + result_off);
 #pragma unroll 4
-      for (int64_t i = lo + b * kArThreads + tid; i < hi; i += kArBlocks * kArThreads)
+      for (int64_t i = lo + b * kArThreads + tid; i < hi; i += nb * kArThreads)
         out_v[i] = __builtin_nontemporal_load(res + i);
     }
   }
 }
 
 // ---- fused all-reduce + residual add + RMSNorm ----------------------------------------------------------------
-// Rows [c * per, (c + 1) * per) are rank c's chunk; row j of a chunk (local index l) belongs to block l % kArBlocks
+// Rows [c * per, (c + 1) * per) are rank c's chunk; row j of a chunk (local index l) belongs to block l % nb
 // in every phase on every rank, so block b still only depends on block b of its peers.  A row is H / 8 16-byte
 // vectors, thread t takes vectors t, t + 256, ... (at most kArVpt of them: H <= 16384).
 constexpr int kArVpt = 8;
@@ -291,6 +297,8 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
   __shared__ float red_s[4];
   if (tid == 0) timeout_s = 0;
   const uint32_t call = ar_next_call(a, b, &call_s);
+  const int nb = a.active;   // (see allreduce_two_shot_kernel)
+  if (b >= nb) return;
   const int64_t stage_off = ar_align(sizeof(ArFlags)) + (call & 1) * ar_align(a.max_bytes);
   const int64_t result_off = ar_align(sizeof(ArFlags)) + (2 + (call & 1)) * ar_align(a.max_bytes);
   const int nvec = a.hidden / 8;
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
     const u32x4* in_v = reinterpret_cast<const u32x4*>(a.in);
     for (int c = 0; c < W; ++c) {
       const int64_t lo = c * per, hi = min(lo + per, static_cast<int64_t>(a.rows));
-      for (int64_t row = lo + b; row < hi; row += kArBlocks)
+      for (int64_t row = lo + b; row < hi; row += nb)
         for (int v = tid; v < nvec; v += kArThreads) my_stage[row * nvec + v] = in_v[row * nvec + v];
     }
   }
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
     u32x4* my_res = reinterpret_cast<u32x4*>(a.peers[r] + result_off);
     u32x4* res_out = reinterpret_cast<u32x4*>(a.out_res);
     const u32x4* resid = reinterpret_cast<const u32x4*>(a.residual);
-    for (int64_t row = lo + b; row < hi; row += kArBlocks) {
+    for (int64_t row = lo + b; row < hi; row += nb) {
       u32x4 ro[kArVpt];
 #pragma unroll
       for (int k = 0; k < kArVpt; ++k) {
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
       if (c == r) continue;
       const int64_t lo = c * per, hi = min(lo + per, static_cast<int64_t>(a.rows));
       const u32x4* src = reinterpret_cast<const u32x4*>(a.peers[c] + result_off);
-      for (int64_t row = lo + b; row < hi; row += kArBlocks) {
+      for (int64_t row = lo + b; row < hi; row += nb) {
         u32x4 ro[kArVpt];
 #pragma unroll
         for (int k = 0; k < kArVpt; ++k) {
@@ -403,6 +411,19 @@ __global__ __launch_bounds__(kArThreads) void allreduce_rmsnorm_kernel(const ArA
 uint32_t ar_spin_limit() {  // (rx_quick_allreduce.hip uses it too)
   const int lg = options().ar_spin_log2;
   return lg >= 10 && lg <= 31 ? 1u << lg : kArSpinLimit;
+}
+
+// Blocks of a launch, the same on every rank (a function of the element count and a process-wide option only): block b
+// only ever talks to block b of its peers, so any grid up to kArBlocks works.  Option ar_blocks forces a count.
+// Round 6, two processes on one GPU, us per call at 32 / 64 / 128 / 256 blocks: two-shot 256 KiB 6.9 / 7.0 / 7.1 / 7.2, 2 MiB
+// 19.6 / 13.2 / 10.0 / 8.6, 8 MiB 55 / 32 / 21 / 16; fused RMSNorm 2 MiB 31.6 / 19.1 / 13.4 / 13.2 -- one pass of 256 threads
+// over a rank's chunk per block, between 32 and kArBlocks blocks.
+static int ar_grid(int64_t vectors, int world) {
+  const int forced = options().ar_blocks;
+  if (forced > 0) return forced < kArBlocks ? forced : kArBlocks;
+  const int64_t per = (vectors + world - 1) / world;                  // vectors of one rank's chunk
+  const int64_t nb = (per + kArThreads - 1) / kArThreads;
+  return static_cast<int>(nb < 32 ? 32 : (nb > kArBlocks ? kArBlocks : nb));
 }
 
 template <bool ONE_SHOT>
@@ -530,6 +551,7 @@ int rx_allreduce(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, int d
   a.out = static_cast<uint16_t*>(out);
   a.n = count;
   auto s = static_cast<hipStream_t>(stream);
+  a.active = ar_grid(a.n / 8, a.world);
   launch_two_shot<false>(a, dtype, s);
   return check_launch("rx_allreduce");
 }
@@ -549,6 +571,7 @@ int rx_allreduce_det(rx_ar_ctx* ctx, const void* in, void* out, int64_t count, i
   a.out = static_cast<uint16_t*>(out);
   a.n = count;
   auto s = static_cast<hipStream_t>(stream);
+  a.active = ar_grid(a.n / 8, a.world);
   launch_two_shot<true>(a, dtype, s);
   return check_launch("rx_allreduce_det");
 }
@@ -579,6 +602,7 @@ int rx_allreduce_rmsnorm(rx_ar_ctx* ctx, const void* in, const void* residual_in
   a.eps = eps;
   a.n = rows * hidden;
   auto s = static_cast<hipStream_t>(stream);
+  a.active = ar_grid(a.n / 8, a.world);
 #define RX_ARN_W(TT, WW) hipLaunchKernelGGL((allreduce_rmsnorm_kernel<TT, WW>), dim3(kArBlocks), dim3(kArThreads), 0, s, a)
 #define RX_ARN_T(TT)                                                  \
   do {                                                                \

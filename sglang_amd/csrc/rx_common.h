@@ -47,6 +47,7 @@ struct Options {
   int merge_in_kernel_max_mb = 4;      // stage 2 inside the stage-1 kernel while the partials are at most this many MB ...
   int merge_in_kernel_max_mb_mla = 4;  // ... and for latent (576 / 512) rows
   int ar_spin_log2 = 27;      // all-reduce kernels: a flag wait gives up (RX_DEVERR_AR_TIMEOUT) after 2^this polls (~1-2 us each); bench.py's first xGMI contact lowers it
+  int ar_blocks = 0;          // peer-to-peer all-reduce kernels: blocks per launch (0: by message size; at most 256)
   int ar_fenced = 0;          // peer-to-peer all-reduce kernels: 1 = system fences / release / acquire around their flags (rx_allreduce.hip)
   int qr_fenced = 0;          // quick all-reduce: 1 = release store / acquire fence around its flags instead of acknowledged uncached stores (rx_quick_allreduce.hip)
   int qr_max_blocks = 0;      // quick all-reduce: cap on its grid (0: 1024 = 4 workgroups per CU); tests walk many tiles per workgroup on small messages

@@ -118,7 +118,7 @@ static const OptionEntry kOptionTable[] = {
     {"ext32_pack_min_tiles", &Options::ext32_pack_min_tiles}, {"ext32_pack4_tiles", &Options::ext32_pack4_tiles}, {"ext32_pack_min_wgs", &Options::ext32_pack_min_wgs},
     {"roctx", &Options::roctx},                           {"qr_max_blocks", &Options::qr_max_blocks},
     {"qr_fenced", &Options::qr_fenced},                   {"ar_fenced", &Options::ar_fenced},
-    {"ar_spin_log2", &Options::ar_spin_log2},
+    {"ar_spin_log2", &Options::ar_spin_log2},             {"ar_blocks", &Options::ar_blocks},
     {"ext64", &Options::ext64},                           {"ext32_count_redo", &Options::ext32_count_redo},
     {"ext32_plain", &Options::ext32_plain},               {"ext32_uni", &Options::ext32_uni},               
                  {"extend_16x16_d128", &Options::extend_16x16_d128},
