@@ -202,9 +202,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_two_shot_kernel(const Ar
       out_v[i] = o;
     }
   }
-#ifndef RX_AR_DET_SECOND_EXCHANGE
   if constexpr (ONE_SHOT) return;  // (the staging buffer of this parity is reused at call + 2, behind the peers' ready(call + 1))
-#endif
   ar_publish_begin(fenced);
   __syncthreads();
   if (tid < W && tid != r)
