@@ -108,3 +108,87 @@ def test_the_check_catches_a_protocol_without_the_second_wait():
             if not ready:
                 break
             broken_step(min(ready, key=lambda r: r.me))
+
+
+# ---- the decode-sized kernels of csrc/rx_allreduce.hip: staging / result buffers alternate by the call's parity ----------------
+class TwoShotRank:
+    """One block index of one rank.  Region: stage[2], result[2] (payload = the call number that wrote it), flags ready / done
+    per source; reads are recorded per reader so that a writer can check that everybody is done with the old payload."""
+
+    def __init__(self, me, world):
+        self.me, self.world = me, world
+        self.call, self.pc, self.finished = 1, 0, False
+        self.stage, self.result = [0, 0], [0, 0]
+        self.ready, self.done = [0] * world, [0] * world
+        self.read_stage = [[0, 0] for _ in range(world)]    # [source][buffer] -> last call whose payload I read
+        self.read_result = [[0, 0] for _ in range(world)]
+
+
+def ts_runnable(r):
+    if r.finished:
+        return False
+    if r.pc == 2:
+        return all(r.ready[p] >= r.call for p in range(r.world) if p != r.me)
+    if r.pc == 5:
+        return all(r.done[p] >= r.call for p in range(r.world) if p != r.me)
+    return True
+
+
+def ts_step(r, ranks, calls, one_shot, buffers=2):
+    buf = r.call % buffers
+    others = [p for p in ranks if p.me != r.me]
+    if r.pc == 0:      # stage my input
+        old = r.stage[buf]
+        for p in others:
+            assert old == 0 or p.read_stage[r.me][buf] >= old, f"rank {r.me} call {r.call}: restages over call {old}, unread by rank {p.me}"
+        r.stage[buf] = r.call
+    elif r.pc == 1:
+        for p in others:
+            p.ready[r.me] = r.call
+    elif r.pc == 3:    # reduce: read every staging buffer, write my result
+        for p in others:
+            assert p.stage[buf] == r.call, f"rank {r.me} call {r.call}: rank {p.me}'s staging buffer holds call {p.stage[buf]}"
+            r.read_stage[p.me][buf] = r.call
+        if not one_shot:
+            old = r.result[buf]
+            for p in others:
+                assert old == 0 or p.read_result[r.me][buf] >= old, f"rank {r.me} call {r.call}: result of call {old} unread by rank {p.me}"
+            r.result[buf] = r.call
+    elif r.pc == 4:
+        for p in others:
+            p.done[r.me] = r.call
+    elif r.pc == 6:    # gather
+        for p in others:
+            assert p.result[buf] == r.call
+            r.read_result[p.me][buf] = r.call
+    r.pc += 1
+    if r.pc == (4 if one_shot else 7):
+        r.pc = 0
+        r.call += 1
+        r.finished = r.call > calls
+
+
+@pytest.mark.parametrize("one_shot", [False, True], ids=["two_shot", "one_shot"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_two_shot_buffers_alternate_safely(world, one_shot):
+    """rx_allreduce.hip header: 'a buffer is reused at g + 2, after the peer's ready of g + 1 proved it finished g' -- for the
+    two-shot form and for the one-shot (deterministic) form, which has no second exchange at all."""
+    rng = random.Random(10 * world + one_shot)
+    picks = [lambda ready: rng.choice(ready)] * 40 + [lambda ready: min(ready, key=lambda r: r.me), lambda ready: max(ready, key=lambda r: r.me),
+                                                      lambda ready: max(ready, key=lambda r: (r.call, r.pc)), lambda ready: min(ready, key=lambda r: (r.call, r.pc))]
+    for pick in picks:
+        ranks = [TwoShotRank(i, world) for i in range(world)]
+        while not all(r.finished for r in ranks):
+            ready = [r for r in ranks if ts_runnable(r)]
+            assert ready, "deadlock"
+            ts_step(pick(ready), ranks, calls=7, one_shot=one_shot)
+
+
+def test_one_buffer_would_not_be_enough_for_the_one_shot_form():
+    """Sanity of the model: with ONE staging buffer (no parity) a fast rank restages while a slow peer still has to read."""
+    ranks = [TwoShotRank(i, 2) for i in range(2)]
+    with pytest.raises(AssertionError, match="restages|holds"):
+        while not all(r.finished for r in ranks):
+            ready = [r for r in ranks if ts_runnable(r)]
+            assert ready, "deadlock"
+            ts_step(min(ready, key=lambda r: r.me), ranks, calls=4, one_shot=True, buffers=1)   # (rank 0 runs whenever it can)
